@@ -1,0 +1,320 @@
+/*
+ * sos_slam.h -- C-ABI of the MI355X (gfx950) hot path of SOS-SLAM's sliding-window photometric
+ * bundle adjustment (OptimizationBackend) and CoarseTracker direct-alignment loop.
+ *
+ * The reference has no FFI for this path; the seam is the set of C++ call sites listed in
+ * SURVEY.md section 8(b).  Each entry point below cites the reference call it replaces
+ * (paths relative to the reference root, `src/` omitted: FS = FullSystem, OB = OptimizationBackend).
+ *
+ * Conventions
+ *   - every function returns an int status: 0 = SOS_OK, negative = error (no exceptions, no exit()).
+ *   - the caller owns every host buffer; the library owns device memory behind opaque handles.
+ *   - handles are not thread-safe; distinct handles are independent; all work of a context is
+ *     issued on ONE HIP stream (the caller's, or one created by the context).
+ *   - NaN / Inf energies are returned as data (the caller turns them into `isLost`,
+ *     FS/FullSystemOptimize.cpp:427-432).
+ *   - matrices are row-major unless stated; the pair index is  h + n*t  (host + nFrames*target), the
+ *     index used by adHost/adTarget/adHTdeltaF/acc (OB/EnergyFunctional.cpp:82-83,169).
+ *   - fp32 arithmetic is evaluated WITHOUT fused multiply-add contraction and in the operation order
+ *     documented in DESIGN.md ("arithmetic convention"), identical on the device and in oracle/.
+ */
+#ifndef SOS_SLAM_H
+#define SOS_SLAM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------------
+ * constants of the path (util/NumType.h:36-45, util/settings.h:187-189, FS/HessianBlocks.h:53-89)
+ * ---------------------------------------------------------------------------------------------- */
+#define SOS_CPARS 4               /* CPARS */
+#define SOS_PATTERN_NUM 8         /* patternNum, staticPattern[8] */
+#define SOS_MAX_FRAMES 32         /* upper bound on window size accepted by the library */
+#define SOS_MAX_SLOTS 64          /* image slots of a context */
+#define SOS_PYR_LEVELS 6          /* PYR_LEVELS */
+
+#define SOS_SCALE_IDEPTH 1.0f
+#define SOS_SCALE_XI_ROT 1.0f
+#define SOS_SCALE_XI_TRANS 0.5f
+#define SOS_SCALE_F 50.0f
+#define SOS_SCALE_C 50.0f
+#define SOS_SCALE_A 10.0f
+#define SOS_SCALE_B 1000.0f
+
+/* ResState (FS/Residuals.h:43) */
+#define SOS_RES_IN 0
+#define SOS_RES_OOB 1
+#define SOS_RES_OUTLIER 2
+
+/* sos_resid.flags bits */
+#define SOS_RF_ACTIVE 1u          /* EFResidual::isActiveAndIsGoodNEW */
+#define SOS_RF_LINEARIZED 2u      /* EFResidual::isLinearized */
+#define SOS_RF_ISNEW 4u           /* PointFrameResidual::isNew */
+
+/* status codes */
+#define SOS_OK 0
+#define SOS_ERR_ARG (-1)
+#define SOS_ERR_HIP (-2)
+#define SOS_ERR_STATE (-3)
+#define SOS_ERR_NOMEM (-4)
+
+/* ------------------------------------------------------------------------------------------------
+ * plain-data records
+ * ---------------------------------------------------------------------------------------------- */
+
+/* every global the path reads, made explicit (util/settings.cpp:47-119, util/globalCalib.cpp:58-64) */
+typedef struct sos_params {
+  int32_t w, h;                    /* wG[0], hG[0]; wM3G = w-3, hM3G = h-3 */
+  float huberTH;                   /* setting_huberTH = 9 */
+  float outlierTHSumComponent;     /* setting_outlierTHSumComponent = 50*50 */
+  float affineOptModeA;            /* setting_affineOptModeA = 1e12 (<0: fixed) */
+  float affineOptModeB;            /* setting_affineOptModeB = 1e8 */
+  float idepthFixPrior;            /* 50*50 */
+  float idepthFixPriorMargFac;     /* 600*600 */
+  float margWeightFac;             /* 0.5*0.5 */
+  float initialCalibHessian;       /* 5e9 */
+  float coarseCutoffTH;            /* 20 */
+  float frameEnergyTHN;            /* 0.7 */
+  float frameEnergyTHFacMedian;    /* 1.5 */
+  float frameEnergyTHConstWeight;  /* 0.5 */
+  float overallEnergyTHWeight;     /* 1 */
+  float reserved[3];
+} sos_params;
+
+/* CalibHessian::value_scaledf / value_scaledi (FS/HessianBlocks.h:476-514) */
+typedef struct sos_calib {
+  float fxl, fyl, cxl, cyl;        /* value_scaledf */
+  float fxli, fyli, cxli, cyli;    /* value_scaledi = 1/fx, 1/fy, -cx/fx, -cy/fy */
+} sos_calib;
+
+/* the part of FrameFramePrecalc the backend reads (FS/HessianBlocks.h:109-134; set():
+ * FS/HessianBlocks.cpp:431-461).  Computed on the host in fp64 and cast. */
+typedef struct sos_precalc {
+  float PRE_KRKiTll[9];            /* row-major */
+  float PRE_KtTll[3];
+  float PRE_RTll_0[9];             /* row-major */
+  float PRE_tTll_0[3];
+  float PRE_aff_mode[2];
+  float PRE_b0_mode;
+  float pad;                       /* 28 floats */
+} sos_precalc;
+
+/* device-relevant part of PointHessian + EFPoint (FS/HessianBlocks.h:556-649,
+ * OB/EnergyFunctionalStructs.h:83-114) */
+typedef struct sos_point {
+  float u, v;
+  float idepth_scaled;
+  float idepth_zero_scaled;
+  float color[SOS_PATTERN_NUM];
+  float weights[SOS_PATTERN_NUM];
+  float priorF;                    /* EFPoint::priorF */
+  float deltaF;                    /* EFPoint::deltaF = idepth - idepth_zero */
+  int32_t host;                    /* frame idx of the host */
+  int32_t pad;                     /* 24 x 4 B */
+} sos_point;
+
+/* PointFrameResidual + EFResidual, index-stable ids (FS/Residuals.h:49-93,
+ * OB/EnergyFunctionalStructs.h:43-81).  Residuals of one point must be contiguous and in the order
+ * of EFPoint::residualsAll; points are in EnergyFunctional::allPoints order (frames -> points,
+ * OB/EnergyFunctional.cpp:1192-1199). */
+typedef struct sos_resid {
+  int32_t point;                   /* index into the point array */
+  int32_t host, target;            /* hostIDX, targetIDX */
+  uint32_t flags;                  /* SOS_RF_* */
+  int32_t state_state;             /* SOS_RES_* */
+  float state_energy;
+} sos_resid;
+
+/* 74-float RawResidualJacobian in the reference's field order (OB/RawResidualJacobian.h:29-55),
+ * used to read a Jacobian back for inspection / parity checks. */
+typedef struct sos_rawjac {
+  float resF[8];
+  float Jpdxi[2][6];
+  float Jpdc[2][4];
+  float Jpdd[2];
+  float JIdx[2][8];
+  float JabF[2][8];
+  float JIdx2[4];                  /* (0,0) (0,1) (1,0) (1,1) */
+  float JabJIdx[4];
+  float Jab2[4];
+} sos_rawjac;
+
+typedef struct sos_ctx sos_ctx;          /* device + stream + frame (image pyramid) store */
+typedef struct sos_ba sos_ba;            /* device backend of one EnergyFunctional */
+typedef struct sos_tracker sos_tracker;  /* device side of one CoarseTracker / ScaleOptimizer */
+
+/* ------------------------------------------------------------------------------------------------
+ * context and frame store
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Create a context on HIP device `device`.  `hip_stream` is a hipStream_t supplied by the caller or
+ * NULL (the context then creates and owns one).  Must fail (SOS_ERR_HIP) when no GPU is present. */
+int sos_ctx_create(int device, void *hip_stream, int w, int h, sos_ctx **out);
+int sos_ctx_destroy(sos_ctx *ctx);
+int sos_ctx_synchronize(sos_ctx *ctx);
+/* number of pyramid levels for (w,h): util/globalCalib.cpp:39-52 */
+int sos_ctx_pyr_levels(const sos_ctx *ctx);
+
+/* Replaces FrameHessian::makeImages (FS/HessianBlocks.cpp:121-176; called at FS/FullSystem.cpp:650,
+ * 1114).  `img` = w*h float irradiance on the host; `gammaBgrad` = 256-entry CalibHessian::B table
+ * or NULL (setting_gammaWeightsPixelSelect != 1).  Builds all levels of dIp / absSquaredGrad in the
+ * slot.  */
+int sos_make_pyramid(sos_ctx *ctx, int slot, const float *img, const float *gammaB);
+/* Upload a host-built level-0 dI (AoS (I,dx,dy), w*h*3 floats) into a slot (no pyramid). */
+int sos_frame_upload_dI(sos_ctx *ctx, int slot, const float *dI_aos3);
+/* Copy one pyramid level back: dI_out (wl*hl*3) and/or absgrad_out (wl*hl) may be NULL. */
+int sos_frame_download_level(sos_ctx *ctx, int slot, int lvl, float *dI_out, float *absgrad_out);
+int sos_frame_release(sos_ctx *ctx, int slot);
+
+/* ------------------------------------------------------------------------------------------------
+ * backend (EnergyFunctional device side)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* new/delete EnergyFunctional: FS/FullSystem.cpp:83-84, 98-110 */
+int sos_ba_create(sos_ctx *ctx, const sos_params *params, sos_ba **out);
+int sos_ba_destroy(sos_ba *ba);
+
+/* Packed snapshot of the window graph.  Replaces the state that insertFrame / insertPoint /
+ * insertResidual / dropResidual / removePoint / marginalizeFrame / makeIDX leave behind
+ * (OB/EnergyFunctional.cpp:644-728, 1186-1202); the graph mutation itself stays host-side.
+ * frame_slot[i] = image slot of frame idx i.  res_toZeroF: R*8 floats (EFResidual::res_toZeroF) or
+ * NULL when no residual is linearized.  lin_J: sos_rawjac per residual with SOS_RF_LINEARIZED (frozen
+ * Jacobian of linearized residuals), indexed like res; may be NULL when none is linearized. */
+int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, int P, const sos_point *pts,
+                      int R, const sos_resid *res, const float *res_toZeroF,
+                      const sos_rawjac *lin_J);
+
+/* Per-step state: replaces FullSystem::setPrecalcValues (FS/FullSystem.cpp:1099-1107) ->
+ * FrameFramePrecalc::set x n^2, EnergyFunctional::setDeltaF (OB/EnergyFunctional.cpp:163-194) and
+ * setAdjointsF (:42-103).  precalc / adHTdeltaF / adHost / adTarget are indexed [h + n*t];
+ * adHost/adTarget are 8x8 row-major doubles; point_* are P floats each (NULL = keep).  */
+int sos_ba_set_state(sos_ba *ba, const sos_calib *calib, const sos_precalc *precalc,
+                     const float *adHTdeltaF /* n*n*8 */, const float *cDeltaF /* 4 */,
+                     const double *adHost /* n*n*64 */, const double *adTarget /* n*n*64 */,
+                     const float *point_idepth_scaled, const float *point_idepth_zero_scaled,
+                     const float *point_deltaF);
+
+/* linearizeAll_Reductor -> PointFrameResidual::linearize over all active (non-linearized) residuals
+ * (FS/FullSystemOptimize.cpp:44-77,125-143; FS/Residuals.cpp:77-271).  frameEnergyTH: n floats.
+ * Outputs (each may be NULL), indexed like the `res` array of set_window:
+ *   energySum        sum of the returned energies (stats[0]), accumulated in double in residual order
+ *   newState         state_NewState (SOS_RES_*)
+ *   newEnergy        state_NewEnergy
+ *   newEnergyWithOutlier  state_NewEnergyWithOutlier (-1 when the residual went OOB)
+ *   centerProjectedTo     R*3 floats
+ * Linearized residuals are skipped (newState = their state_state, newEnergyWithOutlier = -1). */
+int sos_ba_linearize(sos_ba *ba, const float *frameEnergyTH, double *energySum, uint8_t *newState,
+                     float *newEnergy, float *newEnergyWithOutlier, float *centerProjectedTo);
+
+/* applyRes_Reductor -> PointFrameResidual::applyRes(true) -> EFResidual::takeDataF
+ * (FS/FullSystemOptimize.cpp:79-83,339-344,391-396; FS/Residuals.cpp:304-321;
+ * OB/EnergyFunctionalStructs.cpp:36-45). */
+int sos_ba_apply_res(sos_ba *ba);
+
+/* PointFrameResidual::resetOOB over all non-linearized residuals (FS/Residuals.h:83-88,
+ * FS/FullSystemOptimize.cpp:321-324). */
+int sos_ba_reset_oob(sos_ba *ba);
+
+/* EFResidual::fixLinearizationF for `count` residuals (FS/FullSystem.cpp:581;
+ * OB/EnergyFunctionalStructs.cpp:75-103).  Uses the adHTdeltaF/cDeltaF/deltaF of the last set_state. */
+int sos_ba_fix_linearization(sos_ba *ba, const int32_t *residIdx, int count);
+
+/* accumulateAF_MT / accumulateLF_MT / accumulateSCF_MT incl. stitchDoubleMT
+ * (OB/EnergyFunctional.cpp:197-254, 1040-1044; OB/AccumulatedTopHessian.cpp:35-147,231-301;
+ * OB/AccumulatedSCHessian.cpp:32-158).  Each H is dense row-major (4+8n)^2 doubles, each b has 4+8n
+ * doubles, caller-allocated.  H_L/b_L do NOT contain the priors (the host adds cPrior and the frame
+ * priors, OB/AccumulatedTopHessian.cpp:292-300).  Any output pointer may be NULL. */
+int sos_ba_accumulate(sos_ba *ba, double *H_A, double *b_A, double *H_L, double *b_L, double *H_sc,
+                      double *b_sc, int *resInA, int *resInL);
+
+/* Multi-GPU split of sos_ba_accumulate: (1) accumulate the local shard's fp32 blocks into a packed
+ * device buffer, (2) the caller all-reduces that buffer (RCCL), (3) stitch from the reduced buffer.
+ * sos_ba_acc_buffer returns the device pointer and float count of the packed buffer
+ * [top_A n^2*91 | top_L n^2*91 | accD n^3*64 | accE n^2*32 | accEB n^2*8 | Hcc 16 | bc 4 | nresA nresL]. */
+int sos_ba_accumulate_local(sos_ba *ba);
+int sos_ba_acc_buffer(sos_ba *ba, float **dev_ptr, size_t *nfloats);
+int sos_ba_stitch(sos_ba *ba, double *H_A, double *b_A, double *H_L, double *b_L, double *H_sc,
+                  double *b_sc, int *resInA, int *resInL);
+
+/* per-point results of the accumulation: idepth_hessian (OB/AccumulatedSCHessian.cpp:50),
+ * HdiF, bdSumF.  Each P floats, may be NULL. */
+int sos_ba_get_point_hessian(sos_ba *ba, float *idepth_hessian, float *HdiF, float *bdSumF);
+
+/* resubstituteF_MT / resubstituteFPt (OB/EnergyFunctional.cpp:496-551).  x has 4+8n doubles (the
+ * solved increment, before sign flip); pointStep receives PointHessian::step for every point. */
+int sos_ba_resubstitute(sos_ba *ba, const double *x, float *pointStep);
+
+/* calcLEnergyF_MT without the frame / calib prior terms, which stay on the host
+ * (OB/EnergyFunctional.cpp:563-642). */
+int sos_ba_calc_lenergy(sos_ba *ba, double *E);
+
+/* accumulation of marginalizePointsF (OB/EnergyFunctional.cpp:911-921): addPoint<2> + SC addPoint(p,
+ * false) over `count` points, stitchDouble.  priorF of those points must already be scaled by
+ * idepthFixPriorMargFac in the snapshot (OB/EnergyFunctional.cpp:901). */
+int sos_ba_accumulate_marg(sos_ba *ba, const int32_t *pointIdx, int count, double *M, double *Mb,
+                           double *Msc, double *Mbsc, int *resInM);
+
+/* inspection helpers used by the parity tests */
+int sos_ba_get_jacobian(sos_ba *ba, int residIdx, int which /*0 = EFResidual::J, 1 = scratch*/,
+                        sos_rawjac *out);
+int sos_ba_get_residual_flags(sos_ba *ba, uint32_t *flags /*R*/, int32_t *state_state /*R*/,
+                              float *state_energy /*R*/);
+int sos_ba_get_JpJdF(sos_ba *ba, float *JpJdF /*R*8*/);
+int sos_ba_get_res_toZeroF(sos_ba *ba, float *res_toZeroF /*R*8*/);
+
+/* kernel timing on the context's stream with HIP events: runs `iters` back-to-back launches of the
+ * named kernel ("linearize", "top_accumulate", "sc_accumulate", "apply_res", "resubstitute", ...) on
+ * the current window state and returns the average milliseconds per launch. */
+int sos_ba_time_kernel(sos_ba *ba, const char *kernel, const float *frameEnergyTH, int iters,
+                       float *avg_ms);
+
+/* ------------------------------------------------------------------------------------------------
+ * coarse tracker / scale optimizer device side
+ * ---------------------------------------------------------------------------------------------- */
+
+/* new CoarseTracker(w,h,tfm_cam1_cam0,K1): FS/FullSystem.cpp:64-66; FS/ScaleOptimizer.cpp:38-87 */
+int sos_tracker_create(sos_ctx *ctx, const sos_params *params, sos_tracker **out);
+int sos_tracker_destroy(sos_tracker *trk);
+
+/* makeK + setCoarseTrackingRef -> makeCoarseDepthL0 (FS/FullSystem.cpp:889-890;
+ * FS/ScaleOptimizer.cpp:95-118; FS/CoarseTracker.cpp:56-242).  The npts points are those with
+ * lastResiduals[0] IN: u,v = centerProjectedTo[0..1], idepth = centerProjectedTo[2],
+ * hdi = EFPoint::HdiF.  refSlot = image slot of lastRef (its pyramid supplies pc_color).
+ * pc_n_out: pyrLevels ints. */
+int sos_tracker_set_ref(sos_tracker *trk, const sos_calib *calib, int refSlot, int npts,
+                        const float *u, const float *v, const float *idepth, const float *hdi,
+                        int32_t *pc_n_out);
+/* ScaleOptimizer::scaleCoarseDepthL0 (FS/CoarseTracker.cpp:244-251) */
+int sos_tracker_scale_depth(sos_tracker *trk, float scale);
+/* read back one level of the template point cloud (pc_u, pc_v, pc_idepth, pc_color) */
+int sos_tracker_get_pc(sos_tracker *trk, int lvl, float *pc_u, float *pc_v, float *pc_idepth,
+                       float *pc_color);
+
+/* CoarseTracker::calcResPose (FS/CoarseTracker.cpp:612-764).  RKi = R * Ki[lvl] (row-major 3x3
+ * float), t float[3], affLL float[2] are computed by the host exactly as :628-634.  rs receives
+ * [E, numTermsInE, flowT, 0, flowRT, satRatio]. */
+int sos_tracker_calc_res(sos_tracker *trk, int lvl, int newSlot, const float *RKi, const float *t,
+                         const float *affLL, float cutoffTH, double *rs /*6*/);
+/* CoarseTracker::calcGSSSEPose (FS/CoarseTracker.cpp:554-610) on the buffers of the last calc_res.
+ * a = affLL[0] of the pose being linearized, b0 = lastRef_aff_g2l.b.  H 8x8 row-major, b 8. */
+int sos_tracker_calc_gs(sos_tracker *trk, int lvl, float a, float b0, double *H, double *b);
+
+/* ScaleOptimizer::calcResScale / calcGSSSEScale (FS/ScaleOptimizer.cpp:273-437, 232-271).
+ * RKi = rot(tfmF0ToF1) * Ki[lvl], t = trans(tfmF0ToF1); K1 = (fx1,fy1,cx1,cy1) of level `lvl`. */
+int sos_tracker_calc_res_scale(sos_tracker *trk, int lvl, int stereoSlot, const float *RKi,
+                               const float *t, const float *K1, float scale, float cutoffTH,
+                               double *rs /*6*/);
+int sos_tracker_calc_gs_scale(sos_tracker *trk, int lvl, const float *t, const float *K1,
+                              float scale, float *H, float *b);
+
+/* library identification: returns "hip-gfx950" */
+const char *sos_backend_name(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOS_SLAM_H */

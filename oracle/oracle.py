@@ -1,0 +1,430 @@
+"""ctypes front-end of the CPU oracle (oracle/liboracle.so) -- TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product package (sos_slam_amd) never does.  The oracle is "parity unpinned" (see oracle/oracle.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_float_p = C.POINTER(C.c_float)
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int32)
+
+
+class Params(C.Structure):
+    _fields_ = [("w", C.c_int32), ("h", C.c_int32), ("huberTH", C.c_float),
+                ("outlierTHSumComponent", C.c_float), ("affineOptModeA", C.c_float),
+                ("affineOptModeB", C.c_float), ("idepthFixPrior", C.c_float),
+                ("idepthFixPriorMargFac", C.c_float), ("margWeightFac", C.c_float),
+                ("initialCalibHessian", C.c_float), ("coarseCutoffTH", C.c_float),
+                ("frameEnergyTHN", C.c_float), ("frameEnergyTHFacMedian", C.c_float),
+                ("frameEnergyTHConstWeight", C.c_float), ("overallEnergyTHWeight", C.c_float),
+                ("reserved", C.c_float * 3)]
+
+    @classmethod
+    def from_dict(cls, d):
+        p = cls()
+        for k, v in d.items():
+            setattr(p, k, v)
+        return p
+
+
+class Calib(C.Structure):
+    _fields_ = [(k, C.c_float) for k in ("fxl", "fyl", "cxl", "cyl", "fxli", "fyli", "cxli", "cyli")]
+
+    @classmethod
+    def from_K(cls, K):
+        """CalibHessian::setValueScaled, FS/HessianBlocks.h:493-506."""
+        c = cls()
+        f = np.asarray(K, dtype=np.float64).astype(np.float32)
+        c.fxl, c.fyl, c.cxl, c.cyl = [float(x) for x in f]
+        c.fxli = float(np.float32(1.0) / f[0])
+        c.fyli = float(np.float32(1.0) / f[1])
+        c.cxli = float(-f[2] / f[0])
+        c.cyli = float(-f[3] / f[1])
+        return c
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "sos_slam.h"))
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        vp = C.c_void_p
+        L.orc_window_create.restype = vp
+        L.orc_window_create.argtypes = [C.POINTER(Params), C.c_int, C.c_int, vp, C.c_int, vp]
+        L.orc_window_destroy.argtypes = [vp]
+        L.orc_set_image.argtypes = [vp, C.c_int, vp]
+        L.orc_set_lin.argtypes = [vp, vp, vp]
+        L.orc_set_state.argtypes = [vp, C.POINTER(Calib)] + [vp] * 8
+        L.orc_linearize_all.restype = C.c_double
+        L.orc_linearize_all.argtypes = [vp, vp, C.c_int]
+        L.orc_apply_res.argtypes = [vp]
+        L.orc_reset_oob.argtypes = [vp]
+        L.orc_fix_linearization.argtypes = [vp, vp, C.c_int]
+        L.orc_accumulate.argtypes = [vp] + [vp] * 6 + [c_int_p, c_int_p, C.c_int, C.c_int]
+        L.orc_resubstitute.argtypes = [vp, vp, vp, C.c_int]
+        L.orc_calc_lenergy.restype = C.c_double
+        L.orc_calc_lenergy.argtypes = [vp]
+        L.orc_accumulate_marg.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, c_int_p]
+        for name in ("orc_J", "orc_Jnew", "orc_res", "orc_pts", "orc_new_state", "orc_new_energy",
+                     "orc_new_energy_wo", "orc_center", "orc_JpJdF", "orc_res_toZeroF"):
+            getattr(L, name).restype = vp
+            getattr(L, name).argtypes = [vp]
+        L.orc_point_field.restype = vp
+        L.orc_point_field.argtypes = [vp, C.c_int]
+        L.orc_host_init.argtypes = [vp, vp, vp, vp, vp]
+        L.orc_optimize.restype = C.c_float
+        L.orc_optimize.argtypes = [vp, C.c_int, C.c_int, c_int_p]
+        L.orc_gn_iteration.restype = C.c_int
+        L.orc_gn_iteration.argtypes = [vp, C.c_int, C.c_int]
+        L.orc_host_get_frame.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+        L.orc_host_get_calib.argtypes = [vp, vp]
+        L.orc_host_precalc.argtypes = [vp]
+        for name in ("orc_host_get_precalc", "orc_host_get_adHTdeltaF", "orc_host_get_adHost",
+                     "orc_host_get_adTarget", "orc_host_get_lastX"):
+            getattr(L, name).restype = vp
+            getattr(L, name).argtypes = [vp]
+        L.orc_host_get_HM.argtypes = [vp, vp, vp]
+        L.orc_se3_exp12.argtypes = [vp, vp]
+        L.orc_se3_log12.argtypes = [vp, vp]
+        L.orc_se3_adj12.argtypes = [vp, vp]
+        L.orc_se3_mul12.argtypes = [vp, vp, vp]
+        L.orc_se3_inv12.argtypes = [vp, vp]
+        L.orc_solve_ldlt.restype = C.c_int
+        L.orc_solve_ldlt.argtypes = [vp, vp, vp, C.c_int]
+        L.orc_pyr_levels.restype = C.c_int
+        L.orc_pyr_levels.argtypes = [C.c_int, C.c_int]
+        L.orc_make_images.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp]
+        L.orc_tracker_create.restype = vp
+        L.orc_tracker_create.argtypes = [C.POINTER(Params), C.c_int, C.c_int]
+        L.orc_tracker_destroy.argtypes = [vp]
+        L.orc_tracker_set_ref.argtypes = [vp, C.POINTER(Calib), vp, C.c_int, vp, vp, vp, vp, vp]
+        L.orc_tracker_get_pc.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+        L.orc_tracker_scale_depth.argtypes = [vp, C.c_float]
+        L.orc_tracker_calc_res.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_float, vp]
+        L.orc_tracker_calc_gs.argtypes = [vp, C.c_int, C.c_float, C.c_float, vp, vp]
+        L.orc_tracker_calc_res_scale.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_float, C.c_float, vp]
+        L.orc_tracker_calc_gs_scale.argtypes = [vp, C.c_int, vp, vp, C.c_float, vp, vp]
+        L.orc_tracker_warp_n.restype = C.c_int
+        L.orc_tracker_warp_n.argtypes = [vp]
+        L.orc_tracker_track.restype = C.c_int
+        L.orc_tracker_track.argtypes = [vp, vp, C.c_float, C.c_float, vp, vp, vp, C.c_int, vp, vp, vp]
+        L.orc_tracker_optimize_scale.restype = C.c_float
+        L.orc_tracker_optimize_scale.argtypes = [vp, vp, vp, vp, vp, C.c_int]
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _view(ptr, dtype, shape):
+    n = int(np.prod(shape))
+    if n == 0:
+        return np.zeros(shape, dtype=dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+
+def pyr_levels(w, h):
+    return lib().orc_pyr_levels(w, h)
+
+
+def make_images(img, gammaB=None):
+    """FrameHessian::makeImages -> ([dI per level (hl,wl,3)], [absSquaredGrad per level])."""
+    img = np.ascontiguousarray(img, dtype=np.float32)
+    h, w = img.shape
+    lv = pyr_levels(w, h)
+    dI = [np.zeros((h >> l, w >> l, 3), dtype=np.float32) for l in range(lv)]
+    ab = [np.zeros((h >> l, w >> l), dtype=np.float32) for l in range(lv)]
+    pd = (C.c_void_p * lv)(*[d.ctypes.data for d in dI])
+    pa = (C.c_void_p * lv)(*[a.ctypes.data for a in ab])
+    gb = None if gammaB is None else np.ascontiguousarray(gammaB, dtype=np.float32)
+    lib().orc_make_images(_p(img), w, h, _p(gb), lv, pd, pa)
+    return dI, ab
+
+
+class OracleWindow:
+    """One EnergyFunctional window inside the oracle."""
+
+    def __init__(self, params: dict, n: int, points: np.ndarray, resid: np.ndarray):
+        from sos_slam_amd import synth  # dtypes only
+        self._synth = synth
+        self.L = lib()
+        self.params = Params.from_dict(params)
+        self.n, self.P, self.R = n, len(points), len(resid)
+        pts = np.ascontiguousarray(points)
+        res = np.ascontiguousarray(resid)
+        self.h = self.L.orc_window_create(C.byref(self.params), n, self.P, _p(pts), self.R, _p(res))
+        self._keep = []
+
+    def close(self):
+        if self.h:
+            self.L.orc_window_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- inputs
+    def set_image(self, frame, dI):
+        dI = np.ascontiguousarray(dI, dtype=np.float32)
+        self._keep.append(dI)
+        self.L.orc_set_image(self.h, frame, _p(dI))
+
+    def set_lin(self, res_toZeroF, linJ):
+        self.L.orc_set_lin(self.h, _p(res_toZeroF), _p(linJ))
+
+    def set_state(self, calib=None, precalc=None, adHTdeltaF=None, cDeltaF=None, adHost=None, adTarget=None,
+                  idepth=None, idepth_zero=None, deltaF=None):
+        self.L.orc_set_state(self.h, C.byref(calib) if calib is not None else None, _p(precalc),
+                             _p(adHTdeltaF), _p(cDeltaF), _p(adHost), _p(adTarget), _p(idepth),
+                             _p(idepth_zero), _p(deltaF))
+
+    # --- kernel-level calls
+    def linearize(self, frameEnergyTH, nthreads=1):
+        th = np.ascontiguousarray(frameEnergyTH, dtype=np.float32)
+        return self.L.orc_linearize_all(self.h, _p(th), nthreads)
+
+    def apply_res(self):
+        self.L.orc_apply_res(self.h)
+
+    def reset_oob(self):
+        self.L.orc_reset_oob(self.h)
+
+    def fix_linearization(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        self.L.orc_fix_linearization(self.h, _p(idx), len(idx))
+
+    def accumulate(self, fp64_truth=False, nthreads=1):
+        dim = 4 + 8 * self.n
+        out = [np.zeros((dim, dim)), np.zeros(dim), np.zeros((dim, dim)), np.zeros(dim), np.zeros((dim, dim)),
+               np.zeros(dim)]
+        ra, rl = C.c_int32(0), C.c_int32(0)
+        self.L.orc_accumulate(self.h, *[_p(o) for o in out], C.byref(ra), C.byref(rl), int(fp64_truth), nthreads)
+        return dict(H_A=out[0], b_A=out[1], H_L=out[2], b_L=out[3], H_sc=out[4], b_sc=out[5], resInA=ra.value,
+                    resInL=rl.value)
+
+    def accumulate_marg(self, point_idx):
+        dim = 4 + 8 * self.n
+        idx = np.ascontiguousarray(point_idx, dtype=np.int32)
+        out = [np.zeros((dim, dim)), np.zeros(dim), np.zeros((dim, dim)), np.zeros(dim)]
+        rm = C.c_int32(0)
+        self.L.orc_accumulate_marg(self.h, _p(idx), len(idx), *[_p(o) for o in out], C.byref(rm))
+        return dict(M=out[0], Mb=out[1], Msc=out[2], Mbsc=out[3], resInM=rm.value)
+
+    def resubstitute(self, x, nthreads=1):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        step = np.zeros(self.P, dtype=np.float32)
+        self.L.orc_resubstitute(self.h, _p(x), _p(step), nthreads)
+        return step
+
+    def calc_lenergy(self):
+        return self.L.orc_calc_lenergy(self.h)
+
+    # --- views
+    def J(self):
+        return _view(self.L.orc_J(self.h), self._synth.RAWJAC_DTYPE, (self.R,))
+
+    def Jnew(self):
+        return _view(self.L.orc_Jnew(self.h), self._synth.RAWJAC_DTYPE, (self.R,))
+
+    def res(self):
+        return _view(self.L.orc_res(self.h), self._synth.RESID_DTYPE, (self.R,))
+
+    def pts(self):
+        return _view(self.L.orc_pts(self.h), self._synth.POINT_DTYPE, (self.P,))
+
+    def new_state(self):
+        return _view(self.L.orc_new_state(self.h), np.int32, (self.R,))
+
+    def new_energy(self):
+        return _view(self.L.orc_new_energy(self.h), np.float32, (self.R,))
+
+    def new_energy_wo(self):
+        return _view(self.L.orc_new_energy_wo(self.h), np.float32, (self.R,))
+
+    def center(self):
+        return _view(self.L.orc_center(self.h), np.float32, (self.R, 3))
+
+    def JpJdF(self):
+        return _view(self.L.orc_JpJdF(self.h), np.float32, (self.R, 8))
+
+    def res_toZeroF(self):
+        return _view(self.L.orc_res_toZeroF(self.h), np.float32, (self.R, 8))
+
+    def point_field(self, which):
+        names = ["idepth_hessian", "HdiF", "bdSumF", "Hdd_accAF", "bd_accAF", "Hcd_accAF", "Hdd_accLF",
+                 "bd_accLF", "Hcd_accLF", "step", "maxRelBaseline"]
+        k = names.index(which)
+        shape = (self.P, 4) if which.startswith("Hcd") else (self.P,)
+        return _view(self.L.orc_point_field(self.h, k), np.float32, shape)
+
+    # --- host level
+    def host_init(self, frames, K, HM=None, bM=None):
+        fr = np.ascontiguousarray(frames)
+        Kd = np.ascontiguousarray(K, dtype=np.float64)
+        self.L.orc_host_init(self.h, _p(fr), _p(Kd), _p(None if HM is None else np.ascontiguousarray(HM)),
+                             _p(None if bM is None else np.ascontiguousarray(bM)))
+
+    def host_precalc(self):
+        self.L.orc_host_precalc(self.h)
+
+    def optimize(self, iters=6, nthreads=1):
+        it = C.c_int32(0)
+        rmse = self.L.orc_optimize(self.h, iters, nthreads, C.byref(it))
+        return rmse, it.value
+
+    def gn_iteration(self, iteration=0, nthreads=1):
+        return self.L.orc_gn_iteration(self.h, iteration, nthreads)
+
+    def frame(self, f):
+        c2w, st, sz = np.zeros(12), np.zeros(10), np.zeros(10)
+        th = C.c_float(0)
+        self.L.orc_host_get_frame(self.h, f, _p(c2w), _p(st), _p(sz), C.byref(th))
+        return dict(camToWorld=c2w, state=st, state_zero=sz, frameEnergyTH=th.value)
+
+    def calib_value_scaled(self):
+        v = np.zeros(4)
+        self.L.orc_host_get_calib(self.h, _p(v))
+        return v
+
+    def precalc(self):
+        return _view(self.L.orc_host_get_precalc(self.h), self._synth.PRECALC_DTYPE, (self.n * self.n,))
+
+    def adHTdeltaF(self):
+        return _view(self.L.orc_host_get_adHTdeltaF(self.h), np.float32, (self.n * self.n, 8))
+
+    def adHost(self):
+        return _view(self.L.orc_host_get_adHost(self.h), np.float64, (self.n * self.n, 8, 8))
+
+    def adTarget(self):
+        return _view(self.L.orc_host_get_adTarget(self.h), np.float64, (self.n * self.n, 8, 8))
+
+    def lastX(self):
+        return _view(self.L.orc_host_get_lastX(self.h), np.float64, (4 + 8 * self.n,))
+
+
+def window_from_synth(win, nthreads=1):
+    """OracleWindow with images (built by the oracle's makeImages) and host state of a synth.Window."""
+    ow = OracleWindow(win.params, win.n, win.points, win.resid)
+    ow.dI = []
+    for i in range(win.n):
+        dI, _ = make_images(win.images[i])
+        ow.dI.append(dI)
+        ow.set_image(i, dI[0])
+    ow.host_init(win.frames, win.K, win.HM, win.bM)
+    return ow
+
+
+class OracleTracker:
+    def __init__(self, params: dict, w: int, h: int):
+        self.L = lib()
+        self.params = Params.from_dict(params)
+        self.w, self.h = w, h
+        self.levels = pyr_levels(w, h)
+        self.t = self.L.orc_tracker_create(C.byref(self.params), w, h)
+        self._keep = []
+
+    def close(self):
+        if self.t:
+            self.L.orc_tracker_destroy(self.t)
+            self.t = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _pyr(self, dI_levels):
+        arrs = [np.ascontiguousarray(d, dtype=np.float32) for d in dI_levels]
+        self._keep.append(arrs)
+        return (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs]), arrs
+
+    def set_ref(self, calib, ref_dI_levels, u, v, idepth, hdi):
+        ptrs, _ = self._pyr(ref_dI_levels)
+        self._ref_ptrs = ptrs
+        a = [np.ascontiguousarray(x, dtype=np.float32) for x in (u, v, idepth, hdi)]
+        pc_n = np.zeros(self.levels, dtype=np.int32)
+        self.L.orc_tracker_set_ref(self.t, C.byref(calib), ptrs, len(a[0]), *[_p(x) for x in a], _p(pc_n))
+        self.pc_n = pc_n
+        return pc_n
+
+    def get_pc(self, lvl):
+        n = int(self.pc_n[lvl])
+        out = [np.zeros(n, dtype=np.float32) for _ in range(4)]
+        self.L.orc_tracker_get_pc(self.t, lvl, *[_p(o) for o in out])
+        return out
+
+    def scale_depth(self, s):
+        self.L.orc_tracker_scale_depth(self.t, s)
+
+    def calc_res(self, lvl, new_dI, RKi, t, affLL, cutoff):
+        rs = np.zeros(6)
+        a = [np.ascontiguousarray(x, dtype=np.float32) for x in (new_dI, RKi, t, affLL)]
+        self.L.orc_tracker_calc_res(self.t, lvl, *[_p(x) for x in a], cutoff, _p(rs))
+        return rs
+
+    def calc_gs(self, lvl, a, b0):
+        H, b = np.zeros((8, 8)), np.zeros(8)
+        self.L.orc_tracker_calc_gs(self.t, lvl, a, b0, _p(H), _p(b))
+        return H, b
+
+    def calc_res_scale(self, lvl, stereo_dI, RKi, t, K1, scale, cutoff):
+        rs = np.zeros(6)
+        a = [np.ascontiguousarray(x, dtype=np.float32) for x in (stereo_dI, RKi, t, K1)]
+        self.L.orc_tracker_calc_res_scale(self.t, lvl, *[_p(x) for x in a], scale, cutoff, _p(rs))
+        return rs
+
+    def calc_gs_scale(self, lvl, t, K1, scale):
+        H, b = C.c_float(0), C.c_float(0)
+        a = [np.ascontiguousarray(x, dtype=np.float32) for x in (t, K1)]
+        self.L.orc_tracker_calc_gs_scale(self.t, lvl, _p(a[0]), _p(a[1]), scale, C.byref(H), C.byref(b))
+        return H.value, b.value
+
+    def warp_n(self):
+        return self.L.orc_tracker_warp_n(self.t)
+
+    def track(self, new_dI_levels, ref_ab, new_ab, ref_aff, lastToNew12, aff2, coarsest, minRes=None):
+        ptrs, _ = self._pyr(new_dI_levels)
+        T = np.ascontiguousarray(lastToNew12, dtype=np.float64).copy()
+        aff = np.ascontiguousarray(aff2, dtype=np.float64).copy()
+        ra = np.ascontiguousarray(ref_aff, dtype=np.float64)
+        mr = np.full(5, np.nan) if minRes is None else np.ascontiguousarray(minRes, dtype=np.float64)
+        lr, fl = np.zeros(5), np.zeros(3)
+        ok = self.L.orc_tracker_track(self.t, ptrs, ref_ab, new_ab, _p(ra), _p(T), _p(aff), coarsest, _p(mr),
+                                      _p(lr), _p(fl))
+        return ok, T, aff, lr, fl
+
+    def optimize_scale(self, stereo_dI_levels, tfm12, K1, scale, coarsest):
+        ptrs, _ = self._pyr(stereo_dI_levels)
+        s = C.c_float(scale)
+        tf = np.ascontiguousarray(tfm12, dtype=np.float64)
+        k1 = np.ascontiguousarray(K1, dtype=np.float32)
+        r = self.L.orc_tracker_optimize_scale(self.t, ptrs, _p(tf), _p(k1), C.byref(s), coarsest)
+        return r, s.value

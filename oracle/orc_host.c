@@ -1,0 +1,446 @@
+/*
+ * oracle/orc_host.c -- TEST INFRASTRUCTURE (CPU oracle, "parity unpinned", see oracle.h).
+ *
+ * Host-level restatement of the Gauss-Newton loop around the backend:
+ *   FullSystem::optimize / linearizeAll / setNewFrameEnergyTH / doStepFromBackup / backupState
+ *                            FS/FullSystemOptimize.cpp:305-489, 125-182, 84-124, 185-257, 260-269
+ *   FullSystem::setPrecalcValues -> FrameFramePrecalc::set    FS/FullSystem.cpp:1099-1107,
+ *                                                             FS/HessianBlocks.cpp:431-461
+ *   EnergyFunctional::setAdjointsF / setDeltaF / solveSystemF (visual part, IMU off)
+ *                            OB/EnergyFunctional.cpp:42-103, 163-194, 1029-1184
+ *   FrameHessian::setState / setEvalPT / getPrior             FS/HessianBlocks.h:196-260, 280-304
+ *   CalibHessian::setValue                                    FS/HessianBlocks.h:476-491
+ *   AffLight::fromToVecExposure                               util/NumType.h:149-171
+ */
+#include "orc_internal.h"
+
+#include <stdio.h>
+
+/* reference defaults, util/settings.cpp:47-77 */
+#define SETTING_initialRotPrior 1e11f
+#define SETTING_initialTransPrior 1e10f
+#define SETTING_initialAffBPrior 1e14f
+#define SETTING_initialAffAPrior 1e14f
+#define SETTING_thOptIterations 1.2f
+#define SETTING_minOptIterations 1
+
+static void to12(const orc_se3 *T, double *o) { memcpy(o, T->R, 9 * sizeof(double)); memcpy(o + 9, T->t, 3 * sizeof(double)); }
+static orc_se3 from12(const double *i) { orc_se3 T; memcpy(T.R, i, 9 * sizeof(double)); memcpy(T.t, i + 9, 3 * sizeof(double)); return T; }
+
+void orc_se3_exp12(const double *a, double *T12) { orc_se3 T = orc_se3_exp(a); to12(&T, T12); }
+void orc_se3_log12(const double *T12, double *a) { orc_se3 T = from12(T12); orc_se3_log(&T, a); }
+void orc_se3_adj12(const double *T12, double *Ad) { orc_se3 T = from12(T12); orc_se3_adj(&T, Ad); }
+void orc_se3_mul12(const double *A, const double *B, double *C) { orc_se3 a = from12(A), b = from12(B); orc_se3 c = orc_se3_mul(&a, &b); to12(&c, C); }
+void orc_se3_inv12(const double *A, double *C) { orc_se3 a = from12(A); orc_se3 c = orc_se3_inverse(&a); to12(&c, C); }
+int orc_solve_ldlt(const double *A, const double *b, double *x, int n) { return orc_ldlt_solve(A, b, x, n); }
+
+/* util/NumType.h:156-168 */
+static void from_to_vec_exposure(float exposureF, float exposureT, double g2F_a, double g2F_b, double g2T_a,
+                                 double g2T_b, double *out) {
+  if (exposureF == 0 || exposureT == 0) exposureT = exposureF = 1;
+  double a = exp(g2T_a - g2F_a) * exposureT / exposureF;
+  double b = g2T_b - a * g2F_b;
+  out[0] = a; out[1] = b;
+}
+
+static void calib_set_value(orc_window *W, const double *value) { /* FS/HessianBlocks.h:476-491 */
+  for (int i = 0; i < 4; i++) W->c_value[i] = value[i];
+  W->c_value_scaled[0] = SOS_SCALE_F * value[0];
+  W->c_value_scaled[1] = SOS_SCALE_F * value[1];
+  W->c_value_scaled[2] = SOS_SCALE_C * value[2];
+  W->c_value_scaled[3] = SOS_SCALE_C * value[3];
+  sos_calib *C = &W->calib;
+  C->fxl = (float)W->c_value_scaled[0]; C->fyl = (float)W->c_value_scaled[1];
+  C->cxl = (float)W->c_value_scaled[2]; C->cyl = (float)W->c_value_scaled[3];
+  C->fxli = 1.0f / C->fxl; C->fyli = 1.0f / C->fyl;
+  C->cxli = -C->cxl / C->fxl; C->cyli = -C->cyl / C->fyl;
+  for (int i = 0; i < 4; i++) W->c_value_minus_value_zero[i] = W->c_value[i] - W->c_value_zero[i];
+}
+
+static void frame_set_state(orc_hframe *f, const double *state) { /* FS/HessianBlocks.h:217-230 */
+  for (int i = 0; i < 10; i++) f->state[i] = state[i];
+  for (int i = 0; i < 3; i++) f->state_scaled[i] = SOS_SCALE_XI_TRANS * state[i];
+  for (int i = 3; i < 6; i++) f->state_scaled[i] = SOS_SCALE_XI_ROT * state[i];
+  f->state_scaled[6] = SOS_SCALE_A * state[6];
+  f->state_scaled[7] = SOS_SCALE_B * state[7];
+  f->state_scaled[8] = SOS_SCALE_A * state[8];
+  f->state_scaled[9] = SOS_SCALE_B * state[9];
+  orc_se3 E = orc_se3_exp(f->state_scaled);
+  f->PRE_camToWorld = orc_se3_mul(&E, &f->camToWorld_evalPT);
+  f->PRE_worldToCam = orc_se3_inverse(&f->PRE_camToWorld);
+}
+
+static void frame_take_data(orc_window *W, orc_hframe *f) { /* getPrior FS/HessianBlocks.h:280-302 + EFFrame::takeData */
+  double p[10];
+  memset(p, 0, sizeof(p));
+  if (f->frameID == 0) {
+    p[0] = p[1] = p[2] = SETTING_initialTransPrior;
+    p[3] = p[4] = p[5] = SETTING_initialRotPrior;
+    p[6] = SETTING_initialAffAPrior;
+    p[7] = SETTING_initialAffBPrior;
+  } else {
+    p[6] = W->prm.affineOptModeA < 0 ? SETTING_initialAffAPrior : W->prm.affineOptModeA;
+    p[7] = W->prm.affineOptModeB < 0 ? SETTING_initialAffBPrior : W->prm.affineOptModeB;
+  }
+  for (int i = 0; i < 8; i++) {
+    f->prior[i] = p[i];
+    f->delta[i] = f->state[i] - f->state_zero[i];
+    f->delta_prior[i] = f->state[i];
+  }
+}
+
+void orc_precalc_pair(const double *hostEval12, const double *targetEval12, const double *hostPRE12,
+                      const double *targetPRE12, const sos_calib *C, float host_ab, float target_ab,
+                      const double *host_aff, const double *target_aff, double host_b0, sos_precalc *out,
+                      float *distanceLL) { /* FS/HessianBlocks.cpp:431-461 */
+  orc_se3 hE = from12(hostEval12), tE = from12(targetEval12), hP = from12(hostPRE12), tP = from12(targetPRE12);
+  orc_se3 tEi = orc_se3_inverse(&tE);
+  orc_se3 l0 = orc_se3_mul(&tEi, &hE);
+  orc_se3 tPi = orc_se3_inverse(&tP); /* == PRE_worldToCam */
+  orc_se3 l = orc_se3_mul(&tPi, &hP);
+  float R[9], t[3];
+  for (int i = 0; i < 9; i++) { out->PRE_RTll_0[i] = (float)l0.R[i]; R[i] = (float)l.R[i]; }
+  for (int i = 0; i < 3; i++) { out->PRE_tTll_0[i] = (float)l0.t[i]; t[i] = (float)l.t[i]; }
+  if (distanceLL) *distanceLL = (float)sqrt(l.t[0] * l.t[0] + l.t[1] * l.t[1] + l.t[2] * l.t[2]);
+  /* K * R * K^-1 in float; K^-1 = [1/fx 0 -cx/fx; 0 1/fy -cy/fy; 0 0 1] */
+  float K[9] = {C->fxl, 0, C->cxl, 0, C->fyl, C->cyl, 0, 0, 1};
+  float Ki[9] = {C->fxli, 0, C->cxli, 0, C->fyli, C->cyli, 0, 0, 1};
+  float KR[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) KR[3 * i + j] = K[3 * i] * R[j] + K[3 * i + 1] * R[3 + j] + K[3 * i + 2] * R[6 + j];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      out->PRE_KRKiTll[3 * i + j] = KR[3 * i] * Ki[j] + KR[3 * i + 1] * Ki[3 + j] + KR[3 * i + 2] * Ki[6 + j];
+  for (int i = 0; i < 3; i++) out->PRE_KtTll[i] = K[3 * i] * t[0] + K[3 * i + 1] * t[1] + K[3 * i + 2] * t[2];
+  double aff[2];
+  from_to_vec_exposure(host_ab, target_ab, host_aff[0], host_aff[1], target_aff[0], target_aff[1], aff);
+  out->PRE_aff_mode[0] = (float)aff[0];
+  out->PRE_aff_mode[1] = (float)aff[1];
+  out->PRE_b0_mode = (float)host_b0;
+  out->pad = 0;
+}
+
+static void set_adjoints(orc_window *W) { /* OB/EnergyFunctional.cpp:42-103 */
+  int n = W->n;
+  for (int h = 0; h < n; h++)
+    for (int t = 0; t < n; t++) {
+      orc_hframe *host = &W->hf[h], *target = &W->hf[t];
+      orc_se3 w2t = orc_se3_inverse(&target->camToWorld_evalPT);
+      double Ad[36];
+      orc_se3_adj(&w2t, Ad);
+      double AH[64], AT[64];
+      memset(AH, 0, sizeof(AH)); memset(AT, 0, sizeof(AT));
+      for (int i = 0; i < 8; i++) AH[9 * i] = AT[9 * i] = 1;
+      for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) { AH[8 * i + j] = Ad[6 * j + i]; AT[8 * i + j] = -Ad[6 * j + i]; }
+      double aff[2];
+      from_to_vec_exposure(host->ab_exposure, target->ab_exposure, host->state_zero[6] * SOS_SCALE_A,
+                           host->state_zero[7] * SOS_SCALE_B, target->state_zero[6] * SOS_SCALE_A,
+                           target->state_zero[7] * SOS_SCALE_B, aff);
+      float a0 = (float)aff[0];
+      AT[8 * 6 + 6] = -a0; AH[8 * 6 + 6] = a0; AT[8 * 7 + 7] = -1; AH[8 * 7 + 7] = a0;
+      for (int j = 0; j < 8; j++) {
+        for (int i = 0; i < 3; i++) { AH[8 * i + j] *= SOS_SCALE_XI_TRANS; AT[8 * i + j] *= SOS_SCALE_XI_TRANS; }
+        for (int i = 3; i < 6; i++) { AH[8 * i + j] *= SOS_SCALE_XI_ROT; AT[8 * i + j] *= SOS_SCALE_XI_ROT; }
+        AH[8 * 6 + j] *= SOS_SCALE_A; AT[8 * 6 + j] *= SOS_SCALE_A;
+        AH[8 * 7 + j] *= SOS_SCALE_B; AT[8 * 7 + j] *= SOS_SCALE_B;
+      }
+      size_t idx = (size_t)(h + t * n);
+      memcpy(&W->adHost[64 * idx], AH, sizeof(AH));
+      memcpy(&W->adTarget[64 * idx], AT, sizeof(AT));
+      for (int i = 0; i < 64; i++) { W->adHostF[64 * idx + i] = (float)AH[i]; W->adTargetF[64 * idx + i] = (float)AT[i]; }
+    }
+}
+
+static void set_delta(orc_window *W) { /* OB/EnergyFunctional.cpp:163-194 */
+  int n = W->n;
+  for (int h = 0; h < n; h++)
+    for (int t = 0; t < n; t++) {
+      size_t idx = (size_t)(h + t * n);
+      float dh[8], dt[8];
+      for (int i = 0; i < 8; i++) {
+        dh[i] = (float)(W->hf[h].state[i] - W->hf[h].state_zero[i]);
+        dt[i] = (float)(W->hf[t].state[i] - W->hf[t].state_zero[i]);
+      }
+      for (int j = 0; j < 8; j++) {
+        float s1 = 0, s2 = 0;
+        for (int i = 0; i < 8; i++) { s1 += dh[i] * W->adHostF[64 * idx + 8 * i + j]; s2 += dt[i] * W->adTargetF[64 * idx + 8 * i + j]; }
+        W->adHTdeltaF[8 * idx + j] = s1 + s2;
+      }
+    }
+  for (int i = 0; i < 4; i++) W->cDeltaF[i] = (float)W->c_value_minus_value_zero[i];
+  for (int f = 0; f < n; f++)
+    for (int i = 0; i < 8; i++) {
+      W->hf[f].delta[i] = W->hf[f].state[i] - W->hf[f].state_zero[i];
+      W->hf[f].delta_prior[i] = W->hf[f].state[i];
+    }
+  /* p->deltaF = idepth - idepth_zero (SCALE_IDEPTH = 1) */
+  for (int p = 0; p < W->P; p++) W->pts[p].deltaF = W->pts[p].idepth_scaled - W->pts[p].idepth_zero_scaled;
+}
+
+void orc_host_precalc(orc_window *W) { /* FS/FullSystem.cpp:1099-1107 */
+  int n = W->n;
+  for (int h = 0; h < n; h++)
+    for (int t = 0; t < n; t++) {
+      double hE[12], tE[12], hP[12], tP[12];
+      to12(&W->hf[h].camToWorld_evalPT, hE); to12(&W->hf[t].camToWorld_evalPT, tE);
+      to12(&W->hf[h].PRE_camToWorld, hP); to12(&W->hf[t].PRE_camToWorld, tP);
+      double ha[2] = {W->hf[h].state_scaled[6], W->hf[h].state_scaled[7]};
+      double ta[2] = {W->hf[t].state_scaled[6], W->hf[t].state_scaled[7]};
+      orc_precalc_pair(hE, tE, hP, tP, &W->calib, W->hf[h].ab_exposure, W->hf[t].ab_exposure, ha, ta,
+                       W->hf[h].state_zero[7] * SOS_SCALE_B, &W->precalc[h + n * t], 0);
+    }
+  set_delta(W);
+}
+
+void orc_host_init(orc_window *W, const orc_frame_init *frames, const double *calib_value_scaled,
+                   const double *HM, const double *bM) {
+  int n = W->n, dim = 4 + 8 * n;
+  /* CalibHessian(): setValueScaled(initial); value_zero = value */
+  double v[4] = {calib_value_scaled[0] / SOS_SCALE_F, calib_value_scaled[1] / SOS_SCALE_F,
+                 calib_value_scaled[2] / SOS_SCALE_C, calib_value_scaled[3] / SOS_SCALE_C};
+  v[0] = (1.0f / SOS_SCALE_F) * calib_value_scaled[0];
+  v[1] = (1.0f / SOS_SCALE_F) * calib_value_scaled[1];
+  v[2] = (1.0f / SOS_SCALE_C) * calib_value_scaled[2];
+  v[3] = (1.0f / SOS_SCALE_C) * calib_value_scaled[3];
+  for (int i = 0; i < 4; i++) W->c_value_zero[i] = v[i];
+  calib_set_value(W, v);
+  for (int f = 0; f < n; f++) {
+    orc_hframe *F = &W->hf[f];
+    F->camToWorld_evalPT = from12(frames[f].camToWorld);
+    F->ab_exposure = frames[f].ab_exposure;
+    F->frameID = frames[f].frameID;
+    for (int i = 0; i < 10; i++) F->state_zero[i] = (i < 6) ? 0.0 : frames[f].state[i];
+    frame_set_state(F, frames[f].state);
+    memset(F->step, 0, sizeof(F->step));
+    frame_take_data(W, F);
+    W->frameEnergyTH[f] = frames[f].frameEnergyTH;
+  }
+  if (HM) memcpy(W->HM, HM, sizeof(double) * (size_t)dim * dim);
+  if (bM) memcpy(W->bM, bM, sizeof(double) * (size_t)dim);
+  set_adjoints(W);
+  orc_host_precalc(W);
+}
+
+void orc_host_get_frame(orc_window *W, int f, double *c2w, double *state, double *state_zero, float *th) {
+  if (c2w) to12(&W->hf[f].PRE_camToWorld, c2w);
+  if (state) memcpy(state, W->hf[f].state, sizeof(double) * 10);
+  if (state_zero) memcpy(state_zero, W->hf[f].state_zero, sizeof(double) * 10);
+  if (th) *th = W->frameEnergyTH[f];
+}
+void orc_host_get_calib(orc_window *W, double *vs) { memcpy(vs, W->c_value_scaled, sizeof(double) * 4); }
+const sos_precalc *orc_host_get_precalc(orc_window *W) { return W->precalc; }
+const float *orc_host_get_adHTdeltaF(orc_window *W) { return W->adHTdeltaF; }
+const double *orc_host_get_adHost(orc_window *W) { return W->adHost; }
+const double *orc_host_get_adTarget(orc_window *W) { return W->adTarget; }
+const double *orc_host_get_lastX(orc_window *W) { return W->lastX; }
+void orc_host_get_HM(orc_window *W, double *HM, double *bM) {
+  int dim = 4 + 8 * W->n;
+  memcpy(HM, W->HM, sizeof(double) * (size_t)dim * dim);
+  memcpy(bM, W->bM, sizeof(double) * (size_t)dim);
+}
+
+static int cmp_float(const void *a, const void *b) {
+  float x = *(const float *)a, y = *(const float *)b;
+  return (x > y) - (x < y);
+}
+
+static void set_new_frame_energy_th(orc_window *W) { /* FS/FullSystemOptimize.cpp:84-124 */
+  int newest = W->n - 1;
+  float *v = (float *)malloc(sizeof(float) * (size_t)(W->R > 0 ? W->R : 1));
+  int cnt = 0;
+  for (int r = 0; r < W->R; r++) {
+    if (W->res[r].flags & (SOS_RF_LINEARIZED | ORC_RF_REMOVED)) continue;
+    if (W->newEnergyWO[r] >= 0 && W->res[r].target == newest) v[cnt++] = W->newEnergyWO[r];
+  }
+  if (cnt == 0) {
+    W->frameEnergyTH[newest] = 12 * 12 * 8;
+    free(v);
+    return;
+  }
+  int nthIdx = (int)(W->prm.frameEnergyTHN * cnt);
+  qsort(v, (size_t)cnt, sizeof(float), cmp_float); /* nth_element: value at sorted position */
+  float nthElement = sqrtf(v[nthIdx]);
+  float th = nthElement * W->prm.frameEnergyTHFacMedian;
+  th = 26.0f * W->prm.frameEnergyTHConstWeight + th * (1 - W->prm.frameEnergyTHConstWeight);
+  th = th * th;
+  th *= W->prm.overallEnergyTHWeight * W->prm.overallEnergyTHWeight;
+  W->frameEnergyTH[newest] = th;
+  free(v);
+}
+
+/* linearizeAll, FS/FullSystemOptimize.cpp:125-182 */
+static double host_linearize_all(orc_window *W, int fix, int nthreads) {
+  double E = orc_linearize_all(W, W->frameEnergyTH, nthreads);
+  if (fix) { /* linearizeAll_Reductor with fixLinearization, :51-75 */
+    for (int r = 0; r < W->R; r++) {
+      sos_resid *res = &W->res[r];
+      if (res->flags & (SOS_RF_LINEARIZED | ORC_RF_REMOVED)) continue;
+      orc_apply_res_one(W, r);
+      if (res->flags & SOS_RF_ACTIVE) {
+        if (res->flags & SOS_RF_ISNEW) {
+          const sos_point *p = &W->pts[res->point];
+          const sos_precalc *pc = &W->precalc[res->host + W->n * res->target];
+          const float *K = pc->PRE_KRKiTll, *Kt = pc->PRE_KtTll;
+          float inf0 = K[0] * p->u + K[1] * p->v + K[2], inf1 = K[3] * p->u + K[4] * p->v + K[5],
+                inf2 = K[6] * p->u + K[7] * p->v + K[8];
+          float q0 = inf0 + Kt[0] * p->idepth_scaled, q1 = inf1 + Kt[1] * p->idepth_scaled,
+                q2 = inf2 + Kt[2] * p->idepth_scaled;
+          float dx = inf0 / inf2 - q0 / q2, dy = inf1 / inf2 - q1 / q2;
+          float relBS = (float)(0.01 * sqrtf(dx * dx + dy * dy));
+          if (relBS > W->maxRelBaseline[res->point]) W->maxRelBaseline[res->point] = relBS;
+          W->numGoodResiduals[res->point]++;
+        }
+      } else {
+        res->flags |= 0x200u; /* toRemove[tid].push_back; dropped after setNewFrameEnergyTH */
+      }
+    }
+  }
+  set_new_frame_energy_th(W);
+  if (fix) /* :148-179: ef->dropResidual for every residual in toRemove */
+    for (int r = 0; r < W->R; r++)
+      if (W->res[r].flags & 0x200u) W->res[r].flags = (W->res[r].flags & ~0x200u) | ORC_RF_REMOVED;
+  return E;
+}
+
+static void host_apply_res(orc_window *W) {
+  for (int r = 0; r < W->R; r++)
+    if (!(W->res[r].flags & (SOS_RF_LINEARIZED | ORC_RF_REMOVED))) orc_apply_res_one(W, r);
+}
+
+/* solveSystemF, OB/EnergyFunctional.cpp:1029-1184 (IMU off) */
+static void solve_system(orc_window *W, int nthreads) {
+  int n = W->n, dim = 4 + 8 * n;
+  size_t dd = (size_t)dim * dim;
+  double lambda = 1e-5;
+  double *HA = (double *)malloc(sizeof(double) * dd), *HL = (double *)malloc(sizeof(double) * dd),
+         *Hsc = (double *)malloc(sizeof(double) * dd);
+  double *bA = (double *)malloc(sizeof(double) * dim), *bL = (double *)malloc(sizeof(double) * dim),
+         *bsc = (double *)malloc(sizeof(double) * dim);
+  orc_accumulate(W, HA, bA, HL, bL, Hsc, bsc, &W->resInA, &W->resInL, 0, nthreads);
+  /* priors of the L stitch, OB/AccumulatedTopHessian.cpp:292-300 */
+  for (int i = 0; i < 4; i++) {
+    HL[(size_t)i * dim + i] += (double)W->prm.initialCalibHessian;
+    bL[i] += (double)W->prm.initialCalibHessian * (double)W->cDeltaF[i];
+  }
+  for (int h = 0; h < n; h++)
+    for (int i = 0; i < 8; i++) {
+      HL[(size_t)(4 + 8 * h + i) * dim + 4 + 8 * h + i] += W->hf[h].prior[i];
+      bL[4 + 8 * h + i] += W->hf[h].prior[i] * W->hf[h].delta_prior[i];
+    }
+  double *H = (double *)malloc(sizeof(double) * dd), *b = (double *)malloc(sizeof(double) * dim);
+  for (size_t i = 0; i < dd; i++) H[i] = HL[i] + HA[i];
+  for (int i = 0; i < dim; i++) b[i] = bL[i] + bA[i];
+  /* marginalization prior: bM + HM*delta, :1069-1091 */
+  double *delta = (double *)malloc(sizeof(double) * dim);
+  for (int i = 0; i < 4; i++) delta[i] = (double)W->cDeltaF[i];
+  for (int h = 0; h < n; h++)
+    for (int i = 0; i < 8; i++) delta[4 + 8 * h + i] = W->hf[h].delta[i];
+  for (int i = 0; i < dim; i++) {
+    double s = W->bM[i];
+    for (int j = 0; j < dim; j++) s += W->HM[(size_t)i * dim + j] * delta[j];
+    b[i] += s;
+  }
+  for (size_t i = 0; i < dd; i++) H[i] += W->HM[i];
+  for (int i = 0; i < dim; i++) H[(size_t)i * dim + i] *= (1 + lambda);
+  double isc = 1.0f / (1 + lambda);
+  for (size_t i = 0; i < dd; i++) H[i] -= Hsc[i] * isc;
+  for (int i = 0; i < dim; i++) b[i] -= bsc[i];
+  /* :1143-1148 */
+  double *S = (double *)malloc(sizeof(double) * dim), *x = (double *)malloc(sizeof(double) * dim);
+  for (int i = 0; i < dim; i++) S[i] = 1.0 / sqrt(H[(size_t)i * dim + i] + 10);
+  for (int i = 0; i < dim; i++) {
+    for (int j = 0; j < dim; j++) H[(size_t)i * dim + j] *= S[i] * S[j];
+    b[i] *= S[i];
+  }
+  orc_ldlt_solve(H, b, x, dim);
+  for (int i = 0; i < dim; i++) x[i] *= S[i];
+  memcpy(W->lastX, x, sizeof(double) * dim);
+  /* resubstituteF_MT, :496-524 */
+  for (int i = 0; i < 4; i++) W->c_step[i] = -x[i];
+  for (int h = 0; h < n; h++) {
+    for (int i = 0; i < 8; i++) W->hf[h].step[i] = -x[4 + 8 * h + i];
+    W->hf[h].step[8] = W->hf[h].step[9] = 0;
+  }
+  orc_resubstitute(W, x, 0, nthreads);
+  free(HA); free(HL); free(Hsc); free(bA); free(bL); free(bsc); free(H); free(b); free(delta); free(S); free(x);
+}
+
+static void backup_state(orc_window *W) { /* :260-269 */
+  memcpy(W->c_value_backup, W->c_value, sizeof(W->c_value));
+  for (int f = 0; f < W->n; f++) memcpy(W->hf[f].state_backup, W->hf[f].state, sizeof(double) * 10);
+  for (int p = 0; p < W->P; p++) W->idepth_backup[p] = W->pts[p].idepth_scaled;
+}
+
+static int do_step_from_backup(orc_window *W) { /* :185-257 with all step factors = 1 */
+  float sumA = 0, sumB = 0, sumT = 0, sumR = 0, sumID = 0, numID = 0, sumNID = 0;
+  double v[4];
+  for (int i = 0; i < 4; i++) v[i] = W->c_value_backup[i] + 1.0f * W->c_step[i];
+  calib_set_value(W, v);
+  for (int f = 0; f < W->n; f++) {
+    orc_hframe *F = &W->hf[f];
+    double s[10];
+    for (int i = 0; i < 10; i++) s[i] = F->state_backup[i] + 1.0 * F->step[i];
+    frame_set_state(F, s);
+    sumA += F->step[6] * F->step[6];
+    sumB += F->step[7] * F->step[7];
+    sumT += F->step[0] * F->step[0] + F->step[1] * F->step[1] + F->step[2] * F->step[2];
+    sumR += F->step[3] * F->step[3] + F->step[4] * F->step[4] + F->step[5] * F->step[5];
+  }
+  for (int p = 0; p < W->P; p++) {
+    float nid = W->idepth_backup[p] + 1.0f * W->step[p];
+    W->pts[p].idepth_scaled = nid;      /* setIdepth */
+    sumID += W->step[p] * W->step[p];
+    sumNID += fabsf(W->idepth_backup[p]);
+    numID++;
+    W->pts[p].idepth_zero_scaled = nid; /* setIdepthZero */
+  }
+  sumA /= W->n; sumB /= W->n; sumR /= W->n; sumT /= W->n;
+  sumID /= numID; sumNID /= numID;
+  (void)sumID;
+  orc_host_precalc(W);
+  return sqrtf(sumA) < 0.0005 * SETTING_thOptIterations && sqrtf(sumB) < 0.00005 * SETTING_thOptIterations &&
+         sqrtf(sumR) < 0.00005 * SETTING_thOptIterations &&
+         sqrtf(sumT) * sumNID < 0.00005 * SETTING_thOptIterations;
+}
+
+/* one loop body of FS/FullSystemOptimize.cpp:358-413 (forceAceptStep = true) */
+int orc_gn_iteration(orc_window *W, int iteration, int nthreads) {
+  (void)iteration;
+  backup_state(W);
+  solve_system(W, nthreads);
+  int canbreak = do_step_from_backup(W);
+  host_linearize_all(W, 0, nthreads);
+  host_apply_res(W);
+  return canbreak;
+}
+
+float orc_optimize(orc_window *W, int mnumOptIts, int nthreads, int *iters_out) {
+  int n = W->n;
+  if (iters_out) *iters_out = 0;
+  if (n < 2) return 0;
+  if (n < 3) mnumOptIts = 20;
+  if (n < 4) mnumOptIts = 15;
+  orc_reset_oob(W); /* :316-329 */
+  host_linearize_all(W, 0, nthreads);
+  host_apply_res(W);
+  int it = 0;
+  for (int iteration = 0; iteration < mnumOptIts; iteration++) {
+    int canbreak = orc_gn_iteration(W, iteration, nthreads);
+    it++;
+    if (canbreak && iteration >= SETTING_minOptIterations) break;
+  }
+  if (iters_out) *iters_out = it;
+  /* :415-425 */
+  orc_hframe *L = &W->hf[n - 1];
+  double nz[10];
+  memset(nz, 0, sizeof(nz));
+  nz[6] = L->state[6]; nz[7] = L->state[7];
+  L->camToWorld_evalPT = L->PRE_camToWorld; /* setEvalPT */
+  frame_set_state(L, nz);
+  memcpy(L->state_zero, nz, sizeof(nz));
+  set_adjoints(W);
+  orc_host_precalc(W);
+  double lastEnergy = host_linearize_all(W, 1, nthreads);
+  return sqrtf((float)(lastEnergy / (8 * W->resInA)));
+}
