@@ -19,38 +19,7 @@ c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int32)
 
 
-class Params(C.Structure):
-    _fields_ = [("w", C.c_int32), ("h", C.c_int32), ("huberTH", C.c_float),
-                ("outlierTHSumComponent", C.c_float), ("affineOptModeA", C.c_float),
-                ("affineOptModeB", C.c_float), ("idepthFixPrior", C.c_float),
-                ("idepthFixPriorMargFac", C.c_float), ("margWeightFac", C.c_float),
-                ("initialCalibHessian", C.c_float), ("coarseCutoffTH", C.c_float),
-                ("frameEnergyTHN", C.c_float), ("frameEnergyTHFacMedian", C.c_float),
-                ("frameEnergyTHConstWeight", C.c_float), ("overallEnergyTHWeight", C.c_float),
-                ("reserved", C.c_float * 3)]
-
-    @classmethod
-    def from_dict(cls, d):
-        p = cls()
-        for k, v in d.items():
-            setattr(p, k, v)
-        return p
-
-
-class Calib(C.Structure):
-    _fields_ = [(k, C.c_float) for k in ("fxl", "fyl", "cxl", "cyl", "fxli", "fyli", "cxli", "cyli")]
-
-    @classmethod
-    def from_K(cls, K):
-        """CalibHessian::setValueScaled, FS/HessianBlocks.h:493-506."""
-        c = cls()
-        f = np.asarray(K, dtype=np.float64).astype(np.float32)
-        c.fxl, c.fyl, c.cxl, c.cyl = [float(x) for x in f]
-        c.fxli = float(np.float32(1.0) / f[0])
-        c.fyli = float(np.float32(1.0) / f[1])
-        c.cxli = float(-f[2] / f[0])
-        c.cyli = float(-f[3] / f[1])
-        return c
+from sos_slam_amd.records import Calib, Params  # noqa: E402  (record mirrors only, no native code)
 
 
 def build(force: bool = False) -> str:

@@ -270,8 +270,8 @@ static void calc_res(orc_tracker *T, int lvl, const float *dINewl, const float *
     interp33t(dINewl, Ku, Kv, wl, hit);
     if (!isfinite(hit[0])) continue;
     float residual = scaleMode ? hit[0] - refColor : hit[0] - (float)(aff0 * refColor + aff1);
-    float hw = fabs(residual) < huber ? 1 : huber / fabs(residual);
-    if (fabs(residual) > cutoffTH) {
+    float hw = fabsf(residual) < huber ? 1 : huber / fabsf(residual); /* std::fabs(float) in the C++ reference */
+    if (fabsf(residual) > cutoffTH) {
       E += maxEnergy;
       numTermsInE++;
       numSaturated++;

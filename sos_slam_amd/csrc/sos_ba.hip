@@ -1,0 +1,1732 @@
+// sos_ba.hip -- device side of the OptimizationBackend (EnergyFunctional) for gfx950 / MI355X.
+//
+// Kernels (one per reference loop):
+//   k_linearize       PointFrameResidual::linearize           FS/Residuals.cpp:77-271
+//   k_apply_res       applyRes(true) (+ takeDataF, folded)    FS/Residuals.cpp:304-321
+//   k_top_accumulate  AccumulatedTopHessianSSE::addPoint<0|1> OB/AccumulatedTopHessian.cpp:35-147
+//   k_point_prep      per-point sums + Hdi/bdSum              OB/AccumulatedTopHessian.cpp:124-146,
+//                                                             OB/AccumulatedSCHessian.cpp:34-55
+//   k_sc_gram         AccumulatedSCHessianSSE::addPoint       OB/AccumulatedSCHessian.cpp:57-78  (f32 MFMA)
+//   k_reduce_*        sum of the partial accumulators         OB/AccumulatedTopHessian.cpp:252-259
+//   k_stitch_top/_sc  stitchDoubleInternal (fp64)             OB/AccumulatedTopHessian.cpp:231-301,
+//                                                             OB/AccumulatedSCHessian.cpp:80-158
+//   k_resubstitute    resubstituteFPt                         OB/EnergyFunctional.cpp:526-551
+//   k_fix_lin         EFResidual::fixLinearizationF           OB/EnergyFunctionalStructs.cpp:75-103
+//   k_lenergy         calcLEnergyPt                           OB/EnergyFunctional.cpp:563-624
+//
+// Data layout in HBM (DESIGN.md "data layout"):
+//   residuals are sorted by (isLinearized, pair = host + n*target) and padded per pair to tiles of 32;
+//   J[tile][72 planes][32] floats (9216 B per tile, written by ONE linearize block as one contiguous
+//   span); JpJd[s][8]; everything else SoA over the sorted index s.  PointFrameResidual::J and
+//   EFResidual::J share one buffer: with setting_forceAceptStep (util/settings.cpp:58) every linearize
+//   is followed by applyRes, and a residual's J is only ever read while it is active, i.e. after the
+//   apply that would have swapped it in.
+//
+// fp32 arithmetic convention: no FMA contraction (-ffp-contract=off), correctly rounded / and sqrt
+// (hipcc default), sums in the order of the reference source; the 8-pixel pattern sums are evaluated
+// sequentially pixel 0..7 through a DPP row_shr chain so that IN/OOB/OUTLIER sets are bit-exact.
+#include "sos_common.h"
+
+#include <algorithm>
+#include <numeric>
+#include <string>
+
+// ------------------------------------------------------------------------------------------------
+// device-visible description of a packed window
+// ------------------------------------------------------------------------------------------------
+struct BaDev {
+  int n, P, R, Rpad, ntiles, ntilesA;
+  int w, h;
+  float wM3G, hM3G;
+  sos_calib calib;
+  float huberTH, outlierTH, modeA, modeB;
+  const float *img[SOS_MAX_FRAMES];
+  const sos_precalc *precalc;
+  const float *adHTdelta;
+  const float *cdelta;
+  sos_point *pts;
+  const int *s_point, *s_orig;
+  uint8_t *s_flags, *s_state, *s_newstate;
+  float *s_energy, *s_newenergy, *s_newenergywo, *s_ret, *s_center, *s_rtz, *s_pterm;
+  const int *t_pair;
+  float *J, *JpJd;
+  const int *p_begin, *p_list, *p_res_t;
+  float *p_out;  // 16 floats per point
+  uint8_t *o_newstate;
+  float *o_newenergy, *o_newenergywo, *o_center;
+};
+
+#define PO_HDD_A 0
+#define PO_BD_A 1
+#define PO_HCD_A 2
+#define PO_HDD_L 6
+#define PO_BD_L 7
+#define PO_HCD_L 8
+#define PO_HDI 12
+#define PO_BDSUM 13
+#define PO_IDH 14
+#define PO_STEP 15
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ float row_shr(float v) {  // lane i reads lane i-N of its 16-lane row
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + N, 0xf, 0xf, false));
+}
+// ((((((v0+v1)+v2)+v3)+v4)+v5)+v6)+v7 over the 8 lanes of a pattern group; valid in lane 7 of the group
+__device__ __forceinline__ float seqsum8(float v) {
+  float s = 0.0f + row_shr<7>(v);
+  s = s + row_shr<6>(v);
+  s = s + row_shr<5>(v);
+  s = s + row_shr<4>(v);
+  s = s + row_shr<3>(v);
+  s = s + row_shr<2>(v);
+  s = s + row_shr<1>(v);
+  s = s + v;
+  return s;
+}
+
+// ================================================================================================
+// k_linearize: one 256-thread block = one tile of 32 residuals of ONE (host,target) pair;
+// 8 lanes per residual, one lane per pattern pixel.
+// ================================================================================================
+#define SJ_STRIDE 40  // LDS row stride (floats): == 8 mod 32 -> the 8x8 (pixel, residual) stores are 2-way at worst
+
+__global__ __launch_bounds__(256) void k_linearize(BaDev d, const float *__restrict__ frameTH) {
+  __shared__ float sJ[SOS_JPLANES * SJ_STRIDE];
+  __shared__ unsigned int sLin;
+  const int tile = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int rl = tid >> 3, idx = tid & 7;
+  const int lane = tid & 63;
+  const int s = tile * SOS_TILE + rl;
+  const int pair = d.t_pair[tile];
+  const int hIdx = pair % d.n, tIdx = pair / d.n;
+  const sos_precalc *pc = d.precalc + pair;
+  const float *__restrict__ img = d.img[tIdx];
+  if (tid == 0) sLin = 0;
+  __syncthreads();
+
+  const int p_raw = d.s_point[s];
+  const bool valid = p_raw >= 0;
+  const int p = valid ? p_raw : 0;
+  const unsigned flags = d.s_flags[s];
+  const bool isLin = valid && (flags & DF_LINEARIZED);
+  const int st = d.s_state[s];
+  const float old_energy = d.s_energy[s];
+  const sos_point *pt = d.pts + p;
+  const float pu = pt->u, pv = pt->v, id = pt->idepth_scaled, idz = pt->idepth_zero_scaled;
+  const float color = pt->color[idx], pweight = pt->weights[idx];
+
+  const float fxl = d.calib.fxl, fyl = d.calib.fyl, cxl = d.calib.cxl, cyl = d.calib.cyl;
+  const float fxli = d.calib.fxli, fyli = d.calib.fyli;
+
+  // ---- centre projection with the FEJ pose / idepth (FS/ResidualProjections.h:52-73) -- all 8 lanes
+  const float KliP0 = (pu - cxl) * fxli;
+  const float KliP1 = (pv - cyl) * fyli;
+  const float ptp0 = pc->PRE_RTll_0[0] * KliP0 + pc->PRE_RTll_0[1] * KliP1 + pc->PRE_RTll_0[2] + pc->PRE_tTll_0[0] * idz;
+  const float ptp1 = pc->PRE_RTll_0[3] * KliP0 + pc->PRE_RTll_0[4] * KliP1 + pc->PRE_RTll_0[5] + pc->PRE_tTll_0[1] * idz;
+  const float ptp2 = pc->PRE_RTll_0[6] * KliP0 + pc->PRE_RTll_0[7] * KliP1 + pc->PRE_RTll_0[8] + pc->PRE_tTll_0[2] * idz;
+  const float drescale = 1.0f / ptp2;
+  const float new_idepth = idz * drescale;
+  const float cu = ptp0 * drescale, cv = ptp1 * drescale;
+  const float cKu = cu * fxl + cxl, cKv = cv * fyl + cyl;
+  const bool center_ok = (drescale > 0) && cKu > 1.1f && cKv > 1.1f && cKu < d.wM3G && cKv < d.hM3G;
+
+  // ---- this lane's pattern pixel with the current pose / idepth (FS/ResidualProjections.h:43-50)
+  const int px = (int)((0x21420312u >> (4 * idx)) & 0xf) - 2;  // {0,-1,1,-2,0,2,-1,0}
+  const int py = (int)((0x43222110u >> (4 * idx)) & 0xf) - 2;  // {-2,-1,-1,0,0,0,1,2}
+  const float u_pt = pu + (float)px, v_pt = pv + (float)py;
+  const float q0 = pc->PRE_KRKiTll[0] * u_pt + pc->PRE_KRKiTll[1] * v_pt + pc->PRE_KRKiTll[2] + pc->PRE_KtTll[0] * id;
+  const float q1 = pc->PRE_KRKiTll[3] * u_pt + pc->PRE_KRKiTll[4] * v_pt + pc->PRE_KRKiTll[5] + pc->PRE_KtTll[1] * id;
+  const float q2 = pc->PRE_KRKiTll[6] * u_pt + pc->PRE_KRKiTll[7] * v_pt + pc->PRE_KRKiTll[8] + pc->PRE_KtTll[2] * id;
+  const float Ku = q0 / q2, Kv = q1 / q2;
+  const bool inb = Ku > 1.1f && Kv > 1.1f && Ku < d.wM3G && Kv < d.hM3G;
+
+  // ---- bilinear (I,dx,dy) tap (util/globalFuncs.h:68-82); addresses clamped so the loads are always legal
+  int ix = (int)Ku, iy = (int)Kv;
+  const float fdx = Ku - (float)ix, fdy = Kv - (float)iy;
+  ix = min(max(ix, 0), d.w - 2);
+  iy = min(max(iy, 0), d.h - 2);
+  const float *bp = img + 3 * (ix + iy * d.w);
+  const float a0 = bp[0], a1 = bp[1], a2 = bp[2], b0_ = bp[3], b1_ = bp[4], b2_ = bp[5];
+  const float *bq = bp + 3 * d.w;
+  const float c0 = bq[0], c1 = bq[1], c2 = bq[2], d0 = bq[3], d1 = bq[4], d2 = bq[5];
+  const float dxdy = fdx * fdy;
+  const float w11 = dxdy, w01 = fdy - dxdy, w10 = fdx - dxdy, w00 = 1 - fdx - fdy + dxdy;
+  const float hit0 = w11 * d0 + w01 * c0 + w10 * b0_ + w00 * a0;
+  float hit1 = w11 * d1 + w01 * c1 + w10 * b1_ + w00 * a1;
+  float hit2 = w11 * d2 + w01 * c2 + w10 * b2_ + w00 * a2;
+
+  const bool lane_oob = !inb || !isfinite(hit0);
+  const unsigned long long oobmask = __ballot(lane_oob);
+  const bool grp_oob = ((oobmask >> (lane & 56)) & 0xffull) != 0;
+
+  // ---- photometric residual, weights (FS/Residuals.cpp:189-241)
+  const float affLL0 = pc->PRE_aff_mode[0], affLL1 = pc->PRE_aff_mode[1], b0 = pc->PRE_b0_mode;
+  const float residual = hit0 - (float)(affLL0 * color + affLL1);
+  const float drdA = color - b0;
+  float wgt = sqrtf(d.outlierTH / (d.outlierTH + (hit1 * hit1 + hit2 * hit2)));
+  wgt = 0.5f * (wgt + pweight);
+  float hw = fabsf(residual) < d.huberTH ? 1 : d.huberTH / fabsf(residual);
+  const float e_i = wgt * wgt * hw * residual * residual * (2 - hw);
+  if (hw < 1) hw = sqrtf(hw);
+  hw = hw * wgt;
+  hit1 *= hw;
+  hit2 *= hw;
+  const float resF = residual * hw;
+  const float JabF0 = drdA * hw;
+
+  const float energyLeft0 = seqsum8(e_i);
+  const float JIdxJIdx_00 = seqsum8(hit1 * hit1);
+  const float JIdxJIdx_11 = seqsum8(hit2 * hit2);
+  const float JIdxJIdx_10 = seqsum8(hit1 * hit2);
+  const float JabJIdx_00 = seqsum8(drdA * hw * hit1);
+  const float JabJIdx_01 = seqsum8(drdA * hw * hit2);
+  const float JabJIdx_10 = seqsum8(hw * hit1);
+  const float JabJIdx_11 = seqsum8(hw * hit2);
+  const float JabJab_00 = seqsum8(drdA * drdA * hw * hw);
+  const float JabJab_01 = seqsum8(drdA * hw * hw);
+  const float JabJab_11 = seqsum8(hw * hw);
+  const float wJI2_sum = seqsum8(hw * hw * (hit1 * hit1 + hit2 * hit2));
+
+  // ---- per-pixel rows of the Jacobian -> LDS staging
+  sJ[(JP_RESF + idx) * SJ_STRIDE + rl] = resF;
+  sJ[(JP_JIDX0 + idx) * SJ_STRIDE + rl] = hit1;
+  sJ[(JP_JIDX1 + idx) * SJ_STRIDE + rl] = hit2;
+  sJ[(JP_JAB0 + idx) * SJ_STRIDE + rl] = d.modeA < 0 ? 0.0f : JabF0;
+  sJ[(JP_JAB1 + idx) * SJ_STRIDE + rl] = d.modeB < 0 ? 0.0f : hw;
+
+  if (idx == 7) {
+    // ---- geometric Jacobians (FS/Residuals.cpp:116-157)
+    const float *R0 = pc->PRE_RTll_0, *t0 = pc->PRE_tTll_0;
+    const float d_d_x = drescale * (t0[0] - t0[2] * cu) * SOS_SCALE_IDEPTH * fxl;
+    const float d_d_y = drescale * (t0[1] - t0[2] * cv) * SOS_SCALE_IDEPTH * fyl;
+    float dCx2 = drescale * (R0[6] * cu - R0[0]);
+    float dCx3 = fxl * drescale * (R0[7] * cu - R0[1]) * fyli;
+    float dCx0 = KliP0 * dCx2;
+    float dCx1 = KliP1 * dCx3;
+    float dCy2 = fyl * drescale * (R0[6] * cv - R0[3]) * fxli;
+    float dCy3 = drescale * (R0[7] * cv - R0[4]);
+    float dCy0 = KliP0 * dCy2;
+    float dCy1 = KliP1 * dCy3;
+    dCx0 = (dCx0 + cu) * SOS_SCALE_F;
+    dCx1 *= SOS_SCALE_F;
+    dCx2 = (dCx2 + 1) * SOS_SCALE_C;
+    dCx3 *= SOS_SCALE_C;
+    dCy0 *= SOS_SCALE_F;
+    dCy1 = (dCy1 + cv) * SOS_SCALE_F;
+    dCy2 *= SOS_SCALE_C;
+    dCy3 = (dCy3 + 1) * SOS_SCALE_C;
+    const float dxi_x[6] = {new_idepth * fxl, 0.0f, -new_idepth * cu * fxl, -cu * cv * fxl, (1 + cu * cu) * fxl, -cv * fxl};
+    const float dxi_y[6] = {0.0f, new_idepth * fyl, -new_idepth * cv * fyl, -(1 + cv * cv) * fyl, cu * cv * fyl, cu * fyl};
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      sJ[(JP_DXI0 + i) * SJ_STRIDE + rl] = dxi_x[i];
+      sJ[(JP_DXI1 + i) * SJ_STRIDE + rl] = dxi_y[i];
+    }
+    sJ[(JP_DC0 + 0) * SJ_STRIDE + rl] = dCx0;
+    sJ[(JP_DC0 + 1) * SJ_STRIDE + rl] = dCx1;
+    sJ[(JP_DC0 + 2) * SJ_STRIDE + rl] = dCx2;
+    sJ[(JP_DC0 + 3) * SJ_STRIDE + rl] = dCx3;
+    sJ[(JP_DC1 + 0) * SJ_STRIDE + rl] = dCy0;
+    sJ[(JP_DC1 + 1) * SJ_STRIDE + rl] = dCy1;
+    sJ[(JP_DC1 + 2) * SJ_STRIDE + rl] = dCy2;
+    sJ[(JP_DC1 + 3) * SJ_STRIDE + rl] = dCy3;
+    sJ[(JP_DD + 0) * SJ_STRIDE + rl] = d_d_x;
+    sJ[(JP_DD + 1) * SJ_STRIDE + rl] = d_d_y;
+    sJ[(JP_JIDX2 + 0) * SJ_STRIDE + rl] = JIdxJIdx_00;
+    sJ[(JP_JIDX2 + 1) * SJ_STRIDE + rl] = JIdxJIdx_10;
+    sJ[(JP_JIDX2 + 2) * SJ_STRIDE + rl] = JIdxJIdx_11;
+    sJ[(JP_JABJIDX + 0) * SJ_STRIDE + rl] = JabJIdx_00;
+    sJ[(JP_JABJIDX + 1) * SJ_STRIDE + rl] = JabJIdx_01;
+    sJ[(JP_JABJIDX + 2) * SJ_STRIDE + rl] = JabJIdx_10;
+    sJ[(JP_JABJIDX + 3) * SJ_STRIDE + rl] = JabJIdx_11;
+    sJ[(JP_JAB2 + 0) * SJ_STRIDE + rl] = JabJab_00;
+    sJ[(JP_JAB2 + 1) * SJ_STRIDE + rl] = JabJab_01;
+    sJ[(JP_JAB2 + 2) * SJ_STRIDE + rl] = JabJab_11;
+
+    // ---- classification (FS/Residuals.cpp:78-83,107-112,258-270)
+    int newState;
+    float newEnergy = 0.f, newEnergyWO = -1.f, ret;
+    if (!valid) {
+      newState = SOS_RES_OOB;
+      ret = 0.f;
+    } else if (isLin) {  // not in activeResiduals (FS/FullSystemOptimize.cpp:321)
+      newState = st;
+      ret = 0.f;
+      newEnergy = d.s_newenergy[s];
+      atomicOr(&sLin, 1u << rl);
+    } else if (st == SOS_RES_OOB || !center_ok || grp_oob) {
+      newState = SOS_RES_OOB;
+      ret = old_energy;
+      newEnergy = d.s_newenergy[s];
+    } else {
+      float energyLeft = energyLeft0;
+      newEnergyWO = energyLeft;
+      const float th = fmaxf(frameTH[hIdx], frameTH[tIdx]);
+      if (energyLeft > th || wJI2_sum < 2) {
+        energyLeft = th;
+        newState = SOS_RES_OUTLIER;
+      } else {
+        newState = SOS_RES_IN;
+      }
+      newEnergy = energyLeft;
+      ret = energyLeft;
+    }
+    d.s_newstate[s] = (uint8_t)newState;
+    d.s_newenergy[s] = newEnergy;
+    d.s_newenergywo[s] = newEnergyWO;
+    d.s_ret[s] = ret;
+    const bool wrote_center = valid && !isLin && st != SOS_RES_OOB && center_ok;
+    if (wrote_center) {
+      d.s_center[3 * s + 0] = cKu;
+      d.s_center[3 * s + 1] = cKv;
+      d.s_center[3 * s + 2] = new_idepth;
+    }
+    if (valid && !isLin) {
+      // JpJdF of EFResidual::takeDataF (OB/EnergyFunctionalStructs.cpp:39-44)
+      const float v0 = JIdxJIdx_00 * d_d_x + JIdxJIdx_10 * d_d_y;
+      const float v1 = JIdxJIdx_10 * d_d_x + JIdxJIdx_11 * d_d_y;
+      float4 o0, o1;
+      o0.x = dxi_x[0] * v0 + dxi_y[0] * v1;
+      o0.y = dxi_x[1] * v0 + dxi_y[1] * v1;
+      o0.z = dxi_x[2] * v0 + dxi_y[2] * v1;
+      o0.w = dxi_x[3] * v0 + dxi_y[3] * v1;
+      o1.x = dxi_x[4] * v0 + dxi_y[4] * v1;
+      o1.y = dxi_x[5] * v0 + dxi_y[5] * v1;
+      o1.z = JabJIdx_00 * d_d_x + JabJIdx_01 * d_d_y;
+      o1.w = JabJIdx_10 * d_d_x + JabJIdx_11 * d_d_y;
+      float4 *jp = reinterpret_cast<float4 *>(d.JpJd + 8 * (size_t)s);
+      jp[0] = o0;
+      jp[1] = o1;
+    }
+    const int orig = d.s_orig[s];
+    if (orig >= 0) {
+      if (d.o_newstate) d.o_newstate[orig] = (uint8_t)newState;
+      if (d.o_newenergy) d.o_newenergy[orig] = newEnergy;
+      if (d.o_newenergywo) d.o_newenergywo[orig] = newEnergyWO;
+      if (d.o_center && wrote_center) {
+        d.o_center[3 * orig + 0] = cKu;
+        d.o_center[3 * orig + 1] = cKv;
+        d.o_center[3 * orig + 2] = new_idepth;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- copy the staged tile out: 72 rows x 128 B, contiguous 9216 B span of J
+  float *Jt = d.J + (size_t)tile * SOS_TILE_FLOATS;
+  const unsigned linmask = sLin;
+  for (int q = tid; q < SOS_JPLANES * 8; q += 256) {
+    const int plane = q >> 3, chunk = q & 7;
+    const float4 v = *reinterpret_cast<const float4 *>(&sJ[plane * SJ_STRIDE + 4 * chunk]);
+    float *dst = Jt + plane * SOS_TILE + 4 * chunk;
+    const unsigned lm = (linmask >> (4 * chunk)) & 0xfu;
+    if (lm == 0) {
+      *reinterpret_cast<float4 *>(dst) = v;
+    } else {  // keep the frozen Jacobian of linearized residuals sharing this tile (rare)
+      if (!(lm & 1u)) dst[0] = v.x;
+      if (!(lm & 2u)) dst[1] = v.y;
+      if (!(lm & 4u)) dst[2] = v.z;
+      if (!(lm & 8u)) dst[3] = v.w;
+    }
+  }
+}
+
+// sum of the returned energies in double, fixed order: deterministic
+__global__ __launch_bounds__(1024) void k_sum_ret(const float *__restrict__ ret, int n, double *out) {
+  __shared__ double sm[1024];
+  double a = 0;
+  for (int i = threadIdx.x; i < n; i += 1024) a += (double)ret[i];
+  sm[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = sm[0];
+}
+
+// ================================================================================================
+// applyRes(true) / resetOOB
+// ================================================================================================
+__global__ void k_apply_res(BaDev d) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= d.ntilesA * SOS_TILE) return;
+  if (d.s_point[s] < 0) return;
+  unsigned f = d.s_flags[s];
+  if (f & DF_LINEARIZED) return;
+  if (d.s_state[s] == SOS_RES_OOB) return;  // can never go back from OOB
+  const int ns = d.s_newstate[s];
+  f = (ns == SOS_RES_IN) ? (f | DF_ACTIVE) : (f & ~DF_ACTIVE);
+  d.s_flags[s] = (uint8_t)f;
+  d.s_state[s] = (uint8_t)ns;
+  d.s_energy[s] = d.s_newenergy[s];
+}
+
+__global__ void k_reset_oob(BaDev d) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= d.ntilesA * SOS_TILE) return;
+  if (d.s_point[s] < 0 || (d.s_flags[s] & DF_LINEARIZED)) return;
+  d.s_newenergy[s] = 0;
+  d.s_energy[s] = 0;
+  d.s_newstate[s] = SOS_RES_OUTLIER;
+  d.s_state[s] = SOS_RES_IN;
+}
+
+// ================================================================================================
+// k_top_accumulate: lane = residual, half-wave (32 lanes) = tile.  91 uniques of the 13x13 block are
+// formed per residual in registers and reduced over the tile with a transposed butterfly (93 shuffles
+// instead of 5*91); lane l of the half ends up owning 3 of the 96 (padded) sums.
+// ================================================================================================
+template <int HALF>
+__device__ __forceinline__ void bfly_step(float *v, int m, bool hi) {
+#pragma unroll
+  for (int i = 0; i < HALF; i++) {
+    const float a = v[i], b = v[i + HALF];
+    const float send = hi ? a : b;
+    const float keep = hi ? b : a;
+    v[i] = keep + __shfl_xor(send, m, 64);
+  }
+}
+
+// gather variant: `list` holds, per virtual tile, 32 sorted residual indices (-1 = empty)
+template <bool GATHER>
+__global__ __launch_bounds__(256) void k_top_accumulate(BaDev d, int tile0, int ntile, int mode,
+                                                        const int *__restrict__ list,
+                                                        const int *__restrict__ list_pair,
+                                                        float *__restrict__ top_part, int *__restrict__ top_cnt) {
+  const int lane = threadIdx.x & 63;
+  const int vt = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);  // virtual tile
+  const int r = lane & 31;
+  const bool tile_ok = vt < ntile;
+  int s, pair;
+  if (GATHER) {
+    s = tile_ok ? list[vt * SOS_TILE + r] : -1;
+    pair = tile_ok ? list_pair[vt] : 0;
+  } else {
+    s = tile_ok ? (tile0 + vt) * SOS_TILE + r : -1;
+    pair = tile_ok ? d.t_pair[tile0 + vt] : 0;
+  }
+  const bool have = s >= 0 && d.s_point[s >= 0 ? s : 0] >= 0;
+  const int ss = have ? s : 0;
+  const unsigned f = d.s_flags[ss];
+  bool use = have && (f & DF_ACTIVE);
+  if (mode == 0) use = use && !(f & DF_LINEARIZED);
+  if (mode == 1) use = use && (f & DF_LINEARIZED);
+
+  const float *Jt = d.J + (size_t)(ss >> 5) * SOS_TILE_FLOATS + (ss & 31);
+#define JL(pl) Jt[(pl)*SOS_TILE]
+  float x[10], y[10];
+#pragma unroll
+  for (int i = 0; i < 4; i++) { x[i] = JL(JP_DC0 + i); y[i] = JL(JP_DC1 + i); }
+#pragma unroll
+  for (int i = 0; i < 6; i++) { x[4 + i] = JL(JP_DXI0 + i); y[4 + i] = JL(JP_DXI1 + i); }
+  const float Jpdd0 = JL(JP_DD), Jpdd1 = JL(JP_DD + 1);
+  const float a = JL(JP_JIDX2), b = JL(JP_JIDX2 + 1), c = JL(JP_JIDX2 + 2);
+  const float jab00 = JL(JP_JABJIDX), jab01 = JL(JP_JABJIDX + 1), jab10 = JL(JP_JABJIDX + 2), jab11 = JL(JP_JABJIDX + 3);
+  const float ab00 = JL(JP_JAB2), ab01 = JL(JP_JAB2 + 1), ab11 = JL(JP_JAB2 + 2);
+
+  // resApprox (OB/AccumulatedTopHessian.cpp:68-98)
+  float Jp_delta_x = 0, Jp_delta_y = 0, dp6 = 0, dp7 = 0;
+  if (mode == 1) {
+    const float *dp = d.adHTdelta + 8 * pair;
+    float dx = 0, dy = 0, dcx = 0, dcy = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) { dx += x[4 + i] * dp[i]; dy += y[4 + i] * dp[i]; }
+#pragma unroll
+    for (int i = 0; i < 4; i++) { dcx += x[i] * d.cdelta[i]; dcy += y[i] * d.cdelta[i]; }
+    const float dd = d.pts[have ? d.s_point[ss] : 0].deltaF;
+    Jp_delta_x = dx + dcx + Jpdd0 * dd;
+    Jp_delta_y = dy + dcy + Jpdd1 * dd;
+    dp6 = dp[6];
+    dp7 = dp[7];
+  }
+  float JI_r0 = 0, JI_r1 = 0, Jab_r0 = 0, Jab_r1 = 0, rr = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const float ji0 = JL(JP_JIDX0 + i), ji1 = JL(JP_JIDX1 + i), ja0 = JL(JP_JAB0 + i), ja1 = JL(JP_JAB1 + i);
+    float ra;
+    if (mode == 0) ra = JL(JP_RESF + i);
+    else {
+      float rtz = d.s_rtz[8 * (size_t)ss + i];
+      if (mode == 1) {
+        rtz = rtz + ji0 * Jp_delta_x;
+        rtz = rtz + ji1 * Jp_delta_y;
+        rtz = rtz + ja0 * dp6;
+        rtz = rtz + ja1 * dp7;
+      }
+      ra = rtz;
+    }
+    JI_r0 += ra * ji0;
+    JI_r1 += ra * ji1;
+    Jab_r0 += ra * ja0;
+    Jab_r1 += ra * ja1;
+    rr += ra * ra;
+  }
+#undef JL
+  // per-residual terms of the point sums (OB/AccumulatedTopHessian.cpp:124-127)
+  {
+    const float Ji2_Jpdd0 = a * Jpdd0 + b * Jpdd1;
+    const float Ji2_Jpdd1 = b * Jpdd0 + c * Jpdd1;
+    if (have) {
+      float *pt = d.s_pterm + 6 * (size_t)ss;
+      pt[0] = use ? Ji2_Jpdd0 * Jpdd0 + Ji2_Jpdd1 * Jpdd1 : 0.f;
+      pt[1] = use ? JI_r0 * Jpdd0 + JI_r1 * Jpdd1 : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; i++) pt[2 + i] = use ? x[i] * Ji2_Jpdd0 + y[i] * Ji2_Jpdd1 : 0.f;
+    }
+  }
+
+  float v[SOS_TOPN];
+  {
+    int k = 0;
+#pragma unroll
+    for (int rr_ = 0; rr_ < 10; rr_++)
+#pragma unroll
+      for (int cc = rr_; cc < 10; cc++) {  // AccumulatorApprox::update, OB/MatrixAccumulators.h:928-1055
+        const float t = a * x[cc] * x[rr_] + c * y[cc] * y[rr_] + b * (x[cc] * y[rr_] + y[cc] * x[rr_]);
+        v[k++] = use ? t : 0.f;
+      }
+#pragma unroll
+    for (int i = 0; i < 10; i++) {  // updateTopRight :1057-1101
+      v[k++] = use ? x[i] * jab00 + y[i] * jab01 : 0.f;
+      v[k++] = use ? x[i] * jab10 + y[i] * jab11 : 0.f;
+      v[k++] = use ? x[i] * JI_r0 + y[i] * JI_r1 : 0.f;
+    }
+    v[85] = use ? ab00 : 0.f;  // updateBotRight :1103-1112
+    v[86] = use ? ab01 : 0.f;
+    v[87] = use ? Jab_r0 : 0.f;
+    v[88] = use ? ab11 : 0.f;
+    v[89] = use ? Jab_r1 : 0.f;
+    v[90] = use ? rr : 0.f;
+    v[91] = use ? 1.f : 0.f;  // nres
+    v[92] = v[93] = v[94] = v[95] = 0.f;
+  }
+  bfly_step<48>(v, 16, (r & 16) != 0);
+  bfly_step<24>(v, 8, (r & 8) != 0);
+  bfly_step<12>(v, 4, (r & 4) != 0);
+  bfly_step<6>(v, 2, (r & 2) != 0);
+  bfly_step<3>(v, 1, (r & 1) != 0);
+  if (tile_ok) {
+    const int base = ((r >> 4) & 1) * 48 + ((r >> 3) & 1) * 24 + ((r >> 2) & 1) * 12 + ((r >> 1) & 1) * 6 + (r & 1) * 3;
+    float *o = top_part + (size_t)vt * SOS_TOPN + base;
+    o[0] = v[0];
+    o[1] = v[1];
+    o[2] = v[2];
+  }
+  (void)top_cnt;
+}
+
+// per (mode, pair): sum the tile partials in fp64 (as the reference sums its per-thread accumulators,
+// OB/AccumulatedTopHessian.cpp:252-259) and store the fp32 block into the packed accumulator buffer
+__global__ void k_reduce_top(const float *__restrict__ top_part, const int *__restrict__ pair_tile_begin,
+                             float *__restrict__ out /* npairs*91 */, float *__restrict__ nres_out) {
+  const int pair = blockIdx.x;
+  const int k = threadIdx.x;  // 0..95
+  const int t0 = pair_tile_begin[pair], t1 = pair_tile_begin[pair + 1];
+  double a = 0;
+  for (int t = t0; t < t1; t++) a += (double)top_part[(size_t)t * SOS_TOPN + k];
+  if (k < 91) out[(size_t)pair * 91 + k] = (float)a;
+  if (k == 91) atomicAdd(nres_out, (float)a);  // small integers: exact and order-independent
+}
+
+// ================================================================================================
+// k_point_prep: one thread per point, residuals visited in EFPoint::residualsAll order
+// ================================================================================================
+__global__ void k_point_prep(BaDev d, int shiftPriorToZero, const int *__restrict__ plist, int count, int margMode) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const int p = plist ? plist[i] : i;
+  float HddA = 0, bdA = 0, HcdA[4] = {0, 0, 0, 0}, HddL = 0, bdL = 0, HcdL[4] = {0, 0, 0, 0};
+  int ngood = 0;
+  for (int q = d.p_begin[p]; q < d.p_begin[p + 1]; q++) {
+    const int s = d.p_list[q];
+    const unsigned f = d.s_flags[s];
+    if (!(f & DF_ACTIVE)) continue;
+    ngood++;
+    const float *pt = d.s_pterm + 6 * (size_t)s;
+    if ((f & DF_LINEARIZED) || margMode) {
+      HddL += pt[0];
+      bdL += pt[1];
+      for (int k = 0; k < 4; k++) HcdL[k] += pt[2 + k];
+    } else {
+      HddA += pt[0];
+      bdA += pt[1];
+      for (int k = 0; k < 4; k++) HcdA[k] += pt[2 + k];
+    }
+  }
+  float *o = d.p_out + 16 * (size_t)p;
+  o[PO_HDD_A] = HddA;
+  o[PO_BD_A] = bdA;
+  o[PO_HDD_L] = HddL;
+  o[PO_BD_L] = bdL;
+  for (int k = 0; k < 4; k++) { o[PO_HCD_A + k] = HcdA[k]; o[PO_HCD_L + k] = HcdL[k]; }
+  if (ngood == 0) {  // OB/AccumulatedSCHessian.cpp:34-44
+    o[PO_HDI] = 0;
+    o[PO_BDSUM] = 0;
+    o[PO_IDH] = 0;
+    return;
+  }
+  const sos_point *pt = d.pts + p;
+  float H = HddA + HddL + pt->priorF;
+  if (H < 1e-10) H = 1e-10;
+  o[PO_IDH] = H;
+  o[PO_HDI] = (float)(1.0 / (double)H);
+  float bdSum = bdA + bdL;
+  if (shiftPriorToZero) bdSum += pt->priorF * pt->deltaF;
+  o[PO_BDSUM] = bdSum;
+}
+
+// ================================================================================================
+// k_sc_gram: G = sum_p Hdi_p e_p e_p^T with e_p = [JpJdF(p,t=0..n-1) (8n) | Hcd (4) | bdSum | 0...]
+// over a chunk of 64 points of one host.  The D / E / EB / Hcc / bc accumulators of
+// AccumulatedSCHessianSSE::addPoint (OB/AccumulatedSCHessian.cpp:57-78) are sub-blocks of G.
+// v_mfma_f32_16x16x4_f32: K = points.  4 waves share the Dm/16 x Dm/16 output tiles.
+// ================================================================================================
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void k_sc_gram(BaDev d, const int *__restrict__ chunk_pt /* nchunks*64 point ids */,
+                                                 int Dm, int ld, float *__restrict__ gram_part) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *A = smem;              // [64][ld]
+  float *sHdi = smem + 64 * ld; // [64]
+  const int blk = blockIdx.x, tid = threadIdx.x;
+  const int n = d.n;
+  for (int q = tid; q < 64 * ld; q += 256) A[q] = 0.f;
+  __syncthreads();
+  // stage: thread per (point, target)
+  for (int q = tid; q < 64 * (n + 1); q += 256) {
+    const int pl = q / (n + 1), t = q - pl * (n + 1);
+    const int p = chunk_pt[blk * 64 + pl];
+    if (p < 0) {
+      if (t == n) sHdi[pl] = 0.f;
+      continue;
+    }
+    const float *po = d.p_out + 16 * (size_t)p;
+    if (t == n) {
+      sHdi[pl] = po[PO_HDI];
+      float *row = A + pl * ld + 8 * n;
+      for (int k = 0; k < 4; k++) row[k] = po[PO_HCD_A + k] + po[PO_HCD_L + k];
+      row[4] = po[PO_BDSUM];
+    } else {
+      const int s = d.p_res_t[(size_t)p * n + t];
+      if (s >= 0 && (d.s_flags[s] & DF_ACTIVE)) {
+        const float4 *jp = reinterpret_cast<const float4 *>(d.JpJd + 8 * (size_t)s);
+        const float4 v0 = jp[0], v1 = jp[1];
+        float *row = A + pl * ld + 8 * t;
+        row[0] = v0.x; row[1] = v0.y; row[2] = v0.z; row[3] = v0.w;
+        row[4] = v1.x; row[5] = v1.y; row[6] = v1.z; row[7] = v1.w;
+      }
+    }
+  }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;
+  const int T = Dm >> 4;
+  const int kq = lane >> 4, col = lane & 15;
+  for (int tile = wave; tile < T * T; tile += 4) {
+    const int m0 = (tile / T) << 4, n0 = (tile % T) << 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int kk = 0; kk < 16; kk++) {
+      const int k = kk * 4 + kq;
+      const float av = sHdi[k] * A[k * ld + m0 + col];
+      const float bv = A[k * ld + n0 + col];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+    }
+    float *g = gram_part + (size_t)blk * Dm * Dm;
+#pragma unroll
+    for (int rgi = 0; rgi < 4; rgi++) g[(size_t)(m0 + kq * 4 + rgi) * Dm + n0 + col] = acc[rgi];
+  }
+}
+
+// sum chunk partials per host in fp64 and scatter into the packed accD / accE / accEB / Hcc / bc
+__global__ void k_reduce_sc(const float *__restrict__ gram_part, const int *__restrict__ host_chunk_begin, int n,
+                            int Dm, int nchunks, float *__restrict__ accD, float *__restrict__ accE,
+                            float *__restrict__ accEB, float *__restrict__ accHcc, float *__restrict__ accbc) {
+  const int h = blockIdx.y;  // n hosts, + 1 extra block row (h == n) for Hcc / bc over ALL chunks
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h < n) {
+    const int rows = 8 * n, cols = 8 * n + 5;
+    if (e >= rows * cols) return;
+    const int r = e / cols, c = e - r * cols;
+    double a = 0;
+    for (int k = host_chunk_begin[h]; k < host_chunk_begin[h + 1]; k++) a += (double)gram_part[(size_t)k * Dm * Dm + (size_t)r * Dm + c];
+    const int t1 = r >> 3, i = r & 7;
+    if (c < 8 * n) {
+      const int t2 = c >> 3, j = c & 7;
+      accD[(size_t)(h + n * t1 + n * n * t2) * 64 + i * 8 + j] = (float)a;
+    } else if (c < 8 * n + 4) {
+      accE[(size_t)(h + n * t1) * 32 + i * 4 + (c - 8 * n)] = (float)a;
+    } else {
+      accEB[(size_t)(h + n * t1) * 8 + i] = (float)a;
+    }
+  } else {
+    if (e >= 20) return;
+    const int r = 8 * n + (e < 16 ? (e >> 2) : (e - 16)), c = 8 * n + (e < 16 ? (e & 3) : 4);
+    double a = 0;
+    for (int k = 0; k < nchunks; k++) a += (double)gram_part[(size_t)k * Dm * Dm + (size_t)r * Dm + c];
+    if (e < 16) accHcc[e] = (float)a;
+    else accbc[e - 16] = (float)a;
+  }
+}
+
+// ================================================================================================
+// fp64 stitch from the packed fp32 accumulators
+// ================================================================================================
+__device__ __forceinline__ int top_idx(int i, int j) {  // 13x13 symmetric -> index into the 91 uniques
+  if (i > j) { const int t = i; i = j; j = t; }
+  if (j < 10) return i * 10 - (i * (i - 1)) / 2 + (j - i);
+  if (i < 10) return 55 + 3 * i + (j - 10);
+  return 85 + (i == 10 ? (j - 10) : (i == 11 ? 3 + (j - 11) : 5));
+}
+
+// grid: (n*(n+1)/2 + 1, nmodes); block 64.  H_out/b_out hold nmodes consecutive (dim*dim | dim) results.
+__global__ __launch_bounds__(64) void k_stitch_top(int n, const float *__restrict__ acc_top, const double *__restrict__ adHost,
+                                                   const double *__restrict__ adTarget, double *__restrict__ H_out,
+                                                   double *__restrict__ b_out) {
+  __shared__ double sB[64], sA[64], sA2[64], sT[64], sBpc[32], sbp[8];
+  const int dim = 4 + 8 * n;
+  const int tid = threadIdx.x, i = tid >> 3, j = tid & 7;
+  const float *acc = acc_top + (size_t)blockIdx.y * n * n * 91;
+  double *H = H_out + (size_t)blockIdx.y * dim * dim;
+  double *bv = b_out + (size_t)blockIdx.y * dim;
+  const int nblk = n * (n + 1) / 2;
+  if ((int)blockIdx.x == nblk) {  // calib-calib block and calib b
+    if (tid < 20) {
+      const int r = tid < 16 ? (tid >> 2) : (tid - 16), c = tid < 16 ? (tid & 3) : 12;
+      double a = 0;
+      for (int k = 0; k < n * n; k++) a += (double)acc[(size_t)k * 91 + top_idx(r, c)];
+      if (tid < 16) H[(size_t)r * dim + c] = a;
+      else bv[r] = a;
+    }
+    return;
+  }
+  // decode (a <= bb)
+  int a = 0, rem = blockIdx.x;
+  while (rem >= n - a) { rem -= n - a; a++; }
+  const int bb = a + rem;
+  if (a == bb) {
+    double accHH = 0, accHc = 0, accb = 0;
+    for (int q = 0; q < 2 * n; q++) {
+      const int h = q < n ? a : q - n, t = q < n ? q : a;
+      if (q >= n && h == a) continue;  // pair (a,a) already visited
+      const int pidx = h + n * t;
+      const float *blk = acc + (size_t)pidx * 91;
+      const double *Ad = (q < n ? adHost : adTarget) + (size_t)pidx * 64;
+      sB[tid] = (double)blk[top_idx(4 + i, 4 + j)];
+      sA[tid] = Ad[tid];
+      if (tid < 32) sBpc[tid] = (double)blk[top_idx(4 + (tid >> 2), tid & 3)];
+      if (tid < 8) sbp[tid] = (double)blk[top_idx(4 + tid, 12)];
+      __syncthreads();
+      double tv = 0;
+      for (int k = 0; k < 8; k++) tv += sA[i * 8 + k] * sB[k * 8 + j];
+      sT[tid] = tv;
+      __syncthreads();
+      for (int k = 0; k < 8; k++) accHH += sT[i * 8 + k] * sA[j * 8 + k];
+      if (tid < 32) {
+        const int r = tid >> 2, c = tid & 3;
+        for (int k = 0; k < 8; k++) accHc += sA[r * 8 + k] * sBpc[k * 4 + c];
+      }
+      if (tid < 8)
+        for (int k = 0; k < 8; k++) accb += sA[tid * 8 + k] * sbp[k];
+      __syncthreads();
+    }
+    H[(size_t)(4 + 8 * a + i) * dim + 4 + 8 * a + j] = accHH;
+    if (tid < 32) {
+      const int r = tid >> 2, c = tid & 3;
+      H[(size_t)(4 + 8 * a + r) * dim + c] = accHc;
+      H[(size_t)c * dim + 4 + 8 * a + r] = accHc;
+    }
+    if (tid < 8) bv[4 + 8 * a + tid] = accb;
+  } else {
+    // H[a,bb] = AH(a,bb) B(a,bb) AT(a,bb)^T + (AH(bb,a) B(bb,a) AT(bb,a)^T)^T
+    double out = 0;
+    for (int q = 0; q < 2; q++) {
+      const int h = q ? bb : a, t = q ? a : bb;
+      const int pidx = h + n * t;
+      const float *blk = acc + (size_t)pidx * 91;
+      sB[tid] = (double)blk[top_idx(4 + i, 4 + j)];
+      sA[tid] = adHost[(size_t)pidx * 64 + tid];
+      sA2[tid] = adTarget[(size_t)pidx * 64 + tid];
+      __syncthreads();
+      double tv = 0;
+      for (int k = 0; k < 8; k++) tv += sA[i * 8 + k] * sB[k * 8 + j];
+      sT[tid] = tv;
+      __syncthreads();
+      if (q == 0) { for (int k = 0; k < 8; k++) out += sT[i * 8 + k] * sA2[j * 8 + k]; }
+      else { for (int k = 0; k < 8; k++) out += sT[j * 8 + k] * sA2[i * 8 + k]; }
+      __syncthreads();
+    }
+    H[(size_t)(4 + 8 * a + i) * dim + 4 + 8 * bb + j] = out;
+    H[(size_t)(4 + 8 * bb + j) * dim + 4 + 8 * a + i] = out;
+  }
+}
+
+// M[h][t1][g] (8x8 fp64): g == h ? sum_t2 D[h,t1,t2] AH[h,t2]^T : D[h,t1,g] AT[h,g]^T
+__global__ __launch_bounds__(64) void k_sc_M(int n, const float *__restrict__ accD, const double *__restrict__ adHost,
+                                             const double *__restrict__ adTarget, double *__restrict__ M) {
+  __shared__ double sD[64], sA[64];
+  const int tid = threadIdx.x, i = tid >> 3, j = tid & 7;
+  const int h = blockIdx.x % n, t1 = (blockIdx.x / n) % n, g = blockIdx.x / (n * n);
+  double out = 0;
+  const int t2lo = (g == h) ? 0 : g, t2hi = (g == h) ? n : g + 1;
+  for (int t2 = t2lo; t2 < t2hi; t2++) {
+    sD[tid] = (double)accD[(size_t)(h + n * t1 + n * n * t2) * 64 + tid];
+    sA[tid] = ((g == h) ? adHost : adTarget)[(size_t)(h + n * t2) * 64 + tid];
+    __syncthreads();
+    for (int k = 0; k < 8; k++) out += sD[i * 8 + k] * sA[j * 8 + k];
+    __syncthreads();
+  }
+  M[((size_t)(h * n + t1) * n + g) * 64 + tid] = out;
+}
+
+// H_sc[g1,g2] = sum_t1 AH[g1,t1] M[g1][t1][g2] + sum_{h != g1} AT[h,g1] M[h][g1][g2]; diagonal blocks also
+// produce the calib columns and b; the last block writes Hcc / bc.
+__global__ __launch_bounds__(64) void k_stitch_sc(int n, const double *__restrict__ M, const float *__restrict__ accE,
+                                                  const float *__restrict__ accEB, const float *__restrict__ accHcc,
+                                                  const float *__restrict__ accbc, const double *__restrict__ adHost,
+                                                  const double *__restrict__ adTarget, double *__restrict__ H,
+                                                  double *__restrict__ bv) {
+  __shared__ double sM[64], sA[64], sE[32], sEB[8];
+  const int dim = 4 + 8 * n;
+  const int tid = threadIdx.x, i = tid >> 3, j = tid & 7;
+  if ((int)blockIdx.x == n * n) {
+    if (tid < 16) H[(size_t)(tid >> 2) * dim + (tid & 3)] = (double)accHcc[tid];
+    else if (tid < 20) bv[tid - 16] = (double)accbc[tid - 16];
+    return;
+  }
+  const int g1 = blockIdx.x % n, g2 = blockIdx.x / n;
+  double out = 0, outc = 0, outb = 0;
+  for (int q = 0; q < 2 * n; q++) {
+    const int h = q < n ? g1 : q - n, t1 = q < n ? q : g1;
+    if (q >= n && h == g1) continue;
+    const int pidx = h + n * t1;
+    sA[tid] = (q < n ? adHost : adTarget)[(size_t)pidx * 64 + tid];
+    sM[tid] = M[((size_t)(h * n + t1) * n + g2) * 64 + tid];
+    if (g1 == g2) {
+      if (tid < 32) sE[tid] = (double)accE[(size_t)pidx * 32 + tid];
+      if (tid < 8) sEB[tid] = (double)accEB[(size_t)pidx * 8 + tid];
+    }
+    __syncthreads();
+    for (int k = 0; k < 8; k++) out += sA[i * 8 + k] * sM[k * 8 + j];
+    if (g1 == g2) {
+      if (tid < 32) {
+        const int r = tid >> 2, c = tid & 3;
+        for (int k = 0; k < 8; k++) outc += sA[r * 8 + k] * sE[k * 4 + c];
+      }
+      if (tid < 8)
+        for (int k = 0; k < 8; k++) outb += sA[tid * 8 + k] * sEB[k];
+    }
+    __syncthreads();
+  }
+  H[(size_t)(4 + 8 * g1 + i) * dim + 4 + 8 * g2 + j] = out;
+  if (g1 == g2) {
+    if (tid < 32) {
+      const int r = tid >> 2, c = tid & 3;
+      H[(size_t)(4 + 8 * g1 + r) * dim + c] = outc;
+      H[(size_t)c * dim + 4 + 8 * g1 + r] = outc;  // transposed calib rows, OB/AccumulatedSCHessian.h:118-123
+    }
+    if (tid < 8) bv[4 + 8 * g1 + tid] = outb;
+  }
+}
+
+// ================================================================================================
+// resubstituteFPt (OB/EnergyFunctional.cpp:526-551): one thread per point
+// ================================================================================================
+__global__ void k_resubstitute(BaDev d, const float *__restrict__ xc, const float *__restrict__ xAd,
+                               float *__restrict__ step_out) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= d.P) return;
+  float *o = d.p_out + 16 * (size_t)p;
+  int ngood = 0;
+  for (int q = d.p_begin[p]; q < d.p_begin[p + 1]; q++)
+    if (d.s_flags[d.p_list[q]] & DF_ACTIVE) ngood++;
+  float step = 0.f;
+  if (ngood > 0) {
+    float b = o[PO_BDSUM];
+    float dot = 0;
+    for (int k = 0; k < 4; k++) dot += xc[k] * (o[PO_HCD_A + k] + o[PO_HCD_L + k]);
+    b -= dot;
+    for (int q = d.p_begin[p]; q < d.p_begin[p + 1]; q++) {
+      const int s = d.p_list[q];
+      if (!(d.s_flags[s] & DF_ACTIVE)) continue;
+      const int pair = d.t_pair[s >> 5];  // h + n*t
+      const int hh = pair % d.n, tt = pair / d.n;
+      const float *xa = xAd + 8 * (hh * d.n + tt);
+      const float4 *jp = reinterpret_cast<const float4 *>(d.JpJd + 8 * (size_t)s);
+      const float4 v0 = jp[0], v1 = jp[1];
+      float dd = 0;
+      dd += xa[0] * v0.x; dd += xa[1] * v0.y; dd += xa[2] * v0.z; dd += xa[3] * v0.w;
+      dd += xa[4] * v1.x; dd += xa[5] * v1.y; dd += xa[6] * v1.z; dd += xa[7] * v1.w;
+      b -= dd;
+    }
+    step = -b * o[PO_HDI];
+  }
+  o[PO_STEP] = step;
+  if (step_out) step_out[p] = step;
+}
+
+// ================================================================================================
+// fixLinearizationF (OB/EnergyFunctionalStructs.cpp:75-103): one thread per listed residual
+// ================================================================================================
+__global__ void k_fix_lin(BaDev d, const int *__restrict__ slist, int count) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= count) return;
+  const int s = slist[k];
+  const float *Jt = d.J + (size_t)(s >> 5) * SOS_TILE_FLOATS + (s & 31);
+#define JL(pl) Jt[(pl)*SOS_TILE]
+  const int pair = d.t_pair[s >> 5];
+  const float *dp = d.adHTdelta + 8 * pair;
+  const float deltaF = d.pts[d.s_point[s]].deltaF;
+  float dx = 0, dy = 0, dcx = 0, dcy = 0;
+  for (int i = 0; i < 6; i++) { dx += JL(JP_DXI0 + i) * dp[i]; dy += JL(JP_DXI1 + i) * dp[i]; }
+  for (int i = 0; i < 4; i++) { dcx += JL(JP_DC0 + i) * d.cdelta[i]; dcy += JL(JP_DC1 + i) * d.cdelta[i]; }
+  const float Jp_delta_x = dx + dcx + JL(JP_DD) * deltaF;
+  const float Jp_delta_y = dy + dcy + JL(JP_DD + 1) * deltaF;
+  for (int i = 0; i < 8; i++) {
+    float rtz = JL(JP_RESF + i);
+    rtz = rtz - JL(JP_JIDX0 + i) * Jp_delta_x;
+    rtz = rtz - JL(JP_JIDX1 + i) * Jp_delta_y;
+    rtz = rtz - JL(JP_JAB0 + i) * dp[6];
+    rtz = rtz - JL(JP_JAB1 + i) * dp[7];
+    d.s_rtz[8 * (size_t)s + i] = rtz;
+  }
+#undef JL
+  d.s_flags[s] = (uint8_t)(d.s_flags[s] | DF_LINEARIZED);
+}
+
+// calcLEnergyPt residual part (OB/EnergyFunctional.cpp:571-613): per residual energy, summed in double
+__global__ void k_lenergy(BaDev d, double *__restrict__ out_per_res) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= d.Rpad) return;
+  double E = 0;
+  if (d.s_point[s] >= 0) {
+    const unsigned f = d.s_flags[s];
+    if ((f & DF_LINEARIZED) && (f & DF_ACTIVE)) {
+      const float *Jt = d.J + (size_t)(s >> 5) * SOS_TILE_FLOATS + (s & 31);
+#define JL(pl) Jt[(pl)*SOS_TILE]
+      const int pair = d.t_pair[s >> 5];
+      const float *dp = d.adHTdelta + 8 * pair;
+      const float dd = d.pts[d.s_point[s]].deltaF;
+      float dx = 0, dy = 0, dcx = 0, dcy = 0;
+      for (int i = 0; i < 6; i++) { dx += JL(JP_DXI0 + i) * dp[i]; dy += JL(JP_DXI1 + i) * dp[i]; }
+      for (int i = 0; i < 4; i++) { dcx += JL(JP_DC0 + i) * d.cdelta[i]; dcy += JL(JP_DC1 + i) * d.cdelta[i]; }
+      const float Jp_delta_x = dx + dcx + JL(JP_DD) * dd;
+      const float Jp_delta_y = dy + dcy + JL(JP_DD + 1) * dd;
+      for (int i = 0; i < 8; i++) {
+        float Jdelta = JL(JP_JIDX0 + i) * Jp_delta_x;
+        Jdelta = Jdelta + JL(JP_JIDX1 + i) * Jp_delta_y;
+        Jdelta = Jdelta + JL(JP_JAB0 + i) * dp[6];
+        Jdelta = Jdelta + JL(JP_JAB1 + i) * dp[7];
+        float r0 = d.s_rtz[8 * (size_t)s + i];
+        r0 = r0 + r0;
+        r0 = r0 + Jdelta;
+        E += (double)(Jdelta * r0);
+      }
+#undef JL
+    }
+  }
+  out_per_res[s] = E;
+}
+__global__ __launch_bounds__(1024) void k_sum_double(const double *__restrict__ v, int n, double *out) {
+  __shared__ double sm[1024];
+  double a = 0;
+  for (int i = threadIdx.x; i < n; i += 1024) a += v[i];
+  sm[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = sm[0];
+}
+
+// read one Jacobian back in the reference's 74-float layout
+__global__ void k_get_jac(BaDev d, int s, sos_rawjac *out) {
+  if (threadIdx.x != 0) return;
+  const float *Jt = d.J + (size_t)(s >> 5) * SOS_TILE_FLOATS + (s & 31);
+#define JL(pl) Jt[(pl)*SOS_TILE]
+  for (int i = 0; i < 8; i++) {
+    out->resF[i] = JL(JP_RESF + i);
+    out->JIdx[0][i] = JL(JP_JIDX0 + i);
+    out->JIdx[1][i] = JL(JP_JIDX1 + i);
+    out->JabF[0][i] = JL(JP_JAB0 + i);
+    out->JabF[1][i] = JL(JP_JAB1 + i);
+  }
+  for (int i = 0; i < 6; i++) { out->Jpdxi[0][i] = JL(JP_DXI0 + i); out->Jpdxi[1][i] = JL(JP_DXI1 + i); }
+  for (int i = 0; i < 4; i++) { out->Jpdc[0][i] = JL(JP_DC0 + i); out->Jpdc[1][i] = JL(JP_DC1 + i); }
+  out->Jpdd[0] = JL(JP_DD); out->Jpdd[1] = JL(JP_DD + 1);
+  out->JIdx2[0] = JL(JP_JIDX2); out->JIdx2[1] = out->JIdx2[2] = JL(JP_JIDX2 + 1); out->JIdx2[3] = JL(JP_JIDX2 + 2);
+  for (int i = 0; i < 4; i++) out->JabJIdx[i] = JL(JP_JABJIDX + i);
+  out->Jab2[0] = JL(JP_JAB2); out->Jab2[1] = out->Jab2[2] = JL(JP_JAB2 + 1); out->Jab2[3] = JL(JP_JAB2 + 2);
+#undef JL
+}
+// scatter a 74-float Jacobian into the tile layout (frozen J of linearized residuals at set_window)
+__global__ void k_put_jac(BaDev d, const int *__restrict__ slist, const sos_rawjac *__restrict__ src, int count) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= count) return;
+  const int s = slist[k];
+  const sos_rawjac *in = src + k;
+  float *Jt = d.J + (size_t)(s >> 5) * SOS_TILE_FLOATS + (s & 31);
+#define JL(pl) Jt[(pl)*SOS_TILE]
+  for (int i = 0; i < 8; i++) {
+    JL(JP_RESF + i) = in->resF[i];
+    JL(JP_JIDX0 + i) = in->JIdx[0][i];
+    JL(JP_JIDX1 + i) = in->JIdx[1][i];
+    JL(JP_JAB0 + i) = in->JabF[0][i];
+    JL(JP_JAB1 + i) = in->JabF[1][i];
+  }
+  for (int i = 0; i < 6; i++) { JL(JP_DXI0 + i) = in->Jpdxi[0][i]; JL(JP_DXI1 + i) = in->Jpdxi[1][i]; }
+  for (int i = 0; i < 4; i++) { JL(JP_DC0 + i) = in->Jpdc[0][i]; JL(JP_DC1 + i) = in->Jpdc[1][i]; }
+  JL(JP_DD) = in->Jpdd[0]; JL(JP_DD + 1) = in->Jpdd[1];
+  JL(JP_JIDX2) = in->JIdx2[0]; JL(JP_JIDX2 + 1) = in->JIdx2[1]; JL(JP_JIDX2 + 2) = in->JIdx2[3];
+  for (int i = 0; i < 4; i++) JL(JP_JABJIDX + i) = in->JabJIdx[i];
+  JL(JP_JAB2) = in->Jab2[0]; JL(JP_JAB2 + 1) = in->Jab2[1]; JL(JP_JAB2 + 2) = in->Jab2[3];
+#undef JL
+  // JpJdF of the frozen Jacobian (takeDataF was applied before the residual was linearized)
+  const float v0 = in->JIdx2[0] * in->Jpdd[0] + in->JIdx2[1] * in->Jpdd[1];
+  const float v1 = in->JIdx2[2] * in->Jpdd[0] + in->JIdx2[3] * in->Jpdd[1];
+  float *o = d.JpJd + 8 * (size_t)s;
+  for (int i = 0; i < 6; i++) o[i] = in->Jpdxi[0][i] * v0 + in->Jpdxi[1][i] * v1;
+  o[6] = in->JabJIdx[0] * in->Jpdd[0] + in->JabJIdx[1] * in->Jpdd[1];
+  o[7] = in->JabJIdx[2] * in->Jpdd[0] + in->JabJIdx[3] * in->Jpdd[1];
+}
+
+// ================================================================================================
+// host side of the handle
+// ================================================================================================
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t n) {
+    if (n <= cap) return SOS_OK;
+    if (p) hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = n + n / 4 + 64;
+    if (hipMalloc(&p, sizeof(T) * want) != hipSuccess) return SOS_ERR_NOMEM;
+    cap = want;
+    return SOS_OK;
+  }
+  void release() {
+    if (p) hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct sos_ba {
+  sos_ctx *ctx = nullptr;
+  sos_params prm;
+  bool have_window = false, have_state = false;
+  int n = 0, P = 0, R = 0, Rpad = 0, ntiles = 0, ntilesA = 0, nchunks = 0, Dm = 0, ld = 0;
+  int slot[SOS_MAX_FRAMES];
+  std::vector<int> h_s_of_orig;   // original residual index -> sorted index
+  std::vector<int> h_pair_tile_begin;  // [2*n*n + 1]
+  std::vector<sos_point> h_pts;
+  std::vector<sos_resid> h_res;
+  std::vector<int> h_p_begin;
+  sos_calib calib;
+  // device buffers
+  DevBuf<sos_point> d_pts;
+  DevBuf<int> d_s_point, d_s_orig, d_t_pair, d_p_begin, d_p_list, d_p_res_t, d_pair_tile_begin, d_chunk_pt,
+      d_host_chunk_begin, d_tmp_int;
+  DevBuf<uint8_t> d_s_flags, d_s_state, d_s_newstate, d_o_newstate;
+  DevBuf<float> d_s_energy, d_s_newenergy, d_s_newenergywo, d_s_ret, d_s_center, d_s_rtz, d_s_pterm, d_J, d_JpJd,
+      d_p_out, d_o_newenergy, d_o_newenergywo, d_o_center, d_top_part, d_gram_part, d_acc, d_adHTdelta, d_cdelta,
+      d_frameTH, d_xc, d_xAd, d_step;
+  DevBuf<sos_precalc> d_precalc;
+  DevBuf<double> d_adHost, d_adTarget, d_M, d_Hout, d_bout, d_scalar, d_perres;
+  DevBuf<sos_rawjac> d_rawjac;
+  std::vector<float> h_adHostF, h_adTargetF;
+  size_t acc_floats = 0;
+  // offsets into the packed accumulator
+  size_t off_topA = 0, off_topL = 0, off_D = 0, off_E = 0, off_EB = 0, off_Hcc = 0, off_bc = 0, off_nres = 0;
+  BaDev dev;
+};
+
+static inline int divup(int a, int b) { return (a + b - 1) / b; }
+
+extern "C" int sos_ba_create(sos_ctx *ctx, const sos_params *prm, sos_ba **out) {
+  if (!ctx || !prm || !out) return SOS_ERR_ARG;
+  if (prm->w != ctx->w || prm->h != ctx->h) return SOS_ERR_ARG;
+  sos_ba *ba = new sos_ba();
+  ba->ctx = ctx;
+  ba->prm = *prm;
+  memset(&ba->dev, 0, sizeof(ba->dev));
+  *out = ba;
+  return SOS_OK;
+}
+
+extern "C" int sos_ba_destroy(sos_ba *ba) {
+  if (!ba) return SOS_OK;
+  hipSetDevice(ba->ctx->device);
+  hipStreamSynchronize(ba->ctx->stream);
+  ba->d_pts.release();
+  for (DevBuf<int> *b : {&ba->d_s_point, &ba->d_s_orig, &ba->d_t_pair, &ba->d_p_begin, &ba->d_p_list, &ba->d_p_res_t,
+                         &ba->d_pair_tile_begin, &ba->d_chunk_pt, &ba->d_host_chunk_begin, &ba->d_tmp_int})
+    b->release();
+  for (DevBuf<uint8_t> *b : {&ba->d_s_flags, &ba->d_s_state, &ba->d_s_newstate, &ba->d_o_newstate}) b->release();
+  for (DevBuf<float> *b :
+       {&ba->d_s_energy, &ba->d_s_newenergy, &ba->d_s_newenergywo, &ba->d_s_ret, &ba->d_s_center, &ba->d_s_rtz,
+        &ba->d_s_pterm, &ba->d_J, &ba->d_JpJd, &ba->d_p_out, &ba->d_o_newenergy, &ba->d_o_newenergywo, &ba->d_o_center,
+        &ba->d_top_part, &ba->d_gram_part, &ba->d_acc, &ba->d_adHTdelta, &ba->d_cdelta, &ba->d_frameTH, &ba->d_xc,
+        &ba->d_xAd, &ba->d_step})
+    b->release();
+  ba->d_precalc.release();
+  for (DevBuf<double> *b : {&ba->d_adHost, &ba->d_adTarget, &ba->d_M, &ba->d_Hout, &ba->d_bout, &ba->d_scalar, &ba->d_perres})
+    b->release();
+  ba->d_rawjac.release();
+  delete ba;
+  return SOS_OK;
+}
+
+#define ENSURE(buf, n)              \
+  do {                              \
+    int rc_ = (buf).ensure(n);      \
+    if (rc_) return rc_;            \
+  } while (0)
+
+template <typename T>
+static int upload(hipStream_t st, DevBuf<T> &buf, const std::vector<T> &v) {
+  int rc = buf.ensure(v.size() ? v.size() : 1);
+  if (rc) return rc;
+  if (!v.empty()) SOS_HIP(hipMemcpyAsync(buf.p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, st));
+  return SOS_OK;
+}
+
+extern "C" int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, int P, const sos_point *pts, int R,
+                                 const sos_resid *res, const float *res_toZeroF, const sos_rawjac *lin_J) {
+  if (!ba || n < 1 || n > SOS_MAX_FRAMES || P < 0 || R < 0 || !frame_slot || (P && !pts) || (R && !res)) return SOS_ERR_ARG;
+  sos_ctx *c = ba->ctx;
+  SOS_HIP(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  SOS_HIP(hipStreamSynchronize(st));
+  for (int i = 0; i < n; i++) {
+    if (frame_slot[i] < 0 || frame_slot[i] >= SOS_MAX_SLOTS || !c->dI[frame_slot[i]][0]) return SOS_ERR_STATE;
+    ba->slot[i] = frame_slot[i];
+  }
+  // ---- validate the graph: residuals contiguous per point, in point order
+  std::vector<int> p_begin(P + 1, 0);
+  {
+    int r = 0;
+    for (int p = 0; p < P; p++) {
+      p_begin[p] = r;
+      while (r < R && res[r].point == p) r++;
+    }
+    p_begin[P] = r;
+    if (r != R) return SOS_ERR_ARG;
+    for (int i = 0; i < R; i++)
+      if (res[i].host < 0 || res[i].host >= n || res[i].target < 0 || res[i].target >= n || res[i].host != pts[res[i].point].host)
+        return SOS_ERR_ARG;
+    for (int p = 1; p < P; p++)
+      if (pts[p].host < pts[p - 1].host) return SOS_ERR_ARG;  // allPoints order: frames -> points
+  }
+  // ---- sort residuals by (isLinearized, pair), stable in the original (point) order
+  std::vector<int> order(R);
+  std::iota(order.begin(), order.end(), 0);
+  auto key = [&](int r) { return ((res[r].flags & SOS_RF_LINEARIZED) ? n * n : 0) + res[r].host + n * res[r].target; };
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key(a) < key(b); });
+  std::vector<int> s_point, s_orig, t_pair, pair_tile_begin(2 * n * n + 1, 0);
+  std::vector<int> s_of_orig(R, -1);
+  int ntilesA = 0;
+  {
+    size_t pos = 0;
+    for (int k = 0; k < 2 * n * n; k++) {
+      pair_tile_begin[k] = (int)t_pair.size();
+      size_t start = pos;
+      while (pos < order.size() && key(order[pos]) == k) pos++;
+      size_t cnt = pos - start;
+      int tiles = (int)((cnt + SOS_TILE - 1) / SOS_TILE);
+      for (int t = 0; t < tiles; t++) {
+        t_pair.push_back(k % (n * n));
+        for (int q = 0; q < SOS_TILE; q++) {
+          size_t idx = start + (size_t)t * SOS_TILE + q;
+          if (idx < pos) {
+            s_of_orig[order[idx]] = (int)s_point.size();
+            s_point.push_back(res[order[idx]].point);
+            s_orig.push_back(order[idx]);
+          } else {
+            s_point.push_back(-1);
+            s_orig.push_back(-1);
+          }
+        }
+      }
+      if (k == n * n - 1) ntilesA = (int)t_pair.size();
+    }
+    pair_tile_begin[2 * n * n] = (int)t_pair.size();
+  }
+  const int ntiles = (int)t_pair.size();
+  const int Rpad = ntiles * SOS_TILE;
+  ba->n = n; ba->P = P; ba->R = R; ba->Rpad = Rpad; ba->ntiles = ntiles; ba->ntilesA = ntilesA;
+  ba->h_s_of_orig = s_of_orig;
+  ba->h_pair_tile_begin = pair_tile_begin;
+  ba->h_pts.assign(pts, pts + P);
+  ba->h_res.assign(res, res + R);
+  ba->h_p_begin = p_begin;
+
+  std::vector<uint8_t> s_flags(Rpad ? Rpad : 1, 0), s_state(Rpad ? Rpad : 1, SOS_RES_OOB);
+  std::vector<float> s_energy(Rpad ? Rpad : 1, 0.f), s_rtz((size_t)(Rpad ? Rpad : 1) * 8, 0.f);
+  for (int s = 0; s < Rpad; s++) {
+    int o = s_orig[s];
+    if (o < 0) continue;
+    unsigned f = 0;
+    if (res[o].flags & SOS_RF_ACTIVE) f |= DF_ACTIVE;
+    if (res[o].flags & SOS_RF_LINEARIZED) f |= DF_LINEARIZED;
+    if (res[o].flags & SOS_RF_ISNEW) f |= DF_ISNEW;
+    s_flags[s] = (uint8_t)f;
+    s_state[s] = (uint8_t)res[o].state_state;
+    s_energy[s] = res[o].state_energy;
+    if (res_toZeroF) memcpy(&s_rtz[(size_t)s * 8], res_toZeroF + (size_t)o * 8, 8 * sizeof(float));
+  }
+  // per point lists
+  std::vector<int> p_list(R ? R : 1, 0), p_res_t((size_t)(P ? P : 1) * n, -1);
+  for (int o = 0; o < R; o++) {
+    p_list[o] = s_of_orig[o];
+    p_res_t[(size_t)res[o].point * n + res[o].target] = s_of_orig[o];
+  }
+  // chunks of 64 points per host for the Gram kernel
+  std::vector<int> chunk_pt, host_chunk_begin(n + 1, 0);
+  {
+    int p = 0;
+    for (int h = 0; h < n; h++) {
+      host_chunk_begin[h] = (int)(chunk_pt.size() / 64);
+      int start = p;
+      while (p < P && pts[p].host == h) p++;
+      for (int q = start; q < p; q += 64)
+        for (int k = 0; k < 64; k++) chunk_pt.push_back(q + k < p ? q + k : -1);
+    }
+    host_chunk_begin[n] = (int)(chunk_pt.size() / 64);
+  }
+  ba->nchunks = host_chunk_begin[n];
+  ba->Dm = ((8 * n + 5) + 15) / 16 * 16;
+  ba->ld = (ba->Dm % 32 == 16) ? ba->Dm : ba->Dm + 16;
+
+  // ---- upload
+  int rc;
+  if ((rc = upload(st, ba->d_pts, ba->h_pts))) return rc;
+  if ((rc = upload(st, ba->d_s_point, s_point))) return rc;
+  if ((rc = upload(st, ba->d_s_orig, s_orig))) return rc;
+  if ((rc = upload(st, ba->d_t_pair, t_pair))) return rc;
+  if ((rc = upload(st, ba->d_p_begin, p_begin))) return rc;
+  if ((rc = upload(st, ba->d_p_list, p_list))) return rc;
+  if ((rc = upload(st, ba->d_p_res_t, p_res_t))) return rc;
+  if ((rc = upload(st, ba->d_pair_tile_begin, pair_tile_begin))) return rc;
+  if ((rc = upload(st, ba->d_chunk_pt, chunk_pt))) return rc;
+  if ((rc = upload(st, ba->d_host_chunk_begin, host_chunk_begin))) return rc;
+  if ((rc = upload(st, ba->d_s_flags, s_flags))) return rc;
+  if ((rc = upload(st, ba->d_s_state, s_state))) return rc;
+  if ((rc = upload(st, ba->d_s_energy, s_energy))) return rc;
+  if ((rc = upload(st, ba->d_s_rtz, s_rtz))) return rc;
+  const size_t Rp = Rpad ? Rpad : 1, Pp = P ? P : 1, Rr = R ? R : 1;
+  ENSURE(ba->d_s_newstate, Rp); ENSURE(ba->d_s_newenergy, Rp); ENSURE(ba->d_s_newenergywo, Rp); ENSURE(ba->d_s_ret, Rp);
+  ENSURE(ba->d_s_center, Rp * 3); ENSURE(ba->d_s_pterm, Rp * 6);
+  ENSURE(ba->d_J, (size_t)(ntiles ? ntiles : 1) * SOS_TILE_FLOATS); ENSURE(ba->d_JpJd, Rp * 8);
+  ENSURE(ba->d_p_out, Pp * 16);
+  ENSURE(ba->d_o_newstate, Rr); ENSURE(ba->d_o_newenergy, Rr); ENSURE(ba->d_o_newenergywo, Rr); ENSURE(ba->d_o_center, Rr * 3);
+  ENSURE(ba->d_top_part, (size_t)(ntiles ? ntiles : 1) * SOS_TOPN + 64 * SOS_TOPN);
+  ENSURE(ba->d_gram_part, (size_t)(ba->nchunks ? ba->nchunks : 1) * ba->Dm * ba->Dm);
+  const size_t nn = (size_t)n * n;
+  ba->off_topA = 0;
+  ba->off_topL = ba->off_topA + nn * 91;
+  ba->off_D = ba->off_topL + nn * 91;
+  ba->off_E = ba->off_D + nn * n * 64;
+  ba->off_EB = ba->off_E + nn * 32;
+  ba->off_Hcc = ba->off_EB + nn * 8;
+  ba->off_bc = ba->off_Hcc + 16;
+  ba->off_nres = ba->off_bc + 4;
+  ba->acc_floats = ba->off_nres + 2;
+  ENSURE(ba->d_acc, ba->acc_floats);
+  ENSURE(ba->d_precalc, nn); ENSURE(ba->d_adHTdelta, nn * 8); ENSURE(ba->d_cdelta, 4); ENSURE(ba->d_frameTH, n);
+  ENSURE(ba->d_adHost, nn * 64); ENSURE(ba->d_adTarget, nn * 64); ENSURE(ba->d_M, nn * n * 64);
+  const size_t dim = 4 + 8 * (size_t)n;
+  ENSURE(ba->d_Hout, 3 * dim * dim); ENSURE(ba->d_bout, 3 * dim); ENSURE(ba->d_scalar, 8); ENSURE(ba->d_perres, Rp);
+  ENSURE(ba->d_xc, 4); ENSURE(ba->d_xAd, nn * 8); ENSURE(ba->d_step, Pp);
+  SOS_HIP(hipMemsetAsync(ba->d_s_newstate.p, SOS_RES_OOB, Rp, st));
+  SOS_HIP(hipMemsetAsync(ba->d_s_newenergy.p, 0, sizeof(float) * Rp, st));
+  SOS_HIP(hipMemsetAsync(ba->d_s_newenergywo.p, 0, sizeof(float) * Rp, st));
+  SOS_HIP(hipMemsetAsync(ba->d_s_ret.p, 0, sizeof(float) * Rp, st));
+  SOS_HIP(hipMemsetAsync(ba->d_s_center.p, 0, sizeof(float) * Rp * 3, st));
+  SOS_HIP(hipMemsetAsync(ba->d_s_pterm.p, 0, sizeof(float) * Rp * 6, st));
+  SOS_HIP(hipMemsetAsync(ba->d_J.p, 0, sizeof(float) * (size_t)(ntiles ? ntiles : 1) * SOS_TILE_FLOATS, st));
+  SOS_HIP(hipMemsetAsync(ba->d_JpJd.p, 0, sizeof(float) * Rp * 8, st));
+  SOS_HIP(hipMemsetAsync(ba->d_p_out.p, 0, sizeof(float) * Pp * 16, st));
+  SOS_HIP(hipMemsetAsync(ba->d_o_center.p, 0, sizeof(float) * Rr * 3, st));
+
+  BaDev &d = ba->dev;
+  memset(&d, 0, sizeof(d));
+  d.n = n; d.P = P; d.R = R; d.Rpad = Rpad; d.ntiles = ntiles; d.ntilesA = ntilesA;
+  d.w = ba->prm.w; d.h = ba->prm.h;
+  d.wM3G = (float)(ba->prm.w - 3); d.hM3G = (float)(ba->prm.h - 3);
+  d.huberTH = ba->prm.huberTH; d.outlierTH = ba->prm.outlierTHSumComponent;
+  d.modeA = ba->prm.affineOptModeA; d.modeB = ba->prm.affineOptModeB;
+  for (int i = 0; i < n; i++) d.img[i] = c->dI[ba->slot[i]][0];
+  d.precalc = ba->d_precalc.p; d.adHTdelta = ba->d_adHTdelta.p; d.cdelta = ba->d_cdelta.p;
+  d.pts = ba->d_pts.p;
+  d.s_point = ba->d_s_point.p; d.s_orig = ba->d_s_orig.p;
+  d.s_flags = ba->d_s_flags.p; d.s_state = ba->d_s_state.p; d.s_newstate = ba->d_s_newstate.p;
+  d.s_energy = ba->d_s_energy.p; d.s_newenergy = ba->d_s_newenergy.p; d.s_newenergywo = ba->d_s_newenergywo.p;
+  d.s_ret = ba->d_s_ret.p; d.s_center = ba->d_s_center.p; d.s_rtz = ba->d_s_rtz.p; d.s_pterm = ba->d_s_pterm.p;
+  d.t_pair = ba->d_t_pair.p; d.J = ba->d_J.p; d.JpJd = ba->d_JpJd.p;
+  d.p_begin = ba->d_p_begin.p; d.p_list = ba->d_p_list.p; d.p_res_t = ba->d_p_res_t.p; d.p_out = ba->d_p_out.p;
+  d.o_newstate = ba->d_o_newstate.p; d.o_newenergy = ba->d_o_newenergy.p; d.o_newenergywo = ba->d_o_newenergywo.p;
+  d.o_center = ba->d_o_center.p;
+
+  // frozen Jacobians of linearized residuals
+  if (lin_J) {
+    std::vector<int> sl;
+    std::vector<sos_rawjac> jl;
+    for (int o = 0; o < R; o++)
+      if (res[o].flags & SOS_RF_LINEARIZED) { sl.push_back(s_of_orig[o]); jl.push_back(lin_J[o]); }
+    if (!sl.empty()) {
+      if ((rc = upload(st, ba->d_tmp_int, sl))) return rc;
+      if ((rc = upload(st, ba->d_rawjac, jl))) return rc;
+      k_put_jac<<<divup((int)sl.size(), 64), 64, 0, st>>>(d, ba->d_tmp_int.p, ba->d_rawjac.p, (int)sl.size());
+    }
+  }
+  SOS_HIP(hipGetLastError());
+  SOS_HIP(hipStreamSynchronize(st));
+  ba->have_window = true;
+  ba->have_state = false;
+  return SOS_OK;
+}
+
+extern "C" int sos_ba_set_state(sos_ba *ba, const sos_calib *calib, const sos_precalc *precalc, const float *adHTdeltaF,
+                                const float *cDeltaF, const double *adHost, const double *adTarget,
+                                const float *point_idepth_scaled, const float *point_idepth_zero_scaled,
+                                const float *point_deltaF) {
+  if (!ba || !ba->have_window) return SOS_ERR_STATE;
+  sos_ctx *c = ba->ctx;
+  SOS_HIP(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  const size_t nn = (size_t)ba->n * ba->n;
+  if (calib) { ba->calib = *calib; ba->dev.calib = *calib; }
+  if (precalc) SOS_HIP(hipMemcpyAsync(ba->d_precalc.p, precalc, sizeof(sos_precalc) * nn, hipMemcpyHostToDevice, st));
+  if (adHTdeltaF) SOS_HIP(hipMemcpyAsync(ba->d_adHTdelta.p, adHTdeltaF, sizeof(float) * 8 * nn, hipMemcpyHostToDevice, st));
+  if (cDeltaF) SOS_HIP(hipMemcpyAsync(ba->d_cdelta.p, cDeltaF, sizeof(float) * 4, hipMemcpyHostToDevice, st));
+  if (adHost) {
+    SOS_HIP(hipMemcpyAsync(ba->d_adHost.p, adHost, sizeof(double) * 64 * nn, hipMemcpyHostToDevice, st));
+    ba->h_adHostF.resize(64 * nn);
+    for (size_t i = 0; i < 64 * nn; i++) ba->h_adHostF[i] = (float)adHost[i];  // OB/EnergyFunctional.cpp:94-98
+  }
+  if (adTarget) {
+    SOS_HIP(hipMemcpyAsync(ba->d_adTarget.p, adTarget, sizeof(double) * 64 * nn, hipMemcpyHostToDevice, st));
+    ba->h_adTargetF.resize(64 * nn);
+    for (size_t i = 0; i < 64 * nn; i++) ba->h_adTargetF[i] = (float)adTarget[i];
+  }
+  if (point_idepth_scaled || point_idepth_zero_scaled || point_deltaF) {
+    for (int p = 0; p < ba->P; p++) {
+      if (point_idepth_scaled) ba->h_pts[p].idepth_scaled = point_idepth_scaled[p];
+      if (point_idepth_zero_scaled) ba->h_pts[p].idepth_zero_scaled = point_idepth_zero_scaled[p];
+      if (point_deltaF) ba->h_pts[p].deltaF = point_deltaF[p];
+    }
+    if (ba->P) SOS_HIP(hipMemcpyAsync(ba->d_pts.p, ba->h_pts.data(), sizeof(sos_point) * ba->P, hipMemcpyHostToDevice, st));
+  }
+  SOS_HIP(hipStreamSynchronize(st));  // caller buffers are pageable
+  ba->have_state = true;
+  return SOS_OK;
+}
+
+static int launch_linearize(sos_ba *ba) {
+  if (ba->ntilesA > 0) k_linearize<<<ba->ntilesA, 256, 0, ba->ctx->stream>>>(ba->dev, ba->d_frameTH.p);
+  return SOS_OK;
+}
+
+extern "C" int sos_ba_linearize(sos_ba *ba, const float *frameEnergyTH, double *energySum, uint8_t *newState,
+                                float *newEnergy, float *newEnergyWithOutlier, float *centerProjectedTo) {
+  if (!ba || !ba->have_window || !ba->have_state || !frameEnergyTH) return SOS_ERR_STATE;
+  sos_ctx *c = ba->ctx;
+  SOS_HIP(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  SOS_HIP(hipMemcpyAsync(ba->d_frameTH.p, frameEnergyTH, sizeof(float) * ba->n, hipMemcpyHostToDevice, st));
+  launch_linearize(ba);
+  if (energySum) {
+    k_sum_ret<<<1, 1024, 0, st>>>(ba->d_s_ret.p, ba->ntilesA * SOS_TILE, ba->d_scalar.p);
+    SOS_HIP(hipMemcpyAsync(energySum, ba->d_scalar.p, sizeof(double), hipMemcpyDeviceToHost, st));
+  }
+  const size_t R = ba->R;
+  if (newState && R) SOS_HIP(hipMemcpyAsync(newState, ba->d_o_newstate.p, R, hipMemcpyDeviceToHost, st));
+  if (newEnergy && R) SOS_HIP(hipMemcpyAsync(newEnergy, ba->d_o_newenergy.p, sizeof(float) * R, hipMemcpyDeviceToHost, st));
+  if (newEnergyWithOutlier && R)
+    SOS_HIP(hipMemcpyAsync(newEnergyWithOutlier, ba->d_o_newenergywo.p, sizeof(float) * R, hipMemcpyDeviceToHost, st));
+  if (centerProjectedTo && R)
+    SOS_HIP(hipMemcpyAsync(centerProjectedTo, ba->d_o_center.p, sizeof(float) * 3 * R, hipMemcpyDeviceToHost, st));
+  SOS_HIP(hipGetLastError());
+  SOS_HIP(hipStreamSynchronize(st));
+  // linearized residuals are not part of activeResiduals: report their stored state
+  if (newState || newEnergyWithOutlier)
+    for (size_t o = 0; o < R; o++)
+      if (ba->h_res[o].flags & SOS_RF_LINEARIZED) {
+        if (newState) newState[o] = (uint8_t)ba->h_res[o].state_state;
+        if (newEnergyWithOutlier) newEnergyWithOutlier[o] = -1.f;
+      }
+  return SOS_OK;
+}
+
+extern "C" int sos_ba_apply_res(sos_ba *ba) {
+  if (!ba || !ba->have_window) return SOS_ERR_STATE;
+  SOS_HIP(hipSetDevice(ba->ctx->device));
+  const int nthr = ba->ntilesA * SOS_TILE;
+  if (nthr > 0) k_apply_res<<<divup(nthr, 256), 256, 0, ba->ctx->stream>>>(ba->dev);
+  SOS_HIP(hipGetLastError());
+  return SOS_OK;
+}
+
+extern "C" int sos_ba_reset_oob(sos_ba *ba) {
+  if (!ba || !ba->have_window) return SOS_ERR_STATE;
+  SOS_HIP(hipSetDevice(ba->ctx->device));
+  const int nthr = ba->ntilesA * SOS_TILE;
+  if (nthr > 0) k_reset_oob<<<divup(nthr, 256), 256, 0, ba->ctx->stream>>>(ba->dev);
+  SOS_HIP(hipGetLastError());
+  return SOS_OK;
+}
+
+extern "C" int sos_ba_fix_linearization(sos_ba *ba, const int32_t *residIdx, int count) {
+  if (!ba || !ba->have_window || !ba->have_state || (count && !residIdx)) return SOS_ERR_STATE;
+  if (count <= 0) return SOS_OK;
+  SOS_HIP(hipSetDevice(ba->ctx->device));
+  hipStream_t st = ba->ctx->stream;
+  std::vector<int> sl(count);
+  for (int k = 0; k < count; k++) {
+    if (residIdx[k] < 0 || residIdx[k] >= ba->R) return SOS_ERR_ARG;
+    sl[k] = ba->h_s_of_orig[residIdx[k]];
+    ba->h_res[residIdx[k]].flags |= SOS_RF_LINEARIZED;
+  }
+  int rc = upload(st, ba->d_tmp_int, sl);
+  if (rc) return rc;
+  k_fix_lin<<<divup(count, 64), 64, 0, st>>>(ba->dev, ba->d_tmp_int.p, count);
+  SOS_HIP(hipGetLastError());
+  SOS_HIP(hipStreamSynchronize(st));
+  return SOS_OK;
+}
+
+// ---- accumulation pipeline ---------------------------------------------------------------------
+static int launch_top(sos_ba *ba) {
+  hipStream_t st = ba->ctx->stream;
+  const int nA = ba->ntilesA, nL = ba->ntiles - ba->ntilesA;
+  if (nA > 0)
+    k_top_accumulate<false><<<divup(nA, 8), 256, 0, st>>>(ba->dev, 0, nA, 0, nullptr, nullptr, ba->d_top_part.p, nullptr);
+  if (nL > 0)
+    k_top_accumulate<false><<<divup(nL, 8), 256, 0, st>>>(ba->dev, nA, nL, 1, nullptr, nullptr,
+                                                        ba->d_top_part.p + (size_t)nA * SOS_TOPN, nullptr);
+  return SOS_OK;
+}
+static int launch_sc(sos_ba *ba, int shiftPriorToZero) {
+  hipStream_t st = ba->ctx->stream;
+  if (ba->P > 0) k_point_prep<<<divup(ba->P, 128), 128, 0, st>>>(ba->dev, shiftPriorToZero, nullptr, ba->P, 0);
+  if (ba->nchunks > 0) {
+    const size_t lds = sizeof(float) * (64 * (size_t)ba->ld + 64);
+    k_sc_gram<<<ba->nchunks, 256, lds, st>>>(ba->dev, ba->d_chunk_pt.p, ba->Dm, ba->ld, ba->d_gram_part.p);
+  }
+  return SOS_OK;
+}
+static int launch_reduce(sos_ba *ba) {
+  hipStream_t st = ba->ctx->stream;
+  const int n = ba->n;
+  float *acc = ba->d_acc.p;
+  hipMemsetAsync(acc + ba->off_nres, 0, 2 * sizeof(float), st);
+  k_reduce_top<<<n * n, SOS_TOPN, 0, st>>>(ba->d_top_part.p, ba->d_pair_tile_begin.p, acc + ba->off_topA, acc + ba->off_nres);
+  k_reduce_top<<<n * n, SOS_TOPN, 0, st>>>(ba->d_top_part.p, ba->d_pair_tile_begin.p + n * n, acc + ba->off_topL,
+                                           acc + ba->off_nres + 1);
+  const int elems = 8 * n * (8 * n + 5);
+  dim3 grid(divup(elems, 256), n + 1);
+  k_reduce_sc<<<grid, 256, 0, st>>>(ba->d_gram_part.p, ba->d_host_chunk_begin.p, n, ba->Dm, ba->nchunks, acc + ba->off_D,
+                                    acc + ba->off_E, acc + ba->off_EB, acc + ba->off_Hcc, acc + ba->off_bc);
+  return SOS_OK;
+}
+
+extern "C" int sos_ba_accumulate_local(sos_ba *ba) {
+  if (!ba || !ba->have_window || !ba->have_state) return SOS_ERR_STATE;
+  SOS_HIP(hipSetDevice(ba->ctx->device));
+  launch_top(ba);
+  launch_sc(ba, 1);
+  launch_reduce(ba);
+  SOS_HIP(hipGetLastError());
+  return SOS_OK;
+}
+
+extern "C" int sos_ba_acc_buffer(sos_ba *ba, float **dev_ptr, size_t *nfloats) {
+  if (!ba || !ba->have_window) return SOS_ERR_STATE;
+  if (dev_ptr) *dev_ptr = ba->d_acc.p;
+  if (nfloats) *nfloats = ba->acc_floats;
+  return SOS_OK;
+}
+
+extern "C" int sos_ba_stitch(sos_ba *ba, double *H_A, double *b_A, double *H_L, double *b_L, double *H_sc, double *b_sc,
+                             int *resInA, int *resInL) {
+  if (!ba || !ba->have_window || !ba->have_state) return SOS_ERR_STATE;
+  SOS_HIP(hipSetDevice(ba->ctx->device));
+  hipStream_t st = ba->ctx->stream;
+  const int n = ba->n;
+  const size_t dim = 4 + 8 * (size_t)n;
+  float *acc = ba->d_acc.p;
+  double *H = ba->d_Hout.p, *b = ba->d_bout.p;
+  SOS_HIP(hipMemsetAsync(H, 0, sizeof(double) * 3 * dim * dim, st));
+  SOS_HIP(hipMemsetAsync(b, 0, sizeof(double) * 3 * dim, st));
+  dim3 gt(n * (n + 1) / 2 + 1, 2);
+  k_stitch_top<<<gt, 64, 0, st>>>(n, acc + ba->off_topA, ba->d_adHost.p, ba->d_adTarget.p, H, b);
+  k_sc_M<<<n * n * n, 64, 0, st>>>(n, acc + ba->off_D, ba->d_adHost.p, ba->d_adTarget.p, ba->d_M.p);
+  k_stitch_sc<<<n * n + 1, 64, 0, st>>>(n, ba->d_M.p, acc + ba->off_E, acc + ba->off_EB, acc + ba->off_Hcc, acc + ba->off_bc,
+                                        ba->d_adHost.p, ba->d_adTarget.p, H + 2 * dim * dim, b + 2 * dim);
+  SOS_HIP(hipGetLastError());
+  if (H_A) SOS_HIP(hipMemcpyAsync(H_A, H, sizeof(double) * dim * dim, hipMemcpyDeviceToHost, st));
+  if (b_A) SOS_HIP(hipMemcpyAsync(b_A, b, sizeof(double) * dim, hipMemcpyDeviceToHost, st));
+  if (H_L) SOS_HIP(hipMemcpyAsync(H_L, H + dim * dim, sizeof(double) * dim * dim, hipMemcpyDeviceToHost, st));
+  if (b_L) SOS_HIP(hipMemcpyAsync(b_L, b + dim, sizeof(double) * dim, hipMemcpyDeviceToHost, st));
+  if (H_sc) SOS_HIP(hipMemcpyAsync(H_sc, H + 2 * dim * dim, sizeof(double) * dim * dim, hipMemcpyDeviceToHost, st));
+  if (b_sc) SOS_HIP(hipMemcpyAsync(b_sc, b + 2 * dim, sizeof(double) * dim, hipMemcpyDeviceToHost, st));
+  float nres[2] = {0, 0};
+  SOS_HIP(hipMemcpyAsync(nres, acc + ba->off_nres, 2 * sizeof(float), hipMemcpyDeviceToHost, st));
+  SOS_HIP(hipStreamSynchronize(st));
+  if (resInA) *resInA = (int)nres[0];
+  if (resInL) *resInL = (int)nres[1];
+  return SOS_OK;
+}
+
+extern "C" int sos_ba_accumulate(sos_ba *ba, double *H_A, double *b_A, double *H_L, double *b_L, double *H_sc,
+                                 double *b_sc, int *resInA, int *resInL) {
+  int rc = sos_ba_accumulate_local(ba);
+  if (rc) return rc;
+  return sos_ba_stitch(ba, H_A, b_A, H_L, b_L, H_sc, b_sc, resInA, resInL);
+}
+
+extern "C" int sos_ba_get_point_hessian(sos_ba *ba, float *idepth_hessian, float *HdiF, float *bdSumF) {
+  if (!ba || !ba->have_window) return SOS_ERR_STATE;
+  SOS_HIP(hipSetDevice(ba->ctx->device));
+  std::vector<float> po((size_t)ba->P * 16);
+  if (ba->P) SOS_HIP(hipMemcpyAsync(po.data(), ba->d_p_out.p, sizeof(float) * po.size(), hipMemcpyDeviceToHost, ba->ctx->stream));
+  SOS_HIP(hipStreamSynchronize(ba->ctx->stream));
+  for (int p = 0; p < ba->P; p++) {
+    if (idepth_hessian) idepth_hessian[p] = po[(size_t)p * 16 + PO_IDH];
+    if (HdiF) HdiF[p] = po[(size_t)p * 16 + PO_HDI];
+    if (bdSumF) bdSumF[p] = po[(size_t)p * 16 + PO_BDSUM];
+  }
+  return SOS_OK;
+}
+
+extern "C" int sos_ba_resubstitute(sos_ba *ba, const double *x, float *pointStep) {
+  if (!ba || !ba->have_window || !ba->have_state || !x) return SOS_ERR_STATE;
+  SOS_HIP(hipSetDevice(ba->ctx->device));
+  hipStream_t st = ba->ctx->stream;
+  const int n = ba->n, dim = 4 + 8 * n;
+  // xAd (OB/EnergyFunctional.cpp:499-516), fp32, summed left to right
+  std::vector<float> xF(dim), xAd((size_t)n * n * 8);
+  for (int i = 0; i < dim; i++) xF[i] = (float)x[i];
+  for (int h = 0; h < n; h++)
+    for (int t = 0; t < n; t++) {
+      const float *AH = &ba->h_adHostF[64 * (size_t)(h + n * t)], *AT = &ba->h_adTargetF[64 * (size_t)(h + n * t)];
+      for (int j = 0; j < 8; j++) {
+        float s1 = 0, s2 = 0;
+        for (int i = 0; i < 8; i++) {
+          s1 += xF[4 + 8 * h + i] * AH[8 * i + j];
+          s2 += xF[4 + 8 * t + i] * AT[8 * i + j];
+        }
+        xAd[8 * (size_t)(n * h + t) + j] = s1 + s2;
+      }
+    }
+  SOS_HIP(hipMemcpyAsync(ba->d_xc.p, xF.data(), sizeof(float) * 4, hipMemcpyHostToDevice, st));
+  SOS_HIP(hipMemcpyAsync(ba->d_xAd.p, xAd.data(), sizeof(float) * xAd.size(), hipMemcpyHostToDevice, st));
+  if (ba->P > 0) k_resubstitute<<<divup(ba->P, 128), 128, 0, st>>>(ba->dev, ba->d_xc.p, ba->d_xAd.p, ba->d_step.p);
+  SOS_HIP(hipGetLastError());
+  if (pointStep && ba->P) SOS_HIP(hipMemcpyAsync(pointStep, ba->d_step.p, sizeof(float) * ba->P, hipMemcpyDeviceToHost, st));
+  SOS_HIP(hipStreamSynchronize(st));
+  return SOS_OK;
+}
+
+extern "C" int sos_ba_calc_lenergy(sos_ba *ba, double *E) {
+  if (!ba || !ba->have_window || !ba->have_state || !E) return SOS_ERR_STATE;
+  SOS_HIP(hipSetDevice(ba->ctx->device));
+  hipStream_t st = ba->ctx->stream;
+  double e = 0;
+  if (ba->Rpad > 0) {
+    k_lenergy<<<divup(ba->Rpad, 256), 256, 0, st>>>(ba->dev, ba->d_perres.p);
+    k_sum_double<<<1, 1024, 0, st>>>(ba->d_perres.p, ba->Rpad, ba->d_scalar.p);
+    SOS_HIP(hipMemcpyAsync(&e, ba->d_scalar.p, sizeof(double), hipMemcpyDeviceToHost, st));
+    SOS_HIP(hipStreamSynchronize(st));
+  }
+  // E.updateSingle(deltaF^2 * priorF) per point (OB/EnergyFunctional.cpp:620)
+  for (int p = 0; p < ba->P; p++) e += (double)(ba->h_pts[p].deltaF * ba->h_pts[p].deltaF * ba->h_pts[p].priorF);
+  *E = e;
+  return SOS_OK;
+}
+
+extern "C" int sos_ba_accumulate_marg(sos_ba *ba, const int32_t *pointIdx, int count, double *M, double *Mb, double *Msc,
+                                      double *Mbsc, int *resInM) {
+  if (!ba || !ba->have_window || !ba->have_state || (count && !pointIdx)) return SOS_ERR_STATE;
+  SOS_HIP(hipSetDevice(ba->ctx->device));
+  hipStream_t st = ba->ctx->stream;
+  const int n = ba->n;
+  const size_t dim = 4 + 8 * (size_t)n, nn = (size_t)n * n;
+  // virtual tiles: residuals of the listed points grouped by pair (addPoint<2> visits every active one)
+  std::vector<std::vector<int>> bypair(nn);
+  std::vector<int> plist(pointIdx, pointIdx + count);
+  for (int k = 0; k < count; k++) {
+    const int p = pointIdx[k];
+    if (p < 0 || p >= ba->P) return SOS_ERR_ARG;
+    for (int o = ba->h_p_begin[p]; o < ba->h_p_begin[p + 1]; o++)
+      bypair[ba->h_res[o].host + n * ba->h_res[o].target].push_back(ba->h_s_of_orig[o]);
+  }
+  std::vector<int> list, list_pair, pair_tile_begin(nn + 1, 0);
+  for (size_t k = 0; k < nn; k++) {
+    pair_tile_begin[k] = (int)list_pair.size();
+    for (size_t q = 0; q < bypair[k].size(); q += SOS_TILE) {
+      list_pair.push_back((int)k);
+      for (int j = 0; j < SOS_TILE; j++) list.push_back(q + j < bypair[k].size() ? bypair[k][q + j] : -1);
+    }
+  }
+  pair_tile_begin[nn] = (int)list_pair.size();
+  const int nvt = (int)list_pair.size();
+  // chunks of the listed points per host
+  std::vector<int> chunk_pt, host_chunk_begin(n + 1, 0);
+  {
+    std::vector<std::vector<int>> byhost(n);
+    for (int p : plist) byhost[ba->h_pts[p].host].push_back(p);
+    for (int h = 0; h < n; h++) {
+      host_chunk_begin[h] = (int)(chunk_pt.size() / 64);
+      for (size_t q = 0; q < byhost[h].size(); q += 64)
+        for (int k = 0; k < 64; k++) chunk_pt.push_back(q + k < byhost[h].size() ? byhost[h][q + k] : -1);
+    }
+    host_chunk_begin[n] = (int)(chunk_pt.size() / 64);
+  }
+  const int nch = host_chunk_begin[n];
+  // pack [list | list_pair | pair_tile_begin | plist | chunk_pt | host_chunk_begin] into one int upload
+  std::vector<int> blob;
+  auto put = [&](const std::vector<int> &v) { size_t o = blob.size(); blob.insert(blob.end(), v.begin(), v.end()); blob.resize((blob.size() + 3) / 4 * 4); return o; };
+  const size_t o_list = put(list), o_lp = put(list_pair), o_ptb = put(pair_tile_begin), o_pl = put(plist),
+               o_cp = put(chunk_pt), o_hcb = put(host_chunk_begin);
+  if (blob.empty()) blob.push_back(0);
+  int rc = upload(st, ba->d_tmp_int, blob);
+  if (rc) return rc;
+  const int *B = ba->d_tmp_int.p;
+  DevBuf<float> tp, gp, acc;
+  if ((rc = tp.ensure((size_t)(nvt ? nvt : 1) * SOS_TOPN + 64 * SOS_TOPN))) return rc;
+  if ((rc = gp.ensure((size_t)(nch ? nch : 1) * ba->Dm * ba->Dm))) return rc;
+  if ((rc = acc.ensure(ba->acc_floats))) return rc;
+  SOS_HIP(hipMemsetAsync(acc.p, 0, sizeof(float) * ba->acc_floats, st));
+  if (nvt > 0)
+    k_top_accumulate<true><<<divup(nvt, 8), 256, 0, st>>>(ba->dev, 0, nvt, 2, B + o_list, B + o_lp, tp.p, nullptr);
+  k_reduce_top<<<n * n, SOS_TOPN, 0, st>>>(tp.p, B + o_ptb, acc.p + ba->off_topA, acc.p + ba->off_nres);
+  if (count > 0) k_point_prep<<<divup(count, 128), 128, 0, st>>>(ba->dev, 0, B + o_pl, count, 1);
+  if (nch > 0) {
+    const size_t lds = sizeof(float) * (64 * (size_t)ba->ld + 64);
+    k_sc_gram<<<nch, 256, lds, st>>>(ba->dev, B + o_cp, ba->Dm, ba->ld, gp.p);
+  }
+  const int elems = 8 * n * (8 * n + 5);
+  dim3 grid(divup(elems, 256), n + 1);
+  k_reduce_sc<<<grid, 256, 0, st>>>(gp.p, B + o_hcb, n, ba->Dm, nch, acc.p + ba->off_D, acc.p + ba->off_E, acc.p + ba->off_EB,
+                                    acc.p + ba->off_Hcc, acc.p + ba->off_bc);
+  double *H = ba->d_Hout.p, *b = ba->d_bout.p;
+  SOS_HIP(hipMemsetAsync(H, 0, sizeof(double) * 3 * dim * dim, st));
+  SOS_HIP(hipMemsetAsync(b, 0, sizeof(double) * 3 * dim, st));
+  dim3 gt(n * (n + 1) / 2 + 1, 1);
+  k_stitch_top<<<gt, 64, 0, st>>>(n, acc.p + ba->off_topA, ba->d_adHost.p, ba->d_adTarget.p, H, b);
+  k_sc_M<<<n * n * n, 64, 0, st>>>(n, acc.p + ba->off_D, ba->d_adHost.p, ba->d_adTarget.p, ba->d_M.p);
+  k_stitch_sc<<<n * n + 1, 64, 0, st>>>(n, ba->d_M.p, acc.p + ba->off_E, acc.p + ba->off_EB, acc.p + ba->off_Hcc,
+                                        acc.p + ba->off_bc, ba->d_adHost.p, ba->d_adTarget.p, H + 2 * dim * dim, b + 2 * dim);
+  SOS_HIP(hipGetLastError());
+  if (M) SOS_HIP(hipMemcpyAsync(M, H, sizeof(double) * dim * dim, hipMemcpyDeviceToHost, st));
+  if (Mb) SOS_HIP(hipMemcpyAsync(Mb, b, sizeof(double) * dim, hipMemcpyDeviceToHost, st));
+  if (Msc) SOS_HIP(hipMemcpyAsync(Msc, H + 2 * dim * dim, sizeof(double) * dim * dim, hipMemcpyDeviceToHost, st));
+  if (Mbsc) SOS_HIP(hipMemcpyAsync(Mbsc, b + 2 * dim, sizeof(double) * dim, hipMemcpyDeviceToHost, st));
+  float nres = 0;
+  SOS_HIP(hipMemcpyAsync(&nres, acc.p + ba->off_nres, sizeof(float), hipMemcpyDeviceToHost, st));
+  SOS_HIP(hipStreamSynchronize(st));
+  if (resInM) *resInM = (int)nres;
+  tp.release(); gp.release(); acc.release();
+  return SOS_OK;
+}
+
+// ---- inspection ---------------------------------------------------------------------------------
+extern "C" int sos_ba_get_jacobian(sos_ba *ba, int residIdx, int which, sos_rawjac *out) {
+  (void)which;  // one shared buffer, see the header comment of this file
+  if (!ba || !ba->have_window || !out || residIdx < 0 || residIdx >= ba->R) return SOS_ERR_ARG;
+  SOS_HIP(hipSetDevice(ba->ctx->device));
+  int rc = ba->d_rawjac.ensure(1);
+  if (rc) return rc;
+  k_get_jac<<<1, 64, 0, ba->ctx->stream>>>(ba->dev, ba->h_s_of_orig[residIdx], ba->d_rawjac.p);
+  SOS_HIP(hipMemcpyAsync(out, ba->d_rawjac.p, sizeof(sos_rawjac), hipMemcpyDeviceToHost, ba->ctx->stream));
+  SOS_HIP(hipStreamSynchronize(ba->ctx->stream));
+  return SOS_OK;
+}
+
+extern "C" int sos_ba_get_residual_flags(sos_ba *ba, uint32_t *flags, int32_t *state_state, float *state_energy) {
+  if (!ba || !ba->have_window) return SOS_ERR_STATE;
+  SOS_HIP(hipSetDevice(ba->ctx->device));
+  hipStream_t st = ba->ctx->stream;
+  const size_t Rp = ba->Rpad;
+  std::vector<uint8_t> f(Rp), s(Rp);
+  std::vector<float> e(Rp);
+  if (Rp) {
+    SOS_HIP(hipMemcpyAsync(f.data(), ba->d_s_flags.p, Rp, hipMemcpyDeviceToHost, st));
+    SOS_HIP(hipMemcpyAsync(s.data(), ba->d_s_state.p, Rp, hipMemcpyDeviceToHost, st));
+    SOS_HIP(hipMemcpyAsync(e.data(), ba->d_s_energy.p, sizeof(float) * Rp, hipMemcpyDeviceToHost, st));
+  }
+  SOS_HIP(hipStreamSynchronize(st));
+  for (int o = 0; o < ba->R; o++) {
+    const int si = ba->h_s_of_orig[o];
+    if (flags) {
+      uint32_t v = 0;
+      if (f[si] & DF_ACTIVE) v |= SOS_RF_ACTIVE;
+      if (f[si] & DF_LINEARIZED) v |= SOS_RF_LINEARIZED;
+      if (f[si] & DF_ISNEW) v |= SOS_RF_ISNEW;
+      flags[o] = v;
+    }
+    if (state_state) state_state[o] = s[si];
+    if (state_energy) state_energy[o] = e[si];
+  }
+  return SOS_OK;
+}
+
+static int gather_sorted8(sos_ba *ba, const float *dsrc, float *out) {
+  const size_t Rp = ba->Rpad;
+  std::vector<float> v(Rp * 8);
+  if (Rp) SOS_HIP(hipMemcpyAsync(v.data(), dsrc, sizeof(float) * 8 * Rp, hipMemcpyDeviceToHost, ba->ctx->stream));
+  SOS_HIP(hipStreamSynchronize(ba->ctx->stream));
+  for (int o = 0; o < ba->R; o++) memcpy(out + 8 * (size_t)o, &v[8 * (size_t)ba->h_s_of_orig[o]], 8 * sizeof(float));
+  return SOS_OK;
+}
+extern "C" int sos_ba_get_JpJdF(sos_ba *ba, float *JpJdF) {
+  if (!ba || !ba->have_window || !JpJdF) return SOS_ERR_STATE;
+  SOS_HIP(hipSetDevice(ba->ctx->device));
+  return gather_sorted8(ba, ba->d_JpJd.p, JpJdF);
+}
+extern "C" int sos_ba_get_res_toZeroF(sos_ba *ba, float *rtz) {
+  if (!ba || !ba->have_window || !rtz) return SOS_ERR_STATE;
+  SOS_HIP(hipSetDevice(ba->ctx->device));
+  return gather_sorted8(ba, ba->d_s_rtz.p, rtz);
+}
+
+// ---- kernel timing with HIP events on the context's stream ----------------------------------------
+extern "C" int sos_ba_time_kernel(sos_ba *ba, const char *kernel, const float *frameEnergyTH, int iters, float *avg_ms) {
+  if (!ba || !ba->have_window || !ba->have_state || !kernel || iters <= 0 || !avg_ms) return SOS_ERR_STATE;
+  sos_ctx *c = ba->ctx;
+  SOS_HIP(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  if (frameEnergyTH) SOS_HIP(hipMemcpyAsync(ba->d_frameTH.p, frameEnergyTH, sizeof(float) * ba->n, hipMemcpyHostToDevice, st));
+  const std::string k(kernel);
+  auto once = [&]() -> int {
+    if (k == "linearize") return launch_linearize(ba);
+    if (k == "apply_res") return sos_ba_apply_res(ba);
+    if (k == "top_accumulate") return launch_top(ba);
+    if (k == "sc_accumulate") return launch_sc(ba, 1);
+    if (k == "reduce") return launch_reduce(ba);
+    if (k == "accumulate_local") return sos_ba_accumulate_local(ba);
+    return SOS_ERR_ARG;
+  };
+  int rc = once();  // warm-up, also validates the name
+  if (rc) return rc;
+  SOS_HIP(hipStreamSynchronize(st));
+  SOS_HIP(hipEventRecord(c->ev0, st));
+  for (int i = 0; i < iters; i++) once();
+  SOS_HIP(hipEventRecord(c->ev1, st));
+  SOS_HIP(hipEventSynchronize(c->ev1));
+  float ms = 0;
+  SOS_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  SOS_HIP(hipGetLastError());
+  *avg_ms = ms / iters;
+  return SOS_OK;
+}

@@ -1,0 +1,64 @@
+// sos_common.h -- internal declarations shared by the HIP translation units of libsos_slam_hip.so.
+// Target: gfx950 (MI355X, CDNA4) only.  wave = 64 lanes.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/sos_slam.h"
+
+#define SOS_HIP(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      fprintf(stderr, "[sos_slam_hip] %s:%d %s -> %s\n", __FILE__, __LINE__, #expr,            \
+              hipGetErrorString(e_));                                                          \
+      return SOS_ERR_HIP;                                                                      \
+    }                                                                                          \
+  } while (0)
+
+#define SOS_TILE 32          // residuals per Jacobian tile (one 256-thread linearize block)
+#define SOS_JPLANES 72       // unique floats of a RawResidualJacobian (symmetric 2x2s stored once)
+#define SOS_TILE_FLOATS (SOS_JPLANES * SOS_TILE)
+#define SOS_TOPN 96          // 91 uniques of the 13x13 block, padded for the butterfly reduction
+
+// plane numbers inside a Jacobian tile  J[tile][plane][32]
+#define JP_RESF 0      // 8
+#define JP_JIDX0 8     // 8
+#define JP_JIDX1 16    // 8
+#define JP_JAB0 24     // 8
+#define JP_JAB1 32     // 8
+#define JP_DXI0 40     // 6
+#define JP_DXI1 46     // 6
+#define JP_DC0 52      // 4
+#define JP_DC1 56      // 4
+#define JP_DD 60       // 2
+#define JP_JIDX2 62    // 3: 00 01 11
+#define JP_JABJIDX 65  // 4: 00 01 10 11
+#define JP_JAB2 69     // 3: 00 01 11
+
+// internal residual flag bits (device side, one byte per sorted residual)
+#define DF_ACTIVE 1u
+#define DF_LINEARIZED 2u
+#define DF_ISNEW 4u
+
+struct sos_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int w = 0, h = 0, levels = 1;
+  int wl[SOS_PYR_LEVELS] = {0}, hl[SOS_PYR_LEVELS] = {0};
+  float *dI[SOS_MAX_SLOTS][SOS_PYR_LEVELS];
+  float *absg[SOS_MAX_SLOTS][SOS_PYR_LEVELS];
+  bool has_pyr[SOS_MAX_SLOTS];
+  float *d_img = nullptr;     // staging for the raw image
+  float *d_gammaB = nullptr;  // 256 floats
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+int sos_ctx_ensure_slot(sos_ctx *ctx, int slot, bool all_levels);

@@ -1,0 +1,367 @@
+"""ctypes binding of csrc/libsos_slam_hip.so (the C-ABI of include/sos_slam.h).
+
+There is NO CPU fallback: `load()` raises when the library has not been built or cannot be loaded,
+and every context creation raises when no MI355X is visible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+from .records import Calib, Params
+from .synth import RAWJAC_DTYPE
+
+_LIB = None
+
+# every symbol include/sos_slam.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "sos_ctx_create", "sos_ctx_destroy", "sos_ctx_synchronize", "sos_ctx_pyr_levels", "sos_make_pyramid",
+    "sos_frame_upload_dI", "sos_frame_download_level", "sos_frame_release", "sos_ba_create", "sos_ba_destroy",
+    "sos_ba_set_window", "sos_ba_set_state", "sos_ba_linearize", "sos_ba_apply_res", "sos_ba_reset_oob",
+    "sos_ba_fix_linearization", "sos_ba_accumulate", "sos_ba_accumulate_local", "sos_ba_acc_buffer",
+    "sos_ba_stitch", "sos_ba_get_point_hessian", "sos_ba_resubstitute", "sos_ba_calc_lenergy",
+    "sos_ba_accumulate_marg", "sos_ba_get_jacobian", "sos_ba_get_residual_flags", "sos_ba_get_JpJdF",
+    "sos_ba_get_res_toZeroF", "sos_ba_time_kernel", "sos_tracker_create", "sos_tracker_destroy",
+    "sos_tracker_set_ref", "sos_tracker_scale_depth", "sos_tracker_get_pc", "sos_tracker_calc_res",
+    "sos_tracker_calc_gs", "sos_tracker_calc_res_scale", "sos_tracker_calc_gs_scale", "sos_backend_name",
+]
+
+
+class SosError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return _build.HIP_LIB
+
+
+def load():
+    """Load the HIP library; raises SosError if it is missing (no silent fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise SosError(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    try:
+        L = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError as e:  # pragma: no cover
+        raise SosError(f"cannot load {path}: {e}") from e
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    L.sos_backend_name.restype = C.c_char_p
+    L.sos_ctx_create.argtypes = [ci, vp, ci, ci, C.POINTER(vp)]
+    L.sos_ctx_destroy.argtypes = [vp]
+    L.sos_ctx_synchronize.argtypes = [vp]
+    L.sos_ctx_pyr_levels.argtypes = [vp]
+    L.sos_make_pyramid.argtypes = [vp, ci, vp, vp]
+    L.sos_frame_upload_dI.argtypes = [vp, ci, vp]
+    L.sos_frame_download_level.argtypes = [vp, ci, ci, vp, vp]
+    L.sos_frame_release.argtypes = [vp, ci]
+    L.sos_ba_create.argtypes = [vp, C.POINTER(Params), C.POINTER(vp)]
+    L.sos_ba_destroy.argtypes = [vp]
+    L.sos_ba_set_window.argtypes = [vp, ci, vp, ci, vp, ci, vp, vp, vp]
+    L.sos_ba_set_state.argtypes = [vp, C.POINTER(Calib)] + [vp] * 8
+    L.sos_ba_linearize.argtypes = [vp, vp, C.POINTER(C.c_double), vp, vp, vp, vp]
+    L.sos_ba_apply_res.argtypes = [vp]
+    L.sos_ba_reset_oob.argtypes = [vp]
+    L.sos_ba_fix_linearization.argtypes = [vp, vp, ci]
+    L.sos_ba_accumulate.argtypes = [vp] + [vp] * 6 + [C.POINTER(ci), C.POINTER(ci)]
+    L.sos_ba_accumulate_local.argtypes = [vp]
+    L.sos_ba_acc_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.sos_ba_stitch.argtypes = [vp] + [vp] * 6 + [C.POINTER(ci), C.POINTER(ci)]
+    L.sos_ba_get_point_hessian.argtypes = [vp, vp, vp, vp]
+    L.sos_ba_resubstitute.argtypes = [vp, vp, vp]
+    L.sos_ba_calc_lenergy.argtypes = [vp, C.POINTER(C.c_double)]
+    L.sos_ba_accumulate_marg.argtypes = [vp, vp, ci, vp, vp, vp, vp, C.POINTER(ci)]
+    L.sos_ba_get_jacobian.argtypes = [vp, ci, ci, vp]
+    L.sos_ba_get_residual_flags.argtypes = [vp, vp, vp, vp]
+    L.sos_ba_get_JpJdF.argtypes = [vp, vp]
+    L.sos_ba_get_res_toZeroF.argtypes = [vp, vp]
+    L.sos_ba_time_kernel.argtypes = [vp, C.c_char_p, vp, ci, C.POINTER(cf)]
+    L.sos_tracker_create.argtypes = [vp, C.POINTER(Params), C.POINTER(vp)]
+    L.sos_tracker_destroy.argtypes = [vp]
+    L.sos_tracker_set_ref.argtypes = [vp, C.POINTER(Calib), ci, ci, vp, vp, vp, vp, vp]
+    L.sos_tracker_scale_depth.argtypes = [vp, cf]
+    L.sos_tracker_get_pc.argtypes = [vp, ci, vp, vp, vp, vp]
+    L.sos_tracker_calc_res.argtypes = [vp, ci, ci, vp, vp, vp, cf, vp]
+    L.sos_tracker_calc_gs.argtypes = [vp, ci, cf, cf, vp, vp]
+    L.sos_tracker_calc_res_scale.argtypes = [vp, ci, ci, vp, vp, vp, cf, cf, vp]
+    L.sos_tracker_calc_gs_scale.argtypes = [vp, ci, vp, vp, cf, vp, vp]
+    _LIB = L
+    return L
+
+
+def _p(a):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"], "array must be C-contiguous"
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise SosError(f"{what} failed with status {rc}")
+
+
+class Context:
+    """sos_ctx: device + stream + frame (pyramid) store."""
+
+    def __init__(self, w: int, h: int, device: int = 0, stream: int | None = None):
+        self.L = load()
+        self.w, self.h = w, h
+        self.h_ = C.c_void_p()
+        _chk(self.L.sos_ctx_create(device, C.c_void_p(stream) if stream else None, w, h, C.byref(self.h_)),
+             "sos_ctx_create (is an MI355X visible?)")
+        self.levels = self.L.sos_ctx_pyr_levels(self.h_)
+
+    def close(self):
+        if getattr(self, "h_", None):
+            self.L.sos_ctx_destroy(self.h_)
+            self.h_ = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _chk(self.L.sos_ctx_synchronize(self.h_), "sos_ctx_synchronize")
+
+    def make_pyramid(self, slot: int, img: np.ndarray, gammaB: np.ndarray | None = None):
+        img = np.ascontiguousarray(img, dtype=np.float32)
+        assert img.shape == (self.h, self.w)
+        gb = None if gammaB is None else np.ascontiguousarray(gammaB, dtype=np.float32)
+        _chk(self.L.sos_make_pyramid(self.h_, slot, _p(img), _p(gb)), "sos_make_pyramid")
+
+    def upload_dI(self, slot: int, dI: np.ndarray):
+        dI = np.ascontiguousarray(dI, dtype=np.float32)
+        assert dI.shape == (self.h, self.w, 3)
+        _chk(self.L.sos_frame_upload_dI(self.h_, slot, _p(dI)), "sos_frame_upload_dI")
+
+    def download_level(self, slot: int, lvl: int):
+        wl, hl = self.w >> lvl, self.h >> lvl
+        dI = np.zeros((hl, wl, 3), dtype=np.float32)
+        ag = np.zeros((hl, wl), dtype=np.float32)
+        _chk(self.L.sos_frame_download_level(self.h_, slot, lvl, _p(dI), _p(ag)), "sos_frame_download_level")
+        return dI, ag
+
+    def release(self, slot: int):
+        _chk(self.L.sos_frame_release(self.h_, slot), "sos_frame_release")
+
+
+class Backend:
+    """sos_ba: device side of one EnergyFunctional."""
+
+    def __init__(self, ctx: Context, params: dict):
+        self.L = ctx.L
+        self.ctx = ctx
+        self.params = Params.from_dict(params)
+        self.h_ = C.c_void_p()
+        _chk(self.L.sos_ba_create(ctx.h_, C.byref(self.params), C.byref(self.h_)), "sos_ba_create")
+        self.n = self.P = self.R = 0
+
+    def close(self):
+        if getattr(self, "h_", None):
+            self.L.sos_ba_destroy(self.h_)
+            self.h_ = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_window(self, frame_slot, points, resid, res_toZeroF=None, lin_J=None):
+        fs = np.ascontiguousarray(frame_slot, dtype=np.int32)
+        pts = np.ascontiguousarray(points)
+        res = np.ascontiguousarray(resid)
+        self.n, self.P, self.R = len(fs), len(pts), len(res)
+        rtz = None if res_toZeroF is None else np.ascontiguousarray(res_toZeroF, dtype=np.float32)
+        lj = None if lin_J is None else np.ascontiguousarray(lin_J)
+        _chk(self.L.sos_ba_set_window(self.h_, self.n, _p(fs), self.P, _p(pts), self.R, _p(res), _p(rtz), _p(lj)),
+             "sos_ba_set_window")
+
+    def set_state(self, calib=None, precalc=None, adHTdeltaF=None, cDeltaF=None, adHost=None, adTarget=None,
+                  idepth=None, idepth_zero=None, deltaF=None):
+        def f32(a):
+            return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+        def f64(a):
+            return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+        pc = None if precalc is None else np.ascontiguousarray(precalc)
+        _chk(self.L.sos_ba_set_state(self.h_, C.byref(calib) if calib is not None else None, _p(pc),
+                                     _p(f32(adHTdeltaF)), _p(f32(cDeltaF)), _p(f64(adHost)), _p(f64(adTarget)),
+                                     _p(f32(idepth)), _p(f32(idepth_zero)), _p(f32(deltaF))), "sos_ba_set_state")
+
+    def linearize(self, frameEnergyTH, outputs=True):
+        th = np.ascontiguousarray(frameEnergyTH, dtype=np.float32)
+        E = C.c_double(0)
+        if outputs:
+            ns = np.zeros(self.R, dtype=np.uint8)
+            ne = np.zeros(self.R, dtype=np.float32)
+            nw = np.zeros(self.R, dtype=np.float32)
+            ce = np.zeros((self.R, 3), dtype=np.float32)
+            _chk(self.L.sos_ba_linearize(self.h_, _p(th), C.byref(E), _p(ns), _p(ne), _p(nw), _p(ce)),
+                 "sos_ba_linearize")
+            return dict(energy=E.value, newState=ns, newEnergy=ne, newEnergyWithOutlier=nw, center=ce)
+        _chk(self.L.sos_ba_linearize(self.h_, _p(th), C.byref(E), None, None, None, None), "sos_ba_linearize")
+        return dict(energy=E.value)
+
+    def apply_res(self):
+        _chk(self.L.sos_ba_apply_res(self.h_), "sos_ba_apply_res")
+
+    def reset_oob(self):
+        _chk(self.L.sos_ba_reset_oob(self.h_), "sos_ba_reset_oob")
+
+    def fix_linearization(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        _chk(self.L.sos_ba_fix_linearization(self.h_, _p(idx), len(idx)), "sos_ba_fix_linearization")
+
+    def _hb(self):
+        dim = 4 + 8 * self.n
+        return [np.zeros((dim, dim)), np.zeros(dim), np.zeros((dim, dim)), np.zeros(dim), np.zeros((dim, dim)),
+                np.zeros(dim)]
+
+    def accumulate(self):
+        out = self._hb()
+        ra, rl = C.c_int(0), C.c_int(0)
+        _chk(self.L.sos_ba_accumulate(self.h_, *[_p(o) for o in out], C.byref(ra), C.byref(rl)), "sos_ba_accumulate")
+        return dict(H_A=out[0], b_A=out[1], H_L=out[2], b_L=out[3], H_sc=out[4], b_sc=out[5], resInA=ra.value,
+                    resInL=rl.value)
+
+    def accumulate_local(self):
+        _chk(self.L.sos_ba_accumulate_local(self.h_), "sos_ba_accumulate_local")
+
+    def acc_buffer(self):
+        ptr, n = C.c_void_p(), C.c_size_t(0)
+        _chk(self.L.sos_ba_acc_buffer(self.h_, C.byref(ptr), C.byref(n)), "sos_ba_acc_buffer")
+        return ptr.value, n.value
+
+    def stitch(self):
+        out = self._hb()
+        ra, rl = C.c_int(0), C.c_int(0)
+        _chk(self.L.sos_ba_stitch(self.h_, *[_p(o) for o in out], C.byref(ra), C.byref(rl)), "sos_ba_stitch")
+        return dict(H_A=out[0], b_A=out[1], H_L=out[2], b_L=out[3], H_sc=out[4], b_sc=out[5], resInA=ra.value,
+                    resInL=rl.value)
+
+    def point_hessian(self):
+        a = [np.zeros(self.P, dtype=np.float32) for _ in range(3)]
+        _chk(self.L.sos_ba_get_point_hessian(self.h_, *[_p(x) for x in a]), "sos_ba_get_point_hessian")
+        return dict(idepth_hessian=a[0], HdiF=a[1], bdSumF=a[2])
+
+    def resubstitute(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        step = np.zeros(self.P, dtype=np.float32)
+        _chk(self.L.sos_ba_resubstitute(self.h_, _p(x), _p(step)), "sos_ba_resubstitute")
+        return step
+
+    def calc_lenergy(self):
+        E = C.c_double(0)
+        _chk(self.L.sos_ba_calc_lenergy(self.h_, C.byref(E)), "sos_ba_calc_lenergy")
+        return E.value
+
+    def accumulate_marg(self, point_idx):
+        dim = 4 + 8 * self.n
+        idx = np.ascontiguousarray(point_idx, dtype=np.int32)
+        out = [np.zeros((dim, dim)), np.zeros(dim), np.zeros((dim, dim)), np.zeros(dim)]
+        rm = C.c_int(0)
+        _chk(self.L.sos_ba_accumulate_marg(self.h_, _p(idx), len(idx), *[_p(o) for o in out], C.byref(rm)),
+             "sos_ba_accumulate_marg")
+        return dict(M=out[0], Mb=out[1], Msc=out[2], Mbsc=out[3], resInM=rm.value)
+
+    def jacobian(self, r, which=0):
+        out = np.zeros(1, dtype=RAWJAC_DTYPE)
+        _chk(self.L.sos_ba_get_jacobian(self.h_, int(r), which, _p(out)), "sos_ba_get_jacobian")
+        return out[0]
+
+    def residual_flags(self):
+        f = np.zeros(self.R, dtype=np.uint32)
+        s = np.zeros(self.R, dtype=np.int32)
+        e = np.zeros(self.R, dtype=np.float32)
+        _chk(self.L.sos_ba_get_residual_flags(self.h_, _p(f), _p(s), _p(e)), "sos_ba_get_residual_flags")
+        return f, s, e
+
+    def JpJdF(self):
+        o = np.zeros((self.R, 8), dtype=np.float32)
+        _chk(self.L.sos_ba_get_JpJdF(self.h_, _p(o)), "sos_ba_get_JpJdF")
+        return o
+
+    def res_toZeroF(self):
+        o = np.zeros((self.R, 8), dtype=np.float32)
+        _chk(self.L.sos_ba_get_res_toZeroF(self.h_, _p(o)), "sos_ba_get_res_toZeroF")
+        return o
+
+    def time_kernel(self, name: str, frameEnergyTH, iters: int = 100) -> float:
+        th = np.ascontiguousarray(frameEnergyTH, dtype=np.float32)
+        ms = C.c_float(0)
+        _chk(self.L.sos_ba_time_kernel(self.h_, name.encode(), _p(th), iters, C.byref(ms)), f"sos_ba_time_kernel({name})")
+        return ms.value
+
+
+class Tracker:
+    """sos_tracker: device side of one CoarseTracker / ScaleOptimizer."""
+
+    def __init__(self, ctx: Context, params: dict):
+        self.L = ctx.L
+        self.ctx = ctx
+        self.params = Params.from_dict(params)
+        self.h_ = C.c_void_p()
+        _chk(self.L.sos_tracker_create(ctx.h_, C.byref(self.params), C.byref(self.h_)), "sos_tracker_create")
+        self.pc_n = np.zeros(ctx.levels, dtype=np.int32)
+
+    def close(self):
+        if getattr(self, "h_", None):
+            self.L.sos_tracker_destroy(self.h_)
+            self.h_ = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_ref(self, calib, refSlot, u, v, idepth, hdi):
+        a = [np.ascontiguousarray(x, dtype=np.float32) for x in (u, v, idepth, hdi)]
+        _chk(self.L.sos_tracker_set_ref(self.h_, C.byref(calib), refSlot, len(a[0]), *[_p(x) for x in a],
+                                        _p(self.pc_n)), "sos_tracker_set_ref")
+        return self.pc_n.copy()
+
+    def scale_depth(self, s):
+        _chk(self.L.sos_tracker_scale_depth(self.h_, s), "sos_tracker_scale_depth")
+
+    def get_pc(self, lvl):
+        n = int(self.pc_n[lvl])
+        out = [np.zeros(n, dtype=np.float32) for _ in range(4)]
+        _chk(self.L.sos_tracker_get_pc(self.h_, lvl, *[_p(o) for o in out]), "sos_tracker_get_pc")
+        return out
+
+    def calc_res(self, lvl, newSlot, RKi, t, affLL, cutoff):
+        rs = np.zeros(6)
+        a = [np.ascontiguousarray(x, dtype=np.float32) for x in (RKi, t, affLL)]
+        _chk(self.L.sos_tracker_calc_res(self.h_, lvl, newSlot, *[_p(x) for x in a], cutoff, _p(rs)),
+             "sos_tracker_calc_res")
+        return rs
+
+    def calc_gs(self, lvl, a, b0):
+        H, b = np.zeros((8, 8)), np.zeros(8)
+        _chk(self.L.sos_tracker_calc_gs(self.h_, lvl, a, b0, _p(H), _p(b)), "sos_tracker_calc_gs")
+        return H, b
+
+    def calc_res_scale(self, lvl, stereoSlot, RKi, t, K1, scale, cutoff):
+        rs = np.zeros(6)
+        a = [np.ascontiguousarray(x, dtype=np.float32) for x in (RKi, t, K1)]
+        _chk(self.L.sos_tracker_calc_res_scale(self.h_, lvl, stereoSlot, *[_p(x) for x in a], scale, cutoff, _p(rs)),
+             "sos_tracker_calc_res_scale")
+        return rs
+
+    def calc_gs_scale(self, lvl, t, K1, scale):
+        H, b = C.c_float(0), C.c_float(0)
+        a = [np.ascontiguousarray(x, dtype=np.float32) for x in (t, K1)]
+        _chk(self.L.sos_tracker_calc_gs_scale(self.h_, lvl, _p(a[0]), _p(a[1]), scale, C.byref(H), C.byref(b)),
+             "sos_tracker_calc_gs_scale")
+        return H.value, b.value
