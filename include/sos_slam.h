@@ -258,6 +258,10 @@ int sos_ba_calc_lenergy(sos_ba *ba, double *E);
 int sos_ba_accumulate_marg(sos_ba *ba, const int32_t *pointIdx, int count, double *M, double *Mb,
                            double *Msc, double *Mbsc, int *resInM);
 
+/* EFPoint::priorF edits between packs (p->priorF *= setting_idepthFixPriorMargFac,
+ * OB/EnergyFunctional.cpp:901): overwrite priorF of `count` points of the snapshot. */
+int sos_ba_update_point_priors(sos_ba *ba, const int32_t *pointIdx, const float *priorF, int count);
+
 /* inspection helpers used by the parity tests */
 int sos_ba_get_jacobian(sos_ba *ba, int residIdx, int which /*0 = EFResidual::J, 1 = scratch*/,
                         sos_rawjac *out);

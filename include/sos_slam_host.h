@@ -1,0 +1,91 @@
+/*
+ * sos_slam_host.h -- flat C entry points of the C++ host facade (csrc/host/, libsos_host.so).
+ *
+ * The facade keeps the reference's FullSystem / FrameHessian / PointHessian / PointFrameResidual /
+ * CalibHessian / EnergyFunctional surface in C++ (csrc/host/sos_host.hpp) and drives the HIP backend
+ * through the C-ABI of sos_slam.h.  These `sosf_*` functions expose that C++ layer to C / ctypes so the
+ * parity tests and bench.py can run the reference's keyframe cycle:
+ *
+ *   FullSystem::optimize                FS/FullSystemOptimize.cpp:305-489
+ *   FullSystem::makeKeyFrame (backend part: insertFrame / insertPoint / insertResidual,
+ *   flagPointsForRemoval, marginalizePointsF, marginalizeFrame)   FS/FullSystem.cpp:783-931
+ *
+ * Status codes are those of sos_slam.h.
+ */
+#ifndef SOS_SLAM_HOST_H
+#define SOS_SLAM_HOST_H
+
+#include "sos_slam.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sosf_system sosf_system;
+
+/* FrameHessian initialisation: evalPT pose (camToWorld, R row-major 9 + t 3), state (state_zero :=
+ * state with [0..5] = 0, as setEvalPT_scaled / setStateZero leave it), exposure, keyframe id */
+typedef struct sosf_frame_init {
+  double camToWorld[12];
+  double state[10];
+  float ab_exposure;
+  int32_t frameID;
+  float frameEnergyTH;
+  int32_t pad;
+} sosf_frame_init;
+
+int sosf_create(const sos_params *params, int device, void *hip_stream, sosf_system **out);
+int sosf_destroy(sosf_system *sys);
+/* CalibHessian(): setValueScaled(fx,fy,cx,cy); value_zero = value (FS/HessianBlocks.h:453-475) */
+int sosf_set_calib(sosf_system *sys, const double *value_scaled4);
+/* new FrameHessian + makeImages (device) + ef->insertFrame (FS/FullSystem.cpp:650,814) */
+int sosf_add_frame(sosf_system *sys, const sosf_frame_init *f, const float *image);
+/* new PointHessian + ef->insertPoint (FS/FullSystem.cpp:508-510); pts[i].host = frame idx */
+int sosf_add_points(sosf_system *sys, int count, const sos_point *pts);
+/* new PointFrameResidual + ef->insertResidual (FS/FullSystem.cpp:825-828); res[i].point indexes the
+ * points in the order they were added (global running index) */
+int sosf_add_residuals(sosf_system *sys, int count, const sos_resid *res);
+/* marginalisation prior HM (dim x dim row-major), bM; dim = 4 + 8 * nFrames */
+int sosf_set_prior(sosf_system *sys, const double *HM, const double *bM);
+int sosf_get_prior(sosf_system *sys, double *HM, double *bM);
+
+/* FullSystem::optimize(mnumOptIts): returns the RMSE through *rmse */
+int sosf_optimize(sosf_system *sys, int mnumOptIts, float *rmse, int *iterations);
+/* bench support: pack + resetOOB + linearizeAll(false) + applyRes, then single loop bodies
+ * (FS/FullSystemOptimize.cpp:358-413) */
+int sosf_prepare(sosf_system *sys);
+int sosf_gn_iteration(sosf_system *sys, int iteration, int *canbreak);
+/* only the device part of one iteration with the host solve replaced by the last x (profiling) */
+int sosf_counts(sosf_system *sys, int *nFrames, int *nPoints, int *nResiduals);
+
+int sosf_get_frame(sosf_system *sys, int idx, double *camToWorld12, double *state10, double *state_zero10,
+                   float *frameEnergyTH);
+int sosf_get_calib(sosf_system *sys, double *value_scaled4);
+/* per point, in allPoints order: idepth, idepth_hessian, maxRelBaseline, numGoodResiduals (any may be NULL) */
+int sosf_get_points(sosf_system *sys, float *idepth, float *idepth_hessian, float *maxRelBaseline,
+                    int32_t *numGoodResiduals);
+/* per residual, in packing order (points -> residualsAll): state_state, isActive; removed = dropped by
+ * the final linearizeAll(true) */
+int sosf_get_residuals(sosf_system *sys, int32_t *state_state, int32_t *isActive, int32_t *removed);
+int sosf_get_lastX(sosf_system *sys, double *x);
+int sosf_get_stats(sosf_system *sys, int *resInA, int *resInL, int *resInM);
+
+/* FullSystem::flagPointsForRemoval restricted to an explicit list + ef->marginalizePointsF
+ * (FS/FullSystem.cpp:535-614, 909-912; OB/EnergyFunctional.cpp:891-936): the listed points (allPoints
+ * indices) are re-linearized, fixed (fixLinearizationF) and marginalised into HM / bM. */
+int sosf_marginalize_points(sosf_system *sys, const int32_t *pointIdx, int count);
+/* ef->dropPointsF for an explicit list (PS_DROP) */
+int sosf_drop_points(sosf_system *sys, const int32_t *pointIdx, int count);
+/* FullSystem::marginalizeFrame -> ef->marginalizeFrame (FS/FullSystemMarginalize.cpp:143-236,
+ * OB/EnergyFunctional.cpp:730-889, IMU off): frame idx must have no points left */
+int sosf_marginalize_frame(sosf_system *sys, int frameIdx);
+
+/* direct access to the underlying context / backend handles (tracker tests share the frame store) */
+sos_ctx *sosf_ctx(sosf_system *sys);
+sos_ba *sosf_ba(sosf_system *sys);
+int sosf_frame_slot(sosf_system *sys, int frameIdx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -84,6 +84,8 @@ int orc_gn_iteration(orc_window *W, int iteration, int nthreads);
 void orc_host_get_frame(orc_window *W, int frame, double *camToWorld12, double *state10,
                         double *state_zero10, float *frameEnergyTH);
 void orc_host_get_calib(orc_window *W, double *value_scaled4);
+/* yardstick only: accumulate H/b of the GN loop in fp64 instead of the reference's tiered fp32 */
+void orc_host_set_truth_mode(orc_window *W, int on);
 void orc_host_precalc(orc_window *W); /* setPrecalcValues: FS/FullSystem.cpp:1099-1107 */
 const sos_precalc *orc_host_get_precalc(orc_window *W);
 const float *orc_host_get_adHTdeltaF(orc_window *W);

@@ -66,6 +66,7 @@ def lib():
         L.orc_host_get_frame.argtypes = [vp, C.c_int, vp, vp, vp, vp]
         L.orc_host_get_calib.argtypes = [vp, vp]
         L.orc_host_precalc.argtypes = [vp]
+        L.orc_host_set_truth_mode.argtypes = [vp, C.c_int]
         for name in ("orc_host_get_precalc", "orc_host_get_adHTdeltaF", "orc_host_get_adHost",
                      "orc_host_get_adTarget", "orc_host_get_lastX"):
             getattr(L, name).restype = vp
@@ -259,6 +260,9 @@ class OracleWindow:
         Kd = np.ascontiguousarray(K, dtype=np.float64)
         self.L.orc_host_init(self.h, _p(fr), _p(Kd), _p(None if HM is None else np.ascontiguousarray(HM)),
                              _p(None if bM is None else np.ascontiguousarray(bM)))
+
+    def set_truth_mode(self, on=True):
+        self.L.orc_host_set_truth_mode(self.h, int(on))
 
     def host_precalc(self):
         self.L.orc_host_precalc(self.h)

@@ -228,6 +228,7 @@ void orc_host_get_frame(orc_window *W, int f, double *c2w, double *state, double
   if (state_zero) memcpy(state_zero, W->hf[f].state_zero, sizeof(double) * 10);
   if (th) *th = W->frameEnergyTH[f];
 }
+void orc_host_set_truth_mode(orc_window *W, int on) { W->truth_mode = on; }
 void orc_host_get_calib(orc_window *W, double *vs) { memcpy(vs, W->c_value_scaled, sizeof(double) * 4); }
 const sos_precalc *orc_host_get_precalc(orc_window *W) { return W->precalc; }
 const float *orc_host_get_adHTdeltaF(orc_window *W) { return W->adHTdeltaF; }
@@ -317,7 +318,7 @@ static void solve_system(orc_window *W, int nthreads) {
          *Hsc = (double *)malloc(sizeof(double) * dd);
   double *bA = (double *)malloc(sizeof(double) * dim), *bL = (double *)malloc(sizeof(double) * dim),
          *bsc = (double *)malloc(sizeof(double) * dim);
-  orc_accumulate(W, HA, bA, HL, bL, Hsc, bsc, &W->resInA, &W->resInL, 0, nthreads);
+  orc_accumulate(W, HA, bA, HL, bL, Hsc, bsc, &W->resInA, &W->resInL, W->truth_mode, nthreads);
   /* priors of the L stitch, OB/AccumulatedTopHessian.cpp:292-300 */
   for (int i = 0; i < 4; i++) {
     HL[(size_t)i * dim + i] += (double)W->prm.initialCalibHessian;

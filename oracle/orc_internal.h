@@ -45,6 +45,7 @@ struct orc_window {
       c_value_minus_value_zero[4];
   double *HM, *bM, *lastX;
   int resInA, resInL;
+  int truth_mode; /* 1: the GN loop accumulates H/b in fp64 (not the reference's behaviour; error yardstick) */
 };
 
 void orc_apply_res_one(orc_window *W, int r);

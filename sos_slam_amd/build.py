@@ -56,7 +56,7 @@ def build_host(force=False, verbose=False):
     if not srcs:
         return None
     if force or _stale(HOST_LIB, srcs):
-        cmd = ["g++"] + CXX_FLAGS + ["-o", HOST_LIB] + srcs + ["-ldl"]
+        cmd = ["g++"] + CXX_FLAGS + ["-o", HOST_LIB] + srcs + ["-L" + CSRC, "-lsos_slam_hip", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -1,0 +1,1195 @@
+// sos_host.cpp -- implementation of the C++ host facade (see sos_host.hpp) and its flat C entry points
+// (include/sos_slam_host.h).  Compiled with -ffp-contract=off: the fp32 host arithmetic that feeds the
+// C-ABI (precalc, adHTdeltaF, xAd) follows the same convention as the device kernels.
+#include "sos_host.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../../include/sos_slam_host.h"
+
+namespace sos {
+
+// reference defaults that are not part of sos_params (util/settings.cpp:47-77)
+static const float setting_initialRotPrior = 1e11f;
+static const float setting_initialTransPrior = 1e10f;
+static const float setting_initialAffBPrior = 1e14f;
+static const float setting_initialAffAPrior = 1e14f;
+static const float setting_thOptIterations = 1.2f;
+static const int setting_minOptIterations = 1;
+static const float setting_minIdepthH_marg = 50;
+
+// ------------------------------------------------------------------------------------------------
+void AffLight::fromToVecExposure(float exposureF, float exposureT, AffLight g2F, AffLight g2T, double *out) {
+  if (exposureF == 0 || exposureT == 0) exposureT = exposureF = 1;
+  const double a = std::exp(g2T.a - g2F.a) * exposureT / exposureF;
+  const double b = g2T.b - a * g2F.b;
+  out[0] = a;
+  out[1] = b;
+}
+
+CalibHessian::CalibHessian() {
+  for (int i = 0; i < 4; i++) value_zero[i] = value_scaled[i] = value[i] = step[i] = value_backup[i] = value_minus_value_zero[i] = 0;
+  for (int i = 0; i < 4; i++) value_scaledf[i] = value_scaledi[i] = 0;
+}
+void CalibHessian::setValue(const double *v) {  // FS/HessianBlocks.h:476-491
+  for (int i = 0; i < 4; i++) value[i] = v[i];
+  value_scaled[0] = SOS_SCALE_F * v[0];
+  value_scaled[1] = SOS_SCALE_F * v[1];
+  value_scaled[2] = SOS_SCALE_C * v[2];
+  value_scaled[3] = SOS_SCALE_C * v[3];
+  for (int i = 0; i < 4; i++) value_scaledf[i] = (float)value_scaled[i];
+  value_scaledi[0] = 1.0f / value_scaledf[0];
+  value_scaledi[1] = 1.0f / value_scaledf[1];
+  value_scaledi[2] = -value_scaledf[2] / value_scaledf[0];
+  value_scaledi[3] = -value_scaledf[3] / value_scaledf[1];
+  for (int i = 0; i < 4; i++) value_minus_value_zero[i] = value[i] - value_zero[i];
+}
+void CalibHessian::setValueScaled(const double *vs) {  // FS/HessianBlocks.h:493-506
+  for (int i = 0; i < 4; i++) value_scaled[i] = vs[i];
+  for (int i = 0; i < 4; i++) value_scaledf[i] = (float)value_scaled[i];
+  value[0] = (1.0f / SOS_SCALE_F) * vs[0];
+  value[1] = (1.0f / SOS_SCALE_F) * vs[1];
+  value[2] = (1.0f / SOS_SCALE_C) * vs[2];
+  value[3] = (1.0f / SOS_SCALE_C) * vs[3];
+  for (int i = 0; i < 4; i++) value_minus_value_zero[i] = value[i] - value_zero[i];
+  value_scaledi[0] = 1.0f / value_scaledf[0];
+  value_scaledi[1] = 1.0f / value_scaledf[1];
+  value_scaledi[2] = -value_scaledf[2] / value_scaledf[0];
+  value_scaledi[3] = -value_scaledf[3] / value_scaledf[1];
+}
+sos_calib CalibHessian::toCalib() const {
+  sos_calib c;
+  c.fxl = value_scaledf[0]; c.fyl = value_scaledf[1]; c.cxl = value_scaledf[2]; c.cyl = value_scaledf[3];
+  c.fxli = value_scaledi[0]; c.fyli = value_scaledi[1]; c.cxli = value_scaledi[2]; c.cyli = value_scaledi[3];
+  return c;
+}
+
+// ------------------------------------------------------------------------------------------------
+FrameHessian::FrameHessian() {
+  for (int i = 0; i < 10; i++) state_zero[i] = state_scaled[i] = state[i] = step[i] = state_backup[i] = 0;
+}
+FrameHessian::~FrameHessian() {
+  for (PointHessian *p : pointHessians) delete p;
+  for (PointHessian *p : pointHessiansMarginalized) delete p;
+  for (PointHessian *p : pointHessiansOut) delete p;
+}
+PointHessian::~PointHessian() {
+  for (PointFrameResidual *r : residuals) delete r;
+}
+void FrameHessian::setState(const double *s) {  // FS/HessianBlocks.h:217-230
+  for (int i = 0; i < 10; i++) state[i] = s[i];
+  for (int i = 0; i < 3; i++) state_scaled[i] = SOS_SCALE_XI_TRANS * state[i];
+  for (int i = 3; i < 6; i++) state_scaled[i] = SOS_SCALE_XI_ROT * state[i];
+  state_scaled[6] = SOS_SCALE_A * state[6];
+  state_scaled[7] = SOS_SCALE_B * state[7];
+  state_scaled[8] = SOS_SCALE_A * state[8];
+  state_scaled[9] = SOS_SCALE_B * state[9];
+  PRE_camToWorld = SE3::exp(state_scaled) * camToWorld_evalPT;
+  PRE_worldToCam = PRE_camToWorld.inverse();
+}
+void FrameHessian::setStateZero(const double *s) {  // FS/HessianBlocks.cpp:66-101 (nullspaces: dead code downstream)
+  for (int i = 0; i < 10; i++) state_zero[i] = s[i];
+}
+void FrameHessian::setEvalPT(const SE3 &c2w, const double *s) {  // FS/HessianBlocks.h:246-251
+  camToWorld_evalPT = c2w;
+  setState(s);
+  setStateZero(s);
+}
+void FrameHessian::getPrior(double *p, float modeA, float modeB) const {  // FS/HessianBlocks.h:280-302
+  for (int i = 0; i < 10; i++) p[i] = 0;
+  if (frameID == 0) {
+    p[0] = p[1] = p[2] = setting_initialTransPrior;
+    p[3] = p[4] = p[5] = setting_initialRotPrior;
+    p[6] = setting_initialAffAPrior;
+    p[7] = setting_initialAffBPrior;
+  } else {
+    p[6] = modeA < 0 ? setting_initialAffAPrior : modeA;
+    p[7] = modeB < 0 ? setting_initialAffBPrior : modeB;
+  }
+  p[8] = setting_initialAffAPrior;
+  p[9] = setting_initialAffBPrior;
+}
+
+void FrameFramePrecalc::set(const FrameHessian *host, const FrameHessian *target, const CalibHessian *HCalib) {
+  const SE3 leftToLeft_0 = target->camToWorld_evalPT.inverse() * host->camToWorld_evalPT;
+  const SE3 leftToLeft = target->PRE_worldToCam * host->PRE_camToWorld;
+  for (int i = 0; i < 9; i++) { dev.PRE_RTll_0[i] = (float)leftToLeft_0.R[i]; PRE_RTll[i] = (float)leftToLeft.R[i]; }
+  for (int i = 0; i < 3; i++) { dev.PRE_tTll_0[i] = (float)leftToLeft_0.t[i]; PRE_tTll[i] = (float)leftToLeft.t[i]; }
+  distanceLL = (float)std::sqrt(leftToLeft.t[0] * leftToLeft.t[0] + leftToLeft.t[1] * leftToLeft.t[1] + leftToLeft.t[2] * leftToLeft.t[2]);
+  // K, K^-1 = [1/fx 0 -cx/fx; 0 1/fy -cy/fy; 0 0 1] (value_scaledi)
+  const float K[9] = {HCalib->value_scaledf[0], 0, HCalib->value_scaledf[2], 0, HCalib->value_scaledf[1], HCalib->value_scaledf[3], 0, 0, 1};
+  const float Ki[9] = {HCalib->value_scaledi[0], 0, HCalib->value_scaledi[2], 0, HCalib->value_scaledi[1], HCalib->value_scaledi[3], 0, 0, 1};
+  float KR[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) KR[3 * i + j] = K[3 * i] * PRE_RTll[j] + K[3 * i + 1] * PRE_RTll[3 + j] + K[3 * i + 2] * PRE_RTll[6 + j];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      dev.PRE_KRKiTll[3 * i + j] = KR[3 * i] * Ki[j] + KR[3 * i + 1] * Ki[3 + j] + KR[3 * i + 2] * Ki[6 + j];
+      PRE_RKiTll[3 * i + j] = PRE_RTll[3 * i] * Ki[j] + PRE_RTll[3 * i + 1] * Ki[3 + j] + PRE_RTll[3 * i + 2] * Ki[6 + j];
+    }
+  for (int i = 0; i < 3; i++) dev.PRE_KtTll[i] = K[3 * i] * PRE_tTll[0] + K[3 * i + 1] * PRE_tTll[1] + K[3 * i + 2] * PRE_tTll[2];
+  double aff[2];
+  AffLight::fromToVecExposure(host->ab_exposure, target->ab_exposure, host->aff_g2l(), target->aff_g2l(), aff);
+  dev.PRE_aff_mode[0] = (float)aff[0];
+  dev.PRE_aff_mode[1] = (float)aff[1];
+  dev.PRE_b0_mode = (float)host->aff_g2l_0().b;
+  dev.pad = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+EFPoint::EFPoint(PointHessian *d, EFFrame *h, float idepthFixPrior) : data(d), host(h) {
+  priorF = d->hasDepthPrior ? idepthFixPrior * SOS_SCALE_IDEPTH * SOS_SCALE_IDEPTH : 0;  // OB/EnergyFunctionalStructs.cpp:66-72
+  deltaF = d->idepth - d->idepth_zero;
+}
+EFFrame::EFFrame(FrameHessian *d, float modeA, float modeB) : data(d) { takeData(modeA, modeB); }
+void EFFrame::takeData(float modeA, float modeB) {  // OB/EnergyFunctionalStructs.cpp:47-64
+  double p[10];
+  data->getPrior(p, modeA, modeB);
+  for (int i = 0; i < 8; i++) {
+    prior[i] = p[i];
+    delta[i] = data->state[i] - data->state_zero[i];
+    delta_prior[i] = data->state[i];  // getPriorZero() == 0
+  }
+  frameID = data->frameID;
+}
+
+EnergyFunctional::EnergyFunctional(sos_ctx *c, const sos_params &p) : ctx(c), prm(p) {
+  HM.assign(SOS_CPARS * SOS_CPARS, 0.0);
+  bM.assign(SOS_CPARS, 0.0);
+  for (int i = 0; i < 4; i++) { cDeltaF[i] = 0; cPrior[i] = 0; }
+  sos_ba_create(ctx, &prm, &ba);
+}
+EnergyFunctional::~EnergyFunctional() {
+  for (EFFrame *f : frames) {
+    for (EFPoint *p : f->points) {
+      for (EFResidual *r : p->residualsAll) { r->data->efResidual = nullptr; delete r; }
+      p->data->efPoint = nullptr;
+      delete p;
+    }
+    f->data->efFrame = nullptr;
+    delete f;
+  }
+  if (ba) sos_ba_destroy(ba);
+}
+
+void EnergyFunctional::setAdjointsF(CalibHessian *) {  // OB/EnergyFunctional.cpp:42-103
+  const int n = nFrames;
+  adHost.assign((size_t)n * n * 64, 0.0);
+  adTarget.assign((size_t)n * n * 64, 0.0);
+  for (int h = 0; h < n; h++)
+    for (int t = 0; t < n; t++) {
+      const FrameHessian *host = frames[h]->data, *target = frames[t]->data;
+      const SE3 worldToTarget = target->camToWorld_evalPT.inverse();
+      double Ad[36];
+      worldToTarget.Adj(Ad);
+      double *AH = &adHost[(size_t)(h + t * n) * 64], *AT = &adTarget[(size_t)(h + t * n) * 64];
+      for (int i = 0; i < 8; i++) AH[9 * i] = AT[9 * i] = 1;
+      for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) { AH[8 * i + j] = Ad[6 * j + i]; AT[8 * i + j] = -Ad[6 * j + i]; }
+      double aff[2];
+      AffLight::fromToVecExposure(host->ab_exposure, target->ab_exposure, host->aff_g2l_0(), target->aff_g2l_0(), aff);
+      const float a0 = (float)aff[0];
+      AT[8 * 6 + 6] = -a0; AH[8 * 6 + 6] = a0; AT[8 * 7 + 7] = -1; AH[8 * 7 + 7] = a0;
+      for (int j = 0; j < 8; j++) {
+        for (int i = 0; i < 3; i++) { AH[8 * i + j] *= SOS_SCALE_XI_TRANS; AT[8 * i + j] *= SOS_SCALE_XI_TRANS; }
+        for (int i = 3; i < 6; i++) { AH[8 * i + j] *= SOS_SCALE_XI_ROT; AT[8 * i + j] *= SOS_SCALE_XI_ROT; }
+        AH[8 * 6 + j] *= SOS_SCALE_A; AT[8 * 6 + j] *= SOS_SCALE_A;
+        AH[8 * 7 + j] *= SOS_SCALE_B; AT[8 * 7 + j] *= SOS_SCALE_B;
+      }
+    }
+  for (int i = 0; i < 4; i++) cPrior[i] = prm.initialCalibHessian;
+  adHostF.resize(adHost.size());
+  adTargetF.resize(adTarget.size());
+  for (size_t i = 0; i < adHost.size(); i++) { adHostF[i] = (float)adHost[i]; adTargetF[i] = (float)adTarget[i]; }
+  EFAdjointsValid = true;
+}
+
+void EnergyFunctional::setDeltaF(CalibHessian *HCalib) {  // OB/EnergyFunctional.cpp:163-194
+  const int n = nFrames;
+  adHTdeltaF.assign((size_t)n * n * 8, 0.f);
+  for (int h = 0; h < n; h++)
+    for (int t = 0; t < n; t++) {
+      const size_t idx = (size_t)(h + t * n);
+      float dh[8], dt[8];
+      for (int i = 0; i < 8; i++) {
+        dh[i] = (float)(frames[h]->data->state[i] - frames[h]->data->state_zero[i]);
+        dt[i] = (float)(frames[t]->data->state[i] - frames[t]->data->state_zero[i]);
+      }
+      for (int j = 0; j < 8; j++) {
+        float s1 = 0, s2 = 0;
+        for (int i = 0; i < 8; i++) { s1 += dh[i] * adHostF[64 * idx + 8 * i + j]; s2 += dt[i] * adTargetF[64 * idx + 8 * i + j]; }
+        adHTdeltaF[8 * idx + j] = s1 + s2;
+      }
+    }
+  for (int i = 0; i < 4; i++) cDeltaF[i] = (float)HCalib->value_minus_value_zero[i];
+  for (EFFrame *f : frames) {
+    for (int i = 0; i < 8; i++) {
+      f->delta[i] = f->data->state[i] - f->data->state_zero[i];
+      f->delta_prior[i] = f->data->state[i];
+    }
+    for (EFPoint *p : f->points) p->deltaF = p->data->idepth - p->data->idepth_zero;
+  }
+  EFDeltaValid = true;
+}
+
+EFResidual *EnergyFunctional::insertResidual(PointFrameResidual *r) {  // OB/EnergyFunctional.cpp:644-656
+  EFResidual *efr = new EFResidual(r, r->point->efPoint, r->host->efFrame, r->target->efFrame);
+  efr->idxInAll = (int)r->point->efPoint->residualsAll.size();
+  r->point->efPoint->residualsAll.push_back(efr);
+  connectivityMap[(((uint64_t)efr->host->frameID) << 32) + ((uint64_t)efr->target->frameID)].first++;
+  nResiduals++;
+  r->efResidual = efr;
+  packDirty = true;
+  return efr;
+}
+
+EFFrame *EnergyFunctional::insertFrame(FrameHessian *fh, CalibHessian *HCalib) {  // :658-695 (IMU off)
+  EFFrame *eff = new EFFrame(fh, prm.affineOptModeA, prm.affineOptModeB);
+  eff->idx = (int)frames.size();
+  frames.push_back(eff);
+  nFrames++;
+  fh->efFrame = eff;
+  const int ndim = SOS_CPARS + 8 * nFrames, odim = ndim - 8;
+  MatXX HMn((size_t)ndim * ndim, 0.0);
+  VecX bMn(ndim, 0.0);
+  for (int i = 0; i < odim; i++) {
+    for (int j = 0; j < odim; j++) HMn[(size_t)i * ndim + j] = HM[(size_t)i * odim + j];
+    bMn[i] = bM[i];
+  }
+  HM.swap(HMn);
+  bM.swap(bMn);
+  EFIndicesValid = EFAdjointsValid = EFDeltaValid = false;
+  setAdjointsF(HCalib);
+  makeIDX();
+  for (EFFrame *fh2 : frames) {
+    connectivityMap[(((uint64_t)eff->frameID) << 32) + ((uint64_t)fh2->frameID)] = std::make_pair(0, 0);
+    if (fh2 != eff) connectivityMap[(((uint64_t)fh2->frameID) << 32) + ((uint64_t)eff->frameID)] = std::make_pair(0, 0);
+  }
+  packDirty = true;
+  return eff;
+}
+
+EFPoint *EnergyFunctional::insertPoint(PointHessian *ph) {  // :697-708
+  EFPoint *efp = new EFPoint(ph, ph->host->efFrame, prm.idepthFixPrior);
+  efp->idxInPoints = (int)ph->host->efFrame->points.size();
+  ph->host->efFrame->points.push_back(efp);
+  nPoints++;
+  ph->efPoint = efp;
+  EFIndicesValid = false;
+  packDirty = true;
+  return efp;
+}
+
+void EnergyFunctional::dropResidual(EFResidual *r) {  // :710-728
+  EFPoint *p = r->point;
+  p->residualsAll[r->idxInAll] = p->residualsAll.back();
+  p->residualsAll[r->idxInAll]->idxInAll = r->idxInAll;
+  p->residualsAll.pop_back();
+  connectivityMap[(((uint64_t)r->host->frameID) << 32) + ((uint64_t)r->target->frameID)].first--;
+  nResiduals--;
+  r->data->efResidual = nullptr;
+  delete r;
+  packDirty = true;
+}
+
+void EnergyFunctional::removePoint(EFPoint *p) {  // :954-969
+  for (EFResidual *r : std::vector<EFResidual *>(p->residualsAll)) dropResidual(r);
+  EFFrame *h = p->host;
+  h->points[p->idxInPoints] = h->points.back();
+  h->points[p->idxInPoints]->idxInPoints = p->idxInPoints;
+  h->points.pop_back();
+  nPoints--;
+  p->data->efPoint = nullptr;
+  EFIndicesValid = false;
+  packDirty = true;
+  delete p;
+}
+
+void EnergyFunctional::makeIDX() {  // :1186-1202
+  for (size_t i = 0; i < frames.size(); i++) frames[i]->idx = (int)i;
+  allPoints.clear();
+  for (EFFrame *f : frames)
+    for (EFPoint *p : f->points) {
+      allPoints.push_back(p);
+      for (EFResidual *r : p->residualsAll) {
+        r->hostIDX = r->host->idx;
+        r->targetIDX = r->target->idx;
+      }
+    }
+  EFIndicesValid = true;
+}
+
+VecX EnergyFunctional::getStitchedDeltaF() const {  // :1204-1210
+  VecX d(SOS_CPARS + nFrames * 8);
+  for (int i = 0; i < 4; i++) d[i] = (double)cDeltaF[i];
+  for (int h = 0; h < nFrames; h++)
+    for (int i = 0; i < 8; i++) d[SOS_CPARS + 8 * h + i] = frames[h]->delta[i];
+  return d;
+}
+
+int EnergyFunctional::packWindow() {
+  if (!packDirty) return SOS_OK;
+  makeIDX();
+  const int n = nFrames;
+  std::vector<int32_t> slots(n);
+  for (int i = 0; i < n; i++) slots[i] = frames[i]->data->slot;
+  std::vector<sos_point> pts(allPoints.size());
+  std::vector<sos_resid> res;
+  allResiduals.clear();
+  for (size_t k = 0; k < allPoints.size(); k++) {
+    EFPoint *p = allPoints[k];
+    PointHessian *ph = p->data;
+    ph->packIdx = (int)k;
+    sos_point &o = pts[k];
+    o.u = ph->u; o.v = ph->v;
+    o.idepth_scaled = ph->idepth_scaled;
+    o.idepth_zero_scaled = ph->idepth_zero_scaled;
+    std::memcpy(o.color, ph->color, sizeof(o.color));
+    std::memcpy(o.weights, ph->weights, sizeof(o.weights));
+    o.priorF = p->priorF;
+    o.deltaF = p->deltaF;
+    o.host = p->host->idx;
+    o.pad = 0;
+    for (EFResidual *r : p->residualsAll) {
+      sos_resid q;
+      q.point = (int)k;
+      q.host = r->hostIDX;
+      q.target = r->targetIDX;
+      q.flags = (r->isActive() ? SOS_RF_ACTIVE : 0u) | (r->isLinearized ? SOS_RF_LINEARIZED : 0u) | (r->data->isNew ? SOS_RF_ISNEW : 0u);
+      q.state_state = (int)r->data->state_state;
+      q.state_energy = (float)r->data->state_energy;
+      r->data->packIdx = (int)res.size();
+      res.push_back(q);
+      allResiduals.push_back(r);
+    }
+  }
+  int rc = sos_ba_set_window(ba, n, slots.data(), (int)pts.size(), pts.data(), (int)res.size(), res.data(), nullptr, nullptr);
+  if (rc == SOS_OK) packDirty = false;
+  pointStep.assign(pts.size(), 0.f);
+  return rc;
+}
+
+int EnergyFunctional::pushState(CalibHessian *HCalib, bool adjoints) {
+  const int n = nFrames;
+  std::vector<sos_precalc> pc((size_t)n * n);
+  for (int h = 0; h < n; h++)
+    for (int t = 0; t < n; t++) pc[(size_t)(h + n * t)] = frames[h]->data->targetPrecalc[t].dev;
+  std::vector<float> id(allPoints.size()), idz(allPoints.size()), dl(allPoints.size());
+  for (size_t k = 0; k < allPoints.size(); k++) {
+    id[k] = allPoints[k]->data->idepth_scaled;
+    idz[k] = allPoints[k]->data->idepth_zero_scaled;
+    dl[k] = allPoints[k]->deltaF;
+  }
+  const sos_calib c = HCalib->toCalib();
+  return sos_ba_set_state(ba, &c, pc.data(), adHTdeltaF.data(), cDeltaF, adjoints ? adHost.data() : nullptr,
+                          adjoints ? adTarget.data() : nullptr, id.data(), idz.data(), dl.data());
+}
+
+void EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib) {  // :1029-1184, IMU off
+  lambda = 1e-5;
+  const int n = nFrames, dim = SOS_CPARS + 8 * n;
+  const size_t dd = (size_t)dim * dim;
+  MatXX HA(dd), HL(dd), Hsc(dd);
+  VecX bA(dim), bL(dim), bsc(dim);
+  sos_ba_accumulate(ba, HA.data(), bA.data(), HL.data(), bL.data(), Hsc.data(), bsc.data(), &resInA, &resInL);
+  // priors of the L stitch (usePrior = true), OB/AccumulatedTopHessian.cpp:292-300
+  for (int i = 0; i < 4; i++) {
+    HL[(size_t)i * dim + i] += cPrior[i];
+    bL[i] += cPrior[i] * (double)cDeltaF[i];
+  }
+  for (int h = 0; h < n; h++)
+    for (int i = 0; i < 8; i++) {
+      HL[(size_t)(4 + 8 * h + i) * dim + 4 + 8 * h + i] += frames[h]->prior[i];
+      bL[4 + 8 * h + i] += frames[h]->prior[i] * frames[h]->delta_prior[i];
+    }
+  MatXX H(dd);
+  VecX b(dim);
+  for (size_t i = 0; i < dd; i++) H[i] = HL[i] + HA[i];
+  for (int i = 0; i < dim; i++) b[i] = bL[i] + bA[i];
+  const VecX delta = getStitchedDeltaF();
+  for (int i = 0; i < dim; i++) {
+    double s = bM[i];
+    for (int j = 0; j < dim; j++) s += HM[(size_t)i * dim + j] * delta[j];
+    b[i] += s;
+  }
+  for (size_t i = 0; i < dd; i++) H[i] += HM[i];
+  for (int i = 0; i < dim; i++) H[(size_t)i * dim + i] *= (1 + lambda);
+  const double isc = 1.0f / (1 + lambda);
+  for (size_t i = 0; i < dd; i++) H[i] -= Hsc[i] * isc;
+  for (int i = 0; i < dim; i++) b[i] -= bsc[i];
+  VecX S(dim), x;
+  for (int i = 0; i < dim; i++) S[i] = 1.0 / std::sqrt(H[(size_t)i * dim + i] + 10);
+  for (int i = 0; i < dim; i++) {
+    for (int j = 0; j < dim; j++) H[(size_t)i * dim + j] *= S[i] * S[j];
+    b[i] *= S[i];
+  }
+  ldlt_solve(H, b, x, dim);
+  for (int i = 0; i < dim; i++) x[i] *= S[i];
+  lastX = x;
+  // resubstituteF_MT, :496-524
+  for (int i = 0; i < 4; i++) HCalib->step[i] = -x[i];
+  for (EFFrame *h : frames) {
+    for (int i = 0; i < 8; i++) h->data->step[i] = -x[SOS_CPARS + 8 * h->idx + i];
+    h->data->step[8] = h->data->step[9] = 0;
+  }
+  pointStep.resize(allPoints.size());
+  sos_ba_resubstitute(ba, x.data(), pointStep.data());
+  for (size_t k = 0; k < allPoints.size(); k++) allPoints[k]->data->step = pointStep[k];
+}
+
+double EnergyFunctional::calcMEnergyF() {  // :553-561
+  const VecX delta = getStitchedDeltaF();
+  const int dim = (int)delta.size();
+  double e = 0;
+  for (int i = 0; i < dim; i++) {
+    double s = 2 * bM[i];
+    for (int j = 0; j < dim; j++) s += HM[(size_t)i * dim + j] * delta[j];
+    e += delta[i] * s;
+  }
+  return e;
+}
+
+double EnergyFunctional::calcLEnergyF_MT() {  // :626-642
+  double E = 0;
+  for (EFFrame *f : frames)
+    for (int i = 0; i < 8; i++) E += f->delta_prior[i] * f->prior[i] * f->delta_prior[i];
+  float e4 = 0;
+  for (int i = 0; i < 4; i++) e4 += cDeltaF[i] * (float)cPrior[i] * cDeltaF[i];
+  E += e4;
+  double Ed = 0;
+  sos_ba_calc_lenergy(ba, &Ed);
+  return E + Ed;
+}
+
+void EnergyFunctional::marginalizePointsF() {  // :891-936, IMU off
+  allPointsToMarg.clear();
+  std::vector<int32_t> idx;
+  for (EFFrame *f : frames)
+    for (EFPoint *p : f->points)
+      if (p->stateFlag == PS_MARGINALIZE) {
+        p->priorF *= prm.idepthFixPriorMargFac;
+        for (EFResidual *r : p->residualsAll)
+          if (r->isActive()) connectivityMap[(((uint64_t)r->host->frameID) << 32) + ((uint64_t)r->target->frameID)].second++;
+        allPointsToMarg.push_back(p);
+        idx.push_back(p->data->packIdx);
+      }
+  const int dim = SOS_CPARS + 8 * nFrames;
+  const size_t dd = (size_t)dim * dim;
+  MatXX M(dd, 0.0), Msc(dd, 0.0);
+  VecX Mb(dim, 0.0), Mbsc(dim, 0.0);
+  int rin = 0;
+  if (!idx.empty()) {
+    std::vector<float> pr(idx.size());  // priorF changed above: refresh the device copy
+    for (size_t k = 0; k < idx.size(); k++) pr[k] = allPointsToMarg[k]->priorF;
+    sos_ba_update_point_priors(ba, idx.data(), pr.data(), (int)idx.size());
+    sos_ba_accumulate_marg(ba, idx.data(), (int)idx.size(), M.data(), Mb.data(), Msc.data(), Mbsc.data(), &rin);
+  }
+  for (EFPoint *p : allPointsToMarg) removePoint(p);
+  resInM += rin;
+  for (size_t i = 0; i < dd; i++) HM[i] += prm.margWeightFac * (M[i] - Msc[i]);
+  for (int i = 0; i < dim; i++) bM[i] += prm.margWeightFac * (Mb[i] - Mbsc[i]);
+  EFIndicesValid = false;
+  makeIDX();
+}
+
+void EnergyFunctional::dropPointsF() {  // :938-952
+  for (EFFrame *f : frames)
+    for (int i = 0; i < (int)f->points.size(); i++) {
+      EFPoint *p = f->points[i];
+      if (p->stateFlag == PS_DROP) {
+        removePoint(p);
+        i--;
+      }
+    }
+  EFIndicesValid = false;
+  makeIDX();
+}
+
+void EnergyFunctional::marginalizeFrame(EFFrame *fh) {  // :730-889, IMU off
+  const int step = 8, odim = SOS_CPARS + nFrames * step, ndim = odim - step;
+  const int io = SOS_CPARS + fh->idx * step;
+  // move the frame's block to the end (row/column permutation)
+  std::vector<int> perm;
+  for (int i = 0; i < odim; i++)
+    if (i < io || i >= io + step) perm.push_back(i);
+  for (int i = 0; i < step; i++) perm.push_back(io + i);
+  MatXX Hp((size_t)odim * odim);
+  VecX bp(odim);
+  for (int i = 0; i < odim; i++) {
+    bp[i] = bM[perm[i]];
+    for (int j = 0; j < odim; j++) Hp[(size_t)i * odim + j] = HM[(size_t)perm[i] * odim + perm[j]];
+  }
+  // add the prior here (instead of to the active part)
+  for (int i = 0; i < 8; i++) {
+    Hp[(size_t)(ndim + i) * odim + ndim + i] += fh->prior[i];
+    bp[ndim + i] += fh->prior[i] * fh->delta_prior[i];
+  }
+  VecX SVec(odim), SVecI(odim);
+  for (int i = 0; i < odim; i++) {
+    SVec[i] = std::sqrt(std::fabs(Hp[(size_t)i * odim + i]) + 10);
+    SVecI[i] = 1.0 / SVec[i];
+  }
+  for (int i = 0; i < odim; i++) {
+    for (int j = 0; j < odim; j++) Hp[(size_t)i * odim + j] *= SVecI[i] * SVecI[j];
+    bp[i] *= SVecI[i];
+  }
+  std::vector<double> hpi((size_t)step * step), hpinv;
+  for (int i = 0; i < step; i++)
+    for (int j = 0; j < step; j++) hpi[(size_t)i * step + j] = Hp[(size_t)(ndim + i) * odim + ndim + j];
+  mat_inverse(hpi, hpinv, step);
+  // bli = bottomLeft^T * hpi ; top -= bli * bottomLeft
+  MatXX bli((size_t)ndim * step);
+  for (int i = 0; i < ndim; i++)
+    for (int j = 0; j < step; j++) {
+      double s = 0;
+      for (int k = 0; k < step; k++) s += Hp[(size_t)(ndim + k) * odim + i] * hpinv[(size_t)k * step + j];
+      bli[(size_t)i * step + j] = s;
+    }
+  for (int i = 0; i < ndim; i++) {
+    for (int j = 0; j < ndim; j++) {
+      double s = 0;
+      for (int k = 0; k < step; k++) s += bli[(size_t)i * step + k] * Hp[(size_t)(ndim + k) * odim + j];
+      Hp[(size_t)i * odim + j] -= s;
+    }
+    double s = 0;
+    for (int k = 0; k < step; k++) s += bli[(size_t)i * step + k] * bp[ndim + k];
+    bp[i] -= s;
+  }
+  MatXX HMn((size_t)ndim * ndim);
+  VecX bMn(ndim);
+  for (int i = 0; i < ndim; i++) {
+    for (int j = 0; j < ndim; j++) HMn[(size_t)i * ndim + j] = Hp[(size_t)i * odim + j] * SVec[i] * SVec[j];
+    bMn[i] = bp[i] * SVec[i];
+  }
+  HM.assign((size_t)ndim * ndim, 0.0);
+  for (int i = 0; i < ndim; i++)
+    for (int j = 0; j < ndim; j++) HM[(size_t)i * ndim + j] = 0.5 * (HMn[(size_t)i * ndim + j] + HMn[(size_t)j * ndim + i]);
+  bM = bMn;
+  for (unsigned i = fh->idx; i + 1 < frames.size(); i++) {
+    frames[i] = frames[i + 1];
+    frames[i]->idx = (int)i;
+  }
+  frames.pop_back();
+  nFrames--;
+  fh->data->efFrame = nullptr;
+  EFIndicesValid = EFAdjointsValid = EFDeltaValid = false;
+  makeIDX();
+  packDirty = true;
+  delete fh;
+}
+
+// ================================================================================================
+// FullSystem
+// ================================================================================================
+FullSystem::FullSystem(const sos_params &p, int device, void *stream) : prm(p) {
+  std::memset(slotUsed, 0, sizeof(slotUsed));
+  lastError = sos_ctx_create(device, stream, p.w, p.h, &ctx);
+  if (lastError != SOS_OK) {
+    ctx = nullptr;
+    return;
+  }
+  ef = new EnergyFunctional(ctx, prm);
+  if (!ef->ba) {
+    delete ef;
+    ef = nullptr;
+  }
+}
+FullSystem::~FullSystem() {
+  delete ef;
+  for (FrameHessian *f : frameHessians) delete f;
+  if (ctx) sos_ctx_destroy(ctx);
+}
+
+FrameHessian *FullSystem::addFrame(const double *c2w, const double *state10, float ab_exposure, int frameID,
+                                   float frameEnergyTH, const float *image) {
+  int slot = -1;
+  for (int s = 0; s < SOS_MAX_SLOTS; s++)
+    if (!slotUsed[s]) { slot = s; break; }
+  if (slot < 0) return nullptr;
+  if (sos_make_pyramid(ctx, slot, image, nullptr) != SOS_OK) return nullptr;  // makeImages, FS/FullSystem.cpp:650
+  slotUsed[slot] = true;
+  FrameHessian *fh = new FrameHessian();
+  fh->slot = slot;
+  fh->ab_exposure = ab_exposure;
+  fh->frameID = frameID;
+  fh->frameEnergyTH = frameEnergyTH;
+  fh->camToWorld_evalPT = SE3::from12(c2w);
+  double sz[10];
+  for (int i = 0; i < 10; i++) sz[i] = i < 6 ? 0.0 : state10[i];
+  fh->setStateZero(sz);
+  fh->setState(state10);
+  fh->idx = (int)frameHessians.size();
+  frameHessians.push_back(fh);
+  ef->insertFrame(fh, &HCalib);  // FS/FullSystem.cpp:814
+  setPrecalcValues();            // :816
+  return fh;
+}
+
+PointHessian *FullSystem::addPoint(const sos_point &p) {
+  if (p.host < 0 || p.host >= (int)frameHessians.size()) return nullptr;
+  PointHessian *ph = new PointHessian();
+  ph->host = frameHessians[p.host];
+  ph->u = p.u; ph->v = p.v;
+  std::memcpy(ph->color, p.color, sizeof(ph->color));
+  std::memcpy(ph->weights, p.weights, sizeof(ph->weights));
+  ph->setIdepth(p.idepth_scaled * (1.0f / SOS_SCALE_IDEPTH));
+  ph->setIdepthZero(p.idepth_zero_scaled * (1.0f / SOS_SCALE_IDEPTH));
+  ph->hasDepthPrior = p.priorF > 0;
+  ph->lastResiduals[0] = std::make_pair((PointFrameResidual *)nullptr, OOB);
+  ph->lastResiduals[1] = std::make_pair((PointFrameResidual *)nullptr, OOB);
+  ph->host->pointHessians.push_back(ph);
+  ph->userIdx = (int)userPoints.size();
+  userPoints.push_back(ph);
+  ef->insertPoint(ph);
+  return ph;
+}
+
+PointFrameResidual *FullSystem::addResidual(PointHessian *ph, FrameHessian *target, const sos_resid &q) {
+  PointFrameResidual *r = new PointFrameResidual();
+  r->point = ph;
+  r->host = ph->host;
+  r->target = target;
+  r->state_state = (ResState)q.state_state;
+  r->state_energy = q.state_energy;
+  r->isNew = (q.flags & SOS_RF_ISNEW) != 0;
+  ph->residuals.push_back(r);
+  EFResidual *e = ef->insertResidual(r);
+  e->isActiveAndIsGoodNEW = (q.flags & SOS_RF_ACTIVE) != 0;
+  // lastResiduals: [0] = residual to the newest frame, [1] = the one before (FS/FullSystem.cpp:826-828)
+  ph->lastResiduals[1] = ph->lastResiduals[0];
+  ph->lastResiduals[0] = std::make_pair(r, IN);
+  return r;
+}
+
+void FullSystem::setPrecalcValues() {  // FS/FullSystem.cpp:1099-1107
+  for (FrameHessian *fh : frameHessians) {
+    fh->targetPrecalc.resize(frameHessians.size());
+    for (size_t i = 0; i < frameHessians.size(); i++) fh->targetPrecalc[i].set(fh, frameHessians[i], &HCalib);
+  }
+  ef->setDeltaF(&HCalib);
+}
+
+void FullSystem::setNewFrameEnergyTH() {  // FS/FullSystemOptimize.cpp:84-124
+  std::vector<float> allResVec;
+  allResVec.reserve(activeResiduals.size());
+  FrameHessian *newFrame = frameHessians.back();
+  for (PointFrameResidual *r : activeResiduals) {
+    const float e = h_newEnergyWO[r->packIdx];
+    if (e >= 0 && r->target == newFrame) allResVec.push_back(e);
+  }
+  if (allResVec.empty()) {
+    newFrame->frameEnergyTH = 12 * 12 * SOS_PATTERN_NUM;
+    return;
+  }
+  const int nthIdx = (int)(prm.frameEnergyTHN * allResVec.size());
+  std::nth_element(allResVec.begin(), allResVec.begin() + nthIdx, allResVec.end());
+  const float nthElement = sqrtf(allResVec[nthIdx]);
+  newFrame->frameEnergyTH = nthElement * prm.frameEnergyTHFacMedian;
+  newFrame->frameEnergyTH = 26.0f * prm.frameEnergyTHConstWeight + newFrame->frameEnergyTH * (1 - prm.frameEnergyTHConstWeight);
+  newFrame->frameEnergyTH = newFrame->frameEnergyTH * newFrame->frameEnergyTH;
+  newFrame->frameEnergyTH *= prm.overallEnergyTHWeight * prm.overallEnergyTHWeight;
+}
+
+double FullSystem::linearizeAll(bool fix) {  // FS/FullSystemOptimize.cpp:125-182
+  const int n = (int)frameHessians.size();
+  std::vector<float> th(n);
+  for (int i = 0; i < n; i++) th[i] = frameHessians[i]->frameEnergyTH;
+  const size_t R = ef->allResiduals.size();
+  h_newEnergyWO.resize(R);
+  double E = 0;
+  if (!fix) {
+    lastError = sos_ba_linearize(ef->ba, th.data(), &E, nullptr, nullptr, h_newEnergyWO.data(), nullptr);
+    setNewFrameEnergyTH();
+    return E;
+  }
+  h_newState.resize(R);
+  h_newEnergy.resize(R);
+  h_center.resize(3 * R);
+  lastError = sos_ba_linearize(ef->ba, th.data(), &E, h_newState.data(), h_newEnergy.data(), h_newEnergyWO.data(), h_center.data());
+  sos_ba_apply_res(ef->ba);  // r->applyRes(true) inside the reductor, :51
+  std::vector<uint32_t> flags(R);
+  std::vector<int32_t> st(R);
+  std::vector<float> en(R);
+  sos_ba_get_residual_flags(ef->ba, flags.data(), st.data(), en.data());
+  std::vector<PointFrameResidual *> toRemove;
+  for (PointFrameResidual *r : activeResiduals) {
+    const int k = r->packIdx;
+    r->state_NewState = (ResState)h_newState[k];
+    r->state_NewEnergy = h_newEnergy[k];
+    r->state_NewEnergyWithOutlier = h_newEnergyWO[k];
+    if (r->state_NewState != OOB || st[k] != OOB) {
+      // centerProjectedTo is written whenever the centre projection succeeded
+    }
+    r->centerProjectedTo[0] = h_center[3 * k];
+    r->centerProjectedTo[1] = h_center[3 * k + 1];
+    r->centerProjectedTo[2] = h_center[3 * k + 2];
+    r->state_state = (ResState)st[k];
+    r->state_energy = en[k];
+    r->efResidual->isActiveAndIsGoodNEW = (flags[k] & SOS_RF_ACTIVE) != 0;
+    if (r->efResidual->isActive()) {
+      if (r->isNew) {  // :55-71
+        PointHessian *p = r->point;
+        const sos_precalc &pc = r->host->targetPrecalc[r->target->idx].dev;
+        const float *K = pc.PRE_KRKiTll, *Kt = pc.PRE_KtTll;
+        const float inf0 = K[0] * p->u + K[1] * p->v + K[2], inf1 = K[3] * p->u + K[4] * p->v + K[5], inf2 = K[6] * p->u + K[7] * p->v + K[8];
+        const float q0 = inf0 + Kt[0] * p->idepth_scaled, q1 = inf1 + Kt[1] * p->idepth_scaled, q2 = inf2 + Kt[2] * p->idepth_scaled;
+        const float dx = inf0 / inf2 - q0 / q2, dy = inf1 / inf2 - q1 / q2;
+        const float relBS = (float)(0.01 * sqrtf(dx * dx + dy * dy));
+        if (relBS > p->maxRelBaseline) p->maxRelBaseline = relBS;
+        p->numGoodResiduals++;
+      }
+    } else {
+      toRemove.push_back(r);
+    }
+  }
+  setNewFrameEnergyTH();
+  for (PointFrameResidual *r : activeResiduals) {  // :150-156
+    PointHessian *ph = r->point;
+    if (ph->lastResiduals[0].first == r) ph->lastResiduals[0].second = r->state_state;
+    else if (ph->lastResiduals[1].first == r) ph->lastResiduals[1].second = r->state_state;
+  }
+  for (PointFrameResidual *r : toRemove) {  // :158-176
+    PointHessian *ph = r->point;
+    if (ph->lastResiduals[0].first == r) ph->lastResiduals[0].first = nullptr;
+    else if (ph->lastResiduals[1].first == r) ph->lastResiduals[1].first = nullptr;
+    for (size_t k = 0; k < ph->residuals.size(); k++)
+      if (ph->residuals[k] == r) {
+        ef->dropResidual(r->efResidual);
+        ph->residuals[k] = ph->residuals.back();
+        ph->residuals.pop_back();
+        delete r;
+        break;
+      }
+  }
+  return E;
+}
+
+void FullSystem::applyRes() { sos_ba_apply_res(ef->ba); }
+
+void FullSystem::backupState() {  // :260-269
+  std::memcpy(HCalib.value_backup, HCalib.value, sizeof(HCalib.value));
+  for (FrameHessian *fh : frameHessians) {
+    std::memcpy(fh->state_backup, fh->state, sizeof(fh->state));
+    for (PointHessian *ph : fh->pointHessians) ph->idepth_backup = ph->idepth;
+  }
+}
+
+bool FullSystem::doStepFromBackup(float stepfacC, float stepfacT, float stepfacR, float stepfacA, float stepfacD) {
+  double pstepfac[10];
+  for (int i = 0; i < 3; i++) pstepfac[i] = stepfacT;
+  for (int i = 3; i < 6; i++) pstepfac[i] = stepfacR;
+  for (int i = 6; i < 10; i++) pstepfac[i] = stepfacA;
+  float sumA = 0, sumB = 0, sumT = 0, sumR = 0, sumID = 0, numID = 0, sumNID = 0;
+  double v[4];
+  for (int i = 0; i < 4; i++) v[i] = HCalib.value_backup[i] + stepfacC * HCalib.step[i];
+  HCalib.setValue(v);
+  for (FrameHessian *fh : frameHessians) {
+    double s[10];
+    for (int i = 0; i < 10; i++) s[i] = fh->state_backup[i] + pstepfac[i] * fh->step[i];
+    fh->setState(s);
+    sumA += fh->step[6] * fh->step[6];
+    sumB += fh->step[7] * fh->step[7];
+    sumT += fh->step[0] * fh->step[0] + fh->step[1] * fh->step[1] + fh->step[2] * fh->step[2];
+    sumR += fh->step[3] * fh->step[3] + fh->step[4] * fh->step[4] + fh->step[5] * fh->step[5];
+    for (PointHessian *ph : fh->pointHessians) {
+      ph->setIdepth(ph->idepth_backup + stepfacD * ph->step);
+      sumID += ph->step * ph->step;
+      sumNID += fabsf(ph->idepth_backup);
+      numID++;
+      ph->setIdepthZero(ph->idepth_backup + stepfacD * ph->step);
+    }
+  }
+  const float nf = (float)frameHessians.size();
+  sumA /= nf; sumB /= nf; sumR /= nf; sumT /= nf;
+  sumID /= numID; sumNID /= numID;
+  (void)sumID;
+  ef->EFDeltaValid = false;
+  setPrecalcValues();
+  return sqrtf(sumA) < 0.0005 * setting_thOptIterations && sqrtf(sumB) < 0.00005 * setting_thOptIterations &&
+         sqrtf(sumR) < 0.00005 * setting_thOptIterations && sqrtf(sumT) * sumNID < 0.00005 * setting_thOptIterations;
+}
+
+void FullSystem::solveSystem(int iteration, double lambda) { ef->solveSystemF(iteration, lambda, &HCalib); }
+
+int FullSystem::prepare() {  // FS/FullSystemOptimize.cpp:316-344
+  activeResiduals.clear();
+  for (FrameHessian *fh : frameHessians)
+    for (PointHessian *ph : fh->pointHessians)
+      for (PointFrameResidual *r : ph->residuals)
+        if (!r->efResidual->isLinearized) {
+          activeResiduals.push_back(r);
+          r->resetOOB();
+        }
+  int rc = ef->packWindow();
+  if (rc) return rc;
+  setPrecalcValues();
+  rc = ef->pushState(&HCalib, true);
+  if (rc) return rc;
+  sos_ba_reset_oob(ef->ba);
+  linearizeAll(false);
+  applyRes();
+  return lastError;
+}
+
+bool FullSystem::gnIteration(int iteration) {  // :358-413 with setting_forceAceptStep
+  backupState();
+  solveSystem(iteration, 1e-1);
+  const bool canbreak = doStepFromBackup(1, 1, 1, 1, 1);
+  ef->pushState(&HCalib, false);
+  linearizeAll(false);
+  applyRes();
+  return canbreak;
+}
+
+float FullSystem::optimize(int mnumOptIts, int *iterations) {
+  if (iterations) *iterations = 0;
+  if (frameHessians.size() < 2) return 0;
+  if (frameHessians.size() < 3) mnumOptIts = 20;
+  if (frameHessians.size() < 4) mnumOptIts = 15;
+  if (prepare() != SOS_OK) return NAN;
+  int it = 0;
+  for (int iteration = 0; iteration < mnumOptIts; iteration++) {
+    const bool canbreak = gnIteration(iteration);
+    it++;
+    if (canbreak && iteration >= setting_minOptIterations) break;
+  }
+  if (iterations) *iterations = it;
+  // :415-425
+  FrameHessian *last = frameHessians.back();
+  double newStateZero[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  newStateZero[6] = last->state[6];
+  newStateZero[7] = last->state[7];
+  last->setEvalPT(last->PRE_camToWorld, newStateZero);
+  ef->EFDeltaValid = ef->EFAdjointsValid = false;
+  ef->setAdjointsF(&HCalib);
+  setPrecalcValues();
+  ef->pushState(&HCalib, true);
+  const double lastEnergy = linearizeAll(true);
+  if (!std::isfinite(lastEnergy)) isLost = true;
+  // point results the viewer / tracker read: idepth_hessian
+  if (!ef->allPoints.empty()) {
+    std::vector<float> idh(ef->allPoints.size());
+    // the snapshot order is still the one of the last pack: graph edits above only dropped residuals
+    sos_ba_get_point_hessian(ef->ba, idh.data(), nullptr, nullptr);
+    for (FrameHessian *fh : frameHessians)
+      for (PointHessian *ph : fh->pointHessians)
+        if (ph->packIdx >= 0 && ph->packIdx < (int)idh.size()) ph->idepth_hessian = idh[ph->packIdx];
+  }
+  return sqrtf((float)(lastEnergy / (SOS_PATTERN_NUM * ef->resInA)));
+}
+
+void FullSystem::removeOutliers() {  // FS/FullSystemOptimize.cpp:507-526
+  for (FrameHessian *fh : frameHessians)
+    for (unsigned i = 0; i < fh->pointHessians.size(); i++) {
+      PointHessian *ph = fh->pointHessians[i];
+      if (ph->residuals.empty()) {
+        fh->pointHessiansOut.push_back(ph);
+        ph->efPoint->stateFlag = PS_DROP;
+        fh->pointHessians[i] = fh->pointHessians.back();
+        fh->pointHessians.pop_back();
+        i--;
+      }
+    }
+  ef->dropPointsF();
+}
+
+// flagPointsForRemoval for an explicit set (FS/FullSystem.cpp:566-601) followed by
+// ef->marginalizePointsF (FS/FullSystem.cpp:912)
+int FullSystem::marginalizePoints(const std::vector<PointHessian *> &pts) {
+  int rc = ef->packWindow();
+  if (rc) return rc;
+  setPrecalcValues();
+  rc = ef->pushState(&HCalib, true);
+  if (rc) return rc;
+  // r->resetOOB(); r->linearize(); r->applyRes(true) for the residuals of the listed points.  The
+  // device linearizes every active residual at the current state, which leaves all the others unchanged
+  // in value (same state, same thresholds) -- only the listed ones are reset first.
+  const int n = (int)frameHessians.size();
+  std::vector<float> th(n);
+  for (int i = 0; i < n; i++) th[i] = frameHessians[i]->frameEnergyTH;
+  const size_t R = ef->allResiduals.size();
+  // (after optimize() every surviving residual is IN and active, so re-evaluating the untouched ones at
+  // the unchanged state is value-neutral; their host mirrors are not modified and the next pack rebuilds
+  // the device copy from them.)
+  std::vector<uint32_t> f1(R);
+  std::vector<int32_t> s1(R);
+  std::vector<float> e1(R);
+  sos_ba_reset_oob(ef->ba);
+  h_newState.resize(R);
+  h_newEnergy.resize(R);
+  double E = 0;
+  rc = sos_ba_linearize(ef->ba, th.data(), &E, h_newState.data(), h_newEnergy.data(), nullptr, nullptr);
+  if (rc) return rc;
+  sos_ba_apply_res(ef->ba);
+  sos_ba_get_residual_flags(ef->ba, f1.data(), s1.data(), e1.data());
+  std::vector<int32_t> fixIdx;
+  for (PointHessian *ph : pts) {
+    int ngoodRes = 0;
+    for (PointFrameResidual *r : ph->residuals) {
+      const int k = r->packIdx;
+      r->state_state = (ResState)s1[k];
+      r->state_energy = e1[k];
+      r->efResidual->isLinearized = false;
+      r->efResidual->isActiveAndIsGoodNEW = (f1[k] & SOS_RF_ACTIVE) != 0;
+      if (r->efResidual->isActive()) {
+        fixIdx.push_back(k);
+        r->efResidual->isLinearized = true;
+        ngoodRes++;
+      }
+    }
+    (void)ngoodRes;
+    ph->efPoint->stateFlag = (ph->idepth_hessian > setting_minIdepthH_marg) ? PS_MARGINALIZE : PS_DROP;
+    FrameHessian *host = ph->host;
+    if (ph->efPoint->stateFlag == PS_MARGINALIZE) host->pointHessiansMarginalized.push_back(ph);
+    else host->pointHessiansOut.push_back(ph);
+    for (size_t i = 0; i < host->pointHessians.size(); i++)
+      if (host->pointHessians[i] == ph) {
+        host->pointHessians[i] = host->pointHessians.back();
+        host->pointHessians.pop_back();
+        break;
+      }
+  }
+  sos_ba_fix_linearization(ef->ba, fixIdx.data(), (int)fixIdx.size());
+  ef->dropPointsF();         // FS/FullSystem.cpp:909 (PS_DROP ones)
+  // dropPointsF mutated the graph but the device snapshot still holds the to-be-marginalised points at
+  // their packIdx: marginalizePointsF reads them before removing them.
+  ef->marginalizePointsF();  // :912
+  return SOS_OK;
+}
+
+int FullSystem::dropPoints(const std::vector<PointHessian *> &pts) {
+  for (PointHessian *ph : pts) {
+    ph->efPoint->stateFlag = PS_DROP;
+    FrameHessian *host = ph->host;
+    host->pointHessiansOut.push_back(ph);
+    for (size_t i = 0; i < host->pointHessians.size(); i++)
+      if (host->pointHessians[i] == ph) {
+        host->pointHessians[i] = host->pointHessians.back();
+        host->pointHessians.pop_back();
+        break;
+      }
+  }
+  ef->dropPointsF();
+  return SOS_OK;
+}
+
+int FullSystem::marginalizeFrame(FrameHessian *frame) {  // FS/FullSystemMarginalize.cpp:143-236 (backend part)
+  if (!frame->pointHessians.empty()) return SOS_ERR_STATE;
+  ef->marginalizeFrame(frame->efFrame);
+  // drop all observations of existing points in that frame (:148-176)
+  for (FrameHessian *fh : frameHessians) {
+    if (fh == frame) continue;
+    for (PointHessian *ph : fh->pointHessians)
+      for (unsigned i = 0; i < ph->residuals.size(); i++) {
+        PointFrameResidual *r = ph->residuals[i];
+        if (r->target == frame) {
+          if (ph->lastResiduals[0].first == r) ph->lastResiduals[0].first = nullptr;
+          else if (ph->lastResiduals[1].first == r) ph->lastResiduals[1].first = nullptr;
+          ef->dropResidual(r->efResidual);
+          ph->residuals[i] = ph->residuals.back();
+          ph->residuals.pop_back();
+          delete r;
+          break;
+        }
+      }
+  }
+  sos_frame_release(ctx, frame->slot);
+  slotUsed[frame->slot] = false;
+  for (size_t i = 0; i < frameHessians.size(); i++)
+    if (frameHessians[i] == frame) {
+      frameHessians.erase(frameHessians.begin() + i);
+      break;
+    }
+  for (size_t i = 0; i < frameHessians.size(); i++) frameHessians[i]->idx = (int)i;
+  delete frame;  // (the reference hands it to LoopHandler instead, src/LoopClosure/LoopHandler.cpp:249)
+  setPrecalcValues();
+  ef->setAdjointsF(&HCalib);
+  ef->setDeltaF(&HCalib);
+  return SOS_OK;
+}
+
+}  // namespace sos
+
+// ================================================================================================
+// flat C API
+// ================================================================================================
+using namespace sos;
+
+struct sosf_system {
+  FullSystem *fs;
+};
+
+extern "C" int sosf_create(const sos_params *params, int device, void *hip_stream, sosf_system **out) {
+  if (!params || !out) return SOS_ERR_ARG;
+  *out = nullptr;
+  FullSystem *fs = new FullSystem(*params, device, hip_stream);
+  if (!fs->ok()) {
+    int e = fs->lastError ? fs->lastError : SOS_ERR_HIP;
+    delete fs;
+    return e;
+  }
+  sosf_system *s = new sosf_system();
+  s->fs = fs;
+  *out = s;
+  return SOS_OK;
+}
+extern "C" int sosf_destroy(sosf_system *s) {
+  if (!s) return SOS_OK;
+  delete s->fs;
+  delete s;
+  return SOS_OK;
+}
+extern "C" int sosf_set_calib(sosf_system *s, const double *vs) {
+  if (!s || !vs) return SOS_ERR_ARG;
+  CalibHessian &C = s->fs->HCalib;
+  for (int i = 0; i < 4; i++) C.value_zero[i] = 0;
+  C.setValueScaled(vs);
+  for (int i = 0; i < 4; i++) C.value_zero[i] = C.value[i];
+  for (int i = 0; i < 4; i++) C.value_minus_value_zero[i] = 0;
+  return SOS_OK;
+}
+extern "C" int sosf_add_frame(sosf_system *s, const sosf_frame_init *f, const float *image) {
+  if (!s || !f || !image) return SOS_ERR_ARG;
+  return s->fs->addFrame(f->camToWorld, f->state, f->ab_exposure, f->frameID, f->frameEnergyTH, image) ? SOS_OK : SOS_ERR_STATE;
+}
+extern "C" int sosf_add_points(sosf_system *s, int count, const sos_point *pts) {
+  if (!s || (count && !pts)) return SOS_ERR_ARG;
+  for (int i = 0; i < count; i++)
+    if (!s->fs->addPoint(pts[i])) return SOS_ERR_ARG;
+  return SOS_OK;
+}
+extern "C" int sosf_add_residuals(sosf_system *s, int count, const sos_resid *res) {
+  if (!s || (count && !res)) return SOS_ERR_ARG;
+  FullSystem *fs = s->fs;
+  for (int i = 0; i < count; i++) {
+    const sos_resid &q = res[i];
+    if (q.point < 0 || q.point >= (int)fs->userPoints.size() || q.target < 0 || q.target >= (int)fs->frameHessians.size()) return SOS_ERR_ARG;
+    fs->addResidual(fs->userPoints[q.point], fs->frameHessians[q.target], q);
+  }
+  return SOS_OK;
+}
+extern "C" int sosf_set_prior(sosf_system *s, const double *HM, const double *bM) {
+  if (!s || !HM || !bM) return SOS_ERR_ARG;
+  EnergyFunctional *ef = s->fs->ef;
+  const int dim = SOS_CPARS + 8 * ef->nFrames;
+  ef->HM.assign(HM, HM + (size_t)dim * dim);
+  ef->bM.assign(bM, bM + dim);
+  return SOS_OK;
+}
+extern "C" int sosf_get_prior(sosf_system *s, double *HM, double *bM) {
+  if (!s) return SOS_ERR_ARG;
+  EnergyFunctional *ef = s->fs->ef;
+  if (HM) std::memcpy(HM, ef->HM.data(), sizeof(double) * ef->HM.size());
+  if (bM) std::memcpy(bM, ef->bM.data(), sizeof(double) * ef->bM.size());
+  return SOS_OK;
+}
+extern "C" int sosf_optimize(sosf_system *s, int mnumOptIts, float *rmse, int *iterations) {
+  if (!s) return SOS_ERR_ARG;
+  const float r = s->fs->optimize(mnumOptIts, iterations);
+  if (rmse) *rmse = r;
+  return s->fs->lastError;
+}
+extern "C" int sosf_prepare(sosf_system *s) { return s ? s->fs->prepare() : SOS_ERR_ARG; }
+extern "C" int sosf_gn_iteration(sosf_system *s, int iteration, int *canbreak) {
+  if (!s) return SOS_ERR_ARG;
+  const bool cb = s->fs->gnIteration(iteration);
+  if (canbreak) *canbreak = cb ? 1 : 0;
+  return s->fs->lastError;
+}
+extern "C" int sosf_counts(sosf_system *s, int *nF, int *nP, int *nR) {
+  if (!s) return SOS_ERR_ARG;
+  if (nF) *nF = s->fs->ef->nFrames;
+  if (nP) *nP = s->fs->ef->nPoints;
+  if (nR) *nR = s->fs->ef->nResiduals;
+  return SOS_OK;
+}
+extern "C" int sosf_get_frame(sosf_system *s, int idx, double *c2w, double *state, double *state_zero, float *th) {
+  if (!s || idx < 0 || idx >= (int)s->fs->frameHessians.size()) return SOS_ERR_ARG;
+  const FrameHessian *f = s->fs->frameHessians[idx];
+  if (c2w) f->PRE_camToWorld.to12(c2w);
+  if (state) std::memcpy(state, f->state, sizeof(double) * 10);
+  if (state_zero) std::memcpy(state_zero, f->state_zero, sizeof(double) * 10);
+  if (th) *th = f->frameEnergyTH;
+  return SOS_OK;
+}
+extern "C" int sosf_get_calib(sosf_system *s, double *vs) {
+  if (!s || !vs) return SOS_ERR_ARG;
+  std::memcpy(vs, s->fs->HCalib.value_scaled, sizeof(double) * 4);
+  return SOS_OK;
+}
+extern "C" int sosf_get_points(sosf_system *s, float *idepth, float *idh, float *mrb, int32_t *ngr) {
+  if (!s) return SOS_ERR_ARG;
+  size_t k = 0;
+  for (FrameHessian *fh : s->fs->frameHessians)
+    for (EFPoint *p : fh->efFrame->points) {
+      const PointHessian *ph = p->data;
+      if (idepth) idepth[k] = ph->idepth;
+      if (idh) idh[k] = ph->idepth_hessian;
+      if (mrb) mrb[k] = ph->maxRelBaseline;
+      if (ngr) ngr[k] = ph->numGoodResiduals;
+      k++;
+    }
+  return SOS_OK;
+}
+extern "C" int sosf_get_residuals(sosf_system *s, int32_t *state_state, int32_t *isActive, int32_t *removed) {
+  // reported per *user-order* residual is not tracked; this reports the current graph in packing order
+  if (!s) return SOS_ERR_ARG;
+  size_t k = 0;
+  for (FrameHessian *fh : s->fs->frameHessians)
+    for (EFPoint *p : fh->efFrame->points)
+      for (EFResidual *r : p->residualsAll) {
+        if (state_state) state_state[k] = (int)r->data->state_state;
+        if (isActive) isActive[k] = r->isActive() ? 1 : 0;
+        if (removed) removed[k] = 0;
+        k++;
+      }
+  return (int)k >= 0 ? SOS_OK : SOS_ERR_STATE;
+}
+extern "C" int sosf_get_lastX(sosf_system *s, double *x) {
+  if (!s || !x) return SOS_ERR_ARG;
+  std::memcpy(x, s->fs->ef->lastX.data(), sizeof(double) * s->fs->ef->lastX.size());
+  return SOS_OK;
+}
+extern "C" int sosf_get_stats(sosf_system *s, int *a, int *l, int *m) {
+  if (!s) return SOS_ERR_ARG;
+  if (a) *a = s->fs->ef->resInA;
+  if (l) *l = s->fs->ef->resInL;
+  if (m) *m = s->fs->ef->resInM;
+  return SOS_OK;
+}
+static int collect_points(FullSystem *fs, const int32_t *idx, int count, std::vector<PointHessian *> &out) {
+  fs->ef->makeIDX();
+  for (int i = 0; i < count; i++) {
+    if (idx[i] < 0 || idx[i] >= (int)fs->ef->allPoints.size()) return SOS_ERR_ARG;
+    out.push_back(fs->ef->allPoints[idx[i]]->data);
+  }
+  return SOS_OK;
+}
+extern "C" int sosf_marginalize_points(sosf_system *s, const int32_t *pointIdx, int count) {
+  if (!s || (count && !pointIdx)) return SOS_ERR_ARG;
+  std::vector<PointHessian *> pts;
+  int rc = collect_points(s->fs, pointIdx, count, pts);
+  if (rc) return rc;
+  return s->fs->marginalizePoints(pts);
+}
+extern "C" int sosf_drop_points(sosf_system *s, const int32_t *pointIdx, int count) {
+  if (!s || (count && !pointIdx)) return SOS_ERR_ARG;
+  std::vector<PointHessian *> pts;
+  int rc = collect_points(s->fs, pointIdx, count, pts);
+  if (rc) return rc;
+  return s->fs->dropPoints(pts);
+}
+extern "C" int sosf_marginalize_frame(sosf_system *s, int frameIdx) {
+  if (!s || frameIdx < 0 || frameIdx >= (int)s->fs->frameHessians.size()) return SOS_ERR_ARG;
+  return s->fs->marginalizeFrame(s->fs->frameHessians[frameIdx]);
+}
+extern "C" sos_ctx *sosf_ctx(sosf_system *s) { return s ? s->fs->ctx : nullptr; }
+extern "C" sos_ba *sosf_ba(sosf_system *s) { return s ? s->fs->ef->ba : nullptr; }
+extern "C" int sosf_frame_slot(sosf_system *s, int frameIdx) {
+  if (!s || frameIdx < 0 || frameIdx >= (int)s->fs->frameHessians.size()) return -1;
+  return s->fs->frameHessians[frameIdx]->slot;
+}

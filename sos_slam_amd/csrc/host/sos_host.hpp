@@ -1,0 +1,251 @@
+// sos_host.hpp -- C++ host facade keeping the reference's class surface around the HIP backend.
+//
+//   CalibHessian / FrameHessian / PointHessian      FS/HessianBlocks.h:136-649
+//   FrameFramePrecalc                               FS/HessianBlocks.h:109-134, .cpp:431-461
+//   PointFrameResidual                              FS/Residuals.h:49-93
+//   EFFrame / EFPoint / EFResidual, EnergyFunctional  OB/EnergyFunctionalStructs.h:43-134, OB/EnergyFunctional.h:52-154
+//   FullSystem (backend-facing subset)              FS/FullSystem.h:118-288
+//
+// Graph mutation, FEJ bookkeeping, priors, the marginalisation prior HM/bM, the <= (4+8n)-dim fp64
+// solve and frame marginalisation stay on the host (they are O(n^2..n^3) on tiny dense matrices); the
+// per-residual / per-point loops run on the device through the C-ABI of include/sos_slam.h.
+// IMU / spline factors (OB/EnergyFunctional.cpp:256-494) are out of scope of this round.
+#pragma once
+
+#include <cstdint>
+#include <map>
+#include <vector>
+
+#include "../../../include/sos_slam.h"
+#include "sos_math.hpp"
+
+namespace sos {
+
+typedef std::vector<double> VecX;
+typedef std::vector<double> MatXX;  // row-major, dim x dim
+
+struct AffLight {  // util/NumType.h:149-171
+  double a = 0, b = 0;
+  AffLight() {}
+  AffLight(double a_, double b_) : a(a_), b(b_) {}
+  static void fromToVecExposure(float exposureF, float exposureT, AffLight g2F, AffLight g2T, double *out2);
+};
+
+struct FrameHessian;
+struct PointHessian;
+struct PointFrameResidual;
+struct EFFrame;
+struct EFPoint;
+struct EFResidual;
+class EnergyFunctional;
+
+enum ResState { IN = 0, OOB = 1, OUTLIER = 2 };
+enum EFPointStatus { PS_GOOD = 0, PS_MARGINALIZE, PS_DROP };
+
+struct CalibHessian {  // FS/HessianBlocks.h:426-553
+  double value_zero[4], value_scaled[4], value[4], step[4], value_backup[4], value_minus_value_zero[4];
+  float value_scaledf[4], value_scaledi[4];
+  CalibHessian();
+  void setValue(const double *v);
+  void setValueScaled(const double *vs);
+  float fxl() const { return value_scaledf[0]; }
+  float fyl() const { return value_scaledf[1]; }
+  float cxl() const { return value_scaledf[2]; }
+  float cyl() const { return value_scaledf[3]; }
+  sos_calib toCalib() const;
+};
+
+struct FrameFramePrecalc {  // FS/HessianBlocks.h:109-134
+  sos_precalc dev;  // PRE_KRKiTll, PRE_KtTll, PRE_RTll_0, PRE_tTll_0, PRE_aff_mode, PRE_b0_mode
+  float PRE_RTll[9], PRE_RKiTll[9], PRE_tTll[3];
+  float distanceLL;
+  void set(const FrameHessian *host, const FrameHessian *target, const CalibHessian *HCalib);
+};
+
+struct FrameHessian {
+  EFFrame *efFrame = nullptr;
+  int frameID = -1;
+  int idx = 0;
+  int slot = -1;  // device image slot (sos_ctx frame store)
+  float frameEnergyTH = 8 * 8 * SOS_PATTERN_NUM;
+  float ab_exposure = 1;
+  bool flaggedForMarginalization = false;
+  std::vector<PointHessian *> pointHessians, pointHessiansMarginalized, pointHessiansOut;
+  SE3 camToWorld_evalPT;
+  double state_zero[10], state_scaled[10], state[10], step[10], state_backup[10];
+  SE3 PRE_camToWorld, PRE_worldToCam;
+  std::vector<FrameFramePrecalc> targetPrecalc;
+
+  FrameHessian();
+  ~FrameHessian();
+  AffLight aff_g2l() const { return AffLight(state_scaled[6], state_scaled[7]); }
+  AffLight aff_g2l_0() const { return AffLight(state_zero[6] * SOS_SCALE_A, state_zero[7] * SOS_SCALE_B); }
+  void setState(const double *s);
+  void setStateZero(const double *s);
+  void setEvalPT(const SE3 &camToWorld, const double *s);
+  void getPrior(double *p10, float affineOptModeA, float affineOptModeB) const;
+};
+
+struct PointHessian {  // FS/HessianBlocks.h:556-649
+  EFPoint *efPoint = nullptr;
+  float color[SOS_PATTERN_NUM], weights[SOS_PATTERN_NUM];
+  float u = 0, v = 0;
+  FrameHessian *host = nullptr;
+  bool hasDepthPrior = false;
+  float idepth_scaled = 0, idepth_zero_scaled = 0, idepth_zero = 0, idepth = 0, step = 0, idepth_backup = 0;
+  float idepth_hessian = 0, maxRelBaseline = 0;
+  int numGoodResiduals = 0;
+  std::vector<PointFrameResidual *> residuals;
+  std::pair<PointFrameResidual *, ResState> lastResiduals[2];
+  int packIdx = -1;  // index in the last device snapshot (allPoints order)
+  int userIdx = -1;  // running index in which the point was added through the flat API
+  ~PointHessian();
+  void setIdepth(float id) { idepth = id; idepth_scaled = SOS_SCALE_IDEPTH * id; }
+  void setIdepthZero(float id) { idepth_zero = id; idepth_zero_scaled = SOS_SCALE_IDEPTH * id; }
+};
+
+struct PointFrameResidual {  // FS/Residuals.h:49-93
+  EFResidual *efResidual = nullptr;
+  ResState state_state = IN;
+  double state_energy = 0;
+  ResState state_NewState = OUTLIER;
+  double state_NewEnergy = 0, state_NewEnergyWithOutlier = -1;
+  PointHessian *point = nullptr;
+  FrameHessian *host = nullptr, *target = nullptr;
+  bool isNew = true;
+  float centerProjectedTo[3] = {0, 0, 0};
+  int packIdx = -1;
+  void resetOOB() {
+    state_NewEnergy = state_energy = 0;
+    state_NewState = OUTLIER;
+    state_state = IN;
+  }
+};
+
+struct EFResidual {  // OB/EnergyFunctionalStructs.h:43-81
+  PointFrameResidual *data;
+  int hostIDX = 0, targetIDX = 0;
+  EFPoint *point;
+  EFFrame *host, *target;
+  int idxInAll = 0;
+  bool isLinearized = false;
+  bool isActiveAndIsGoodNEW = false;
+  bool isActive() const { return isActiveAndIsGoodNEW; }
+  EFResidual(PointFrameResidual *org, EFPoint *p, EFFrame *h, EFFrame *t) : data(org), point(p), host(h), target(t) {}
+};
+
+struct EFPoint {  // OB/EnergyFunctionalStructs.h:83-114
+  PointHessian *data;
+  float priorF = 0, deltaF = 0;
+  int idxInPoints = 0;
+  EFFrame *host;
+  std::vector<EFResidual *> residualsAll;
+  float HdiF = 0, bdSumF = 0;
+  EFPointStatus stateFlag = PS_GOOD;
+  EFPoint(PointHessian *d, EFFrame *h, float idepthFixPrior);
+};
+
+struct EFFrame {  // OB/EnergyFunctionalStructs.h:116-134
+  double prior[8], delta_prior[8], delta[8];
+  std::vector<EFPoint *> points;
+  FrameHessian *data;
+  int idx = 0;
+  int frameID = -1;
+  EFFrame(FrameHessian *d, float modeA, float modeB);
+  void takeData(float modeA, float modeB);
+};
+
+class EnergyFunctional {  // OB/EnergyFunctional.h:52-154
+ public:
+  EnergyFunctional(sos_ctx *ctx, const sos_params &prm);
+  ~EnergyFunctional();
+
+  EFResidual *insertResidual(PointFrameResidual *r);
+  EFFrame *insertFrame(FrameHessian *fh, CalibHessian *HCalib);
+  EFPoint *insertPoint(PointHessian *ph);
+  void dropResidual(EFResidual *r);
+  void marginalizeFrame(EFFrame *fh);
+  void removePoint(EFPoint *pt);
+  void marginalizePointsF();
+  void dropPointsF();
+  void solveSystemF(int iteration, double lambda, CalibHessian *HCalib);
+  double calcMEnergyF();
+  double calcLEnergyF_MT();
+  void makeIDX();
+  void setDeltaF(CalibHessian *HCalib);
+  void setAdjointsF(CalibHessian *HCalib);
+
+  // device snapshot management
+  int packWindow();                       // sos_ba_set_window from the current graph (when dirty)
+  int pushState(CalibHessian *HCalib, bool adjoints);  // sos_ba_set_state
+  sos_ba *ba = nullptr;
+  sos_ctx *ctx = nullptr;
+  bool packDirty = true;
+
+  std::vector<EFFrame *> frames;
+  int nPoints = 0, nFrames = 0, nResiduals = 0;
+  MatXX HM;
+  VecX bM;
+  int resInA = 0, resInL = 0, resInM = 0;
+  VecX lastX;
+  std::map<uint64_t, std::pair<int, int>> connectivityMap;
+  std::vector<EFPoint *> allPoints;
+  std::vector<EFResidual *> allResiduals;  // packing order
+  std::vector<float> pointStep;            // last resubstitute result, packing order
+
+  sos_params prm;
+  float cDeltaF[4];
+  double cPrior[4];
+  std::vector<double> adHost, adTarget;    // n*n*64
+  std::vector<float> adHostF, adTargetF, adHTdeltaF;
+  bool EFAdjointsValid = false, EFIndicesValid = false, EFDeltaValid = false;
+
+ private:
+  VecX getStitchedDeltaF() const;
+  std::vector<EFPoint *> allPointsToMarg;
+};
+
+// backend-facing part of FullSystem (FS/FullSystem.h:118-288)
+class FullSystem {
+ public:
+  FullSystem(const sos_params &prm, int device, void *stream);
+  ~FullSystem();
+  bool ok() const { return ctx != nullptr && ef != nullptr; }
+
+  FrameHessian *addFrame(const double *camToWorld12, const double *state10, float ab_exposure, int frameID,
+                         float frameEnergyTH, const float *image);
+  PointHessian *addPoint(const sos_point &p);
+  PointFrameResidual *addResidual(PointHessian *ph, FrameHessian *target, const sos_resid &r);
+
+  float optimize(int mnumOptIts, int *iterations);            // FS/FullSystemOptimize.cpp:305-489
+  int prepare();                                              // :316-344
+  bool gnIteration(int iteration);                            // :358-413
+  void setPrecalcValues();                                    // FS/FullSystem.cpp:1099-1107
+  void removeOutliers();                                      // FS/FullSystemOptimize.cpp:507-526
+  int marginalizePoints(const std::vector<PointHessian *> &pts);  // flagPointsForRemoval core + marginalizePointsF
+  int dropPoints(const std::vector<PointHessian *> &pts);
+  int marginalizeFrame(FrameHessian *fh);                     // FS/FullSystemMarginalize.cpp:143-236
+
+  sos_params prm;
+  sos_ctx *ctx = nullptr;
+  EnergyFunctional *ef = nullptr;
+  CalibHessian HCalib;
+  std::vector<FrameHessian *> frameHessians;
+  std::vector<PointHessian *> userPoints;  // in the order they were added through the flat API
+  bool isLost = false;
+  int lastError = 0;
+  bool slotUsed[SOS_MAX_SLOTS];
+
+ private:
+  double linearizeAll(bool fixLinearization);                 // :125-182
+  void setNewFrameEnergyTH();                                 // :84-124
+  void applyRes();                                            // :79-83
+  void backupState();                                         // :260-269
+  bool doStepFromBackup(float stepfacC, float stepfacT, float stepfacR, float stepfacA, float stepfacD);  // :185-257
+  void solveSystem(int iteration, double lambda);             // :491-497
+  std::vector<PointFrameResidual *> activeResiduals;
+  std::vector<uint8_t> h_newState;
+  std::vector<float> h_newEnergy, h_newEnergyWO, h_center;
+};
+
+}  // namespace sos

@@ -1,0 +1,173 @@
+// sos_math.hpp -- fp64 math floor of the host facade: SE3 with the semantics of the reference's
+// vendored Sophus 0.9a (thirdparty/Sophus/sophus/se3.hpp:131-139 Adj, :168-173 inverse, :407-428 exp;
+// so3.hpp:343-368 expAndTheta) and a symmetric-pivoting LDL^T solve in place of Eigen's
+// `.ldlt().solve` (OB/EnergyFunctional.cpp:1148).  Eigen is not available in this image.
+#pragma once
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace sos {
+
+struct SE3 {
+  double R[9];  // row-major
+  double t[3];
+
+  SE3() {
+    std::memset(R, 0, sizeof(R));
+    R[0] = R[4] = R[8] = 1;
+    t[0] = t[1] = t[2] = 0;
+  }
+  static SE3 from12(const double *p) {
+    SE3 T;
+    std::memcpy(T.R, p, 9 * sizeof(double));
+    std::memcpy(T.t, p + 9, 3 * sizeof(double));
+    return T;
+  }
+  void to12(double *p) const {
+    std::memcpy(p, R, 9 * sizeof(double));
+    std::memcpy(p + 9, t, 3 * sizeof(double));
+  }
+  SE3 operator*(const SE3 &o) const {
+    SE3 c;
+    for (int i = 0; i < 3; i++) {
+      for (int j = 0; j < 3; j++) c.R[3 * i + j] = R[3 * i] * o.R[j] + R[3 * i + 1] * o.R[3 + j] + R[3 * i + 2] * o.R[6 + j];
+      c.t[i] = t[i] + (R[3 * i] * o.t[0] + R[3 * i + 1] * o.t[1] + R[3 * i + 2] * o.t[2]);
+    }
+    return c;
+  }
+  SE3 inverse() const {
+    SE3 c;
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) c.R[3 * i + j] = R[3 * j + i];
+    for (int i = 0; i < 3; i++) c.t[i] = -(c.R[3 * i] * t[0] + c.R[3 * i + 1] * t[1] + c.R[3 * i + 2] * t[2]);
+    return c;
+  }
+  // 6x6 row-major [R, hat(t) R; 0, R]
+  void Adj(double *Ad) const {
+    const double H[9] = {0, -t[2], t[1], t[2], 0, -t[0], -t[1], t[0], 0};
+    std::memset(Ad, 0, 36 * sizeof(double));
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        Ad[6 * i + j] = R[3 * i + j];
+        Ad[6 * (i + 3) + j + 3] = R[3 * i + j];
+        Ad[6 * i + j + 3] = H[3 * i] * R[j] + H[3 * i + 1] * R[3 + j] + H[3 * i + 2] * R[6 + j];
+      }
+  }
+  // tangent = [upsilon(3), omega(3)]
+  static SE3 exp(const double *a) {
+    const double eps = 1e-10;
+    const double *om = a + 3;
+    const double theta_sq = om[0] * om[0] + om[1] * om[1] + om[2] * om[2];
+    const double theta = std::sqrt(theta_sq);
+    double imag, real;
+    if (theta < eps) {
+      const double po4 = theta_sq * theta_sq;
+      imag = 0.5 - (1.0 / 48.0) * theta_sq + (1.0 / 3840.0) * po4;
+      real = 1.0 - 0.5 * theta_sq + (1.0 / 384.0) * po4;
+    } else {
+      imag = std::sin(0.5 * theta) / theta;
+      real = std::cos(0.5 * theta);
+    }
+    double qw = real, qx = imag * om[0], qy = imag * om[1], qz = imag * om[2];
+    const double nrm = std::sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+    qw /= nrm; qx /= nrm; qy /= nrm; qz /= nrm;
+    SE3 T;
+    const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+    const double twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx,
+                 tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+    T.R[0] = 1 - (tyy + tzz); T.R[1] = txy - twz; T.R[2] = txz + twy;
+    T.R[3] = txy + twz; T.R[4] = 1 - (txx + tzz); T.R[5] = tyz - twx;
+    T.R[6] = txz - twy; T.R[7] = tyz + twx; T.R[8] = 1 - (txx + tyy);
+    const double Om[9] = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
+    double Om2[9], V[9];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) Om2[3 * i + j] = Om[3 * i] * Om[j] + Om[3 * i + 1] * Om[3 + j] + Om[3 * i + 2] * Om[6 + j];
+    if (theta < eps) {
+      std::memcpy(V, T.R, sizeof(V));
+    } else {
+      const double c1 = (1.0 - std::cos(theta)) / theta_sq, c2 = (theta - std::sin(theta)) / (theta_sq * theta);
+      for (int i = 0; i < 9; i++) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + c1 * Om[i] + c2 * Om2[i];
+    }
+    for (int i = 0; i < 3; i++) T.t[i] = V[3 * i] * a[0] + V[3 * i + 1] * a[1] + V[3 * i + 2] * a[2];
+    return T;
+  }
+};
+
+// x = A^-1 b for symmetric A (n x n row-major) by LDL^T with symmetric pivoting; exact-zero pivots
+// contribute nothing (Eigen LDLT::solve semantics).
+inline void ldlt_solve(const std::vector<double> &A, const std::vector<double> &b, std::vector<double> &x, int n) {
+  const size_t N = (size_t)n;
+  std::vector<double> M(A), L(N * N, 0.0), D(N), y(N);
+  std::vector<int> perm(N);
+  for (int i = 0; i < n; i++) perm[i] = i;
+  for (int k = 0; k < n; k++) {
+    int p = k;
+    double best = std::fabs(M[k * N + k]);
+    for (int i = k + 1; i < n; i++)
+      if (std::fabs(M[i * N + i]) > best) { best = std::fabs(M[i * N + i]); p = i; }
+    if (p != k) {
+      for (int j = 0; j < n; j++) std::swap(M[k * N + j], M[p * N + j]);
+      for (int j = 0; j < n; j++) std::swap(M[j * N + k], M[j * N + p]);
+      for (int j = 0; j < k; j++) std::swap(L[k * N + j], L[p * N + j]);
+      std::swap(perm[k], perm[p]);
+    }
+    const double d = M[k * N + k];
+    D[k] = d;
+    L[k * N + k] = 1.0;
+    if (!(std::fabs(d) > 2.2250738585072014e-308)) continue;
+    for (int i = k + 1; i < n; i++) L[i * N + k] = M[i * N + k] / d;
+    for (int i = k + 1; i < n; i++) {
+      const double lik = L[i * N + k];
+      if (lik == 0.0) continue;
+      for (int j = k + 1; j < n; j++) M[i * N + j] -= lik * M[k * N + j];
+    }
+  }
+  for (int i = 0; i < n; i++) y[i] = b[perm[i]];
+  for (int i = 0; i < n; i++) {
+    double s = y[i];
+    for (int j = 0; j < i; j++) s -= L[i * N + j] * y[j];
+    y[i] = s;
+  }
+  for (int i = 0; i < n; i++) y[i] = (std::fabs(D[i]) > 2.2250738585072014e-308) ? y[i] / D[i] : 0.0;
+  for (int i = n - 1; i >= 0; i--) {
+    double s = y[i];
+    for (int j = i + 1; j < n; j++) s -= L[j * N + i] * y[j];
+    y[i] = s;
+  }
+  x.assign(N, 0.0);
+  for (int i = 0; i < n; i++) x[perm[i]] = y[i];
+}
+
+// dense inverse (Gauss-Jordan, partial pivoting) in place of Eigen `.inverse()` (OB/EnergyFunctional.cpp:841)
+inline bool mat_inverse(const std::vector<double> &A, std::vector<double> &Ai, int n) {
+  const size_t N = (size_t)n;
+  std::vector<double> M(N * 2 * N, 0.0);
+  for (int i = 0; i < n; i++) {
+    for (int j = 0; j < n; j++) M[i * 2 * N + j] = A[i * N + j];
+    M[i * 2 * N + N + i] = 1.0;
+  }
+  for (int k = 0; k < n; k++) {
+    int p = k;
+    for (int i = k + 1; i < n; i++)
+      if (std::fabs(M[i * 2 * N + k]) > std::fabs(M[p * 2 * N + k])) p = i;
+    if (p != k)
+      for (int j = 0; j < 2 * n; j++) std::swap(M[k * 2 * N + j], M[p * 2 * N + j]);
+    const double d = M[k * 2 * N + k];
+    if (d == 0.0) return false;
+    for (int j = 0; j < 2 * n; j++) M[k * 2 * N + j] /= d;
+    for (int i = 0; i < n; i++)
+      if (i != k) {
+        const double f = M[i * 2 * N + k];
+        if (f != 0.0)
+          for (int j = 0; j < 2 * n; j++) M[i * 2 * N + j] -= f * M[k * 2 * N + j];
+      }
+  }
+  Ai.assign(N * N, 0.0);
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) Ai[i * N + j] = M[i * 2 * N + N + j];
+  return true;
+}
+
+}  // namespace sos

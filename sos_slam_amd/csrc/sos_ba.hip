@@ -1640,6 +1640,18 @@ extern "C" int sos_ba_accumulate_marg(sos_ba *ba, const int32_t *pointIdx, int c
   return SOS_OK;
 }
 
+extern "C" int sos_ba_update_point_priors(sos_ba *ba, const int32_t *pointIdx, const float *priorF, int count) {
+  if (!ba || !ba->have_window || (count && (!pointIdx || !priorF))) return SOS_ERR_STATE;
+  SOS_HIP(hipSetDevice(ba->ctx->device));
+  for (int k = 0; k < count; k++) {
+    if (pointIdx[k] < 0 || pointIdx[k] >= ba->P) return SOS_ERR_ARG;
+    ba->h_pts[pointIdx[k]].priorF = priorF[k];
+  }
+  if (ba->P) SOS_HIP(hipMemcpyAsync(ba->d_pts.p, ba->h_pts.data(), sizeof(sos_point) * ba->P, hipMemcpyHostToDevice, ba->ctx->stream));
+  SOS_HIP(hipStreamSynchronize(ba->ctx->stream));
+  return SOS_OK;
+}
+
 // ---- inspection ---------------------------------------------------------------------------------
 extern "C" int sos_ba_get_jacobian(sos_ba *ba, int residIdx, int which, sos_rawjac *out) {
   (void)which;  // one shared buffer, see the header comment of this file

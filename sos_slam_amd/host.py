@@ -1,0 +1,184 @@
+"""ctypes binding of csrc/libsos_host.so: the C++ host facade (FullSystem / EnergyFunctional surface)
+driving the HIP backend.  No CPU fallback: creation fails when the HIP library or the GPU is missing."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+from . import lib as _lib
+from .records import Params
+from .synth import FRAME_INIT_DTYPE
+
+_HOST = None
+
+
+def load():
+    global _HOST
+    if _HOST is not None:
+        return _HOST
+    _lib.load()  # libsos_host.so links against libsos_slam_hip.so
+    path = _build.HOST_LIB
+    if not os.path.exists(path):
+        raise _lib.SosError(f"{path} not built (run __graft_entry__.build())")
+    L = C.CDLL(path)
+    vp, ci = C.c_void_p, C.c_int
+    L.sosf_create.argtypes = [C.POINTER(Params), ci, vp, C.POINTER(vp)]
+    L.sosf_destroy.argtypes = [vp]
+    L.sosf_set_calib.argtypes = [vp, vp]
+    L.sosf_add_frame.argtypes = [vp, vp, vp]
+    L.sosf_add_points.argtypes = [vp, ci, vp]
+    L.sosf_add_residuals.argtypes = [vp, ci, vp]
+    L.sosf_set_prior.argtypes = [vp, vp, vp]
+    L.sosf_get_prior.argtypes = [vp, vp, vp]
+    L.sosf_optimize.argtypes = [vp, ci, C.POINTER(C.c_float), C.POINTER(ci)]
+    L.sosf_prepare.argtypes = [vp]
+    L.sosf_gn_iteration.argtypes = [vp, ci, C.POINTER(ci)]
+    L.sosf_counts.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
+    L.sosf_get_frame.argtypes = [vp, ci, vp, vp, vp, C.POINTER(C.c_float)]
+    L.sosf_get_calib.argtypes = [vp, vp]
+    L.sosf_get_points.argtypes = [vp, vp, vp, vp, vp]
+    L.sosf_get_residuals.argtypes = [vp, vp, vp, vp]
+    L.sosf_get_lastX.argtypes = [vp, vp]
+    L.sosf_get_stats.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
+    L.sosf_marginalize_points.argtypes = [vp, vp, ci]
+    L.sosf_drop_points.argtypes = [vp, vp, ci]
+    L.sosf_marginalize_frame.argtypes = [vp, ci]
+    L.sosf_ctx.restype = vp
+    L.sosf_ctx.argtypes = [vp]
+    L.sosf_ba.restype = vp
+    L.sosf_ba.argtypes = [vp]
+    L.sosf_frame_slot.argtypes = [vp, ci]
+    _HOST = L
+    return L
+
+
+_p = _lib._p
+_chk = _lib._chk
+
+
+class System:
+    """FullSystem (backend-facing subset): frames, points, residuals, optimize(), marginalisation."""
+
+    def __init__(self, params: dict, device: int = 0, stream: int | None = None):
+        self.L = load()
+        self.params = Params.from_dict(params)
+        self.h_ = C.c_void_p()
+        _chk(self.L.sosf_create(C.byref(self.params), device, C.c_void_p(stream) if stream else None,
+                                C.byref(self.h_)), "sosf_create (is an MI355X visible?)")
+
+    @classmethod
+    def from_window(cls, win, device: int = 0):
+        s = cls(win.params, device)
+        s.set_calib(win.K)
+        for i in range(win.n):
+            s.add_frame(win.frames[i], win.images[i])
+        s.add_points(win.points)
+        s.add_residuals(win.resid)
+        s.set_prior(win.HM, win.bM)
+        return s
+
+    def close(self):
+        if getattr(self, "h_", None):
+            self.L.sosf_destroy(self.h_)
+            self.h_ = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_calib(self, K):
+        k = np.ascontiguousarray(K, dtype=np.float64)
+        _chk(self.L.sosf_set_calib(self.h_, _p(k)), "sosf_set_calib")
+
+    def add_frame(self, frame_init, image):
+        f = np.ascontiguousarray(np.asarray(frame_init, dtype=FRAME_INIT_DTYPE).reshape(1))
+        img = np.ascontiguousarray(image, dtype=np.float32)
+        _chk(self.L.sosf_add_frame(self.h_, _p(f), _p(img)), "sosf_add_frame")
+
+    def add_points(self, pts):
+        pts = np.ascontiguousarray(pts)
+        _chk(self.L.sosf_add_points(self.h_, len(pts), _p(pts)), "sosf_add_points")
+
+    def add_residuals(self, res):
+        res = np.ascontiguousarray(res)
+        _chk(self.L.sosf_add_residuals(self.h_, len(res), _p(res)), "sosf_add_residuals")
+
+    def set_prior(self, HM, bM):
+        _chk(self.L.sosf_set_prior(self.h_, _p(np.ascontiguousarray(HM, dtype=np.float64)),
+                                   _p(np.ascontiguousarray(bM, dtype=np.float64))), "sosf_set_prior")
+
+    def counts(self):
+        a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+        _chk(self.L.sosf_counts(self.h_, C.byref(a), C.byref(b), C.byref(c)), "sosf_counts")
+        return a.value, b.value, c.value
+
+    def get_prior(self):
+        n = self.counts()[0]
+        dim = 4 + 8 * n
+        HM, bM = np.zeros((dim, dim)), np.zeros(dim)
+        _chk(self.L.sosf_get_prior(self.h_, _p(HM), _p(bM)), "sosf_get_prior")
+        return HM, bM
+
+    def optimize(self, iters=6):
+        r, it = C.c_float(0), C.c_int(0)
+        _chk(self.L.sosf_optimize(self.h_, iters, C.byref(r), C.byref(it)), "sosf_optimize")
+        return r.value, it.value
+
+    def prepare(self):
+        _chk(self.L.sosf_prepare(self.h_), "sosf_prepare")
+
+    def gn_iteration(self, iteration=0):
+        cb = C.c_int(0)
+        _chk(self.L.sosf_gn_iteration(self.h_, iteration, C.byref(cb)), "sosf_gn_iteration")
+        return bool(cb.value)
+
+    def frame(self, idx):
+        c2w, st, sz = np.zeros(12), np.zeros(10), np.zeros(10)
+        th = C.c_float(0)
+        _chk(self.L.sosf_get_frame(self.h_, idx, _p(c2w), _p(st), _p(sz), C.byref(th)), "sosf_get_frame")
+        return dict(camToWorld=c2w, state=st, state_zero=sz, frameEnergyTH=th.value)
+
+    def calib_value_scaled(self):
+        v = np.zeros(4)
+        _chk(self.L.sosf_get_calib(self.h_, _p(v)), "sosf_get_calib")
+        return v
+
+    def points(self):
+        P = self.counts()[1]
+        idp, idh, mrb = [np.zeros(P, dtype=np.float32) for _ in range(3)]
+        ngr = np.zeros(P, dtype=np.int32)
+        _chk(self.L.sosf_get_points(self.h_, _p(idp), _p(idh), _p(mrb), _p(ngr)), "sosf_get_points")
+        return dict(idepth=idp, idepth_hessian=idh, maxRelBaseline=mrb, numGoodResiduals=ngr)
+
+    def residuals(self):
+        R = self.counts()[2]
+        st, act, rem = [np.zeros(R, dtype=np.int32) for _ in range(3)]
+        _chk(self.L.sosf_get_residuals(self.h_, _p(st), _p(act), _p(rem)), "sosf_get_residuals")
+        return dict(state_state=st, isActive=act)
+
+    def lastX(self):
+        n = self.counts()[0]
+        x = np.zeros(4 + 8 * n)
+        _chk(self.L.sosf_get_lastX(self.h_, _p(x)), "sosf_get_lastX")
+        return x
+
+    def stats(self):
+        a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+        _chk(self.L.sosf_get_stats(self.h_, C.byref(a), C.byref(b), C.byref(c)), "sosf_get_stats")
+        return dict(resInA=a.value, resInL=b.value, resInM=c.value)
+
+    def marginalize_points(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        _chk(self.L.sosf_marginalize_points(self.h_, _p(idx), len(idx)), "sosf_marginalize_points")
+
+    def drop_points(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        _chk(self.L.sosf_drop_points(self.h_, _p(idx), len(idx)), "sosf_drop_points")
+
+    def marginalize_frame(self, frame_idx):
+        _chk(self.L.sosf_marginalize_frame(self.h_, frame_idx), "sosf_marginalize_frame")

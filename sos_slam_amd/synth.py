@@ -141,8 +141,8 @@ class _Scene:
         return self.texture(px, py), s
 
 
-def make_window(name: str = "W12", seed: int = SEED, noise_sigma: float = 1.0, state_noise: float = 1e-3,
-                idepth_noise: float = 0.01, **override) -> Window:
+def make_window(name: str = "W12", seed: int = SEED, noise_sigma: float = 1.0, state_noise: float = 3e-4,
+                idepth_noise: float = 0.002, **override) -> Window:
     cfg = dict(WINDOWS[name]) if name in WINDOWS else {}
     cfg.update(override)
     n, P, w, h = cfg["n"], cfg["P"], cfg["w"], cfg["h"]
