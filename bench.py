@@ -1,0 +1,177 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the MI355X hot path (BASELINE.json: point-residuals/sec + GN-iter/sec
+on a 12-KF x 4096-point window).
+
+A "step" is one Gauss-Newton iteration of the sliding-window bundle adjustment, i.e. one loop body of
+FullSystem::optimize (FS/FullSystemOptimize.cpp:358-413): accumulate A/L/SC on the device, fp64 stitch,
+host solve, back-substitution, step + precalc, re-linearise every active residual, applyRes.  `value` =
+point-residuals linearised per second through whole iterations, summed over all ranks.
+
+  python bench.py --gpus 1 --steps K --warmup W           single GPU
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   one rank per GPU (RCCL)
+
+Multi-GPU (weak scaling): every rank holds the same 12 keyframes and its own shard of 4096
+points; the packed fp32 H/b accumulators are all-reduced over RCCL once per iteration, every rank then runs
+the identical fp64 stitch + solve.  The timed region is bracketed by barrier + torch.cuda.synchronize and
+the MAX over ranks is reported.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+LINEARIZE_BYTES_PER_RESIDUAL = 776  # 80 point + 384 gather + 296 J + 16 state
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--window", default="W12")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(win, seconds):
+    """The oracle's GN loop (C restatement of the reference's CPU path, 6-thread pool with the reference's
+    chunking) timed on this box's host cores on a bounded number of iterations of the same window."""
+    from oracle import oracle as orc
+    cores = min(6, os.cpu_count() or 1)
+
+    def run(nthreads, budget):
+        ow = orc.window_from_synth(win)
+        ow.reset_oob()
+        th = np.array([ow.frame(f)["frameEnergyTH"] for f in range(win.n)], np.float32)
+        ow.linearize(th, nthreads=nthreads)
+        ow.apply_res()
+        ow.gn_iteration(0, nthreads=nthreads)  # warm-up
+        t0 = time.perf_counter()
+        it = 0
+        while True:
+            ow.gn_iteration(it + 1, nthreads=nthreads)
+            it += 1
+            if time.perf_counter() - t0 > budget or it >= 200:
+                break
+        dt = time.perf_counter() - t0
+        ow.close()
+        return win.R * it / dt, it / dt, it
+
+    v6, g6, it6 = run(cores, seconds * 0.7)
+    v1, g1, it1 = run(1, seconds * 0.3)
+    return {"value": v6, "unit": "point-residuals/s", "cores": cores, "kind": "port",
+            "sample": f"{it6} Gauss-Newton iterations of the same {win.name} window ({win.R} residuals) with the "
+                      f"oracle's {cores}-thread pool; 1 thread: {it1} iterations",
+            "gn_iter_per_s": g6, "value_1thread": v1, "gn_iter_per_s_1thread": g1}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from sos_slam_amd import host, lib, synth
+    from sos_slam_amd import distributed as sdist
+
+    # every rank: same frames / images (seed), its own point shard (point_seed)
+    win = synth.make_window(args.window, point_seed=synth.SEED + 1000 * rank if world > 1 else None)
+    sysm = host.System.from_window(win, device=local_rank)
+    if world > 1:
+        sdist.attach(sysm, dist, torch)
+    sysm.prepare()
+    R_local = win.R
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        sysm.gn_iteration(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        sysm.gn_iteration(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    R_total = R_local
+    if dist is not None:
+        t = torch.tensor([dt, float(R_local)], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt = float(tmax[0].item())
+        R_total = int(t[1].item())
+
+    out = None
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = R_total * args.steps / dt
+        # ---- roofline of the dominant kernel (linearize): HIP events on the library's stream
+        L = lib.load()
+        import ctypes as C
+        ms = C.c_float(0)
+        th = np.array([sysm.frame(f)["frameEnergyTH"] for f in range(win.n)], np.float32)
+        L.sos_ba_time_kernel(L_host_ba(sysm), b"linearize", th.ctypes.data_as(C.c_void_p), 300, C.byref(ms))
+        lin_ms = ms.value
+        achieved = R_local * LINEARIZE_BYTES_PER_RESIDUAL / (lin_ms * 1e-3) / 1e9
+        kern = {}
+        for name in ("apply_res", "top_accumulate", "sc_accumulate", "reduce"):
+            L.sos_ba_time_kernel(L_host_ba(sysm), name.encode(), th.ctypes.data_as(C.c_void_p), 200, C.byref(ms))
+            kern[name + "_us"] = round(ms.value * 1e3, 2)
+        out = {
+            "metric": "point-residuals/sec", "value": value, "unit": "point-residuals/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.window}: {win.n} KF x {win.P} points per GPU, {win.w}x{win.h}, "
+                                   f"{R_local} point-residuals per GPU; step = one Gauss-Newton iteration "
+                                   "(accumulate A/L/SC, fp64 stitch, solve, back-substitute, step, re-linearise, "
+                                   "applyRes)", "window": args.window, "keyframes": win.n, "points_per_gpu": win.P,
+                       "residuals_per_gpu": R_local, "residuals_total": R_total},
+            "gn_iter_per_s": args.steps / dt,
+            "linearize_point_residuals_per_s": R_local / (lin_ms * 1e-3),
+            "kernels_us": dict(linearize_us=round(lin_ms * 1e3, 2), **kern),
+            "roofline": {"kernel": "k_linearize", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_residual": LINEARIZE_BYTES_PER_RESIDUAL, "avg_launch_us": lin_ms * 1e3},
+        }
+    sysm.close()
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(win, args.cpu_seconds)
+            out["speedup_vs_cpu_gn_iter"] = out["gn_iter_per_s"] / out["cpu_baseline"]["gn_iter_per_s"]
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def L_host_ba(sysm):
+    from sos_slam_amd import host
+    import ctypes as C
+    return C.c_void_p(host.load().sosf_ba(sysm.h_))
+
+
+if __name__ == "__main__":
+    main()

@@ -80,6 +80,19 @@ int sosf_drop_points(sosf_system *sys, const int32_t *pointIdx, int count);
  * OB/EnergyFunctional.cpp:730-889, IMU off): frame idx must have no points left */
 int sosf_marginalize_frame(sosf_system *sys, int frameIdx);
 
+/* Multi-GPU hooks: when set, solveSystemF accumulates the local shard, hands the packed
+ * fp32 accumulator buffer (device pointer) to `allreduce` (RCCL sum over ranks, must be complete on return)
+ * and stitches from the reduced buffer; setNewFrameEnergyTH asks `nth` for the global order statistic:
+ * given the local energies of residuals targeting the newest frame, return the element at index
+ * (int)(frac * N_global) of the globally sorted list (or a negative value if the global list is empty). */
+typedef void (*sosf_allreduce_fn)(void *user, float *dev_ptr, size_t nfloats);
+typedef float (*sosf_nth_fn)(void *user, const float *energies, int count, float frac);
+int sosf_set_hooks(sosf_system *sys, sosf_allreduce_fn allreduce, sosf_nth_fn nth, void *user);
+
+/* accumulated wall-clock seconds per phase of sosf_gn_iteration: 0 accumulate+stitch, 1 assemble+solve,
+ * 2 resubstitute, 3 step+precalc, 4 set_state upload, 5 linearize, 6 applyRes */
+int sosf_get_timing(double *phases8, int reset);
+
 /* direct access to the underlying context / backend handles (tracker tests share the frame store) */
 sos_ctx *sosf_ctx(sosf_system *sys);
 sos_ba *sosf_ba(sosf_system *sys);

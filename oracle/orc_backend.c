@@ -879,28 +879,55 @@ static void sc_stitch_job(void *c, int first, int last, int tid) {
   sc_stitch_range(A->W, A->S, A->nacc, A->f64, first, last, A->Hs[tid], A->bs[tid]);
 }
 
-static top_acc *top_alloc(int n, int nacc) {
-  top_acc *T = (top_acc *)calloc((size_t)nacc, sizeof(top_acc));
-  for (int i = 0; i < nacc; i++) T[i].acc = (acc_approx *)calloc((size_t)n * n, sizeof(acc_approx));
-  return T;
-}
-static void top_free(top_acc *T, int nacc) {
-  for (int i = 0; i < nacc; i++) free(T[i].acc);
-  free(T);
-}
-static sc_acc *sc_alloc(int n, int nacc) {
-  sc_acc *S = (sc_acc *)calloc((size_t)nacc, sizeof(sc_acc));
-  for (int i = 0; i < nacc; i++) {
-    S[i].accE = (acc_xx *)calloc((size_t)n * n, sizeof(acc_xx));
-    S[i].accEB = (acc_xx *)calloc((size_t)n * n, sizeof(acc_xx));
-    S[i].accD = (acc_xx *)calloc((size_t)n * n * n, sizeof(acc_xx));
+/* The reference keeps its per-thread accumulators alive and re-initialises them with setZero on the
+ * worker threads (OB/EnergyFunctional.cpp:199-201): cache them per (n, nacc) and zero in parallel. */
+static top_acc *g_top_cache = 0;
+static sc_acc *g_sc_cache = 0;
+static int g_cache_n = 0, g_cache_nacc = 0;
+typedef struct zero_ctx { top_acc *T; sc_acc *S; int n; } zero_ctx;
+static void zero_job(void *c, int first, int last, int tid) {
+  (void)tid;
+  zero_ctx *Z = (zero_ctx *)c;
+  size_t nn = (size_t)Z->n * Z->n;
+  for (int i = first; i < last; i++) {
+    if (Z->T) { memset(Z->T[i].acc, 0, nn * sizeof(acc_approx)); Z->T[i].nres = 0; }
+    if (Z->S) {
+      memset(Z->S[i].accE, 0, nn * sizeof(acc_xx)); memset(Z->S[i].accEB, 0, nn * sizeof(acc_xx));
+      memset(Z->S[i].accD, 0, nn * Z->n * sizeof(acc_xx));
+      memset(&Z->S[i].accHcc, 0, sizeof(acc_xx)); memset(&Z->S[i].accbc, 0, sizeof(acc_xx));
+    }
   }
-  return S;
 }
-static void sc_free(sc_acc *S, int nacc) {
-  for (int i = 0; i < nacc; i++) { free(S[i].accE); free(S[i].accEB); free(S[i].accD); }
-  free(S);
+static void cache_ensure(int n, int nacc) {
+  if (g_cache_n == n && g_cache_nacc == nacc) return;
+  if (g_top_cache) {
+    for (int i = 0; i < g_cache_nacc; i++) { free(g_top_cache[i].acc); free(g_sc_cache[i].accE); free(g_sc_cache[i].accEB); free(g_sc_cache[i].accD); }
+    free(g_top_cache); free(g_sc_cache);
+  }
+  g_top_cache = (top_acc *)calloc((size_t)nacc, sizeof(top_acc));
+  g_sc_cache = (sc_acc *)calloc((size_t)nacc, sizeof(sc_acc));
+  for (int i = 0; i < nacc; i++) {
+    g_top_cache[i].acc = (acc_approx *)calloc((size_t)n * n, sizeof(acc_approx));
+    g_sc_cache[i].accE = (acc_xx *)calloc((size_t)n * n, sizeof(acc_xx));
+    g_sc_cache[i].accEB = (acc_xx *)calloc((size_t)n * n, sizeof(acc_xx));
+    g_sc_cache[i].accD = (acc_xx *)calloc((size_t)n * n * n, sizeof(acc_xx));
+  }
+  g_cache_n = n; g_cache_nacc = nacc;
 }
+static top_acc *top_alloc(int n, int nacc) {
+  cache_ensure(n, nacc);
+  zero_ctx Z = {g_top_cache, 0, n};
+  orc_parallel_for(nacc, zero_job, &Z, 0, nacc, 1);
+  return g_top_cache;
+}
+static void top_free(top_acc *T, int nacc) { (void)T; (void)nacc; }
+static sc_acc *sc_alloc(int n, int nacc) {
+  cache_ensure(n, nacc);
+  zero_ctx Z = {0, g_sc_cache, n};
+  orc_parallel_for(nacc, zero_job, &Z, 0, nacc, 1);
+  return g_sc_cache;
+}
+static void sc_free(sc_acc *S, int nacc) { (void)S; (void)nacc; }
 
 static void run_stitch(accum_ctx *A, orc_job_fn job, int nthreads, double *H, double *b) {
   orc_window *W = A->W;

@@ -11,7 +11,22 @@
 
 #include "../../../include/sos_slam_host.h"
 
+#include <chrono>
+
 namespace sos {
+
+// wall-clock phase timers of the GN iteration (sosf_get_timing): 0 accumulate+stitch (device, D2H),
+// 1 assemble+solve (host), 2 resubstitute, 3 step+precalc (host), 4 pushState, 5 linearize, 6 applyRes
+double g_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+static inline double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+struct PhaseTimer {
+  int k;
+  double t0;
+  explicit PhaseTimer(int k_) : k(k_), t0(now_s()) {}
+  ~PhaseTimer() { g_phase[k] += now_s() - t0; }
+};
 
 // reference defaults that are not part of sos_params (util/settings.cpp:47-77)
 static const float setting_initialRotPrior = 1e11f;
@@ -395,7 +410,20 @@ void EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib) { 
   const size_t dd = (size_t)dim * dim;
   MatXX HA(dd), HL(dd), Hsc(dd);
   VecX bA(dim), bL(dim), bsc(dim);
-  sos_ba_accumulate(ba, HA.data(), bA.data(), HL.data(), bL.data(), Hsc.data(), bsc.data(), &resInA, &resInL);
+  double t_acc0 = now_s();
+  if (allreduceHook) {  // shard-local sums -> RCCL all-reduce of the packed fp32 blocks -> identical stitch on every rank
+    float *dev = nullptr;
+    size_t nfl = 0;
+    sos_ba_accumulate_local(ba);
+    sos_ba_acc_buffer(ba, &dev, &nfl);
+    sos_ctx_synchronize(ctx);
+    allreduceHook(hookUser, dev, nfl);
+    sos_ba_stitch(ba, HA.data(), bA.data(), HL.data(), bL.data(), Hsc.data(), bsc.data(), &resInA, &resInL);
+  } else {
+    sos_ba_accumulate(ba, HA.data(), bA.data(), HL.data(), bL.data(), Hsc.data(), bsc.data(), &resInA, &resInL);
+  }
+  g_phase[0] += now_s() - t_acc0;
+  double t_sol0 = now_s();
   // priors of the L stitch (usePrior = true), OB/AccumulatedTopHessian.cpp:292-300
   for (int i = 0; i < 4; i++) {
     HL[(size_t)i * dim + i] += cPrior[i];
@@ -436,6 +464,8 @@ void EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib) { 
     for (int i = 0; i < 8; i++) h->data->step[i] = -x[SOS_CPARS + 8 * h->idx + i];
     h->data->step[8] = h->data->step[9] = 0;
   }
+  g_phase[1] += now_s() - t_sol0;
+  PhaseTimer tr(2);
   pointStep.resize(allPoints.size());
   sos_ba_resubstitute(ba, x.data(), pointStep.data());
   for (size_t k = 0; k < allPoints.size(); k++) allPoints[k]->data->step = pointStep[k];
@@ -681,13 +711,23 @@ void FullSystem::setNewFrameEnergyTH() {  // FS/FullSystemOptimize.cpp:84-124
     const float e = h_newEnergyWO[r->packIdx];
     if (e >= 0 && r->target == newFrame) allResVec.push_back(e);
   }
-  if (allResVec.empty()) {
-    newFrame->frameEnergyTH = 12 * 12 * SOS_PATTERN_NUM;
-    return;
+  float nthValue;
+  if (ef->nthHook) {  // global order statistic over all shards
+    nthValue = ef->nthHook(ef->hookUser, allResVec.data(), (int)allResVec.size(), prm.frameEnergyTHN);
+    if (nthValue < 0) {
+      newFrame->frameEnergyTH = 12 * 12 * SOS_PATTERN_NUM;
+      return;
+    }
+  } else {
+    if (allResVec.empty()) {
+      newFrame->frameEnergyTH = 12 * 12 * SOS_PATTERN_NUM;
+      return;
+    }
+    const int nthIdx = (int)(prm.frameEnergyTHN * allResVec.size());
+    std::nth_element(allResVec.begin(), allResVec.begin() + nthIdx, allResVec.end());
+    nthValue = allResVec[nthIdx];
   }
-  const int nthIdx = (int)(prm.frameEnergyTHN * allResVec.size());
-  std::nth_element(allResVec.begin(), allResVec.begin() + nthIdx, allResVec.end());
-  const float nthElement = sqrtf(allResVec[nthIdx]);
+  const float nthElement = sqrtf(nthValue);
   newFrame->frameEnergyTH = nthElement * prm.frameEnergyTHFacMedian;
   newFrame->frameEnergyTH = 26.0f * prm.frameEnergyTHConstWeight + newFrame->frameEnergyTH * (1 - prm.frameEnergyTHConstWeight);
   newFrame->frameEnergyTH = newFrame->frameEnergyTH * newFrame->frameEnergyTH;
@@ -838,10 +878,11 @@ int FullSystem::prepare() {  // FS/FullSystemOptimize.cpp:316-344
 bool FullSystem::gnIteration(int iteration) {  // :358-413 with setting_forceAceptStep
   backupState();
   solveSystem(iteration, 1e-1);
-  const bool canbreak = doStepFromBackup(1, 1, 1, 1, 1);
-  ef->pushState(&HCalib, false);
-  linearizeAll(false);
-  applyRes();
+  bool canbreak;
+  { PhaseTimer t(3); canbreak = doStepFromBackup(1, 1, 1, 1, 1); }
+  { PhaseTimer t(4); ef->pushState(&HCalib, false); }
+  { PhaseTimer t(5); linearizeAll(false); }
+  { PhaseTimer t(6); applyRes(); }
   return canbreak;
 }
 
@@ -1186,6 +1227,18 @@ extern "C" int sosf_drop_points(sosf_system *s, const int32_t *pointIdx, int cou
 extern "C" int sosf_marginalize_frame(sosf_system *s, int frameIdx) {
   if (!s || frameIdx < 0 || frameIdx >= (int)s->fs->frameHessians.size()) return SOS_ERR_ARG;
   return s->fs->marginalizeFrame(s->fs->frameHessians[frameIdx]);
+}
+extern "C" int sosf_get_timing(double *phases8, int reset) {
+  if (phases8) std::memcpy(phases8, sos::g_phase, sizeof(double) * 8);
+  if (reset) std::memset(sos::g_phase, 0, sizeof(double) * 8);
+  return SOS_OK;
+}
+extern "C" int sosf_set_hooks(sosf_system *s, sosf_allreduce_fn ar, sosf_nth_fn nth, void *user) {
+  if (!s) return SOS_ERR_ARG;
+  s->fs->ef->allreduceHook = ar;
+  s->fs->ef->nthHook = nth;
+  s->fs->ef->hookUser = user;
+  return SOS_OK;
 }
 extern "C" sos_ctx *sosf_ctx(sosf_system *s) { return s ? s->fs->ctx : nullptr; }
 extern "C" sos_ba *sosf_ba(sosf_system *s) { return s ? s->fs->ef->ba : nullptr; }

@@ -193,6 +193,11 @@ class EnergyFunctional {  // OB/EnergyFunctional.h:52-154
   std::vector<EFResidual *> allResiduals;  // packing order
   std::vector<float> pointStep;            // last resubstitute result, packing order
 
+  // multi-GPU hooks (see include/sos_slam_host.h)
+  void (*allreduceHook)(void *, float *, size_t) = nullptr;
+  float (*nthHook)(void *, const float *, int, float) = nullptr;
+  void *hookUser = nullptr;
+
   sos_params prm;
   float cDeltaF[4];
   double cPrior[4];

@@ -142,7 +142,7 @@ class _Scene:
 
 
 def make_window(name: str = "W12", seed: int = SEED, noise_sigma: float = 1.0, state_noise: float = 3e-4,
-                idepth_noise: float = 0.002, **override) -> Window:
+                idepth_noise: float = 0.002, point_seed: int | None = None, **override) -> Window:
     cfg = dict(WINDOWS[name]) if name in WINDOWS else {}
     cfg.update(override)
     n, P, w, h = cfg["n"], cfg["P"], cfg["w"], cfg["h"]
@@ -177,7 +177,11 @@ def make_window(name: str = "W12", seed: int = SEED, noise_sigma: float = 1.0, s
         frames[i]["frameID"] = i
         frames[i]["frameEnergyTH"] = 8 * 8 * 8
 
-    # points: P/n per host at integer pixels
+    # points: P/n per host at integer pixels (point_seed: a different point set on the same frames, used to
+    # give every rank of a multi-GPU run its own shard)
+    rng_main = rng
+    if point_seed is not None:
+        rng = np.random.default_rng(point_seed)
     pts = np.zeros(P, dtype=POINT_DTYPE)
     per = [P // n + (1 if i < P % n else 0) for i in range(n)]
     k = 0
@@ -227,6 +231,7 @@ def make_window(name: str = "W12", seed: int = SEED, noise_sigma: float = 1.0, s
                 res_list.append((pi, hst, t_, RF_ISNEW, RES_IN, 0.0))
     resid = np.array(res_list, dtype=RESID_DTYPE) if res_list else np.zeros(0, dtype=RESID_DTYPE)
 
+    rng = rng_main
     dim = 4 + 8 * n
     A = rng.normal(0, 1.0, (dim, dim))
     HM = 10.0 * (A @ A.T) / dim + 100.0 * np.eye(dim)
