@@ -240,6 +240,23 @@ int sos_ba_acc_buffer(sos_ba *ba, float **dev_ptr, size_t *nfloats);
 int sos_ba_stitch(sos_ba *ba, double *H_A, double *b_A, double *H_L, double *b_L, double *H_sc,
                   double *b_sc, int *resInA, int *resInL);
 
+/* ---- fused per-iteration entry points (MI355X-first: two device round trips per Gauss-Newton iteration) ----
+ * sos_ba_gn_accumulate = accumulateAF_MT + accumulateLF_MT + accumulateSCF_MT + stitch with
+ * H_top = HL_top + HA_top, b_top = bL_top + bA_top (OB/EnergyFunctional.cpp:1040-1047, priors excluded);
+ * one packed device->host copy through pinned memory. */
+int sos_ba_gn_accumulate(sos_ba *ba, double *H_top, double *b_top, double *H_sc, double *b_sc, int *resInA,
+                         int *resInL);
+/* sos_ba_gn_step = resubstituteF_MT(x) (OB/EnergyFunctional.cpp:1182) + the point part of
+ * doStepFromBackup on the device (idepth += stepfacD*step; idepth_zero = idepth,
+ * FS/FullSystemOptimize.cpp:207-213) + setPrecalcValues/setDeltaF upload + linearizeAll(false)
+ * (+ applyRes_Reductor when applyRes != 0, FS/FullSystemOptimize.cpp:371,391-396).  x == NULL skips the
+ * back-substitution / point step.  Outputs (any may be NULL): energySum; newestEnergies = the
+ * state_NewEnergyWithOutlier >= 0 of the residuals targeting the newest frame (capacity >= R floats),
+ * what setNewFrameEnergyTH needs (FS/FullSystemOptimize.cpp:91-95); pointStep = PointHessian::step (P). */
+int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const sos_calib *calib, const sos_precalc *precalc,
+                   const float *adHTdeltaF, const float *cDeltaF, const float *frameEnergyTH, int applyRes,
+                   double *energySum, float *newestEnergies, int *newestCount, float *pointStep);
+
 /* per-point results of the accumulation: idepth_hessian (OB/AccumulatedSCHessian.cpp:50),
  * HdiF, bdSumF.  Each P floats, may be NULL. */
 int sos_ba_get_point_hessian(sos_ba *ba, float *idepth_hessian, float *HdiF, float *bdSumF);

@@ -21,8 +21,8 @@ HOST_SOURCES = ["host/sos_host.cpp"]
 HOST_LIB = os.path.join(CSRC, "libsos_host.so")
 
 HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared",
-               "-Wno-unused-value"]
-CXX_FLAGS = ["-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-pthread"]
+               "-fno-slp-vectorize", "-Wno-unused-value"]
+CXX_FLAGS = ["-O3", "-mavx2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-pthread"]
 
 
 def _stale(target, sources):
@@ -44,7 +44,8 @@ def hipcc_path():
 def build_hip(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
     if force or _stale(HIP_LIB, srcs):
-        cmd = [hipcc_path()] + HIPCC_FLAGS + ["-o", HIP_LIB] + srcs
+        extra = os.environ.get("SOS_HIPCC_EXTRA", "").split()  # experiment knob, e.g. -DSOS_LIN_WAVES=5
+        cmd = [hipcc_path()] + HIPCC_FLAGS + extra + ["-o", HIP_LIB] + srcs
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

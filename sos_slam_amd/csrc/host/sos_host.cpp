@@ -404,14 +404,16 @@ int EnergyFunctional::pushState(CalibHessian *HCalib, bool adjoints) {
                           adjoints ? adTarget.data() : nullptr, id.data(), idz.data(), dl.data());
 }
 
-void EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib) {  // :1029-1184, IMU off
+void EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib, bool deferResubstitute) {  // :1029-1184, IMU off
   lambda = 1e-5;
   const int n = nFrames, dim = SOS_CPARS + 8 * n;
   const size_t dd = (size_t)dim * dim;
-  MatXX HA(dd), HL(dd), Hsc(dd);
-  VecX bA(dim), bL(dim), bsc(dim);
+  MatXX HA(dd), HL, Hsc(dd);
+  VecX bA(dim), bL, bsc(dim);
   double t_acc0 = now_s();
   if (allreduceHook) {  // shard-local sums -> RCCL all-reduce of the packed fp32 blocks -> identical stitch on every rank
+    HL.assign(dd, 0.0);
+    bL.assign(dim, 0.0);
     float *dev = nullptr;
     size_t nfl = 0;
     sos_ba_accumulate_local(ba);
@@ -419,25 +421,25 @@ void EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib) { 
     sos_ctx_synchronize(ctx);
     allreduceHook(hookUser, dev, nfl);
     sos_ba_stitch(ba, HA.data(), bA.data(), HL.data(), bL.data(), Hsc.data(), bsc.data(), &resInA, &resInL);
-  } else {
-    sos_ba_accumulate(ba, HA.data(), bA.data(), HL.data(), bL.data(), Hsc.data(), bsc.data(), &resInA, &resInL);
+    for (size_t i = 0; i < dd; i++) HA[i] += HL[i];
+    for (int i = 0; i < dim; i++) bA[i] += bL[i];
+  } else {  // HA := HL_top + HA_top already summed by the library
+    sos_ba_gn_accumulate(ba, HA.data(), bA.data(), Hsc.data(), bsc.data(), &resInA, &resInL);
   }
   g_phase[0] += now_s() - t_acc0;
   double t_sol0 = now_s();
+  MatXX &H = HA;
+  VecX &b = bA;
   // priors of the L stitch (usePrior = true), OB/AccumulatedTopHessian.cpp:292-300
   for (int i = 0; i < 4; i++) {
-    HL[(size_t)i * dim + i] += cPrior[i];
-    bL[i] += cPrior[i] * (double)cDeltaF[i];
+    H[(size_t)i * dim + i] += cPrior[i];
+    b[i] += cPrior[i] * (double)cDeltaF[i];
   }
   for (int h = 0; h < n; h++)
     for (int i = 0; i < 8; i++) {
-      HL[(size_t)(4 + 8 * h + i) * dim + 4 + 8 * h + i] += frames[h]->prior[i];
-      bL[4 + 8 * h + i] += frames[h]->prior[i] * frames[h]->delta_prior[i];
+      H[(size_t)(4 + 8 * h + i) * dim + 4 + 8 * h + i] += frames[h]->prior[i];
+      b[4 + 8 * h + i] += frames[h]->prior[i] * frames[h]->delta_prior[i];
     }
-  MatXX H(dd);
-  VecX b(dim);
-  for (size_t i = 0; i < dd; i++) H[i] = HL[i] + HA[i];
-  for (int i = 0; i < dim; i++) b[i] = bL[i] + bA[i];
   const VecX delta = getStitchedDeltaF();
   for (int i = 0; i < dim; i++) {
     double s = bM[i];
@@ -465,6 +467,7 @@ void EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib) { 
     h->data->step[8] = h->data->step[9] = 0;
   }
   g_phase[1] += now_s() - t_sol0;
+  if (deferResubstitute) return;  // done by sos_ba_gn_step together with the next linearisation
   PhaseTimer tr(2);
   pointStep.resize(allPoints.size());
   sos_ba_resubstitute(ba, x.data(), pointStep.data());
@@ -711,6 +714,11 @@ void FullSystem::setNewFrameEnergyTH() {  // FS/FullSystemOptimize.cpp:84-124
     const float e = h_newEnergyWO[r->packIdx];
     if (e >= 0 && r->target == newFrame) allResVec.push_back(e);
   }
+  setNewFrameEnergyTH(allResVec);
+}
+
+void FullSystem::setNewFrameEnergyTH(std::vector<float> &allResVec) {
+  FrameHessian *newFrame = frameHessians.back();
   float nthValue;
   if (ef->nthHook) {  // global order statistic over all shards
     nthValue = ef->nthHook(ef->hookUser, allResVec.data(), (int)allResVec.size(), prm.frameEnergyTHN);
@@ -818,7 +826,7 @@ void FullSystem::backupState() {  // :260-269
   }
 }
 
-bool FullSystem::doStepFromBackup(float stepfacC, float stepfacT, float stepfacR, float stepfacA, float stepfacD) {
+bool FullSystem::doStepFromBackup(float stepfacC, float stepfacT, float stepfacR, float stepfacA, float stepfacD, bool pointsOnDevice) {
   double pstepfac[10];
   for (int i = 0; i < 3; i++) pstepfac[i] = stepfacT;
   for (int i = 3; i < 6; i++) pstepfac[i] = stepfacR;
@@ -836,11 +844,11 @@ bool FullSystem::doStepFromBackup(float stepfacC, float stepfacT, float stepfacR
     sumT += fh->step[0] * fh->step[0] + fh->step[1] * fh->step[1] + fh->step[2] * fh->step[2];
     sumR += fh->step[3] * fh->step[3] + fh->step[4] * fh->step[4] + fh->step[5] * fh->step[5];
     for (PointHessian *ph : fh->pointHessians) {
-      ph->setIdepth(ph->idepth_backup + stepfacD * ph->step);
+      if (!pointsOnDevice) ph->setIdepth(ph->idepth_backup + stepfacD * ph->step);
       sumID += ph->step * ph->step;
       sumNID += fabsf(ph->idepth_backup);
       numID++;
-      ph->setIdepthZero(ph->idepth_backup + stepfacD * ph->step);
+      if (!pointsOnDevice) ph->setIdepthZero(ph->idepth_backup + stepfacD * ph->step);
     }
   }
   const float nf = (float)frameHessians.size();
@@ -853,7 +861,7 @@ bool FullSystem::doStepFromBackup(float stepfacC, float stepfacT, float stepfacR
          sqrtf(sumR) < 0.00005 * setting_thOptIterations && sqrtf(sumT) * sumNID < 0.00005 * setting_thOptIterations;
 }
 
-void FullSystem::solveSystem(int iteration, double lambda) { ef->solveSystemF(iteration, lambda, &HCalib); }
+void FullSystem::solveSystem(int iteration, double lambda) { ef->solveSystemF(iteration, lambda, &HCalib, false); }
 
 int FullSystem::prepare() {  // FS/FullSystemOptimize.cpp:316-344
   activeResiduals.clear();
@@ -877,12 +885,36 @@ int FullSystem::prepare() {  // FS/FullSystemOptimize.cpp:316-344
 
 bool FullSystem::gnIteration(int iteration) {  // :358-413 with setting_forceAceptStep
   backupState();
-  solveSystem(iteration, 1e-1);
+  ef->solveSystemF(iteration, 1e-1, &HCalib, true);  // x, frame / calib steps; back-substitution deferred
   bool canbreak;
-  { PhaseTimer t(3); canbreak = doStepFromBackup(1, 1, 1, 1, 1); }
-  { PhaseTimer t(4); ef->pushState(&HCalib, false); }
-  { PhaseTimer t(5); linearizeAll(false); }
-  { PhaseTimer t(6); applyRes(); }
+  { PhaseTimer t(3); canbreak = doStepFromBackup(1, 1, 1, 1, 1, true); }
+  {
+    // resubstitute + point step (device) + new state upload + linearizeAll(false) + applyRes: one round trip
+    PhaseTimer t(5);
+    const int n = (int)frameHessians.size();
+    std::vector<sos_precalc> pc((size_t)n * n);
+    for (int h = 0; h < n; h++)
+      for (int tt = 0; tt < n; tt++) pc[(size_t)(h + n * tt)] = frameHessians[h]->targetPrecalc[tt].dev;
+    std::vector<float> th(n);
+    for (int i = 0; i < n; i++) th[i] = frameHessians[i]->frameEnergyTH;
+    const sos_calib cal = HCalib.toCalib();
+    newestE.resize(ef->allResiduals.size() + 1);
+    int cnt = 0;
+    double E = 0;
+    ef->pointStep.resize(ef->allPoints.size());
+    lastError = sos_ba_gn_step(ef->ba, ef->lastX.data(), 1.0f, &cal, pc.data(), ef->adHTdeltaF.data(), ef->cDeltaF, th.data(),
+                               1, &E, newestE.data(), &cnt, ef->pointStep.data());
+    newestE.resize(cnt);
+    // point part of doStepFromBackup on the host mirrors (FS/FullSystemOptimize.cpp:207-213)
+    for (size_t k = 0; k < ef->allPoints.size(); k++) {
+      PointHessian *ph = ef->allPoints[k]->data;
+      ph->step = ef->pointStep[k];
+      ph->setIdepth(ph->idepth_backup + 1.0f * ph->step);
+      ph->setIdepthZero(ph->idepth_backup + 1.0f * ph->step);
+      ef->allPoints[k]->deltaF = 0;
+    }
+    setNewFrameEnergyTH(newestE);
+  }
   return canbreak;
 }
 

@@ -168,7 +168,7 @@ class EnergyFunctional {  // OB/EnergyFunctional.h:52-154
   void removePoint(EFPoint *pt);
   void marginalizePointsF();
   void dropPointsF();
-  void solveSystemF(int iteration, double lambda, CalibHessian *HCalib);
+  void solveSystemF(int iteration, double lambda, CalibHessian *HCalib, bool deferResubstitute = false);
   double calcMEnergyF();
   double calcLEnergyF_MT();
   void makeIDX();
@@ -244,13 +244,15 @@ class FullSystem {
  private:
   double linearizeAll(bool fixLinearization);                 // :125-182
   void setNewFrameEnergyTH();                                 // :84-124
+  void setNewFrameEnergyTH(std::vector<float> &energiesOfNewestFrame);
   void applyRes();                                            // :79-83
   void backupState();                                         // :260-269
-  bool doStepFromBackup(float stepfacC, float stepfacT, float stepfacR, float stepfacA, float stepfacD);  // :185-257
+  bool doStepFromBackup(float stepfacC, float stepfacT, float stepfacR, float stepfacA, float stepfacD,
+                        bool pointsOnDevice = false);  // :185-257
   void solveSystem(int iteration, double lambda);             // :491-497
   std::vector<PointFrameResidual *> activeResiduals;
   std::vector<uint8_t> h_newState;
-  std::vector<float> h_newEnergy, h_newEnergyWO, h_center;
+  std::vector<float> h_newEnergy, h_newEnergyWO, h_center, newestE;
 };
 
 }  // namespace sos

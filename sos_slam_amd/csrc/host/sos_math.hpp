@@ -95,46 +95,59 @@ struct SE3 {
   }
 };
 
-// x = A^-1 b for symmetric A (n x n row-major) by LDL^T with symmetric pivoting; exact-zero pivots
-// contribute nothing (Eigen LDLT::solve semantics).
+// x = A^-1 b for symmetric A (n x n row-major) by LDL^T with symmetric pivoting on the largest |diagonal|;
+// exact-zero pivots contribute nothing (Eigen LDLT::solve semantics).  Works on the lower triangle with
+// contiguous, vectorisable inner loops (the (4+8n)-dim solve sits on the critical path of every iteration).
 inline void ldlt_solve(const std::vector<double> &A, const std::vector<double> &b, std::vector<double> &x, int n) {
   const size_t N = (size_t)n;
-  std::vector<double> M(A), L(N * N, 0.0), D(N), y(N);
+  std::vector<double> M(N * N), D(N), y(N), ck(N);
   std::vector<int> perm(N);
-  for (int i = 0; i < n; i++) perm[i] = i;
+  for (int i = 0; i < n; i++) {
+    perm[i] = i;
+    for (int j = 0; j <= i; j++) M[i * N + j] = A[i * N + j];  // lower triangle
+  }
+  auto at = [&](int i, int j) -> double & { return i >= j ? M[(size_t)i * N + j] : M[(size_t)j * N + i]; };
   for (int k = 0; k < n; k++) {
     int p = k;
     double best = std::fabs(M[k * N + k]);
     for (int i = k + 1; i < n; i++)
       if (std::fabs(M[i * N + i]) > best) { best = std::fabs(M[i * N + i]); p = i; }
-    if (p != k) {
-      for (int j = 0; j < n; j++) std::swap(M[k * N + j], M[p * N + j]);
-      for (int j = 0; j < n; j++) std::swap(M[j * N + k], M[j * N + p]);
-      for (int j = 0; j < k; j++) std::swap(L[k * N + j], L[p * N + j]);
+    if (p != k) {  // symmetric swap of rows/columns k and p within the lower triangle (L part included)
+      for (int j = 0; j < k; j++) std::swap(M[k * N + j], M[p * N + j]);
+      std::swap(M[k * N + k], M[p * N + p]);
+      for (int j = k + 1; j < p; j++) std::swap(at(j, k), at(p, j));
+      for (int j = p + 1; j < n; j++) std::swap(at(j, k), at(j, p));
       std::swap(perm[k], perm[p]);
     }
     const double d = M[k * N + k];
     D[k] = d;
-    L[k * N + k] = 1.0;
-    if (!(std::fabs(d) > 2.2250738585072014e-308)) continue;
-    for (int i = k + 1; i < n; i++) L[i * N + k] = M[i * N + k] / d;
+    if (!(std::fabs(d) > 2.2250738585072014e-308)) {
+      for (int i = k + 1; i < n; i++) M[i * N + k] = 0.0;
+      continue;
+    }
+    for (int i = k + 1; i < n; i++) ck[i] = M[i * N + k];
+    const double dinv = 1.0 / d;
     for (int i = k + 1; i < n; i++) {
-      const double lik = L[i * N + k];
-      if (lik == 0.0) continue;
-      for (int j = k + 1; j < n; j++) M[i * N + j] -= lik * M[k * N + j];
+      const double lik = ck[i] / d;
+      (void)dinv;
+      double *__restrict row = &M[i * N];
+      const double *__restrict c = ck.data();
+      for (int j = k + 1; j <= i; j++) row[j] -= lik * c[j];
+      row[k] = lik;  // L(i,k)
     }
   }
   for (int i = 0; i < n; i++) y[i] = b[perm[i]];
   for (int i = 0; i < n; i++) {
     double s = y[i];
-    for (int j = 0; j < i; j++) s -= L[i * N + j] * y[j];
+    const double *row = &M[i * N];
+    for (int j = 0; j < i; j++) s -= row[j] * y[j];
     y[i] = s;
   }
   for (int i = 0; i < n; i++) y[i] = (std::fabs(D[i]) > 2.2250738585072014e-308) ? y[i] / D[i] : 0.0;
-  for (int i = n - 1; i >= 0; i--) {
-    double s = y[i];
-    for (int j = i + 1; j < n; j++) s -= L[j * N + i] * y[j];
-    y[i] = s;
+  for (int i = n - 1; i >= 0; i--) {  // L^T z = y, column-oriented so the inner loop stays contiguous
+    const double yi = y[i];
+    const double *row = &M[i * N];
+    for (int j = 0; j < i; j++) y[j] -= row[j] * yi;
   }
   x.assign(N, 0.0);
   for (int i = 0; i < n; i++) x[perm[i]] = y[i];

@@ -47,13 +47,21 @@ struct BaDev {
   sos_point *pts;
   const int *s_point, *s_orig;
   uint8_t *s_flags, *s_state, *s_newstate;
-  float *s_energy, *s_newenergy, *s_newenergywo, *s_ret, *s_center, *s_rtz, *s_pterm;
+  float *s_energy, *s_newenergy, *s_newenergywo, *s_ret, *s_center, *s_rtz, *s_pterm;  // s_pterm: 8 floats / residual
   const int *t_pair;
   float *J, *JpJd;
   const int *p_begin, *p_list, *p_res_t;
   float *p_out;  // 16 floats per point
   uint8_t *o_newstate;
   float *o_newenergy, *o_newenergywo, *o_center;
+  // packed per-iteration outputs (sos_ba_gn_step): per-tile energy sums, energies of the residuals that
+  // target the newest frame (contiguous in the sorted order), point steps
+  double *tile_esum;
+  float *o_newest;
+  int newest_begin, newest_count;
+  const int2 *p_list2;  // per point residual list: (sorted index, xAd index = n*h + t)
+  float4 *r_geo;        // per sorted residual: u, v, idepth_scaled, idepth_zero_scaled of its point
+  const float *r_cw;    // per sorted residual: color[8], weights[8] of its point
 };
 
 #define PO_HDD_A 0
@@ -70,37 +78,57 @@ struct BaDev {
 // ------------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------------
-template <int N>
-__device__ __forceinline__ float row_shr(float v) {  // lane i reads lane i-N of its 16-lane row
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + N, 0xf, 0xf, false));
-}
-// ((((((v0+v1)+v2)+v3)+v4)+v5)+v6)+v7 over the 8 lanes of a pattern group; valid in lane 7 of the group
+// ((((((v0+v1)+v2)+v3)+v4)+v5)+v6)+v7 over the 8 lanes of a pattern group (the reference's sequential
+// pixel loop, FS/Residuals.cpp:177-243); valid in lane 7 of the group.  One fused v_add_f32_dpp per term:
+// lane i adds lane (i-k)'s value of its 16-lane row (row_shr:k, 0 beyond the row start).  hipcc does not fuse
+// __builtin_amdgcn_update_dpp into the add here (it emits mov 0 + mov_dpp + add), hence the asm block; the
+// leading s_nop covers the VALU-write -> DPP-read hazard on `v` (2 wait states).
 __device__ __forceinline__ float seqsum8(float v) {
-  float s = 0.0f + row_shr<7>(v);
-  s = s + row_shr<6>(v);
-  s = s + row_shr<5>(v);
-  s = s + row_shr<4>(v);
-  s = s + row_shr<3>(v);
-  s = s + row_shr<2>(v);
-  s = s + row_shr<1>(v);
-  s = s + v;
+  float s;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %1, %2 row_shr:7 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %0, %1, %0 row_shr:6 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %0, %1, %0 row_shr:5 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %0, %1, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %0, %1, %0 row_shr:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %0, %1, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_e32 %0, %0, %1"
+      : "=&v"(s)
+      : "v"(v), "v"(0.0f));
   return s;
 }
 
 // ================================================================================================
-// k_linearize: one 256-thread block = one tile of 32 residuals of ONE (host,target) pair;
-// 8 lanes per residual, one lane per pattern pixel.
+// k_linearize: one 256-thread block = one tile of 32 residuals of ONE (host,target) pair; 8 lanes per
+// residual, one lane per pattern pixel; lane 7 of each group additionally does the per-residual part
+// (FEJ centre projection, geometric Jacobians, classification, JpJdF).  The kernel is latency-bound at
+// window sizes of 10^4..10^5 residuals (a handful of blocks per CU), so the design minimises the number
+// of DEPENDENT memory levels: the point data is replicated per residual in sorted order (r_geo / r_cw,
+// exactly the 80 B "point record" of the algorithmic byte count), so the chain is
+//   {r_geo[s], r_cw[s]}  ||  {tile -> pair -> precalc (scalar loads)}  ->  projection -> 4 image taps.
+// The staged 72 x 32 tile leaves as one contiguous 9216-byte span of J.
 // ================================================================================================
 #define SJ_STRIDE 40  // LDS row stride (floats): == 8 mod 32 -> the 8x8 (pixel, residual) stores are 2-way at worst
 
-__global__ __launch_bounds__(256) void k_linearize(BaDev d, const float *__restrict__ frameTH) {
+#ifndef SOS_LIN_WAVES
+#define SOS_LIN_WAVES 4
+#endif
+__global__ __launch_bounds__(256, SOS_LIN_WAVES) void k_linearize(BaDev d, const float *__restrict__ frameTH, int doApply) {
   __shared__ float sJ[SOS_JPLANES * SJ_STRIDE];
+  __shared__ float sRet[SOS_TILE];
   __shared__ unsigned int sLin;
   const int tile = blockIdx.x;
   const int tid = threadIdx.x;
   const int rl = tid >> 3, idx = tid & 7;
   const int lane = tid & 63;
   const int s = tile * SOS_TILE + rl;
+  // independent vector loads first
+  const float4 geo = d.r_geo[s];                       // u, v, idepth, idepth_zero
+  const float color = d.r_cw[16 * (size_t)s + idx], pweight = d.r_cw[16 * (size_t)s + 8 + idx];
+  const unsigned flags = d.s_flags[s];
+  const int st = d.s_state[s];
   const int pair = d.t_pair[tile];
   const int hIdx = pair % d.n, tIdx = pair / d.n;
   const sos_precalc *pc = d.precalc + pair;
@@ -108,31 +136,9 @@ __global__ __launch_bounds__(256) void k_linearize(BaDev d, const float *__restr
   if (tid == 0) sLin = 0;
   __syncthreads();
 
-  const int p_raw = d.s_point[s];
-  const bool valid = p_raw >= 0;
-  const int p = valid ? p_raw : 0;
-  const unsigned flags = d.s_flags[s];
+  const bool valid = (flags & DF_VALID) != 0;
   const bool isLin = valid && (flags & DF_LINEARIZED);
-  const int st = d.s_state[s];
-  const float old_energy = d.s_energy[s];
-  const sos_point *pt = d.pts + p;
-  const float pu = pt->u, pv = pt->v, id = pt->idepth_scaled, idz = pt->idepth_zero_scaled;
-  const float color = pt->color[idx], pweight = pt->weights[idx];
-
-  const float fxl = d.calib.fxl, fyl = d.calib.fyl, cxl = d.calib.cxl, cyl = d.calib.cyl;
-  const float fxli = d.calib.fxli, fyli = d.calib.fyli;
-
-  // ---- centre projection with the FEJ pose / idepth (FS/ResidualProjections.h:52-73) -- all 8 lanes
-  const float KliP0 = (pu - cxl) * fxli;
-  const float KliP1 = (pv - cyl) * fyli;
-  const float ptp0 = pc->PRE_RTll_0[0] * KliP0 + pc->PRE_RTll_0[1] * KliP1 + pc->PRE_RTll_0[2] + pc->PRE_tTll_0[0] * idz;
-  const float ptp1 = pc->PRE_RTll_0[3] * KliP0 + pc->PRE_RTll_0[4] * KliP1 + pc->PRE_RTll_0[5] + pc->PRE_tTll_0[1] * idz;
-  const float ptp2 = pc->PRE_RTll_0[6] * KliP0 + pc->PRE_RTll_0[7] * KliP1 + pc->PRE_RTll_0[8] + pc->PRE_tTll_0[2] * idz;
-  const float drescale = 1.0f / ptp2;
-  const float new_idepth = idz * drescale;
-  const float cu = ptp0 * drescale, cv = ptp1 * drescale;
-  const float cKu = cu * fxl + cxl, cKv = cv * fyl + cyl;
-  const bool center_ok = (drescale > 0) && cKu > 1.1f && cKv > 1.1f && cKu < d.wM3G && cKv < d.hM3G;
+  const float pu = geo.x, pv = geo.y, id = geo.z, idz = geo.w;
 
   // ---- this lane's pattern pixel with the current pose / idepth (FS/ResidualProjections.h:43-50)
   const int px = (int)((0x21420312u >> (4 * idx)) & 0xf) - 2;  // {0,-1,1,-2,0,2,-1,0}
@@ -175,8 +181,13 @@ __global__ __launch_bounds__(256) void k_linearize(BaDev d, const float *__restr
   hw = hw * wgt;
   hit1 *= hw;
   hit2 *= hw;
-  const float resF = residual * hw;
-  const float JabF0 = drdA * hw;
+
+  // ---- per-pixel rows of the Jacobian -> LDS staging
+  sJ[(JP_RESF + idx) * SJ_STRIDE + rl] = residual * hw;
+  sJ[(JP_JIDX0 + idx) * SJ_STRIDE + rl] = hit1;
+  sJ[(JP_JIDX1 + idx) * SJ_STRIDE + rl] = hit2;
+  sJ[(JP_JAB0 + idx) * SJ_STRIDE + rl] = d.modeA < 0 ? 0.0f : drdA * hw;
+  sJ[(JP_JAB1 + idx) * SJ_STRIDE + rl] = d.modeB < 0 ? 0.0f : hw;
 
   const float energyLeft0 = seqsum8(e_i);
   const float JIdxJIdx_00 = seqsum8(hit1 * hit1);
@@ -191,16 +202,22 @@ __global__ __launch_bounds__(256) void k_linearize(BaDev d, const float *__restr
   const float JabJab_11 = seqsum8(hw * hw);
   const float wJI2_sum = seqsum8(hw * hw * (hit1 * hit1 + hit2 * hit2));
 
-  // ---- per-pixel rows of the Jacobian -> LDS staging
-  sJ[(JP_RESF + idx) * SJ_STRIDE + rl] = resF;
-  sJ[(JP_JIDX0 + idx) * SJ_STRIDE + rl] = hit1;
-  sJ[(JP_JIDX1 + idx) * SJ_STRIDE + rl] = hit2;
-  sJ[(JP_JAB0 + idx) * SJ_STRIDE + rl] = d.modeA < 0 ? 0.0f : JabF0;
-  sJ[(JP_JAB1 + idx) * SJ_STRIDE + rl] = d.modeB < 0 ? 0.0f : hw;
-
   if (idx == 7) {
-    // ---- geometric Jacobians (FS/Residuals.cpp:116-157)
+    const float fxl = d.calib.fxl, fyl = d.calib.fyl, cxl = d.calib.cxl, cyl = d.calib.cyl;
+    const float fxli = d.calib.fxli, fyli = d.calib.fyli;
     const float *R0 = pc->PRE_RTll_0, *t0 = pc->PRE_tTll_0;
+    // ---- centre projection with the FEJ pose / idepth (FS/ResidualProjections.h:52-73)
+    const float KliP0 = (pu - cxl) * fxli;
+    const float KliP1 = (pv - cyl) * fyli;
+    const float ptp0 = R0[0] * KliP0 + R0[1] * KliP1 + R0[2] + t0[0] * idz;
+    const float ptp1 = R0[3] * KliP0 + R0[4] * KliP1 + R0[5] + t0[1] * idz;
+    const float ptp2 = R0[6] * KliP0 + R0[7] * KliP1 + R0[8] + t0[2] * idz;
+    const float drescale = 1.0f / ptp2;
+    const float new_idepth = idz * drescale;
+    const float cu = ptp0 * drescale, cv = ptp1 * drescale;
+    const float cKu = cu * fxl + cxl, cKv = cv * fyl + cyl;
+    const bool center_ok = (drescale > 0) && cKu > 1.1f && cKv > 1.1f && cKu < d.wM3G && cKv < d.hM3G;
+    // ---- geometric Jacobians (FS/Residuals.cpp:116-157)
     const float d_d_x = drescale * (t0[0] - t0[2] * cu) * SOS_SCALE_IDEPTH * fxl;
     const float d_d_y = drescale * (t0[1] - t0[2] * cv) * SOS_SCALE_IDEPTH * fyl;
     float dCx2 = drescale * (R0[6] * cu - R0[0]);
@@ -260,7 +277,7 @@ __global__ __launch_bounds__(256) void k_linearize(BaDev d, const float *__restr
       atomicOr(&sLin, 1u << rl);
     } else if (st == SOS_RES_OOB || !center_ok || grp_oob) {
       newState = SOS_RES_OOB;
-      ret = old_energy;
+      ret = d.s_energy[s];
       newEnergy = d.s_newenergy[s];
     } else {
       float energyLeft = energyLeft0;
@@ -279,6 +296,15 @@ __global__ __launch_bounds__(256) void k_linearize(BaDev d, const float *__restr
     d.s_newenergy[s] = newEnergy;
     d.s_newenergywo[s] = newEnergyWO;
     d.s_ret[s] = ret;
+    sRet[rl] = ret;
+    if (d.o_newest && tIdx == d.n - 1) d.o_newest[s - d.newest_begin] = newEnergyWO;
+    bool activeAfter = (flags & DF_ACTIVE) != 0;
+    if (doApply && valid && !isLin && st != SOS_RES_OOB) {  // applyRes(true), FS/Residuals.cpp:304-321
+      activeAfter = newState == SOS_RES_IN;
+      d.s_flags[s] = (uint8_t)(activeAfter ? (flags | DF_ACTIVE) : (flags & ~DF_ACTIVE));
+      d.s_state[s] = (uint8_t)newState;
+      d.s_energy[s] = newEnergy;
+    }
     const bool wrote_center = valid && !isLin && st != SOS_RES_OOB && center_ok;
     if (wrote_center) {
       d.s_center[3 * s + 0] = cKu;
@@ -298,6 +324,9 @@ __global__ __launch_bounds__(256) void k_linearize(BaDev d, const float *__restr
       o1.y = dxi_x[5] * v0 + dxi_y[5] * v1;
       o1.z = JabJIdx_00 * d_d_x + JabJIdx_01 * d_d_y;
       o1.w = JabJIdx_10 * d_d_x + JabJIdx_11 * d_d_y;
+      // JpJd holds EFResidual::JpJdF while the residual is active and zeros otherwise, so the Schur
+      // and back-substitution kernels need no flag lookups (x - 0 == x exactly)
+      if (doApply && !activeAfter) o0 = o1 = make_float4(0.f, 0.f, 0.f, 0.f);
       float4 *jp = reinterpret_cast<float4 *>(d.JpJd + 8 * (size_t)s);
       jp[0] = o0;
       jp[1] = o1;
@@ -315,6 +344,12 @@ __global__ __launch_bounds__(256) void k_linearize(BaDev d, const float *__restr
     }
   }
   __syncthreads();
+  if (tid < 64 && d.tile_esum) {  // returned energies of the tile: fp64 butterfly over the 32 residuals
+    double a = (tid < SOS_TILE) ? (double)sRet[tid] : 0.0;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (tid == 0) d.tile_esum[tile] = a;
+  }
 
   // ---- copy the staged tile out: 72 rows x 128 B, contiguous 9216 B span of J
   float *Jt = d.J + (size_t)tile * SOS_TILE_FLOATS;
@@ -364,6 +399,10 @@ __global__ void k_apply_res(BaDev d) {
   d.s_flags[s] = (uint8_t)f;
   d.s_state[s] = (uint8_t)ns;
   d.s_energy[s] = d.s_newenergy[s];
+  if (ns != SOS_RES_IN) {
+    float4 *jp = reinterpret_cast<float4 *>(d.JpJd + 8 * (size_t)s);
+    jp[0] = jp[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 }
 
 __global__ void k_reset_oob(BaDev d) {
@@ -472,11 +511,18 @@ __global__ __launch_bounds__(256) void k_top_accumulate(BaDev d, int tile0, int 
     const float Ji2_Jpdd0 = a * Jpdd0 + b * Jpdd1;
     const float Ji2_Jpdd1 = b * Jpdd0 + c * Jpdd1;
     if (have) {
-      float *pt = d.s_pterm + 6 * (size_t)ss;
-      pt[0] = use ? Ji2_Jpdd0 * Jpdd0 + Ji2_Jpdd1 * Jpdd1 : 0.f;
-      pt[1] = use ? JI_r0 * Jpdd0 + JI_r1 * Jpdd1 : 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; i++) pt[2 + i] = use ? x[i] * Ji2_Jpdd0 + y[i] * Ji2_Jpdd1 : 0.f;
+      float4 p0, p1;
+      p0.x = use ? Ji2_Jpdd0 * Jpdd0 + Ji2_Jpdd1 * Jpdd1 : 0.f;
+      p0.y = use ? JI_r0 * Jpdd0 + JI_r1 * Jpdd1 : 0.f;
+      p0.z = use ? x[0] * Ji2_Jpdd0 + y[0] * Ji2_Jpdd1 : 0.f;
+      p0.w = use ? x[1] * Ji2_Jpdd0 + y[1] * Ji2_Jpdd1 : 0.f;
+      p1.x = use ? x[2] * Ji2_Jpdd0 + y[2] * Ji2_Jpdd1 : 0.f;
+      p1.y = use ? x[3] * Ji2_Jpdd0 + y[3] * Ji2_Jpdd1 : 0.f;
+      p1.z = use ? 1.f : 0.f;                                   // counts towards ngoodres
+      p1.w = (mode != 0) ? 1.f : 0.f;                           // goes to the *_accLF sums
+      float4 *pt = reinterpret_cast<float4 *>(d.s_pterm + 8 * (size_t)ss);
+      pt[0] = p0;
+      pt[1] = p1;
     }
   }
 
@@ -520,105 +566,183 @@ __global__ __launch_bounds__(256) void k_top_accumulate(BaDev d, int tile0, int 
   (void)top_cnt;
 }
 
-// per (mode, pair): sum the tile partials in fp64 (as the reference sums its per-thread accumulators,
-// OB/AccumulatedTopHessian.cpp:252-259) and store the fp32 block into the packed accumulator buffer
-__global__ void k_reduce_top(const float *__restrict__ top_part, const int *__restrict__ pair_tile_begin,
-                             float *__restrict__ out /* npairs*91 */, float *__restrict__ nres_out) {
-  const int pair = blockIdx.x;
-  const int k = threadIdx.x;  // 0..95
-  const int t0 = pair_tile_begin[pair], t1 = pair_tile_begin[pair + 1];
-  double a = 0;
-  for (int t = t0; t < t1; t++) a += (double)top_part[(size_t)t * SOS_TOPN + k];
-  if (k < 91) out[(size_t)pair * 91 + k] = (float)a;
-  if (k == 91) atomicAdd(nres_out, (float)a);  // small integers: exact and order-independent
+// ================================================================================================
+// k_reduce_all: ONE launch that (a) sums the tile partials of every (mode, pair) in fp64 (as the
+// reference sums its per-thread accumulators, OB/AccumulatedTopHessian.cpp:252-259) into the packed
+// fp32 accumulator, (b) sums the Gram partials per host and scatters them into accD / accE / accEB,
+// (c) Hcc / bc, (d) the residual counts.  Block roles are selected by blockIdx ranges.
+// ================================================================================================
+struct ReduceArgs {
+  const float *top_part;
+  const int *pair_tile_begin;  // [2*n*n + 1]
+  const float *gram_part;
+  const int *host_chunk_begin;  // [n + 1]
+  int n, Dm, nchunks, nmodes;
+  int b_top, b_sc, b_tail;  // number of blocks per role
+  float *accTop;            // nmodes * n*n * 91
+  float *accD, *accE, *accEB, *accHcc, *accbc, *nres;
+};
+
+__global__ __launch_bounds__(128) void k_reduce_all(ReduceArgs a) {
+  int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int n = a.n;
+  if (b < a.b_top) {  // ---- (a) one block per (mode, pair)
+    if (tid >= SOS_TOPN) return;
+    const int t0 = a.pair_tile_begin[b], t1 = a.pair_tile_begin[b + 1];
+    double s = 0;
+    for (int t = t0; t < t1; t++) s += (double)a.top_part[(size_t)t * SOS_TOPN + tid];
+    if (tid < 91) a.accTop[(size_t)b * 91 + tid] = (float)s;
+    return;
+  }
+  b -= a.b_top;
+  if (b < a.b_sc) {  // ---- (b) Gram sub-blocks of host h
+    const int cols = 8 * n + 5, per_host = 8 * n * cols;
+    const int e = b * 128 + tid;
+    if (e >= n * per_host) return;
+    const int h = e / per_host, q = e - h * per_host;
+    const int r = q / cols, c = q - r * cols;
+    double s = 0;
+    for (int k = a.host_chunk_begin[h]; k < a.host_chunk_begin[h + 1]; k++)
+      s += (double)a.gram_part[(size_t)k * a.Dm * a.Dm + (size_t)r * a.Dm + c];
+    const int t1 = r >> 3, i = r & 7;
+    if (c < 8 * n) {
+      const int t2 = c >> 3, j = c & 7;
+      a.accD[(size_t)(h + n * t1 + n * n * t2) * 64 + i * 8 + j] = (float)s;
+    } else if (c < 8 * n + 4) {
+      a.accE[(size_t)(h + n * t1) * 32 + i * 4 + (c - 8 * n)] = (float)s;
+    } else {
+      a.accEB[(size_t)(h + n * t1) * 8 + i] = (float)s;
+    }
+    return;
+  }
+  // ---- (c)+(d) tail blocks: one block per scalar (16 Hcc + 4 bc + nmodes counts), strided loads and a
+  // fixed-shape tree in fp64 (a single thread walking 10^2..10^3 dependent-latency loads costs 100s of us)
+  b -= a.b_sc;
+  __shared__ double sm[128];
+  double v = 0;
+  if (b < 20) {
+    const int r = 8 * n + (b < 16 ? (b >> 2) : (b - 16)), c = 8 * n + (b < 16 ? (b & 3) : 4);
+    for (int k = tid; k < a.nchunks; k += 128) v += (double)a.gram_part[(size_t)k * a.Dm * a.Dm + (size_t)r * a.Dm + c];
+  } else {
+    const int m = b - 20;
+    const int t0 = a.pair_tile_begin[m * n * n], t1 = a.pair_tile_begin[(m + 1) * n * n];
+    for (int t = t0 + tid; t < t1; t += 128) v += (double)a.top_part[(size_t)t * SOS_TOPN + 91];
+  }
+  sm[tid] = v;
+  __syncthreads();
+  for (int o = 64; o > 0; o >>= 1) {
+    if (tid < o) sm[tid] += sm[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (b < 16) a.accHcc[b] = (float)sm[0];
+    else if (b < 20) a.accbc[b - 16] = (float)sm[0];
+    else a.nres[b - 20] = (float)sm[0];
+  }
 }
 
 // ================================================================================================
-// k_point_prep: one thread per point, residuals visited in EFPoint::residualsAll order
+// k_point_prep: one thread per point, residuals visited in EFPoint::residualsAll order.  The loop is
+// unrolled by 4 with all loads of a group issued before the (order-preserving) accumulation.
 // ================================================================================================
-__global__ void k_point_prep(BaDev d, int shiftPriorToZero, const int *__restrict__ plist, int count, int margMode) {
+__global__ void k_point_prep(BaDev d, int shiftPriorToZero, const int *__restrict__ plist, int count) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   const int p = plist ? plist[i] : i;
   float HddA = 0, bdA = 0, HcdA[4] = {0, 0, 0, 0}, HddL = 0, bdL = 0, HcdL[4] = {0, 0, 0, 0};
-  int ngood = 0;
-  for (int q = d.p_begin[p]; q < d.p_begin[p + 1]; q++) {
-    const int s = d.p_list[q];
-    const unsigned f = d.s_flags[s];
-    if (!(f & DF_ACTIVE)) continue;
-    ngood++;
-    const float *pt = d.s_pterm + 6 * (size_t)s;
-    if ((f & DF_LINEARIZED) || margMode) {
-      HddL += pt[0];
-      bdL += pt[1];
-      for (int k = 0; k < 4; k++) HcdL[k] += pt[2 + k];
-    } else {
-      HddA += pt[0];
-      bdA += pt[1];
-      for (int k = 0; k < 4; k++) HcdA[k] += pt[2 + k];
+  float ngood = 0;
+  const int q0 = d.p_begin[p], q1 = d.p_begin[p + 1];
+  for (int q = q0; q < q1; q += 4) {
+    float4 a[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int qq = min(q + k, q1 - 1);
+      const int s = d.p_list2[qq].x;
+      const float4 *pt = reinterpret_cast<const float4 *>(d.s_pterm + 8 * (size_t)s);
+      a[k] = pt[0];
+      b[k] = pt[1];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (q + k >= q1) break;
+      if (b[k].z == 0.f) continue;  // not active
+      ngood += 1.f;
+      if (b[k].w != 0.f) {
+        HddL += a[k].x; bdL += a[k].y;
+        HcdL[0] += a[k].z; HcdL[1] += a[k].w; HcdL[2] += b[k].x; HcdL[3] += b[k].y;
+      } else {
+        HddA += a[k].x; bdA += a[k].y;
+        HcdA[0] += a[k].z; HcdA[1] += a[k].w; HcdA[2] += b[k].x; HcdA[3] += b[k].y;
+      }
     }
   }
   float *o = d.p_out + 16 * (size_t)p;
-  o[PO_HDD_A] = HddA;
-  o[PO_BD_A] = bdA;
-  o[PO_HDD_L] = HddL;
-  o[PO_BD_L] = bdL;
-  for (int k = 0; k < 4; k++) { o[PO_HCD_A + k] = HcdA[k]; o[PO_HCD_L + k] = HcdL[k]; }
-  if (ngood == 0) {  // OB/AccumulatedSCHessian.cpp:34-44
-    o[PO_HDI] = 0;
-    o[PO_BDSUM] = 0;
-    o[PO_IDH] = 0;
-    return;
+  float4 o0, o1, o2, o3;
+  o0.x = HddA; o0.y = bdA; o0.z = HcdA[0]; o0.w = HcdA[1];
+  o1.x = HcdA[2]; o1.y = HcdA[3]; o1.z = HddL; o1.w = bdL;
+  o2.x = HcdL[0]; o2.y = HcdL[1]; o2.z = HcdL[2]; o2.w = HcdL[3];
+  o3.w = o[PO_STEP];
+  if (ngood == 0.f) {  // OB/AccumulatedSCHessian.cpp:34-44
+    o3.x = 0; o3.y = 0; o3.z = 0;
+  } else {
+    const sos_point *pt = d.pts + p;
+    float H = HddA + HddL + pt->priorF;
+    if (H < 1e-10) H = 1e-10;
+    o3.z = H;
+    o3.x = (float)(1.0 / (double)H);
+    float bdSum = bdA + bdL;
+    if (shiftPriorToZero) bdSum += pt->priorF * pt->deltaF;
+    o3.y = bdSum;
   }
-  const sos_point *pt = d.pts + p;
-  float H = HddA + HddL + pt->priorF;
-  if (H < 1e-10) H = 1e-10;
-  o[PO_IDH] = H;
-  o[PO_HDI] = (float)(1.0 / (double)H);
-  float bdSum = bdA + bdL;
-  if (shiftPriorToZero) bdSum += pt->priorF * pt->deltaF;
-  o[PO_BDSUM] = bdSum;
+  float4 *ov = reinterpret_cast<float4 *>(o);
+  ov[0] = o0; ov[1] = o1; ov[2] = o2; ov[3] = o3;
 }
 
 // ================================================================================================
 // k_sc_gram: G = sum_p Hdi_p e_p e_p^T with e_p = [JpJdF(p,t=0..n-1) (8n) | Hcd (4) | bdSum | 0...]
-// over a chunk of 64 points of one host.  The D / E / EB / Hcc / bc accumulators of
+// over a chunk of SOS_GC points of one host.  The D / E / EB / Hcc / bc accumulators of
 // AccumulatedSCHessianSSE::addPoint (OB/AccumulatedSCHessian.cpp:57-78) are sub-blocks of G.
 // v_mfma_f32_16x16x4_f32: K = points.  4 waves share the Dm/16 x Dm/16 output tiles.
+// JpJd rows of inactive residuals are zero (see k_linearize / k_apply_res), so no flag lookups.
 // ================================================================================================
+#define SOS_GC 32
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void k_sc_gram(BaDev d, const int *__restrict__ chunk_pt /* nchunks*64 point ids */,
+__global__ __launch_bounds__(256) void k_sc_gram(BaDev d, const int *__restrict__ chunk_pt /* nchunks*SOS_GC point ids */,
                                                  int Dm, int ld, float *__restrict__ gram_part) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *A = smem;              // [64][ld]
-  float *sHdi = smem + 64 * ld; // [64]
+  float *A = smem;                   // [SOS_GC][ld]
+  float *sHdi = smem + SOS_GC * ld;  // [SOS_GC]
   const int blk = blockIdx.x, tid = threadIdx.x;
   const int n = d.n;
-  for (int q = tid; q < 64 * ld; q += 256) A[q] = 0.f;
+  for (int q = tid; q < SOS_GC * ld / 4; q += 256) reinterpret_cast<float4 *>(A)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
   // stage: thread per (point, target)
-  for (int q = tid; q < 64 * (n + 1); q += 256) {
+  for (int q = tid; q < SOS_GC * (n + 1); q += 256) {
     const int pl = q / (n + 1), t = q - pl * (n + 1);
-    const int p = chunk_pt[blk * 64 + pl];
+    const int p = chunk_pt[blk * SOS_GC + pl];
     if (p < 0) {
       if (t == n) sHdi[pl] = 0.f;
       continue;
     }
-    const float *po = d.p_out + 16 * (size_t)p;
     if (t == n) {
-      sHdi[pl] = po[PO_HDI];
+      const float4 *po = reinterpret_cast<const float4 *>(d.p_out + 16 * (size_t)p);
+      const float4 v0 = po[0], v1 = po[1], v2 = po[2], v3 = po[3];
+      sHdi[pl] = v3.x;
       float *row = A + pl * ld + 8 * n;
-      for (int k = 0; k < 4; k++) row[k] = po[PO_HCD_A + k] + po[PO_HCD_L + k];
-      row[4] = po[PO_BDSUM];
+      row[0] = v0.z + v2.x;  // Hcd_accAF + Hcd_accLF
+      row[1] = v0.w + v2.y;
+      row[2] = v1.x + v2.z;
+      row[3] = v1.y + v2.w;
+      row[4] = v3.y;         // bdSumF
     } else {
       const int s = d.p_res_t[(size_t)p * n + t];
-      if (s >= 0 && (d.s_flags[s] & DF_ACTIVE)) {
+      if (s >= 0) {
         const float4 *jp = reinterpret_cast<const float4 *>(d.JpJd + 8 * (size_t)s);
-        const float4 v0 = jp[0], v1 = jp[1];
-        float *row = A + pl * ld + 8 * t;
-        row[0] = v0.x; row[1] = v0.y; row[2] = v0.z; row[3] = v0.w;
-        row[4] = v1.x; row[5] = v1.y; row[6] = v1.z; row[7] = v1.w;
+        float4 *row = reinterpret_cast<float4 *>(A + pl * ld + 8 * t);
+        row[0] = jp[0];
+        row[1] = jp[1];
       }
     }
   }
@@ -626,55 +750,25 @@ __global__ __launch_bounds__(256) void k_sc_gram(BaDev d, const int *__restrict_
   const int wave = tid >> 6, lane = tid & 63;
   const int T = Dm >> 4;
   const int kq = lane >> 4, col = lane & 15;
+  float *g = gram_part + (size_t)blk * Dm * Dm;
   for (int tile = wave; tile < T * T; tile += 4) {
     const int m0 = (tile / T) << 4, n0 = (tile % T) << 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int kk = 0; kk < 16; kk++) {
+#pragma unroll
+    for (int kk = 0; kk < SOS_GC / 4; kk++) {
       const int k = kk * 4 + kq;
       const float av = sHdi[k] * A[k * ld + m0 + col];
       const float bv = A[k * ld + n0 + col];
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
     }
-    float *g = gram_part + (size_t)blk * Dm * Dm;
 #pragma unroll
     for (int rgi = 0; rgi < 4; rgi++) g[(size_t)(m0 + kq * 4 + rgi) * Dm + n0 + col] = acc[rgi];
   }
 }
 
-// sum chunk partials per host in fp64 and scatter into the packed accD / accE / accEB / Hcc / bc
-__global__ void k_reduce_sc(const float *__restrict__ gram_part, const int *__restrict__ host_chunk_begin, int n,
-                            int Dm, int nchunks, float *__restrict__ accD, float *__restrict__ accE,
-                            float *__restrict__ accEB, float *__restrict__ accHcc, float *__restrict__ accbc) {
-  const int h = blockIdx.y;  // n hosts, + 1 extra block row (h == n) for Hcc / bc over ALL chunks
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (h < n) {
-    const int rows = 8 * n, cols = 8 * n + 5;
-    if (e >= rows * cols) return;
-    const int r = e / cols, c = e - r * cols;
-    double a = 0;
-    for (int k = host_chunk_begin[h]; k < host_chunk_begin[h + 1]; k++) a += (double)gram_part[(size_t)k * Dm * Dm + (size_t)r * Dm + c];
-    const int t1 = r >> 3, i = r & 7;
-    if (c < 8 * n) {
-      const int t2 = c >> 3, j = c & 7;
-      accD[(size_t)(h + n * t1 + n * n * t2) * 64 + i * 8 + j] = (float)a;
-    } else if (c < 8 * n + 4) {
-      accE[(size_t)(h + n * t1) * 32 + i * 4 + (c - 8 * n)] = (float)a;
-    } else {
-      accEB[(size_t)(h + n * t1) * 8 + i] = (float)a;
-    }
-  } else {
-    if (e >= 20) return;
-    const int r = 8 * n + (e < 16 ? (e >> 2) : (e - 16)), c = 8 * n + (e < 16 ? (e & 3) : 4);
-    double a = 0;
-    for (int k = 0; k < nchunks; k++) a += (double)gram_part[(size_t)k * Dm * Dm + (size_t)r * Dm + c];
-    if (e < 16) accHcc[e] = (float)a;
-    else accbc[e - 16] = (float)a;
-  }
-}
-
 // ================================================================================================
-// fp64 stitch from the packed fp32 accumulators
+// fp64 stitch from the packed fp32 accumulators, two stages each (products per pair / triple in
+// parallel, then fixed-order sums per output block: deterministic, no atomics)
 // ================================================================================================
 __device__ __forceinline__ int top_idx(int i, int j) {  // 13x13 symmetric -> index into the 91 uniques
   if (i > j) { const int t = i; i = j; j = t; }
@@ -683,115 +777,205 @@ __device__ __forceinline__ int top_idx(int i, int j) {  // 13x13 symmetric -> in
   return 85 + (i == 10 ? (j - 10) : (i == 11 ? 3 + (j - 11) : 5));
 }
 
-// grid: (n*(n+1)/2 + 1, nmodes); block 64.  H_out/b_out hold nmodes consecutive (dim*dim | dim) results.
-__global__ __launch_bounds__(64) void k_stitch_top(int n, const float *__restrict__ acc_top, const double *__restrict__ adHost,
-                                                   const double *__restrict__ adTarget, double *__restrict__ H_out,
-                                                   double *__restrict__ b_out) {
-  __shared__ double sB[64], sA[64], sA2[64], sT[64], sBpc[32], sbp[8];
+#define SOS_TOPC 272  // doubles per pair: P1 P2 P3 (64 each), Hc1 Hc2 (32 each), b1 b2 (8 each)
+
+// stage 1, grid (n*n, nmodes): pair (h,t) -> AH B AH^T, AT B AT^T, AH B AT^T, AH Bpc, AT Bpc, AH bp, AT bp
+// (OB/AccumulatedTopHessian.cpp:261-288)
+__global__ __launch_bounds__(64) void k_stitch_top_pairs(int n, const float *__restrict__ acc_top, const double *__restrict__ adHost,
+                                                         const double *__restrict__ adTarget, double *__restrict__ C,
+                                                         double *__restrict__ Ccc) {
+  __shared__ double sB[64], sAH[64], sAT[64], sT1[64], sT2[64], sBpc[32], sbp[8];
+  const int tid = threadIdx.x, i = tid >> 3, j = tid & 7;
+  const int pidx = blockIdx.x;
+  if (pidx >= n * n) {  // 20 extra blocks: H_cc (16) and b_c (4) = sums over all pairs, strided loads + fp64 tree
+    const int v = pidx - n * n;
+    const int r = v < 16 ? (v >> 2) : (v - 16), c = v < 16 ? (v & 3) : 12;
+    const float *acc = acc_top + (size_t)blockIdx.y * n * n * 91;
+    double sv = 0;
+    for (int k = tid; k < n * n; k += 64) sv += (double)acc[(size_t)k * 91 + top_idx(r, c)];
+    sT1[tid] = sv;
+    __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) {
+      if (tid < o) sT1[tid] += sT1[tid + o];
+      __syncthreads();
+    }
+    if (tid == 0) Ccc[(size_t)blockIdx.y * 20 + v] = sT1[0];
+    return;
+  }
+  const float *blk = acc_top + ((size_t)blockIdx.y * n * n + pidx) * 91;
+  double *out = C + ((size_t)blockIdx.y * n * n + pidx) * SOS_TOPC;
+  sB[tid] = (double)blk[top_idx(4 + i, 4 + j)];
+  sAH[tid] = adHost[(size_t)pidx * 64 + tid];
+  sAT[tid] = adTarget[(size_t)pidx * 64 + tid];
+  if (tid < 32) sBpc[tid] = (double)blk[top_idx(4 + (tid >> 2), tid & 3)];
+  if (tid < 8) sbp[tid] = (double)blk[top_idx(4 + tid, 12)];
+  __syncthreads();
+  double t1 = 0, t2 = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    t1 += sAH[i * 8 + k] * sB[k * 8 + j];
+    t2 += sAT[i * 8 + k] * sB[k * 8 + j];
+  }
+  sT1[tid] = t1;
+  sT2[tid] = t2;
+  __syncthreads();
+  double p1 = 0, p2 = 0, p3 = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    p1 += sT1[i * 8 + k] * sAH[j * 8 + k];
+    p2 += sT2[i * 8 + k] * sAT[j * 8 + k];
+    p3 += sT1[i * 8 + k] * sAT[j * 8 + k];
+  }
+  out[tid] = p1;
+  out[64 + tid] = p2;
+  out[128 + tid] = p3;
+  if (tid < 32) {
+    const int r = tid >> 2, c = tid & 3;
+    double h1 = 0, h2 = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      h1 += sAH[r * 8 + k] * sBpc[k * 4 + c];
+      h2 += sAT[r * 8 + k] * sBpc[k * 4 + c];
+    }
+    out[192 + tid] = h1;
+    out[224 + tid] = h2;
+  }
+  if (tid < 8) {
+    double b1 = 0, b2 = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      b1 += sAH[tid * 8 + k] * sbp[k];
+      b2 += sAT[tid * 8 + k] * sbp[k];
+    }
+    out[256 + tid] = b1;
+    out[264 + tid] = b2;
+  }
+}
+
+// stage 2, grid (n*(n+1)/2 + 1, nmodes): fixed-order sums per output block + symmetrisation
+// (OB/AccumulatedTopHessian.h:113-126).  Hb = per mode [dim*dim H | dim b].
+__global__ __launch_bounds__(64) void k_stitch_top_sum(int n, const double *__restrict__ Ccc, const double *__restrict__ C,
+                                                       double *__restrict__ Hb, size_t mode_stride) {
   const int dim = 4 + 8 * n;
   const int tid = threadIdx.x, i = tid >> 3, j = tid & 7;
-  const float *acc = acc_top + (size_t)blockIdx.y * n * n * 91;
-  double *H = H_out + (size_t)blockIdx.y * dim * dim;
-  double *bv = b_out + (size_t)blockIdx.y * dim;
+  const double *Cm = C + (size_t)blockIdx.y * n * n * SOS_TOPC;
+  double *H = Hb + (size_t)blockIdx.y * mode_stride;
+  double *bv = H + (size_t)dim * dim;
   const int nblk = n * (n + 1) / 2;
-  if ((int)blockIdx.x == nblk) {  // calib-calib block and calib b
+  if ((int)blockIdx.x == nblk) {
     if (tid < 20) {
-      const int r = tid < 16 ? (tid >> 2) : (tid - 16), c = tid < 16 ? (tid & 3) : 12;
-      double a = 0;
-      for (int k = 0; k < n * n; k++) a += (double)acc[(size_t)k * 91 + top_idx(r, c)];
-      if (tid < 16) H[(size_t)r * dim + c] = a;
-      else bv[r] = a;
+      const double sv = Ccc[(size_t)blockIdx.y * 20 + tid];
+      if (tid < 16) H[(size_t)(tid >> 2) * dim + (tid & 3)] = sv;
+      else bv[tid - 16] = sv;
     }
     return;
   }
-  // decode (a <= bb)
   int a = 0, rem = blockIdx.x;
   while (rem >= n - a) { rem -= n - a; a++; }
   const int bb = a + rem;
   if (a == bb) {
-    double accHH = 0, accHc = 0, accb = 0;
-    for (int q = 0; q < 2 * n; q++) {
-      const int h = q < n ? a : q - n, t = q < n ? q : a;
-      if (q >= n && h == a) continue;  // pair (a,a) already visited
-      const int pidx = h + n * t;
-      const float *blk = acc + (size_t)pidx * 91;
-      const double *Ad = (q < n ? adHost : adTarget) + (size_t)pidx * 64;
-      sB[tid] = (double)blk[top_idx(4 + i, 4 + j)];
-      sA[tid] = Ad[tid];
-      if (tid < 32) sBpc[tid] = (double)blk[top_idx(4 + (tid >> 2), tid & 3)];
-      if (tid < 8) sbp[tid] = (double)blk[top_idx(4 + tid, 12)];
-      __syncthreads();
-      double tv = 0;
-      for (int k = 0; k < 8; k++) tv += sA[i * 8 + k] * sB[k * 8 + j];
-      sT[tid] = tv;
-      __syncthreads();
-      for (int k = 0; k < 8; k++) accHH += sT[i * 8 + k] * sA[j * 8 + k];
-      if (tid < 32) {
-        const int r = tid >> 2, c = tid & 3;
-        for (int k = 0; k < 8; k++) accHc += sA[r * 8 + k] * sBpc[k * 4 + c];
-      }
-      if (tid < 8)
-        for (int k = 0; k < 8; k++) accb += sA[tid * 8 + k] * sbp[k];
-      __syncthreads();
+    double sH = 0, sHc = 0, sb = 0;
+    // fixed order: pairs (a,t) t = 0..n-1 (host side), then pairs (h,a) h = 0..n-1 (target side; (a,a) is empty)
+    const int hc = tid & 31, bc_ = tid & 7;
+#pragma unroll 4
+    for (int t = 0; t < n; t++) {
+      const double *c = Cm + (size_t)(a + n * t) * SOS_TOPC;
+      const double v0 = c[tid], v1 = c[192 + hc], v2 = c[256 + bc_];
+      sH += v0; sHc += v1; sb += v2;
     }
-    H[(size_t)(4 + 8 * a + i) * dim + 4 + 8 * a + j] = accHH;
+#pragma unroll 4
+    for (int h = 0; h < n; h++) {
+      const double *c = Cm + (size_t)(h + n * a) * SOS_TOPC;
+      const double v0 = c[64 + tid], v1 = c[224 + hc], v2 = c[264 + bc_];
+      sH += v0; sHc += v1; sb += v2;
+    }
+    H[(size_t)(4 + 8 * a + i) * dim + 4 + 8 * a + j] = sH;
     if (tid < 32) {
-      const int r = tid >> 2, c = tid & 3;
-      H[(size_t)(4 + 8 * a + r) * dim + c] = accHc;
-      H[(size_t)c * dim + 4 + 8 * a + r] = accHc;
+      const int r = tid >> 2, cc = tid & 3;
+      H[(size_t)(4 + 8 * a + r) * dim + cc] = sHc;
+      H[(size_t)cc * dim + 4 + 8 * a + r] = sHc;
     }
-    if (tid < 8) bv[4 + 8 * a + tid] = accb;
+    if (tid < 8) bv[4 + 8 * a + tid] = sb;
   } else {
-    // H[a,bb] = AH(a,bb) B(a,bb) AT(a,bb)^T + (AH(bb,a) B(bb,a) AT(bb,a)^T)^T
-    double out = 0;
-    for (int q = 0; q < 2; q++) {
-      const int h = q ? bb : a, t = q ? a : bb;
-      const int pidx = h + n * t;
-      const float *blk = acc + (size_t)pidx * 91;
-      sB[tid] = (double)blk[top_idx(4 + i, 4 + j)];
-      sA[tid] = adHost[(size_t)pidx * 64 + tid];
-      sA2[tid] = adTarget[(size_t)pidx * 64 + tid];
-      __syncthreads();
-      double tv = 0;
-      for (int k = 0; k < 8; k++) tv += sA[i * 8 + k] * sB[k * 8 + j];
-      sT[tid] = tv;
-      __syncthreads();
-      if (q == 0) { for (int k = 0; k < 8; k++) out += sT[i * 8 + k] * sA2[j * 8 + k]; }
-      else { for (int k = 0; k < 8; k++) out += sT[j * 8 + k] * sA2[i * 8 + k]; }
-      __syncthreads();
-    }
-    H[(size_t)(4 + 8 * a + i) * dim + 4 + 8 * bb + j] = out;
-    H[(size_t)(4 + 8 * bb + j) * dim + 4 + 8 * a + i] = out;
+    const double *c1 = Cm + (size_t)(a + n * bb) * SOS_TOPC, *c2 = Cm + (size_t)(bb + n * a) * SOS_TOPC;
+    const double o = c1[128 + i * 8 + j] + c2[128 + j * 8 + i];
+    H[(size_t)(4 + 8 * a + i) * dim + 4 + 8 * bb + j] = o;
+    H[(size_t)(4 + 8 * bb + j) * dim + 4 + 8 * a + i] = o;
   }
 }
 
-// M[h][t1][g] (8x8 fp64): g == h ? sum_t2 D[h,t1,t2] AH[h,t2]^T : D[h,t1,g] AT[h,g]^T
-__global__ __launch_bounds__(64) void k_sc_M(int n, const float *__restrict__ accD, const double *__restrict__ adHost,
-                                             const double *__restrict__ adTarget, double *__restrict__ M) {
-  __shared__ double sD[64], sA[64];
+#define SOS_SCC 128  // doubles per (h,t1,g): C1 = AH[h,t1] M, C2 = AT[h,t1] M
+#define SOS_SCE 80   // doubles per (h,t1): AH E (32), AT E (32), AH EB (8), AT EB (8)
+
+// stage 1, grid n^3: (h, t1, g):  M = (g == h) ? sum_t2 D[h,t1,t2] AH[h,t2]^T : D[h,t1,g] AT[h,g]^T, then
+// C1 = AH[h,t1] M, C2 = AT[h,t1] M (OB/AccumulatedSCHessian.cpp:117-139 regrouped); blocks with g == 0
+// also produce the calib column / b products of (h,t1) (:107-115)
+__global__ __launch_bounds__(64) void k_sc_MC(int n, const float *__restrict__ accD, const float *__restrict__ accE,
+                                              const float *__restrict__ accEB, const double *__restrict__ adHost,
+                                              const double *__restrict__ adTarget, double *__restrict__ C, double *__restrict__ Ce) {
+  __shared__ double sD[64], sA[64], sM[64], sAH[64], sAT[64], sE[32], sEB[8];
   const int tid = threadIdx.x, i = tid >> 3, j = tid & 7;
   const int h = blockIdx.x % n, t1 = (blockIdx.x / n) % n, g = blockIdx.x / (n * n);
-  double out = 0;
+  double m = 0;
   const int t2lo = (g == h) ? 0 : g, t2hi = (g == h) ? n : g + 1;
   for (int t2 = t2lo; t2 < t2hi; t2++) {
     sD[tid] = (double)accD[(size_t)(h + n * t1 + n * n * t2) * 64 + tid];
     sA[tid] = ((g == h) ? adHost : adTarget)[(size_t)(h + n * t2) * 64 + tid];
     __syncthreads();
-    for (int k = 0; k < 8; k++) out += sD[i * 8 + k] * sA[j * 8 + k];
+#pragma unroll
+    for (int k = 0; k < 8; k++) m += sD[i * 8 + k] * sA[j * 8 + k];
     __syncthreads();
   }
-  M[((size_t)(h * n + t1) * n + g) * 64 + tid] = out;
+  sM[tid] = m;
+  const int pidx = h + n * t1;
+  sAH[tid] = adHost[(size_t)pidx * 64 + tid];
+  sAT[tid] = adTarget[(size_t)pidx * 64 + tid];
+  if (g == 0) {
+    if (tid < 32) sE[tid] = (double)accE[(size_t)pidx * 32 + tid];
+    if (tid < 8) sEB[tid] = (double)accEB[(size_t)pidx * 8 + tid];
+  }
+  __syncthreads();
+  double c1 = 0, c2 = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    c1 += sAH[i * 8 + k] * sM[k * 8 + j];
+    c2 += sAT[i * 8 + k] * sM[k * 8 + j];
+  }
+  double *out = C + ((size_t)(h * n + t1) * n + g) * SOS_SCC;
+  out[tid] = c1;
+  out[64 + tid] = c2;
+  if (g == 0) {
+    double *oe = Ce + (size_t)pidx * SOS_SCE;
+    if (tid < 32) {
+      const int r = tid >> 2, c = tid & 3;
+      double e1 = 0, e2 = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        e1 += sAH[r * 8 + k] * sE[k * 4 + c];
+        e2 += sAT[r * 8 + k] * sE[k * 4 + c];
+      }
+      oe[tid] = e1;
+      oe[32 + tid] = e2;
+    }
+    if (tid < 8) {
+      double b1 = 0, b2 = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        b1 += sAH[tid * 8 + k] * sEB[k];
+        b2 += sAT[tid * 8 + k] * sEB[k];
+      }
+      oe[64 + tid] = b1;
+      oe[72 + tid] = b2;
+    }
+  }
 }
 
-// H_sc[g1,g2] = sum_t1 AH[g1,t1] M[g1][t1][g2] + sum_{h != g1} AT[h,g1] M[h][g1][g2]; diagonal blocks also
-// produce the calib columns and b; the last block writes Hcc / bc.
-__global__ __launch_bounds__(64) void k_stitch_sc(int n, const double *__restrict__ M, const float *__restrict__ accE,
-                                                  const float *__restrict__ accEB, const float *__restrict__ accHcc,
-                                                  const float *__restrict__ accbc, const double *__restrict__ adHost,
-                                                  const double *__restrict__ adTarget, double *__restrict__ H,
-                                                  double *__restrict__ bv) {
-  __shared__ double sM[64], sA[64], sE[32], sEB[8];
+// stage 2, grid n*n + 1: H_sc[g1,g2] = sum_t1 C1[g1][t1][g2] + sum_{h != g1} C2[h][g1][g2]
+__global__ __launch_bounds__(64) void k_sc_sum(int n, const double *__restrict__ C, const double *__restrict__ Ce,
+                                               const float *__restrict__ accHcc, const float *__restrict__ accbc,
+                                               double *__restrict__ H) {
   const int dim = 4 + 8 * n;
+  double *bv = H + (size_t)dim * dim;
   const int tid = threadIdx.x, i = tid >> 3, j = tid & 7;
   if ((int)blockIdx.x == n * n) {
     if (tid < 16) H[(size_t)(tid >> 2) * dim + (tid & 3)] = (double)accHcc[tid];
@@ -799,74 +983,95 @@ __global__ __launch_bounds__(64) void k_stitch_sc(int n, const double *__restric
     return;
   }
   const int g1 = blockIdx.x % n, g2 = blockIdx.x / n;
-  double out = 0, outc = 0, outb = 0;
-  for (int q = 0; q < 2 * n; q++) {
-    const int h = q < n ? g1 : q - n, t1 = q < n ? q : g1;
-    if (q >= n && h == g1) continue;
-    const int pidx = h + n * t1;
-    sA[tid] = (q < n ? adHost : adTarget)[(size_t)pidx * 64 + tid];
-    sM[tid] = M[((size_t)(h * n + t1) * n + g2) * 64 + tid];
-    if (g1 == g2) {
-      if (tid < 32) sE[tid] = (double)accE[(size_t)pidx * 32 + tid];
-      if (tid < 8) sEB[tid] = (double)accEB[(size_t)pidx * 8 + tid];
-    }
-    __syncthreads();
-    for (int k = 0; k < 8; k++) out += sA[i * 8 + k] * sM[k * 8 + j];
-    if (g1 == g2) {
-      if (tid < 32) {
-        const int r = tid >> 2, c = tid & 3;
-        for (int k = 0; k < 8; k++) outc += sA[r * 8 + k] * sE[k * 4 + c];
-      }
-      if (tid < 8)
-        for (int k = 0; k < 8; k++) outb += sA[tid * 8 + k] * sEB[k];
-    }
-    __syncthreads();
-  }
-  H[(size_t)(4 + 8 * g1 + i) * dim + 4 + 8 * g2 + j] = out;
+  double s = 0, sc = 0, sb = 0;
+  // the (h = g1, t1 = g1) terms are exact zeros (a point has no residual to its own host), so both sums
+  // can run branch-free over all n
+#pragma unroll 4
+  for (int t1 = 0; t1 < n; t1++) s += C[((size_t)(g1 * n + t1) * n + g2) * SOS_SCC + tid];
+#pragma unroll 4
+  for (int h = 0; h < n; h++) s += C[((size_t)(h * n + g1) * n + g2) * SOS_SCC + 64 + tid];
+  H[(size_t)(4 + 8 * g1 + i) * dim + 4 + 8 * g2 + j] = s;
   if (g1 == g2) {
+    const int hc = tid & 31, bc_ = tid & 7;
+#pragma unroll 4
+    for (int t1 = 0; t1 < n; t1++) {
+      const double *e = Ce + (size_t)(g1 + n * t1) * SOS_SCE;
+      const double v1 = e[hc], v2 = e[64 + bc_];
+      sc += v1; sb += v2;
+    }
+#pragma unroll 4
+    for (int h = 0; h < n; h++) {
+      const double *e = Ce + (size_t)(h + n * g1) * SOS_SCE;
+      const double v1 = e[32 + hc], v2 = e[72 + bc_];
+      sc += v1; sb += v2;
+    }
     if (tid < 32) {
       const int r = tid >> 2, c = tid & 3;
-      H[(size_t)(4 + 8 * g1 + r) * dim + c] = outc;
-      H[(size_t)c * dim + 4 + 8 * g1 + r] = outc;  // transposed calib rows, OB/AccumulatedSCHessian.h:118-123
+      H[(size_t)(4 + 8 * g1 + r) * dim + c] = sc;
+      H[(size_t)c * dim + 4 + 8 * g1 + r] = sc;  // transposed calib rows, OB/AccumulatedSCHessian.h:118-123
     }
-    if (tid < 8) bv[4 + 8 * g1 + tid] = outb;
+    if (tid < 8) bv[4 + 8 * g1 + tid] = sb;
   }
 }
 
 // ================================================================================================
-// resubstituteFPt (OB/EnergyFunctional.cpp:526-551): one thread per point
+// resubstituteFPt (OB/EnergyFunctional.cpp:526-551): one thread per point; loads of 4 residuals are in
+// flight together, the subtraction order is the reference's.  With applyStep the point's idepth is
+// advanced on the device exactly as doStepFromBackup does on the host
+// (FS/FullSystemOptimize.cpp:207-213: setIdepth(backup + fac*step); setIdepthZero(same)).
 // ================================================================================================
 __global__ void k_resubstitute(BaDev d, const float *__restrict__ xc, const float *__restrict__ xAd,
-                               float *__restrict__ step_out) {
+                               float *__restrict__ step_out, int applyStep, float stepfacD) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= d.P) return;
   float *o = d.p_out + 16 * (size_t)p;
-  int ngood = 0;
-  for (int q = d.p_begin[p]; q < d.p_begin[p + 1]; q++)
-    if (d.s_flags[d.p_list[q]] & DF_ACTIVE) ngood++;
+  const float4 *ov = reinterpret_cast<const float4 *>(o);
+  const float4 v0 = ov[0], v1 = ov[1], v2 = ov[2], v3 = ov[3];
   float step = 0.f;
-  if (ngood > 0) {
-    float b = o[PO_BDSUM];
+  if (v3.x != 0.f) {  // HdiF == 0 <=> no active residual (ngoodres == 0)
+    float b = v3.y;
     float dot = 0;
-    for (int k = 0; k < 4; k++) dot += xc[k] * (o[PO_HCD_A + k] + o[PO_HCD_L + k]);
+    dot += xc[0] * (v0.z + v2.x);
+    dot += xc[1] * (v0.w + v2.y);
+    dot += xc[2] * (v1.x + v2.z);
+    dot += xc[3] * (v1.y + v2.w);
     b -= dot;
-    for (int q = d.p_begin[p]; q < d.p_begin[p + 1]; q++) {
-      const int s = d.p_list[q];
-      if (!(d.s_flags[s] & DF_ACTIVE)) continue;
-      const int pair = d.t_pair[s >> 5];  // h + n*t
-      const int hh = pair % d.n, tt = pair / d.n;
-      const float *xa = xAd + 8 * (hh * d.n + tt);
-      const float4 *jp = reinterpret_cast<const float4 *>(d.JpJd + 8 * (size_t)s);
-      const float4 v0 = jp[0], v1 = jp[1];
-      float dd = 0;
-      dd += xa[0] * v0.x; dd += xa[1] * v0.y; dd += xa[2] * v0.z; dd += xa[3] * v0.w;
-      dd += xa[4] * v1.x; dd += xa[5] * v1.y; dd += xa[6] * v1.z; dd += xa[7] * v1.w;
-      b -= dd;
+    const int q0 = d.p_begin[p], q1 = d.p_begin[p + 1];
+    for (int q = q0; q < q1; q += 4) {
+      float4 ja[4], jb[4], xa[4], xb[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int2 e = d.p_list2[min(q + k, q1 - 1)];
+        const float4 *jp = reinterpret_cast<const float4 *>(d.JpJd + 8 * (size_t)e.x);
+        const float4 *xp = reinterpret_cast<const float4 *>(xAd + 8 * (size_t)e.y);
+        ja[k] = jp[0]; jb[k] = jp[1];
+        xa[k] = xp[0]; xb[k] = xp[1];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (q + k >= q1) break;
+        float dd = 0;  // inactive residuals hold JpJd == 0: dd == 0 and b - 0 == b
+        dd += xa[k].x * ja[k].x; dd += xa[k].y * ja[k].y; dd += xa[k].z * ja[k].z; dd += xa[k].w * ja[k].w;
+        dd += xb[k].x * jb[k].x; dd += xb[k].y * jb[k].y; dd += xb[k].z * jb[k].z; dd += xb[k].w * jb[k].w;
+        b -= dd;
+      }
     }
-    step = -b * o[PO_HDI];
+    step = -b * v3.x;
   }
   o[PO_STEP] = step;
   if (step_out) step_out[p] = step;
+  if (applyStep) {
+    sos_point *pt = d.pts + p;
+    const float idn = pt->idepth_scaled + stepfacD * step;
+    pt->idepth_scaled = idn;
+    pt->idepth_zero_scaled = idn;
+    pt->deltaF = 0.f;
+    const int q0 = d.p_begin[p], q1 = d.p_begin[p + 1];
+    for (int q = q0; q < q1; q++) {
+      float2 *g = reinterpret_cast<float2 *>(d.r_geo + d.p_list2[q].x) + 1;
+      *g = make_float2(idn, idn);
+    }
+  }
 }
 
 // ================================================================================================
@@ -942,6 +1147,18 @@ __global__ __launch_bounds__(1024) void k_sum_double(const double *__restrict__ 
     __syncthreads();
   }
   if (threadIdx.x == 0) *out = sm[0];
+}
+
+// copy the (idepth, idepth_zero) of every point into the per-residual records after a host-side update
+__global__ void k_refresh_geo(BaDev d) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= d.Rpad) return;
+  const int p = d.s_point[s];
+  if (p < 0) return;
+  float4 g = d.r_geo[s];
+  g.z = d.pts[p].idepth_scaled;
+  g.w = d.pts[p].idepth_zero_scaled;
+  d.r_geo[s] = g;
 }
 
 // read one Jacobian back in the reference's 74-float layout
@@ -1037,11 +1254,21 @@ struct sos_ba {
       d_host_chunk_begin, d_tmp_int;
   DevBuf<uint8_t> d_s_flags, d_s_state, d_s_newstate, d_o_newstate;
   DevBuf<float> d_s_energy, d_s_newenergy, d_s_newenergywo, d_s_ret, d_s_center, d_s_rtz, d_s_pterm, d_J, d_JpJd,
-      d_p_out, d_o_newenergy, d_o_newenergywo, d_o_center, d_top_part, d_gram_part, d_acc, d_adHTdelta, d_cdelta,
-      d_frameTH, d_xc, d_xAd, d_step;
-  DevBuf<sos_precalc> d_precalc;
-  DevBuf<double> d_adHost, d_adTarget, d_M, d_Hout, d_bout, d_scalar, d_perres;
+      d_p_out, d_o_newenergy, d_o_newenergywo, d_o_center, d_top_part, d_gram_part, d_acc;
+  DevBuf<double> d_adHost, d_adTarget, d_Hout, d_scalar, d_perres;
   DevBuf<sos_rawjac> d_rawjac;
+  DevBuf<int2> d_p_list2;
+  DevBuf<float4> d_r_geo;
+  DevBuf<float> d_r_cw;
+  DevBuf<float> d_stage;   // [precalc n*n*28 | adHTdelta n*n*8 | cdelta 4 | frameTH n(+pad) | xc 4 | xAd n*n*8]
+  DevBuf<char> d_outpack;  // [tile_esum ntilesA doubles | newest energies | point steps]
+  DevBuf<double> d_C;      // stitch stage-1 products
+  size_t st_pre = 0, st_adh = 0, st_cd = 0, st_th = 0, st_xc = 0, st_xad = 0, st_floats = 0;
+  size_t out_esum = 0, out_newest = 0, out_step = 0, out_bytes = 0;
+  int newest_begin = 0, newest_count = 0;
+  char *pin = nullptr;     // pinned host staging: [stage | outpack | Hb]
+  size_t pin_bytes = 0, pin_stage = 0, pin_out = 0, pin_hb = 0;
+  size_t hb_mode_stride = 0;  // doubles per (H | b) block in d_Hout
   std::vector<float> h_adHostF, h_adTargetF;
   size_t acc_floats = 0;
   // offsets into the packed accumulator
@@ -1074,13 +1301,13 @@ extern "C" int sos_ba_destroy(sos_ba *ba) {
   for (DevBuf<float> *b :
        {&ba->d_s_energy, &ba->d_s_newenergy, &ba->d_s_newenergywo, &ba->d_s_ret, &ba->d_s_center, &ba->d_s_rtz,
         &ba->d_s_pterm, &ba->d_J, &ba->d_JpJd, &ba->d_p_out, &ba->d_o_newenergy, &ba->d_o_newenergywo, &ba->d_o_center,
-        &ba->d_top_part, &ba->d_gram_part, &ba->d_acc, &ba->d_adHTdelta, &ba->d_cdelta, &ba->d_frameTH, &ba->d_xc,
-        &ba->d_xAd, &ba->d_step})
+        &ba->d_top_part, &ba->d_gram_part, &ba->d_acc})
     b->release();
-  ba->d_precalc.release();
-  for (DevBuf<double> *b : {&ba->d_adHost, &ba->d_adTarget, &ba->d_M, &ba->d_Hout, &ba->d_bout, &ba->d_scalar, &ba->d_perres})
+  for (DevBuf<double> *b : {&ba->d_adHost, &ba->d_adTarget, &ba->d_Hout, &ba->d_scalar, &ba->d_perres})
     b->release();
   ba->d_rawjac.release();
+  ba->d_p_list2.release(); ba->d_r_geo.release(); ba->d_r_cw.release(); ba->d_stage.release(); ba->d_outpack.release(); ba->d_C.release();
+  if (ba->pin) hipHostFree(ba->pin);
   delete ba;
   return SOS_OK;
 }
@@ -1174,7 +1401,7 @@ extern "C" int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, i
   for (int s = 0; s < Rpad; s++) {
     int o = s_orig[s];
     if (o < 0) continue;
-    unsigned f = 0;
+    unsigned f = DF_VALID;
     if (res[o].flags & SOS_RF_ACTIVE) f |= DF_ACTIVE;
     if (res[o].flags & SOS_RF_LINEARIZED) f |= DF_LINEARIZED;
     if (res[o].flags & SOS_RF_ISNEW) f |= DF_ISNEW;
@@ -1183,10 +1410,22 @@ extern "C" int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, i
     s_energy[s] = res[o].state_energy;
     if (res_toZeroF) memcpy(&s_rtz[(size_t)s * 8], res_toZeroF + (size_t)o * 8, 8 * sizeof(float));
   }
+  // per-residual copies of the point record in sorted order (k_linearize reads them without indirection)
+  std::vector<float4> r_geo(Rpad ? Rpad : 1, make_float4(0.f, 0.f, 1.f, 1.f));
+  std::vector<float> r_cw((size_t)(Rpad ? Rpad : 1) * 16, 0.f);
+  for (int s = 0; s < Rpad; s++) {
+    if (s_point[s] < 0) continue;
+    const sos_point &q = pts[s_point[s]];
+    r_geo[s] = make_float4(q.u, q.v, q.idepth_scaled, q.idepth_zero_scaled);
+    memcpy(&r_cw[(size_t)s * 16], q.color, 8 * sizeof(float));
+    memcpy(&r_cw[(size_t)s * 16 + 8], q.weights, 8 * sizeof(float));
+  }
   // per point lists
   std::vector<int> p_list(R ? R : 1, 0), p_res_t((size_t)(P ? P : 1) * n, -1);
+  std::vector<int2> p_list2(R ? R : 1);
   for (int o = 0; o < R; o++) {
     p_list[o] = s_of_orig[o];
+    p_list2[o] = make_int2(s_of_orig[o], n * res[o].host + res[o].target);
     p_res_t[(size_t)res[o].point * n + res[o].target] = s_of_orig[o];
   }
   // chunks of 64 points per host for the Gram kernel
@@ -1194,13 +1433,13 @@ extern "C" int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, i
   {
     int p = 0;
     for (int h = 0; h < n; h++) {
-      host_chunk_begin[h] = (int)(chunk_pt.size() / 64);
+      host_chunk_begin[h] = (int)(chunk_pt.size() / SOS_GC);
       int start = p;
       while (p < P && pts[p].host == h) p++;
-      for (int q = start; q < p; q += 64)
-        for (int k = 0; k < 64; k++) chunk_pt.push_back(q + k < p ? q + k : -1);
+      for (int q = start; q < p; q += SOS_GC)
+        for (int k = 0; k < SOS_GC; k++) chunk_pt.push_back(q + k < p ? q + k : -1);
     }
-    host_chunk_begin[n] = (int)(chunk_pt.size() / 64);
+    host_chunk_begin[n] = (int)(chunk_pt.size() / SOS_GC);
   }
   ba->nchunks = host_chunk_begin[n];
   ba->Dm = ((8 * n + 5) + 15) / 16 * 16;
@@ -1214,6 +1453,9 @@ extern "C" int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, i
   if ((rc = upload(st, ba->d_t_pair, t_pair))) return rc;
   if ((rc = upload(st, ba->d_p_begin, p_begin))) return rc;
   if ((rc = upload(st, ba->d_p_list, p_list))) return rc;
+  if ((rc = upload(st, ba->d_p_list2, p_list2))) return rc;
+  if ((rc = upload(st, ba->d_r_geo, r_geo))) return rc;
+  if ((rc = upload(st, ba->d_r_cw, r_cw))) return rc;
   if ((rc = upload(st, ba->d_p_res_t, p_res_t))) return rc;
   if ((rc = upload(st, ba->d_pair_tile_begin, pair_tile_begin))) return rc;
   if ((rc = upload(st, ba->d_chunk_pt, chunk_pt))) return rc;
@@ -1224,7 +1466,7 @@ extern "C" int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, i
   if ((rc = upload(st, ba->d_s_rtz, s_rtz))) return rc;
   const size_t Rp = Rpad ? Rpad : 1, Pp = P ? P : 1, Rr = R ? R : 1;
   ENSURE(ba->d_s_newstate, Rp); ENSURE(ba->d_s_newenergy, Rp); ENSURE(ba->d_s_newenergywo, Rp); ENSURE(ba->d_s_ret, Rp);
-  ENSURE(ba->d_s_center, Rp * 3); ENSURE(ba->d_s_pterm, Rp * 6);
+  ENSURE(ba->d_s_center, Rp * 3); ENSURE(ba->d_s_pterm, Rp * 8);
   ENSURE(ba->d_J, (size_t)(ntiles ? ntiles : 1) * SOS_TILE_FLOATS); ENSURE(ba->d_JpJd, Rp * 8);
   ENSURE(ba->d_p_out, Pp * 16);
   ENSURE(ba->d_o_newstate, Rr); ENSURE(ba->d_o_newenergy, Rr); ENSURE(ba->d_o_newenergywo, Rr); ENSURE(ba->d_o_center, Rr * 3);
@@ -1241,17 +1483,48 @@ extern "C" int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, i
   ba->off_nres = ba->off_bc + 4;
   ba->acc_floats = ba->off_nres + 2;
   ENSURE(ba->d_acc, ba->acc_floats);
-  ENSURE(ba->d_precalc, nn); ENSURE(ba->d_adHTdelta, nn * 8); ENSURE(ba->d_cdelta, 4); ENSURE(ba->d_frameTH, n);
-  ENSURE(ba->d_adHost, nn * 64); ENSURE(ba->d_adTarget, nn * 64); ENSURE(ba->d_M, nn * n * 64);
+  // device staging of the per-step inputs (one H2D per step)
+  ba->st_pre = 0;
+  ba->st_adh = ba->st_pre + nn * 28;
+  ba->st_cd = ba->st_adh + nn * 8;
+  ba->st_th = ba->st_cd + 4;
+  ba->st_xc = ba->st_th + ((size_t)n + 3) / 4 * 4;
+  ba->st_xad = ba->st_xc + 4;
+  ba->st_floats = ba->st_xad + nn * 8;
+  ENSURE(ba->d_stage, ba->st_floats);
+  ENSURE(ba->d_adHost, nn * 64); ENSURE(ba->d_adTarget, nn * 64);
   const size_t dim = 4 + 8 * (size_t)n;
-  ENSURE(ba->d_Hout, 3 * dim * dim); ENSURE(ba->d_bout, 3 * dim); ENSURE(ba->d_scalar, 8); ENSURE(ba->d_perres, Rp);
-  ENSURE(ba->d_xc, 4); ENSURE(ba->d_xAd, nn * 8); ENSURE(ba->d_step, Pp);
+  ba->hb_mode_stride = dim * dim + dim;
+  ENSURE(ba->d_Hout, 3 * ba->hb_mode_stride); ENSURE(ba->d_scalar, 8); ENSURE(ba->d_perres, Rp);
+  ENSURE(ba->d_C, 2 * nn * SOS_TOPC + nn * n * SOS_SCC + nn * SOS_SCE + 64);
+  // packed per-step outputs (one D2H per step)
+  ba->newest_begin = pair_tile_begin[n * (n - 1)] * SOS_TILE;
+  ba->newest_count = (ntilesA - pair_tile_begin[n * (n - 1)]) * SOS_TILE;
+  ba->out_esum = 0;
+  ba->out_newest = sizeof(double) * (size_t)(ntilesA ? ntilesA : 1);
+  ba->out_step = ba->out_newest + sizeof(float) * (size_t)ba->newest_count;
+  ba->out_bytes = ba->out_step + sizeof(float) * Pp;
+  ENSURE(ba->d_outpack, ba->out_bytes);
+  {
+    const size_t need_stage = sizeof(float) * ba->st_floats, need_out = ba->out_bytes,
+                 need_hb = sizeof(double) * 3 * ba->hb_mode_stride + 16;
+    const size_t tot = need_stage + need_out + need_hb + 256;
+    if (tot > ba->pin_bytes) {
+      if (ba->pin) hipHostFree(ba->pin);
+      ba->pin = nullptr;
+      SOS_HIP(hipHostMalloc((void **)&ba->pin, tot + tot / 4, hipHostMallocDefault));
+      ba->pin_bytes = tot + tot / 4;
+    }
+    ba->pin_stage = 0;
+    ba->pin_out = (need_stage + 63) / 64 * 64;
+    ba->pin_hb = ba->pin_out + (need_out + 63) / 64 * 64;
+  }
   SOS_HIP(hipMemsetAsync(ba->d_s_newstate.p, SOS_RES_OOB, Rp, st));
   SOS_HIP(hipMemsetAsync(ba->d_s_newenergy.p, 0, sizeof(float) * Rp, st));
   SOS_HIP(hipMemsetAsync(ba->d_s_newenergywo.p, 0, sizeof(float) * Rp, st));
   SOS_HIP(hipMemsetAsync(ba->d_s_ret.p, 0, sizeof(float) * Rp, st));
   SOS_HIP(hipMemsetAsync(ba->d_s_center.p, 0, sizeof(float) * Rp * 3, st));
-  SOS_HIP(hipMemsetAsync(ba->d_s_pterm.p, 0, sizeof(float) * Rp * 6, st));
+  SOS_HIP(hipMemsetAsync(ba->d_s_pterm.p, 0, sizeof(float) * Rp * 8, st));
   SOS_HIP(hipMemsetAsync(ba->d_J.p, 0, sizeof(float) * (size_t)(ntiles ? ntiles : 1) * SOS_TILE_FLOATS, st));
   SOS_HIP(hipMemsetAsync(ba->d_JpJd.p, 0, sizeof(float) * Rp * 8, st));
   SOS_HIP(hipMemsetAsync(ba->d_p_out.p, 0, sizeof(float) * Pp * 16, st));
@@ -1265,7 +1538,16 @@ extern "C" int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, i
   d.huberTH = ba->prm.huberTH; d.outlierTH = ba->prm.outlierTHSumComponent;
   d.modeA = ba->prm.affineOptModeA; d.modeB = ba->prm.affineOptModeB;
   for (int i = 0; i < n; i++) d.img[i] = c->dI[ba->slot[i]][0];
-  d.precalc = ba->d_precalc.p; d.adHTdelta = ba->d_adHTdelta.p; d.cdelta = ba->d_cdelta.p;
+  d.precalc = reinterpret_cast<const sos_precalc *>(ba->d_stage.p + ba->st_pre);
+  d.adHTdelta = ba->d_stage.p + ba->st_adh;
+  d.cdelta = ba->d_stage.p + ba->st_cd;
+  d.tile_esum = reinterpret_cast<double *>(ba->d_outpack.p + ba->out_esum);
+  d.o_newest = reinterpret_cast<float *>(ba->d_outpack.p + ba->out_newest);
+  d.newest_begin = ba->newest_begin;
+  d.newest_count = ba->newest_count;
+  d.p_list2 = ba->d_p_list2.p;
+  d.r_geo = ba->d_r_geo.p;
+  d.r_cw = ba->d_r_cw.p;
   d.pts = ba->d_pts.p;
   d.s_point = ba->d_s_point.p; d.s_orig = ba->d_s_orig.p;
   d.s_flags = ba->d_s_flags.p; d.s_state = ba->d_s_state.p; d.s_newstate = ba->d_s_newstate.p;
@@ -1295,6 +1577,10 @@ extern "C" int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, i
   return SOS_OK;
 }
 
+// stage pointers
+static inline float *stg(sos_ba *ba, size_t off) { return ba->d_stage.p + off; }
+static inline float *pstg(sos_ba *ba, size_t off) { return reinterpret_cast<float *>(ba->pin + ba->pin_stage) + off; }
+
 extern "C" int sos_ba_set_state(sos_ba *ba, const sos_calib *calib, const sos_precalc *precalc, const float *adHTdeltaF,
                                 const float *cDeltaF, const double *adHost, const double *adTarget,
                                 const float *point_idepth_scaled, const float *point_idepth_zero_scaled,
@@ -1303,11 +1589,21 @@ extern "C" int sos_ba_set_state(sos_ba *ba, const sos_calib *calib, const sos_pr
   sos_ctx *c = ba->ctx;
   SOS_HIP(hipSetDevice(c->device));
   hipStream_t st = c->stream;
+  SOS_HIP(hipStreamSynchronize(st));  // the pinned staging area may still be in flight
   const size_t nn = (size_t)ba->n * ba->n;
   if (calib) { ba->calib = *calib; ba->dev.calib = *calib; }
-  if (precalc) SOS_HIP(hipMemcpyAsync(ba->d_precalc.p, precalc, sizeof(sos_precalc) * nn, hipMemcpyHostToDevice, st));
-  if (adHTdeltaF) SOS_HIP(hipMemcpyAsync(ba->d_adHTdelta.p, adHTdeltaF, sizeof(float) * 8 * nn, hipMemcpyHostToDevice, st));
-  if (cDeltaF) SOS_HIP(hipMemcpyAsync(ba->d_cdelta.p, cDeltaF, sizeof(float) * 4, hipMemcpyHostToDevice, st));
+  if (precalc) {
+    memcpy(pstg(ba, ba->st_pre), precalc, sizeof(sos_precalc) * nn);
+    SOS_HIP(hipMemcpyAsync(stg(ba, ba->st_pre), pstg(ba, ba->st_pre), sizeof(sos_precalc) * nn, hipMemcpyHostToDevice, st));
+  }
+  if (adHTdeltaF) {
+    memcpy(pstg(ba, ba->st_adh), adHTdeltaF, sizeof(float) * 8 * nn);
+    SOS_HIP(hipMemcpyAsync(stg(ba, ba->st_adh), pstg(ba, ba->st_adh), sizeof(float) * 8 * nn, hipMemcpyHostToDevice, st));
+  }
+  if (cDeltaF) {
+    memcpy(pstg(ba, ba->st_cd), cDeltaF, sizeof(float) * 4);
+    SOS_HIP(hipMemcpyAsync(stg(ba, ba->st_cd), pstg(ba, ba->st_cd), sizeof(float) * 4, hipMemcpyHostToDevice, st));
+  }
   if (adHost) {
     SOS_HIP(hipMemcpyAsync(ba->d_adHost.p, adHost, sizeof(double) * 64 * nn, hipMemcpyHostToDevice, st));
     ba->h_adHostF.resize(64 * nn);
@@ -1325,14 +1621,15 @@ extern "C" int sos_ba_set_state(sos_ba *ba, const sos_calib *calib, const sos_pr
       if (point_deltaF) ba->h_pts[p].deltaF = point_deltaF[p];
     }
     if (ba->P) SOS_HIP(hipMemcpyAsync(ba->d_pts.p, ba->h_pts.data(), sizeof(sos_point) * ba->P, hipMemcpyHostToDevice, st));
+    if (ba->Rpad > 0) k_refresh_geo<<<divup(ba->Rpad, 256), 256, 0, st>>>(ba->dev);
   }
   SOS_HIP(hipStreamSynchronize(st));  // caller buffers are pageable
   ba->have_state = true;
   return SOS_OK;
 }
 
-static int launch_linearize(sos_ba *ba) {
-  if (ba->ntilesA > 0) k_linearize<<<ba->ntilesA, 256, 0, ba->ctx->stream>>>(ba->dev, ba->d_frameTH.p);
+static int launch_linearize(sos_ba *ba, int doApply) {
+  if (ba->ntilesA > 0) k_linearize<<<ba->ntilesA, 256, 0, ba->ctx->stream>>>(ba->dev, stg(ba, ba->st_th), doApply);
   return SOS_OK;
 }
 
@@ -1342,8 +1639,8 @@ extern "C" int sos_ba_linearize(sos_ba *ba, const float *frameEnergyTH, double *
   sos_ctx *c = ba->ctx;
   SOS_HIP(hipSetDevice(c->device));
   hipStream_t st = c->stream;
-  SOS_HIP(hipMemcpyAsync(ba->d_frameTH.p, frameEnergyTH, sizeof(float) * ba->n, hipMemcpyHostToDevice, st));
-  launch_linearize(ba);
+  SOS_HIP(hipMemcpyAsync(stg(ba, ba->st_th), frameEnergyTH, sizeof(float) * ba->n, hipMemcpyHostToDevice, st));
+  launch_linearize(ba, 0);
   if (energySum) {
     k_sum_ret<<<1, 1024, 0, st>>>(ba->d_s_ret.p, ba->ntilesA * SOS_TILE, ba->d_scalar.p);
     SOS_HIP(hipMemcpyAsync(energySum, ba->d_scalar.p, sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1415,27 +1712,44 @@ static int launch_top(sos_ba *ba) {
                                                         ba->d_top_part.p + (size_t)nA * SOS_TOPN, nullptr);
   return SOS_OK;
 }
+static size_t gram_lds(const sos_ba *ba) { return sizeof(float) * ((size_t)SOS_GC * ba->ld + SOS_GC); }
 static int launch_sc(sos_ba *ba, int shiftPriorToZero) {
   hipStream_t st = ba->ctx->stream;
-  if (ba->P > 0) k_point_prep<<<divup(ba->P, 128), 128, 0, st>>>(ba->dev, shiftPriorToZero, nullptr, ba->P, 0);
-  if (ba->nchunks > 0) {
-    const size_t lds = sizeof(float) * (64 * (size_t)ba->ld + 64);
-    k_sc_gram<<<ba->nchunks, 256, lds, st>>>(ba->dev, ba->d_chunk_pt.p, ba->Dm, ba->ld, ba->d_gram_part.p);
-  }
+  if (ba->P > 0) k_point_prep<<<divup(ba->P, 64), 64, 0, st>>>(ba->dev, shiftPriorToZero, nullptr, ba->P);
+  if (ba->nchunks > 0) k_sc_gram<<<ba->nchunks, 256, gram_lds(ba), st>>>(ba->dev, ba->d_chunk_pt.p, ba->Dm, ba->ld, ba->d_gram_part.p);
   return SOS_OK;
 }
+static void fill_reduce(const sos_ba *ba, ReduceArgs &a, const float *top_part, const int *pair_tile_begin, const float *gram_part,
+                        const int *host_chunk_begin, int nchunks, int nmodes, float *acc) {
+  const int n = ba->n;
+  a.top_part = top_part; a.pair_tile_begin = pair_tile_begin; a.gram_part = gram_part; a.host_chunk_begin = host_chunk_begin;
+  a.n = n; a.Dm = ba->Dm; a.nchunks = nchunks; a.nmodes = nmodes;
+  a.b_top = nmodes * n * n;
+  a.b_sc = divup(n * 8 * n * (8 * n + 5), 128);
+  a.b_tail = 20 + nmodes;
+  a.accTop = acc + ba->off_topA;
+  a.accD = acc + ba->off_D; a.accE = acc + ba->off_E; a.accEB = acc + ba->off_EB;
+  a.accHcc = acc + ba->off_Hcc; a.accbc = acc + ba->off_bc; a.nres = acc + ba->off_nres;
+}
 static int launch_reduce(sos_ba *ba) {
+  ReduceArgs a;
+  fill_reduce(ba, a, ba->d_top_part.p, ba->d_pair_tile_begin.p, ba->d_gram_part.p, ba->d_host_chunk_begin.p, ba->nchunks, 2,
+              ba->d_acc.p);
+  k_reduce_all<<<a.b_top + a.b_sc + a.b_tail, 128, 0, ba->ctx->stream>>>(a);
+  return SOS_OK;
+}
+// stitch kernels: d_Hout = [H_A | b_A | H_L | b_L | H_sc | b_sc]
+static int launch_stitch(sos_ba *ba, const float *acc, int nmodes) {
   hipStream_t st = ba->ctx->stream;
   const int n = ba->n;
-  float *acc = ba->d_acc.p;
-  hipMemsetAsync(acc + ba->off_nres, 0, 2 * sizeof(float), st);
-  k_reduce_top<<<n * n, SOS_TOPN, 0, st>>>(ba->d_top_part.p, ba->d_pair_tile_begin.p, acc + ba->off_topA, acc + ba->off_nres);
-  k_reduce_top<<<n * n, SOS_TOPN, 0, st>>>(ba->d_top_part.p, ba->d_pair_tile_begin.p + n * n, acc + ba->off_topL,
-                                           acc + ba->off_nres + 1);
-  const int elems = 8 * n * (8 * n + 5);
-  dim3 grid(divup(elems, 256), n + 1);
-  k_reduce_sc<<<grid, 256, 0, st>>>(ba->d_gram_part.p, ba->d_host_chunk_begin.p, n, ba->Dm, ba->nchunks, acc + ba->off_D,
-                                    acc + ba->off_E, acc + ba->off_EB, acc + ba->off_Hcc, acc + ba->off_bc);
+  const size_t nn = (size_t)n * n;
+  double *Ctop = ba->d_C.p, *Csc = Ctop + 2 * nn * SOS_TOPC, *Ce = Csc + nn * n * SOS_SCC, *Ccc = Ce + nn * SOS_SCE;
+  double *H = ba->d_Hout.p;
+  dim3 g1(n * n + 20, nmodes), g2(n * (n + 1) / 2 + 1, nmodes);
+  k_stitch_top_pairs<<<g1, 64, 0, st>>>(n, acc + ba->off_topA, ba->d_adHost.p, ba->d_adTarget.p, Ctop, Ccc);
+  k_sc_MC<<<n * n * n, 64, 0, st>>>(n, acc + ba->off_D, acc + ba->off_E, acc + ba->off_EB, ba->d_adHost.p, ba->d_adTarget.p, Csc, Ce);
+  k_stitch_top_sum<<<g2, 64, 0, st>>>(n, Ccc, Ctop, H, ba->hb_mode_stride);
+  k_sc_sum<<<n * n + 1, 64, 0, st>>>(n, Csc, Ce, acc + ba->off_Hcc, acc + ba->off_bc, H + 2 * ba->hb_mode_stride);
   return SOS_OK;
 }
 
@@ -1456,35 +1770,39 @@ extern "C" int sos_ba_acc_buffer(sos_ba *ba, float **dev_ptr, size_t *nfloats) {
   return SOS_OK;
 }
 
+// D2H of the stitched system through the pinned buffer (one copy + the two counts)
+static int fetch_hb(sos_ba *ba, const float *acc, double *H_A, double *b_A, double *H_L, double *b_L, double *H_sc, double *b_sc,
+                    int *resInA, int *resInL, bool haveL) {
+  hipStream_t st = ba->ctx->stream;
+  const size_t dim = 4 + 8 * (size_t)ba->n, ms = ba->hb_mode_stride;
+  double *ph = reinterpret_cast<double *>(ba->pin + ba->pin_hb);
+  float *pn = reinterpret_cast<float *>(ph + 3 * ms);
+  SOS_HIP(hipMemcpyAsync(ph, ba->d_Hout.p, sizeof(double) * 3 * ms, hipMemcpyDeviceToHost, st));
+  SOS_HIP(hipMemcpyAsync(pn, acc + ba->off_nres, 2 * sizeof(float), hipMemcpyDeviceToHost, st));
+  SOS_HIP(hipStreamSynchronize(st));
+  if (H_A) memcpy(H_A, ph, sizeof(double) * dim * dim);
+  if (b_A) memcpy(b_A, ph + dim * dim, sizeof(double) * dim);
+  if (haveL) {
+    if (H_L) memcpy(H_L, ph + ms, sizeof(double) * dim * dim);
+    if (b_L) memcpy(b_L, ph + ms + dim * dim, sizeof(double) * dim);
+  } else {
+    if (H_L) memset(H_L, 0, sizeof(double) * dim * dim);
+    if (b_L) memset(b_L, 0, sizeof(double) * dim);
+  }
+  if (H_sc) memcpy(H_sc, ph + 2 * ms, sizeof(double) * dim * dim);
+  if (b_sc) memcpy(b_sc, ph + 2 * ms + dim * dim, sizeof(double) * dim);
+  if (resInA) *resInA = (int)pn[0];
+  if (resInL) *resInL = haveL ? (int)pn[1] : 0;
+  return SOS_OK;
+}
+
 extern "C" int sos_ba_stitch(sos_ba *ba, double *H_A, double *b_A, double *H_L, double *b_L, double *H_sc, double *b_sc,
                              int *resInA, int *resInL) {
   if (!ba || !ba->have_window || !ba->have_state) return SOS_ERR_STATE;
   SOS_HIP(hipSetDevice(ba->ctx->device));
-  hipStream_t st = ba->ctx->stream;
-  const int n = ba->n;
-  const size_t dim = 4 + 8 * (size_t)n;
-  float *acc = ba->d_acc.p;
-  double *H = ba->d_Hout.p, *b = ba->d_bout.p;
-  SOS_HIP(hipMemsetAsync(H, 0, sizeof(double) * 3 * dim * dim, st));
-  SOS_HIP(hipMemsetAsync(b, 0, sizeof(double) * 3 * dim, st));
-  dim3 gt(n * (n + 1) / 2 + 1, 2);
-  k_stitch_top<<<gt, 64, 0, st>>>(n, acc + ba->off_topA, ba->d_adHost.p, ba->d_adTarget.p, H, b);
-  k_sc_M<<<n * n * n, 64, 0, st>>>(n, acc + ba->off_D, ba->d_adHost.p, ba->d_adTarget.p, ba->d_M.p);
-  k_stitch_sc<<<n * n + 1, 64, 0, st>>>(n, ba->d_M.p, acc + ba->off_E, acc + ba->off_EB, acc + ba->off_Hcc, acc + ba->off_bc,
-                                        ba->d_adHost.p, ba->d_adTarget.p, H + 2 * dim * dim, b + 2 * dim);
+  launch_stitch(ba, ba->d_acc.p, 2);
   SOS_HIP(hipGetLastError());
-  if (H_A) SOS_HIP(hipMemcpyAsync(H_A, H, sizeof(double) * dim * dim, hipMemcpyDeviceToHost, st));
-  if (b_A) SOS_HIP(hipMemcpyAsync(b_A, b, sizeof(double) * dim, hipMemcpyDeviceToHost, st));
-  if (H_L) SOS_HIP(hipMemcpyAsync(H_L, H + dim * dim, sizeof(double) * dim * dim, hipMemcpyDeviceToHost, st));
-  if (b_L) SOS_HIP(hipMemcpyAsync(b_L, b + dim, sizeof(double) * dim, hipMemcpyDeviceToHost, st));
-  if (H_sc) SOS_HIP(hipMemcpyAsync(H_sc, H + 2 * dim * dim, sizeof(double) * dim * dim, hipMemcpyDeviceToHost, st));
-  if (b_sc) SOS_HIP(hipMemcpyAsync(b_sc, b + 2 * dim, sizeof(double) * dim, hipMemcpyDeviceToHost, st));
-  float nres[2] = {0, 0};
-  SOS_HIP(hipMemcpyAsync(nres, acc + ba->off_nres, 2 * sizeof(float), hipMemcpyDeviceToHost, st));
-  SOS_HIP(hipStreamSynchronize(st));
-  if (resInA) *resInA = (int)nres[0];
-  if (resInL) *resInL = (int)nres[1];
-  return SOS_OK;
+  return fetch_hb(ba, ba->d_acc.p, H_A, b_A, H_L, b_L, H_sc, b_sc, resInA, resInL, true);
 }
 
 extern "C" int sos_ba_accumulate(sos_ba *ba, double *H_A, double *b_A, double *H_L, double *b_L, double *H_sc,
@@ -1492,6 +1810,43 @@ extern "C" int sos_ba_accumulate(sos_ba *ba, double *H_A, double *b_A, double *H
   int rc = sos_ba_accumulate_local(ba);
   if (rc) return rc;
   return sos_ba_stitch(ba, H_A, b_A, H_L, b_L, H_sc, b_sc, resInA, resInL);
+}
+
+// Fused per-iteration call #1: accumulate + stitch, H_top = H_A + H_L, b_top = b_A + b_L (no priors).
+extern "C" int sos_ba_gn_accumulate(sos_ba *ba, double *H_top, double *b_top, double *H_sc, double *b_sc, int *resInA,
+                                    int *resInL) {
+  if (!ba || !ba->have_window || !ba->have_state || !H_top || !b_top || !H_sc || !b_sc) return SOS_ERR_STATE;
+  SOS_HIP(hipSetDevice(ba->ctx->device));
+  hipStream_t st = ba->ctx->stream;
+  const bool haveL = ba->ntiles > ba->ntilesA;
+  launch_top(ba);
+  launch_sc(ba, 1);
+  launch_reduce(ba);
+  launch_stitch(ba, ba->d_acc.p, haveL ? 2 : 1);
+  SOS_HIP(hipGetLastError());
+  const size_t dim = 4 + 8 * (size_t)ba->n, ms = ba->hb_mode_stride;
+  double *ph = reinterpret_cast<double *>(ba->pin + ba->pin_hb);
+  float *pn = reinterpret_cast<float *>(ph + 3 * ms);
+  if (haveL) {
+    SOS_HIP(hipMemcpyAsync(ph, ba->d_Hout.p, sizeof(double) * 3 * ms, hipMemcpyDeviceToHost, st));
+  } else {  // skip the (all-zero) L block
+    SOS_HIP(hipMemcpyAsync(ph, ba->d_Hout.p, sizeof(double) * ms, hipMemcpyDeviceToHost, st));
+    SOS_HIP(hipMemcpyAsync(ph + 2 * ms, ba->d_Hout.p + 2 * ms, sizeof(double) * ms, hipMemcpyDeviceToHost, st));
+  }
+  SOS_HIP(hipMemcpyAsync(pn, ba->d_acc.p + ba->off_nres, 2 * sizeof(float), hipMemcpyDeviceToHost, st));
+  SOS_HIP(hipStreamSynchronize(st));
+  if (haveL) {
+    for (size_t i = 0; i < dim * dim; i++) H_top[i] = ph[ms + i] + ph[i];  // HL_top + HA_top
+    for (size_t i = 0; i < dim; i++) b_top[i] = ph[ms + dim * dim + i] + ph[dim * dim + i];
+  } else {
+    memcpy(H_top, ph, sizeof(double) * dim * dim);
+    memcpy(b_top, ph + dim * dim, sizeof(double) * dim);
+  }
+  memcpy(H_sc, ph + 2 * ms, sizeof(double) * dim * dim);
+  memcpy(b_sc, ph + 2 * ms + dim * dim, sizeof(double) * dim);
+  if (resInA) *resInA = (int)pn[0];
+  if (resInL) *resInL = haveL ? (int)pn[1] : 0;
+  return SOS_OK;
 }
 
 extern "C" int sos_ba_get_point_hessian(sos_ba *ba, float *idepth_hessian, float *HdiF, float *bdSumF) {
@@ -1508,32 +1863,101 @@ extern "C" int sos_ba_get_point_hessian(sos_ba *ba, float *idepth_hessian, float
   return SOS_OK;
 }
 
-extern "C" int sos_ba_resubstitute(sos_ba *ba, const double *x, float *pointStep) {
-  if (!ba || !ba->have_window || !ba->have_state || !x) return SOS_ERR_STATE;
-  SOS_HIP(hipSetDevice(ba->ctx->device));
-  hipStream_t st = ba->ctx->stream;
+// xc / xAd (OB/EnergyFunctional.cpp:499-516) into the pinned stage, fp32, summed left to right
+static void fill_x(sos_ba *ba, const double *x) {
   const int n = ba->n, dim = 4 + 8 * n;
-  // xAd (OB/EnergyFunctional.cpp:499-516), fp32, summed left to right
-  std::vector<float> xF(dim), xAd((size_t)n * n * 8);
+  float xF[4 + 8 * SOS_MAX_FRAMES];
   for (int i = 0; i < dim; i++) xF[i] = (float)x[i];
+  float *xc = pstg(ba, ba->st_xc), *xAd = pstg(ba, ba->st_xad);
+  for (int i = 0; i < 4; i++) xc[i] = xF[i];
   for (int h = 0; h < n; h++)
     for (int t = 0; t < n; t++) {
       const float *AH = &ba->h_adHostF[64 * (size_t)(h + n * t)], *AT = &ba->h_adTargetF[64 * (size_t)(h + n * t)];
+      float *o = xAd + 8 * (size_t)(n * h + t);
       for (int j = 0; j < 8; j++) {
         float s1 = 0, s2 = 0;
         for (int i = 0; i < 8; i++) {
           s1 += xF[4 + 8 * h + i] * AH[8 * i + j];
           s2 += xF[4 + 8 * t + i] * AT[8 * i + j];
         }
-        xAd[8 * (size_t)(n * h + t) + j] = s1 + s2;
+        o[j] = s1 + s2;
       }
     }
-  SOS_HIP(hipMemcpyAsync(ba->d_xc.p, xF.data(), sizeof(float) * 4, hipMemcpyHostToDevice, st));
-  SOS_HIP(hipMemcpyAsync(ba->d_xAd.p, xAd.data(), sizeof(float) * xAd.size(), hipMemcpyHostToDevice, st));
-  if (ba->P > 0) k_resubstitute<<<divup(ba->P, 128), 128, 0, st>>>(ba->dev, ba->d_xc.p, ba->d_xAd.p, ba->d_step.p);
-  SOS_HIP(hipGetLastError());
-  if (pointStep && ba->P) SOS_HIP(hipMemcpyAsync(pointStep, ba->d_step.p, sizeof(float) * ba->P, hipMemcpyDeviceToHost, st));
+}
+
+extern "C" int sos_ba_resubstitute(sos_ba *ba, const double *x, float *pointStep) {
+  if (!ba || !ba->have_window || !ba->have_state || !x) return SOS_ERR_STATE;
+  SOS_HIP(hipSetDevice(ba->ctx->device));
+  hipStream_t st = ba->ctx->stream;
+  const size_t nn = (size_t)ba->n * ba->n;
   SOS_HIP(hipStreamSynchronize(st));
+  fill_x(ba, x);
+  SOS_HIP(hipMemcpyAsync(stg(ba, ba->st_xc), pstg(ba, ba->st_xc), sizeof(float) * (4 + 8 * nn), hipMemcpyHostToDevice, st));
+  float *dstep = reinterpret_cast<float *>(ba->d_outpack.p + ba->out_step);
+  if (ba->P > 0) k_resubstitute<<<divup(ba->P, 64), 64, 0, st>>>(ba->dev, stg(ba, ba->st_xc), stg(ba, ba->st_xad), dstep, 0, 1.f);
+  SOS_HIP(hipGetLastError());
+  if (pointStep && ba->P) SOS_HIP(hipMemcpyAsync(pointStep, dstep, sizeof(float) * ba->P, hipMemcpyDeviceToHost, st));
+  SOS_HIP(hipStreamSynchronize(st));
+  return SOS_OK;
+}
+
+// Fused per-iteration call #2: back-substitution with x, point step applied on the device
+// (doStepFromBackup), new per-step state, linearizeAll(false) (+ applyRes when applyRes != 0).
+// One H2D of the packed inputs, one D2H of the packed outputs, one synchronisation.
+extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const sos_calib *calib, const sos_precalc *precalc,
+                              const float *adHTdeltaF, const float *cDeltaF, const float *frameEnergyTH, int applyRes,
+                              double *energySum, float *newestEnergies, int *newestCount, float *pointStep) {
+  if (!ba || !ba->have_window || !ba->have_state || !calib || !precalc || !adHTdeltaF || !cDeltaF || !frameEnergyTH)
+    return SOS_ERR_STATE;
+  sos_ctx *c = ba->ctx;
+  SOS_HIP(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  const size_t nn = (size_t)ba->n * ba->n;
+  ba->calib = *calib;
+  ba->dev.calib = *calib;
+  memcpy(pstg(ba, ba->st_pre), precalc, sizeof(sos_precalc) * nn);
+  memcpy(pstg(ba, ba->st_adh), adHTdeltaF, sizeof(float) * 8 * nn);
+  memcpy(pstg(ba, ba->st_cd), cDeltaF, sizeof(float) * 4);
+  memcpy(pstg(ba, ba->st_th), frameEnergyTH, sizeof(float) * ba->n);
+  float *dstep = reinterpret_cast<float *>(ba->d_outpack.p + ba->out_step);
+  if (x) {
+    // the back-substitution uses the OLD state's point sums but only xc/xAd from the stage: upload those
+    // first, run it, then overwrite the rest of the stage for the linearisation at the new state
+    fill_x(ba, x);
+    SOS_HIP(hipMemcpyAsync(stg(ba, 0), pstg(ba, 0), sizeof(float) * ba->st_floats, hipMemcpyHostToDevice, st));
+    if (ba->P > 0)
+      k_resubstitute<<<divup(ba->P, 64), 64, 0, st>>>(ba->dev, stg(ba, ba->st_xc), stg(ba, ba->st_xad), dstep, 1, stepfacD);
+  } else {
+    SOS_HIP(hipMemcpyAsync(stg(ba, 0), pstg(ba, 0), sizeof(float) * ba->st_xc, hipMemcpyHostToDevice, st));
+  }
+  launch_linearize(ba, applyRes ? 1 : 0);
+  SOS_HIP(hipGetLastError());
+  char *po = ba->pin + ba->pin_out;
+  SOS_HIP(hipMemcpyAsync(po, ba->d_outpack.p, ba->out_bytes, hipMemcpyDeviceToHost, st));
+  SOS_HIP(hipStreamSynchronize(st));
+  if (energySum) {
+    const double *es = reinterpret_cast<const double *>(po + ba->out_esum);
+    double e = 0;
+    for (int t = 0; t < ba->ntilesA; t++) e += es[t];
+    *energySum = e;
+  }
+  if (newestEnergies) {
+    const float *ne = reinterpret_cast<const float *>(po + ba->out_newest);
+    int k = 0;
+    for (int i = 0; i < ba->newest_count; i++)
+      if (ne[i] >= 0) newestEnergies[k++] = ne[i];
+    if (newestCount) *newestCount = k;
+  }
+  const float *hs = reinterpret_cast<const float *>(po + ba->out_step);
+  if (x) {
+    for (int p = 0; p < ba->P; p++) {  // keep the host mirror of the snapshot in step with the device
+      const float idn = ba->h_pts[p].idepth_scaled + stepfacD * hs[p];
+      ba->h_pts[p].idepth_scaled = idn;
+      ba->h_pts[p].idepth_zero_scaled = idn;
+      ba->h_pts[p].deltaF = 0.f;
+    }
+    if (pointStep) memcpy(pointStep, hs, sizeof(float) * ba->P);
+  }
   return SOS_OK;
 }
 
@@ -1560,7 +1984,7 @@ extern "C" int sos_ba_accumulate_marg(sos_ba *ba, const int32_t *pointIdx, int c
   SOS_HIP(hipSetDevice(ba->ctx->device));
   hipStream_t st = ba->ctx->stream;
   const int n = ba->n;
-  const size_t dim = 4 + 8 * (size_t)n, nn = (size_t)n * n;
+  const size_t nn = (size_t)n * n;
   // virtual tiles: residuals of the listed points grouped by pair (addPoint<2> visits every active one)
   std::vector<std::vector<int>> bypair(nn);
   std::vector<int> plist(pointIdx, pointIdx + count);
@@ -1586,11 +2010,11 @@ extern "C" int sos_ba_accumulate_marg(sos_ba *ba, const int32_t *pointIdx, int c
     std::vector<std::vector<int>> byhost(n);
     for (int p : plist) byhost[ba->h_pts[p].host].push_back(p);
     for (int h = 0; h < n; h++) {
-      host_chunk_begin[h] = (int)(chunk_pt.size() / 64);
-      for (size_t q = 0; q < byhost[h].size(); q += 64)
-        for (int k = 0; k < 64; k++) chunk_pt.push_back(q + k < byhost[h].size() ? byhost[h][q + k] : -1);
+      host_chunk_begin[h] = (int)(chunk_pt.size() / SOS_GC);
+      for (size_t q = 0; q < byhost[h].size(); q += SOS_GC)
+        for (int k = 0; k < SOS_GC; k++) chunk_pt.push_back(q + k < byhost[h].size() ? byhost[h][q + k] : -1);
     }
-    host_chunk_begin[n] = (int)(chunk_pt.size() / 64);
+    host_chunk_begin[n] = (int)(chunk_pt.size() / SOS_GC);
   }
   const int nch = host_chunk_begin[n];
   // pack [list | list_pair | pair_tile_begin | plist | chunk_pt | host_chunk_begin] into one int upload
@@ -1609,35 +2033,16 @@ extern "C" int sos_ba_accumulate_marg(sos_ba *ba, const int32_t *pointIdx, int c
   SOS_HIP(hipMemsetAsync(acc.p, 0, sizeof(float) * ba->acc_floats, st));
   if (nvt > 0)
     k_top_accumulate<true><<<divup(nvt, 8), 256, 0, st>>>(ba->dev, 0, nvt, 2, B + o_list, B + o_lp, tp.p, nullptr);
-  k_reduce_top<<<n * n, SOS_TOPN, 0, st>>>(tp.p, B + o_ptb, acc.p + ba->off_topA, acc.p + ba->off_nres);
-  if (count > 0) k_point_prep<<<divup(count, 128), 128, 0, st>>>(ba->dev, 0, B + o_pl, count, 1);
-  if (nch > 0) {
-    const size_t lds = sizeof(float) * (64 * (size_t)ba->ld + 64);
-    k_sc_gram<<<nch, 256, lds, st>>>(ba->dev, B + o_cp, ba->Dm, ba->ld, gp.p);
-  }
-  const int elems = 8 * n * (8 * n + 5);
-  dim3 grid(divup(elems, 256), n + 1);
-  k_reduce_sc<<<grid, 256, 0, st>>>(gp.p, B + o_hcb, n, ba->Dm, nch, acc.p + ba->off_D, acc.p + ba->off_E, acc.p + ba->off_EB,
-                                    acc.p + ba->off_Hcc, acc.p + ba->off_bc);
-  double *H = ba->d_Hout.p, *b = ba->d_bout.p;
-  SOS_HIP(hipMemsetAsync(H, 0, sizeof(double) * 3 * dim * dim, st));
-  SOS_HIP(hipMemsetAsync(b, 0, sizeof(double) * 3 * dim, st));
-  dim3 gt(n * (n + 1) / 2 + 1, 1);
-  k_stitch_top<<<gt, 64, 0, st>>>(n, acc.p + ba->off_topA, ba->d_adHost.p, ba->d_adTarget.p, H, b);
-  k_sc_M<<<n * n * n, 64, 0, st>>>(n, acc.p + ba->off_D, ba->d_adHost.p, ba->d_adTarget.p, ba->d_M.p);
-  k_stitch_sc<<<n * n + 1, 64, 0, st>>>(n, ba->d_M.p, acc.p + ba->off_E, acc.p + ba->off_EB, acc.p + ba->off_Hcc,
-                                        acc.p + ba->off_bc, ba->d_adHost.p, ba->d_adTarget.p, H + 2 * dim * dim, b + 2 * dim);
+  if (count > 0) k_point_prep<<<divup(count, 64), 64, 0, st>>>(ba->dev, 0, B + o_pl, count);
+  if (nch > 0) k_sc_gram<<<nch, 256, gram_lds(ba), st>>>(ba->dev, B + o_cp, ba->Dm, ba->ld, gp.p);
+  ReduceArgs a;
+  fill_reduce(ba, a, tp.p, B + o_ptb, gp.p, B + o_hcb, nch, 1, acc.p);
+  k_reduce_all<<<a.b_top + a.b_sc + a.b_tail, 128, 0, st>>>(a);
+  launch_stitch(ba, acc.p, 1);
   SOS_HIP(hipGetLastError());
-  if (M) SOS_HIP(hipMemcpyAsync(M, H, sizeof(double) * dim * dim, hipMemcpyDeviceToHost, st));
-  if (Mb) SOS_HIP(hipMemcpyAsync(Mb, b, sizeof(double) * dim, hipMemcpyDeviceToHost, st));
-  if (Msc) SOS_HIP(hipMemcpyAsync(Msc, H + 2 * dim * dim, sizeof(double) * dim * dim, hipMemcpyDeviceToHost, st));
-  if (Mbsc) SOS_HIP(hipMemcpyAsync(Mbsc, b + 2 * dim, sizeof(double) * dim, hipMemcpyDeviceToHost, st));
-  float nres = 0;
-  SOS_HIP(hipMemcpyAsync(&nres, acc.p + ba->off_nres, sizeof(float), hipMemcpyDeviceToHost, st));
-  SOS_HIP(hipStreamSynchronize(st));
-  if (resInM) *resInM = (int)nres;
+  rc = fetch_hb(ba, acc.p, M, Mb, nullptr, nullptr, Msc, Mbsc, resInM, nullptr, false);
   tp.release(); gp.release(); acc.release();
-  return SOS_OK;
+  return rc;
 }
 
 extern "C" int sos_ba_update_point_priors(sos_ba *ba, const int32_t *pointIdx, const float *priorF, int count) {
@@ -1718,15 +2123,23 @@ extern "C" int sos_ba_time_kernel(sos_ba *ba, const char *kernel, const float *f
   sos_ctx *c = ba->ctx;
   SOS_HIP(hipSetDevice(c->device));
   hipStream_t st = c->stream;
-  if (frameEnergyTH) SOS_HIP(hipMemcpyAsync(ba->d_frameTH.p, frameEnergyTH, sizeof(float) * ba->n, hipMemcpyHostToDevice, st));
+  if (frameEnergyTH) SOS_HIP(hipMemcpyAsync(stg(ba, ba->st_th), frameEnergyTH, sizeof(float) * ba->n, hipMemcpyHostToDevice, st));
   const std::string k(kernel);
   auto once = [&]() -> int {
-    if (k == "linearize") return launch_linearize(ba);
+    if (k == "linearize") return launch_linearize(ba, 0);
+    if (k == "linearize_apply") return launch_linearize(ba, 1);
     if (k == "apply_res") return sos_ba_apply_res(ba);
     if (k == "top_accumulate") return launch_top(ba);
     if (k == "sc_accumulate") return launch_sc(ba, 1);
     if (k == "reduce") return launch_reduce(ba);
+    if (k == "stitch") return launch_stitch(ba, ba->d_acc.p, 2);
     if (k == "accumulate_local") return sos_ba_accumulate_local(ba);
+    if (k == "resubstitute") {
+      if (ba->P > 0)
+        k_resubstitute<<<divup(ba->P, 64), 64, 0, st>>>(ba->dev, stg(ba, ba->st_xc), stg(ba, ba->st_xad),
+                                                        reinterpret_cast<float *>(ba->d_outpack.p + ba->out_step), 0, 1.f);
+      return SOS_OK;
+    }
     return SOS_ERR_ARG;
   };
   int rc = once();  // warm-up, also validates the name

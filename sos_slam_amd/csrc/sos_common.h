@@ -46,6 +46,7 @@
 #define DF_ACTIVE 1u
 #define DF_LINEARIZED 2u
 #define DF_ISNEW 4u
+#define DF_VALID 8u  // a real residual (not tile padding)
 
 struct sos_ctx {
   int device = 0;

@@ -22,7 +22,7 @@ SYMBOLS = [
     "sos_frame_upload_dI", "sos_frame_download_level", "sos_frame_release", "sos_ba_create", "sos_ba_destroy",
     "sos_ba_set_window", "sos_ba_set_state", "sos_ba_linearize", "sos_ba_apply_res", "sos_ba_reset_oob",
     "sos_ba_fix_linearization", "sos_ba_accumulate", "sos_ba_accumulate_local", "sos_ba_acc_buffer",
-    "sos_ba_stitch", "sos_ba_get_point_hessian", "sos_ba_resubstitute", "sos_ba_calc_lenergy",
+    "sos_ba_stitch", "sos_ba_gn_accumulate", "sos_ba_gn_step", "sos_ba_get_point_hessian", "sos_ba_resubstitute", "sos_ba_calc_lenergy",
     "sos_ba_accumulate_marg", "sos_ba_update_point_priors", "sos_ba_get_jacobian", "sos_ba_get_residual_flags", "sos_ba_get_JpJdF",
     "sos_ba_get_res_toZeroF", "sos_ba_time_kernel", "sos_tracker_create", "sos_tracker_destroy",
     "sos_tracker_set_ref", "sos_tracker_scale_depth", "sos_tracker_get_pc", "sos_tracker_calc_res",
@@ -73,6 +73,8 @@ def load():
     L.sos_ba_accumulate_local.argtypes = [vp]
     L.sos_ba_acc_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.sos_ba_stitch.argtypes = [vp] + [vp] * 6 + [C.POINTER(ci), C.POINTER(ci)]
+    L.sos_ba_gn_accumulate.argtypes = [vp, vp, vp, vp, vp, C.POINTER(ci), C.POINTER(ci)]
+    L.sos_ba_gn_step.argtypes = [vp, vp, cf, C.POINTER(Calib), vp, vp, vp, vp, ci, C.POINTER(C.c_double), vp, C.POINTER(ci), vp]
     L.sos_ba_get_point_hessian.argtypes = [vp, vp, vp, vp]
     L.sos_ba_resubstitute.argtypes = [vp, vp, vp]
     L.sos_ba_calc_lenergy.argtypes = [vp, C.POINTER(C.c_double)]
