@@ -89,6 +89,27 @@ typedef void (*sosf_allreduce_fn)(void *user, float *dev_ptr, size_t nfloats);
 typedef float (*sosf_nth_fn)(void *user, const float *energies, int count, float frac);
 int sosf_set_hooks(sosf_system *sys, sosf_allreduce_fn allreduce, sosf_nth_fn nth, void *user);
 
+/* ---- CoarseTracker / ScaleOptimizer (FS/CoarseTracker.h:27-48, FS/ScaleOptimizer.h:43-104) -------------
+ * The LM loops run on the host (8x8 fp64 / scalar solves, SE3 updates), the per-pixel work on the device. */
+typedef struct sosf_tracker sosf_tracker;
+/* makeImages of a frame that is not (yet) a keyframe (FS/FullSystem.cpp:650, 1114): returns its image slot */
+int sosf_upload_image(sosf_system *sys, const float *image, int *slot_out);
+int sosf_release_image(sosf_system *sys, int slot);
+int sosf_tracker_create(sosf_system *sys, sosf_tracker **out);
+int sosf_tracker_destroy(sosf_tracker *trk);
+/* makeK + setCoarseTrackingRef(frameHessians) (FS/FullSystem.cpp:889-890): reference = newest keyframe, points =
+ * those whose lastResiduals[0] is IN (centerProjectedTo, HdiF of the last optimize()) */
+int sosf_tracker_set_ref(sosf_tracker *trk, int32_t *pc_n_out);
+int sosf_tracker_set_ref_raw(sosf_tracker *trk, int npts, const float *u, const float *v, const float *idepth,
+                             const float *hdi, int32_t *pc_n_out);
+sos_tracker *sosf_tracker_handle(sosf_tracker *trk);
+/* trackNewestCoarse (FS/CoarseTracker.cpp:366-552); lastToNew12 / aff2 are in/out */
+int sosf_tracker_track(sosf_tracker *trk, int newSlot, float new_ab_exposure, double *lastToNew12, double *aff2,
+                       int coarsestLvl, const double *minResForAbort5, double *lastResiduals5, double *flow3, int *ok);
+/* optimizeScale (FS/ScaleOptimizer.cpp:120-230) */
+int sosf_tracker_optimize_scale(sosf_tracker *trk, int stereoSlot, const double *tfmF0ToF1_12, const float *K1_level0,
+                                float *scale_inout, int coarsestLvl, float *rmse);
+
 /* accumulated wall-clock seconds per phase of sosf_gn_iteration: 0 accumulate+stitch, 1 assemble+solve,
  * 2 resubstitute, 3 step+precalc, 4 set_state upload, 5 linearize, 6 applyRes */
 int sosf_get_timing(double *phases8, int reset);

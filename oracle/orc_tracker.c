@@ -136,8 +136,13 @@ static void dilate(orc_tracker *T, int lvl, int diag) { /* FS/CoarseTracker.cpp:
   for (int i = wl; i < wh; i++) {
     if (bak[i] <= 0) {
       float sum = 0, num = 0, numn = 0;
-      for (int k = 0; k < 4; k++)
+      for (int k = 0; k < 4; k++) {
+        /* the reference reads one element outside the map for the first / last cell of the loop (index -1
+         * and w*h with the diagonal pattern); both cells are border cells that never reach the template,
+         * so the tap is skipped here */
+        if (i + off[k] < 0 || i + off[k] >= wl * T->h[lvl]) continue;
         if (bak[i + off[k]] > 0) { sum += id[i + off[k]]; num += bak[i + off[k]]; numn++; }
+      }
       if (numn > 0) { id[i] = sum / numn; ws[i] = num / numn; }
     }
   }

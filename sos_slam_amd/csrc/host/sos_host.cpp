@@ -945,12 +945,15 @@ float FullSystem::optimize(int mnumOptIts, int *iterations) {
   if (!std::isfinite(lastEnergy)) isLost = true;
   // point results the viewer / tracker read: idepth_hessian
   if (!ef->allPoints.empty()) {
-    std::vector<float> idh(ef->allPoints.size());
+    std::vector<float> idh(ef->allPoints.size()), hdi(ef->allPoints.size()), bds(ef->allPoints.size());
     // the snapshot order is still the one of the last pack: graph edits above only dropped residuals
-    sos_ba_get_point_hessian(ef->ba, idh.data(), nullptr, nullptr);
+    sos_ba_get_point_hessian(ef->ba, idh.data(), hdi.data(), bds.data());
     for (FrameHessian *fh : frameHessians)
       for (PointHessian *ph : fh->pointHessians)
-        if (ph->packIdx >= 0 && ph->packIdx < (int)idh.size()) ph->idepth_hessian = idh[ph->packIdx];
+        if (ph->packIdx >= 0 && ph->packIdx < (int)idh.size()) {
+          ph->idepth_hessian = idh[ph->packIdx];
+          if (ph->efPoint) { ph->efPoint->HdiF = hdi[ph->packIdx]; ph->efPoint->bdSumF = bds[ph->packIdx]; }
+        }
   }
   return sqrtf((float)(lastEnergy / (SOS_PATTERN_NUM * ef->resInA)));
 }
@@ -1083,6 +1086,244 @@ int FullSystem::marginalizeFrame(FrameHessian *frame) {  // FS/FullSystemMargina
   ef->setAdjointsF(&HCalib);
   ef->setDeltaF(&HCalib);
   return SOS_OK;
+}
+
+// ================================================================================================
+// CoarseTracker / ScaleOptimizer host loops
+// ================================================================================================
+CoarseTracker::CoarseTracker(sos_ctx *c, const sos_params &p) : ctx(c), prm(p) {
+  levels = sos_ctx_pyr_levels(c);
+  for (int l = 0; l < SOS_PYR_LEVELS; l++) pc_n[l] = 0;
+  if (sos_tracker_create(c, &prm, &trk) != SOS_OK) trk = nullptr;
+}
+CoarseTracker::~CoarseTracker() {
+  if (trk) sos_tracker_destroy(trk);
+}
+
+void CoarseTracker::makeK(const CalibHessian *HCalib) {
+  calib = HCalib->toCalib();
+  fx[0] = HCalib->fxl(); fy[0] = HCalib->fyl(); cx[0] = HCalib->cxl(); cy[0] = HCalib->cyl();
+  for (int l = 1; l < levels; l++) {
+    fx[l] = fx[l - 1] * 0.5;
+    fy[l] = fy[l - 1] * 0.5;
+    cx[l] = (cx[0] + 0.5) / ((int)1 << l) - 0.5;
+    cy[l] = (cy[0] + 0.5) / ((int)1 << l) - 0.5;
+  }
+  for (int l = 0; l < levels; l++) {  // K^-1 of [fx 0 cx; 0 fy cy; 0 0 1]
+    float *k = Ki[l];
+    for (int i = 0; i < 9; i++) k[i] = 0;
+    k[0] = 1.0f / fx[l]; k[2] = -cx[l] / fx[l];
+    k[4] = 1.0f / fy[l]; k[5] = -cy[l] / fy[l];
+    k[8] = 1;
+  }
+}
+
+int CoarseTracker::setCoarseTrackingRefRaw(const FrameHessian *lastRef, int npts, const float *u, const float *v,
+                                           const float *idepth, const float *hdi) {
+  refFrameID = lastRef->frameID;
+  ref_ab_exposure = lastRef->ab_exposure;
+  lastRef_aff_g2l = lastRef->aff_g2l();
+  firstCoarseRMSE = -1;
+  return sos_tracker_set_ref(trk, &calib, lastRef->slot, npts, u, v, idepth, hdi, pc_n);
+}
+
+int CoarseTracker::setCoarseTrackingRef(const std::vector<FrameHessian *> &frameHessians) {
+  const FrameHessian *lastRef = frameHessians.back();
+  std::vector<float> u, v, id, hdi;
+  for (FrameHessian *fh : frameHessians)
+    for (PointHessian *ph : fh->pointHessians)
+      if (ph->lastResiduals[0].first != nullptr && ph->lastResiduals[0].second == IN) {  // FS/CoarseTracker.cpp:64-66
+        const PointFrameResidual *r = ph->lastResiduals[0].first;
+        if (r->target != lastRef) continue;
+        u.push_back(r->centerProjectedTo[0]);
+        v.push_back(r->centerProjectedTo[1]);
+        id.push_back(r->centerProjectedTo[2]);
+        hdi.push_back(ph->efPoint ? ph->efPoint->HdiF : 0.f);
+      }
+  return setCoarseTrackingRefRaw(lastRef, (int)u.size(), u.data(), v.data(), id.data(), hdi.data());
+}
+
+void CoarseTracker::scaleCoarseDepthL0(float scale) { sos_tracker_scale_depth(trk, scale); }
+
+static void rki_of(const SE3 &T, const float *Ki, float *RKi, float *t) {
+  float Rf[9];
+  for (int i = 0; i < 9; i++) Rf[i] = (float)T.R[i];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) RKi[3 * r + c] = Rf[3 * r] * Ki[c] + Rf[3 * r + 1] * Ki[3 + c] + Rf[3 * r + 2] * Ki[6 + c];
+  for (int i = 0; i < 3; i++) t[i] = (float)T.t[i];
+}
+
+bool CoarseTracker::trackNewestCoarse(int newSlot, float new_ab_exposure, SE3 &lastToNew_out, AffLight &aff_g2l_out,
+                                      int coarsestLvl, const double *minResForAbort, double *lastResiduals) {
+  for (int i = 0; i < 5; i++) lastResiduals[i] = NAN;
+  lastFlowIndicators[0] = lastFlowIndicators[1] = lastFlowIndicators[2] = 1000;
+  const int maxIterations[] = {10, 20, 50, 50, 50};
+  const float lambdaExtrapolationLimit = 0.001;
+  SE3 refToNew_current = lastToNew_out;
+  AffLight aff_g2l_current = aff_g2l_out;
+  bool haveRepeated = false;
+  const float modeA = prm.affineOptModeA, modeB = prm.affineOptModeB;
+  auto calcRes = [&](int lvl, const SE3 &T, const AffLight &aff, float cutoff, double *rs, float *a_out) {
+    float RKi[9], t[3], affLL[2];
+    rki_of(T, Ki[lvl], RKi, t);
+    double a2[2];
+    AffLight::fromToVecExposure(ref_ab_exposure, new_ab_exposure, lastRef_aff_g2l, aff, a2);
+    affLL[0] = (float)a2[0];
+    affLL[1] = (float)a2[1];
+    if (a_out) *a_out = affLL[0];
+    sos_tracker_calc_res(trk, lvl, newSlot, RKi, t, affLL, cutoff, rs);
+  };
+  for (int lvl = coarsestLvl; lvl >= 0; lvl--) {
+    double H[64], b[8], resOld[6], resNew[6];
+    float levelCutoffRepeat = 1, a_cur = 1;
+    calcRes(lvl, refToNew_current, aff_g2l_current, prm.coarseCutoffTH * levelCutoffRepeat, resOld, &a_cur);
+    while (resOld[5] > 0.6 && levelCutoffRepeat < 50) {
+      levelCutoffRepeat *= 2;
+      calcRes(lvl, refToNew_current, aff_g2l_current, prm.coarseCutoffTH * levelCutoffRepeat, resOld, &a_cur);
+    }
+    sos_tracker_calc_gs(trk, lvl, a_cur, (float)lastRef_aff_g2l.b, H, b);
+    float lambda = 0.01;
+    for (int iteration = 0; iteration < maxIterations[lvl]; iteration++) {
+      std::vector<double> Hl(H, H + 64), nb(8), inc;
+      for (int i = 0; i < 8; i++) { Hl[9 * i] *= (1 + lambda); nb[i] = -b[i]; }
+      ldlt_solve(Hl, nb, inc, 8);
+      if (modeA < 0 && modeB < 0) {  // fix a, b
+        std::vector<double> Hs(36), bs(6), xs;
+        for (int r = 0; r < 6; r++) { for (int cc = 0; cc < 6; cc++) Hs[6 * r + cc] = Hl[8 * r + cc]; bs[r] = nb[r]; }
+        ldlt_solve(Hs, bs, xs, 6);
+        for (int r = 0; r < 6; r++) inc[r] = xs[r];
+        inc[6] = inc[7] = 0;
+      }
+      if (!(modeA < 0) && modeB < 0) {  // fix b
+        std::vector<double> Hs(49), bs(7), xs;
+        for (int r = 0; r < 7; r++) { for (int cc = 0; cc < 7; cc++) Hs[7 * r + cc] = Hl[8 * r + cc]; bs[r] = nb[r]; }
+        ldlt_solve(Hs, bs, xs, 7);
+        for (int r = 0; r < 7; r++) inc[r] = xs[r];
+        inc[7] = 0;
+      }
+      if (modeA < 0 && !(modeB < 0)) {  // fix a
+        std::vector<double> HS(Hl), bS(b, b + 8), Hs(49), bs(7), xs;
+        for (int r = 0; r < 8; r++) HS[8 * r + 6] = HS[8 * r + 7];
+        for (int cc = 0; cc < 8; cc++) HS[8 * 6 + cc] = HS[8 * 7 + cc];
+        bS[6] = bS[7];
+        for (int r = 0; r < 7; r++) { for (int cc = 0; cc < 7; cc++) Hs[7 * r + cc] = HS[8 * r + cc]; bs[r] = -bS[r]; }
+        ldlt_solve(Hs, bs, xs, 7);
+        for (int r = 0; r < 8; r++) inc[r] = 0;
+        for (int r = 0; r < 6; r++) inc[r] = xs[r];
+        inc[7] = xs[6];
+      }
+      float extrapFac = 1;
+      if (lambda < lambdaExtrapolationLimit) extrapFac = sqrt(sqrt(lambdaExtrapolationLimit / lambda));
+      for (int i = 0; i < 8; i++) inc[i] *= extrapFac;
+      double incScaled[8];
+      for (int i = 0; i < 8; i++) incScaled[i] = inc[i];
+      for (int i = 0; i < 3; i++) incScaled[i] *= SOS_SCALE_XI_ROT;      // (sic) FS/CoarseTracker.cpp:455-459
+      for (int i = 3; i < 6; i++) incScaled[i] *= SOS_SCALE_XI_TRANS;
+      incScaled[6] *= SOS_SCALE_A;
+      incScaled[7] *= SOS_SCALE_B;
+      double sum = 0;
+      for (int i = 0; i < 8; i++) sum += incScaled[i];
+      if (!std::isfinite(sum)) for (int i = 0; i < 8; i++) incScaled[i] = 0;
+      const SE3 refToNew_new = SE3::exp(incScaled) * refToNew_current;
+      AffLight aff_g2l_new = aff_g2l_current;
+      aff_g2l_new.a += incScaled[6];
+      aff_g2l_new.b += incScaled[7];
+      float a_new = 1;
+      calcRes(lvl, refToNew_new, aff_g2l_new, prm.coarseCutoffTH * levelCutoffRepeat, resNew, &a_new);
+      const bool accept = (resNew[0] / resNew[1]) < (resOld[0] / resOld[1]);
+      if (accept) {
+        sos_tracker_calc_gs(trk, lvl, a_new, (float)lastRef_aff_g2l.b, H, b);
+        for (int i = 0; i < 6; i++) resOld[i] = resNew[i];
+        aff_g2l_current = aff_g2l_new;
+        refToNew_current = refToNew_new;
+        lambda *= 0.5;
+      } else {
+        lambda *= 4;
+        if (lambda < lambdaExtrapolationLimit) lambda = lambdaExtrapolationLimit;
+      }
+      double nrm = 0;
+      for (int i = 0; i < 8; i++) nrm += inc[i] * inc[i];
+      if (!(std::sqrt(nrm) > 1e-3)) break;
+    }
+    lastResiduals[lvl] = sqrtf((float)(resOld[0] / resOld[1]));
+    lastFlowIndicators[0] = resOld[2];
+    lastFlowIndicators[1] = resOld[3];
+    lastFlowIndicators[2] = resOld[4];
+    if (lastResiduals[lvl] > 1.5 * minResForAbort[lvl]) return false;
+    if (levelCutoffRepeat > 1 && !haveRepeated) {
+      lvl++;
+      haveRepeated = true;
+    }
+  }
+  lastToNew_out = refToNew_current;
+  aff_g2l_out = aff_g2l_current;
+  if ((modeA != 0 && (fabsf((float)aff_g2l_out.a) > 1.2)) || (modeB != 0 && (fabsf((float)aff_g2l_out.b) > 200))) return false;
+  double rel[2];
+  AffLight::fromToVecExposure(ref_ab_exposure, new_ab_exposure, lastRef_aff_g2l, aff_g2l_out, rel);
+  const float relA = (float)rel[0], relB = (float)rel[1];
+  if ((modeA == 0 && (fabsf(logf(relA)) > 1.5)) || (modeB == 0 && (fabsf(relB) > 200))) return false;
+  if (modeA < 0) aff_g2l_out.a = 0;
+  if (modeB < 0) aff_g2l_out.b = 0;
+  return true;
+}
+
+float CoarseTracker::optimizeScale(int stereoSlot, const SE3 &tfmF0ToF1, const float *K1_0, float &scale, int coarsestLvl) {
+  double last_residuals[5] = {NAN, NAN, NAN, NAN, NAN};
+  const int maxIterations[] = {10, 20, 50, 50, 50};
+  const float lambdaExtrapolationLimit = 0.001;
+  float scale_current = scale;
+  bool haveRepeated = false;
+  float fx1[SOS_PYR_LEVELS], fy1[SOS_PYR_LEVELS], cx1[SOS_PYR_LEVELS], cy1[SOS_PYR_LEVELS];
+  fx1[0] = K1_0[0]; fy1[0] = K1_0[1]; cx1[0] = K1_0[2]; cy1[0] = K1_0[3];  // FS/ScaleOptimizer.cpp:66-76
+  for (int l = 1; l < levels; l++) {
+    fx1[l] = fx1[l - 1] * 0.5;
+    fy1[l] = fy1[l - 1] * 0.5;
+    cx1[l] = (cx1[0] + 0.5) / ((int)1 << l) - 0.5;
+    cy1[l] = (cy1[0] + 0.5) / ((int)1 << l) - 0.5;
+  }
+  for (int lvl = coarsestLvl; lvl >= 0; lvl--) {
+    float H = 0, b = 0, levelCutoffRepeat = 1;
+    double resOld[6], resNew[6];
+    const float K1[4] = {fx1[lvl], fy1[lvl], cx1[lvl], cy1[lvl]};
+    float RKi[9], tf[3];
+    rki_of(tfmF0ToF1, Ki[lvl], RKi, tf);
+    sos_tracker_calc_res_scale(trk, lvl, stereoSlot, RKi, tf, K1, scale_current, prm.coarseCutoffTH * levelCutoffRepeat, resOld);
+    while (resOld[5] > 0.6 && levelCutoffRepeat < 50) {
+      levelCutoffRepeat *= 2;
+      sos_tracker_calc_res_scale(trk, lvl, stereoSlot, RKi, tf, K1, scale_current, prm.coarseCutoffTH * levelCutoffRepeat, resOld);
+    }
+    sos_tracker_calc_gs_scale(trk, lvl, tf, K1, scale_current, &H, &b);
+    float lambda = 0.01;
+    for (int iteration = 0; iteration < maxIterations[lvl]; iteration++) {
+      float Hl = H;
+      Hl *= (1 + lambda);
+      float inc = -b / Hl;
+      float extrapFac = 1;
+      if (lambda < lambdaExtrapolationLimit) extrapFac = sqrt(sqrt(lambdaExtrapolationLimit / lambda));
+      inc *= extrapFac;
+      if (!std::isfinite(inc) || fabs(inc) > scale_current) inc = 0.0;
+      const float scale_new = scale_current + inc;
+      sos_tracker_calc_res_scale(trk, lvl, stereoSlot, RKi, tf, K1, scale_new, prm.coarseCutoffTH * levelCutoffRepeat, resNew);
+      const bool accept = (resNew[0] / resNew[1]) < (resOld[0] / resOld[1]);
+      if (accept) {
+        sos_tracker_calc_gs_scale(trk, lvl, tf, K1, scale_new, &H, &b);
+        for (int i = 0; i < 6; i++) resOld[i] = resNew[i];
+        scale_current = scale_new;
+        lambda *= 0.5;
+      } else {
+        lambda *= 4;
+        if (lambda < lambdaExtrapolationLimit) lambda = lambdaExtrapolationLimit;
+      }
+      if (!(inc > 1e-3)) break;
+    }
+    last_residuals[lvl] = sqrtf((float)(resOld[0] / resOld[1]));
+    if (levelCutoffRepeat > 1 && !haveRepeated) {
+      lvl++;
+      haveRepeated = true;
+    }
+  }
+  scale = scale_current;
+  return (float)last_residuals[0];
 }
 
 }  // namespace sos
@@ -1270,6 +1511,81 @@ extern "C" int sosf_set_hooks(sosf_system *s, sosf_allreduce_fn ar, sosf_nth_fn 
   s->fs->ef->allreduceHook = ar;
   s->fs->ef->nthHook = nth;
   s->fs->ef->hookUser = user;
+  return SOS_OK;
+}
+struct sosf_tracker {
+  CoarseTracker *ct;
+  FullSystem *fs;
+};
+extern "C" int sosf_upload_image(sosf_system *s, const float *image, int *slot_out) {
+  if (!s || !image || !slot_out) return SOS_ERR_ARG;
+  FullSystem *fs = s->fs;
+  for (int k = 0; k < SOS_MAX_SLOTS; k++)
+    if (!fs->slotUsed[k]) {
+      int rc = sos_make_pyramid(fs->ctx, k, image, nullptr);
+      if (rc) return rc;
+      fs->slotUsed[k] = true;
+      *slot_out = k;
+      return SOS_OK;
+    }
+  return SOS_ERR_STATE;
+}
+extern "C" int sosf_release_image(sosf_system *s, int slot) {
+  if (!s || slot < 0 || slot >= SOS_MAX_SLOTS) return SOS_ERR_ARG;
+  s->fs->slotUsed[slot] = false;
+  return sos_frame_release(s->fs->ctx, slot);
+}
+extern "C" int sosf_tracker_create(sosf_system *s, sosf_tracker **out) {
+  if (!s || !out) return SOS_ERR_ARG;
+  CoarseTracker *ct = new CoarseTracker(s->fs->ctx, s->fs->prm);
+  if (!ct->ok()) { delete ct; return SOS_ERR_HIP; }
+  sosf_tracker *t = new sosf_tracker();
+  t->ct = ct;
+  t->fs = s->fs;
+  *out = t;
+  return SOS_OK;
+}
+extern "C" int sosf_tracker_destroy(sosf_tracker *t) {
+  if (!t) return SOS_OK;
+  delete t->ct;
+  delete t;
+  return SOS_OK;
+}
+extern "C" int sosf_tracker_set_ref(sosf_tracker *t, int32_t *pc_n_out) {
+  if (!t) return SOS_ERR_ARG;
+  t->ct->makeK(&t->fs->HCalib);
+  int rc = t->ct->setCoarseTrackingRef(t->fs->frameHessians);
+  if (pc_n_out) for (int l = 0; l < t->ct->levels; l++) pc_n_out[l] = t->ct->pc_n[l];
+  return rc;
+}
+extern "C" int sosf_tracker_set_ref_raw(sosf_tracker *t, int npts, const float *u, const float *v, const float *idepth,
+                                        const float *hdi, int32_t *pc_n_out) {
+  if (!t) return SOS_ERR_ARG;
+  t->ct->makeK(&t->fs->HCalib);
+  int rc = t->ct->setCoarseTrackingRefRaw(t->fs->frameHessians.back(), npts, u, v, idepth, hdi);
+  if (pc_n_out) for (int l = 0; l < t->ct->levels; l++) pc_n_out[l] = t->ct->pc_n[l];
+  return rc;
+}
+extern "C" sos_tracker *sosf_tracker_handle(sosf_tracker *t) { return t ? t->ct->trk : nullptr; }
+extern "C" int sosf_tracker_track(sosf_tracker *t, int newSlot, float new_ab_exposure, double *lastToNew12, double *aff2,
+                                  int coarsestLvl, const double *minResForAbort5, double *lastResiduals5, double *flow3,
+                                  int *ok) {
+  if (!t || !lastToNew12 || !aff2 || !minResForAbort5 || !lastResiduals5) return SOS_ERR_ARG;
+  SE3 T = SE3::from12(lastToNew12);
+  AffLight aff(aff2[0], aff2[1]);
+  const bool good = t->ct->trackNewestCoarse(newSlot, new_ab_exposure, T, aff, coarsestLvl, minResForAbort5, lastResiduals5);
+  T.to12(lastToNew12);
+  aff2[0] = aff.a;
+  aff2[1] = aff.b;
+  if (flow3) for (int i = 0; i < 3; i++) flow3[i] = t->ct->lastFlowIndicators[i];
+  if (ok) *ok = good ? 1 : 0;
+  return SOS_OK;
+}
+extern "C" int sosf_tracker_optimize_scale(sosf_tracker *t, int stereoSlot, const double *tfmF0ToF1_12, const float *K1,
+                                           float *scale_inout, int coarsestLvl, float *rmse) {
+  if (!t || !tfmF0ToF1_12 || !K1 || !scale_inout) return SOS_ERR_ARG;
+  const float r = t->ct->optimizeScale(stereoSlot, SE3::from12(tfmF0ToF1_12), K1, *scale_inout, coarsestLvl);
+  if (rmse) *rmse = r;
   return SOS_OK;
 }
 extern "C" sos_ctx *sosf_ctx(sosf_system *s) { return s ? s->fs->ctx : nullptr; }

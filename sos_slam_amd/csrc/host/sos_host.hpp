@@ -255,4 +255,36 @@ class FullSystem {
   std::vector<float> h_newEnergy, h_newEnergyWO, h_center, newestE;
 };
 
+// FS/CoarseTracker.h:27-48 + FS/ScaleOptimizer.h:43-104: host control flow (LM loops, SE3 updates, 8x8 / scalar
+// solves) around the device primitives sos_tracker_calc_res / calc_gs / calc_res_scale / calc_gs_scale.
+class CoarseTracker {
+ public:
+  CoarseTracker(sos_ctx *ctx, const sos_params &prm);
+  ~CoarseTracker();
+  bool ok() const { return trk != nullptr; }
+  void makeK(const CalibHessian *HCalib);                          // FS/ScaleOptimizer.cpp:95-118
+  // makeCoarseDepthL0 inputs collected as FS/CoarseTracker.cpp:62-79 does
+  int setCoarseTrackingRef(const std::vector<FrameHessian *> &frameHessians);   // :232-242
+  int setCoarseTrackingRefRaw(const FrameHessian *lastRef, int npts, const float *u, const float *v, const float *idepth,
+                              const float *hdi);
+  bool trackNewestCoarse(int newSlot, float new_ab_exposure, SE3 &lastToNew_out, AffLight &aff_g2l_out, int coarsestLvl,
+                         const double *minResForAbort5, double *lastResiduals5);   // :366-552
+  float optimizeScale(int stereoSlot, const SE3 &tfmF0ToF1, const float *K1_level0, float &scale, int coarsestLvl);  // FS/ScaleOptimizer.cpp:120-230
+  void scaleCoarseDepthL0(float scale);
+
+  sos_tracker *trk = nullptr;
+  sos_ctx *ctx = nullptr;
+  sos_params prm;
+  int levels = 1;
+  float fx[SOS_PYR_LEVELS], fy[SOS_PYR_LEVELS], cx[SOS_PYR_LEVELS], cy[SOS_PYR_LEVELS], Ki[SOS_PYR_LEVELS][9];
+  sos_calib calib;
+  int pc_n[SOS_PYR_LEVELS];
+  // outputs the reference exposes as fields (FS/CoarseTracker.h:41-48)
+  int refFrameID = -1;
+  float ref_ab_exposure = 1;
+  AffLight lastRef_aff_g2l;
+  double lastFlowIndicators[3] = {1000, 1000, 1000};
+  double firstCoarseRMSE = -1;
+};
+
 }  // namespace sos

@@ -116,9 +116,13 @@ __global__ void k_dilate(float *__restrict__ idepth, float *__restrict__ wsum, c
   if (i >= wl * hl - wl) return;
   if (bak[i] > 0) return;
   const int o0 = diag ? 1 + wl : 1, o1 = diag ? -1 - wl : -1, o2 = diag ? wl - 1 : wl, o3 = diag ? -wl + 1 : -wl;
+  // The reference's loop touches index -1 (first cell, diagonal pattern) and index w*h (last cell): one element
+  // outside the map.  Both cells lie in the 2-pixel border that never reaches the template, so the taps
+  // are treated as empty here instead of reading outside the allocation.
+  const int last = wl * hl - 1;
   float sum = 0, num = 0, numn = 0;
-  if (bak[i + o0] > 0) { sum += idepth[i + o0]; num += bak[i + o0]; numn++; }
-  if (bak[i + o1] > 0) { sum += idepth[i + o1]; num += bak[i + o1]; numn++; }
+  if (i + o0 <= last && bak[i + o0] > 0) { sum += idepth[i + o0]; num += bak[i + o0]; numn++; }
+  if (i + o1 >= 0 && bak[i + o1] > 0) { sum += idepth[i + o1]; num += bak[i + o1]; numn++; }
   if (bak[i + o2] > 0) { sum += idepth[i + o2]; num += bak[i + o2]; numn++; }
   if (bak[i + o3] > 0) { sum += idepth[i + o3]; num += bak[i + o3]; numn++; }
   if (numn > 0) {

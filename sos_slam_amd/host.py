@@ -46,6 +46,17 @@ def load():
     L.sosf_marginalize_points.argtypes = [vp, vp, ci]
     L.sosf_drop_points.argtypes = [vp, vp, ci]
     L.sosf_marginalize_frame.argtypes = [vp, ci]
+    L.sosf_upload_image.argtypes = [vp, vp, C.POINTER(ci)]
+    L.sosf_release_image.argtypes = [vp, ci]
+    L.sosf_tracker_create.argtypes = [vp, C.POINTER(vp)]
+    L.sosf_tracker_destroy.argtypes = [vp]
+    L.sosf_tracker_set_ref.argtypes = [vp, vp]
+    L.sosf_tracker_set_ref_raw.argtypes = [vp, ci, vp, vp, vp, vp, vp]
+    L.sosf_tracker_handle.restype = vp
+    L.sosf_tracker_handle.argtypes = [vp]
+    L.sosf_tracker_track.argtypes = [vp, ci, C.c_float, vp, vp, ci, vp, vp, vp, C.POINTER(ci)]
+    L.sosf_tracker_optimize_scale.argtypes = [vp, ci, vp, vp, C.POINTER(C.c_float), ci, C.POINTER(C.c_float)]
+    L.sosf_get_timing.argtypes = [vp, ci]
     L.sosf_ctx.restype = vp
     L.sosf_ctx.argtypes = [vp]
     L.sosf_ba.restype = vp
@@ -182,3 +193,74 @@ class System:
 
     def marginalize_frame(self, frame_idx):
         _chk(self.L.sosf_marginalize_frame(self.h_, frame_idx), "sosf_marginalize_frame")
+
+
+    def upload_image(self, image) -> int:
+        img = np.ascontiguousarray(image, dtype=np.float32)
+        slot = C.c_int(-1)
+        _chk(self.L.sosf_upload_image(self.h_, _p(img), C.byref(slot)), "sosf_upload_image")
+        return slot.value
+
+    def frame_slot(self, idx) -> int:
+        return self.L.sosf_frame_slot(self.h_, idx)
+
+
+class HostTracker:
+    """CoarseTracker / ScaleOptimizer of the C++ facade (host LM loops + device primitives)."""
+
+    def __init__(self, sysm: System):
+        self.L = sysm.L
+        self.sys = sysm
+        self.h_ = C.c_void_p()
+        _chk(self.L.sosf_tracker_create(sysm.h_, C.byref(self.h_)), "sosf_tracker_create")
+        self.pc_n = np.zeros(6, dtype=np.int32)
+
+    def close(self):
+        if getattr(self, "h_", None):
+            self.L.sosf_tracker_destroy(self.h_)
+            self.h_ = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_ref(self):
+        _chk(self.L.sosf_tracker_set_ref(self.h_, _p(self.pc_n)), "sosf_tracker_set_ref")
+        return self.pc_n.copy()
+
+    def set_ref_raw(self, u, v, idepth, hdi):
+        a = [np.ascontiguousarray(x, dtype=np.float32) for x in (u, v, idepth, hdi)]
+        _chk(self.L.sosf_tracker_set_ref_raw(self.h_, len(a[0]), *[_p(x) for x in a], _p(self.pc_n)),
+             "sosf_tracker_set_ref_raw")
+        return self.pc_n.copy()
+
+    def device(self):
+        """The underlying sos_tracker as a lib.Tracker-like object (primitives calc_res / calc_gs ...)."""
+        t = _lib.Tracker.__new__(_lib.Tracker)
+        t.L = _lib.load()
+        t.ctx = None
+        t.h_ = None  # not owned
+        t._borrowed = C.c_void_p(self.L.sosf_tracker_handle(self.h_))
+        t.pc_n = self.pc_n
+        return t
+
+    def track(self, newSlot, new_ab_exposure, lastToNew12, aff2, coarsest, minRes=None):
+        T = np.ascontiguousarray(lastToNew12, dtype=np.float64).copy()
+        aff = np.ascontiguousarray(aff2, dtype=np.float64).copy()
+        mr = np.full(5, np.nan) if minRes is None else np.ascontiguousarray(minRes, dtype=np.float64)
+        lr, fl = np.zeros(5), np.zeros(3)
+        ok = C.c_int(0)
+        _chk(self.L.sosf_tracker_track(self.h_, newSlot, new_ab_exposure, _p(T), _p(aff), coarsest, _p(mr), _p(lr), _p(fl),
+                                       C.byref(ok)), "sosf_tracker_track")
+        return bool(ok.value), T, aff, lr, fl
+
+    def optimize_scale(self, stereoSlot, tfm12, K1, scale, coarsest):
+        s = C.c_float(scale)
+        r = C.c_float(0)
+        tf = np.ascontiguousarray(tfm12, dtype=np.float64)
+        k1 = np.ascontiguousarray(K1, dtype=np.float32)
+        _chk(self.L.sosf_tracker_optimize_scale(self.h_, stereoSlot, _p(tf), _p(k1), C.byref(s), coarsest, C.byref(r)),
+             "sosf_tracker_optimize_scale")
+        return r.value, s.value

@@ -308,6 +308,11 @@ class Backend:
 
 class Tracker:
     """sos_tracker: device side of one CoarseTracker / ScaleOptimizer."""
+    _borrowed = None
+
+    @property
+    def _h(self):
+        return self._borrowed if self._borrowed is not None else self.h_
 
     def __init__(self, ctx: Context, params: dict):
         self.L = ctx.L
@@ -330,41 +335,41 @@ class Tracker:
 
     def set_ref(self, calib, refSlot, u, v, idepth, hdi):
         a = [np.ascontiguousarray(x, dtype=np.float32) for x in (u, v, idepth, hdi)]
-        _chk(self.L.sos_tracker_set_ref(self.h_, C.byref(calib), refSlot, len(a[0]), *[_p(x) for x in a],
+        _chk(self.L.sos_tracker_set_ref(self._h, C.byref(calib), refSlot, len(a[0]), *[_p(x) for x in a],
                                         _p(self.pc_n)), "sos_tracker_set_ref")
         return self.pc_n.copy()
 
     def scale_depth(self, s):
-        _chk(self.L.sos_tracker_scale_depth(self.h_, s), "sos_tracker_scale_depth")
+        _chk(self.L.sos_tracker_scale_depth(self._h, s), "sos_tracker_scale_depth")
 
     def get_pc(self, lvl):
         n = int(self.pc_n[lvl])
         out = [np.zeros(n, dtype=np.float32) for _ in range(4)]
-        _chk(self.L.sos_tracker_get_pc(self.h_, lvl, *[_p(o) for o in out]), "sos_tracker_get_pc")
+        _chk(self.L.sos_tracker_get_pc(self._h, lvl, *[_p(o) for o in out]), "sos_tracker_get_pc")
         return out
 
     def calc_res(self, lvl, newSlot, RKi, t, affLL, cutoff):
         rs = np.zeros(6)
         a = [np.ascontiguousarray(x, dtype=np.float32) for x in (RKi, t, affLL)]
-        _chk(self.L.sos_tracker_calc_res(self.h_, lvl, newSlot, *[_p(x) for x in a], cutoff, _p(rs)),
+        _chk(self.L.sos_tracker_calc_res(self._h, lvl, newSlot, *[_p(x) for x in a], cutoff, _p(rs)),
              "sos_tracker_calc_res")
         return rs
 
     def calc_gs(self, lvl, a, b0):
         H, b = np.zeros((8, 8)), np.zeros(8)
-        _chk(self.L.sos_tracker_calc_gs(self.h_, lvl, a, b0, _p(H), _p(b)), "sos_tracker_calc_gs")
+        _chk(self.L.sos_tracker_calc_gs(self._h, lvl, a, b0, _p(H), _p(b)), "sos_tracker_calc_gs")
         return H, b
 
     def calc_res_scale(self, lvl, stereoSlot, RKi, t, K1, scale, cutoff):
         rs = np.zeros(6)
         a = [np.ascontiguousarray(x, dtype=np.float32) for x in (RKi, t, K1)]
-        _chk(self.L.sos_tracker_calc_res_scale(self.h_, lvl, stereoSlot, *[_p(x) for x in a], scale, cutoff, _p(rs)),
+        _chk(self.L.sos_tracker_calc_res_scale(self._h, lvl, stereoSlot, *[_p(x) for x in a], scale, cutoff, _p(rs)),
              "sos_tracker_calc_res_scale")
         return rs
 
     def calc_gs_scale(self, lvl, t, K1, scale):
         H, b = C.c_float(0), C.c_float(0)
         a = [np.ascontiguousarray(x, dtype=np.float32) for x in (t, K1)]
-        _chk(self.L.sos_tracker_calc_gs_scale(self.h_, lvl, _p(a[0]), _p(a[1]), scale, C.byref(H), C.byref(b)),
+        _chk(self.L.sos_tracker_calc_gs_scale(self._h, lvl, _p(a[0]), _p(a[1]), scale, C.byref(H), C.byref(b)),
              "sos_tracker_calc_gs_scale")
         return H.value, b.value

@@ -91,6 +91,10 @@ class Window:
     HM: np.ndarray           # (4+8n, 4+8n) float64
     bM: np.ndarray           # (4+8n,) float64
     params: dict
+    extra_images: np.ndarray = None   # (k, h, w): frames that are NOT keyframes of the window (tracker inputs)
+    extra_poses: np.ndarray = None    # (k, 12) camToWorld (R row-major | t) used to render them
+    extra_aff: np.ndarray = None      # (k, 2) affine brightness (a, b) applied when rendering them
+    stereo_tfm: np.ndarray = None     # (12,) tfmF0ToF1 of the stereo partner extra[1]: p1 = R p0 + t
 
     @property
     def P(self) -> int:
@@ -142,7 +146,8 @@ class _Scene:
 
 
 def make_window(name: str = "W12", seed: int = SEED, noise_sigma: float = 1.0, state_noise: float = 3e-4,
-                idepth_noise: float = 0.002, point_seed: int | None = None, **override) -> Window:
+                idepth_noise: float = 0.002, point_seed: int | None = None, extra_frames: int = 0,
+                stereo_baseline: float = 0.11, **override) -> Window:
     cfg = dict(WINDOWS[name]) if name in WINDOWS else {}
     cfg.update(override)
     n, P, w, h = cfg["n"], cfg["P"], cfg["w"], cfg["h"]
@@ -176,6 +181,28 @@ def make_window(name: str = "W12", seed: int = SEED, noise_sigma: float = 1.0, s
         frames[i]["ab_exposure"] = 1.0
         frames[i]["frameID"] = i
         frames[i]["frameEnergyTH"] = 8 * 8 * 8
+
+    # frames outside the window, for the coarse tracker: extra[0] continues the trajectory (the "new frame"),
+    # extra[1] is a stereo partner of the newest keyframe: cam1 = cam0 shifted by the baseline along x plus the
+    # millimetre-level y/z offsets every calibrated rig has (with tz == 0 exactly the reference's calcGSSSEScale
+    # turns its zero-padded SSE lanes into inf * 0 = NaN, FS/ScaleOptimizer.cpp:255-259 -- not a case to pin)
+    stereo_off = np.array([stereo_baseline, 0.0012, 0.0021])
+    ex_img, ex_pose, ex_aff = [], [], []
+    for k in range(extra_frames):
+        if k == 1:
+            Rk = frames[n - 1]["camToWorld"][:9].reshape(3, 3).copy()
+            tk = frames[n - 1]["camToWorld"][9:] + Rk @ stereo_off
+            a_k, b_k = 0.0, 0.0
+        else:
+            i = n + k * 0.35
+            Rk = so3_exp(0.01 * i * np.array([0.3, 1.0, 0.2]))
+            tk = 0.08 * i * np.array([1.0, 0.1, 0.05])
+            a_k, b_k = rng.normal(0, 0.02), rng.normal(0, 2.0)
+        img, _ = scene.render(Rk, tk, K, w, h)
+        img = np.exp(a_k) * img + b_k + rng.normal(0, noise_sigma, img.shape)
+        ex_img.append(np.clip(img, 0.0, 255.0).astype(np.float32))
+        ex_pose.append(np.concatenate([Rk.reshape(-1), tk]))
+        ex_aff.append((a_k, b_k))
 
     # points: P/n per host at integer pixels (point_seed: a different point set on the same frames, used to
     # give every rank of a multi-GPU run its own shard)
@@ -237,7 +264,11 @@ def make_window(name: str = "W12", seed: int = SEED, noise_sigma: float = 1.0, s
     HM = 10.0 * (A @ A.T) / dim + 100.0 * np.eye(dim)
     bM = rng.normal(0, 1.0, dim)
     return Window(name=name, n=n, w=w, h=h, K=K, images=images, frames=frames, points=pts, resid=resid,
-                  HM=HM, bM=bM, params=default_params(w, h))
+                  HM=HM, bM=bM, params=default_params(w, h),
+                  extra_images=np.stack(ex_img) if ex_img else None,
+                  extra_poses=np.stack(ex_pose) if ex_pose else None,
+                  extra_aff=np.array(ex_aff) if ex_aff else None,
+                  stereo_tfm=np.concatenate([np.eye(3).reshape(-1), -stereo_off]))
 
 
 def shard_points(win: Window, rank: int, world: int) -> np.ndarray:

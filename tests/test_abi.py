@@ -1,0 +1,56 @@
+"""The C-ABI libraries load on a GPU-less box and export every symbol the headers declare; creating a
+context without a GPU fails loudly (there is no CPU fallback in the product)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(sos[f]?_[a-zA-Z0-9_]+)\s*\(", txt)) - {"sosf_allreduce_fn", "sosf_nth_fn"})
+
+
+def test_hip_library_exports_header_symbols():
+    from sos_slam_amd import lib
+    L = lib.load()
+    names = _declared("sos_slam.h")
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(L, n), n
+    assert set(lib.SYMBOLS) <= set(names)
+    assert L.sos_backend_name() == b"hip-gfx950"
+
+
+def test_host_library_exports_header_symbols():
+    from sos_slam_amd import host
+    L = host.load()
+    for n in _declared("sos_slam_host.h"):
+        assert hasattr(L, n), n
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from sos_slam_amd import host, lib, synth
+    with pytest.raises(lib.SosError):
+        lib.Context(64, 64)
+    with pytest.raises(lib.SosError):
+        host.System(synth.default_params(64, 64))
+
+
+def test_record_layouts_match_header():
+    """numpy / ctypes mirrors have the sizes the C structs have."""
+    from sos_slam_amd import records, synth
+    assert synth.POINT_DTYPE.itemsize == 96
+    assert synth.RESID_DTYPE.itemsize == 24
+    assert synth.PRECALC_DTYPE.itemsize == 112
+    assert synth.RAWJAC_DTYPE.itemsize == 74 * 4
+    assert synth.FRAME_INIT_DTYPE.itemsize == 12 * 8 + 10 * 8 + 16
+    assert C.sizeof(records.Params) == 18 * 4
+    assert C.sizeof(records.Calib) == 32

@@ -1,0 +1,97 @@
+"""N > 1 path on CPU (gloo, world_size 2): point sharding + the ONE exchange step of the path.
+
+Every rank holds the same frames and a contiguous shard of the allPoints order; the shard-local accumulator
+sums are all-reduced and must equal the single-process accumulation of the whole window; the order statistic
+behind frameEnergyTH is computed from an all-gather.  The arithmetic under test here is the oracle's (tests
+may use it); the HIP path exercises the same sharding / hooks on the GPU box (bench.py --gpus N).
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import oracle as orc
+from sos_slam_amd import distributed as sdist
+from sos_slam_amd import synth
+
+WORLD = 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    win = synth.make_window("T4")
+    shard = synth.take_shard(win, synth.shard_points(win, rank, WORLD))
+    ow = orc.window_from_synth(shard)
+    th = np.full(win.n, 512.0, np.float32)
+    ow.reset_oob()
+    E = ow.linearize(th)
+    ow.apply_res()
+    acc = ow.accumulate(fp64_truth=True)
+    # the exchange step: one all-reduce of the packed H/b blocks (fp64 here, fp32 on the device)
+    packed = torch.from_numpy(np.concatenate([acc[k].reshape(-1) for k in ("H_A", "b_A", "H_sc", "b_sc")] +
+                                             [np.array([E, acc["resInA"]], dtype=np.float64)]))
+    dist.all_reduce(packed)
+    # global order statistic of the newest frame's energies
+    res = ow.res()
+    wo = ow.new_energy_wo()
+    local = wo[(res["target"] == win.n - 1) & (wo >= 0)]
+    nth = sdist.global_nth(dist, local, 0.7)
+    if rank == 0:
+        q.put((packed.numpy().copy(), nth, shard.P, shard.R))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_accumulation_equals_whole_window():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, port, q)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    packed, nth, P0, R0 = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    win = synth.make_window("T4")
+    ow = orc.window_from_synth(win)
+    th = np.full(win.n, 512.0, np.float32)
+    ow.reset_oob()
+    E = ow.linearize(th)
+    ow.apply_res()
+    acc = ow.accumulate(fp64_truth=True)
+    ref = np.concatenate([acc[k].reshape(-1) for k in ("H_A", "b_A", "H_sc", "b_sc")] +
+                         [np.array([E, acc["resInA"]], dtype=np.float64)])
+    assert np.allclose(packed, ref, rtol=1e-12, atol=1e-9 * np.abs(ref).max())
+    res = ow.res()
+    wo = ow.new_energy_wo()
+    allv = np.sort(wo[(res["target"] == win.n - 1) & (wo >= 0)])
+    assert nth == pytest.approx(float(allv[int(0.7 * len(allv))]))
+    assert 0 < P0 < win.P and 0 < R0 < win.R
+
+
+def test_shards_partition_the_window():
+    win = synth.make_window("T6")
+    for world in (2, 4, 8):
+        idx = [synth.shard_points(win, r, world) for r in range(world)]
+        allidx = np.concatenate(idx)
+        assert np.array_equal(allidx, np.arange(win.P))          # contiguous slices of the allPoints order
+        counts = [synth.take_shard(win, i).R for i in idx]
+        assert sum(counts) == win.R
+        assert max(counts) - min(counts) <= win.R / world * 0.25  # balanced by residual count
+        sh = synth.take_shard(win, idx[1])
+        assert np.all(np.diff(sh.resid["point"]) >= 0) and sh.resid["point"].max() == sh.P - 1
