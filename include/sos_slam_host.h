@@ -64,6 +64,8 @@ int sosf_get_calib(sosf_system *sys, double *value_scaled4);
 /* per point, in allPoints order: idepth, idepth_hessian, maxRelBaseline, numGoodResiduals (any may be NULL) */
 int sosf_get_points(sosf_system *sys, float *idepth, float *idepth_hessian, float *maxRelBaseline,
                     int32_t *numGoodResiduals);
+/* per point still in the window, same order: the running index under which it was added (sosf_add_points) */
+int sosf_get_point_ids(sosf_system *sys, int32_t *addIdx);
 /* per residual, in packing order (points -> residualsAll): state_state, isActive; removed = dropped by
  * the final linearizeAll(true) */
 int sosf_get_residuals(sosf_system *sys, int32_t *state_state, int32_t *isActive, int32_t *removed);
@@ -71,8 +73,9 @@ int sosf_get_lastX(sosf_system *sys, double *x);
 int sosf_get_stats(sosf_system *sys, int *resInA, int *resInL, int *resInM);
 
 /* FullSystem::flagPointsForRemoval restricted to an explicit list + ef->marginalizePointsF
- * (FS/FullSystem.cpp:535-614, 909-912; OB/EnergyFunctional.cpp:891-936): the listed points (allPoints
- * indices) are re-linearized, fixed (fixLinearizationF) and marginalised into HM / bM. */
+ * (FS/FullSystem.cpp:535-614, 909-912; OB/EnergyFunctional.cpp:891-936): the listed points (by the running
+ * index under which they were added) are re-linearized, fixed (fixLinearizationF) and marginalised into
+ * HM / bM, or dropped when their idepth_hessian is below setting_minIdepthH_marg. */
 int sosf_marginalize_points(sosf_system *sys, const int32_t *pointIdx, int count);
 /* ef->dropPointsF for an explicit list (PS_DROP) */
 int sosf_drop_points(sosf_system *sys, const int32_t *pointIdx, int count);

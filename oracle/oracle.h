@@ -93,6 +93,14 @@ const double *orc_host_get_adHost(orc_window *W);
 const double *orc_host_get_adTarget(orc_window *W);
 const double *orc_host_get_lastX(orc_window *W);
 void orc_host_get_HM(orc_window *W, double *HM, double *bM);
+/* EFFrame::prior / delta_prior (OB/EnergyFunctionalStructs.cpp:105-130) */
+void orc_host_get_frame_prior(orc_window *W, int frame, double *prior8, double *delta_prior8);
+/* keyframe-rate marginalisation: flagPointsForRemoval (explicit list) + dropPointsF + marginalizePointsF
+ * (FS/FullSystem.cpp:573-596, 909-912; OB/EnergyFunctional.cpp:891-952) and the prior part of
+ * marginalizeFrame (OB/EnergyFunctional.cpp:730-889, IMU off) */
+void orc_host_drop_points(orc_window *W, const int32_t *pointIdx, int count);
+void orc_host_marginalize_points(orc_window *W, const int32_t *pointIdx, int count, int32_t *marg_flag_out);
+void orc_host_marginalize_frame_prior(orc_window *W, int frameIdx, double *HM_out /*(dim-8)^2*/, double *bM_out);
 
 /* ---- stateless helpers ---------------------------------------------------------------------------*/
 /* FrameFramePrecalc::set (FS/HessianBlocks.cpp:431-461) for one ordered pair */

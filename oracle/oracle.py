@@ -72,6 +72,10 @@ def lib():
             getattr(L, name).restype = vp
             getattr(L, name).argtypes = [vp]
         L.orc_host_get_HM.argtypes = [vp, vp, vp]
+        L.orc_host_get_frame_prior.argtypes = [vp, C.c_int, vp, vp]
+        L.orc_host_drop_points.argtypes = [vp, vp, C.c_int]
+        L.orc_host_marginalize_points.argtypes = [vp, vp, C.c_int, vp]
+        L.orc_host_marginalize_frame_prior.argtypes = [vp, C.c_int, vp, vp]
         L.orc_se3_exp12.argtypes = [vp, vp]
         L.orc_se3_log12.argtypes = [vp, vp]
         L.orc_se3_adj12.argtypes = [vp, vp]
@@ -300,6 +304,35 @@ class OracleWindow:
 
     def lastX(self):
         return _view(self.L.orc_host_get_lastX(self.h), np.float64, (4 + 8 * self.n,))
+
+    def get_prior(self):
+        dim = 4 + 8 * self.n
+        HM, bM = np.zeros((dim, dim)), np.zeros(dim)
+        self.L.orc_host_get_HM(self.h, _p(HM), _p(bM))
+        return HM, bM
+
+    def frame_prior(self, f):
+        pr, dp = np.zeros(8), np.zeros(8)
+        self.L.orc_host_get_frame_prior(self.h, f, _p(pr), _p(dp))
+        return pr, dp
+
+    def drop_points(self, idx):
+        a = np.ascontiguousarray(idx, dtype=np.int32)
+        self.L.orc_host_drop_points(self.h, _p(a), len(a))
+
+    def marginalize_points(self, idx):
+        """flagPointsForRemoval (explicit list) + dropPointsF + marginalizePointsF; returns 1 = marginalised,
+        0 = dropped per listed point."""
+        a = np.ascontiguousarray(idx, dtype=np.int32)
+        flag = np.zeros(len(a), dtype=np.int32)
+        self.L.orc_host_marginalize_points(self.h, _p(a), len(a), _p(flag))
+        return flag
+
+    def marginalize_frame_prior(self, frame_idx):
+        dim = 4 + 8 * self.n - 8
+        HM, bM = np.zeros((dim, dim)), np.zeros(dim)
+        self.L.orc_host_marginalize_frame_prior(self.h, frame_idx, _p(HM), _p(bM))
+        return HM, bM
 
 
 def window_from_synth(win, nthreads=1):

@@ -386,6 +386,15 @@ void orc_apply_res_one(orc_window *W, int r) { /* FS/Residuals.cpp:304-321 */
   res->state_energy = W->newEnergy[r];
 }
 
+/* single-residual pieces of FullSystem::flagPointsForRemoval (FS/FullSystem.cpp:577-584) */
+double orc_linearize_one(orc_window *W, int r, const float *frameEnergyTH) { return linearize_one(W, r, frameEnergyTH); }
+void orc_reset_oob_one(orc_window *W, int r) { /* FS/Residuals.h:83-88 */
+  W->newEnergy[r] = 0;
+  W->res[r].state_energy = 0;
+  W->newState[r] = SOS_RES_OUTLIER;
+  W->res[r].state_state = SOS_RES_IN;
+}
+
 void orc_apply_res(orc_window *W) {
   for (int r = 0; r < W->R; r++)
     if (!(W->res[r].flags & SOS_RF_LINEARIZED)) orc_apply_res_one(W, r);

@@ -235,6 +235,10 @@ const float *orc_host_get_adHTdeltaF(orc_window *W) { return W->adHTdeltaF; }
 const double *orc_host_get_adHost(orc_window *W) { return W->adHost; }
 const double *orc_host_get_adTarget(orc_window *W) { return W->adTarget; }
 const double *orc_host_get_lastX(orc_window *W) { return W->lastX; }
+void orc_host_get_frame_prior(orc_window *W, int frame, double *prior8, double *delta_prior8) {
+  memcpy(prior8, W->hf[frame].prior, sizeof(double) * 8);
+  memcpy(delta_prior8, W->hf[frame].delta_prior, sizeof(double) * 8);
+}
 void orc_host_get_HM(orc_window *W, double *HM, double *bM) {
   int dim = 4 + 8 * W->n;
   memcpy(HM, W->HM, sizeof(double) * (size_t)dim * dim);
@@ -444,4 +448,118 @@ float orc_optimize(orc_window *W, int mnumOptIts, int nthreads, int *iters_out) 
   orc_host_precalc(W);
   double lastEnergy = host_linearize_all(W, 1, nthreads);
   return sqrtf((float)(lastEnergy / (8 * W->resInA)));
+}
+
+/* ================================================================================================
+ * keyframe-rate marginalisation (backend part of FullSystem::makeKeyFrame, FS/FullSystem.cpp:899-931)
+ * ============================================================================================== */
+#define SETTING_minIdepthH_marg 50.0f /* U/settings.cpp:62 */
+
+static void remove_point(orc_window *W, int p) { /* EnergyFunctional::removePoint, OB/EnergyFunctional.cpp:954-971 */
+  for (int r = W->pt_begin[p]; r < W->pt_begin[p + 1]; r++) W->res[r].flags |= ORC_RF_REMOVED;
+}
+
+/* ef->dropPointsF for an explicit list (OB/EnergyFunctional.cpp:938-952) */
+void orc_host_drop_points(orc_window *W, const int32_t *pointIdx, int count) {
+  for (int k = 0; k < count; k++) remove_point(W, pointIdx[k]);
+}
+
+/* FullSystem::flagPointsForRemoval restricted to an explicit list of inlier points (FS/FullSystem.cpp:573-596),
+ * ef->dropPointsF (:909) and ef->marginalizePointsF (:912; OB/EnergyFunctional.cpp:891-936, IMU off).
+ * marg_flag_out[k] = 1 if point k was marginalised, 0 if it was dropped (idepth_hessian too small). */
+void orc_host_marginalize_points(orc_window *W, const int32_t *pointIdx, int count, int32_t *marg_flag_out) {
+  int n = W->n, dim = 4 + 8 * n;
+  size_t dd = (size_t)dim * dim;
+  int32_t *marg = (int32_t *)malloc(sizeof(int32_t) * (size_t)(count > 0 ? count : 1));
+  int nmarg = 0;
+  for (int k = 0; k < count; k++) {
+    int p = pointIdx[k];
+    for (int r = W->pt_begin[p]; r < W->pt_begin[p + 1]; r++) {
+      if (W->res[r].flags & ORC_RF_REMOVED) continue; /* not in ph->residuals any more */
+      orc_reset_oob_one(W, r);
+      W->retEnergy[r] = orc_linearize_one(W, r, W->frameEnergyTH);
+      W->res[r].flags &= ~SOS_RF_LINEARIZED;
+      orc_apply_res_one(W, r);
+      if (W->res[r].flags & SOS_RF_ACTIVE) {
+        int32_t rr = r;
+        orc_fix_linearization(W, &rr, 1);
+      }
+    }
+    if (W->idepth_hessian[p] > SETTING_minIdepthH_marg) {
+      marg[nmarg++] = p;
+      if (marg_flag_out) marg_flag_out[k] = 1;
+    } else {
+      remove_point(W, p); /* PS_DROP -> dropPointsF */
+      if (marg_flag_out) marg_flag_out[k] = 0;
+    }
+  }
+  /* marginalizePointsF */
+  for (int k = 0; k < nmarg; k++) W->pts[marg[k]].priorF *= W->prm.idepthFixPriorMargFac;
+  double *M = (double *)malloc(sizeof(double) * dd), *Msc = (double *)malloc(sizeof(double) * dd);
+  double *Mb = (double *)malloc(sizeof(double) * dim), *Mbsc = (double *)malloc(sizeof(double) * dim);
+  int resInM = 0;
+  orc_accumulate_marg(W, marg, nmarg, M, Mb, Msc, Mbsc, &resInM);
+  for (int k = 0; k < nmarg; k++) remove_point(W, marg[k]);
+  for (size_t i = 0; i < dd; i++) W->HM[i] += W->prm.margWeightFac * (M[i] - Msc[i]);
+  for (int i = 0; i < dim; i++) W->bM[i] += W->prm.margWeightFac * (Mb[i] - Mbsc[i]);
+  free(M); free(Msc); free(Mb); free(Mbsc); free(marg);
+}
+
+/* EnergyFunctional::marginalizeFrame (OB/EnergyFunctional.cpp:730-889, IMU off), prior part only: the window
+ * itself is not re-indexed, the (dim-8)-dimensional HM / bM the reference would hold afterwards are returned. */
+void orc_host_marginalize_frame_prior(orc_window *W, int frameIdx, double *HM_out, double *bM_out) {
+  int n = W->n, step = 8, odim = 4 + n * step, ndim = odim - step;
+  int io = 4 + frameIdx * step, ntail = step * (n - frameIdx - 1);
+  int *perm = (int *)malloc(sizeof(int) * odim);
+  /* :797-811: the frame's block is moved behind the tail (three block copies = this permutation) */
+  for (int i = 0; i < io; i++) perm[i] = i;
+  for (int i = 0; i < ntail; i++) perm[io + i] = io + step + i;
+  for (int i = 0; i < step; i++) perm[io + ntail + i] = io + i;
+  double *H = (double *)malloc(sizeof(double) * (size_t)odim * odim), *b = (double *)malloc(sizeof(double) * odim);
+  for (int i = 0; i < odim; i++) {
+    b[i] = W->bM[perm[i]];
+    for (int j = 0; j < odim; j++) H[(size_t)i * odim + j] = W->HM[(size_t)perm[i] * odim + perm[j]];
+  }
+  const orc_hframe *fh = &W->hf[frameIdx];
+  for (int i = 0; i < 8; i++) { /* :814-815 */
+    H[(size_t)(ndim + i) * odim + ndim + i] += fh->prior[i];
+    b[ndim + i] += fh->prior[i] * fh->delta_prior[i];
+  }
+  double *SVec = (double *)malloc(sizeof(double) * odim), *SVecI = (double *)malloc(sizeof(double) * odim);
+  for (int i = 0; i < odim; i++) { /* :826-828 */
+    SVec[i] = sqrt(fabs(H[(size_t)i * odim + i]) + 10);
+    SVecI[i] = 1.0 / SVec[i];
+  }
+  for (int i = 0; i < odim; i++) {
+    for (int j = 0; j < odim; j++) H[(size_t)i * odim + j] = SVecI[i] * H[(size_t)i * odim + j] * SVecI[j];
+    b[i] = SVecI[i] * b[i];
+  }
+  double hpi[64], hpinv[64];
+  for (int i = 0; i < step; i++)
+    for (int j = 0; j < step; j++) hpi[i * step + j] = H[(size_t)(ndim + i) * odim + ndim + j];
+  orc_mat_inverse(hpi, hpinv, step); /* :840-843 (the two 0.5*(hpi+hpi) lines are identities) */
+  double *bli = (double *)malloc(sizeof(double) * (size_t)ndim * step);
+  for (int i = 0; i < ndim; i++) /* bli = bottomLeft^T * hpi, :847 */
+    for (int j = 0; j < step; j++) {
+      double s = 0;
+      for (int k = 0; k < step; k++) s += H[(size_t)(ndim + k) * odim + i] * hpinv[k * step + j];
+      bli[(size_t)i * step + j] = s;
+    }
+  for (int i = 0; i < ndim; i++) { /* :848-850 */
+    for (int j = 0; j < ndim; j++) {
+      double s = 0;
+      for (int k = 0; k < step; k++) s += bli[(size_t)i * step + k] * H[(size_t)(ndim + k) * odim + j];
+      H[(size_t)i * odim + j] -= s;
+    }
+    double s = 0;
+    for (int k = 0; k < step; k++) s += bli[(size_t)i * step + k] * b[ndim + k];
+    b[i] -= s;
+  }
+  for (int i = 0; i < ndim; i++) /* un-scale, symmetrise: :853-859 */
+    for (int j = 0; j < ndim; j++) {
+      double hij = SVec[i] * H[(size_t)i * odim + j] * SVec[j], hji = SVec[j] * H[(size_t)j * odim + i] * SVec[i];
+      HM_out[(size_t)i * ndim + j] = 0.5 * (hij + hji);
+    }
+  for (int i = 0; i < ndim; i++) bM_out[i] = SVec[i] * b[i];
+  free(perm); free(H); free(b); free(SVec); free(SVecI); free(bli);
 }

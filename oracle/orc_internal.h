@@ -49,5 +49,7 @@ struct orc_window {
 };
 
 void orc_apply_res_one(orc_window *W, int r);
+double orc_linearize_one(orc_window *W, int r, const float *frameEnergyTH);
+void orc_reset_oob_one(orc_window *W, int r);
 
 #endif

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unordered_map>
 
 #include "../../../include/sos_slam_host.h"
 
@@ -1476,11 +1477,22 @@ extern "C" int sosf_get_stats(sosf_system *s, int *a, int *l, int *m) {
   return SOS_OK;
 }
 static int collect_points(FullSystem *fs, const int32_t *idx, int count, std::vector<PointHessian *> &out) {
-  fs->ef->makeIDX();
+  // idx = running index in which the point was added (stable across removals)
+  std::unordered_map<int, PointHessian *> byUser;
+  for (FrameHessian *fh : fs->frameHessians)
+    for (PointHessian *ph : fh->pointHessians) byUser[ph->userIdx] = ph;
   for (int i = 0; i < count; i++) {
-    if (idx[i] < 0 || idx[i] >= (int)fs->ef->allPoints.size()) return SOS_ERR_ARG;
-    out.push_back(fs->ef->allPoints[idx[i]]->data);
+    auto it = byUser.find(idx[i]);
+    if (it == byUser.end()) return SOS_ERR_ARG;
+    out.push_back(it->second);
   }
+  return SOS_OK;
+}
+extern "C" int sosf_get_point_ids(sosf_system *s, int32_t *userIdx) {
+  if (!s || !userIdx) return SOS_ERR_ARG;
+  size_t k = 0;
+  for (FrameHessian *fh : s->fs->frameHessians)
+    for (EFPoint *p : fh->efFrame->points) userIdx[k++] = p->data->userIdx;
   return SOS_OK;
 }
 extern "C" int sosf_marginalize_points(sosf_system *s, const int32_t *pointIdx, int count) {

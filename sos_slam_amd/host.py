@@ -40,6 +40,7 @@ def load():
     L.sosf_get_frame.argtypes = [vp, ci, vp, vp, vp, C.POINTER(C.c_float)]
     L.sosf_get_calib.argtypes = [vp, vp]
     L.sosf_get_points.argtypes = [vp, vp, vp, vp, vp]
+    L.sosf_get_point_ids.argtypes = [vp, vp]
     L.sosf_get_residuals.argtypes = [vp, vp, vp, vp]
     L.sosf_get_lastX.argtypes = [vp, vp]
     L.sosf_get_stats.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
@@ -182,6 +183,12 @@ class System:
         a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
         _chk(self.L.sosf_get_stats(self.h_, C.byref(a), C.byref(b), C.byref(c)), "sosf_get_stats")
         return dict(resInA=a.value, resInL=b.value, resInM=c.value)
+
+    def point_ids(self):
+        _, P, _ = self.counts()
+        ids = np.zeros(P, dtype=np.int32)
+        _chk(self.L.sosf_get_point_ids(self.h_, _p(ids)), "sosf_get_point_ids")
+        return ids
 
     def marginalize_points(self, idx):
         idx = np.ascontiguousarray(idx, dtype=np.int32)

@@ -277,6 +277,11 @@ class Backend:
              "sos_ba_accumulate_marg")
         return dict(M=out[0], Mb=out[1], Msc=out[2], Mbsc=out[3], resInM=rm.value)
 
+    def update_point_priors(self, point_idx, priorF):
+        idx = np.ascontiguousarray(point_idx, dtype=np.int32)
+        pr = np.ascontiguousarray(priorF, dtype=np.float32)
+        _chk(self.L.sos_ba_update_point_priors(self.h_, _p(idx), _p(pr), len(idx)), "sos_ba_update_point_priors")
+
     def jacobian(self, r, which=0):
         out = np.zeros(1, dtype=RAWJAC_DTYPE)
         _chk(self.L.sos_ba_get_jacobian(self.h_, int(r), which, _p(out)), "sos_ba_get_jacobian")

@@ -118,3 +118,59 @@ def test_outlier_and_oob_edges(case):
     ow.linearize(th)
     g = ba.linearize(th)
     assert np.array_equal(g["newState"].astype(np.int32), ow.new_state())
+
+
+@pytest.mark.parametrize("name", ["T4", "T6"])
+def test_fix_linearization_marginalise_and_linearized_mode(name):
+    """F4 fixLinearizationF, F14 marginalisation accumulate (addPoint<2>), F7 mode 1 (linearised residuals after
+    a re-pack with frozen Jacobians) and F13 calcLEnergy against the oracle on identical state."""
+    from sos_slam_amd import lib
+    win = synth.make_window(name)
+    ow = hp.oracle_window(win)
+    ctx, ba = hp.gpu_backend(win, ow)
+    th = np.full(win.n, 512.0, np.float32)
+    ow.reset_oob(); ba.reset_oob()
+    ow.linearize(th); ba.linearize(th)
+    ow.apply_res(); ba.apply_res()
+    # an accumulate leaves Hdd/bd/Hcd and idepth_hessian behind, as optimize() would have
+    ow.accumulate(); ba.accumulate()
+    res = ow.res()
+    pts_sel = np.flatnonzero(win.points["host"] == 0)[::2]
+    in_sel = np.isin(res["point"], pts_sel)
+    ridx = np.flatnonzero(in_sel & ((res["flags"] & 1) != 0)).astype(np.int32)
+    assert len(ridx) > 20
+    ow.fix_linearization(ridx)
+    ba.fix_linearization(ridx)
+    assert np.array_equal(ba.res_toZeroF()[ridx], ow.res_toZeroF()[ridx])
+    f, s, e = ba.residual_flags()
+    assert np.array_equal(f & 3, ow.res()["flags"] & 3)
+    # --- marginalisation accumulate: priorF *= idepthFixPriorMargFac first (OB/EnergyFunctional.cpp:901)
+    prior = ow.pts()["priorF"][pts_sel] * np.float32(win.params["idepthFixPriorMargFac"])
+    ow.pts()["priorF"][pts_sel] = prior
+    ba.update_point_priors(pts_sel, prior)
+    m_o = ow.accumulate_marg(pts_sel)
+    m_g = ba.accumulate_marg(pts_sel)
+    assert m_g["resInM"] == m_o["resInM"] == len(ridx)
+    for k in ("M", "Mb", "Msc", "Mbsc"):
+        assert hp.relerr(m_g[k], m_o[k]) < H_TOL, (k, hp.relerr(m_g[k], m_o[k]))
+    # --- linearised residuals through a re-pack: frozen J + res_toZeroF travel with the snapshot
+    ctx2 = lib.Context(win.w, win.h)
+    for i in range(win.n):
+        ctx2.make_pyramid(i, win.images[i])
+    ba2 = lib.Backend(ctx2, win.params)
+    res_now = ow.res().copy()
+    res_now["flags"] &= 7
+    ba2.set_window(np.arange(win.n), ow.pts().copy(), res_now, ow.res_toZeroF().copy(), ow.J().copy())
+    hp.push_state(ba2, ow)
+    # the active (non-linearised) residuals need their Jacobians on the new backend: one linearize + applyRes
+    ba2.linearize(th)
+    ba2.apply_res()
+    a_g = ba2.accumulate()
+    a_t = ow.accumulate(fp64_truth=True)
+    assert a_g["resInA"] == a_t["resInA"] and a_g["resInL"] == a_t["resInL"] == len(ridx)
+    for k in ("H_A", "b_A", "H_L", "b_L", "H_sc", "b_sc"):
+        assert hp.relerr(a_g[k], a_t[k]) < H_TOL, (k, hp.relerr(a_g[k], a_t[k]))
+    E_o, E_g = ow.calc_lenergy(), ba2.calc_lenergy()
+    assert abs(E_g - E_o) <= 1e-5 * max(abs(E_o), 1e-6)
+    for o in (ba2, ctx2, ba, ctx, ow):
+        o.close()

@@ -183,3 +183,60 @@ def test_energy_threshold_statistic():
     assert th > 0 and np.isfinite(th)
     # older frames keep their threshold
     assert ow.frame(0)["frameEnergyTH"] == pytest.approx(512.0)
+
+
+def test_marginalize_frame_is_dense_schur_complement():
+    """marginalizeFrame (OB/EnergyFunctional.cpp:730-889, IMU off) = eliminating the frame's 8 variables (with its
+    prior added) from HM / bM; the reference's Jacobi scaling and symmetrisation do not change the result."""
+    win = synth.make_window("T4")
+    rng = np.random.default_rng(11)
+    dim = 4 + 8 * win.n
+    A = rng.normal(size=(dim, dim + 5))
+    HM = A @ A.T * 1e3 + np.diag(rng.uniform(1, 1e6, dim))
+    bM = rng.normal(size=dim) * 1e2
+    win.HM, win.bM = HM, bM
+    ow = orc.window_from_synth(win)
+    for f in (0, 2, win.n - 2):
+        Hn, bn = ow.marginalize_frame_prior(f)
+        fr = ow.frame(f)
+        keep = np.r_[0:4 + 8 * f, 4 + 8 * (f + 1):dim]
+        drop = np.r_[4 + 8 * f:4 + 8 * (f + 1)]
+        # frame prior of a non-first frame: 0 on the pose, affine priors on a,b (FS/HessianBlocks.h:283-303)
+        Hd = HM[np.ix_(drop, drop)].copy()
+        prior = ow.frame_prior(f)
+        Hd += np.diag(prior[0])
+        bd = bM[drop] + prior[0] * prior[1]
+        B = HM[np.ix_(keep, drop)]
+        H_ref = HM[np.ix_(keep, keep)] - B @ np.linalg.solve(Hd, B.T)
+        b_ref = bM[keep] - B @ np.linalg.solve(Hd, bd)
+        assert np.abs(Hn - H_ref).max() < 1e-9 * np.abs(H_ref).max()
+        assert np.abs(bn - b_ref).max() < 1e-9 * np.abs(b_ref).max()
+        assert np.array_equal(Hn, Hn.T)
+        assert fr is not None
+    ow.close()
+
+
+def test_marginalize_points_is_additive():
+    """marginalizePointsF adds margWeightFac * (M - Msc) per point: marginalising a set in one call or in two
+    gives the same prior up to fp32 summation order, and leaves the other points untouched."""
+    win = synth.make_window("T4")
+    sel = np.flatnonzero(win.points["host"] == 0)
+
+    def run(batches):
+        ow = orc.window_from_synth(win)
+        ow.optimize(3)
+        flags = [ow.marginalize_points(b) for b in batches]
+        HM, bM = ow.get_prior()
+        removed = (ow.res()["flags"] & 0x100) != 0
+        pts_of_removed = np.unique(ow.res()["point"][removed])
+        ow.close()
+        return HM, bM, np.concatenate(flags), pts_of_removed
+
+    H1, b1, f1, rm1 = run([sel])
+    H2, b2, f2, rm2 = run([sel[: len(sel) // 2], sel[len(sel) // 2:]])
+    assert np.array_equal(f1, f2) and f1.sum() > 5
+    assert np.abs(H1).max() > 0
+    assert np.abs(H1 - H2).max() < 1e-5 * np.abs(H1).max()
+    assert np.abs(b1 - b2).max() < 1e-5 * max(np.abs(b1).max(), 1e-12)
+    observed = np.unique(win.resid["point"])
+    assert np.isin(sel[np.isin(sel, observed)], rm1).all()
