@@ -1,0 +1,52 @@
+"""The RCCL exchange path on one GPU: a world-size-1 `nccl` process group drives the facade's all-reduce and
+order-statistic hooks (sos_slam_amd/distributed.py).  With one rank the all-reduce is the identity, so the hooked
+run must reproduce the un-hooked run bit for bit -- this pins the plumbing (packed device buffer handed to
+torch zero-copy, stream ordering around the collective, hook signatures); the N > 1 arithmetic is covered by
+tests/test_distributed_gloo.py on CPU."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from sos_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_hooked_run_equals_plain_run():
+    import torch
+    import torch.distributed as dist
+    from sos_slam_amd import distributed as sdist
+    from sos_slam_amd import host
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        win = synth.make_window("T6")
+        out = []
+        for hooked in (False, True):
+            sysm = host.System.from_window(win)
+            if hooked:
+                sdist.attach(sysm, dist, torch)
+            rmse, its = sysm.optimize(4)
+            pts = sysm.points()
+            out.append((rmse, its, sysm.lastX().copy(), pts["idepth"].copy(),
+                        [sysm.frame(f)["frameEnergyTH"] for f in range(win.n)]))
+            sysm.close()
+        a, b = out
+        assert a[0] == b[0] and a[1] == b[1]
+        assert np.array_equal(a[2], b[2])
+        assert np.array_equal(a[3], b[3])
+        assert a[4] == b[4]
+    finally:
+        dist.destroy_process_group()
