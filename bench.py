@@ -100,6 +100,7 @@ def main():
     if world > 1:
         sdist.attach(sysm, dist, torch)
     sysm.prepare()
+    sysm.set_pipeline(True)  # the loop below never stops on `canbreak`: every step may prefetch the next accumulate
     R_local = win.R
 
     def barrier():

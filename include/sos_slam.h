@@ -257,6 +257,13 @@ int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const sos_calib 
                    const float *adHTdeltaF, const float *cDeltaF, const float *frameEnergyTH, int applyRes,
                    double *energySum, float *newestEnergies, int *newestCount, float *pointStep);
 
+/* Pipelining switch of the fused calls: when on, sos_ba_gn_step(applyRes != 0) enqueues the accumulate + stitch of
+ * the NEXT iteration right behind the linearisation (it depends on device state only) and returns as soon as the
+ * linearisation results are on the host; the following sos_ba_gn_accumulate then only waits for it.  Any other
+ * state-changing call in between discards the prefetched result.  Leave it off for the last iteration of a loop:
+ * the per-point results (sos_ba_get_point_hessian) always belong to the latest accumulate that ran. */
+int sos_ba_set_prefetch(sos_ba *ba, int on);
+
 /* per-point results of the accumulation: idepth_hessian (OB/AccumulatedSCHessian.cpp:50),
  * HdiF, bdSumF.  Each P floats, may be NULL. */
 int sos_ba_get_point_hessian(sos_ba *ba, float *idepth_hessian, float *HdiF, float *bdSumF);

@@ -55,6 +55,9 @@ int sosf_optimize(sosf_system *sys, int mnumOptIts, float *rmse, int *iterations
  * (FS/FullSystemOptimize.cpp:358-413) */
 int sosf_prepare(sosf_system *sys);
 int sosf_gn_iteration(sosf_system *sys, int iteration, int *canbreak);
+/* the caller will keep calling sosf_gn_iteration whatever `canbreak` says (benchmark loops): lets every iteration
+ * prefetch the next accumulate (sos_ba_set_prefetch); optimize() decides per iteration by itself */
+int sosf_set_pipeline(sosf_system *sys, int on);
 /* only the device part of one iteration with the host solve replaced by the last x (profiling) */
 int sosf_counts(sosf_system *sys, int *nFrames, int *nPoints, int *nResiduals);
 

@@ -884,7 +884,7 @@ int FullSystem::prepare() {  // FS/FullSystemOptimize.cpp:316-344
   return lastError;
 }
 
-bool FullSystem::gnIteration(int iteration) {  // :358-413 with setting_forceAceptStep
+bool FullSystem::gnIteration(int iteration, bool mayContinue) {  // :358-413 with setting_forceAceptStep
   backupState();
   ef->solveSystemF(iteration, 1e-1, &HCalib, true);  // x, frame / calib steps; back-substitution deferred
   bool canbreak;
@@ -903,6 +903,9 @@ bool FullSystem::gnIteration(int iteration) {  // :358-413 with setting_forceAce
     int cnt = 0;
     double E = 0;
     ef->pointStep.resize(ef->allPoints.size());
+    // the next iteration's accumulate can be enqueued behind this linearisation when there will be one
+    const bool more = pipelineAlways || (mayContinue && !(canbreak && iteration >= setting_minOptIterations));
+    sos_ba_set_prefetch(ef->ba, (more && !ef->allreduceHook) ? 1 : 0);
     lastError = sos_ba_gn_step(ef->ba, ef->lastX.data(), 1.0f, &cal, pc.data(), ef->adHTdeltaF.data(), ef->cDeltaF, th.data(),
                                1, &E, newestE.data(), &cnt, ef->pointStep.data());
     newestE.resize(cnt);
@@ -927,7 +930,7 @@ float FullSystem::optimize(int mnumOptIts, int *iterations) {
   if (prepare() != SOS_OK) return NAN;
   int it = 0;
   for (int iteration = 0; iteration < mnumOptIts; iteration++) {
-    const bool canbreak = gnIteration(iteration);
+    const bool canbreak = gnIteration(iteration, iteration + 1 < mnumOptIts);
     it++;
     if (canbreak && iteration >= setting_minOptIterations) break;
   }
@@ -1411,9 +1414,15 @@ extern "C" int sosf_optimize(sosf_system *s, int mnumOptIts, float *rmse, int *i
 extern "C" int sosf_prepare(sosf_system *s) { return s ? s->fs->prepare() : SOS_ERR_ARG; }
 extern "C" int sosf_gn_iteration(sosf_system *s, int iteration, int *canbreak) {
   if (!s) return SOS_ERR_ARG;
-  const bool cb = s->fs->gnIteration(iteration);
+  const bool cb = s->fs->gnIteration(iteration, false);
   if (canbreak) *canbreak = cb ? 1 : 0;
   return s->fs->lastError;
+}
+extern "C" int sosf_set_pipeline(sosf_system *s, int on) {
+  if (!s) return SOS_ERR_ARG;
+  s->fs->pipelineAlways = on != 0;
+  if (!on) sos_ba_set_prefetch(s->fs->ef->ba, 0);
+  return SOS_OK;
 }
 extern "C" int sosf_counts(sosf_system *s, int *nF, int *nP, int *nR) {
   if (!s) return SOS_ERR_ARG;

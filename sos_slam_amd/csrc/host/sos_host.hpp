@@ -224,7 +224,8 @@ class FullSystem {
 
   float optimize(int mnumOptIts, int *iterations);            // FS/FullSystemOptimize.cpp:305-489
   int prepare();                                              // :316-344
-  bool gnIteration(int iteration);                            // :358-413
+  bool gnIteration(int iteration, bool mayContinue = false);  // :358-413
+  bool pipelineAlways = false;  // flat API: the caller iterates regardless of canbreak
   void setPrecalcValues();                                    // FS/FullSystem.cpp:1099-1107
   void removeOutliers();                                      // FS/FullSystemOptimize.cpp:507-526
   int marginalizePoints(const std::vector<PointHessian *> &pts);  // flagPointsForRemoval core + marginalizePointsF

@@ -973,13 +973,15 @@ __global__ __launch_bounds__(64) void k_sc_MC(int n, const float *__restrict__ a
 // stage 2, grid n*n + 1: H_sc[g1,g2] = sum_t1 C1[g1][t1][g2] + sum_{h != g1} C2[h][g1][g2]
 __global__ __launch_bounds__(64) void k_sc_sum(int n, const double *__restrict__ C, const double *__restrict__ Ce,
                                                const float *__restrict__ accHcc, const float *__restrict__ accbc,
-                                               double *__restrict__ H) {
+                                               double *__restrict__ H, const float *__restrict__ nres,
+                                               float *__restrict__ nres_out) {
   const int dim = 4 + 8 * n;
   double *bv = H + (size_t)dim * dim;
   const int tid = threadIdx.x, i = tid >> 3, j = tid & 7;
   if ((int)blockIdx.x == n * n) {
     if (tid < 16) H[(size_t)(tid >> 2) * dim + (tid & 3)] = (double)accHcc[tid];
     else if (tid < 20) bv[tid - 16] = (double)accbc[tid - 16];
+    else if (tid < 22 && nres_out) nres_out[tid - 20] = nres[tid - 20];  // residual counts travel with H/b
     return;
   }
   const int g1 = blockIdx.x % n, g2 = blockIdx.x / n;
@@ -1266,8 +1268,13 @@ struct sos_ba {
   size_t st_pre = 0, st_adh = 0, st_cd = 0, st_th = 0, st_xc = 0, st_xad = 0, st_floats = 0;
   size_t out_esum = 0, out_newest = 0, out_step = 0, out_bytes = 0;
   int newest_begin = 0, newest_count = 0;
-  char *pin = nullptr;     // pinned host staging: [stage | outpack | Hb]
+  char *pin = nullptr;     // pinned + device-mapped host block: [stage | outpack | Hb]; the fused per-iteration
+  char *pin_dev = nullptr; // calls let kernels read / write it directly (no copy commands on the critical path)
   size_t pin_bytes = 0, pin_stage = 0, pin_out = 0, pin_hb = 0;
+  bool prefetch = false;      // sos_ba_set_prefetch: gn_step enqueues the next gn_accumulate behind the linearisation
+  bool acc_inflight = false;  // ... and this says its result is (or will be) in the mapped Hb block
+  bool acc_inflight_haveL = false;
+  hipEvent_t ev_step = nullptr;
   size_t hb_mode_stride = 0;  // doubles per (H | b) block in d_Hout
   std::vector<float> h_adHostF, h_adTargetF;
   size_t acc_floats = 0;
@@ -1285,7 +1292,18 @@ extern "C" int sos_ba_create(sos_ctx *ctx, const sos_params *prm, sos_ba **out) 
   ba->ctx = ctx;
   ba->prm = *prm;
   memset(&ba->dev, 0, sizeof(ba->dev));
+  if (hipSetDevice(ctx->device) != hipSuccess || hipEventCreateWithFlags(&ba->ev_step, hipEventDisableTiming) != hipSuccess) {
+    delete ba;
+    return SOS_ERR_HIP;
+  }
   *out = ba;
+  return SOS_OK;
+}
+
+extern "C" int sos_ba_set_prefetch(sos_ba *ba, int on) {
+  if (!ba) return SOS_ERR_ARG;
+  ba->prefetch = on != 0;
+  if (!on) ba->acc_inflight = false;
   return SOS_OK;
 }
 
@@ -1308,6 +1326,7 @@ extern "C" int sos_ba_destroy(sos_ba *ba) {
   ba->d_rawjac.release();
   ba->d_p_list2.release(); ba->d_r_geo.release(); ba->d_r_cw.release(); ba->d_stage.release(); ba->d_outpack.release(); ba->d_C.release();
   if (ba->pin) hipHostFree(ba->pin);
+  if (ba->ev_step) hipEventDestroy(ba->ev_step);
   delete ba;
   return SOS_OK;
 }
@@ -1328,6 +1347,7 @@ static int upload(hipStream_t st, DevBuf<T> &buf, const std::vector<T> &v) {
 
 extern "C" int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, int P, const sos_point *pts, int R,
                                  const sos_resid *res, const float *res_toZeroF, const sos_rawjac *lin_J) {
+  if (ba) ba->acc_inflight = false;  // any state change invalidates a prefetched accumulate
   if (!ba || n < 1 || n > SOS_MAX_FRAMES || P < 0 || R < 0 || !frame_slot || (P && !pts) || (R && !res)) return SOS_ERR_ARG;
   sos_ctx *c = ba->ctx;
   SOS_HIP(hipSetDevice(c->device));
@@ -1512,8 +1532,10 @@ extern "C" int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, i
     if (tot > ba->pin_bytes) {
       if (ba->pin) hipHostFree(ba->pin);
       ba->pin = nullptr;
-      SOS_HIP(hipHostMalloc((void **)&ba->pin, tot + tot / 4, hipHostMallocDefault));
+      SOS_HIP(hipHostMalloc((void **)&ba->pin, tot + tot / 4, hipHostMallocMapped));
+      SOS_HIP(hipHostGetDevicePointer((void **)&ba->pin_dev, ba->pin, 0));
       ba->pin_bytes = tot + tot / 4;
+      memset(ba->pin, 0, ba->pin_bytes);
     }
     ba->pin_stage = 0;
     ba->pin_out = (need_stage + 63) / 64 * 64;
@@ -1585,6 +1607,7 @@ extern "C" int sos_ba_set_state(sos_ba *ba, const sos_calib *calib, const sos_pr
                                 const float *cDeltaF, const double *adHost, const double *adTarget,
                                 const float *point_idepth_scaled, const float *point_idepth_zero_scaled,
                                 const float *point_deltaF) {
+  if (ba) ba->acc_inflight = false;  // any state change invalidates a prefetched accumulate
   if (!ba || !ba->have_window) return SOS_ERR_STATE;
   sos_ctx *c = ba->ctx;
   SOS_HIP(hipSetDevice(c->device));
@@ -1628,6 +1651,18 @@ extern "C" int sos_ba_set_state(sos_ba *ba, const sos_calib *calib, const sos_pr
   return SOS_OK;
 }
 
+// per-step inputs: device-mapped pinned host block -> device staging, by a kernel instead of a copy command
+__global__ void k_stage_in(float4 *__restrict__ dst, const float4 *__restrict__ src, int n4) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n4) dst[i] = src[i];
+}
+static int stage_in(sos_ba *ba, size_t nfloats) {
+  const int n4 = (int)((nfloats + 3) / 4);
+  k_stage_in<<<divup(n4, 256), 256, 0, ba->ctx->stream>>>(reinterpret_cast<float4 *>(ba->d_stage.p),
+                                                        reinterpret_cast<const float4 *>(ba->pin_dev + ba->pin_stage), n4);
+  return SOS_OK;
+}
+
 static int launch_linearize(sos_ba *ba, int doApply) {
   if (ba->ntilesA > 0) k_linearize<<<ba->ntilesA, 256, 0, ba->ctx->stream>>>(ba->dev, stg(ba, ba->st_th), doApply);
   return SOS_OK;
@@ -1635,6 +1670,7 @@ static int launch_linearize(sos_ba *ba, int doApply) {
 
 extern "C" int sos_ba_linearize(sos_ba *ba, const float *frameEnergyTH, double *energySum, uint8_t *newState,
                                 float *newEnergy, float *newEnergyWithOutlier, float *centerProjectedTo) {
+  if (ba) ba->acc_inflight = false;  // any state change invalidates a prefetched accumulate
   if (!ba || !ba->have_window || !ba->have_state || !frameEnergyTH) return SOS_ERR_STATE;
   sos_ctx *c = ba->ctx;
   SOS_HIP(hipSetDevice(c->device));
@@ -1665,6 +1701,7 @@ extern "C" int sos_ba_linearize(sos_ba *ba, const float *frameEnergyTH, double *
 }
 
 extern "C" int sos_ba_apply_res(sos_ba *ba) {
+  if (ba) ba->acc_inflight = false;  // any state change invalidates a prefetched accumulate
   if (!ba || !ba->have_window) return SOS_ERR_STATE;
   SOS_HIP(hipSetDevice(ba->ctx->device));
   const int nthr = ba->ntilesA * SOS_TILE;
@@ -1674,6 +1711,7 @@ extern "C" int sos_ba_apply_res(sos_ba *ba) {
 }
 
 extern "C" int sos_ba_reset_oob(sos_ba *ba) {
+  if (ba) ba->acc_inflight = false;  // any state change invalidates a prefetched accumulate
   if (!ba || !ba->have_window) return SOS_ERR_STATE;
   SOS_HIP(hipSetDevice(ba->ctx->device));
   const int nthr = ba->ntilesA * SOS_TILE;
@@ -1683,6 +1721,7 @@ extern "C" int sos_ba_reset_oob(sos_ba *ba) {
 }
 
 extern "C" int sos_ba_fix_linearization(sos_ba *ba, const int32_t *residIdx, int count) {
+  if (ba) ba->acc_inflight = false;  // any state change invalidates a prefetched accumulate
   if (!ba || !ba->have_window || !ba->have_state || (count && !residIdx)) return SOS_ERR_STATE;
   if (count <= 0) return SOS_OK;
   SOS_HIP(hipSetDevice(ba->ctx->device));
@@ -1739,21 +1778,23 @@ static int launch_reduce(sos_ba *ba) {
   return SOS_OK;
 }
 // stitch kernels: d_Hout = [H_A | b_A | H_L | b_L | H_sc | b_sc]
-static int launch_stitch(sos_ba *ba, const float *acc, int nmodes) {
+static int launch_stitch(sos_ba *ba, const float *acc, int nmodes, double *Hout = nullptr) {
   hipStream_t st = ba->ctx->stream;
   const int n = ba->n;
   const size_t nn = (size_t)n * n;
   double *Ctop = ba->d_C.p, *Csc = Ctop + 2 * nn * SOS_TOPC, *Ce = Csc + nn * n * SOS_SCC, *Ccc = Ce + nn * SOS_SCE;
-  double *H = ba->d_Hout.p;
+  double *H = Hout ? Hout : ba->d_Hout.p;
   dim3 g1(n * n + 20, nmodes), g2(n * (n + 1) / 2 + 1, nmodes);
   k_stitch_top_pairs<<<g1, 64, 0, st>>>(n, acc + ba->off_topA, ba->d_adHost.p, ba->d_adTarget.p, Ctop, Ccc);
   k_sc_MC<<<n * n * n, 64, 0, st>>>(n, acc + ba->off_D, acc + ba->off_E, acc + ba->off_EB, ba->d_adHost.p, ba->d_adTarget.p, Csc, Ce);
   k_stitch_top_sum<<<g2, 64, 0, st>>>(n, Ccc, Ctop, H, ba->hb_mode_stride);
-  k_sc_sum<<<n * n + 1, 64, 0, st>>>(n, Csc, Ce, acc + ba->off_Hcc, acc + ba->off_bc, H + 2 * ba->hb_mode_stride);
+  k_sc_sum<<<n * n + 1, 64, 0, st>>>(n, Csc, Ce, acc + ba->off_Hcc, acc + ba->off_bc, H + 2 * ba->hb_mode_stride, acc + ba->off_nres,
+                                     Hout ? reinterpret_cast<float *>(Hout + 3 * ba->hb_mode_stride) : nullptr);
   return SOS_OK;
 }
 
 extern "C" int sos_ba_accumulate_local(sos_ba *ba) {
+  if (ba) ba->acc_inflight = false;  // any state change invalidates a prefetched accumulate
   if (!ba || !ba->have_window || !ba->have_state) return SOS_ERR_STATE;
   SOS_HIP(hipSetDevice(ba->ctx->device));
   launch_top(ba);
@@ -1798,6 +1839,7 @@ static int fetch_hb(sos_ba *ba, const float *acc, double *H_A, double *b_A, doub
 
 extern "C" int sos_ba_stitch(sos_ba *ba, double *H_A, double *b_A, double *H_L, double *b_L, double *H_sc, double *b_sc,
                              int *resInA, int *resInL) {
+  if (ba) ba->acc_inflight = false;  // any state change invalidates a prefetched accumulate
   if (!ba || !ba->have_window || !ba->have_state) return SOS_ERR_STATE;
   SOS_HIP(hipSetDevice(ba->ctx->device));
   launch_stitch(ba, ba->d_acc.p, 2);
@@ -1812,29 +1854,34 @@ extern "C" int sos_ba_accumulate(sos_ba *ba, double *H_A, double *b_A, double *H
   return sos_ba_stitch(ba, H_A, b_A, H_L, b_L, H_sc, b_sc, resInA, resInL);
 }
 
+// accumulate + stitch of the whole window with the stage-2 stitch kernels writing H/b (and the residual counts)
+// straight into the device-mapped pinned block: no copy command between the last kernel and the host
+static int enqueue_gn_accumulate(sos_ba *ba) {
+  const bool haveL = ba->ntiles > ba->ntilesA;
+  launch_top(ba);
+  launch_sc(ba, 1);
+  launch_reduce(ba);
+  launch_stitch(ba, ba->d_acc.p, haveL ? 2 : 1, reinterpret_cast<double *>(ba->pin_dev + ba->pin_hb));
+  ba->acc_inflight_haveL = haveL;
+  return SOS_OK;
+}
+
 // Fused per-iteration call #1: accumulate + stitch, H_top = H_A + H_L, b_top = b_A + b_L (no priors).
 extern "C" int sos_ba_gn_accumulate(sos_ba *ba, double *H_top, double *b_top, double *H_sc, double *b_sc, int *resInA,
                                     int *resInL) {
   if (!ba || !ba->have_window || !ba->have_state || !H_top || !b_top || !H_sc || !b_sc) return SOS_ERR_STATE;
   SOS_HIP(hipSetDevice(ba->ctx->device));
   hipStream_t st = ba->ctx->stream;
-  const bool haveL = ba->ntiles > ba->ntilesA;
-  launch_top(ba);
-  launch_sc(ba, 1);
-  launch_reduce(ba);
-  launch_stitch(ba, ba->d_acc.p, haveL ? 2 : 1);
-  SOS_HIP(hipGetLastError());
-  const size_t dim = 4 + 8 * (size_t)ba->n, ms = ba->hb_mode_stride;
-  double *ph = reinterpret_cast<double *>(ba->pin + ba->pin_hb);
-  float *pn = reinterpret_cast<float *>(ph + 3 * ms);
-  if (haveL) {
-    SOS_HIP(hipMemcpyAsync(ph, ba->d_Hout.p, sizeof(double) * 3 * ms, hipMemcpyDeviceToHost, st));
-  } else {  // skip the (all-zero) L block
-    SOS_HIP(hipMemcpyAsync(ph, ba->d_Hout.p, sizeof(double) * ms, hipMemcpyDeviceToHost, st));
-    SOS_HIP(hipMemcpyAsync(ph + 2 * ms, ba->d_Hout.p + 2 * ms, sizeof(double) * ms, hipMemcpyDeviceToHost, st));
+  if (!ba->acc_inflight) {  // otherwise the previous sos_ba_gn_step already enqueued it (sos_ba_set_prefetch)
+    enqueue_gn_accumulate(ba);
+    SOS_HIP(hipGetLastError());
   }
-  SOS_HIP(hipMemcpyAsync(pn, ba->d_acc.p + ba->off_nres, 2 * sizeof(float), hipMemcpyDeviceToHost, st));
+  ba->acc_inflight = false;
+  const bool haveL = ba->acc_inflight_haveL;
   SOS_HIP(hipStreamSynchronize(st));
+  const size_t dim = 4 + 8 * (size_t)ba->n, ms = ba->hb_mode_stride;
+  const double *ph = reinterpret_cast<const double *>(ba->pin + ba->pin_hb);
+  const float *pn = reinterpret_cast<const float *>(ph + 3 * ms);
   if (haveL) {
     for (size_t i = 0; i < dim * dim; i++) H_top[i] = ph[ms + i] + ph[i];  // HL_top + HA_top
     for (size_t i = 0; i < dim; i++) b_top[i] = ph[ms + dim * dim + i] + ph[dim * dim + i];
@@ -1886,6 +1933,7 @@ static void fill_x(sos_ba *ba, const double *x) {
 }
 
 extern "C" int sos_ba_resubstitute(sos_ba *ba, const double *x, float *pointStep) {
+  if (ba) ba->acc_inflight = false;  // any state change invalidates a prefetched accumulate
   if (!ba || !ba->have_window || !ba->have_state || !x) return SOS_ERR_STATE;
   SOS_HIP(hipSetDevice(ba->ctx->device));
   hipStream_t st = ba->ctx->stream;
@@ -1915,26 +1963,37 @@ extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const
   const size_t nn = (size_t)ba->n * ba->n;
   ba->calib = *calib;
   ba->dev.calib = *calib;
+  ba->acc_inflight = false;
   memcpy(pstg(ba, ba->st_pre), precalc, sizeof(sos_precalc) * nn);
   memcpy(pstg(ba, ba->st_adh), adHTdeltaF, sizeof(float) * 8 * nn);
   memcpy(pstg(ba, ba->st_cd), cDeltaF, sizeof(float) * 4);
   memcpy(pstg(ba, ba->st_th), frameEnergyTH, sizeof(float) * ba->n);
-  float *dstep = reinterpret_cast<float *>(ba->d_outpack.p + ba->out_step);
+  // outputs go straight to the device-mapped pinned block: per-tile energy sums, newest-frame energies, point steps
+  char *po = ba->pin + ba->pin_out, *po_dev = ba->pin_dev + ba->pin_out;
+  float *dstep = reinterpret_cast<float *>(po_dev + ba->out_step);
+  BaDev dv = ba->dev;
+  dv.tile_esum = reinterpret_cast<double *>(po_dev + ba->out_esum);
+  dv.o_newest = reinterpret_cast<float *>(po_dev + ba->out_newest);
   if (x) {
-    // the back-substitution uses the OLD state's point sums but only xc/xAd from the stage: upload those
-    // first, run it, then overwrite the rest of the stage for the linearisation at the new state
+    // the back-substitution uses the OLD state's point sums and only xc/xAd from the stage
     fill_x(ba, x);
-    SOS_HIP(hipMemcpyAsync(stg(ba, 0), pstg(ba, 0), sizeof(float) * ba->st_floats, hipMemcpyHostToDevice, st));
+    stage_in(ba, ba->st_floats);
     if (ba->P > 0)
-      k_resubstitute<<<divup(ba->P, 64), 64, 0, st>>>(ba->dev, stg(ba, ba->st_xc), stg(ba, ba->st_xad), dstep, 1, stepfacD);
+      k_resubstitute<<<divup(ba->P, 64), 64, 0, st>>>(dv, stg(ba, ba->st_xc), stg(ba, ba->st_xad), dstep, 1, stepfacD);
   } else {
-    SOS_HIP(hipMemcpyAsync(stg(ba, 0), pstg(ba, 0), sizeof(float) * ba->st_xc, hipMemcpyHostToDevice, st));
+    stage_in(ba, ba->st_xc);
   }
-  launch_linearize(ba, applyRes ? 1 : 0);
+  if (ba->ntilesA > 0) k_linearize<<<ba->ntilesA, 256, 0, st>>>(dv, stg(ba, ba->st_th), applyRes ? 1 : 0);
   SOS_HIP(hipGetLastError());
-  char *po = ba->pin + ba->pin_out;
-  SOS_HIP(hipMemcpyAsync(po, ba->d_outpack.p, ba->out_bytes, hipMemcpyDeviceToHost, st));
-  SOS_HIP(hipStreamSynchronize(st));
+  if (ba->prefetch && applyRes) {  // the next iteration's accumulate + stitch runs while the host digests this step
+    SOS_HIP(hipEventRecord(ba->ev_step, st));
+    enqueue_gn_accumulate(ba);
+    SOS_HIP(hipGetLastError());
+    ba->acc_inflight = true;
+    SOS_HIP(hipEventSynchronize(ba->ev_step));
+  } else {
+    SOS_HIP(hipStreamSynchronize(st));
+  }
   if (energySum) {
     const double *es = reinterpret_cast<const double *>(po + ba->out_esum);
     double e = 0;
@@ -1980,6 +2039,7 @@ extern "C" int sos_ba_calc_lenergy(sos_ba *ba, double *E) {
 
 extern "C" int sos_ba_accumulate_marg(sos_ba *ba, const int32_t *pointIdx, int count, double *M, double *Mb, double *Msc,
                                       double *Mbsc, int *resInM) {
+  if (ba) ba->acc_inflight = false;  // any state change invalidates a prefetched accumulate
   if (!ba || !ba->have_window || !ba->have_state || (count && !pointIdx)) return SOS_ERR_STATE;
   SOS_HIP(hipSetDevice(ba->ctx->device));
   hipStream_t st = ba->ctx->stream;
@@ -2046,6 +2106,7 @@ extern "C" int sos_ba_accumulate_marg(sos_ba *ba, const int32_t *pointIdx, int c
 }
 
 extern "C" int sos_ba_update_point_priors(sos_ba *ba, const int32_t *pointIdx, const float *priorF, int count) {
+  if (ba) ba->acc_inflight = false;  // any state change invalidates a prefetched accumulate
   if (!ba || !ba->have_window || (count && (!pointIdx || !priorF))) return SOS_ERR_STATE;
   SOS_HIP(hipSetDevice(ba->ctx->device));
   for (int k = 0; k < count; k++) {
@@ -2119,6 +2180,7 @@ extern "C" int sos_ba_get_res_toZeroF(sos_ba *ba, float *rtz) {
 
 // ---- kernel timing with HIP events on the context's stream ----------------------------------------
 extern "C" int sos_ba_time_kernel(sos_ba *ba, const char *kernel, const float *frameEnergyTH, int iters, float *avg_ms) {
+  if (ba) ba->acc_inflight = false;  // any state change invalidates a prefetched accumulate
   if (!ba || !ba->have_window || !ba->have_state || !kernel || iters <= 0 || !avg_ms) return SOS_ERR_STATE;
   sos_ctx *c = ba->ctx;
   SOS_HIP(hipSetDevice(c->device));

@@ -36,6 +36,7 @@ def load():
     L.sosf_optimize.argtypes = [vp, ci, C.POINTER(C.c_float), C.POINTER(ci)]
     L.sosf_prepare.argtypes = [vp]
     L.sosf_gn_iteration.argtypes = [vp, ci, C.POINTER(ci)]
+    L.sosf_set_pipeline.argtypes = [vp, ci]
     L.sosf_counts.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
     L.sosf_get_frame.argtypes = [vp, ci, vp, vp, vp, C.POINTER(C.c_float)]
     L.sosf_get_calib.argtypes = [vp, vp]
@@ -143,6 +144,9 @@ class System:
 
     def prepare(self):
         _chk(self.L.sosf_prepare(self.h_), "sosf_prepare")
+
+    def set_pipeline(self, on=True):
+        _chk(self.L.sosf_set_pipeline(self.h_, int(on)), "sosf_set_pipeline")
 
     def gn_iteration(self, iteration=0):
         cb = C.c_int(0)
