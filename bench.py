@@ -110,12 +110,14 @@ def main():
 
     for i in range(args.warmup):
         sysm.gn_iteration(i)
+    host.timing(reset=True)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         sysm.gn_iteration(args.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
+    phases = host.timing()
     R_total = R_local
     if dist is not None:
         t = torch.tensor([dt, float(R_local)], dtype=torch.float64, device="cuda")
@@ -153,6 +155,9 @@ def main():
             "gn_iter_per_s": args.steps / dt,
             "linearize_point_residuals_per_s": R_local / (lin_ms * 1e-3),
             "kernels_us": dict(linearize_us=round(lin_ms * 1e3, 2), **kern),
+            "host_phases_us": {k: round(v / args.steps * 1e6, 1) for k, v in zip(
+                ("gn_accumulate_wait", "assemble", "ldlt", "step_and_precalc", "precalc", "gn_step_call_and_post", "post",
+                 "backup"), phases)},
             "roofline": {"kernel": "k_linearize", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "bytes_per_residual": LINEARIZE_BYTES_PER_RESIDUAL, "avg_launch_us": lin_ms * 1e3},

@@ -116,8 +116,9 @@ int sosf_tracker_track(sosf_tracker *trk, int newSlot, float new_ab_exposure, do
 int sosf_tracker_optimize_scale(sosf_tracker *trk, int stereoSlot, const double *tfmF0ToF1_12, const float *K1_level0,
                                 float *scale_inout, int coarsestLvl, float *rmse);
 
-/* accumulated wall-clock seconds per phase of sosf_gn_iteration: 0 accumulate+stitch, 1 assemble+solve,
- * 2 resubstitute, 3 step+precalc, 4 set_state upload, 5 linearize, 6 applyRes */
+/* accumulated wall-clock seconds per phase of sosf_gn_iteration: 0 sos_ba_gn_accumulate (wait + copy), 1 assemble
+ * H/b, 2 LDLT, 3 doStepFromBackup (includes 4), 4 setPrecalcValues, 5 sos_ba_gn_step + post-processing (includes 6),
+ * 6 host mirrors + setNewFrameEnergyTH, 7 backupState */
 int sosf_get_timing(double *phases8, int reset);
 
 /* direct access to the underlying context / backend handles (tracker tests share the frame store) */

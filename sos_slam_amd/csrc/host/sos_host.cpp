@@ -96,6 +96,7 @@ FrameHessian::~FrameHessian() {
 PointHessian::~PointHessian() {
   for (PointFrameResidual *r : residuals) delete r;
 }
+static int g_evalCounter = 0;  // unique id of every evalPT ever set: keys the cached FEJ products
 void FrameHessian::setState(const double *s) {  // FS/HessianBlocks.h:217-230
   for (int i = 0; i < 10; i++) state[i] = s[i];
   for (int i = 0; i < 3; i++) state_scaled[i] = SOS_SCALE_XI_TRANS * state[i];
@@ -112,6 +113,8 @@ void FrameHessian::setStateZero(const double *s) {  // FS/HessianBlocks.cpp:66-1
 }
 void FrameHessian::setEvalPT(const SE3 &c2w, const double *s) {  // FS/HessianBlocks.h:246-251
   camToWorld_evalPT = c2w;
+  worldToCam_evalPT = c2w.inverse();
+  evalVersion = ++g_evalCounter;
   setState(s);
   setStateZero(s);
 }
@@ -131,10 +134,15 @@ void FrameHessian::getPrior(double *p, float modeA, float modeB) const {  // FS/
 }
 
 void FrameFramePrecalc::set(const FrameHessian *host, const FrameHessian *target, const CalibHessian *HCalib) {
-  const SE3 leftToLeft_0 = target->camToWorld_evalPT.inverse() * host->camToWorld_evalPT;
+  if (hostEvalVersion != host->evalVersion || targetEvalVersion != target->evalVersion) {
+    const SE3 leftToLeft_0 = target->worldToCam_evalPT * host->camToWorld_evalPT;
+    for (int i = 0; i < 9; i++) dev.PRE_RTll_0[i] = (float)leftToLeft_0.R[i];
+    for (int i = 0; i < 3; i++) dev.PRE_tTll_0[i] = (float)leftToLeft_0.t[i];
+    hostEvalVersion = host->evalVersion; targetEvalVersion = target->evalVersion;
+  }
   const SE3 leftToLeft = target->PRE_worldToCam * host->PRE_camToWorld;
-  for (int i = 0; i < 9; i++) { dev.PRE_RTll_0[i] = (float)leftToLeft_0.R[i]; PRE_RTll[i] = (float)leftToLeft.R[i]; }
-  for (int i = 0; i < 3; i++) { dev.PRE_tTll_0[i] = (float)leftToLeft_0.t[i]; PRE_tTll[i] = (float)leftToLeft.t[i]; }
+  for (int i = 0; i < 9; i++) PRE_RTll[i] = (float)leftToLeft.R[i];
+  for (int i = 0; i < 3; i++) PRE_tTll[i] = (float)leftToLeft.t[i];
   distanceLL = (float)std::sqrt(leftToLeft.t[0] * leftToLeft.t[0] + leftToLeft.t[1] * leftToLeft.t[1] + leftToLeft.t[2] * leftToLeft.t[2]);
   // K, K^-1 = [1/fx 0 -cx/fx; 0 1/fy -cy/fy; 0 0 1] (value_scaledi)
   const float K[9] = {HCalib->value_scaledf[0], 0, HCalib->value_scaledf[2], 0, HCalib->value_scaledf[1], HCalib->value_scaledf[3], 0, 0, 1};
@@ -224,7 +232,7 @@ void EnergyFunctional::setAdjointsF(CalibHessian *) {  // OB/EnergyFunctional.cp
   EFAdjointsValid = true;
 }
 
-void EnergyFunctional::setDeltaF(CalibHessian *HCalib) {  // OB/EnergyFunctional.cpp:163-194
+void EnergyFunctional::setDeltaF(CalibHessian *HCalib, bool points) {  // OB/EnergyFunctional.cpp:163-194
   const int n = nFrames;
   adHTdeltaF.assign((size_t)n * n * 8, 0.f);
   for (int h = 0; h < n; h++)
@@ -247,7 +255,8 @@ void EnergyFunctional::setDeltaF(CalibHessian *HCalib) {  // OB/EnergyFunctional
       f->delta[i] = f->data->state[i] - f->data->state_zero[i];
       f->delta_prior[i] = f->data->state[i];
     }
-    for (EFPoint *p : f->points) p->deltaF = p->data->idepth - p->data->idepth_zero;
+    if (points)  // skipped while the device owns the point state inside the GN loop (mirrors are refreshed after the step)
+      for (EFPoint *p : f->points) p->deltaF = p->data->idepth - p->data->idepth_zero;
   }
   EFDeltaValid = true;
 }
@@ -458,6 +467,8 @@ void EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib, bo
     for (int j = 0; j < dim; j++) H[(size_t)i * dim + j] *= S[i] * S[j];
     b[i] *= S[i];
   }
+  g_phase[1] += now_s() - t_sol0;
+  t_sol0 = now_s();
   ldlt_solve(H, b, x, dim);
   for (int i = 0; i < dim; i++) x[i] *= S[i];
   lastX = x;
@@ -467,9 +478,8 @@ void EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib, bo
     for (int i = 0; i < 8; i++) h->data->step[i] = -x[SOS_CPARS + 8 * h->idx + i];
     h->data->step[8] = h->data->step[9] = 0;
   }
-  g_phase[1] += now_s() - t_sol0;
+  g_phase[2] += now_s() - t_sol0;
   if (deferResubstitute) return;  // done by sos_ba_gn_step together with the next linearisation
-  PhaseTimer tr(2);
   pointStep.resize(allPoints.size());
   sos_ba_resubstitute(ba, x.data(), pointStep.data());
   for (size_t k = 0; k < allPoints.size(); k++) allPoints[k]->data->step = pointStep[k];
@@ -652,6 +662,8 @@ FrameHessian *FullSystem::addFrame(const double *c2w, const double *state10, flo
   fh->frameID = frameID;
   fh->frameEnergyTH = frameEnergyTH;
   fh->camToWorld_evalPT = SE3::from12(c2w);
+  fh->worldToCam_evalPT = fh->camToWorld_evalPT.inverse();
+  fh->evalVersion = ++g_evalCounter;
   double sz[10];
   for (int i = 0; i < 10; i++) sz[i] = i < 6 ? 0.0 : state10[i];
   fh->setStateZero(sz);
@@ -699,12 +711,12 @@ PointFrameResidual *FullSystem::addResidual(PointHessian *ph, FrameHessian *targ
   return r;
 }
 
-void FullSystem::setPrecalcValues() {  // FS/FullSystem.cpp:1099-1107
+void FullSystem::setPrecalcValues(bool points) {  // FS/FullSystem.cpp:1099-1107
   for (FrameHessian *fh : frameHessians) {
     fh->targetPrecalc.resize(frameHessians.size());
     for (size_t i = 0; i < frameHessians.size(); i++) fh->targetPrecalc[i].set(fh, frameHessians[i], &HCalib);
   }
-  ef->setDeltaF(&HCalib);
+  ef->setDeltaF(&HCalib, points);
 }
 
 void FullSystem::setNewFrameEnergyTH() {  // FS/FullSystemOptimize.cpp:84-124
@@ -821,9 +833,15 @@ void FullSystem::applyRes() { sos_ba_apply_res(ef->ba); }
 
 void FullSystem::backupState() {  // :260-269
   std::memcpy(HCalib.value_backup, HCalib.value, sizeof(HCalib.value));
+  backupSumNID = 0;
+  backupNumID = 0;
   for (FrameHessian *fh : frameHessians) {
     std::memcpy(fh->state_backup, fh->state, sizeof(fh->state));
-    for (PointHessian *ph : fh->pointHessians) ph->idepth_backup = ph->idepth;
+    for (PointHessian *ph : fh->pointHessians) {
+      ph->idepth_backup = ph->idepth;
+      backupSumNID += fabsf(ph->idepth_backup);  // same order as the loop of doStepFromBackup, FS/FullSystemOptimize.cpp:207-213
+      backupNumID++;
+    }
   }
 }
 
@@ -844,20 +862,22 @@ bool FullSystem::doStepFromBackup(float stepfacC, float stepfacT, float stepfacR
     sumB += fh->step[7] * fh->step[7];
     sumT += fh->step[0] * fh->step[0] + fh->step[1] * fh->step[1] + fh->step[2] * fh->step[2];
     sumR += fh->step[3] * fh->step[3] + fh->step[4] * fh->step[4] + fh->step[5] * fh->step[5];
+    if (pointsOnDevice) continue;  // sumNID / numID come from backupState (they only read idepth_backup)
     for (PointHessian *ph : fh->pointHessians) {
-      if (!pointsOnDevice) ph->setIdepth(ph->idepth_backup + stepfacD * ph->step);
+      ph->setIdepth(ph->idepth_backup + stepfacD * ph->step);
       sumID += ph->step * ph->step;
       sumNID += fabsf(ph->idepth_backup);
       numID++;
-      if (!pointsOnDevice) ph->setIdepthZero(ph->idepth_backup + stepfacD * ph->step);
+      ph->setIdepthZero(ph->idepth_backup + stepfacD * ph->step);
     }
   }
+  if (pointsOnDevice) { sumNID = backupSumNID; numID = backupNumID; }
   const float nf = (float)frameHessians.size();
   sumA /= nf; sumB /= nf; sumR /= nf; sumT /= nf;
   sumID /= numID; sumNID /= numID;
   (void)sumID;
   ef->EFDeltaValid = false;
-  setPrecalcValues();
+  { PhaseTimer tp(4); setPrecalcValues(!pointsOnDevice); }
   return sqrtf(sumA) < 0.0005 * setting_thOptIterations && sqrtf(sumB) < 0.00005 * setting_thOptIterations &&
          sqrtf(sumR) < 0.00005 * setting_thOptIterations && sqrtf(sumT) * sumNID < 0.00005 * setting_thOptIterations;
 }
@@ -885,7 +905,7 @@ int FullSystem::prepare() {  // FS/FullSystemOptimize.cpp:316-344
 }
 
 bool FullSystem::gnIteration(int iteration, bool mayContinue) {  // :358-413 with setting_forceAceptStep
-  backupState();
+  { PhaseTimer tb(7); backupState(); }
   ef->solveSystemF(iteration, 1e-1, &HCalib, true);  // x, frame / calib steps; back-substitution deferred
   bool canbreak;
   { PhaseTimer t(3); canbreak = doStepFromBackup(1, 1, 1, 1, 1, true); }
@@ -909,6 +929,7 @@ bool FullSystem::gnIteration(int iteration, bool mayContinue) {  // :358-413 wit
     lastError = sos_ba_gn_step(ef->ba, ef->lastX.data(), 1.0f, &cal, pc.data(), ef->adHTdeltaF.data(), ef->cDeltaF, th.data(),
                                1, &E, newestE.data(), &cnt, ef->pointStep.data());
     newestE.resize(cnt);
+    PhaseTimer tpost(6);
     // point part of doStepFromBackup on the host mirrors (FS/FullSystemOptimize.cpp:207-213)
     for (size_t k = 0; k < ef->allPoints.size(); k++) {
       PointHessian *ph = ef->allPoints[k]->data;

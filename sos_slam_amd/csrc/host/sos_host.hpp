@@ -55,10 +55,13 @@ struct CalibHessian {  // FS/HessianBlocks.h:426-553
   sos_calib toCalib() const;
 };
 
+struct FrameHessian;
 struct FrameFramePrecalc {  // FS/HessianBlocks.h:109-134
   sos_precalc dev;  // PRE_KRKiTll, PRE_KtTll, PRE_RTll_0, PRE_tTll_0, PRE_aff_mode, PRE_b0_mode
   float PRE_RTll[9], PRE_RKiTll[9], PRE_tTll[3];
   float distanceLL;
+  const FrameHessian *hostPtr = nullptr, *targetPtr = nullptr;
+  int hostEvalVersion = -1, targetEvalVersion = -1;  // the evalPT (FEJ) products only change with setEvalPT
   void set(const FrameHessian *host, const FrameHessian *target, const CalibHessian *HCalib);
 };
 
@@ -72,6 +75,8 @@ struct FrameHessian {
   bool flaggedForMarginalization = false;
   std::vector<PointHessian *> pointHessians, pointHessiansMarginalized, pointHessiansOut;
   SE3 camToWorld_evalPT;
+  SE3 worldToCam_evalPT;  // cached inverse
+  int evalVersion = 0;    // bumped by setEvalPT
   double state_zero[10], state_scaled[10], state[10], step[10], state_backup[10];
   SE3 PRE_camToWorld, PRE_worldToCam;
   std::vector<FrameFramePrecalc> targetPrecalc;
@@ -172,7 +177,7 @@ class EnergyFunctional {  // OB/EnergyFunctional.h:52-154
   double calcMEnergyF();
   double calcLEnergyF_MT();
   void makeIDX();
-  void setDeltaF(CalibHessian *HCalib);
+  void setDeltaF(CalibHessian *HCalib, bool points = true);
   void setAdjointsF(CalibHessian *HCalib);
 
   // device snapshot management
@@ -226,7 +231,7 @@ class FullSystem {
   int prepare();                                              // :316-344
   bool gnIteration(int iteration, bool mayContinue = false);  // :358-413
   bool pipelineAlways = false;  // flat API: the caller iterates regardless of canbreak
-  void setPrecalcValues();                                    // FS/FullSystem.cpp:1099-1107
+  void setPrecalcValues(bool points = true);                  // FS/FullSystem.cpp:1099-1107
   void removeOutliers();                                      // FS/FullSystemOptimize.cpp:507-526
   int marginalizePoints(const std::vector<PointHessian *> &pts);  // flagPointsForRemoval core + marginalizePointsF
   int dropPoints(const std::vector<PointHessian *> &pts);
@@ -248,6 +253,7 @@ class FullSystem {
   void setNewFrameEnergyTH(std::vector<float> &energiesOfNewestFrame);
   void applyRes();                                            // :79-83
   void backupState();                                         // :260-269
+  float backupSumNID = 0, backupNumID = 0;
   bool doStepFromBackup(float stepfacC, float stepfacT, float stepfacR, float stepfacA, float stepfacD,
                         bool pointsOnDevice = false);  // :185-257
   void solveSystem(int iteration, double lambda);             // :491-497

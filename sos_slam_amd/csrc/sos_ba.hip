@@ -201,6 +201,10 @@ __global__ __launch_bounds__(256, SOS_LIN_WAVES) void k_linearize(BaDev d, const
   const float JabJab_01 = seqsum8(drdA * hw * hw);
   const float JabJab_11 = seqsum8(hw * hw);
   const float wJI2_sum = seqsum8(hw * hw * (hit1 * hit1 + hit2 * hit2));
+  // JI_r of AccumulatedTopHessianSSE::addPoint<0> (OB/AccumulatedTopHessian.cpp:101-110): feeds the per-residual
+  // terms of the point sums, produced here so that the Schur side does not have to wait for the top accumulation
+  const float JI_r0 = seqsum8(residual * hw * hit1);
+  const float JI_r1 = seqsum8(residual * hw * hit2);
 
   if (idx == 7) {
     const float fxl = d.calib.fxl, fyl = d.calib.fyl, cxl = d.calib.cxl, cyl = d.calib.cyl;
@@ -326,10 +330,25 @@ __global__ __launch_bounds__(256, SOS_LIN_WAVES) void k_linearize(BaDev d, const
       o1.w = JabJIdx_10 * d_d_x + JabJIdx_11 * d_d_y;
       // JpJd holds EFResidual::JpJdF while the residual is active and zeros otherwise, so the Schur
       // and back-substitution kernels need no flag lookups (x - 0 == x exactly)
-      if (doApply && !activeAfter) o0 = o1 = make_float4(0.f, 0.f, 0.f, 0.f);
+      // per-residual terms of Hdd_acc / bd_acc / Hcd_acc (OB/AccumulatedTopHessian.cpp:124-127), zero while inactive.
+      // Without doApply they are provisional like JpJd: k_apply_res clears them if the residual does not end up IN.
+      const bool termsLive = doApply ? activeAfter : (st != SOS_RES_OOB);
+      float4 p0, p1;
+      p0.x = v0 * d_d_x + v1 * d_d_y;
+      p0.y = JI_r0 * d_d_x + JI_r1 * d_d_y;
+      p0.z = dCx0 * v0 + dCy0 * v1;
+      p0.w = dCx1 * v0 + dCy1 * v1;
+      p1.x = dCx2 * v0 + dCy2 * v1;
+      p1.y = dCx3 * v0 + dCy3 * v1;
+      p1.z = 1.f;  // counts towards ngoodres
+      p1.w = 0.f;  // *_accAF sums
+      if (!termsLive) o0 = o1 = p0 = p1 = make_float4(0.f, 0.f, 0.f, 0.f);
       float4 *jp = reinterpret_cast<float4 *>(d.JpJd + 8 * (size_t)s);
       jp[0] = o0;
       jp[1] = o1;
+      float4 *pt = reinterpret_cast<float4 *>(d.s_pterm + 8 * (size_t)s);
+      pt[0] = p0;
+      pt[1] = p1;
     }
     const int orig = d.s_orig[s];
     if (orig >= 0) {
@@ -393,7 +412,7 @@ __global__ void k_apply_res(BaDev d) {
   if (d.s_point[s] < 0) return;
   unsigned f = d.s_flags[s];
   if (f & DF_LINEARIZED) return;
-  if (d.s_state[s] == SOS_RES_OOB) return;  // can never go back from OOB
+  if (d.s_state[s] == SOS_RES_OOB) return;  // can never go back from OOB (k_linearize left JpJd / pterm zero)
   const int ns = d.s_newstate[s];
   f = (ns == SOS_RES_IN) ? (f | DF_ACTIVE) : (f & ~DF_ACTIVE);
   d.s_flags[s] = (uint8_t)f;
@@ -402,6 +421,8 @@ __global__ void k_apply_res(BaDev d) {
   if (ns != SOS_RES_IN) {
     float4 *jp = reinterpret_cast<float4 *>(d.JpJd + 8 * (size_t)s);
     jp[0] = jp[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 *pt = reinterpret_cast<float4 *>(d.s_pterm + 8 * (size_t)s);
+    pt[0] = pt[1] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 
@@ -433,12 +454,11 @@ __device__ __forceinline__ void bfly_step(float *v, int m, bool hi) {
 
 // gather variant: `list` holds, per virtual tile, 32 sorted residual indices (-1 = empty)
 template <bool GATHER>
-__global__ __launch_bounds__(256) void k_top_accumulate(BaDev d, int tile0, int ntile, int mode,
-                                                        const int *__restrict__ list,
-                                                        const int *__restrict__ list_pair,
-                                                        float *__restrict__ top_part, int *__restrict__ top_cnt) {
+__device__ __forceinline__ void top_accumulate_body(const BaDev &d, int blk, int tile0, int ntile, int mode,
+                                                    const int *__restrict__ list, const int *__restrict__ list_pair,
+                                                    float *__restrict__ top_part) {
   const int lane = threadIdx.x & 63;
-  const int vt = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);  // virtual tile
+  const int vt = (blk * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);  // virtual tile
   const int r = lane & 31;
   const bool tile_ok = vt < ntile;
   int s, pair;
@@ -510,7 +530,7 @@ __global__ __launch_bounds__(256) void k_top_accumulate(BaDev d, int tile0, int 
   {
     const float Ji2_Jpdd0 = a * Jpdd0 + b * Jpdd1;
     const float Ji2_Jpdd1 = b * Jpdd0 + c * Jpdd1;
-    if (have) {
+    if (have && mode != 0) {  // mode 0: written by k_linearize / k_apply_res
       float4 p0, p1;
       p0.x = use ? Ji2_Jpdd0 * Jpdd0 + Ji2_Jpdd1 * Jpdd1 : 0.f;
       p0.y = use ? JI_r0 * Jpdd0 + JI_r1 * Jpdd1 : 0.f;
@@ -563,7 +583,14 @@ __global__ __launch_bounds__(256) void k_top_accumulate(BaDev d, int tile0, int 
     o[1] = v[1];
     o[2] = v[2];
   }
+}
+template <bool GATHER>
+__global__ __launch_bounds__(256) void k_top_accumulate(BaDev d, int tile0, int ntile, int mode,
+                                                        const int *__restrict__ list,
+                                                        const int *__restrict__ list_pair,
+                                                        float *__restrict__ top_part, int *__restrict__ top_cnt) {
   (void)top_cnt;
+  top_accumulate_body<GATHER>(d, blockIdx.x, tile0, ntile, mode, list, list_pair, top_part);
 }
 
 // ================================================================================================
@@ -646,10 +673,8 @@ __global__ __launch_bounds__(128) void k_reduce_all(ReduceArgs a) {
 // k_point_prep: one thread per point, residuals visited in EFPoint::residualsAll order.  The loop is
 // unrolled by 4 with all loads of a group issued before the (order-preserving) accumulation.
 // ================================================================================================
-__global__ void k_point_prep(BaDev d, int shiftPriorToZero, const int *__restrict__ plist, int count) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  const int p = plist ? plist[i] : i;
+struct PrepOut { float hdi, hcd[4], bdsum; };
+__device__ __forceinline__ PrepOut point_prep_body(const BaDev &d, int shiftPriorToZero, int p) {
   float HddA = 0, bdA = 0, HcdA[4] = {0, 0, 0, 0}, HddL = 0, bdL = 0, HcdL[4] = {0, 0, 0, 0};
   float ngood = 0;
   const int q0 = d.p_begin[p], q1 = d.p_begin[p + 1];
@@ -697,6 +722,16 @@ __global__ void k_point_prep(BaDev d, int shiftPriorToZero, const int *__restric
   }
   float4 *ov = reinterpret_cast<float4 *>(o);
   ov[0] = o0; ov[1] = o1; ov[2] = o2; ov[3] = o3;
+  PrepOut r;
+  r.hdi = o3.x;
+  r.hcd[0] = o0.z + o2.x; r.hcd[1] = o0.w + o2.y; r.hcd[2] = o1.x + o2.z; r.hcd[3] = o1.y + o2.w;  // Hcd_accAF + Hcd_accLF
+  r.bdsum = o3.y;
+  return r;
+}
+__global__ void k_point_prep(BaDev d, int shiftPriorToZero, const int *__restrict__ plist, int count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  point_prep_body(d, shiftPriorToZero, plist ? plist[i] : i);
 }
 
 // ================================================================================================
@@ -709,33 +744,43 @@ __global__ void k_point_prep(BaDev d, int shiftPriorToZero, const int *__restric
 #define SOS_GC 32
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void k_sc_gram(BaDev d, const int *__restrict__ chunk_pt /* nchunks*SOS_GC point ids */,
-                                                 int Dm, int ld, float *__restrict__ gram_part) {
+// PREP: -1 = the per-point sums were produced by k_point_prep (p_out); 0 / 1 = produce them here for the chunk's
+// own points with shiftPriorToZero = PREP (the points of a window are partitioned over the chunks)
+template <int PREP>
+__device__ __forceinline__ void sc_gram_body(const BaDev &d, int blk, const int *__restrict__ chunk_pt, int Dm, int ld,
+                                             float *__restrict__ gram_part) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *A = smem;                   // [SOS_GC][ld]
   float *sHdi = smem + SOS_GC * ld;  // [SOS_GC]
-  const int blk = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   const int n = d.n;
   for (int q = tid; q < SOS_GC * ld / 4; q += 256) reinterpret_cast<float4 *>(A)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
-  // stage: thread per (point, target)
+  // stage: thread per (point, target); t == n is the point's own column block (Hcd, bdSum) and Hdi
   for (int q = tid; q < SOS_GC * (n + 1); q += 256) {
-    const int pl = q / (n + 1), t = q - pl * (n + 1);
+    const int t = q / SOS_GC, pl = q - t * SOS_GC;  // the 32 prep items (t == n) end up in one half-wave
     const int p = chunk_pt[blk * SOS_GC + pl];
     if (p < 0) {
       if (t == n) sHdi[pl] = 0.f;
       continue;
     }
     if (t == n) {
-      const float4 *po = reinterpret_cast<const float4 *>(d.p_out + 16 * (size_t)p);
-      const float4 v0 = po[0], v1 = po[1], v2 = po[2], v3 = po[3];
-      sHdi[pl] = v3.x;
       float *row = A + pl * ld + 8 * n;
-      row[0] = v0.z + v2.x;  // Hcd_accAF + Hcd_accLF
-      row[1] = v0.w + v2.y;
-      row[2] = v1.x + v2.z;
-      row[3] = v1.y + v2.w;
-      row[4] = v3.y;         // bdSumF
+      if (PREP >= 0) {
+        const PrepOut r = point_prep_body(d, PREP, p);
+        sHdi[pl] = r.hdi;
+        row[0] = r.hcd[0]; row[1] = r.hcd[1]; row[2] = r.hcd[2]; row[3] = r.hcd[3];
+        row[4] = r.bdsum;
+      } else {
+        const float4 *po = reinterpret_cast<const float4 *>(d.p_out + 16 * (size_t)p);
+        const float4 v0 = po[0], v1 = po[1], v2 = po[2], v3 = po[3];
+        sHdi[pl] = v3.x;
+        row[0] = v0.z + v2.x;  // Hcd_accAF + Hcd_accLF
+        row[1] = v0.w + v2.y;
+        row[2] = v1.x + v2.z;
+        row[3] = v1.y + v2.w;
+        row[4] = v3.y;         // bdSumF
+      }
     } else {
       const int s = d.p_res_t[(size_t)p * n + t];
       if (s >= 0) {
@@ -765,6 +810,19 @@ __global__ __launch_bounds__(256) void k_sc_gram(BaDev d, const int *__restrict_
     for (int rgi = 0; rgi < 4; rgi++) g[(size_t)(m0 + kq * 4 + rgi) * Dm + n0 + col] = acc[rgi];
   }
 }
+__global__ __launch_bounds__(256) void k_sc_gram(BaDev d, const int *__restrict__ chunk_pt /* nchunks*SOS_GC point ids */,
+                                                 int Dm, int ld, float *__restrict__ gram_part) {
+  sc_gram_body<-1>(d, blockIdx.x, chunk_pt, Dm, ld, gram_part);
+}
+// One launch for the two independent halves of the accumulation of a window without linearised residuals:
+// blocks [0, nTopBlocks) = AccumulatedTopHessian over the A tiles, the rest = per-point sums + Schur Gram chunks
+// (their inputs JpJd / pterm come from k_linearize, not from the top pass).
+__global__ __launch_bounds__(256) void k_accumulate_fused(BaDev d, int nTopBlocks, float *__restrict__ top_part,
+                                                          const int *__restrict__ chunk_pt, int Dm, int ld,
+                                                          float *__restrict__ gram_part) {
+  if ((int)blockIdx.x < nTopBlocks) top_accumulate_body<false>(d, blockIdx.x, 0, d.ntilesA, 0, nullptr, nullptr, top_part);
+  else sc_gram_body<1>(d, blockIdx.x - nTopBlocks, chunk_pt, Dm, ld, gram_part);
+}
 
 // ================================================================================================
 // fp64 stitch from the packed fp32 accumulators, two stages each (products per pair / triple in
@@ -781,16 +839,16 @@ __device__ __forceinline__ int top_idx(int i, int j) {  // 13x13 symmetric -> in
 
 // stage 1, grid (n*n, nmodes): pair (h,t) -> AH B AH^T, AT B AT^T, AH B AT^T, AH Bpc, AT Bpc, AH bp, AT bp
 // (OB/AccumulatedTopHessian.cpp:261-288)
-__global__ __launch_bounds__(64) void k_stitch_top_pairs(int n, const float *__restrict__ acc_top, const double *__restrict__ adHost,
+__device__ __forceinline__ void stitch_top_pairs_body(int bx, int by, int n, const float *__restrict__ acc_top, const double *__restrict__ adHost,
                                                          const double *__restrict__ adTarget, double *__restrict__ C,
                                                          double *__restrict__ Ccc) {
   __shared__ double sB[64], sAH[64], sAT[64], sT1[64], sT2[64], sBpc[32], sbp[8];
   const int tid = threadIdx.x, i = tid >> 3, j = tid & 7;
-  const int pidx = blockIdx.x;
+  const int pidx = bx;
   if (pidx >= n * n) {  // 20 extra blocks: H_cc (16) and b_c (4) = sums over all pairs, strided loads + fp64 tree
     const int v = pidx - n * n;
     const int r = v < 16 ? (v >> 2) : (v - 16), c = v < 16 ? (v & 3) : 12;
-    const float *acc = acc_top + (size_t)blockIdx.y * n * n * 91;
+    const float *acc = acc_top + (size_t)by * n * n * 91;
     double sv = 0;
     for (int k = tid; k < n * n; k += 64) sv += (double)acc[(size_t)k * 91 + top_idx(r, c)];
     sT1[tid] = sv;
@@ -799,11 +857,11 @@ __global__ __launch_bounds__(64) void k_stitch_top_pairs(int n, const float *__r
       if (tid < o) sT1[tid] += sT1[tid + o];
       __syncthreads();
     }
-    if (tid == 0) Ccc[(size_t)blockIdx.y * 20 + v] = sT1[0];
+    if (tid == 0) Ccc[(size_t)by * 20 + v] = sT1[0];
     return;
   }
-  const float *blk = acc_top + ((size_t)blockIdx.y * n * n + pidx) * 91;
-  double *out = C + ((size_t)blockIdx.y * n * n + pidx) * SOS_TOPC;
+  const float *blk = acc_top + ((size_t)by * n * n + pidx) * 91;
+  double *out = C + ((size_t)by * n * n + pidx) * SOS_TOPC;
   sB[tid] = (double)blk[top_idx(4 + i, 4 + j)];
   sAH[tid] = adHost[(size_t)pidx * 64 + tid];
   sAT[tid] = adTarget[(size_t)pidx * 64 + tid];
@@ -851,26 +909,30 @@ __global__ __launch_bounds__(64) void k_stitch_top_pairs(int n, const float *__r
     out[264 + tid] = b2;
   }
 }
+__global__ __launch_bounds__(64) void k_stitch_top_pairs(int n, const float *__restrict__ acc_top, const double *__restrict__ adHost,
+                                                         const double *__restrict__ adTarget, double *__restrict__ C,
+                                                         double *__restrict__ Ccc) { stitch_top_pairs_body(blockIdx.x, blockIdx.y, n, acc_top, adHost, adTarget, C, Ccc); }
+
 
 // stage 2, grid (n*(n+1)/2 + 1, nmodes): fixed-order sums per output block + symmetrisation
 // (OB/AccumulatedTopHessian.h:113-126).  Hb = per mode [dim*dim H | dim b].
-__global__ __launch_bounds__(64) void k_stitch_top_sum(int n, const double *__restrict__ Ccc, const double *__restrict__ C,
+__device__ __forceinline__ void stitch_top_sum_body(int bx, int by, int n, const double *__restrict__ Ccc, const double *__restrict__ C,
                                                        double *__restrict__ Hb, size_t mode_stride) {
   const int dim = 4 + 8 * n;
   const int tid = threadIdx.x, i = tid >> 3, j = tid & 7;
-  const double *Cm = C + (size_t)blockIdx.y * n * n * SOS_TOPC;
-  double *H = Hb + (size_t)blockIdx.y * mode_stride;
+  const double *Cm = C + (size_t)by * n * n * SOS_TOPC;
+  double *H = Hb + (size_t)by * mode_stride;
   double *bv = H + (size_t)dim * dim;
   const int nblk = n * (n + 1) / 2;
-  if ((int)blockIdx.x == nblk) {
+  if (bx == nblk) {
     if (tid < 20) {
-      const double sv = Ccc[(size_t)blockIdx.y * 20 + tid];
+      const double sv = Ccc[(size_t)by * 20 + tid];
       if (tid < 16) H[(size_t)(tid >> 2) * dim + (tid & 3)] = sv;
       else bv[tid - 16] = sv;
     }
     return;
   }
-  int a = 0, rem = blockIdx.x;
+  int a = 0, rem = bx;
   while (rem >= n - a) { rem -= n - a; a++; }
   const int bb = a + rem;
   if (a == bb) {
@@ -903,6 +965,9 @@ __global__ __launch_bounds__(64) void k_stitch_top_sum(int n, const double *__re
     H[(size_t)(4 + 8 * bb + j) * dim + 4 + 8 * a + i] = o;
   }
 }
+__global__ __launch_bounds__(64) void k_stitch_top_sum(int n, const double *__restrict__ Ccc, const double *__restrict__ C,
+                                                       double *__restrict__ Hb, size_t mode_stride) { stitch_top_sum_body(blockIdx.x, blockIdx.y, n, Ccc, C, Hb, mode_stride); }
+
 
 #define SOS_SCC 128  // doubles per (h,t1,g): C1 = AH[h,t1] M, C2 = AT[h,t1] M
 #define SOS_SCE 80   // doubles per (h,t1): AH E (32), AT E (32), AH EB (8), AT EB (8)
@@ -910,12 +975,12 @@ __global__ __launch_bounds__(64) void k_stitch_top_sum(int n, const double *__re
 // stage 1, grid n^3: (h, t1, g):  M = (g == h) ? sum_t2 D[h,t1,t2] AH[h,t2]^T : D[h,t1,g] AT[h,g]^T, then
 // C1 = AH[h,t1] M, C2 = AT[h,t1] M (OB/AccumulatedSCHessian.cpp:117-139 regrouped); blocks with g == 0
 // also produce the calib column / b products of (h,t1) (:107-115)
-__global__ __launch_bounds__(64) void k_sc_MC(int n, const float *__restrict__ accD, const float *__restrict__ accE,
+__device__ __forceinline__ void sc_MC_body(int bx, int by, int n, const float *__restrict__ accD, const float *__restrict__ accE,
                                               const float *__restrict__ accEB, const double *__restrict__ adHost,
                                               const double *__restrict__ adTarget, double *__restrict__ C, double *__restrict__ Ce) {
   __shared__ double sD[64], sA[64], sM[64], sAH[64], sAT[64], sE[32], sEB[8];
   const int tid = threadIdx.x, i = tid >> 3, j = tid & 7;
-  const int h = blockIdx.x % n, t1 = (blockIdx.x / n) % n, g = blockIdx.x / (n * n);
+  const int h = bx % n, t1 = (bx / n) % n, g = bx / (n * n);
   double m = 0;
   const int t2lo = (g == h) ? 0 : g, t2hi = (g == h) ? n : g + 1;
   for (int t2 = t2lo; t2 < t2hi; t2++) {
@@ -969,22 +1034,26 @@ __global__ __launch_bounds__(64) void k_sc_MC(int n, const float *__restrict__ a
     }
   }
 }
+__global__ __launch_bounds__(64) void k_sc_MC(int n, const float *__restrict__ accD, const float *__restrict__ accE,
+                                              const float *__restrict__ accEB, const double *__restrict__ adHost,
+                                              const double *__restrict__ adTarget, double *__restrict__ C, double *__restrict__ Ce) { sc_MC_body(blockIdx.x, blockIdx.y, n, accD, accE, accEB, adHost, adTarget, C, Ce); }
+
 
 // stage 2, grid n*n + 1: H_sc[g1,g2] = sum_t1 C1[g1][t1][g2] + sum_{h != g1} C2[h][g1][g2]
-__global__ __launch_bounds__(64) void k_sc_sum(int n, const double *__restrict__ C, const double *__restrict__ Ce,
+__device__ __forceinline__ void sc_sum_body(int bx, int by, int n, const double *__restrict__ C, const double *__restrict__ Ce,
                                                const float *__restrict__ accHcc, const float *__restrict__ accbc,
                                                double *__restrict__ H, const float *__restrict__ nres,
                                                float *__restrict__ nres_out) {
   const int dim = 4 + 8 * n;
   double *bv = H + (size_t)dim * dim;
   const int tid = threadIdx.x, i = tid >> 3, j = tid & 7;
-  if ((int)blockIdx.x == n * n) {
+  if (bx == n * n) {
     if (tid < 16) H[(size_t)(tid >> 2) * dim + (tid & 3)] = (double)accHcc[tid];
     else if (tid < 20) bv[tid - 16] = (double)accbc[tid - 16];
     else if (tid < 22 && nres_out) nres_out[tid - 20] = nres[tid - 20];  // residual counts travel with H/b
     return;
   }
-  const int g1 = blockIdx.x % n, g2 = blockIdx.x / n;
+  const int g1 = bx % n, g2 = bx / n;
   double s = 0, sc = 0, sb = 0;
   // the (h = g1, t1 = g1) terms are exact zeros (a point has no residual to its own host), so both sums
   // can run branch-free over all n
@@ -1014,6 +1083,31 @@ __global__ __launch_bounds__(64) void k_sc_sum(int n, const double *__restrict__
     }
     if (tid < 8) bv[4 + 8 * g1 + tid] = sb;
   }
+}
+__global__ __launch_bounds__(64) void k_sc_sum(int n, const double *__restrict__ C, const double *__restrict__ Ce,
+                                               const float *__restrict__ accHcc, const float *__restrict__ accbc,
+                                               double *__restrict__ H, const float *__restrict__ nres,
+                                               float *__restrict__ nres_out) { sc_sum_body(blockIdx.x, blockIdx.y, n, C, Ce, accHcc, accbc, H, nres, nres_out); }
+
+
+// The two stage-1 kernels (and the two stage-2 kernels) are independent of each other: one launch per stage.
+struct StitchArgs {
+  int n, nmodes;
+  const float *acc_top, *accD, *accE, *accEB, *accHcc, *accbc, *nres;
+  const double *adHost, *adTarget;
+  double *Ctop, *Ccc, *Csc, *Ce, *H;
+  float *nres_out;
+  size_t mode_stride;
+};
+__global__ __launch_bounds__(64) void k_stitch_stage1(StitchArgs a) {
+  const int per = a.n * a.n + 20, ntop = per * a.nmodes;
+  if ((int)blockIdx.x < ntop) stitch_top_pairs_body(blockIdx.x % per, blockIdx.x / per, a.n, a.acc_top, a.adHost, a.adTarget, a.Ctop, a.Ccc);
+  else sc_MC_body(blockIdx.x - ntop, 0, a.n, a.accD, a.accE, a.accEB, a.adHost, a.adTarget, a.Csc, a.Ce);
+}
+__global__ __launch_bounds__(64) void k_stitch_stage2(StitchArgs a) {
+  const int per = a.n * (a.n + 1) / 2 + 1, ntop = per * a.nmodes;
+  if ((int)blockIdx.x < ntop) stitch_top_sum_body(blockIdx.x % per, blockIdx.x / per, a.n, a.Ccc, a.Ctop, a.H, a.mode_stride);
+  else sc_sum_body(blockIdx.x - ntop, 0, a.n, a.Csc, a.Ce, a.accHcc, a.accbc, a.H + 2 * a.mode_stride, a.nres, a.nres_out);
 }
 
 // ================================================================================================
@@ -1103,6 +1197,10 @@ __global__ void k_fix_lin(BaDev d, const int *__restrict__ slist, int count) {
   }
 #undef JL
   d.s_flags[s] = (uint8_t)(d.s_flags[s] | DF_LINEARIZED);
+  // a residual linearised after the pack sits in an A tile no mode-0 pass visits any more: until the snapshot is
+  // re-packed only the marginalisation pass (mode 2) gives it point terms again
+  float4 *pt = reinterpret_cast<float4 *>(d.s_pterm + 8 * (size_t)s);
+  pt[0] = pt[1] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // calcLEnergyPt residual part (OB/EnergyFunctional.cpp:571-613): per residual energy, summed in double
@@ -1784,12 +1882,16 @@ static int launch_stitch(sos_ba *ba, const float *acc, int nmodes, double *Hout 
   const size_t nn = (size_t)n * n;
   double *Ctop = ba->d_C.p, *Csc = Ctop + 2 * nn * SOS_TOPC, *Ce = Csc + nn * n * SOS_SCC, *Ccc = Ce + nn * SOS_SCE;
   double *H = Hout ? Hout : ba->d_Hout.p;
-  dim3 g1(n * n + 20, nmodes), g2(n * (n + 1) / 2 + 1, nmodes);
-  k_stitch_top_pairs<<<g1, 64, 0, st>>>(n, acc + ba->off_topA, ba->d_adHost.p, ba->d_adTarget.p, Ctop, Ccc);
-  k_sc_MC<<<n * n * n, 64, 0, st>>>(n, acc + ba->off_D, acc + ba->off_E, acc + ba->off_EB, ba->d_adHost.p, ba->d_adTarget.p, Csc, Ce);
-  k_stitch_top_sum<<<g2, 64, 0, st>>>(n, Ccc, Ctop, H, ba->hb_mode_stride);
-  k_sc_sum<<<n * n + 1, 64, 0, st>>>(n, Csc, Ce, acc + ba->off_Hcc, acc + ba->off_bc, H + 2 * ba->hb_mode_stride, acc + ba->off_nres,
-                                     Hout ? reinterpret_cast<float *>(Hout + 3 * ba->hb_mode_stride) : nullptr);
+  StitchArgs a;
+  a.n = n; a.nmodes = nmodes;
+  a.acc_top = acc + ba->off_topA; a.accD = acc + ba->off_D; a.accE = acc + ba->off_E; a.accEB = acc + ba->off_EB;
+  a.accHcc = acc + ba->off_Hcc; a.accbc = acc + ba->off_bc; a.nres = acc + ba->off_nres;
+  a.adHost = ba->d_adHost.p; a.adTarget = ba->d_adTarget.p;
+  a.Ctop = Ctop; a.Ccc = Ccc; a.Csc = Csc; a.Ce = Ce; a.H = H;
+  a.nres_out = Hout ? reinterpret_cast<float *>(Hout + 3 * ba->hb_mode_stride) : nullptr;
+  a.mode_stride = ba->hb_mode_stride;
+  k_stitch_stage1<<<(n * n + 20) * nmodes + n * n * n, 64, 0, st>>>(a);
+  k_stitch_stage2<<<(n * (n + 1) / 2 + 1) * nmodes + n * n + 1, 64, 0, st>>>(a);
   return SOS_OK;
 }
 
@@ -1858,8 +1960,14 @@ extern "C" int sos_ba_accumulate(sos_ba *ba, double *H_A, double *b_A, double *H
 // straight into the device-mapped pinned block: no copy command between the last kernel and the host
 static int enqueue_gn_accumulate(sos_ba *ba) {
   const bool haveL = ba->ntiles > ba->ntilesA;
-  launch_top(ba);
-  launch_sc(ba, 1);
+  if (!haveL && ba->ntilesA > 0 && ba->nchunks > 0) {  // top and Schur halves are independent: one launch
+    const int nTop = divup(ba->ntilesA, 8);
+    k_accumulate_fused<<<nTop + ba->nchunks, 256, gram_lds(ba), ba->ctx->stream>>>(ba->dev, nTop, ba->d_top_part.p, ba->d_chunk_pt.p,
+                                                                                ba->Dm, ba->ld, ba->d_gram_part.p);
+  } else {  // linearised residuals: their point terms come from the mode-1 top pass
+    launch_top(ba);
+    launch_sc(ba, 1);
+  }
   launch_reduce(ba);
   launch_stitch(ba, ba->d_acc.p, haveL ? 2 : 1, reinterpret_cast<double *>(ba->pin_dev + ba->pin_hb));
   ba->acc_inflight_haveL = haveL;

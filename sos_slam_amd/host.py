@@ -72,6 +72,13 @@ _p = _lib._p
 _chk = _lib._chk
 
 
+def timing(reset=False):
+    """Accumulated seconds per host phase of sosf_gn_iteration (see include/sos_slam_host.h)."""
+    ph = np.zeros(8)
+    load().sosf_get_timing(_p(ph), int(reset))
+    return ph
+
+
 class System:
     """FullSystem (backend-facing subset): frames, points, residuals, optimize(), marginalisation."""
 
