@@ -121,6 +121,10 @@ int sosf_tracker_optimize_scale(sosf_tracker *trk, int stereoSlot, const double 
  * 6 host mirrors + setNewFrameEnergyTH, 7 backupState */
 int sosf_get_timing(double *phases8, int reset);
 
+/* the facade's dense symmetric solve (pivoted LDL^T standing in for Eigen's ldlt().solve, OB/EnergyFunctional.cpp:1148);
+ * which = 0: blocked production variant, 1: unblocked reference variant.  Exposed for the CPU test-suite. */
+int sosf_ldlt_solve(const double *A, const double *b, double *x, int n, int which);
+
 /* direct access to the underlying context / backend handles (tracker tests share the frame store) */
 sos_ctx *sosf_ctx(sosf_system *sys);
 sos_ba *sosf_ba(sosf_system *sys);

@@ -1543,6 +1543,14 @@ extern "C" int sosf_marginalize_frame(sosf_system *s, int frameIdx) {
   if (!s || frameIdx < 0 || frameIdx >= (int)s->fs->frameHessians.size()) return SOS_ERR_ARG;
   return s->fs->marginalizeFrame(s->fs->frameHessians[frameIdx]);
 }
+extern "C" int sosf_ldlt_solve(const double *A, const double *b, double *x, int n, int which) {
+  if (!A || !b || !x || n <= 0) return SOS_ERR_ARG;
+  std::vector<double> Av(A, A + (size_t)n * n), bv(b, b + n), xv;
+  if (which == 0) ldlt_solve(Av, bv, xv, n);
+  else ldlt_solve_ref(Av, bv, xv, n);
+  std::memcpy(x, xv.data(), sizeof(double) * n);
+  return SOS_OK;
+}
 extern "C" int sosf_get_timing(double *phases8, int reset) {
   if (phases8) std::memcpy(phases8, sos::g_phase, sizeof(double) * 8);
   if (reset) std::memset(sos::g_phase, 0, sizeof(double) * 8);

@@ -4,6 +4,9 @@
 // `.ldlt().solve` (OB/EnergyFunctional.cpp:1148).  Eigen is not available in this image.
 #pragma once
 
+#include <immintrin.h>
+
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -96,9 +99,9 @@ struct SE3 {
 };
 
 // x = A^-1 b for symmetric A (n x n row-major) by LDL^T with symmetric pivoting on the largest |diagonal|;
-// exact-zero pivots contribute nothing (Eigen LDLT::solve semantics).  Works on the lower triangle with
-// contiguous, vectorisable inner loops (the (4+8n)-dim solve sits on the critical path of every iteration).
-inline void ldlt_solve(const std::vector<double> &A, const std::vector<double> &b, std::vector<double> &x, int n) {
+// exact-zero pivots contribute nothing (Eigen LDLT::solve semantics, OB/EnergyFunctional.cpp:1148).
+// Reference implementation: unblocked right-looking elimination on the lower triangle.
+inline void ldlt_solve_ref(const std::vector<double> &A, const std::vector<double> &b, std::vector<double> &x, int n) {
   const size_t N = (size_t)n;
   std::vector<double> M(N * N), D(N), y(N), ck(N);
   std::vector<int> perm(N);
@@ -126,10 +129,8 @@ inline void ldlt_solve(const std::vector<double> &A, const std::vector<double> &
       continue;
     }
     for (int i = k + 1; i < n; i++) ck[i] = M[i * N + k];
-    const double dinv = 1.0 / d;
     for (int i = k + 1; i < n; i++) {
       const double lik = ck[i] / d;
-      (void)dinv;
       double *__restrict row = &M[i * N];
       const double *__restrict c = ck.data();
       for (int j = k + 1; j <= i; j++) row[j] -= lik * c[j];
@@ -144,13 +145,139 @@ inline void ldlt_solve(const std::vector<double> &A, const std::vector<double> &
     y[i] = s;
   }
   for (int i = 0; i < n; i++) y[i] = (std::fabs(D[i]) > 2.2250738585072014e-308) ? y[i] / D[i] : 0.0;
-  for (int i = n - 1; i >= 0; i--) {  // L^T z = y, column-oriented so the inner loop stays contiguous
+  for (int i = n - 1; i >= 0; i--) {
     const double yi = y[i];
     const double *row = &M[i * N];
     for (int j = 0; j < i; j++) y[j] -= row[j] * yi;
   }
   x.assign(N, 0.0);
   for (int i = 0; i < n; i++) x[perm[i]] = y[i];
+}
+
+// ---- production LDL^T (the (4+8n)-dim solve sits on the critical path of every Gauss-Newton iteration) ----------
+// Same pivoting rule (largest |diagonal|, first occurrence) and zero-pivot semantics as ldlt_solve_ref, organised for
+// speed: the matrix is held as the UPPER triangle row-major (U[j][i], j < i), so that the sub-diagonal part of
+// column k of L is the contiguous row k of U; the trailing matrix is updated once per panel of LDLT_NB pivots
+// (rank-NB update from the contiguous panel copies WT = L*D and LT = L); inside a panel the candidate diagonal is
+// kept up to date separately and a column is brought up to date only when it becomes the pivot column.
+// AVX2 + FMA: this is fp64 host arithmetic feeding a linear solve; the no-contraction rule of the fp32 residual
+// path does not apply here.
+#define LDLT_NB 8
+__attribute__((target("avx2,fma"))) inline int ldlt_argmax_abs(const double *v, int lo, int hi) {
+  const __m256d sign = _mm256_set1_pd(-0.0);
+  __m256d m = _mm256_setzero_pd();
+  int i = lo;
+  double best = 0.0;
+  for (; i + 4 <= hi; i += 4) m = _mm256_max_pd(m, _mm256_andnot_pd(sign, _mm256_loadu_pd(v + i)));
+  double t[4];
+  _mm256_storeu_pd(t, m);
+  best = std::max(std::max(t[0], t[1]), std::max(t[2], t[3]));
+  for (; i < hi; i++) best = std::max(best, std::fabs(v[i]));
+  for (i = lo; i < hi; i++)
+    if (std::fabs(v[i]) == best) return i;
+  return lo;  // only reached with NaNs in v: keep the current pivot
+}
+// U[j][i] -= sum_c L(j,c) * W(i,c) for k1 <= j < i < n, two rows j at a time
+__attribute__((target("avx2,fma"))) inline void ldlt_trailing_update(double *U, const double *WT, const double *LT, int n, int k1, int kb) {
+  const size_t N = (size_t)n;
+  int j = k1;
+  for (; j + 1 < n; j += 2) {
+    double *r0 = U + (size_t)j * N, *r1 = r0 + N;
+    __m256d l0[LDLT_NB], l1[LDLT_NB];
+    for (int c = 0; c < kb; c++) { l0[c] = _mm256_set1_pd(LT[c * N + j]); l1[c] = _mm256_set1_pd(LT[c * N + j + 1]); }
+    {  // row j needs i > j, row j+1 needs i > j+1: i = j+1 of row j on its own
+      double s0 = 0;
+      for (int c = 0; c < kb; c++) s0 += LT[c * N + j] * WT[c * N + j + 1];
+      r0[j + 1] -= s0;
+    }
+    int i = j + 2;
+    for (; i + 4 <= n; i += 4) {
+      __m256d a0 = _mm256_loadu_pd(r0 + i), a1 = _mm256_loadu_pd(r1 + i);
+      for (int c = 0; c < kb; c++) {
+        const __m256d w = _mm256_loadu_pd(WT + c * N + i);
+        a0 = _mm256_fnmadd_pd(l0[c], w, a0);
+        a1 = _mm256_fnmadd_pd(l1[c], w, a1);
+      }
+      _mm256_storeu_pd(r0 + i, a0);
+      _mm256_storeu_pd(r1 + i, a1);
+    }
+    for (; i < n; i++) {
+      double s0 = 0, s1 = 0;
+      for (int c = 0; c < kb; c++) { s0 += LT[c * N + j] * WT[c * N + i]; s1 += LT[c * N + j + 1] * WT[c * N + i]; }
+      r0[i] -= s0;
+      r1[i] -= s1;
+    }
+  }
+  // a last single row j = n-1 has no entries right of the diagonal
+}
+__attribute__((target("avx2,fma"))) inline void ldlt_solve(const std::vector<double> &A, const std::vector<double> &b, std::vector<double> &x, int n) {
+  const size_t N = (size_t)n;
+  static thread_local std::vector<double> U, D, y, diag, WT, LT;
+  static thread_local std::vector<int> perm;
+  U.resize(N * N); D.resize(N); y.resize(N); diag.resize(N); perm.resize(N);
+  WT.resize((size_t)LDLT_NB * N); LT.resize((size_t)LDLT_NB * N);
+  for (int j = 0; j < n; j++) {
+    const double *src = &A[j * N];  // A is symmetric: row j right of the diagonal == column j below it
+    double *dst = &U[j * N];
+    for (int i = j + 1; i < n; i++) dst[i] = src[i];
+    diag[j] = src[j];
+  }
+  for (int k0 = 0; k0 < n; k0 += LDLT_NB) {
+    const int kb = std::min(LDLT_NB, n - k0), k1 = k0 + kb;
+    for (int k = k0; k < k1; k++) {
+      const int q = k - k0;  // pivots of this panel already eliminated
+      const int p = ldlt_argmax_abs(diag.data(), k, n);
+      perm[k] = p;  // interchange k (LAPACK ipiv style)
+      if (p != k) {  // symmetric swap k <-> p (k < p) of the not yet eliminated part.  Finished L columns keep the row
+                     // order they were computed in; the substitutions below replay the interchanges one by one instead
+        for (int j = k + 1; j < p; j++) std::swap(U[k * N + j], U[j * N + p]);
+        double *rk = &U[k * N], *rp = &U[p * N];
+        for (int i = p + 1; i < n; i++) std::swap(rk[i], rp[i]);
+        std::swap(diag[k], diag[p]);
+        for (int c = 0; c < q; c++) { std::swap(WT[c * N + k], WT[c * N + p]); std::swap(LT[c * N + k], LT[c * N + p]); }
+      }
+      const double d = diag[k];
+      D[k] = d;
+      double *wt = &WT[(size_t)q * N], *lt = &LT[(size_t)q * N];  // column k of L*D and of L
+      double *uk = &U[k * N];
+      if (!(std::fabs(d) > 2.2250738585072014e-308)) {
+        for (int i = k + 1; i < n; i++) { uk[i] = 0.0; wt[i] = 0.0; lt[i] = 0.0; }
+        continue;
+      }
+      // bring column k (rows below the diagonal) up to date with the q earlier pivots of the panel
+      for (int i = k + 1; i < n; i++) wt[i] = uk[i];
+      for (int c = 0; c < q; c++) {
+        const double lkc = LT[c * N + k];
+        const double *wc = &WT[c * N];
+        if (lkc != 0.0)
+          for (int i = k + 1; i < n; i++) wt[i] -= wc[i] * lkc;
+      }
+      const double dinv = 1.0 / d;
+      for (int i = k + 1; i < n; i++) {
+        const double a = wt[i], l = a * dinv;
+        lt[i] = l;
+        uk[i] = l;  // L(i,k)
+        diag[i] -= a * l;
+      }
+    }
+    if (k1 < n) ldlt_trailing_update(U.data(), WT.data(), LT.data(), n, k1, kb);
+  }
+  for (int i = 0; i < n; i++) y[i] = b[i];
+  for (int k = 0; k < n; k++) {  // L z = P b, column-oriented: L(i,k) = U[k][i]
+    std::swap(y[k], y[perm[k]]);
+    const double yk = y[k];
+    const double *uk = &U[k * N];
+    for (int i = k + 1; i < n; i++) y[i] -= uk[i] * yk;
+  }
+  for (int i = 0; i < n; i++) y[i] = (std::fabs(D[i]) > 2.2250738585072014e-308) ? y[i] / D[i] : 0.0;
+  for (int k = n - 1; k >= 0; k--) {  // L^T w = z
+    const double *uk = &U[k * N];
+    double sacc = y[k];
+    for (int i = k + 1; i < n; i++) sacc -= uk[i] * y[i];
+    y[k] = sacc;
+    std::swap(y[k], y[perm[k]]);
+  }
+  x.assign(y.begin(), y.begin() + n);
 }
 
 // dense inverse (Gauss-Jordan, partial pivoting) in place of Eigen `.inverse()` (OB/EnergyFunctional.cpp:841)

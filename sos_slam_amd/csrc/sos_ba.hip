@@ -30,6 +30,7 @@
 #include <algorithm>
 #include <numeric>
 #include <string>
+#include <chrono>
 
 // ------------------------------------------------------------------------------------------------
 // device-visible description of a packed window
@@ -1116,10 +1117,8 @@ __global__ __launch_bounds__(64) void k_stitch_stage2(StitchArgs a) {
 // advanced on the device exactly as doStepFromBackup does on the host
 // (FS/FullSystemOptimize.cpp:207-213: setIdepth(backup + fac*step); setIdepthZero(same)).
 // ================================================================================================
-__global__ void k_resubstitute(BaDev d, const float *__restrict__ xc, const float *__restrict__ xAd,
-                               float *__restrict__ step_out, int applyStep, float stepfacD) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= d.P) return;
+__device__ __forceinline__ void resubstitute_body(const BaDev &d, int p, const float *xc, const float *xAd,
+                                                  float *__restrict__ step_out, int applyStep, float stepfacD) {
   float *o = d.p_out + 16 * (size_t)p;
   const float4 *ov = reinterpret_cast<const float4 *>(o);
   const float4 v0 = ov[0], v1 = ov[1], v2 = ov[2], v3 = ov[3];
@@ -1168,6 +1167,48 @@ __global__ void k_resubstitute(BaDev d, const float *__restrict__ xc, const floa
       *g = make_float2(idn, idn);
     }
   }
+}
+__global__ void k_resubstitute(BaDev d, const float *__restrict__ xc, const float *__restrict__ xAd,
+                               float *__restrict__ step_out, int applyStep, float stepfacD) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= d.P) return;
+  resubstitute_body(d, p, xc, xAd, step_out, applyStep, stepfacD);
+}
+
+// Fused per-iteration variant: the solved increment x arrives as a kernel argument; every block rebuilds the
+// xAd table (OB/EnergyFunctional.cpp:503-516: xAd[h,t] = x_h^T adHostF + x_t^T adTargetF, fp32, summed left to
+// right) in LDS from the resident fp32 adjoints, so the back-substitution depends on no staged data.  Blocks
+// beyond the point blocks copy the per-step inputs of the following linearisation (precalc, adHTdelta, cDelta,
+// frame thresholds) from the device-mapped pinned block into device memory.
+struct XArg { float v[SOS_CPARS + 8 * SOS_MAX_FRAMES]; };
+__global__ __launch_bounds__(256) void k_resub_fused(BaDev d, XArg x, const float *__restrict__ adHF, const float *__restrict__ adTF,
+                                                     float *__restrict__ step_out, float stepfacD, int nPointBlocks,
+                                                     float4 *__restrict__ stage_dst, const float4 *__restrict__ stage_src, int n4) {
+  extern __shared__ __attribute__((aligned(16))) float sxAd[];
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= nPointBlocks) {
+    const int i = ((int)blockIdx.x - nPointBlocks) * 256 + tid;
+    if (i < n4) stage_dst[i] = stage_src[i];
+    return;
+  }
+  const int n = d.n;
+  for (int q = tid; q < n * n * 8; q += 256) {
+    const int idx = q >> 3, j = q & 7;  // idx = n*h + t (p_list2[].y)
+    const int h = idx / n, t = idx - h * n;
+    const float *AH = adHF + 64 * (size_t)(h + n * t), *AT = adTF + 64 * (size_t)(h + n * t);
+    float s1 = 0, s2 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      s1 += x.v[SOS_CPARS + 8 * h + i] * AH[8 * i + j];
+      s2 += x.v[SOS_CPARS + 8 * t + i] * AT[8 * i + j];
+    }
+    sxAd[q] = s1 + s2;
+  }
+  __syncthreads();
+  const int p = blockIdx.x * 256 + tid;
+  if (p >= d.P) return;
+  const float xc[4] = {x.v[0], x.v[1], x.v[2], x.v[3]};
+  resubstitute_body(d, p, xc, sxAd, step_out, 1, stepfacD);
 }
 
 // ================================================================================================
@@ -1336,7 +1377,10 @@ struct DevBuf {
   }
 };
 
+static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 struct sos_ba {
+  double tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // SOS_TIMING=1: seconds in the phases of sos_ba_gn_step / gn_accumulate
+  long tm_calls = 0;
   sos_ctx *ctx = nullptr;
   sos_params prm;
   bool have_window = false, have_state = false;
@@ -1375,6 +1419,7 @@ struct sos_ba {
   hipEvent_t ev_step = nullptr;
   size_t hb_mode_stride = 0;  // doubles per (H | b) block in d_Hout
   std::vector<float> h_adHostF, h_adTargetF;
+  DevBuf<float> d_adHostF, d_adTargetF;  // fp32 copies for the in-kernel xAd table
   size_t acc_floats = 0;
   // offsets into the packed accumulator
   size_t off_topA = 0, off_topL = 0, off_D = 0, off_E = 0, off_EB = 0, off_Hcc = 0, off_bc = 0, off_nres = 0;
@@ -1407,6 +1452,12 @@ extern "C" int sos_ba_set_prefetch(sos_ba *ba, int on) {
 
 extern "C" int sos_ba_destroy(sos_ba *ba) {
   if (!ba) return SOS_OK;
+  if (getenv("SOS_TIMING") && ba->tm_calls) {
+    const double k = 1e6 / (double)ba->tm_calls;
+    fprintf(stderr, "[sos_ba timing, us/call over %ld gn_step calls] stage-memcpy %.1f fill_x %.1f launch(step) %.1f launch(prefetch) %.1f "
+                    "wait(step) %.1f unpack %.1f | gn_accumulate wait %.1f\n",
+            ba->tm_calls, ba->tm[0] * k, ba->tm[1] * k, (ba->tm[2] - ba->tm[1]) * k, ba->tm[3] * k, ba->tm[4] * k, ba->tm[5] * k, ba->tm[6] * k);
+  }
   hipSetDevice(ba->ctx->device);
   hipStreamSynchronize(ba->ctx->stream);
   ba->d_pts.release();
@@ -1417,7 +1468,7 @@ extern "C" int sos_ba_destroy(sos_ba *ba) {
   for (DevBuf<float> *b :
        {&ba->d_s_energy, &ba->d_s_newenergy, &ba->d_s_newenergywo, &ba->d_s_ret, &ba->d_s_center, &ba->d_s_rtz,
         &ba->d_s_pterm, &ba->d_J, &ba->d_JpJd, &ba->d_p_out, &ba->d_o_newenergy, &ba->d_o_newenergywo, &ba->d_o_center,
-        &ba->d_top_part, &ba->d_gram_part, &ba->d_acc})
+        &ba->d_top_part, &ba->d_gram_part, &ba->d_acc, &ba->d_adHostF, &ba->d_adTargetF})
     b->release();
   for (DevBuf<double> *b : {&ba->d_adHost, &ba->d_adTarget, &ba->d_Hout, &ba->d_scalar, &ba->d_perres})
     b->release();
@@ -1729,11 +1780,15 @@ extern "C" int sos_ba_set_state(sos_ba *ba, const sos_calib *calib, const sos_pr
     SOS_HIP(hipMemcpyAsync(ba->d_adHost.p, adHost, sizeof(double) * 64 * nn, hipMemcpyHostToDevice, st));
     ba->h_adHostF.resize(64 * nn);
     for (size_t i = 0; i < 64 * nn; i++) ba->h_adHostF[i] = (float)adHost[i];  // OB/EnergyFunctional.cpp:94-98
+    if (ba->d_adHostF.ensure(64 * nn)) return SOS_ERR_NOMEM;
+    SOS_HIP(hipMemcpyAsync(ba->d_adHostF.p, ba->h_adHostF.data(), sizeof(float) * 64 * nn, hipMemcpyHostToDevice, st));
   }
   if (adTarget) {
     SOS_HIP(hipMemcpyAsync(ba->d_adTarget.p, adTarget, sizeof(double) * 64 * nn, hipMemcpyHostToDevice, st));
     ba->h_adTargetF.resize(64 * nn);
     for (size_t i = 0; i < 64 * nn; i++) ba->h_adTargetF[i] = (float)adTarget[i];
+    if (ba->d_adTargetF.ensure(64 * nn)) return SOS_ERR_NOMEM;
+    SOS_HIP(hipMemcpyAsync(ba->d_adTargetF.p, ba->h_adTargetF.data(), sizeof(float) * 64 * nn, hipMemcpyHostToDevice, st));
   }
   if (point_idepth_scaled || point_idepth_zero_scaled || point_deltaF) {
     for (int p = 0; p < ba->P; p++) {
@@ -1986,7 +2041,9 @@ extern "C" int sos_ba_gn_accumulate(sos_ba *ba, double *H_top, double *b_top, do
   }
   ba->acc_inflight = false;
   const bool haveL = ba->acc_inflight_haveL;
+  const double ta = now_s();
   SOS_HIP(hipStreamSynchronize(st));
+  ba->tm[6] += now_s() - ta;
   const size_t dim = 4 + 8 * (size_t)ba->n, ms = ba->hb_mode_stride;
   const double *ph = reinterpret_cast<const double *>(ba->pin + ba->pin_hb);
   const float *pn = reinterpret_cast<const float *>(ph + 3 * ms);
@@ -2072,6 +2129,7 @@ extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const
   ba->calib = *calib;
   ba->dev.calib = *calib;
   ba->acc_inflight = false;
+  const double t0 = now_s();
   memcpy(pstg(ba, ba->st_pre), precalc, sizeof(sos_precalc) * nn);
   memcpy(pstg(ba, ba->st_adh), adHTdeltaF, sizeof(float) * 8 * nn);
   memcpy(pstg(ba, ba->st_cd), cDeltaF, sizeof(float) * 4);
@@ -2082,8 +2140,18 @@ extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const
   BaDev dv = ba->dev;
   dv.tile_esum = reinterpret_cast<double *>(po_dev + ba->out_esum);
   dv.o_newest = reinterpret_cast<float *>(po_dev + ba->out_newest);
-  if (x) {
-    // the back-substitution uses the OLD state's point sums and only xc/xAd from the stage
+  const double t1 = now_s();
+  if (x && ba->P > 0 && ba->d_adHostF.p && ba->d_adTargetF.p) {
+    // back-substitution from x alone + stage-in of the linearisation inputs: one launch
+    XArg xa;
+    const int dim = 4 + 8 * ba->n;
+    for (int i = 0; i < dim; i++) xa.v[i] = (float)x[i];
+    const int n4 = (int)((ba->st_xc + 3) / 4), nPB = divup(ba->P, 256);
+    ba->tm[1] += now_s() - t1;
+    k_resub_fused<<<nPB + divup(n4, 256), 256, sizeof(float) * 8 * nn, st>>>(
+        dv, xa, ba->d_adHostF.p, ba->d_adTargetF.p, dstep, stepfacD, nPB, reinterpret_cast<float4 *>(ba->d_stage.p),
+        reinterpret_cast<const float4 *>(ba->pin_dev + ba->pin_stage), n4);
+  } else if (x) {
     fill_x(ba, x);
     stage_in(ba, ba->st_floats);
     if (ba->P > 0)
@@ -2093,15 +2161,20 @@ extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const
   }
   if (ba->ntilesA > 0) k_linearize<<<ba->ntilesA, 256, 0, st>>>(dv, stg(ba, ba->st_th), applyRes ? 1 : 0);
   SOS_HIP(hipGetLastError());
+  const double t2 = now_s();
+  double t3 = t2;
   if (ba->prefetch && applyRes) {  // the next iteration's accumulate + stitch runs while the host digests this step
     SOS_HIP(hipEventRecord(ba->ev_step, st));
     enqueue_gn_accumulate(ba);
     SOS_HIP(hipGetLastError());
     ba->acc_inflight = true;
+    t3 = now_s();
     SOS_HIP(hipEventSynchronize(ba->ev_step));
   } else {
     SOS_HIP(hipStreamSynchronize(st));
   }
+  const double t4 = now_s();
+  ba->tm[0] += t1 - t0; ba->tm[2] += t2 - t1; ba->tm[3] += t3 - t2; ba->tm[4] += t4 - t3; ba->tm_calls++;
   if (energySum) {
     const double *es = reinterpret_cast<const double *>(po + ba->out_esum);
     double e = 0;
@@ -2125,6 +2198,7 @@ extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const
     }
     if (pointStep) memcpy(pointStep, hs, sizeof(float) * ba->P);
   }
+  ba->tm[5] += now_s() - t4;
   return SOS_OK;
 }
 

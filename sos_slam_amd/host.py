@@ -59,6 +59,7 @@ def load():
     L.sosf_tracker_track.argtypes = [vp, ci, C.c_float, vp, vp, ci, vp, vp, vp, C.POINTER(ci)]
     L.sosf_tracker_optimize_scale.argtypes = [vp, ci, vp, vp, C.POINTER(C.c_float), ci, C.POINTER(C.c_float)]
     L.sosf_get_timing.argtypes = [vp, ci]
+    L.sosf_ldlt_solve.argtypes = [vp, vp, vp, ci, ci]
     L.sosf_ctx.restype = vp
     L.sosf_ctx.argtypes = [vp]
     L.sosf_ba.restype = vp
@@ -70,6 +71,15 @@ def load():
 
 _p = _lib._p
 _chk = _lib._chk
+
+
+def ldlt_solve(A, b, which=0):
+    """The facade's pivoted LDL^T solve (which=0 blocked production variant, 1 unblocked reference)."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    x = np.zeros(len(b))
+    _chk(load().sosf_ldlt_solve(_p(A), _p(b), _p(x), len(b), which), "sosf_ldlt_solve")
+    return x
 
 
 def timing(reset=False):

@@ -54,3 +54,29 @@ def test_record_layouts_match_header():
     assert synth.FRAME_INIT_DTYPE.itemsize == 12 * 8 + 10 * 8 + 16
     assert C.sizeof(records.Params) == 18 * 4
     assert C.sizeof(records.Calib) == 32
+
+
+def test_facade_ldlt_variants_agree():
+    """The blocked LDL^T on the GN critical path against the unblocked reference variant and numpy, including a
+    singular matrix (exact-zero pivots contribute nothing, as with Eigen's ldlt().solve) -- host code, no GPU."""
+    import numpy as np
+    from sos_slam_amd import host
+    rng = np.random.default_rng(5)
+    for n in (4, 12, 13, 37, 100, 132):
+        B = rng.normal(size=(n, n + 3))
+        sc = 1 + 30.0 * (np.arange(n) % 7 == 0)
+        A = (B @ B.T) * sc[:, None] * sc[None, :]
+        b = rng.normal(size=n)
+        x0, x1 = host.ldlt_solve(A, b, 0), host.ldlt_solve(A, b, 1)
+        xr = np.linalg.solve(A, b)
+        assert np.abs(x0 - xr).max() < 1e-9 * np.abs(xr).max()
+        assert np.abs(x0 - x1).max() < 1e-10 * np.abs(xr).max()
+        if n > 6:
+            A2 = A.copy()
+            A2[5, :] = 0
+            A2[:, 5] = 0
+            y0, y1 = host.ldlt_solve(A2, b, 0), host.ldlt_solve(A2, b, 1)
+            assert y0[5] == 0 and y1[5] == 0
+            keep = np.arange(n) != 5
+            yr = np.linalg.solve(A2[np.ix_(keep, keep)], b[keep])
+            assert np.abs(y0[keep] - yr).max() < 1e-9 * np.abs(yr).max()
