@@ -1181,34 +1181,114 @@ __global__ void k_resubstitute(BaDev d, const float *__restrict__ xc, const floa
 // beyond the point blocks copy the per-step inputs of the following linearisation (precalc, adHTdelta, cDelta,
 // frame thresholds) from the device-mapped pinned block into device memory.
 struct XArg { float v[SOS_CPARS + 8 * SOS_MAX_FRAMES]; };
-__global__ __launch_bounds__(256) void k_resub_fused(BaDev d, XArg x, const float *__restrict__ adHF, const float *__restrict__ adTF,
+#define SOS_RSB 256
+__global__ __launch_bounds__(SOS_RSB) void k_resub_fused(BaDev d, XArg x, const float *__restrict__ adHF, const float *__restrict__ adTF,
                                                      float *__restrict__ step_out, float stepfacD, int nPointBlocks,
                                                      float4 *__restrict__ stage_dst, const float4 *__restrict__ stage_src, int n4) {
-  extern __shared__ __attribute__((aligned(16))) float sxAd[];
+  extern __shared__ __attribute__((aligned(16))) float sxAd[];  // [n*n*8] table, then [dim] copy of x
   const int tid = threadIdx.x;
   if ((int)blockIdx.x >= nPointBlocks) {
-    const int i = ((int)blockIdx.x - nPointBlocks) * 256 + tid;
+    const int i = ((int)blockIdx.x - nPointBlocks) * SOS_RSB + tid;
+#ifndef RSB_NOSTAGE
     if (i < n4) stage_dst[i] = stage_src[i];
+#endif
     return;
   }
-  const int n = d.n;
-  for (int q = tid; q < n * n * 8; q += 256) {
-    const int idx = q >> 3, j = q & 7;  // idx = n*h + t (p_list2[].y)
+  const int n = d.n, dim = SOS_CPARS + 8 * n;
+  float *sx = sxAd + n * n * 8;
+  // ---- every global load of this thread's point is issued before the table is built: the memory latencies of the
+  // point record, its residual list and the JpJd rows overlap with each other's and with the table build
+  const int p = blockIdx.x * SOS_RSB + tid;
+  const bool live = p < d.P;
+  const int pp = live ? p : 0;
+  const float4 *ov = reinterpret_cast<const float4 *>(d.p_out + 16 * (size_t)pp);
+  const float4 v0 = ov[0], v1 = ov[1], v2 = ov[2], v3 = ov[3];
+  const int q0 = d.p_begin[pp], q1 = live ? d.p_begin[pp + 1] : q0;
+  const int cnt = q1 - q0;
+  constexpr int RU = 16;  // residuals held in registers; longer lists finish in the tail loop below
+  int2 e[RU];
+  float4 ja[RU], jb[RU];
+#pragma unroll
+  for (int k = 0; k < RU; k++) e[k] = (k < cnt) ? d.p_list2[q0 + k] : make_int2(0, 0);
+#pragma unroll
+  for (int k = 0; k < RU; k++) {
+    if (k < cnt) {
+      const float4 *jp = reinterpret_cast<const float4 *>(d.JpJd + 8 * (size_t)e[k].x);
+      ja[k] = jp[0];
+      jb[k] = jp[1];
+    } else {
+      ja[k] = jb[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  for (int i = tid; i < dim; i += SOS_RSB) sx[i] = x.v[i];  // one coalesced read of the kernel argument
+  __syncthreads();
+  // item = (pair idx = n*h + t, half jh): 4 of the 8 outputs from 8 + 8 float4 loads of the adjoint rows
+  for (int q = tid; q < n * n * 2; q += SOS_RSB) {
+    const int idx = q >> 1, jh = q & 1;
     const int h = idx / n, t = idx - h * n;
-    const float *AH = adHF + 64 * (size_t)(h + n * t), *AT = adTF + 64 * (size_t)(h + n * t);
-    float s1 = 0, s2 = 0;
+    const float4 *AH = reinterpret_cast<const float4 *>(adHF + 64 * (size_t)(h + n * t)) + jh;
+    const float4 *AT = reinterpret_cast<const float4 *>(adTF + 64 * (size_t)(h + n * t)) + jh;
+    float4 ah[8], at[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { ah[i] = AH[2 * i]; at[i] = AT[2 * i]; }
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-      s1 += x.v[SOS_CPARS + 8 * h + i] * AH[8 * i + j];
-      s2 += x.v[SOS_CPARS + 8 * t + i] * AT[8 * i + j];
+      const float xh = sx[SOS_CPARS + 8 * h + i], xt = sx[SOS_CPARS + 8 * t + i];
+      s1.x += xh * ah[i].x; s1.y += xh * ah[i].y; s1.z += xh * ah[i].z; s1.w += xh * ah[i].w;
+      s2.x += xt * at[i].x; s2.y += xt * at[i].y; s2.z += xt * at[i].z; s2.w += xt * at[i].w;
     }
-    sxAd[q] = s1 + s2;
+    float4 o;
+    o.x = s1.x + s2.x; o.y = s1.y + s2.y; o.z = s1.z + s2.z; o.w = s1.w + s2.w;
+    reinterpret_cast<float4 *>(sxAd)[q] = o;
   }
   __syncthreads();
-  const int p = blockIdx.x * 256 + tid;
-  if (p >= d.P) return;
-  const float xc[4] = {x.v[0], x.v[1], x.v[2], x.v[3]};
-  resubstitute_body(d, p, xc, sxAd, step_out, 1, stepfacD);
+  if (!live) return;
+  // ---- resubstituteFPt (OB/EnergyFunctional.cpp:526-551), subtraction order = EFPoint::residualsAll order
+  float step = 0.f;
+  if (v3.x != 0.f) {  // HdiF == 0 <=> no active residual (ngoodres == 0)
+    float b = v3.y;
+    float dot = 0;
+    dot += sx[0] * (v0.z + v2.x);
+    dot += sx[1] * (v0.w + v2.y);
+    dot += sx[2] * (v1.x + v2.z);
+    dot += sx[3] * (v1.y + v2.w);
+    b -= dot;
+#pragma unroll
+    for (int k = 0; k < RU; k++) {
+      if (k < cnt) {
+        const float4 *xp = reinterpret_cast<const float4 *>(sxAd + 8 * (size_t)e[k].y);
+        const float4 xa = xp[0], xb = xp[1];
+        float dd = 0;  // inactive residuals hold JpJd == 0: dd == 0 and b - 0 == b
+        dd += xa.x * ja[k].x; dd += xa.y * ja[k].y; dd += xa.z * ja[k].z; dd += xa.w * ja[k].w;
+        dd += xb.x * jb[k].x; dd += xb.y * jb[k].y; dd += xb.z * jb[k].z; dd += xb.w * jb[k].w;
+        b -= dd;
+      }
+    }
+    for (int q = q0 + RU; q < q1; q++) {  // windows with more than RU observations of one point
+      const int2 ee = d.p_list2[q];
+      const float4 *jp = reinterpret_cast<const float4 *>(d.JpJd + 8 * (size_t)ee.x);
+      const float4 *xp = reinterpret_cast<const float4 *>(sxAd + 8 * (size_t)ee.y);
+      const float4 a0 = jp[0], a1 = jp[1], xa = xp[0], xb = xp[1];
+      float dd = 0;
+      dd += xa.x * a0.x; dd += xa.y * a0.y; dd += xa.z * a0.z; dd += xa.w * a0.w;
+      dd += xb.x * a1.x; dd += xb.y * a1.y; dd += xb.z * a1.z; dd += xb.w * a1.w;
+      b -= dd;
+    }
+    step = -b * v3.x;
+  }
+  d.p_out[16 * (size_t)p + PO_STEP] = step;
+  if (step_out) step_out[p] = step;
+  // point part of doStepFromBackup (FS/FullSystemOptimize.cpp:207-213) + the per-residual copies of the point
+  sos_point *pt = d.pts + p;
+  const float idn = pt->idepth_scaled + stepfacD * step;
+  pt->idepth_scaled = idn;
+  pt->idepth_zero_scaled = idn;
+  pt->deltaF = 0.f;
+#pragma unroll
+  for (int k = 0; k < RU; k++)
+    if (k < cnt) *(reinterpret_cast<float2 *>(d.r_geo + e[k].x) + 1) = make_float2(idn, idn);
+  for (int q = q0 + RU; q < q1; q++) *(reinterpret_cast<float2 *>(d.r_geo + d.p_list2[q].x) + 1) = make_float2(idn, idn);
 }
 
 // ================================================================================================
@@ -2146,9 +2226,9 @@ extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const
     XArg xa;
     const int dim = 4 + 8 * ba->n;
     for (int i = 0; i < dim; i++) xa.v[i] = (float)x[i];
-    const int n4 = (int)((ba->st_xc + 3) / 4), nPB = divup(ba->P, 256);
+    const int n4 = (int)((ba->st_xc + 3) / 4), nPB = divup(ba->P, SOS_RSB);
     ba->tm[1] += now_s() - t1;
-    k_resub_fused<<<nPB + divup(n4, 256), 256, sizeof(float) * 8 * nn, st>>>(
+    k_resub_fused<<<nPB + divup(n4, SOS_RSB), SOS_RSB, sizeof(float) * (8 * nn + 4 + 8 * (size_t)ba->n), st>>>(
         dv, xa, ba->d_adHostF.p, ba->d_adTargetF.p, dstep, stepfacD, nPB, reinterpret_cast<float4 *>(ba->d_stage.p),
         reinterpret_cast<const float4 *>(ba->pin_dev + ba->pin_stage), n4);
   } else if (x) {
