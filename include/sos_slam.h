@@ -242,8 +242,9 @@ int sos_ba_stitch(sos_ba *ba, double *H_A, double *b_A, double *H_L, double *b_L
 
 /* ---- fused per-iteration entry points (MI355X-first: two device round trips per Gauss-Newton iteration) ----
  * sos_ba_gn_accumulate = accumulateAF_MT + accumulateLF_MT + accumulateSCF_MT + stitch with
- * H_top = HL_top + HA_top, b_top = bL_top + bA_top (OB/EnergyFunctional.cpp:1040-1047, priors excluded);
- * one packed device->host copy through pinned memory. */
+ * H_top = HL_top + HA_top, b_top = bL_top + bA_top (OB/EnergyFunctional.cpp:1040-1047, priors excluded).
+ * Only the UPPER triangle (col >= row) of H_top and H_sc is written -- the matrices are symmetric and the
+ * LDL^T solve reads one triangle; the stitch kernels store straight into device-mapped pinned memory. */
 int sos_ba_gn_accumulate(sos_ba *ba, double *H_top, double *b_top, double *H_sc, double *b_sc, int *resInA,
                          int *resInL);
 /* sos_ba_gn_step = resubstituteF_MT(x) (OB/EnergyFunctional.cpp:1182) + the point part of

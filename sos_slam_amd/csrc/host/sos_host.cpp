@@ -418,8 +418,9 @@ void EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib, bo
   lambda = 1e-5;
   const int n = nFrames, dim = SOS_CPARS + 8 * n;
   const size_t dd = (size_t)dim * dim;
-  MatXX HA(dd), HL, Hsc(dd);
-  VecX bA(dim), bL, bsc(dim);
+  MatXX &HA = scrHA, &Hsc = scrHsc, HL;  // scratch members: no per-iteration allocation / zero fill
+  VecX &bA = scrbA, &bsc = scrbsc, bL;
+  HA.resize(dd); Hsc.resize(dd); bA.resize(dim); bsc.resize(dim);
   double t_acc0 = now_s();
   if (allreduceHook) {  // shard-local sums -> RCCL all-reduce of the packed fp32 blocks -> identical stitch on every rank
     HL.assign(dd, 0.0);
@@ -456,16 +457,23 @@ void EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib, bo
     for (int j = 0; j < dim; j++) s += HM[(size_t)i * dim + j] * delta[j];
     b[i] += s;
   }
-  for (size_t i = 0; i < dd; i++) H[i] += HM[i];
-  for (int i = 0; i < dim; i++) H[(size_t)i * dim + i] *= (1 + lambda);
+  // from here on only the upper triangle (col >= row) of H is maintained: the fused device call delivers just that
+  // half, and the LDL^T below reads just that half (Eigen's LDLT likewise reads one triangle of HFinal_top)
   const double isc = 1.0f / (1 + lambda);
-  for (size_t i = 0; i < dd; i++) H[i] -= Hsc[i] * isc;
   for (int i = 0; i < dim; i++) b[i] -= bsc[i];
   VecX S(dim), x;
-  for (int i = 0; i < dim; i++) S[i] = 1.0 / std::sqrt(H[(size_t)i * dim + i] + 10);
   for (int i = 0; i < dim; i++) {
-    for (int j = 0; j < dim; j++) H[(size_t)i * dim + j] *= S[i] * S[j];
-    b[i] *= S[i];
+    const size_t o = (size_t)i * dim + i;
+    const double hii = (H[o] + HM[o]) * (1 + lambda) - Hsc[o] * isc;
+    S[i] = 1.0 / std::sqrt(hii + 10);
+  }
+  for (int i = 0; i < dim; i++) {
+    double *hr = &H[(size_t)i * dim];
+    const double *mr = &HM[(size_t)i * dim], *sr = &Hsc[(size_t)i * dim];
+    const double si = S[i];
+    hr[i] = ((hr[i] + mr[i]) * (1 + lambda) - sr[i] * isc) * (si * si);
+    for (int j = i + 1; j < dim; j++) hr[j] = ((hr[j] + mr[j]) - sr[j] * isc) * (si * S[j]);
+    b[i] *= si;
   }
   g_phase[1] += now_s() - t_sol0;
   t_sol0 = now_s();

@@ -178,6 +178,8 @@ class EnergyFunctional {  // OB/EnergyFunctional.h:52-154
   double calcLEnergyF_MT();
   void makeIDX();
   void setDeltaF(CalibHessian *HCalib, bool points = true);
+  MatXX scrHA, scrHsc;  // solveSystemF scratch
+  VecX scrbA, scrbsc;
   void setAdjointsF(CalibHessian *HCalib);
 
   // device snapshot management

@@ -1884,6 +1884,21 @@ extern "C" int sos_ba_set_state(sos_ba *ba, const sos_calib *calib, const sos_pr
   return SOS_OK;
 }
 
+// calibration kernels for the memory-traffic counters (MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are only
+// calibrated for wide streaming access): a pure 16 B/lane streaming read and a pure streaming write of known size
+__global__ void k_calib_read(const float4 *__restrict__ src, size_t n4, float *__restrict__ sink) {
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 v = src[i];
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  if (a.x + a.y + a.z + a.w == 1234.5678f) sink[0] = a.x;  // keeps the loads alive, never true in practice
+}
+__global__ void k_calib_write(float4 *__restrict__ dst, size_t n4) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // per-step inputs: device-mapped pinned host block -> device staging, by a kernel instead of a copy command
 __global__ void k_stage_in(float4 *__restrict__ dst, const float4 *__restrict__ src, int n4) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2458,6 +2473,14 @@ extern "C" int sos_ba_time_kernel(sos_ba *ba, const char *kernel, const float *f
     if (k == "reduce") return launch_reduce(ba);
     if (k == "stitch") return launch_stitch(ba, ba->d_acc.p, 2);
     if (k == "accumulate_local") return sos_ba_accumulate_local(ba);
+    if (k == "calib_read") {  // streams the whole Jacobian buffer: ntiles * 9216 B
+      k_calib_read<<<2048, 256, 0, st>>>(reinterpret_cast<const float4 *>(ba->d_J.p), (size_t)ba->ntiles * SOS_TILE_FLOATS / 4, ba->d_top_part.p);
+      return SOS_OK;
+    }
+    if (k == "calib_write") {  // overwrites the Gram partials (scratch, regenerated by every accumulate): nchunks * Dm^2 * 4 B
+      k_calib_write<<<2048, 256, 0, st>>>(reinterpret_cast<float4 *>(ba->d_gram_part.p), (size_t)ba->nchunks * ba->Dm * ba->Dm / 4);
+      return SOS_OK;
+    }
     if (k == "resubstitute") {
       if (ba->P > 0)
         k_resubstitute<<<divup(ba->P, 64), 64, 0, st>>>(ba->dev, stg(ba, ba->st_xc), stg(ba, ba->st_xad),
