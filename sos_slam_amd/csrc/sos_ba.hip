@@ -918,7 +918,7 @@ __global__ __launch_bounds__(64) void k_stitch_top_pairs(int n, const float *__r
 // stage 2, grid (n*(n+1)/2 + 1, nmodes): fixed-order sums per output block + symmetrisation
 // (OB/AccumulatedTopHessian.h:113-126).  Hb = per mode [dim*dim H | dim b].
 __device__ __forceinline__ void stitch_top_sum_body(int bx, int by, int n, const double *__restrict__ Ccc, const double *__restrict__ C,
-                                                       double *__restrict__ Hb, size_t mode_stride) {
+                                                       double *__restrict__ Hb, size_t mode_stride, bool upperOnly = false) {
   const int dim = 4 + 8 * n;
   const int tid = threadIdx.x, i = tid >> 3, j = tid & 7;
   const double *Cm = C + (size_t)by * n * n * SOS_TOPC;
@@ -955,7 +955,7 @@ __device__ __forceinline__ void stitch_top_sum_body(int bx, int by, int n, const
     H[(size_t)(4 + 8 * a + i) * dim + 4 + 8 * a + j] = sH;
     if (tid < 32) {
       const int r = tid >> 2, cc = tid & 3;
-      H[(size_t)(4 + 8 * a + r) * dim + cc] = sHc;
+      if (!upperOnly) H[(size_t)(4 + 8 * a + r) * dim + cc] = sHc;
       H[(size_t)cc * dim + 4 + 8 * a + r] = sHc;
     }
     if (tid < 8) bv[4 + 8 * a + tid] = sb;
@@ -963,7 +963,7 @@ __device__ __forceinline__ void stitch_top_sum_body(int bx, int by, int n, const
     const double *c1 = Cm + (size_t)(a + n * bb) * SOS_TOPC, *c2 = Cm + (size_t)(bb + n * a) * SOS_TOPC;
     const double o = c1[128 + i * 8 + j] + c2[128 + j * 8 + i];
     H[(size_t)(4 + 8 * a + i) * dim + 4 + 8 * bb + j] = o;
-    H[(size_t)(4 + 8 * bb + j) * dim + 4 + 8 * a + i] = o;
+    if (!upperOnly) H[(size_t)(4 + 8 * bb + j) * dim + 4 + 8 * a + i] = o;
   }
 }
 __global__ __launch_bounds__(64) void k_stitch_top_sum(int n, const double *__restrict__ Ccc, const double *__restrict__ C,
@@ -1044,7 +1044,7 @@ __global__ __launch_bounds__(64) void k_sc_MC(int n, const float *__restrict__ a
 __device__ __forceinline__ void sc_sum_body(int bx, int by, int n, const double *__restrict__ C, const double *__restrict__ Ce,
                                                const float *__restrict__ accHcc, const float *__restrict__ accbc,
                                                double *__restrict__ H, const float *__restrict__ nres,
-                                               float *__restrict__ nres_out) {
+                                               float *__restrict__ nres_out, bool upperOnly = false) {
   const int dim = 4 + 8 * n;
   double *bv = H + (size_t)dim * dim;
   const int tid = threadIdx.x, i = tid >> 3, j = tid & 7;
@@ -1055,6 +1055,7 @@ __device__ __forceinline__ void sc_sum_body(int bx, int by, int n, const double 
     return;
   }
   const int g1 = bx % n, g2 = bx / n;
+  if (upperOnly && g1 > g2) return;  // the solve reads one triangle only
   double s = 0, sc = 0, sb = 0;
   // the (h = g1, t1 = g1) terms are exact zeros (a point has no residual to its own host), so both sums
   // can run branch-free over all n
@@ -1079,7 +1080,7 @@ __device__ __forceinline__ void sc_sum_body(int bx, int by, int n, const double 
     }
     if (tid < 32) {
       const int r = tid >> 2, c = tid & 3;
-      H[(size_t)(4 + 8 * g1 + r) * dim + c] = sc;
+      if (!upperOnly) H[(size_t)(4 + 8 * g1 + r) * dim + c] = sc;
       H[(size_t)c * dim + 4 + 8 * g1 + r] = sc;  // transposed calib rows, OB/AccumulatedSCHessian.h:118-123
     }
     if (tid < 8) bv[4 + 8 * g1 + tid] = sb;
@@ -1099,6 +1100,7 @@ struct StitchArgs {
   double *Ctop, *Ccc, *Csc, *Ce, *H;
   float *nres_out;
   size_t mode_stride;
+  int upperOnly;  // write only the block-upper triangle (+ calib rows): all the host solve reads
 };
 __global__ __launch_bounds__(64) void k_stitch_stage1(StitchArgs a) {
   const int per = a.n * a.n + 20, ntop = per * a.nmodes;
@@ -1107,8 +1109,8 @@ __global__ __launch_bounds__(64) void k_stitch_stage1(StitchArgs a) {
 }
 __global__ __launch_bounds__(64) void k_stitch_stage2(StitchArgs a) {
   const int per = a.n * (a.n + 1) / 2 + 1, ntop = per * a.nmodes;
-  if ((int)blockIdx.x < ntop) stitch_top_sum_body(blockIdx.x % per, blockIdx.x / per, a.n, a.Ccc, a.Ctop, a.H, a.mode_stride);
-  else sc_sum_body(blockIdx.x - ntop, 0, a.n, a.Csc, a.Ce, a.accHcc, a.accbc, a.H + 2 * a.mode_stride, a.nres, a.nres_out);
+  if ((int)blockIdx.x < ntop) stitch_top_sum_body(blockIdx.x % per, blockIdx.x / per, a.n, a.Ccc, a.Ctop, a.H, a.mode_stride, a.upperOnly != 0);
+  else sc_sum_body(blockIdx.x - ntop, 0, a.n, a.Csc, a.Ce, a.accHcc, a.accbc, a.H + 2 * a.mode_stride, a.nres, a.nres_out, a.upperOnly != 0);
 }
 
 // ================================================================================================
@@ -2040,6 +2042,7 @@ static int launch_stitch(sos_ba *ba, const float *acc, int nmodes, double *Hout 
   a.Ctop = Ctop; a.Ccc = Ccc; a.Csc = Csc; a.Ce = Ce; a.H = H;
   a.nres_out = Hout ? reinterpret_cast<float *>(Hout + 3 * ba->hb_mode_stride) : nullptr;
   a.mode_stride = ba->hb_mode_stride;
+  a.upperOnly = Hout ? 1 : 0;
   k_stitch_stage1<<<(n * n + 20) * nmodes + n * n * n, 64, 0, st>>>(a);
   k_stitch_stage2<<<(n * (n + 1) / 2 + 1) * nmodes + n * n + 1, 64, 0, st>>>(a);
   return SOS_OK;
@@ -2142,14 +2145,21 @@ extern "C" int sos_ba_gn_accumulate(sos_ba *ba, double *H_top, double *b_top, do
   const size_t dim = 4 + 8 * (size_t)ba->n, ms = ba->hb_mode_stride;
   const double *ph = reinterpret_cast<const double *>(ba->pin + ba->pin_hb);
   const float *pn = reinterpret_cast<const float *>(ph + 3 * ms);
+  // only the upper triangle (col >= row) is produced and copied: it is all the solve reads
+  for (size_t i = 0; i < dim; i++) {
+    const size_t o = i * dim + i, len = dim - i;
+    if (haveL) {
+      for (size_t j = 0; j < len; j++) H_top[o + j] = ph[ms + o + j] + ph[o + j];  // HL_top + HA_top
+    } else {
+      memcpy(H_top + o, ph + o, sizeof(double) * len);
+    }
+    memcpy(H_sc + o, ph + 2 * ms + o, sizeof(double) * len);
+  }
   if (haveL) {
-    for (size_t i = 0; i < dim * dim; i++) H_top[i] = ph[ms + i] + ph[i];  // HL_top + HA_top
     for (size_t i = 0; i < dim; i++) b_top[i] = ph[ms + dim * dim + i] + ph[dim * dim + i];
   } else {
-    memcpy(H_top, ph, sizeof(double) * dim * dim);
     memcpy(b_top, ph + dim * dim, sizeof(double) * dim);
   }
-  memcpy(H_sc, ph + 2 * ms, sizeof(double) * dim * dim);
   memcpy(b_sc, ph + 2 * ms + dim * dim, sizeof(double) * dim);
   if (resInA) *resInA = (int)pn[0];
   if (resInL) *resInL = haveL ? (int)pn[1] : 0;
