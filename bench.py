@@ -30,6 +30,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 LINEARIZE_BYTES_PER_RESIDUAL = 776  # 80 point + 384 gather + 296 J + 16 state
+TOP_BYTES_PER_RESIDUAL = 312        # top accumulate = J read 296 + indices/flags 16
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -136,11 +137,17 @@ def main():
         import ctypes as C
         ms = C.c_float(0)
         th = np.array([sysm.frame(f)["frameEnergyTH"] for f in range(win.n)], np.float32)
+        # the kernel the timed loop runs: PointFrameResidual::linearize + applyRes + AccumulatedTopHessian::addPoint<0>
+        # fused (the Jacobian tile is reduced in LDS and never written) = F1 + F3 + F7 of SURVEY.md 8(a)
+        L.sos_ba_time_kernel(L_host_ba(sysm), b"linearize_fused", th.ctypes.data_as(C.c_void_p), 300, C.byref(ms))
+        fused_ms = ms.value
+        fused_bytes = LINEARIZE_BYTES_PER_RESIDUAL + TOP_BYTES_PER_RESIDUAL
+        achieved = R_local * fused_bytes / (fused_ms * 1e-3) / 1e9
+        # the stand-alone linearize (J stored; final linearizeAll(true), marginalisation) for comparison
         L.sos_ba_time_kernel(L_host_ba(sysm), b"linearize", th.ctypes.data_as(C.c_void_p), 300, C.byref(ms))
         lin_ms = ms.value
-        achieved = R_local * LINEARIZE_BYTES_PER_RESIDUAL / (lin_ms * 1e-3) / 1e9
-        kern = {}
-        for name in ("apply_res", "top_accumulate", "sc_accumulate", "reduce"):
+        kern = {"linearize_fused_us": round(fused_ms * 1e3, 2)}
+        for name in ("apply_res", "top_accumulate", "sc_accumulate", "sc_gram_prep", "reduce", "stitch"):
             L.sos_ba_time_kernel(L_host_ba(sysm), name.encode(), th.ctypes.data_as(C.c_void_p), 200, C.byref(ms))
             kern[name + "_us"] = round(ms.value * 1e3, 2)
         out = {
@@ -158,9 +165,15 @@ def main():
             "host_phases_us": {k: round(v / args.steps * 1e6, 1) for k, v in zip(
                 ("gn_accumulate_wait", "assemble", "ldlt", "step_and_precalc", "precalc", "gn_step_call_and_post", "post",
                  "backup"), phases)},
-            "roofline": {"kernel": "k_linearize", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "bytes_per_residual": LINEARIZE_BYTES_PER_RESIDUAL, "avg_launch_us": lin_ms * 1e3},
+            "roofline": {"kernel": "k_linearize (fused: linearize + applyRes + top-Hessian tile sums, J kept in LDS)",
+                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.window),
+                         "bytes_per_residual": fused_bytes,
+                         "bytes_per_residual_parts": {"linearize": LINEARIZE_BYTES_PER_RESIDUAL, "top_accumulate": TOP_BYTES_PER_RESIDUAL},
+                         "avg_launch_us": fused_ms * 1e3,
+                         "unfused_linearize": {"avg_launch_us": lin_ms * 1e3, "bytes_per_residual": LINEARIZE_BYTES_PER_RESIDUAL,
+                                               "achieved": R_local * LINEARIZE_BYTES_PER_RESIDUAL / (lin_ms * 1e-3) / 1e9,
+                                               "frac": R_local * LINEARIZE_BYTES_PER_RESIDUAL / (lin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
         }
     sysm.close()
     if rank == 0:
@@ -171,6 +184,19 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(window):
+    """HBM-side bytes per launch of the roofline kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; see
+    profiles/*pmc*.json and tools/pmc_probe.py).  Counters cannot be read from inside the process: null when no
+    summary for this window is committed."""
+    path = os.path.join(ROOT, "profiles", f"pmc_{window}.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["k_linearize_fused"]["traffic_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def L_host_ba(sysm):

@@ -113,15 +113,80 @@ __device__ __forceinline__ float seqsum8(float v) {
 // ================================================================================================
 #define SJ_STRIDE 40  // LDS row stride (floats): == 8 mod 32 -> the 8x8 (pixel, residual) stores are 2-way at worst
 
+// ------------------------------------------------------------------------------------------------
+// The 96 per-residual values of AccumulatedTopHessianSSE::addPoint (OB/AccumulatedTopHessian.cpp:112-122 ->
+// AccumulatorApprox::update / updateTopRight / updateBotRight, OB/MatrixAccumulators.h:928-1112) in the order of
+// the packed 13x13 block: 55 uniques of the 10x10 [C xi] block, 30 top-right entries, 6 bottom-right, the
+// residual count, 4 zeros.  top_value<K> is the K-th of them, with the same expression shapes as
+// top_accumulate_body so that both produce identical per-residual terms.
+// ------------------------------------------------------------------------------------------------
+struct TopIn {
+  float x[10], y[10];  // Jpdc[0..3] | Jpdxi[0..5], rows 0 and 1
+  float a, b, c;       // JIdx2 00 01 11
+  float jab00, jab01, jab10, jab11, ab00, ab01, ab11;
+  float JI_r0, JI_r1, Jab_r0, Jab_r1, rr;
+};
+__host__ __device__ constexpr int top_row_of(int k) {
+  int r = 0, rem = k;
+  while (rem >= 10 - r) { rem -= 10 - r; r++; }
+  return r;
+}
+__host__ __device__ constexpr int top_col_of(int k) {
+  int r = 0, rem = k;
+  while (rem >= 10 - r) { rem -= 10 - r; r++; }
+  return r + rem;
+}
+template <int K>
+__device__ __forceinline__ float top_value(const TopIn &in) {
+  if constexpr (K < 55) {
+    constexpr int rr_ = top_row_of(K), cc = top_col_of(K);
+    return in.a * in.x[cc] * in.x[rr_] + in.c * in.y[cc] * in.y[rr_] + in.b * (in.x[cc] * in.y[rr_] + in.y[cc] * in.x[rr_]);
+  } else if constexpr (K < 85) {
+    constexpr int i = (K - 55) / 3, w = (K - 55) % 3;
+    if constexpr (w == 0) return in.x[i] * in.jab00 + in.y[i] * in.jab01;
+    else if constexpr (w == 1) return in.x[i] * in.jab10 + in.y[i] * in.jab11;
+    else return in.x[i] * in.JI_r0 + in.y[i] * in.JI_r1;
+  } else if constexpr (K == 85) return in.ab00;
+  else if constexpr (K == 86) return in.ab01;
+  else if constexpr (K == 87) return in.Jab_r0;
+  else if constexpr (K == 88) return in.ab11;
+  else if constexpr (K == 89) return in.Jab_r1;
+  else if constexpr (K == 90) return in.rr;
+  else if constexpr (K == 91) return 1.f;
+  else return 0.f;
+}
+template <int P>
+__device__ __forceinline__ void top_values12(const TopIn &in, float *v) {
+  v[0] = top_value<12 * P + 0>(in); v[1] = top_value<12 * P + 1>(in); v[2] = top_value<12 * P + 2>(in);
+  v[3] = top_value<12 * P + 3>(in); v[4] = top_value<12 * P + 4>(in); v[5] = top_value<12 * P + 5>(in);
+  v[6] = top_value<12 * P + 6>(in); v[7] = top_value<12 * P + 7>(in); v[8] = top_value<12 * P + 8>(in);
+  v[9] = top_value<12 * P + 9>(in); v[10] = top_value<12 * P + 10>(in); v[11] = top_value<12 * P + 11>(in);
+}
+
 #ifndef SOS_LIN_WAVES
 #define SOS_LIN_WAVES 4
 #endif
-__global__ __launch_bounds__(256, SOS_LIN_WAVES) void k_linearize(BaDev d, const float *__restrict__ frameTH, int doApply) {
+#ifdef SOS_LIN_PROFILE  // developer build: per-block phase timestamps (s_memtime) of k_linearize
+__device__ unsigned long long g_lin_prof[8192 * 8];
+#define LIN_STAMP(i) do { if (tid == 0 && blockIdx.x < 8192) g_lin_prof[blockIdx.x * 8 + (i)] = clock64(); } while (0)
+extern "C" int sos_debug_lin_prof(unsigned long long *out, int nblocks) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lin_prof), sizeof(unsigned long long) * 8 * nblocks) == hipSuccess ? 0 : -2;
+}
+#else
+#define LIN_STAMP(i)
+#endif
+// fuse_top != nullptr (requires doApply): the block also accumulates its tile's 13x13 block sums (mode 0 of
+// AccumulatedTopHessianSSE::addPoint) from the tile still in LDS into fuse_top[tile*96..] and does NOT write the tile
+// to HBM -- the Jacobians of a Gauss-Newton iteration are consumed where they are produced.
+__global__ __launch_bounds__(256, SOS_LIN_WAVES) void k_linearize(BaDev d, const float *__restrict__ frameTH, int doApply,
+                                                                  float *__restrict__ fuse_top) {
   __shared__ float sJ[SOS_JPLANES * SJ_STRIDE];
+  __shared__ float sX[6 * SJ_STRIDE];  // per residual: JI_r0 JI_r1 Jab_r0 Jab_r1 rr use
   __shared__ float sRet[SOS_TILE];
   __shared__ unsigned int sLin;
   const int tile = blockIdx.x;
   const int tid = threadIdx.x;
+  LIN_STAMP(0);
   const int rl = tid >> 3, idx = tid & 7;
   const int lane = tid & 63;
   const int s = tile * SOS_TILE + rl;
@@ -149,6 +214,7 @@ __global__ __launch_bounds__(256, SOS_LIN_WAVES) void k_linearize(BaDev d, const
   const float q1 = pc->PRE_KRKiTll[3] * u_pt + pc->PRE_KRKiTll[4] * v_pt + pc->PRE_KRKiTll[5] + pc->PRE_KtTll[1] * id;
   const float q2 = pc->PRE_KRKiTll[6] * u_pt + pc->PRE_KRKiTll[7] * v_pt + pc->PRE_KRKiTll[8] + pc->PRE_KtTll[2] * id;
   const float Ku = q0 / q2, Kv = q1 / q2;
+  LIN_STAMP(1);  // first-level loads (geo, precalc) have arrived
   const bool inb = Ku > 1.1f && Kv > 1.1f && Ku < d.wM3G && Kv < d.hM3G;
 
   // ---- bilinear (I,dx,dy) tap (util/globalFuncs.h:68-82); addresses clamped so the loads are always legal
@@ -166,6 +232,7 @@ __global__ __launch_bounds__(256, SOS_LIN_WAVES) void k_linearize(BaDev d, const
   float hit1 = w11 * d1 + w01 * c1 + w10 * b1_ + w00 * a1;
   float hit2 = w11 * d2 + w01 * c2 + w10 * b2_ + w00 * a2;
 
+  LIN_STAMP(2);  // image taps have arrived
   const bool lane_oob = !inb || !isfinite(hit0);
   const unsigned long long oobmask = __ballot(lane_oob);
   const bool grp_oob = ((oobmask >> (lane & 56)) & 0xffull) != 0;
@@ -206,7 +273,12 @@ __global__ __launch_bounds__(256, SOS_LIN_WAVES) void k_linearize(BaDev d, const
   // terms of the point sums, produced here so that the Schur side does not have to wait for the top accumulation
   const float JI_r0 = seqsum8(residual * hw * hit1);
   const float JI_r1 = seqsum8(residual * hw * hit2);
+  const float jabF0 = d.modeA < 0 ? 0.0f : drdA * hw, jabF1 = d.modeB < 0 ? 0.0f : hw;
+  const float Jab_r0 = seqsum8(residual * hw * jabF0);
+  const float Jab_r1 = seqsum8(residual * hw * jabF1);
+  const float rr_sum = seqsum8(residual * hw * (residual * hw));
 
+  LIN_STAMP(3);  // per-pixel part + DPP sums done
   if (idx == 7) {
     const float fxl = d.calib.fxl, fyl = d.calib.fyl, cxl = d.calib.cxl, cyl = d.calib.cyl;
     const float fxli = d.calib.fxli, fyli = d.calib.fyli;
@@ -297,26 +369,29 @@ __global__ __launch_bounds__(256, SOS_LIN_WAVES) void k_linearize(BaDev d, const
       newEnergy = energyLeft;
       ret = energyLeft;
     }
+    const bool wr = doApply != 2;  // 2 = refresh: recompute the tile at the unchanged state and store nothing but J
+    if (wr) {
     d.s_newstate[s] = (uint8_t)newState;
     d.s_newenergy[s] = newEnergy;
     d.s_newenergywo[s] = newEnergyWO;
     d.s_ret[s] = ret;
     sRet[rl] = ret;
     if (d.o_newest && tIdx == d.n - 1) d.o_newest[s - d.newest_begin] = newEnergyWO;
+    }
     bool activeAfter = (flags & DF_ACTIVE) != 0;
-    if (doApply && valid && !isLin && st != SOS_RES_OOB) {  // applyRes(true), FS/Residuals.cpp:304-321
+    if (doApply == 1 && valid && !isLin && st != SOS_RES_OOB) {  // applyRes(true), FS/Residuals.cpp:304-321
       activeAfter = newState == SOS_RES_IN;
       d.s_flags[s] = (uint8_t)(activeAfter ? (flags | DF_ACTIVE) : (flags & ~DF_ACTIVE));
       d.s_state[s] = (uint8_t)newState;
       d.s_energy[s] = newEnergy;
     }
-    const bool wrote_center = valid && !isLin && st != SOS_RES_OOB && center_ok;
+    const bool wrote_center = wr && valid && !isLin && st != SOS_RES_OOB && center_ok;
     if (wrote_center) {
       d.s_center[3 * s + 0] = cKu;
       d.s_center[3 * s + 1] = cKv;
       d.s_center[3 * s + 2] = new_idepth;
     }
-    if (valid && !isLin) {
+    if (wr && valid && !isLin) {
       // JpJdF of EFResidual::takeDataF (OB/EnergyFunctionalStructs.cpp:39-44)
       const float v0 = JIdxJIdx_00 * d_d_x + JIdxJIdx_10 * d_d_y;
       const float v1 = JIdxJIdx_10 * d_d_x + JIdxJIdx_11 * d_d_y;
@@ -351,8 +426,16 @@ __global__ __launch_bounds__(256, SOS_LIN_WAVES) void k_linearize(BaDev d, const
       pt[0] = p0;
       pt[1] = p1;
     }
+    if (fuse_top) {  // inputs of the fused block accumulation that are not planes of the tile
+      sX[0 * SJ_STRIDE + rl] = JI_r0;
+      sX[1 * SJ_STRIDE + rl] = JI_r1;
+      sX[2 * SJ_STRIDE + rl] = Jab_r0;
+      sX[3 * SJ_STRIDE + rl] = Jab_r1;
+      sX[4 * SJ_STRIDE + rl] = rr_sum;
+      sX[5 * SJ_STRIDE + rl] = (valid && !isLin && activeAfter) ? 1.f : 0.f;
+    }
     const int orig = d.s_orig[s];
-    if (orig >= 0) {
+    if (wr && orig >= 0) {
       if (d.o_newstate) d.o_newstate[orig] = (uint8_t)newState;
       if (d.o_newenergy) d.o_newenergy[orig] = newEnergy;
       if (d.o_newenergywo) d.o_newenergywo[orig] = newEnergyWO;
@@ -363,12 +446,59 @@ __global__ __launch_bounds__(256, SOS_LIN_WAVES) void k_linearize(BaDev d, const
       }
     }
   }
+  LIN_STAMP(4);  // leader part done (this wave)
   __syncthreads();
-  if (tid < 64 && d.tile_esum) {  // returned energies of the tile: fp64 butterfly over the 32 residuals
+  LIN_STAMP(5);
+  if (tid < 64 && d.tile_esum && doApply != 2) {  // returned energies of the tile: fp64 butterfly over the 32 residuals
     double a = (tid < SOS_TILE) ? (double)sRet[tid] : 0.0;
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
     if (tid == 0) d.tile_esum[tile] = a;
+  }
+
+  if (fuse_top) {
+    // ---- fused AccumulatedTopHessianSSE::addPoint<0> over the tile: thread = (residual r, part), part = 12 of the
+    // 96 values; sum over the 32 residuals by an xor butterfly inside each half-wave (fixed tree: deterministic)
+    const int r = tid & 31, part = tid >> 5;
+    TopIn in;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { in.x[i] = sJ[(JP_DC0 + i) * SJ_STRIDE + r]; in.y[i] = sJ[(JP_DC1 + i) * SJ_STRIDE + r]; }
+#pragma unroll
+    for (int i = 0; i < 6; i++) { in.x[4 + i] = sJ[(JP_DXI0 + i) * SJ_STRIDE + r]; in.y[4 + i] = sJ[(JP_DXI1 + i) * SJ_STRIDE + r]; }
+    in.a = sJ[(JP_JIDX2 + 0) * SJ_STRIDE + r]; in.b = sJ[(JP_JIDX2 + 1) * SJ_STRIDE + r]; in.c = sJ[(JP_JIDX2 + 2) * SJ_STRIDE + r];
+    in.jab00 = sJ[(JP_JABJIDX + 0) * SJ_STRIDE + r]; in.jab01 = sJ[(JP_JABJIDX + 1) * SJ_STRIDE + r];
+    in.jab10 = sJ[(JP_JABJIDX + 2) * SJ_STRIDE + r]; in.jab11 = sJ[(JP_JABJIDX + 3) * SJ_STRIDE + r];
+    in.ab00 = sJ[(JP_JAB2 + 0) * SJ_STRIDE + r]; in.ab01 = sJ[(JP_JAB2 + 1) * SJ_STRIDE + r]; in.ab11 = sJ[(JP_JAB2 + 2) * SJ_STRIDE + r];
+    in.JI_r0 = sX[0 * SJ_STRIDE + r]; in.JI_r1 = sX[1 * SJ_STRIDE + r];
+    in.Jab_r0 = sX[2 * SJ_STRIDE + r]; in.Jab_r1 = sX[3 * SJ_STRIDE + r];
+    in.rr = sX[4 * SJ_STRIDE + r];
+    const bool use = sX[5 * SJ_STRIDE + r] != 0.f;
+    float v[12];
+    switch (part) {
+      case 0: top_values12<0>(in, v); break;
+      case 1: top_values12<1>(in, v); break;
+      case 2: top_values12<2>(in, v); break;
+      case 3: top_values12<3>(in, v); break;
+      case 4: top_values12<4>(in, v); break;
+      case 5: top_values12<5>(in, v); break;
+      case 6: top_values12<6>(in, v); break;
+      default: top_values12<7>(in, v); break;
+    }
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+      float a = use ? v[k] : 0.f;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+      v[k] = a;
+    }
+    if (r == 0) {
+      float4 *o = reinterpret_cast<float4 *>(fuse_top + (size_t)tile * SOS_TOPN + 12 * part);
+      o[0] = make_float4(v[0], v[1], v[2], v[3]);
+      o[1] = make_float4(v[4], v[5], v[6], v[7]);
+      o[2] = make_float4(v[8], v[9], v[10], v[11]);
+    }
+    LIN_STAMP(6);
+    return;  // the tile itself stays on chip
   }
 
   // ---- copy the staged tile out: 72 rows x 128 B, contiguous 9216 B span of J
@@ -388,6 +518,7 @@ __global__ __launch_bounds__(256, SOS_LIN_WAVES) void k_linearize(BaDev d, const
       if (!(lm & 8u)) dst[3] = v.w;
     }
   }
+  LIN_STAMP(6);
 }
 
 // sum of the returned energies in double, fixed order: deterministic
@@ -814,6 +945,10 @@ __device__ __forceinline__ void sc_gram_body(const BaDev &d, int blk, const int 
 __global__ __launch_bounds__(256) void k_sc_gram(BaDev d, const int *__restrict__ chunk_pt /* nchunks*SOS_GC point ids */,
                                                  int Dm, int ld, float *__restrict__ gram_part) {
   sc_gram_body<-1>(d, blockIdx.x, chunk_pt, Dm, ld, gram_part);
+}
+__global__ __launch_bounds__(256) void k_sc_gram_prep(BaDev d, const int *__restrict__ chunk_pt, int Dm, int ld,
+                                                      float *__restrict__ gram_part) {
+  sc_gram_body<1>(d, blockIdx.x, chunk_pt, Dm, ld, gram_part);
 }
 // One launch for the two independent halves of the accumulation of a window without linearised residuals:
 // blocks [0, nTopBlocks) = AccumulatedTopHessian over the A tiles, the rest = per-point sums + Schur Gram chunks
@@ -1498,6 +1633,7 @@ struct sos_ba {
   bool prefetch = false;      // sos_ba_set_prefetch: gn_step enqueues the next gn_accumulate behind the linearisation
   bool acc_inflight = false;  // ... and this says its result is (or will be) in the mapped Hb block
   bool acc_inflight_haveL = false;
+  bool J_valid = true;        // false after a pipelined sos_ba_gn_step: the tiles were consumed on chip, d_J is stale
   hipEvent_t ev_step = nullptr;
   size_t hb_mode_stride = 0;  // doubles per (H | b) block in d_Hout
   std::vector<float> h_adHostF, h_adTargetF;
@@ -1914,7 +2050,16 @@ static int stage_in(sos_ba *ba, size_t nfloats) {
 }
 
 static int launch_linearize(sos_ba *ba, int doApply) {
-  if (ba->ntilesA > 0) k_linearize<<<ba->ntilesA, 256, 0, ba->ctx->stream>>>(ba->dev, stg(ba, ba->st_th), doApply);
+  if (ba->ntilesA > 0) k_linearize<<<ba->ntilesA, 256, 0, ba->ctx->stream>>>(ba->dev, stg(ba, ba->st_th), doApply, nullptr);
+  return SOS_OK;
+}
+
+// d_J is not written by the pipelined iterations (the tiles are reduced on chip): any consumer of the stored
+// Jacobians first recomputes them at the unchanged linearisation state (identical values, nothing else is written)
+static int ensure_J(sos_ba *ba) {
+  if (ba->J_valid) return SOS_OK;
+  if (ba->ntilesA > 0) k_linearize<<<ba->ntilesA, 256, 0, ba->ctx->stream>>>(ba->dev, stg(ba, ba->st_th), 2, nullptr);
+  ba->J_valid = true;
   return SOS_OK;
 }
 
@@ -1927,6 +2072,7 @@ extern "C" int sos_ba_linearize(sos_ba *ba, const float *frameEnergyTH, double *
   hipStream_t st = c->stream;
   SOS_HIP(hipMemcpyAsync(stg(ba, ba->st_th), frameEnergyTH, sizeof(float) * ba->n, hipMemcpyHostToDevice, st));
   launch_linearize(ba, 0);
+  ba->J_valid = true;
   if (energySum) {
     k_sum_ret<<<1, 1024, 0, st>>>(ba->d_s_ret.p, ba->ntilesA * SOS_TILE, ba->d_scalar.p);
     SOS_HIP(hipMemcpyAsync(energySum, ba->d_scalar.p, sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1971,6 +2117,7 @@ extern "C" int sos_ba_reset_oob(sos_ba *ba) {
 }
 
 extern "C" int sos_ba_fix_linearization(sos_ba *ba, const int32_t *residIdx, int count) {
+  if (ba && ba->have_window && ba->have_state) ensure_J(ba);
   if (ba) ba->acc_inflight = false;  // any state change invalidates a prefetched accumulate
   if (!ba || !ba->have_window || !ba->have_state || (count && !residIdx)) return SOS_ERR_STATE;
   if (count <= 0) return SOS_OK;
@@ -1993,6 +2140,7 @@ extern "C" int sos_ba_fix_linearization(sos_ba *ba, const int32_t *residIdx, int
 // ---- accumulation pipeline ---------------------------------------------------------------------
 static int launch_top(sos_ba *ba) {
   hipStream_t st = ba->ctx->stream;
+  ensure_J(ba);
   const int nA = ba->ntilesA, nL = ba->ntiles - ba->ntilesA;
   if (nA > 0)
     k_top_accumulate<false><<<divup(nA, 8), 256, 0, st>>>(ba->dev, 0, nA, 0, nullptr, nullptr, ba->d_top_part.p, nullptr);
@@ -2111,9 +2259,13 @@ extern "C" int sos_ba_accumulate(sos_ba *ba, double *H_A, double *b_A, double *H
 
 // accumulate + stitch of the whole window with the stage-2 stitch kernels writing H/b (and the residual counts)
 // straight into the device-mapped pinned block: no copy command between the last kernel and the host
-static int enqueue_gn_accumulate(sos_ba *ba) {
+static int enqueue_gn_accumulate(sos_ba *ba, bool topDone = false) {
   const bool haveL = ba->ntiles > ba->ntilesA;
-  if (!haveL && ba->ntilesA > 0 && ba->nchunks > 0) {  // top and Schur halves are independent: one launch
+  if (topDone && !haveL) {  // the tile sums came out of the linearisation itself: only the Schur half is left
+    if (ba->nchunks > 0)
+      k_sc_gram_prep<<<ba->nchunks, 256, gram_lds(ba), ba->ctx->stream>>>(ba->dev, ba->d_chunk_pt.p, ba->Dm, ba->ld, ba->d_gram_part.p);
+  } else if (!haveL && ba->ntilesA > 0 && ba->nchunks > 0) {  // top and Schur halves are independent: one launch
+    ensure_J(ba);
     const int nTop = divup(ba->ntilesA, 8);
     k_accumulate_fused<<<nTop + ba->nchunks, 256, gram_lds(ba), ba->ctx->stream>>>(ba->dev, nTop, ba->d_top_part.p, ba->d_chunk_pt.p,
                                                                                 ba->Dm, ba->ld, ba->d_gram_part.p);
@@ -2264,13 +2416,17 @@ extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const
   } else {
     stage_in(ba, ba->st_xc);
   }
-  if (ba->ntilesA > 0) k_linearize<<<ba->ntilesA, 256, 0, st>>>(dv, stg(ba, ba->st_th), applyRes ? 1 : 0);
+  // pipelined iterations of a window without linearised residuals reduce the tiles on chip (no J traffic at all)
+  const bool fuseTop = ba->prefetch && applyRes && ba->ntiles == ba->ntilesA;
+  if (ba->ntilesA > 0)
+    k_linearize<<<ba->ntilesA, 256, 0, st>>>(dv, stg(ba, ba->st_th), applyRes ? 1 : 0, fuseTop ? ba->d_top_part.p : nullptr);
+  ba->J_valid = !fuseTop;
   SOS_HIP(hipGetLastError());
   const double t2 = now_s();
   double t3 = t2;
   if (ba->prefetch && applyRes) {  // the next iteration's accumulate + stitch runs while the host digests this step
     SOS_HIP(hipEventRecord(ba->ev_step, st));
-    enqueue_gn_accumulate(ba);
+    enqueue_gn_accumulate(ba, fuseTop);
     SOS_HIP(hipGetLastError());
     ba->acc_inflight = true;
     t3 = now_s();
@@ -2326,6 +2482,7 @@ extern "C" int sos_ba_calc_lenergy(sos_ba *ba, double *E) {
 
 extern "C" int sos_ba_accumulate_marg(sos_ba *ba, const int32_t *pointIdx, int count, double *M, double *Mb, double *Msc,
                                       double *Mbsc, int *resInM) {
+  if (ba && ba->have_window && ba->have_state) ensure_J(ba);
   if (ba) ba->acc_inflight = false;  // any state change invalidates a prefetched accumulate
   if (!ba || !ba->have_window || !ba->have_state || (count && !pointIdx)) return SOS_ERR_STATE;
   SOS_HIP(hipSetDevice(ba->ctx->device));
@@ -2407,6 +2564,7 @@ extern "C" int sos_ba_update_point_priors(sos_ba *ba, const int32_t *pointIdx, c
 
 // ---- inspection ---------------------------------------------------------------------------------
 extern "C" int sos_ba_get_jacobian(sos_ba *ba, int residIdx, int which, sos_rawjac *out) {
+  if (ba && ba->have_window && ba->have_state) ensure_J(ba);
   (void)which;  // one shared buffer, see the header comment of this file
   if (!ba || !ba->have_window || !out || residIdx < 0 || residIdx >= ba->R) return SOS_ERR_ARG;
   SOS_HIP(hipSetDevice(ba->ctx->device));
@@ -2477,6 +2635,15 @@ extern "C" int sos_ba_time_kernel(sos_ba *ba, const char *kernel, const float *f
   auto once = [&]() -> int {
     if (k == "linearize") return launch_linearize(ba, 0);
     if (k == "linearize_apply") return launch_linearize(ba, 1);
+    if (k == "linearize_fused") {  // what the pipelined iterations run: linearize + applyRes + tile block sums, no J store
+      if (ba->ntilesA > 0) k_linearize<<<ba->ntilesA, 256, 0, st>>>(ba->dev, stg(ba, ba->st_th), 1, ba->d_top_part.p);
+      ba->J_valid = false;
+      return SOS_OK;
+    }
+    if (k == "sc_gram_prep") {
+      if (ba->nchunks > 0) k_sc_gram_prep<<<ba->nchunks, 256, gram_lds(ba), st>>>(ba->dev, ba->d_chunk_pt.p, ba->Dm, ba->ld, ba->d_gram_part.p);
+      return SOS_OK;
+    }
     if (k == "apply_res") return sos_ba_apply_res(ba);
     if (k == "top_accumulate") return launch_top(ba);
     if (k == "sc_accumulate") return launch_sc(ba, 1);

@@ -27,7 +27,7 @@ L = lib.load()
 ba = C.c_void_p(host.load().sosf_ba(sysm.h_))
 th = np.array([sysm.frame(f)["frameEnergyTH"] for f in range(win.n)], np.float32)
 ms = C.c_float(0)
-for name in ("calib_read", "calib_write", "linearize_apply", "top_accumulate", "sc_accumulate", "reduce", "stitch"):
+for name in ("calib_read", "calib_write", "linearize_fused", "linearize_apply", "top_accumulate", "sc_gram_prep", "reduce", "stitch"):
     L.sos_ba_time_kernel(ba, name.encode(), th.ctypes.data_as(C.c_void_p), 20, C.byref(ms))
 print(json.dumps({"window": win.name, "residuals": int(win.R), "points": int(win.P)}))
 sysm.close()
