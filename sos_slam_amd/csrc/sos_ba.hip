@@ -521,6 +521,387 @@ __global__ __launch_bounds__(256, SOS_LIN_WAVES) void k_linearize(BaDev d, const
   LIN_STAMP(6);
 }
 
+template <int HALF>
+__device__ __forceinline__ void bfly_step(float *v, int m, bool hi);
+
+// ================================================================================================
+// k_linearize2: the production form of the kernel above, restructured around the finding that the kernel is bound
+// by VALU issue, not by memory (rocprof: every wave of k_linearize spends a third of its instructions in the
+// per-residual "leader" part with 1 of 8 lanes active).  One 512-thread block = two tiles; three phases:
+//   1  all 8 waves, lane = pattern pixel: projection, image taps, photometric rows, the 8-pixel sequential sums
+//      (DPP chains); lane 7 of each group leaves the 17 sums of its residual in LDS
+//   2  ONE wave (rotating with the block index so the work spreads over the SIMDs), lane = residual, all 64 lanes
+//      busy: FEJ centre projection, geometric Jacobians, classification, applyRes, JpJdF, point terms and -- when
+//      fuse_top is given -- the 13x13 block sums of AccumulatedTopHessianSSE::addPoint<0> over each tile
+//      (transposed butterfly over the 32 lanes of a tile, 24 values at a time)
+//   3  all waves: coalesced store of the two staged tiles (skipped when fused: the tiles never leave the chip)
+// Per-element arithmetic is the same expression for expression as in k_linearize: outputs are bit-identical
+// (tests/test_gpu_backend.py), only the tile sums of the fused mode use a different (still fixed) summation tree.
+// ================================================================================================
+#define L2_TILES 2
+#define L2_NS 18  // 17 sums + group-out-of-bounds flag
+__global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(BaDev d, const float *__restrict__ frameTH, int doApply,
+                                                               float *__restrict__ fuse_top) {
+  __shared__ float sJ2[L2_TILES][SOS_JPLANES * SJ_STRIDE];
+  __shared__ float sS[L2_NS][32 * L2_TILES];
+  __shared__ unsigned int sLin2[L2_TILES];
+  const int tid = threadIdx.x;
+  const int tloc = tid >> 8, t256 = tid & 255;
+  const int tile = blockIdx.x * L2_TILES + tloc;
+  const bool tile_ok = tile < d.ntilesA;
+  const int rl = t256 >> 3, idx = t256 & 7;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int w2 = blockIdx.x & 7;  // the wave of this block that runs phase 2
+  float *sJ = sJ2[tloc];
+  if (tid < L2_TILES) sLin2[tid] = 0;
+
+  // ---- phase-2 operands of this lane's residual are requested up front so their latency hides behind phase 1
+  const int r64 = lane, tl2 = r64 >> 5, rr2 = r64 & 31;
+  const int tile2 = blockIdx.x * L2_TILES + tl2;
+  const bool p2 = (wave == w2) && tile2 < d.ntilesA;
+  const int s2 = (p2 ? tile2 : 0) * SOS_TILE + rr2;
+  float4 geo2 = make_float4(0.f, 0.f, 0.f, 0.f);
+  unsigned flags2 = 0;
+  int st2 = 0, pair2 = 0;
+  float R0[9], t0[3], eOld2 = 0.f, neOld2 = 0.f;
+  if (p2) {
+    geo2 = d.r_geo[s2];
+    flags2 = d.s_flags[s2];
+    st2 = d.s_state[s2];
+    pair2 = d.t_pair[tile2];
+    eOld2 = d.s_energy[s2];
+    neOld2 = d.s_newenergy[s2];
+    const sos_precalc *pc2 = d.precalc + pair2;
+#pragma unroll
+    for (int i = 0; i < 9; i++) R0[i] = pc2->PRE_RTll_0[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) t0[i] = pc2->PRE_tTll_0[i];
+  }
+
+  // =============================== phase 1: lane = pattern pixel ===============================
+  if (tile_ok) {
+    const int s = tile * SOS_TILE + rl;
+    const float4 geo = d.r_geo[s];
+    const float color = d.r_cw[16 * (size_t)s + idx], pweight = d.r_cw[16 * (size_t)s + 8 + idx];
+    const int pair = d.t_pair[tile];
+    const int tIdx = pair / d.n;
+    const sos_precalc *pc = d.precalc + pair;
+    const float *__restrict__ img = d.img[tIdx];
+    const float pu = geo.x, pv = geo.y, id = geo.z;
+
+    // this lane's pattern pixel with the current pose / idepth (FS/ResidualProjections.h:43-50)
+    const int px = (int)((0x21420312u >> (4 * idx)) & 0xf) - 2;  // {0,-1,1,-2,0,2,-1,0}
+    const int py = (int)((0x43222110u >> (4 * idx)) & 0xf) - 2;  // {-2,-1,-1,0,0,0,1,2}
+    const float u_pt = pu + (float)px, v_pt = pv + (float)py;
+    const float q0 = pc->PRE_KRKiTll[0] * u_pt + pc->PRE_KRKiTll[1] * v_pt + pc->PRE_KRKiTll[2] + pc->PRE_KtTll[0] * id;
+    const float q1 = pc->PRE_KRKiTll[3] * u_pt + pc->PRE_KRKiTll[4] * v_pt + pc->PRE_KRKiTll[5] + pc->PRE_KtTll[1] * id;
+    const float q2 = pc->PRE_KRKiTll[6] * u_pt + pc->PRE_KRKiTll[7] * v_pt + pc->PRE_KRKiTll[8] + pc->PRE_KtTll[2] * id;
+    const float Ku = q0 / q2, Kv = q1 / q2;
+    const bool inb = Ku > 1.1f && Kv > 1.1f && Ku < d.wM3G && Kv < d.hM3G;
+
+    // bilinear (I,dx,dy) tap (util/globalFuncs.h:68-82); addresses clamped so the loads are always legal
+    int ix = (int)Ku, iy = (int)Kv;
+    const float fdx = Ku - (float)ix, fdy = Kv - (float)iy;
+    ix = min(max(ix, 0), d.w - 2);
+    iy = min(max(iy, 0), d.h - 2);
+    const float *bp = img + 3 * (ix + iy * d.w);
+    const float a0 = bp[0], a1 = bp[1], a2 = bp[2], b0_ = bp[3], b1_ = bp[4], b2_ = bp[5];
+    const float *bq = bp + 3 * d.w;
+    const float c0 = bq[0], c1 = bq[1], c2 = bq[2], d0 = bq[3], d1 = bq[4], d2 = bq[5];
+    const float dxdy = fdx * fdy;
+    const float w11 = dxdy, w01 = fdy - dxdy, w10 = fdx - dxdy, w00 = 1 - fdx - fdy + dxdy;
+    const float hit0 = w11 * d0 + w01 * c0 + w10 * b0_ + w00 * a0;
+    float hit1 = w11 * d1 + w01 * c1 + w10 * b1_ + w00 * a1;
+    float hit2 = w11 * d2 + w01 * c2 + w10 * b2_ + w00 * a2;
+
+    const bool lane_oob = !inb || !isfinite(hit0);
+    const unsigned long long oobmask = __ballot(lane_oob);
+    const bool grp_oob = ((oobmask >> (lane & 56)) & 0xffull) != 0;
+
+    // photometric residual, weights (FS/Residuals.cpp:189-241)
+    const float affLL0 = pc->PRE_aff_mode[0], affLL1 = pc->PRE_aff_mode[1], b0 = pc->PRE_b0_mode;
+    const float residual = hit0 - (float)(affLL0 * color + affLL1);
+    const float drdA = color - b0;
+    float wgt = sqrtf(d.outlierTH / (d.outlierTH + (hit1 * hit1 + hit2 * hit2)));
+    wgt = 0.5f * (wgt + pweight);
+    float hw = fabsf(residual) < d.huberTH ? 1 : d.huberTH / fabsf(residual);
+    const float e_i = wgt * wgt * hw * residual * residual * (2 - hw);
+    if (hw < 1) hw = sqrtf(hw);
+    hw = hw * wgt;
+    hit1 *= hw;
+    hit2 *= hw;
+    const float jabF0 = d.modeA < 0 ? 0.0f : drdA * hw, jabF1 = d.modeB < 0 ? 0.0f : hw;
+
+    if (!fuse_top) {  // per-pixel rows of the Jacobian -> LDS staging (only needed when the tile is stored)
+      sJ[(JP_RESF + idx) * SJ_STRIDE + rl] = residual * hw;
+      sJ[(JP_JIDX0 + idx) * SJ_STRIDE + rl] = hit1;
+      sJ[(JP_JIDX1 + idx) * SJ_STRIDE + rl] = hit2;
+      sJ[(JP_JAB0 + idx) * SJ_STRIDE + rl] = jabF0;
+      sJ[(JP_JAB1 + idx) * SJ_STRIDE + rl] = jabF1;
+    }
+
+    float sm[17];
+    sm[0] = seqsum8(e_i);                                  // energyLeft
+    sm[1] = seqsum8(hit1 * hit1);                          // JIdxJIdx_00
+    sm[2] = seqsum8(hit2 * hit2);                          // JIdxJIdx_11
+    sm[3] = seqsum8(hit1 * hit2);                          // JIdxJIdx_10
+    sm[4] = seqsum8(drdA * hw * hit1);                     // JabJIdx_00
+    sm[5] = seqsum8(drdA * hw * hit2);                     // JabJIdx_01
+    sm[6] = seqsum8(hw * hit1);                            // JabJIdx_10
+    sm[7] = seqsum8(hw * hit2);                            // JabJIdx_11
+    sm[8] = seqsum8(drdA * drdA * hw * hw);                // JabJab_00
+    sm[9] = seqsum8(drdA * hw * hw);                       // JabJab_01
+    sm[10] = seqsum8(hw * hw);                             // JabJab_11
+    sm[11] = seqsum8(hw * hw * (hit1 * hit1 + hit2 * hit2));  // wJI2_sum
+    sm[12] = seqsum8(residual * hw * hit1);                // JI_r0 (OB/AccumulatedTopHessian.cpp:101-110)
+    sm[13] = seqsum8(residual * hw * hit2);                // JI_r1
+    sm[14] = seqsum8(residual * hw * jabF0);               // Jab_r0
+    sm[15] = seqsum8(residual * hw * jabF1);               // Jab_r1
+    sm[16] = seqsum8(residual * hw * (residual * hw));     // rr
+    if (idx == 7) {
+      const int c = tloc * 32 + rl;
+#pragma unroll
+      for (int k = 0; k < 17; k++) sS[k][c] = sm[k];
+      sS[17][c] = grp_oob ? 1.f : 0.f;
+    }
+  }
+  __syncthreads();
+
+  // =============================== phase 2: lane = residual (one wave) ===============================
+  if (p2) {
+    float *sJr = sJ2[tl2];
+    const int s = s2, rl_ = rr2, c = r64;
+    const unsigned flags = flags2;
+    const int st = st2;
+    const int hIdx = pair2 % d.n, tIdx = pair2 / d.n;
+    const bool valid = (flags & DF_VALID) != 0;
+    const bool isLin = valid && (flags & DF_LINEARIZED);
+    const float pu = geo2.x, pv = geo2.y, idz = geo2.w;
+    const float energyLeft0 = sS[0][c], JIdxJIdx_00 = sS[1][c], JIdxJIdx_11 = sS[2][c], JIdxJIdx_10 = sS[3][c];
+    const float JabJIdx_00 = sS[4][c], JabJIdx_01 = sS[5][c], JabJIdx_10 = sS[6][c], JabJIdx_11 = sS[7][c];
+    const float JabJab_00 = sS[8][c], JabJab_01 = sS[9][c], JabJab_11 = sS[10][c], wJI2_sum = sS[11][c];
+    const float JI_r0 = sS[12][c], JI_r1 = sS[13][c], Jab_r0 = sS[14][c], Jab_r1 = sS[15][c], rr_sum = sS[16][c];
+    const bool grp_oob = sS[17][c] != 0.f;
+
+    const float fxl = d.calib.fxl, fyl = d.calib.fyl, cxl = d.calib.cxl, cyl = d.calib.cyl;
+    const float fxli = d.calib.fxli, fyli = d.calib.fyli;
+    // ---- centre projection with the FEJ pose / idepth (FS/ResidualProjections.h:52-73)
+    const float KliP0 = (pu - cxl) * fxli;
+    const float KliP1 = (pv - cyl) * fyli;
+    const float ptp0 = R0[0] * KliP0 + R0[1] * KliP1 + R0[2] + t0[0] * idz;
+    const float ptp1 = R0[3] * KliP0 + R0[4] * KliP1 + R0[5] + t0[1] * idz;
+    const float ptp2 = R0[6] * KliP0 + R0[7] * KliP1 + R0[8] + t0[2] * idz;
+    const float drescale = 1.0f / ptp2;
+    const float new_idepth = idz * drescale;
+    const float cu = ptp0 * drescale, cv = ptp1 * drescale;
+    const float cKu = cu * fxl + cxl, cKv = cv * fyl + cyl;
+    const bool center_ok = (drescale > 0) && cKu > 1.1f && cKv > 1.1f && cKu < d.wM3G && cKv < d.hM3G;
+    // ---- geometric Jacobians (FS/Residuals.cpp:116-157)
+    const float d_d_x = drescale * (t0[0] - t0[2] * cu) * SOS_SCALE_IDEPTH * fxl;
+    const float d_d_y = drescale * (t0[1] - t0[2] * cv) * SOS_SCALE_IDEPTH * fyl;
+    float dCx2 = drescale * (R0[6] * cu - R0[0]);
+    float dCx3 = fxl * drescale * (R0[7] * cu - R0[1]) * fyli;
+    float dCx0 = KliP0 * dCx2;
+    float dCx1 = KliP1 * dCx3;
+    float dCy2 = fyl * drescale * (R0[6] * cv - R0[3]) * fxli;
+    float dCy3 = drescale * (R0[7] * cv - R0[4]);
+    float dCy0 = KliP0 * dCy2;
+    float dCy1 = KliP1 * dCy3;
+    dCx0 = (dCx0 + cu) * SOS_SCALE_F;
+    dCx1 *= SOS_SCALE_F;
+    dCx2 = (dCx2 + 1) * SOS_SCALE_C;
+    dCx3 *= SOS_SCALE_C;
+    dCy0 *= SOS_SCALE_F;
+    dCy1 = (dCy1 + cv) * SOS_SCALE_F;
+    dCy2 *= SOS_SCALE_C;
+    dCy3 = (dCy3 + 1) * SOS_SCALE_C;
+    const float dxi_x[6] = {new_idepth * fxl, 0.0f, -new_idepth * cu * fxl, -cu * cv * fxl, (1 + cu * cu) * fxl, -cv * fxl};
+    const float dxi_y[6] = {0.0f, new_idepth * fyl, -new_idepth * cv * fyl, -(1 + cv * cv) * fyl, cu * cv * fyl, cu * fyl};
+    if (!fuse_top) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        sJr[(JP_DXI0 + i) * SJ_STRIDE + rl_] = dxi_x[i];
+        sJr[(JP_DXI1 + i) * SJ_STRIDE + rl_] = dxi_y[i];
+      }
+      sJr[(JP_DC0 + 0) * SJ_STRIDE + rl_] = dCx0;
+      sJr[(JP_DC0 + 1) * SJ_STRIDE + rl_] = dCx1;
+      sJr[(JP_DC0 + 2) * SJ_STRIDE + rl_] = dCx2;
+      sJr[(JP_DC0 + 3) * SJ_STRIDE + rl_] = dCx3;
+      sJr[(JP_DC1 + 0) * SJ_STRIDE + rl_] = dCy0;
+      sJr[(JP_DC1 + 1) * SJ_STRIDE + rl_] = dCy1;
+      sJr[(JP_DC1 + 2) * SJ_STRIDE + rl_] = dCy2;
+      sJr[(JP_DC1 + 3) * SJ_STRIDE + rl_] = dCy3;
+      sJr[(JP_DD + 0) * SJ_STRIDE + rl_] = d_d_x;
+      sJr[(JP_DD + 1) * SJ_STRIDE + rl_] = d_d_y;
+      sJr[(JP_JIDX2 + 0) * SJ_STRIDE + rl_] = JIdxJIdx_00;
+      sJr[(JP_JIDX2 + 1) * SJ_STRIDE + rl_] = JIdxJIdx_10;
+      sJr[(JP_JIDX2 + 2) * SJ_STRIDE + rl_] = JIdxJIdx_11;
+      sJr[(JP_JABJIDX + 0) * SJ_STRIDE + rl_] = JabJIdx_00;
+      sJr[(JP_JABJIDX + 1) * SJ_STRIDE + rl_] = JabJIdx_01;
+      sJr[(JP_JABJIDX + 2) * SJ_STRIDE + rl_] = JabJIdx_10;
+      sJr[(JP_JABJIDX + 3) * SJ_STRIDE + rl_] = JabJIdx_11;
+      sJr[(JP_JAB2 + 0) * SJ_STRIDE + rl_] = JabJab_00;
+      sJr[(JP_JAB2 + 1) * SJ_STRIDE + rl_] = JabJab_01;
+      sJr[(JP_JAB2 + 2) * SJ_STRIDE + rl_] = JabJab_11;
+    }
+
+    // ---- classification (FS/Residuals.cpp:78-83,107-112,258-270)
+    int newState;
+    float newEnergy = 0.f, newEnergyWO = -1.f, ret;
+    if (!valid) {
+      newState = SOS_RES_OOB;
+      ret = 0.f;
+    } else if (isLin) {  // not in activeResiduals (FS/FullSystemOptimize.cpp:321)
+      newState = st;
+      ret = 0.f;
+      newEnergy = neOld2;
+      atomicOr(&sLin2[tl2], 1u << rl_);
+    } else if (st == SOS_RES_OOB || !center_ok || grp_oob) {
+      newState = SOS_RES_OOB;
+      ret = eOld2;
+      newEnergy = neOld2;
+    } else {
+      float energyLeft = energyLeft0;
+      newEnergyWO = energyLeft;
+      const float th = fmaxf(frameTH[hIdx], frameTH[tIdx]);
+      if (energyLeft > th || wJI2_sum < 2) {
+        energyLeft = th;
+        newState = SOS_RES_OUTLIER;
+      } else {
+        newState = SOS_RES_IN;
+      }
+      newEnergy = energyLeft;
+      ret = energyLeft;
+    }
+    const bool wr = doApply != 2;  // 2 = refresh: recompute the tile at the unchanged state and store nothing but J
+    if (wr) {
+      d.s_newstate[s] = (uint8_t)newState;
+      d.s_newenergy[s] = newEnergy;
+      d.s_newenergywo[s] = newEnergyWO;
+      d.s_ret[s] = ret;
+      if (d.o_newest && tIdx == d.n - 1) d.o_newest[s - d.newest_begin] = newEnergyWO;
+    }
+    bool activeAfter = (flags & DF_ACTIVE) != 0;
+    if (doApply == 1 && valid && !isLin && st != SOS_RES_OOB) {  // applyRes(true), FS/Residuals.cpp:304-321
+      activeAfter = newState == SOS_RES_IN;
+      d.s_flags[s] = (uint8_t)(activeAfter ? (flags | DF_ACTIVE) : (flags & ~DF_ACTIVE));
+      d.s_state[s] = (uint8_t)newState;
+      d.s_energy[s] = newEnergy;
+    }
+    const bool wrote_center = wr && valid && !isLin && st != SOS_RES_OOB && center_ok;
+    if (wrote_center) {
+      d.s_center[3 * s + 0] = cKu;
+      d.s_center[3 * s + 1] = cKv;
+      d.s_center[3 * s + 2] = new_idepth;
+    }
+    if (wr && valid && !isLin) {
+      // JpJdF of EFResidual::takeDataF (OB/EnergyFunctionalStructs.cpp:39-44)
+      const float v0 = JIdxJIdx_00 * d_d_x + JIdxJIdx_10 * d_d_y;
+      const float v1 = JIdxJIdx_10 * d_d_x + JIdxJIdx_11 * d_d_y;
+      float4 o0, o1;
+      o0.x = dxi_x[0] * v0 + dxi_y[0] * v1;
+      o0.y = dxi_x[1] * v0 + dxi_y[1] * v1;
+      o0.z = dxi_x[2] * v0 + dxi_y[2] * v1;
+      o0.w = dxi_x[3] * v0 + dxi_y[3] * v1;
+      o1.x = dxi_x[4] * v0 + dxi_y[4] * v1;
+      o1.y = dxi_x[5] * v0 + dxi_y[5] * v1;
+      o1.z = JabJIdx_00 * d_d_x + JabJIdx_01 * d_d_y;
+      o1.w = JabJIdx_10 * d_d_x + JabJIdx_11 * d_d_y;
+      // per-residual terms of Hdd_acc / bd_acc / Hcd_acc (OB/AccumulatedTopHessian.cpp:124-127), zero while inactive;
+      // without doApply they are provisional like JpJd: k_apply_res clears them if the residual does not end up IN
+      const bool termsLive = doApply ? activeAfter : (st != SOS_RES_OOB);
+      float4 p0, p1;
+      p0.x = v0 * d_d_x + v1 * d_d_y;
+      p0.y = JI_r0 * d_d_x + JI_r1 * d_d_y;
+      p0.z = dCx0 * v0 + dCy0 * v1;
+      p0.w = dCx1 * v0 + dCy1 * v1;
+      p1.x = dCx2 * v0 + dCy2 * v1;
+      p1.y = dCx3 * v0 + dCy3 * v1;
+      p1.z = 1.f;  // counts towards ngoodres
+      p1.w = 0.f;  // *_accAF sums
+      if (!termsLive) o0 = o1 = p0 = p1 = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 *jp = reinterpret_cast<float4 *>(d.JpJd + 8 * (size_t)s);
+      jp[0] = o0;
+      jp[1] = o1;
+      float4 *pt = reinterpret_cast<float4 *>(d.s_pterm + 8 * (size_t)s);
+      pt[0] = p0;
+      pt[1] = p1;
+    }
+    const int orig = d.s_orig[s];
+    if (wr && orig >= 0) {
+      if (d.o_newstate) d.o_newstate[orig] = (uint8_t)newState;
+      if (d.o_newenergy) d.o_newenergy[orig] = newEnergy;
+      if (d.o_newenergywo) d.o_newenergywo[orig] = newEnergyWO;
+      if (d.o_center && wrote_center) {
+        d.o_center[3 * orig + 0] = cKu;
+        d.o_center[3 * orig + 1] = cKv;
+        d.o_center[3 * orig + 2] = new_idepth;
+      }
+    }
+    if (d.tile_esum && wr) {  // returned energies of the tile: fp64 butterfly over its 32 residuals
+      double a = (double)ret;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+      if (rl_ == 0) d.tile_esum[tile2] = a;
+    }
+    if (fuse_top) {
+      // ---- AccumulatedTopHessianSSE::addPoint<0> over the tile, 24 of the 96 values at a time
+      TopIn in;
+      in.x[0] = dCx0; in.x[1] = dCx1; in.x[2] = dCx2; in.x[3] = dCx3;
+      in.y[0] = dCy0; in.y[1] = dCy1; in.y[2] = dCy2; in.y[3] = dCy3;
+#pragma unroll
+      for (int i = 0; i < 6; i++) { in.x[4 + i] = dxi_x[i]; in.y[4 + i] = dxi_y[i]; }
+      in.a = JIdxJIdx_00; in.b = JIdxJIdx_10; in.c = JIdxJIdx_11;
+      in.jab00 = JabJIdx_00; in.jab01 = JabJIdx_01; in.jab10 = JabJIdx_10; in.jab11 = JabJIdx_11;
+      in.ab00 = JabJab_00; in.ab01 = JabJab_01; in.ab11 = JabJab_11;
+      in.JI_r0 = JI_r0; in.JI_r1 = JI_r1; in.Jab_r0 = Jab_r0; in.Jab_r1 = Jab_r1; in.rr = rr_sum;
+      const bool use = valid && !isLin && activeAfter;
+      const int base3 = ((rl_ >> 4) & 1) * 12 + ((rl_ >> 3) & 1) * 6 + ((rl_ >> 2) & 1) * 3;
+      float *out = fuse_top + (size_t)tile2 * SOS_TOPN;
+      float v[24];
+#define TOP_PASS(Q)                                                                              \
+      top_values12<2 * (Q)>(in, v);                                                                \
+      top_values12<2 * (Q) + 1>(in, v + 12);                                                       \
+      _Pragma("unroll") for (int k = 0; k < 24; k++) v[k] = use ? v[k] : 0.f;                      \
+      bfly_step<12>(v, 16, (rl_ & 16) != 0);                                                       \
+      bfly_step<6>(v, 8, (rl_ & 8) != 0);                                                          \
+      bfly_step<3>(v, 4, (rl_ & 4) != 0);                                                          \
+      _Pragma("unroll") for (int k = 0; k < 3; k++) {                                              \
+        v[k] += __shfl_xor(v[k], 2, 64);                                                           \
+        v[k] += __shfl_xor(v[k], 1, 64);                                                           \
+      }                                                                                            \
+      if ((rl_ & 3) == 0) { out[24 * (Q) + base3] = v[0]; out[24 * (Q) + base3 + 1] = v[1]; out[24 * (Q) + base3 + 2] = v[2]; }
+      TOP_PASS(0)
+      TOP_PASS(1)
+      TOP_PASS(2)
+      TOP_PASS(3)
+#undef TOP_PASS
+    }
+  }
+  if (fuse_top) return;  // the tiles stay on chip
+  __syncthreads();
+
+  // =============================== phase 3: coalesced store of the staged tiles ===============================
+  if (tile_ok) {
+    float *Jt = d.J + (size_t)tile * SOS_TILE_FLOATS;
+    const unsigned linmask = sLin2[tloc];
+    for (int q = t256; q < SOS_JPLANES * 8; q += 256) {
+      const int plane = q >> 3, chunk = q & 7;
+      const float4 v = *reinterpret_cast<const float4 *>(&sJ[plane * SJ_STRIDE + 4 * chunk]);
+      float *dst = Jt + plane * SOS_TILE + 4 * chunk;
+      const unsigned lm = (linmask >> (4 * chunk)) & 0xfu;
+      if (lm == 0) {
+        *reinterpret_cast<float4 *>(dst) = v;
+      } else {  // keep the frozen Jacobian of linearized residuals sharing this tile (rare)
+        if (!(lm & 1u)) dst[0] = v.x;
+        if (!(lm & 2u)) dst[1] = v.y;
+        if (!(lm & 4u)) dst[2] = v.z;
+        if (!(lm & 8u)) dst[3] = v.w;
+      }
+    }
+  }
+}
+
 // sum of the returned energies in double, fixed order: deterministic
 __global__ __launch_bounds__(1024) void k_sum_ret(const float *__restrict__ ret, int n, double *out) {
   __shared__ double sm[1024];
@@ -2049,8 +2430,19 @@ static int stage_in(sos_ba *ba, size_t nfloats) {
   return SOS_OK;
 }
 
+// SOS_LINEARIZE_V1=1 selects the original one-tile-per-block kernel (kept for A/B measurements and as the reference
+// the restructured kernel is checked against bit for bit)
+static bool lin_v1() {
+  static const bool v = getenv("SOS_LINEARIZE_V1") != nullptr;
+  return v;
+}
+static void launch_lin_kernel(sos_ba *ba, const BaDev &dv, int mode, float *fuse_top) {
+  if (ba->ntilesA <= 0) return;
+  if (lin_v1()) k_linearize<<<ba->ntilesA, 256, 0, ba->ctx->stream>>>(dv, stg(ba, ba->st_th), mode, fuse_top);
+  else k_linearize2<<<divup(ba->ntilesA, L2_TILES), 256 * L2_TILES, 0, ba->ctx->stream>>>(dv, stg(ba, ba->st_th), mode, fuse_top);
+}
 static int launch_linearize(sos_ba *ba, int doApply) {
-  if (ba->ntilesA > 0) k_linearize<<<ba->ntilesA, 256, 0, ba->ctx->stream>>>(ba->dev, stg(ba, ba->st_th), doApply, nullptr);
+  launch_lin_kernel(ba, ba->dev, doApply, nullptr);
   return SOS_OK;
 }
 
@@ -2058,7 +2450,7 @@ static int launch_linearize(sos_ba *ba, int doApply) {
 // Jacobians first recomputes them at the unchanged linearisation state (identical values, nothing else is written)
 static int ensure_J(sos_ba *ba) {
   if (ba->J_valid) return SOS_OK;
-  if (ba->ntilesA > 0) k_linearize<<<ba->ntilesA, 256, 0, ba->ctx->stream>>>(ba->dev, stg(ba, ba->st_th), 2, nullptr);
+  launch_lin_kernel(ba, ba->dev, 2, nullptr);
   ba->J_valid = true;
   return SOS_OK;
 }
@@ -2418,8 +2810,7 @@ extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const
   }
   // pipelined iterations of a window without linearised residuals reduce the tiles on chip (no J traffic at all)
   const bool fuseTop = ba->prefetch && applyRes && ba->ntiles == ba->ntilesA;
-  if (ba->ntilesA > 0)
-    k_linearize<<<ba->ntilesA, 256, 0, st>>>(dv, stg(ba, ba->st_th), applyRes ? 1 : 0, fuseTop ? ba->d_top_part.p : nullptr);
+  launch_lin_kernel(ba, dv, applyRes ? 1 : 0, fuseTop ? ba->d_top_part.p : nullptr);
   ba->J_valid = !fuseTop;
   SOS_HIP(hipGetLastError());
   const double t2 = now_s();
@@ -2636,7 +3027,7 @@ extern "C" int sos_ba_time_kernel(sos_ba *ba, const char *kernel, const float *f
     if (k == "linearize") return launch_linearize(ba, 0);
     if (k == "linearize_apply") return launch_linearize(ba, 1);
     if (k == "linearize_fused") {  // what the pipelined iterations run: linearize + applyRes + tile block sums, no J store
-      if (ba->ntilesA > 0) k_linearize<<<ba->ntilesA, 256, 0, st>>>(ba->dev, stg(ba, ba->st_th), 1, ba->d_top_part.p);
+      launch_lin_kernel(ba, ba->dev, 1, ba->d_top_part.p);
       ba->J_valid = false;
       return SOS_OK;
     }
