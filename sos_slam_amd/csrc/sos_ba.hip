@@ -1191,18 +1191,25 @@ __device__ __forceinline__ PrepOut point_prep_body(const BaDev &d, int shiftPrio
   float HddA = 0, bdA = 0, HcdA[4] = {0, 0, 0, 0}, HddL = 0, bdL = 0, HcdL[4] = {0, 0, 0, 0};
   float ngood = 0;
   const int q0 = d.p_begin[p], q1 = d.p_begin[p + 1];
-  for (int q = q0; q < q1; q += 4) {
-    float4 a[4], b[4];
+  // residual list, point record and the per-residual terms are requested level by level for ALL residuals of the
+  // point at once (groups of PU): the sums below stay in residualsAll order, only the memory latencies overlap
+  constexpr int PU = 8;
+  const sos_point *ptp = d.pts + p;
+  const float priorF = ptp->priorF, deltaF = ptp->deltaF;
+  const float stepOld = d.p_out[16 * (size_t)p + PO_STEP];
+  for (int q = q0; q < q1; q += PU) {
+    int sidx[PU];
+    float4 a[PU], b[PU];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int qq = min(q + k, q1 - 1);
-      const int s = d.p_list2[qq].x;
-      const float4 *pt = reinterpret_cast<const float4 *>(d.s_pterm + 8 * (size_t)s);
+    for (int k = 0; k < PU; k++) sidx[k] = d.p_list2[min(q + k, q1 - 1)].x;
+#pragma unroll
+    for (int k = 0; k < PU; k++) {
+      const float4 *pt = reinterpret_cast<const float4 *>(d.s_pterm + 8 * (size_t)sidx[k]);
       a[k] = pt[0];
       b[k] = pt[1];
     }
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < PU; k++) {
       if (q + k >= q1) break;
       if (b[k].z == 0.f) continue;  // not active
       ngood += 1.f;
@@ -1220,17 +1227,16 @@ __device__ __forceinline__ PrepOut point_prep_body(const BaDev &d, int shiftPrio
   o0.x = HddA; o0.y = bdA; o0.z = HcdA[0]; o0.w = HcdA[1];
   o1.x = HcdA[2]; o1.y = HcdA[3]; o1.z = HddL; o1.w = bdL;
   o2.x = HcdL[0]; o2.y = HcdL[1]; o2.z = HcdL[2]; o2.w = HcdL[3];
-  o3.w = o[PO_STEP];
+  o3.w = stepOld;
   if (ngood == 0.f) {  // OB/AccumulatedSCHessian.cpp:34-44
     o3.x = 0; o3.y = 0; o3.z = 0;
   } else {
-    const sos_point *pt = d.pts + p;
-    float H = HddA + HddL + pt->priorF;
+    float H = HddA + HddL + priorF;
     if (H < 1e-10) H = 1e-10;
     o3.z = H;
     o3.x = (float)(1.0 / (double)H);
     float bdSum = bdA + bdL;
-    if (shiftPriorToZero) bdSum += pt->priorF * pt->deltaF;
+    if (shiftPriorToZero) bdSum += priorF * deltaF;
     o3.y = bdSum;
   }
   float4 *ov = reinterpret_cast<float4 *>(o);
