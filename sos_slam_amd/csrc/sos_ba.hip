@@ -114,6 +114,32 @@ __device__ __forceinline__ float seqsum8(float v) {
 #define SJ_STRIDE 40  // LDS row stride (floats): == 8 mod 32 -> the 8x8 (pixel, residual) stores are 2-way at worst
 
 // ------------------------------------------------------------------------------------------------
+// Completion signal of a kernel to the host without a stream marker: every block, after its last host-visible
+// store, fences at system scope and bumps a device counter; the block that completes the launch (the counter is
+// cumulative: target = launches so far x blocks) stores the launch sequence number into a flag in device-mapped
+// pinned host memory.  The host polls that flag instead of waiting on an event / the stream, which removes the
+// marker packet (~6 us of bubble in front of the next kernel) and the runtime's wake-up latency.
+// ------------------------------------------------------------------------------------------------
+// k_publish: the one-thread kernel variant of the same idea -- queued behind the producing kernel, it starts only
+// after that kernel's end-of-kernel release, so its store of the sequence number tells the polling host that the
+// producer's results are visible (no per-block fences inside the producer).
+__global__ void k_publish(int *flag, int seq) { __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+struct DoneSignal {
+  int *ctr;    // device counter (nullptr = no signalling)
+  int *flag;   // device address of the mapped host flag
+  int target;  // counter value that completes this launch
+  int seq;     // value to publish
+};
+__device__ __forceinline__ void signal_block_done(const DoneSignal &sg) {  // call from ONE thread of the block
+  __threadfence_system();
+  const int old = atomicAdd(sg.ctr, 1);
+  if (old == sg.target - 1) {
+    __threadfence_system();
+    __hip_atomic_store(sg.flag, sg.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // The 96 per-residual values of AccumulatedTopHessianSSE::addPoint (OB/AccumulatedTopHessian.cpp:112-122 ->
 // AccumulatorApprox::update / updateTopRight / updateBotRight, OB/MatrixAccumulators.h:928-1112) in the order of
 // the packed 13x13 block: 55 uniques of the 10x10 [C xi] block, 30 top-right entries, 6 bottom-right, the
@@ -541,7 +567,7 @@ __device__ __forceinline__ void bfly_step(float *v, int m, bool hi);
 #define L2_TILES 2
 #define L2_NS 18  // 17 sums + group-out-of-bounds flag
 __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(BaDev d, const float *__restrict__ frameTH, int doApply,
-                                                               float *__restrict__ fuse_top) {
+                                                               float *__restrict__ fuse_top, DoneSignal sg) {
   __shared__ float sJ2[L2_TILES][SOS_JPLANES * SJ_STRIDE];
   __shared__ float sS[L2_NS][32 * L2_TILES];
   __shared__ unsigned int sLin2[L2_TILES];
@@ -878,6 +904,8 @@ __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(BaDev d, const
 #undef TOP_PASS
     }
   }
+  // everything the host reads (tile energies, newest-frame energies) was stored by the phase-2 wave
+  if (sg.ctr && wave == w2 && lane == 0) signal_block_done(sg);
   if (fuse_top) return;  // the tiles stay on chip
   __syncthreads();
 
@@ -1623,6 +1651,7 @@ struct StitchArgs {
   float *nres_out;
   size_t mode_stride;
   int upperOnly;  // write only the block-upper triangle (+ calib rows): all the host solve reads
+  DoneSignal sg;  // stage 2 -> host
 };
 __global__ __launch_bounds__(64) void k_stitch_stage1(StitchArgs a) {
   const int per = a.n * a.n + 20, ntop = per * a.nmodes;
@@ -1633,6 +1662,10 @@ __global__ __launch_bounds__(64) void k_stitch_stage2(StitchArgs a) {
   const int per = a.n * (a.n + 1) / 2 + 1, ntop = per * a.nmodes;
   if ((int)blockIdx.x < ntop) stitch_top_sum_body(blockIdx.x % per, blockIdx.x / per, a.n, a.Ccc, a.Ctop, a.H, a.mode_stride, a.upperOnly != 0);
   else sc_sum_body(blockIdx.x - ntop, 0, a.n, a.Csc, a.Ce, a.accHcc, a.accbc, a.H + 2 * a.mode_stride, a.nres, a.nres_out, a.upperOnly != 0);
+  if (a.sg.ctr) {
+    __syncthreads();  // all stores of the block issued
+    if (threadIdx.x == 0) signal_block_done(a.sg);
+  }
 }
 
 // ================================================================================================
@@ -2016,10 +2049,12 @@ struct sos_ba {
   int newest_begin = 0, newest_count = 0;
   char *pin = nullptr;     // pinned + device-mapped host block: [stage | outpack | Hb]; the fused per-iteration
   char *pin_dev = nullptr; // calls let kernels read / write it directly (no copy commands on the critical path)
-  size_t pin_bytes = 0, pin_stage = 0, pin_out = 0, pin_hb = 0;
+  size_t pin_bytes = 0, pin_stage = 0, pin_out = 0, pin_hb = 0, pin_flags = 0;  // flags: 2 ints, 64 B apart
   bool prefetch = false;      // sos_ba_set_prefetch: gn_step enqueues the next gn_accumulate behind the linearisation
   bool acc_inflight = false;  // ... and this says its result is (or will be) in the mapped Hb block
   bool acc_inflight_haveL = false;
+  DevBuf<int> d_sigctr;       // [0] linearize launches, [1] stitch launches (cumulative block counters)
+  int sig_lin_blocks = 0, sig_lin_seq = 0, sig_st_seq = 0, sig_st_blocks_total = 0;
   bool J_valid = true;        // false after a pipelined sos_ba_gn_step: the tiles were consumed on chip, d_J is stale
   hipEvent_t ev_step = nullptr;
   size_t hb_mode_stride = 0;  // doubles per (H | b) block in d_Hout
@@ -2067,7 +2102,7 @@ extern "C" int sos_ba_destroy(sos_ba *ba) {
   hipStreamSynchronize(ba->ctx->stream);
   ba->d_pts.release();
   for (DevBuf<int> *b : {&ba->d_s_point, &ba->d_s_orig, &ba->d_t_pair, &ba->d_p_begin, &ba->d_p_list, &ba->d_p_res_t,
-                         &ba->d_pair_tile_begin, &ba->d_chunk_pt, &ba->d_host_chunk_begin, &ba->d_tmp_int})
+                         &ba->d_pair_tile_begin, &ba->d_chunk_pt, &ba->d_host_chunk_begin, &ba->d_tmp_int, &ba->d_sigctr})
     b->release();
   for (DevBuf<uint8_t> *b : {&ba->d_s_flags, &ba->d_s_state, &ba->d_s_newstate, &ba->d_o_newstate}) b->release();
   for (DevBuf<float> *b :
@@ -2281,7 +2316,7 @@ extern "C" int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, i
   ENSURE(ba->d_outpack, ba->out_bytes);
   {
     const size_t need_stage = sizeof(float) * ba->st_floats, need_out = ba->out_bytes,
-                 need_hb = sizeof(double) * 3 * ba->hb_mode_stride + 16;
+                 need_hb = sizeof(double) * 3 * ba->hb_mode_stride + 16 + 128;  // + completion flags
     const size_t tot = need_stage + need_out + need_hb + 256;
     if (tot > ba->pin_bytes) {
       if (ba->pin) hipHostFree(ba->pin);
@@ -2294,7 +2329,13 @@ extern "C" int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, i
     ba->pin_stage = 0;
     ba->pin_out = (need_stage + 63) / 64 * 64;
     ba->pin_hb = ba->pin_out + (need_out + 63) / 64 * 64;
+    ba->pin_flags = ba->pin_hb + (sizeof(double) * 3 * ba->hb_mode_stride + 16 + 63) / 64 * 64;
+    memset(ba->pin + ba->pin_flags, 0, 128);
   }
+  ENSURE(ba->d_sigctr, 32);
+  SOS_HIP(hipMemsetAsync(ba->d_sigctr.p, 0, sizeof(int) * 32, st));
+  ba->sig_lin_seq = ba->sig_st_seq = 0;
+  ba->sig_lin_blocks = ba->sig_st_blocks_total = 0;
   SOS_HIP(hipMemsetAsync(ba->d_s_newstate.p, SOS_RES_OOB, Rp, st));
   SOS_HIP(hipMemsetAsync(ba->d_s_newenergy.p, 0, sizeof(float) * Rp, st));
   SOS_HIP(hipMemsetAsync(ba->d_s_newenergywo.p, 0, sizeof(float) * Rp, st));
@@ -2442,10 +2483,45 @@ static bool lin_v1() {
   static const bool v = getenv("SOS_LINEARIZE_V1") != nullptr;
   return v;
 }
-static void launch_lin_kernel(sos_ba *ba, const BaDev &dv, int mode, float *fuse_top) {
-  if (ba->ntilesA <= 0) return;
-  if (lin_v1()) k_linearize<<<ba->ntilesA, 256, 0, ba->ctx->stream>>>(dv, stg(ba, ba->st_th), mode, fuse_top);
-  else k_linearize2<<<divup(ba->ntilesA, L2_TILES), 256 * L2_TILES, 0, ba->ctx->stream>>>(dv, stg(ba, ba->st_th), mode, fuse_top);
+// host side of DoneSignal: poll the mapped flag; after 50 ms fall back to a stream synchronisation (a failed launch
+// must not hang the caller)
+static int wait_flag(sos_ba *ba, size_t flag_off, int seq) {
+  int *flag = reinterpret_cast<int *>(ba->pin + flag_off);
+  const double t0 = now_s();
+  unsigned spins = 0;
+  while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) < seq) {
+    __builtin_ia32_pause();
+    if ((++spins & 4095u) == 0 && now_s() - t0 > 0.05) {
+      SOS_HIP(hipStreamSynchronize(ba->ctx->stream));
+      return __atomic_load_n(flag, __ATOMIC_ACQUIRE) >= seq ? SOS_OK : SOS_ERR_HIP;
+    }
+  }
+  return SOS_OK;
+}
+// returns the sequence number to wait for (0 = this launch does not signal)
+static int launch_lin_kernel(sos_ba *ba, const BaDev &dv, int mode, float *fuse_top, bool signal = false) {
+  if (ba->ntilesA <= 0) return 0;
+  if (lin_v1()) {
+    k_linearize<<<ba->ntilesA, 256, 0, ba->ctx->stream>>>(dv, stg(ba, ba->st_th), mode, fuse_top);
+    return 0;
+  }
+  const int nb = divup(ba->ntilesA, L2_TILES);
+  DoneSignal sg = {nullptr, nullptr, 0, 0};
+  static const bool inKernel = getenv("SOS_SIGNAL_IN_KERNEL") != nullptr;  // per-block fences: measured slower
+  int seq = 0;
+  if (signal) {
+    seq = ++ba->sig_lin_seq;
+    if (inKernel) {
+      ba->sig_lin_blocks += nb;
+      sg.ctr = ba->d_sigctr.p;
+      sg.flag = reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags);
+      sg.target = ba->sig_lin_blocks;
+      sg.seq = seq;
+    }
+  }
+  k_linearize2<<<nb, 256 * L2_TILES, 0, ba->ctx->stream>>>(dv, stg(ba, ba->st_th), mode, fuse_top, sg);
+  if (signal && !inKernel) k_publish<<<1, 1, 0, ba->ctx->stream>>>(reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags), seq);
+  return seq;
 }
 static int launch_linearize(sos_ba *ba, int doApply) {
   launch_lin_kernel(ba, ba->dev, doApply, nullptr);
@@ -2589,8 +2665,22 @@ static int launch_stitch(sos_ba *ba, const float *acc, int nmodes, double *Hout 
   a.nres_out = Hout ? reinterpret_cast<float *>(Hout + 3 * ba->hb_mode_stride) : nullptr;
   a.mode_stride = ba->hb_mode_stride;
   a.upperOnly = Hout ? 1 : 0;
+  a.sg = {nullptr, nullptr, 0, 0};
+  const int nb2 = (n * (n + 1) / 2 + 1) * nmodes + n * n + 1;
+  static const bool inKernel = getenv("SOS_SIGNAL_IN_KERNEL") != nullptr;
+  if (Hout) {  // the fused path: the host polls for the end of stage 2
+    ++ba->sig_st_seq;
+    if (inKernel) {
+      ba->sig_st_blocks_total += nb2;
+      a.sg.ctr = ba->d_sigctr.p + 16;
+      a.sg.flag = reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags + 64);
+      a.sg.target = ba->sig_st_blocks_total;
+      a.sg.seq = ba->sig_st_seq;
+    }
+  }
   k_stitch_stage1<<<(n * n + 20) * nmodes + n * n * n, 64, 0, st>>>(a);
-  k_stitch_stage2<<<(n * (n + 1) / 2 + 1) * nmodes + n * n + 1, 64, 0, st>>>(a);
+  k_stitch_stage2<<<nb2, 64, 0, st>>>(a);
+  if (Hout && !inKernel) k_publish<<<1, 1, 0, st>>>(reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags + 64), ba->sig_st_seq);
   return SOS_OK;
 }
 
@@ -2690,7 +2780,10 @@ extern "C" int sos_ba_gn_accumulate(sos_ba *ba, double *H_top, double *b_top, do
   ba->acc_inflight = false;
   const bool haveL = ba->acc_inflight_haveL;
   const double ta = now_s();
-  SOS_HIP(hipStreamSynchronize(st));
+  {
+    const int rcw = wait_flag(ba, ba->pin_flags + 64, ba->sig_st_seq);
+    if (rcw) return rcw;
+  }
   ba->tm[6] += now_s() - ta;
   const size_t dim = 4 + 8 * (size_t)ba->n, ms = ba->hb_mode_stride;
   const double *ph = reinterpret_cast<const double *>(ba->pin + ba->pin_hb);
@@ -2816,18 +2909,26 @@ extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const
   }
   // pipelined iterations of a window without linearised residuals reduce the tiles on chip (no J traffic at all)
   const bool fuseTop = ba->prefetch && applyRes && ba->ntiles == ba->ntilesA;
-  launch_lin_kernel(ba, dv, applyRes ? 1 : 0, fuseTop ? ba->d_top_part.p : nullptr);
+  const int waitSeq = launch_lin_kernel(ba, dv, applyRes ? 1 : 0, fuseTop ? ba->d_top_part.p : nullptr, true);
   ba->J_valid = !fuseTop;
   SOS_HIP(hipGetLastError());
   const double t2 = now_s();
   double t3 = t2;
   if (ba->prefetch && applyRes) {  // the next iteration's accumulate + stitch runs while the host digests this step
-    SOS_HIP(hipEventRecord(ba->ev_step, st));
+    if (!waitSeq) SOS_HIP(hipEventRecord(ba->ev_step, st));
     enqueue_gn_accumulate(ba, fuseTop);
     SOS_HIP(hipGetLastError());
     ba->acc_inflight = true;
     t3 = now_s();
-    SOS_HIP(hipEventSynchronize(ba->ev_step));
+    if (waitSeq) {
+      const int rcw = wait_flag(ba, ba->pin_flags, waitSeq);
+      if (rcw) return rcw;
+    } else {
+      SOS_HIP(hipEventSynchronize(ba->ev_step));
+    }
+  } else if (waitSeq) {
+    const int rcw = wait_flag(ba, ba->pin_flags, waitSeq);
+    if (rcw) return rcw;
   } else {
     SOS_HIP(hipStreamSynchronize(st));
   }
