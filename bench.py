@@ -11,8 +11,9 @@ point-residuals linearised per second through whole iterations, summed over all 
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   one rank per GPU (RCCL)
 
 Multi-GPU (weak scaling): every rank holds the same 12 keyframes and its own shard of 4096
-points; the packed fp32 H/b accumulators are all-reduced over RCCL once per iteration, every rank then runs
-the identical fp64 stitch + solve.  The timed region is bracketed by barrier + torch.cuda.synchronize and
+points; the packed fp32 H/b accumulators are all-reduced over RCCL once per iteration (by the library itself, on
+its stream, inside the prefetched accumulate chain: sos_ba_set_comm), every rank then runs the identical fp64
+stitch + solve.  The timed region is bracketed by barrier + torch.cuda.synchronize and
 the MAX over ranks is reported.
 """
 from __future__ import annotations
@@ -87,9 +88,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_dist = world == 1 and os.environ.get("SOS_BENCH_FORCE_DIST") == "1"  # exercise the exchange path on one GPU
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     from sos_slam_amd import host, lib, synth
@@ -98,8 +101,13 @@ def main():
     # every rank: same frames / images (seed), its own point shard (point_seed)
     win = synth.make_window(args.window, point_seed=synth.SEED + 1000 * rank if world > 1 else None)
     sysm = host.System.from_window(win, device=local_rank)
-    if world > 1:
-        sdist.attach(sysm, dist, torch)
+    comm = None
+    if dist is not None:
+        if os.environ.get("SOS_BENCH_HOOKS") == "1":  # callback-based exchange through torch.distributed (slower)
+            sdist.attach(sysm, dist, torch)
+        else:  # RCCL collectives enqueued by the library itself on its stream
+            comm = sdist.NativeComm(dist, torch, local_rank)
+            comm.attach(sysm)
     sysm.prepare()
     sysm.set_pipeline(True)  # the loop below never stops on `canbreak`: every step may prefetch the next accumulate
     R_local = win.R
@@ -158,7 +166,11 @@ def main():
                                    f"{R_local} point-residuals per GPU; step = one Gauss-Newton iteration "
                                    "(accumulate A/L/SC, fp64 stitch, solve, back-substitute, step, re-linearise, "
                                    "applyRes)", "window": args.window, "keyframes": win.n, "points_per_gpu": win.P,
-                       "residuals_per_gpu": R_local, "residuals_total": R_total},
+                       "residuals_per_gpu": R_local, "residuals_total": R_total,
+                       "parallelism": ("single GPU" if dist is None else
+                                       f"{world} ranks, points sharded, frames replicated; one RCCL all-reduce of the "
+                                       "packed fp32 accumulator + one all-gather of newest-frame energies per "
+                                       "iteration, enqueued by the library on its stream")},
             "gn_iter_per_s": args.steps / dt,
             "linearize_point_residuals_per_s": R_local / (lin_ms * 1e-3),
             "kernels_us": dict(linearize_us=round(lin_ms * 1e3, 2), **kern),
@@ -175,6 +187,8 @@ def main():
                                                "achieved": R_local * LINEARIZE_BYTES_PER_RESIDUAL / (lin_ms * 1e-3) / 1e9,
                                                "frac": R_local * LINEARIZE_BYTES_PER_RESIDUAL / (lin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
         }
+    if comm is not None:
+        comm.close()
     sysm.close()
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:

@@ -146,6 +146,7 @@ typedef struct sos_rawjac {
 typedef struct sos_ctx sos_ctx;          /* device + stream + frame (image pyramid) store */
 typedef struct sos_ba sos_ba;            /* device backend of one EnergyFunctional */
 typedef struct sos_tracker sos_tracker;  /* device side of one CoarseTracker / ScaleOptimizer */
+typedef struct sos_comm sos_comm;        /* RCCL communicator of the multi-GPU path (one process per GPU) */
 
 /* ------------------------------------------------------------------------------------------------
  * context and frame store
@@ -264,6 +265,28 @@ int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const sos_calib 
  * state-changing call in between discards the prefetched result.  Leave it off for the last iteration of a loop:
  * the per-point results (sos_ba_get_point_hessian) always belong to the latest accumulate that ran. */
 int sos_ba_set_prefetch(sos_ba *ba, int on);
+
+/* ---- multi-GPU exchange; the reference has no counterpart: it is a single-process CPU backend ----
+ * One process per GPU, every rank the same keyframes and its own shard of the points.  librccl is bound at run
+ * time: sos_rccl_load(path) (NULL = "librccl.so" from the loader path; pass the copy the host process already uses).
+ * Rank 0 obtains a 128-byte id (sos_rccl_unique_id), distributes it by any means, every rank calls sos_comm_create.
+ * sos_ba_set_comm attaches the communicator to a backend: from then on the fused calls sum the packed fp32
+ * accumulator blocks over all ranks (ONE all-reduce per Gauss-Newton iteration, enqueued on the library's stream
+ * between the local accumulation and the stitch) and sos_ba_gn_step returns the newest-frame energies of ALL ranks
+ * (one all-gather), so every rank derives the same frameEnergyTH and solves the same system.  All ranks must issue
+ * the same sequence of fused calls.  comm == NULL detaches. */
+int sos_rccl_load(const char *librccl_path);
+int sos_rccl_unique_id(void *id128);
+int sos_comm_create(const void *id128, int nranks, int rank, int device, sos_comm **out);
+int sos_comm_destroy(sos_comm *comm);
+int sos_comm_size(const sos_comm *comm);
+int sos_comm_rank(const sos_comm *comm);
+int sos_ba_set_comm(sos_ba *ba, sos_comm *comm);
+/* number of floats sos_ba_gn_step may write to `newestEnergies` (all ranks' lists when a communicator is attached) */
+int sos_ba_newest_capacity(sos_ba *ba, int *count);
+/* all-gather of newest-frame energies for callers outside the fused calls (final linearizeAll(true)): `all` needs
+ * sos_ba_newest_capacity floats; without a communicator it copies the local list */
+int sos_ba_gather_energies(sos_ba *ba, const float *local, int count, float *all, int *total);
 
 /* per-point results of the accumulation: idepth_hessian (OB/AccumulatedSCHessian.cpp:50),
  * HdiF, bdSumF.  Each P floats, may be NULL. */

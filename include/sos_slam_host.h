@@ -94,6 +94,9 @@ int sosf_marginalize_frame(sosf_system *sys, int frameIdx);
 typedef void (*sosf_allreduce_fn)(void *user, float *dev_ptr, size_t nfloats);
 typedef float (*sosf_nth_fn)(void *user, const float *energies, int count, float frac);
 int sosf_set_hooks(sosf_system *sys, sosf_allreduce_fn allreduce, sosf_nth_fn nth, void *user);
+/* Native exchange: attach an RCCL communicator (sos_comm_create) to the system's backend; the all-reduce / all-gather
+ * then run on the library's stream inside the fused calls (no callbacks, pipelining stays on).  NULL detaches. */
+int sosf_set_comm(sosf_system *sys, sos_comm *comm);
 
 /* ---- CoarseTracker / ScaleOptimizer (FS/CoarseTracker.h:27-48, FS/ScaleOptimizer.h:43-104) -------------
  * The LM loops run on the host (8x8 fp64 / scalar solves, SE3 updates), the per-pixel work on the device. */

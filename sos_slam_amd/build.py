@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(HERE, "..", "include")
 
-HIP_SOURCES = ["sos_ctx.hip", "sos_ba.hip", "sos_tracker.hip"]
+HIP_SOURCES = ["sos_ctx.hip", "sos_ba.hip", "sos_tracker.hip", "sos_comm.hip"]
 HIP_LIB = os.path.join(CSRC, "libsos_slam_hip.so")
 HOST_SOURCES = ["host/sos_host.cpp"]
 HOST_LIB = os.path.join(CSRC, "libsos_host.so")
@@ -45,7 +45,7 @@ def build_hip(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
     if force or _stale(HIP_LIB, srcs):
         extra = os.environ.get("SOS_HIPCC_EXTRA", "").split()  # experiment knob, e.g. -DSOS_LIN_WAVES=5
-        cmd = [hipcc_path()] + HIPCC_FLAGS + extra + ["-o", HIP_LIB] + srcs
+        cmd = [hipcc_path()] + HIPCC_FLAGS + extra + ["-o", HIP_LIB] + srcs + ["-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -735,6 +735,15 @@ void FullSystem::setNewFrameEnergyTH() {  // FS/FullSystemOptimize.cpp:84-124
     const float e = h_newEnergyWO[r->packIdx];
     if (e >= 0 && r->target == newFrame) allResVec.push_back(e);
   }
+  if (comm) {  // multi-GPU: the statistic is taken over the residuals of all ranks
+    int cap = 0, tot = 0;
+    sos_ba_newest_capacity(ef->ba, &cap);
+    std::vector<float> all((size_t)cap + 1);
+    if (sos_ba_gather_energies(ef->ba, allResVec.data(), (int)allResVec.size(), all.data(), &tot) == SOS_OK) {
+      all.resize(tot);
+      allResVec.swap(all);
+    }
+  }
   setNewFrameEnergyTH(allResVec);
 }
 
@@ -927,7 +936,11 @@ bool FullSystem::gnIteration(int iteration, bool mayContinue) {  // :358-413 wit
     std::vector<float> th(n);
     for (int i = 0; i < n; i++) th[i] = frameHessians[i]->frameEnergyTH;
     const sos_calib cal = HCalib.toCalib();
-    newestE.resize(ef->allResiduals.size() + 1);
+    {
+      int cap = 0;
+      sos_ba_newest_capacity(ef->ba, &cap);
+      newestE.resize((size_t)cap + 1);
+    }
     int cnt = 0;
     double E = 0;
     ef->pointStep.resize(ef->allPoints.size());
@@ -1452,6 +1465,11 @@ extern "C" int sosf_set_pipeline(sosf_system *s, int on) {
   s->fs->pipelineAlways = on != 0;
   if (!on) sos_ba_set_prefetch(s->fs->ef->ba, 0);
   return SOS_OK;
+}
+extern "C" int sosf_set_comm(sosf_system *s, sos_comm *comm) {
+  if (!s) return SOS_ERR_ARG;
+  s->fs->comm = comm;
+  return sos_ba_set_comm(s->fs->ef->ba, comm);
 }
 extern "C" int sosf_counts(sosf_system *s, int *nF, int *nP, int *nR) {
   if (!s) return SOS_ERR_ARG;

@@ -232,6 +232,7 @@ class FullSystem {
   float optimize(int mnumOptIts, int *iterations);            // FS/FullSystemOptimize.cpp:305-489
   int prepare();                                              // :316-344
   bool gnIteration(int iteration, bool mayContinue = false);  // :358-413
+  sos_comm *comm = nullptr;     // RCCL communicator attached to the backend (multi-GPU), not owned
   bool pipelineAlways = false;  // flat API: the caller iterates regardless of canbreak
   void setPrecalcValues(bool points = true);                  // FS/FullSystem.cpp:1099-1107
   void removeOutliers();                                      // FS/FullSystemOptimize.cpp:507-526

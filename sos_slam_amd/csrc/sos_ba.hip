@@ -2055,6 +2055,14 @@ struct sos_ba {
   bool acc_inflight_haveL = false;
   DevBuf<int> d_sigctr;       // [0] linearize launches, [1] stitch launches (cumulative block counters)
   int sig_lin_blocks = 0, sig_lin_seq = 0, sig_st_seq = 0, sig_st_blocks_total = 0;
+  // multi-GPU (sos_ba_set_comm): common capacity of the newest-frame energy lists, local / gathered device lists and
+  // the device-mapped host copy of the gathered list
+  sos_comm *comm = nullptr;
+  int comm_size = 1, newest_cap = 0;
+  bool anyL = false;  // some rank holds linearised residuals
+  DevBuf<float> d_newest_local, d_newest_all;
+  float *pin_newest = nullptr, *pin_newest_dev = nullptr;
+  size_t pin_newest_floats = 0;
   bool J_valid = true;        // false after a pipelined sos_ba_gn_step: the tiles were consumed on chip, d_J is stale
   hipEvent_t ev_step = nullptr;
   size_t hb_mode_stride = 0;  // doubles per (H | b) block in d_Hout
@@ -2116,6 +2124,8 @@ extern "C" int sos_ba_destroy(sos_ba *ba) {
   ba->d_p_list2.release(); ba->d_r_geo.release(); ba->d_r_cw.release(); ba->d_stage.release(); ba->d_outpack.release(); ba->d_C.release();
   if (ba->pin) hipHostFree(ba->pin);
   if (ba->ev_step) hipEventDestroy(ba->ev_step);
+  if (ba->pin_newest) hipHostFree(ba->pin_newest);
+  ba->d_newest_local.release(); ba->d_newest_all.release();
   delete ba;
   return SOS_OK;
 }
@@ -2133,6 +2143,8 @@ static int upload(hipStream_t st, DevBuf<T> &buf, const std::vector<T> &v) {
   if (!v.empty()) SOS_HIP(hipMemcpyAsync(buf.p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, st));
   return SOS_OK;
 }
+
+static int comm_setup_window(sos_ba *ba);
 
 extern "C" int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, int P, const sos_point *pts, int R,
                                  const sos_resid *res, const float *res_toZeroF, const sos_rawjac *lin_J) {
@@ -2391,7 +2403,7 @@ extern "C" int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, i
   SOS_HIP(hipStreamSynchronize(st));
   ba->have_window = true;
   ba->have_state = false;
-  return SOS_OK;
+  return comm_setup_window(ba);
 }
 
 // stage pointers
@@ -2525,6 +2537,92 @@ static int launch_lin_kernel(sos_ba *ba, const BaDev &dv, int mode, float *fuse_
 }
 static int launch_linearize(sos_ba *ba, int doApply) {
   launch_lin_kernel(ba, ba->dev, doApply, nullptr);
+  return SOS_OK;
+}
+
+__global__ void k_fill_f32(float *__restrict__ p, float v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ void k_copy_f32(float *__restrict__ dst, const float *__restrict__ src, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+// per-window setup of the exchange: the ranks agree on the capacity of the energy lists (max over ranks) and on
+// whether any of them holds linearised residuals (decides the number of stitch modes)
+static int comm_setup_window(sos_ba *ba) {
+  if (!ba->comm || !ba->have_window) return SOS_OK;
+  hipStream_t st = ba->ctx->stream;
+  ba->comm_size = sos_comm_size(ba->comm);
+  int h2[2] = {ba->newest_count, ba->ntiles > ba->ntilesA ? 1 : 0};
+  if (ba->d_tmp_int.ensure(2)) return SOS_ERR_NOMEM;
+  SOS_HIP(hipMemcpyAsync(ba->d_tmp_int.p, h2, sizeof(h2), hipMemcpyHostToDevice, st));
+  int rc = sos_comm_allreduce_max_i32(ba->comm, ba->d_tmp_int.p, 2, st);
+  if (rc) return rc;
+  SOS_HIP(hipMemcpyAsync(h2, ba->d_tmp_int.p, sizeof(h2), hipMemcpyDeviceToHost, st));
+  SOS_HIP(hipStreamSynchronize(st));
+  ba->newest_cap = h2[0] > 0 ? h2[0] : 1;
+  ba->anyL = h2[1] != 0;
+  const size_t tot = (size_t)ba->newest_cap * ba->comm_size;
+  if (ba->d_newest_local.ensure(ba->newest_cap) || ba->d_newest_all.ensure(tot)) return SOS_ERR_NOMEM;
+  if (tot > ba->pin_newest_floats) {
+    if (ba->pin_newest) hipHostFree(ba->pin_newest);
+    ba->pin_newest = nullptr;
+    SOS_HIP(hipHostMalloc((void **)&ba->pin_newest, sizeof(float) * (tot + tot / 4 + 64), hipHostMallocMapped));
+    SOS_HIP(hipHostGetDevicePointer((void **)&ba->pin_newest_dev, ba->pin_newest, 0));
+    ba->pin_newest_floats = tot + tot / 4 + 64;
+  }
+  k_fill_f32<<<divup(ba->newest_cap, 256), 256, 0, st>>>(ba->d_newest_local.p, -1.f, ba->newest_cap);  // padding = "no energy"
+  SOS_HIP(hipGetLastError());
+  SOS_HIP(hipStreamSynchronize(st));
+  return SOS_OK;
+}
+
+extern "C" int sos_ba_set_comm(sos_ba *ba, sos_comm *comm) {
+  if (!ba) return SOS_ERR_ARG;
+  SOS_HIP(hipSetDevice(ba->ctx->device));
+  SOS_HIP(hipStreamSynchronize(ba->ctx->stream));
+  ba->acc_inflight = false;
+  ba->comm = comm;
+  ba->comm_size = comm ? sos_comm_size(comm) : 1;
+  if (!comm) { ba->anyL = false; return SOS_OK; }
+  return comm_setup_window(ba);
+}
+
+// the same all-gather for callers outside the fused calls (the final linearizeAll(true) of optimize()): local
+// energies (>= 0, at most the window's newest-frame residual count) in, the energies of all ranks out
+extern "C" int sos_ba_gather_energies(sos_ba *ba, const float *local, int count, float *all, int *total) {
+  if (!ba || !ba->have_window || count < 0 || (count && !local) || !all || !total) return SOS_ERR_ARG;
+  if (!ba->comm) {
+    if (count) memcpy(all, local, sizeof(float) * count);
+    *total = count;
+    return SOS_OK;
+  }
+  if (count > ba->newest_cap) return SOS_ERR_ARG;
+  SOS_HIP(hipSetDevice(ba->ctx->device));
+  hipStream_t st = ba->ctx->stream;
+  SOS_HIP(hipStreamSynchronize(st));
+  const int tot = ba->newest_cap * ba->comm_size;
+  for (int i = 0; i < ba->newest_cap; i++) ba->pin_newest[i] = i < count ? local[i] : -1.f;
+  k_copy_f32<<<divup(ba->newest_cap, 256), 256, 0, st>>>(ba->d_newest_local.p, ba->pin_newest_dev, ba->newest_cap);
+  const int rcc = sos_comm_allgather_f32(ba->comm, ba->d_newest_local.p, ba->d_newest_all.p, ba->newest_cap, st);
+  if (rcc) return rcc;
+  k_copy_f32<<<divup(tot, 256), 256, 0, st>>>(ba->pin_newest_dev, ba->d_newest_all.p, tot);
+  SOS_HIP(hipGetLastError());
+  SOS_HIP(hipStreamSynchronize(st));
+  int k = 0;
+  for (int i = 0; i < tot; i++)
+    if (ba->pin_newest[i] >= 0) all[k++] = ba->pin_newest[i];
+  *total = k;
+  // leave the local list padded for the fused path (it only rewrites its first newest_count entries)
+  k_fill_f32<<<divup(ba->newest_cap, 256), 256, 0, st>>>(ba->d_newest_local.p, -1.f, ba->newest_cap);
+  SOS_HIP(hipStreamSynchronize(st));
+  return SOS_OK;
+}
+
+extern "C" int sos_ba_newest_capacity(sos_ba *ba, int *count) {
+  if (!ba || !count || !ba->have_window) return SOS_ERR_STATE;
+  *count = ba->comm ? ba->newest_cap * ba->comm_size : ba->newest_count;
   return SOS_OK;
 }
 
@@ -2748,11 +2846,11 @@ extern "C" int sos_ba_accumulate(sos_ba *ba, double *H_A, double *b_A, double *H
 // accumulate + stitch of the whole window with the stage-2 stitch kernels writing H/b (and the residual counts)
 // straight into the device-mapped pinned block: no copy command between the last kernel and the host
 static int enqueue_gn_accumulate(sos_ba *ba, bool topDone = false) {
-  const bool haveL = ba->ntiles > ba->ntilesA;
-  if (topDone && !haveL) {  // the tile sums came out of the linearisation itself: only the Schur half is left
+  const bool haveL = ba->ntiles > ba->ntilesA || (ba->comm && ba->anyL);
+  if (topDone && ba->ntiles == ba->ntilesA) {  // the tile sums came out of the linearisation itself: only the Schur half is left
     if (ba->nchunks > 0)
       k_sc_gram_prep<<<ba->nchunks, 256, gram_lds(ba), ba->ctx->stream>>>(ba->dev, ba->d_chunk_pt.p, ba->Dm, ba->ld, ba->d_gram_part.p);
-  } else if (!haveL && ba->ntilesA > 0 && ba->nchunks > 0) {  // top and Schur halves are independent: one launch
+  } else if (ba->ntiles == ba->ntilesA && ba->ntilesA > 0 && ba->nchunks > 0) {  // top and Schur halves are independent: one launch
     ensure_J(ba);
     const int nTop = divup(ba->ntilesA, 8);
     k_accumulate_fused<<<nTop + ba->nchunks, 256, gram_lds(ba), ba->ctx->stream>>>(ba->dev, nTop, ba->d_top_part.p, ba->d_chunk_pt.p,
@@ -2762,6 +2860,10 @@ static int enqueue_gn_accumulate(sos_ba *ba, bool topDone = false) {
     launch_sc(ba, 1);
   }
   launch_reduce(ba);
+  if (ba->comm) {  // THE exchange step of the path: packed fp32 blocks summed over all ranks, on this stream
+    const int rcc = sos_comm_allreduce_sum_f32(ba->comm, ba->d_acc.p, ba->acc_floats, ba->ctx->stream);
+    if (rcc) return rcc;
+  }
   launch_stitch(ba, ba->d_acc.p, haveL ? 2 : 1, reinterpret_cast<double *>(ba->pin_dev + ba->pin_hb));
   ba->acc_inflight_haveL = haveL;
   return SOS_OK;
@@ -2887,7 +2989,7 @@ extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const
   float *dstep = reinterpret_cast<float *>(po_dev + ba->out_step);
   BaDev dv = ba->dev;
   dv.tile_esum = reinterpret_cast<double *>(po_dev + ba->out_esum);
-  dv.o_newest = reinterpret_cast<float *>(po_dev + ba->out_newest);
+  dv.o_newest = ba->comm ? ba->d_newest_local.p : reinterpret_cast<float *>(po_dev + ba->out_newest);
   const double t1 = now_s();
   if (x && ba->P > 0 && ba->d_adHostF.p && ba->d_adTargetF.p) {
     // back-substitution from x alone + stage-in of the linearisation inputs: one launch
@@ -2909,7 +3011,15 @@ extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const
   }
   // pipelined iterations of a window without linearised residuals reduce the tiles on chip (no J traffic at all)
   const bool fuseTop = ba->prefetch && applyRes && ba->ntiles == ba->ntilesA;
-  const int waitSeq = launch_lin_kernel(ba, dv, applyRes ? 1 : 0, fuseTop ? ba->d_top_part.p : nullptr, true);
+  int waitSeq = launch_lin_kernel(ba, dv, applyRes ? 1 : 0, fuseTop ? ba->d_top_part.p : nullptr, ba->comm == nullptr);
+  if (ba->comm) {  // energies of the newest frame of ALL ranks (same frameEnergyTH everywhere), then tell the host
+    const int tot = ba->newest_cap * ba->comm_size;
+    const int rcc = sos_comm_allgather_f32(ba->comm, ba->d_newest_local.p, ba->d_newest_all.p, ba->newest_cap, st);
+    if (rcc) return rcc;
+    k_copy_f32<<<divup(tot, 256), 256, 0, st>>>(ba->pin_newest_dev, ba->d_newest_all.p, tot);
+    waitSeq = ++ba->sig_lin_seq;
+    k_publish<<<1, 1, 0, st>>>(reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags), waitSeq);
+  }
   ba->J_valid = !fuseTop;
   SOS_HIP(hipGetLastError());
   const double t2 = now_s();
@@ -2941,9 +3051,10 @@ extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const
     *energySum = e;
   }
   if (newestEnergies) {
-    const float *ne = reinterpret_cast<const float *>(po + ba->out_newest);
+    const float *ne = ba->comm ? ba->pin_newest : reinterpret_cast<const float *>(po + ba->out_newest);
+    const int cnt = ba->comm ? ba->newest_cap * ba->comm_size : ba->newest_count;
     int k = 0;
-    for (int i = 0; i < ba->newest_count; i++)
+    for (int i = 0; i < cnt; i++)
       if (ne[i] >= 0) newestEnergies[k++] = ne[i];
     if (newestCount) *newestCount = k;
   }

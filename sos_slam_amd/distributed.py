@@ -55,3 +55,50 @@ def attach(sysm, dist, torch):
     rc = L.sosf_set_hooks(sysm.h_, sysm._ar_cb, sysm._nth_cb, None)
     if rc != 0:
         raise RuntimeError(f"sosf_set_hooks failed: {rc}")
+
+
+class NativeComm:
+    """RCCL communicator owned by the library (sos_comm): the per-iteration all-reduce / all-gather run on the
+    library's own stream inside the fused calls, with no Python or host round trip (include/sos_slam.h, "multi-GPU
+    exchange").  torch.distributed is only used once, to hand rank 0's 128-byte RCCL id to the other ranks."""
+
+    def __init__(self, dist, torch, device: int):
+        import os
+        from . import lib as _lib
+        self.L = _lib.load()
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")  # the copy torch already loaded
+        rc = self.L.sos_rccl_load(path.encode() if os.path.exists(path) else None)
+        if rc != 0:
+            raise RuntimeError(f"sos_rccl_load failed: {rc}")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        idbuf = (C.c_ubyte * 128)()
+        if rank == 0:
+            rc = self.L.sos_rccl_unique_id(idbuf)
+            if rc != 0:
+                raise RuntimeError(f"sos_rccl_unique_id failed: {rc}")
+        t = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8, device="cuda")
+        dist.broadcast(t, src=0)
+        raw = bytes(t.cpu().tolist())
+        idbuf = (C.c_ubyte * 128).from_buffer_copy(raw)
+        self.h = C.c_void_p()
+        rc = self.L.sos_comm_create(idbuf, world, rank, device, C.byref(self.h))
+        if rc != 0:
+            raise RuntimeError(f"sos_comm_create failed: {rc}")
+        self._systems = []
+
+    def attach(self, sysm):
+        from . import host
+        rc = host.load().sosf_set_comm(sysm.h_, self.h)
+        if rc != 0:
+            raise RuntimeError(f"sosf_set_comm failed: {rc}")
+        self._systems.append(sysm)
+
+    def close(self):
+        from . import host
+        for s in self._systems:
+            if getattr(s, "h_", None):
+                host.load().sosf_set_comm(s.h_, None)
+        self._systems = []
+        if self.h:
+            self.L.sos_comm_destroy(self.h)
+            self.h = C.c_void_p()

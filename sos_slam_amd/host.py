@@ -37,6 +37,7 @@ def load():
     L.sosf_prepare.argtypes = [vp]
     L.sosf_gn_iteration.argtypes = [vp, ci, C.POINTER(ci)]
     L.sosf_set_pipeline.argtypes = [vp, ci]
+    L.sosf_set_comm.argtypes = [vp, vp]
     L.sosf_counts.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
     L.sosf_get_frame.argtypes = [vp, ci, vp, vp, vp, C.POINTER(C.c_float)]
     L.sosf_get_calib.argtypes = [vp, vp]

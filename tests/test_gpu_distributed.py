@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def test_hooked_run_equals_plain_run():
+def test_exchange_paths_equal_plain_run():
     import torch
     import torch.distributed as dist
     from sos_slam_amd import distributed as sdist
@@ -34,19 +34,31 @@ def test_hooked_run_equals_plain_run():
     try:
         win = synth.make_window("T6")
         out = []
-        for hooked in (False, True):
+        comm = sdist.NativeComm(dist, torch, 0)
+        for mode in ("plain", "hooks", "native"):
             sysm = host.System.from_window(win)
-            if hooked:
+            if mode == "hooks":
                 sdist.attach(sysm, dist, torch)
+            elif mode == "native":  # RCCL all-reduce / all-gather enqueued by the library on its own stream
+                comm.attach(sysm)
             rmse, its = sysm.optimize(4)
             pts = sysm.points()
             out.append((rmse, its, sysm.lastX().copy(), pts["idepth"].copy(),
                         [sysm.frame(f)["frameEnergyTH"] for f in range(win.n)]))
+            if mode == "native":
+                # a few pipelined loop bodies as bench.py runs them (prefetched accumulate incl. the all-reduce)
+                sysm.prepare()
+                sysm.set_pipeline(True)
+                for it in range(3):
+                    sysm.gn_iteration(it)
+                assert np.isfinite(sysm.lastX()).all()
+                comm.close()
             sysm.close()
-        a, b = out
-        assert a[0] == b[0] and a[1] == b[1]
-        assert np.array_equal(a[2], b[2])
-        assert np.array_equal(a[3], b[3])
-        assert a[4] == b[4]
+        a = out[0]
+        for b in out[1:]:
+            assert a[0] == b[0] and a[1] == b[1]
+            assert np.array_equal(a[2], b[2])
+            assert np.array_equal(a[3], b[3])
+            assert a[4] == b[4]
     finally:
         dist.destroy_process_group()
