@@ -173,42 +173,80 @@ __attribute__((target("avx2,fma"))) inline int ldlt_argmax_abs(const double *v, 
   _mm256_storeu_pd(t, m);
   best = std::max(std::max(t[0], t[1]), std::max(t[2], t[3]));
   for (; i < hi; i++) best = std::max(best, std::fabs(v[i]));
-  for (i = lo; i < hi; i++)
+  const __m256d vb = _mm256_set1_pd(best);
+  for (i = lo; i + 4 <= hi; i += 4) {
+    const int m = _mm256_movemask_pd(_mm256_cmp_pd(_mm256_andnot_pd(sign, _mm256_loadu_pd(v + i)), vb, _CMP_EQ_OQ));
+    if (m) return i + __builtin_ctz(m);
+  }
+  for (; i < hi; i++)
     if (std::fabs(v[i]) == best) return i;
   return lo;  // only reached with NaNs in v: keep the current pivot
 }
-// U[j][i] -= sum_c L(j,c) * W(i,c) for k1 <= j < i < n, two rows j at a time
+// U[j][i] -= sum_c L(j,c) * W(i,c) for k1 <= j < i < n.  Three rows j at a time and the panel in two halves of four
+// columns: 12 broadcast registers + 3 accumulators + 1 operand fill the 16 ymm registers, so the inner loop runs on
+// the FMA ports (12 FMAs per 4 + 3 loads) instead of on the load ports.
 __attribute__((target("avx2,fma"))) inline void ldlt_trailing_update(double *U, const double *WT, const double *LT, int n, int k1, int kb) {
   const size_t N = (size_t)n;
   int j = k1;
-  for (; j + 1 < n; j += 2) {
-    double *r0 = U + (size_t)j * N, *r1 = r0 + N;
-    __m256d l0[LDLT_NB], l1[LDLT_NB];
-    for (int c = 0; c < kb; c++) { l0[c] = _mm256_set1_pd(LT[c * N + j]); l1[c] = _mm256_set1_pd(LT[c * N + j + 1]); }
-    {  // row j needs i > j, row j+1 needs i > j+1: i = j+1 of row j on its own
-      double s0 = 0;
-      for (int c = 0; c < kb; c++) s0 += LT[c * N + j] * WT[c * N + j + 1];
-      r0[j + 1] -= s0;
-    }
-    int i = j + 2;
-    for (; i + 4 <= n; i += 4) {
-      __m256d a0 = _mm256_loadu_pd(r0 + i), a1 = _mm256_loadu_pd(r1 + i);
+  for (; j + 2 < n; j += 3) {
+    double *r0 = U + (size_t)j * N, *r1 = r0 + N, *r2 = r1 + N;
+    // leading entries that are not common to the three rows: (j, j+1), (j, j+2), (j+1, j+2)
+    {
+      double s01 = 0, s02 = 0, s12 = 0;
       for (int c = 0; c < kb; c++) {
-        const __m256d w = _mm256_loadu_pd(WT + c * N + i);
-        a0 = _mm256_fnmadd_pd(l0[c], w, a0);
-        a1 = _mm256_fnmadd_pd(l1[c], w, a1);
+        const double l0 = LT[c * N + j], l1 = LT[c * N + j + 1];
+        s01 += l0 * WT[c * N + j + 1];
+        s02 += l0 * WT[c * N + j + 2];
+        s12 += l1 * WT[c * N + j + 2];
       }
-      _mm256_storeu_pd(r0 + i, a0);
-      _mm256_storeu_pd(r1 + i, a1);
+      r0[j + 1] -= s01;
+      r0[j + 2] -= s02;
+      r1[j + 2] -= s12;
     }
-    for (; i < n; i++) {
-      double s0 = 0, s1 = 0;
-      for (int c = 0; c < kb; c++) { s0 += LT[c * N + j] * WT[c * N + i]; s1 += LT[c * N + j + 1] * WT[c * N + i]; }
-      r0[i] -= s0;
-      r1[i] -= s1;
+    for (int c0 = 0; c0 < kb; c0 += 4) {
+      const int cb = std::min(4, kb - c0);
+      __m256d l0[4], l1[4], l2[4];
+      for (int c = 0; c < 4; c++) {
+        const bool on = c < cb;
+        l0[c] = _mm256_set1_pd(on ? LT[(c0 + c) * N + j] : 0.0);
+        l1[c] = _mm256_set1_pd(on ? LT[(c0 + c) * N + j + 1] : 0.0);
+        l2[c] = _mm256_set1_pd(on ? LT[(c0 + c) * N + j + 2] : 0.0);
+      }
+      const double *w0 = WT + (size_t)(c0 + 0) * N, *w1 = WT + (size_t)(c0 + (cb > 1 ? 1 : 0)) * N,
+                   *w2 = WT + (size_t)(c0 + (cb > 2 ? 2 : 0)) * N, *w3 = WT + (size_t)(c0 + (cb > 3 ? 3 : 0)) * N;
+      int i = j + 3;
+      for (; i + 4 <= n; i += 4) {
+        __m256d a0 = _mm256_loadu_pd(r0 + i), a1 = _mm256_loadu_pd(r1 + i), a2 = _mm256_loadu_pd(r2 + i);
+        __m256d w = _mm256_loadu_pd(w0 + i);
+        a0 = _mm256_fnmadd_pd(l0[0], w, a0); a1 = _mm256_fnmadd_pd(l1[0], w, a1); a2 = _mm256_fnmadd_pd(l2[0], w, a2);
+        w = _mm256_loadu_pd(w1 + i);
+        a0 = _mm256_fnmadd_pd(l0[1], w, a0); a1 = _mm256_fnmadd_pd(l1[1], w, a1); a2 = _mm256_fnmadd_pd(l2[1], w, a2);
+        w = _mm256_loadu_pd(w2 + i);
+        a0 = _mm256_fnmadd_pd(l0[2], w, a0); a1 = _mm256_fnmadd_pd(l1[2], w, a1); a2 = _mm256_fnmadd_pd(l2[2], w, a2);
+        w = _mm256_loadu_pd(w3 + i);
+        a0 = _mm256_fnmadd_pd(l0[3], w, a0); a1 = _mm256_fnmadd_pd(l1[3], w, a1); a2 = _mm256_fnmadd_pd(l2[3], w, a2);
+        _mm256_storeu_pd(r0 + i, a0);
+        _mm256_storeu_pd(r1 + i, a1);
+        _mm256_storeu_pd(r2 + i, a2);
+      }
+      for (; i < n; i++) {
+        double s0 = 0, s1 = 0, s2 = 0;
+        for (int c = 0; c < cb; c++) {
+          const double w = WT[(c0 + c) * N + i];
+          s0 += LT[(c0 + c) * N + j] * w; s1 += LT[(c0 + c) * N + j + 1] * w; s2 += LT[(c0 + c) * N + j + 2] * w;
+        }
+        r0[i] -= s0; r1[i] -= s1; r2[i] -= s2;
+      }
     }
   }
-  // a last single row j = n-1 has no entries right of the diagonal
+  for (; j + 1 < n; j++) {  // at most two remaining rows (the last one has no entries right of the diagonal)
+    double *r0 = U + (size_t)j * N;
+    for (int i = j + 1; i < n; i++) {
+      double s0 = 0;
+      for (int c = 0; c < kb; c++) s0 += LT[c * N + j] * WT[c * N + i];
+      r0[i] -= s0;
+    }
+  }
 }
 __attribute__((target("avx2,fma"))) inline void ldlt_solve(const std::vector<double> &A, const std::vector<double> &b, std::vector<double> &x, int n) {
   const size_t N = (size_t)n;
@@ -245,12 +283,20 @@ __attribute__((target("avx2,fma"))) inline void ldlt_solve(const std::vector<dou
         continue;
       }
       // bring column k (rows below the diagonal) up to date with the q earlier pivots of the panel
-      for (int i = k + 1; i < n; i++) wt[i] = uk[i];
-      for (int c = 0; c < q; c++) {
-        const double lkc = LT[c * N + k];
-        const double *wc = &WT[c * N];
-        if (lkc != 0.0)
-          for (int i = k + 1; i < n; i++) wt[i] -= wc[i] * lkc;
+      {
+        int i = k + 1;
+        __m256d lk[LDLT_NB];
+        for (int c = 0; c < q; c++) lk[c] = _mm256_set1_pd(LT[c * N + k]);
+        for (; i + 4 <= n; i += 4) {
+          __m256d a = _mm256_loadu_pd(uk + i);
+          for (int c = 0; c < q; c++) a = _mm256_fnmadd_pd(_mm256_loadu_pd(&WT[c * N + i]), lk[c], a);
+          _mm256_storeu_pd(wt + i, a);
+        }
+        for (; i < n; i++) {
+          double a = uk[i];
+          for (int c = 0; c < q; c++) a -= WT[c * N + i] * LT[c * N + k];
+          wt[i] = a;
+        }
       }
       const double dinv = 1.0 / d;
       for (int i = k + 1; i < n; i++) {
@@ -270,11 +316,19 @@ __attribute__((target("avx2,fma"))) inline void ldlt_solve(const std::vector<dou
     for (int i = k + 1; i < n; i++) y[i] -= uk[i] * yk;
   }
   for (int i = 0; i < n; i++) y[i] = (std::fabs(D[i]) > 2.2250738585072014e-308) ? y[i] / D[i] : 0.0;
-  for (int k = n - 1; k >= 0; k--) {  // L^T w = z
+  for (int k = n - 1; k >= 0; k--) {  // L^T w = z: dot product with four independent vector accumulators
     const double *uk = &U[k * N];
-    double sacc = y[k];
-    for (int i = k + 1; i < n; i++) sacc -= uk[i] * y[i];
-    y[k] = sacc;
+    __m256d a0 = _mm256_setzero_pd(), a1 = _mm256_setzero_pd();
+    int i = k + 1;
+    for (; i + 8 <= n; i += 8) {
+      a0 = _mm256_fmadd_pd(_mm256_loadu_pd(uk + i), _mm256_loadu_pd(&y[i]), a0);
+      a1 = _mm256_fmadd_pd(_mm256_loadu_pd(uk + i + 4), _mm256_loadu_pd(&y[i + 4]), a1);
+    }
+    double t[4];
+    _mm256_storeu_pd(t, _mm256_add_pd(a0, a1));
+    double dot = (t[0] + t[1]) + (t[2] + t[3]);
+    for (; i < n; i++) dot += uk[i] * y[i];
+    y[k] -= dot;
     std::swap(y[k], y[perm[k]]);
   }
   x.assign(y.begin(), y.begin() + n);
