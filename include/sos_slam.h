@@ -351,6 +351,12 @@ int sos_tracker_get_pc(sos_tracker *trk, int lvl, float *pc_u, float *pc_v, floa
  * [E, numTermsInE, flowT, 0, flowRT, satRatio]. */
 int sos_tracker_calc_res(sos_tracker *trk, int lvl, int newSlot, const float *RKi, const float *t,
                          const float *affLL, float cutoffTH, double *rs /*6*/);
+/* Latency hint for the LM loops: with on != 0 every sos_tracker_calc_res also runs calcGSSSEPose for the pose it
+ * was given (a = affLL[0], b0 = the hint) behind itself, and every sos_tracker_calc_res_scale runs calcGSSSEScale;
+ * the matching sos_tracker_calc_gs / _calc_gs_scale call is then answered without touching the device (an accepted
+ * LM step costs one round trip instead of two).  Results are identical with or without the hint. */
+int sos_tracker_set_gs_hint(sos_tracker *trk, int on, float b0);
+
 /* CoarseTracker::calcGSSSEPose (FS/CoarseTracker.cpp:554-610) on the buffers of the last calc_res.
  * a = affLL[0] of the pose being linearized, b0 = lastRef_aff_g2l.b.  H 8x8 row-major, b 8. */
 int sos_tracker_calc_gs(sos_tracker *trk, int lvl, float a, float b0, double *H, double *b);

@@ -1209,6 +1209,7 @@ bool CoarseTracker::trackNewestCoarse(int newSlot, float new_ab_exposure, SE3 &l
   AffLight aff_g2l_current = aff_g2l_out;
   bool haveRepeated = false;
   const float modeA = prm.affineOptModeA, modeB = prm.affineOptModeB;
+  sos_tracker_set_gs_hint(trk, 1, (float)lastRef_aff_g2l.b);  // calcGSSSE rides behind every calcRes (accepted steps: 1 round trip)
   auto calcRes = [&](int lvl, const SE3 &T, const AffLight &aff, float cutoff, double *rs, float *a_out) {
     float RKi[9], t[3], affLL[2];
     rki_of(T, Ki[lvl], RKi, t);
@@ -1327,6 +1328,7 @@ float CoarseTracker::optimizeScale(int stereoSlot, const SE3 &tfmF0ToF1, const f
     cx1[l] = (cx1[0] + 0.5) / ((int)1 << l) - 0.5;
     cy1[l] = (cy1[0] + 0.5) / ((int)1 << l) - 0.5;
   }
+  sos_tracker_set_gs_hint(trk, 1, 0.f);
   for (int lvl = coarsestLvl; lvl >= 0; lvl--) {
     float H = 0, b = 0, levelCutoffRepeat = 1;
     double resOld[6], resNew[6];

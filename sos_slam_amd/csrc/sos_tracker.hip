@@ -41,6 +41,20 @@ struct sos_tracker {
   float *d_pixv = nullptr;
   int maxblk = 0;
   bool have_ref = false;
+  // results come back through device-mapped pinned memory (no copy command per call): [0,8) calcRes sums,
+  // [8,53) calcGSSSE sums
+  double *pin_o = nullptr, *pin_o_dev = nullptr;
+  float *d_part2 = nullptr;  // per-block partials of the speculative calcGSSSE
+  // Speculation: the LM loops call calcRes and, when the step is accepted (the common case), calcGSSSE on the same
+  // buffers.  With a hint for b0 (sos_tracker_set_gs_hint) calcRes also runs calcGSSSE behind itself, and the
+  // following sos_tracker_calc_gs with the same (lvl, a, b0) is answered from the host copy: one round trip, not two.
+  bool hint_on = false;
+  float hint_b0 = 0;
+  bool gs_cached = false;
+  int gs_lvl = -1;
+  float gs_a = 0, gs_b0 = 0;
+  bool gss_cached = false;  // scale variant: (lvl, t, K1, scale)
+  float gss_key[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 static inline int divup(int a, int b) { return (a + b - 1) / b; }
@@ -71,6 +85,9 @@ extern "C" int sos_tracker_create(sos_ctx *ctx, const sos_params *prm, sos_track
   SOS_HIP(hipMalloc(&T->d_counts, sizeof(int) * (T->maxblk + 1)));
   SOS_HIP(hipMalloc(&T->d_part, sizeof(float) * 48 * T->maxblk));
   SOS_HIP(hipMalloc(&T->d_out, sizeof(double) * 64));
+  SOS_HIP(hipMalloc(&T->d_part2, sizeof(float) * 48 * T->maxblk));
+  SOS_HIP(hipHostMalloc((void **)&T->pin_o, sizeof(double) * 64, hipHostMallocMapped));
+  SOS_HIP(hipHostGetDevicePointer((void **)&T->pin_o_dev, T->pin_o, 0));
   SOS_HIP(hipMalloc(&T->d_pix, sizeof(int) * n0));
   SOS_HIP(hipMalloc(&T->d_pixv, sizeof(float) * 2 * n0));
   *out = T;
@@ -86,6 +103,8 @@ extern "C" int sos_tracker_destroy(sos_tracker *T) {
     hipFree(T->pc_u[l]); hipFree(T->pc_v[l]); hipFree(T->pc_idepth[l]); hipFree(T->pc_color[l]);
   }
   for (int k = 0; k < 8; k++) hipFree(T->buf[k]);
+  hipFree(T->d_part2);
+  if (T->pin_o) hipHostFree(T->pin_o);
   hipFree(T->d_counts); hipFree(T->d_part); hipFree(T->d_out); hipFree(T->d_pix); hipFree(T->d_pixv);
   delete T;
   return SOS_OK;
@@ -441,15 +460,16 @@ static void fill_common(sos_tracker *T, ResArgs &a, int lvl, const float *RKi, c
   a.maxEnergy = 2 * a.huber * cutoffTH - a.huber * a.huber;
 }
 
+struct GsArgs;
+static void enqueue_gs(sos_tracker *T, int lvl, float a, float b0, int nblk);
+static void enqueue_gs_scale(sos_tracker *T, int lvl, const float *t, const float *K1, float scale, int nblk);
+
 static int finish_res(sos_tracker *T, int nblk, double *rs) {
   hipStream_t st = T->ctx->stream;
-  double o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (nblk > 0) {
-    k_sum_parts<<<1, 64, 0, st>>>(T->d_part, nblk, 8, T->d_out);
-    SOS_HIP(hipMemcpyAsync(o, T->d_out, sizeof(double) * 8, hipMemcpyDeviceToHost, st));
-  }
   SOS_HIP(hipGetLastError());
   SOS_HIP(hipStreamSynchronize(st));
+  double o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (nblk > 0) memcpy(o, T->pin_o, sizeof(o));
   const int numTermsInE = (int)o[1], numWarped = (int)o[2], numSaturated = (int)o[3];
   T->buf_count = numWarped;
   T->buf_n = (numWarped + 3) / 4 * 4;
@@ -460,6 +480,14 @@ static int finish_res(sos_tracker *T, int nblk, double *rs) {
   rs[3] = 0;
   rs[4] = sumRT / (sumNum + 0.1);
   rs[5] = numSaturated / (float)numTermsInE;
+  return SOS_OK;
+}
+
+extern "C" int sos_tracker_set_gs_hint(sos_tracker *T, int on, float b0) {
+  if (!T) return SOS_ERR_ARG;
+  T->hint_on = on != 0;
+  T->hint_b0 = b0;
+  T->gs_cached = false;
   return SOS_OK;
 }
 
@@ -475,7 +503,15 @@ extern "C" int sos_tracker_calc_res(sos_tracker *T, int lvl, int newSlot, const 
   a.fxl = T->fx[lvl]; a.fyl = T->fy[lvl]; a.cxl = T->cx[lvl]; a.cyl = T->cy[lvl];
   a.aff0 = affLL[0]; a.aff1 = affLL[1];
   const int nblk = divup(a.n, 256);
-  if (nblk > 0) k_calc_res<false><<<nblk, 256, 0, c->stream>>>(a, T->d_part);
+  T->gs_cached = T->gss_cached = false;
+  if (nblk > 0) {
+    k_calc_res<false><<<nblk, 256, 0, c->stream>>>(a, T->d_part);
+    k_sum_parts<<<1, 64, 0, c->stream>>>(T->d_part, nblk, 8, T->pin_o_dev);
+    if (T->hint_on) {  // speculative calcGSSSE for this pose (see sos_tracker)
+      enqueue_gs(T, lvl, affLL[0], T->hint_b0, nblk);
+      T->gs_cached = true; T->gs_lvl = lvl; T->gs_a = affLL[0]; T->gs_b0 = T->hint_b0;
+    }
+  }
   T->buf_lvl = lvl;
   return finish_res(T, nblk, rs);
 }
@@ -492,7 +528,17 @@ extern "C" int sos_tracker_calc_res_scale(sos_tracker *T, int lvl, int stereoSlo
   a.fxl = K1[0]; a.fyl = K1[1]; a.cxl = K1[2]; a.cyl = K1[3];
   a.aff0 = 1; a.aff1 = 0;
   const int nblk = divup(a.n, 256);
-  if (nblk > 0) k_calc_res<true><<<nblk, 256, 0, c->stream>>>(a, T->d_part);
+  T->gs_cached = T->gss_cached = false;
+  if (nblk > 0) {
+    k_calc_res<true><<<nblk, 256, 0, c->stream>>>(a, T->d_part);
+    k_sum_parts<<<1, 64, 0, c->stream>>>(T->d_part, nblk, 8, T->pin_o_dev);
+    if (T->hint_on) {  // calcGSSSEScale needs nothing beyond what calcResScale was given
+      enqueue_gs_scale(T, lvl, t, K1, scale, nblk);
+      T->gss_cached = true;
+      T->gss_key[0] = (float)lvl; T->gss_key[1] = t[0]; T->gss_key[2] = t[1]; T->gss_key[3] = t[2];
+      T->gss_key[4] = K1[0]; T->gss_key[5] = K1[1]; T->gss_key[6] = scale;
+    }
+  }
   T->buf_lvl = lvl;
   return finish_res(T, nblk, rs);
 }
@@ -560,26 +606,44 @@ __global__ __launch_bounds__(256) void k_calc_gs_scale(GsArgs g, float *__restri
   block_sum<3>(v, sm, part + 3 * (size_t)blockIdx.x);
 }
 
-extern "C" int sos_tracker_calc_gs(sos_tracker *T, int lvl, float a, float b0, double *H_out, double *b_out) {
-  if (!T || !T->have_ref || lvl != T->buf_lvl || !H_out || !b_out) return SOS_ERR_STATE;
-  sos_ctx *c = T->ctx;
-  SOS_HIP(hipSetDevice(c->device));
-  hipStream_t st = c->stream;
+static void enqueue_gs(sos_tracker *T, int lvl, float a, float b0, int nblk) {
   GsArgs g;
   for (int k = 0; k < 8; k++) g.buf[k] = T->buf[k];
   g.n = T->pc_n[lvl];
   g.fxl = T->fx[lvl]; g.fyl = T->fy[lvl]; g.a = a; g.b0 = b0;
   g.s = 1; g.tx = g.ty = g.tz = 0;
+  hipStream_t st = T->ctx->stream;
+  k_calc_gs<<<nblk, 256, 0, st>>>(g, T->d_part2);
+  k_sum_parts<<<1, 64, 0, st>>>(T->d_part2, nblk, 45, T->pin_o_dev + 8);
+}
+static void enqueue_gs_scale(sos_tracker *T, int lvl, const float *t, const float *K1, float scale, int nblk) {
+  GsArgs g;
+  for (int k = 0; k < 8; k++) g.buf[k] = T->buf[k];
+  g.n = T->pc_n[lvl];
+  g.fxl = K1[0]; g.fyl = K1[1]; g.a = 0; g.b0 = 0;
+  g.s = scale; g.tx = t[0]; g.ty = t[1]; g.tz = t[2];
+  hipStream_t st = T->ctx->stream;
+  k_calc_gs_scale<<<nblk, 256, 0, st>>>(g, T->d_part2);
+  k_sum_parts<<<1, 64, 0, st>>>(T->d_part2, nblk, 3, T->pin_o_dev + 8);
+}
+
+extern "C" int sos_tracker_calc_gs(sos_tracker *T, int lvl, float a, float b0, double *H_out, double *b_out) {
+  if (!T || !T->have_ref || lvl != T->buf_lvl || !H_out || !b_out) return SOS_ERR_STATE;
+  sos_ctx *c = T->ctx;
+  SOS_HIP(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
   double o[45];
   for (int k = 0; k < 45; k++) o[k] = 0;
-  const int nblk = divup(g.n, 256);
+  const int nblk = divup(T->pc_n[lvl], 256);
   if (nblk > 0) {
-    k_calc_gs<<<nblk, 256, 0, st>>>(g, T->d_part);
-    k_sum_parts<<<1, 64, 0, st>>>(T->d_part, nblk, 45, T->d_out);
-    SOS_HIP(hipMemcpyAsync(o, T->d_out, sizeof(double) * 45, hipMemcpyDeviceToHost, st));
+    if (!(T->gs_cached && T->gs_lvl == lvl && T->gs_a == a && T->gs_b0 == b0)) {  // not speculated: run it now
+      enqueue_gs(T, lvl, a, b0, nblk);
+      SOS_HIP(hipGetLastError());
+      SOS_HIP(hipStreamSynchronize(st));
+      T->gs_cached = true; T->gs_lvl = lvl; T->gs_a = a; T->gs_b0 = b0;
+    }
+    memcpy(o, T->pin_o + 8, sizeof(o));
   }
-  SOS_HIP(hipGetLastError());
-  SOS_HIP(hipStreamSynchronize(st));
   float Hf[81];
   int idx = 0;
   for (int r = 0; r < 9; r++)
@@ -604,20 +668,19 @@ extern "C" int sos_tracker_calc_gs_scale(sos_tracker *T, int lvl, const float *t
   sos_ctx *c = T->ctx;
   SOS_HIP(hipSetDevice(c->device));
   hipStream_t st = c->stream;
-  GsArgs g;
-  for (int k = 0; k < 8; k++) g.buf[k] = T->buf[k];
-  g.n = T->pc_n[lvl];
-  g.fxl = K1[0]; g.fyl = K1[1]; g.a = 0; g.b0 = 0;
-  g.s = scale; g.tx = t[0]; g.ty = t[1]; g.tz = t[2];
   double o[3] = {0, 0, 0};
-  const int nblk = divup(g.n, 256);
+  const int nblk = divup(T->pc_n[lvl], 256);
   if (nblk > 0) {
-    k_calc_gs_scale<<<nblk, 256, 0, st>>>(g, T->d_part);
-    k_sum_parts<<<1, 64, 0, st>>>(T->d_part, nblk, 3, T->d_out);
-    SOS_HIP(hipMemcpyAsync(o, T->d_out, sizeof(double) * 3, hipMemcpyDeviceToHost, st));
+    const float key[7] = {(float)lvl, t[0], t[1], t[2], K1[0], K1[1], scale};
+    if (!(T->gss_cached && memcmp(key, T->gss_key, sizeof(key)) == 0)) {
+      enqueue_gs_scale(T, lvl, t, K1, scale, nblk);
+      SOS_HIP(hipGetLastError());
+      SOS_HIP(hipStreamSynchronize(st));
+      T->gss_cached = true;
+      memcpy(T->gss_key, key, sizeof(key));
+    }
+    memcpy(o, T->pin_o + 8, sizeof(o));
   }
-  SOS_HIP(hipGetLastError());
-  SOS_HIP(hipStreamSynchronize(st));
   const int n = T->buf_n;
   *H_out = (float)o[0] * (1.0f / n);
   *b_out = (float)o[1] * (1.0f / n);

@@ -23,7 +23,7 @@ SYMBOLS = [
     "sos_ba_set_window", "sos_ba_set_state", "sos_ba_linearize", "sos_ba_apply_res", "sos_ba_reset_oob",
     "sos_ba_fix_linearization", "sos_ba_accumulate", "sos_ba_accumulate_local", "sos_ba_acc_buffer",
     "sos_ba_stitch", "sos_ba_gn_accumulate", "sos_ba_gn_step", "sos_ba_get_point_hessian", "sos_ba_resubstitute", "sos_ba_calc_lenergy",
-    "sos_ba_accumulate_marg", "sos_ba_update_point_priors", "sos_ba_set_prefetch", "sos_rccl_load", "sos_rccl_unique_id", "sos_comm_create", "sos_comm_destroy", "sos_comm_size",
+    "sos_ba_accumulate_marg", "sos_ba_update_point_priors", "sos_ba_set_prefetch", "sos_tracker_set_gs_hint", "sos_rccl_load", "sos_rccl_unique_id", "sos_comm_create", "sos_comm_destroy", "sos_comm_size",
     "sos_comm_rank", "sos_ba_set_comm", "sos_ba_newest_capacity", "sos_ba_gather_energies", "sos_ba_get_jacobian", "sos_ba_get_residual_flags", "sos_ba_get_JpJdF",
     "sos_ba_get_res_toZeroF", "sos_ba_time_kernel", "sos_tracker_create", "sos_tracker_destroy",
     "sos_tracker_set_ref", "sos_tracker_scale_depth", "sos_tracker_get_pc", "sos_tracker_calc_res",
@@ -82,6 +82,7 @@ def load():
     L.sos_ba_accumulate_marg.argtypes = [vp, vp, ci, vp, vp, vp, vp, C.POINTER(ci)]
     L.sos_ba_update_point_priors.argtypes = [vp, vp, vp, ci]
     L.sos_ba_set_prefetch.argtypes = [vp, ci]
+    L.sos_tracker_set_gs_hint.argtypes = [vp, ci, C.c_float]
     L.sos_rccl_load.argtypes = [C.c_char_p]
     L.sos_rccl_unique_id.argtypes = [vp]
     L.sos_comm_create.argtypes = [vp, ci, ci, ci, C.POINTER(vp)]

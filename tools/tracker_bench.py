@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""Timing of the CoarseTracker / ScaleOptimizer path on the device against the oracle port on the host cores
+(trackNewestCoarse and optimizeScale on a W12-sized keyframe window, 752x480, 5 pyramid levels)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import oracle as orc  # noqa: E402
+from sos_slam_amd import host, synth  # noqa: E402
+from sos_slam_amd.records import Calib  # noqa: E402
+from tests.test_oracle_math import se3_exp, se3_mul  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "W7"
+win = synth.make_window(name, extra_frames=2)
+sysm = host.System.from_window(win)
+sysm.optimize(3)
+ht = host.HostTracker(sysm)
+pc_n = ht.set_ref()
+new_slot = sysm.upload_image(win.extra_images[0])
+st_slot = sysm.upload_image(win.extra_images[1])
+levels = int(np.count_nonzero(pc_n)) if np.count_nonzero(pc_n) else len(pc_n)
+ref = win.frames[win.n - 1]["camToWorld"]
+new = win.extra_poses[0]
+Rr, tr, Rn, tn = ref[:9].reshape(3, 3), ref[9:], new[:9].reshape(3, 3), new[9:]
+T0 = np.concatenate([(Rn.T @ Rr).reshape(-1), Rn.T @ (tr - tn)])
+Tinit = se3_mul(se3_exp(np.array([0.004, -0.003, 0.002, 0.002, -0.002, 0.001])), T0)
+
+
+def timeit(fn, reps):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    return (time.perf_counter() - t0) / reps
+
+
+t_set = timeit(lambda: ht.set_ref(), 20)
+t_trk = timeit(lambda: ht.track(new_slot, 1.0, Tinit, np.zeros(2), levels - 1), 20)
+K1 = np.array(sysm.calib_value_scaled(), np.float32)
+t_scl = timeit(lambda: ht.optimize_scale(st_slot, win.stereo_tfm, K1, 1.2, levels - 1), 20)
+out = {"window": name, "template_pixels_per_level": [int(x) for x in pc_n[:levels]],
+       "gpu_ms": {"set_ref": t_set * 1e3, "track": t_trk * 1e3, "optimize_scale": t_scl * 1e3}}
+
+# oracle port on the host (single thread, as the reference's tracker is)
+ow = orc.window_from_synth(win)
+ow.optimize(3)
+res = ow.res()
+sel = (res["target"] == win.n - 1) & ((res["flags"] & 0x101) == 1) & (res["state_state"] == 0)
+c = ow.center()[sel]
+hdi = ow.point_field("HdiF")[res["point"][sel]]
+calib = Calib.from_K(ow.calib_value_scaled())
+ot = orc.OracleTracker(win.params, win.w, win.h)
+new_dI, _ = orc.make_images(win.extra_images[0])
+st_dI, _ = orc.make_images(win.extra_images[1])
+ref_aff = np.array([ow.frame(win.n - 1)["state"][6] * 10.0, ow.frame(win.n - 1)["state"][7] * 1000.0])
+c_set = timeit(lambda: ot.set_ref(calib, ow.dI[win.n - 1], c[:, 0], c[:, 1], c[:, 2], hdi), 5)
+c_trk = timeit(lambda: ot.track(new_dI, 1.0, 1.0, ref_aff, Tinit, np.zeros(2), levels - 1), 5)
+c_scl = timeit(lambda: ot.optimize_scale(st_dI, win.stereo_tfm, K1, 1.2, levels - 1), 5)
+out["cpu_port_ms"] = {"set_ref": c_set * 1e3, "track": c_trk * 1e3, "optimize_scale": c_scl * 1e3}
+print(json.dumps(out))
