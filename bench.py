@@ -192,12 +192,46 @@ def main():
     sysm.close()
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
+            out["tracker"] = tracker_timing(args.window, local_rank)
             out["cpu_baseline"] = cpu_baseline(win, args.cpu_seconds)
             out["speedup_vs_cpu_gn_iter"] = out["gn_iter_per_s"] / out["cpu_baseline"]["gn_iter_per_s"]
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def tracker_timing(window, device):
+    """CoarseTracker / ScaleOptimizer latencies on the device (the other half of the hot path):
+    trackNewestCoarse and optimizeScale of a new frame against the newest keyframe of the same window type."""
+    from sos_slam_amd import host, synth
+    from tests.test_oracle_math import se3_exp, se3_mul
+    win = synth.make_window(window, extra_frames=2)
+    sysm = host.System.from_window(win, device=device)
+    sysm.optimize(3)
+    ht = host.HostTracker(sysm)
+    pc_n = ht.set_ref()
+    levels = int(np.count_nonzero(pc_n))
+    new_slot, st_slot = sysm.upload_image(win.extra_images[0]), sysm.upload_image(win.extra_images[1])
+    ref, new = win.frames[win.n - 1]["camToWorld"], win.extra_poses[0]
+    Rr, tr, Rn, tn = ref[:9].reshape(3, 3), ref[9:], new[:9].reshape(3, 3), new[9:]
+    T0 = np.concatenate([(Rn.T @ Rr).reshape(-1), Rn.T @ (tr - tn)])
+    Tinit = se3_mul(se3_exp(np.array([0.004, -0.003, 0.002, 0.002, -0.002, 0.001])), T0)
+    K1 = np.array(sysm.calib_value_scaled(), np.float32)
+
+    def timeit(fn, reps=20):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    out = {"template_pixels_per_level": [int(x) for x in pc_n[:levels]],
+           "set_coarse_tracking_ref_ms": timeit(ht.set_ref),
+           "track_newest_coarse_ms": timeit(lambda: ht.track(new_slot, 1.0, Tinit, np.zeros(2), levels - 1)),
+           "optimize_scale_ms": timeit(lambda: ht.optimize_scale(st_slot, win.stereo_tfm, K1, 1.2, levels - 1))}
+    sysm.close()
+    return out
 
 
 def pmc_traffic(window):

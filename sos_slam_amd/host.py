@@ -112,6 +112,8 @@ class System:
         return s
 
     def close(self):
+        for t in list(getattr(self, "_trackers", [])):  # trackers borrow the system's context: they go first
+            t.close()
         if getattr(self, "h_", None):
             self.L.sosf_destroy(self.h_)
             self.h_ = None
@@ -243,11 +245,17 @@ class HostTracker:
         self.h_ = C.c_void_p()
         _chk(self.L.sosf_tracker_create(sysm.h_, C.byref(self.h_)), "sosf_tracker_create")
         self.pc_n = np.zeros(6, dtype=np.int32)
+        if not hasattr(sysm, "_trackers"):
+            sysm._trackers = []
+        sysm._trackers.append(self)
 
     def close(self):
         if getattr(self, "h_", None):
-            self.L.sosf_tracker_destroy(self.h_)
+            if getattr(self.sys, "h_", None):  # after the system is gone its context is gone too
+                self.L.sosf_tracker_destroy(self.h_)
             self.h_ = None
+        if self in getattr(self.sys, "_trackers", []):
+            self.sys._trackers.remove(self)
 
     def __del__(self):
         try:
