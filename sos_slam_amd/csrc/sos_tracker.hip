@@ -355,9 +355,17 @@ __device__ __forceinline__ void block_sum(float *v, float *sm /* NV*4 */, float 
   if (threadIdx.x < NV) out[threadIdx.x] = (sm[threadIdx.x * 4] + sm[threadIdx.x * 4 + 1]) + (sm[threadIdx.x * 4 + 2] + sm[threadIdx.x * 4 + 3]);
 }
 
-template <bool SCALE>
-__global__ __launch_bounds__(256) void k_calc_res(ResArgs a, float *__restrict__ part /* nblk*8 */) {
+// parameters of the calcGSSSE that may ride inside k_calc_res (speculation, see sos_tracker)
+struct GsFuse {
+  float fxl, fyl, a, b0;   // pose variant: fx, fy of the level, affLL[0], b0
+  float s, tx, ty, tz;     // scale variant
+};
+template <bool SCALE, bool GS>
+__global__ __launch_bounds__(256) void k_calc_res(ResArgs a, float *__restrict__ part /* nblk*8 */, GsFuse gf,
+                                                  float *__restrict__ part_gs /* nblk*45 | nblk*3 */) {
   __shared__ float sm[8 * 4];
+  __shared__ float smg[(SCALE ? 3 : 45) * 4];
+  float gsb[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // this pixel's warp-buffer entries, as stored
   const int i = blockIdx.x * 256 + threadIdx.x;
   float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // E, numTermsInE, numWarped, numSaturated, flowT, flowRT, flowNum, -
   if (i < a.n) {
@@ -422,23 +430,85 @@ __global__ __launch_bounds__(256) void k_calc_res(ResArgs a, float *__restrict__
         }
       }
     }
-    a.buf[0][i] = warped ? o0 : 0.f;
-    a.buf[1][i] = warped ? o1 : 0.f;
-    a.buf[2][i] = warped ? o2 : 0.f;
-    a.buf[3][i] = b3;
-    a.buf[4][i] = b4;
-    a.buf[5][i] = b5;
-    a.buf[6][i] = b6;
-    a.buf[7][i] = b7;
+    gsb[0] = warped ? o0 : 0.f; gsb[1] = warped ? o1 : 0.f; gsb[2] = warped ? o2 : 0.f;
+    gsb[3] = b3; gsb[4] = b4; gsb[5] = b5; gsb[6] = b6; gsb[7] = b7;
+#pragma unroll
+    for (int k = 0; k < 8; k++) a.buf[k][i] = gsb[k];
   }
   block_sum<8>(v, sm, part + 8 * (size_t)blockIdx.x);
+  if (GS) {  // the same arithmetic as k_calc_gs / k_calc_gs_scale on the values just stored
+    if (SCALE) {
+      float g3[3] = {0, 0, 0};
+      if (i < a.n) {
+        const float dxfx = gsb[3] * gf.fxl, dyfy = gsb[4] * gf.fyl;
+        const float rx1 = gsb[0], rx2 = gsb[1], rx3 = gsb[2];
+        const float deno_sqrt = gf.s * rx3 + gf.tz;
+        const float deno = 1.0f / (deno_sqrt * deno_sqrt);
+        const float xno = rx1 * gf.tz - rx3 * gf.tx, yno = rx2 * gf.tz - rx3 * gf.ty;
+        const float J0 = dxfx * (deno * xno) + dyfy * (deno * yno);
+        const float J1 = gsb[5], w = gsb[6];
+        if (w != 0.f) {
+          const float J0w = J0 * w, J1w = J1 * w;
+          g3[0] = J0w * J0;
+          g3[1] = J0w * J1;
+          g3[2] = J1w * J1;
+        }
+      }
+      block_sum<3>(g3, smg, part_gs + 3 * (size_t)blockIdx.x);
+    } else {
+      float g45[45];
+#pragma unroll
+      for (int k = 0; k < 45; k++) g45[k] = 0.f;
+      if (i < a.n) {
+        const float dx = gsb[3] * gf.fxl, dy = gsb[4] * gf.fyl;
+        const float u = gsb[1], vv = gsb[2], id = gsb[0];
+        float J[9];
+        J[0] = id * dx;
+        J[1] = id * dy;
+        J[2] = 0 - id * (u * dx + vv * dy);
+        J[3] = 0 - (u * vv * dx + dy * (1 + vv * vv));
+        J[4] = u * vv * dy + dx * (1 + u * u);
+        J[5] = u * dy - vv * dx;
+        J[6] = gf.a * (gf.b0 - gsb[7]);
+        J[7] = -1;
+        J[8] = gsb[5];
+        const float w = gsb[6];
+        int idx = 0;
+#pragma unroll
+        for (int r = 0; r < 9; r++) {
+          const float Jw = J[r] * w;
+#pragma unroll
+          for (int cc = r; cc < 9; cc++) g45[idx++] = Jw * J[cc];
+        }
+      }
+      block_sum<45>(g45, smg, part_gs + 45 * (size_t)blockIdx.x);
+    }
+  }
 }
 
+// both final sums of a speculative call in one launch
+__global__ void k_sum_parts2(const float *__restrict__ p1, int nv1, double *__restrict__ o1, const float *__restrict__ p2, int nv2,
+                             double *__restrict__ o2, int nblk) {
+  const int k = threadIdx.x;
+  if (k < nv1) {
+    double a = 0;
+#pragma unroll 8
+    for (int b = 0; b < nblk; b++) a += (double)p1[(size_t)b * nv1 + k];
+    o1[k] = a;
+  } else if (k < nv1 + nv2) {
+    const int q = k - nv1;
+    double a = 0;
+#pragma unroll 8
+    for (int b = 0; b < nblk; b++) a += (double)p2[(size_t)b * nv2 + q];
+    o2[q] = a;
+  }
+}
 // final fixed-order sum of per-block partials in double
 __global__ void k_sum_parts(const float *__restrict__ part, int nblk, int nv, double *__restrict__ out) {
   const int k = threadIdx.x;
   if (k >= nv) return;
   double a = 0;
+#pragma unroll 8
   for (int b = 0; b < nblk; b++) a += (double)part[(size_t)b * nv + k];
   out[k] = a;
 }
@@ -505,11 +575,14 @@ extern "C" int sos_tracker_calc_res(sos_tracker *T, int lvl, int newSlot, const 
   const int nblk = divup(a.n, 256);
   T->gs_cached = T->gss_cached = false;
   if (nblk > 0) {
-    k_calc_res<false><<<nblk, 256, 0, c->stream>>>(a, T->d_part);
-    k_sum_parts<<<1, 64, 0, c->stream>>>(T->d_part, nblk, 8, T->pin_o_dev);
-    if (T->hint_on) {  // speculative calcGSSSE for this pose (see sos_tracker)
-      enqueue_gs(T, lvl, affLL[0], T->hint_b0, nblk);
+    GsFuse gf = {T->fx[lvl], T->fy[lvl], affLL[0], T->hint_b0, 1.f, 0.f, 0.f, 0.f};
+    if (T->hint_on) {  // speculative calcGSSSE for this pose inside the same kernel (see sos_tracker)
+      k_calc_res<false, true><<<nblk, 256, 0, c->stream>>>(a, T->d_part, gf, T->d_part2);
+      k_sum_parts2<<<1, 64, 0, c->stream>>>(T->d_part, 8, T->pin_o_dev, T->d_part2, 45, T->pin_o_dev + 8, nblk);
       T->gs_cached = true; T->gs_lvl = lvl; T->gs_a = affLL[0]; T->gs_b0 = T->hint_b0;
+    } else {
+      k_calc_res<false, false><<<nblk, 256, 0, c->stream>>>(a, T->d_part, gf, nullptr);
+      k_sum_parts<<<1, 64, 0, c->stream>>>(T->d_part, nblk, 8, T->pin_o_dev);
     }
   }
   T->buf_lvl = lvl;
@@ -530,10 +603,13 @@ extern "C" int sos_tracker_calc_res_scale(sos_tracker *T, int lvl, int stereoSlo
   const int nblk = divup(a.n, 256);
   T->gs_cached = T->gss_cached = false;
   if (nblk > 0) {
-    k_calc_res<true><<<nblk, 256, 0, c->stream>>>(a, T->d_part);
-    k_sum_parts<<<1, 64, 0, c->stream>>>(T->d_part, nblk, 8, T->pin_o_dev);
-    if (T->hint_on) {  // calcGSSSEScale needs nothing beyond what calcResScale was given
-      enqueue_gs_scale(T, lvl, t, K1, scale, nblk);
+    GsFuse gf = {K1[0], K1[1], 0.f, 0.f, scale, t[0], t[1], t[2]};
+    if (!T->hint_on) {
+      k_calc_res<true, false><<<nblk, 256, 0, c->stream>>>(a, T->d_part, gf, nullptr);
+      k_sum_parts<<<1, 64, 0, c->stream>>>(T->d_part, nblk, 8, T->pin_o_dev);
+    } else {  // calcGSSSEScale needs nothing beyond what calcResScale was given: same kernel
+      k_calc_res<true, true><<<nblk, 256, 0, c->stream>>>(a, T->d_part, gf, T->d_part2);
+      k_sum_parts2<<<1, 64, 0, c->stream>>>(T->d_part, 8, T->pin_o_dev, T->d_part2, 3, T->pin_o_dev + 8, nblk);
       T->gss_cached = true;
       T->gss_key[0] = (float)lvl; T->gss_key[1] = t[0]; T->gss_key[2] = t[1]; T->gss_key[3] = t[2];
       T->gss_key[4] = K1[0]; T->gss_key[5] = K1[1]; T->gss_key[6] = scale;
