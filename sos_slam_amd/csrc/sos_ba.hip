@@ -1159,6 +1159,7 @@ __global__ __launch_bounds__(128) void k_reduce_all(ReduceArgs a) {
     if (tid >= SOS_TOPN) return;
     const int t0 = a.pair_tile_begin[b], t1 = a.pair_tile_begin[b + 1];
     double s = 0;
+#pragma unroll 8
     for (int t = t0; t < t1; t++) s += (double)a.top_part[(size_t)t * SOS_TOPN + tid];
     if (tid < 91) a.accTop[(size_t)b * 91 + tid] = (float)s;
     return;
@@ -1171,7 +1172,9 @@ __global__ __launch_bounds__(128) void k_reduce_all(ReduceArgs a) {
     const int h = e / per_host, q = e - h * per_host;
     const int r = q / cols, c = q - r * cols;
     double s = 0;
-    for (int k = a.host_chunk_begin[h]; k < a.host_chunk_begin[h + 1]; k++)
+    const int kc0 = a.host_chunk_begin[h], kc1 = a.host_chunk_begin[h + 1];
+#pragma unroll 8
+    for (int k = kc0; k < kc1; k++)
       s += (double)a.gram_part[(size_t)k * a.Dm * a.Dm + (size_t)r * a.Dm + c];
     const int t1 = r >> 3, i = r & 7;
     if (c < 8 * n) {
