@@ -358,6 +358,7 @@ VecX EnergyFunctional::getStitchedDeltaF() const {  // :1204-1210
 
 int EnergyFunctional::packWindow() {
   if (!packDirty) return SOS_OK;
+  const double tpk0 = now_s();
   makeIDX();
   const int n = nFrames;
   std::vector<int32_t> slots(n);
@@ -392,7 +393,9 @@ int EnergyFunctional::packWindow() {
       allResiduals.push_back(r);
     }
   }
+  const double tq = now_s();
   int rc = sos_ba_set_window(ba, n, slots.data(), (int)pts.size(), pts.data(), (int)res.size(), res.data(), nullptr, nullptr);
+  if (getenv("SOS_TIMING")) fprintf(stderr, "[packWindow] host records %.0f us, sos_ba_set_window %.0f us\n", (tq - tpk0) * 1e6, (now_s() - tq) * 1e6);
   if (rc == SOS_OK) packDirty = false;
   pointStep.assign(pts.size(), 0.f);
   return rc;
@@ -910,14 +913,19 @@ int FullSystem::prepare() {  // FS/FullSystemOptimize.cpp:316-344
           activeResiduals.push_back(r);
           r->resetOOB();
         }
+  const bool tmg = getenv("SOS_TIMING") != nullptr;
+  const double t0 = now_s();
   int rc = ef->packWindow();
   if (rc) return rc;
+  const double t1 = now_s();
   setPrecalcValues();
   rc = ef->pushState(&HCalib, true);
   if (rc) return rc;
+  const double t2 = now_s();
   sos_ba_reset_oob(ef->ba);
   linearizeAll(false);
   applyRes();
+  if (tmg) fprintf(stderr, "[prepare] packWindow %.0f us, precalc+pushState %.0f us, resetOOB+linearize+apply %.0f us\n", (t1 - t0) * 1e6, (t2 - t1) * 1e6, (now_s() - t2) * 1e6);
   return lastError;
 }
 
@@ -969,7 +977,10 @@ float FullSystem::optimize(int mnumOptIts, int *iterations) {
   if (frameHessians.size() < 2) return 0;
   if (frameHessians.size() < 3) mnumOptIts = 20;
   if (frameHessians.size() < 4) mnumOptIts = 15;
+  const bool tmg = getenv("SOS_TIMING") != nullptr;
+  const double tp0 = now_s();
   if (prepare() != SOS_OK) return NAN;
+  const double tp1 = now_s();
   int it = 0;
   for (int iteration = 0; iteration < mnumOptIts; iteration++) {
     const bool canbreak = gnIteration(iteration, iteration + 1 < mnumOptIts);
@@ -977,6 +988,7 @@ float FullSystem::optimize(int mnumOptIts, int *iterations) {
     if (canbreak && iteration >= setting_minOptIterations) break;
   }
   if (iterations) *iterations = it;
+  const double tp2 = now_s();
   // :415-425
   FrameHessian *last = frameHessians.back();
   double newStateZero[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -987,7 +999,10 @@ float FullSystem::optimize(int mnumOptIts, int *iterations) {
   ef->setAdjointsF(&HCalib);
   setPrecalcValues();
   ef->pushState(&HCalib, true);
+  const double tp3 = now_s();
   const double lastEnergy = linearizeAll(true);
+  const double tp4 = now_s();
+  if (tmg) fprintf(stderr, "[optimize] prepare %.0f us, %d iterations %.0f us, adjoints+precalc+push %.0f us, linearizeAll(true) %.0f us\n", (tp1 - tp0) * 1e6, it, (tp2 - tp1) * 1e6, (tp3 - tp2) * 1e6, (tp4 - tp3) * 1e6);
   if (!std::isfinite(lastEnergy)) isLost = true;
   // point results the viewer / tracker read: idepth_hessian
   if (!ef->allPoints.empty()) {
