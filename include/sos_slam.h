@@ -287,6 +287,10 @@ int sos_ba_newest_capacity(sos_ba *ba, int *count);
 /* all-gather of newest-frame energies for callers outside the fused calls (final linearizeAll(true)): `all` needs
  * sos_ba_newest_capacity floats; without a communicator it copies the local list */
 int sos_ba_gather_energies(sos_ba *ba, const float *local, int count, float *all, int *total);
+/* sum of a host fp64 buffer over all ranks, for the keyframe-rate exchanges (the shard-local M - Msc of
+ * marginalizePointsF must be summed before it enters HM so that every rank keeps the same prior); no-op without a
+ * communicator */
+int sos_ba_allreduce_f64(sos_ba *ba, double *buf, size_t count);
 
 /* per-point results of the accumulation: idepth_hessian (OB/AccumulatedSCHessian.cpp:50),
  * HdiF, bdSumF.  Each P floats, may be NULL. */

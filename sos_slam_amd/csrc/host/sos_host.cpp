@@ -545,8 +545,14 @@ void EnergyFunctional::marginalizePointsF() {  // :891-936, IMU off
   }
   for (EFPoint *p : allPointsToMarg) removePoint(p);
   resInM += rin;
-  for (size_t i = 0; i < dd; i++) HM[i] += prm.margWeightFac * (M[i] - Msc[i]);
-  for (int i = 0; i < dim; i++) bM[i] += prm.margWeightFac * (Mb[i] - Mbsc[i]);
+  {  // multi-GPU: every rank marginalised its own shard; the prior update is the sum over ranks (no-op on one GPU)
+    std::vector<double> upd(dd + dim);
+    for (size_t i = 0; i < dd; i++) upd[i] = M[i] - Msc[i];
+    for (int i = 0; i < dim; i++) upd[dd + i] = Mb[i] - Mbsc[i];
+    sos_ba_allreduce_f64(ba, upd.data(), upd.size());
+    for (size_t i = 0; i < dd; i++) HM[i] += prm.margWeightFac * upd[i];
+    for (int i = 0; i < dim; i++) bM[i] += prm.margWeightFac * upd[dd + i];
+  }
   EFIndicesValid = false;
   makeIDX();
 }

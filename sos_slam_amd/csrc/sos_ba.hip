@@ -2646,6 +2646,24 @@ extern "C" int sos_ba_gather_energies(sos_ba *ba, const float *local, int count,
   return SOS_OK;
 }
 
+// sum of a host fp64 buffer over all ranks (keyframe-rate exchanges such as the marginalisation prior update):
+// staged through the stitch output buffer; a no-op without a communicator
+extern "C" int sos_ba_allreduce_f64(sos_ba *ba, double *buf, size_t count) {
+  if (!ba || !buf) return SOS_ERR_ARG;
+  if (!ba->comm || count == 0) return SOS_OK;
+  SOS_HIP(hipSetDevice(ba->ctx->device));
+  hipStream_t st = ba->ctx->stream;
+  DevBuf<double> tmp;
+  if (tmp.ensure(count)) return SOS_ERR_NOMEM;
+  SOS_HIP(hipMemcpyAsync(tmp.p, buf, sizeof(double) * count, hipMemcpyHostToDevice, st));
+  const int rc = sos_comm_allreduce_sum_f64(ba->comm, tmp.p, count, st);
+  if (rc) { tmp.release(); return rc; }
+  SOS_HIP(hipMemcpyAsync(buf, tmp.p, sizeof(double) * count, hipMemcpyDeviceToHost, st));
+  SOS_HIP(hipStreamSynchronize(st));
+  tmp.release();
+  return SOS_OK;
+}
+
 extern "C" int sos_ba_newest_capacity(sos_ba *ba, int *count) {
   if (!ba || !count || !ba->have_window) return SOS_ERR_STATE;
   *count = ba->comm ? ba->newest_cap * ba->comm_size : ba->newest_count;

@@ -98,6 +98,9 @@ int sos_comm_allreduce_sum_f32(sos_comm *c, float *buf, size_t count, hipStream_
 int sos_comm_allreduce_max_i32(sos_comm *c, int *buf, size_t count, hipStream_t st) {
   return rccl_check(g_rccl.AllReduce(buf, buf, count, ncclInt32, ncclMax, c->comm, st), "ncclAllReduce(max,i32)");
 }
+int sos_comm_allreduce_sum_f64(sos_comm *c, double *buf, size_t count, hipStream_t st) {
+  return rccl_check(g_rccl.AllReduce(buf, buf, count, ncclFloat64, ncclSum, c->comm, st), "ncclAllReduce(sum,f64)");
+}
 int sos_comm_allgather_f32(sos_comm *c, const float *send, float *recv, size_t sendcount, hipStream_t st) {
   return rccl_check(g_rccl.AllGather(send, recv, sendcount, ncclFloat32, c->comm, st), "ncclAllGather(f32)");
 }

@@ -67,4 +67,5 @@ int sos_ctx_ensure_slot(sos_ctx *ctx, int slot, bool all_levels);
 // RCCL communicator (sos_comm.hip): collectives enqueued on the caller's stream
 int sos_comm_allreduce_sum_f32(sos_comm *c, float *buf, size_t count, hipStream_t st);
 int sos_comm_allreduce_max_i32(sos_comm *c, int *buf, size_t count, hipStream_t st);
+int sos_comm_allreduce_sum_f64(sos_comm *c, double *buf, size_t count, hipStream_t st);
 int sos_comm_allgather_f32(sos_comm *c, const float *send, float *recv, size_t sendcount, hipStream_t st);

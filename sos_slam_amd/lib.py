@@ -24,7 +24,7 @@ SYMBOLS = [
     "sos_ba_fix_linearization", "sos_ba_accumulate", "sos_ba_accumulate_local", "sos_ba_acc_buffer",
     "sos_ba_stitch", "sos_ba_gn_accumulate", "sos_ba_gn_step", "sos_ba_get_point_hessian", "sos_ba_resubstitute", "sos_ba_calc_lenergy",
     "sos_ba_accumulate_marg", "sos_ba_update_point_priors", "sos_ba_set_prefetch", "sos_tracker_set_gs_hint", "sos_rccl_load", "sos_rccl_unique_id", "sos_comm_create", "sos_comm_destroy", "sos_comm_size",
-    "sos_comm_rank", "sos_ba_set_comm", "sos_ba_newest_capacity", "sos_ba_gather_energies", "sos_ba_get_jacobian", "sos_ba_get_residual_flags", "sos_ba_get_JpJdF",
+    "sos_comm_rank", "sos_ba_set_comm", "sos_ba_newest_capacity", "sos_ba_gather_energies", "sos_ba_allreduce_f64", "sos_ba_get_jacobian", "sos_ba_get_residual_flags", "sos_ba_get_JpJdF",
     "sos_ba_get_res_toZeroF", "sos_ba_time_kernel", "sos_tracker_create", "sos_tracker_destroy",
     "sos_tracker_set_ref", "sos_tracker_scale_depth", "sos_tracker_get_pc", "sos_tracker_calc_res",
     "sos_tracker_calc_gs", "sos_tracker_calc_res_scale", "sos_tracker_calc_gs_scale", "sos_backend_name",
@@ -92,6 +92,7 @@ def load():
     L.sos_ba_set_comm.argtypes = [vp, vp]
     L.sos_ba_newest_capacity.argtypes = [vp, C.POINTER(ci)]
     L.sos_ba_gather_energies.argtypes = [vp, vp, ci, vp, C.POINTER(ci)]
+    L.sos_ba_allreduce_f64.argtypes = [vp, vp, C.c_size_t]
     L.sos_ba_get_jacobian.argtypes = [vp, ci, ci, vp]
     L.sos_ba_get_residual_flags.argtypes = [vp, vp, vp, vp]
     L.sos_ba_get_JpJdF.argtypes = [vp, vp]

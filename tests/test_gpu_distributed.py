@@ -33,7 +33,7 @@ def test_exchange_paths_equal_plain_run():
     dist.init_process_group("nccl", rank=0, world_size=1)
     try:
         win = synth.make_window("T6")
-        out = []
+        out, priors = [], []
         comm = sdist.NativeComm(dist, torch, 0)
         for mode in ("plain", "hooks", "native"):
             sysm = host.System.from_window(win)
@@ -45,6 +45,11 @@ def test_exchange_paths_equal_plain_run():
             pts = sysm.points()
             out.append((rmse, its, sysm.lastX().copy(), pts["idepth"].copy(),
                         [sysm.frame(f)["frameEnergyTH"] for f in range(win.n)]))
+            if mode != "hooks":  # keyframe-rate exchange: the marginalisation prior update is summed over ranks
+                ids = sysm.point_ids()
+                sel = ids[win.points["host"][ids] == 0][:16]
+                sysm.marginalize_points(sel)
+                priors.append(sysm.get_prior())
             if mode == "native":
                 # a few pipelined loop bodies as bench.py runs them (prefetched accumulate incl. the all-reduce)
                 sysm.prepare()
@@ -60,5 +65,7 @@ def test_exchange_paths_equal_plain_run():
             assert np.array_equal(a[2], b[2])
             assert np.array_equal(a[3], b[3])
             assert a[4] == b[4]
+        assert np.array_equal(priors[0][0], priors[1][0]) and np.array_equal(priors[0][1], priors[1][1])
+        assert np.abs(priors[0][0]).max() > 0
     finally:
         dist.destroy_process_group()
