@@ -565,7 +565,7 @@ __device__ __forceinline__ void bfly_step(float *v, int m, bool hi);
 // (tests/test_gpu_backend.py), only the tile sums of the fused mode use a different (still fixed) summation tree.
 // ================================================================================================
 #define L2_TILES 2
-#define L2_NS 18  // 17 sums + group-out-of-bounds flag
+#define L2_NS 19  // 17 sums + group-out-of-bounds flag + (phase 2 ->) contributes-to-the-block-sums flag
 __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(BaDev d, const float *__restrict__ frameTH, int doApply,
                                                                float *__restrict__ fuse_top, DoneSignal sg) {
   __shared__ float sJ2[L2_TILES][SOS_JPLANES * SJ_STRIDE];
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(BaDev d, const
     dCy3 = (dCy3 + 1) * SOS_SCALE_C;
     const float dxi_x[6] = {new_idepth * fxl, 0.0f, -new_idepth * cu * fxl, -cu * cv * fxl, (1 + cu * cu) * fxl, -cv * fxl};
     const float dxi_y[6] = {0.0f, new_idepth * fyl, -new_idepth * cv * fyl, -(1 + cv * cv) * fyl, cu * cv * fyl, cu * fyl};
-    if (!fuse_top) {
+    {  // per-residual planes: part of the stored tile, and the inputs of the fused block sums below
 #pragma unroll
       for (int i = 0; i < 6; i++) {
         sJr[(JP_DXI0 + i) * SJ_STRIDE + rl_] = dxi_x[i];
@@ -870,18 +870,29 @@ __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(BaDev d, const
       for (int o = 16; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
       if (rl_ == 0) d.tile_esum[tile2] = a;
     }
-    if (fuse_top) {
-      // ---- AccumulatedTopHessianSSE::addPoint<0> over the tile, 24 of the 96 values at a time
+    if (fuse_top) sS[18][c] = (valid && !isLin && activeAfter) ? 1.f : 0.f;
+  }
+  // everything the host reads (tile energies, newest-frame energies) was stored by the phase-2 wave
+  if (sg.ctr && wave == w2 && lane == 0) signal_block_done(sg);
+  if (fuse_top) {
+    // ---- AccumulatedTopHessianSSE::addPoint<0> over both tiles: four waves, each 24 of the 96 values, lane = residual
+    // (inputs from the per-residual planes phase 2 just staged); transposed butterfly over the 32 lanes of a tile
+    __syncthreads();
+    const int pw = (wave - w2) & 7;
+    if (pw < 4 && tile2 < d.ntilesA) {
+      const float *sJr = sJ2[tl2];
+      const int rl_ = rr2, c = r64;
       TopIn in;
-      in.x[0] = dCx0; in.x[1] = dCx1; in.x[2] = dCx2; in.x[3] = dCx3;
-      in.y[0] = dCy0; in.y[1] = dCy1; in.y[2] = dCy2; in.y[3] = dCy3;
 #pragma unroll
-      for (int i = 0; i < 6; i++) { in.x[4 + i] = dxi_x[i]; in.y[4 + i] = dxi_y[i]; }
-      in.a = JIdxJIdx_00; in.b = JIdxJIdx_10; in.c = JIdxJIdx_11;
-      in.jab00 = JabJIdx_00; in.jab01 = JabJIdx_01; in.jab10 = JabJIdx_10; in.jab11 = JabJIdx_11;
-      in.ab00 = JabJab_00; in.ab01 = JabJab_01; in.ab11 = JabJab_11;
-      in.JI_r0 = JI_r0; in.JI_r1 = JI_r1; in.Jab_r0 = Jab_r0; in.Jab_r1 = Jab_r1; in.rr = rr_sum;
-      const bool use = valid && !isLin && activeAfter;
+      for (int i = 0; i < 4; i++) { in.x[i] = sJr[(JP_DC0 + i) * SJ_STRIDE + rl_]; in.y[i] = sJr[(JP_DC1 + i) * SJ_STRIDE + rl_]; }
+#pragma unroll
+      for (int i = 0; i < 6; i++) { in.x[4 + i] = sJr[(JP_DXI0 + i) * SJ_STRIDE + rl_]; in.y[4 + i] = sJr[(JP_DXI1 + i) * SJ_STRIDE + rl_]; }
+      in.a = sJr[(JP_JIDX2 + 0) * SJ_STRIDE + rl_]; in.b = sJr[(JP_JIDX2 + 1) * SJ_STRIDE + rl_]; in.c = sJr[(JP_JIDX2 + 2) * SJ_STRIDE + rl_];
+      in.jab00 = sJr[(JP_JABJIDX + 0) * SJ_STRIDE + rl_]; in.jab01 = sJr[(JP_JABJIDX + 1) * SJ_STRIDE + rl_];
+      in.jab10 = sJr[(JP_JABJIDX + 2) * SJ_STRIDE + rl_]; in.jab11 = sJr[(JP_JABJIDX + 3) * SJ_STRIDE + rl_];
+      in.ab00 = sJr[(JP_JAB2 + 0) * SJ_STRIDE + rl_]; in.ab01 = sJr[(JP_JAB2 + 1) * SJ_STRIDE + rl_]; in.ab11 = sJr[(JP_JAB2 + 2) * SJ_STRIDE + rl_];
+      in.JI_r0 = sS[12][c]; in.JI_r1 = sS[13][c]; in.Jab_r0 = sS[14][c]; in.Jab_r1 = sS[15][c]; in.rr = sS[16][c];
+      const bool use = sS[18][c] != 0.f;
       const int base3 = ((rl_ >> 4) & 1) * 12 + ((rl_ >> 3) & 1) * 6 + ((rl_ >> 2) & 1) * 3;
       float *out = fuse_top + (size_t)tile2 * SOS_TOPN;
       float v[24];
@@ -897,16 +908,16 @@ __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(BaDev d, const
         v[k] += __shfl_xor(v[k], 1, 64);                                                           \
       }                                                                                            \
       if ((rl_ & 3) == 0) { out[24 * (Q) + base3] = v[0]; out[24 * (Q) + base3 + 1] = v[1]; out[24 * (Q) + base3 + 2] = v[2]; }
-      TOP_PASS(0)
-      TOP_PASS(1)
-      TOP_PASS(2)
-      TOP_PASS(3)
+      switch (pw) {
+        case 0: { TOP_PASS(0) } break;
+        case 1: { TOP_PASS(1) } break;
+        case 2: { TOP_PASS(2) } break;
+        default: { TOP_PASS(3) } break;
+      }
 #undef TOP_PASS
     }
+    return;  // the tiles stay on chip
   }
-  // everything the host reads (tile energies, newest-frame energies) was stored by the phase-2 wave
-  if (sg.ctr && wave == w2 && lane == 0) signal_block_done(sg);
-  if (fuse_top) return;  // the tiles stay on chip
   __syncthreads();
 
   // =============================== phase 3: coalesced store of the staged tiles ===============================
