@@ -1375,8 +1375,12 @@ __global__ __launch_bounds__(256) void k_sc_gram(BaDev d, const int *__restrict_
                                                  int Dm, int ld, float *__restrict__ gram_part) {
   sc_gram_body<-1>(d, blockIdx.x, chunk_pt, Dm, ld, gram_part);
 }
+// `flag` != nullptr: this kernel is queued right behind a producer whose results the host is polling for; a kernel
+// only starts after its predecessor's end-of-kernel release, so the first thread can publish the predecessor's
+// sequence number at once -- the separate k_publish launch (and its ~5 us in the chain) disappears.
 __global__ __launch_bounds__(256) void k_sc_gram_prep(BaDev d, const int *__restrict__ chunk_pt, int Dm, int ld,
-                                                      float *__restrict__ gram_part) {
+                                                      float *__restrict__ gram_part, int *flag, int seq) {
+  if (flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   sc_gram_body<1>(d, blockIdx.x, chunk_pt, Dm, ld, gram_part);
 }
 // One launch for the two independent halves of the accumulation of a window without linearised residuals:
@@ -2548,7 +2552,7 @@ static int wait_flag(sos_ba *ba, size_t flag_off, int seq) {
   return SOS_OK;
 }
 // returns the sequence number to wait for (0 = this launch does not signal)
-static int launch_lin_kernel(sos_ba *ba, const BaDev &dv, int mode, float *fuse_top, bool signal = false) {
+static int launch_lin_kernel(sos_ba *ba, const BaDev &dv, int mode, float *fuse_top, bool signal = false, bool deferPublish = false) {
   if (ba->ntilesA <= 0) return 0;
   if (lin_v1()) {
     k_linearize<<<ba->ntilesA, 256, 0, ba->ctx->stream>>>(dv, stg(ba, ba->st_th), mode, fuse_top);
@@ -2569,7 +2573,7 @@ static int launch_lin_kernel(sos_ba *ba, const BaDev &dv, int mode, float *fuse_
     }
   }
   k_linearize2<<<nb, 256 * L2_TILES, 0, ba->ctx->stream>>>(dv, stg(ba, ba->st_th), mode, fuse_top, sg);
-  if (signal && !inKernel) k_publish<<<1, 1, 0, ba->ctx->stream>>>(reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags), seq);
+  if (signal && !inKernel && !deferPublish) k_publish<<<1, 1, 0, ba->ctx->stream>>>(reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags), seq);
   return seq;
 }
 static int launch_linearize(sos_ba *ba, int doApply) {
@@ -2900,17 +2904,21 @@ extern "C" int sos_ba_accumulate(sos_ba *ba, double *H_A, double *b_A, double *H
 
 // accumulate + stitch of the whole window with the stage-2 stitch kernels writing H/b (and the residual counts)
 // straight into the device-mapped pinned block: no copy command between the last kernel and the host
-static int enqueue_gn_accumulate(sos_ba *ba, bool topDone = false) {
+static int enqueue_gn_accumulate(sos_ba *ba, bool topDone = false, int *pubFlag = nullptr, int pubSeq = 0) {
   const bool haveL = ba->ntiles > ba->ntilesA || (ba->comm && ba->anyL);
   if (topDone && ba->ntiles == ba->ntilesA) {  // the tile sums came out of the linearisation itself: only the Schur half is left
     if (ba->nchunks > 0)
-      k_sc_gram_prep<<<ba->nchunks, 256, gram_lds(ba), ba->ctx->stream>>>(ba->dev, ba->d_chunk_pt.p, ba->Dm, ba->ld, ba->d_gram_part.p);
+      k_sc_gram_prep<<<ba->nchunks, 256, gram_lds(ba), ba->ctx->stream>>>(ba->dev, ba->d_chunk_pt.p, ba->Dm, ba->ld, ba->d_gram_part.p,
+                                                                             pubFlag, pubSeq);
+    else if (pubFlag) k_publish<<<1, 1, 0, ba->ctx->stream>>>(pubFlag, pubSeq);
   } else if (ba->ntiles == ba->ntilesA && ba->ntilesA > 0 && ba->nchunks > 0) {  // top and Schur halves are independent: one launch
+    if (pubFlag) k_publish<<<1, 1, 0, ba->ctx->stream>>>(pubFlag, pubSeq);
     ensure_J(ba);
     const int nTop = divup(ba->ntilesA, 8);
     k_accumulate_fused<<<nTop + ba->nchunks, 256, gram_lds(ba), ba->ctx->stream>>>(ba->dev, nTop, ba->d_top_part.p, ba->d_chunk_pt.p,
                                                                                 ba->Dm, ba->ld, ba->d_gram_part.p);
   } else {  // linearised residuals: their point terms come from the mode-1 top pass
+    if (pubFlag) k_publish<<<1, 1, 0, ba->ctx->stream>>>(pubFlag, pubSeq);
     launch_top(ba);
     launch_sc(ba, 1);
   }
@@ -3066,7 +3074,9 @@ extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const
   }
   // pipelined iterations of a window without linearised residuals reduce the tiles on chip (no J traffic at all)
   const bool fuseTop = ba->prefetch && applyRes && ba->ntiles == ba->ntilesA;
-  int waitSeq = launch_lin_kernel(ba, dv, applyRes ? 1 : 0, fuseTop ? ba->d_top_part.p : nullptr, ba->comm == nullptr);
+  // when the next accumulate is enqueued right behind, its first kernel publishes this step's completion
+  const bool chainPublish = ba->prefetch && applyRes && ba->comm == nullptr && !lin_v1() && getenv("SOS_SIGNAL_IN_KERNEL") == nullptr && getenv("SOS_NO_CHAIN_PUBLISH") == nullptr;
+  int waitSeq = launch_lin_kernel(ba, dv, applyRes ? 1 : 0, fuseTop ? ba->d_top_part.p : nullptr, ba->comm == nullptr, chainPublish);
   if (ba->comm) {  // energies of the newest frame of ALL ranks (same frameEnergyTH everywhere), then tell the host
     const int tot = ba->newest_cap * ba->comm_size;
     const int rcc = sos_comm_allgather_f32(ba->comm, ba->d_newest_local.p, ba->d_newest_all.p, ba->newest_cap, st);
@@ -3081,7 +3091,7 @@ extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const
   double t3 = t2;
   if (ba->prefetch && applyRes) {  // the next iteration's accumulate + stitch runs while the host digests this step
     if (!waitSeq) SOS_HIP(hipEventRecord(ba->ev_step, st));
-    enqueue_gn_accumulate(ba, fuseTop);
+    enqueue_gn_accumulate(ba, fuseTop, chainPublish ? reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags) : nullptr, waitSeq);
     SOS_HIP(hipGetLastError());
     ba->acc_inflight = true;
     t3 = now_s();
@@ -3305,7 +3315,7 @@ extern "C" int sos_ba_time_kernel(sos_ba *ba, const char *kernel, const float *f
       return SOS_OK;
     }
     if (k == "sc_gram_prep") {
-      if (ba->nchunks > 0) k_sc_gram_prep<<<ba->nchunks, 256, gram_lds(ba), st>>>(ba->dev, ba->d_chunk_pt.p, ba->Dm, ba->ld, ba->d_gram_part.p);
+      if (ba->nchunks > 0) k_sc_gram_prep<<<ba->nchunks, 256, gram_lds(ba), st>>>(ba->dev, ba->d_chunk_pt.p, ba->Dm, ba->ld, ba->d_gram_part.p, nullptr, 0);
       return SOS_OK;
     }
     if (k == "apply_res") return sos_ba_apply_res(ba);
