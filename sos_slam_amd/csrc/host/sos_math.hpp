@@ -155,8 +155,8 @@ inline void ldlt_solve_ref(const std::vector<double> &A, const std::vector<doubl
 }
 
 // ---- production LDL^T (the (4+8n)-dim solve sits on the critical path of every Gauss-Newton iteration) ----------
-// Same pivoting rule (largest |diagonal|, first occurrence) and zero-pivot semantics as ldlt_solve_ref, organised for
-// speed: the matrix is held as the UPPER triangle row-major (U[j][i], j < i), so that the sub-diagonal part of
+// Diagonal pivoting like ldlt_solve_ref (largest |diagonal|), relaxed to threshold pivoting (see below), and the same
+// zero-pivot semantics, organised for speed: the matrix is held as the UPPER triangle row-major (U[j][i], j < i), so that the sub-diagonal part of
 // column k of L is the contiguous row k of U; the trailing matrix is updated once per panel of LDLT_NB pivots
 // (rank-NB update from the contiguous panel copies WT = L*D and LT = L); inside a panel the candidate diagonal is
 // kept up to date separately and a column is brought up to date only when it becomes the pivot column.
@@ -264,7 +264,11 @@ __attribute__((target("avx2,fma"))) inline void ldlt_solve(const std::vector<dou
     const int kb = std::min(LDLT_NB, n - k0), k1 = k0 + kb;
     for (int k = k0; k < k1; k++) {
       const int q = k - k0;  // pivots of this panel already eliminated
-      const int p = ldlt_argmax_abs(diag.data(), k, n);
+      int p = ldlt_argmax_abs(diag.data(), k, n);
+      // threshold pivoting: the natural pivot is kept while it is within a factor 10 of the largest candidate (element
+      // growth stays bounded by that factor); interchanges -- strided row/column swaps -- happen only when they buy
+      // stability.  Jacobi-scaled normal matrices (diagonal ~ 1) hardly ever need one.
+      if (std::fabs(diag[k]) >= 0.1 * std::fabs(diag[p])) p = k;
       perm[k] = p;  // interchange k (LAPACK ipiv style)
       if (p != k) {  // symmetric swap k <-> p (k < p) of the not yet eliminated part.  Finished L columns keep the row
                      // order they were computed in; the substitutions below replay the interchanges one by one instead
