@@ -568,7 +568,11 @@ __device__ __forceinline__ void bfly_step(float *v, int m, bool hi);
 #define L2_NS 19  // 17 sums + group-out-of-bounds flag + (phase 2 ->) contributes-to-the-block-sums flag
 __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(BaDev d, const float *__restrict__ frameTH, int doApply,
                                                                float *__restrict__ fuse_top, DoneSignal sg) {
-  __shared__ float sJ2[L2_TILES][SOS_JPLANES * SJ_STRIDE];
+  // one LDS arena: the tile staging [2][72 planes][40], and -- in fused mode, before phase 2 touches the tiles -- the
+  // transposition buffer of the 17 x 8 addends per residual: [residual 0..63][sum 0..16][pixel 0..7]
+  __shared__ __attribute__((aligned(16))) float sBig[32 * L2_TILES * 17 * 8];
+  static_assert(32 * L2_TILES * 17 * 8 >= L2_TILES * SOS_JPLANES * SJ_STRIDE, "arena holds the tile staging");
+  float(*sJ2)[SOS_JPLANES * SJ_STRIDE] = reinterpret_cast<float(*)[SOS_JPLANES * SJ_STRIDE]>(sBig);
   __shared__ float sS[L2_NS][32 * L2_TILES];
   __shared__ unsigned int sLin2[L2_TILES];
   const int tid = threadIdx.x;
@@ -666,6 +670,30 @@ __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(BaDev d, const
       sJ[(JP_JAB1 + idx) * SJ_STRIDE + rl] = jabF1;
     }
 
+    if (fuse_top) {
+      // Fused mode: the seventeen 8-pixel sums are not formed by DPP chains (7 dependent adds x 17 per wave, a third of
+      // this phase's instructions) but transposed through LDS: every pixel lane drops its 17 addends, then one thread
+      // per (residual, sum) adds the 8 addends in pattern order -- the same left-to-right sum, bit for bit.
+      float *ad = sBig + ((size_t)(tloc * 32 + rl) * 17) * 8 + idx;  // bank = (8 c + idx) mod 64: conflict-free
+      ad[0 * 8] = e_i;
+      ad[1 * 8] = hit1 * hit1;
+      ad[2 * 8] = hit2 * hit2;
+      ad[3 * 8] = hit1 * hit2;
+      ad[4 * 8] = drdA * hw * hit1;
+      ad[5 * 8] = drdA * hw * hit2;
+      ad[6 * 8] = hw * hit1;
+      ad[7 * 8] = hw * hit2;
+      ad[8 * 8] = drdA * drdA * hw * hw;
+      ad[9 * 8] = drdA * hw * hw;
+      ad[10 * 8] = hw * hw;
+      ad[11 * 8] = hw * hw * (hit1 * hit1 + hit2 * hit2);
+      ad[12 * 8] = residual * hw * hit1;
+      ad[13 * 8] = residual * hw * hit2;
+      ad[14 * 8] = residual * hw * jabF0;
+      ad[15 * 8] = residual * hw * jabF1;
+      ad[16 * 8] = residual * hw * (residual * hw);
+      if (idx == 7) sS[17][tloc * 32 + rl] = grp_oob ? 1.f : 0.f;
+    } else {
     float sm[17];
     sm[0] = seqsum8(e_i);                                  // energyLeft
     sm[1] = seqsum8(hit1 * hit1);                          // JIdxJIdx_00
@@ -690,8 +718,21 @@ __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(BaDev d, const
       for (int k = 0; k < 17; k++) sS[k][c] = sm[k];
       sS[17][c] = grp_oob ? 1.f : 0.f;
     }
+    }
   }
   __syncthreads();
+  if (fuse_top) {  // the sums: thread = (residual c, sum k), eight addends in pattern order 0..7
+    for (int item = tid; item < 32 * L2_TILES * 17; item += 256 * L2_TILES) {
+      const float4 a0 = *reinterpret_cast<const float4 *>(sBig + (size_t)item * 8);
+      const float4 a1 = *reinterpret_cast<const float4 *>(sBig + (size_t)item * 8 + 4);
+      float acc = 0.0f + a0.x;  // seqsum8 starts from 0 + p0 as well
+      acc = acc + a0.y; acc = acc + a0.z; acc = acc + a0.w;
+      acc = acc + a1.x; acc = acc + a1.y; acc = acc + a1.z; acc = acc + a1.w;
+      const int c = item / 17, k = item - c * 17;
+      sS[k][c] = acc;
+    }
+    __syncthreads();
+  }
 
   // =============================== phase 2: lane = residual (one wave) ===============================
   if (p2) {
