@@ -584,6 +584,7 @@ __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(BaDev d, const
   const int w2 = blockIdx.x & 7;  // the wave of this block that runs phase 2
   float *sJ = sJ2[tloc];
   if (tid < L2_TILES) sLin2[tid] = 0;
+  LIN_STAMP(0);
 
   // ---- phase-2 operands of this lane's residual are requested up front so their latency hides behind phase 1
   const int r64 = lane, tl2 = r64 >> 5, rr2 = r64 & 31;
@@ -627,6 +628,7 @@ __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(BaDev d, const
     const float q1 = pc->PRE_KRKiTll[3] * u_pt + pc->PRE_KRKiTll[4] * v_pt + pc->PRE_KRKiTll[5] + pc->PRE_KtTll[1] * id;
     const float q2 = pc->PRE_KRKiTll[6] * u_pt + pc->PRE_KRKiTll[7] * v_pt + pc->PRE_KRKiTll[8] + pc->PRE_KtTll[2] * id;
     const float Ku = q0 / q2, Kv = q1 / q2;
+    LIN_STAMP(1);
     const bool inb = Ku > 1.1f && Kv > 1.1f && Ku < d.wM3G && Kv < d.hM3G;
 
     // bilinear (I,dx,dy) tap (util/globalFuncs.h:68-82); addresses clamped so the loads are always legal
@@ -644,6 +646,7 @@ __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(BaDev d, const
     float hit1 = w11 * d1 + w01 * c1 + w10 * b1_ + w00 * a1;
     float hit2 = w11 * d2 + w01 * c2 + w10 * b2_ + w00 * a2;
 
+    LIN_STAMP(2);
     const bool lane_oob = !inb || !isfinite(hit0);
     const unsigned long long oobmask = __ballot(lane_oob);
     const bool grp_oob = ((oobmask >> (lane & 56)) & 0xffull) != 0;
@@ -720,7 +723,9 @@ __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(BaDev d, const
     }
     }
   }
+  LIN_STAMP(3);
   __syncthreads();
+  LIN_STAMP(4);
   if (fuse_top) {  // the sums: thread = (residual c, sum k), eight addends in pattern order 0..7
     for (int item = tid; item < 32 * L2_TILES * 17; item += 256 * L2_TILES) {
       const float4 a0 = *reinterpret_cast<const float4 *>(sBig + (size_t)item * 8);
@@ -734,6 +739,7 @@ __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(BaDev d, const
     __syncthreads();
   }
 
+  LIN_STAMP(5);
   // =============================== phase 2: lane = residual (one wave) ===============================
   if (p2) {
     float *sJr = sJ2[tl2];
@@ -919,6 +925,7 @@ __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(BaDev d, const
     // ---- AccumulatedTopHessianSSE::addPoint<0> over both tiles: four waves, each 24 of the 96 values, lane = residual
     // (inputs from the per-residual planes phase 2 just staged); transposed butterfly over the 32 lanes of a tile
     __syncthreads();
+    LIN_STAMP(6);
     const int pw = (wave - w2) & 7;
     if (pw < 4 && tile2 < d.ntilesA) {
       const float *sJr = sJ2[tl2];
@@ -957,6 +964,7 @@ __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(BaDev d, const
       }
 #undef TOP_PASS
     }
+    LIN_STAMP(7);
     return;  // the tiles stay on chip
   }
   __syncthreads();

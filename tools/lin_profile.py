@@ -19,19 +19,20 @@ L = lib.load()
 ba = C.c_void_p(host.load().sosf_ba(sysm.h_))
 th = np.array([sysm.frame(f)["frameEnergyTH"] for f in range(win.n)], np.float32)
 ms = C.c_float(0)
-for name in (sys.argv[2:] or ["linearize", "linearize_fused"]):
+for name in (sys.argv[2:] or ["linearize_fused"]):
     L.sos_ba_time_kernel(ba, name.encode(), th.ctypes.data_as(C.c_void_p), 1, C.byref(ms))
     nb = min(8192, (win.R + 31) // 32 + 200)
     out = np.zeros((nb, 8), dtype=np.uint64)
     L.sos_debug_lin_prof(out.ctypes.data_as(C.c_void_p), nb)
     out = out[out[:, 0] > 0].astype(np.int64)
     t0 = out[:, 0].min()
-    rel = (out[:, :7] - t0) / 100.0  # s_memtime ticks at 100 MHz -> us
+    ncol = 8
+    rel = (out[:, :ncol] - t0) * 1.0  # s_memtime ticks (shader clock cycles); clocks of different XCDs are not aligned
     print(name, "blocks", len(out), "avg launch us", round(ms.value * 1e3, 2))
-    names = ["start", "L1 loads", "taps", "pixel+dpp", "leader", "barrier", "end"]
+    names = ["start", "L1 loads", "taps", "phase1 end", "barrier1", "sums+barrier2", "phase2+barrier3", "end"]
     for k, nm in enumerate(names):
         col = rel[:, k]
         print(f"  {nm:10s} min {col.min():7.2f} p50 {np.median(col):7.2f} p90 {np.percentile(col, 90):7.2f} max {col.max():7.2f}")
     d = np.diff(rel, axis=1)
-    print("  per-phase median us:", [round(float(np.median(d[:, k])), 2) for k in range(6)])
+    print("  per-phase median cycles:", [int(np.median(d[:, k])) for k in range(ncol - 1)], "block total", int(np.median(rel[:, ncol - 1] - rel[:, 0])))
 sysm.close()
