@@ -19,6 +19,8 @@
 //   * all reductions are fixed-shape trees: results are run-to-run deterministic.
 #include "sos_common.h"
 
+#include <chrono>
+
 #include <algorithm>
 #include <cmath>
 #include <unordered_map>
@@ -43,7 +45,8 @@ struct sos_tracker {
   bool have_ref = false;
   // results come back through device-mapped pinned memory (no copy command per call): [0,8) calcRes sums,
   // [8,53) calcGSSSE sums
-  double *pin_o = nullptr, *pin_o_dev = nullptr;
+  double *pin_o = nullptr, *pin_o_dev = nullptr;  // [60] doubles as the completion flag (int)
+  int seq = 0;
   float *d_part2 = nullptr;  // per-block partials of the speculative calcGSSSE
   // Speculation: the LM loops call calcRes and, when the step is accepted (the common case), calcGSSSE on the same
   // buffers.  With a hint for b0 (sos_tracker_set_gs_hint) calcRes also runs calcGSSSE behind itself, and the
@@ -88,6 +91,7 @@ extern "C" int sos_tracker_create(sos_ctx *ctx, const sos_params *prm, sos_track
   SOS_HIP(hipMalloc(&T->d_part2, sizeof(float) * 48 * T->maxblk));
   SOS_HIP(hipHostMalloc((void **)&T->pin_o, sizeof(double) * 64, hipHostMallocMapped));
   SOS_HIP(hipHostGetDevicePointer((void **)&T->pin_o_dev, T->pin_o, 0));
+  memset(T->pin_o, 0, sizeof(double) * 64);
   SOS_HIP(hipMalloc(&T->d_pix, sizeof(int) * n0));
   SOS_HIP(hipMalloc(&T->d_pixv, sizeof(float) * 2 * n0));
   *out = T;
@@ -487,8 +491,10 @@ __global__ __launch_bounds__(256) void k_calc_res(ResArgs a, float *__restrict__
 }
 
 // both final sums of a speculative call in one launch
+// These two kernels are ONE wave each; their results go to device-mapped host memory.  A system-scope fence executed by
+// the whole wave orders every lane's stores before lane 0 publishes the sequence number the host is polling for.
 __global__ void k_sum_parts2(const float *__restrict__ p1, int nv1, double *__restrict__ o1, const float *__restrict__ p2, int nv2,
-                             double *__restrict__ o2, int nblk) {
+                             double *__restrict__ o2, int nblk, int *flag, int seq) {
   const int k = threadIdx.x;
   if (k < nv1) {
     double a = 0;
@@ -502,15 +508,25 @@ __global__ void k_sum_parts2(const float *__restrict__ p1, int nv1, double *__re
     for (int b = 0; b < nblk; b++) a += (double)p2[(size_t)b * nv2 + q];
     o2[q] = a;
   }
+  if (flag) {
+    __threadfence_system();
+    if (k == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 // final fixed-order sum of per-block partials in double
-__global__ void k_sum_parts(const float *__restrict__ part, int nblk, int nv, double *__restrict__ out) {
+__global__ void k_sum_parts(const float *__restrict__ part, int nblk, int nv, double *__restrict__ out, int *flag = nullptr,
+                            int seq = 0) {
   const int k = threadIdx.x;
-  if (k >= nv) return;
-  double a = 0;
+  if (k < nv) {
+    double a = 0;
 #pragma unroll 8
-  for (int b = 0; b < nblk; b++) a += (double)part[(size_t)b * nv + k];
-  out[k] = a;
+    for (int b = 0; b < nblk; b++) a += (double)part[(size_t)b * nv + k];
+    out[k] = a;
+  }
+  if (flag) {
+    __threadfence_system();
+    if (k == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 static void fill_common(sos_tracker *T, ResArgs &a, int lvl, const float *RKi, const float *t, float scale, bool scaleMode,
@@ -537,7 +553,21 @@ static void enqueue_gs_scale(sos_tracker *T, int lvl, const float *t, const floa
 static int finish_res(sos_tracker *T, int nblk, double *rs) {
   hipStream_t st = T->ctx->stream;
   SOS_HIP(hipGetLastError());
-  SOS_HIP(hipStreamSynchronize(st));
+  if (nblk > 0) {  // poll the flag the last (single-wave) kernel publishes; stream sync as the 50 ms fallback
+    int *flag = reinterpret_cast<int *>(T->pin_o + 60);
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != T->seq) {
+      __builtin_ia32_pause();
+      if ((++spins & 4095u) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.05) {
+        SOS_HIP(hipStreamSynchronize(st));
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != T->seq) return SOS_ERR_HIP;
+        break;
+      }
+    }
+  } else {
+    SOS_HIP(hipStreamSynchronize(st));
+  }
   double o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (nblk > 0) memcpy(o, T->pin_o, sizeof(o));
   const int numTermsInE = (int)o[1], numWarped = (int)o[2], numSaturated = (int)o[3];
@@ -578,11 +608,12 @@ extern "C" int sos_tracker_calc_res(sos_tracker *T, int lvl, int newSlot, const 
     GsFuse gf = {T->fx[lvl], T->fy[lvl], affLL[0], T->hint_b0, 1.f, 0.f, 0.f, 0.f};
     if (T->hint_on) {  // speculative calcGSSSE for this pose inside the same kernel (see sos_tracker)
       k_calc_res<false, true><<<nblk, 256, 0, c->stream>>>(a, T->d_part, gf, T->d_part2);
-      k_sum_parts2<<<1, 64, 0, c->stream>>>(T->d_part, 8, T->pin_o_dev, T->d_part2, 45, T->pin_o_dev + 8, nblk);
+      k_sum_parts2<<<1, 64, 0, c->stream>>>(T->d_part, 8, T->pin_o_dev, T->d_part2, 45, T->pin_o_dev + 8, nblk,
+                                           reinterpret_cast<int *>(T->pin_o_dev + 60), ++T->seq);
       T->gs_cached = true; T->gs_lvl = lvl; T->gs_a = affLL[0]; T->gs_b0 = T->hint_b0;
     } else {
       k_calc_res<false, false><<<nblk, 256, 0, c->stream>>>(a, T->d_part, gf, nullptr);
-      k_sum_parts<<<1, 64, 0, c->stream>>>(T->d_part, nblk, 8, T->pin_o_dev);
+      k_sum_parts<<<1, 64, 0, c->stream>>>(T->d_part, nblk, 8, T->pin_o_dev, reinterpret_cast<int *>(T->pin_o_dev + 60), ++T->seq);
     }
   }
   T->buf_lvl = lvl;
@@ -606,10 +637,11 @@ extern "C" int sos_tracker_calc_res_scale(sos_tracker *T, int lvl, int stereoSlo
     GsFuse gf = {K1[0], K1[1], 0.f, 0.f, scale, t[0], t[1], t[2]};
     if (!T->hint_on) {
       k_calc_res<true, false><<<nblk, 256, 0, c->stream>>>(a, T->d_part, gf, nullptr);
-      k_sum_parts<<<1, 64, 0, c->stream>>>(T->d_part, nblk, 8, T->pin_o_dev);
+      k_sum_parts<<<1, 64, 0, c->stream>>>(T->d_part, nblk, 8, T->pin_o_dev, reinterpret_cast<int *>(T->pin_o_dev + 60), ++T->seq);
     } else {  // calcGSSSEScale needs nothing beyond what calcResScale was given: same kernel
       k_calc_res<true, true><<<nblk, 256, 0, c->stream>>>(a, T->d_part, gf, T->d_part2);
-      k_sum_parts2<<<1, 64, 0, c->stream>>>(T->d_part, 8, T->pin_o_dev, T->d_part2, 3, T->pin_o_dev + 8, nblk);
+      k_sum_parts2<<<1, 64, 0, c->stream>>>(T->d_part, 8, T->pin_o_dev, T->d_part2, 3, T->pin_o_dev + 8, nblk,
+                                           reinterpret_cast<int *>(T->pin_o_dev + 60), ++T->seq);
       T->gss_cached = true;
       T->gss_key[0] = (float)lvl; T->gss_key[1] = t[0]; T->gss_key[2] = t[1]; T->gss_key[3] = t[2];
       T->gss_key[4] = K1[0]; T->gss_key[5] = K1[1]; T->gss_key[6] = scale;
