@@ -85,7 +85,7 @@ extern "C" int sos_tracker_create(sos_ctx *ctx, const sos_params *prm, sos_track
   size_t n0 = (size_t)ctx->w * ctx->h;
   for (int k = 0; k < 8; k++) SOS_HIP(hipMalloc(&T->buf[k], sizeof(float) * (n0 + 4)));
   T->maxblk = divup((int)n0, 256) + 1;
-  SOS_HIP(hipMalloc(&T->d_counts, sizeof(int) * (T->maxblk + 1)));
+  SOS_HIP(hipMalloc(&T->d_counts, sizeof(int) * 2 * (T->maxblk + 8)));  // all levels side by side
   SOS_HIP(hipMalloc(&T->d_part, sizeof(float) * 48 * T->maxblk));
   SOS_HIP(hipMalloc(&T->d_out, sizeof(double) * 64));
   SOS_HIP(hipMalloc(&T->d_part2, sizeof(float) * 48 * T->maxblk));
@@ -208,15 +208,35 @@ __global__ __launch_bounds__(256) void k_normalize(float *__restrict__ idepth, f
     pcol[o] = col;
   }
 }
-__global__ void k_scan_counts(int *counts, int n) {  // exclusive scan in place; counts[n] = total
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  int a = 0;
-  for (int i = 0; i < n; i++) {
-    int c = counts[i];
-    counts[i] = a;
-    a += c;
+// exclusive scan of the per-block counts in place (order-preserving compaction offsets); counts[n] = total, which
+// also goes to `total_out` (device-mapped host memory).  One block of 1024 threads, chunks of 1024 with a carry.
+__global__ __launch_bounds__(1024) void k_scan_counts(int *counts, int n, int *total_out) {
+  __shared__ int sm[1024];
+  __shared__ int carry;
+  const int tid = threadIdx.x;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + tid;
+    const int v = i < n ? counts[i] : 0;
+    sm[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {  // inclusive Hillis-Steele scan
+      const int t = tid >= o ? sm[tid - o] : 0;
+      __syncthreads();
+      sm[tid] += t;
+      __syncthreads();
+    }
+    const int c0 = carry;
+    if (i < n) counts[i] = c0 + sm[tid] - v;  // exclusive
+    __syncthreads();
+    if (tid == 1023) carry = c0 + sm[1023];
+    __syncthreads();
   }
-  counts[n] = a;
+  if (tid == 0) {
+    counts[n] = carry;
+    if (total_out) *total_out = carry;
+  }
 }
 __global__ void k_scale_depth(float *__restrict__ pid, int n, float scale) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -283,17 +303,23 @@ extern "C" int sos_tracker_set_ref(sos_tracker *T, const sos_calib *calib, int r
     const int span = npx - 2 * T->w[l];
     if (span > 0) k_dilate<<<divup(span, 256), 256, 0, st>>>(T->idepth[l], T->wsum[l], T->wbak[l], T->w[l], T->h[l], l < 2);
   }
-  for (int l = 0; l < T->levels; l++) {
-    const int npx = T->w[l] * T->h[l];
-    const int nb = divup(npx, 256);
-    const float *ref = c->dI[refSlot][l];
-    k_normalize<<<nb, 256, 0, st>>>(T->idepth[l], T->wsum[l], ref, T->w[l], T->h[l], 0, T->d_counts, nullptr, nullptr,
-                                    nullptr, nullptr);
-    k_scan_counts<<<1, 64, 0, st>>>(T->d_counts, nb);
-    k_normalize<<<nb, 256, 0, st>>>(T->idepth[l], T->wsum[l], ref, T->w[l], T->h[l], 1, T->d_counts, T->pc_u[l],
-                                    T->pc_v[l], T->pc_idepth[l], T->pc_color[l]);
-    SOS_HIP(hipMemcpyAsync(&T->pc_n[l], T->d_counts + nb, sizeof(int), hipMemcpyDeviceToHost, st));
+  {
+    int *tot_dev = reinterpret_cast<int *>(T->pin_o_dev + 61);  // 6 ints in the tail of the mapped result block
+    int off = 0;
+    for (int l = 0; l < T->levels; l++) {  // every level has its own slice of the count buffer: one sync for all levels
+      const int npx = T->w[l] * T->h[l];
+      const int nb = divup(npx, 256);
+      const float *ref = c->dI[refSlot][l];
+      int *cnt = T->d_counts + off;
+      k_normalize<<<nb, 256, 0, st>>>(T->idepth[l], T->wsum[l], ref, T->w[l], T->h[l], 0, cnt, nullptr, nullptr, nullptr, nullptr);
+      k_scan_counts<<<1, 1024, 0, st>>>(cnt, nb, tot_dev + l);
+      k_normalize<<<nb, 256, 0, st>>>(T->idepth[l], T->wsum[l], ref, T->w[l], T->h[l], 1, cnt, T->pc_u[l], T->pc_v[l],
+                                      T->pc_idepth[l], T->pc_color[l]);
+      off += nb + 1;
+    }
     SOS_HIP(hipStreamSynchronize(st));
+    const int *tot = reinterpret_cast<const int *>(T->pin_o + 61);
+    for (int l = 0; l < T->levels; l++) T->pc_n[l] = tot[l];
   }
   SOS_HIP(hipGetLastError());
   if (pc_n_out)
