@@ -374,6 +374,63 @@ int sos_tracker_calc_gs_scale(sos_tracker *trk, int lvl, const float *t, const f
                               float scale, float *H, float *b);
 
 /* library identification: returns "hip-gfx950" */
+/* ------------------------------------------------------------------------------------------------
+ * immature points (first part): construction and epipolar tracing
+ * ---------------------------------------------------------------------------------------------- */
+
+/* ImmaturePointStatus (FS/ImmaturePoint.h:40-47) */
+#define SOS_IPS_GOOD 0
+#define SOS_IPS_OOB 1
+#define SOS_IPS_OUTLIER 2
+#define SOS_IPS_SKIPPED 3
+#define SOS_IPS_BADCONDITION 4
+#define SOS_IPS_UNINITIALIZED 5
+
+/* the globals traceOn / the constructor read (util/settings.cpp:82-83,118,128-143) */
+typedef struct sos_trace_params {
+  float maxPixSearch;           /* 0.027 */
+  float stepsize;               /* setting_trace_stepsize = 1 */
+  float GNThreshold;            /* 0.1 */
+  float extraSlackOnTH;         /* 1.2 */
+  float slackInterval;          /* 1.5 */
+  float minImprovementFactor;   /* 2 */
+  float huberTH;                /* 9 */
+  float outlierTHSumComponent;  /* 50*50 */
+  float outlierTH;              /* 12*12 */
+  float overallEnergyTHWeight;  /* 1 */
+  int32_t GNIterations;         /* 3 */
+  int32_t minTraceTestRadius;   /* 2 */
+} sos_trace_params;
+
+/* the fields of ImmaturePoint the tracing reads and writes (FS/ImmaturePoint.h:54-100); 128 bytes */
+typedef struct sos_immature {
+  float u, v;
+  float idepth_min, idepth_max;
+  float color[SOS_PATTERN_NUM];
+  float weights[SOS_PATTERN_NUM];
+  float gradH[4];                /* (0,0) (0,1) (1,0) (1,1) */
+  float energyTH;
+  float quality;
+  float lastTraceUV[2];
+  float lastTracePixelInterval;
+  int32_t lastTraceStatus;       /* SOS_IPS_* */
+  int32_t pad[2];
+} sos_immature;
+
+/* new ImmaturePoint(u, v, host, ...) for `count` pixel positions of the frame in image slot hostSlot
+ * (FS/ImmaturePoint.cpp:30-59; called from FullSystem::makeNewTraces, FS/FullSystem.cpp:1080-1097) */
+int sos_immature_init(sos_ctx *ctx, const sos_trace_params *prm, int hostSlot, int count, const int32_t *u,
+                      const int32_t *v, sos_immature *out);
+/* ph->traceOn(fh, KRKi, Kt, aff, ...) over the `count` immature points of one host frame against the frame in
+ * frameSlot: the inner loop of FullSystem::traceNewCoarse (FS/FullSystem.cpp:323-350; FS/ImmaturePoint.cpp:70-415).
+ * KRKi (3x3 row-major), Kt, aff are computed by the caller exactly as FS/FullSystem.cpp:326-332.  pts is in/out. */
+int sos_immature_trace(sos_ctx *ctx, const sos_trace_params *prm, int frameSlot, int count, sos_immature *pts,
+                       const float *KRKi, const float *Kt, const float *aff);
+/* the whole of FullSystem::traceNewCoarse (both loops of FS/FullSystem.cpp:323-350) in one launch: point i belongs to
+ * keyframe hostOfPoint[i] (0..nhosts-1); KRKi / Kt / aff hold nhosts entries of 9 / 3 / 2 floats */
+int sos_immature_trace_all(sos_ctx *ctx, const sos_trace_params *prm, int frameSlot, int count, sos_immature *pts,
+                           const int32_t *hostOfPoint, int nhosts, const float *KRKi, const float *Kt, const float *aff);
+
 const char *sos_backend_name(void);
 
 #ifdef __cplusplus

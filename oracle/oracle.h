@@ -153,4 +153,10 @@ float orc_tracker_optimize_scale(orc_tracker *T, float *const *stereo_dI, const 
 #ifdef __cplusplus
 }
 #endif
+/* ---- immature points (orc_immature.c): ImmaturePoint constructor and traceOn ------------------------------------ */
+void orc_immature_init(const sos_trace_params *prm, const float *host_dI_aos3, int w, int h, int count, const int32_t *u,
+                       const int32_t *v, sos_immature *out);
+void orc_immature_trace(const sos_trace_params *prm, const float *frame_dI_aos3, int w, int h, int count, sos_immature *pts,
+                        const float *KRKi, const float *Kt, const float *aff);
+
 #endif

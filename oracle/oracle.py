@@ -72,6 +72,8 @@ def lib():
             getattr(L, name).restype = vp
             getattr(L, name).argtypes = [vp]
         L.orc_host_get_HM.argtypes = [vp, vp, vp]
+        L.orc_immature_init.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
+        L.orc_immature_trace.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
         L.orc_host_get_frame_prior.argtypes = [vp, C.c_int, vp, vp]
         L.orc_host_drop_points.argtypes = [vp, vp, C.c_int]
         L.orc_host_marginalize_points.argtypes = [vp, vp, C.c_int, vp]
@@ -137,6 +139,28 @@ def make_images(img, gammaB=None):
     gb = None if gammaB is None else np.ascontiguousarray(gammaB, dtype=np.float32)
     lib().orc_make_images(_p(img), w, h, _p(gb), lv, pd, pa)
     return dI, ab
+
+
+def immature_init(prm, host_dI0, u, v):
+    """ImmaturePoint constructor over pixel positions (u, v) of a host frame (level-0 dI, (h, w, 3))."""
+    from sos_slam_amd.records import IMMATURE_DTYPE
+    dI = np.ascontiguousarray(host_dI0, dtype=np.float32)
+    h, w = dI.shape[:2]
+    u = np.ascontiguousarray(u, dtype=np.int32)
+    v = np.ascontiguousarray(v, dtype=np.int32)
+    out = np.zeros(len(u), dtype=IMMATURE_DTYPE)
+    lib().orc_immature_init(C.byref(prm), _p(dI), w, h, len(u), _p(u), _p(v), _p(out))
+    return out
+
+
+def immature_trace(prm, frame_dI0, pts, KRKi, Kt, aff):
+    """ImmaturePoint::traceOn over all points against one frame; returns the updated records."""
+    dI = np.ascontiguousarray(frame_dI0, dtype=np.float32)
+    h, w = dI.shape[:2]
+    pts = np.ascontiguousarray(pts).copy()
+    a = [np.ascontiguousarray(x, dtype=np.float32) for x in (KRKi, Kt, aff)]
+    lib().orc_immature_trace(C.byref(prm), _p(dI), w, h, len(pts), _p(pts), *[_p(x) for x in a])
+    return pts
 
 
 class OracleWindow:

@@ -1,0 +1,252 @@
+/* oracle/orc_immature.c -- TEST INFRASTRUCTURE (CPU oracle, see oracle.h; PARITY UNPINNED).
+ *
+ * Restatement of the immature-point front of the window:
+ *   ImmaturePoint::ImmaturePoint   FS/ImmaturePoint.cpp:30-59   (pattern colours, weights, gradH, energyTH)
+ *   ImmaturePoint::traceOn         FS/ImmaturePoint.cpp:70-415  (epipolar search, GN refinement, new idepth interval)
+ * with getInterpolatedElement31 / 33 / 33BiLin of U/globalFuncs.h:68-82,122-136,161-182.  fp32, no FMA contraction,
+ * sums in source order -- the convention of the rest of the oracle. */
+#include <math.h>
+#include <string.h>
+
+#include "oracle.h"
+
+static const int PATTERN[8][2] = {{0, -2}, {-1, -1}, {1, -1}, {-2, 0}, {0, 0}, {2, 0}, {-1, 1}, {0, 2}}; /* U/settings.h:64-75 staticPattern[8] */
+
+static inline int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+/* taps are clamped to the image (the reference reads whatever lies there; the search keeps 4 px of margin) */
+static inline const float *texel(const float *dI, int ix, int iy, int w, int h) {
+  return dI + 3 * ((size_t)clampi(ix, 0, w - 1) + (size_t)clampi(iy, 0, h - 1) * w);
+}
+static float interp31(const float *dI, float x, float y, int w, int h) {
+  int ix = (int)x, iy = (int)y;
+  float dx = x - ix, dy = y - iy, dxdy = dx * dy;
+  return dxdy * texel(dI, ix + 1, iy + 1, w, h)[0] + (dy - dxdy) * texel(dI, ix, iy + 1, w, h)[0] +
+         (dx - dxdy) * texel(dI, ix + 1, iy, w, h)[0] + (1 - dx - dy + dxdy) * texel(dI, ix, iy, w, h)[0];
+}
+static void interp33(const float *dI, float x, float y, int w, int h, float *o) {
+  int ix = (int)x, iy = (int)y;
+  float dx = x - ix, dy = y - iy, dxdy = dx * dy;
+  const float *a = texel(dI, ix, iy, w, h), *b = texel(dI, ix + 1, iy, w, h), *c = texel(dI, ix, iy + 1, w, h),
+              *d = texel(dI, ix + 1, iy + 1, w, h);
+  for (int k = 0; k < 3; k++) o[k] = dxdy * d[k] + (dy - dxdy) * c[k] + (dx - dxdy) * b[k] + (1 - dx - dy + dxdy) * a[k];
+}
+static void interp33bilin(const float *dI, float x, float y, int w, int h, float *o) {
+  int ix = (int)x, iy = (int)y;
+  float tl = texel(dI, ix, iy, w, h)[0], tr = texel(dI, ix + 1, iy, w, h)[0], bl = texel(dI, ix, iy + 1, w, h)[0],
+        br = texel(dI, ix + 1, iy + 1, w, h)[0];
+  float dx = x - ix, dy = y - iy;
+  float topInt = dx * tr + (1 - dx) * tl, botInt = dx * br + (1 - dx) * bl;
+  float leftInt = dy * bl + (1 - dy) * tl, rightInt = dy * br + (1 - dy) * tr;
+  o[0] = dx * rightInt + (1 - dx) * leftInt;
+  o[1] = rightInt - leftInt;
+  o[2] = botInt - topInt;
+}
+
+void orc_immature_init(const sos_trace_params *P, const float *host_dI, int w, int h, int count, const int32_t *u,
+                       const int32_t *v, sos_immature *out) { /* FS/ImmaturePoint.cpp:30-59 */
+  for (int i = 0; i < count; i++) {
+    sos_immature *p = &out[i];
+    memset(p, 0, sizeof(*p));
+    p->u = (float)u[i];
+    p->v = (float)v[i];
+    p->idepth_min = 0;
+    p->idepth_max = NAN;
+    p->lastTraceStatus = SOS_IPS_UNINITIALIZED;
+    float g00 = 0, g01 = 0, g10 = 0, g11 = 0;
+    int bad = 0;
+    for (int idx = 0; idx < 8; idx++) {
+      float ptc[3];
+      interp33bilin(host_dI, p->u + PATTERN[idx][0], p->v + PATTERN[idx][1], w, h, ptc);
+      p->color[idx] = ptc[0];
+      if (!isfinite(p->color[idx])) {
+        p->energyTH = NAN;
+        bad = 1;
+        break;
+      }
+      g00 += ptc[1] * ptc[1]; g01 += ptc[1] * ptc[2]; g10 += ptc[2] * ptc[1]; g11 += ptc[2] * ptc[2];
+      p->weights[idx] = sqrtf(P->outlierTHSumComponent / (P->outlierTHSumComponent + (ptc[1] * ptc[1] + ptc[2] * ptc[2])));
+    }
+    p->gradH[0] = g00; p->gradH[1] = g01; p->gradH[2] = g10; p->gradH[3] = g11;
+    if (bad) continue; /* the reference returns from the constructor: quality stays unset */
+    p->energyTH = 8 * P->outlierTH;
+    p->energyTH *= P->overallEnergyTHWeight * P->overallEnergyTHWeight;
+    p->quality = 10000;
+  }
+}
+
+static int trace_one(const sos_trace_params *P, const float *dI, int w, int h, sos_immature *p, const float *K, const float *Kt,
+                     const float *aff) { /* FS/ImmaturePoint.cpp:70-415 */
+#define OOB_RETURN(st)              \
+  do {                              \
+    p->lastTraceUV[0] = -1;         \
+    p->lastTraceUV[1] = -1;         \
+    p->lastTracePixelInterval = 0;  \
+    return p->lastTraceStatus = (st); \
+  } while (0)
+  if (p->lastTraceStatus == SOS_IPS_OOB) return p->lastTraceStatus;
+  float maxPixSearch = (w + h) * P->maxPixSearch;
+  float pr0 = K[0] * p->u + K[1] * p->v + K[2] * 1.0f, pr1 = K[3] * p->u + K[4] * p->v + K[5] * 1.0f,
+        pr2 = K[6] * p->u + K[7] * p->v + K[8] * 1.0f;
+  float ptpMin0 = pr0 + Kt[0] * p->idepth_min, ptpMin1 = pr1 + Kt[1] * p->idepth_min, ptpMin2 = pr2 + Kt[2] * p->idepth_min;
+  float uMin = ptpMin0 / ptpMin2, vMin = ptpMin1 / ptpMin2;
+  if (!(uMin > 4 && vMin > 4 && uMin < w - 5 && vMin < h - 5)) OOB_RETURN(SOS_IPS_OOB);
+  float dist, uMax, vMax;
+  if (isfinite(p->idepth_max)) {
+    float q0 = pr0 + Kt[0] * p->idepth_max, q1 = pr1 + Kt[1] * p->idepth_max, q2 = pr2 + Kt[2] * p->idepth_max;
+    uMax = q0 / q2;
+    vMax = q1 / q2;
+    if (!(uMax > 4 && vMax > 4 && uMax < w - 5 && vMax < h - 5)) OOB_RETURN(SOS_IPS_OOB);
+    dist = (uMin - uMax) * (uMin - uMax) + (vMin - vMax) * (vMin - vMax);
+    dist = sqrtf(dist);
+    if (dist < P->slackInterval) {
+      p->lastTraceUV[0] = (uMax + uMin) * 0.5f;
+      p->lastTraceUV[1] = (vMax + vMin) * 0.5f;
+      p->lastTracePixelInterval = dist;
+      return p->lastTraceStatus = SOS_IPS_SKIPPED;
+    }
+  } else {
+    dist = maxPixSearch;
+    float q0 = pr0 + Kt[0] * 0.01f, q1 = pr1 + Kt[1] * 0.01f, q2 = pr2 + Kt[2] * 0.01f;
+    uMax = q0 / q2;
+    vMax = q1 / q2;
+    float ddx = uMax - uMin, ddy = vMax - vMin;
+    float d = 1.0f / sqrtf(ddx * ddx + ddy * ddy);
+    uMax = uMin + dist * ddx * d;
+    vMax = vMin + dist * ddy * d;
+    if (!(uMax > 4 && vMax > 4 && uMax < w - 5 && vMax < h - 5)) OOB_RETURN(SOS_IPS_OOB);
+  }
+  if (!(p->idepth_min < 0 || (ptpMin2 > 0.75f && ptpMin2 < 1.5f))) OOB_RETURN(SOS_IPS_OOB);
+
+  float dx = P->stepsize * (uMax - uMin), dy = P->stepsize * (vMax - vMin);
+  const float *G = p->gradH;
+  float a = (dx * G[0] + dy * G[2]) * dx + (dx * G[1] + dy * G[3]) * dy;
+  float b = (dy * G[0] + (-dx) * G[2]) * dy + (dy * G[1] + (-dx) * G[3]) * (-dx);
+  float errorInPixel = 0.2f + 0.2f * (a + b) / a;
+  if (errorInPixel * P->minImprovementFactor > dist && isfinite(p->idepth_max)) {
+    p->lastTraceUV[0] = (uMax + uMin) * 0.5f;
+    p->lastTraceUV[1] = (vMax + vMin) * 0.5f;
+    p->lastTracePixelInterval = dist;
+    return p->lastTraceStatus = SOS_IPS_BADCONDITION;
+  }
+  if (errorInPixel > 10) errorInPixel = 10;
+
+  dx /= dist;
+  dy /= dist;
+  if (dist > maxPixSearch) {
+    uMax = uMin + maxPixSearch * dx;
+    vMax = vMin + maxPixSearch * dy;
+    dist = maxPixSearch;
+  }
+  int numSteps = (int)(1.9999f + dist / P->stepsize);
+  float randShift = uMin * 1000 - floorf(uMin * 1000);
+  float ptx = uMin - randShift * dx, pty = vMin - randShift * dy;
+  float rp[8][2];
+  for (int idx = 0; idx < 8; idx++) {
+    rp[idx][0] = K[0] * PATTERN[idx][0] + K[1] * PATTERN[idx][1];
+    rp[idx][1] = K[3] * PATTERN[idx][0] + K[4] * PATTERN[idx][1];
+  }
+  if (!isfinite(dx) || !isfinite(dy)) OOB_RETURN(SOS_IPS_OOB);
+
+  float errors[100];
+  float bestU = 0, bestV = 0, bestEnergy = 1e10f;
+  int bestIdx = -1;
+  if (numSteps >= 100) numSteps = 99;
+  for (int i = 0; i < numSteps; i++) {
+    float energy = 0;
+    for (int idx = 0; idx < 8; idx++) {
+      float hitColor = interp31(dI, (float)(ptx + rp[idx][0]), (float)(pty + rp[idx][1]), w, h);
+      if (!isfinite(hitColor)) {
+        energy += 1e5f;
+        continue;
+      }
+      float residual = hitColor - (float)(aff[0] * p->color[idx] + aff[1]);
+      float hw = fabsf(residual) < P->huberTH ? 1 : P->huberTH / fabsf(residual);
+      energy += hw * residual * residual * (2 - hw);
+    }
+    errors[i] = energy;
+    if (energy < bestEnergy) {
+      bestU = ptx;
+      bestV = pty;
+      bestEnergy = energy;
+      bestIdx = i;
+    }
+    ptx += dx;
+    pty += dy;
+  }
+  float secondBest = 1e10f;
+  for (int i = 0; i < numSteps; i++)
+    if ((i < bestIdx - P->minTraceTestRadius || i > bestIdx + P->minTraceTestRadius) && errors[i] < secondBest) secondBest = errors[i];
+  float newQuality = secondBest / bestEnergy;
+  if (newQuality < p->quality || numSteps > 10) p->quality = newQuality;
+
+  float uBak = bestU, vBak = bestV, gnstepsize = 1, stepBack = 0;
+  if (P->GNIterations > 0) bestEnergy = 1e5f;
+  for (int it = 0; it < P->GNIterations; it++) {
+    float H = 1, bb = 0, energy = 0;
+    for (int idx = 0; idx < 8; idx++) {
+      float hit[3];
+      interp33(dI, (float)(bestU + rp[idx][0]), (float)(bestV + rp[idx][1]), w, h, hit);
+      if (!isfinite(hit[0])) {
+        energy += 1e5f;
+        continue;
+      }
+      float residual = hit[0] - (aff[0] * p->color[idx] + aff[1]);
+      float dResdDist = dx * hit[1] + dy * hit[2];
+      float hw = fabsf(residual) < P->huberTH ? 1 : P->huberTH / fabsf(residual);
+      H += hw * dResdDist * dResdDist;
+      bb += hw * residual * dResdDist;
+      energy += p->weights[idx] * p->weights[idx] * hw * residual * residual * (2 - hw);
+    }
+    if (energy > bestEnergy) {
+      stepBack *= 0.5f;
+      bestU = uBak + stepBack * dx;
+      bestV = vBak + stepBack * dy;
+    } else {
+      float step = -gnstepsize * bb / H;
+      if (step < -0.5f) step = -0.5f;
+      else if (step > 0.5f) step = 0.5f;
+      if (!isfinite(step)) step = 0;
+      uBak = bestU;
+      vBak = bestV;
+      stepBack = step;
+      bestU += step * dx;
+      bestV += step * dy;
+      bestEnergy = energy;
+    }
+    if (fabsf(stepBack) < P->GNThreshold) break;
+  }
+  if (!(bestEnergy < p->energyTH * P->extraSlackOnTH)) {
+    p->lastTracePixelInterval = 0;
+    p->lastTraceUV[0] = p->lastTraceUV[1] = -1;
+    if (p->lastTraceStatus == SOS_IPS_OUTLIER) return p->lastTraceStatus = SOS_IPS_OOB;
+    return p->lastTraceStatus = SOS_IPS_OUTLIER;
+  }
+  if (dx * dx > dy * dy) {
+    p->idepth_min = (pr2 * (bestU - errorInPixel * dx) - pr0) / (Kt[0] - Kt[2] * (bestU - errorInPixel * dx));
+    p->idepth_max = (pr2 * (bestU + errorInPixel * dx) - pr0) / (Kt[0] - Kt[2] * (bestU + errorInPixel * dx));
+  } else {
+    p->idepth_min = (pr2 * (bestV - errorInPixel * dy) - pr1) / (Kt[1] - Kt[2] * (bestV - errorInPixel * dy));
+    p->idepth_max = (pr2 * (bestV + errorInPixel * dy) - pr1) / (Kt[1] - Kt[2] * (bestV + errorInPixel * dy));
+  }
+  if (p->idepth_min > p->idepth_max) {
+    float t = p->idepth_min;
+    p->idepth_min = p->idepth_max;
+    p->idepth_max = t;
+  }
+  if (!isfinite(p->idepth_min) || !isfinite(p->idepth_max) || (p->idepth_max < 0)) {
+    p->lastTracePixelInterval = 0;
+    p->lastTraceUV[0] = p->lastTraceUV[1] = -1;
+    return p->lastTraceStatus = SOS_IPS_OUTLIER;
+  }
+  p->lastTracePixelInterval = 2 * errorInPixel;
+  p->lastTraceUV[0] = bestU;
+  p->lastTraceUV[1] = bestV;
+  return p->lastTraceStatus = SOS_IPS_GOOD;
+#undef OOB_RETURN
+}
+
+void orc_immature_trace(const sos_trace_params *P, const float *frame_dI, int w, int h, int count, sos_immature *pts,
+                        const float *KRKi, const float *Kt, const float *aff) { /* the loop of FS/FullSystem.cpp:334-350 */
+  for (int i = 0; i < count; i++) trace_one(P, frame_dI, w, h, &pts[i], KRKi, Kt, aff);
+}

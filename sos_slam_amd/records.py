@@ -39,3 +39,26 @@ class Calib(C.Structure):
         c.cxli = float(-f[2] / f[0])
         c.cyli = float(-f[3] / f[1])
         return c
+
+
+class TraceParams(C.Structure):
+    """sos_trace_params: the globals ImmaturePoint's constructor / traceOn read (util/settings.cpp:82-83,118,128-143)."""
+    _fields_ = [(k, C.c_float) for k in ("maxPixSearch", "stepsize", "GNThreshold", "extraSlackOnTH", "slackInterval",
+                                           "minImprovementFactor", "huberTH", "outlierTHSumComponent", "outlierTH",
+                                           "overallEnergyTHWeight")] + [("GNIterations", C.c_int32),
+                                                                        ("minTraceTestRadius", C.c_int32)]
+
+    @classmethod
+    def default(cls, **over):
+        p = cls(0.027, 1.0, 0.1, 1.2, 1.5, 2.0, 9.0, 50.0 * 50.0, 12.0 * 12.0, 1.0, 3, 2)
+        for k, v in over.items():
+            setattr(p, k, v)
+        return p
+
+
+# numpy mirror of sos_immature (128 bytes)
+IMMATURE_DTYPE = np.dtype([("u", "f4"), ("v", "f4"), ("idepth_min", "f4"), ("idepth_max", "f4"), ("color", "f4", (8,)),
+                           ("weights", "f4", (8,)), ("gradH", "f4", (4,)), ("energyTH", "f4"), ("quality", "f4"),
+                           ("lastTraceUV", "f4", (2,)), ("lastTracePixelInterval", "f4"), ("lastTraceStatus", "i4"),
+                           ("pad", "i4", (2,))])
+assert IMMATURE_DTYPE.itemsize == 128

@@ -1,0 +1,41 @@
+"""Shared set-up of the immature-point tests: candidate pixels on a host keyframe and the host->frame quantities
+FullSystem::traceNewCoarse hands to traceOn (FS/FullSystem.cpp:317-332)."""
+import numpy as np
+
+
+def se3_inv(T):
+    R, t = T[:9].reshape(3, 3), T[9:]
+    return np.concatenate([R.T.reshape(-1), -(R.T @ t)])
+
+
+def se3_mul(A, B):
+    Ra, ta, Rb, tb = A[:9].reshape(3, 3), A[9:], B[:9].reshape(3, 3), B[9:]
+    return np.concatenate([(Ra @ Rb).reshape(-1), Ra @ tb + ta])
+
+
+def host_to_frame(K4, host_c2w, frame_c2w, host_aff=(0.0, 0.0), frame_aff=(0.0, 0.0), host_exp=1.0, frame_exp=1.0):
+    """KRKi (3x3 float32), Kt (3), aff (2) as computed at FS/FullSystem.cpp:326-332."""
+    K = np.array([[K4[0], 0, K4[2]], [0, K4[1], K4[3]], [0, 0, 1]], dtype=np.float32)
+    T = se3_mul(se3_inv(frame_c2w), host_c2w)
+    R = T[:9].reshape(3, 3).astype(np.float32)
+    t = T[9:].astype(np.float32)
+    KRKi = (K @ R @ np.linalg.inv(K).astype(np.float32)).astype(np.float32)
+    Kt = (K @ t).astype(np.float32)
+    a = np.exp(frame_aff[0] - host_aff[0]) * frame_exp / host_exp   # AffLight::fromToVecExposure
+    b = frame_aff[1] - a * host_aff[1]
+    return KRKi, Kt, np.array([a, b], dtype=np.float32)
+
+
+def candidates(win, host, count, seed=3):
+    """Integer pixel positions on keyframe `host`: the window's own points of that host (rounded), so that their
+    (noisy) inverse depth is known, topped up with random pixels."""
+    rng = np.random.default_rng(seed)
+    sel = np.flatnonzero(win.points["host"] == host)
+    u = np.rint(win.points["u"][sel]).astype(np.int32)
+    v = np.rint(win.points["v"][sel]).astype(np.int32)
+    idepth = win.points["idepth_scaled"][sel].astype(np.float64)
+    extra = max(0, count - len(u))
+    u = np.concatenate([u, rng.integers(6, win.w - 6, extra).astype(np.int32)])[:count]
+    v = np.concatenate([v, rng.integers(6, win.h - 6, extra).astype(np.int32)])[:count]
+    idepth = np.concatenate([idepth, np.full(extra, np.nan)])[:count]
+    return u, v, idepth

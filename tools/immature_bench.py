@@ -1,0 +1,75 @@
+#!/usr/bin/env python
+"""Timing of FullSystem::traceNewCoarse's inner loops (ImmaturePoint::traceOn over the immature points of every
+keyframe against a new frame) on the device against the oracle port on one host core (the reference traces
+single-threaded, FS/FullSystem.cpp:311-350)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import oracle as orc  # noqa: E402
+from sos_slam_amd import lib, synth  # noqa: E402
+from sos_slam_amd.records import TraceParams  # noqa: E402
+from tests import immature_helpers as ih  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "W7"
+per_host = int(sys.argv[2]) if len(sys.argv) > 2 else 1500   # setting_desiredImmatureDensity
+win = synth.make_window(name, extra_frames=1)
+prm = TraceParams.default()
+ctx = lib.Context(win.w, win.h)
+for i in range(win.n):
+    ctx.make_pyramid(i, win.images[i])
+ctx.make_pyramid(win.n, win.extra_images[0])
+new_dI, _ = orc.make_images(win.extra_images[0])
+hosts = []
+for h in range(win.n):
+    u, v, _ = ih.candidates(win, h, per_host, seed=h)
+    pts = ctx.immature_init(prm, h, u, v)
+    # give the points a finite interval the way earlier traces would have: one trace against a neighbour keyframe
+    nb = h + 1 if h + 1 < win.n else h - 1
+    KRKi, Kt, aff = ih.host_to_frame(win.K, win.frames[h]["camToWorld"], win.frames[nb]["camToWorld"])
+    pts = ctx.immature_trace(prm, nb, pts, KRKi, Kt, aff)
+    hosts.append((pts, ih.host_to_frame(win.K, win.frames[h]["camToWorld"], win.extra_poses[0])))
+
+
+all_pts = np.concatenate([p for p, _ in hosts])
+host_of = np.concatenate([np.full(len(p), k, np.int32) for k, (p, _) in enumerate(hosts)])
+KR = np.stack([kk[0].reshape(-1) for _, kk in hosts])
+KT = np.stack([kk[1] for _, kk in hosts])
+AF = np.stack([kk[2] for _, kk in hosts])
+
+
+def run_gpu():
+    out = ctx.immature_trace_all(prm, win.n, all_pts, host_of, KR, KT, AF)
+    o, r = 0, []
+    for p, _ in hosts:
+        r.append(out[o:o + len(p)])
+        o += len(p)
+    return r
+
+
+def run_cpu():
+    return [orc.immature_trace(prm, new_dI[0], pts, *kk) for pts, kk in hosts]
+
+
+g = run_gpu()
+t0 = time.perf_counter()
+for _ in range(10):
+    run_gpu()
+t_gpu = (time.perf_counter() - t0) / 10
+c = run_cpu()
+t0 = time.perf_counter()
+for _ in range(3):
+    run_cpu()
+t_cpu = (time.perf_counter() - t0) / 3
+same = all(np.array_equal(a["lastTraceStatus"], b["lastTraceStatus"]) and np.array_equal(a["idepth_min"], b["idepth_min"], equal_nan=True)
+           for a, b in zip(g, c))
+st = np.concatenate([a["lastTraceStatus"] for a in g])
+print(json.dumps({"window": name, "keyframes": win.n, "immature_points": int(len(st)), "gpu_ms": t_gpu * 1e3, "cpu_port_ms_1thread": t_cpu * 1e3,
+                  "points_per_s_gpu": len(st) / t_gpu, "identical_to_oracle": bool(same),
+                  "status_histogram": np.bincount(st, minlength=6).tolist()}))
+ctx.close()
