@@ -431,6 +431,45 @@ int sos_immature_trace(sos_ctx *ctx, const sos_trace_params *prm, int frameSlot,
 int sos_immature_trace_all(sos_ctx *ctx, const sos_trace_params *prm, int frameSlot, int count, sos_immature *pts,
                            const int32_t *hostOfPoint, int nhosts, const float *KRKi, const float *Kt, const float *aff);
 
+/* ---- point activation: FullSystem::optimizeImmaturePoint over the candidates chosen by activatePointsMT ------------
+ * (FS/FullSystemOptPoint.cpp:47-192 with ImmaturePoint::linearizeResidual, FS/ImmaturePoint.cpp:475-545; the loop
+ * FS/FullSystem.cpp:365-374,476-487).  A 1-D Levenberg-Marquardt on the inverse depth of every candidate against
+ * all other keyframes of the window. */
+typedef struct sos_activate_params {
+  float huberTH;                /* setting_huberTH = 9 */
+  float minIdepthH_act;         /* setting_minIdepthH_act = 100 */
+  int32_t GNIts;                /* setting_GNItsOnPointActivation = 3 */
+  int32_t minObs;               /* the minObs argument (1 from activatePointsMT_Reductor) */
+} sos_activate_params;
+
+/* what linearizeResidual reads of host->targetPrecalc[target] (FS/HessianBlocks.h:109-134): the CURRENT-state
+ * PRE_RTll / PRE_tTll (not the _0 pair of sos_precalc) and PRE_aff_mode; 16 floats */
+typedef struct sos_pair_tfm {
+  float R[9];                   /* PRE_RTll, row-major */
+  float t[3];                   /* PRE_tTll */
+  float aff[2];                 /* PRE_aff_mode */
+  float pad[2];
+} sos_pair_tfm;
+
+#define SOS_ACT_SKIP 0          /* returned 0: not well constrained, the point stays immature */
+#define SOS_ACT_DELETE (-1)     /* returned (PointHessian*)-1: outlier / non-finite, the candidate is deleted */
+#define SOS_ACT_ACTIVATED 1     /* a PointHessian is created with idepth, residuals to the frames of inMask */
+typedef struct sos_activation {
+  int32_t status;               /* SOS_ACT_* */
+  float idepth;                 /* currentIdepth at exit (setIdepthZero / setIdepth, FS/FullSystemOptPoint.cpp:158-159) */
+  uint32_t inMask;              /* bit t set: the residual towards frame idx t ended ResState::IN (:162-168) */
+  float energy, Hdd, bd;        /* lastEnergy, lastHdd, lastbd at exit (inspection / parity) */
+  int32_t iterations;           /* LM iterations run */
+  int32_t pad;
+} sos_activation;
+
+/* optimizeImmaturePoint for `count` candidates.  nFrames keyframes, frame idx f has its images in slot
+ * frameSlot[f]; pairs[host + nFrames * target]; hostOfPoint[i] = frame idx of the host of pts[i].  pts is read only
+ * (u, v, color, weights, energyTH, idepth_min, idepth_max). */
+int sos_immature_activate(sos_ctx *ctx, const sos_activate_params *prm, const sos_calib *calib, int nFrames,
+                          const int32_t *frameSlot, const sos_pair_tfm *pairs, int count, const sos_immature *pts,
+                          const int32_t *hostOfPoint, sos_activation *out);
+
 const char *sos_backend_name(void);
 
 #ifdef __cplusplus

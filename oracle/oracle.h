@@ -158,5 +158,9 @@ void orc_immature_init(const sos_trace_params *prm, const float *host_dI_aos3, i
                        const int32_t *v, sos_immature *out);
 void orc_immature_trace(const sos_trace_params *prm, const float *frame_dI_aos3, int w, int h, int count, sos_immature *pts,
                         const float *KRKi, const float *Kt, const float *aff);
+/* FullSystem::optimizeImmaturePoint over `count` candidates (FS/FullSystemOptPoint.cpp:47-192); dI[f] = level-0 image of frame idx f */
+void orc_immature_activate(const sos_activate_params *prm, const sos_calib *calib, int w, int h, int n, const float *const *dI,
+                           const sos_pair_tfm *pairs, int count, const sos_immature *pts, const int32_t *hostOf,
+                           sos_activation *out);
 
 #endif

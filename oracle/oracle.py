@@ -74,6 +74,7 @@ def lib():
         L.orc_host_get_HM.argtypes = [vp, vp, vp]
         L.orc_immature_init.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
         L.orc_immature_trace.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
+        L.orc_immature_activate.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp]
         L.orc_host_get_frame_prior.argtypes = [vp, C.c_int, vp, vp]
         L.orc_host_drop_points.argtypes = [vp, vp, C.c_int]
         L.orc_host_marginalize_points.argtypes = [vp, vp, C.c_int, vp]
@@ -161,6 +162,22 @@ def immature_trace(prm, frame_dI0, pts, KRKi, Kt, aff):
     a = [np.ascontiguousarray(x, dtype=np.float32) for x in (KRKi, Kt, aff)]
     lib().orc_immature_trace(C.byref(prm), _p(dI), w, h, len(pts), _p(pts), *[_p(x) for x in a])
     return pts
+
+
+def immature_activate(prm, calib, frame_dI0, pairs, pts, host_of):
+    """FullSystem::optimizeImmaturePoint over all candidates; frame_dI0[f] = level-0 dI (h, w, 3) of frame idx f."""
+    from sos_slam_amd.records import ACTIVATION_DTYPE, PAIR_TFM_DTYPE
+    imgs = [np.ascontiguousarray(x, dtype=np.float32) for x in frame_dI0]
+    n = len(imgs)
+    h, w = imgs[0].shape[:2]
+    ptrs = (C.c_void_p * n)(*[x.ctypes.data for x in imgs])
+    pairs = np.ascontiguousarray(pairs, dtype=PAIR_TFM_DTYPE)
+    assert pairs.size == n * n
+    pts = np.ascontiguousarray(pts)
+    ho = np.ascontiguousarray(host_of, dtype=np.int32)
+    out = np.zeros(len(pts), dtype=ACTIVATION_DTYPE)
+    lib().orc_immature_activate(C.byref(prm), C.byref(calib), w, h, n, ptrs, _p(pairs), len(pts), _p(pts), _p(ho), _p(out))
+    return out
 
 
 class OracleWindow:

@@ -250,3 +250,156 @@ void orc_immature_trace(const sos_trace_params *P, const float *frame_dI, int w,
                         const float *KRKi, const float *Kt, const float *aff) { /* the loop of FS/FullSystem.cpp:334-350 */
   for (int i = 0; i < count; i++) trace_one(P, frame_dI, w, h, &pts[i], KRKi, Kt, aff);
 }
+
+/* ---- point activation ------------------------------------------------------------------------------------------------
+ * ImmaturePoint::linearizeResidual  FS/ImmaturePoint.cpp:475-545 (projectPoint: FS/ResidualProjections.h:52-73,
+ * derive_idepth: :33-41) and FullSystem::optimizeImmaturePoint  FS/FullSystemOptPoint.cpp:47-192. */
+typedef struct {
+  int state_state, state_NewState;
+  float state_energy, state_NewEnergy; /* doubles in the reference, but they only ever hold float values */
+  int target;
+} tmp_res;
+
+static float lin_residual(const sos_activate_params *P, const sos_calib *C, int w, int h, const float *dIl, const sos_pair_tfm *T,
+                          const sos_immature *p, float slack, tmp_res *tr, float *Hdd, float *bd, float idepth) {
+  if (tr->state_state == SOS_RES_OOB) { /* :479-482 */
+    tr->state_NewState = SOS_RES_OOB;
+    return tr->state_energy;
+  }
+  const float wM3G = (float)(w - 3), hM3G = (float)(h - 3);
+  const float *R = T->R, *t = T->t;
+  float energyLeft = 0;
+  for (int idx = 0; idx < 8; idx++) { /* :497-533 */
+    int dx = PATTERN[idx][0], dy = PATTERN[idx][1];
+    float KliP0 = (p->u + dx - C->cxl) * C->fxli;
+    float KliP1 = (p->v + dy - C->cyl) * C->fyli;
+    float ptp0 = R[0] * KliP0 + R[1] * KliP1 + R[2] + t[0] * idepth;
+    float ptp1 = R[3] * KliP0 + R[4] * KliP1 + R[5] + t[1] * idepth;
+    float ptp2 = R[6] * KliP0 + R[7] * KliP1 + R[8] + t[2] * idepth;
+    float drescale = 1.0f / ptp2;
+    int ok = drescale > 0;
+    float u = 0, v = 0, Ku = 0, Kv = 0;
+    if (ok) {
+      u = ptp0 * drescale;
+      v = ptp1 * drescale;
+      Ku = u * C->fxl + C->cxl;
+      Kv = v * C->fyl + C->cyl;
+      ok = Ku > 1.1f && Kv > 1.1f && Ku < wM3G && Kv < hM3G;
+    }
+    if (!ok) { /* :505-509 -- Hdd / bd keep the terms of the pattern pixels before this one */
+      tr->state_NewState = SOS_RES_OOB;
+      return tr->state_energy;
+    }
+    float hit[3];
+    interp33(dIl, Ku, Kv, w, h, hit);
+    if (!isfinite(hit[0])) { /* :513-516 */
+      tr->state_NewState = SOS_RES_OOB;
+      return tr->state_energy;
+    }
+    float residual = hit[0] - (T->aff[0] * p->color[idx] + T->aff[1]);
+    float hw = fabsf(residual) < P->huberTH ? 1 : P->huberTH / fabsf(residual);
+    energyLeft += p->weights[idx] * p->weights[idx] * hw * residual * residual * (2 - hw);
+    float dxInterp = hit[1] * C->fxl, dyInterp = hit[2] * C->fyl;
+    float d_idepth = (dxInterp * drescale * (t[0] - t[2] * u) + dyInterp * drescale * (t[1] - t[2] * v)) * SOS_SCALE_IDEPTH;
+    hw *= p->weights[idx] * p->weights[idx];
+    *Hdd += (hw * d_idepth) * d_idepth;
+    *bd += (hw * residual) * d_idepth;
+  }
+  if (energyLeft > p->energyTH * slack) { /* :535-541 */
+    energyLeft = p->energyTH * slack;
+    tr->state_NewState = SOS_RES_OUTLIER;
+  } else {
+    tr->state_NewState = SOS_RES_IN;
+  }
+  tr->state_NewEnergy = energyLeft;
+  return energyLeft;
+}
+
+void orc_immature_activate(const sos_activate_params *P, const sos_calib *C, int w, int h, int n, const float *const *dI,
+                           const sos_pair_tfm *pairs, int count, const sos_immature *pts, const int32_t *hostOf,
+                           sos_activation *out) {
+  for (int i = 0; i < count; i++) {
+    const sos_immature *p = &pts[i];
+    sos_activation *o = &out[i];
+    memset(o, 0, sizeof(*o));
+    const int host = hostOf[i];
+    tmp_res tr[SOS_MAX_FRAMES];
+    int nres = 0;
+    for (int f = 0; f < n; f++) /* :49-58 */
+      if (f != host) {
+        tr[nres].state_NewEnergy = tr[nres].state_energy = 0;
+        tr[nres].state_NewState = SOS_RES_OUTLIER;
+        tr[nres].state_state = SOS_RES_IN;
+        tr[nres].target = f;
+        nres++;
+      }
+    float lastEnergy = 0, lastHdd = 0, lastbd = 0;
+    float currentIdepth = (p->idepth_max + p->idepth_min) * 0.5f;
+    for (int k = 0; k < nres; k++) { /* :68-73 */
+      lastEnergy = (float)((double)lastEnergy + (double)lin_residual(P, C, w, h, dI[tr[k].target], &pairs[host + n * tr[k].target], p,
+                                                                     1000, &tr[k], &lastHdd, &lastbd, currentIdepth));
+      tr[k].state_state = tr[k].state_NewState;
+      tr[k].state_energy = tr[k].state_NewEnergy;
+    }
+    o->idepth = currentIdepth; o->energy = lastEnergy; o->Hdd = lastHdd; o->bd = lastbd;
+    if (!isfinite(lastEnergy) || lastHdd < P->minIdepthH_act) { /* :75-80 */
+      o->status = SOS_ACT_SKIP;
+      continue;
+    }
+    float lambda = 0.1f;
+    int skip = 0, it = 0;
+    for (int iteration = 0; iteration < P->GNIts; iteration++) { /* :88-130 */
+      it++;
+      float H = lastHdd;
+      H *= 1 + lambda;
+      float step = (float)((1.0 / (double)H) * (double)lastbd);
+      float newIdepth = currentIdepth - step;
+      float newHdd = 0, newbd = 0, newEnergy = 0;
+      for (int k = 0; k < nres; k++)
+        newEnergy = (float)((double)newEnergy + (double)lin_residual(P, C, w, h, dI[tr[k].target], &pairs[host + n * tr[k].target], p, 1,
+                                                                     &tr[k], &newHdd, &newbd, newIdepth));
+      if (!isfinite(lastEnergy) || newHdd < P->minIdepthH_act) { /* :102-107 */
+        skip = 1;
+        break;
+      }
+      if (newEnergy < lastEnergy) {
+        currentIdepth = newIdepth;
+        lastHdd = newHdd;
+        lastbd = newbd;
+        lastEnergy = newEnergy;
+        for (int k = 0; k < nres; k++) {
+          tr[k].state_state = tr[k].state_NewState;
+          tr[k].state_energy = tr[k].state_NewEnergy;
+        }
+        lambda = (float)(lambda * 0.5);
+      } else {
+        lambda *= 5;
+      }
+      if ((double)fabsf(step) < 0.0001 * (double)currentIdepth) break; /* :128-129 */
+    }
+    o->idepth = currentIdepth; o->energy = lastEnergy; o->Hdd = lastHdd; o->bd = lastbd; o->iterations = it;
+    if (skip) {
+      o->status = SOS_ACT_SKIP;
+      continue;
+    }
+    if (!isfinite(currentIdepth)) { /* :132-137 */
+      o->status = SOS_ACT_DELETE;
+      continue;
+    }
+    int numGoodRes = 0;
+    for (int k = 0; k < nres; k++)
+      if (tr[k].state_state == SOS_RES_IN) {
+        numGoodRes++;
+        o->inMask |= 1u << tr[k].target;
+      }
+    if (numGoodRes < P->minObs) { /* :144-149 */
+      o->status = SOS_ACT_DELETE;
+      continue;
+    }
+    if (!isfinite(p->energyTH)) { /* PointHessian ctor copies energyTH (FS/HessianBlocks.cpp:33-52); :151-155 */
+      o->status = SOS_ACT_DELETE;
+      continue;
+    }
+    o->status = SOS_ACT_ACTIVATED;
+  }
+}

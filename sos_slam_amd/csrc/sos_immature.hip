@@ -278,6 +278,217 @@ __global__ __launch_bounds__(64) void k_immature_trace_batch(sos_trace_params P,
   pts[i] = p;
 }
 
+
+// ---- point activation: FullSystem::optimizeImmaturePoint (FS/FullSystemOptPoint.cpp:47-192) ---------------------------
+// One wave per candidate: lane = (residual slot g = lane >> 3, pattern pixel = lane & 7), residuals beyond 8 in further
+// chunks.  The reference accumulates Hdd / bd in ONE running float over residuals x pattern pixels (and keeps the
+// partial terms of a residual that leaves the image half way through its pattern), so the wave replays exactly that
+// chain: every lane computes its addend, then the addends are folded in lane order by wave-uniform code.
+struct ActImages {
+  const float *dI[SOS_MAX_FRAMES];
+};
+constexpr int ACT_MAXC = (SOS_MAX_FRAMES - 1 + 7) / 8;
+
+__device__ __forceinline__ float lane_value(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+struct ActState {
+  int st[ACT_MAXC], nw[ACT_MAXC];        // state_state / state_NewState of the residual of this lane group, per chunk
+  float stE[ACT_MAXC], nwE[ACT_MAXC];    // state_energy / state_NewEnergy
+};
+
+__device__ __forceinline__ float act_eval(const sos_activate_params &P, const sos_calib &C, int w, int h, int n, int host,
+                                          const ActImages &A, const sos_pair_tfm *__restrict__ pairs, float pu, float pv,
+                                          float color, float weight, float energyTH, float slack, float idepth, ActState &S,
+                                          float &Hdd, float &bd) {
+  const int lane = threadIdx.x, g = lane >> 3, pix = lane & 7;
+  const int nres = n - 1;
+  const float wM3G = (float)(w - 3), hM3G = (float)(h - 3);
+  float E = 0;
+#pragma unroll
+  for (int c = 0; c < ACT_MAXC; c++) {
+    if (c * 8 >= nres) break;
+    const int r = c * 8 + g;
+    const bool valid = r < nres;
+    const bool skip = !valid || S.st[c] == SOS_RES_OOB;  // FS/ImmaturePoint.cpp:479-482
+    bool fail = false;
+    float et = 0, ht = 0, bt = 0;
+    if (!skip) {
+      const int target = r < host ? r : r + 1;
+      const sos_pair_tfm &T = pairs[host + n * target];
+      const float KliP0 = (pu + c_pattern[pix][0] - C.cxl) * C.fxli;
+      const float KliP1 = (pv + c_pattern[pix][1] - C.cyl) * C.fyli;
+      const float ptp0 = T.R[0] * KliP0 + T.R[1] * KliP1 + T.R[2] + T.t[0] * idepth;
+      const float ptp1 = T.R[3] * KliP0 + T.R[4] * KliP1 + T.R[5] + T.t[1] * idepth;
+      const float ptp2 = T.R[6] * KliP0 + T.R[7] * KliP1 + T.R[8] + T.t[2] * idepth;
+      const float drescale = 1.0f / ptp2;
+      bool ok = drescale > 0;
+      float u = 0, v = 0, Ku = 0, Kv = 0;
+      if (ok) {
+        u = ptp0 * drescale;
+        v = ptp1 * drescale;
+        Ku = u * C.fxl + C.cxl;
+        Kv = v * C.fyl + C.cyl;
+        ok = Ku > 1.1f && Kv > 1.1f && Ku < wM3G && Kv < hM3G;
+      }
+      if (ok) {
+        float hit[3];
+        interp33(A.dI[target], Ku, Kv, w, h, hit);
+        if (isfinite(hit[0])) {
+          const float residual = hit[0] - (T.aff[0] * color + T.aff[1]);
+          float hw = fabsf(residual) < P.huberTH ? 1 : P.huberTH / fabsf(residual);
+          et = weight * weight * hw * residual * residual * (2 - hw);
+          const float dxInterp = hit[1] * C.fxl, dyInterp = hit[2] * C.fyl;
+          const float d_idepth = (dxInterp * drescale * (T.t[0] - T.t[2] * u) + dyInterp * drescale * (T.t[1] - T.t[2] * v)) * SOS_SCALE_IDEPTH;
+          hw *= weight * weight;
+          ht = (hw * d_idepth) * d_idepth;
+          bt = (hw * residual) * d_idepth;
+        } else {
+          fail = true;
+        }
+      } else {
+        fail = true;
+      }
+    }
+    const unsigned long long failB = __ballot(fail);
+    const unsigned m8 = (unsigned)(failB >> (g * 8)) & 0xffu;
+    const int first = m8 ? __ffs(m8) - 1 : 8;  // first pattern pixel at which the residual returns OOB
+    unsigned long long cB = __ballot(!skip && pix < first);
+    while (cB) {  // the running sums of FS/ImmaturePoint.cpp:531-532, residual-major, pattern order
+      const int l = __ffsll((long long)cB) - 1;
+      cB &= cB - 1;
+      Hdd += lane_value(ht, l);
+      bd += lane_value(bt, l);
+    }
+    // energyLeft of the group: 0 + e0 + e1 + ... + e7 in order
+    float eg = et;
+#pragma unroll
+    for (int k = 1; k < 8; k++) {
+      const float prev = __shfl_up(eg, 1, 8);
+      if (pix == k) eg = prev + et;
+    }
+    eg = __shfl(eg, 7, 8);
+    float ret;
+    if (skip) {
+      if (valid) S.nw[c] = SOS_RES_OOB;
+      ret = S.stE[c];
+    } else if (first < 8) {
+      S.nw[c] = SOS_RES_OOB;
+      ret = S.stE[c];
+    } else {
+      const float th = energyTH * slack;  // :535-541
+      if (eg > th) {
+        eg = th;
+        S.nw[c] = SOS_RES_OUTLIER;
+      } else {
+        S.nw[c] = SOS_RES_IN;
+      }
+      S.nwE[c] = eg;
+      ret = eg;
+    }
+#pragma unroll
+    for (int gg = 0; gg < 8; gg++)
+      if (c * 8 + gg < nres) E = E + lane_value(ret, gg * 8);
+  }
+  return E;
+}
+
+__global__ __launch_bounds__(64) void k_immature_activate(sos_activate_params P, sos_calib C, int w, int h, int n, ActImages A,
+                                                          const sos_pair_tfm *__restrict__ pairs, int count,
+                                                          const sos_immature *__restrict__ pts, const int *__restrict__ hostOf,
+                                                          sos_activation *__restrict__ out) {
+  const int i = blockIdx.x;
+  if (i >= count) return;
+  const int lane = threadIdx.x, g = lane >> 3, pix = lane & 7;
+  const sos_immature &p = pts[i];
+  const float pu = p.u, pv = p.v, color = p.color[pix], weight = p.weights[pix], energyTH = p.energyTH;
+  const int host = hostOf[i];
+  const int nres = n - 1;
+  ActState S;
+#pragma unroll
+  for (int c = 0; c < ACT_MAXC; c++) {  // FS/FullSystemOptPoint.cpp:49-58
+    S.st[c] = SOS_RES_IN;
+    S.nw[c] = SOS_RES_OUTLIER;
+    S.stE[c] = S.nwE[c] = 0;
+  }
+  float lastHdd = 0, lastbd = 0;
+  float currentIdepth = (p.idepth_max + p.idepth_min) * 0.5f;
+  float lastEnergy = act_eval(P, C, w, h, n, host, A, pairs, pu, pv, color, weight, energyTH, 1000.0f, currentIdepth, S, lastHdd, lastbd);
+#pragma unroll
+  for (int c = 0; c < ACT_MAXC; c++) {
+    S.st[c] = S.nw[c];
+    S.stE[c] = S.nwE[c];
+  }
+  int status = SOS_ACT_ACTIVATED, it = 0;
+  if (!isfinite(lastEnergy) || lastHdd < P.minIdepthH_act) {  // :75-80
+    status = SOS_ACT_SKIP;
+  } else {
+    float lambda = 0.1f;
+    for (int iteration = 0; iteration < P.GNIts; iteration++) {  // :88-130
+      it++;
+      float H = lastHdd;
+      H *= 1 + lambda;
+      const float step = (float)((1.0 / (double)H) * (double)lastbd);
+      const float newIdepth = currentIdepth - step;
+      float newHdd = 0, newbd = 0;
+      const float newEnergy = act_eval(P, C, w, h, n, host, A, pairs, pu, pv, color, weight, energyTH, 1.0f, newIdepth, S, newHdd, newbd);
+      if (!isfinite(lastEnergy) || newHdd < P.minIdepthH_act) {  // :102-107
+        status = SOS_ACT_SKIP;
+        break;
+      }
+      if (newEnergy < lastEnergy) {
+        currentIdepth = newIdepth;
+        lastHdd = newHdd;
+        lastbd = newbd;
+        lastEnergy = newEnergy;
+#pragma unroll
+        for (int c = 0; c < ACT_MAXC; c++) {
+          S.st[c] = S.nw[c];
+          S.stE[c] = S.nwE[c];
+        }
+        lambda *= 0.5f;
+      } else {
+        lambda *= 5;
+      }
+      if ((double)fabsf(step) < 0.0001 * (double)currentIdepth) break;  // :128-129
+    }
+  }
+  unsigned inMask = 0;
+  int numGood = 0;
+  if (status == SOS_ACT_ACTIVATED) {
+    if (!isfinite(currentIdepth)) {  // :132-137
+      status = SOS_ACT_DELETE;
+    } else {
+#pragma unroll
+      for (int c = 0; c < ACT_MAXC; c++) {
+        if (c * 8 >= nres) break;
+        const int r = c * 8 + g;
+        const unsigned long long b = __ballot(r < nres && pix == 0 && S.st[c] == SOS_RES_IN);
+#pragma unroll
+        for (int gg = 0; gg < 8; gg++)
+          if ((b >> (gg * 8)) & 1ull) {
+            const int rr = c * 8 + gg;
+            inMask |= 1u << (rr < host ? rr : rr + 1);
+            numGood++;
+          }
+      }
+      if (numGood < P.minObs) status = SOS_ACT_DELETE;          // :144-149
+      else if (!isfinite(energyTH)) status = SOS_ACT_DELETE;    // :151-155
+    }
+  }
+  if (lane == 0) {
+    sos_activation o;
+    o.status = status;
+    o.idepth = currentIdepth;
+    o.inMask = inMask;
+    o.energy = lastEnergy;
+    o.Hdd = lastHdd;
+    o.bd = lastbd;
+    o.iterations = it;
+    o.pad = 0;
+    out[i] = o;
+  }
+}
+
 // device-mapped pinned in/out block for the point records, grown on demand (process lifetime, per device)
 struct Stage {
   char *host = nullptr, *dev = nullptr;
@@ -373,5 +584,40 @@ extern "C" int sos_immature_trace_all(sos_ctx *c, const sos_trace_params *prm, i
   SOS_HIP(hipGetLastError());
   SOS_HIP(hipStreamSynchronize(c->stream));
   memcpy(pts, st->host, sizeof(sos_immature) * (size_t)count);
+  return SOS_OK;
+}
+
+extern "C" int sos_immature_activate(sos_ctx *c, const sos_activate_params *prm, const sos_calib *calib, int nFrames,
+                                     const int32_t *frameSlot, const sos_pair_tfm *pairs, int count, const sos_immature *pts,
+                                     const int32_t *hostOfPoint, sos_activation *out) {
+  if (!c || !prm || !calib || !frameSlot || !pairs || count < 0 || (count && (!pts || !hostOfPoint || !out))) return SOS_ERR_ARG;
+  if (nFrames < 1 || nFrames > SOS_MAX_FRAMES) return SOS_ERR_ARG;
+  ActImages A;
+  memset(&A, 0, sizeof(A));
+  for (int f = 0; f < nFrames; f++) {
+    if (frameSlot[f] < 0 || frameSlot[f] >= SOS_MAX_SLOTS || !c->dI[frameSlot[f]][0]) return SOS_ERR_STATE;
+    A.dI[f] = c->dI[frameSlot[f]][0];
+  }
+  for (int i = 0; i < count; i++)
+    if (hostOfPoint[i] < 0 || hostOfPoint[i] >= nFrames) return SOS_ERR_ARG;
+  if (count == 0) return SOS_OK;
+  SOS_HIP(hipSetDevice(c->device));
+  Stage *st;
+  const size_t szP = sizeof(sos_immature) * (size_t)count, szH = (sizeof(int32_t) * (size_t)count + 127) / 128 * 128,
+               szT = sizeof(sos_pair_tfm) * (size_t)nFrames * nFrames, szO = sizeof(sos_activation) * (size_t)count;
+  int rc = stage_ensure(c->device, szP + szH + szT + szO, &st);
+  if (rc) return rc;
+  SOS_HIP(hipStreamSynchronize(c->stream));
+  memcpy(st->host, pts, szP);
+  memcpy(st->host + szP, hostOfPoint, sizeof(int32_t) * (size_t)count);
+  memcpy(st->host + szP + szH, pairs, szT);
+  k_immature_activate<<<count, 64, 0, c->stream>>>(*prm, *calib, c->w, c->h, nFrames, A,
+                                                   reinterpret_cast<const sos_pair_tfm *>(st->dev + szP + szH), count,
+                                                   reinterpret_cast<const sos_immature *>(st->dev),
+                                                   reinterpret_cast<const int *>(st->dev + szP),
+                                                   reinterpret_cast<sos_activation *>(st->dev + szP + szH + szT));
+  SOS_HIP(hipGetLastError());
+  SOS_HIP(hipStreamSynchronize(c->stream));
+  memcpy(out, st->host + szP + szH + szT, szO);
   return SOS_OK;
 }

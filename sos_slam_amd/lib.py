@@ -23,7 +23,7 @@ SYMBOLS = [
     "sos_ba_set_window", "sos_ba_set_state", "sos_ba_linearize", "sos_ba_apply_res", "sos_ba_reset_oob",
     "sos_ba_fix_linearization", "sos_ba_accumulate", "sos_ba_accumulate_local", "sos_ba_acc_buffer",
     "sos_ba_stitch", "sos_ba_gn_accumulate", "sos_ba_gn_step", "sos_ba_get_point_hessian", "sos_ba_resubstitute", "sos_ba_calc_lenergy",
-    "sos_ba_accumulate_marg", "sos_ba_update_point_priors", "sos_ba_set_prefetch", "sos_tracker_set_gs_hint", "sos_immature_init", "sos_immature_trace", "sos_immature_trace_all", "sos_rccl_load", "sos_rccl_unique_id", "sos_comm_create", "sos_comm_destroy", "sos_comm_size",
+    "sos_ba_accumulate_marg", "sos_ba_update_point_priors", "sos_ba_set_prefetch", "sos_tracker_set_gs_hint", "sos_immature_init", "sos_immature_trace", "sos_immature_trace_all", "sos_immature_activate", "sos_rccl_load", "sos_rccl_unique_id", "sos_comm_create", "sos_comm_destroy", "sos_comm_size",
     "sos_comm_rank", "sos_ba_set_comm", "sos_ba_newest_capacity", "sos_ba_gather_energies", "sos_ba_allreduce_f64", "sos_ba_get_jacobian", "sos_ba_get_residual_flags", "sos_ba_get_JpJdF",
     "sos_ba_get_res_toZeroF", "sos_ba_time_kernel", "sos_tracker_create", "sos_tracker_destroy",
     "sos_tracker_set_ref", "sos_tracker_scale_depth", "sos_tracker_get_pc", "sos_tracker_calc_res",
@@ -86,6 +86,7 @@ def load():
     L.sos_immature_init.argtypes = [vp, vp, ci, ci, vp, vp, vp]
     L.sos_immature_trace.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp]
     L.sos_immature_trace_all.argtypes = [vp, vp, ci, ci, vp, vp, ci, vp, vp, vp]
+    L.sos_immature_activate.argtypes = [vp, vp, vp, ci, vp, vp, ci, vp, vp, vp]
     L.sos_rccl_load.argtypes = [C.c_char_p]
     L.sos_rccl_unique_id.argtypes = [vp]
     L.sos_comm_create.argtypes = [vp, ci, ci, ci, C.POINTER(vp)]
@@ -169,6 +170,20 @@ class Context:
         _chk(self.L.sos_immature_trace_all(self.h_, C.byref(prm), frame_slot, len(pts), _p(pts), _p(ho), len(a[1]) // 3 if a[1].ndim == 1 else a[1].shape[0],
                                            *[_p(x) for x in a]), "sos_immature_trace_all")
         return pts
+
+    def immature_activate(self, prm, calib, frame_slots, pairs, pts, host_of):
+        """FullSystem::optimizeImmaturePoint over all candidates; returns ACTIVATION_DTYPE records."""
+        from .records import ACTIVATION_DTYPE, PAIR_TFM_DTYPE
+        slots = np.ascontiguousarray(frame_slots, dtype=np.int32)
+        n = len(slots)
+        pairs = np.ascontiguousarray(pairs, dtype=PAIR_TFM_DTYPE)
+        assert pairs.size == n * n
+        pts = np.ascontiguousarray(pts)
+        ho = np.ascontiguousarray(host_of, dtype=np.int32)
+        out = np.zeros(len(pts), dtype=ACTIVATION_DTYPE)
+        _chk(self.L.sos_immature_activate(self.h_, C.byref(prm), C.byref(calib), n, _p(slots), _p(pairs), len(pts), _p(pts),
+                                          _p(ho), _p(out)), "sos_immature_activate")
+        return out
 
     def immature_trace(self, prm, frame_slot: int, pts, KRKi, Kt, aff):
         pts = np.ascontiguousarray(pts).copy()

@@ -62,3 +62,23 @@ IMMATURE_DTYPE = np.dtype([("u", "f4"), ("v", "f4"), ("idepth_min", "f4"), ("ide
                            ("lastTraceUV", "f4", (2,)), ("lastTracePixelInterval", "f4"), ("lastTraceStatus", "i4"),
                            ("pad", "i4", (2,))])
 assert IMMATURE_DTYPE.itemsize == 128
+
+
+class ActivateParams(C.Structure):
+    """sos_activate_params: globals of FullSystem::optimizeImmaturePoint (util/settings.cpp:61,118,133)."""
+    _fields_ = [("huberTH", C.c_float), ("minIdepthH_act", C.c_float), ("GNIts", C.c_int32), ("minObs", C.c_int32)]
+
+    @classmethod
+    def default(cls, **over):
+        p = cls(9.0, 100.0, 3, 1)
+        for k, v in over.items():
+            setattr(p, k, v)
+        return p
+
+
+# numpy mirrors of sos_pair_tfm (64 bytes) and sos_activation (32 bytes)
+PAIR_TFM_DTYPE = np.dtype([("R", "f4", (9,)), ("t", "f4", (3,)), ("aff", "f4", (2,)), ("pad", "f4", (2,))])
+ACTIVATION_DTYPE = np.dtype([("status", "i4"), ("idepth", "f4"), ("inMask", "u4"), ("energy", "f4"), ("Hdd", "f4"),
+                             ("bd", "f4"), ("iterations", "i4"), ("pad", "i4")])
+assert PAIR_TFM_DTYPE.itemsize == 64 and ACTIVATION_DTYPE.itemsize == 32
+ACT_SKIP, ACT_DELETE, ACT_ACTIVATED = 0, -1, 1

@@ -39,3 +39,23 @@ def candidates(win, host, count, seed=3):
     v = np.concatenate([v, rng.integers(6, win.h - 6, extra).astype(np.int32)])[:count]
     idepth = np.concatenate([idepth, np.full(extra, np.nan)])[:count]
     return u, v, idepth
+
+
+def pair_tfms(win, aff=None):
+    """PRE_RTll / PRE_tTll / PRE_aff_mode of host->targetPrecalc[target] for every ordered pair, indexed
+    host + n * target (FrameFramePrecalc::set, FS/HessianBlocks.cpp:431-461): leftToLeft = target_w2c * host_c2w."""
+    from sos_slam_amd.records import PAIR_TFM_DTYPE
+    n = win.n
+    out = np.zeros(n * n, dtype=PAIR_TFM_DTYPE)
+    for hst in range(n):
+        for tgt in range(n):
+            T = se3_mul(se3_inv(win.frames[tgt]["camToWorld"]), win.frames[hst]["camToWorld"])
+            o = out[hst + n * tgt]
+            o["R"] = T[:9].astype(np.float32)
+            o["t"] = T[9:].astype(np.float32)
+            if aff is None:
+                o["aff"] = (1.0, 0.0)
+            else:
+                a = np.exp(aff[tgt][0] - aff[hst][0])
+                o["aff"] = (a, aff[tgt][1] - a * aff[hst][1])
+    return out

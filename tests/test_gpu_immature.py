@@ -76,3 +76,68 @@ def test_init_and_successive_traces_bit_exact(name, count):
     # empty input
     assert len(ctx.immature_trace(prm, host + 1, p0[:0], KRKi, Kt, aff)) == 0
     ctx.close()
+
+
+def _act_same(a, b):
+    for f in a.dtype.names:
+        if f == "pad":
+            continue
+        if not np.array_equal(a[f], b[f], equal_nan=True):
+            bad = np.flatnonzero(~((a[f] == b[f]) | ((a[f] != a[f]) & (b[f] != b[f]))))
+            return f"{f}: {len(bad)} records differ, first {bad[:5]}: {a[f][bad[:3]]} vs {b[f][bad[:3]]}"
+    return None
+
+
+@pytest.mark.parametrize("name,per_host", [("T6", 150), ("W7", 300), ("W12", 120)])
+def test_activation_bit_exact(name, per_host):
+    """optimizeImmaturePoint through the C-ABI against the oracle: status, inverse depth, IN mask, energy, Hdd, bd and
+    iteration count of every candidate identical (windows of 6, 7 and 12 keyframes: one and two residual chunks)."""
+    from sos_slam_amd import lib
+    from sos_slam_amd.records import ActivateParams, Calib
+    win = synth.make_window(name)
+    prm = TraceParams.default()
+    calib = Calib.from_K(win.K)
+    ctx = lib.Context(win.w, win.h)
+    dI0 = []
+    for i in range(win.n):
+        ctx.make_pyramid(i, win.images[i])
+        dI0.append(orc.make_images(win.images[i])[0][0])
+    rng = np.random.default_rng(11)
+    aff = [(0.01 * rng.standard_normal(), 2.0 * rng.standard_normal()) for _ in range(win.n)]
+    pairs = ih.pair_tfms(win, aff)
+    parts, hosts = [], []
+    for host in range(win.n):
+        u, v, idepth = ih.candidates(win, host, per_host, seed=host)
+        pts = ctx.immature_init(prm, host, u, v)
+        known = np.isfinite(idepth)
+        # intervals: around the window's inverse depth where known (off-centre, different widths), wide guesses elsewhere
+        wdt = rng.uniform(0.02, 0.4, len(pts))
+        off = rng.uniform(-0.1, 0.1, len(pts))
+        mid = np.where(known, idepth * (1 + off), rng.uniform(0.05, 1.5, len(pts)))
+        pts["idepth_min"] = (mid * (1 - wdt)).astype(np.float32)
+        pts["idepth_max"] = (mid * (1 + wdt)).astype(np.float32)
+        parts.append(pts)
+        hosts.append(np.full(len(pts), host, np.int32))
+    pts, hosts = np.concatenate(parts), np.concatenate(hosts)
+    # edge cases: never traced (NaN upper bound), negative / huge inverse depth, NaN energyTH, border pixels
+    pts["idepth_max"][0:3] = np.nan
+    pts["idepth_min"][3:6] = -3.0
+    pts["idepth_max"][6:9] = 40.0
+    pts["energyTH"][9:12] = np.nan
+    pts["u"][12:15] = [2, win.w - 3, 5]
+    pts["v"][12:15] = [2, win.h - 3, win.h - 4]
+    for aprm in (ActivateParams.default(), ActivateParams.default(GNIts=6, minObs=2, minIdepthH_act=30.0, huberTH=4.0)):
+        o_o = orc.immature_activate(aprm, calib, dI0, pairs, pts, hosts)
+        o_g = ctx.immature_activate(aprm, calib, np.arange(win.n), pairs, pts, hosts)
+        assert _act_same(o_g, o_o) is None, _act_same(o_g, o_o)
+        assert {-1, 0, 1}.issubset(set(int(s) for s in o_o["status"])), np.bincount(o_o["status"] + 1)
+    # image slots in another order than the frame idx
+    perm = np.arange(win.n)[::-1].copy()
+    ctx2 = lib.Context(win.w, win.h)
+    for i in range(win.n):
+        ctx2.make_pyramid(int(perm[i]), win.images[i])
+    o_p = ctx2.immature_activate(ActivateParams.default(), calib, perm, pairs, pts, hosts)
+    assert _act_same(o_p, orc.immature_activate(ActivateParams.default(), calib, dI0, pairs, pts, hosts)) is None
+    assert len(ctx.immature_activate(ActivateParams.default(), calib, np.arange(win.n), pairs, pts[:0], hosts[:0])) == 0
+    ctx2.close()
+    ctx.close()

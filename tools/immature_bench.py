@@ -69,7 +69,31 @@ t_cpu = (time.perf_counter() - t0) / 3
 same = all(np.array_equal(a["lastTraceStatus"], b["lastTraceStatus"]) and np.array_equal(a["idepth_min"], b["idepth_min"], equal_nan=True)
            for a, b in zip(g, c))
 st = np.concatenate([a["lastTraceStatus"] for a in g])
+
+# activation (FullSystem::optimizeImmaturePoint over the candidates activatePointsMT picks: ~2000 a keyframe at start-up,
+# a few hundred in steady state); the reference spreads them over its worker threads, the port runs on one
+from sos_slam_amd.records import ActivateParams, Calib  # noqa: E402
+aprm, calib = ActivateParams.default(), Calib.from_K(win.K)
+pairs = ih.pair_tfms(win)
+traced = np.concatenate(g)
+cand = np.flatnonzero(np.isfinite(traced["idepth_max"]) & (traced["lastTraceStatus"] != 2))[:2000]
+cpts, chost = traced[cand], host_of[cand]
+dI0 = [orc.make_images(win.images[f])[0][0] for f in range(win.n)]
+slots = np.arange(win.n)
+a_g = ctx.immature_activate(aprm, calib, slots, pairs, cpts, chost)
+t0 = time.perf_counter()
+for _ in range(20):
+    ctx.immature_activate(aprm, calib, slots, pairs, cpts, chost)
+t_act_gpu = (time.perf_counter() - t0) / 20
+a_c = orc.immature_activate(aprm, calib, dI0, pairs, cpts, chost)
+t0 = time.perf_counter()
+for _ in range(3):
+    orc.immature_activate(aprm, calib, dI0, pairs, cpts, chost)
+t_act_cpu = (time.perf_counter() - t0) / 3
+act = {"candidates": int(len(cand)), "gpu_ms": t_act_gpu * 1e3, "cpu_port_ms_1thread": t_act_cpu * 1e3,
+       "identical_to_oracle": bool(all(np.array_equal(a_g[f], a_c[f], equal_nan=True) for f in a_g.dtype.names if f != "pad")),
+       "status_histogram_skip_delete_activated": [int((a_g["status"] == k).sum()) for k in (0, -1, 1)]}
 print(json.dumps({"window": name, "keyframes": win.n, "immature_points": int(len(st)), "gpu_ms": t_gpu * 1e3, "cpu_port_ms_1thread": t_cpu * 1e3,
                   "points_per_s_gpu": len(st) / t_gpu, "identical_to_oracle": bool(same),
-                  "status_histogram": np.bincount(st, minlength=6).tolist()}))
+                  "status_histogram": np.bincount(st, minlength=6).tolist(), "activation": act}))
 ctx.close()
