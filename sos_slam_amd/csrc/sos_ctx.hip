@@ -49,6 +49,7 @@ extern "C" int sos_ctx_create(int device, void *hip_stream, int w, int h, sos_ct
   }
   memset(c->dI, 0, sizeof(c->dI));
   memset(c->absg, 0, sizeof(c->absg));
+  memset(c->dIt, 0, sizeof(c->dIt));
   memset(c->has_pyr, 0, sizeof(c->has_pyr));
   SOS_HIP(hipMalloc(&c->d_img, sizeof(float) * (size_t)w * h));
   SOS_HIP(hipMalloc(&c->d_gammaB, sizeof(float) * 256));
@@ -67,6 +68,8 @@ extern "C" int sos_ctx_destroy(sos_ctx *c) {
       if (c->dI[s][l]) hipFree(c->dI[s][l]);
       if (c->absg[s][l]) hipFree(c->absg[s][l]);
     }
+  for (int s = 0; s < SOS_MAX_SLOTS; s++)
+    if (c->dIt[s]) hipFree(c->dIt[s]);
   hipFree(c->d_img);
   hipFree(c->d_gammaB);
   hipEventDestroy(c->ev0);
@@ -92,6 +95,7 @@ int sos_ctx_ensure_slot(sos_ctx *c, int slot, bool all_levels) {
     if (!c->dI[slot][l]) SOS_HIP(hipMalloc(&c->dI[slot][l], sizeof(float) * 3 * npx));
     if (!c->absg[slot][l]) SOS_HIP(hipMalloc(&c->absg[slot][l], sizeof(float) * npx));
   }
+  if (!c->dIt[slot]) SOS_HIP(hipMalloc(&c->dIt[slot], sizeof(float) * sos_tiled_floats(c->w, c->h)));
   return SOS_OK;
 }
 
@@ -138,6 +142,29 @@ __global__ void k_pyr_grad(float *__restrict__ dI, float *__restrict__ absg, int
   absg[idx] = ag;
 }
 
+// level 0 -> tiled copy: one thread per float of the tiled buffer (coalesced stores; the loads of a block fall into
+// two image rows)
+__global__ void k_tile_level0(const float *__restrict__ dI, float *__restrict__ dIt, int w, int h, int tpr, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const size_t tile = i / SOS_TLINE;
+  const int f = (int)(i - tile * SOS_TLINE);
+  const int ty = (int)(tile / tpr), tx = (int)(tile - (size_t)ty * tpr);
+  float v = 0.f;
+  if (f < 3 * SOS_TW * SOS_TH) {
+    const int t = f / 3, ch = f - 3 * t;
+    const int x = tx * SOS_TW + (t % SOS_TW), y = ty * SOS_TH + (t / SOS_TW);
+    if (x < w && y < h) v = dI[3 * ((size_t)y * w + x) + ch];
+  }
+  dIt[i] = v;
+}
+static int launch_tile_level0(sos_ctx *c, int slot) {
+  const size_t total = sos_tiled_floats(c->w, c->h);
+  k_tile_level0<<<(unsigned)((total + 255) / 256), 256, 0, c->stream>>>(c->dI[slot][0], c->dIt[slot], c->w, c->h,
+                                                                          sos_tiles_per_row(c->w), total);
+  return hipGetLastError() == hipSuccess ? SOS_OK : SOS_ERR_HIP;
+}
+
 extern "C" int sos_make_pyramid(sos_ctx *c, int slot, const float *img, const float *gammaB) {
   if (!c || !img) return SOS_ERR_ARG;
   SOS_HIP(hipSetDevice(c->device));
@@ -157,6 +184,8 @@ extern "C" int sos_make_pyramid(sos_ctx *c, int slot, const float *img, const fl
                                                       gammaB ? c->d_gammaB : nullptr);
   }
   SOS_HIP(hipGetLastError());
+  rc = launch_tile_level0(c, slot);
+  if (rc) return rc;
   SOS_HIP(hipStreamSynchronize(c->stream));  // `img` is a caller-owned pageable buffer
   c->has_pyr[slot] = true;
   return SOS_OK;
@@ -169,6 +198,8 @@ extern "C" int sos_frame_upload_dI(sos_ctx *c, int slot, const float *dI) {
   if (rc) return rc;
   SOS_HIP(hipMemcpyAsync(c->dI[slot][0], dI, sizeof(float) * 3 * (size_t)c->w * c->h, hipMemcpyHostToDevice,
                          c->stream));
+  rc = launch_tile_level0(c, slot);
+  if (rc) return rc;
   SOS_HIP(hipStreamSynchronize(c->stream));
   return SOS_OK;
 }
@@ -194,6 +225,7 @@ extern "C" int sos_frame_release(sos_ctx *c, int slot) {
     if (c->dI[slot][l]) { hipFree(c->dI[slot][l]); c->dI[slot][l] = nullptr; }
     if (c->absg[slot][l]) { hipFree(c->absg[slot][l]); c->absg[slot][l] = nullptr; }
   }
+  if (c->dIt[slot]) { hipFree(c->dIt[slot]); c->dIt[slot] = nullptr; }
   c->has_pyr[slot] = false;
   return SOS_OK;
 }

@@ -59,12 +59,16 @@ def test_exchange_paths_equal_plain_run():
                 assert np.isfinite(sysm.lastX()).all()
                 comm.close()
             sysm.close()
-        a = out[0]
-        for b in out[1:]:
-            assert a[0] == b[0] and a[1] == b[1]
-            assert np.array_equal(a[2], b[2])
-            assert np.array_equal(a[3], b[3])
-            assert a[4] == b[4]
+        a, hooks, native = out
+        # the library-enqueued RCCL path runs the same kernels as the plain run (pipelined iterations, block sums on the
+        # matrix cores): bit-identical.  The host-callback path cannot prefetch, so its intermediate iterations take the
+        # stored-tile kernels, whose fp32 block sums round differently: equal to fp32 accumulation noise.
+        assert a[0] == native[0] and a[1] == native[1]
+        assert np.array_equal(a[2], native[2]) and np.array_equal(a[3], native[3]) and a[4] == native[4]
+        assert abs(a[0] - hooks[0]) <= 1e-5 * a[0] and a[1] == hooks[1]
+        assert np.abs(a[2] - hooks[2]).max() <= 1e-5
+        assert np.abs(a[3] - hooks[3]).max() <= 1e-5 * np.abs(a[3]).max()
+        assert np.allclose(a[4], hooks[4], rtol=1e-3)
         assert np.array_equal(priors[0][0], priors[1][0]) and np.array_equal(priors[0][1], priors[1][1])
         assert np.abs(priors[0][0]).max() > 0
     finally:

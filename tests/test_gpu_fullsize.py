@@ -96,7 +96,8 @@ def test_w12_shards_add_up_and_pipelined_loop():
         plain.gn_iteration(it)
         piped.gn_iteration(it)
     assert plain.stats() == piped.stats()
-    assert np.abs(plain.lastX() - piped.lastX()).max() <= 1e-6 * max(np.abs(plain.lastX()).max(), 1e-3) + 1e-9
+    # different fp32 summation of the block sums (stored tiles: butterfly; pipelined: matrix cores): fp32 noise apart
+    assert np.abs(plain.lastX() - piped.lastX()).max() <= 5e-7
     plain.close(); piped.close()
 
 
