@@ -155,6 +155,12 @@ def main():
         L.sos_ba_time_kernel(L_host_ba(sysm), b"linearize", th.ctypes.data_as(C.c_void_p), 300, C.byref(ms))
         lin_ms = ms.value
         kern = {"linearize_fused_us": round(fused_ms * 1e3, 2)}
+        # yardsticks under the same launch conditions: an empty kernel of the linearisation's grid / block / LDS size, and a
+        # streaming read of as many bytes as the fused kernel's algorithmic traffic
+        L.sos_ba_time_kernel(L_host_ba(sysm), b"lin_floor", th.ctypes.data_as(C.c_void_p), 300, C.byref(ms))
+        floor_ms = ms.value
+        L.sos_ba_time_kernel(L_host_ba(sysm), b"stream_equal", th.ctypes.data_as(C.c_void_p), 300, C.byref(ms))
+        stream_ms = ms.value
         for name in ("apply_res", "top_accumulate", "sc_accumulate", "sc_gram_prep", "reduce", "stitch"):
             L.sos_ba_time_kernel(L_host_ba(sysm), name.encode(), th.ctypes.data_as(C.c_void_p), 200, C.byref(ms))
             kern[name + "_us"] = round(ms.value * 1e3, 2)
@@ -183,6 +189,10 @@ def main():
                          "bytes_per_residual": fused_bytes,
                          "bytes_per_residual_parts": {"linearize": LINEARIZE_BYTES_PER_RESIDUAL, "top_accumulate": TOP_BYTES_PER_RESIDUAL},
                          "avg_launch_us": fused_ms * 1e3,
+                         "launch_floor_us": floor_ms * 1e3, "equal_bytes_stream_read_us": stream_ms * 1e3,
+                         "note": "launch_floor_us = empty kernel with the same grid, block and LDS size; "
+                                 "equal_bytes_stream_read_us = coalesced 16 B/lane read of residuals x bytes_per_residual "
+                                 "bytes (both back to back on the same stream, like avg_launch_us)",
                          "unfused_linearize": {"avg_launch_us": lin_ms * 1e3, "bytes_per_residual": LINEARIZE_BYTES_PER_RESIDUAL,
                                                "achieved": R_local * LINEARIZE_BYTES_PER_RESIDUAL / (lin_ms * 1e-3) / 1e9,
                                                "frac": R_local * LINEARIZE_BYTES_PER_RESIDUAL / (lin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},

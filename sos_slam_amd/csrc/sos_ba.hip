@@ -571,8 +571,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define L2_NS 18  // 17 sums + group-out-of-bounds flag
 #define L2_LR_PST 68                          // row pitch of an operand plane: 64 rows (row type x residual) + 4
 #define L2_LR_TILE (2 * 16 * L2_LR_PST + 32)  // L and R planes of one tile; + 32 floats so the two tiles hit different banks
+// FUSED selects the pipelined form (fuse_top given, doApply = 1, tiles never stored) at compile time: two kernels with
+// their own names in a profile and their own register allocation
+template <bool FUSED>
 __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(BaDev d, const float *__restrict__ frameTH, int doApply,
-                                                               float *__restrict__ fuse_top, DoneSignal sg) {
+                                                               float *__restrict__ fuse_top_, DoneSignal sg) {
+  float *__restrict__ const fuse_top = FUSED ? fuse_top_ : nullptr;
+  __builtin_assume(!FUSED || fuse_top != nullptr);
+  if (FUSED) doApply = 1;
   // one LDS arena: the tile staging [2][72 planes][40], and -- in fused mode, before phase 2 touches the tiles -- the
   // transposition buffer of the 17 x 8 addends per residual: [residual 0..63][sum 0..16][pixel 0..7]
   __shared__ __attribute__((aligned(16))) float sBig[32 * L2_TILES * 17 * 8];
@@ -674,11 +680,19 @@ __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(BaDev d, const
     const float affLL0 = pc->PRE_aff_mode[0], affLL1 = pc->PRE_aff_mode[1], b0 = pc->PRE_b0_mode;
     const float residual = hit0 - (float)(affLL0 * color + affLL1);
     const float drdA = color - b0;
+#ifdef SOS_EXP_CHEAP
+    float wgt = __builtin_amdgcn_rsqf((d.outlierTH + (hit1 * hit1 + hit2 * hit2)) * (1.0f / 2500.f));
+    wgt = 0.5f * (wgt + pweight);
+    float hw = fabsf(residual) < d.huberTH ? 1 : d.huberTH * __builtin_amdgcn_rcpf(fabsf(residual));
+    const float e_i = wgt * wgt * hw * residual * residual * (2 - hw);
+    if (hw < 1) hw = __builtin_amdgcn_sqrtf(hw);
+#else
     float wgt = sqrtf(d.outlierTH / (d.outlierTH + (hit1 * hit1 + hit2 * hit2)));
     wgt = 0.5f * (wgt + pweight);
     float hw = fabsf(residual) < d.huberTH ? 1 : d.huberTH / fabsf(residual);
     const float e_i = wgt * wgt * hw * residual * residual * (2 - hw);
     if (hw < 1) hw = sqrtf(hw);
+#endif
     hw = hw * wgt;
     hit1 *= hw;
     hit2 *= hw;
@@ -2214,7 +2228,7 @@ struct sos_ba {
       d_host_chunk_begin, d_tmp_int;
   DevBuf<uint8_t> d_s_flags, d_s_state, d_s_newstate, d_o_newstate;
   DevBuf<float> d_s_energy, d_s_newenergy, d_s_newenergywo, d_s_ret, d_s_center, d_s_rtz, d_s_pterm, d_J, d_JpJd,
-      d_p_out, d_o_newenergy, d_o_newenergywo, d_o_center, d_top_part, d_gram_part, d_acc;
+      d_p_out, d_o_newenergy, d_o_newenergywo, d_o_center, d_top_part, d_gram_part, d_acc, d_calib;
   DevBuf<double> d_adHost, d_adTarget, d_Hout, d_scalar, d_perres;
   DevBuf<sos_rawjac> d_rawjac;
   DevBuf<int2> d_p_list2;
@@ -2295,7 +2309,7 @@ extern "C" int sos_ba_destroy(sos_ba *ba) {
   for (DevBuf<float> *b :
        {&ba->d_s_energy, &ba->d_s_newenergy, &ba->d_s_newenergywo, &ba->d_s_ret, &ba->d_s_center, &ba->d_s_rtz,
         &ba->d_s_pterm, &ba->d_J, &ba->d_JpJd, &ba->d_p_out, &ba->d_o_newenergy, &ba->d_o_newenergywo, &ba->d_o_center,
-        &ba->d_top_part, &ba->d_gram_part, &ba->d_acc, &ba->d_adHostF, &ba->d_adTargetF})
+        &ba->d_top_part, &ba->d_gram_part, &ba->d_acc, &ba->d_adHostF, &ba->d_adTargetF, &ba->d_calib})
     b->release();
   for (DevBuf<double> *b : {&ba->d_adHost, &ba->d_adTarget, &ba->d_Hout, &ba->d_scalar, &ba->d_perres})
     b->release();
@@ -2715,7 +2729,8 @@ static int launch_lin_kernel(sos_ba *ba, const BaDev &dv, int mode, float *fuse_
       sg.seq = seq;
     }
   }
-  k_linearize2<<<nb, 256 * L2_TILES, 0, ba->ctx->stream>>>(dv, stg(ba, ba->st_th), mode, fuse_top, sg);
+  if (fuse_top && mode == 1) k_linearize2<true><<<nb, 256 * L2_TILES, 0, ba->ctx->stream>>>(dv, stg(ba, ba->st_th), mode, fuse_top, sg);
+  else k_linearize2<false><<<nb, 256 * L2_TILES, 0, ba->ctx->stream>>>(dv, stg(ba, ba->st_th), mode, nullptr, sg);
   if (signal && !inKernel && !deferPublish) k_publish<<<1, 1, 0, ba->ctx->stream>>>(reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags), seq);
   return seq;
 }
@@ -3455,6 +3470,15 @@ extern "C" int sos_ba_time_kernel(sos_ba *ba, const char *kernel, const float *f
     if (k == "linearize_fused") {  // what the pipelined iterations run: linearize + applyRes + tile block sums, no J store
       launch_lin_kernel(ba, ba->dev, 1, ba->d_top_part.p);
       ba->J_valid = false;
+      return SOS_OK;
+    }
+    if (k == "stream_equal") {  // streaming read of as many bytes as the fused linearisation's algorithmic traffic
+      const size_t floats = (size_t)ba->R * 1088 / 4;
+      if (ba->d_calib.cap < floats) {
+        if (ba->d_calib.ensure(floats)) return SOS_ERR_NOMEM;
+        SOS_HIP(hipMemsetAsync(ba->d_calib.p, 0, sizeof(float) * floats, st));
+      }
+      k_calib_read<<<2048, 256, 0, st>>>(reinterpret_cast<const float4 *>(ba->d_calib.p), floats / 4, ba->d_top_part.p);
       return SOS_OK;
     }
     if (k == "lin_floor") {  // empty kernel with the linearisation's grid, block and LDS size

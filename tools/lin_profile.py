@@ -33,15 +33,6 @@ for name in (sys.argv[2:] or ["linearize_fused"]):
     for k, nm in enumerate(names):
         col = rel[:, k]
         print(f"  {nm:10s} min {col.min():7.2f} p50 {np.median(col):7.2f} p90 {np.percentile(col, 90):7.2f} max {col.max():7.2f}")
-    # per XCD (blocks are dealt round-robin over the 8 XCDs; clocks are comparable inside one)
-    allout = out
-    for x in range(8):
-        g = allout[x::8].astype(np.float64) if len(allout) % 8 == 0 else allout[np.arange(len(allout)) % 8 == x].astype(np.float64)
-        med = np.median(g[:, 0])
-        g = g[np.abs(g[:, 0] - med) < 2e5]   # drop stale stamps of earlier launches
-        t0x = g[:, 0].min()
-        st, en = g[:, 0] - t0x, g[:, 7] - t0x
-        print(f"  xcd {x}: blocks {len(g)} start p50 {np.median(st):7.0f} p90 {np.percentile(st, 90):7.0f} max {st.max():7.0f} | end p50 {np.median(en):7.0f} max {en.max():7.0f} | dur p50 {np.median(en - st):7.0f} max {(en - st).max():7.0f}")
     d = np.diff(rel, axis=1)
     print("  per-phase median cycles:", [int(np.median(d[:, k])) for k in range(ncol - 1)], "block total", int(np.median(rel[:, ncol - 1] - rel[:, 0])))
 sysm.close()
