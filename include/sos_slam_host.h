@@ -128,6 +128,27 @@ int sosf_get_timing(double *phases8, int reset);
  * which = 0: blocked production variant, 1: unblocked reference variant.  Exposed for the CPU test-suite. */
 int sosf_ldlt_solve(const double *A, const double *b, double *x, int n, int which);
 
+/* ---- candidate selection of FullSystem::activatePointsMT (FS/FullSystem.cpp:375-470) with CoarseDistanceMap
+ * (FS/CoarseTracker.cpp:766-954): host logic around sos_immature_activate.  The loop is inherently ordered (every
+ * accepted candidate is inserted into the distance map before the next one is tested), so it stays on the host.
+ *   currentMinActDist update of :377-399 */
+float sosf_next_min_act_dist(float currentMinActDist, int nPoints, float desiredPointDensity);
+/* makeDistanceMap + the candidate loop.  w1 x h1 = level-1 image size; per keyframe f (idx order, `newest` skipped):
+ * KRKi[f] (3x3 row-major) = K[1] * R(newest <- f) * Ki[0], Kt[f] = K[1] * t(newest <- f), computed by the caller
+ * exactly as FS/FullSystem.cpp:410-415 / FS/CoarseTracker.cpp:806-809.  Active points (u, v, idepth_scaled, host
+ * idx) in frames -> points order; candidates in the order the reference visits them (frames, then
+ * host->immaturePoints), with cand_type = ImmaturePoint::my_type and hostFlagged[f] = flaggedForMarginalization.
+ * decision[i]: SOSF_SEL_KEEP (stays immature), SOSF_SEL_DELETE, SOSF_SEL_OPTIMIZE (goes to sos_immature_activate,
+ * in this order).  distFinal (optional, w1*h1): fwdWarpedIDDistFinal after the loop. */
+#define SOSF_SEL_KEEP 0
+#define SOSF_SEL_OPTIMIZE 1
+#define SOSF_SEL_DELETE (-1)
+int sosf_activate_select(int w1, int h1, int nFrames, int newest, const float *KRKi, const float *Kt, int nActive,
+                         const float *act_u, const float *act_v, const float *act_idepth_scaled, const int32_t *act_host,
+                         float currentMinActDist, float minTraceQuality, int nCand, const sos_immature *cand,
+                         const int32_t *cand_host, const float *cand_type, const uint8_t *hostFlagged, int8_t *decision,
+                         float *distFinal);
+
 /* direct access to the underlying context / backend handles (tracker tests share the frame store) */
 sos_ctx *sosf_ctx(sosf_system *sys);
 sos_ba *sosf_ba(sosf_system *sys);

@@ -162,5 +162,13 @@ void orc_immature_trace(const sos_trace_params *prm, const float *frame_dI_aos3,
 void orc_immature_activate(const sos_activate_params *prm, const sos_calib *calib, int w, int h, int n, const float *const *dI,
                            const sos_pair_tfm *pairs, int count, const sos_immature *pts, const int32_t *hostOf,
                            sos_activation *out);
+/* candidate selection of FullSystem::activatePointsMT with CoarseDistanceMap (FS/FullSystem.cpp:375-470,
+ * FS/CoarseTracker.cpp:793-925); same arguments as sosf_activate_select */
+float orc_next_min_act_dist(float currentMinActDist, int nPoints, float desiredPointDensity);
+int orc_activate_select(int w1, int h1, int nFrames, int newest, const float *KRKi, const float *Kt, int nActive,
+                        const float *act_u, const float *act_v, const float *act_idepth_scaled, const int32_t *act_host,
+                        float currentMinActDist, float minTraceQuality, int nCand, const sos_immature *cand,
+                        const int32_t *cand_host, const float *cand_type, const uint8_t *hostFlagged, int8_t *decision,
+                        float *distFinal);
 
 #endif

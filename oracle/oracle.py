@@ -75,6 +75,9 @@ def lib():
         L.orc_immature_init.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
         L.orc_immature_trace.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
         L.orc_immature_activate.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp]
+        L.orc_activate_select.argtypes = [C.c_int] * 4 + [vp, vp, C.c_int, vp, vp, vp, vp, C.c_float, C.c_float, C.c_int, vp, vp, vp, vp, vp, vp]
+        L.orc_next_min_act_dist.argtypes = [C.c_float, C.c_int, C.c_float]
+        L.orc_next_min_act_dist.restype = C.c_float
         L.orc_host_get_frame_prior.argtypes = [vp, C.c_int, vp, vp]
         L.orc_host_drop_points.argtypes = [vp, vp, C.c_int]
         L.orc_host_marginalize_points.argtypes = [vp, vp, C.c_int, vp]
@@ -178,6 +181,36 @@ def immature_activate(prm, calib, frame_dI0, pairs, pts, host_of):
     out = np.zeros(len(pts), dtype=ACTIVATION_DTYPE)
     lib().orc_immature_activate(C.byref(prm), C.byref(calib), w, h, n, ptrs, _p(pairs), len(pts), _p(pts), _p(ho), _p(out))
     return out
+
+
+def _select_args(w1, h1, newest, KRKi, Kt, act, min_dist, min_quality, cand, cand_host, cand_type, host_flagged):
+    KRKi = np.ascontiguousarray(KRKi, dtype=np.float32).reshape(-1, 9)
+    Kt = np.ascontiguousarray(Kt, dtype=np.float32).reshape(-1, 3)
+    n = len(KRKi)
+    au, av, aid = [np.ascontiguousarray(act[k], dtype=np.float32) for k in ("u", "v", "idepth_scaled")]
+    ah = np.ascontiguousarray(act["host"], dtype=np.int32)
+    cand = np.ascontiguousarray(cand)
+    ch = np.ascontiguousarray(cand_host, dtype=np.int32)
+    ct = np.ascontiguousarray(cand_type, dtype=np.float32)
+    hf = np.ascontiguousarray(host_flagged, dtype=np.uint8)
+    dec = np.zeros(len(cand), dtype=np.int8)
+    dist = np.zeros((h1, w1), dtype=np.float32)
+    keep = (KRKi, Kt, au, av, aid, ah, cand, ch, ct, hf)
+    args = [w1, h1, n, newest, _p(KRKi), _p(Kt), len(au), _p(au), _p(av), _p(aid), _p(ah), float(min_dist), float(min_quality),
+            len(cand), _p(cand), _p(ch), _p(ct), _p(hf), _p(dec), _p(dist)]
+    return args, dec, dist, keep
+
+
+def activate_select(w1, h1, newest, KRKi, Kt, act, min_dist, min_quality, cand, cand_host, cand_type, host_flagged):
+    """Candidate loop of FullSystem::activatePointsMT; returns (decision int8[nCand], fwdWarpedIDDistFinal (h1, w1))."""
+    args, dec, dist, keep = _select_args(w1, h1, newest, KRKi, Kt, act, min_dist, min_quality, cand, cand_host, cand_type, host_flagged)
+    rc = lib().orc_activate_select(*args)
+    assert rc == 0
+    return dec, dist
+
+
+def next_min_act_dist(cur, n_points, desired):
+    return float(lib().orc_next_min_act_dist(cur, n_points, desired))
 
 
 class OracleWindow:

@@ -403,3 +403,129 @@ void orc_immature_activate(const sos_activate_params *P, const sos_calib *C, int
     o->status = SOS_ACT_ACTIVATED;
   }
 }
+
+/* ---- candidate selection -----------------------------------------------------------------------------------------------
+ * CoarseDistanceMap::makeDistanceMap / growDistBFS / addIntoDistFinal  FS/CoarseTracker.cpp:793-925 and the candidate
+ * loop of FullSystem::activatePointsMT  FS/FullSystem.cpp:375-470, as written there (two coordinate lists swapped per
+ * round, the even / odd round bodies spelled out). */
+#include <stdlib.h>
+
+typedef struct {
+  int w1, h1;
+  float *dist;
+  int *l1, *l2; /* (x, y) pairs */
+} distmap;
+
+static void grow_bfs(distmap *m, int bfsNum) { /* :828-917 */
+  int w1 = m->w1, h1 = m->h1;
+  float *D = m->dist;
+  for (int k = 1; k < 40; k++) {
+    int bfsNum2 = bfsNum;
+    int *t = m->l1; m->l1 = m->l2; m->l2 = t;
+    bfsNum = 0;
+    if (k % 2 == 0) {
+      for (int i = 0; i < bfsNum2; i++) {
+        int x = m->l2[2 * i], y = m->l2[2 * i + 1];
+        if (x == 0 || y == 0 || x == w1 - 1 || y == h1 - 1) continue;
+        int idx = x + y * w1;
+        if (D[idx + 1] > k) { D[idx + 1] = k; m->l1[2 * bfsNum] = x + 1; m->l1[2 * bfsNum + 1] = y; bfsNum++; }
+        if (D[idx - 1] > k) { D[idx - 1] = k; m->l1[2 * bfsNum] = x - 1; m->l1[2 * bfsNum + 1] = y; bfsNum++; }
+        if (D[idx + w1] > k) { D[idx + w1] = k; m->l1[2 * bfsNum] = x; m->l1[2 * bfsNum + 1] = y + 1; bfsNum++; }
+        if (D[idx - w1] > k) { D[idx - w1] = k; m->l1[2 * bfsNum] = x; m->l1[2 * bfsNum + 1] = y - 1; bfsNum++; }
+      }
+    } else {
+      for (int i = 0; i < bfsNum2; i++) {
+        int x = m->l2[2 * i], y = m->l2[2 * i + 1];
+        if (x == 0 || y == 0 || x == w1 - 1 || y == h1 - 1) continue;
+        int idx = x + y * w1;
+        if (D[idx + 1] > k) { D[idx + 1] = k; m->l1[2 * bfsNum] = x + 1; m->l1[2 * bfsNum + 1] = y; bfsNum++; }
+        if (D[idx - 1] > k) { D[idx - 1] = k; m->l1[2 * bfsNum] = x - 1; m->l1[2 * bfsNum + 1] = y; bfsNum++; }
+        if (D[idx + w1] > k) { D[idx + w1] = k; m->l1[2 * bfsNum] = x; m->l1[2 * bfsNum + 1] = y + 1; bfsNum++; }
+        if (D[idx - w1] > k) { D[idx - w1] = k; m->l1[2 * bfsNum] = x; m->l1[2 * bfsNum + 1] = y - 1; bfsNum++; }
+        if (D[idx + 1 + w1] > k) { D[idx + 1 + w1] = k; m->l1[2 * bfsNum] = x + 1; m->l1[2 * bfsNum + 1] = y + 1; bfsNum++; }
+        if (D[idx - 1 + w1] > k) { D[idx - 1 + w1] = k; m->l1[2 * bfsNum] = x - 1; m->l1[2 * bfsNum + 1] = y + 1; bfsNum++; }
+        if (D[idx - 1 - w1] > k) { D[idx - 1 - w1] = k; m->l1[2 * bfsNum] = x - 1; m->l1[2 * bfsNum + 1] = y - 1; bfsNum++; }
+        if (D[idx + 1 - w1] > k) { D[idx + 1 - w1] = k; m->l1[2 * bfsNum] = x + 1; m->l1[2 * bfsNum + 1] = y - 1; bfsNum++; }
+      }
+    }
+  }
+}
+
+float orc_next_min_act_dist(float d, int nPoints, float desired) { /* FS/FullSystem.cpp:377-399 */
+  if (nPoints < desired * 0.66) d -= 0.8;
+  if (nPoints < desired * 0.8) d -= 0.5;
+  else if (nPoints < desired * 0.9) d -= 0.2;
+  else if (nPoints < desired) d -= 0.1;
+  if (nPoints > desired * 1.5) d += 0.8;
+  if (nPoints > desired * 1.3) d += 0.5;
+  if (nPoints > desired * 1.15) d += 0.2;
+  if (nPoints > desired) d += 0.1;
+  if (d < 0) d = 0;
+  if (d > 4) d = 4;
+  return d;
+}
+
+int orc_activate_select(int w1, int h1, int nFrames, int newest, const float *KRKi, const float *Kt, int nActive,
+                        const float *act_u, const float *act_v, const float *act_id, const int32_t *act_host,
+                        float currentMinActDist, float minTraceQuality, int nCand, const sos_immature *cand,
+                        const int32_t *cand_host, const float *cand_type, const uint8_t *hostFlagged, int8_t *decision,
+                        float *distFinal) {
+  (void)nFrames;
+  distmap m;
+  m.w1 = w1; m.h1 = h1;
+  m.dist = (float *)malloc(sizeof(float) * (size_t)w1 * h1);
+  m.l1 = (int *)malloc(sizeof(int) * 2 * (size_t)w1 * h1);
+  m.l2 = (int *)malloc(sizeof(int) * 2 * (size_t)w1 * h1);
+  for (int i = 0; i < w1 * h1; i++) m.dist[i] = 1000; /* :797-798 */
+  int numItems = 0;
+  for (int i = 0; i < nActive; i++) { /* :803-823 */
+    int f = act_host[i];
+    if (f == newest) continue;
+    const float *K = KRKi + 9 * f, *T = Kt + 3 * f;
+    float p0 = K[0] * act_u[i] + K[1] * act_v[i] + K[2] + T[0] * act_id[i];
+    float p1 = K[3] * act_u[i] + K[4] * act_v[i] + K[5] + T[1] * act_id[i];
+    float p2 = K[6] * act_u[i] + K[7] * act_v[i] + K[8] + T[2] * act_id[i];
+    int u = p0 / p2 + 0.5f;
+    int v = p1 / p2 + 0.5f;
+    if (!(u > 0 && v > 0 && u < w1 && v < h1)) continue;
+    m.dist[u + w1 * v] = 0;
+    m.l1[2 * numItems] = u; m.l1[2 * numItems + 1] = v;
+    numItems++;
+  }
+  grow_bfs(&m, numItems);
+  for (int i = 0; i < nCand; i++) { /* FS/FullSystem.cpp:417-470 */
+    const sos_immature *ph = &cand[i];
+    int f = cand_host[i];
+    if (!isfinite(ph->idepth_max) || ph->lastTraceStatus == SOS_IPS_OUTLIER) { decision[i] = -1; continue; }
+    int canActivate = (ph->lastTraceStatus == SOS_IPS_GOOD || ph->lastTraceStatus == SOS_IPS_SKIPPED ||
+                       ph->lastTraceStatus == SOS_IPS_BADCONDITION || ph->lastTraceStatus == SOS_IPS_OOB) &&
+                      ph->lastTracePixelInterval < 8 && ph->quality > minTraceQuality && (ph->idepth_max + ph->idepth_min) > 0;
+    if (!canActivate) {
+      decision[i] = (hostFlagged[f] || ph->lastTraceStatus == SOS_IPS_OOB) ? -1 : 0;
+      continue;
+    }
+    const float *K = KRKi + 9 * f, *T = Kt + 3 * f;
+    float idm = 0.5f * (ph->idepth_max + ph->idepth_min);
+    float p0 = K[0] * ph->u + K[1] * ph->v + K[2] + T[0] * idm;
+    float p1 = K[3] * ph->u + K[4] * ph->v + K[5] + T[1] * idm;
+    float p2 = K[6] * ph->u + K[7] * ph->v + K[8] + T[2] * idm;
+    int u = p0 / p2 + 0.5f;
+    int v = p1 / p2 + 0.5f;
+    if (u > 0 && v > 0 && u < w1 && v < h1) {
+      float dist = m.dist[u + w1 * v] + (p0 - floorf(p0));
+      if (dist >= currentMinActDist * cand_type[i]) {
+        m.l1[0] = u; m.l1[1] = v; /* addIntoDistFinal, FS/CoarseTracker.cpp:919-925 */
+        m.dist[u + w1 * v] = 0;
+        grow_bfs(&m, 1);
+        decision[i] = 1;
+      } else {
+        decision[i] = 0;
+      }
+    } else {
+      decision[i] = -1;
+    }
+  }
+  if (distFinal) memcpy(distFinal, m.dist, sizeof(float) * (size_t)w1 * h1);
+  free(m.dist); free(m.l1); free(m.l2);
+  return 0;
+}

@@ -1693,3 +1693,128 @@ extern "C" int sosf_frame_slot(sosf_system *s, int frameIdx) {
   if (!s || frameIdx < 0 || frameIdx >= (int)s->fs->frameHessians.size()) return -1;
   return s->fs->frameHessians[frameIdx]->slot;
 }
+
+
+// ================================================================================================
+// Candidate selection of FullSystem::activatePointsMT (FS/FullSystem.cpp:375-470) around the device-side
+// optimizeImmaturePoint; CoarseDistanceMap (FS/CoarseTracker.cpp:766-954) as a breadth-first distance transform
+// ================================================================================================
+namespace {
+struct DistanceMap {
+  int w1, h1;
+  std::vector<float> dist;
+  std::vector<int> bfs1, bfs2;  // packed (x | y << 16)
+  DistanceMap(int w, int h) : w1(w), h1(h), dist((size_t)w * h, 1000.f), bfs1((size_t)w * h), bfs2((size_t)w * h) {}
+  inline void relax(int idx, int x, int y, int k, int &num) {
+    if (dist[idx] > k) {
+      dist[idx] = (float)k;
+      bfs1[num++] = x | (y << 16);
+    }
+  }
+  void grow(int bfsNum) {  // growDistBFS, FS/CoarseTracker.cpp:828-917: 4-neighbours on even rounds, 8 on odd ones
+    for (int k = 1; k < 40; k++) {
+      const int bfsNum2 = bfsNum;
+      std::swap(bfs1, bfs2);
+      bfsNum = 0;
+      for (int i = 0; i < bfsNum2; i++) {
+        const int x = bfs2[i] & 0xffff, y = bfs2[i] >> 16;
+        if (x == 0 || y == 0 || x == w1 - 1 || y == h1 - 1) continue;
+        const int idx = x + y * w1;
+        relax(idx + 1, x + 1, y, k, bfsNum);
+        relax(idx - 1, x - 1, y, k, bfsNum);
+        relax(idx + w1, x, y + 1, k, bfsNum);
+        relax(idx - w1, x, y - 1, k, bfsNum);
+        if (k & 1) {
+          relax(idx + 1 + w1, x + 1, y + 1, k, bfsNum);
+          relax(idx - 1 + w1, x - 1, y + 1, k, bfsNum);
+          relax(idx - 1 - w1, x - 1, y - 1, k, bfsNum);
+          relax(idx + 1 - w1, x + 1, y - 1, k, bfsNum);
+        }
+      }
+    }
+  }
+  void add(int u, int v) {  // addIntoDistFinal, :919-925
+    bfs1[0] = u | (v << 16);
+    dist[u + w1 * v] = 0;
+    grow(1);
+  }
+};
+}  // namespace
+
+extern "C" float sosf_next_min_act_dist(float d, int nPoints, float desired) {  // FS/FullSystem.cpp:377-399
+  if (nPoints < desired * 0.66) d -= 0.8;
+  if (nPoints < desired * 0.8) d -= 0.5;
+  else if (nPoints < desired * 0.9) d -= 0.2;
+  else if (nPoints < desired) d -= 0.1;
+  if (nPoints > desired * 1.5) d += 0.8;
+  if (nPoints > desired * 1.3) d += 0.5;
+  if (nPoints > desired * 1.15) d += 0.2;
+  if (nPoints > desired) d += 0.1;
+  if (d < 0) d = 0;
+  if (d > 4) d = 4;
+  return d;
+}
+
+extern "C" int sosf_activate_select(int w1, int h1, int nFrames, int newest, const float *KRKi, const float *Kt, int nActive,
+                                    const float *act_u, const float *act_v, const float *act_id, const int32_t *act_host,
+                                    float currentMinActDist, float minTraceQuality, int nCand, const sos_immature *cand,
+                                    const int32_t *cand_host, const float *cand_type, const uint8_t *hostFlagged,
+                                    int8_t *decision, float *distFinal) {
+  if (w1 < 3 || h1 < 3 || w1 > 65535 || h1 > 32767 || nFrames < 1 || newest < 0 || newest >= nFrames || !KRKi || !Kt ||
+      nActive < 0 || nCand < 0 || (nActive && (!act_u || !act_v || !act_id || !act_host)) ||
+      (nCand && (!cand || !cand_host || !cand_type || !hostFlagged || !decision)))
+    return SOS_ERR_ARG;
+  DistanceMap dm(w1, h1);
+  // makeDistanceMap, FS/CoarseTracker.cpp:793-826
+  int numItems = 0;
+  for (int i = 0; i < nActive; i++) {
+    const int f = act_host[i];
+    if (f < 0 || f >= nFrames) return SOS_ERR_ARG;
+    if (f == newest) continue;
+    const float *K = KRKi + 9 * f, *T = Kt + 3 * f;
+    const float p0 = K[0] * act_u[i] + K[1] * act_v[i] + K[2] + T[0] * act_id[i];
+    const float p1 = K[3] * act_u[i] + K[4] * act_v[i] + K[5] + T[1] * act_id[i];
+    const float p2 = K[6] * act_u[i] + K[7] * act_v[i] + K[8] + T[2] * act_id[i];
+    const int u = (int)(p0 / p2 + 0.5f), v = (int)(p1 / p2 + 0.5f);
+    if (!(u > 0 && v > 0 && u < w1 && v < h1)) continue;
+    dm.dist[u + w1 * v] = 0;
+    dm.bfs1[numItems++] = u | (v << 16);
+  }
+  dm.grow(numItems);
+  // the candidate loop, FS/FullSystem.cpp:417-470
+  for (int i = 0; i < nCand; i++) {
+    const sos_immature &ph = cand[i];
+    const int f = cand_host[i];
+    if (f < 0 || f >= nFrames || f == newest) return SOS_ERR_ARG;
+    if (!std::isfinite(ph.idepth_max) || ph.lastTraceStatus == SOS_IPS_OUTLIER) {  // :423-430
+      decision[i] = SOSF_SEL_DELETE;
+      continue;
+    }
+    const bool canActivate = (ph.lastTraceStatus == SOS_IPS_GOOD || ph.lastTraceStatus == SOS_IPS_SKIPPED ||
+                              ph.lastTraceStatus == SOS_IPS_BADCONDITION || ph.lastTraceStatus == SOS_IPS_OOB) &&
+                             ph.lastTracePixelInterval < 8 && ph.quality > minTraceQuality && (ph.idepth_max + ph.idepth_min) > 0;
+    if (!canActivate) {  // :441-451
+      decision[i] = (hostFlagged[f] || ph.lastTraceStatus == SOS_IPS_OOB) ? SOSF_SEL_DELETE : SOSF_SEL_KEEP;
+      continue;
+    }
+    const float *K = KRKi + 9 * f, *T = Kt + 3 * f;
+    const float idm = 0.5f * (ph.idepth_max + ph.idepth_min);
+    const float p0 = K[0] * ph.u + K[1] * ph.v + K[2] + T[0] * idm;
+    const float p1 = K[3] * ph.u + K[4] * ph.v + K[5] + T[1] * idm;
+    const float p2 = K[6] * ph.u + K[7] * ph.v + K[8] + T[2] * idm;
+    const int u = (int)(p0 / p2 + 0.5f), v = (int)(p1 / p2 + 0.5f);
+    if (u > 0 && v > 0 && u < w1 && v < h1) {
+      const float dist = dm.dist[u + w1 * v] + (p0 - floorf(p0));  // :461-462 (the fractional part of ptp[0], as written)
+      if (dist >= currentMinActDist * cand_type[i]) {
+        dm.add(u, v);
+        decision[i] = SOSF_SEL_OPTIMIZE;
+      } else {
+        decision[i] = SOSF_SEL_KEEP;
+      }
+    } else {
+      decision[i] = SOSF_SEL_DELETE;  // :468-471
+    }
+  }
+  if (distFinal) memcpy(distFinal, dm.dist.data(), sizeof(float) * (size_t)w1 * h1);
+  return SOS_OK;
+}

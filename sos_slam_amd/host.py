@@ -61,6 +61,9 @@ def load():
     L.sosf_tracker_optimize_scale.argtypes = [vp, ci, vp, vp, C.POINTER(C.c_float), ci, C.POINTER(C.c_float)]
     L.sosf_get_timing.argtypes = [vp, ci]
     L.sosf_ldlt_solve.argtypes = [vp, vp, vp, ci, ci]
+    L.sosf_activate_select.argtypes = [ci] * 4 + [vp, vp, ci, vp, vp, vp, vp, C.c_float, C.c_float, ci, vp, vp, vp, vp, vp, vp]
+    L.sosf_next_min_act_dist.argtypes = [C.c_float, ci, C.c_float]
+    L.sosf_next_min_act_dist.restype = C.c_float
     L.sosf_ctx.restype = vp
     L.sosf_ctx.argtypes = [vp]
     L.sosf_ba.restype = vp
@@ -81,6 +84,29 @@ def ldlt_solve(A, b, which=0):
     x = np.zeros(len(b))
     _chk(load().sosf_ldlt_solve(_p(A), _p(b), _p(x), len(b), which), "sosf_ldlt_solve")
     return x
+
+
+def activate_select(w1, h1, newest, KRKi, Kt, act, min_dist, min_quality, cand, cand_host, cand_type, host_flagged):
+    """Candidate loop of FullSystem::activatePointsMT (sosf_activate_select); `act` = structured array with u, v,
+    idepth_scaled, host of the active points.  Returns (decision int8[nCand], fwdWarpedIDDistFinal (h1, w1))."""
+    KRKi = np.ascontiguousarray(KRKi, dtype=np.float32).reshape(-1, 9)
+    Kt = np.ascontiguousarray(Kt, dtype=np.float32).reshape(-1, 3)
+    au, av, aid = [np.ascontiguousarray(act[k], dtype=np.float32) for k in ("u", "v", "idepth_scaled")]
+    ah = np.ascontiguousarray(act["host"], dtype=np.int32)
+    cand = np.ascontiguousarray(cand)
+    ch = np.ascontiguousarray(cand_host, dtype=np.int32)
+    ct = np.ascontiguousarray(cand_type, dtype=np.float32)
+    hf = np.ascontiguousarray(host_flagged, dtype=np.uint8)
+    dec = np.zeros(len(cand), dtype=np.int8)
+    dist = np.zeros((h1, w1), dtype=np.float32)
+    _chk(load().sosf_activate_select(w1, h1, len(KRKi), newest, _p(KRKi), _p(Kt), len(au), _p(au), _p(av), _p(aid), _p(ah),
+                                     float(min_dist), float(min_quality), len(cand), _p(cand), _p(ch), _p(ct), _p(hf), _p(dec),
+                                     _p(dist)), "sosf_activate_select")
+    return dec, dist
+
+
+def next_min_act_dist(cur, n_points, desired):
+    return float(load().sosf_next_min_act_dist(cur, n_points, desired))
 
 
 def timing(reset=False):

@@ -59,3 +59,20 @@ def pair_tfms(win, aff=None):
                 a = np.exp(aff[tgt][0] - aff[hst][0])
                 o["aff"] = (a, aff[tgt][1] - a * aff[hst][1])
     return out
+
+
+def level1_to_newest(win, newest):
+    """KRKi = K[1] * R(newest <- f) * Ki[0] and Kt = K[1] * t(newest <- f) for every keyframe f, in float32 as
+    FS/FullSystem.cpp:410-415 / CoarseDistanceMap::makeK (FS/CoarseTracker.cpp:927-954) compute them."""
+    fx, fy, cx, cy = [np.float32(x) for x in win.K]
+    K0 = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], dtype=np.float32)
+    K1 = np.array([[fx * np.float32(0.5), 0, (cx + np.float32(0.5)) / np.float32(2) - np.float32(0.5)],
+                   [0, fy * np.float32(0.5), (cy + np.float32(0.5)) / np.float32(2) - np.float32(0.5)], [0, 0, 1]], dtype=np.float32)
+    Ki0 = np.linalg.inv(K0).astype(np.float32)
+    KRKi, Kt = [], []
+    for f in range(win.n):
+        T = se3_mul(se3_inv(win.frames[newest]["camToWorld"]), win.frames[f]["camToWorld"])
+        R, t = T[:9].reshape(3, 3).astype(np.float32), T[9:].astype(np.float32)
+        KRKi.append(((K1 @ R).astype(np.float32) @ Ki0).astype(np.float32).reshape(-1))
+        Kt.append((K1 @ t).astype(np.float32))
+    return np.stack(KRKi), np.stack(Kt)

@@ -1,0 +1,94 @@
+"""Candidate selection of FullSystem::activatePointsMT (host logic: CoarseDistanceMap + the ordered accept loop).
+CPU tests: the oracle restatement against an independent numpy distance transform, and the facade's implementation
+(libsos_host, sosf_activate_select) against the oracle, decision for decision."""
+import numpy as np
+
+from oracle import oracle as orc
+from sos_slam_amd import synth
+from sos_slam_amd.records import IMMATURE_DTYPE
+from tests import immature_helpers as ih
+
+
+def _brute_distance(w1, h1, seeds):
+    """Rounds k = 1..39: cells first reached in round k get k; odd rounds grow over 8 neighbours, even rounds over 4;
+    cells on the image border never spread (FS/CoarseTracker.cpp:838-840)."""
+    D = np.full((h1, w1), 1000.0, dtype=np.float32)
+    for u, v in seeds:
+        D[v, u] = 0
+    inner = np.zeros((h1, w1), bool)
+    inner[1:-1, 1:-1] = True
+    for k in range(1, 40):
+        src = (D == k - 1) & inner
+        reach = np.zeros_like(src)
+        shifts = [(0, 1), (0, -1), (1, 0), (-1, 0)] + ([(1, 1), (1, -1), (-1, -1), (-1, 1)] if k % 2 else [])
+        for dy, dx in shifts:
+            reach |= np.roll(np.roll(src, dy, 0), dx, 1)
+        D[reach & (D > k)] = k
+    return D
+
+
+def _scenario(seed=5, n_cand=1500):
+    win = synth.make_window("T6")
+    newest = win.n - 1
+    w1, h1 = win.w // 2, win.h // 2
+    KRKi, Kt = ih.level1_to_newest(win, newest)
+    rng = np.random.default_rng(seed)
+    act = win.points[::3]    # a sparse set of active points: room for new ones
+    cand = np.zeros(n_cand, dtype=IMMATURE_DTYPE)
+    hosts = np.sort(rng.integers(0, newest, n_cand)).astype(np.int32)   # frames order
+    cand["u"] = rng.integers(4, win.w - 4, n_cand)
+    cand["v"] = rng.integers(4, win.h - 4, n_cand)
+    idm = rng.uniform(0.1, 1.5, n_cand)
+    cand["idepth_min"] = idm * 0.9
+    cand["idepth_max"] = idm * 1.1
+    cand["quality"] = rng.uniform(1.0, 8.0, n_cand)
+    cand["lastTracePixelInterval"] = rng.uniform(0.0, 12.0, n_cand)
+    cand["lastTraceStatus"] = rng.choice([0, 0, 0, 3, 4, 1, 2, 5], n_cand)
+    cand["idepth_max"][rng.random(n_cand) < 0.05] = np.nan       # never traced
+    cand["idepth_min"][rng.random(n_cand) < 0.03] = -5.0         # sum of the bounds not positive
+    ctype = rng.choice([1.0, 2.0, 4.0], n_cand).astype(np.float32)
+    flagged = np.zeros(win.n, np.uint8)
+    flagged[1] = 1
+    return win, newest, w1, h1, KRKi, Kt, act, cand, hosts, ctype, flagged
+
+
+def test_distance_map_matches_brute_force():
+    win, newest, w1, h1, KRKi, Kt, act, cand, hosts, ctype, flagged = _scenario()
+    dec, D = orc.activate_select(w1, h1, newest, KRKi, Kt, act, 2.0, 3.0, cand[:0], hosts[:0], ctype[:0], flagged)
+    seeds = set()
+    for p in act:
+        f = int(p["host"])
+        if f == newest:
+            continue
+        K, T = KRKi[f].reshape(3, 3), Kt[f]
+        ptp = (K @ np.array([p["u"], p["v"], 1], np.float32)).astype(np.float32) + T * np.float32(p["idepth_scaled"])
+        u, v = int(ptp[0] / ptp[2] + np.float32(0.5)), int(ptp[1] / ptp[2] + np.float32(0.5))
+        if 0 < u < w1 and 0 < v < h1:
+            seeds.add((u, v))
+    assert len(seeds) > 50
+    B = _brute_distance(w1, h1, seeds)
+    assert np.mean(D == B) > 0.999          # a handful of seeds may round differently in numpy's matrix product
+    assert D.max() == 1000 or D.max() <= 39
+
+
+def test_facade_selection_equals_oracle():
+    from sos_slam_amd import host
+    win, newest, w1, h1, KRKi, Kt, act, cand, hosts, ctype, flagged = _scenario()
+    for min_dist in (0.0, 1.0, 2.0, 4.0):
+        d_o, D_o = orc.activate_select(w1, h1, newest, KRKi, Kt, act, min_dist, 3.0, cand, hosts, ctype, flagged)
+        d_f, D_f = host.activate_select(w1, h1, newest, KRKi, Kt, act, min_dist, 3.0, cand, hosts, ctype, flagged)
+        assert np.array_equal(d_o, d_f)
+        assert np.array_equal(D_o, D_f)
+        assert {-1, 0, 1}.issubset(set(int(x) for x in d_o)) or min_dist == 0.0
+    # denser requirement -> fewer accepted; accepted candidates keep their distance from each other
+    n_acc = [int((orc.activate_select(w1, h1, newest, KRKi, Kt, act, md, 3.0, cand, hosts, ctype, flagged)[0] == 1).sum())
+             for md in (0.0, 1.0, 2.0, 4.0)]
+    assert n_acc[0] >= n_acc[1] >= n_acc[2] >= n_acc[3] > 0
+    # candidates whose host is flagged for marginalisation and that cannot activate are deleted, others kept
+    d_o, _ = orc.activate_select(w1, h1, newest, KRKi, Kt, act, 2.0, 3.0, cand, hosts, ctype, flagged)
+    cannot = (cand["lastTraceStatus"] == 5) & np.isfinite(cand["idepth_max"])
+    assert np.all(d_o[cannot & (hosts == 1)] == -1) and np.all(d_o[cannot & (hosts != 1)] == 0)
+    # the density controller
+    for cur, npts, des in ((2.0, 500, 2000.0), (2.0, 1700, 2000.0), (2.0, 1950, 2000.0), (2.0, 2500, 2000.0), (3.9, 4000, 2000.0), (0.1, 10, 2000.0)):
+        assert host.next_min_act_dist(cur, npts, des) == orc.next_min_act_dist(cur, npts, des)
+    assert orc.next_min_act_dist(0.1, 10, 2000.0) == 0.0 and orc.next_min_act_dist(3.9, 4000, 2000.0) == 4.0

@@ -141,3 +141,57 @@ def test_activation_bit_exact(name, per_host):
     assert len(ctx.immature_activate(ActivateParams.default(), calib, np.arange(win.n), pairs, pts[:0], hosts[:0])) == 0
     ctx2.close()
     ctx.close()
+
+
+def test_activate_points_flow_index_sets():
+    """FullSystem::activatePointsMT end to end: traced candidates -> host-side selection (distance map) -> device-side
+    optimizeImmaturePoint -> the sets of activated / deleted / kept candidates and the new points' inverse depths and
+    residual targets, identical to the oracle's flow."""
+    from sos_slam_amd import host, lib
+    from sos_slam_amd.records import ActivateParams, Calib
+    win = synth.make_window("W7")
+    newest = win.n - 1
+    prm, aprm, calib = TraceParams.default(), ActivateParams.default(), Calib.from_K(win.K)
+    ctx = lib.Context(win.w, win.h)
+    dI0 = []
+    for i in range(win.n):
+        ctx.make_pyramid(i, win.images[i])
+        dI0.append(orc.make_images(win.images[i])[0][0])
+    # candidates of every older keyframe, traced against two later keyframes (device; checked against the oracle elsewhere)
+    parts, hosts = [], []
+    for hst in range(newest):
+        u, v, _ = ih.candidates(win, hst, 400, seed=hst)
+        pts = ctx.immature_init(prm, hst, u, v)
+        for tgt in (hst + 1, newest) if hst + 1 != newest else (newest,):
+            KRKi, Kt, aff = ih.host_to_frame(win.K, win.frames[hst]["camToWorld"], win.frames[tgt]["camToWorld"])
+            pts = ctx.immature_trace(prm, tgt, pts, KRKi, Kt, aff)
+        parts.append(pts)
+        hosts.append(np.full(len(pts), hst, np.int32))
+    cand, chost = np.concatenate(parts), np.concatenate(hosts)
+    ctype = np.ones(len(cand), np.float32)
+    act = win.points[::4]
+    KRKi1, Kt1 = ih.level1_to_newest(win, newest)
+    flagged = np.zeros(win.n, np.uint8)
+    flagged[0] = 1
+    pairs = ih.pair_tfms(win)
+    w1, h1 = win.w // 2, win.h // 2
+    min_dist = host.next_min_act_dist(2.0, len(act), 2000.0)
+    assert min_dist == orc.next_min_act_dist(2.0, len(act), 2000.0)
+
+    def flow(select, activate):
+        dec, _ = select(w1, h1, newest, KRKi1, Kt1, act, min_dist, 3.0, cand, chost, ctype, flagged)
+        todo = np.flatnonzero(dec == 1)
+        res = activate(cand[todo], chost[todo])
+        return dec, todo, res
+
+    d_o, t_o, r_o = flow(orc.activate_select, lambda p, h: orc.immature_activate(aprm, calib, dI0, pairs, p, h))
+    d_g, t_g, r_g = flow(host.activate_select, lambda p, h: ctx.immature_activate(aprm, calib, np.arange(win.n), pairs, p, h))
+    assert np.array_equal(d_o, d_g) and np.array_equal(t_o, t_g)
+    assert _act_same(r_g, r_o) is None, _act_same(r_g, r_o)
+    activated = t_g[r_g["status"] == 1]
+    assert len(activated) > 100 and (d_g == -1).sum() > 0 and (d_g == 0).sum() > 0
+    # what FS/FullSystem.cpp:489-509 does with the results: new points, deletions, survivors
+    gone = set(np.flatnonzero(d_g == -1)) | set(t_g[(r_g["status"] == -1) | ((r_g["status"] == 0) & (cand["lastTraceStatus"][t_g] == 1))])
+    survivors = set(range(len(cand))) - gone - set(activated)
+    assert len(survivors) + len(gone) + len(activated) == len(cand)
+    ctx.close()
