@@ -190,9 +190,13 @@ def main():
                          "bytes_per_residual_parts": {"linearize": LINEARIZE_BYTES_PER_RESIDUAL, "top_accumulate": TOP_BYTES_PER_RESIDUAL},
                          "avg_launch_us": fused_ms * 1e3,
                          "launch_floor_us": floor_ms * 1e3, "equal_bytes_stream_read_us": stream_ms * 1e3,
+                         "measured_stream_peak": R_local * fused_bytes / (stream_ms * 1e-3) / 1e9,
+                         "frac_of_measured_stream": stream_ms / fused_ms,
                          "note": "launch_floor_us = empty kernel with the same grid, block and LDS size; "
                                  "equal_bytes_stream_read_us = coalesced 16 B/lane read of residuals x bytes_per_residual "
-                                 "bytes (both back to back on the same stream, like avg_launch_us)",
+                                 "bytes (both back to back on the same stream, like avg_launch_us); measured_stream_peak = "
+                                 "those bytes / that time in GB/s, frac_of_measured_stream = achieved / measured_stream_peak "
+                                 "(the north star's 'measured HBM roofline'; `peak` / `frac` use the nominal 8 TB/s)",
                          "unfused_linearize": {"avg_launch_us": lin_ms * 1e3, "bytes_per_residual": LINEARIZE_BYTES_PER_RESIDUAL,
                                                "achieved": R_local * LINEARIZE_BYTES_PER_RESIDUAL / (lin_ms * 1e-3) / 1e9,
                                                "frac": R_local * LINEARIZE_BYTES_PER_RESIDUAL / (lin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},

@@ -470,6 +470,35 @@ int sos_immature_activate(sos_ctx *ctx, const sos_activate_params *prm, const so
                           const int32_t *frameSlot, const sos_pair_tfm *pairs, int count, const sos_immature *pts,
                           const int32_t *hostOfPoint, sos_activation *out);
 
+/* ---- pixel selection in front of the immature points: PixelSelector (FS/PixelSelector2.cpp) ----------------------------
+ * makeHists :69-155 (per 32x32 cell gradient histogram -> threshold, 3x3 smoothing), select :292-424 (one pixel per
+ * pot / 2 pot / 4 pot cell on three pyramid levels, direction chosen from a random pattern indexed by the running
+ * count of level-0 selections), makeMaps :157-290 (re-selection with another potential, random sub-sampling). */
+typedef struct sos_pixsel_params {
+  float minGradHistCut;             /* setting_minGradHistCut = 0.5 */
+  float minGradHistAdd;             /* setting_minGradHistAdd = 7 */
+  float gradDownweightPerLevel;     /* setting_gradDownweightPerLevel = 0.75 */
+  int32_t selectDirectionDistribution; /* setting_selectDirectionDistribution = true */
+} sos_pixsel_params;
+typedef struct sos_pixsel sos_pixsel;
+/* new PixelSelector(w, h): randomPattern = w*h bytes, rand() & 0xFF after srand(3141592) (:37-40), supplied by the
+ * caller */
+int sos_pixsel_create(sos_ctx *ctx, const sos_pixsel_params *prm, const uint8_t *randomPattern, sos_pixsel **out);
+int sos_pixsel_destroy(sos_pixsel *ps);
+/* makeHists of the frame in `slot` (pyramid made by sos_make_pyramid); ths / thsSmoothed: (w/32)*(h/32) floats, optional */
+int sos_pixsel_make_hists(sos_pixsel *ps, int slot, float *ths, float *thsSmoothed);
+/* select(fh, map_out, pot, thFactor) after make_hists of the same slot; map_out: w*h floats (0, 1, 2, 4), optional;
+ * n: counts of level-0 / 1 / 2 selections */
+int sos_pixsel_select(sos_pixsel *ps, int slot, int pot, float thFactor, float *map_out, int32_t n[3]);
+/* makeMaps(fh, map_out, density, recursionsLeft, false, thFactor): runs make_hists when the slot changed, select, the
+ * re-selection recursion and the sub-sampling; *currentPotential in / out; *numSelected = the return value (numHaveSub).
+ * map_out optional. */
+int sos_pixsel_make_maps(sos_pixsel *ps, int slot, float density, int recursionsLeft, float thFactor, int32_t *currentPotential,
+                         float *map_out, int32_t *numSelected);
+/* the loop of FullSystem::makeNewTraces (FS/FullSystem.cpp:1083-1095) over the last map: selected pixels with
+ * padding + 1 <= x < w - padding - 2 (same for y) in row-major order; capacity entries at most, *count = all of them */
+int sos_pixsel_list(sos_pixsel *ps, int patternPadding, int capacity, int32_t *u, int32_t *v, float *type, int32_t *count);
+
 const char *sos_backend_name(void);
 
 #ifdef __cplusplus

@@ -171,4 +171,13 @@ int orc_activate_select(int w1, int h1, int nFrames, int newest, const float *KR
                         const int32_t *cand_host, const float *cand_type, const uint8_t *hostFlagged, int8_t *decision,
                         float *distFinal);
 
+/* ---- pixel selection (orc_pixsel.c): PixelSelector::makeHists / select / makeMaps, FS/PixelSelector2.cpp ------------ */
+void orc_pixsel_make_hists(const sos_pixsel_params *prm, const float *absg0, int w, int h, float *ths, float *thsSmoothed);
+void orc_pixsel_select(const sos_pixsel_params *prm, const float *dI, const float *absg0, const float *absg1, const float *absg2,
+                       int w, int h, const uint8_t *randomPattern, const float *thsSmoothed, int pot, float thFactor,
+                       float *map_out, int32_t n_out[3]);
+int orc_pixsel_make_maps(const sos_pixsel_params *prm, const float *dI, const float *absg0, const float *absg1, const float *absg2,
+                         int w, int h, const uint8_t *randomPattern, const float *thsSmoothed, float density, int recursionsLeft,
+                         float thFactor, int *pot, float *map_out);
+
 #endif

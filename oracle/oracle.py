@@ -75,6 +75,9 @@ def lib():
         L.orc_immature_init.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
         L.orc_immature_trace.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
         L.orc_immature_activate.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp]
+        L.orc_pixsel_make_hists.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
+        L.orc_pixsel_select.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_float, vp, vp]
+        L.orc_pixsel_make_maps.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, C.c_float, C.c_int, C.c_float, vp, vp]
         L.orc_activate_select.argtypes = [C.c_int] * 4 + [vp, vp, C.c_int, vp, vp, vp, vp, C.c_float, C.c_float, C.c_int, vp, vp, vp, vp, vp, vp]
         L.orc_next_min_act_dist.argtypes = [C.c_float, C.c_int, C.c_float]
         L.orc_next_min_act_dist.restype = C.c_float
@@ -211,6 +214,44 @@ def activate_select(w1, h1, newest, KRKi, Kt, act, min_dist, min_quality, cand, 
 
 def next_min_act_dist(cur, n_points, desired):
     return float(lib().orc_next_min_act_dist(cur, n_points, desired))
+
+
+class PixelSelector:
+    """PixelSelector restatement over one frame's level-0 dI and absSquaredGrad levels 0..2 (orc_make_images output)."""
+
+    def __init__(self, prm, pattern, w, h):
+        self.prm, self.w, self.h = prm, w, h
+        self.pattern = np.ascontiguousarray(pattern, dtype=np.uint8)
+        self.current_potential = 3
+        self.ths = self.sm = None
+
+    def make_hists(self, absg0):
+        n = (self.w // 32) * (self.h // 32)
+        self.ths, self.sm = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        a = np.ascontiguousarray(absg0, dtype=np.float32)
+        lib().orc_pixsel_make_hists(C.byref(self.prm), _p(a), self.w, self.h, _p(self.ths), _p(self.sm))
+        return self.ths, self.sm
+
+    def _imgs(self, dI, absg):
+        return [np.ascontiguousarray(dI[0], dtype=np.float32)] + [np.ascontiguousarray(absg[l], dtype=np.float32) for l in range(3)]
+
+    def select(self, dI, absg, pot, th_factor=1.0):
+        im = self._imgs(dI, absg)
+        m = np.zeros((self.h, self.w), np.float32)
+        n = np.zeros(3, np.int32)
+        lib().orc_pixsel_select(C.byref(self.prm), _p(im[0]), _p(im[1]), _p(im[2]), _p(im[3]), self.w, self.h, _p(self.pattern),
+                                _p(self.sm), pot, th_factor, _p(m), _p(n))
+        return m, n
+
+    def make_maps(self, dI, absg, density, recursions_left=1, th_factor=1.0):
+        im = self._imgs(dI, absg)
+        m = np.zeros((self.h, self.w), np.float32)
+        pot = C.c_int(self.current_potential)
+        lib().orc_pixsel_make_maps.restype = C.c_int
+        num = lib().orc_pixsel_make_maps(C.byref(self.prm), _p(im[0]), _p(im[1]), _p(im[2]), _p(im[3]), self.w, self.h,
+                                         _p(self.pattern), _p(self.sm), density, recursions_left, th_factor, C.byref(pot), _p(m))
+        self.current_potential = pot.value
+        return m, int(num)
 
 
 class OracleWindow:

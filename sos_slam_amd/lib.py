@@ -23,7 +23,7 @@ SYMBOLS = [
     "sos_ba_set_window", "sos_ba_set_state", "sos_ba_linearize", "sos_ba_apply_res", "sos_ba_reset_oob",
     "sos_ba_fix_linearization", "sos_ba_accumulate", "sos_ba_accumulate_local", "sos_ba_acc_buffer",
     "sos_ba_stitch", "sos_ba_gn_accumulate", "sos_ba_gn_step", "sos_ba_get_point_hessian", "sos_ba_resubstitute", "sos_ba_calc_lenergy",
-    "sos_ba_accumulate_marg", "sos_ba_update_point_priors", "sos_ba_set_prefetch", "sos_tracker_set_gs_hint", "sos_immature_init", "sos_immature_trace", "sos_immature_trace_all", "sos_immature_activate", "sos_rccl_load", "sos_rccl_unique_id", "sos_comm_create", "sos_comm_destroy", "sos_comm_size",
+    "sos_ba_accumulate_marg", "sos_ba_update_point_priors", "sos_ba_set_prefetch", "sos_tracker_set_gs_hint", "sos_immature_init", "sos_immature_trace", "sos_immature_trace_all", "sos_immature_activate", "sos_pixsel_create", "sos_pixsel_destroy", "sos_pixsel_make_hists", "sos_pixsel_select", "sos_pixsel_make_maps", "sos_pixsel_list", "sos_rccl_load", "sos_rccl_unique_id", "sos_comm_create", "sos_comm_destroy", "sos_comm_size",
     "sos_comm_rank", "sos_ba_set_comm", "sos_ba_newest_capacity", "sos_ba_gather_energies", "sos_ba_allreduce_f64", "sos_ba_get_jacobian", "sos_ba_get_residual_flags", "sos_ba_get_JpJdF",
     "sos_ba_get_res_toZeroF", "sos_ba_time_kernel", "sos_tracker_create", "sos_tracker_destroy",
     "sos_tracker_set_ref", "sos_tracker_scale_depth", "sos_tracker_get_pc", "sos_tracker_calc_res",
@@ -87,6 +87,12 @@ def load():
     L.sos_immature_trace.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp]
     L.sos_immature_trace_all.argtypes = [vp, vp, ci, ci, vp, vp, ci, vp, vp, vp]
     L.sos_immature_activate.argtypes = [vp, vp, vp, ci, vp, vp, ci, vp, vp, vp]
+    L.sos_pixsel_create.argtypes = [vp, vp, vp, C.POINTER(vp)]
+    L.sos_pixsel_destroy.argtypes = [vp]
+    L.sos_pixsel_make_hists.argtypes = [vp, ci, vp, vp]
+    L.sos_pixsel_select.argtypes = [vp, ci, ci, C.c_float, vp, vp]
+    L.sos_pixsel_make_maps.argtypes = [vp, ci, C.c_float, ci, C.c_float, vp, vp, vp]
+    L.sos_pixsel_list.argtypes = [vp, ci, ci, vp, vp, vp, vp]
     L.sos_rccl_load.argtypes = [C.c_char_p]
     L.sos_rccl_unique_id.argtypes = [vp]
     L.sos_comm_create.argtypes = [vp, ci, ci, ci, C.POINTER(vp)]
@@ -435,3 +441,56 @@ class Tracker:
         _chk(self.L.sos_tracker_calc_gs_scale(self._h, lvl, _p(a[0]), _p(a[1]), scale, C.byref(H), C.byref(b)),
              "sos_tracker_calc_gs_scale")
         return H.value, b.value
+
+
+class PixelSelector:
+    """sos_pixsel: PixelSelector (FS/PixelSelector2.cpp) over the frames of a Context."""
+
+    def __init__(self, ctx: Context, prm, pattern):
+        self.L = load()
+        self.ctx = ctx
+        self.w, self.h = ctx.w, ctx.h
+        pattern = np.ascontiguousarray(pattern, dtype=np.uint8)
+        assert pattern.size == self.w * self.h
+        self.h_ = C.c_void_p()
+        _chk(self.L.sos_pixsel_create(ctx.h_, C.byref(prm), _p(pattern), C.byref(self.h_)), "sos_pixsel_create")
+        self.current_potential = 3
+
+    def close(self):
+        if self.h_:
+            self.L.sos_pixsel_destroy(self.h_)
+            self.h_ = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def make_hists(self, slot):
+        n = (self.w // 32) * (self.h // 32)
+        ths, sm = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        _chk(self.L.sos_pixsel_make_hists(self.h_, slot, _p(ths), _p(sm)), "sos_pixsel_make_hists")
+        return ths, sm
+
+    def select(self, slot, pot, th_factor=1.0, want_map=True):
+        m = np.zeros((self.h, self.w), np.float32) if want_map else None
+        n = np.zeros(3, np.int32)
+        _chk(self.L.sos_pixsel_select(self.h_, slot, pot, th_factor, _p(m), _p(n)), "sos_pixsel_select")
+        return m, n
+
+    def make_maps(self, slot, density, recursions_left=1, th_factor=1.0, want_map=True):
+        m = np.zeros((self.h, self.w), np.float32) if want_map else None
+        pot = C.c_int32(self.current_potential)
+        num = C.c_int32(0)
+        _chk(self.L.sos_pixsel_make_maps(self.h_, slot, density, recursions_left, th_factor, C.byref(pot), _p(m), C.byref(num)),
+             "sos_pixsel_make_maps")
+        self.current_potential = pot.value
+        return m, num.value
+
+    def list(self, pattern_padding=2, capacity=1 << 16):
+        u, v, t = np.zeros(capacity, np.int32), np.zeros(capacity, np.int32), np.zeros(capacity, np.float32)
+        cnt = C.c_int32(0)
+        _chk(self.L.sos_pixsel_list(self.h_, pattern_padding, capacity, _p(u), _p(v), _p(t), C.byref(cnt)), "sos_pixsel_list")
+        k = min(cnt.value, capacity)
+        return u[:k], v[:k], t[:k]

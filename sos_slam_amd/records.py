@@ -82,3 +82,23 @@ ACTIVATION_DTYPE = np.dtype([("status", "i4"), ("idepth", "f4"), ("inMask", "u4"
                              ("bd", "f4"), ("iterations", "i4"), ("pad", "i4")])
 assert PAIR_TFM_DTYPE.itemsize == 64 and ACTIVATION_DTYPE.itemsize == 32
 ACT_SKIP, ACT_DELETE, ACT_ACTIVATED = 0, -1, 1
+
+
+class PixselParams(C.Structure):
+    """sos_pixsel_params: globals of PixelSelector (util/settings.cpp:122-125)."""
+    _fields_ = [("minGradHistCut", C.c_float), ("minGradHistAdd", C.c_float), ("gradDownweightPerLevel", C.c_float),
+                ("selectDirectionDistribution", C.c_int32)]
+
+    @classmethod
+    def default(cls, **over):
+        p = cls(0.5, 7.0, 0.75, 1)
+        for k, v in over.items():
+            setattr(p, k, v)
+        return p
+
+
+def random_pattern(npx):
+    """PixelSelector's randomPattern: glibc rand() & 0xFF after srand(3141592) (FS/PixelSelector2.cpp:37-40)."""
+    libc = C.CDLL("libc.so.6")
+    libc.srand(3141592)
+    return np.fromiter((libc.rand() & 0xFF for _ in range(npx)), dtype=np.uint8, count=npx)

@@ -93,7 +93,30 @@ t_act_cpu = (time.perf_counter() - t0) / 3
 act = {"candidates": int(len(cand)), "gpu_ms": t_act_gpu * 1e3, "cpu_port_ms_1thread": t_act_cpu * 1e3,
        "identical_to_oracle": bool(all(np.array_equal(a_g[f], a_c[f], equal_nan=True) for f in a_g.dtype.names if f != "pad")),
        "status_histogram_skip_delete_activated": [int((a_g["status"] == k).sum()) for k in (0, -1, 1)]}
+# pixel selection in front of the constructor (PixelSelector::makeMaps, once per keyframe)
+from sos_slam_amd.records import PixselParams, random_pattern  # noqa: E402
+pat = random_pattern(win.w * win.h)
+pprm = PixselParams.default()
+sel_g, sel_o = lib.PixelSelector(ctx, pprm, pat), orc.PixelSelector(pprm, pat, win.w, win.h)
+dIk, absgk = orc.make_images(win.images[0])
+sel_o.make_hists(absgk[0])
+sel_g.make_hists(0)
+m_g, n_g = sel_g.make_maps(0, 1500.0)
+m_o, n_o = sel_o.make_maps(dIk, absgk, 1500.0)
+t0 = time.perf_counter()
+for _ in range(20):
+    sel_g.current_potential = 3
+    sel_g.make_maps(0, 1500.0, want_map=False)
+t_sel_gpu = (time.perf_counter() - t0) / 20
+t0 = time.perf_counter()
+for _ in range(5):
+    sel_o.current_potential = 3
+    sel_o.make_maps(dIk, absgk, 1500.0)
+t_sel_cpu = (time.perf_counter() - t0) / 5
+pixsel = {"make_maps_gpu_ms": t_sel_gpu * 1e3, "make_maps_cpu_port_ms": t_sel_cpu * 1e3, "selected": int(n_g),
+          "identical_to_oracle": bool(n_g == n_o and np.array_equal(m_g, m_o))}
+sel_g.close()
 print(json.dumps({"window": name, "keyframes": win.n, "immature_points": int(len(st)), "gpu_ms": t_gpu * 1e3, "cpu_port_ms_1thread": t_cpu * 1e3,
                   "points_per_s_gpu": len(st) / t_gpu, "identical_to_oracle": bool(same),
-                  "status_histogram": np.bincount(st, minlength=6).tolist(), "activation": act}))
+                  "status_histogram": np.bincount(st, minlength=6).tolist(), "activation": act, "pixel_selection": pixsel}))
 ctx.close()
