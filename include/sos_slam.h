@@ -499,6 +499,47 @@ int sos_pixsel_make_maps(sos_pixsel *ps, int slot, float density, int recursions
  * padding + 1 <= x < w - padding - 2 (same for y) in row-major order; capacity entries at most, *count = all of them */
 int sos_pixsel_list(sos_pixsel *ps, int patternPadding, int capacity, int32_t *u, int32_t *v, float *type, int32_t *count);
 
+/* ---- image front-end: Undistort / PhotometricUndistorter (U/Undistort.cpp) --------------------------------------------
+ * The DSO camera file (4 lines: model + parameters, input size, "crop" | "none" | fx fy cx cy 0, output size;
+ * getUndistorterForFile :240-351, readFromFile :679-890), the rectified camera matrix (makeOptimalK_crop :557-672),
+ * the remap table (distortCoordinates of the five models :902-1126) and per frame the photometric correction
+ * (processFrame :194-227) + bilinear remap (undistort :361-458) feeding the pyramid.  The table is built once on the
+ * host (libm transcendental functions, as the reference); the per-frame work runs on the device. */
+#define SOS_CAM_RADTAN 0
+#define SOS_CAM_PINHOLE 1
+#define SOS_CAM_EQUIDISTANT 2
+#define SOS_CAM_KB 3
+#define SOS_CAM_FOV 4
+#define SOS_RECT_CROP (-1)
+#define SOS_RECT_NONE (-3)
+#define SOS_RECT_GIVEN 0
+typedef struct sos_camera_model {
+  int32_t model;            /* SOS_CAM_* */
+  int32_t rect;             /* SOS_RECT_* */
+  double pars[8];           /* parsOrg after the relative-format rescale (fx fy cx cy + distortion) */
+  int32_t wOrg, hOrg, w, h; /* input and output size */
+  float outCal[5];          /* line 3 when SOS_RECT_GIVEN (relative fx fy cx cy, 0) */
+  int32_t pad;
+} sos_camera_model;
+/* parses the text of a camera file; returns SOS_ERR_ARG on the formats the reference rejects ("full" is not
+ * implemented there either) */
+int sos_camera_parse(const char *text, sos_camera_model *out);
+
+typedef struct sos_undistort sos_undistort;
+/* G: inverse response, GDepth >= 256 strictly increasing entries as read from pcalib.txt (normalised here as
+ * :84-92), or NULL; vignette: wOrg*hOrg values of the vignette image (any scale; divided by their maximum as :113-141),
+ * or NULL.  photometricMode = setting_photometricCalibration (0 none, 1 response only, 2 response + vignette).  The
+ * context must have been created with the model's output size. */
+int sos_undistort_create(sos_ctx *ctx, const sos_camera_model *cam, const float *G, int GDepth, const float *vignette,
+                         int photometricMode, sos_undistort **out);
+int sos_undistort_destroy(sos_undistort *u);
+/* K = rectified fx fy cx cy; remapX / remapY: w*h floats, optional */
+int sos_undistort_get(sos_undistort *u, float K[4], float *remapX, float *remapY, int32_t *passthrough);
+/* Undistort::undistort<T>(image_raw, exposure, timestamp, factor) followed by FrameHessian::makeImages into `slot`
+ * (bytesPerPixel 1 or 2); image_out (optional, w*h floats) receives the undistorted irradiance image. */
+int sos_undistort_frame(sos_undistort *u, const void *raw, int bytesPerPixel, float exposure, float factor, int slot,
+                        const float *gammaBgrad, float *image_out);
+
 const char *sos_backend_name(void);
 
 #ifdef __cplusplus

@@ -180,4 +180,12 @@ int orc_pixsel_make_maps(const sos_pixsel_params *prm, const float *dI, const fl
                          int w, int h, const uint8_t *randomPattern, const float *thsSmoothed, float density, int recursionsLeft,
                          float thFactor, int *pot, float *map_out);
 
+/* ---- image front-end (orc_undistort.c): camera file, rectified K + remap table, photometric + geometric undistortion -- */
+int orc_camera_parse(const char *text, sos_camera_model *out);
+int orc_undistort_setup(const sos_camera_model *cam, double K[4], float *remapX, float *remapY, int *passthrough);
+int orc_photometric_setup(float *G, int GDepth, const float *vignette, int n, int photometricMode, float *vignetteInv);
+void orc_undistort_frame(const sos_camera_model *cam, const float *remapX, const float *remapY, int passthrough, const float *G,
+                         int valid, const float *vignetteInv, int photometricMode, const void *raw, int bpp, float exposure,
+                         float factor, float *out);
+
 #endif

@@ -75,6 +75,10 @@ def lib():
         L.orc_immature_init.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
         L.orc_immature_trace.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
         L.orc_immature_activate.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp]
+        L.orc_camera_parse.argtypes = [C.c_char_p, vp]
+        L.orc_undistort_setup.argtypes = [vp, vp, vp, vp, vp]
+        L.orc_photometric_setup.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp]
+        L.orc_undistort_frame.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_float, C.c_float, vp]
         L.orc_pixsel_make_hists.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
         L.orc_pixsel_select.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_float, vp, vp]
         L.orc_pixsel_make_maps.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, C.c_float, C.c_int, C.c_float, vp, vp]
@@ -214,6 +218,39 @@ def activate_select(w1, h1, newest, KRKi, Kt, act, min_dist, min_quality, cand, 
 
 def next_min_act_dist(cur, n_points, desired):
     return float(lib().orc_next_min_act_dist(cur, n_points, desired))
+
+
+class Undistorter:
+    """Undistort + PhotometricUndistorter restatement (orc_undistort.c)."""
+
+    def __init__(self, text, G=None, vignette=None, photometric_mode=2):
+        from sos_slam_amd.records import CameraModel
+        self.cam = CameraModel()
+        if lib().orc_camera_parse(text.encode(), C.byref(self.cam)) != 0:
+            raise ValueError("camera file rejected")
+        m = self.cam
+        self.K = np.zeros(4, np.float64)
+        self.remapX = np.zeros((m.h, m.w), np.float32)
+        self.remapY = np.zeros_like(self.remapX)
+        pt = C.c_int(0)
+        if lib().orc_undistort_setup(C.byref(m), _p(self.K), _p(self.remapX), _p(self.remapY), C.byref(pt)) != 0:
+            raise ValueError("no rectification found")
+        self.passthrough = bool(pt.value)
+        self.mode = photometric_mode
+        self.valid = 0
+        self.G = self.vinv = None
+        if G is not None and vignette is not None:
+            self.G = np.ascontiguousarray(G, dtype=np.float32).copy()
+            v = np.ascontiguousarray(vignette, dtype=np.float32)
+            self.vinv = np.zeros(v.size, np.float32)
+            self.valid = lib().orc_photometric_setup(_p(self.G), len(self.G), _p(v), v.size, photometric_mode, _p(self.vinv))
+
+    def frame(self, raw, exposure, factor=1.0):
+        raw = np.ascontiguousarray(raw)
+        out = np.zeros((self.cam.h, self.cam.w), np.float32)
+        lib().orc_undistort_frame(C.byref(self.cam), _p(self.remapX), _p(self.remapY), int(self.passthrough), _p(self.G), int(self.valid),
+                                  _p(self.vinv), self.mode, _p(raw), raw.dtype.itemsize, exposure, factor, _p(out))
+        return out
 
 
 class PixelSelector:

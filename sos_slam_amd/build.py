@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(HERE, "..", "include")
 
-HIP_SOURCES = ["sos_ctx.hip", "sos_ba.hip", "sos_tracker.hip", "sos_comm.hip", "sos_immature.hip", "sos_pixsel.hip"]
+HIP_SOURCES = ["sos_ctx.hip", "sos_ba.hip", "sos_tracker.hip", "sos_comm.hip", "sos_immature.hip", "sos_pixsel.hip", "sos_undistort.hip"]
 HIP_LIB = os.path.join(CSRC, "libsos_slam_hip.so")
 HOST_SOURCES = ["host/sos_host.cpp"]
 HOST_LIB = os.path.join(CSRC, "libsos_host.so")

@@ -72,6 +72,7 @@ struct sos_ctx {
 };
 
 int sos_ctx_ensure_slot(sos_ctx *ctx, int slot, bool all_levels);
+int sos_ctx_pyramid_from_staged(sos_ctx *ctx, int slot, const float *gammaB);  // makeImages from the float image in ctx->d_img
 
 // RCCL communicator (sos_comm.hip): collectives enqueued on the caller's stream
 int sos_comm_allreduce_sum_f32(sos_comm *c, float *buf, size_t count, hipStream_t st);

@@ -165,13 +165,11 @@ static int launch_tile_level0(sos_ctx *c, int slot) {
   return hipGetLastError() == hipSuccess ? SOS_OK : SOS_ERR_HIP;
 }
 
-extern "C" int sos_make_pyramid(sos_ctx *c, int slot, const float *img, const float *gammaB) {
-  if (!c || !img) return SOS_ERR_ARG;
-  SOS_HIP(hipSetDevice(c->device));
+// FrameHessian::makeImages from the float image already in c->d_img (sos_make_pyramid, sos_undistort_frame)
+int sos_ctx_pyramid_from_staged(sos_ctx *c, int slot, const float *gammaB) {
   int rc = sos_ctx_ensure_slot(c, slot, true);
   if (rc) return rc;
   size_t npx0 = (size_t)c->w * c->h;
-  SOS_HIP(hipMemcpyAsync(c->d_img, img, sizeof(float) * npx0, hipMemcpyHostToDevice, c->stream));
   if (gammaB) SOS_HIP(hipMemcpyAsync(c->d_gammaB, gammaB, sizeof(float) * 256, hipMemcpyHostToDevice, c->stream));
   const int B = 256;
   k_pyr_level0<<<(unsigned)((npx0 + B - 1) / B), B, 0, c->stream>>>(c->d_img, c->dI[slot][0], (int)npx0);
@@ -186,8 +184,19 @@ extern "C" int sos_make_pyramid(sos_ctx *c, int slot, const float *img, const fl
   SOS_HIP(hipGetLastError());
   rc = launch_tile_level0(c, slot);
   if (rc) return rc;
-  SOS_HIP(hipStreamSynchronize(c->stream));  // `img` is a caller-owned pageable buffer
   c->has_pyr[slot] = true;
+  return SOS_OK;
+}
+
+extern "C" int sos_make_pyramid(sos_ctx *c, int slot, const float *img, const float *gammaB) {
+  if (!c || !img) return SOS_ERR_ARG;
+  SOS_HIP(hipSetDevice(c->device));
+  int rc = sos_ctx_ensure_slot(c, slot, true);
+  if (rc) return rc;
+  SOS_HIP(hipMemcpyAsync(c->d_img, img, sizeof(float) * (size_t)c->w * c->h, hipMemcpyHostToDevice, c->stream));
+  rc = sos_ctx_pyramid_from_staged(c, slot, gammaB);
+  if (rc) return rc;
+  SOS_HIP(hipStreamSynchronize(c->stream));  // `img` is a caller-owned pageable buffer
   return SOS_OK;
 }
 

@@ -23,7 +23,7 @@ SYMBOLS = [
     "sos_ba_set_window", "sos_ba_set_state", "sos_ba_linearize", "sos_ba_apply_res", "sos_ba_reset_oob",
     "sos_ba_fix_linearization", "sos_ba_accumulate", "sos_ba_accumulate_local", "sos_ba_acc_buffer",
     "sos_ba_stitch", "sos_ba_gn_accumulate", "sos_ba_gn_step", "sos_ba_get_point_hessian", "sos_ba_resubstitute", "sos_ba_calc_lenergy",
-    "sos_ba_accumulate_marg", "sos_ba_update_point_priors", "sos_ba_set_prefetch", "sos_tracker_set_gs_hint", "sos_immature_init", "sos_immature_trace", "sos_immature_trace_all", "sos_immature_activate", "sos_pixsel_create", "sos_pixsel_destroy", "sos_pixsel_make_hists", "sos_pixsel_select", "sos_pixsel_make_maps", "sos_pixsel_list", "sos_rccl_load", "sos_rccl_unique_id", "sos_comm_create", "sos_comm_destroy", "sos_comm_size",
+    "sos_ba_accumulate_marg", "sos_ba_update_point_priors", "sos_ba_set_prefetch", "sos_tracker_set_gs_hint", "sos_immature_init", "sos_immature_trace", "sos_immature_trace_all", "sos_immature_activate", "sos_pixsel_create", "sos_pixsel_destroy", "sos_pixsel_make_hists", "sos_pixsel_select", "sos_pixsel_make_maps", "sos_pixsel_list", "sos_camera_parse", "sos_undistort_create", "sos_undistort_destroy", "sos_undistort_get", "sos_undistort_frame", "sos_rccl_load", "sos_rccl_unique_id", "sos_comm_create", "sos_comm_destroy", "sos_comm_size",
     "sos_comm_rank", "sos_ba_set_comm", "sos_ba_newest_capacity", "sos_ba_gather_energies", "sos_ba_allreduce_f64", "sos_ba_get_jacobian", "sos_ba_get_residual_flags", "sos_ba_get_JpJdF",
     "sos_ba_get_res_toZeroF", "sos_ba_time_kernel", "sos_tracker_create", "sos_tracker_destroy",
     "sos_tracker_set_ref", "sos_tracker_scale_depth", "sos_tracker_get_pc", "sos_tracker_calc_res",
@@ -93,6 +93,11 @@ def load():
     L.sos_pixsel_select.argtypes = [vp, ci, ci, C.c_float, vp, vp]
     L.sos_pixsel_make_maps.argtypes = [vp, ci, C.c_float, ci, C.c_float, vp, vp, vp]
     L.sos_pixsel_list.argtypes = [vp, ci, ci, vp, vp, vp, vp]
+    L.sos_camera_parse.argtypes = [C.c_char_p, vp]
+    L.sos_undistort_create.argtypes = [vp, vp, vp, ci, vp, ci, C.POINTER(vp)]
+    L.sos_undistort_destroy.argtypes = [vp]
+    L.sos_undistort_get.argtypes = [vp, vp, vp, vp, vp]
+    L.sos_undistort_frame.argtypes = [vp, vp, ci, C.c_float, C.c_float, ci, vp, vp]
     L.sos_rccl_load.argtypes = [C.c_char_p]
     L.sos_rccl_unique_id.argtypes = [vp]
     L.sos_comm_create.argtypes = [vp, ci, ci, ci, C.POINTER(vp)]
@@ -144,7 +149,19 @@ class Context:
              "sos_ctx_create (is an MI355X visible?)")
         self.levels = self.L.sos_ctx_pyr_levels(self.h_)
 
+    def _adopt(self, child):
+        """objects holding device state of this context are closed before it"""
+        import weakref
+        if not hasattr(self, "_children"):
+            self._children = []
+        self._children.append(weakref.ref(child))
+
     def close(self):
+        for r in getattr(self, "_children", []):
+            ch = r()
+            if ch is not None:
+                ch.close()
+        self._children = []
         if getattr(self, "h_", None):
             self.L.sos_ctx_destroy(self.h_)
             self.h_ = None
@@ -454,6 +471,7 @@ class PixelSelector:
         assert pattern.size == self.w * self.h
         self.h_ = C.c_void_p()
         _chk(self.L.sos_pixsel_create(ctx.h_, C.byref(prm), _p(pattern), C.byref(self.h_)), "sos_pixsel_create")
+        ctx._adopt(self)
         self.current_potential = 3
 
     def close(self):
@@ -494,3 +512,51 @@ class PixelSelector:
         _chk(self.L.sos_pixsel_list(self.h_, pattern_padding, capacity, _p(u), _p(v), _p(t), C.byref(cnt)), "sos_pixsel_list")
         k = min(cnt.value, capacity)
         return u[:k], v[:k], t[:k]
+
+
+def camera_parse(text: str):
+    """sos_camera_parse: the 4-line DSO camera file -> records.CameraModel (raises on the formats the reference rejects)."""
+    from .records import CameraModel
+    m = CameraModel()
+    _chk(load().sos_camera_parse(text.encode(), C.byref(m)), "sos_camera_parse")
+    return m
+
+
+class Undistorter:
+    """sos_undistort: Undistort + PhotometricUndistorter feeding the pyramid of a Context (created with the output size)."""
+
+    def __init__(self, ctx: Context, cam, G=None, vignette=None, photometric_mode=2):
+        self.L, self.ctx, self.cam = load(), ctx, cam
+        g = None if G is None else np.ascontiguousarray(G, dtype=np.float32)
+        v = None if vignette is None else np.ascontiguousarray(vignette, dtype=np.float32)
+        self.h_ = C.c_void_p()
+        _chk(self.L.sos_undistort_create(ctx.h_, C.byref(cam), _p(g), 0 if g is None else len(g), _p(v), photometric_mode, C.byref(self.h_)),
+             "sos_undistort_create")
+        ctx._adopt(self)
+
+    def close(self):
+        if self.h_:
+            self.L.sos_undistort_destroy(self.h_)
+            self.h_ = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def get(self):
+        K = np.zeros(4, np.float32)
+        rx = np.zeros((self.cam.h, self.cam.w), np.float32)
+        ry = np.zeros_like(rx)
+        pt = C.c_int32(0)
+        _chk(self.L.sos_undistort_get(self.h_, _p(K), _p(rx), _p(ry), C.byref(pt)), "sos_undistort_get")
+        return K, rx, ry, bool(pt.value)
+
+    def frame(self, raw, exposure, slot, factor=1.0, gammaB=None, want_image=True):
+        raw = np.ascontiguousarray(raw)
+        assert raw.dtype in (np.uint8, np.uint16) and raw.shape == (self.cam.hOrg, self.cam.wOrg)
+        out = np.zeros((self.cam.h, self.cam.w), np.float32) if want_image else None
+        gb = None if gammaB is None else np.ascontiguousarray(gammaB, dtype=np.float32)
+        _chk(self.L.sos_undistort_frame(self.h_, _p(raw), raw.dtype.itemsize, exposure, factor, slot, _p(gb), _p(out)), "sos_undistort_frame")
+        return out

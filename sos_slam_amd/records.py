@@ -102,3 +102,14 @@ def random_pattern(npx):
     libc = C.CDLL("libc.so.6")
     libc.srand(3141592)
     return np.fromiter((libc.rand() & 0xFF for _ in range(npx)), dtype=np.uint8, count=npx)
+
+
+class CameraModel(C.Structure):
+    """sos_camera_model: a parsed DSO camera file (U/Undistort.cpp:240-351, 679-800)."""
+    _fields_ = [("model", C.c_int32), ("rect", C.c_int32), ("pars", C.c_double * 8), ("wOrg", C.c_int32), ("hOrg", C.c_int32),
+                ("w", C.c_int32), ("h", C.c_int32), ("outCal", C.c_float * 5), ("pad", C.c_int32)]
+
+
+CAM_RADTAN, CAM_PINHOLE, CAM_EQUIDISTANT, CAM_KB, CAM_FOV = range(5)
+RECT_CROP, RECT_NONE, RECT_GIVEN = -1, -3, 0
+assert C.sizeof(CameraModel) == 112
