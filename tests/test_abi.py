@@ -56,6 +56,27 @@ def test_record_layouts_match_header():
     assert C.sizeof(records.Calib) == 32
 
 
+def test_record_sizes_against_the_compiled_header(tmp_path):
+    """sizeof of every record of include/sos_slam.h, as gcc lays it out, against the Python mirrors."""
+    import subprocess
+    from sos_slam_amd import records, synth
+    mirrors = {"sos_point": synth.POINT_DTYPE.itemsize, "sos_resid": synth.RESID_DTYPE.itemsize,
+               "sos_precalc": synth.PRECALC_DTYPE.itemsize, "sos_rawjac": synth.RAWJAC_DTYPE.itemsize,
+               "sos_params": C.sizeof(records.Params), "sos_calib": C.sizeof(records.Calib),
+               "sos_trace_params": C.sizeof(records.TraceParams), "sos_immature": records.IMMATURE_DTYPE.itemsize,
+               "sos_activate_params": C.sizeof(records.ActivateParams), "sos_pair_tfm": records.PAIR_TFM_DTYPE.itemsize,
+               "sos_activation": records.ACTIVATION_DTYPE.itemsize, "sos_pixsel_params": C.sizeof(records.PixselParams),
+               "sos_camera_model": C.sizeof(records.CameraModel)}
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "sos_slam.h"\nint main(void) {\n' +
+                   "".join(f'  printf("{n} %zu\\n", sizeof({n}));\n' for n in mirrors) + "  return 0;\n}\n")
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for n, size in mirrors.items():
+        assert int(got[n]) == size, (n, got[n], size)
+
+
 def test_facade_ldlt_variants_agree():
     """The blocked LDL^T on the GN critical path against the unblocked reference variant and numpy, including a
     singular matrix (exact-zero pivots contribute nothing, as with Eigen's ldlt().solve) -- host code, no GPU."""
