@@ -259,6 +259,12 @@ int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const sos_calib 
                    const float *adHTdeltaF, const float *cDeltaF, const float *frameEnergyTH, int applyRes,
                    double *energySum, float *newestEnergies, int *newestCount, float *pointStep);
 
+/* The back-substitution half of sos_ba_gn_step, enqueued ahead: it needs x alone, so the caller issues it right after the
+ * solve and computes the new poses / precalc records while it runs; the following sos_ba_gn_step must then be given
+ * x = NULL.  SOS_ERR_STATE when the window cannot take this path (no points / no fp32 adjoints yet): pass x to
+ * sos_ba_gn_step as before. */
+int sos_ba_gn_resub(sos_ba *ba, const double *x, float stepfacD);
+
 /* Pipelining switch of the fused calls: when on, sos_ba_gn_step(applyRes != 0) enqueues the accumulate + stitch of
  * the NEXT iteration right behind the linearisation (it depends on device state only) and returns as soon as the
  * linearisation results are on the host; the following sos_ba_gn_accumulate then only waits for it.  Any other

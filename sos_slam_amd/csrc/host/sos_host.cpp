@@ -938,6 +938,8 @@ int FullSystem::prepare() {  // FS/FullSystemOptimize.cpp:316-344
 bool FullSystem::gnIteration(int iteration, bool mayContinue) {  // :358-413 with setting_forceAceptStep
   { PhaseTimer tb(7); backupState(); }
   ef->solveSystemF(iteration, 1e-1, &HCalib, true);  // x, frame / calib steps; back-substitution deferred
+  // the back-substitution needs x alone: it runs on the device while the host derives the new poses and precalc records
+  const bool resubAhead = sos_ba_gn_resub(ef->ba, ef->lastX.data(), 1.0f) == SOS_OK;
   bool canbreak;
   { PhaseTimer t(3); canbreak = doStepFromBackup(1, 1, 1, 1, 1, true); }
   {
@@ -961,7 +963,7 @@ bool FullSystem::gnIteration(int iteration, bool mayContinue) {  // :358-413 wit
     // the next iteration's accumulate can be enqueued behind this linearisation when there will be one
     const bool more = pipelineAlways || (mayContinue && !(canbreak && iteration >= setting_minOptIterations));
     sos_ba_set_prefetch(ef->ba, (more && !ef->allreduceHook) ? 1 : 0);
-    lastError = sos_ba_gn_step(ef->ba, ef->lastX.data(), 1.0f, &cal, pc.data(), ef->adHTdeltaF.data(), ef->cDeltaF, th.data(),
+    lastError = sos_ba_gn_step(ef->ba, resubAhead ? nullptr : ef->lastX.data(), 1.0f, &cal, pc.data(), ef->adHTdeltaF.data(), ef->cDeltaF, th.data(),
                                1, &E, newestE.data(), &cnt, ef->pointStep.data());
     newestE.resize(cnt);
     PhaseTimer tpost(6);

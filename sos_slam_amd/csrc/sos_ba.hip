@@ -1934,6 +1934,22 @@ __global__ void k_expand_precalc(int ntiles, const int *__restrict__ t_pair, con
 // frame thresholds) from the device-mapped pinned block into device memory.
 struct XArg { float v[SOS_CPARS + 8 * SOS_MAX_FRAMES]; };
 #define SOS_RSB 256
+// one stage-in block: the first nStageBlocks copy the per-step inputs, the rest write the per-tile precalc records
+// straight from the mapped block
+__device__ __forceinline__ void stage_block(int sb, int tid, const BaDev &d, float4 *__restrict__ stage_dst, const float4 *__restrict__ stage_src,
+                                            int n4, int nStageBlocks, const float4 *__restrict__ pre_src, float4 *__restrict__ t_pre) {
+  if (sb < nStageBlocks) {
+    const int i = sb * SOS_RSB + tid;
+    if (i < n4) stage_dst[i] = stage_src[i];
+  } else {
+    expand_precalc_item((sb - nStageBlocks) * SOS_RSB + tid, d.ntiles, d.t_pair, pre_src, t_pre);
+  }
+}
+// the stage-in alone, for a linearisation whose back-substitution was enqueued ahead (sos_ba_gn_resub)
+__global__ __launch_bounds__(SOS_RSB) void k_stage_expand(BaDev d, float4 *__restrict__ stage_dst, const float4 *__restrict__ stage_src, int n4,
+                                                      int nStageBlocks, const float4 *__restrict__ pre_src, float4 *__restrict__ t_pre) {
+  stage_block((int)blockIdx.x, threadIdx.x, d, stage_dst, stage_src, n4, nStageBlocks, pre_src, t_pre);
+}
 __global__ __launch_bounds__(SOS_RSB) void k_resub_fused(BaDev d, XArg x, const float *__restrict__ adHF, const float *__restrict__ adTF,
                                                      float *__restrict__ step_out, float stepfacD, int nPointBlocks,
                                                      float4 *__restrict__ stage_dst, const float4 *__restrict__ stage_src, int n4,
@@ -1941,13 +1957,7 @@ __global__ __launch_bounds__(SOS_RSB) void k_resub_fused(BaDev d, XArg x, const 
   extern __shared__ __attribute__((aligned(16))) float sxAd[];  // [n*n*8] table, then [dim] copy of x
   const int tid = threadIdx.x;
   if ((int)blockIdx.x >= nPointBlocks) {
-    const int sb = (int)blockIdx.x - nPointBlocks;
-    if (sb < nStageBlocks) {
-      const int i = sb * SOS_RSB + tid;
-      if (i < n4) stage_dst[i] = stage_src[i];
-    } else {  // per-tile precalc records straight from the mapped block
-      expand_precalc_item((sb - nStageBlocks) * SOS_RSB + tid, d.ntiles, d.t_pair, pre_src, t_pre);
-    }
+    stage_block((int)blockIdx.x - nPointBlocks, tid, d, stage_dst, stage_src, n4, nStageBlocks, pre_src, t_pre);
     return;
   }
   const int n = d.n, dim = SOS_CPARS + 8 * n;
@@ -2267,6 +2277,7 @@ struct sos_ba {
   DevBuf<char> d_outpack;  // [tile_esum ntilesA doubles | newest energies | point steps]
   DevBuf<double> d_C;      // stitch stage-1 products
   size_t st_pre = 0, st_adh = 0, st_cd = 0, st_th = 0, st_xc = 0, st_xad = 0, st_floats = 0;
+  bool resub_pending = false;  // sos_ba_gn_resub enqueued the back-substitution of the step sos_ba_gn_step is about to take
   size_t out_esum = 0, out_newest = 0, out_step = 0, out_bytes = 0;
   int newest_begin = 0, newest_count = 0;
   char *pin = nullptr;     // pinned + device-mapped host block: [stage | outpack | Hb]; the fused per-iteration
@@ -3239,6 +3250,28 @@ extern "C" int sos_ba_resubstitute(sos_ba *ba, const double *x, float *pointStep
 // Fused per-iteration call #2: back-substitution with x, point step applied on the device
 // (doStepFromBackup), new per-step state, linearizeAll(false) (+ applyRes when applyRes != 0).
 // One H2D of the packed inputs, one D2H of the packed outputs, one synchronisation.
+// The back-substitution of a step depends on x alone: enqueued as soon as the solve is done, it runs while the host
+// still derives the new poses and the n^2 precalc records; the following sos_ba_gn_step(x = NULL) then only stages
+// those in (one launch) ahead of the linearisation.
+extern "C" int sos_ba_gn_resub(sos_ba *ba, const double *x, float stepfacD) {
+  if (!ba || !x || !ba->have_window || !ba->have_state) return SOS_ERR_STATE;
+  if (!(ba->P > 0 && ba->d_adHostF.p && ba->d_adTargetF.p)) return SOS_ERR_STATE;  // caller passes x to sos_ba_gn_step instead
+  sos_ctx *c = ba->ctx;
+  SOS_HIP(hipSetDevice(c->device));
+  ba->acc_inflight = false;
+  const size_t nn = (size_t)ba->n * ba->n;
+  XArg xa;
+  const int dim = 4 + 8 * ba->n;
+  for (int i = 0; i < dim; i++) xa.v[i] = (float)x[i];
+  float *dstep = reinterpret_cast<float *>(ba->pin_dev + ba->pin_out + ba->out_step);
+  const int nPB = divup(ba->P, SOS_RSB);
+  k_resub_fused<<<nPB, SOS_RSB, sizeof(float) * (8 * nn + 4 + 8 * (size_t)ba->n), c->stream>>>(
+      ba->dev, xa, ba->d_adHostF.p, ba->d_adTargetF.p, dstep, stepfacD, nPB, nullptr, nullptr, 0, 0, nullptr, nullptr);
+  SOS_HIP(hipGetLastError());
+  ba->resub_pending = true;
+  return SOS_OK;
+}
+
 extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const sos_calib *calib, const sos_precalc *precalc,
                               const float *adHTdeltaF, const float *cDeltaF, const float *frameEnergyTH, int applyRes,
                               double *energySum, float *newestEnergies, int *newestCount, float *pointStep) {
@@ -3263,7 +3296,14 @@ extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const
   dv.tile_esum = reinterpret_cast<double *>(po_dev + ba->out_esum);
   dv.o_newest = ba->comm ? ba->d_newest_local.p : reinterpret_cast<float *>(po_dev + ba->out_newest);
   const double t1 = now_s();
-  if (x && ba->P > 0 && ba->d_adHostF.p && ba->d_adTargetF.p) {
+  const bool resubAhead = !x && ba->resub_pending;
+  ba->resub_pending = false;
+  if (resubAhead) {  // the back-substitution is already running: only the stage-in is left, one launch
+    const int n4 = (int)((ba->st_xc + 3) / 4), nSB = divup(n4, SOS_RSB), nEB = divup(8 * ba->ntiles, SOS_RSB);
+    k_stage_expand<<<nSB + nEB, SOS_RSB, 0, st>>>(dv, reinterpret_cast<float4 *>(ba->d_stage.p), reinterpret_cast<const float4 *>(ba->pin_dev + ba->pin_stage),
+                                                 n4, nSB, reinterpret_cast<const float4 *>(ba->pin_dev + ba->pin_stage + sizeof(float) * ba->st_pre),
+                                                 ba->d_t_pre.p);
+  } else if (x && ba->P > 0 && ba->d_adHostF.p && ba->d_adTargetF.p) {
     // back-substitution from x alone + stage-in of the linearisation inputs: one launch
     XArg xa;
     const int dim = 4 + 8 * ba->n;
@@ -3335,7 +3375,7 @@ extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const
     if (newestCount) *newestCount = k;
   }
   const float *hs = reinterpret_cast<const float *>(po + ba->out_step);
-  if (x) {
+  if (x || resubAhead) {
     for (int p = 0; p < ba->P; p++) {  // keep the host mirror of the snapshot in step with the device
       const float idn = ba->h_pts[p].idepth_scaled + stepfacD * hs[p];
       ba->h_pts[p].idepth_scaled = idn;
