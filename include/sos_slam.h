@@ -350,6 +350,13 @@ int sos_tracker_destroy(sos_tracker *trk);
 int sos_tracker_set_ref(sos_tracker *trk, const sos_calib *calib, int refSlot, int npts,
                         const float *u, const float *v, const float *idepth, const float *hdi,
                         int32_t *pc_n_out);
+/* Loop-closure aligner (N4): PoseEstimator::makeK + `pts = matched_frame->pts_dso`
+ * (src/LoopClosure/PoseEstimator.cpp:129-148, 296-297).  The tracker object takes n 3-D points (xyz, AoS) of the
+ * matched keyframe with one reference colour per pyramid level (colors[l * n + i]) as its template; afterwards
+ * sos_tracker_calc_res runs PoseEstimator::calcRes (:128-286; the 3x3 argument is the plain rotation of refToNew)
+ * and sos_tracker_calc_gs runs PoseEstimator::calcGSSSE (:75-126).  sos_tracker_set_ref switches back. */
+int sos_tracker_set_points3d(sos_tracker *trk, const sos_calib *calib, int n, const float *xyz, const float *colors);
+
 /* ScaleOptimizer::scaleCoarseDepthL0 (FS/CoarseTracker.cpp:244-251) */
 int sos_tracker_scale_depth(sos_tracker *trk, float scale);
 /* read back one level of the template point cloud (pc_u, pc_v, pc_idepth, pc_color) */

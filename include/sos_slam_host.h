@@ -115,6 +115,17 @@ sos_tracker *sosf_tracker_handle(sosf_tracker *trk);
 /* trackNewestCoarse (FS/CoarseTracker.cpp:366-552); lastToNew12 / aff2 are in/out */
 int sosf_tracker_track(sosf_tracker *trk, int newSlot, float new_ab_exposure, double *lastToNew12, double *aff2,
                        int coarsestLvl, const double *minResForAbort5, double *lastResiduals5, double *flow3, int *ok);
+/* Loop-closure aligner (N4), PoseEstimator::estimate (src/LoopClosure/PoseEstimator.cpp:288-495): set_points3d takes
+ * `matched_frame->pts_dso` (xyz AoS; colors[l * n + i]), the camera of the current frame and the matched frame's
+ * exposure; pose_estimate runs the LM loop from refToNew12 (in / out) on the pyramid in newSlot and applies the three
+ * acceptance tests (affine parameters sane, pose_error < setting_loop_direct_thres, inlier percentage > INNER_PERCENT). */
+int sosf_tracker_set_points3d(sosf_tracker *trk, const sos_calib *cam, float matched_ab_exposure, int n, const float *xyz,
+                              const float *colors);
+int sosf_tracker_pose_estimate(sosf_tracker *trk, int newSlot, float new_ab_exposure, double *refToNew12, int coarsestLvl,
+                               float loopDirectThres, int innerPercent, float *poseError, int *inlierPercent, int *ok);
+/* LoopHandler::savePose (src/LoopClosure/LoopHandler.cpp:62-76): one line per keyframe, "incoming_id tx ty tz" with
+ * std::setprecision(6) default-float formatting (= "%.6g"); t_wc holds n translations */
+int sosf_write_poses(const char *path, int n, const int32_t *incoming_id, const double *t_wc);
 /* optimizeScale (FS/ScaleOptimizer.cpp:120-230) */
 int sosf_tracker_optimize_scale(sosf_tracker *trk, int stereoSlot, const double *tfmF0ToF1_12, const float *K1_level0,
                                 float *scale_inout, int coarsestLvl, float *rmse);

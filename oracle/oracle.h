@@ -141,6 +141,11 @@ void orc_tracker_calc_res_scale(orc_tracker *T, int lvl, const float *stereo_dI,
 void orc_tracker_calc_gs_scale(orc_tracker *T, int lvl, const float *t, const float *K1, float scale,
                                float *H, float *b);
 int orc_tracker_warp_n(orc_tracker *T);
+/* loop-closure aligner: PoseEstimator's template (3-D points + per-level colours); calc_res then follows
+ * src/LoopClosure/PoseEstimator.cpp:128-286, and orc_tracker_track with zero reference affine parameters and no abort
+ * thresholds is PoseEstimator::estimate :288-495 up to its three acceptance tests (orc_tracker_last_inners for the third) */
+void orc_tracker_set_points3d(orc_tracker *T, const sos_calib *calib, int n, const float *xyz, const float *colors);
+void orc_tracker_last_inners(orc_tracker *T, int *out);
 /* whole LM loop, FS/CoarseTracker.cpp:366-552. lastToNew12 and aff2 are in/out. Returns 1 = ok */
 int orc_tracker_track(orc_tracker *T, float *const *new_dI, float ref_ab_exposure,
                       float new_ab_exposure, const double *ref_aff_g2l, double *lastToNew12,

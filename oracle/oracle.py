@@ -109,6 +109,8 @@ def lib():
         L.orc_tracker_calc_gs.argtypes = [vp, C.c_int, C.c_float, C.c_float, vp, vp]
         L.orc_tracker_calc_res_scale.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_float, C.c_float, vp]
         L.orc_tracker_calc_gs_scale.argtypes = [vp, C.c_int, vp, vp, C.c_float, vp, vp]
+        L.orc_tracker_set_points3d.argtypes = [vp, C.POINTER(Calib), C.c_int, vp, vp]
+        L.orc_tracker_last_inners.argtypes = [vp, vp]
         L.orc_tracker_warp_n.restype = C.c_int
         L.orc_tracker_warp_n.argtypes = [vp]
         L.orc_tracker_track.restype = C.c_int
@@ -578,6 +580,26 @@ class OracleTracker:
         ok = self.L.orc_tracker_track(self.t, ptrs, ref_ab, new_ab, _p(ra), _p(T), _p(aff), coarsest, _p(mr),
                                       _p(lr), _p(fl))
         return ok, T, aff, lr, fl
+
+    def set_points3d(self, calib, xyz, colors):
+        """PoseEstimator template: xyz (n, 3), colors (levels, n)."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        col = np.ascontiguousarray(colors, dtype=np.float32)
+        assert col.shape == (self.levels, len(xyz))
+        self._n3d = len(xyz)
+        self.L.orc_tracker_set_points3d(self.t, C.byref(calib), len(xyz), _p(xyz), _p(col))
+
+    def pose_estimate(self, new_dI_levels, matched_ab, new_ab, refToNew12, coarsest, loop_direct_thres, inner_percent=90):
+        """PoseEstimator::estimate: the LM loop with zero reference affine parameters and no abort thresholds, then the
+        three acceptance tests (src/LoopClosure/PoseEstimator.cpp:455-485)."""
+        aff_good, T, aff, lr, fl = self.track(new_dI_levels, matched_ab, new_ab, (0.0, 0.0), refToNew12, (0.0, 0.0), coarsest,
+                                              minRes=np.full(5, np.inf))
+        inn = np.zeros(6, np.int32)
+        self.L.orc_tracker_last_inners(self.t, _p(inn))
+        pose_error = np.float32(lr[0])
+        inlier_percent = int(np.float32(100) * np.float32(inn[0]) / np.float32(self._n3d))
+        ok = bool(aff_good) and bool(pose_error < np.float32(loop_direct_thres)) and inlier_percent > inner_percent
+        return ok, T, float(pose_error), inlier_percent
 
     def optimize_scale(self, stereo_dI_levels, tfm12, K1, scale, coarsest):
         ptrs, _ = self._pyr(stereo_dI_levels)

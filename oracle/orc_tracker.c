@@ -78,6 +78,10 @@ struct orc_tracker {
   float *buf[8];
   int buf_n;
   float *const *ref_dI;
+  /* loop-closure aligner (PoseEstimator): 3-D points with one colour per level */
+  int loop_mode, l_n;
+  float *l_xyz, *l_col[SOS_PYR_LEVELS];
+  int lastInners[SOS_PYR_LEVELS];
 };
 
 orc_tracker *orc_tracker_create(const sos_params *prm, int w, int h) {
@@ -106,6 +110,8 @@ void orc_tracker_destroy(orc_tracker *T) {
     free(T->pc_u[l]); free(T->pc_v[l]); free(T->pc_idepth[l]); free(T->pc_color[l]);
   }
   for (int k = 0; k < 8; k++) free(T->buf[k]);
+  free(T->l_xyz);
+  for (int l = 0; l < SOS_PYR_LEVELS; l++) free(T->l_col[l]);
   free(T);
 }
 
@@ -150,6 +156,7 @@ static void dilate(orc_tracker *T, int lvl, int diag) { /* FS/CoarseTracker.cpp:
 
 void orc_tracker_set_ref(orc_tracker *T, const sos_calib *C, float *const *ref_dI, int npts, const float *u,
                          const float *v, const float *idepth, const float *hdi, int32_t *pc_n_out) {
+  T->loop_mode = 0;
   make_K(T, C);
   T->ref_dI = ref_dI;
   memset(T->idepth[0], 0, sizeof(float) * (size_t)T->w[0] * T->h[0]);
@@ -308,9 +315,95 @@ static void calc_res(orc_tracker *T, int lvl, const float *dINewl, const float *
   rs[5] = numSaturated / (float)numTermsInE;
 }
 
+/* PoseEstimator::calcRes, src/LoopClosure/PoseEstimator.cpp:128-286 */
+static void calc_res_loop(orc_tracker *T, int lvl, const float *dINewl, const float *R, const float *t, float aff0, float aff1,
+                          float cutoffTH, double *rs) {
+  float E = 0;
+  int numTermsInE = 0, numTermsInWarped = 0, numSaturated = 0;
+  int wl = T->w[lvl], hl = T->h[lvl];
+  float fxl = T->fx[lvl], fyl = T->fy[lvl], cxl = T->cx[lvl], cyl = T->cy[lvl];
+  float sumSquaredShiftT = 0, sumSquaredShiftRT = 0, sumSquaredShiftNum = 0;
+  float huber = T->prm.huberTH;
+  float maxEnergy = 2 * huber * cutoffTH - huber * huber;
+  for (int i = 0; i < T->l_n; i++) {
+    float x = T->l_xyz[3 * i], y = T->l_xyz[3 * i + 1], z = T->l_xyz[3 * i + 2];
+    float u0 = x / z, v0 = y / z;
+    float Ku0 = fxl * u0 + cxl, Kv0 = fyl * v0 + cyl;
+    float pt0 = R[0] * x + R[1] * y + R[2] * z + t[0];
+    float pt1 = R[3] * x + R[4] * y + R[5] * z + t[1];
+    float pt2 = R[6] * x + R[7] * y + R[8] * z + t[2];
+    float u = pt0 / pt2, v = pt1 / pt2;
+    float Ku = fxl * u + cxl, Kv = fyl * v + cyl;
+    float new_idepth = 1 / pt2;
+    if (lvl == 0 && i % 32 == 0) { /* :190-223 */
+      float pT0 = x + t[0], pT1 = y + t[1], pT2 = 1 + t[2];
+      float KuT = fxl * (pT0 / pT2) + cxl, KvT = fyl * (pT1 / pT2) + cyl;
+      float qT0 = x - t[0], qT1 = y - t[1], qT2 = 1 - t[2];
+      float KuT2 = fxl * (qT0 / qT2) + cxl, KvT2 = fyl * (qT1 / qT2) + cyl;
+      float p30 = R[0] * x + R[1] * y + R[2] - t[0], p31 = R[3] * x + R[4] * y + R[5] - t[1], p32 = R[6] * x + R[7] * y + R[8] - t[2];
+      float Ku3 = fxl * (p30 / p32) + cxl, Kv3 = fyl * (p31 / p32) + cyl;
+      sumSquaredShiftT += (KuT - Ku0) * (KuT - Ku0) + (KvT - Kv0) * (KvT - Kv0);
+      sumSquaredShiftT += (KuT2 - Ku0) * (KuT2 - Ku0) + (KvT2 - Kv0) * (KvT2 - Kv0);
+      sumSquaredShiftRT += (Ku - Ku0) * (Ku - Ku0) + (Kv - Kv0) * (Kv - Kv0);
+      sumSquaredShiftRT += (Ku3 - Ku0) * (Ku3 - Ku0) + (Kv3 - Kv0) * (Kv3 - Kv0);
+      sumSquaredShiftNum += 2;
+    }
+    if (!(Ku > 2 && Kv > 2 && Ku < wl - 3 && Kv < hl - 3 && new_idepth > 0)) continue;
+    float refColor = T->l_col[lvl][i];
+    float hit[3];
+    interp33t(dINewl, Ku, Kv, wl, hit);
+    if (!isfinite(hit[0])) continue;
+    float residual = hit[0] - (float)(aff0 * refColor + aff1);
+    float hw = fabsf(residual) < huber ? 1 : huber / fabsf(residual);
+    if (fabsf(residual) > cutoffTH) {
+      E += maxEnergy;
+      numTermsInE++;
+      numSaturated++;
+    } else {
+      E += hw * residual * residual * (2 - hw);
+      numTermsInE++;
+      int k = numTermsInWarped;
+      T->buf[0][k] = new_idepth; T->buf[1][k] = u; T->buf[2][k] = v; T->buf[3][k] = hit[1]; T->buf[4][k] = hit[2];
+      T->buf[5][k] = residual; T->buf[6][k] = hw; T->buf[7][k] = refColor;
+      numTermsInWarped++;
+    }
+  }
+  while (numTermsInWarped % 4 != 0) {
+    for (int k = 0; k < 8; k++) T->buf[k][numTermsInWarped] = 0;
+    numTermsInWarped++;
+  }
+  T->buf_n = numTermsInWarped;
+  rs[0] = E;
+  rs[1] = numTermsInE;
+  rs[2] = sumSquaredShiftT / (sumSquaredShiftNum + 0.1);
+  rs[3] = 0;
+  rs[4] = sumSquaredShiftRT / (sumSquaredShiftNum + 0.1);
+  rs[5] = numSaturated / (float)numTermsInE;
+}
+
 void orc_tracker_calc_res(orc_tracker *T, int lvl, const float *new_dI, const float *RKi, const float *t,
                           const float *affLL, float cutoffTH, double *rs) {
-  calc_res(T, lvl, new_dI, RKi, t, affLL[0], affLL[1], 0, 1.0f, 0, cutoffTH, rs);
+  if (T->loop_mode) calc_res_loop(T, lvl, new_dI, RKi, t, affLL[0], affLL[1], cutoffTH, rs);
+  else calc_res(T, lvl, new_dI, RKi, t, affLL[0], affLL[1], 0, 1.0f, 0, cutoffTH, rs);
+}
+
+/* PoseEstimator::makeK + pts = matched_frame->pts_dso (:129-148, 296-297): xyz AoS, colors[l * n + i] */
+void orc_tracker_set_points3d(orc_tracker *T, const sos_calib *calib, int n, const float *xyz, const float *colors) {
+  make_K(T, calib);
+  for (int l = 0; l < T->levels; l++) { /* the estimator projects with R alone: no K^-1 in front */
+    for (int q = 0; q < 9; q++) T->Ki[l][q] = (q % 4 == 0) ? 1.0f : 0.0f;
+    free(T->l_col[l]);
+    T->l_col[l] = (float *)malloc(sizeof(float) * (size_t)(n ? n : 1));
+    memcpy(T->l_col[l], colors + (size_t)l * n, sizeof(float) * (size_t)n);
+  }
+  free(T->l_xyz);
+  T->l_xyz = (float *)malloc(sizeof(float) * 3 * (size_t)(n ? n : 1));
+  memcpy(T->l_xyz, xyz, sizeof(float) * 3 * (size_t)n);
+  T->l_n = n;
+  T->loop_mode = 1;
+}
+void orc_tracker_last_inners(orc_tracker *T, int *out) {
+  for (int l = 0; l < T->levels; l++) out[l] = T->lastInners[l];
 }
 void orc_tracker_calc_res_scale(orc_tracker *T, int lvl, const float *stereo_dI, const float *RKi, const float *t,
                                 const float *K1, float scale, float cutoffTH, double *rs) {
@@ -525,6 +618,7 @@ int orc_tracker_track(orc_tracker *T, float *const *new_dI, float ref_ab, float 
       if (!(sqrt(nrm) > 1e-3)) break;
     }
     lastResiduals[lvl] = sqrtf((float)(resOld[0] / resOld[1]));
+    T->lastInners[lvl] = (int)resOld[1];
     flow3[0] = resOld[2]; flow3[1] = resOld[3]; flow3[2] = resOld[4];
     if (lastResiduals[lvl] > 1.5 * minResForAbort[lvl]) return 0;
     if (levelCutoffRepeat > 1 && !haveRepeated) {

@@ -1316,6 +1316,7 @@ bool CoarseTracker::trackNewestCoarse(int newSlot, float new_ab_exposure, SE3 &l
       if (!(std::sqrt(nrm) > 1e-3)) break;
     }
     lastResiduals[lvl] = sqrtf((float)(resOld[0] / resOld[1]));
+    lastInners[lvl] = (int)resOld[1];
     lastFlowIndicators[0] = resOld[2];
     lastFlowIndicators[1] = resOld[3];
     lastFlowIndicators[2] = resOld[4];
@@ -1335,6 +1336,32 @@ bool CoarseTracker::trackNewestCoarse(int newSlot, float new_ab_exposure, SE3 &l
   if (modeA < 0) aff_g2l_out.a = 0;
   if (modeB < 0) aff_g2l_out.b = 0;
   return true;
+}
+
+int CoarseTracker::setPoints3d(const sos_calib &cam, float matched_ab_exposure, int n, const float *xyz, const float *colors) {
+  // makeK(cur_frame->cam); pts = matched_frame->pts_dso; refAffGToL = AffLight(); refAbExposure = matched ab_exposure (:294-304)
+  calib = cam;
+  for (int l = 0; l < levels; l++)
+    for (int q = 0; q < 9; q++) Ki[l][q] = (q % 4 == 0) ? 1.0f : 0.0f;  // the estimator projects with R alone
+  lastRef_aff_g2l = AffLight(0, 0);
+  ref_ab_exposure = matched_ab_exposure;
+  loopPoints = n;
+  return sos_tracker_set_points3d(trk, &cam, n, xyz, colors);
+}
+
+bool CoarseTracker::poseEstimate(int newSlot, float new_ab_exposure, SE3 &refToNew, int coarsestLvl, float loopDirectThres,
+                                 int innerPercent, float *poseError, int *inlierPercent) {
+  const double noAbort[5] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY};
+  double lastResiduals[5];
+  AffLight aff(0, 0);  // aff_g2l_current = AffLight(), :305
+  const bool aff_good = trackNewestCoarse(newSlot, new_ab_exposure, refToNew, aff, coarsestLvl, noAbort, lastResiduals);
+  const float pose_error = (float)lastResiduals[0];
+  const bool low_res = pose_error < loopDirectThres;                                   // :470
+  const int inlier_percent = (int)(100 * float(lastInners[0]) / (float)loopPoints);   // :473 (size_t -> float division)
+  const bool enough_inlier = inlier_percent > innerPercent;
+  if (poseError) *poseError = pose_error;
+  if (inlierPercent) *inlierPercent = inlier_percent;
+  return aff_good && low_res && enough_inlier;
 }
 
 float CoarseTracker::optimizeScale(int stereoSlot, const SE3 &tfmF0ToF1, const float *K1_0, float &scale, int coarsestLvl) {
@@ -1679,6 +1706,28 @@ extern "C" int sosf_tracker_track(sosf_tracker *t, int newSlot, float new_ab_exp
   aff2[0] = aff.a;
   aff2[1] = aff.b;
   if (flow3) for (int i = 0; i < 3; i++) flow3[i] = t->ct->lastFlowIndicators[i];
+  if (ok) *ok = good ? 1 : 0;
+  return SOS_OK;
+}
+extern "C" int sosf_write_poses(const char *path, int n, const int32_t *incoming_id, const double *t_wc) {
+  if (!path || n < 0 || (n && (!incoming_id || !t_wc))) return SOS_ERR_ARG;
+  FILE *f = fopen(path, "w");
+  if (!f) return SOS_ERR_STATE;
+  for (int i = 0; i < n; i++) fprintf(f, "%d %.6g %.6g %.6g\n", incoming_id[i], t_wc[3 * i], t_wc[3 * i + 1], t_wc[3 * i + 2]);
+  fclose(f);
+  return SOS_OK;
+}
+extern "C" int sosf_tracker_set_points3d(sosf_tracker *t, const sos_calib *cam, float matched_ab_exposure, int n, const float *xyz,
+                                         const float *colors) {
+  if (!t || !cam) return SOS_ERR_ARG;
+  return t->ct->setPoints3d(*cam, matched_ab_exposure, n, xyz, colors);
+}
+extern "C" int sosf_tracker_pose_estimate(sosf_tracker *t, int newSlot, float new_ab_exposure, double *refToNew12, int coarsestLvl,
+                                          float loopDirectThres, int innerPercent, float *poseError, int *inlierPercent, int *ok) {
+  if (!t || !refToNew12) return SOS_ERR_ARG;
+  SE3 T = SE3::from12(refToNew12);
+  const bool good = t->ct->poseEstimate(newSlot, new_ab_exposure, T, coarsestLvl, loopDirectThres, innerPercent, poseError, inlierPercent);
+  T.to12(refToNew12);
   if (ok) *ok = good ? 1 : 0;
   return SOS_OK;
 }

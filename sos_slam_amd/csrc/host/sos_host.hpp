@@ -281,6 +281,12 @@ class CoarseTracker {
                          const double *minResForAbort5, double *lastResiduals5);   // :366-552
   float optimizeScale(int stereoSlot, const SE3 &tfmF0ToF1, const float *K1_level0, float &scale, int coarsestLvl);  // FS/ScaleOptimizer.cpp:120-230
   void scaleCoarseDepthL0(float scale);
+  // loop-closure aligner (src/LoopClosure/PoseEstimator.cpp): template = 3-D points of the matched keyframe with one colour per
+  // level; estimate() = the same Levenberg-Marquardt loop with zero reference affine parameters, no abort thresholds and
+  // PoseEstimator's three acceptance tests (:455-485)
+  int setPoints3d(const sos_calib &cam, float matched_ab_exposure, int n, const float *xyz, const float *colors);
+  bool poseEstimate(int newSlot, float new_ab_exposure, SE3 &refToNew, int coarsestLvl, float loopDirectThres, int innerPercent,
+                    float *poseError, int *inlierPercent);
 
   sos_tracker *trk = nullptr;
   sos_ctx *ctx = nullptr;
@@ -295,6 +301,8 @@ class CoarseTracker {
   AffLight lastRef_aff_g2l;
   double lastFlowIndicators[3] = {1000, 1000, 1000};
   double firstCoarseRMSE = -1;
+  int lastInners[SOS_PYR_LEVELS] = {0};
+  int loopPoints = 0;
 };
 
 }  // namespace sos

@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <cmath>
 #include <unordered_map>
+#include <vector>
 
 struct sos_tracker {
   sos_ctx *ctx = nullptr;
@@ -57,6 +58,10 @@ struct sos_tracker {
   int gs_lvl = -1;
   float gs_a = 0, gs_b0 = 0;
   bool gss_cached = false;  // scale variant: (lvl, t, K1, scale)
+  // loop-closure aligner (PoseEstimator, src/LoopClosure/PoseEstimator.cpp): 3-D points with one colour per level
+  bool loop_mode = false;
+  float *l_xyz[3] = {nullptr, nullptr, nullptr}, *l_col[SOS_PYR_LEVELS] = {nullptr};
+  int l_n = 0, l_cap = 0;
   float gss_key[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
@@ -107,6 +112,8 @@ extern "C" int sos_tracker_destroy(sos_tracker *T) {
     hipFree(T->pc_u[l]); hipFree(T->pc_v[l]); hipFree(T->pc_idepth[l]); hipFree(T->pc_color[l]);
   }
   for (int k = 0; k < 8; k++) hipFree(T->buf[k]);
+  for (int k = 0; k < 3; k++) hipFree(T->l_xyz[k]);
+  for (int l = 0; l < SOS_PYR_LEVELS; l++) hipFree(T->l_col[l]);
   hipFree(T->d_part2);
   if (T->pin_o) hipHostFree(T->pin_o);
   hipFree(T->d_counts); hipFree(T->d_part); hipFree(T->d_out); hipFree(T->d_pix); hipFree(T->d_pixv);
@@ -250,6 +257,7 @@ extern "C" int sos_tracker_set_ref(sos_tracker *T, const sos_calib *calib, int r
   if (refSlot < 0 || refSlot >= SOS_MAX_SLOTS || !c->has_pyr[refSlot]) return SOS_ERR_STATE;
   SOS_HIP(hipSetDevice(c->device));
   hipStream_t st = c->stream;
+  T->loop_mode = false;
   // makeK, FS/ScaleOptimizer.cpp:95-118
   T->fx[0] = calib->fxl; T->fy[0] = calib->fyl; T->cx[0] = calib->cxl; T->cy[0] = calib->cyl;
   for (int l = 1; l < T->levels; l++) {
@@ -329,6 +337,46 @@ extern "C" int sos_tracker_set_ref(sos_tracker *T, const sos_calib *calib, int r
   return SOS_OK;
 }
 
+// PoseEstimator::makeK + pts = matched_frame->pts_dso (src/LoopClosure/PoseEstimator.cpp:129-148, 296-297): the tracker
+// object becomes the loop-closure aligner -- its template is n 3-D points of the matched keyframe, each with one
+// reference colour per pyramid level (colors[l * n + i]).  calc_res / calc_gs then run PoseEstimator::calcRes / calcGSSSE.
+extern "C" int sos_tracker_set_points3d(sos_tracker *T, const sos_calib *calib, int n, const float *xyz, const float *colors) {
+  if (!T || !calib || n < 0 || (n && (!xyz || !colors))) return SOS_ERR_ARG;
+  sos_ctx *c = T->ctx;
+  if ((size_t)n > (size_t)T->w[0] * T->h[0]) return SOS_ERR_ARG;
+  SOS_HIP(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  T->fx[0] = calib->fxl; T->fy[0] = calib->fyl; T->cx[0] = calib->cxl; T->cy[0] = calib->cyl;
+  for (int l = 1; l < T->levels; l++) {
+    T->fx[l] = T->fx[l - 1] * 0.5;
+    T->fy[l] = T->fy[l - 1] * 0.5;
+    T->cx[l] = (T->cx[0] + 0.5) / ((int)1 << l) - 0.5;
+    T->cy[l] = (T->cy[0] + 0.5) / ((int)1 << l) - 0.5;
+  }
+  if (n > T->l_cap) {
+    for (int k = 0; k < 3; k++) { hipFree(T->l_xyz[k]); T->l_xyz[k] = nullptr; }
+    for (int l = 0; l < SOS_PYR_LEVELS; l++) { hipFree(T->l_col[l]); T->l_col[l] = nullptr; }
+    const int cap = n + n / 4 + 64;
+    for (int k = 0; k < 3; k++) SOS_HIP(hipMalloc(&T->l_xyz[k], sizeof(float) * cap));
+    for (int l = 0; l < T->levels; l++) SOS_HIP(hipMalloc(&T->l_col[l], sizeof(float) * cap));
+    T->l_cap = cap;
+  }
+  std::vector<float> soa((size_t)3 * n);
+  for (int i = 0; i < n; i++)
+    for (int k = 0; k < 3; k++) soa[(size_t)k * n + i] = xyz[3 * (size_t)i + k];
+  for (int k = 0; k < 3 && n; k++) SOS_HIP(hipMemcpyAsync(T->l_xyz[k], soa.data() + (size_t)k * n, sizeof(float) * n, hipMemcpyHostToDevice, st));
+  for (int l = 0; l < T->levels && n; l++)
+    SOS_HIP(hipMemcpyAsync(T->l_col[l], colors + (size_t)l * n, sizeof(float) * n, hipMemcpyHostToDevice, st));
+  SOS_HIP(hipStreamSynchronize(st));
+  for (int l = 0; l < T->levels; l++) T->pc_n[l] = n;
+  T->l_n = n;
+  T->loop_mode = true;
+  T->have_ref = true;
+  T->gs_cached = T->gss_cached = false;
+  T->buf_lvl = -1;
+  return SOS_OK;
+}
+
 extern "C" int sos_tracker_scale_depth(sos_tracker *T, float scale) {  // FS/CoarseTracker.cpp:244-251
   if (!T || !T->have_ref) return SOS_ERR_STATE;
   SOS_HIP(hipSetDevice(T->ctx->device));
@@ -390,29 +438,55 @@ struct GsFuse {
   float fxl, fyl, a, b0;   // pose variant: fx, fy of the level, affLL[0], b0
   float s, tx, ty, tz;     // scale variant
 };
-template <bool SCALE, bool GS>
+// MODE 0: CoarseTracker::calcRes, 1: ScaleOptimizer::calcResScale, 2: PoseEstimator::calcRes (3-D points x y z in pu pv pid)
+template <int MODE, bool GS>
 __global__ __launch_bounds__(256) void k_calc_res(ResArgs a, float *__restrict__ part /* nblk*8 */, GsFuse gf,
                                                   float *__restrict__ part_gs /* nblk*45 | nblk*3 */) {
   __shared__ float sm[8 * 4];
-  __shared__ float smg[(SCALE ? 3 : 45) * 4];
+  __shared__ float smg[(MODE == 1 ? 3 : 45) * 4];
   float gsb[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // this pixel's warp-buffer entries, as stored
   const int i = blockIdx.x * 256 + threadIdx.x;
   float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // E, numTermsInE, numWarped, numSaturated, flowT, flowRT, flowNum, -
   if (i < a.n) {
-    const float id = a.pid[i], x = a.pu[i], y = a.pv[i];
-    const float pt0 = a.M[0] * x + a.M[1] * y + a.M[2] + a.t[0] * id;
-    const float pt1 = a.M[3] * x + a.M[4] * y + a.M[5] + a.t[1] * id;
-    const float pt2 = a.M[6] * x + a.M[7] * y + a.M[8] + a.t[2] * id;
+    const float id = a.pid[i], x = a.pu[i], y = a.pv[i];  // MODE 2: id holds z
+    float pt0, pt1, pt2;
+    if (MODE == 2) {  // pt = R (x, y, z) + t, src/LoopClosure/PoseEstimator.cpp:181-183
+      pt0 = a.M[0] * x + a.M[1] * y + a.M[2] * id + a.t[0];
+      pt1 = a.M[3] * x + a.M[4] * y + a.M[5] * id + a.t[1];
+      pt2 = a.M[6] * x + a.M[7] * y + a.M[8] * id + a.t[2];
+    } else {
+      pt0 = a.M[0] * x + a.M[1] * y + a.M[2] + a.t[0] * id;
+      pt1 = a.M[3] * x + a.M[4] * y + a.M[5] + a.t[1] * id;
+      pt2 = a.M[6] * x + a.M[7] * y + a.M[8] + a.t[2] * id;
+    }
     const float u = pt0 / pt2, vv = pt1 / pt2;
     const float Ku = a.fxl * u + a.cxl, Kv = a.fyl * vv + a.cyl;
-    const float new_idepth = id / pt2;
+    const float new_idepth = MODE == 2 ? 1 / pt2 : id / pt2;
     float o0 = new_idepth, o1 = u, o2 = vv;
-    if (SCALE) {  // FS/ScaleOptimizer.cpp:333
+    if (MODE == 1) {  // FS/ScaleOptimizer.cpp:333
       o0 = (a.RKi[0] * x + a.RKi[1] * y + a.RKi[2]) / id;
       o1 = (a.RKi[3] * x + a.RKi[4] * y + a.RKi[5]) / id;
       o2 = (a.RKi[6] * x + a.RKi[7] * y + a.RKi[8]) / id;
     }
-    if (a.lvl == 0 && (i & 31) == 0) {  // flow indicators, FS/CoarseTracker.cpp:666-696
+    if (MODE == 2 && a.lvl == 0 && (i & 31) == 0) {  // flow indicators of PoseEstimator::calcRes, :190-223
+      const float Ku0 = a.fxl * (x / id) + a.cxl, Kv0 = a.fyl * (y / id) + a.cyl;
+      const float pT0 = x + a.t[0], pT1 = y + a.t[1], pT2 = 1 + a.t[2];
+      const float KuT = a.fxl * (pT0 / pT2) + a.cxl, KvT = a.fyl * (pT1 / pT2) + a.cyl;
+      const float qT0 = x - a.t[0], qT1 = y - a.t[1], qT2 = 1 - a.t[2];
+      const float KuT2 = a.fxl * (qT0 / qT2) + a.cxl, KvT2 = a.fyl * (qT1 / qT2) + a.cyl;
+      const float p30 = a.M[0] * x + a.M[1] * y + a.M[2] - a.t[0], p31 = a.M[3] * x + a.M[4] * y + a.M[5] - a.t[1],
+                  p32 = a.M[6] * x + a.M[7] * y + a.M[8] - a.t[2];
+      const float Ku3 = a.fxl * (p30 / p32) + a.cxl, Kv3 = a.fyl * (p31 / p32) + a.cyl;
+      float sT = 0, sRT = 0;
+      sT += (KuT - Ku0) * (KuT - Ku0) + (KvT - Kv0) * (KvT - Kv0);
+      sT += (KuT2 - Ku0) * (KuT2 - Ku0) + (KvT2 - Kv0) * (KvT2 - Kv0);
+      sRT += (Ku - Ku0) * (Ku - Ku0) + (Kv - Kv0) * (Kv - Kv0);
+      sRT += (Ku3 - Ku0) * (Ku3 - Ku0) + (Kv3 - Kv0) * (Kv3 - Kv0);
+      v[4] = sT;
+      v[5] = sRT;
+      v[6] = 2.f;
+    }
+    if (MODE != 2 && a.lvl == 0 && (i & 31) == 0) {  // flow indicators, FS/CoarseTracker.cpp:666-696
       const float a0 = a.KiS[0] * x + a.KiS[1] * y + a.KiS[2], a1 = a.KiS[3] * x + a.KiS[4] * y + a.KiS[5],
                   a2 = a.KiS[6] * x + a.KiS[7] * y + a.KiS[8];
       const float pT0 = a0 + a.t[0] * id, pT1 = a1 + a.t[1] * id, pT2 = a2 + a.t[2] * id;
@@ -445,7 +519,7 @@ __global__ __launch_bounds__(256) void k_calc_res(ResArgs a, float *__restrict__
       const float hit1 = w11 * bq[4] + w01 * bq[1] + w10 * bp[4] + w00 * bp[1];
       const float hit2 = w11 * bq[5] + w01 * bq[2] + w10 * bp[5] + w00 * bp[2];
       if (isfinite(hit0)) {
-        const float residual = SCALE ? hit0 - refColor : hit0 - (float)(a.aff0 * refColor + a.aff1);
+        const float residual = MODE == 1 ? hit0 - refColor : hit0 - (float)(a.aff0 * refColor + a.aff1);
         const float hw = fabsf(residual) < a.huber ? 1 : a.huber / fabsf(residual);
         if (fabsf(residual) > a.cutoff) {
           v[0] = a.maxEnergy;
@@ -467,7 +541,7 @@ __global__ __launch_bounds__(256) void k_calc_res(ResArgs a, float *__restrict__
   }
   block_sum<8>(v, sm, part + 8 * (size_t)blockIdx.x);
   if (GS) {  // the same arithmetic as k_calc_gs / k_calc_gs_scale on the values just stored
-    if (SCALE) {
+    if (MODE == 1) {
       float g3[3] = {0, 0, 0};
       if (i < a.n) {
         const float dxfx = gsb[3] * gf.fxl, dyfy = gsb[4] * gf.fyl;
@@ -558,6 +632,7 @@ __global__ void k_sum_parts(const float *__restrict__ part, int nblk, int nv, do
 static void fill_common(sos_tracker *T, ResArgs &a, int lvl, const float *RKi, const float *t, float scale, bool scaleMode,
                         float cutoffTH) {
   a.pu = T->pc_u[lvl]; a.pv = T->pc_v[lvl]; a.pid = T->pc_idepth[lvl]; a.pcol = T->pc_color[lvl];
+  if (T->loop_mode) { a.pu = T->l_xyz[0]; a.pv = T->l_xyz[1]; a.pid = T->l_xyz[2]; a.pcol = T->l_col[lvl]; }
   for (int k = 0; k < 8; k++) a.buf[k] = T->buf[k];
   a.n = T->pc_n[lvl]; a.lvl = lvl; a.wl = T->w[lvl]; a.hl = T->h[lvl];
   float Ki[9] = {1.0f / T->fx[lvl], 0, -T->cx[lvl] / T->fx[lvl], 0, 1.0f / T->fy[lvl], -T->cy[lvl] / T->fy[lvl], 0, 0, 1};
@@ -632,13 +707,23 @@ extern "C" int sos_tracker_calc_res(sos_tracker *T, int lvl, int newSlot, const 
   T->gs_cached = T->gss_cached = false;
   if (nblk > 0) {
     GsFuse gf = {T->fx[lvl], T->fy[lvl], affLL[0], T->hint_b0, 1.f, 0.f, 0.f, 0.f};
-    if (T->hint_on) {  // speculative calcGSSSE for this pose inside the same kernel (see sos_tracker)
-      k_calc_res<false, true><<<nblk, 256, 0, c->stream>>>(a, T->d_part, gf, T->d_part2);
+    if (T->loop_mode) {  // PoseEstimator::calcRes: RKi is the plain rotation here
+      if (T->hint_on) k_calc_res<2, true><<<nblk, 256, 0, c->stream>>>(a, T->d_part, gf, T->d_part2);
+      else k_calc_res<2, false><<<nblk, 256, 0, c->stream>>>(a, T->d_part, gf, nullptr);
+      if (T->hint_on) {
+        k_sum_parts2<<<1, 64, 0, c->stream>>>(T->d_part, 8, T->pin_o_dev, T->d_part2, 45, T->pin_o_dev + 8, nblk,
+                                             reinterpret_cast<int *>(T->pin_o_dev + 60), ++T->seq);
+        T->gs_cached = true; T->gs_lvl = lvl; T->gs_a = affLL[0]; T->gs_b0 = T->hint_b0;
+      } else {
+        k_sum_parts<<<1, 64, 0, c->stream>>>(T->d_part, nblk, 8, T->pin_o_dev, reinterpret_cast<int *>(T->pin_o_dev + 60), ++T->seq);
+      }
+    } else if (T->hint_on) {  // speculative calcGSSSE for this pose inside the same kernel (see sos_tracker)
+      k_calc_res<0, true><<<nblk, 256, 0, c->stream>>>(a, T->d_part, gf, T->d_part2);
       k_sum_parts2<<<1, 64, 0, c->stream>>>(T->d_part, 8, T->pin_o_dev, T->d_part2, 45, T->pin_o_dev + 8, nblk,
                                            reinterpret_cast<int *>(T->pin_o_dev + 60), ++T->seq);
       T->gs_cached = true; T->gs_lvl = lvl; T->gs_a = affLL[0]; T->gs_b0 = T->hint_b0;
     } else {
-      k_calc_res<false, false><<<nblk, 256, 0, c->stream>>>(a, T->d_part, gf, nullptr);
+      k_calc_res<0, false><<<nblk, 256, 0, c->stream>>>(a, T->d_part, gf, nullptr);
       k_sum_parts<<<1, 64, 0, c->stream>>>(T->d_part, nblk, 8, T->pin_o_dev, reinterpret_cast<int *>(T->pin_o_dev + 60), ++T->seq);
     }
   }
@@ -662,10 +747,10 @@ extern "C" int sos_tracker_calc_res_scale(sos_tracker *T, int lvl, int stereoSlo
   if (nblk > 0) {
     GsFuse gf = {K1[0], K1[1], 0.f, 0.f, scale, t[0], t[1], t[2]};
     if (!T->hint_on) {
-      k_calc_res<true, false><<<nblk, 256, 0, c->stream>>>(a, T->d_part, gf, nullptr);
+      k_calc_res<1, false><<<nblk, 256, 0, c->stream>>>(a, T->d_part, gf, nullptr);
       k_sum_parts<<<1, 64, 0, c->stream>>>(T->d_part, nblk, 8, T->pin_o_dev, reinterpret_cast<int *>(T->pin_o_dev + 60), ++T->seq);
     } else {  // calcGSSSEScale needs nothing beyond what calcResScale was given: same kernel
-      k_calc_res<true, true><<<nblk, 256, 0, c->stream>>>(a, T->d_part, gf, T->d_part2);
+      k_calc_res<1, true><<<nblk, 256, 0, c->stream>>>(a, T->d_part, gf, T->d_part2);
       k_sum_parts2<<<1, 64, 0, c->stream>>>(T->d_part, 8, T->pin_o_dev, T->d_part2, 3, T->pin_o_dev + 8, nblk,
                                            reinterpret_cast<int *>(T->pin_o_dev + 60), ++T->seq);
       T->gss_cached = true;

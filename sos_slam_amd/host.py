@@ -58,6 +58,9 @@ def load():
     L.sosf_tracker_handle.restype = vp
     L.sosf_tracker_handle.argtypes = [vp]
     L.sosf_tracker_track.argtypes = [vp, ci, C.c_float, vp, vp, ci, vp, vp, vp, C.POINTER(ci)]
+    L.sosf_write_poses.argtypes = [C.c_char_p, ci, vp, vp]
+    L.sosf_tracker_set_points3d.argtypes = [vp, vp, C.c_float, ci, vp, vp]
+    L.sosf_tracker_pose_estimate.argtypes = [vp, ci, C.c_float, vp, ci, C.c_float, ci, vp, vp, vp]
     L.sosf_tracker_optimize_scale.argtypes = [vp, ci, vp, vp, C.POINTER(C.c_float), ci, C.POINTER(C.c_float)]
     L.sosf_get_timing.argtypes = [vp, ci]
     L.sosf_ldlt_solve.argtypes = [vp, vp, vp, ci, ci]
@@ -107,6 +110,13 @@ def activate_select(w1, h1, newest, KRKi, Kt, act, min_dist, min_quality, cand, 
 
 def next_min_act_dist(cur, n_points, desired):
     return float(load().sosf_next_min_act_dist(cur, n_points, desired))
+
+
+def write_poses(path, incoming_id, t_wc):
+    """LoopHandler::savePose: "incoming_id tx ty tz" per keyframe, 6 significant digits."""
+    ids = np.ascontiguousarray(incoming_id, dtype=np.int32)
+    t = np.ascontiguousarray(t_wc, dtype=np.float64).reshape(-1, 3)
+    _chk(load().sosf_write_poses(str(path).encode(), len(ids), _p(ids), _p(t)), "sosf_write_poses")
 
 
 def timing(reset=False):
@@ -318,6 +328,21 @@ class HostTracker:
         _chk(self.L.sosf_tracker_track(self.h_, newSlot, new_ab_exposure, _p(T), _p(aff), coarsest, _p(mr), _p(lr), _p(fl),
                                        C.byref(ok)), "sosf_tracker_track")
         return bool(ok.value), T, aff, lr, fl
+
+    def set_points3d(self, calib, matched_ab_exposure, xyz, colors):
+        """PoseEstimator template (loop-closure aligner): xyz (n, 3), colors (levels, n)."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        col = np.ascontiguousarray(colors, dtype=np.float32)
+        assert col.ndim == 2 and col.shape[1] == len(xyz)
+        _chk(self.L.sosf_tracker_set_points3d(self.h_, C.byref(calib), matched_ab_exposure, len(xyz), _p(xyz), _p(col)),
+             "sosf_tracker_set_points3d")
+
+    def pose_estimate(self, newSlot, new_ab_exposure, refToNew12, coarsest, loop_direct_thres, inner_percent=90):
+        T = np.ascontiguousarray(refToNew12, dtype=np.float64).copy()
+        err, pct, ok = C.c_float(0), C.c_int(0), C.c_int(0)
+        _chk(self.L.sosf_tracker_pose_estimate(self.h_, newSlot, new_ab_exposure, _p(T), coarsest, loop_direct_thres, inner_percent,
+                                               C.byref(err), C.byref(pct), C.byref(ok)), "sosf_tracker_pose_estimate")
+        return bool(ok.value), T, err.value, pct.value
 
     def optimize_scale(self, stereoSlot, tfm12, K1, scale, coarsest):
         s = C.c_float(scale)

@@ -26,7 +26,7 @@ SYMBOLS = [
     "sos_ba_accumulate_marg", "sos_ba_update_point_priors", "sos_ba_set_prefetch", "sos_tracker_set_gs_hint", "sos_immature_init", "sos_immature_trace", "sos_immature_trace_all", "sos_immature_activate", "sos_pixsel_create", "sos_pixsel_destroy", "sos_pixsel_make_hists", "sos_pixsel_select", "sos_pixsel_make_maps", "sos_pixsel_list", "sos_camera_parse", "sos_undistort_create", "sos_undistort_destroy", "sos_undistort_get", "sos_undistort_frame", "sos_rccl_load", "sos_rccl_unique_id", "sos_comm_create", "sos_comm_destroy", "sos_comm_size",
     "sos_comm_rank", "sos_ba_set_comm", "sos_ba_newest_capacity", "sos_ba_gather_energies", "sos_ba_allreduce_f64", "sos_ba_get_jacobian", "sos_ba_get_residual_flags", "sos_ba_get_JpJdF",
     "sos_ba_get_res_toZeroF", "sos_ba_time_kernel", "sos_tracker_create", "sos_tracker_destroy",
-    "sos_tracker_set_ref", "sos_tracker_scale_depth", "sos_tracker_get_pc", "sos_tracker_calc_res",
+    "sos_tracker_set_ref", "sos_tracker_set_points3d", "sos_tracker_scale_depth", "sos_tracker_get_pc", "sos_tracker_calc_res",
     "sos_tracker_calc_gs", "sos_tracker_calc_res_scale", "sos_tracker_calc_gs_scale", "sos_backend_name",
 ]
 
@@ -116,6 +116,7 @@ def load():
     L.sos_tracker_create.argtypes = [vp, C.POINTER(Params), C.POINTER(vp)]
     L.sos_tracker_destroy.argtypes = [vp]
     L.sos_tracker_set_ref.argtypes = [vp, C.POINTER(Calib), ci, ci, vp, vp, vp, vp, vp]
+    L.sos_tracker_set_points3d.argtypes = [vp, C.POINTER(Calib), ci, vp, vp]
     L.sos_tracker_scale_depth.argtypes = [vp, cf]
     L.sos_tracker_get_pc.argtypes = [vp, ci, vp, vp, vp, vp]
     L.sos_tracker_calc_res.argtypes = [vp, ci, ci, vp, vp, vp, cf, vp]
@@ -432,6 +433,11 @@ class Tracker:
         out = [np.zeros(n, dtype=np.float32) for _ in range(4)]
         _chk(self.L.sos_tracker_get_pc(self._h, lvl, *[_p(o) for o in out]), "sos_tracker_get_pc")
         return out
+
+    def set_points3d(self, calib, xyz, colors):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        col = np.ascontiguousarray(colors, dtype=np.float32)
+        _chk(self.L.sos_tracker_set_points3d(self._h, C.byref(calib), len(xyz), _p(xyz), _p(col)), "sos_tracker_set_points3d")
 
     def calc_res(self, lvl, newSlot, RKi, t, affLL, cutoff):
         rs = np.zeros(6)

@@ -77,6 +77,17 @@ def test_record_sizes_against_the_compiled_header(tmp_path):
         assert int(got[n]) == size, (n, got[n], size)
 
 
+def test_poses_file_format(tmp_path):
+    """poses.txt as LoopHandler::savePose writes it (src/LoopClosure/LoopHandler.cpp:62-76): default-float, 6 digits."""
+    import numpy as np
+    from sos_slam_amd import host
+    ids = [3, 17, 250]
+    t = np.array([[0.0, -1.5, 123456.789], [1e-7, 0.333333333, -2.0000004], [12.5, 1e10, -0.000123456789]])
+    host.write_poses(tmp_path / "poses.txt", ids, t)
+    lines = (tmp_path / "poses.txt").read_text().splitlines()
+    assert lines == ["3 0 -1.5 123457", "17 1e-07 0.333333 -2", "250 12.5 1e+10 -0.000123457"]
+
+
 def test_facade_ldlt_variants_agree():
     """The blocked LDL^T on the GN critical path against the unblocked reference variant and numpy, including a
     singular matrix (exact-zero pivots contribute nothing, as with Eigen's ldlt().solve) -- host code, no GPU."""

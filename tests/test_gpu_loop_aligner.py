@@ -1,0 +1,95 @@
+"""GPU parity of the loop-closure aligner (PoseEstimator::calcRes / calcGSSSE / estimate, src/LoopClosure/PoseEstimator.cpp)
+built on the tracker kernels: 3-D template points of a matched keyframe with one colour per pyramid level, aligned
+against another frame's pyramid.  Integer statistics of calcRes bit-exact, float sums within the tree-vs-sequential
+tolerance of the tracker tests, and the LM loop lands on the oracle's pose; as a known-answer test the estimate must also
+recover the pose the frame was rendered with."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from sos_slam_amd import synth
+from sos_slam_amd.records import Calib
+from tests import immature_helpers as ih
+
+pytestmark = pytest.mark.gpu
+SUM_TOL = 1e-5
+
+
+def _template(win, frame, dI_levels, n_max=1500):
+    """pts_dso as LoopHandler builds them (src/LoopClosure/LoopHandler.cpp:189-209) from the window's points hosted in `frame`."""
+    sel = np.flatnonzero(win.points["host"] == frame)[:n_max]
+    u, v, idp = [win.points[k][sel].astype(np.float64) for k in ("u", "v", "idepth_scaled")]
+    fx, fy, cx, cy = [float(np.float32(x)) for x in win.K]
+    xyz = np.stack([(u - cx) / fx / idp, (v - cy) / fy / idp, 1 / idp], axis=1).astype(np.float32)
+    cols = []
+    for lvl, dI in enumerate(dI_levels):
+        ul = ((u + 0.5) / (1 << lvl) - 0.5).astype(np.float32)
+        vl = ((v + 0.5) / (1 << lvl) - 0.5).astype(np.float32)
+        ix, iy = ul.astype(np.int32), vl.astype(np.int32)
+        dx, dy = ul - ix, vl - iy
+        I = dI[..., 0]
+        ix1, iy1 = np.minimum(ix + 1, I.shape[1] - 1), np.minimum(iy + 1, I.shape[0] - 1)
+        dxdy = dx * dy
+        cols.append((dxdy * I[iy1, ix1] + (dy - dxdy) * I[iy1, ix] + (dx - dxdy) * I[iy, ix1] + (1 - dx - dy + dxdy) * I[iy, ix]).astype(np.float32))
+    return xyz, np.stack(cols)
+
+
+@pytest.fixture(scope="module")
+def rig():
+    from sos_slam_amd import host
+    win = synth.make_window("T6", extra_frames=1, idepth_noise=0.0)
+    sysm = host.System.from_window(win)
+    matched = win.n - 2
+    dI_m, _ = orc.make_images(win.images[matched])
+    new_dI, _ = orc.make_images(win.extra_images[0])
+    xyz, cols = _template(win, matched, dI_m)
+    calib = Calib.from_K(np.array(win.K, dtype=np.float32).astype(np.float64))
+    ot = orc.OracleTracker(win.params, win.w, win.h)
+    ot.set_points3d(calib, xyz, cols)
+    ht = host.HostTracker(sysm)
+    ht.set_points3d(calib, 1.0, xyz, cols)
+    slot = sysm.upload_image(win.extra_images[0])
+    true_T = ih.se3_mul(ih.se3_inv(win.extra_poses[0]), win.frames[matched]["camToWorld"])   # matched -> new
+    yield dict(win=win, sysm=sysm, ot=ot, ht=ht, new_dI=new_dI, slot=slot, true_T=true_T, n=len(xyz))
+    ht.close()
+    sysm.close()
+
+
+def test_calc_res_and_gs_match(rig):
+    dev = rig["ht"].device()
+    T = rig["true_T"]
+    R = (T[:9].reshape(3, 3) @ np.array([[1, 0.002, 0], [-0.002, 1, 0.001], [0, -0.001, 1]])).astype(np.float32)
+    t = (T[9:] + [0.003, -0.002, 0.004]).astype(np.float32)
+    for lvl in range(rig["ot"].levels):
+        for cutoff in (20.0, 5.0):
+            rs_g = dev.calc_res(lvl, rig["slot"], R.reshape(-1), t, (1.02, -1.5), cutoff)
+            rs_o = rig["ot"].calc_res(lvl, rig["new_dI"][lvl], R.reshape(-1), t, (1.02, -1.5), cutoff)
+            assert rs_g[1] == rs_o[1] and rs_o[1] > 0.5 * rig["n"], (lvl, rs_g, rs_o)      # numTermsInE
+            assert abs(rs_g[5] - rs_o[5]) < 1e-6                                              # saturated ratio
+            for k in (0, 2, 4):
+                assert abs(rs_g[k] - rs_o[k]) <= SUM_TOL * max(abs(rs_o[k]), 1e-3), (lvl, k, rs_g[k], rs_o[k])
+            H_g, b_g = dev.calc_gs(lvl, 1.02, 0.0)
+            H_o, b_o = rig["ot"].calc_gs(lvl, 1.02, 0.0)
+            assert np.abs(H_g - H_o).max() <= 1e-4 * np.abs(H_o).max() and np.abs(b_g - b_o).max() <= 1e-4 * max(np.abs(b_o).max(), 1e-6)
+
+
+def test_estimate_recovers_the_rendered_pose(rig):
+    win, T_true = rig["win"], rig["true_T"]
+    start = T_true.copy()
+    start[9:] += [0.01, -0.008, 0.012]          # a loop candidate's coarse initial guess
+    coarsest = rig["ot"].levels - 1
+    ok_o, T_o, err_o, pct_o = rig["ot"].pose_estimate(rig["new_dI"], 1.0, 1.0, start, coarsest, loop_direct_thres=10.0)
+    ok_g, T_g, err_g, pct_g = rig["ht"].pose_estimate(rig["slot"], 1.0, start, coarsest, loop_direct_thres=10.0)
+    assert ok_o == ok_g and pct_o == pct_g, (ok_o, ok_g, pct_o, pct_g)
+    assert np.abs(T_g - T_o).max() < 2e-4 and abs(err_g - err_o) < 1e-3 * max(err_o, 1e-3)
+    # known answer: the pose the frame was rendered with
+    assert np.abs(T_g[9:] - T_true[9:]).max() < 0.2 * np.abs(start[9:] - T_true[9:]).max(), (T_g[9:], T_true[9:])
+    assert np.abs(T_g[:9] - T_true[:9]).max() < 2e-3
+    assert ok_g and pct_g > 90 and err_g < 10.0
+    # acceptance tests: an impossible residual threshold rejects, on both sides
+    assert not rig["ot"].pose_estimate(rig["new_dI"], 1.0, 1.0, start, coarsest, loop_direct_thres=1e-3)[0]
+    assert not rig["ht"].pose_estimate(rig["slot"], 1.0, start, coarsest, loop_direct_thres=1e-3)[0]
+    # the object goes back to being the coarse tracker
+    sel = np.flatnonzero(win.points["host"] == win.n - 1)[:300]
+    pc = rig["ht"].set_ref_raw(win.points["u"][sel], win.points["v"][sel], win.points["idepth_scaled"][sel], np.full(len(sel), 1e-3, np.float32))
+    assert pc[0] > 0
