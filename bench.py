@@ -161,7 +161,7 @@ def main():
         floor_ms = ms.value
         L.sos_ba_time_kernel(L_host_ba(sysm), b"stream_equal", th.ctypes.data_as(C.c_void_p), 300, C.byref(ms))
         stream_ms = ms.value
-        for name in ("apply_res", "top_accumulate", "sc_accumulate", "sc_gram_prep", "reduce", "stitch"):
+        for name in ("apply_res", "top_accumulate", "sc_accumulate", "sc_gram_prep", "reduce", "stitch", "resub_fused"):
             L.sos_ba_time_kernel(L_host_ba(sysm), name.encode(), th.ctypes.data_as(C.c_void_p), 200, C.byref(ms))
             kern[name + "_us"] = round(ms.value * 1e3, 2)
         out = {

@@ -66,6 +66,7 @@ struct BaDev {
   float *o_newest;
   int newest_begin, newest_count;
   const int2 *p_list2;  // per point residual list: (sorted index, xAd index = n*h + t)
+  const int2 *p_list16; // the first 16 entries of every point's list at a fixed stride (x = -1: none): no p_begin lookup in front
   float4 *r_geo;        // per sorted residual: u, v, idepth_scaled, idepth_zero_scaled of its point
   const float *r_cw;    // per sorted residual: color[8], weights[8] of its point
 };
@@ -1974,29 +1975,15 @@ __global__ __launch_bounds__(SOS_RSB) void k_resub_fused(BaDev d, XArg x, const 
   constexpr int RU = 16;  // residuals held in registers; longer lists finish in the tail loop below
   int2 e[RU];
   float4 ja[RU], jb[RU];
-#pragma unroll
-  for (int k = 0; k < RU; k++) e[k] = (k < cnt) ? d.p_list2[q0 + k] : make_int2(0, 0);
-#pragma unroll
-  for (int k = 0; k < RU; k++) {
-    if (k < cnt) {
-      const float4 *jp = reinterpret_cast<const float4 *>(d.JpJd + 8 * (size_t)e[k].x);
-      ja[k] = jp[0];
-      jb[k] = jp[1];
-    } else {
-      ja[k] = jb[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
   for (int i = tid; i < dim; i += SOS_RSB) sx[i] = x.v[i];  // one coalesced read of the kernel argument
   __syncthreads();
-  // item = (pair idx = n*h + t, half jh): 4 of the 8 outputs from 8 + 8 float4 loads of the adjoint rows
-  for (int q = tid; q < n * n * 2; q += SOS_RSB) {
-    const int idx = q >> 1, jh = q & 1;
+  // The table (item = (pair idx = n*h + t, half jh): 4 of the 8 outputs from 8 + 8 float4 loads of the adjoint rows)
+  // depends on nothing else: its loads are issued ahead of the point's dependent chain (list entries -> JpJd rows), so the
+  // two run side by side instead of one after the other.
+  const int nItems = n * n * 2;
+  auto table_item = [&](int q, const float4 *ah, const float4 *at) {
+    const int idx = q >> 1;
     const int h = idx / n, t = idx - h * n;
-    const float4 *AH = reinterpret_cast<const float4 *>(adHF + 64 * (size_t)(h + n * t)) + jh;
-    const float4 *AT = reinterpret_cast<const float4 *>(adTF + 64 * (size_t)(h + n * t)) + jh;
-    float4 ah[8], at[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) { ah[i] = AH[2 * i]; at[i] = AT[2 * i]; }
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -2007,6 +1994,37 @@ __global__ __launch_bounds__(SOS_RSB) void k_resub_fused(BaDev d, XArg x, const 
     float4 o;
     o.x = s1.x + s2.x; o.y = s1.y + s2.y; o.z = s1.z + s2.z; o.w = s1.w + s2.w;
     reinterpret_cast<float4 *>(sxAd)[q] = o;
+  };
+  auto table_load = [&](int q, float4 *ah, float4 *at) {
+    const int idx = q >> 1, jh = q & 1;
+    const int h = idx / n, t = idx - h * n;
+    const float4 *AH = reinterpret_cast<const float4 *>(adHF + 64 * (size_t)(h + n * t)) + jh;
+    const float4 *AT = reinterpret_cast<const float4 *>(adTF + 64 * (size_t)(h + n * t)) + jh;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { ah[i] = AH[2 * i]; at[i] = AT[2 * i]; }
+  };
+  {
+    float4 ah[8], at[8];
+    const bool first = tid < nItems;
+    if (first) table_load(tid, ah, at);
+#pragma unroll
+    for (int k = 0; k < RU; k++) e[k] = d.p_list16[16 * (size_t)pp + k];  // fixed stride: no dependent lookup in front
+    if (first) table_item(tid, ah, at);
+  }
+#pragma unroll
+  for (int k = 0; k < RU; k++) {
+    if (live && e[k].x >= 0) {
+      const float4 *jp = reinterpret_cast<const float4 *>(d.JpJd + 8 * (size_t)e[k].x);
+      ja[k] = jp[0];
+      jb[k] = jp[1];
+    } else {
+      ja[k] = jb[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  for (int q = tid + SOS_RSB; q < nItems; q += SOS_RSB) {
+    float4 ah[8], at[8];
+    table_load(q, ah, at);
+    table_item(q, ah, at);
   }
   __syncthreads();
   if (!live) return;
@@ -2022,7 +2040,7 @@ __global__ __launch_bounds__(SOS_RSB) void k_resub_fused(BaDev d, XArg x, const 
     b -= dot;
 #pragma unroll
     for (int k = 0; k < RU; k++) {
-      if (k < cnt) {
+      if (e[k].x >= 0) {
         const float4 *xp = reinterpret_cast<const float4 *>(sxAd + 8 * (size_t)e[k].y);
         const float4 xa = xp[0], xb = xp[1];
         float dd = 0;  // inactive residuals hold JpJd == 0: dd == 0 and b - 0 == b
@@ -2053,7 +2071,7 @@ __global__ __launch_bounds__(SOS_RSB) void k_resub_fused(BaDev d, XArg x, const 
   pt->deltaF = 0.f;
 #pragma unroll
   for (int k = 0; k < RU; k++)
-    if (k < cnt) *(reinterpret_cast<float2 *>(d.r_geo + e[k].x) + 1) = make_float2(idn, idn);
+    if (e[k].x >= 0) *(reinterpret_cast<float2 *>(d.r_geo + e[k].x) + 1) = make_float2(idn, idn);
   for (int q = q0 + RU; q < q1; q++) *(reinterpret_cast<float2 *>(d.r_geo + d.p_list2[q].x) + 1) = make_float2(idn, idn);
 }
 
@@ -2270,7 +2288,7 @@ struct sos_ba {
   DevBuf<const float *> d_t_img;
   DevBuf<int> d_t_ht;
   DevBuf<sos_rawjac> d_rawjac;
-  DevBuf<int2> d_p_list2;
+  DevBuf<int2> d_p_list2, d_p_list16;
   DevBuf<float4> d_r_geo;
   DevBuf<float> d_r_cw;
   DevBuf<float> d_stage;   // [precalc n*n*28 | adHTdelta n*n*8 | cdelta 4 | frameTH n(+pad) | xc 4 | xAd n*n*8]
@@ -2355,7 +2373,7 @@ extern "C" int sos_ba_destroy(sos_ba *ba) {
     b->release();
   ba->d_rawjac.release();
   ba->d_t_pre.release(); ba->d_t_img.release(); ba->d_t_ht.release();
-  ba->d_p_list2.release(); ba->d_r_geo.release(); ba->d_r_cw.release(); ba->d_stage.release(); ba->d_outpack.release(); ba->d_C.release();
+  ba->d_p_list2.release(); ba->d_p_list16.release(); ba->d_r_geo.release(); ba->d_r_cw.release(); ba->d_stage.release(); ba->d_outpack.release(); ba->d_C.release();
   if (ba->pin) hipHostFree(ba->pin);
   if (ba->ev_step) hipEventDestroy(ba->ev_step);
   if (ba->pin_newest) hipHostFree(ba->pin_newest);
@@ -2517,6 +2535,12 @@ extern "C" int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, i
   if ((rc = upload(st, ba->d_p_begin, p_begin))) return rc;
   if ((rc = upload(st, ba->d_p_list, p_list))) return rc;
   if ((rc = upload(st, ba->d_p_list2, p_list2))) return rc;
+  {
+    std::vector<int2> p_list16((size_t)(P ? P : 1) * 16, make_int2(-1, 0));
+    for (int pt = 0; pt < P; pt++)
+      for (int q = p_begin[pt], k = 0; q < p_begin[pt + 1] && k < 16; q++, k++) p_list16[(size_t)pt * 16 + k] = p_list2[q];
+    if ((rc = upload(st, ba->d_p_list16, p_list16))) return rc;
+  }
   if ((rc = upload(st, ba->d_p_res_t, p_res_t))) return rc;
   if ((rc = upload(st, ba->d_pair_tile_begin, pair_tile_begin))) return rc;
   if ((rc = upload(st, ba->d_chunk_pt, chunk_pt))) return rc;
@@ -2624,6 +2648,7 @@ extern "C" int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, i
   d.newest_begin = ba->newest_begin;
   d.newest_count = ba->newest_count;
   d.p_list2 = ba->d_p_list2.p;
+  d.p_list16 = ba->d_p_list16.p;
   d.r_geo = ba->d_r_geo.p;
   d.r_cw = ba->d_r_cw.p;
   d.pts = ba->d_pts.p;
@@ -3594,6 +3619,18 @@ extern "C" int sos_ba_time_kernel(sos_ba *ba, const char *kernel, const float *f
     }
     if (k == "calib_write") {  // overwrites the Gram partials (scratch, regenerated by every accumulate): nchunks * Dm^2 * 4 B
       k_calib_write<<<2048, 256, 0, st>>>(reinterpret_cast<float4 *>(ba->d_gram_part.p), (size_t)ba->nchunks * ba->Dm * ba->Dm / 4);
+      return SOS_OK;
+    }
+    if (k == "resub_fused") {  // the back-substitution of a pipelined step (x = 0: the state is left where it is)
+      if (ba->P > 0 && ba->d_adHostF.p && ba->d_adTargetF.p) {
+        XArg xa;
+        memset(&xa, 0, sizeof(xa));
+        const size_t nn = (size_t)ba->n * ba->n;
+        const int nPB = divup(ba->P, SOS_RSB);
+        k_resub_fused<<<nPB, SOS_RSB, sizeof(float) * (8 * nn + 4 + 8 * (size_t)ba->n), st>>>(
+            ba->dev, xa, ba->d_adHostF.p, ba->d_adTargetF.p, reinterpret_cast<float *>(ba->d_outpack.p + ba->out_step), 0.f, nPB, nullptr, nullptr, 0, 0,
+            nullptr, nullptr);
+      }
       return SOS_OK;
     }
     if (k == "resubstitute") {

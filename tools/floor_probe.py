@@ -11,7 +11,7 @@ for name in ("W12", "W16"):
     ba = C.c_void_p(host.load().sosf_ba(sysm.h_))
     th = np.array([sysm.frame(f)["frameEnergyTH"] for f in range(win.n)], np.float32)
     ms = C.c_float(0)
-    for k in ("lin_floor", "linearize_fused", "linearize", "calib_read", "calib_write", "sc_gram_prep", "stitch", "reduce"):
+    for k in ("lin_floor", "linearize_fused", "linearize", "calib_read", "calib_write", "sc_gram_prep", "stitch", "reduce", "resub_fused"):
         rc = L.sos_ba_time_kernel(ba, k.encode(), th.ctypes.data_as(C.c_void_p), 200, C.byref(ms))
         print(name, k, rc, round(ms.value * 1e3, 2), "us")
     sysm.close()
