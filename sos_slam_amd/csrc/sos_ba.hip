@@ -1349,15 +1349,17 @@ __global__ __launch_bounds__(128) void k_reduce_all(ReduceArgs a) {
     if (e >= n * per_host) return;
     const int h = e / per_host, q = e - h * per_host;
     const int r = q / cols, c = q - r * cols;
+    if ((r >> 4) > (c >> 4)) return;  // only the 16x16 tiles on and above the diagonal exist; their owners write the mirror image too
     double s = 0;
     const int kc0 = a.host_chunk_begin[h], kc1 = a.host_chunk_begin[h + 1];
+    const size_t off = (size_t)r * a.Dm + c;
 #pragma unroll 8
-    for (int k = kc0; k < kc1; k++)
-      s += (double)a.gram_part[(size_t)k * a.Dm * a.Dm + (size_t)r * a.Dm + c];
+    for (int k = kc0; k < kc1; k++) s += (double)a.gram_part[(size_t)k * a.Dm * a.Dm + off];
     const int t1 = r >> 3, i = r & 7;
     if (c < 8 * n) {
       const int t2 = c >> 3, j = c & 7;
       a.accD[(size_t)(h + n * t1 + n * n * t2) * 64 + i * 8 + j] = (float)s;
+      if ((r >> 4) < (c >> 4)) a.accD[(size_t)(h + n * t2 + n * n * t1) * 64 + j * 8 + i] = (float)s;  // G symmetric
     } else if (c < 8 * n + 4) {
       a.accE[(size_t)(h + n * t1) * 32 + i * 4 + (c - 8 * n)] = (float)s;
     } else {
@@ -1523,8 +1525,12 @@ __device__ __forceinline__ void sc_gram_body(const BaDev &d, int blk, const int 
   const int T = Dm >> 4;
   const int kq = lane >> 4, col = lane & 15;
   float *g = gram_part + (size_t)blk * Dm * Dm;
-  for (int tile = wave; tile < T * T; tile += 4) {
-    const int m0 = (tile / T) << 4, n0 = (tile % T) << 4;
+  // G is symmetric: only the 16x16 tiles on and above the diagonal are formed and stored (T (T + 1) / 2 of T^2); the
+  // consumers read the mirror image for the rest (k_reduce_all)
+  for (int ut = wave; ut < T * (T + 1) / 2; ut += 4) {
+    int mt = 0, rem = ut;
+    while (rem >= T - mt) { rem -= T - mt; mt++; }
+    const int m0 = mt << 4, n0 = (mt + rem) << 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < SOS_GC / 4; kk++) {
