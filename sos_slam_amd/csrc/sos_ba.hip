@@ -1719,27 +1719,32 @@ __global__ __launch_bounds__(64) void k_stitch_top_sum(int n, const double *__re
 __device__ __forceinline__ void sc_MC_body(int bx, int by, int n, const float *__restrict__ accD, const float *__restrict__ accE,
                                               const float *__restrict__ accEB, const double *__restrict__ adHost,
                                               const double *__restrict__ adTarget, double *__restrict__ C, double *__restrict__ Ce) {
-  __shared__ double sD[64], sA[64], sM[64], sAH[64], sAT[64], sE[32], sEB[8];
+  // every operand of the block is requested before anything is waited for: the g == h blocks sum over all t2, and
+  // staging one (D, A) pair per iteration made them a chain of n dependent round trips -- the critical path of the stage
+  extern __shared__ __attribute__((aligned(16))) double sDA[];  // [n][64] D blocks, then [n][64] adjoint blocks
+  double *sD = sDA, *sA = sDA + (size_t)n * 64;
+  __shared__ double sM[64], sAH[64], sAT[64], sE[32], sEB[8];
   const int tid = threadIdx.x, i = tid >> 3, j = tid & 7;
   const int h = bx % n, t1 = (bx / n) % n, g = bx / (n * n);
-  double m = 0;
   const int t2lo = (g == h) ? 0 : g, t2hi = (g == h) ? n : g + 1;
-  for (int t2 = t2lo; t2 < t2hi; t2++) {
-    sD[tid] = (double)accD[(size_t)(h + n * t1 + n * n * t2) * 64 + tid];
-    sA[tid] = ((g == h) ? adHost : adTarget)[(size_t)(h + n * t2) * 64 + tid];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 8; k++) m += sD[i * 8 + k] * sA[j * 8 + k];
-    __syncthreads();
-  }
-  sM[tid] = m;
   const int pidx = h + n * t1;
+  for (int t2 = t2lo; t2 < t2hi; t2++) {
+    sD[(t2 - t2lo) * 64 + tid] = (double)accD[(size_t)(h + n * t1 + n * n * t2) * 64 + tid];
+    sA[(t2 - t2lo) * 64 + tid] = ((g == h) ? adHost : adTarget)[(size_t)(h + n * t2) * 64 + tid];
+  }
   sAH[tid] = adHost[(size_t)pidx * 64 + tid];
   sAT[tid] = adTarget[(size_t)pidx * 64 + tid];
   if (g == 0) {
     if (tid < 32) sE[tid] = (double)accE[(size_t)pidx * 32 + tid];
     if (tid < 8) sEB[tid] = (double)accEB[(size_t)pidx * 8 + tid];
   }
+  __syncthreads();
+  double m = 0;
+  for (int q = 0; q < t2hi - t2lo; q++) {  // same order of additions as before: t2 ascending, k ascending
+#pragma unroll
+    for (int k = 0; k < 8; k++) m += sD[q * 64 + i * 8 + k] * sA[q * 64 + j * 8 + k];
+  }
+  sM[tid] = m;
   __syncthreads();
   double c1 = 0, c2 = 0;
 #pragma unroll
@@ -3086,7 +3091,7 @@ static int launch_stitch(sos_ba *ba, const float *acc, int nmodes, double *Hout 
       a.sg.seq = ba->sig_st_seq;
     }
   }
-  k_stitch_stage1<<<(n * n + 20) * nmodes + n * n * n, 64, 0, st>>>(a);
+  k_stitch_stage1<<<(n * n + 20) * nmodes + n * n * n, 64, sizeof(double) * 128 * (size_t)n, st>>>(a);
   k_stitch_stage2<<<nb2, 64, 0, st>>>(a);
   if (Hout && !inKernel) k_publish<<<1, 1, 0, st>>>(reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags + 64), ba->sig_st_seq);
   return SOS_OK;
