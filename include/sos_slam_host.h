@@ -160,6 +160,63 @@ int sosf_activate_select(int w1, int h1, int nFrames, int newest, const float *K
                          const int32_t *cand_host, const float *cand_type, const uint8_t *hostFlagged, int8_t *decision,
                          float *distFinal);
 
+/* ---- IMU / spline factor assembly on the backend boundary ---------------------------------------
+ * The host-side fp64 block that sits inside EnergyFunctional::solveSystemF between accumulate and solve:
+ * getImuHessian / getImuHessianCurrentFrame (OB/EnergyFunctional.cpp:288-494), FrameHessian::getImuHi
+ * (FS/HessianBlocks.cpp:178-225), expandHbtoFitImu (:256-286) and the IMU branch of solveSystemF (:1053-1171: expanded
+ * system, marginalisation prior, Schur complement, spline constraint rows, removal of unconstrained states, Jacobi-scaled
+ * LDLT, split of x into pose / scale / IMU steps).  State layout per keyframe, as in the reference: 8 (pose, a, b) + 6
+ * (accelerometer, gyroscope bias) + 15 (spline: linear rot 3, quadratic trans 3 rot 3, cubic trans 3 rot 3) = 29; full
+ * dimension CPARS + 1 (scale) + 29 n. */
+#define SOSF_IMU_DIM(n) (4 + 1 + 29 * (n))
+typedef struct sosf_imu_settings {
+  double weight_imu[36];       /* setting_weight_imu, 6x6 row-major */
+  double weight_imu_bias[36];  /* setting_weight_imu_bias */
+  double gravity[3];           /* setting_gravity */
+  double rot_imu_cam[9];       /* setting_rot_imu_cam, row-major */
+  double maxImuInterval;       /* setting_maxImuInterval */
+  int32_t enable_scale_opt;    /* setting_enable_scale_opt */
+  int32_t pad;
+} sosf_imu_settings;
+typedef struct sosf_imu_calib {   /* the IMU part of CalibHessian (FS/HessianBlocks.h:439-445) */
+  double scale, scale_zero;
+  int32_t scale_trapped, imu_initialized;
+} sosf_imu_calib;
+typedef struct sosf_imu_frame {
+  double timestamp;            /* shell->timestamp */
+  double camToWorld[12];       /* PRE_camToWorld: R row-major | t */
+  double evalPT_R[9];          /* get_camToWorld_evalPT().rotationMatrix() */
+  double state_imu[21];        /* FrameHessian::state_imu (unscaled) */
+  double state_imu_zero[21];
+  int32_t trackingRefIsPrev;   /* shell->trackingRef == the previous keyframe's shell */
+  int32_t n_imu;
+  const double *imu;           /* n_imu x 7: timestamp, acc xyz, gyro xyz (FrameHessian::imu_data) */
+} sosf_imu_frame;
+/* getImuHi for one IMU sample at relative time tt <= 0: JsTW (6), JfTW (29 x 6 row-major), Hss, Hff (29 x 29), Hfs (29) */
+int sosf_imu_get_Hi(const sosf_imu_settings *S, const sosf_imu_calib *C, const sosf_imu_frame *f, double tt, double *JsTW,
+                    double *JfTW, double *Hss, double *Hff, double *Hfs);
+/* getImuHessian: H (dim x dim), b (dim), the stacked spline constraints J_cst (n_cst x dim, caller provides 6 n rows),
+ * r_cst, and spline_valid per frame */
+int sosf_imu_hessian(const sosf_imu_settings *S, const sosf_imu_calib *C, int n, const sosf_imu_frame *frames, double *H, double *b,
+                     double *J_cst, double *r_cst, int32_t *n_cst, int32_t *spline_valid);
+/* expandHbtoFitImu: (4 + 8 n) -> SOSF_IMU_DIM(n) */
+int sosf_imu_expand(int n, const double *H, const double *b, double *He, double *be);
+/* the IMU branch of solveSystemF from the accumulated H_top = HA + HL, b_top, H_sc, b_sc (dimension 4 + 8 n), the
+ * marginalisation prior HM / bM (dimension SOSF_IMU_DIM(n)) and delta = getStitchedDeltaF(): x (4 + 8 n), scale_step,
+ * step_imu (n x 21) */
+int sosf_imu_solve(const sosf_imu_settings *S, const sosf_imu_calib *C, int n, const sosf_imu_frame *frames, const double *H_top,
+                   const double *b_top, const double *H_sc, const double *b_sc, const double *HM, const double *bM,
+                   const double *delta, double lambda, double *x, double *scale_step, double *step_imu);
+
+/* Switches the facade's solveSystemF to the IMU branch (S != NULL) or back (S == NULL).  The records are caller-owned and
+ * must outlive the system's iterations: frames[i] belongs to keyframe idx i (its camToWorld / evalPT_R are refreshed by
+ * the facade before every solve; state_imu and calib->scale are stepped after it, as doStepFromBackup does with unit
+ * step factors); HM / bM: the marginalisation prior in the expanded dimension SOSF_IMU_DIM(n). */
+int sosf_set_imu(sosf_system *sys, const sosf_imu_settings *S, sosf_imu_calib *calib, sosf_imu_frame *frames, const double *HM,
+                 const double *bM);
+/* scale_step and step_imu (n x 21) of the last solve */
+int sosf_get_imu_step(sosf_system *sys, double *scale_step, double *step_imu);
+
 /* direct access to the underlying context / backend handles (tracker tests share the frame store) */
 sos_ctx *sosf_ctx(sosf_system *sys);
 sos_ba *sosf_ba(sosf_system *sys);

@@ -193,4 +193,7 @@ void orc_undistort_frame(const sos_camera_model *cam, const float *remapX, const
                          int valid, const float *vignetteInv, int photometricMode, const void *raw, int bpp, float exposure,
                          float factor, float *out);
 
+/* ---- IMU / spline factor assembly (orc_imu.c); the record types live in include/sos_slam_host.h --------------------- */
+struct sosf_imu_settings; struct sosf_imu_calib; struct sosf_imu_frame;
+
 #endif

@@ -608,3 +608,9 @@ class OracleTracker:
         k1 = np.ascontiguousarray(K1, dtype=np.float32)
         r = self.L.orc_tracker_optimize_scale(self.t, ptrs, _p(tf), _p(k1), C.byref(s), coarsest)
         return r, s.value
+
+
+def imu():
+    """The oracle's IMU / spline factor assembly (orc_imu_*), same call surface as sos_slam_amd.host.imu()."""
+    from sos_slam_amd.host import _ImuApi
+    return _ImuApi(lib(), "orc_imu_")

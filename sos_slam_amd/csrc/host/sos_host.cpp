@@ -455,6 +455,37 @@ void EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib, bo
       b[4 + 8 * h + i] += frames[h]->prior[i] * frames[h]->delta_prior[i];
     }
   const VecX delta = getStitchedDeltaF();
+  if (imuSettings) {  // setting_enable_imu && HCalib->imu_initialized: the IMU branch, OB/EnergyFunctional.cpp:1053-1171
+    for (int i = 0; i < dim; i++)  // the fused device call delivers the upper triangle only
+      for (int j = i + 1; j < dim; j++) {
+        H[(size_t)j * dim + i] = H[(size_t)i * dim + j];
+        Hsc[(size_t)j * dim + i] = Hsc[(size_t)i * dim + j];
+      }
+    for (int h = 0; h < n; h++) {
+      frames[h]->data->PRE_camToWorld.to12(imuFrames[h].camToWorld);
+      std::memcpy(imuFrames[h].evalPT_R, frames[h]->data->camToWorld_evalPT.R, sizeof(double) * 9);
+    }
+    VecX x(dim);
+    imuStep.assign((size_t)21 * n, 0.0);
+    sosf_imu_solve(imuSettings, imuCalib, n, imuFrames, H.data(), b.data(), Hsc.data(), bsc.data(), imuHM, imuBM, delta.data(), lambda,
+                   x.data(), &imuScaleStep, imuStep.data());
+    lastX = x;
+    for (int i = 0; i < 4; i++) HCalib->step[i] = -x[i];
+    for (EFFrame *h : frames) {
+      for (int i = 0; i < 8; i++) h->data->step[i] = -x[SOS_CPARS + 8 * h->idx + i];
+      h->data->step[8] = h->data->step[9] = 0;
+    }
+    // IMU and scale update of doStepFromBackup with unit step factors (FS/FullSystemOptimize.cpp:218-230)
+    imuCalib->scale += imuScaleStep;
+    for (int h = 0; h < n; h++)
+      for (int k = 0; k < 21; k++) imuFrames[h].state_imu[k] += imuStep[(size_t)21 * h + k];
+    g_phase[2] += now_s() - t_sol0;
+    if (deferResubstitute) return;
+    pointStep.resize(allPoints.size());
+    sos_ba_resubstitute(ba, x.data(), pointStep.data());
+    for (size_t k = 0; k < allPoints.size(); k++) allPoints[k]->data->step = pointStep[k];
+    return;
+  }
   for (int i = 0; i < dim; i++) {
     double s = bM[i];
     for (int j = 0; j < dim; j++) s += HM[(size_t)i * dim + j] * delta[j];
@@ -1707,6 +1738,21 @@ extern "C" int sosf_tracker_track(sosf_tracker *t, int newSlot, float new_ab_exp
   aff2[1] = aff.b;
   if (flow3) for (int i = 0; i < 3; i++) flow3[i] = t->ct->lastFlowIndicators[i];
   if (ok) *ok = good ? 1 : 0;
+  return SOS_OK;
+}
+extern "C" int sosf_set_imu(sosf_system *sy, const sosf_imu_settings *S, sosf_imu_calib *C, sosf_imu_frame *frames, const double *HM,
+                            const double *bM) {
+  if (!sy) return SOS_ERR_ARG;
+  EnergyFunctional *ef = sy->fs->ef;
+  if (S && (!C || !frames || !HM || !bM)) return SOS_ERR_ARG;
+  ef->imuSettings = S; ef->imuCalib = C; ef->imuFrames = frames; ef->imuHM = HM; ef->imuBM = bM;
+  return SOS_OK;
+}
+extern "C" int sosf_get_imu_step(sosf_system *sy, double *scale_step, double *step_imu) {
+  if (!sy) return SOS_ERR_ARG;
+  EnergyFunctional *ef = sy->fs->ef;
+  if (scale_step) *scale_step = ef->imuScaleStep;
+  if (step_imu && !ef->imuStep.empty()) std::memcpy(step_imu, ef->imuStep.data(), sizeof(double) * ef->imuStep.size());
   return SOS_OK;
 }
 extern "C" int sosf_write_poses(const char *path, int n, const int32_t *incoming_id, const double *t_wc) {

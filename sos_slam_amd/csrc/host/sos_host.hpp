@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../../include/sos_slam.h"
+#include "../../../include/sos_slam_host.h"
 #include "sos_math.hpp"
 
 namespace sos {
@@ -202,6 +203,15 @@ class EnergyFunctional {  // OB/EnergyFunctional.h:52-154
 
   // multi-GPU hooks (see include/sos_slam_host.h)
   void (*allreduceHook)(void *, float *, size_t) = nullptr;
+  // IMU / spline factors (sos_imu.cpp): when set, solveSystemF takes the IMU branch of OB/EnergyFunctional.cpp:1053-1171
+  // with these caller-owned records (poses refreshed here every solve, states and scale stepped after it) and the prior
+  // in the expanded dimension
+  const sosf_imu_settings *imuSettings = nullptr;
+  sosf_imu_calib *imuCalib = nullptr;
+  sosf_imu_frame *imuFrames = nullptr;
+  const double *imuHM = nullptr, *imuBM = nullptr;
+  double imuScaleStep = 0;
+  std::vector<double> imuStep;
   float (*nthHook)(void *, const float *, int, float) = nullptr;
   void *hookUser = nullptr;
 

@@ -1,0 +1,452 @@
+// sos_imu.cpp -- IMU / spline factor assembly on the backend boundary, host side, fp64:
+//   FrameHessian::getImuHi + spline accessors   FS/HessianBlocks.cpp:178-225, FS/HessianBlocks.h:352-412
+//   EnergyFunctional::getImuHessian{,CurrentFrame}, expandHbtoFitImu   OB/EnergyFunctional.cpp:256-494
+//   the IMU branch of EnergyFunctional::solveSystemF                   OB/EnergyFunctional.cpp:1053-1171
+// This is the block the reference runs between the accumulation (device, sos_ba_gn_accumulate) and the solve; it works
+// on the stitched H / b the device hands over and on per-keyframe IMU records the caller keeps (sosf_imu_frame).
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../../include/sos_slam_host.h"
+#include "sos_math.hpp"
+
+namespace {
+using sos::SE3;
+constexpr int CP = 4;
+constexpr double kScale = 200.0, kSlRot = 100.0, kSqTrans = 1000.0, kSqRot = 1000.0, kScTrans = 1000.0, kScRot = 1000.0, kBa = 100.0,
+                 kBg = 1.0, kXiRot = 1.0, kXiTrans = 0.5;  // FS/HessianBlocks.h:53-79
+
+struct V3 {
+  double v[3];
+  double &operator[](int i) { return v[i]; }
+  double operator[](int i) const { return v[i]; }
+};
+struct M3 {
+  double m[9];
+  double &operator()(int r, int c) { return m[3 * r + c]; }
+  double operator()(int r, int c) const { return m[3 * r + c]; }
+  M3 T() const {
+    M3 o;
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) o(r, c) = (*this)(c, r);
+    return o;
+  }
+  M3 operator*(const M3 &b) const {
+    M3 o;
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) o(r, c) = (*this)(r, 0) * b(0, c) + (*this)(r, 1) * b(1, c) + (*this)(r, 2) * b(2, c);
+    return o;
+  }
+  V3 operator*(const V3 &x) const {
+    V3 o;
+    for (int r = 0; r < 3; r++) o[r] = (*this)(r, 0) * x[0] + (*this)(r, 1) * x[1] + (*this)(r, 2) * x[2];
+    return o;
+  }
+  static M3 from(const double *p) {
+    M3 o;
+    std::memcpy(o.m, p, sizeof(o.m));
+    return o;
+  }
+  static M3 hat(const V3 &w) { return M3{{0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0}}; }
+};
+M3 so3_exp(const V3 &w) {  // Sophus SO3::exp through the unit quaternion, as SE3::exp does
+  const double a[6] = {0, 0, 0, w[0], w[1], w[2]};
+  return M3::from(SE3::exp(a).R);
+}
+V3 so3_log(const M3 &R) {  // Sophus SO3::log (so3.hpp:491-526) on Eigen's matrix -> quaternion conversion
+  double q[4];             // w x y z
+  const double tr = R(0, 0) + R(1, 1) + R(2, 2);
+  if (tr > 0) {
+    double s = std::sqrt(tr + 1.0);
+    q[0] = 0.5 * s;
+    s = 0.5 / s;
+    q[1] = (R(2, 1) - R(1, 2)) * s;
+    q[2] = (R(0, 2) - R(2, 0)) * s;
+    q[3] = (R(1, 0) - R(0, 1)) * s;
+  } else {
+    int i = 0;
+    if (R(1, 1) > R(0, 0)) i = 1;
+    if (R(2, 2) > R(i, i)) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    double s = std::sqrt(R(i, i) - R(j, j) - R(k, k) + 1.0);
+    q[1 + i] = 0.5 * s;
+    s = 0.5 / s;
+    q[0] = (R(k, j) - R(j, k)) * s;
+    q[1 + j] = (R(j, i) + R(i, j)) * s;
+    q[1 + k] = (R(k, i) + R(i, k)) * s;
+  }
+  const double sq = q[1] * q[1] + q[2] * q[2] + q[3] * q[3], nrm = std::sqrt(sq), w = q[0];
+  double f;
+  if (nrm < 1e-10) f = 2.0 / w - 2.0 * sq / (w * w * w);
+  else if (std::fabs(w) < 1e-10) f = (w > 0 ? M_PI : -M_PI) / nrm;
+  else f = 2.0 * std::atan(nrm / w) / nrm;
+  return V3{{f * q[1], f * q[2], f * q[3]}};
+}
+
+// one keyframe's IMU state as the reference's Eigen::Ref views see it
+struct ImuView {
+  const sosf_imu_frame &f;
+  double sc[21];
+  explicit ImuView(const sosf_imu_frame &fr) : f(fr) {
+    const double k[7] = {kBa, kBg, kSlRot, kSqTrans, kSqRot, kScTrans, kScRot};
+    for (int s = 0; s < 7; s++)
+      for (int i = 0; i < 3; i++) sc[3 * s + i] = k[s] * f.state_imu[3 * s + i];
+  }
+  double bias(int i) const { return sc[i]; }
+  V3 acc(double t, bool zero) const {  // getSplineAcc
+    V3 a;
+    for (int i = 0; i < 3; i++)
+      a[i] = zero ? 2 * kSqTrans * f.state_imu_zero[9 + i] + 6 * t * kScTrans * f.state_imu_zero[15 + i] : 2 * sc[9 + i] + 6 * t * sc[15 + i];
+    return a;
+  }
+  V3 gyro(double t) const {  // getSplineGryo
+    V3 g;
+    for (int i = 0; i < 3; i++) g[i] = sc[6 + i] + (2 * t * sc[12 + i] + 3 * t * t * sc[18 + i]);
+    return g;
+  }
+  M3 R_c_t(double t, bool zero) const {  // getSplineR_c_t
+    const double t2 = t * t;
+    V3 w;
+    for (int i = 0; i < 3; i++)
+      w[i] = zero ? t * kSlRot * f.state_imu_zero[6 + i] + t2 * kSqRot * f.state_imu_zero[12 + i] + t * t2 * kScRot * f.state_imu_zero[18 + i]
+                  : t * sc[6 + i] + (t2 * sc[12 + i] + t * t2 * sc[18 + i]);
+    return so3_exp(w);
+  }
+};
+
+struct HiOut {
+  double JsTW[6], JfTW[29 * 6], Hss, Hff[29 * 29], Hfs[29];
+};
+void get_Hi(const sosf_imu_settings &S, const sosf_imu_calib &C, const sosf_imu_frame &fr, double tt, HiOut &o) {
+  const ImuView f(fr);
+  const bool trapped = C.scale_trapped != 0;
+  const double tt2 = tt * tt, scale_scaled = (trapped ? C.scale_zero : C.scale) * kScale;
+  const V3 a = f.acc(tt, trapped);
+  V3 acc_w;
+  for (int i = 0; i < 3; i++) acc_w[i] = scale_scaled * a[i] + S.gravity[i];
+  const M3 Ric = M3::from(S.rot_imu_cam);
+  const M3 rot_t_w = f.R_c_t(tt, trapped).T() * M3::from(fr.evalPT_R).T();
+  const M3 rot_i_w = Ric * rot_t_w;
+  const M3 R_acc_t_hat = Ric * M3::hat(rot_t_w * acc_w);
+  double Js[6] = {0, 0, 0, 0, 0, 0};
+  std::vector<double> Jf(6 * 29, 0.0);
+  auto J = [&](int r, int c) -> double & { return Jf[29 * r + c]; };
+  const V3 ra = rot_i_w * a;
+  for (int i = 0; i < 3; i++) Js[i] = kScale * ra[i];
+  if (trapped) {  // the pose columns take part only once the scale is trapped
+    const M3 d = rot_i_w * M3::hat(acc_w);
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) J(r, 3 + c) = kXiRot * d(r, c);
+  }
+  for (int r = 0; r < 3; r++) {
+    J(r, 8 + r) = kBa;
+    J(3 + r, 11 + r) = kBg;
+    for (int c = 0; c < 3; c++) {
+      J(r, 14 + c) = kSlRot * R_acc_t_hat(r, c) * tt;
+      J(r, 20 + c) = kSqRot * R_acc_t_hat(r, c) * tt2;
+      J(r, 26 + c) = kScRot * R_acc_t_hat(r, c) * tt * tt2;
+      J(r, 17 + c) = kSqTrans * rot_i_w(r, c) * 2 * scale_scaled;
+      J(r, 23 + c) = kScTrans * rot_i_w(r, c) * 6 * tt * scale_scaled;
+      J(3 + r, 14 + c) = kSlRot * Ric(r, c);
+      J(3 + r, 20 + c) = kSqRot * Ric(r, c) * 2 * tt;
+      J(3 + r, 26 + c) = kScRot * Ric(r, c) * 3 * tt2;
+    }
+  }
+  for (int c = 0; c < 6; c++) {
+    double s = 0;
+    for (int k = 0; k < 6; k++) s += Js[k] * S.weight_imu[6 * k + c];
+    o.JsTW[c] = s;
+  }
+  for (int r = 0; r < 29; r++)
+    for (int c = 0; c < 6; c++) {
+      double s = 0;
+      for (int k = 0; k < 6; k++) s += J(k, r) * S.weight_imu[6 * k + c];
+      o.JfTW[6 * r + c] = s;
+    }
+  o.Hss = 0;
+  for (int k = 0; k < 6; k++) o.Hss += o.JsTW[k] * Js[k];
+  for (int r = 0; r < 29; r++) {
+    for (int c = 0; c < 29; c++) {
+      double s = 0;
+      for (int k = 0; k < 6; k++) s += o.JfTW[6 * r + k] * J(k, c);
+      o.Hff[29 * r + c] = s;
+    }
+    double s = 0;
+    for (int k = 0; k < 6; k++) s += o.JfTW[6 * r + k] * Js[k];
+    o.Hfs[r] = s;
+  }
+}
+
+// dense row-major matrix with the handful of block operations the assembly needs
+struct Dense {
+  int rows, cols;
+  std::vector<double> a;
+  Dense(int r, int c) : rows(r), cols(c), a((size_t)r * c, 0.0) {}
+  double &operator()(int r, int c) { return a[(size_t)r * cols + c]; }
+  double operator()(int r, int c) const { return a[(size_t)r * cols + c]; }
+};
+
+struct Assembly {
+  Dense H;
+  std::vector<double> b;
+  std::vector<std::vector<double>> Jrows;  // constraint rows
+  std::vector<double> r;
+  std::vector<int> spline_valid;
+  Assembly(int dim, int n) : H(dim, dim), b(dim, 0.0), spline_valid(n, 0) {}
+};
+
+void add_frame(const sosf_imu_settings &S, const sosf_imu_calib &C, int n, const sosf_imu_frame *F, int fi, Assembly &A) {
+  const int dim = SOSF_IMU_DIM(n);
+  const sosf_imu_frame &cur = F[fi], &prv = F[fi - 1];
+  const ImuView vc(cur), vp(prv);
+  const double tpf = prv.timestamp - cur.timestamp, tpf2 = tpf * tpf;
+  const int ci = CP + 1 + 29 * fi, pi = CP + 1 + 29 * (fi - 1);
+  // bias random walk between consecutive keyframes
+  double W[36], rb[6], tb[6];
+  for (int k = 0; k < 36; k++) W[k] = S.weight_imu_bias[k] / -tpf;
+  for (int k = 0; k < 6; k++) rb[k] = vc.bias(k) - vp.bias(k);
+  for (int r = 0; r < 6; r++) {
+    double s = 0;
+    for (int k = 0; k < 6; k++) s += W[6 * r + k] * rb[k];
+    tb[r] = s * (r < 3 ? kBa : kBg);
+  }
+  for (int r = 0; r < 6; r++)
+    for (int c = 0; c < 6; c++) {
+      double w = W[6 * r + c];
+      if (r < 3 && c < 3) w *= (kBa * kBa);
+      if (r >= 3 && c >= 3) w *= (kBg * kBg);
+      A.H(pi + 8 + r, pi + 8 + c) += w;
+      A.H(ci + 8 + r, ci + 8 + c) += w;
+      A.H(pi + 8 + r, ci + 8 + c) += -w;
+      A.H(ci + 8 + r, pi + 8 + c) += -w;
+    }
+  for (int r = 0; r < 6; r++) {
+    A.b[pi + 8 + r] += -tb[r];
+    A.b[ci + 8 + r] += tb[r];
+  }
+  const bool valid = cur.trackingRefIsPrev && (-tpf < S.maxImuInterval);
+  A.spline_valid[fi] = valid ? 1 : 0;
+  if (!valid) return;
+  const bool vel_valid = fi < n - 1;
+  const int rows = vel_valid ? 6 : 3, row0 = (int)A.Jrows.size();
+  for (int k = 0; k < rows; k++) {
+    A.Jrows.emplace_back((size_t)dim, 0.0);
+    A.r.push_back(0.0);
+  }
+  // spline rotation against the relative rotation of the two keyframes
+  const M3 Rc = M3::from(cur.camToWorld), Rp = M3::from(prv.camToWorld);
+  const M3 meas = Rc.T() * Rp, pred = vc.R_c_t(tpf, false);
+  const V3 rr = so3_log(meas.T() * pred);
+  const M3 Rpe = M3::from(prv.evalPT_R).T();
+  for (int r = 0; r < 3; r++) {
+    A.r[row0 + r] = rr[r];
+    std::vector<double> &J = A.Jrows[row0 + r];
+    for (int c = 0; c < 3; c++) {
+      J[pi + 3 + c] = -kXiRot * Rpe(r, c);
+      J[ci + 3 + c] = kXiRot * Rpe(r, c);
+    }
+    J[ci + 14 + r] = kSlRot * tpf;
+    J[ci + 20 + r] = kSqRot * tpf2;
+    J[ci + 26 + r] = kScRot * tpf * tpf2;
+  }
+  if (vel_valid) {  // velocity continuity with the following keyframe
+    const sosf_imu_frame &nxt = F[fi + 1];
+    const ImuView vn(nxt);
+    const double tnf = cur.timestamp - nxt.timestamp;
+    if (nxt.trackingRefIsPrev && (-tnf < S.maxImuInterval)) {
+      const int ni = CP + 1 + 29 * (fi + 1);
+      const double tnf2 = tnf * tnf;
+      for (int r = 0; r < 3; r++) {
+        const double dso = (1 / tpf) * (prv.camToWorld[9 + r] - cur.camToWorld[9 + r]) - (1 / tnf) * (cur.camToWorld[9 + r] - nxt.camToWorld[9 + r]);
+        const double imu = tpf * vc.sc[9 + r] + tpf2 * vc.sc[15 + r] + tnf * vn.sc[9 + r] + 2 * tnf2 * vn.sc[15 + r];
+        A.r[row0 + 3 + r] = imu - dso;
+        std::vector<double> &J = A.Jrows[row0 + 3 + r];
+        J[pi + r] = -kXiTrans / tpf;
+        J[ci + r] = kXiTrans * (1 / tpf + 1 / tnf);
+        J[ni + r] = -kXiTrans / tnf;
+        J[ci + 17 + r] = kSqTrans * tpf;
+        J[ci + 23 + r] = kScTrans * tpf2;
+        J[ni + 17 + r] = kSqTrans * tnf;
+        J[ni + 23 + r] = kScTrans * 2 * tnf2;
+      }
+    }
+  }
+  // IMU samples against the spline
+  auto add_H = [&](double Hss, const double *Hff, const double *Hfs) {
+    A.H(CP, CP) += Hss;
+    for (int r = 0; r < 29; r++) {
+      A.H(ci + r, CP) += Hfs[r];
+      A.H(CP, ci + r) += Hfs[r];
+      for (int c = 0; c < 29; c++) A.H(ci + r, ci + c) += Hff[29 * r + c];
+    }
+  };
+  HiOut hi;
+  if (C.scale_trapped) {  // first-estimate Jacobians: the per-sample Hessians are summed once (setImuStateZero) and added whole
+    double sHss = 0;
+    std::vector<double> sHff(29 * 29, 0.0), sHfs(29, 0.0);
+    for (int j = 0; j < cur.n_imu; j++) {
+      get_Hi(S, C, cur, cur.imu[7 * j] - cur.timestamp, hi);
+      sHss += hi.Hss;
+      for (int k = 0; k < 29 * 29; k++) sHff[k] += hi.Hff[k];
+      for (int k = 0; k < 29; k++) sHfs[k] += hi.Hfs[k];
+    }
+    add_H(sHss, sHff.data(), sHfs.data());
+  }
+  const M3 Ric = M3::from(S.rot_imu_cam), Rwc = Rc.T();
+  const double scale_scaled = C.scale * kScale;
+  for (int j = 0; j < cur.n_imu; j++) {
+    const double tt = cur.imu[7 * j] - cur.timestamp;
+    const V3 a = vc.acc(tt, false);
+    V3 aw;
+    for (int i = 0; i < 3; i++) aw[i] = scale_scaled * a[i] + S.gravity[i];
+    const V3 pa = ((Ric * vc.R_c_t(tt, false).T()) * Rwc) * aw, pg = Ric * vc.gyro(tt);
+    double res[6];
+    for (int i = 0; i < 3; i++) {
+      res[i] = (pa[i] + vc.bias(i)) - cur.imu[7 * j + 1 + i];
+      res[3 + i] = (pg[i] + vc.bias(3 + i)) - cur.imu[7 * j + 4 + i];
+    }
+    get_Hi(S, C, cur, tt, hi);
+    if (!C.scale_trapped) add_H(hi.Hss, hi.Hff, hi.Hfs);
+    double s = 0;
+    for (int k = 0; k < 6; k++) s += hi.JsTW[k] * res[k];
+    A.b[CP] += s;
+    for (int r = 0; r < 29; r++) {
+      double t = 0;
+      for (int k = 0; k < 6; k++) t += hi.JfTW[6 * r + k] * res[k];
+      A.b[ci + r] += t;
+    }
+  }
+}
+
+Assembly assemble(const sosf_imu_settings &S, const sosf_imu_calib &C, int n, const sosf_imu_frame *F) {
+  Assembly A(SOSF_IMU_DIM(n), n);
+  for (int i = 1; i < n; i++) add_frame(S, C, n, F, i, A);
+  return A;
+}
+
+void expand(int n, const double *H, const double *b, Dense &He, std::vector<double> &be) {
+  const int d0 = CP + 8 * n;
+  auto src = [&](int r, int c) { return H[(size_t)r * d0 + c]; };
+  auto map = [&](int k) { return k < CP ? k : CP + 1 + 29 * ((k - CP) / 8) + (k - CP) % 8; };  // dso index -> expanded index
+  for (int r = 0; r < d0; r++) {
+    be[map(r)] += b[r];
+    for (int c = 0; c < d0; c++) He(map(r), map(c)) += src(r, c);
+  }
+}
+}  // namespace
+
+extern "C" int sosf_imu_get_Hi(const sosf_imu_settings *S, const sosf_imu_calib *C, const sosf_imu_frame *f, double tt, double *JsTW,
+                               double *JfTW, double *Hss, double *Hff, double *Hfs) {
+  if (!S || !C || !f || !JsTW || !JfTW || !Hss || !Hff || !Hfs) return SOS_ERR_ARG;
+  HiOut o;
+  get_Hi(*S, *C, *f, tt, o);
+  std::memcpy(JsTW, o.JsTW, sizeof(o.JsTW));
+  std::memcpy(JfTW, o.JfTW, sizeof(o.JfTW));
+  *Hss = o.Hss;
+  std::memcpy(Hff, o.Hff, sizeof(o.Hff));
+  std::memcpy(Hfs, o.Hfs, sizeof(o.Hfs));
+  return SOS_OK;
+}
+
+extern "C" int sosf_imu_hessian(const sosf_imu_settings *S, const sosf_imu_calib *C, int n, const sosf_imu_frame *frames, double *H,
+                                double *b, double *J_cst, double *r_cst, int32_t *n_cst, int32_t *spline_valid) {
+  if (!S || !C || n < 1 || !frames || !H || !b || !J_cst || !r_cst || !n_cst || !spline_valid) return SOS_ERR_ARG;
+  const int dim = SOSF_IMU_DIM(n);
+  const Assembly A = assemble(*S, *C, n, frames);
+  std::memcpy(H, A.H.a.data(), sizeof(double) * (size_t)dim * dim);
+  std::memcpy(b, A.b.data(), sizeof(double) * dim);
+  for (size_t k = 0; k < A.Jrows.size(); k++) {
+    std::memcpy(J_cst + k * dim, A.Jrows[k].data(), sizeof(double) * dim);
+    r_cst[k] = A.r[k];
+  }
+  *n_cst = (int32_t)A.Jrows.size();
+  for (int i = 0; i < n; i++) spline_valid[i] = A.spline_valid[i];
+  return SOS_OK;
+}
+
+extern "C" int sosf_imu_expand(int n, const double *H, const double *b, double *He, double *be) {
+  if (n < 1 || !H || !b || !He || !be) return SOS_ERR_ARG;
+  const int dim = SOSF_IMU_DIM(n);
+  Dense E(dim, dim);
+  std::vector<double> e(dim, 0.0);
+  expand(n, H, b, E, e);
+  std::memcpy(He, E.a.data(), sizeof(double) * (size_t)dim * dim);
+  std::memcpy(be, e.data(), sizeof(double) * dim);
+  return SOS_OK;
+}
+
+extern "C" int sosf_imu_solve(const sosf_imu_settings *S, const sosf_imu_calib *C, int n, const sosf_imu_frame *F, const double *H_top,
+                              const double *b_top, const double *H_sc, const double *b_sc, const double *HM, const double *bM,
+                              const double *delta, double lambda, double *x, double *scale_step, double *step_imu) {
+  if (!S || !C || n < 1 || !F || !H_top || !b_top || !H_sc || !b_sc || !HM || !bM || !delta || !x || !scale_step || !step_imu) return SOS_ERR_ARG;
+  const int dimI = SOSF_IMU_DIM(n);
+  Assembly A = assemble(*S, *C, n, F);  // H_imu, b_imu, constraints
+  Dense Hf(dimI, dimI);
+  std::vector<double> bf(dimI, 0.0);
+  expand(n, H_top, b_top, Hf, bf);       // expandHbtoFitImu(HFinal_top, bFinal_top); += H_imu, b_imu
+  for (size_t k = 0; k < Hf.a.size(); k++) Hf.a[k] += A.H.a[k];
+  for (int k = 0; k < dimI; k++) bf[k] += A.b[k];
+  // marginalisation prior around the expanded delta
+  std::vector<double> d2(dimI, 0.0);
+  for (int i = 0; i < CP; i++) d2[i] = delta[i];
+  if (C->scale_trapped) d2[CP] = C->scale - C->scale_zero;
+  for (int i = 0; i < n; i++) {
+    for (int k = 0; k < 8; k++) d2[CP + 1 + 29 * i + k] = delta[CP + 8 * i + k];
+    if (C->scale_trapped)
+      for (int k = 0; k < 21; k++) d2[CP + 1 + 29 * i + 8 + k] = F[i].state_imu[k] - F[i].state_imu_zero[k];
+  }
+  for (int r = 0; r < dimI; r++) {
+    double s = bM[r];
+    for (int c = 0; c < dimI; c++) {
+      s += HM[(size_t)r * dimI + c] * d2[c];
+      Hf(r, c) += HM[(size_t)r * dimI + c];
+    }
+    bf[r] += s;
+  }
+  // Schur complement of the points
+  Dense Hs(dimI, dimI);
+  std::vector<double> bs(dimI, 0.0);
+  expand(n, H_sc, b_sc, Hs, bs);
+  for (int i = 0; i < dimI; i++) Hf(i, i) *= (1 + lambda);
+  const double f = 1.0f / (1 + lambda);
+  for (size_t k = 0; k < Hf.a.size(); k++) Hf.a[k] -= Hs.a[k] * f;
+  for (int k = 0; k < dimI; k++) bf[k] -= bs[k];
+  // KKT system with the spline constraints, then only the states that are constrained: the kept indices in order
+  const int cdim = (int)A.Jrows.size();
+  std::vector<int> keep;
+  for (int i = 0; i < CP; i++) keep.push_back(i);
+  if (!S->enable_scale_opt) keep.push_back(CP);
+  for (int i = 0; i < n; i++)
+    for (int k = 0; k < (A.spline_valid[i] ? 29 : 14); k++) keep.push_back(CP + 1 + 29 * i + k);
+  const int ms = (int)keep.size(), m = ms + cdim;
+  std::vector<double> K((size_t)m * m, 0.0), rhs(m, 0.0), sI(m), sol;
+  for (int r = 0; r < ms; r++) {
+    for (int c = 0; c < ms; c++) K[(size_t)r * m + c] = Hf(keep[r], keep[c]);
+    for (int k = 0; k < cdim; k++) K[(size_t)r * m + ms + k] = K[(size_t)(ms + k) * m + r] = A.Jrows[k][keep[r]];
+    rhs[r] = bf[keep[r]];
+  }
+  for (int k = 0; k < cdim; k++) rhs[ms + k] = A.r[k];
+  for (int i = 0; i < m; i++) sI[i] = 1.0 / std::sqrt(K[(size_t)i * m + i] + 10);
+  for (int r = 0; r < m; r++) {
+    for (int c = 0; c < m; c++) K[(size_t)r * m + c] *= sI[r] * sI[c];
+    rhs[r] *= sI[r];
+  }
+  sos::ldlt_solve_ref(K, rhs, sol, m);  // Eigen-style pivoting on the largest |diagonal|: the KKT matrix is indefinite
+  for (int i = 0; i < m; i++) sol[i] *= sI[i];
+  // split into the dso increment, the scale step and the IMU steps
+  std::memset(x, 0, sizeof(double) * (CP + 8 * n));
+  std::memset(step_imu, 0, sizeof(double) * 21 * n);
+  *scale_step = 0;
+  for (int r = 0; r < ms; r++) {
+    const int g = keep[r];
+    if (g < CP) x[g] = sol[r];
+    else if (g == CP) *scale_step = -sol[r];
+    else {
+      const int i = (g - CP - 1) / 29, k = (g - CP - 1) % 29;
+      if (k < 8) x[CP + 8 * i + k] = sol[r];
+      else step_imu[21 * i + (k - 8)] = -sol[r];
+    }
+  }
+  return SOS_OK;
+}

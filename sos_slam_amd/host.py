@@ -59,6 +59,8 @@ def load():
     L.sosf_tracker_handle.argtypes = [vp]
     L.sosf_tracker_track.argtypes = [vp, ci, C.c_float, vp, vp, ci, vp, vp, vp, C.POINTER(ci)]
     L.sosf_write_poses.argtypes = [C.c_char_p, ci, vp, vp]
+    L.sosf_set_imu.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.sosf_get_imu_step.argtypes = [vp, vp, vp]
     L.sosf_tracker_set_points3d.argtypes = [vp, vp, C.c_float, ci, vp, vp]
     L.sosf_tracker_pose_estimate.argtypes = [vp, ci, C.c_float, vp, ci, C.c_float, ci, vp, vp, vp]
     L.sosf_tracker_optimize_scale.argtypes = [vp, ci, vp, vp, C.POINTER(C.c_float), ci, C.POINTER(C.c_float)]
@@ -200,6 +202,27 @@ class System:
 
     def prepare(self):
         _chk(self.L.sosf_prepare(self.h_), "sosf_prepare")
+
+    def set_imu(self, S=None, calib=None, frames=None, HM=None, bM=None):
+        """IMU branch of solveSystemF on / off; the records stay owned (and kept alive) by this object."""
+        if S is None:
+            self._imu = None
+            _chk(self.L.sosf_set_imu(self.h_, None, None, None, None, None), "sosf_set_imu")
+            return
+        from .records import ImuFrame
+        arr = (ImuFrame * len(frames))(*frames)
+        HM = np.ascontiguousarray(HM, dtype=np.float64)
+        bM = np.ascontiguousarray(bM, dtype=np.float64)
+        self._imu = (S, calib, arr, frames, HM, bM)
+        _chk(self.L.sosf_set_imu(self.h_, C.byref(S), C.byref(calib), arr, _p(HM), _p(bM)), "sosf_set_imu")
+
+    def imu_state(self):
+        """(scale_step, step_imu (n, 21), state_imu (n, 21), scale) after the last solve"""
+        S, calib, arr, frames, HM, bM = self._imu
+        n = len(arr)
+        ss, st = C.c_double(0), np.zeros((n, 21))
+        _chk(self.L.sosf_get_imu_step(self.h_, C.byref(ss), _p(st)), "sosf_get_imu_step")
+        return ss.value, st, np.array([list(arr[i].state_imu) for i in range(n)]), calib.scale
 
     def set_pipeline(self, on=True):
         _chk(self.L.sosf_set_pipeline(self.h_, int(on)), "sosf_set_pipeline")
@@ -352,3 +375,59 @@ class HostTracker:
         _chk(self.L.sosf_tracker_optimize_scale(self.h_, stereoSlot, _p(tf), _p(k1), C.byref(s), coarsest, C.byref(r)),
              "sosf_tracker_optimize_scale")
         return r.value, s.value
+
+class _ImuApi:
+    """Shared ctypes plumbing of the IMU / spline assembly (facade: sosf_imu_*, oracle: orc_imu_*)."""
+
+    def __init__(self, L, prefix):
+        self.L, self.p = L, prefix
+        vp = C.c_void_p
+        getattr(L, prefix + "get_Hi").argtypes = [vp, vp, vp, C.c_double, vp, vp, vp, vp, vp]
+        getattr(L, prefix + "hessian").argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+        getattr(L, prefix + "expand").argtypes = [C.c_int, vp, vp, vp, vp]
+        getattr(L, prefix + "solve").argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_double, vp, vp, vp]
+
+    @staticmethod
+    def _frames(frames):
+        from sos_slam_amd.records import ImuFrame
+        arr = (ImuFrame * len(frames))(*frames)
+        return arr
+
+    def get_Hi(self, S, Cal, frame, tt):
+        JsTW, JfTW, Hss, Hff, Hfs = np.zeros(6), np.zeros((29, 6)), C.c_double(0), np.zeros((29, 29)), np.zeros(29)
+        getattr(self.L, self.p + "get_Hi")(C.byref(S), C.byref(Cal), C.byref(frame), tt, _p(JsTW), _p(JfTW), C.byref(Hss), _p(Hff), _p(Hfs))
+        return JsTW, JfTW, Hss.value, Hff, Hfs
+
+    def hessian(self, S, Cal, frames):
+        from sos_slam_amd.records import imu_dim
+        n = len(frames)
+        dim = imu_dim(n)
+        H, b = np.zeros((dim, dim)), np.zeros(dim)
+        J, r = np.zeros((6 * n, dim)), np.zeros(6 * n)
+        nc = C.c_int32(0)
+        sv = np.zeros(n, np.int32)
+        arr = self._frames(frames)
+        getattr(self.L, self.p + "hessian")(C.byref(S), C.byref(Cal), n, arr, _p(H), _p(b), _p(J), _p(r), C.byref(nc), _p(sv))
+        return H, b, J[:nc.value], r[:nc.value], sv
+
+    def expand(self, n, H, b):
+        from sos_slam_amd.records import imu_dim
+        dim = imu_dim(n)
+        He, be = np.zeros((dim, dim)), np.zeros(dim)
+        H = np.ascontiguousarray(H, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        getattr(self.L, self.p + "expand")(n, _p(H), _p(b), _p(He), _p(be))
+        return He, be
+
+    def solve(self, S, Cal, frames, H_top, b_top, H_sc, b_sc, HM, bM, delta, lam=1e-5):
+        n = len(frames)
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (H_top, b_top, H_sc, b_sc, HM, bM, delta)]
+        x, ss, si = np.zeros(4 + 8 * n), C.c_double(0), np.zeros((n, 21))
+        arr = self._frames(frames)
+        getattr(self.L, self.p + "solve")(C.byref(S), C.byref(Cal), n, arr, *[_p(v) for v in a], lam, _p(x), C.byref(ss), _p(si))
+        return x, ss.value, si
+
+
+def imu():
+    """The facade's IMU / spline factor assembly (sosf_imu_*)."""
+    return _ImuApi(load(), "sosf_imu_")

@@ -113,3 +113,24 @@ class CameraModel(C.Structure):
 CAM_RADTAN, CAM_PINHOLE, CAM_EQUIDISTANT, CAM_KB, CAM_FOV = range(5)
 RECT_CROP, RECT_NONE, RECT_GIVEN = -1, -3, 0
 assert C.sizeof(CameraModel) == 112
+
+
+class ImuSettings(C.Structure):
+    """sosf_imu_settings (util/settings.cpp:184-196, src/main.cpp:122-150)."""
+    _fields_ = [("weight_imu", C.c_double * 36), ("weight_imu_bias", C.c_double * 36), ("gravity", C.c_double * 3),
+                ("rot_imu_cam", C.c_double * 9), ("maxImuInterval", C.c_double), ("enable_scale_opt", C.c_int32), ("pad", C.c_int32)]
+
+
+class ImuCalib(C.Structure):
+    _fields_ = [("scale", C.c_double), ("scale_zero", C.c_double), ("scale_trapped", C.c_int32), ("imu_initialized", C.c_int32)]
+
+
+class ImuFrame(C.Structure):
+    """sosf_imu_frame; `imu` points at n_imu x 7 doubles kept alive by the caller."""
+    _fields_ = [("timestamp", C.c_double), ("camToWorld", C.c_double * 12), ("evalPT_R", C.c_double * 9),
+                ("state_imu", C.c_double * 21), ("state_imu_zero", C.c_double * 21), ("trackingRefIsPrev", C.c_int32),
+                ("n_imu", C.c_int32), ("imu", C.c_void_p)]
+
+
+def imu_dim(n):
+    return 4 + 1 + 29 * n

@@ -1,0 +1,168 @@
+"""IMU / spline factor assembly on the backend boundary, CPU: the facade's C++ implementation
+(sosf_imu_*) against the oracle restatement (orc_imu_*), and known-answer tests of the restatement itself: the IMU
+Jacobians against finite differences of the predicted measurement, the structure of expandHbtoFitImu, and the solved
+step satisfying the spline constraints of the KKT system it came from."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from sos_slam_amd.records import ImuCalib, ImuFrame, ImuSettings, imu_dim
+
+SC = dict(BA=100.0, BG=1.0, SL_ROT=100.0, SQ_TRANS=1000.0, SQ_ROT=1000.0, SC_TRANS=1000.0, SC_ROT=1000.0, SCALE=200.0)
+
+
+def _rot(w):
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    return np.eye(3) if th < 1e-12 else np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+
+
+def _scene(n=5, seed=0, trapped=True, scale_opt=False, n_imu=12):
+    rng = np.random.default_rng(seed)
+    S = ImuSettings()
+    W = np.diag(rng.uniform(0.5, 2.0, 6))
+    S.weight_imu[:] = list(W.reshape(-1))
+    S.weight_imu_bias[:] = list(np.diag(rng.uniform(5, 20, 6)).reshape(-1))
+    S.gravity[:] = [0.1, 9.7, 0.4]
+    S.rot_imu_cam[:] = list(_rot(rng.normal(0, 0.4, 3)).reshape(-1))
+    S.maxImuInterval = 0.5
+    S.enable_scale_opt = int(scale_opt)
+    cal = ImuCalib(1.02 / SC["SCALE"] * SC["SCALE"] / SC["SCALE"], 1.0 / SC["SCALE"], int(trapped), 1)
+    frames, keep = [], []
+    t = 10.0
+    for i in range(n):
+        f = ImuFrame()
+        t += rng.uniform(0.08, 0.2) if i != 3 else 0.9          # one gap longer than maxImuInterval: that spline is invalid
+        f.timestamp = t
+        R = _rot(rng.normal(0, 0.2, 3))
+        f.camToWorld[:] = list(R.reshape(-1)) + list(rng.normal(0, 1.0, 3) + [0.3 * i, 0, 0])
+        f.evalPT_R[:] = list((R @ _rot(rng.normal(0, 0.01, 3))).reshape(-1))
+        st = np.concatenate([rng.normal(0, 2e-4, 3), rng.normal(0, 2e-3, 3), rng.normal(0, 2e-3, 3), rng.normal(0, 2e-4, 3),
+                             rng.normal(0, 2e-4, 3), rng.normal(0, 1e-4, 3), rng.normal(0, 1e-4, 3)])
+        f.state_imu[:] = list(st)
+        f.state_imu_zero[:] = list(st + rng.normal(0, 1e-6, 21))
+        f.trackingRefIsPrev = 1 if i != 2 else 0                  # and one keyframe tracked against an older reference
+        imu = np.zeros((n_imu, 7))
+        imu[:, 0] = t - np.sort(rng.uniform(0, 0.08, n_imu))[::-1]
+        imu[:, 1:4] = rng.normal(0, 0.3, (n_imu, 3)) + [0, 9.8, 0]
+        imu[:, 4:7] = rng.normal(0, 0.05, (n_imu, 3))
+        keep.append(np.ascontiguousarray(imu))
+        f.n_imu = n_imu
+        f.imu = keep[-1].ctypes.data
+        frames.append(f)
+    return S, cal, frames, keep
+
+
+@pytest.mark.parametrize("trapped,scale_opt", [(True, False), (False, False), (True, True)])
+def test_facade_equals_oracle(trapped, scale_opt):
+    from sos_slam_amd import host
+    S, cal, frames, keep = _scene(trapped=trapped, scale_opt=scale_opt)
+    fo, ff = orc.imu(), host.imu()
+    for a, b in zip(fo.get_Hi(S, cal, frames[1], -0.03), ff.get_Hi(S, cal, frames[1], -0.03)):
+        assert np.allclose(a, b, rtol=1e-12, atol=1e-12)
+    Ho, bo, Jo, ro, svo = fo.hessian(S, cal, frames)
+    Hf, bf, Jf, rf, svf = ff.hessian(S, cal, frames)
+    assert np.array_equal(svo, svf) and list(svo) == [0, 1, 0, 0, 1] and Jo.shape == Jf.shape == (6 + 3, imu_dim(5))
+    assert np.allclose(Ho, Hf, rtol=1e-11, atol=1e-9) and np.allclose(bo, bf, rtol=1e-11, atol=1e-9)
+    assert np.allclose(Jo, Jf, rtol=1e-12, atol=1e-12) and np.allclose(ro, rf, rtol=1e-10, atol=1e-12)
+    assert np.allclose(Ho, Ho.T, atol=1e-9 * np.abs(Ho).max())
+    n = len(frames)
+    rng = np.random.default_rng(3)
+    d0, dI = 4 + 8 * n, imu_dim(n)
+    A = rng.normal(size=(d0, d0 + 4))
+    H_top = A @ A.T * 50 + np.eye(d0) * 200
+    B = rng.normal(size=(d0, 6))
+    H_sc = B @ B.T
+    b_top, b_sc, delta = rng.normal(size=d0) * 10, rng.normal(size=d0), rng.normal(size=d0) * 1e-3
+    Mq = rng.normal(size=(dI, 8))
+    HM, bM = Mq @ Mq.T + np.eye(dI) * 5, rng.normal(size=dI)
+    for a, b in zip(fo.expand(n, H_top, b_top), ff.expand(n, H_top, b_top)):
+        assert np.array_equal(a, b)
+    xo, so, sio = fo.solve(S, cal, frames, H_top, b_top, H_sc, b_sc, HM, bM, delta)
+    xf, sf, sif = ff.solve(S, cal, frames, H_top, b_top, H_sc, b_sc, HM, bM, delta)
+    sc = max(np.abs(xo).max(), np.abs(sio).max(), 1e-9)
+    assert np.abs(xo - xf).max() < 1e-8 * sc and abs(so - sf) < 1e-8 * max(abs(so), 1e-9) and np.abs(sio - sif).max() < 1e-8 * sc
+    assert (so == 0.0) == bool(scale_opt)
+    assert np.all(sio[~svo.astype(bool), 6:] == 0)            # no spline step for keyframes without a valid spline
+
+
+def test_expand_places_blocks():
+    n = 3
+    d0 = 4 + 8 * n
+    H = np.arange(d0 * d0, dtype=np.float64).reshape(d0, d0)
+    b = np.arange(d0, dtype=np.float64)
+    He, be = orc.imu().expand(n, H, b)
+    idx = np.array([k if k < 4 else 5 + 29 * ((k - 4) // 8) + (k - 4) % 8 for k in range(d0)])
+    assert np.array_equal(He[np.ix_(idx, idx)], H) and np.array_equal(be[idx], b)
+    rest = np.ones(imu_dim(n), bool)
+    rest[idx] = False
+    assert np.all(He[rest] == 0) and np.all(He[:, rest] == 0) and np.all(be[rest] == 0)
+
+
+def test_imu_jacobians_match_finite_differences():
+    """getImuHi: with unit weights JfTW = Jf^T is the derivative of the predicted IMU sample with respect to the keyframe's
+    bias / spline states (unscaled), Js with respect to the scale."""
+    S, cal, frames, keep = _scene(trapped=False)
+    S.weight_imu[:] = list(np.eye(6).reshape(-1))
+    f, tt = frames[1], -0.04
+    api = orc.imu()
+
+    def predict(state, scale):
+        """imu_pred of getImuHessianCurrentFrame (OB/EnergyFunctional.cpp:389-399), independent numpy restatement"""
+        k = np.repeat([SC["BA"], SC["BG"], SC["SL_ROT"], SC["SQ_TRANS"], SC["SQ_ROT"], SC["SC_TRANS"], SC["SC_ROT"]], 3)
+        s = state * k
+        Ric = np.array(S.rot_imu_cam).reshape(3, 3)
+        Rwc = np.array(f.camToWorld[:9]).reshape(3, 3).T
+        so3 = tt * s[6:9] + tt * tt * s[12:15] + tt ** 3 * s[18:21]
+        acc = 2 * s[9:12] + 6 * tt * s[15:18]
+        gyro = s[6:9] + 2 * tt * s[12:15] + 3 * tt * tt * s[18:21]
+        pa = Ric @ _rot(so3).T @ Rwc @ (scale * SC["SCALE"] * acc + np.array(S.gravity))
+        return np.concatenate([pa, Ric @ gyro]) + s[:6]
+
+    # evaluate the analytic Jacobian at evalPT == current rotation so that both describe the same point
+    f.evalPT_R[:] = list(f.camToWorld[:9])
+    JsTW, JfTW, Hss, Hff, Hfs = api.get_Hi(S, cal, f, tt)
+    st = np.array(f.state_imu[:])
+    base = predict(st, cal.scale)
+    for k in range(21):
+        e = np.zeros(21)
+        e[k] = 1e-7
+        num = (predict(st + e, cal.scale) - predict(st - e, cal.scale)) / 2e-7
+        assert np.allclose(JfTW[8 + k], num, rtol=2e-3, atol=2e-3 * np.abs(JfTW[8:]).max()), k
+    num_s = (predict(st, cal.scale + 1e-7) - predict(st, cal.scale - 1e-7)) / 2e-7
+    assert np.allclose(JsTW, num_s, rtol=1e-5, atol=1e-6 * np.abs(num_s).max())
+    assert np.allclose(Hff, JfTW @ JfTW.T) and np.allclose(Hfs, JfTW @ JsTW) and np.isclose(Hss, JsTW @ JsTW)
+    assert np.all(JfTW[:8] == 0)           # the pose columns stay out until the scale is trapped (FS/HessianBlocks.cpp:200-204)
+    assert np.isfinite(base).all()
+
+
+def test_solved_step_satisfies_the_spline_constraints():
+    S, cal, frames, keep = _scene(trapped=True, scale_opt=False)
+    n = len(frames)
+    api = orc.imu()
+    H, b, J, r, sv = api.hessian(S, cal, frames)
+    rng = np.random.default_rng(7)
+    d0, dI = 4 + 8 * n, imu_dim(n)
+    A = rng.normal(size=(d0, d0 + 4))
+    H_top, b_top = A @ A.T * 50 + np.eye(d0) * 200, rng.normal(size=d0) * 10
+    H_sc, b_sc = np.zeros((d0, d0)), np.zeros(d0)
+    HM, bM, delta = np.eye(dI) * 3.0, np.zeros(dI), np.zeros(d0)
+    x, s_step, s_imu = api.solve(S, cal, frames, H_top, b_top, H_sc, b_sc, HM, bM, delta)
+    full = np.zeros(dI)                  # the solution vector of the KKT system before its split into steps (:1150-1167)
+    full[:4] = x[:4]
+    full[4] = -s_step
+    for i in range(n):
+        full[5 + 29 * i:5 + 29 * i + 8] = x[4 + 8 * i:12 + 8 * i]
+        full[5 + 29 * i + 8:5 + 29 * (i + 1)] = -s_imu[i]
+    assert np.allclose(J @ full, r, rtol=1e-7, atol=1e-9 * max(np.abs(r).max(), 1.0))     # second block row of the KKT system
+    # and the first block row on the kept states: H x + J^T mu = b has a solution mu (least squares residual ~ 0)
+    keep_idx = np.array([k for k in range(dI) if k < 5 or (k - 5) % 29 < (29 if sv[(k - 5) // 29] else 14)])
+    He, be = api.expand(n, H_top, b_top)
+    Hfull = He + H + HM
+    Hfull[np.diag_indices(dI)] *= 1 + 1e-5
+    bfull = be + b + bM
+    res = bfull[keep_idx] - Hfull[np.ix_(keep_idx, keep_idx)] @ full[keep_idx]
+    mu, *_ = np.linalg.lstsq(J[:, keep_idx].T, res, rcond=None)
+    assert np.abs(J[:, keep_idx].T @ mu - res).max() < 1e-6 * max(np.abs(res).max(), 1.0)
