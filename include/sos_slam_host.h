@@ -208,6 +208,15 @@ int sosf_imu_solve(const sosf_imu_settings *S, const sosf_imu_calib *C, int n, c
                    const double *b_top, const double *H_sc, const double *b_sc, const double *HM, const double *bM,
                    const double *delta, double lambda, double *x, double *scale_step, double *step_imu);
 
+/* EnergyFunctional::marginalizeFrame with IMU enabled (OB/EnergyFunctional.cpp:730-889): the IMU factors linking keyframe
+ * idx to its neighbours are folded into the prior (getImuHessianCurrentFrame of idx + 1 and, if idx > 0, of idx, linearised
+ * at delta: HM += margWeightFac * HM_change, bM += margWeightFac * (bM_change - HM_change * delta2)), the keyframe's 29
+ * states are moved to the end, its pose prior added, the 15 spline states dropped when no valid spline constrains them,
+ * and the block is eliminated by a Jacobi-scaled Schur complement.  HM / bM: SOSF_IMU_DIM(n) in, SOSF_IMU_DIM(n - 1) out
+ * (written to HM_out / bM_out); delta = getStitchedDeltaF() (4 + 8 n); prior8 / delta_prior8 = fh->prior, fh->delta_prior. */
+int sosf_imu_marginalize_frame(const sosf_imu_settings *S, const sosf_imu_calib *C, int n, const sosf_imu_frame *frames, int idx,
+                               const double *delta, const double *prior8, const double *delta_prior8, double margWeightFac,
+                               const double *HM, const double *bM, double *HM_out, double *bM_out);
 /* Switches the facade's solveSystemF to the IMU branch (S != NULL) or back (S == NULL).  The records are caller-owned and
  * must outlive the system's iterations: frames[i] belongs to keyframe idx i (its camToWorld / evalPT_R are refreshed by
  * the facade before every solve; state_imu and calib->scale are stepped after it, as doStepFromBackup does with unit

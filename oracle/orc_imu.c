@@ -431,3 +431,122 @@ int orc_imu_solve(const sosf_imu_settings *S, const sosf_imu_calib *C, int n, co
   free(A); free(rhs); free(sol); free(sI);
   return 0;
 }
+
+/* general n x n inverse by Gauss-Jordan elimination with partial pivoting (stand-in for Eigen's MatrixXd::inverse) */
+static void dense_inverse(double *A, int n) {
+  double *M = (double *)malloc(sizeof(double) * (size_t)n * 2 * n);
+  for (int r = 0; r < n; r++)
+    for (int c = 0; c < 2 * n; c++) M[(size_t)r * 2 * n + c] = c < n ? A[(size_t)r * n + c] : (c - n == r ? 1.0 : 0.0);
+  for (int k = 0; k < n; k++) {
+    int p = k;
+    for (int r = k + 1; r < n; r++)
+      if (fabs(M[(size_t)r * 2 * n + k]) > fabs(M[(size_t)p * 2 * n + k])) p = r;
+    if (p != k)
+      for (int c = 0; c < 2 * n; c++) { double t = M[(size_t)k * 2 * n + c]; M[(size_t)k * 2 * n + c] = M[(size_t)p * 2 * n + c]; M[(size_t)p * 2 * n + c] = t; }
+    double d = M[(size_t)k * 2 * n + k];
+    for (int c = 0; c < 2 * n; c++) M[(size_t)k * 2 * n + c] /= d;
+    for (int r = 0; r < n; r++) {
+      if (r == k) continue;
+      double f = M[(size_t)r * 2 * n + k];
+      if (f == 0) continue;
+      for (int c = 0; c < 2 * n; c++) M[(size_t)r * 2 * n + c] -= f * M[(size_t)k * 2 * n + c];
+    }
+  }
+  for (int r = 0; r < n; r++)
+    for (int c = 0; c < n; c++) A[(size_t)r * n + c] = M[(size_t)r * 2 * n + n + c];
+  free(M);
+}
+
+/* marginalizeFrame with IMU enabled, OB/EnergyFunctional.cpp:730-889 */
+int orc_imu_marginalize_frame(const sosf_imu_settings *S, const sosf_imu_calib *C, int n, const sosf_imu_frame *F, int idx,
+                              const double *delta, const double *prior8, const double *delta_prior8, double margWeightFac,
+                              const double *HM_in, const double *bM_in, double *HM_out, double *bM_out) {
+  const int dim = SOSF_IMU_DIM(n);
+  double *HM = (double *)malloc(sizeof(double) * (size_t)dim * dim), *bM = (double *)malloc(sizeof(double) * dim);
+  memcpy(HM, HM_in, sizeof(double) * (size_t)dim * dim);
+  memcpy(bM, bM_in, sizeof(double) * dim);
+  /* :748-785 */
+  double *Hc = (double *)calloc((size_t)dim * dim, sizeof(double)), *bc = (double *)calloc(dim, sizeof(double)), *d2 = (double *)calloc(dim, sizeof(double));
+  double *Jc = (double *)malloc(sizeof(double) * 6 * (size_t)dim), rc[6];
+  int32_t *sv = (int32_t *)calloc(n, sizeof(int32_t));
+  for (int i = 0; i < CP; i++) d2[i] = delta[i];
+  if (C->scale_trapped) d2[CP] = C->scale - C->scale_zero;
+  imu_hessian_frame(S, C, n, F, idx + 1, Hc, bc, Jc, rc, sv);
+  for (int k = 0; k < 8; k++) d2[CP + 1 + 29 * (idx + 1) + k] = delta[CP + 8 * (idx + 1) + k];
+  if (C->scale_trapped)
+    for (int k = 0; k < 21; k++) d2[CP + 1 + 29 * (idx + 1) + 8 + k] = F[idx + 1].state_imu[k] - F[idx + 1].state_imu_zero[k];
+  int spline_valid_idx = 0;
+  if (idx > 0) {
+    imu_hessian_frame(S, C, n, F, idx, Hc, bc, Jc, rc, sv);
+    spline_valid_idx = sv[idx];
+    for (int k = 0; k < 8; k++) d2[CP + 1 + 29 * (idx - 1) + k] = delta[CP + 8 * (idx - 1) + k];
+    if (C->scale_trapped)
+      for (int k = 0; k < 21; k++) d2[CP + 1 + 29 * (idx - 1) + 8 + k] = F[idx - 1].state_imu[k] - F[idx - 1].state_imu_zero[k];
+  }
+  for (int r = 0; r < dim; r++) {
+    double a = 0;
+    for (int c = 0; c < dim; c++) a += Hc[(size_t)r * dim + c] * d2[c];
+    bc[r] -= a;
+  }
+  for (size_t k = 0; k < (size_t)dim * dim; k++) HM[k] += margWeightFac * Hc[k];
+  for (int k = 0; k < dim; k++) bM[k] += margWeightFac * bc[k];
+  /* move the keyframe's block to the end, :787-809 */
+  const int args = CP + 1;
+  int step = 29;
+  int odim = args + n * step, ndim = odim - step;
+  const int io = args + idx * step, ntail = step * (n - idx - 1);
+  int *perm = (int *)malloc(sizeof(int) * odim);
+  for (int k = 0; k < odim; k++) perm[k] = k < io ? k : (k < io + ntail ? k + step : k - ntail); /* new position k holds old perm[k] */
+  double *H2 = (double *)malloc(sizeof(double) * (size_t)odim * odim), *b2 = (double *)malloc(sizeof(double) * odim);
+  for (int r = 0; r < odim; r++) {
+    b2[r] = bM[perm[r]];
+    for (int c = 0; c < odim; c++) H2[(size_t)r * odim + c] = HM[(size_t)perm[r] * odim + perm[c]];
+  }
+  for (int k = 0; k < 8; k++) { /* :812-813 */
+    H2[(size_t)(io + ntail + k) * odim + io + ntail + k] += prior8[k];
+    b2[io + ntail + k] += prior8[k] * delta_prior8[k];
+  }
+  /* discard the spline part when nothing constrains it, :818-822 */
+  int cur = odim;
+  if (!((idx > 0) && spline_valid_idx)) { cur = odim - 15; step = 14; }
+  double *Hs = (double *)malloc(sizeof(double) * (size_t)cur * cur), *bs = (double *)malloc(sizeof(double) * cur), *sv_ = (double *)malloc(sizeof(double) * cur);
+  for (int r = 0; r < cur; r++) {
+    sv_[r] = sqrt(fabs(H2[(size_t)r * odim + r]) + 10);
+    bs[r] = b2[r];
+  }
+  for (int r = 0; r < cur; r++) {
+    for (int c = 0; c < cur; c++) Hs[(size_t)r * cur + c] = (1.0 / sv_[r]) * H2[(size_t)r * odim + c] * (1.0 / sv_[c]);
+    bs[r] = (1.0 / sv_[r]) * bs[r];
+  }
+  /* invert the bottom block, :837-841 (the two 0.5f * (hpi + hpi) lines are identities) */
+  double *hpi = (double *)malloc(sizeof(double) * (size_t)step * step);
+  for (int r = 0; r < step; r++)
+    for (int c = 0; c < step; c++) hpi[(size_t)r * step + c] = Hs[(size_t)(ndim + r) * cur + ndim + c];
+  dense_inverse(hpi, step);
+  /* Schur complement, :844-848 */
+  double *bli = (double *)malloc(sizeof(double) * (size_t)ndim * step);
+  for (int r = 0; r < ndim; r++)
+    for (int c = 0; c < step; c++) {
+      double a = 0;
+      for (int k = 0; k < step; k++) a += Hs[(size_t)(ndim + k) * cur + r] * hpi[(size_t)k * step + c];
+      bli[(size_t)r * step + c] = a;
+    }
+  for (int r = 0; r < ndim; r++) {
+    for (int c = 0; c < ndim; c++) {
+      double a = 0;
+      for (int k = 0; k < step; k++) a += bli[(size_t)r * step + k] * Hs[(size_t)(ndim + k) * cur + c];
+      Hs[(size_t)r * cur + c] -= a;
+    }
+    double a = 0;
+    for (int k = 0; k < step; k++) a += bli[(size_t)r * step + k] * bs[ndim + k];
+    bs[r] -= a;
+  }
+  /* unscale and symmetrise, :851-857 */
+  for (int r = 0; r < ndim; r++) {
+    for (int c = 0; c < ndim; c++)
+      HM_out[(size_t)r * ndim + c] = 0.5 * (sv_[r] * Hs[(size_t)r * cur + c] * sv_[c] + sv_[c] * Hs[(size_t)c * cur + r] * sv_[r]);
+    bM_out[r] = sv_[r] * bs[r];
+  }
+  free(HM); free(bM); free(Hc); free(bc); free(d2); free(Jc); free(sv); free(perm); free(H2); free(b2); free(Hs); free(bs); free(sv_); free(hpi); free(bli);
+  return 0;
+}

@@ -450,3 +450,118 @@ extern "C" int sosf_imu_solve(const sosf_imu_settings *S, const sosf_imu_calib *
   }
   return SOS_OK;
 }
+
+namespace {
+// inverse of a small dense matrix: LU with partial pivoting, then the columns of the identity
+std::vector<double> inverse(std::vector<double> A, int n) {
+  std::vector<int> piv(n);
+  for (int k = 0; k < n; k++) {
+    int p = k;
+    for (int r = k + 1; r < n; r++)
+      if (std::fabs(A[(size_t)r * n + k]) > std::fabs(A[(size_t)p * n + k])) p = r;
+    piv[k] = p;
+    if (p != k)
+      for (int c = 0; c < n; c++) std::swap(A[(size_t)k * n + c], A[(size_t)p * n + c]);
+    const double d = A[(size_t)k * n + k];
+    for (int r = k + 1; r < n; r++) {
+      const double f = A[(size_t)r * n + k] / d;
+      A[(size_t)r * n + k] = f;
+      for (int c = k + 1; c < n; c++) A[(size_t)r * n + c] -= f * A[(size_t)k * n + c];
+    }
+  }
+  std::vector<double> X((size_t)n * n, 0.0), col(n);
+  for (int j = 0; j < n; j++) {
+    for (int r = 0; r < n; r++) col[r] = r == j ? 1.0 : 0.0;
+    for (int k = 0; k < n; k++) std::swap(col[k], col[piv[k]]);
+    for (int r = 1; r < n; r++)
+      for (int c = 0; c < r; c++) col[r] -= A[(size_t)r * n + c] * col[c];
+    for (int r = n - 1; r >= 0; r--) {
+      for (int c = r + 1; c < n; c++) col[r] -= A[(size_t)r * n + c] * col[c];
+      col[r] /= A[(size_t)r * n + r];
+    }
+    for (int r = 0; r < n; r++) X[(size_t)r * n + j] = col[r];
+  }
+  return X;
+}
+}  // namespace
+
+extern "C" int sosf_imu_marginalize_frame(const sosf_imu_settings *S, const sosf_imu_calib *C, int n, const sosf_imu_frame *F, int idx,
+                                          const double *delta, const double *prior8, const double *delta_prior8, double margWeightFac,
+                                          const double *HM_in, const double *bM_in, double *HM_out, double *bM_out) {
+  if (!S || !C || !F || n < 2 || idx < 0 || idx >= n - 1 || !delta || !prior8 || !delta_prior8 || !HM_in || !bM_in || !HM_out || !bM_out)
+    return SOS_ERR_ARG;
+  const int dim = SOSF_IMU_DIM(n);
+  // the IMU factors that tie the keyframe to its neighbours, linearised at the current delta, go into the prior
+  Assembly A(dim, n);
+  add_frame(*S, *C, n, F, idx + 1, A);
+  if (idx > 0) add_frame(*S, *C, n, F, idx, A);
+  std::vector<double> d2(dim, 0.0);
+  for (int i = 0; i < CP; i++) d2[i] = delta[i];
+  if (C->scale_trapped) d2[CP] = C->scale - C->scale_zero;
+  for (int nb : {idx + 1, idx - 1}) {
+    if (nb < 0) continue;
+    for (int k = 0; k < 8; k++) d2[CP + 1 + 29 * nb + k] = delta[CP + 8 * nb + k];
+    if (C->scale_trapped)
+      for (int k = 0; k < 21; k++) d2[CP + 1 + 29 * nb + 8 + k] = F[nb].state_imu[k] - F[nb].state_imu_zero[k];
+  }
+  Dense HM(dim, dim);
+  std::vector<double> bM(dim);
+  for (int r = 0; r < dim; r++) {
+    double hd = 0;
+    for (int c = 0; c < dim; c++) {
+      hd += A.H(r, c) * d2[c];
+      HM(r, c) = HM_in[(size_t)r * dim + c] + margWeightFac * A.H(r, c);
+    }
+    bM[r] = bM_in[r] + margWeightFac * (A.b[r] - hd);
+  }
+  // order of the states with the keyframe's block last; without a valid spline its 15 spline states are not eliminated
+  // but simply dropped
+  const int args = CP + 1, io = args + 29 * idx, ndim = dim - 29;
+  const bool constrained = idx > 0 && A.spline_valid[idx];
+  const int step = constrained ? 29 : 14, cur = ndim + step;
+  std::vector<int> ord;
+  for (int k = 0; k < dim; k++)
+    if (k < io || k >= io + 29) ord.push_back(k);
+  for (int k = 0; k < step; k++) ord.push_back(io + k);
+  std::vector<double> Hs((size_t)cur * cur), bs(cur), sc(cur);
+  for (int r = 0; r < cur; r++) {
+    for (int c = 0; c < cur; c++) Hs[(size_t)r * cur + c] = HM(ord[r], ord[c]);
+    bs[r] = bM[ord[r]];
+  }
+  for (int k = 0; k < 8; k++) {  // the keyframe's pose prior joins here (marginalizeFrame :812-813)
+    Hs[(size_t)(ndim + k) * cur + ndim + k] += prior8[k];
+    bs[ndim + k] += prior8[k] * delta_prior8[k];
+  }
+  for (int r = 0; r < cur; r++) sc[r] = std::sqrt(std::fabs(Hs[(size_t)r * cur + r]) + 10);
+  for (int r = 0; r < cur; r++) {
+    for (int c = 0; c < cur; c++) Hs[(size_t)r * cur + c] = (1.0 / sc[r]) * Hs[(size_t)r * cur + c] * (1.0 / sc[c]);
+    bs[r] = (1.0 / sc[r]) * bs[r];
+  }
+  std::vector<double> blk((size_t)step * step);
+  for (int r = 0; r < step; r++)
+    for (int c = 0; c < step; c++) blk[(size_t)r * step + c] = Hs[(size_t)(ndim + r) * cur + ndim + c];
+  const std::vector<double> hpi = inverse(blk, step);
+  std::vector<double> bli((size_t)ndim * step);
+  for (int r = 0; r < ndim; r++)
+    for (int c = 0; c < step; c++) {
+      double s = 0;
+      for (int k = 0; k < step; k++) s += Hs[(size_t)(ndim + k) * cur + r] * hpi[(size_t)k * step + c];
+      bli[(size_t)r * step + c] = s;
+    }
+  for (int r = 0; r < ndim; r++) {
+    for (int c = 0; c < ndim; c++) {
+      double s = 0;
+      for (int k = 0; k < step; k++) s += bli[(size_t)r * step + k] * Hs[(size_t)(ndim + k) * cur + c];
+      Hs[(size_t)r * cur + c] -= s;
+    }
+    double s = 0;
+    for (int k = 0; k < step; k++) s += bli[(size_t)r * step + k] * bs[ndim + k];
+    bs[r] -= s;
+  }
+  for (int r = 0; r < ndim; r++) {
+    for (int c = 0; c < ndim; c++)
+      HM_out[(size_t)r * ndim + c] = 0.5 * (sc[r] * Hs[(size_t)r * cur + c] * sc[c] + sc[c] * Hs[(size_t)c * cur + r] * sc[r]);
+    bM_out[r] = sc[r] * bs[r];
+  }
+  return SOS_OK;
+}

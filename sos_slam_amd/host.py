@@ -385,6 +385,7 @@ class _ImuApi:
         getattr(L, prefix + "get_Hi").argtypes = [vp, vp, vp, C.c_double, vp, vp, vp, vp, vp]
         getattr(L, prefix + "hessian").argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
         getattr(L, prefix + "expand").argtypes = [C.c_int, vp, vp, vp, vp]
+        getattr(L, prefix + "marginalize_frame").argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_double, vp, vp, vp, vp]
         getattr(L, prefix + "solve").argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_double, vp, vp, vp]
 
     @staticmethod
@@ -418,6 +419,17 @@ class _ImuApi:
         b = np.ascontiguousarray(b, dtype=np.float64)
         getattr(self.L, self.p + "expand")(n, _p(H), _p(b), _p(He), _p(be))
         return He, be
+
+    def marginalize_frame(self, S, Cal, frames, idx, delta, prior8, delta_prior8, HM, bM, marg_weight=0.25):
+        from sos_slam_amd.records import imu_dim
+        n = len(frames)
+        nd = imu_dim(n - 1)
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (delta, prior8, delta_prior8, HM, bM)]
+        Ho, bo = np.zeros((nd, nd)), np.zeros(nd)
+        arr = self._frames(frames)
+        getattr(self.L, self.p + "marginalize_frame")(C.byref(S), C.byref(Cal), n, arr, idx, _p(a[0]), _p(a[1]), _p(a[2]), marg_weight,
+                                                      _p(a[3]), _p(a[4]), _p(Ho), _p(bo))
+        return Ho, bo
 
     def solve(self, S, Cal, frames, H_top, b_top, H_sc, b_sc, HM, bM, delta, lam=1e-5):
         n = len(frames)

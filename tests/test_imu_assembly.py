@@ -166,3 +166,60 @@ def test_solved_step_satisfies_the_spline_constraints():
     res = bfull[keep_idx] - Hfull[np.ix_(keep_idx, keep_idx)] @ full[keep_idx]
     mu, *_ = np.linalg.lstsq(J[:, keep_idx].T, res, rcond=None)
     assert np.abs(J[:, keep_idx].T @ mu - res).max() < 1e-6 * max(np.abs(res).max(), 1.0)
+
+
+def _marg_inputs(n, seed=5):
+    rng = np.random.default_rng(seed)
+    dI = imu_dim(n)
+    Mq = rng.normal(size=(dI, dI + 3))
+    HM, bM = Mq @ Mq.T * 3 + np.eye(dI) * 40, rng.normal(size=dI) * 5
+    delta = rng.normal(size=4 + 8 * n) * 1e-3
+    prior8 = rng.uniform(1, 50, 8)
+    dprior8 = rng.normal(size=8) * 1e-2
+    return HM, bM, delta, prior8, dprior8
+
+
+def _schur_known_answer(n, idx, step, HM, bM, prior8, dprior8):
+    """marginalizeFrame's algebra in numpy: move the keyframe's block last, add its pose prior, drop what is not
+    eliminated, eliminate the rest (OB/EnergyFunctional.cpp:790-880; the Jacobi scaling cancels analytically)."""
+    dI, io = imu_dim(n), 5 + 29 * idx
+    keep = [k for k in range(dI) if not io <= k < io + 29]
+    order = keep + list(range(io, io + step))
+    H, b = HM[np.ix_(order, order)].copy(), bM[order].copy()
+    nk = len(keep)
+    H[nk:nk + 8, nk:nk + 8] += np.diag(prior8)
+    b[nk:nk + 8] += prior8 * dprior8
+    K = H[:nk, nk:] @ np.linalg.inv(H[nk:, nk:])
+    return H[:nk, :nk] - K @ H[nk:, :nk], b[:nk] - K @ b[nk:]
+
+
+@pytest.mark.parametrize("idx,step", [(1, 29), (0, 14), (3, 14)])
+def test_marginalize_frame_is_the_schur_complement(idx, step):
+    """IMU columns of EnergyFunctional::marginalizeFrame.  With margWeightFac = 0 the keyframe's IMU factors add
+    nothing and the result is a plain Schur complement; a keyframe whose spline is not constrained (first keyframe,
+    or a gap longer than maxImuInterval) has its 15 spline states dropped, not eliminated."""
+    from sos_slam_amd import host
+    S, cal, frames, keep = _scene()
+    n = len(frames)
+    HM, bM, delta, prior8, dprior8 = _marg_inputs(n)
+    He, be = _schur_known_answer(n, idx, step, HM, bM, prior8, dprior8)
+    for api in (orc.imu(), host.imu()):
+        Ho, bo = api.marginalize_frame(S, cal, frames, idx, delta, prior8, dprior8, HM, bM, marg_weight=0.0)
+        assert Ho.shape == (imu_dim(n - 1),) * 2
+        assert np.array_equal(Ho, Ho.T)
+        assert np.abs(Ho - He).max() < 1e-9 * np.abs(He).max() and np.abs(bo - be).max() < 1e-9 * np.abs(be).max()
+
+
+@pytest.mark.parametrize("trapped", [True, False])
+@pytest.mark.parametrize("idx", [0, 1, 2, 3])
+def test_marginalize_frame_facade_equals_oracle(idx, trapped):
+    from sos_slam_amd import host
+    S, cal, frames, keep = _scene(trapped=trapped)
+    n = len(frames)
+    HM, bM, delta, prior8, dprior8 = _marg_inputs(n, seed=7 + idx)
+    Ho, bo = orc.imu().marginalize_frame(S, cal, frames, idx, delta, prior8, dprior8, HM, bM)
+    Hf, bf = host.imu().marginalize_frame(S, cal, frames, idx, delta, prior8, dprior8, HM, bM)
+    assert np.abs(Ho - Hf).max() < 1e-9 * np.abs(Ho).max() and np.abs(bo - bf).max() < 1e-9 * np.abs(bo).max()
+    # the keyframe's IMU factors did enter: the result differs from the factor-free Schur complement
+    H0, b0 = orc.imu().marginalize_frame(S, cal, frames, idx, delta, prior8, dprior8, HM, bM, marg_weight=0.0)
+    assert np.abs(Ho - H0).max() > 1e-6 * np.abs(H0).max()
