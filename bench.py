@@ -102,12 +102,28 @@ def main():
     win = synth.make_window(args.window, point_seed=synth.SEED + 1000 * rank if world > 1 else None)
     sysm = host.System.from_window(win, device=local_rank)
     comm = None
+    exchange = "enqueued by the library on its stream"
     if dist is not None:
         if os.environ.get("SOS_BENCH_HOOKS") == "1":  # callback-based exchange through torch.distributed (slower)
             sdist.attach(sysm, dist, torch)
+            exchange = "rccl via torch.distributed hooks"
         else:  # RCCL collectives enqueued by the library itself on its stream
-            comm = sdist.NativeComm(dist, torch, local_rank)
-            comm.attach(sysm)
+            err = None
+            try:
+                comm = sdist.NativeComm(dist, torch, local_rank)
+                comm.attach(sysm)
+            except Exception as e:  # noqa: BLE001 -- every rank has to take the same exchange path
+                err, comm = e, None
+            ok = torch.tensor([0 if err else 1], dtype=torch.int32, device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:  # some rank could not set up the library's communicator: exchange through torch.distributed
+                if rank == 0:
+                    print(f"[bench] library-owned RCCL communicator unavailable ({err}); using the torch.distributed hooks", file=sys.stderr)
+                if comm is not None:
+                    comm.close()
+                    comm = None
+                sdist.attach(sysm, dist, torch)
+                exchange = "rccl via torch.distributed hooks"
     sysm.prepare()
     sysm.set_pipeline(True)  # the loop below never stops on `canbreak`: every step may prefetch the next accumulate
     R_local = win.R
@@ -176,7 +192,7 @@ def main():
                        "parallelism": ("single GPU" if dist is None else
                                        f"{world} ranks, points sharded, frames replicated; one RCCL all-reduce of the "
                                        "packed fp32 accumulator + one all-gather of newest-frame energies per "
-                                       "iteration, enqueued by the library on its stream")},
+                                       "iteration, " + exchange)},
             "gn_iter_per_s": args.steps / dt,
             "linearize_point_residuals_per_s": R_local / (lin_ms * 1e-3),
             "kernels_us": dict(linearize_us=round(lin_ms * 1e3, 2), **kern),

@@ -68,14 +68,15 @@ class NativeComm:
         self.L = _lib.load()
         path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")  # the copy torch already loaded
         rc = self.L.sos_rccl_load(path.encode() if os.path.exists(path) else None)
-        if rc != 0:
-            raise RuntimeError(f"sos_rccl_load failed: {rc}")
         rank, world = dist.get_rank(), dist.get_world_size()
         idbuf = (C.c_ubyte * 128)()
-        if rank == 0:
+        if rank == 0 and rc == 0:
             rc = self.L.sos_rccl_unique_id(idbuf)
-            if rc != 0:
-                raise RuntimeError(f"sos_rccl_unique_id failed: {rc}")
+        # the ranks must leave this constructor the same way: agree on the local status before anybody raises
+        st = torch.tensor([rc != 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(st, op=dist.ReduceOp.MAX)
+        if int(st.item()) != 0:
+            raise RuntimeError(f"RCCL not usable by the library on some rank (local status {rc})")
         t = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8, device="cuda")
         dist.broadcast(t, src=0)
         raw = bytes(t.cpu().tolist())
