@@ -152,7 +152,7 @@ typedef struct sos_comm sos_comm;        /* RCCL communicator of the multi-GPU p
  * context and frame store
  * ---------------------------------------------------------------------------------------------- */
 
-/* Create a context on HIP device `device`.  `hip_stream` is a hipStream_t supplied by the caller or
+/* (handle lifetime: no reference counterpart)  Create a context on HIP device `device`.  `hip_stream` is a hipStream_t supplied by the caller or
  * NULL (the context then creates and owns one).  Must fail (SOS_ERR_HIP) when no GPU is present. */
 int sos_ctx_create(int device, void *hip_stream, int w, int h, sos_ctx **out);
 int sos_ctx_destroy(sos_ctx *ctx);
@@ -259,7 +259,7 @@ int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const sos_calib 
                    const float *adHTdeltaF, const float *cDeltaF, const float *frameEnergyTH, int applyRes,
                    double *energySum, float *newestEnergies, int *newestCount, float *pointStep);
 
-/* The back-substitution half of sos_ba_gn_step, enqueued ahead: it needs x alone, so the caller issues it right after the
+/* The back-substitution half of sos_ba_gn_step (resubstituteF_MT / resubstituteFPt, OB/EnergyFunctional.cpp:496-551), enqueued ahead: it needs x alone, so the caller issues it right after the
  * solve and computes the new poses / precalc records while it runs; the following sos_ba_gn_step must then be given
  * x = NULL.  SOS_ERR_STATE when the window cannot take this path (no points / no fp32 adjoints yet): pass x to
  * sos_ba_gn_step as before. */
@@ -320,7 +320,8 @@ int sos_ba_accumulate_marg(sos_ba *ba, const int32_t *pointIdx, int count, doubl
  * OB/EnergyFunctional.cpp:901): overwrite priorF of `count` points of the snapshot. */
 int sos_ba_update_point_priors(sos_ba *ba, const int32_t *pointIdx, const float *priorF, int count);
 
-/* inspection helpers used by the parity tests */
+/* inspection helpers used by the parity tests (no reference counterpart: the reference reads these members directly --
+ * EFResidual::J / JpJdF / res_toZeroF, OB/EnergyFunctionalStructs.h:70-73; PointFrameResidual::state_state, FS/Residuals.h:57) */
 int sos_ba_get_jacobian(sos_ba *ba, int residIdx, int which /*0 = EFResidual::J, 1 = scratch*/,
                         sos_rawjac *out);
 int sos_ba_get_residual_flags(sos_ba *ba, uint32_t *flags /*R*/, int32_t *state_state /*R*/,
@@ -359,7 +360,8 @@ int sos_tracker_set_points3d(sos_tracker *trk, const sos_calib *calib, int n, co
 
 /* ScaleOptimizer::scaleCoarseDepthL0 (FS/CoarseTracker.cpp:244-251) */
 int sos_tracker_scale_depth(sos_tracker *trk, float scale);
-/* read back one level of the template point cloud (pc_u, pc_v, pc_idepth, pc_color) */
+/* read back one level of the template point cloud (pc_u, pc_v, pc_idepth, pc_color) that makeCoarseDepthL0 builds
+ * (FS/CoarseTracker.cpp:200-229, the normalisation loop); inspection helper of the parity tests */
 int sos_tracker_get_pc(sos_tracker *trk, int lvl, float *pc_u, float *pc_v, float *pc_idepth,
                        float *pc_color);
 
@@ -476,7 +478,8 @@ typedef struct sos_activation {
   int32_t pad;
 } sos_activation;
 
-/* optimizeImmaturePoint for `count` candidates.  nFrames keyframes, frame idx f has its images in slot
+/* FullSystem::optimizeImmaturePoint (FS/FullSystemOptPoint.cpp:47-192; called from activatePointsMT_Reductor,
+ * FS/FullSystem.cpp:311-325) for `count` candidates.  nFrames keyframes, frame idx f has its images in slot
  * frameSlot[f]; pairs[host + nFrames * target]; hostOfPoint[i] = frame idx of the host of pts[i].  pts is read only
  * (u, v, color, weights, energyTH, idepth_min, idepth_max). */
 int sos_immature_activate(sos_ctx *ctx, const sos_activate_params *prm, const sos_calib *calib, int nFrames,
@@ -498,12 +501,12 @@ typedef struct sos_pixsel sos_pixsel;
  * caller */
 int sos_pixsel_create(sos_ctx *ctx, const sos_pixsel_params *prm, const uint8_t *randomPattern, sos_pixsel **out);
 int sos_pixsel_destroy(sos_pixsel *ps);
-/* makeHists of the frame in `slot` (pyramid made by sos_make_pyramid); ths / thsSmoothed: (w/32)*(h/32) floats, optional */
+/* PixelSelector::makeHists (FS/PixelSelector2.cpp:69-155) of the frame in `slot` (pyramid made by sos_make_pyramid); ths / thsSmoothed: (w/32)*(h/32) floats, optional */
 int sos_pixsel_make_hists(sos_pixsel *ps, int slot, float *ths, float *thsSmoothed);
-/* select(fh, map_out, pot, thFactor) after make_hists of the same slot; map_out: w*h floats (0, 1, 2, 4), optional;
+/* PixelSelector::select (FS/PixelSelector2.cpp:292-424): select(fh, map_out, pot, thFactor) after make_hists of the same slot; map_out: w*h floats (0, 1, 2, 4), optional;
  * n: counts of level-0 / 1 / 2 selections */
 int sos_pixsel_select(sos_pixsel *ps, int slot, int pot, float thFactor, float *map_out, int32_t n[3]);
-/* makeMaps(fh, map_out, density, recursionsLeft, false, thFactor): runs make_hists when the slot changed, select, the
+/* PixelSelector::makeMaps (FS/PixelSelector2.cpp:157-290): makeMaps(fh, map_out, density, recursionsLeft, false, thFactor): runs make_hists when the slot changed, select, the
  * re-selection recursion and the sub-sampling; *currentPotential in / out; *numSelected = the return value (numHaveSub).
  * map_out optional. */
 int sos_pixsel_make_maps(sos_pixsel *ps, int slot, float density, int recursionsLeft, float thFactor, int32_t *currentPotential,
@@ -534,7 +537,7 @@ typedef struct sos_camera_model {
   float outCal[5];          /* line 3 when SOS_RECT_GIVEN (relative fx fy cx cy, 0) */
   int32_t pad;
 } sos_camera_model;
-/* parses the text of a camera file; returns SOS_ERR_ARG on the formats the reference rejects ("full" is not
+/* Undistort::getUndistorterForFile + readFromFile (U/Undistort.cpp:240-351, 679-890) on the text of a camera file; returns SOS_ERR_ARG on the formats the reference rejects ("full" is not
  * implemented there either) */
 int sos_camera_parse(const char *text, sos_camera_model *out);
 
@@ -546,9 +549,11 @@ typedef struct sos_undistort sos_undistort;
 int sos_undistort_create(sos_ctx *ctx, const sos_camera_model *cam, const float *G, int GDepth, const float *vignette,
                          int photometricMode, sos_undistort **out);
 int sos_undistort_destroy(sos_undistort *u);
-/* K = rectified fx fy cx cy; remapX / remapY: w*h floats, optional */
+/* Undistort::getK / the remap table built by readFromFile (U/Undistort.cpp:557-672 makeOptimalK_crop, :836-890):
+ * K = rectified fx fy cx cy; remapX / remapY: w*h floats, optional */
 int sos_undistort_get(sos_undistort *u, float K[4], float *remapX, float *remapY, int32_t *passthrough);
-/* Undistort::undistort<T>(image_raw, exposure, timestamp, factor) followed by FrameHessian::makeImages into `slot`
+/* Undistort::undistort<T>(image_raw, exposure, timestamp, factor) (U/Undistort.cpp:361-458, photometric part
+ * processFrame :194-227) followed by FrameHessian::makeImages into `slot`
  * (bytesPerPixel 1 or 2); image_out (optional, w*h floats) receives the undistorted irradiance image. */
 int sos_undistort_frame(sos_undistort *u, const void *raw, int bytesPerPixel, float exposure, float factor, int slot,
                         const float *gammaBgrad, float *image_out);

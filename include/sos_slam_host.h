@@ -34,6 +34,8 @@ typedef struct sosf_frame_init {
   int32_t pad;
 } sosf_frame_init;
 
+/* new FullSystem (constructor / destructor FS/FullSystem.cpp:58-96, 98-110: EnergyFunctional, CalibHessian, empty window)
+ * on HIP device `device`; fails with SOS_ERR_HIP when there is no GPU */
 int sosf_create(const sos_params *params, int device, void *hip_stream, sosf_system **out);
 int sosf_destroy(sosf_system *sys);
 /* CalibHessian(): setValueScaled(fx,fy,cx,cy); value_zero = value (FS/HessianBlocks.h:453-475) */
@@ -45,11 +47,11 @@ int sosf_add_points(sosf_system *sys, int count, const sos_point *pts);
 /* new PointFrameResidual + ef->insertResidual (FS/FullSystem.cpp:825-828); res[i].point indexes the
  * points in the order they were added (global running index) */
 int sosf_add_residuals(sosf_system *sys, int count, const sos_resid *res);
-/* marginalisation prior HM (dim x dim row-major), bM; dim = 4 + 8 * nFrames */
+/* marginalisation prior EnergyFunctional::HM / bM (OB/EnergyFunctional.h:137-138; dim x dim row-major, dim = 4 + 8 * nFrames) */
 int sosf_set_prior(sosf_system *sys, const double *HM, const double *bM);
 int sosf_get_prior(sosf_system *sys, double *HM, double *bM);
 
-/* FullSystem::optimize(mnumOptIts): returns the RMSE through *rmse */
+/* FullSystem::optimize(mnumOptIts) (FS/FullSystemOptimize.cpp:305-489): returns the RMSE through *rmse */
 int sosf_optimize(sosf_system *sys, int mnumOptIts, float *rmse, int *iterations);
 /* bench support: pack + resetOOB + linearizeAll(false) + applyRes, then single loop bodies
  * (FS/FullSystemOptimize.cpp:358-413) */
@@ -80,7 +82,7 @@ int sosf_get_stats(sosf_system *sys, int *resInA, int *resInL, int *resInM);
  * index under which they were added) are re-linearized, fixed (fixLinearizationF) and marginalised into
  * HM / bM, or dropped when their idepth_hessian is below setting_minIdepthH_marg. */
 int sosf_marginalize_points(sosf_system *sys, const int32_t *pointIdx, int count);
-/* ef->dropPointsF for an explicit list (PS_DROP) */
+/* ef->dropPointsF (OB/EnergyFunctional.cpp:938-952) for an explicit list (PS_DROP) */
 int sosf_drop_points(sosf_system *sys, const int32_t *pointIdx, int count);
 /* FullSystem::marginalizeFrame -> ef->marginalizeFrame (FS/FullSystemMarginalize.cpp:143-236,
  * OB/EnergyFunctional.cpp:730-889, IMU off): frame idx must have no points left */
