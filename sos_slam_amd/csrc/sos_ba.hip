@@ -37,6 +37,7 @@
 // ------------------------------------------------------------------------------------------------
 struct BaDev {
   int n, P, R, Rpad, ntiles, ntilesA;
+  int lin_nd;  // k_linearize2: number of leading two-tile blocks (set per launch, lin_grid)
   int w, h;
   float wM3G, hM3G;
   sos_calib calib;
@@ -200,7 +201,12 @@ __device__ __forceinline__ void top_values12(const TopIn &in, float *v) {
 #endif
 #ifdef SOS_LIN_PROFILE  // developer build: per-block phase timestamps (s_memtime) of k_linearize
 __device__ unsigned long long g_lin_prof[8192 * 8];
-#define LIN_STAMP(i) do { if (tid == 0 && blockIdx.x < 8192) g_lin_prof[blockIdx.x * 8 + (i)] = clock64(); } while (0)
+#ifdef SOS_LIN_PROFILE_WALL  // 100 MHz constant clock, common to all XCDs: block start / end spread over the chip
+#define LIN_CLOCK() wall_clock64()
+#else
+#define LIN_CLOCK() clock64()
+#endif
+#define LIN_STAMP(i) do { if (tid == 0 && blockIdx.x < 8192) g_lin_prof[blockIdx.x * 8 + (i)] = LIN_CLOCK(); } while (0)
 extern "C" int sos_debug_lin_prof(unsigned long long *out, int nblocks) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lin_prof), sizeof(unsigned long long) * 8 * nblocks) == hipSuccess ? 0 : -2;
 }
@@ -593,8 +599,12 @@ __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(BaDev d, const
   __shared__ unsigned int sLin2[L2_TILES];
   const int tid = threadIdx.x;
   const int tloc = tid >> 8, t256 = tid & 255;
-  const int tile = blockIdx.x * L2_TILES + tloc;
-  const bool tile_ok = tile < d.ntilesA;
+  // blocks [0, lin_nd) own two tiles, the blocks behind them one (the second half idles): with an odd number of tiles per
+  // CU the grid is cut so that every CU gets the same number of tiles instead of whole two-tile blocks
+  const int tbase = (int)blockIdx.x < d.lin_nd ? (int)blockIdx.x * L2_TILES : d.lin_nd + (int)blockIdx.x;
+  const int tlim = (int)blockIdx.x < d.lin_nd ? d.ntilesA : min(d.ntilesA, tbase + 1);
+  const int tile = tbase + tloc;
+  const bool tile_ok = tile < tlim;
   const int rl = t256 >> 3, idx = t256 & 7;
   const int lane = tid & 63, wave = tid >> 6;
   const int w2 = blockIdx.x & 7;  // the wave of this block that runs phase 2
@@ -618,9 +628,9 @@ __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(BaDev d, const
 
   // ---- phase-2 operands of this lane's residual are requested next so their latency hides behind phase 1
   const int r64 = lane, tl2 = r64 >> 5, rr2 = r64 & 31;
-  const int tile2 = blockIdx.x * L2_TILES + tl2;
+  const int tile2 = tbase + tl2;
   const int role = (wave - w2) & 7;  // phase-2 role of this wave: 0 in stored-tile mode, 0..3 in fused mode
-  const bool p2 = role < (fuse_top ? 4 : 1) && tile2 < d.ntilesA;
+  const bool p2 = role < (fuse_top ? 4 : 1) && tile2 < tlim;
   const int s2 = (p2 ? tile2 : 0) * SOS_TILE + rr2;
   float4 geo2 = make_float4(0.f, 0.f, 0.f, 0.f);
   unsigned flags2 = 0;
@@ -654,7 +664,12 @@ __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(BaDev d, const
     const float q1 = krk[3] * u_pt + krk[4] * v_pt + krk[5] + ktt[1] * id;
     const float q2 = krk[6] * u_pt + krk[7] * v_pt + krk[8] + ktt[2] * id;
     const float Ku = q0 / q2, Kv = q1 / q2;
+#ifdef SOS_LIN_PROFILE_HWID  // where the block runs: HW_ID (cu 11:8, sh 12, se 15:13) | XCC_ID << 32
+    if (tid == 0 && blockIdx.x < 8192)
+      g_lin_prof[blockIdx.x * 8 + 1] = (unsigned long long)__builtin_amdgcn_s_getreg(0xF804) | ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32);
+#else
     LIN_STAMP(1);
+#endif
     const bool inb = Ku > 1.1f && Kv > 1.1f && Ku < d.wM3G && Kv < d.hM3G;
 
     // bilinear (I,dx,dy) tap (util/globalFuncs.h:68-82); addresses clamped so the loads are always legal
@@ -1031,8 +1046,8 @@ __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(BaDev d, const
     // v_mfma_f32_16x16x4_f32 x 16, one wave per tile
     __syncthreads();
     LIN_STAMP(6);
-    const int tlm = role - 4, tilem = blockIdx.x * L2_TILES + tlm;
-    if (role >= 4 && role < 4 + L2_TILES && tilem < d.ntilesA) {
+    const int tlm = role - 4, tilem = tbase + tlm;
+    if (role >= 4 && role < 4 + L2_TILES && tilem < tlim) {
       const float *Lb = sBig + tlm * L2_LR_TILE, *Rb = Lb + 16 * L2_LR_PST;
       const int m = lane & 15, kq = lane >> 4;
       const bool aLive = m < 10 || m == 13 || m == 14;  // the other rows of L are zero by construction (never stored)
@@ -2806,6 +2821,22 @@ static int wait_flag(sos_ba *ba, size_t flag_off, int seq) {
   }
   return SOS_OK;
 }
+// Grid of k_linearize2: *nd two-tile blocks followed by one-tile blocks.  A window whose tiles come to an odd number q
+// per CU (W12: 1272 tiles on 256 CUs, q = 5) would leave CUs with three two-tile blocks next to CUs with two (6 against
+// 4 tiles; the kernel ends with the slowest CU); (q - 1) / 2 two-tile blocks + 1 one-tile block per CU give every CU q.
+static int lin_grid(sos_ba *ba, int *nd) {
+  static int ncu = 0;
+  if (!ncu) {
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ba->ctx->device) != hipSuccess || ncu <= 0) ncu = 256;
+  }
+  static const char *ov = getenv("SOS_LIN_ND");  // experiment knob: number of two-tile blocks (-1 = all)
+  const int T = ba->ntilesA, q = divup(T, ncu);
+  int n2 = divup(T, L2_TILES);
+  if (ov && atoi(ov) >= 0) n2 = std::min(atoi(ov), T / 2);
+  else if (!ov && (q & 1) && q >= 3) n2 = std::min(T / 2, ncu * (q - 1) / 2);
+  *nd = n2;
+  return n2 + std::max(0, T - L2_TILES * n2);
+}
 // returns the sequence number to wait for (0 = this launch does not signal)
 static int launch_lin_kernel(sos_ba *ba, const BaDev &dv, int mode, float *fuse_top, bool signal = false, bool deferPublish = false) {
   if (ba->ntilesA <= 0) return 0;
@@ -2813,7 +2844,10 @@ static int launch_lin_kernel(sos_ba *ba, const BaDev &dv, int mode, float *fuse_
     k_linearize<<<ba->ntilesA, 256, 0, ba->ctx->stream>>>(dv, stg(ba, ba->st_th), mode, fuse_top);
     return 0;
   }
-  const int nb = divup(ba->ntilesA, L2_TILES);
+  int nd;
+  const int nb = lin_grid(ba, &nd);
+  BaDev dv2 = dv;
+  dv2.lin_nd = nd;
   DoneSignal sg = {nullptr, nullptr, 0, 0};
   static const bool inKernel = getenv("SOS_SIGNAL_IN_KERNEL") != nullptr;  // per-block fences: measured slower
   int seq = 0;
@@ -2827,8 +2861,8 @@ static int launch_lin_kernel(sos_ba *ba, const BaDev &dv, int mode, float *fuse_
       sg.seq = seq;
     }
   }
-  if (fuse_top && mode == 1) k_linearize2<true><<<nb, 256 * L2_TILES, 0, ba->ctx->stream>>>(dv, stg(ba, ba->st_th), mode, fuse_top, sg);
-  else k_linearize2<false><<<nb, 256 * L2_TILES, 0, ba->ctx->stream>>>(dv, stg(ba, ba->st_th), mode, nullptr, sg);
+  if (fuse_top && mode == 1) k_linearize2<true><<<nb, 256 * L2_TILES, 0, ba->ctx->stream>>>(dv2, stg(ba, ba->st_th), mode, fuse_top, sg);
+  else k_linearize2<false><<<nb, 256 * L2_TILES, 0, ba->ctx->stream>>>(dv2, stg(ba, ba->st_th), mode, nullptr, sg);
   if (signal && !inKernel && !deferPublish) k_publish<<<1, 1, 0, ba->ctx->stream>>>(reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags), seq);
   return seq;
 }
@@ -3611,7 +3645,8 @@ extern "C" int sos_ba_time_kernel(sos_ba *ba, const char *kernel, const float *f
       return SOS_OK;
     }
     if (k == "lin_floor") {  // empty kernel with the linearisation's grid, block and LDS size
-      k_lin_floor<<<divup(ba->ntilesA, L2_TILES), 256 * L2_TILES, 0, st>>>(nullptr);
+      int ndFloor;
+      k_lin_floor<<<lin_grid(ba, &ndFloor), 256 * L2_TILES, 0, st>>>(nullptr);
       return SOS_OK;
     }
     if (k == "sc_gram_prep") {
