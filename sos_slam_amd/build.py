@@ -21,7 +21,10 @@ HOST_SOURCES = ["host/sos_host.cpp", "host/sos_imu.cpp"]
 HOST_LIB = os.path.join(CSRC, "libsos_host.so")
 
 HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared",
-               "-fno-slp-vectorize", "-Wno-unused-value"]
+               "-fno-slp-vectorize", "-Wno-unused-value",
+               # leading scalar kernel arguments are delivered in SGPRs at wave start instead of being fetched from the
+               # kernel-argument segment (the kernels keep the fetching preamble for firmware without the feature)
+               "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 CXX_FLAGS = ["-O3", "-mavx2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-pthread"]
 
 

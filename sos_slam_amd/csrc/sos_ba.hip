@@ -584,8 +584,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // FUSED selects the pipelined form (fuse_top given, doApply = 1, tiles never stored) at compile time: two kernels with
 // their own names in a profile and their own register allocation
 template <bool FUSED>
-__global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(BaDev d, const float *__restrict__ frameTH, int doApply,
-                                                               float *__restrict__ fuse_top_, DoneSignal sg) {
+__global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(const float4 *__restrict__ a_r_geo, const float *__restrict__ a_r_cw,
+                                                               const float4 *__restrict__ a_t_pre, const float *const *__restrict__ a_t_img,
+                                                               int a_ntilesA, int a_lin_nd, BaDev d, const float *__restrict__ frameTH,
+                                                               int doApply, float *__restrict__ fuse_top_, DoneSignal sg) {
+  // the leading scalar arguments (what the first loads of a block need) arrive preloaded in SGPRs
+  // (-amdgpu-kernarg-preload-count): the block does not wait for the kernel-argument segment before its first requests
   float *__restrict__ const fuse_top = FUSED ? fuse_top_ : nullptr;
   __builtin_assume(!FUSED || fuse_top != nullptr);
   if (FUSED) doApply = 1;
@@ -601,8 +605,8 @@ __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(BaDev d, const
   const int tloc = tid >> 8, t256 = tid & 255;
   // blocks [0, lin_nd) own two tiles, the blocks behind them one (the second half idles): with an odd number of tiles per
   // CU the grid is cut so that every CU gets the same number of tiles instead of whole two-tile blocks
-  const int tbase = (int)blockIdx.x < d.lin_nd ? (int)blockIdx.x * L2_TILES : d.lin_nd + (int)blockIdx.x;
-  const int tlim = (int)blockIdx.x < d.lin_nd ? d.ntilesA : min(d.ntilesA, tbase + 1);
+  const int tbase = (int)blockIdx.x < a_lin_nd ? (int)blockIdx.x * L2_TILES : a_lin_nd + (int)blockIdx.x;
+  const int tlim = (int)blockIdx.x < a_lin_nd ? a_ntilesA : min(a_ntilesA, tbase + 1);
   const int tile = tbase + tloc;
   const bool tile_ok = tile < tlim;
   const int rl = t256 >> 3, idx = t256 & 7;
@@ -616,10 +620,10 @@ __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(BaDev d, const
   // ahead of them delays the projection (measured: 3.0 k -> 1.1 k cycles to the first use when nothing precedes them)
   const int tile1 = tile_ok ? tile : 0;
   const int s1 = tile1 * SOS_TILE + rl;
-  const float4 geo = d.r_geo[s1];
-  const float color = d.r_cw[16 * (size_t)s1 + idx], pweight = d.r_cw[16 * (size_t)s1 + 8 + idx];
-  const sos_precalc *pc = reinterpret_cast<const sos_precalc *>(d.t_pre + 8 * (size_t)tile1);  // tile-indexed: no dependent load
-  const float *__restrict__ img = d.t_img[tile1];
+  const float4 geo = a_r_geo[s1];
+  const float color = a_r_cw[16 * (size_t)s1 + idx], pweight = a_r_cw[16 * (size_t)s1 + 8 + idx];
+  const sos_precalc *pc = reinterpret_cast<const sos_precalc *>(a_t_pre + 8 * (size_t)tile1);  // tile-indexed: no dependent load
+  const float *__restrict__ img = a_t_img[tile1];
   float krk[9], ktt[3];
 #pragma unroll
   for (int i = 0; i < 9; i++) krk[i] = pc->PRE_KRKiTll[i];
@@ -638,14 +642,14 @@ __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(BaDev d, const
   float R0[9], t0[3], eOld2 = 0.f, neOld2 = 0.f, th2 = 0.f;
   int orig2 = -1;
   if (p2) {
-    geo2 = d.r_geo[s2];
+    geo2 = a_r_geo[s2];
     flags2 = d.s_flags[s2];
     st2 = d.s_state[s2];
     pair2 = d.t_ht[tile2];  // host idx | target idx << 16
     eOld2 = d.s_energy[s2];
     neOld2 = d.s_newenergy[s2];
     if (role == 0) orig2 = d.s_orig[s2];
-    const sos_precalc *pc2 = reinterpret_cast<const sos_precalc *>(d.t_pre + 8 * (size_t)tile2);
+    const sos_precalc *pc2 = reinterpret_cast<const sos_precalc *>(a_t_pre + 8 * (size_t)tile2);
 #pragma unroll
     for (int i = 0; i < 9; i++) R0[i] = pc2->PRE_RTll_0[i];
 #pragma unroll
@@ -2861,8 +2865,10 @@ static int launch_lin_kernel(sos_ba *ba, const BaDev &dv, int mode, float *fuse_
       sg.seq = seq;
     }
   }
-  if (fuse_top && mode == 1) k_linearize2<true><<<nb, 256 * L2_TILES, 0, ba->ctx->stream>>>(dv2, stg(ba, ba->st_th), mode, fuse_top, sg);
-  else k_linearize2<false><<<nb, 256 * L2_TILES, 0, ba->ctx->stream>>>(dv2, stg(ba, ba->st_th), mode, nullptr, sg);
+  if (fuse_top && mode == 1)
+    k_linearize2<true><<<nb, 256 * L2_TILES, 0, ba->ctx->stream>>>(dv2.r_geo, dv2.r_cw, dv2.t_pre, dv2.t_img, dv2.ntilesA, nd, dv2, stg(ba, ba->st_th), mode, fuse_top, sg);
+  else
+    k_linearize2<false><<<nb, 256 * L2_TILES, 0, ba->ctx->stream>>>(dv2.r_geo, dv2.r_cw, dv2.t_pre, dv2.t_img, dv2.ntilesA, nd, dv2, stg(ba, ba->st_th), mode, nullptr, sg);
   if (signal && !inKernel && !deferPublish) k_publish<<<1, 1, 0, ba->ctx->stream>>>(reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags), seq);
   return seq;
 }
