@@ -49,6 +49,7 @@ struct sos_tracker {
   double *pin_o = nullptr, *pin_o_dev = nullptr;  // [60] doubles as the completion flag (int)
   int seq = 0;
   float *d_part2 = nullptr;  // per-block partials of the speculative calcGSSSE
+  int *d_fusectr = nullptr;  // arrival counter of the in-kernel final sums (zero between launches)
   // Speculation: the LM loops call calcRes and, when the step is accepted (the common case), calcGSSSE on the same
   // buffers.  With a hint for b0 (sos_tracker_set_gs_hint) calcRes also runs calcGSSSE behind itself, and the
   // following sos_tracker_calc_gs with the same (lvl, a, b0) is answered from the host copy: one round trip, not two.
@@ -94,6 +95,8 @@ extern "C" int sos_tracker_create(sos_ctx *ctx, const sos_params *prm, sos_track
   SOS_HIP(hipMalloc(&T->d_part, sizeof(float) * 48 * T->maxblk));
   SOS_HIP(hipMalloc(&T->d_out, sizeof(double) * 64));
   SOS_HIP(hipMalloc(&T->d_part2, sizeof(float) * 48 * T->maxblk));
+  SOS_HIP(hipMalloc(&T->d_fusectr, sizeof(int) * 4));
+  SOS_HIP(hipMemset(T->d_fusectr, 0, sizeof(int) * 4));
   SOS_HIP(hipHostMalloc((void **)&T->pin_o, sizeof(double) * 64, hipHostMallocMapped));
   SOS_HIP(hipHostGetDevicePointer((void **)&T->pin_o_dev, T->pin_o, 0));
   memset(T->pin_o, 0, sizeof(double) * 64);
@@ -115,6 +118,7 @@ extern "C" int sos_tracker_destroy(sos_tracker *T) {
   for (int k = 0; k < 3; k++) hipFree(T->l_xyz[k]);
   for (int l = 0; l < SOS_PYR_LEVELS; l++) hipFree(T->l_col[l]);
   hipFree(T->d_part2);
+  hipFree(T->d_fusectr);
   if (T->pin_o) hipHostFree(T->pin_o);
   hipFree(T->d_counts); hipFree(T->d_part); hipFree(T->d_out); hipFree(T->d_pix); hipFree(T->d_pixv);
   delete T;
@@ -439,9 +443,45 @@ struct GsFuse {
   float s, tx, ty, tz;     // scale variant
 };
 // MODE 0: CoarseTracker::calcRes, 1: ScaleOptimizer::calcResScale, 2: PoseEstimator::calcRes (3-D points x y z in pu pv pid)
+// Final sums inside the producing kernel: the block whose arrival completes the grid adds the per-block partials in block
+// order (exactly what k_sum_parts / k_sum_parts2 do in a second launch) and publishes the result to the polling host.
+// One release fence per block (wave 0 wrote the partials), one acquire in the last block.
+struct FuseSum {
+  int *ctr;         // arrival counter, zero between launches (nullptr: the partials are summed by a second kernel)
+  double *o1, *o2;  // device-mapped host destinations of the 8 residual sums and of the 45 / 3 Hessian sums
+  int *flag;
+  int seq;
+};
+template <int NV2>
+__device__ __forceinline__ void fused_final_sum(const FuseSum &fs, const float *__restrict__ part, const float *__restrict__ part_gs) {
+  if (!fs.ctr || threadIdx.x >= 64) return;  // wave 0 only: it stored this block's partials
+  const int k = threadIdx.x;
+  __threadfence();
+  int old = 0;
+  if (k == 0) old = atomicAdd(fs.ctr, 1);
+  old = __shfl(old, 0, 64);
+  if (old != (int)gridDim.x - 1) return;
+  __threadfence();
+  if (k == 0) *fs.ctr = 0;
+  const int nblk = gridDim.x;
+  if (k < 8) {
+    double acc = 0;
+#pragma unroll 8
+    for (int b = 0; b < nblk; b++) acc += (double)part[(size_t)b * 8 + k];
+    fs.o1[k] = acc;
+  } else if (k < 8 + NV2) {
+    const int q = k - 8;
+    double acc = 0;
+#pragma unroll 8
+    for (int b = 0; b < nblk; b++) acc += (double)part_gs[(size_t)b * NV2 + q];
+    fs.o2[q] = acc;
+  }
+  __threadfence_system();
+  if (k == 0) __hip_atomic_store(fs.flag, fs.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 template <int MODE, bool GS>
 __global__ __launch_bounds__(256) void k_calc_res(ResArgs a, float *__restrict__ part /* nblk*8 */, GsFuse gf,
-                                                  float *__restrict__ part_gs /* nblk*45 | nblk*3 */) {
+                                                  float *__restrict__ part_gs /* nblk*45 | nblk*3 */, FuseSum fs) {
   __shared__ float sm[8 * 4];
   __shared__ float smg[(MODE == 1 ? 3 : 45) * 4];
   float gsb[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // this pixel's warp-buffer entries, as stored
@@ -588,6 +628,7 @@ __global__ __launch_bounds__(256) void k_calc_res(ResArgs a, float *__restrict__
       block_sum<45>(g45, smg, part_gs + 45 * (size_t)blockIdx.x);
     }
   }
+  fused_final_sum<GS ? (MODE == 1 ? 3 : 45) : 0>(fs, part, part_gs);
 }
 
 // both final sums of a speculative call in one launch
@@ -692,6 +733,20 @@ extern "C" int sos_tracker_set_gs_hint(sos_tracker *T, int on, float b0) {
   return SOS_OK;
 }
 
+// destinations of the final sums of a calc_res launch.  The in-kernel form pays one device-scope fence per block
+// (~0.13 us each, serialised per XCD) to save a launch: measured faster up to about 30 blocks (W7: trackNewestCoarse
+// 0.45 -> 0.42 ms, optimizeScale 0.20 -> 0.18 ms), even at 40-55 blocks; above the threshold the second kernel stays
+static FuseSum fuse_sum(sos_tracker *T, int nblk) {
+  static const int maxFused = getenv("SOS_TRACKER_FUSE_MAX") ? atoi(getenv("SOS_TRACKER_FUSE_MAX")) : 32;
+  FuseSum fs;
+  fs.ctr = nblk <= maxFused ? T->d_fusectr : nullptr;
+  fs.o1 = T->pin_o_dev;
+  fs.o2 = T->pin_o_dev + 8;
+  fs.flag = reinterpret_cast<int *>(T->pin_o_dev + 60);
+  fs.seq = ++T->seq;
+  return fs;
+}
+
 extern "C" int sos_tracker_calc_res(sos_tracker *T, int lvl, int newSlot, const float *RKi, const float *t, const float *affLL,
                                     float cutoffTH, double *rs) {
   if (!T || !T->have_ref || lvl < 0 || lvl >= T->levels || !RKi || !t || !affLL || !rs) return SOS_ERR_ARG;
@@ -708,23 +763,25 @@ extern "C" int sos_tracker_calc_res(sos_tracker *T, int lvl, int newSlot, const 
   if (nblk > 0) {
     GsFuse gf = {T->fx[lvl], T->fy[lvl], affLL[0], T->hint_b0, 1.f, 0.f, 0.f, 0.f};
     if (T->loop_mode) {  // PoseEstimator::calcRes: RKi is the plain rotation here
-      if (T->hint_on) k_calc_res<2, true><<<nblk, 256, 0, c->stream>>>(a, T->d_part, gf, T->d_part2);
-      else k_calc_res<2, false><<<nblk, 256, 0, c->stream>>>(a, T->d_part, gf, nullptr);
+      const FuseSum fs = fuse_sum(T, nblk);
+      if (T->hint_on) k_calc_res<2, true><<<nblk, 256, 0, c->stream>>>(a, T->d_part, gf, T->d_part2, fs);
+      else k_calc_res<2, false><<<nblk, 256, 0, c->stream>>>(a, T->d_part, gf, nullptr, fs);
       if (T->hint_on) {
-        k_sum_parts2<<<1, 64, 0, c->stream>>>(T->d_part, 8, T->pin_o_dev, T->d_part2, 45, T->pin_o_dev + 8, nblk,
-                                             reinterpret_cast<int *>(T->pin_o_dev + 60), ++T->seq);
+        if (!fs.ctr)
+          k_sum_parts2<<<1, 64, 0, c->stream>>>(T->d_part, 8, T->pin_o_dev, T->d_part2, 45, T->pin_o_dev + 8, nblk, fs.flag, fs.seq);
         T->gs_cached = true; T->gs_lvl = lvl; T->gs_a = affLL[0]; T->gs_b0 = T->hint_b0;
-      } else {
-        k_sum_parts<<<1, 64, 0, c->stream>>>(T->d_part, nblk, 8, T->pin_o_dev, reinterpret_cast<int *>(T->pin_o_dev + 60), ++T->seq);
+      } else if (!fs.ctr) {
+        k_sum_parts<<<1, 64, 0, c->stream>>>(T->d_part, nblk, 8, T->pin_o_dev, fs.flag, fs.seq);
       }
     } else if (T->hint_on) {  // speculative calcGSSSE for this pose inside the same kernel (see sos_tracker)
-      k_calc_res<0, true><<<nblk, 256, 0, c->stream>>>(a, T->d_part, gf, T->d_part2);
-      k_sum_parts2<<<1, 64, 0, c->stream>>>(T->d_part, 8, T->pin_o_dev, T->d_part2, 45, T->pin_o_dev + 8, nblk,
-                                           reinterpret_cast<int *>(T->pin_o_dev + 60), ++T->seq);
+      const FuseSum fs = fuse_sum(T, nblk);
+      k_calc_res<0, true><<<nblk, 256, 0, c->stream>>>(a, T->d_part, gf, T->d_part2, fs);
+      if (!fs.ctr) k_sum_parts2<<<1, 64, 0, c->stream>>>(T->d_part, 8, T->pin_o_dev, T->d_part2, 45, T->pin_o_dev + 8, nblk, fs.flag, fs.seq);
       T->gs_cached = true; T->gs_lvl = lvl; T->gs_a = affLL[0]; T->gs_b0 = T->hint_b0;
     } else {
-      k_calc_res<0, false><<<nblk, 256, 0, c->stream>>>(a, T->d_part, gf, nullptr);
-      k_sum_parts<<<1, 64, 0, c->stream>>>(T->d_part, nblk, 8, T->pin_o_dev, reinterpret_cast<int *>(T->pin_o_dev + 60), ++T->seq);
+      const FuseSum fs = fuse_sum(T, nblk);
+      k_calc_res<0, false><<<nblk, 256, 0, c->stream>>>(a, T->d_part, gf, nullptr, fs);
+      if (!fs.ctr) k_sum_parts<<<1, 64, 0, c->stream>>>(T->d_part, nblk, 8, T->pin_o_dev, fs.flag, fs.seq);
     }
   }
   T->buf_lvl = lvl;
@@ -747,12 +804,13 @@ extern "C" int sos_tracker_calc_res_scale(sos_tracker *T, int lvl, int stereoSlo
   if (nblk > 0) {
     GsFuse gf = {K1[0], K1[1], 0.f, 0.f, scale, t[0], t[1], t[2]};
     if (!T->hint_on) {
-      k_calc_res<1, false><<<nblk, 256, 0, c->stream>>>(a, T->d_part, gf, nullptr);
-      k_sum_parts<<<1, 64, 0, c->stream>>>(T->d_part, nblk, 8, T->pin_o_dev, reinterpret_cast<int *>(T->pin_o_dev + 60), ++T->seq);
+      const FuseSum fs = fuse_sum(T, nblk);
+      k_calc_res<1, false><<<nblk, 256, 0, c->stream>>>(a, T->d_part, gf, nullptr, fs);
+      if (!fs.ctr) k_sum_parts<<<1, 64, 0, c->stream>>>(T->d_part, nblk, 8, T->pin_o_dev, fs.flag, fs.seq);
     } else {  // calcGSSSEScale needs nothing beyond what calcResScale was given: same kernel
-      k_calc_res<1, true><<<nblk, 256, 0, c->stream>>>(a, T->d_part, gf, T->d_part2);
-      k_sum_parts2<<<1, 64, 0, c->stream>>>(T->d_part, 8, T->pin_o_dev, T->d_part2, 3, T->pin_o_dev + 8, nblk,
-                                           reinterpret_cast<int *>(T->pin_o_dev + 60), ++T->seq);
+      const FuseSum fs = fuse_sum(T, nblk);
+      k_calc_res<1, true><<<nblk, 256, 0, c->stream>>>(a, T->d_part, gf, T->d_part2, fs);
+      if (!fs.ctr) k_sum_parts2<<<1, 64, 0, c->stream>>>(T->d_part, 8, T->pin_o_dev, T->d_part2, 3, T->pin_o_dev + 8, nblk, fs.flag, fs.seq);
       T->gss_cached = true;
       T->gss_key[0] = (float)lvl; T->gss_key[1] = t[0]; T->gss_key[2] = t[1]; T->gss_key[3] = t[2];
       T->gss_key[4] = K1[0]; T->gss_key[5] = K1[1]; T->gss_key[6] = scale;
