@@ -622,8 +622,13 @@ __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(const float4 *
   const int s1 = tile1 * SOS_TILE + rl;
   const float4 geo = a_r_geo[s1];
   const float color = a_r_cw[16 * (size_t)s1 + idx], pweight = a_r_cw[16 * (size_t)s1 + 8 + idx];
-  const sos_precalc *pc = reinterpret_cast<const sos_precalc *>(a_t_pre + 8 * (size_t)tile1);  // tile-indexed: no dependent load
-  const float *__restrict__ img = a_t_img[tile1];
+  // the tile is the same for all lanes of a wave (256 threads per tile): made explicit, its precalc record and image
+  // pointer come through the scalar cache instead of as 64-lane broadcasts through the vector memory pipeline
+  // (7 -> 3 vector loads per wave in front of the projection; -4 % kernel time.  The same for the phase-2 operands,
+  // two tiles per wave selected per lane, measured no further gain and is not done)
+  const int tile1u = __builtin_amdgcn_readfirstlane(tile1);
+  const sos_precalc *pc = reinterpret_cast<const sos_precalc *>(a_t_pre + 8 * (size_t)tile1u);  // tile-indexed: no dependent load
+  const float *__restrict__ img = a_t_img[tile1u];
   float krk[9], ktt[3];
 #pragma unroll
   for (int i = 0; i < 9; i++) krk[i] = pc->PRE_KRKiTll[i];
