@@ -69,7 +69,7 @@ struct BaDev {
   const int2 *p_list2;  // per point residual list: (sorted index, xAd index = n*h + t)
   const int2 *p_list16; // the first 16 entries of every point's list at a fixed stride (x = -1: none): no p_begin lookup in front
   float4 *r_geo;        // per sorted residual: u, v, idepth_scaled, idepth_zero_scaled of its point
-  const float *r_cw;    // per sorted residual: color[8], weights[8] of its point
+  const float *r_cw;    // per sorted residual: (color, weight) of its point's 8 pattern pixels, interleaved
 };
 
 #define PO_HDD_A 0
@@ -230,7 +230,8 @@ __global__ __launch_bounds__(256, SOS_LIN_WAVES) void k_linearize(BaDev d, const
   const int s = tile * SOS_TILE + rl;
   // independent vector loads first
   const float4 geo = d.r_geo[s];                       // u, v, idepth, idepth_zero
-  const float color = d.r_cw[16 * (size_t)s + idx], pweight = d.r_cw[16 * (size_t)s + 8 + idx];
+  const float2 cw = reinterpret_cast<const float2 *>(d.r_cw)[8 * (size_t)s + idx];
+  const float color = cw.x, pweight = cw.y;
   const unsigned flags = d.s_flags[s];
   const int st = d.s_state[s];
   const int pair = d.t_pair[tile];
@@ -621,7 +622,8 @@ __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(const float4 *
   const int tile1 = tile_ok ? tile : 0;
   const int s1 = tile1 * SOS_TILE + rl;
   const float4 geo = a_r_geo[s1];
-  const float color = a_r_cw[16 * (size_t)s1 + idx], pweight = a_r_cw[16 * (size_t)s1 + 8 + idx];
+  const float2 cw = reinterpret_cast<const float2 *>(a_r_cw)[8 * (size_t)s1 + idx];  // one 8-byte load per pixel lane
+  const float color = cw.x, pweight = cw.y;
   // the tile is the same for all lanes of a wave (256 threads per tile): made explicit, its precalc record and image
   // pointer come through the scalar cache instead of as 64-lane broadcasts through the vector memory pipeline
   // (7 -> 3 vector loads per wave in front of the projection; -4 % kernel time.  The same for the phase-2 operands,
@@ -2207,8 +2209,9 @@ __global__ void k_expand_points(BaDev d) {
     w1 = make_float4(q->weights[4], q->weights[5], q->weights[6], q->weights[7]);
   }
   d.r_geo[s] = g;
-  float4 *o = reinterpret_cast<float4 *>(const_cast<float *>(d.r_cw) + 16 * (size_t)s);
-  o[0] = c0; o[1] = c1; o[2] = w0; o[3] = w1;
+  float4 *o = reinterpret_cast<float4 *>(const_cast<float *>(d.r_cw) + 16 * (size_t)s);  // (color, weight) pairs per pattern pixel
+  o[0] = make_float4(c0.x, w0.x, c0.y, w0.y); o[1] = make_float4(c0.z, w0.z, c0.w, w0.w);
+  o[2] = make_float4(c1.x, w1.x, c1.y, w1.y); o[3] = make_float4(c1.z, w1.z, c1.w, w1.w);
 }
 __global__ void k_refresh_geo(BaDev d) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
