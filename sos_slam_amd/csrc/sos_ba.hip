@@ -584,7 +584,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define L2_LR_TILE (2 * 16 * L2_LR_PST + 32)  // L and R planes of one tile; + 32 floats so the two tiles hit different banks
 // FUSED selects the pipelined form (fuse_top given, doApply = 1, tiles never stored) at compile time: two kernels with
 // their own names in a profile and their own register allocation
-template <bool FUSED>
+// SCALAR1: per-tile constants of phase 1 through the scalar cache (below); chosen per launch
+template <bool FUSED, bool SCALAR1>
 __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(const float4 *__restrict__ a_r_geo, const float *__restrict__ a_r_cw,
                                                                const float4 *__restrict__ a_t_pre, const float *const *__restrict__ a_t_img,
                                                                int a_ntilesA, int a_lin_nd, BaDev d, const float *__restrict__ frameTH,
@@ -626,9 +627,11 @@ __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(const float4 *
   const float color = cw.x, pweight = cw.y;
   // the tile is the same for all lanes of a wave (256 threads per tile): made explicit, its precalc record and image
   // pointer come through the scalar cache instead of as 64-lane broadcasts through the vector memory pipeline
-  // (7 -> 3 vector loads per wave in front of the projection; -4 % kernel time.  The same for the phase-2 operands,
-  // two tiles per wave selected per lane, measured no further gain and is not done)
-  const int tile1u = __builtin_amdgcn_readfirstlane(tile1);
+  // (7 -> 3 vector loads per wave in front of the projection).  Measured: -4 % when the grid is one round of resident
+  // blocks that all start together and crowd the vector memory pipeline (W12: 10.0 -> 9.6 us), +6 % when blocks start
+  // one by one as others retire (W16: 21.7 -> 23.1 us, the scalar cache's miss path is the slower one then) -- hence a
+  // per-launch choice.  The same for the phase-2 operands, two tiles per wave selected per lane, gave nothing.
+  const int tile1u = SCALAR1 ? __builtin_amdgcn_readfirstlane(tile1) : tile1;
   const sos_precalc *pc = reinterpret_cast<const sos_precalc *>(a_t_pre + 8 * (size_t)tile1u);  // tile-indexed: no dependent load
   const float *__restrict__ img = a_t_img[tile1u];
   float krk[9], ktt[3];
@@ -2836,11 +2839,15 @@ static int wait_flag(sos_ba *ba, size_t flag_off, int seq) {
 // Grid of k_linearize2: *nd two-tile blocks followed by one-tile blocks.  A window whose tiles come to an odd number q
 // per CU (W12: 1272 tiles on 256 CUs, q = 5) would leave CUs with three two-tile blocks next to CUs with two (6 against
 // 4 tiles; the kernel ends with the slowest CU); (q - 1) / 2 two-tile blocks + 1 one-tile block per CU give every CU q.
-static int lin_grid(sos_ba *ba, int *nd) {
+static int lin_ncu(sos_ba *ba) {
   static int ncu = 0;
   if (!ncu) {
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ba->ctx->device) != hipSuccess || ncu <= 0) ncu = 256;
   }
+  return ncu;
+}
+static int lin_grid(sos_ba *ba, int *nd) {
+  const int ncu = lin_ncu(ba);
   static const char *ov = getenv("SOS_LIN_ND");  // experiment knob: number of two-tile blocks (-1 = all)
   const int T = ba->ntilesA, q = divup(T, ncu);
   int n2 = divup(T, L2_TILES);
@@ -2873,10 +2880,19 @@ static int launch_lin_kernel(sos_ba *ba, const BaDev &dv, int mode, float *fuse_
       sg.seq = seq;
     }
   }
-  if (fuse_top && mode == 1)
-    k_linearize2<true><<<nb, 256 * L2_TILES, 0, ba->ctx->stream>>>(dv2.r_geo, dv2.r_cw, dv2.t_pre, dv2.t_img, dv2.ntilesA, nd, dv2, stg(ba, ba->st_th), mode, fuse_top, sg);
-  else
-    k_linearize2<false><<<nb, 256 * L2_TILES, 0, ba->ctx->stream>>>(dv2.r_geo, dv2.r_cw, dv2.t_pre, dv2.t_img, dv2.ntilesA, nd, dv2, stg(ba, ba->st_th), mode, nullptr, sg);
+  // one round of resident blocks (3 per CU)?  then the scalar-cache form of the first loads
+  static const char *sc1 = getenv("SOS_LIN_SCALAR1");  // experiment knob: 0 / 1 overrides the rule
+  const bool scalar1 = sc1 ? atoi(sc1) != 0 : nb <= 3 * lin_ncu(ba);
+#define SOS_LAUNCH_LIN2(F, S1, FT) \
+  k_linearize2<F, S1><<<nb, 256 * L2_TILES, 0, ba->ctx->stream>>>(dv2.r_geo, dv2.r_cw, dv2.t_pre, dv2.t_img, dv2.ntilesA, nd, dv2, stg(ba, ba->st_th), mode, FT, sg)
+  if (fuse_top && mode == 1) {
+    if (scalar1) SOS_LAUNCH_LIN2(true, true, fuse_top);
+    else SOS_LAUNCH_LIN2(true, false, fuse_top);
+  } else {
+    if (scalar1) SOS_LAUNCH_LIN2(false, true, nullptr);
+    else SOS_LAUNCH_LIN2(false, false, nullptr);
+  }
+#undef SOS_LAUNCH_LIN2
   if (signal && !inKernel && !deferPublish) k_publish<<<1, 1, 0, ba->ctx->stream>>>(reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags), seq);
   return seq;
 }
