@@ -2011,7 +2011,6 @@ __global__ __launch_bounds__(SOS_RSB) void k_resub_fused(BaDev d, XArg x, const 
   const float4 *ov = reinterpret_cast<const float4 *>(d.p_out + 16 * (size_t)pp);
   const float4 v0 = ov[0], v1 = ov[1], v2 = ov[2], v3 = ov[3];
   const int q0 = d.p_begin[pp], q1 = live ? d.p_begin[pp + 1] : q0;
-  const int cnt = q1 - q0;
   constexpr int RU = 16;  // residuals held in registers; longer lists finish in the tail loop below
   int2 e[RU];
   float4 ja[RU], jb[RU];
@@ -3257,7 +3256,6 @@ extern "C" int sos_ba_gn_accumulate(sos_ba *ba, double *H_top, double *b_top, do
                                     int *resInL) {
   if (!ba || !ba->have_window || !ba->have_state || !H_top || !b_top || !H_sc || !b_sc) return SOS_ERR_STATE;
   SOS_HIP(hipSetDevice(ba->ctx->device));
-  hipStream_t st = ba->ctx->stream;
   if (!ba->acc_inflight) {  // otherwise the previous sos_ba_gn_step already enqueued it (sos_ba_set_prefetch)
     enqueue_gn_accumulate(ba);
     SOS_HIP(hipGetLastError());
