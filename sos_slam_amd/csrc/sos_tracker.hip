@@ -418,18 +418,28 @@ struct ResArgs {
   float aff0, aff1, huber, cutoff, maxEnergy;
 };
 
+// Sum over the 64 lanes of a wave with DPP adds (VALU rate; the shuffle form is one LDS-crossbar round trip per step,
+// 6 x NV dependent ds_bpermute per wave -- 5 of the 7 us of a residual launch with its 53 sums): inclusive scan inside
+// each 16-lane row (row_shr 1, 2, 4, 8), then lane 15 of a row is added into the next row (row_bcast:15 on rows 1 and
+// 3, row_bcast:31 on rows 2 and 3).  Fixed order; lane 63 holds the sum.
+#define SOS_DPP_ADD(v, ctrl, rmask, bound) \
+  (v) += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), (rmask), 0xf, (bound)))
+__device__ __forceinline__ float wave_sum63(float a) {
+  SOS_DPP_ADD(a, 0x111, 0xf, true);   // row_shr:1
+  SOS_DPP_ADD(a, 0x112, 0xf, true);   // row_shr:2
+  SOS_DPP_ADD(a, 0x114, 0xf, true);   // row_shr:4
+  SOS_DPP_ADD(a, 0x118, 0xf, true);   // row_shr:8
+  SOS_DPP_ADD(a, 0x142, 0xa, false);  // row_bcast:15 -> rows 1, 3
+  SOS_DPP_ADD(a, 0x143, 0xc, false);  // row_bcast:31 -> rows 2, 3
+  return a;
+}
 // block-level fixed-tree sum of NV floats held per thread; result in sm[0..NV) of thread 0's view
 template <int NV>
 __device__ __forceinline__ void block_sum(float *v, float *sm /* NV*4 */, float *out) {
 #pragma unroll
-  for (int k = 0; k < NV; k++) {
-    float a = v[k];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-    v[k] = a;
-  }
+  for (int k = 0; k < NV; k++) v[k] = wave_sum63(v[k]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) {
+  if (lane == 63) {
 #pragma unroll
     for (int k = 0; k < NV; k++) sm[k * 4 + wave] = v[k];
   }
