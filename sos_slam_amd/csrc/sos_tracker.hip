@@ -419,7 +419,7 @@ struct ResArgs {
 };
 
 // Sum over the 64 lanes of a wave with DPP adds (VALU rate; the shuffle form is one LDS-crossbar round trip per step,
-// 6 x NV dependent ds_bpermute per wave -- 5 of the 7 us of a residual launch with its 53 sums): inclusive scan inside
+// 6 x NV dependent ds_bpermute per wave, about 2 us per LM step with the 53 sums of a residual launch): inclusive scan inside
 // each 16-lane row (row_shr 1, 2, 4, 8), then lane 15 of a row is added into the next row (row_bcast:15 on rows 1 and
 // 3, row_bcast:31 on rows 2 and 3).  Fixed order; lane 63 holds the sum.
 #define SOS_DPP_ADD(v, ctrl, rmask, bound) \
