@@ -159,28 +159,51 @@ __device__ __forceinline__ int trace_one(const sos_trace_params &P, const float 
   float bestU = 0, bestV = 0, bestEnergy = 1e10f;
   int bestIdx = -1;
   if (numSteps >= 100) numSteps = 99;
-  for (int i = 0; i < numSteps; i++) {
+  // The steps are independent of each other (only the best-so-far bookkeeping is sequential): four of them are
+  // evaluated together so that their 4 x 32 texel requests are in flight at once instead of one step per memory round
+  // trip; positions by repeated addition and the bookkeeping in step order, as in the one-step loop -> same records.
+  auto step_energy = [&](float qx, float qy) -> float {
     float energy = 0;
 #pragma unroll
     for (int idx = 0; idx < 8; idx++) {
-      const float hitColor = interp31(dI, (float)(ptx + rp[idx][0]), (float)(pty + rp[idx][1]), w, h);
-      if (!isfinite(hitColor)) {
-        energy += 1e5f;
-        continue;
-      }
+      const float hitColor = interp31(dI, (float)(qx + rp[idx][0]), (float)(qy + rp[idx][1]), w, h);
       const float residual = hitColor - (float)(aff[0] * p.color[idx] + aff[1]);
       const float hw = fabsf(residual) < P.huberTH ? 1 : P.huberTH / fabsf(residual);
-      energy += hw * residual * residual * (2 - hw);
+      const float e = hw * residual * residual * (2 - hw);
+      energy += isfinite(hitColor) ? e : 1e5f;
     }
-    errors[i] = energy;
-    if (energy < bestEnergy) {
-      bestU = ptx;
-      bestV = pty;
-      bestEnergy = energy;
-      bestIdx = i;
+    return energy;
+  };
+  constexpr int TU = 4;
+  for (int i0 = 0; i0 < numSteps; i0 += TU) {
+    float qx[TU], qy[TU], en[TU];
+#pragma unroll
+    for (int k = 0; k < TU; k++) {
+      qx[k] = ptx;
+      qy[k] = pty;
+      ptx += dx;
+      pty += dy;
     }
-    ptx += dx;
-    pty += dy;
+    if (i0 + TU <= numSteps) {  // full group: no per-step branches between the requests
+#pragma unroll
+      for (int k = 0; k < TU; k++) en[k] = step_energy(qx[k], qy[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < TU; k++) en[k] = (i0 + k < numSteps) ? step_energy(qx[k], qy[k]) : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < TU; k++) {
+      const int i = i0 + k;
+      if (i < numSteps) {
+        errors[i] = en[k];
+        if (en[k] < bestEnergy) {
+          bestU = qx[k];
+          bestV = qy[k];
+          bestEnergy = en[k];
+          bestIdx = i;
+        }
+      }
+    }
   }
   float secondBest = 1e10f;
   for (int i = 0; i < numSteps; i++)
