@@ -66,3 +66,24 @@ def test_switches(modeA, modeB, huber, outlier):
     so, sg = ow2.res(), sysm.stats()
     assert sg["resInA"] > 0
     sysm.close(); ow2.close()
+
+
+@pytest.mark.parametrize("env,target", [
+    ({"SOS_LIN_SCALAR1": "0"}, "tests/test_gpu_backend.py"),      # vector-load form of the phase-1 tile constants (multi-round grids)
+    ({"SOS_LIN_ND": "0"}, "tests/test_gpu_backend.py"),           # every block owns one tile
+    ({"SOS_LIN_ND": "-1"}, "tests/test_gpu_backend.py"),          # every block owns two tiles
+    ({"SOS_TRACKER_FUSE_MAX": "0"}, "tests/test_gpu_tracker.py"),  # final sums by the second kernel on every level
+    ({"SOS_TRACKER_FUSE_MAX": "1000"}, "tests/test_gpu_tracker.py"),  # ... by the last-arriving block on every level
+])
+def test_launch_variants_keep_parity(env, target):
+    """Launch-shape choices the library makes per window (read once per process from the environment when forced) must
+    not change results: the parity suite of the affected path is run again in a child process under each override."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-m", "pytest", target, "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"], cwd=root, env=e,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
