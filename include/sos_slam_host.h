@@ -96,6 +96,13 @@ int sosf_marginalize_frame(sosf_system *sys, int frameIdx);
 typedef void (*sosf_allreduce_fn)(void *user, float *dev_ptr, size_t nfloats);
 typedef float (*sosf_nth_fn)(void *user, const float *energies, int count, float frac);
 int sosf_set_hooks(sosf_system *sys, sosf_allreduce_fn allreduce, sosf_nth_fn nth, void *user);
+/* Companion of the callback exchange for the keyframe-rate fp64 sums: the shard-local M - Msc (and resInM) of
+ * marginalizePointsF (OB/EnergyFunctional.cpp:891-936) and the mean |idepth| behind the termination test of
+ * doStepFromBackup (FS/FullSystemOptimize.cpp:240-257) must be identical on every rank.  `buf` is a HOST buffer,
+ * summed over ranks in place.  With sosf_set_hooks but without this hook sosf_marginalize_points returns SOS_ERR_STATE
+ * instead of letting the priors diverge.  Shard-local by design (not exchanged): EnergyFunctional::connectivityMap. */
+typedef void (*sosf_allreduce_f64_fn)(void *user, double *host_buf, size_t count);
+int sosf_set_allreduce_f64_hook(sosf_system *sys, sosf_allreduce_f64_fn allreduce_f64);
 /* Native exchange: attach an RCCL communicator (sos_comm_create) to the system's backend; the all-reduce / all-gather
  * then run on the library's stream inside the fused calls (no callbacks, pipelining stays on).  NULL detaches. */
 int sosf_set_comm(sosf_system *sys, sos_comm *comm);

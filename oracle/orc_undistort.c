@@ -43,7 +43,7 @@ int orc_camera_parse(const char *text, sos_camera_model *out) {
     snprintf(buf, sizeof(buf), "%s%%lf %%lf %%lf %%lf %%lf", prefix);
     if (sscanf(l[0], buf, &q[0], &q[1], &q[2], &q[3], &q[4]) != 5) return -1;
   } else {
-    snprintf(buf, sizeof(buf), "%s%%lf %%lf %%lf %%lf %%lf %%lf %%lf %%lf %%lf %%lf", prefix);
+    snprintf(buf, sizeof(buf), "%s%%lf %%lf %%lf %%lf %%lf %%lf %%lf %%lf", prefix);
     if (sscanf(l[0], buf, &q[0], &q[1], &q[2], &q[3], &q[4], &q[5], &q[6], &q[7]) != 8) return -1;
   }
   if (sscanf(l[1], "%d %d", &out->wOrg, &out->hOrg) != 2) return -1;

@@ -356,8 +356,16 @@ VecX EnergyFunctional::getStitchedDeltaF() const {  // :1204-1210
   return d;
 }
 
+int EnergyFunctional::allreduceF64(double *buf, size_t count) {
+  if (commAttached) return sos_ba_allreduce_f64(ba, buf, count);
+  if (allreduceF64Hook) { allreduceF64Hook(hookUser, buf, count); return SOS_OK; }
+  return allreduceHook ? SOS_ERR_STATE : SOS_OK;
+}
+
 int EnergyFunctional::packWindow() {
-  if (!packDirty) return SOS_OK;
+  // graph edits are shard-local (linearizeAll(true) / removeOutliers drop residuals on some ranks only), and
+  // sos_ba_set_window agrees on capacities with a collective once a communicator is attached: every rank repacks
+  if (!packDirty && !commAttached) return SOS_OK;
   const double tpk0 = now_s();
   makeIDX();
   const int n = nFrames;
@@ -417,7 +425,7 @@ int EnergyFunctional::pushState(CalibHessian *HCalib, bool adjoints) {
                           adjoints ? adTarget.data() : nullptr, id.data(), idz.data(), dl.data());
 }
 
-void EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib, bool deferResubstitute) {  // :1029-1184, IMU off
+int EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib, bool deferResubstitute) {  // :1029-1184, IMU off
   lambda = 1e-5;
   const int n = nFrames, dim = SOS_CPARS + 8 * n;
   const size_t dd = (size_t)dim * dim;
@@ -430,15 +438,18 @@ void EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib, bo
     bL.assign(dim, 0.0);
     float *dev = nullptr;
     size_t nfl = 0;
-    sos_ba_accumulate_local(ba);
-    sos_ba_acc_buffer(ba, &dev, &nfl);
-    sos_ctx_synchronize(ctx);
+    int rc = sos_ba_accumulate_local(ba);
+    if (rc == SOS_OK) rc = sos_ba_acc_buffer(ba, &dev, &nfl);
+    if (rc == SOS_OK) rc = sos_ctx_synchronize(ctx);
+    if (rc != SOS_OK) return rc;
     allreduceHook(hookUser, dev, nfl);
-    sos_ba_stitch(ba, HA.data(), bA.data(), HL.data(), bL.data(), Hsc.data(), bsc.data(), &resInA, &resInL);
+    rc = sos_ba_stitch(ba, HA.data(), bA.data(), HL.data(), bL.data(), Hsc.data(), bsc.data(), &resInA, &resInL);
+    if (rc != SOS_OK) return rc;
     for (size_t i = 0; i < dd; i++) HA[i] += HL[i];
     for (int i = 0; i < dim; i++) bA[i] += bL[i];
   } else {  // HA := HL_top + HA_top already summed by the library
-    sos_ba_gn_accumulate(ba, HA.data(), bA.data(), Hsc.data(), bsc.data(), &resInA, &resInL);
+    const int rc = sos_ba_gn_accumulate(ba, HA.data(), bA.data(), Hsc.data(), bsc.data(), &resInA, &resInL);
+    if (rc != SOS_OK) return rc;  // H / b were not delivered: nothing below may consume them
   }
   g_phase[0] += now_s() - t_acc0;
   double t_sol0 = now_s();
@@ -480,11 +491,12 @@ void EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib, bo
     for (int h = 0; h < n; h++)
       for (int k = 0; k < 21; k++) imuFrames[h].state_imu[k] += imuStep[(size_t)21 * h + k];
     g_phase[2] += now_s() - t_sol0;
-    if (deferResubstitute) return;
+    if (deferResubstitute) return SOS_OK;
     pointStep.resize(allPoints.size());
-    sos_ba_resubstitute(ba, x.data(), pointStep.data());
+    const int rcr = sos_ba_resubstitute(ba, x.data(), pointStep.data());
+    if (rcr != SOS_OK) return rcr;
     for (size_t k = 0; k < allPoints.size(); k++) allPoints[k]->data->step = pointStep[k];
-    return;
+    return SOS_OK;
   }
   for (int i = 0; i < dim; i++) {
     double s = bM[i];
@@ -521,10 +533,12 @@ void EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib, bo
     h->data->step[8] = h->data->step[9] = 0;
   }
   g_phase[2] += now_s() - t_sol0;
-  if (deferResubstitute) return;  // done by sos_ba_gn_step together with the next linearisation
+  if (deferResubstitute) return SOS_OK;  // done by sos_ba_gn_step together with the next linearisation
   pointStep.resize(allPoints.size());
-  sos_ba_resubstitute(ba, x.data(), pointStep.data());
+  const int rcr = sos_ba_resubstitute(ba, x.data(), pointStep.data());
+  if (rcr != SOS_OK) return rcr;
   for (size_t k = 0; k < allPoints.size(); k++) allPoints[k]->data->step = pointStep[k];
+  return SOS_OK;
 }
 
 double EnergyFunctional::calcMEnergyF() {  // :553-561
@@ -551,7 +565,7 @@ double EnergyFunctional::calcLEnergyF_MT() {  // :626-642
   return E + Ed;
 }
 
-void EnergyFunctional::marginalizePointsF() {  // :891-936, IMU off
+int EnergyFunctional::marginalizePointsF() {  // :891-936, IMU off
   allPointsToMarg.clear();
   std::vector<int32_t> idx;
   for (EFFrame *f : frames)
@@ -571,21 +585,30 @@ void EnergyFunctional::marginalizePointsF() {  // :891-936, IMU off
   if (!idx.empty()) {
     std::vector<float> pr(idx.size());  // priorF changed above: refresh the device copy
     for (size_t k = 0; k < idx.size(); k++) pr[k] = allPointsToMarg[k]->priorF;
-    sos_ba_update_point_priors(ba, idx.data(), pr.data(), (int)idx.size());
-    sos_ba_accumulate_marg(ba, idx.data(), (int)idx.size(), M.data(), Mb.data(), Msc.data(), Mbsc.data(), &rin);
+    int rcm = sos_ba_update_point_priors(ba, idx.data(), pr.data(), (int)idx.size());
+    if (rcm == SOS_OK) rcm = sos_ba_accumulate_marg(ba, idx.data(), (int)idx.size(), M.data(), Mb.data(), Msc.data(), Mbsc.data(), &rin);
+    if (rcm != SOS_OK) {  // nothing consumed: the points stay in the window, the prior is untouched
+      for (EFPoint *p : allPointsToMarg) p->priorF /= prm.idepthFixPriorMargFac;
+      return rcm;
+    }
   }
   for (EFPoint *p : allPointsToMarg) removePoint(p);
-  resInM += rin;
-  {  // multi-GPU: every rank marginalised its own shard; the prior update is the sum over ranks (no-op on one GPU)
-    std::vector<double> upd(dd + dim);
+  int rcx = SOS_OK;
+  {  // multi-GPU: every rank marginalised its own shard; the prior update (and resInM) is the sum over ranks
+    std::vector<double> upd(dd + dim + 1);
     for (size_t i = 0; i < dd; i++) upd[i] = M[i] - Msc[i];
     for (int i = 0; i < dim; i++) upd[dd + i] = Mb[i] - Mbsc[i];
-    sos_ba_allreduce_f64(ba, upd.data(), upd.size());
-    for (size_t i = 0; i < dd; i++) HM[i] += prm.margWeightFac * upd[i];
-    for (int i = 0; i < dim; i++) bM[i] += prm.margWeightFac * upd[dd + i];
+    upd[dd + dim] = rin;
+    rcx = allreduceF64(upd.data(), upd.size());
+    if (rcx == SOS_OK) {  // on failure the prior is left untouched instead of diverging between ranks
+      for (size_t i = 0; i < dd; i++) HM[i] += prm.margWeightFac * upd[i];
+      for (int i = 0; i < dim; i++) bM[i] += prm.margWeightFac * upd[dd + i];
+      resInM += (int)upd[dd + dim];
+    }
   }
   EFIndicesValid = false;
   makeIDX();
+  return rcx;
 }
 
 void EnergyFunctional::dropPointsF() {  // :938-952
@@ -601,7 +624,7 @@ void EnergyFunctional::dropPointsF() {  // :938-952
   makeIDX();
 }
 
-void EnergyFunctional::marginalizeFrame(EFFrame *fh) {  // :730-889, IMU off
+int EnergyFunctional::marginalizeFrame(EFFrame *fh) {  // :730-889, IMU off
   const int step = 8, odim = SOS_CPARS + nFrames * step, ndim = odim - step;
   const int io = SOS_CPARS + fh->idx * step;
   // move the frame's block to the end (row/column permutation)
@@ -632,7 +655,7 @@ void EnergyFunctional::marginalizeFrame(EFFrame *fh) {  // :730-889, IMU off
   std::vector<double> hpi((size_t)step * step), hpinv;
   for (int i = 0; i < step; i++)
     for (int j = 0; j < step; j++) hpi[(size_t)i * step + j] = Hp[(size_t)(ndim + i) * odim + ndim + j];
-  mat_inverse(hpi, hpinv, step);
+  if (!mat_inverse(hpi, hpinv, step)) return SOS_ERR_STATE;  // the reference asserts isfinite(hpi) here (:844); HM / bM untouched
   // bli = bottomLeft^T * hpi ; top -= bli * bottomLeft
   MatXX bli((size_t)ndim * step);
   for (int i = 0; i < ndim; i++)
@@ -672,6 +695,7 @@ void EnergyFunctional::marginalizeFrame(EFFrame *fh) {  // :730-889, IMU off
   makeIDX();
   packDirty = true;
   delete fh;
+  return SOS_OK;
 }
 
 // ================================================================================================
@@ -900,6 +924,18 @@ void FullSystem::backupState() {  // :260-269
       backupNumID++;
     }
   }
+  // multi-GPU: the points are sharded, the termination test of doStepFromBackup (sqrtf(sumT) * sumNID) must come out the
+  // same on every rank or the ranks leave the loop -- and the collectives of the fused calls -- at different iterations.
+  // Benchmark loops (pipelineAlways) ignore canbreak and skip the exchange.
+  if (ef->multiRank() && !pipelineAlways) {
+    double v[2] = {backupSumNID, backupNumID};
+    if (ef->allreduceF64(v, 2) == SOS_OK) {
+      backupSumNID = (float)v[0];
+      backupNumID = (float)v[1];
+    } else {
+      lastError = SOS_ERR_STATE;
+    }
+  }
 }
 
 bool FullSystem::doStepFromBackup(float stepfacC, float stepfacT, float stepfacR, float stepfacA, float stepfacD, bool pointsOnDevice) {
@@ -939,7 +975,7 @@ bool FullSystem::doStepFromBackup(float stepfacC, float stepfacT, float stepfacR
          sqrtf(sumR) < 0.00005 * setting_thOptIterations && sqrtf(sumT) * sumNID < 0.00005 * setting_thOptIterations;
 }
 
-void FullSystem::solveSystem(int iteration, double lambda) { ef->solveSystemF(iteration, lambda, &HCalib, false); }
+void FullSystem::solveSystem(int iteration, double lambda) { rcAcc(ef->solveSystemF(iteration, lambda, &HCalib, false)); }
 
 int FullSystem::prepare() {  // FS/FullSystemOptimize.cpp:316-344
   activeResiduals.clear();
@@ -968,7 +1004,10 @@ int FullSystem::prepare() {  // FS/FullSystemOptimize.cpp:316-344
 
 bool FullSystem::gnIteration(int iteration, bool mayContinue) {  // :358-413 with setting_forceAceptStep
   { PhaseTimer tb(7); backupState(); }
-  ef->solveSystemF(iteration, 1e-1, &HCalib, true);  // x, frame / calib steps; back-substitution deferred
+  if (rcAcc(ef->solveSystemF(iteration, 1e-1, &HCalib, true)) != SOS_OK) {  // x, frame / calib steps; back-substitution deferred
+    isLost = true;  // a failed device call: no step is taken on undelivered H / b
+    return true;
+  }
   // the back-substitution needs x alone: it runs on the device while the host derives the new poses and precalc records
   const bool resubAhead = sos_ba_gn_resub(ef->ba, ef->lastX.data(), 1.0f) == SOS_OK;
   bool canbreak;
@@ -1133,8 +1172,7 @@ int FullSystem::marginalizePoints(const std::vector<PointHessian *> &pts) {
   ef->dropPointsF();         // FS/FullSystem.cpp:909 (PS_DROP ones)
   // dropPointsF mutated the graph but the device snapshot still holds the to-be-marginalised points at
   // their packIdx: marginalizePointsF reads them before removing them.
-  ef->marginalizePointsF();  // :912
-  return SOS_OK;
+  return ef->marginalizePointsF();  // :912
 }
 
 int FullSystem::dropPoints(const std::vector<PointHessian *> &pts) {
@@ -1155,7 +1193,10 @@ int FullSystem::dropPoints(const std::vector<PointHessian *> &pts) {
 
 int FullSystem::marginalizeFrame(FrameHessian *frame) {  // FS/FullSystemMarginalize.cpp:143-236 (backend part)
   if (!frame->pointHessians.empty()) return SOS_ERR_STATE;
-  ef->marginalizeFrame(frame->efFrame);
+  {
+    const int rc = ef->marginalizeFrame(frame->efFrame);
+    if (rc != SOS_OK) { isLost = true; return lastError = rc; }
+  }
   // drop all observations of existing points in that frame (:148-176)
   for (FrameHessian *fh : frameHessians) {
     if (fh == frame) continue;
@@ -1181,6 +1222,11 @@ int FullSystem::marginalizeFrame(FrameHessian *frame) {  // FS/FullSystemMargina
       break;
     }
   for (size_t i = 0; i < frameHessians.size(); i++) frameHessians[i]->idx = (int)i;
+  // the frame owns its marginalised / dropped points: their flat-API indices must not resolve any more
+  for (PointHessian *ph : frame->pointHessiansMarginalized)
+    if (ph->userIdx >= 0 && ph->userIdx < (int)userPoints.size()) userPoints[ph->userIdx] = nullptr;
+  for (PointHessian *ph : frame->pointHessiansOut)
+    if (ph->userIdx >= 0 && ph->userIdx < (int)userPoints.size()) userPoints[ph->userIdx] = nullptr;
   delete frame;  // (the reference hands it to LoopHandler instead, src/LoopClosure/LoopHandler.cpp:249)
   setPrecalcValues();
   ef->setAdjointsF(&HCalib);
@@ -1264,6 +1310,7 @@ bool CoarseTracker::trackNewestCoarse(int newSlot, float new_ab_exposure, SE3 &l
   bool haveRepeated = false;
   const float modeA = prm.affineOptModeA, modeB = prm.affineOptModeB;
   sos_tracker_set_gs_hint(trk, 1, (float)lastRef_aff_g2l.b);  // calcGSSSE rides behind every calcRes (accepted steps: 1 round trip)
+  bool devError = false;
   auto calcRes = [&](int lvl, const SE3 &T, const AffLight &aff, float cutoff, double *rs, float *a_out) {
     float RKi[9], t[3], affLL[2];
     rki_of(T, Ki[lvl], RKi, t);
@@ -1272,7 +1319,10 @@ bool CoarseTracker::trackNewestCoarse(int newSlot, float new_ab_exposure, SE3 &l
     affLL[0] = (float)a2[0];
     affLL[1] = (float)a2[1];
     if (a_out) *a_out = affLL[0];
-    sos_tracker_calc_res(trk, lvl, newSlot, RKi, t, affLL, cutoff, rs);
+    if (sos_tracker_calc_res(trk, lvl, newSlot, RKi, t, affLL, cutoff, rs) != SOS_OK) {
+      devError = true;  // a failed device call must not leave uninitialised sums behind: the loop sees a lost track
+      rs[0] = NAN; rs[1] = 0; rs[2] = rs[3] = rs[4] = NAN; rs[5] = 0;
+    }
   };
   for (int lvl = coarsestLvl; lvl >= 0; lvl--) {
     double H[64], b[8], resOld[6], resNew[6];
@@ -1346,6 +1396,7 @@ bool CoarseTracker::trackNewestCoarse(int newSlot, float new_ab_exposure, SE3 &l
       for (int i = 0; i < 8; i++) nrm += inc[i] * inc[i];
       if (!(std::sqrt(nrm) > 1e-3)) break;
     }
+    if (devError) return false;
     lastResiduals[lvl] = sqrtf((float)(resOld[0] / resOld[1]));
     lastInners[lvl] = (int)resOld[1];
     lastFlowIndicators[0] = resOld[2];
@@ -1511,7 +1562,9 @@ extern "C" int sosf_add_residuals(sosf_system *s, int count, const sos_resid *re
   for (int i = 0; i < count; i++) {
     const sos_resid &q = res[i];
     if (q.point < 0 || q.point >= (int)fs->userPoints.size() || q.target < 0 || q.target >= (int)fs->frameHessians.size()) return SOS_ERR_ARG;
-    fs->addResidual(fs->userPoints[q.point], fs->frameHessians[q.target], q);
+    PointHessian *ph = fs->userPoints[q.point];
+    if (!ph || !ph->efPoint) return SOS_ERR_ARG;  // marginalised / dropped, or its host frame left the window
+    fs->addResidual(ph, fs->frameHessians[q.target], q);
   }
   return SOS_OK;
 }
@@ -1552,7 +1605,9 @@ extern "C" int sosf_set_pipeline(sosf_system *s, int on) {
 extern "C" int sosf_set_comm(sosf_system *s, sos_comm *comm) {
   if (!s) return SOS_ERR_ARG;
   s->fs->comm = comm;
-  return sos_ba_set_comm(s->fs->ef->ba, comm);
+  const int rc = sos_ba_set_comm(s->fs->ef->ba, comm);
+  s->fs->ef->commAttached = (rc == SOS_OK && comm != nullptr);
+  return rc;
 }
 extern "C" int sosf_counts(sosf_system *s, int *nF, int *nP, int *nR) {
   if (!s) return SOS_ERR_ARG;
@@ -1670,6 +1725,12 @@ extern "C" int sosf_set_hooks(sosf_system *s, sosf_allreduce_fn ar, sosf_nth_fn 
   s->fs->ef->allreduceHook = ar;
   s->fs->ef->nthHook = nth;
   s->fs->ef->hookUser = user;
+  if (!ar) s->fs->ef->allreduceF64Hook = nullptr;
+  return SOS_OK;
+}
+extern "C" int sosf_set_allreduce_f64_hook(sosf_system *s, sosf_allreduce_f64_fn ar64) {
+  if (!s) return SOS_ERR_ARG;
+  s->fs->ef->allreduceF64Hook = ar64;
   return SOS_OK;
 }
 struct sosf_tracker {

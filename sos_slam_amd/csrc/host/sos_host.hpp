@@ -170,11 +170,11 @@ class EnergyFunctional {  // OB/EnergyFunctional.h:52-154
   EFFrame *insertFrame(FrameHessian *fh, CalibHessian *HCalib);
   EFPoint *insertPoint(PointHessian *ph);
   void dropResidual(EFResidual *r);
-  void marginalizeFrame(EFFrame *fh);
+  int marginalizeFrame(EFFrame *fh);
   void removePoint(EFPoint *pt);
-  void marginalizePointsF();
+  int marginalizePointsF();
   void dropPointsF();
-  void solveSystemF(int iteration, double lambda, CalibHessian *HCalib, bool deferResubstitute = false);
+  int solveSystemF(int iteration, double lambda, CalibHessian *HCalib, bool deferResubstitute = false);
   double calcMEnergyF();
   double calcLEnergyF_MT();
   void makeIDX();
@@ -213,7 +213,13 @@ class EnergyFunctional {  // OB/EnergyFunctional.h:52-154
   double imuScaleStep = 0;
   std::vector<double> imuStep;
   float (*nthHook)(void *, const float *, int, float) = nullptr;
+  void (*allreduceF64Hook)(void *, double *, size_t) = nullptr;  // host fp64 sum over ranks (keyframe-rate exchanges)
   void *hookUser = nullptr;
+  bool commAttached = false;  // sos_ba_set_comm holds an RCCL communicator: sos_ba_set_window is then a collective
+  bool multiRank() const { return commAttached || allreduceHook != nullptr; }
+  // sum of a host fp64 buffer over all ranks: native communicator, else the fp64 hook; SOS_ERR_STATE when the system runs
+  // on callback hooks without one (the fp32 hook cannot carry the prior update)
+  int allreduceF64(double *buf, size_t count);
 
   sos_params prm;
   float cDeltaF[4];
@@ -267,6 +273,7 @@ class FullSystem {
   void applyRes();                                            // :79-83
   void backupState();                                         // :260-269
   float backupSumNID = 0, backupNumID = 0;
+  int rcAcc(int rc) { if (rc != SOS_OK && lastError == SOS_OK) lastError = rc; return rc; }
   bool doStepFromBackup(float stepfacC, float stepfacT, float stepfacR, float stepfacA, float stepfacD,
                         bool pointsOnDevice = false);  // :185-257
   void solveSystem(int iteration, double lambda);             // :491-497

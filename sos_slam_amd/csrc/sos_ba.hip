@@ -2334,6 +2334,7 @@ struct sos_ba {
   DevBuf<float> d_stage;   // [precalc n*n*28 | adHTdelta n*n*8 | cdelta 4 | frameTH n(+pad) | xc 4 | xAd n*n*8]
   DevBuf<char> d_outpack;  // [tile_esum ntilesA doubles | newest energies | point steps]
   DevBuf<double> d_C;      // stitch stage-1 products
+  DevBuf<double> d_ar64;   // sos_ba_allreduce_f64 staging
   size_t st_pre = 0, st_adh = 0, st_cd = 0, st_th = 0, st_xc = 0, st_xad = 0, st_floats = 0;
   bool resub_pending = false;  // sos_ba_gn_resub enqueued the back-substitution of the step sos_ba_gn_step is about to take
   size_t out_esum = 0, out_newest = 0, out_step = 0, out_bytes = 0;
@@ -2413,7 +2414,7 @@ extern "C" int sos_ba_destroy(sos_ba *ba) {
     b->release();
   ba->d_rawjac.release();
   ba->d_t_pre.release(); ba->d_t_img.release(); ba->d_t_ht.release();
-  ba->d_p_list2.release(); ba->d_p_list16.release(); ba->d_r_geo.release(); ba->d_r_cw.release(); ba->d_stage.release(); ba->d_outpack.release(); ba->d_C.release();
+  ba->d_p_list2.release(); ba->d_p_list16.release(); ba->d_r_geo.release(); ba->d_r_cw.release(); ba->d_stage.release(); ba->d_outpack.release(); ba->d_C.release(); ba->d_ar64.release();
   if (ba->pin) hipHostFree(ba->pin);
   if (ba->ev_step) hipEventDestroy(ba->ev_step);
   if (ba->pin_newest) hipHostFree(ba->pin_newest);
@@ -2987,14 +2988,12 @@ extern "C" int sos_ba_allreduce_f64(sos_ba *ba, double *buf, size_t count) {
   if (!ba->comm || count == 0) return SOS_OK;
   SOS_HIP(hipSetDevice(ba->ctx->device));
   hipStream_t st = ba->ctx->stream;
-  DevBuf<double> tmp;
-  if (tmp.ensure(count)) return SOS_ERR_NOMEM;
-  SOS_HIP(hipMemcpyAsync(tmp.p, buf, sizeof(double) * count, hipMemcpyHostToDevice, st));
-  const int rc = sos_comm_allreduce_sum_f64(ba->comm, tmp.p, count, st);
-  if (rc) { tmp.release(); return rc; }
-  SOS_HIP(hipMemcpyAsync(buf, tmp.p, sizeof(double) * count, hipMemcpyDeviceToHost, st));
+  if (ba->d_ar64.ensure(count)) return SOS_ERR_NOMEM;  // kept on the handle: no allocation to leak on the error exits
+  SOS_HIP(hipMemcpyAsync(ba->d_ar64.p, buf, sizeof(double) * count, hipMemcpyHostToDevice, st));
+  const int rc = sos_comm_allreduce_sum_f64(ba->comm, ba->d_ar64.p, count, st);
+  if (rc) return rc;
+  SOS_HIP(hipMemcpyAsync(buf, ba->d_ar64.p, sizeof(double) * count, hipMemcpyDeviceToHost, st));
   SOS_HIP(hipStreamSynchronize(st));
-  tmp.release();
   return SOS_OK;
 }
 

@@ -14,6 +14,7 @@ import numpy as np
 
 AR_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)
 NTH_FN = C.CFUNCTYPE(C.c_float, C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_float)
+AR64_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_size_t)
 
 
 class _DevView:
@@ -48,13 +49,28 @@ def attach(sysm, dist, torch):
         local = np.ctypeslib.as_array(ptr, shape=(count,)).copy() if count > 0 else np.zeros(0, np.float32)
         return global_nth(dist, local, frac)
 
+    def _ar64(user, ptr, n):
+        # keyframe-rate fp64 sums (marginalisation prior update, mean |idepth| of the termination test): host buffer
+        buf = np.ctypeslib.as_array(ptr, shape=(n,))
+        on_gpu = dist.get_backend() == "nccl"
+        t = torch.from_numpy(buf.copy())
+        if on_gpu:
+            t = t.cuda()
+        dist.all_reduce(t)
+        buf[:] = t.cpu().numpy()
+
     sysm._ar_cb = AR_FN(_ar)  # keep the callbacks alive
     sysm._nth_cb = NTH_FN(_nth)
+    sysm._ar64_cb = AR64_FN(_ar64)
     L = host.load()
     L.sosf_set_hooks.argtypes = [C.c_void_p, AR_FN, NTH_FN, C.c_void_p]
     rc = L.sosf_set_hooks(sysm.h_, sysm._ar_cb, sysm._nth_cb, None)
     if rc != 0:
         raise RuntimeError(f"sosf_set_hooks failed: {rc}")
+    L.sosf_set_allreduce_f64_hook.argtypes = [C.c_void_p, AR64_FN]
+    rc = L.sosf_set_allreduce_f64_hook(sysm.h_, sysm._ar64_cb)
+    if rc != 0:
+        raise RuntimeError(f"sosf_set_allreduce_f64_hook failed: {rc}")
 
 
 class NativeComm:

@@ -45,11 +45,12 @@ def test_exchange_paths_equal_plain_run():
             pts = sysm.points()
             out.append((rmse, its, sysm.lastX().copy(), pts["idepth"].copy(),
                         [sysm.frame(f)["frameEnergyTH"] for f in range(win.n)]))
-            if mode != "hooks":  # keyframe-rate exchange: the marginalisation prior update is summed over ranks
-                ids = sysm.point_ids()
-                sel = ids[win.points["host"][ids] == 0][:16]
-                sysm.marginalize_points(sel)
-                priors.append(sysm.get_prior())
+            # keyframe-rate exchange: the marginalisation prior update is summed over ranks (native: RCCL fp64 all-reduce
+            # on the library's stream; hooks: the fp64 callback)
+            ids = sysm.point_ids()
+            sel = ids[win.points["host"][ids] == 0][:16]
+            sysm.marginalize_points(sel)
+            priors.append(sysm.get_prior())
             if mode == "native":
                 # a few pipelined loop bodies as bench.py runs them (prefetched accumulate incl. the all-reduce)
                 sysm.prepare()
@@ -69,7 +70,8 @@ def test_exchange_paths_equal_plain_run():
         assert np.abs(a[2] - hooks[2]).max() <= 1e-5
         assert np.abs(a[3] - hooks[3]).max() <= 1e-5 * np.abs(a[3]).max()
         assert np.allclose(a[4], hooks[4], rtol=1e-3)
-        assert np.array_equal(priors[0][0], priors[1][0]) and np.array_equal(priors[0][1], priors[1][1])
+        assert np.array_equal(priors[0][0], priors[2][0]) and np.array_equal(priors[0][1], priors[2][1])
         assert np.abs(priors[0][0]).max() > 0
+        assert np.abs(priors[0][0] - priors[1][0]).max() <= 1e-3 * np.abs(priors[0][0]).max()
     finally:
         dist.destroy_process_group()
