@@ -235,7 +235,7 @@ def tracker_timing(window, device):
     """CoarseTracker / ScaleOptimizer latencies on the device (the other half of the hot path):
     trackNewestCoarse and optimizeScale of a new frame against the newest keyframe of the same window type."""
     from sos_slam_amd import host, synth
-    from tests.test_oracle_math import se3_exp, se3_mul
+    from sos_slam_amd.synth import se3_exp12 as se3_exp, se3_mul12 as se3_mul
     win = synth.make_window(window, extra_frames=2)
     sysm = host.System.from_window(win, device=device)
     sysm.optimize(3)

@@ -53,6 +53,13 @@ int sosf_get_prior(sosf_system *sys, double *HM, double *bM);
 
 /* FullSystem::optimize(mnumOptIts) (FS/FullSystemOptimize.cpp:305-489): returns the RMSE through *rmse */
 int sosf_optimize(sosf_system *sys, int mnumOptIts, float *rmse, int *iterations);
+/* setting_forceAceptStep (util/settings.cpp:117, default on).  Off: every Gauss-Newton step is kept only when
+ * E_photometric + E_L + E_M decreased (FS/FullSystemOptimize.cpp:387-413); a rejected step is undone with loadSateBackup
+ * (:271-287) and the window linearised again at the old state.  The device side then runs the two-step protocol of
+ * sos_ba_linearize / sos_ba_apply_res (PointFrameResidual::J and EFResidual::J as separate buffers) instead of the fused
+ * calls.  sosf_get_rejected_steps: rejected steps of the last sosf_optimize. */
+int sosf_set_force_accept_step(sosf_system *sys, int on);
+int sosf_get_rejected_steps(sosf_system *sys, int *count);
 /* bench support: pack + resetOOB + linearizeAll(false) + applyRes, then single loop bodies
  * (FS/FullSystemOptimize.cpp:358-413) */
 int sosf_prepare(sosf_system *sys);
@@ -74,8 +81,16 @@ int sosf_get_point_ids(sosf_system *sys, int32_t *addIdx);
 /* per residual, in packing order (points -> residualsAll): state_state, isActive; removed = dropped by
  * the final linearizeAll(true) */
 int sosf_get_residuals(sosf_system *sys, int32_t *state_state, int32_t *isActive, int32_t *removed);
+/* identity of every residual of the current graph, same order as sosf_get_residuals: the running index under which
+ * its point was added and the frameID of its target keyframe (the "active index set" of the parity tests) */
+int sosf_get_residual_ids(sosf_system *sys, int32_t *pointAddIdx, int32_t *targetFrameID);
 int sosf_get_lastX(sosf_system *sys, double *x);
 int sosf_get_stats(sosf_system *sys, int *resInA, int *resInL, int *resInM);
+/* inspection: with keep on, every solveSystemF keeps what it assembled from the device's accumulation before the solve --
+ * H_top = HA + HL with the calibration / frame priors of the L stitch (OB/AccumulatedTopHessian.cpp:292-300), b_top, and
+ * the Schur side H_sc, b_sc, all (4 + 8 n) full symmetric row-major -- i.e. the inputs of OB/EnergyFunctional.cpp:1046-1171 */
+int sosf_keep_last_system(sosf_system *sys, int on);
+int sosf_get_last_system(sosf_system *sys, double *H_top, double *b_top, double *H_sc, double *b_sc);
 
 /* FullSystem::flagPointsForRemoval restricted to an explicit list + ef->marginalizePointsF
  * (FS/FullSystem.cpp:535-614, 909-912; OB/EnergyFunctional.cpp:891-936): the listed points (by the running

@@ -77,6 +77,23 @@ typedef struct orc_frame_init {
 
 void orc_host_init(orc_window *W, const orc_frame_init *frames, const double *calib_value_scaled,
                    const double *HM, const double *bM);
+/* rolling windows: explicit FEJ point per frame (evalPT pose + state_zero) and calibration value / value_zero */
+typedef struct orc_frame_init_ex {
+  double camToWorld[12];   /* evalPT */
+  double state[10];
+  double state_zero[10];
+  float ab_exposure;
+  int32_t frameID;
+  float frameEnergyTH;
+  int32_t pad;
+} orc_frame_init_ex;
+void orc_host_init_ex(orc_window *W, const orc_frame_init_ex *frames, const double *calib_value, const double *calib_value_zero,
+                      const double *HM, const double *bM);
+void orc_host_get_calib_value(orc_window *W, double *value4, double *value_zero4);
+void orc_host_get_evalpt(orc_window *W, int frame, double *camToWorld_evalPT12);
+int32_t *orc_num_good_residuals(orc_window *W);
+/* optimize() with setting_forceAceptStep selectable (FS/FullSystemOptimize.cpp:387-413: loadSateBackup on a rejected step) */
+float orc_optimize_ex(orc_window *W, int mnumOptIts, int nthreads, int forceAccept, int *iterations_out, int *rejected_out);
 /* runs optimize(mnumOptIts); returns RMSE; fills iteration count */
 float orc_optimize(orc_window *W, int mnumOptIts, int nthreads, int *iterations_out);
 /* one loop body of FS/FullSystemOptimize.cpp:358-413 (used by the CPU-baseline timing) */
@@ -141,6 +158,8 @@ void orc_tracker_calc_res_scale(orc_tracker *T, int lvl, const float *stereo_dI,
 void orc_tracker_calc_gs_scale(orc_tracker *T, int lvl, const float *t, const float *K1, float scale,
                                float *H, float *b);
 int orc_tracker_warp_n(orc_tracker *T);
+/* yardstick only: fp64 accumulation of the calcRes / calcGSSSE sums */
+void orc_tracker_set_truth_mode(orc_tracker *T, int on);
 /* loop-closure aligner: PoseEstimator's template (3-D points + per-level colours); calc_res then follows
  * src/LoopClosure/PoseEstimator.cpp:128-286, and orc_tracker_track with zero reference affine parameters and no abort
  * thresholds is PoseEstimator::estimate :288-495 up to its three acceptance tests (orc_tracker_last_inners for the third) */

@@ -61,6 +61,14 @@ def lib():
         L.orc_host_init.argtypes = [vp, vp, vp, vp, vp]
         L.orc_optimize.restype = C.c_float
         L.orc_optimize.argtypes = [vp, C.c_int, C.c_int, c_int_p]
+        L.orc_optimize_ex.restype = C.c_float
+        L.orc_optimize_ex.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_int_p, c_int_p]
+        L.orc_num_good_residuals.restype = vp
+        L.orc_num_good_residuals.argtypes = [vp]
+        L.orc_host_init_ex.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.orc_host_get_calib_value.argtypes = [vp, vp, vp]
+        L.orc_host_get_evalpt.argtypes = [vp, C.c_int, vp]
+        L.orc_tracker_set_truth_mode.argtypes = [vp, C.c_int]
         L.orc_gn_iteration.restype = C.c_int
         L.orc_gn_iteration.argtypes = [vp, C.c_int, C.c_int]
         L.orc_host_get_frame.argtypes = [vp, C.c_int, vp, vp, vp, vp]
@@ -430,6 +438,33 @@ class OracleWindow:
         rmse = self.L.orc_optimize(self.h, iters, nthreads, C.byref(it))
         return rmse, it.value
 
+    def optimize_ex(self, iters=6, force_accept=True, nthreads=1):
+        """optimize() with setting_forceAceptStep selectable; returns (rmse, iterations, rejected steps)."""
+        it, rej = C.c_int32(0), C.c_int32(0)
+        rmse = self.L.orc_optimize_ex(self.h, iters, nthreads, int(force_accept), C.byref(it), C.byref(rej))
+        return rmse, it.value, rej.value
+
+    def num_good_residuals(self):
+        return _view(self.L.orc_num_good_residuals(self.h), np.int32, (self.P,))
+
+    def host_init_ex(self, frames_ex, calib_value, calib_value_zero, HM, bM):
+        """rolling-window init: frames_ex = FRAME_INIT_EX_DTYPE records (evalPT pose, state, state_zero, ...)"""
+        fr = np.ascontiguousarray(frames_ex)
+        v = np.ascontiguousarray(calib_value, dtype=np.float64)
+        vz = np.ascontiguousarray(calib_value_zero, dtype=np.float64)
+        self.L.orc_host_init_ex(self.h, _p(fr), _p(v), _p(vz), _p(np.ascontiguousarray(HM, dtype=np.float64)),
+                                _p(np.ascontiguousarray(bM, dtype=np.float64)))
+
+    def calib_value(self):
+        v, vz = np.zeros(4), np.zeros(4)
+        self.L.orc_host_get_calib_value(self.h, _p(v), _p(vz))
+        return v, vz
+
+    def evalpt(self, f):
+        c = np.zeros(12)
+        self.L.orc_host_get_evalpt(self.h, f, _p(c))
+        return c
+
     def gn_iteration(self, iteration=0, nthreads=1):
         return self.L.orc_gn_iteration(self.h, iteration, nthreads)
 
@@ -569,6 +604,10 @@ class OracleTracker:
 
     def warp_n(self):
         return self.L.orc_tracker_warp_n(self.t)
+
+    def set_truth_mode(self, on=True):
+        """yardstick: fp64 accumulation of the calcRes / calcGSSSE sums"""
+        self.L.orc_tracker_set_truth_mode(self.t, int(on))
 
     def track(self, new_dI_levels, ref_ab, new_ab, ref_aff, lastToNew12, aff2, coarsest, minRes=None):
         ptrs, _ = self._pyr(new_dI_levels)

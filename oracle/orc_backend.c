@@ -152,6 +152,8 @@ float *orc_point_field(orc_window *W, int which) {
   }
 }
 
+int32_t *orc_num_good_residuals(orc_window *W) { return W->numGoodResiduals; }
+
 /* ================================================================================================
  * linearize -- FS/Residuals.cpp:77-271
  * ============================================================================================== */

@@ -15,6 +15,7 @@
 #include "orc_internal.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 
 /* reference defaults, util/settings.cpp:47-77 */
 #define SETTING_initialRotPrior 1e11f
@@ -222,6 +223,36 @@ void orc_host_init(orc_window *W, const orc_frame_init *frames, const double *ca
   orc_host_precalc(W);
 }
 
+/* Rolling-window entry: a window that has lived through earlier keyframes.  Every frame brings its own FEJ point
+ * (evalPT pose and state_zero differ from the current state), the calibration brings value and value_zero
+ * (FS/HessianBlocks.h:453-475), and the prior HM / bM is the one earlier marginalisations left. */
+void orc_host_init_ex(orc_window *W, const orc_frame_init_ex *frames, const double *calib_value, const double *calib_value_zero,
+                      const double *HM, const double *bM) {
+  int n = W->n, dim = 4 + 8 * n;
+  for (int i = 0; i < 4; i++) W->c_value_zero[i] = calib_value_zero[i];
+  calib_set_value(W, calib_value);
+  for (int f = 0; f < n; f++) {
+    orc_hframe *F = &W->hf[f];
+    F->camToWorld_evalPT = from12(frames[f].camToWorld);
+    F->ab_exposure = frames[f].ab_exposure;
+    F->frameID = frames[f].frameID;
+    for (int i = 0; i < 10; i++) F->state_zero[i] = frames[f].state_zero[i];
+    frame_set_state(F, frames[f].state);
+    memset(F->step, 0, sizeof(F->step));
+    frame_take_data(W, F);
+    W->frameEnergyTH[f] = frames[f].frameEnergyTH;
+  }
+  if (HM) memcpy(W->HM, HM, sizeof(double) * (size_t)dim * dim);
+  if (bM) memcpy(W->bM, bM, sizeof(double) * (size_t)dim);
+  set_adjoints(W);
+  orc_host_precalc(W);
+}
+void orc_host_get_calib_value(orc_window *W, double *value4, double *value_zero4) {
+  if (value4) memcpy(value4, W->c_value, sizeof(double) * 4);
+  if (value_zero4) memcpy(value_zero4, W->c_value_zero, sizeof(double) * 4);
+}
+void orc_host_get_evalpt(orc_window *W, int f, double *c2w_evalPT12) { to12(&W->hf[f].camToWorld_evalPT, c2w_evalPT12); }
+
 void orc_host_get_frame(orc_window *W, int f, double *c2w, double *state, double *state_zero, float *th) {
   if (c2w) to12(&W->hf[f].PRE_camToWorld, c2w);
   if (state) memcpy(state, W->hf[f].state, sizeof(double) * 10);
@@ -418,6 +449,97 @@ int orc_gn_iteration(orc_window *W, int iteration, int nthreads) {
   host_linearize_all(W, 0, nthreads);
   host_apply_res(W);
   return canbreak;
+}
+
+/* calcLEnergyF_MT (OB/EnergyFunctional.cpp:626-642) and calcMEnergyF (:553-561): only evaluated when
+ * setting_forceAceptStep is off (FS/FullSystemOptimize.cpp:289-296, 498-504) */
+static double host_calc_lenergy(orc_window *W) {
+  double E = 0;
+  for (int f = 0; f < W->n; f++)
+    for (int i = 0; i < 8; i++) E += W->hf[f].delta_prior[i] * W->hf[f].prior[i] * W->hf[f].delta_prior[i];
+  float e4 = 0;
+  for (int i = 0; i < 4; i++) e4 += W->cDeltaF[i] * (float)W->prm.initialCalibHessian * W->cDeltaF[i];
+  E += e4;
+  return E + orc_calc_lenergy(W);
+}
+static double host_calc_menergy(orc_window *W) {
+  int n = W->n, dim = 4 + 8 * n;
+  double *delta = (double *)malloc(sizeof(double) * dim);
+  for (int i = 0; i < 4; i++) delta[i] = (double)W->cDeltaF[i];
+  for (int h = 0; h < n; h++)
+    for (int i = 0; i < 8; i++) delta[4 + 8 * h + i] = W->hf[h].delta[i];
+  double e = 0;
+  for (int i = 0; i < dim; i++) {
+    double s = 2 * W->bM[i];
+    for (int j = 0; j < dim; j++) s += W->HM[(size_t)i * dim + j] * delta[j];
+    e += delta[i] * s;
+  }
+  free(delta);
+  return e;
+}
+
+static void load_state_backup(orc_window *W) { /* loadSateBackup, FS/FullSystemOptimize.cpp:271-287 */
+  calib_set_value(W, W->c_value_backup);
+  for (int f = 0; f < W->n; f++) frame_set_state(&W->hf[f], W->hf[f].state_backup);
+  for (int p = 0; p < W->P; p++) {
+    W->pts[p].idepth_scaled = W->idepth_backup[p];
+    W->pts[p].idepth_zero_scaled = W->idepth_backup[p];
+  }
+  orc_host_precalc(W);
+}
+
+/* FullSystem::optimize with setting_forceAceptStep selectable (FS/FullSystemOptimize.cpp:305-425): with forceAccept == 0
+ * a step is kept only when E_photometric + E_L + E_M decreases; otherwise the backup is restored and the window is
+ * linearised again at the old state.  rejected_out: number of rejected steps. */
+float orc_optimize_ex(orc_window *W, int mnumOptIts, int nthreads, int forceAccept, int *iters_out, int *rejected_out) {
+  int n = W->n;
+  if (iters_out) *iters_out = 0;
+  if (rejected_out) *rejected_out = 0;
+  if (n < 2) return 0;
+  if (n < 3) mnumOptIts = 20;
+  if (n < 4) mnumOptIts = 15;
+  orc_reset_oob(W);
+  double lastEnergy = host_linearize_all(W, 0, nthreads);
+  double lastEnergyL = forceAccept ? 0 : host_calc_lenergy(W);
+  double lastEnergyM = forceAccept ? 0 : host_calc_menergy(W);
+  host_apply_res(W);
+  int it = 0, rej = 0;
+  for (int iteration = 0; iteration < mnumOptIts; iteration++) {
+    backup_state(W);
+    solve_system(W, nthreads);
+    int canbreak = do_step_from_backup(W);
+    double newEnergy = host_linearize_all(W, 0, nthreads);
+    double newEnergyL = forceAccept ? 0 : host_calc_lenergy(W);
+    double newEnergyM = forceAccept ? 0 : host_calc_menergy(W);
+    if (getenv("ORC_DEBUG"))
+      fprintf(stderr, "[orc_optimize_ex] it %d new %.9g (%.9g %.9g %.9g) last %.9g (%.9g %.9g %.9g)\n", iteration, newEnergy + newEnergyL + newEnergyM,
+              newEnergy, newEnergyL, newEnergyM, lastEnergy + lastEnergyL + lastEnergyM, lastEnergy, lastEnergyL, lastEnergyM);
+    if (forceAccept || (newEnergy + newEnergyL + newEnergyM < lastEnergy + lastEnergyL + lastEnergyM)) {
+      host_apply_res(W);
+      lastEnergy = newEnergy; lastEnergyL = newEnergyL; lastEnergyM = newEnergyM;
+    } else {
+      load_state_backup(W);
+      lastEnergy = host_linearize_all(W, 0, nthreads);
+      lastEnergyL = host_calc_lenergy(W);
+      lastEnergyM = host_calc_menergy(W);
+      rej++;
+    }
+    it++;
+    if (canbreak && iteration >= SETTING_minOptIterations) break;
+  }
+  if (iters_out) *iters_out = it;
+  if (rejected_out) *rejected_out = rej;
+  orc_hframe *L = &W->hf[n - 1];
+  double nz[10];
+  memset(nz, 0, sizeof(nz));
+  nz[6] = L->state[6]; nz[7] = L->state[7];
+  L->camToWorld_evalPT = L->PRE_camToWorld;
+  frame_set_state(L, nz);
+  memcpy(L->state_zero, nz, sizeof(nz));
+  set_adjoints(W);
+  orc_host_precalc(W);
+  lastEnergy = host_linearize_all(W, 1, nthreads);
+  return sqrtf((float)(lastEnergy / (8 * W->resInA)));
 }
 
 float orc_optimize(orc_window *W, int mnumOptIts, int nthreads, int *iters_out) {

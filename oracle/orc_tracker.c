@@ -82,6 +82,7 @@ struct orc_tracker {
   int loop_mode, l_n;
   float *l_xyz, *l_col[SOS_PYR_LEVELS];
   int lastInners[SOS_PYR_LEVELS];
+  int truth; /* yardstick only: sums of calcRes / calcGSSSE accumulated in fp64 (not the reference's behaviour) */
 };
 
 orc_tracker *orc_tracker_create(const sos_params *prm, int w, int h) {
@@ -221,6 +222,7 @@ void orc_tracker_scale_depth(orc_tracker *T, float scale) { /* FS/CoarseTracker.
     for (int p = 0; p < T->pc_n[l]; p++) T->pc_idepth[l][p] /= scale;
 }
 int orc_tracker_warp_n(orc_tracker *T) { return T->buf_n; }
+void orc_tracker_set_truth_mode(orc_tracker *T, int on) { T->truth = on; }
 
 static inline void interp33t(const float *mat, float x, float y, int width, float *out) {
   int ix = (int)x, iy = (int)y;
@@ -235,6 +237,7 @@ static inline void interp33t(const float *mat, float x, float y, int width, floa
 static void calc_res(orc_tracker *T, int lvl, const float *dINewl, const float *RKi, const float *t, float aff0,
                      float aff1, const float *K1, float scale, int scaleMode, float cutoffTH, double *rs) {
   float E = 0;
+  double Ed = 0, sT = 0, sRT = 0; /* truth-mode (fp64) shadows of E and the flow sums */
   int numTermsInE = 0, numTermsInWarped = 0, numSaturated = 0;
   int wl = T->w[lvl], hl = T->h[lvl];
   float fxl = scaleMode ? K1[0] : T->fx[lvl], fyl = scaleMode ? K1[1] : T->fy[lvl];
@@ -274,6 +277,8 @@ static void calc_res(orc_tracker *T, int lvl, const float *dINewl, const float *
       sumSquaredShiftT += (KuT2 - x) * (KuT2 - x) + (KvT2 - y) * (KvT2 - y);
       sumSquaredShiftRT += (Ku - x) * (Ku - x) + (Kv - y) * (Kv - y);
       sumSquaredShiftRT += (Ku3 - x) * (Ku3 - x) + (Kv3 - y) * (Kv3 - y);
+      sT += (double)((KuT - x) * (KuT - x) + (KvT - y) * (KvT - y)) + (double)((KuT2 - x) * (KuT2 - x) + (KvT2 - y) * (KvT2 - y));
+      sRT += (double)((Ku - x) * (Ku - x) + (Kv - y) * (Kv - y)) + (double)((Ku3 - x) * (Ku3 - x) + (Kv3 - y) * (Kv3 - y));
       sumSquaredShiftNum += 2;
     }
     if (!(Ku > 2 && Kv > 2 && Ku < wl - 3 && Kv < hl - 3 && new_idepth > 0)) continue;
@@ -285,10 +290,12 @@ static void calc_res(orc_tracker *T, int lvl, const float *dINewl, const float *
     float hw = fabsf(residual) < huber ? 1 : huber / fabsf(residual); /* std::fabs(float) in the C++ reference */
     if (fabsf(residual) > cutoffTH) {
       E += maxEnergy;
+      Ed += (double)maxEnergy;
       numTermsInE++;
       numSaturated++;
     } else {
       E += hw * residual * residual * (2 - hw);
+      Ed += (double)(hw * residual * residual * (2 - hw));
       numTermsInE++;
       int k = numTermsInWarped;
       T->buf[0][k] = scaleMode ? rx0 : new_idepth;
@@ -313,6 +320,11 @@ static void calc_res(orc_tracker *T, int lvl, const float *dINewl, const float *
   rs[3] = 0;
   rs[4] = sumSquaredShiftRT / (sumSquaredShiftNum + 0.1);
   rs[5] = numSaturated / (float)numTermsInE;
+  if (T->truth) {
+    rs[0] = Ed;
+    rs[2] = sT / ((double)sumSquaredShiftNum + 0.1);
+    rs[4] = sRT / ((double)sumSquaredShiftNum + 0.1);
+  }
 }
 
 /* PoseEstimator::calcRes, src/LoopClosure/PoseEstimator.cpp:128-286 */
@@ -432,6 +444,8 @@ void orc_tracker_calc_gs(orc_tracker *T, int lvl, float a, float b0, double *H_o
   acc_sse A;
   memset(&A, 0, sizeof(A));
   A.nvals = 45;
+  double Hd[81];
+  memset(Hd, 0, sizeof(Hd));
   float fxl = T->fx[lvl], fyl = T->fy[lvl];
   int n = T->buf_n;
   for (int i = 0; i < n; i += 4) {
@@ -452,7 +466,7 @@ void orc_tracker_calc_gs(orc_tracker *T, int lvl, float a, float b0, double *H_o
       int idx = 0;
       for (int r = 0; r < 9; r++) { /* updateSSE_eighted */
         float Jw = J[r] * w;
-        for (int c = r; c < 9; c++) { A.D[4 * idx + l] += Jw * J[c]; idx++; }
+        for (int c = r; c < 9; c++) { A.D[4 * idx + l] += Jw * J[c]; Hd[9 * r + c] += (double)(Jw * J[c]); idx++; }
       }
     }
     A.numIn1++;
@@ -472,6 +486,12 @@ void orc_tracker_calc_gs(orc_tracker *T, int lvl, float a, float b0, double *H_o
     for (int c = 0; c < 8; c++) H_out[8 * r + c] = (double)Hf[9 * r + c] * inv;
     b_out[r] = (double)Hf[9 * r + 8] * inv;
   }
+  if (T->truth) { /* yardstick: the same fp32 products summed in fp64 */
+    for (int r = 0; r < 8; r++) {
+      for (int c = 0; c < 8; c++) H_out[8 * r + c] = Hd[9 * (r < c ? r : c) + (r < c ? c : r)] * inv;
+      b_out[r] = Hd[9 * r + 8] * inv;
+    }
+  }
   const double sc[8] = {SOS_SCALE_XI_ROT, SOS_SCALE_XI_ROT, SOS_SCALE_XI_ROT, SOS_SCALE_XI_TRANS,
                         SOS_SCALE_XI_TRANS, SOS_SCALE_XI_TRANS, SOS_SCALE_A, SOS_SCALE_B}; /* :598-609 */
   for (int r = 0; r < 8; r++) {
@@ -486,6 +506,7 @@ void orc_tracker_calc_gs_scale(orc_tracker *T, int lvl, const float *t, const fl
   acc_sse A;
   memset(&A, 0, sizeof(A));
   A.nvals = 3;
+  double d00 = 0, d01 = 0;
   int n = T->buf_n;
   float tx = t[0], ty = t[1], tz = t[2];
   for (int i = 0; i < n; i += 4) {
@@ -501,6 +522,8 @@ void orc_tracker_calc_gs_scale(orc_tracker *T, int lvl, const float *t, const fl
       A.D[0 + l] += J0w * J0;
       A.D[4 + l] += J0w * J1;
       A.D[8 + l] += J1w * J1;
+      d00 += (double)(J0w * J0);
+      d01 += (double)(J0w * J1);
     }
     A.numIn1++;
     sse_shift(&A, 0);
@@ -510,6 +533,7 @@ void orc_tracker_calc_gs_scale(orc_tracker *T, int lvl, const float *t, const fl
   float h01 = A.D1m[4] + A.D1m[5] + A.D1m[6] + A.D1m[7];
   *H_out = h00 * (1.0f / n);
   *b_out = h01 * (1.0f / n);
+  if (T->truth) { *H_out = (float)(d00 * (1.0 / n)); *b_out = (float)(d01 * (1.0 / n)); }
 }
 
 /* util/NumType.h:156-168 */

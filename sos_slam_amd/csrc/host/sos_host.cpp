@@ -466,6 +466,14 @@ int EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib, boo
       b[4 + 8 * h + i] += frames[h]->prior[i] * frames[h]->delta_prior[i];
     }
   const VecX delta = getStitchedDeltaF();
+  if (keepSystem) {  // inspection (sosf_get_last_system): the assembled H_top / b_top (priors in) and H_sc / b_sc, mirrored
+    keptH = H; keptHsc = Hsc; keptb = b; keptbsc = bsc;
+    for (int i = 0; i < dim; i++)
+      for (int j = i + 1; j < dim; j++) {
+        keptH[(size_t)j * dim + i] = keptH[(size_t)i * dim + j];
+        keptHsc[(size_t)j * dim + i] = keptHsc[(size_t)i * dim + j];
+      }
+  }
   if (imuSettings) {  // setting_enable_imu && HCalib->imu_initialized: the IMU branch, OB/EnergyFunctional.cpp:1053-1171
     for (int i = 0; i < dim; i++)  // the fused device call delivers the upper triangle only
       for (int j = i + 1; j < dim; j++) {
@@ -996,7 +1004,11 @@ int FullSystem::prepare() {  // FS/FullSystemOptimize.cpp:316-344
   if (rc) return rc;
   const double t2 = now_s();
   sos_ba_reset_oob(ef->ba);
-  linearizeAll(false);
+  prepareEnergy = linearizeAll(false);
+  if (!forceAcceptStep) {  // lastEnergyL / lastEnergyM of FS/FullSystemOptimize.cpp:335-336, evaluated before the first applyRes
+    prepareEnergyL = ef->calcLEnergyF_MT();
+    prepareEnergyM = ef->calcMEnergyF();
+  }
   applyRes();
   if (tmg) fprintf(stderr, "[prepare] packWindow %.0f us, precalc+pushState %.0f us, resetOOB+linearize+apply %.0f us\n", (t1 - t0) * 1e6, (t2 - t1) * 1e6, (now_s() - t2) * 1e6);
   return lastError;
@@ -1050,6 +1062,46 @@ bool FullSystem::gnIteration(int iteration, bool mayContinue) {  // :358-413 wit
   return canbreak;
 }
 
+void FullSystem::loadSateBackup() {  // FS/FullSystemOptimize.cpp:271-287 (IMU off)
+  HCalib.setValue(HCalib.value_backup);
+  for (FrameHessian *fh : frameHessians) {
+    fh->setState(fh->state_backup);
+    for (PointHessian *ph : fh->pointHessians) {
+      ph->setIdepth(ph->idepth_backup);
+      ph->setIdepthZero(ph->idepth_backup);
+    }
+  }
+  ef->EFDeltaValid = false;
+  setPrecalcValues();
+}
+
+// One loop body of FS/FullSystemOptimize.cpp:358-413 with setting_forceAceptStep OFF: the step is evaluated with the
+// two-step device protocol (sos_ba_linearize fills PointFrameResidual::J, nothing is committed), accepted with applyRes
+// when the total energy decreased, otherwise undone with loadSateBackup and the window is linearised again at the old state.
+bool FullSystem::gnIterationChecked(int iteration, double &lastE, double &lastEL, double &lastEM) {
+  backupState();
+  if (rcAcc(ef->solveSystemF(iteration, 1e-1, &HCalib, false)) != SOS_OK) {
+    isLost = true;
+    return true;
+  }
+  const bool canbreak = doStepFromBackup(1, 1, 1, 1, 1, false);
+  rcAcc(ef->pushState(&HCalib, false));
+  const double newE = linearizeAll(false);
+  const double newEL = ef->calcLEnergyF_MT(), newEM = ef->calcMEnergyF();
+  if (newE + newEL + newEM < lastE + lastEL + lastEM) {
+    applyRes();
+    lastE = newE; lastEL = newEL; lastEM = newEM;
+  } else {
+    loadSateBackup();
+    rcAcc(ef->pushState(&HCalib, false));
+    lastE = linearizeAll(false);
+    lastEL = ef->calcLEnergyF_MT();
+    lastEM = ef->calcMEnergyF();
+    stepsRejected++;
+  }
+  return canbreak;
+}
+
 float FullSystem::optimize(int mnumOptIts, int *iterations) {
   if (iterations) *iterations = 0;
   if (frameHessians.size() < 2) return 0;
@@ -1060,8 +1112,10 @@ float FullSystem::optimize(int mnumOptIts, int *iterations) {
   if (prepare() != SOS_OK) return NAN;
   const double tp1 = now_s();
   int it = 0;
+  stepsRejected = 0;
+  double lastE = prepareEnergy, lastEL = prepareEnergyL, lastEM = prepareEnergyM;
   for (int iteration = 0; iteration < mnumOptIts; iteration++) {
-    const bool canbreak = gnIteration(iteration, iteration + 1 < mnumOptIts);
+    const bool canbreak = forceAcceptStep ? gnIteration(iteration, iteration + 1 < mnumOptIts) : gnIterationChecked(iteration, lastE, lastEL, lastEM);
     it++;
     if (canbreak && iteration >= setting_minOptIterations) break;
   }
@@ -1596,6 +1650,16 @@ extern "C" int sosf_gn_iteration(sosf_system *s, int iteration, int *canbreak) {
   if (canbreak) *canbreak = cb ? 1 : 0;
   return s->fs->lastError;
 }
+extern "C" int sosf_set_force_accept_step(sosf_system *s, int on) {
+  if (!s) return SOS_ERR_ARG;
+  s->fs->forceAcceptStep = on != 0;
+  return SOS_OK;
+}
+extern "C" int sosf_get_rejected_steps(sosf_system *s, int *count) {
+  if (!s || !count) return SOS_ERR_ARG;
+  *count = s->fs->stepsRejected;
+  return SOS_OK;
+}
 extern "C" int sosf_set_pipeline(sosf_system *s, int on) {
   if (!s) return SOS_ERR_ARG;
   s->fs->pipelineAlways = on != 0;
@@ -1658,9 +1722,37 @@ extern "C" int sosf_get_residuals(sosf_system *s, int32_t *state_state, int32_t 
       }
   return (int)k >= 0 ? SOS_OK : SOS_ERR_STATE;
 }
+extern "C" int sosf_get_residual_ids(sosf_system *s, int32_t *pointAddIdx, int32_t *targetFrameID) {
+  if (!s) return SOS_ERR_ARG;
+  size_t k = 0;
+  for (FrameHessian *fh : s->fs->frameHessians)
+    for (EFPoint *p : fh->efFrame->points)
+      for (EFResidual *r : p->residualsAll) {
+        if (pointAddIdx) pointAddIdx[k] = p->data->userIdx;
+        if (targetFrameID) targetFrameID[k] = r->target->frameID;
+        k++;
+      }
+  return SOS_OK;
+}
 extern "C" int sosf_get_lastX(sosf_system *s, double *x) {
   if (!s || !x) return SOS_ERR_ARG;
   std::memcpy(x, s->fs->ef->lastX.data(), sizeof(double) * s->fs->ef->lastX.size());
+  return SOS_OK;
+}
+extern "C" int sosf_keep_last_system(sosf_system *s, int on) {
+  if (!s) return SOS_ERR_ARG;
+  s->fs->ef->keepSystem = on != 0;
+  return SOS_OK;
+}
+extern "C" int sosf_get_last_system(sosf_system *s, double *H_top, double *b_top, double *H_sc, double *b_sc) {
+  if (!s) return SOS_ERR_ARG;
+  EnergyFunctional *ef = s->fs->ef;
+  const size_t dim = (size_t)(SOS_CPARS + 8 * ef->nFrames);
+  if (ef->keptH.size() != dim * dim) return SOS_ERR_STATE;
+  if (H_top) std::memcpy(H_top, ef->keptH.data(), sizeof(double) * dim * dim);
+  if (b_top) std::memcpy(b_top, ef->keptb.data(), sizeof(double) * dim);
+  if (H_sc) std::memcpy(H_sc, ef->keptHsc.data(), sizeof(double) * dim * dim);
+  if (b_sc) std::memcpy(b_sc, ef->keptbsc.data(), sizeof(double) * dim);
   return SOS_OK;
 }
 extern "C" int sosf_get_stats(sosf_system *s, int *a, int *l, int *m) {

@@ -180,6 +180,9 @@ class EnergyFunctional {  // OB/EnergyFunctional.h:52-154
   void makeIDX();
   void setDeltaF(CalibHessian *HCalib, bool points = true);
   MatXX scrHA, scrHsc;  // solveSystemF scratch
+  bool keepSystem = false;  // sosf_keep_last_system: solveSystemF keeps a copy of what it assembled
+  MatXX keptH, keptHsc;
+  VecX keptb, keptbsc;
   VecX scrbA, scrbsc;
   void setAdjointsF(CalibHessian *HCalib);
 
@@ -250,6 +253,10 @@ class FullSystem {
   bool gnIteration(int iteration, bool mayContinue = false);  // :358-413
   sos_comm *comm = nullptr;     // RCCL communicator attached to the backend (multi-GPU), not owned
   bool pipelineAlways = false;  // flat API: the caller iterates regardless of canbreak
+  bool forceAcceptStep = true;  // setting_forceAceptStep (util/settings.cpp:117); false: energy-checked steps with loadSateBackup
+  int stepsRejected = 0;        // rejected steps of the last optimize()
+  void loadSateBackup();                                      // FS/FullSystemOptimize.cpp:271-287
+  bool gnIterationChecked(int iteration, double &lastE, double &lastEL, double &lastEM);  // :358-413, forceAceptStep off
   void setPrecalcValues(bool points = true);                  // FS/FullSystem.cpp:1099-1107
   void removeOutliers();                                      // FS/FullSystemOptimize.cpp:507-526
   int marginalizePoints(const std::vector<PointHessian *> &pts);  // flagPointsForRemoval core + marginalizePointsF
@@ -273,6 +280,7 @@ class FullSystem {
   void applyRes();                                            // :79-83
   void backupState();                                         // :260-269
   float backupSumNID = 0, backupNumID = 0;
+  double prepareEnergy = 0, prepareEnergyL = 0, prepareEnergyM = 0;
   int rcAcc(int rc) { if (rc != SOS_OK && lastError == SOS_OK) lastError = rc; return rc; }
   bool doStepFromBackup(float stepfacC, float stepfacT, float stepfacR, float stepfacA, float stepfacD,
                         bool pointsOnDevice = false);  // :185-257

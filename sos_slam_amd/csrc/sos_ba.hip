@@ -17,10 +17,13 @@
 // Data layout in HBM (DESIGN.md "data layout"):
 //   residuals are sorted by (isLinearized, pair = host + n*target) and padded per pair to tiles of 32;
 //   J[tile][72 planes][32] floats (9216 B per tile, written by ONE linearize block as one contiguous
-//   span); JpJd[s][8]; everything else SoA over the sorted index s.  PointFrameResidual::J and
-//   EFResidual::J share one buffer: with setting_forceAceptStep (util/settings.cpp:58) every linearize
-//   is followed by applyRes, and a residual's J is only ever read while it is active, i.e. after the
-//   apply that would have swapped it in.
+//   span); JpJd[s][8]; everything else SoA over the sorted index s.  The fused Gauss-Newton calls
+//   (linearize + applyRes in one launch, the default setting_forceAceptStep path, util/settings.cpp:117)
+//   write EFResidual::J directly.  The two-step protocol -- sos_ba_linearize, then sos_ba_apply_res or
+//   not (a rejected step, FS/FullSystemOptimize.cpp:387-413) -- keeps the reference's two Jacobians per
+//   residual: the linearisation fills PointFrameResidual::J (d_Jnew, with its provisional JpJdF / point
+//   terms) and k_commit_new moves it into EFResidual::J (d_J) for the residuals that end up IN, the swap
+//   of FS/Residuals.cpp:304-321.
 //
 // fp32 arithmetic convention: no FMA contraction (-ffp-contract=off), correctly rounded / and sqrt
 // (hipcc default), sums in the order of the reference source; the 8-pixel pattern sums are evaluated
@@ -1171,6 +1174,27 @@ __global__ void k_apply_res(BaDev d) {
     jp[0] = jp[1] = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 *pt = reinterpret_cast<float4 *>(d.s_pterm + 8 * (size_t)s);
     pt[0] = pt[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+// PointFrameResidual::applyRes(true), Jacobian half (FS/Residuals.cpp:311-319: std::swap(J, efResidual->J) + takeDataF for
+// the residuals whose new state is IN): one block per tile copies the columns of the committed residuals from the
+// scratch tile (PointFrameResidual::J) into the applied tile (EFResidual::J), with their JpJdF rows and point terms.
+// Runs BEFORE k_apply_res (it reads the states that kernel overwrites).
+__global__ __launch_bounds__(256) void k_commit_new(BaDev d, const float *__restrict__ Jnew, const float *__restrict__ JpJdNew,
+                                                     const float *__restrict__ ptermNew) {
+  const int tile = blockIdx.x, r = threadIdx.x & 31;
+  const int s = tile * SOS_TILE + r;
+  const bool commit = d.s_point[s] >= 0 && !(d.s_flags[s] & DF_LINEARIZED) && d.s_state[s] != SOS_RES_OOB &&
+                      d.s_newstate[s] == SOS_RES_IN;
+  if (!commit) return;
+  const size_t base = (size_t)tile * SOS_TILE_FLOATS + r;
+  for (int pl = threadIdx.x >> 5; pl < SOS_JPLANES; pl += 8) d.J[base + (size_t)pl * SOS_TILE] = Jnew[base + (size_t)pl * SOS_TILE];
+  if (threadIdx.x < 32) {
+    const float4 *a = reinterpret_cast<const float4 *>(JpJdNew + 8 * (size_t)s), *b = reinterpret_cast<const float4 *>(ptermNew + 8 * (size_t)s);
+    float4 *ja = reinterpret_cast<float4 *>(d.JpJd + 8 * (size_t)s), *pb = reinterpret_cast<float4 *>(d.s_pterm + 8 * (size_t)s);
+    ja[0] = a[0]; ja[1] = a[1];
+    pb[0] = b[0]; pb[1] = b[1];
   }
 }
 
@@ -2335,6 +2359,8 @@ struct sos_ba {
   DevBuf<char> d_outpack;  // [tile_esum ntilesA doubles | newest energies | point steps]
   DevBuf<double> d_C;      // stitch stage-1 products
   DevBuf<double> d_ar64;   // sos_ba_allreduce_f64 staging
+  DevBuf<float> d_Jnew, d_JpJd_new, d_pterm_new;  // PointFrameResidual::J side of the two-step protocol (lazily allocated)
+  bool pending_new = false;  // a sos_ba_linearize result waits in d_Jnew for sos_ba_apply_res
   size_t st_pre = 0, st_adh = 0, st_cd = 0, st_th = 0, st_xc = 0, st_xad = 0, st_floats = 0;
   bool resub_pending = false;  // sos_ba_gn_resub enqueued the back-substitution of the step sos_ba_gn_step is about to take
   size_t out_esum = 0, out_newest = 0, out_step = 0, out_bytes = 0;
@@ -2414,7 +2440,7 @@ extern "C" int sos_ba_destroy(sos_ba *ba) {
     b->release();
   ba->d_rawjac.release();
   ba->d_t_pre.release(); ba->d_t_img.release(); ba->d_t_ht.release();
-  ba->d_p_list2.release(); ba->d_p_list16.release(); ba->d_r_geo.release(); ba->d_r_cw.release(); ba->d_stage.release(); ba->d_outpack.release(); ba->d_C.release(); ba->d_ar64.release();
+  ba->d_p_list2.release(); ba->d_p_list16.release(); ba->d_r_geo.release(); ba->d_r_cw.release(); ba->d_stage.release(); ba->d_outpack.release(); ba->d_C.release(); ba->d_ar64.release(); ba->d_Jnew.release(); ba->d_JpJd_new.release(); ba->d_pterm_new.release();
   if (ba->pin) hipHostFree(ba->pin);
   if (ba->ev_step) hipEventDestroy(ba->ev_step);
   if (ba->pin_newest) hipHostFree(ba->pin_newest);
@@ -3020,8 +3046,18 @@ extern "C" int sos_ba_linearize(sos_ba *ba, const float *frameEnergyTH, double *
   SOS_HIP(hipSetDevice(c->device));
   hipStream_t st = c->stream;
   SOS_HIP(hipMemcpyAsync(stg(ba, ba->st_th), frameEnergyTH, sizeof(float) * ba->n, hipMemcpyHostToDevice, st));
-  launch_linearize(ba, 0);
-  ba->J_valid = true;
+  {  // the new Jacobians go to the PointFrameResidual::J side; EFResidual::J changes at sos_ba_apply_res only
+    const size_t Rp = (size_t)ba->Rpad;
+    if (ba->d_Jnew.ensure((size_t)(ba->ntiles ? ba->ntiles : 1) * SOS_TILE_FLOATS) || ba->d_JpJd_new.ensure(Rp * 8 + 8) ||
+        ba->d_pterm_new.ensure(Rp * 8 + 8))
+      return SOS_ERR_NOMEM;
+    BaDev dv = ba->dev;
+    dv.J = ba->d_Jnew.p;
+    dv.JpJd = ba->d_JpJd_new.p;
+    dv.s_pterm = ba->d_pterm_new.p;
+    launch_lin_kernel(ba, dv, 0, nullptr);
+    ba->pending_new = true;
+  }
   if (energySum) {
     k_sum_ret<<<1, 1024, 0, st>>>(ba->d_s_ret.p, ba->ntilesA * SOS_TILE, ba->d_scalar.p);
     SOS_HIP(hipMemcpyAsync(energySum, ba->d_scalar.p, sizeof(double), hipMemcpyDeviceToHost, st));
@@ -3050,6 +3086,11 @@ extern "C" int sos_ba_apply_res(sos_ba *ba) {
   if (!ba || !ba->have_window) return SOS_ERR_STATE;
   SOS_HIP(hipSetDevice(ba->ctx->device));
   const int nthr = ba->ntilesA * SOS_TILE;
+  if (nthr > 0 && ba->pending_new) {
+    k_commit_new<<<ba->ntilesA, 256, 0, ba->ctx->stream>>>(ba->dev, ba->d_Jnew.p, ba->d_JpJd_new.p, ba->d_pterm_new.p);
+    ba->J_valid = true;  // every residual that is active after this apply has just received its Jacobian
+  }
+  ba->pending_new = false;
   if (nthr > 0) k_apply_res<<<divup(nthr, 256), 256, 0, ba->ctx->stream>>>(ba->dev);
   SOS_HIP(hipGetLastError());
   return SOS_OK;
@@ -3586,13 +3627,15 @@ extern "C" int sos_ba_update_point_priors(sos_ba *ba, const int32_t *pointIdx, c
 
 // ---- inspection ---------------------------------------------------------------------------------
 extern "C" int sos_ba_get_jacobian(sos_ba *ba, int residIdx, int which, sos_rawjac *out) {
-  if (ba && ba->have_window && ba->have_state) ensure_J(ba);
-  (void)which;  // one shared buffer, see the header comment of this file
+  if (ba && ba->have_window && ba->have_state && which == 0) ensure_J(ba);
   if (!ba || !ba->have_window || !out || residIdx < 0 || residIdx >= ba->R) return SOS_ERR_ARG;
+  if (which != 0 && !ba->d_Jnew.p) return SOS_ERR_STATE;  // no sos_ba_linearize has filled PointFrameResidual::J yet
   SOS_HIP(hipSetDevice(ba->ctx->device));
   int rc = ba->d_rawjac.ensure(1);
   if (rc) return rc;
-  k_get_jac<<<1, 64, 0, ba->ctx->stream>>>(ba->dev, ba->h_s_of_orig[residIdx], ba->d_rawjac.p);
+  BaDev dv = ba->dev;
+  if (which != 0) dv.J = ba->d_Jnew.p;
+  k_get_jac<<<1, 64, 0, ba->ctx->stream>>>(dv, ba->h_s_of_orig[residIdx], ba->d_rawjac.p);
   SOS_HIP(hipMemcpyAsync(out, ba->d_rawjac.p, sizeof(sos_rawjac), hipMemcpyDeviceToHost, ba->ctx->stream));
   SOS_HIP(hipStreamSynchronize(ba->ctx->stream));
   return SOS_OK;

@@ -45,6 +45,11 @@ def load():
     L.sosf_get_point_ids.argtypes = [vp, vp]
     L.sosf_get_residuals.argtypes = [vp, vp, vp, vp]
     L.sosf_get_lastX.argtypes = [vp, vp]
+    L.sosf_get_residual_ids.argtypes = [vp, vp, vp]
+    L.sosf_keep_last_system.argtypes = [vp, ci]
+    L.sosf_get_last_system.argtypes = [vp, vp, vp, vp, vp]
+    L.sosf_set_force_accept_step.argtypes = [vp, ci]
+    L.sosf_get_rejected_steps.argtypes = [vp, C.POINTER(ci)]
     L.sosf_get_stats.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
     L.sosf_marginalize_points.argtypes = [vp, vp, ci]
     L.sosf_drop_points.argtypes = [vp, vp, ci]
@@ -255,6 +260,31 @@ class System:
         st, act, rem = [np.zeros(R, dtype=np.int32) for _ in range(3)]
         _chk(self.L.sosf_get_residuals(self.h_, _p(st), _p(act), _p(rem)), "sosf_get_residuals")
         return dict(state_state=st, isActive=act)
+
+    def keep_last_system(self, on=True):
+        _chk(self.L.sosf_keep_last_system(self.h_, int(on)), "sosf_keep_last_system")
+
+    def last_system(self):
+        """(H_top, b_top, H_sc, b_sc) the last solveSystemF assembled (priors of the L stitch included)"""
+        dim = 4 + 8 * self.counts()[0]
+        H, Hsc, b, bsc = np.zeros((dim, dim)), np.zeros((dim, dim)), np.zeros(dim), np.zeros(dim)
+        _chk(self.L.sosf_get_last_system(self.h_, _p(H), _p(b), _p(Hsc), _p(bsc)), "sosf_get_last_system")
+        return H, b, Hsc, bsc
+
+    def residual_ids(self):
+        """(point add-index, target frameID) per residual of the current graph, order of residuals()"""
+        R = self.counts()[2]
+        pi, tf = np.zeros(R, dtype=np.int32), np.zeros(R, dtype=np.int32)
+        _chk(self.L.sosf_get_residual_ids(self.h_, _p(pi), _p(tf)), "sosf_get_residual_ids")
+        return pi, tf
+
+    def set_force_accept_step(self, on=True):
+        _chk(self.L.sosf_set_force_accept_step(self.h_, int(on)), "sosf_set_force_accept_step")
+
+    def rejected_steps(self):
+        c = C.c_int(0)
+        _chk(self.L.sosf_get_rejected_steps(self.h_, C.byref(c)), "sosf_get_rejected_steps")
+        return c.value
 
     def lastX(self):
         n = self.counts()[0]

@@ -77,6 +77,30 @@ def so3_exp(w):
     return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * (K @ K)
 
 
+def se3_exp12(tangent6):
+    """Sophus convention (thirdparty/Sophus/sophus/se3.hpp:550-585): tangent = (upsilon, omega); returns R row-major | t."""
+    a = np.asarray(tangent6, dtype=np.float64)
+    ups, w = a[:3], a[3:]
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]], dtype=np.float64)
+    R = so3_exp(w)
+    if th < 1e-10:
+        V = np.eye(3) + 0.5 * K
+    else:
+        V = np.eye(3) + (1 - np.cos(th)) / th ** 2 * K + (th - np.sin(th)) / th ** 3 * (K @ K)
+    return np.concatenate([R.reshape(-1), V @ ups])
+
+
+def se3_mul12(A, B):
+    Ra, ta, Rb, tb = A[:9].reshape(3, 3), A[9:], B[:9].reshape(3, 3), B[9:]
+    return np.concatenate([(Ra @ Rb).reshape(-1), Ra @ tb + ta])
+
+
+def se3_inv12(A):
+    R, t = A[:9].reshape(3, 3), A[9:]
+    return np.concatenate([R.T.reshape(-1), -R.T @ t])
+
+
 @dataclasses.dataclass
 class Window:
     name: str

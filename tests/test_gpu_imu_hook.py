@@ -96,3 +96,54 @@ def test_imu_branch_wiring():
     sysm.gn_iteration(1)
     assert np.isfinite(sysm.lastX()).all()
     sysm.close()
+
+
+@pytest.mark.parametrize("name,trapped", [("T6", 1), ("T6", 0), ("W7", 1)])
+def test_imu_branch_step_equals_oracle_solve_on_device_system(name, trapped):
+    """N1 on the device's own numbers: the facade's IMU branch (OB/EnergyFunctional.cpp:1053-1171) runs on the H / b the
+    kernels delivered; the oracle's restatement of that branch (orc_imu_solve) is given exactly those matrices, the
+    records as the facade filled them and the same delta -- the pose increment, the scale step and the 21 IMU steps per
+    keyframe must agree to solver round-off."""
+    from sos_slam_amd import host
+    win = synth.make_window(name)
+    n = win.n
+    d0, dI = 4 + 8 * n, imu_dim(n)
+    idx = np.array([k if k < 4 else 5 + 29 * ((k - 4) // 8) + (k - 4) % 8 for k in range(d0)])
+    HMi, bMi = np.zeros((dI, dI)), np.zeros(dI)
+    HMi[np.ix_(idx, idx)] = win.HM
+    bMi[idx] = win.bM
+    HMi += np.eye(dI) * 1e-3
+    sysm = host.System.from_window(win)
+    sysm.prepare()
+    sysm.keep_last_system(True)
+    S, cal, frames, keep = _records(win)
+    cal.scale_trapped = trapped
+    sysm.set_imu(S, cal, frames, HMi, bMi)
+    st0 = np.array([list(f.state_imu) for f in frames])
+    scale0 = cal.scale
+    delta = np.zeros(d0)
+    for f in range(n):
+        fr = sysm.frame(f)
+        delta[4 + 8 * f:12 + 8 * f] = fr["state"][:8] - fr["state_zero"][:8]
+    sysm.gn_iteration(0)
+    H, b, Hsc, bsc = sysm.last_system()
+    assert np.abs(H - H.T).max() == 0 and np.abs(H).max() > 0 and np.abs(Hsc).max() > 0
+    x_g = sysm.lastX()
+    ss_g, st_g, _, _ = sysm.imu_state()
+    # the oracle's branch on the same inputs: records with the poses of that solve and the pre-step IMU states / scale
+    S2, cal2, frames2, keep2 = _records(win)
+    cal2.scale_trapped = trapped
+    cal2.scale = scale0
+    arr = sysm._imu[2]
+    for i in range(n):
+        frames2[i].camToWorld[:] = list(arr[i].camToWorld)
+        frames2[i].evalPT_R[:] = list(arr[i].evalPT_R)
+        frames2[i].state_imu[:] = list(st0[i])
+        frames2[i].state_imu_zero[:] = list(st0[i])
+    x_o, ss_o, st_o = orc.imu().solve(S2, cal2, frames2, H, b, Hsc, bsc, HMi, bMi, delta, lam=1e-5)
+    sx = max(np.abs(x_o).max(), 1e-12)
+    assert np.abs(x_g - x_o).max() <= 1e-7 * sx, (np.abs(x_g - x_o).max(), sx)
+    assert abs(ss_g - ss_o) <= 1e-7 * max(abs(ss_o), 1e-9)
+    assert np.abs(st_g - st_o).max() <= 1e-7 * max(np.abs(st_o).max(), 1e-12)
+    assert np.abs(st_o).max() > 0 and ss_o != 0
+    sysm.close()

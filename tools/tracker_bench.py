@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 from oracle import oracle as orc  # noqa: E402
 from sos_slam_amd import host, synth  # noqa: E402
 from sos_slam_amd.records import Calib  # noqa: E402
-from tests.test_oracle_math import se3_exp, se3_mul  # noqa: E402
+from sos_slam_amd.synth import se3_exp12 as se3_exp, se3_mul12 as se3_mul  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "W7"
 win = synth.make_window(name, extra_frames=2)
