@@ -73,36 +73,57 @@ def test_optimize_pose_rmse_and_index_sets(name):
     ot.close()
 
 
-@pytest.mark.parametrize("name,kw", [("T4", {}), ("T4", dict(state_noise=3e-2, idepth_noise=0.1)), ("T6", {})])
+REJECT_CASES = [("T4", {}), ("T4", dict(state_noise=1e-2, idepth_noise=0.1, seed=synth.SEED + 1)),
+                ("T4", dict(state_noise=2e-2, idepth_noise=0.05, seed=synth.SEED + 2)),
+                ("T4", dict(state_noise=3e-2, idepth_noise=0.1)), ("T6", {})]
+
+
+@pytest.mark.parametrize("name,kw", REJECT_CASES)
 def test_step_rejection_matches_oracle(name, kw):
-    """setting_forceAceptStep off (FS/FullSystemOptimize.cpp:387-413): the default T4 window accepts two steps and then
-    rejects the rest (energy rises by 1.7e-4 relative near convergence); the badly initialised one rejects its second
-    step, re-linearises at the backup state -- where the new frame threshold makes the same step acceptable -- and
-    carries on.  Same accept / reject sequence, iteration count, final poses and index sets as the oracle."""
+    """setting_forceAceptStep off (FS/FullSystemOptimize.cpp:387-413).  The default T4 window accepts two steps and then
+    rejects the rest (the energy rises by 1.7e-4 relative near convergence); the perturbed windows reject one to three
+    steps in the middle of the loop -- after a rejection the window is re-linearised at the backup state, where the
+    re-estimated frame threshold can make the same step acceptable.  Same accept / reject sequence, iteration count and
+    index sets as the oracle; poses within the yardstick (the last case starts centimetres off: its fp32 and
+    fp64-accumulated oracle runs already differ by 3e-4, so it only pins the decisions)."""
     from sos_slam_amd import host
     win = synth.make_window(name, **kw)
-    ow = hp.oracle_window(win)
+    ow, ot = hp.oracle_window(win), hp.oracle_window(win)
+    ot.set_truth_mode(True)
     rm_o, it_o, rej_o = ow.optimize_ex(6, force_accept=False)
+    rm_t, it_t, rej_t = ot.optimize_ex(6, force_accept=False)
     sysm = host.System.from_window(win)
     sysm.set_force_accept_step(False)
     rm_g, it_g = sysm.optimize(6)
     rej_g = sysm.rejected_steps()
-    print(f"{name} {kw}: iterations {it_g}/{it_o}, rejected {rej_g}/{rej_o}, rmse {rm_g}/{rm_o}")
+    noise = _pose_rmse(ow.frame, ot.frame, win.n)
+    e_ref = _pose_rmse(sysm.frame, ow.frame, win.n)
+    e_tru = _pose_rmse(sysm.frame, ot.frame, win.n)
+    print(f"{name} {kw}: iterations {it_g}/{it_o}, rejected {rej_g}/{rej_o}, rmse {rm_g}/{rm_o}/{rm_t}, pose device-oracle {e_ref:.3g} "
+          f"device-truth {e_tru:.3g} oracle-truth {noise:.3g}")
     assert (it_g, rej_g) == (it_o, rej_o)
     if name == "T4":
         assert rej_o >= 1
-    assert abs(rm_g - rm_o) <= 1e-4 * abs(rm_o)
-    tol = 1e-5 if not kw else 1e-4           # the badly initialised window moves by centimetres per step
+    assert abs(rm_g - rm_o) <= max(1e-5 * abs(rm_o), 3 * abs(rm_o - rm_t))
+    assert e_ref < max(POSE_TOL, 3 * noise), (e_ref, noise)
+    assert e_tru < max(POSE_TOL, 2 * noise), (e_tru, noise)
+    if noise < 1e-5:                      # the index sets are only comparable while the runs have not drifted apart
+        ro = ow.res()
+        alive = (ro["flags"] & 0x100) == 0
+        pi, tf = sysm.residual_ids()
+        assert set(zip(pi.tolist(), tf.tolist())) == set(zip(ro["point"][alive].tolist(), ro["target"][alive].tolist()))
+    # the default mode on the same object afterwards equals a fresh forced run (no state leaks out of the checked loop)
+    sysm.set_force_accept_step(True)
+    fresh = host.System.from_window(win)
+    fresh.optimize(6)
+    sysm2 = host.System.from_window(win)
+    sysm2.set_force_accept_step(False)
+    sysm2.set_force_accept_step(True)
+    sysm2.optimize(6)
     for f in range(win.n):
-        assert np.abs(sysm.frame(f)["camToWorld"] - ow.frame(f)["camToWorld"]).max() < tol
-        assert np.abs(sysm.frame(f)["state"] - ow.frame(f)["state"]).max() < tol
-    ro = ow.res()
-    alive = (ro["flags"] & 0x100) == 0
-    pi, tf = sysm.residual_ids()
-    assert set(zip(pi.tolist(), tf.tolist())) == set(zip(ro["point"][alive].tolist(), ro["target"][alive].tolist()))
-    # the default path on the same object afterwards: forced acceptance again, equal to a fresh forced run
-    sysm.close()
-    ow.close()
+        assert np.array_equal(fresh.frame(f)["camToWorld"], sysm2.frame(f)["camToWorld"])
+    for x in (sysm, fresh, sysm2, ow, ot):
+        x.close()
 
 
 def test_two_buffer_protocol_keeps_applied_jacobians():

@@ -1,0 +1,101 @@
+"""The C restatement of the hot path (oracle/orc_backend.c, fp32) against an independent NumPy fp64 reading of the same
+reference functions (oracle/mirror_np.py): FrameFramePrecalc::set, PointFrameResidual::linearize, takeDataF and the
+accumulated top / Schur systems restated as dense normal equations.  A misreading of the reference would have to be made
+twice, in two different formulations, to get through here.  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import mirror_np as mir
+from oracle import oracle as orc
+from sos_slam_amd import synth
+
+CASES = [("T3", {}), ("T4", {}), ("T4", dict(state_noise=3e-3, idepth_noise=0.05, noise_sigma=4.0)), ("T6", {}),
+         ("T4", dict(w=154, h=46, P=300))]
+
+
+def _inputs(win, ow):
+    n = win.n
+    evalPT = np.stack([ow.evalpt(f) for f in range(n)])
+    pre = np.stack([ow.frame(f)["camToWorld"] for f in range(n)])
+    st = np.stack([ow.frame(f)["state"] for f in range(n)])
+    sz = np.stack([ow.frame(f)["state_zero"] for f in range(n)])
+    aff = np.stack([st[:, 6] * synth.SCALE_A, st[:, 7] * synth.SCALE_B], axis=1)
+    return evalPT, pre, aff, sz[:, 7] * synth.SCALE_B
+
+
+@pytest.mark.parametrize("name,kw", CASES)
+def test_precalc_linearize_and_system_agree_with_the_numpy_mirror(name, kw):
+    win = synth.make_window(name, **kw)
+    ow = orc.window_from_synth(win)
+    n = win.n
+    K = ow.calib_value_scaled()
+    evalPT, pre, aff, b0 = _inputs(win, ow)
+    # ---- FrameFramePrecalc::set
+    pm = mir.precalc(evalPT, pre, K, np.ones(n), aff, b0)
+    pc = ow.precalc()
+    offd = np.array([h != t for t in range(n) for h in range(n)])
+    for key, field, shape in (("KRKi", "PRE_KRKiTll", (3, 3)), ("Kt", "PRE_KtTll", (3,)), ("R0", "PRE_RTll_0", (3, 3)),
+                              ("t0", "PRE_tTll_0", (3,)), ("aff", "PRE_aff_mode", (2,))):
+        a, b = pm[key], pc[field].reshape((n * n,) + shape).astype(np.float64)
+        # K R K^-1 and K t are float products of entries up to fx, cx: their round-off scales with the focal length
+        tol = 2e-6 * (float(np.max(K)) if key in ("KRKi", "Kt") else max(np.abs(b).max(), 1.0))
+        assert np.abs(a - b)[offd].max() <= tol, (key, np.abs(a - b)[offd].max(), tol)
+    assert np.abs(pm["b0"] - pc["PRE_b0_mode"]).max() <= 1e-6 * max(np.abs(pm["b0"]).max(), 1.0)
+    # ---- linearize (the mirror gets the oracle's fp32 precalc records, so only the linearisation itself is compared)
+    pcf = dict(KRKi=pc["PRE_KRKiTll"].reshape(-1, 3, 3), Kt=pc["PRE_KtTll"], R0=pc["PRE_RTll_0"].reshape(-1, 3, 3), t0=pc["PRE_tTll_0"],
+               aff=pc["PRE_aff_mode"], b0=pc["PRE_b0_mode"])
+    th = np.array([ow.frame(f)["frameEnergyTH"] for f in range(n)], np.float32)
+    if kw:
+        th[:] = 300.0          # bring the outlier threshold into the energy distribution of the perturbed windows
+    ow.reset_oob()
+    ow.linearize(th)
+    pts, res = ow.pts().copy(), ow.res().copy()
+    m = mir.linearize(pts, res, pcf, K, [d[0] for d in ow.dI], th, win.params)
+    ns, en, wo = ow.new_state(), ow.new_energy(), ow.new_energy_wo()
+    thmax = np.maximum(th[res["host"]], th[res["target"]])
+    near = (np.abs(m["energy_wo"] - thmax) <= 1e-3 * thmax) | (m["energy_wo"] < 0)
+    same = m["new_state"] == ns
+    assert same[~near].all(), np.flatnonzero(~same & ~near)[:10]
+    assert (~same).sum() <= 2
+    ok = same & (ns != mir.RES_OOB)
+    assert ok.sum() > 0.5 * len(res)
+    assert np.abs(m["energy_wo"][ok] - wo[ok]).max() <= 2e-4 * np.abs(wo[ok]).max()
+    assert np.abs(m["energy"][ok] - en[ok]).max() <= 2e-4 * np.abs(en[ok]).max()
+    cen = ow.center()
+    cok = same & m["center_ok"]
+    assert np.abs(m["center"][cok] - cen[cok]).max() <= 1e-4 * np.abs(cen[cok]).max()
+    Jn = ow.Jnew()
+    for f in ("resF", "Jpdxi", "Jpdc", "Jpdd", "JIdx", "JabF"):
+        a, b = m["J"][f][ok], Jn[f][ok].astype(np.float64)
+        assert np.abs(a - b).max() <= 3e-4 * np.abs(b).max(), (f, np.abs(a - b).max(), np.abs(b).max())
+    for f in ("JIdx2", "JabJIdx", "Jab2"):
+        a, b = m["J"][f][ok].reshape(-1, 4), Jn[f][ok].astype(np.float64)
+        assert np.abs(a - b).max() <= 3e-4 * np.abs(b).max(), f
+    if kw.get("state_noise"):
+        assert (ns == mir.RES_OUTLIER).sum() > 3        # the perturbed window exercises the outlier branch
+    # ---- applyRes + takeDataF, then the accumulated system against the dense normal equations
+    ow.apply_res()
+    act = (ow.res()["flags"] & 1) != 0
+    assert np.array_equal(act, (ns == mir.RES_IN) & (res["state_state"] != mir.RES_OOB))
+    both = act & same
+    jp = ow.JpJdF()
+    assert np.abs(m["JpJdF"][both] - jp[both]).max() <= 5e-4 * np.abs(jp[both]).max()
+    # the mirror's own Jacobians (fp64) of exactly the oracle's active set
+    t = ow.accumulate(fp64_truth=True)
+    d = mir.dense_system(m["J"], both, res, pts, n, ow.adHost(), ow.adTarget(), np.zeros(4))
+    if (act & ~same).sum() == 0:
+        for k in ("H_A", "H_sc"):
+            assert np.linalg.norm(d[k] - t[k]) <= 2e-4 * np.linalg.norm(t[k]), (k, np.linalg.norm(d[k] - t[k]) / np.linalg.norm(t[k]))
+        for k in ("b_A", "b_sc"):
+            assert np.linalg.norm(d[k] - t[k]) <= 2e-3 * np.linalg.norm(t[k]), (k, np.linalg.norm(d[k] - t[k]) / np.linalg.norm(t[k]))
+        idh = ow.point_field("idepth_hessian").astype(np.float64)
+        assert np.abs(d["idepth_hessian"] - idh).max() <= 5e-4 * idh.max()
+        hdi = ow.point_field("HdiF").astype(np.float64)
+        assert np.abs(d["HdiF"] - hdi).max() <= 5e-4 * hdi.max()
+        # the reduced system both readings would solve: same Gauss-Newton direction
+        dim = 4 + 8 * n
+        reg = np.eye(dim) * 1e-3 * np.abs(np.diag(t["H_A"])).max()
+        xo = np.linalg.solve(t["H_A"] - t["H_sc"] + win.HM + reg, t["b_A"] - t["b_sc"])
+        xm = np.linalg.solve(d["H_A"] - d["H_sc"] + win.HM + reg, d["b_A"] - d["b_sc"])
+        assert np.linalg.norm(xo - xm) <= 5e-3 * np.linalg.norm(xo)
+    ow.close()
