@@ -42,6 +42,34 @@ int sosf_destroy(sosf_system *sys);
 int sosf_set_calib(sosf_system *sys, const double *value_scaled4);
 /* new FrameHessian + makeImages (device) + ef->insertFrame (FS/FullSystem.cpp:650,814) */
 int sosf_add_frame(sosf_system *sys, const sosf_frame_init *f, const float *image);
+/* the same for a frame whose pyramid is already in image slot `slot` (it was tracked first: sosf_upload_image) */
+int sosf_add_frame_from_slot(sosf_system *sys, const sosf_frame_init *f, int slot);
+
+/* ---- keyframe-rate host logic of FullSystem::makeKeyFrame (FS/FullSystem.cpp:783-931), in the order it runs ----------
+ * flagFramesForMarginalization (FS/FullSystemMarginalize.cpp:53-133), BEFORE the new keyframe is added: numImmature[i] =
+ * immaturePoints.size() of keyframe idx i (the immature points live with the caller); flagged[i] out. */
+int sosf_flag_frames_for_marginalization(sosf_system *sys, const int32_t *numImmature, uint8_t *flagged);
+/* "add new residuals for old points" (FS/FullSystem.cpp:818-832): one residual towards the newest keyframe for every
+ * active point of the older ones, lastResiduals shifted */
+int sosf_add_new_frame_residuals(sosf_system *sys, int *count);
+/* the points sos_immature_activate returned SOS_ACT_ACTIVATED for (tail of optimizeImmaturePoint,
+ * FS/FullSystemOptPoint.cpp:151-185, and activatePointsMT :497-505): idepth / idepth_zero = the activation's idepth,
+ * residuals towards the keyframes (idx) whose bit is set in inMask[i], lastResiduals towards the two newest */
+int sosf_add_activated_points(sosf_system *sys, int count, const sos_point *pts, const uint32_t *inMask);
+/* FullSystem::removeOutliers (FS/FullSystemOptimize.cpp:507-526) */
+int sosf_remove_outliers(sosf_system *sys, int *dropped);
+/* FullSystem::flagPointsForRemoval (FS/FullSystem.cpp:535-614: isOOB / isInlierNew decisions, re-linearisation and
+ * fixLinearizationF of the points that leave as inliers) + ef->dropPointsF + ef->marginalizePointsF (:909, :912) */
+int sosf_flag_points_for_removal(sosf_system *sys, int *nMarginalized, int *nDropped);
+/* "Marginalize Frames" (FS/FullSystem.cpp:926-931 -> FS/FullSystemMarginalize.cpp:143-236): every flagged keyframe leaves;
+ * frameIDs / camToWorld12 (cap entries) receive its id and the pose it leaves with (what the reference hands to the
+ * pose graph / viewer as the keyframe's final pose) */
+int sosf_marginalize_flagged_frames(sosf_system *sys, int cap, int32_t *frameIDs, double *camToWorld12, int *count);
+/* identity of the window's points in allPoints order (host frameID, u, v, host idx) and per keyframe: frameID, flagged,
+ * sizes of pointHessians / pointHessiansMarginalized / pointHessiansOut (any pointer may be NULL) */
+int sosf_get_point_keys(sosf_system *sys, int32_t *hostFrameID, float *u, float *v, int32_t *hostIdx);
+int sosf_get_frame_ids(sosf_system *sys, int32_t *frameID, uint8_t *flagged, int32_t *nPoints, int32_t *nMarg, int32_t *nOut);
+
 /* new PointHessian + ef->insertPoint (FS/FullSystem.cpp:508-510); pts[i].host = frame idx */
 int sosf_add_points(sosf_system *sys, int count, const sos_point *pts);
 /* new PointFrameResidual + ef->insertResidual (FS/FullSystem.cpp:825-828); res[i].point indexes the
@@ -128,6 +156,9 @@ typedef struct sosf_tracker sosf_tracker;
 /* makeImages of a frame that is not (yet) a keyframe (FS/FullSystem.cpp:650, 1114): returns its image slot */
 int sosf_upload_image(sosf_system *sys, const float *image, int *slot_out);
 int sosf_release_image(sosf_system *sys, int slot);
+/* reserves a free image slot of the system's context without filling it: the caller builds the pyramid there itself
+ * (sos_undistort_frame on sosf_ctx(sys): raw camera frame -> undistortion -> pyramid, U/Undistort.cpp:361-458) */
+int sosf_alloc_slot(sosf_system *sys, int *slot_out);
 int sosf_tracker_create(sosf_system *sys, sosf_tracker **out);
 int sosf_tracker_destroy(sosf_tracker *trk);
 /* makeK + setCoarseTrackingRef(frameHessians) (FS/FullSystem.cpp:889-890): reference = newest keyframe, points =

@@ -729,12 +729,17 @@ FullSystem::~FullSystem() {
 }
 
 FrameHessian *FullSystem::addFrame(const double *c2w, const double *state10, float ab_exposure, int frameID,
-                                   float frameEnergyTH, const float *image) {
+                                   float frameEnergyTH, const float *image, int haveSlot) {
   int slot = -1;
-  for (int s = 0; s < SOS_MAX_SLOTS; s++)
-    if (!slotUsed[s]) { slot = s; break; }
-  if (slot < 0) return nullptr;
-  if (sos_make_pyramid(ctx, slot, image, nullptr) != SOS_OK) return nullptr;  // makeImages, FS/FullSystem.cpp:650
+  if (image) {
+    for (int s = 0; s < SOS_MAX_SLOTS; s++)
+      if (!slotUsed[s]) { slot = s; break; }
+    if (slot < 0) return nullptr;
+    if (sos_make_pyramid(ctx, slot, image, nullptr) != SOS_OK) return nullptr;  // makeImages, FS/FullSystem.cpp:650
+  } else {  // the frame was tracked first: its pyramid already sits in a slot (sosf_upload_image / sos_undistort_frame)
+    if (haveSlot < 0 || haveSlot >= SOS_MAX_SLOTS) return nullptr;
+    slot = haveSlot;
+  }
   slotUsed[slot] = true;
   FrameHessian *fh = new FrameHessian();
   fh->slot = slot;
@@ -1168,7 +1173,11 @@ void FullSystem::removeOutliers() {  // FS/FullSystemOptimize.cpp:507-526
 
 // flagPointsForRemoval for an explicit set (FS/FullSystem.cpp:566-601) followed by
 // ef->marginalizePointsF (FS/FullSystem.cpp:912)
-int FullSystem::marginalizePoints(const std::vector<PointHessian *> &pts) {
+int FullSystem::marginalizePoints(const std::vector<PointHessian *> &pts, bool alreadyDetached) {
+  if (pts.empty()) {  // nothing to linearise: only the PS_DROP points leave (ef->dropPointsF, FS/FullSystem.cpp:909)
+    ef->dropPointsF();
+    return SOS_OK;
+  }
   int rc = ef->packWindow();
   if (rc) return rc;
   setPrecalcValues();
@@ -1212,10 +1221,11 @@ int FullSystem::marginalizePoints(const std::vector<PointHessian *> &pts) {
     }
     (void)ngoodRes;
     ph->efPoint->stateFlag = (ph->idepth_hessian > setting_minIdepthH_marg) ? PS_MARGINALIZE : PS_DROP;
+    ph->wasMarginalized = ph->efPoint->stateFlag == PS_MARGINALIZE;
     FrameHessian *host = ph->host;
     if (ph->efPoint->stateFlag == PS_MARGINALIZE) host->pointHessiansMarginalized.push_back(ph);
     else host->pointHessiansOut.push_back(ph);
-    for (size_t i = 0; i < host->pointHessians.size(); i++)
+    for (size_t i = 0; !alreadyDetached && i < host->pointHessians.size(); i++)
       if (host->pointHessians[i] == ph) {
         host->pointHessians[i] = host->pointHessians.back();
         host->pointHessians.pop_back();
@@ -1285,6 +1295,200 @@ int FullSystem::marginalizeFrame(FrameHessian *frame) {  // FS/FullSystemMargina
   setPrecalcValues();
   ef->setAdjointsF(&HCalib);
   ef->setDeltaF(&HCalib);
+  return SOS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// keyframe-rate host logic of FullSystem::makeKeyFrame around the backend (FS/FullSystem.cpp:783-931)
+// ------------------------------------------------------------------------------------------------
+static const float setting_minPointsRemaining = 0.05f;    // util/settings.cpp:67-70
+static const float setting_maxLogAffFacInWindow = 0.7f;
+static const int setting_minFrames = 5, setting_maxFrames = 7, setting_minFrameAge = 1;  // :73-75
+static const int setting_minGoodActiveResForMarg = 3, setting_minGoodResForMarg = 4;     // :95-96
+
+// FS/FullSystemMarginalize.cpp:53-133; called BEFORE the new keyframe joins frameHessians (FS/FullSystem.cpp:798)
+void FullSystem::flagFramesForMarginalization() {
+  if (setting_minFrameAge > setting_maxFrames) {
+    for (int i = setting_maxFrames; i < (int)frameHessians.size(); i++) frameHessians[i - setting_maxFrames]->flaggedForMarginalization = true;
+    return;
+  }
+  int flagged = 0;
+  for (FrameHessian *fh : frameHessians) {
+    const int in = (int)fh->pointHessians.size() + fh->numImmature;
+    const int out = (int)fh->pointHessiansMarginalized.size() + (int)fh->pointHessiansOut.size();
+    double refToFh[2];
+    AffLight::fromToVecExposure(frameHessians.back()->ab_exposure, fh->ab_exposure, frameHessians.back()->aff_g2l(), fh->aff_g2l(), refToFh);
+    if ((in < setting_minPointsRemaining * (in + out) || fabs(logf((float)refToFh[0])) > setting_maxLogAffFacInWindow) &&
+        ((int)frameHessians.size()) - flagged > setting_minFrames) {
+      fh->flaggedForMarginalization = true;
+      flagged++;
+    }
+  }
+  if ((int)frameHessians.size() - flagged >= setting_maxFrames) {  // marginalize one: the keyframe closest to the others
+    double smallestScore = 1;
+    FrameHessian *toMarginalize = nullptr;
+    FrameHessian *latest = frameHessians.back();
+    for (FrameHessian *fh : frameHessians) {
+      if (fh->frameID > latest->frameID - setting_minFrameAge || fh->frameID == 0) continue;
+      double distScore = 0;
+      for (size_t t = 0; t < fh->targetPrecalc.size(); t++) {
+        const FrameHessian *target = frameHessians[t];
+        if (target->frameID > latest->frameID - setting_minFrameAge + 1 || target == fh) continue;
+        distScore += 1 / (1e-5 + fh->targetPrecalc[t].distanceLL);
+      }
+      distScore *= -sqrtf(fh->targetPrecalc.back().distanceLL);
+      if (distScore < smallestScore) {
+        smallestScore = distScore;
+        toMarginalize = fh;
+      }
+    }
+    if (toMarginalize) toMarginalize->flaggedForMarginalization = true;  // (the reference dereferences unconditionally)
+  }
+}
+
+// the loop "add new residuals for old points" of makeKeyFrame, FS/FullSystem.cpp:818-832
+int FullSystem::addResidualsToNewestFrame() {
+  FrameHessian *fh = frameHessians.back();
+  int added = 0;
+  for (FrameHessian *fh1 : frameHessians) {
+    if (fh1 == fh) continue;
+    for (PointHessian *ph : fh1->pointHessians) {
+      PointFrameResidual *r = new PointFrameResidual();
+      r->point = ph; r->host = fh1; r->target = fh;
+      r->state_state = IN;                      // r->setState(ResState::IN)
+      ph->residuals.push_back(r);
+      ef->insertResidual(r);
+      ph->lastResiduals[1] = ph->lastResiduals[0];
+      ph->lastResiduals[0] = std::make_pair(r, IN);
+      added++;
+    }
+  }
+  return added;
+}
+
+// the tail of FullSystem::optimizeImmaturePoint (FS/FullSystemOptPoint.cpp:151-185) and of activatePointsMT
+// (FS/FullSystem.cpp:497-505) for one candidate the device activated: PointHessian(rawPoint), residuals towards the
+// keyframes whose bit is set in inMask (frame idx order), lastResiduals as the reference leaves them
+PointHessian *FullSystem::addActivatedPoint(const sos_point &p, uint32_t inMask) {
+  if (p.host < 0 || p.host >= (int)frameHessians.size()) return nullptr;
+  PointHessian *ph = new PointHessian();
+  ph->host = frameHessians[p.host];
+  ph->hasDepthPrior = false;
+  ph->u = p.u; ph->v = p.v;
+  std::memcpy(ph->color, p.color, sizeof(ph->color));
+  std::memcpy(ph->weights, p.weights, sizeof(ph->weights));
+  ph->lastResiduals[0] = std::make_pair((PointFrameResidual *)nullptr, OOB);
+  ph->lastResiduals[1] = std::make_pair((PointFrameResidual *)nullptr, OOB);
+  ph->setIdepthZero(p.idepth_scaled * (1.0f / SOS_SCALE_IDEPTH));
+  ph->setIdepth(p.idepth_scaled * (1.0f / SOS_SCALE_IDEPTH));
+  const int nf = (int)frameHessians.size();
+  FrameHessian *newest = frameHessians.back(), *second = nf < 2 ? nullptr : frameHessians[nf - 2];
+  for (int t = 0; t < nf; t++) {
+    if (!((inMask >> t) & 1u) || frameHessians[t] == ph->host) continue;
+    PointFrameResidual *r = new PointFrameResidual();
+    r->point = ph; r->host = ph->host; r->target = frameHessians[t];
+    r->state_NewEnergy = r->state_energy = 0;
+    r->state_NewState = OUTLIER;
+    r->state_state = IN;
+    ph->residuals.push_back(r);
+    if (r->target == newest) ph->lastResiduals[0] = std::make_pair(r, IN);
+    else if (r->target == second) ph->lastResiduals[1] = std::make_pair(r, IN);
+  }
+  ph->host->pointHessians.push_back(ph);
+  ph->userIdx = (int)userPoints.size();
+  userPoints.push_back(ph);
+  ef->insertPoint(ph);
+  for (PointFrameResidual *r : ph->residuals) ef->insertResidual(r);
+  return ph;
+}
+
+static bool pointIsOOB(const PointHessian *ph, const std::vector<FrameHessian *> &toMarg) {  // FS/HessianBlocks.h:619-643
+  int visInToMarg = 0;
+  for (const PointFrameResidual *r : ph->residuals) {
+    if (r->state_state != IN) continue;
+    for (const FrameHessian *k : toMarg)
+      if (r->target == k) visInToMarg++;
+  }
+  if ((int)ph->residuals.size() >= setting_minGoodActiveResForMarg && ph->numGoodResiduals > setting_minGoodResForMarg + 10 &&
+      (int)ph->residuals.size() - visInToMarg < setting_minGoodActiveResForMarg)
+    return true;
+  if (ph->lastResiduals[0].second == OOB) return true;
+  if (ph->residuals.size() < 2) return false;
+  if (ph->lastResiduals[0].second == OUTLIER && ph->lastResiduals[1].second == OUTLIER) return true;
+  return false;
+}
+
+// FullSystem::flagPointsForRemoval (FS/FullSystem.cpp:535-614) followed by ef->dropPointsF and ef->marginalizePointsF
+// (makeKeyFrame :908-912).  The decisions are the reference's; the per-residual work of the points that get
+// marginalised (resetOOB, linearize, applyRes, fixLinearizationF) runs on the device for the whole set at once.
+int FullSystem::flagPointsForRemoval(int *nMarg, int *nDrop) {
+  std::vector<FrameHessian *> fhsToMargPoints;
+  for (FrameHessian *fh : frameHessians)
+    if (fh->flaggedForMarginalization) fhsToMargPoints.push_back(fh);
+  std::vector<PointHessian *> inliers;  // (isOOB || host flagged) && isInlierNew: linearised, then marginalised or dropped
+  int dropped = 0;
+  for (FrameHessian *host : frameHessians) {
+    for (size_t i = 0; i < host->pointHessians.size(); i++) {
+      PointHessian *ph = host->pointHessians[i];
+      if (ph->idepth_scaled < 0 || ph->residuals.empty()) {
+        host->pointHessiansOut.push_back(ph);
+        ph->efPoint->stateFlag = PS_DROP;
+        host->pointHessians[i] = nullptr;
+        dropped++;
+      } else if (pointIsOOB(ph, fhsToMargPoints) || host->flaggedForMarginalization) {
+        const bool isInlierNew = (int)ph->residuals.size() >= setting_minGoodActiveResForMarg && ph->numGoodResiduals >= setting_minGoodResForMarg;
+        if (isInlierNew) {
+          inliers.push_back(ph);  // stays in host->pointHessians until marginalizePoints moves it
+        } else {
+          host->pointHessiansOut.push_back(ph);
+          ph->efPoint->stateFlag = PS_DROP;
+          host->pointHessians[i] = nullptr;
+          dropped++;
+        }
+      }
+    }
+    // compaction of the reference: holes are filled from the back, in index order (:604-611); the points queued for
+    // marginalisation keep their slot until marginalizePoints takes them out one by one the same way
+  }
+  // the reference removes dropped and to-be-marginalised points in ONE pass per host (hole filled from the back); to end
+  // with the same pointHessians order, mark the inliers as holes too and compact once
+  for (PointHessian *ph : inliers) {
+    FrameHessian *host = ph->host;
+    for (size_t i = 0; i < host->pointHessians.size(); i++)
+      if (host->pointHessians[i] == ph) { host->pointHessians[i] = nullptr; break; }
+  }
+  for (FrameHessian *host : frameHessians)
+    for (int i = 0; i < (int)host->pointHessians.size(); i++)
+      if (host->pointHessians[i] == nullptr) {
+        host->pointHessians[i] = host->pointHessians.back();
+        host->pointHessians.pop_back();
+        i--;
+      }
+  const int rc = marginalizePoints(inliers, /*alreadyDetached=*/true);
+  int margd = 0;
+  for (PointHessian *ph : inliers)
+    if (ph->wasMarginalized) margd++;
+  if (nMarg) *nMarg = margd;
+  if (nDrop) *nDrop = dropped + ((int)inliers.size() - margd);
+  return rc;
+}
+
+// the loop "Marginalize Frames" of makeKeyFrame, FS/FullSystem.cpp:926-931
+int FullSystem::marginalizeFlaggedFrames(int cap, int32_t *frameIDs, double *camToWorld12, int *count) {
+  int k = 0;
+  for (unsigned i = 0; i < frameHessians.size(); i++)
+    if (frameHessians[i]->flaggedForMarginalization) {
+      FrameHessian *fh = frameHessians[i];
+      if (k < cap) {
+        if (frameIDs) frameIDs[k] = fh->frameID;
+        if (camToWorld12) fh->PRE_camToWorld.to12(camToWorld12 + 12 * (size_t)k);
+      }
+      k++;
+      const int rc = marginalizeFrame(fh);
+      if (rc != SOS_OK) return rc;
+      i = 0;  // (sic: the reference restarts at index 1 after the increment; flagged frame 0 would be caught first)
+    }
+  if (count) *count = k;
   return SOS_OK;
 }
 
@@ -1604,6 +1808,71 @@ extern "C" int sosf_add_frame(sosf_system *s, const sosf_frame_init *f, const fl
   if (!s || !f || !image) return SOS_ERR_ARG;
   return s->fs->addFrame(f->camToWorld, f->state, f->ab_exposure, f->frameID, f->frameEnergyTH, image) ? SOS_OK : SOS_ERR_STATE;
 }
+extern "C" int sosf_add_frame_from_slot(sosf_system *s, const sosf_frame_init *f, int slot) {
+  if (!s || !f) return SOS_ERR_ARG;
+  return s->fs->addFrame(f->camToWorld, f->state, f->ab_exposure, f->frameID, f->frameEnergyTH, nullptr, slot) ? SOS_OK : SOS_ERR_STATE;
+}
+extern "C" int sosf_flag_frames_for_marginalization(sosf_system *s, const int32_t *numImmature, uint8_t *flagged) {
+  if (!s) return SOS_ERR_ARG;
+  FullSystem *fs = s->fs;
+  for (size_t i = 0; i < fs->frameHessians.size(); i++) fs->frameHessians[i]->numImmature = numImmature ? numImmature[i] : 0;
+  fs->flagFramesForMarginalization();
+  if (flagged) for (size_t i = 0; i < fs->frameHessians.size(); i++) flagged[i] = fs->frameHessians[i]->flaggedForMarginalization ? 1 : 0;
+  return SOS_OK;
+}
+extern "C" int sosf_add_new_frame_residuals(sosf_system *s, int *count) {
+  if (!s || s->fs->frameHessians.empty()) return SOS_ERR_ARG;
+  const int c = s->fs->addResidualsToNewestFrame();
+  if (count) *count = c;
+  return SOS_OK;
+}
+extern "C" int sosf_add_activated_points(sosf_system *s, int count, const sos_point *pts, const uint32_t *inMask) {
+  if (!s || (count && (!pts || !inMask))) return SOS_ERR_ARG;
+  for (int i = 0; i < count; i++)
+    if (!s->fs->addActivatedPoint(pts[i], inMask[i])) return SOS_ERR_ARG;
+  return SOS_OK;
+}
+extern "C" int sosf_remove_outliers(sosf_system *s, int *dropped) {
+  if (!s) return SOS_ERR_ARG;
+  const int before = s->fs->ef->nPoints;
+  s->fs->removeOutliers();
+  if (dropped) *dropped = before - s->fs->ef->nPoints;
+  return SOS_OK;
+}
+extern "C" int sosf_flag_points_for_removal(sosf_system *s, int *nMarginalized, int *nDropped) {
+  if (!s) return SOS_ERR_ARG;
+  return s->fs->flagPointsForRemoval(nMarginalized, nDropped);
+}
+extern "C" int sosf_marginalize_flagged_frames(sosf_system *s, int cap, int32_t *frameIDs, double *camToWorld12, int *count) {
+  if (!s) return SOS_ERR_ARG;
+  return s->fs->marginalizeFlaggedFrames(cap, frameIDs, camToWorld12, count);
+}
+extern "C" int sosf_get_point_keys(sosf_system *s, int32_t *hostFrameID, float *u, float *v, int32_t *hostIdx) {
+  if (!s) return SOS_ERR_ARG;
+  size_t k = 0;
+  for (FrameHessian *fh : s->fs->frameHessians)
+    for (EFPoint *p : fh->efFrame->points) {
+      if (hostFrameID) hostFrameID[k] = fh->frameID;
+      if (u) u[k] = p->data->u;
+      if (v) v[k] = p->data->v;
+      if (hostIdx) hostIdx[k] = fh->idx;
+      k++;
+    }
+  return SOS_OK;
+}
+extern "C" int sosf_get_frame_ids(sosf_system *s, int32_t *frameID, uint8_t *flagged, int32_t *nPoints, int32_t *nMarg, int32_t *nOut) {
+  if (!s) return SOS_ERR_ARG;
+  size_t k = 0;
+  for (FrameHessian *fh : s->fs->frameHessians) {
+    if (frameID) frameID[k] = fh->frameID;
+    if (flagged) flagged[k] = fh->flaggedForMarginalization ? 1 : 0;
+    if (nPoints) nPoints[k] = (int)fh->pointHessians.size();
+    if (nMarg) nMarg[k] = (int)fh->pointHessiansMarginalized.size();
+    if (nOut) nOut[k] = (int)fh->pointHessiansOut.size();
+    k++;
+  }
+  return SOS_OK;
+}
 extern "C" int sosf_add_points(sosf_system *s, int count, const sos_point *pts) {
   if (!s || (count && !pts)) return SOS_ERR_ARG;
   for (int i = 0; i < count; i++)
@@ -1837,6 +2106,16 @@ extern "C" int sosf_upload_image(sosf_system *s, const float *image, int *slot_o
       int rc = sos_make_pyramid(fs->ctx, k, image, nullptr);
       if (rc) return rc;
       fs->slotUsed[k] = true;
+      *slot_out = k;
+      return SOS_OK;
+    }
+  return SOS_ERR_STATE;
+}
+extern "C" int sosf_alloc_slot(sosf_system *s, int *slot_out) {
+  if (!s || !slot_out) return SOS_ERR_ARG;
+  for (int k = 0; k < SOS_MAX_SLOTS; k++)
+    if (!s->fs->slotUsed[k]) {
+      s->fs->slotUsed[k] = true;
       *slot_out = k;
       return SOS_OK;
     }

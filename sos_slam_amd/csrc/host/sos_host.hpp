@@ -74,6 +74,7 @@ struct FrameHessian {
   float frameEnergyTH = 8 * 8 * SOS_PATTERN_NUM;
   float ab_exposure = 1;
   bool flaggedForMarginalization = false;
+  int numImmature = 0;  // immaturePoints.size(): the immature points live with the caller (records of sos_immature)
   std::vector<PointHessian *> pointHessians, pointHessiansMarginalized, pointHessiansOut;
   SE3 camToWorld_evalPT;
   SE3 worldToCam_evalPT;  // cached inverse
@@ -103,6 +104,7 @@ struct PointHessian {  // FS/HessianBlocks.h:556-649
   int numGoodResiduals = 0;
   std::vector<PointFrameResidual *> residuals;
   std::pair<PointFrameResidual *, ResState> lastResiduals[2];
+  bool wasMarginalized = false;  // flagPointsForRemoval: PS_MARGINALIZE (vs PS_DROP)
   int packIdx = -1;  // index in the last device snapshot (allPoints order)
   int userIdx = -1;  // running index in which the point was added through the flat API
   ~PointHessian();
@@ -244,7 +246,7 @@ class FullSystem {
   bool ok() const { return ctx != nullptr && ef != nullptr; }
 
   FrameHessian *addFrame(const double *camToWorld12, const double *state10, float ab_exposure, int frameID,
-                         float frameEnergyTH, const float *image);
+                         float frameEnergyTH, const float *image, int haveSlot = -1);
   PointHessian *addPoint(const sos_point &p);
   PointFrameResidual *addResidual(PointHessian *ph, FrameHessian *target, const sos_resid &r);
 
@@ -259,7 +261,12 @@ class FullSystem {
   bool gnIterationChecked(int iteration, double &lastE, double &lastEL, double &lastEM);  // :358-413, forceAceptStep off
   void setPrecalcValues(bool points = true);                  // FS/FullSystem.cpp:1099-1107
   void removeOutliers();                                      // FS/FullSystemOptimize.cpp:507-526
-  int marginalizePoints(const std::vector<PointHessian *> &pts);  // flagPointsForRemoval core + marginalizePointsF
+  int marginalizePoints(const std::vector<PointHessian *> &pts, bool alreadyDetached = false);  // flagPointsForRemoval core + marginalizePointsF
+  void flagFramesForMarginalization();                        // FS/FullSystemMarginalize.cpp:53-133
+  int addResidualsToNewestFrame();                            // FS/FullSystem.cpp:818-832
+  PointHessian *addActivatedPoint(const sos_point &p, uint32_t inMask);  // FS/FullSystemOptPoint.cpp:151-185
+  int flagPointsForRemoval(int *nMarg, int *nDrop);           // FS/FullSystem.cpp:535-614 + :909, :912
+  int marginalizeFlaggedFrames(int cap, int32_t *frameIDs, double *camToWorld12, int *count);  // :926-931
   int dropPoints(const std::vector<PointHessian *> &pts);
   int marginalizeFrame(FrameHessian *fh);                     // FS/FullSystemMarginalize.cpp:143-236
 

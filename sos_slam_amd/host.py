@@ -46,6 +46,17 @@ def load():
     L.sosf_get_residuals.argtypes = [vp, vp, vp, vp]
     L.sosf_get_lastX.argtypes = [vp, vp]
     L.sosf_get_residual_ids.argtypes = [vp, vp, vp]
+    L.sosf_add_frame_from_slot.argtypes = [vp, vp, ci]
+    L.sosf_alloc_slot.argtypes = [vp, C.POINTER(ci)]
+    L.sosf_release_image.argtypes = [vp, ci]
+    L.sosf_flag_frames_for_marginalization.argtypes = [vp, vp, vp]
+    L.sosf_add_new_frame_residuals.argtypes = [vp, C.POINTER(ci)]
+    L.sosf_add_activated_points.argtypes = [vp, ci, vp, vp]
+    L.sosf_remove_outliers.argtypes = [vp, C.POINTER(ci)]
+    L.sosf_flag_points_for_removal.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
+    L.sosf_marginalize_flagged_frames.argtypes = [vp, ci, vp, vp, C.POINTER(ci)]
+    L.sosf_get_point_keys.argtypes = [vp, vp, vp, vp, vp]
+    L.sosf_get_frame_ids.argtypes = [vp, vp, vp, vp, vp, vp]
     L.sosf_keep_last_system.argtypes = [vp, ci]
     L.sosf_get_last_system.argtypes = [vp, vp, vp, vp, vp]
     L.sosf_set_force_accept_step.argtypes = [vp, ci]
@@ -157,6 +168,9 @@ class System:
     def close(self):
         for t in list(getattr(self, "_trackers", [])):  # trackers borrow the system's context: they go first
             t.close()
+        if getattr(self, "_ctx", None) is not None:   # ... and so do the front-end objects created on context()
+            self._ctx.close()
+            self._ctx = None
         if getattr(self, "h_", None):
             self.L.sosf_destroy(self.h_)
             self.h_ = None
@@ -261,6 +275,59 @@ class System:
         _chk(self.L.sosf_get_residuals(self.h_, _p(st), _p(act), _p(rem)), "sosf_get_residuals")
         return dict(state_state=st, isActive=act)
 
+    # ---- keyframe-rate host logic of makeKeyFrame (FS/FullSystem.cpp:783-931)
+    def add_frame_from_slot(self, frame_init, slot):
+        f = np.ascontiguousarray(np.asarray(frame_init, dtype=FRAME_INIT_DTYPE).reshape(1))
+        _chk(self.L.sosf_add_frame_from_slot(self.h_, _p(f), int(slot)), "sosf_add_frame_from_slot")
+
+    def flag_frames_for_marginalization(self, num_immature):
+        n = self.counts()[0]
+        ni = np.ascontiguousarray(num_immature, dtype=np.int32)
+        assert len(ni) == n
+        fl = np.zeros(n, dtype=np.uint8)
+        _chk(self.L.sosf_flag_frames_for_marginalization(self.h_, _p(ni), _p(fl)), "sosf_flag_frames_for_marginalization")
+        return fl.astype(bool)
+
+    def add_new_frame_residuals(self):
+        c = C.c_int(0)
+        _chk(self.L.sosf_add_new_frame_residuals(self.h_, C.byref(c)), "sosf_add_new_frame_residuals")
+        return c.value
+
+    def add_activated_points(self, pts, in_mask):
+        pts = np.ascontiguousarray(pts)
+        m = np.ascontiguousarray(in_mask, dtype=np.uint32)
+        _chk(self.L.sosf_add_activated_points(self.h_, len(pts), _p(pts), _p(m)), "sosf_add_activated_points")
+
+    def remove_outliers(self):
+        c = C.c_int(0)
+        _chk(self.L.sosf_remove_outliers(self.h_, C.byref(c)), "sosf_remove_outliers")
+        return c.value
+
+    def flag_points_for_removal(self):
+        a, b = C.c_int(0), C.c_int(0)
+        _chk(self.L.sosf_flag_points_for_removal(self.h_, C.byref(a), C.byref(b)), "sosf_flag_points_for_removal")
+        return a.value, b.value
+
+    def marginalize_flagged_frames(self, cap=8):
+        ids, poses, c = np.zeros(cap, np.int32), np.zeros((cap, 12)), C.c_int(0)
+        _chk(self.L.sosf_marginalize_flagged_frames(self.h_, cap, _p(ids), _p(poses), C.byref(c)), "sosf_marginalize_flagged_frames")
+        return ids[:c.value].copy(), poses[:c.value].copy()
+
+    def point_keys(self):
+        """(host frameID, u, v, host idx) per point in allPoints order"""
+        P = self.counts()[1]
+        hf, hi = np.zeros(P, np.int32), np.zeros(P, np.int32)
+        u, v = np.zeros(P, np.float32), np.zeros(P, np.float32)
+        _chk(self.L.sosf_get_point_keys(self.h_, _p(hf), _p(u), _p(v), _p(hi)), "sosf_get_point_keys")
+        return hf, u, v, hi
+
+    def frame_ids(self):
+        n = self.counts()[0]
+        fid, npt, nm, no = [np.zeros(n, np.int32) for _ in range(4)]
+        fl = np.zeros(n, np.uint8)
+        _chk(self.L.sosf_get_frame_ids(self.h_, _p(fid), _p(fl), _p(npt), _p(nm), _p(no)), "sosf_get_frame_ids")
+        return dict(frameID=fid, flagged=fl.astype(bool), nPoints=npt, nMarg=nm, nOut=no)
+
     def keep_last_system(self, on=True):
         _chk(self.L.sosf_keep_last_system(self.h_, int(on)), "sosf_keep_last_system")
 
@@ -320,6 +387,21 @@ class System:
         slot = C.c_int(-1)
         _chk(self.L.sosf_upload_image(self.h_, _p(img), C.byref(slot)), "sosf_upload_image")
         return slot.value
+
+    def alloc_slot(self) -> int:
+        slot = C.c_int(-1)
+        _chk(self.L.sosf_alloc_slot(self.h_, C.byref(slot)), "sosf_alloc_slot")
+        return slot.value
+
+    def release_image(self, slot):
+        _chk(self.L.sosf_release_image(self.h_, int(slot)), "sosf_release_image")
+
+    def context(self):
+        """The system's own sos_ctx as a non-owning lib.Context (front-end objects -- undistorter, pixel selector, immature
+        kernels -- work on the same frame store)."""
+        if getattr(self, "_ctx", None) is None:
+            self._ctx = _lib.BorrowedContext(self.L.sosf_ctx(self.h_), self.params.w, self.params.h)
+        return self._ctx
 
     def frame_slot(self, idx) -> int:
         return self.L.sosf_frame_slot(self.h_, idx)

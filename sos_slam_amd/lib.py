@@ -238,6 +238,25 @@ class Context:
         _chk(self.L.sos_frame_release(self.h_, slot), "sos_frame_release")
 
 
+class BorrowedContext(Context):
+    """A sos_ctx owned by somebody else (the facade's FullSystem): same methods, close() only closes the objects created
+    on it."""
+
+    def __init__(self, handle: int, w: int, h: int):
+        self.L = load()
+        self.w, self.h = w, h
+        self.h_ = C.c_void_p(handle)
+        self.levels = self.L.sos_ctx_pyr_levels(self.h_)
+
+    def close(self):
+        for r in getattr(self, "_children", []):
+            ch = r()
+            if ch is not None:
+                ch.close()
+        self._children = []
+        self.h_ = None
+
+
 class Backend:
     """sos_ba: device side of one EnergyFunctional."""
 

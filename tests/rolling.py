@@ -1,0 +1,926 @@
+"""Rolling-window harness: a synthetic keyframe sequence driven through FullSystem::makeKeyFrame's backend chain
+(FS/FullSystem.cpp:783-931) twice -- once on the device through the C++ facade, once through the CPU oracle -- so that the
+poses that LEAVE the window (the marginalised poses of the north star) and every index set on the way can be compared.
+
+Per new frame, both chains run, in the reference's order:
+  undistortion + pyramid -> trackNewestCoarse against the newest keyframe -> traceNewCoarse of all immature points ->
+  flagFramesForMarginalization -> insertFrame -> residuals of the old points towards the new keyframe -> activatePointsMT
+  (distance-map selection, optimizeImmaturePoint) -> optimize(6) -> removeOutliers -> setCoarseTrackingRef ->
+  flagPointsForRemoval + dropPointsF + marginalizePointsF -> makeNewTraces (pixel selection, ImmaturePoint constructors) ->
+  marginalizeFrame for the flagged keyframes.
+
+The stage ORDER and the bookkeeping of the immature points (which the facade leaves with the caller) are shared code
+(`Chain`); everything else differs: the device chain calls the facade's C++ (flagFramesForMarginalization,
+flagPointsForRemoval, removeOutliers, marginalizeFrame ... in csrc/host/sos_host.cpp) and the HIP kernels, the oracle chain
+keeps its own Python graph of frames / points / residuals (`OGraph`, a second statement of the same reference logic) and
+calls the C restatement for the arithmetic.
+"""
+from __future__ import annotations
+
+import dataclasses
+
+import numpy as np
+
+from oracle import oracle as orc
+from sos_slam_amd import synth
+from sos_slam_amd.records import (ACT_ACTIVATED, ACT_DELETE, IMMATURE_DTYPE, PAIR_TFM_DTYPE, ActivateParams, Calib, PixselParams,
+                                  TraceParams, random_pattern)
+
+SCALE_A, SCALE_B = synth.SCALE_A, synth.SCALE_B
+IPS_GOOD, IPS_OOB, IPS_OUTLIER, IPS_SKIPPED, IPS_BADCONDITION, IPS_UNINITIALIZED = 0, 1, 2, 3, 4, 5
+FRAME_INIT_EX_DTYPE = np.dtype([("camToWorld", "f8", (12,)), ("state", "f8", (10,)), ("state_zero", "f8", (10,)), ("ab_exposure", "f4"),
+                                ("frameID", "i4"), ("frameEnergyTH", "f4"), ("pad", "i4")], align=True)
+# reference settings read by the host logic (util/settings.cpp:61-96)
+MIN_IDEPTH_H_MARG = 50.0
+MIN_POINTS_REMAINING, MAX_LOG_AFF_FAC = 0.05, 0.7
+MIN_FRAMES, MAX_FRAMES, MIN_FRAME_AGE = 5, 7, 1
+MIN_GOOD_ACTIVE_RES, MIN_GOOD_RES = 3, 4
+
+
+def se3_inv(T):
+    return synth.se3_inv12(T)
+
+
+def se3_mul(A, B):
+    return synth.se3_mul12(A, B)
+
+
+# ------------------------------------------------------------------------------------------------
+# the synthetic sequence
+# ------------------------------------------------------------------------------------------------
+class Scenario:
+    """A camera moving past the textured surface of sos_slam_amd.synth: raw 8-bit frames, ground-truth poses, a bootstrap
+    window (what the initialiser would hand over: n0 keyframes at their true poses with noisy inverse depths)."""
+
+    def __init__(self, w=320, h=240, n_frames=26, n0=4, points0=360, seed=synth.SEED + 77, step=0.07, noise_sigma=1.0,
+                 desired_points=1000.0, immature_density=450.0):
+        self.w, self.h, self.n_frames, self.n0 = w, h, n_frames, n0
+        self.desired_points, self.immature_density = desired_points, immature_density
+        rng = np.random.default_rng(seed)
+        s = w / 752.0
+        K = np.array([458.654 * s, 457.296 * s, (367.215 + 0.5) * s - 0.5, (248.375 + 0.5) * s - 0.5])
+        self.K = K.astype(np.float32).astype(np.float64)
+        self.scene = synth._Scene(rng, s)
+        self.poses, self.raw, self.depth, self.aff_true = [], [], [], []
+        for i in range(n_frames):
+            R = synth.so3_exp(0.008 * i * np.array([0.3, 1.0, 0.2]))
+            t = step * i * np.array([1.0, 0.1, 0.05])
+            a_i, b_i = (0.0, 0.0) if i == 0 else (rng.normal(0, 0.01), rng.normal(0, 1.0))
+            img, dep = self.scene.render(R, t, self.K, w, h)
+            img = np.exp(a_i) * img + b_i + rng.normal(0, noise_sigma, img.shape)
+            self.raw.append(np.clip(np.rint(img), 0, 255).astype(np.uint8))
+            self.depth.append(dep)
+            self.poses.append(np.concatenate([R.reshape(-1), t]))
+            self.aff_true.append((a_i, b_i))
+        self.cam_txt = f"Pinhole {self.K[0]:.9g} {self.K[1]:.9g} {self.K[2]:.9g} {self.K[3]:.9g} 0\n{w} {h}\nnone\n{w} {h}\n"
+        self.params = synth.default_params(w, h)
+        self.pattern = random_pattern(w * h)
+        self.rng_boot = np.random.default_rng(seed + 1)
+        self.points0 = points0
+
+    def bootstrap_points(self, images):
+        """(POINT_DTYPE records, residual (point, target idx) list) of the bootstrap window from its undistorted images"""
+        n0, w, h = self.n0, self.w, self.h
+        rng = self.rng_boot
+        pts = np.zeros(self.points0, dtype=synth.POINT_DTYPE)
+        per = [self.points0 // n0 + (1 if i < self.points0 % n0 else 0) for i in range(n0)]
+        c = np.float32(50.0 * 50.0)
+        k = 0
+        taken = set()
+        for hst in range(n0):
+            I = images[hst]
+            m = 0
+            while m < per[hst]:
+                u, v = int(rng.integers(6, w - 6)), int(rng.integers(6, h - 6))
+                if (hst, u, v) in taken:
+                    continue
+                taken.add((hst, u, v))
+                p = pts[k]
+                p["u"], p["v"] = u, v
+                idn = np.float32((1.0 / self.depth[hst][v, u]) * (1.0 + rng.normal(0, 0.01)))
+                p["idepth_scaled"] = p["idepth_zero_scaled"] = idn
+                for q in range(8):
+                    x, y = u + synth.PATTERN[q, 0], v + synth.PATTERN[q, 1]
+                    tl, tr, bl = I[y, x], I[y, x + 1], I[y + 1, x]
+                    gx, gy = np.float32(tr - tl), np.float32(bl - tl)
+                    p["color"][q] = tl
+                    p["weights"][q] = np.sqrt(c / (c + (gx * gx + gy * gy)), dtype=np.float32)
+                p["host"] = hst
+                k += 1
+                m += 1
+        fx, fy, cx, cy = self.K
+        res = []
+        for pi in range(len(pts)):
+            p = pts[pi]
+            hst = int(p["host"])
+            Rh, th = self.poses[hst][:9].reshape(3, 3), self.poses[hst][9:]
+            X = np.array([(p["u"] - cx) / fx, (p["v"] - cy) / fy, 1.0]) / float(p["idepth_scaled"])
+            Xw = Rh @ X + th
+            for t_ in range(n0):
+                if t_ == hst:
+                    continue
+                Rt, tt = self.poses[t_][:9].reshape(3, 3), self.poses[t_][9:]
+                Xc = Rt.T @ (Xw - tt)
+                if Xc[2] <= 0.05:
+                    continue
+                Ku, Kv = fx * Xc[0] / Xc[2] + cx, fy * Xc[1] / Xc[2] + cy
+                if 5.0 < Ku < w - 7.0 and 5.0 < Kv < h - 7.0:
+                    res.append((pi, t_))
+        return pts, res
+
+
+# ------------------------------------------------------------------------------------------------
+# geometry every chain derives from ITS OWN poses / calibration, in float as the reference does
+# ------------------------------------------------------------------------------------------------
+def host_to_frame(K4, host_c2w, frame_c2w, host_aff, frame_aff):
+    """KRKi, Kt, aff of FullSystem::traceNewCoarse (FS/FullSystem.cpp:326-336), exposures 1"""
+    K = np.array([[K4[0], 0, K4[2]], [0, K4[1], K4[3]], [0, 0, 1]], dtype=np.float32)
+    T = se3_mul(se3_inv(frame_c2w), host_c2w)
+    R, t = T[:9].reshape(3, 3).astype(np.float32), T[9:].astype(np.float32)
+    KRKi = (K @ R @ np.linalg.inv(K).astype(np.float32)).astype(np.float32)
+    a = np.exp(frame_aff[0] - host_aff[0])
+    return KRKi.reshape(-1), (K @ t).astype(np.float32), np.array([a, frame_aff[1] - a * host_aff[1]], dtype=np.float32)
+
+
+def level1_to_newest(K4, poses, newest):
+    fx, fy, cx, cy = [np.float32(x) for x in K4]
+    K0 = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], dtype=np.float32)
+    K1 = np.array([[fx * np.float32(0.5), 0, (cx + np.float32(0.5)) / np.float32(2) - np.float32(0.5)],
+                   [0, fy * np.float32(0.5), (cy + np.float32(0.5)) / np.float32(2) - np.float32(0.5)], [0, 0, 1]], dtype=np.float32)
+    Ki0 = np.linalg.inv(K0).astype(np.float32)
+    KRKi, Kt = [], []
+    for f in range(len(poses)):
+        T = se3_mul(se3_inv(poses[newest]), poses[f])
+        R, t = T[:9].reshape(3, 3).astype(np.float32), T[9:].astype(np.float32)
+        KRKi.append(((K1 @ R).astype(np.float32) @ Ki0).astype(np.float32).reshape(-1))
+        Kt.append((K1 @ t).astype(np.float32))
+    return np.stack(KRKi), np.stack(Kt)
+
+
+def pair_tfms(poses, affs):
+    n = len(poses)
+    out = np.zeros(n * n, dtype=PAIR_TFM_DTYPE)
+    for hst in range(n):
+        for tgt in range(n):
+            T = se3_mul(se3_inv(poses[tgt]), poses[hst])
+            o = out[hst + n * tgt]
+            o["R"], o["t"] = T[:9].astype(np.float32), T[9:].astype(np.float32)
+            a = np.exp(affs[tgt][0] - affs[hst][0])
+            o["aff"] = (a, affs[tgt][1] - a * affs[hst][1])
+    return out
+
+
+def next_min_act_dist(d, n_points, desired):  # FS/FullSystem.cpp:377-399, in float like the member it updates
+    d = np.float32(d)
+    if n_points < desired * 0.66: d = np.float32(d - 0.8)
+    if n_points < desired * 0.8: d = np.float32(d - 0.5)
+    elif n_points < desired * 0.9: d = np.float32(d - 0.2)
+    elif n_points < desired: d = np.float32(d - 0.1)
+    if n_points > desired * 1.5: d = np.float32(d + 0.8)
+    if n_points > desired * 1.3: d = np.float32(d + 0.5)
+    if n_points > desired * 1.15: d = np.float32(d + 0.2)
+    if n_points > desired: d = np.float32(d + 0.1)
+    return float(min(max(d, np.float32(0)), np.float32(4)))
+
+
+# ------------------------------------------------------------------------------------------------
+# shared stage order + immature-point bookkeeping
+# ------------------------------------------------------------------------------------------------
+@dataclasses.dataclass
+class KeyframeLog:
+    frameID: int
+    tracked_pose: np.ndarray
+    tracked_aff: np.ndarray
+    flagged: list
+    activated: list          # (host frameID, u, v) in insertion order
+    deleted_immature: int
+    n_points_before_opt: int
+    rmse: float
+    iterations: int
+    window_ids: list
+    window_poses: dict       # frameID -> camToWorld (12) after optimize()
+    residual_set: set        # (host frameID, u, v, target frameID) after optimize()
+    outliers_removed: int
+    marg_points: int
+    dropped_points: int
+    point_set_after: set     # (host frameID, u, v) after flagPointsForRemoval
+    new_immature: int
+    marginalized: list       # [(frameID, camToWorld (12))]
+    HM: np.ndarray
+    bM: np.ndarray
+
+
+class Chain:
+    """Stage order of FullSystem::makeKeyFrame and the immature-point containers (FrameHessian::immaturePoints)."""
+
+    def __init__(self, sc: Scenario):
+        self.sc = sc
+        self.tprm, self.aprm, self.pprm = TraceParams.default(), ActivateParams.default(), PixselParams.default()
+        self.imm = {}        # frameID -> IMMATURE_DTYPE records, in FrameHessian::immaturePoints order
+        self.imm_type = {}   # frameID -> my_type per record
+        self.currentMinActDist = 2.0
+        self.logs = []
+        self.handles = {}    # frameID -> front-end handle of the keyframes in the window
+        self.next_frame = sc.n0
+
+    # ---- backend interface (implemented by DeviceChain / OracleChain)
+    def n(self): raise NotImplementedError
+
+    # ---- bootstrap: the window the initialiser would hand over
+    def bootstrap(self):
+        sc = self.sc
+        hs = [self.front_end(sc.raw[i]) for i in range(sc.n0)]
+        images = [self.irradiance(h) for h in hs]
+        pts, res = sc.bootstrap_points(images)
+        self.init_window(hs, [sc.poses[i] for i in range(sc.n0)], [sc.aff_true[i] for i in range(sc.n0)], pts, res)
+        for i in range(sc.n0):
+            self.handles[i] = hs[i]
+            self.imm[i] = np.zeros(0, dtype=IMMATURE_DTYPE)
+            self.imm_type[i] = np.zeros(0, np.float32)
+        rmse, its = self.optimize(6)
+        self.remove_outliers()
+        self.tracker_set_ref()
+        for i in range(sc.n0):      # makeNewTraces on every bootstrap keyframe: the sequence starts with candidates
+            self.make_new_traces(i)
+        self.last_rel = None
+        return rmse, its
+
+    def make_new_traces(self, frameID):   # FS/FullSystem.cpp:1071-1097
+        u, v, typ = self.pixel_select(self.handles[frameID], self.sc.immature_density)
+        rec = self.immature_init(self.handles[frameID], u, v)
+        ok = np.isfinite(rec["energyTH"])
+        self.imm[frameID] = rec[ok].copy()
+        self.imm_type[frameID] = typ[ok].astype(np.float32).copy()
+        return int(ok.sum())
+
+    # ---- one new frame = one keyframe
+    def step(self):
+        sc = self.sc
+        k = self.next_frame
+        self.next_frame += 1
+        h_new = self.front_end(sc.raw[k])
+        ids = self.window_ids()
+        ref_pose = self.kf_pose(len(ids) - 1)
+        # initial guess: constant motion (the last relative pose), FS/FullSystem.cpp:163-200 tries this one first
+        if self.last_rel is None:
+            T_init = se3_mul(se3_inv(sc.poses[k]), sc.poses[k - 1])
+            T_init = se3_mul(synth.se3_exp12(np.array([0.002, -0.001, 0.001, 0.001, -0.001, 0.0005])), T_init)
+        else:
+            T_init = self.last_rel
+        ok, T, aff, lres, flow = self.track(h_new, T_init, np.array(self.kf_aff(len(ids) - 1)))
+        assert ok, "tracking lost"
+        self.last_rel = T.copy()
+        c2w = se3_mul(ref_pose, se3_inv(T))          # shell->camToWorld = trackingRef->camToWorld * camToTrackingRef
+        # ---- makeKeyFrame
+        n = self.n()
+        poses = [self.kf_pose(i) for i in range(n)]
+        affs = [self.kf_aff(i) for i in range(n)]
+        K4 = self.K()
+        # traceNewCoarse
+        for i, fid in enumerate(ids):
+            if len(self.imm[fid]) == 0:
+                continue
+            KRKi, Kt, a = host_to_frame(K4, poses[i], c2w, affs[i], aff)
+            self.imm[fid] = self.trace(h_new, self.imm[fid], KRKi, Kt, a)
+        flagged = self.flag_frames([len(self.imm[f]) for f in ids])
+        self.add_keyframe(h_new, c2w, aff, k)
+        self.handles[k] = h_new
+        self.imm[k] = np.zeros(0, dtype=IMMATURE_DTYPE)
+        self.imm_type[k] = np.zeros(0, np.float32)
+        self.add_old_point_residuals()
+        activated, deleted = self.activate_points(flagged)
+        npts = self.n_points()
+        rmse, its = self.optimize(6)
+        ids2 = self.window_ids()
+        window_poses = {fid: self.kf_pose(i).copy() for i, fid in enumerate(ids2)}
+        residual_set = self.residual_set()
+        nout = self.remove_outliers()
+        self.tracker_set_ref()
+        nmarg, ndrop = self.flag_points_for_removal()
+        point_set = self.point_set()
+        nimm = self.make_new_traces(k)
+        marg = self.marginalize_flagged()
+        for fid, _ in marg:
+            self.release(self.handles.pop(fid))
+            self.imm.pop(fid)
+            self.imm_type.pop(fid)
+        HM, bM = self.prior()
+        self.logs.append(KeyframeLog(k, T, np.asarray(aff, dtype=np.float64), [ids[i] for i in np.flatnonzero(flagged)], activated, deleted, npts, rmse,
+                                     its, ids2, window_poses, residual_set, nout, nmarg, ndrop, point_set, nimm, marg, HM, bM))
+        return self.logs[-1]
+
+    def activate_points(self, flagged_old):     # FS/FullSystem.cpp:376-533
+        sc = self.sc
+        self.currentMinActDist = next_min_act_dist(self.currentMinActDist, self.n_points(), sc.desired_points)
+        n = self.n()
+        ids = self.window_ids()
+        newest = n - 1
+        poses = [self.kf_pose(i) for i in range(n)]
+        affs = [self.kf_aff(i) for i in range(n)]
+        KRKi1, Kt1 = level1_to_newest(self.K(), poses, newest)
+        cand, cand_host, cand_type, src = [], [], [], []
+        for i, fid in enumerate(ids[:-1]):
+            m = len(self.imm[fid])
+            cand.append(self.imm[fid])
+            cand_host.append(np.full(m, i, np.int32))
+            cand_type.append(self.imm_type[fid])
+            src += [(fid, j) for j in range(m)]
+        cand = np.concatenate(cand) if cand else np.zeros(0, dtype=IMMATURE_DTYPE)
+        cand_host = np.concatenate(cand_host) if cand_host else np.zeros(0, np.int32)
+        cand_type = np.concatenate(cand_type) if cand_type else np.zeros(0, np.float32)
+        host_flagged = np.zeros(n, np.uint8)
+        host_flagged[:len(flagged_old)] = np.asarray(flagged_old, dtype=np.uint8)
+        dec = self.select(sc.w // 2, sc.h // 2, newest, KRKi1, Kt1, self.active_points(), self.currentMinActDist, 3.0, cand, cand_host,
+                          cand_type, host_flagged)
+        todo = np.flatnonzero(dec == 1)
+        act = self.activate(cand[todo], cand_host[todo], poses, affs)
+        gone = set(np.flatnonzero(dec == -1).tolist())
+        new_pts, masks, keys = [], [], []
+        for j, a in zip(todo, act):
+            if a["status"] == ACT_ACTIVATED:
+                p = np.zeros(1, dtype=synth.POINT_DTYPE)[0]
+                r = cand[j]
+                p["u"], p["v"] = r["u"], r["v"]
+                p["idepth_scaled"] = p["idepth_zero_scaled"] = a["idepth"]
+                p["color"], p["weights"] = r["color"], r["weights"]
+                p["host"] = cand_host[j]
+                new_pts.append(p)
+                masks.append(int(a["inMask"]))
+                keys.append((ids[cand_host[j]], float(r["u"]), float(r["v"])))
+                gone.add(int(j))
+            elif a["status"] == ACT_DELETE or r_status(cand[j]) == IPS_OOB:
+                gone.add(int(j))
+        if new_pts:
+            self.add_activated(np.array(new_pts, dtype=synth.POINT_DTYPE), np.array(masks, dtype=np.uint32))
+        # removal with the reference's swap-from-the-back compaction (:519-531) per host
+        by_host = {}
+        for j in gone:
+            fid, loc = src[j]
+            by_host.setdefault(fid, set()).add(loc)
+        for fid, locs in by_host.items():
+            recs, typ = list(self.imm[fid]), list(self.imm_type[fid])
+            alive = [j not in locs for j in range(len(recs))]
+            i = 0
+            while i < len(recs):
+                if not alive[i]:
+                    recs[i], typ[i], alive[i] = recs[-1], typ[-1], alive[-1]
+                    recs.pop(); typ.pop(); alive.pop()
+                    continue
+                i += 1
+            self.imm[fid] = np.array(recs, dtype=IMMATURE_DTYPE) if recs else np.zeros(0, dtype=IMMATURE_DTYPE)
+            self.imm_type[fid] = np.array(typ, dtype=np.float32)
+        return keys, len(gone) - len(keys)
+
+
+def r_status(rec):
+    return int(rec["lastTraceStatus"])
+
+
+# ------------------------------------------------------------------------------------------------
+# device chain: facade (C++) + HIP kernels
+# ------------------------------------------------------------------------------------------------
+class DeviceChain(Chain):
+    def __init__(self, sc):
+        super().__init__(sc)
+        from sos_slam_amd import host, lib
+        self.host, self.lib = host, lib
+        self.sysm = host.System(sc.params)
+        self.sysm.set_calib(sc.K)
+        self.ctx = self.sysm.context()
+        self.und = lib.Undistorter(self.ctx, lib.camera_parse(sc.cam_txt))
+        self.sel = lib.PixelSelector(self.ctx, self.pprm, sc.pattern)
+        self.trk = None
+
+    def close(self):
+        self.sysm.close()
+
+    def n(self): return self.sysm.counts()[0]
+    def n_points(self): return self.sysm.counts()[1]
+    def K(self): return self.sysm.calib_value_scaled()
+    def window_ids(self): return self.sysm.frame_ids()["frameID"].tolist()
+    def kf_pose(self, i): return self.sysm.frame(i)["camToWorld"]
+
+    def kf_aff(self, i):
+        st = self.sysm.frame(i)["state"]
+        return (st[6] * SCALE_A, st[7] * SCALE_B)
+
+    def front_end(self, raw):
+        slot = self.sysm.alloc_slot()
+        self.und.frame(raw, 0.0, slot, want_image=False)
+        return slot
+
+    def irradiance(self, slot):
+        return self.ctx.download_level(slot, 0)[0][..., 0].copy()
+
+    def release(self, slot):
+        pass   # the facade released the keyframe's slot with the frame (marginalizeFrame)
+
+    def init_window(self, hs, poses, affs, pts, res):
+        for i, (slot, T, aff) in enumerate(zip(hs, poses, affs)):
+            f = np.zeros(1, dtype=synth.FRAME_INIT_DTYPE)[0]
+            f["camToWorld"] = T
+            f["state"][6], f["state"][7] = aff[0] / SCALE_A, aff[1] / SCALE_B
+            f["ab_exposure"], f["frameID"], f["frameEnergyTH"] = 1.0, i, 8 * 8 * 8
+            self.sysm.add_frame_from_slot(f, slot)
+        self.sysm.add_points(pts)
+        rr = np.zeros(len(res), dtype=synth.RESID_DTYPE)
+        for k, (pi, t) in enumerate(res):
+            rr[k] = (pi, pts[pi]["host"], t, synth.RF_ISNEW, synth.RES_IN, 0.0)
+        self.sysm.add_residuals(rr)
+
+    def tracker_set_ref(self):
+        if self.trk is None:
+            self.trk = self.host.HostTracker(self.sysm)
+        self.trk.set_ref()
+
+    def track(self, slot, T_init, ref_aff):
+        levels = self.ctx.levels
+        ok, T, aff, lres, flow = self.trk.track(slot, 1.0, T_init, ref_aff, levels - 1)
+        return ok, T, aff, lres, flow
+
+    def trace(self, slot, recs, KRKi, Kt, aff):
+        return self.ctx.immature_trace(self.tprm, slot, recs, KRKi, Kt, aff)
+
+    def flag_frames(self, num_immature):
+        return self.sysm.flag_frames_for_marginalization(num_immature)
+
+    def add_keyframe(self, slot, c2w, aff, frameID):
+        f = np.zeros(1, dtype=synth.FRAME_INIT_DTYPE)[0]
+        f["camToWorld"] = c2w
+        f["state"][6], f["state"][7] = aff[0] / SCALE_A, aff[1] / SCALE_B
+        f["ab_exposure"], f["frameID"], f["frameEnergyTH"] = 1.0, frameID, 8 * 8 * 8
+        self.sysm.add_frame_from_slot(f, slot)
+
+    def add_old_point_residuals(self):
+        return self.sysm.add_new_frame_residuals()
+
+    def active_points(self):
+        hf, u, v, hi = self.sysm.point_keys()
+        p = self.sysm.points()
+        out = np.zeros(len(u), dtype=[("u", "f4"), ("v", "f4"), ("idepth_scaled", "f4"), ("host", "i4")])
+        out["u"], out["v"], out["idepth_scaled"], out["host"] = u, v, p["idepth"], hi
+        return out
+
+    def select(self, w1, h1, newest, KRKi, Kt, act, min_dist, min_quality, cand, cand_host, cand_type, flagged):
+        return self.host.activate_select(w1, h1, newest, KRKi, Kt, act, min_dist, min_quality, cand, cand_host, cand_type, flagged)[0]
+
+    def activate(self, recs, host_idx, poses, affs):
+        n = self.n()
+        calib = Calib.from_K(self.K())
+        slots = [self.sysm.frame_slot(i) for i in range(n)]
+        return self.ctx.immature_activate(self.aprm, calib, slots, pair_tfms(poses, affs), recs, host_idx)
+
+    def add_activated(self, pts, masks):
+        self.sysm.add_activated_points(pts, masks)
+
+    def optimize(self, its):
+        return self.sysm.optimize(its)
+
+    def remove_outliers(self):
+        return self.sysm.remove_outliers()
+
+    def flag_points_for_removal(self):
+        return self.sysm.flag_points_for_removal()
+
+    def pixel_select(self, slot, density):
+        self.sel.make_maps(slot, density, want_map=False)
+        return self.sel.list(pattern_padding=2)
+
+    def immature_init(self, slot, u, v):
+        return self.ctx.immature_init(self.tprm, slot, u, v)
+
+    def marginalize_flagged(self):
+        ids, poses = self.sysm.marginalize_flagged_frames()
+        return [(int(i), p.copy()) for i, p in zip(ids, poses)]
+
+    def prior(self):
+        return self.sysm.get_prior()
+
+    def residual_set(self):
+        hf, u, v, _ = self.sysm.point_keys()
+        ids = self.sysm.point_ids()
+        key = {int(i): (int(a), float(b), float(c)) for i, a, b, c in zip(ids, hf, u, v)}
+        pi, tf = self.sysm.residual_ids()
+        return {key[int(p)] + (int(t),) for p, t in zip(pi, tf)}
+
+    def point_set(self):
+        hf, u, v, _ = self.sysm.point_keys()
+        return {(int(a), float(b), float(c)) for a, b, c in zip(hf, u, v)}
+
+
+# ------------------------------------------------------------------------------------------------
+# oracle chain: its own graph (second statement of the host logic) + the C restatement for the arithmetic
+# ------------------------------------------------------------------------------------------------
+class ORes:
+    __slots__ = ("point", "target", "state_state", "state_energy", "center")
+
+    def __init__(self, point, target):
+        self.point, self.target = point, target
+        self.state_state, self.state_energy = synth.RES_IN, 0.0
+        self.center = np.zeros(3, np.float32)
+
+
+class OPoint:
+    def __init__(self, host, rec_u, rec_v, idepth, color, weights):
+        self.host = host
+        self.u, self.v = np.float32(rec_u), np.float32(rec_v)
+        self.idepth = self.idepth_zero = np.float32(idepth)
+        self.color, self.weights = np.array(color, np.float32), np.array(weights, np.float32)
+        self.residuals = []          # EFPoint::residualsAll order (insert at the back, drop = swap with the back)
+        self.last = [[None, synth.RES_OOB], [None, synth.RES_OOB]]
+        self.numGoodResiduals = 0
+        self.maxRelBaseline = np.float32(0)
+        self.idepth_hessian = np.float32(0)
+        self.HdiF = np.float32(0)
+        self.priorF = np.float32(0)
+
+    def key(self):
+        return (self.host.frameID, float(self.u), float(self.v))
+
+    def drop_residual(self, r):
+        i = self.residuals.index(r)
+        self.residuals[i] = self.residuals[-1]
+        self.residuals.pop()
+
+
+class OFrame:
+    def __init__(self, frameID, handle, c2w, aff):
+        self.frameID, self.handle = frameID, handle
+        self.evalPT = np.array(c2w, dtype=np.float64)
+        self.state = np.zeros(10)
+        self.state[6], self.state[7] = aff[0] / SCALE_A, aff[1] / SCALE_B
+        self.state_zero = self.state.copy()
+        self.pre = self.evalPT.copy()      # PRE_camToWorld
+        self.frameEnergyTH = np.float32(8 * 8 * 8)
+        self.flagged = False
+        self.points = []
+        self.n_marg = self.n_out = 0
+
+
+class OracleChain(Chain):
+    def __init__(self, sc, truth=False):
+        super().__init__(sc)
+        self.truth = truth
+        self.und = orc.Undistorter(sc.cam_txt)
+        self.sel = orc.PixelSelector(self.pprm, sc.pattern, sc.w, sc.h)
+        self.frames = []
+        # CalibHessian(): setValueScaled then value_zero = value (FS/HessianBlocks.h:453-475): (1.0f / SCALE_F) * value_scaled
+        self.calib_value = np.array([float(np.float32(1.0) / np.float32(50.0)) * v for v in sc.K])
+        self.calib_value_zero = self.calib_value.copy()
+        self.HM, self.bM = np.zeros((4, 4)), np.zeros(4)
+        self.trk = None
+        self.sel_slot = None
+
+    def close(self):
+        pass
+
+    # ---- queries
+    def n(self): return len(self.frames)
+    def n_points(self): return sum(len(f.points) for f in self.frames)
+    def K(self): return np.array([50.0 * self.calib_value[0], 50.0 * self.calib_value[1], 50.0 * self.calib_value[2], 50.0 * self.calib_value[3]])
+    def window_ids(self): return [f.frameID for f in self.frames]
+    def kf_pose(self, i): return self.frames[i].pre
+    def kf_aff(self, i): return (self.frames[i].state[6] * SCALE_A, self.frames[i].state[7] * SCALE_B)
+
+    def front_end(self, raw):
+        img = self.und.frame(raw, 0.0)
+        dI, absg = orc.make_images(img)
+        return dict(dI=dI, absg=absg)
+
+    def irradiance(self, h):
+        return h["dI"][0][..., 0].copy()
+
+    def release(self, h):
+        pass
+
+    def _grow_prior(self):
+        odim = self.HM.shape[0]
+        HM, bM = np.zeros((odim + 8, odim + 8)), np.zeros(odim + 8)
+        HM[:odim, :odim], bM[:odim] = self.HM, self.bM
+        self.HM, self.bM = HM, bM
+
+    def init_window(self, hs, poses, affs, pts, res):
+        for i, (h, T, aff) in enumerate(zip(hs, poses, affs)):
+            self.frames.append(OFrame(i, h, T, aff))
+            self._grow_prior()
+        plist = []
+        for p in pts:
+            op = OPoint(self.frames[int(p["host"])], p["u"], p["v"], p["idepth_scaled"], p["color"], p["weights"])
+            self.frames[int(p["host"])].points.append(op)
+            plist.append(op)
+        for pi, t in res:                      # sosf_add_residuals semantics: lastResiduals shifted per added residual
+            op = plist[pi]
+            r = ORes(op, self.frames[t])
+            op.residuals.append(r)
+            op.last[1] = op.last[0]
+            op.last[0] = [r, synth.RES_IN]
+
+    # ---- tracker
+    def tracker_set_ref(self):   # CoarseTracker::setCoarseTrackingRef, FS/CoarseTracker.cpp:56-79, 232-242
+        last = self.frames[-1]
+        u, v, idp, hdi = [], [], [], []
+        for f in self.frames:
+            for p in f.points:
+                r, st = p.last[0]
+                if r is not None and st == synth.RES_IN and r.target is last:
+                    u.append(r.center[0]); v.append(r.center[1]); idp.append(r.center[2]); hdi.append(p.HdiF)
+        self.trk = orc.OracleTracker(self.sc.params, self.sc.w, self.sc.h)
+        self.trk.set_truth_mode(self.truth)
+        self.trk.set_ref(Calib.from_K(self.K()), last.handle["dI"], np.array(u, np.float32), np.array(v, np.float32), np.array(idp, np.float32),
+                         np.array(hdi, np.float32))
+        self.trk_ref_aff = np.array(self.kf_aff(len(self.frames) - 1))
+
+    def track(self, h, T_init, ref_aff):
+        levels = self.trk.levels
+        ok, T, aff, lres, flow = self.trk.track(h["dI"], 1.0, 1.0, self.trk_ref_aff, T_init, ref_aff, levels - 1)
+        return bool(ok), T, aff, lres, flow
+
+    def trace(self, h, recs, KRKi, Kt, aff):
+        return orc.immature_trace(self.tprm, h["dI"][0], recs, KRKi, Kt, aff)
+
+    # ---- FullSystem::flagFramesForMarginalization, FS/FullSystemMarginalize.cpp:53-133
+    def flag_frames(self, num_immature):
+        fr = self.frames
+        flagged = 0
+        back = fr[-1]
+        for f, ni in zip(fr, num_immature):
+            n_in = len(f.points) + ni
+            n_out = f.n_marg + f.n_out
+            a = np.exp(f.state[6] * SCALE_A - back.state[6] * SCALE_A)      # fromToVecExposure(back -> f)[0], exposures 1
+            if (n_in < MIN_POINTS_REMAINING * (n_in + n_out) or abs(np.log(np.float32(a))) > MAX_LOG_AFF_FAC) and len(fr) - flagged > MIN_FRAMES:
+                f.flagged = True
+                flagged += 1
+        if len(fr) - flagged >= MAX_FRAMES:
+            smallest, pick = 1.0, None
+            latest = fr[-1]
+            for f in fr:
+                if f.frameID > latest.frameID - MIN_FRAME_AGE or f.frameID == 0:
+                    continue
+                score = 0.0
+                for t in fr:
+                    if t.frameID > latest.frameID - MIN_FRAME_AGE + 1 or t is f:
+                        continue
+                    score += 1 / (1e-5 + self._distance(f, t))
+                score *= -np.sqrt(np.float32(self._distance(f, fr[-1])))
+                if score < smallest:
+                    smallest, pick = score, f
+            if pick is not None:
+                pick.flagged = True
+        return np.array([f.flagged for f in fr])
+
+    @staticmethod
+    def _distance(host, target):     # FrameFramePrecalc::distanceLL (float)
+        T = se3_mul(se3_inv(target.pre), host.pre)
+        return float(np.float32(np.linalg.norm(T[9:])))
+
+    def add_keyframe(self, h, c2w, aff, frameID):
+        self.frames.append(OFrame(frameID, h, c2w, aff))
+        self._grow_prior()
+
+    def add_old_point_residuals(self):    # FS/FullSystem.cpp:818-832
+        new = self.frames[-1]
+        c = 0
+        for f in self.frames[:-1]:
+            for p in f.points:
+                r = ORes(p, new)
+                p.residuals.append(r)
+                p.last[1] = p.last[0]
+                p.last[0] = [r, synth.RES_IN]
+                c += 1
+        return c
+
+    def active_points(self):
+        n = self.n_points()
+        out = np.zeros(n, dtype=[("u", "f4"), ("v", "f4"), ("idepth_scaled", "f4"), ("host", "i4")])
+        k = 0
+        for i, f in enumerate(self.frames):
+            for p in f.points:
+                out[k] = (p.u, p.v, p.idepth, i)
+                k += 1
+        return out
+
+    def select(self, w1, h1, newest, KRKi, Kt, act, min_dist, min_quality, cand, cand_host, cand_type, flagged):
+        return orc.activate_select(w1, h1, newest, KRKi, Kt, act, min_dist, min_quality, cand, cand_host, cand_type, flagged)[0]
+
+    def activate(self, recs, host_idx, poses, affs):
+        calib = Calib.from_K(self.K())
+        return orc.immature_activate(self.aprm, calib, [f.handle["dI"][0] for f in self.frames], pair_tfms(poses, affs), recs, host_idx)
+
+    def add_activated(self, pts, masks):       # FS/FullSystemOptPoint.cpp:151-185
+        nf = len(self.frames)
+        newest, second = self.frames[-1], (self.frames[-2] if nf >= 2 else None)
+        for p, m in zip(pts, masks):
+            host = self.frames[int(p["host"])]
+            op = OPoint(host, p["u"], p["v"], p["idepth_scaled"], p["color"], p["weights"])
+            for t in range(nf):
+                if not ((int(m) >> t) & 1) or self.frames[t] is host:
+                    continue
+                r = ORes(op, self.frames[t])
+                op.residuals.append(r)
+                if r.target is newest:
+                    op.last[0] = [r, synth.RES_IN]
+                elif r.target is second:
+                    op.last[1] = [r, synth.RES_IN]
+            host.points.append(op)
+
+    # ---- optimize(): pack the graph, run the C restatement's loop, read everything back
+    def _pack(self):
+        n = len(self.frames)
+        idx = {id(f): i for i, f in enumerate(self.frames)}
+        plist = [p for f in self.frames for p in f.points]
+        pts = np.zeros(len(plist), dtype=synth.POINT_DTYPE)
+        rlist = []
+        for k, p in enumerate(plist):
+            pts[k]["u"], pts[k]["v"] = p.u, p.v
+            pts[k]["idepth_scaled"], pts[k]["idepth_zero_scaled"] = p.idepth, p.idepth_zero
+            pts[k]["color"], pts[k]["weights"] = p.color, p.weights
+            pts[k]["priorF"] = p.priorF
+            pts[k]["deltaF"] = np.float32(p.idepth - p.idepth_zero)
+            pts[k]["host"] = idx[id(p.host)]
+            for r in p.residuals:
+                rlist.append((k, r))
+        res = np.zeros(len(rlist), dtype=synth.RESID_DTYPE)
+        for j, (k, r) in enumerate(rlist):
+            # optimize() starts with resetOOB on every residual; isActive of the last apply is what the graph carries
+            res[j] = (k, pts[k]["host"], idx[id(r.target)], synth.RF_ISNEW | synth.RF_ACTIVE, r.state_state, r.state_energy)
+        ow = orc.OracleWindow(self.sc.params, n, pts, res)
+        for i, f in enumerate(self.frames):
+            ow.set_image(i, f.handle["dI"][0])
+        fe = np.zeros(n, dtype=FRAME_INIT_EX_DTYPE)
+        for i, f in enumerate(self.frames):
+            fe[i]["camToWorld"], fe[i]["state"], fe[i]["state_zero"] = f.evalPT, f.state, f.state_zero
+            fe[i]["ab_exposure"], fe[i]["frameID"], fe[i]["frameEnergyTH"] = 1.0, f.frameID, f.frameEnergyTH
+        ow.host_init_ex(fe, self.calib_value, self.calib_value_zero, self.HM, self.bM)
+        ow.set_truth_mode(self.truth)
+        return ow, plist, rlist
+
+    def _unpack_frames(self, ow):
+        for i, f in enumerate(self.frames):
+            fr = ow.frame(i)
+            f.state, f.state_zero, f.pre = fr["state"].copy(), fr["state_zero"].copy(), fr["camToWorld"].copy()
+            f.evalPT = ow.evalpt(i)
+            f.frameEnergyTH = np.float32(fr["frameEnergyTH"])
+        self.calib_value, _ = ow.calib_value()
+
+    def optimize(self, its):
+        ow, plist, rlist = self._pack()
+        rmse, it = ow.optimize(its)
+        self._unpack_frames(ow)
+        po, ro, cen = ow.pts(), ow.res(), ow.center()
+        ngr, mrb = ow.num_good_residuals(), ow.point_field("maxRelBaseline")
+        idh, hdi = ow.point_field("idepth_hessian"), ow.point_field("HdiF")
+        has_act = np.zeros(len(plist), bool)
+        for k, p in enumerate(plist):
+            p.idepth, p.idepth_zero = po[k]["idepth_scaled"], po[k]["idepth_zero_scaled"]
+            p.numGoodResiduals += int(ngr[k])
+            p.maxRelBaseline = max(p.maxRelBaseline, mrb[k])
+            p.idepth_hessian, p.HdiF = idh[k], hdi[k]
+        # linearizeAll(true): states, lastResiduals bookkeeping, removal of the residuals that are not active (:148-179)
+        for j, (k, r) in enumerate(rlist):
+            r.state_state, r.state_energy = int(ro[j]["state_state"]), float(ro[j]["state_energy"])
+            r.center = cen[j].copy()
+            p = r.point
+            if p.last[0][0] is r:
+                p.last[0][1] = r.state_state
+            elif p.last[1][0] is r:
+                p.last[1][1] = r.state_state
+        for j, (k, r) in enumerate(rlist):
+            if ro[j]["flags"] & 0x100:
+                p = r.point
+                if p.last[0][0] is r:
+                    p.last[0][0] = None
+                elif p.last[1][0] is r:
+                    p.last[1][0] = None
+                p.drop_residual(r)
+        ow.close()
+        return rmse, it
+
+    def remove_outliers(self):     # FS/FullSystemOptimize.cpp:507-526
+        c = 0
+        for f in self.frames:
+            i = 0
+            while i < len(f.points):
+                if not f.points[i].residuals:
+                    f.n_out += 1
+                    f.points[i] = f.points[-1]
+                    f.points.pop()
+                    c += 1
+                    continue
+                i += 1
+        return c
+
+    def _is_oob(self, p, to_marg):     # FS/HessianBlocks.h:619-643
+        vis = sum(1 for r in p.residuals if r.state_state == synth.RES_IN and r.target in to_marg)
+        if len(p.residuals) >= MIN_GOOD_ACTIVE_RES and p.numGoodResiduals > MIN_GOOD_RES + 10 and len(p.residuals) - vis < MIN_GOOD_ACTIVE_RES:
+            return True
+        if p.last[0][1] == synth.RES_OOB:
+            return True
+        if len(p.residuals) < 2:
+            return False
+        return p.last[0][1] == synth.RES_OUTLIER and p.last[1][1] == synth.RES_OUTLIER
+
+    def flag_points_for_removal(self):    # FS/FullSystem.cpp:535-614 + dropPointsF + marginalizePointsF
+        to_marg_frames = [f for f in self.frames if f.flagged]
+        inliers, dropped = [], 0
+        for f in self.frames:
+            holes = set()
+            for i, p in enumerate(f.points):
+                if p.idepth < 0 or not p.residuals:
+                    f.n_out += 1
+                    holes.add(i); dropped += 1
+                elif self._is_oob(p, to_marg_frames) or f.flagged:
+                    if len(p.residuals) >= MIN_GOOD_ACTIVE_RES and p.numGoodResiduals >= MIN_GOOD_RES:
+                        inliers.append(p)
+                    else:
+                        f.n_out += 1
+                        dropped += 1
+                    holes.add(i)
+            i = 0
+            alive = [j not in holes for j in range(len(f.points))]
+            pts = f.points
+            while i < len(pts):
+                if not alive[i]:
+                    pts[i], alive[i] = pts[-1], alive[-1]
+                    pts.pop(); alive.pop()
+                    continue
+                i += 1
+        margd = 0
+        if inliers:
+            # the window as the C restatement sees it at this moment: remaining points + the inliers that are about to leave
+            keep = [p for f in self.frames for p in f.points]
+            order = {id(f): i for i, f in enumerate(self.frames)}
+            allp = sorted(keep + inliers, key=lambda p: order[id(p.host)])   # frames -> points (stable)
+            saved = {id(f): f.points for f in self.frames}
+            for f in self.frames:
+                f.points = [p for p in allp if p.host is f]
+            ow, plist, rlist = self._pack()
+            for f in self.frames:
+                f.points = saved[id(f)]
+            pos = {id(p): k for k, p in enumerate(plist)}
+            # per-point results of the last accumulate of optimize() decide marginalise vs drop
+            idh = ow.point_field("idepth_hessian")
+            for k, p in enumerate(plist):
+                idh[k] = p.idepth_hessian
+            sel = np.array([pos[id(p)] for p in inliers], dtype=np.int32)
+            flag = ow.marginalize_points(sel)
+            self.HM, self.bM = ow.get_prior()
+            for p, fl in zip(inliers, flag):
+                if fl:
+                    p.host.n_marg += 1
+                    margd += 1
+                else:
+                    p.host.n_out += 1
+            ow.close()
+        return margd, dropped + (len(inliers) - margd)
+
+    def pixel_select(self, h, density):     # makeMaps + the scan of FullSystem::makeNewTraces (FS/FullSystem.cpp:1083-1095)
+        if self.sel_slot is not h:
+            self.sel.make_hists(h["absg"][0])
+            self.sel_slot = h
+        m, num = self.sel.make_maps(h["dI"], h["absg"], density)
+        pad = 2
+        sub = m[pad + 1:self.sc.h - pad - 2, pad + 1:self.sc.w - pad - 2]
+        ys, xs = np.nonzero(sub)                                    # row-major
+        u, v = (xs + pad + 1).astype(np.int32), (ys + pad + 1).astype(np.int32)
+        return u, v, m[v, u].astype(np.float32)
+
+    def immature_init(self, h, u, v):
+        return orc.immature_init(self.tprm, h["dI"][0], u, v)
+
+    def marginalize_flagged(self):     # FS/FullSystem.cpp:926-931, OB/EnergyFunctional.cpp:730-889 (prior), FS/FullSystemMarginalize.cpp:143-236
+        out = []
+        i = 0
+        while i < len(self.frames):
+            f = self.frames[i]
+            if not f.flagged:
+                i += 1
+                continue
+            assert not f.points
+            out.append((f.frameID, f.pre.copy()))
+            ow, plist, rlist = self._pack()
+            self.HM, self.bM = ow.marginalize_frame_prior(i)
+            ow.close()
+            for g in self.frames:
+                if g is f:
+                    continue
+                for p in g.points:
+                    for r in list(p.residuals):
+                        if r.target is f:
+                            if p.last[0][0] is r:
+                                p.last[0][0] = None
+                            elif p.last[1][0] is r:
+                                p.last[1][0] = None
+                            p.drop_residual(r)
+                            break
+            self.frames.pop(i)
+            i = 0
+        return out
+
+    def prior(self):
+        return self.HM.copy(), self.bM.copy()
+
+    def residual_set(self):
+        return {p.key() + (r.target.frameID,) for f in self.frames for p in f.points for r in p.residuals}
+
+    def point_set(self):
+        return {p.key() for f in self.frames for p in f.points}
