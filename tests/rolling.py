@@ -75,13 +75,13 @@ class Scenario:
         self.cam_txt = f"Pinhole {self.K[0]:.9g} {self.K[1]:.9g} {self.K[2]:.9g} {self.K[3]:.9g} 0\n{w} {h}\nnone\n{w} {h}\n"
         self.params = synth.default_params(w, h)
         self.pattern = random_pattern(w * h)
-        self.rng_boot = np.random.default_rng(seed + 1)
+        self.seed_boot = seed + 1
         self.points0 = points0
 
     def bootstrap_points(self, images):
         """(POINT_DTYPE records, residual (point, target idx) list) of the bootstrap window from its undistorted images"""
         n0, w, h = self.n0, self.w, self.h
-        rng = self.rng_boot
+        rng = np.random.default_rng(self.seed_boot)     # the same points for every chain
         pts = np.zeros(self.points0, dtype=synth.POINT_DTYPE)
         per = [self.points0 // n0 + (1 if i < self.points0 % n0 else 0) for i in range(n0)]
         c = np.float32(50.0 * 50.0)
