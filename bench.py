@@ -10,11 +10,15 @@ point-residuals linearised per second through whole iterations, summed over all 
   python bench.py --gpus 1 --steps K --warmup W           single GPU
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   one rank per GPU (RCCL)
 
-Multi-GPU (weak scaling): every rank holds the same 12 keyframes and its own shard of 4096
-points; the packed fp32 H/b accumulators are all-reduced over RCCL once per iteration (by the library itself, on
-its stream, inside the prefetched accumulate chain: sos_ba_set_comm), every rank then runs the identical fp64
-stitch + solve.  The timed region is bracketed by barrier + torch.cuda.synchronize and
-the MAX over ranks is reported.
+Multi-GPU: every rank holds the same keyframes and a shard of the points; the packed fp32 H/b
+accumulators are all-reduced over RCCL once per iteration (by the library itself, on its stream, inside the prefetched
+accumulate chain: sos_ba_set_comm), every rank then runs the identical fp64 stitch + solve.
+  --scaling weak   (default) every rank its own W12 shard of 4096 points: per-GPU work fixed
+  --scaling strong BASELINE.json config 5: ONE window (default W16: 16 KF x 8192 points) whose points are sharded over
+                   the ranks (contiguous slices of the allPoints order balanced by residual count)
+The timed region is bracketed by barrier + torch.cuda.synchronize and the MAX over ranks is reported.  A Gauss-Newton
+iteration takes under 0.1 ms, so every step is timed as the mean of `--inner` consecutive iterations (default: enough for
+a timed region of >= 50 ms); ms_per_step and value are per single iteration.
 """
 from __future__ import annotations
 
@@ -32,6 +36,9 @@ if ROOT not in sys.path:
 
 LINEARIZE_BYTES_PER_RESIDUAL = 776  # 80 point + 384 gather + 296 J + 16 state
 TOP_BYTES_PER_RESIDUAL = 312        # top accumulate = J read 296 + indices/flags 16
+# what the FUSED kernel has to move at least (the Jacobian tile never leaves the chip): 80 point copies + 384 texels +
+# 16 state + 32 JpJdF + 32 point terms + 12 centre + 12 tile block sums (384 B per 32 residuals) ~ 568 B
+FUSED_MIN_BYTES_PER_RESIDUAL = 568
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -40,20 +47,28 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--window", default="W12")
+    ap.add_argument("--window", default=None, help="W7 / W12 / W16 (default: W12, or W16 with --scaling strong)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--inner", type=int, default=0, help="GN iterations per timed step (0 = enough for a >= 50 ms region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
+    ap.add_argument("--cpu-seconds", type=float, default=14.0)
+    a = ap.parse_args()
+    if a.window is None:
+        a.window = "W16" if a.scaling == "strong" else "W12"
+    if a.inner <= 0:
+        a.inner = max(1, -(-700 // max(a.steps, 1)))   # ~0.08 ms per iteration: steps x inner >= 700 iterations
+    return a
 
 
 def cpu_baseline(win, seconds):
-    """The oracle's GN loop (C restatement of the reference's CPU path, 6-thread pool with the reference's
-    chunking) timed on this box's host cores on a bounded number of iterations of the same window."""
+    """The C restatement of the reference's CPU path (kind "port"), timing build: -O3 -march=native like the reference's
+    own CMakeLists.txt:26, compiled on this box; the reference's 6-thread fork/join pool with its chunking
+    (util/IndexThreadReduce.h) and, beside it, one thread.  A bounded number of GN iterations of the same window."""
     from oracle import oracle as orc
     cores = min(6, os.cpu_count() or 1)
 
     def run(nthreads, budget):
-        ow = orc.window_from_synth(win)
+        ow = orc.window_from_synth(win, fast=True)
         ow.reset_oob()
         th = np.array([ow.frame(f)["frameEnergyTH"] for f in range(win.n)], np.float32)
         ow.linearize(th, nthreads=nthreads)
@@ -64,18 +79,24 @@ def cpu_baseline(win, seconds):
         while True:
             ow.gn_iteration(it + 1, nthreads=nthreads)
             it += 1
-            if time.perf_counter() - t0 > budget or it >= 200:
+            if time.perf_counter() - t0 > budget or it >= 400:
                 break
         dt = time.perf_counter() - t0
         ow.close()
         return win.R * it / dt, it / dt, it
 
-    v6, g6, it6 = run(cores, seconds * 0.7)
-    v1, g1, it1 = run(1, seconds * 0.3)
+    v6, g6, it6 = run(cores, seconds * 0.6)
+    v1, g1, it1 = run(1, seconds * 0.4)
+    try:
+        model = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
+    except Exception:  # noqa: BLE001
+        model = "unknown"
     return {"value": v6, "unit": "point-residuals/s", "cores": cores, "kind": "port",
             "sample": f"{it6} Gauss-Newton iterations of the same {win.name} window ({win.R} residuals) with the "
-                      f"oracle's {cores}-thread pool; 1 thread: {it1} iterations",
-            "gn_iter_per_s": g6, "value_1thread": v1, "gn_iter_per_s_1thread": g1}
+                      f"reference's {cores}-thread pool structure; 1 thread: {it1} iterations",
+            "build": "gcc -O3 -march=native (oracle/Makefile: fast), built on this host", "host_cpu": model,
+            "host_logical_cpus": os.cpu_count(),
+            "gn_iter_per_s": g6, "value_1thread": v1, "gn_iter_per_s_1thread": g1, "thread_scaling": g6 / g1}
 
 
 def main():
@@ -98,8 +119,13 @@ def main():
     from sos_slam_amd import host, lib, synth
     from sos_slam_amd import distributed as sdist
 
-    # every rank: same frames / images (seed), its own point shard (point_seed)
-    win = synth.make_window(args.window, point_seed=synth.SEED + 1000 * rank if world > 1 else None)
+    if args.scaling == "strong":
+        # config 5: ONE window, its points sharded over the ranks (all residuals of a point on one rank)
+        full = synth.make_window(args.window)
+        win = synth.take_shard(full, synth.shard_points(full, rank, world)) if world > 1 else full
+    else:
+        # every rank: same frames / images (seed), its own point set (point_seed): per-GPU work fixed
+        win = synth.make_window(args.window, point_seed=synth.SEED + 1000 * rank if world > 1 else None)
     sysm = host.System.from_window(win, device=local_rank)
     comm = None
     exchange = "enqueued by the library on its stream"
@@ -133,16 +159,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    inner = args.inner
+    for i in range(args.warmup * inner):
         sysm.gn_iteration(i)
     host.timing(reset=True)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        sysm.gn_iteration(args.warmup + i)
+    for i in range(args.steps * inner):     # K steps, each the mean of `inner` consecutive Gauss-Newton iterations
+        sysm.gn_iteration(args.warmup * inner + i)
     barrier()
     dt = time.perf_counter() - t0
     phases = host.timing()
+    iters = args.steps * inner
     R_total = R_local
     if dist is not None:
         t = torch.tensor([dt, float(R_local)], dtype=torch.float64, device="cuda")
@@ -153,9 +181,15 @@ def main():
         R_total = int(t[1].item())
 
     out = None
+    exchange_us = None
+    if dist is not None and comm is not None:   # the collective alone (every rank has to take part)
+        import ctypes as C
+        ms_x = C.c_float(0)
+        lib.load().sos_ba_time_kernel(L_host_ba(sysm), b"exchange", None, 200, C.byref(ms_x))
+        exchange_us = ms_x.value * 1e3
     if rank == 0:
-        ms_per_step = dt / args.steps * 1e3
-        value = R_total * args.steps / dt
+        ms_per_step = dt / iters * 1e3
+        value = R_total * iters / dt
         # ---- roofline of the dominant kernel (linearize): HIP events on the library's stream
         L = lib.load()
         import ctypes as C
@@ -171,38 +205,50 @@ def main():
         L.sos_ba_time_kernel(L_host_ba(sysm), b"linearize", th.ctypes.data_as(C.c_void_p), 300, C.byref(ms))
         lin_ms = ms.value
         kern = {"linearize_fused_us": round(fused_ms * 1e3, 2)}
+        achieved_min = R_local * FUSED_MIN_BYTES_PER_RESIDUAL / (fused_ms * 1e-3) / 1e9
         # yardsticks under the same launch conditions: an empty kernel of the linearisation's grid / block / LDS size, and a
         # streaming read of as many bytes as the fused kernel's algorithmic traffic
         L.sos_ba_time_kernel(L_host_ba(sysm), b"lin_floor", th.ctypes.data_as(C.c_void_p), 300, C.byref(ms))
         floor_ms = ms.value
         L.sos_ba_time_kernel(L_host_ba(sysm), b"stream_equal", th.ctypes.data_as(C.c_void_p), 300, C.byref(ms))
         stream_ms = ms.value
+        L.sos_ba_time_kernel(L_host_ba(sysm), b"stream_large", th.ctypes.data_as(C.c_void_p), 50, C.byref(ms))
+        large_ms = ms.value   # coalesced read of a 1 GiB buffer: the chip's streaming bandwidth without launch effects
         for name in ("apply_res", "top_accumulate", "sc_accumulate", "sc_gram_prep", "reduce", "stitch", "resub_fused"):
             L.sos_ba_time_kernel(L_host_ba(sysm), name.encode(), th.ctypes.data_as(C.c_void_p), 200, C.byref(ms))
             kern[name + "_us"] = round(ms.value * 1e3, 2)
         out = {
             "metric": "point-residuals/sec", "value": value, "unit": "point-residuals/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.window}: {win.n} KF x {win.P} points per GPU, {win.w}x{win.h}, "
-                                   f"{R_local} point-residuals per GPU; step = one Gauss-Newton iteration "
-                                   "(accumulate A/L/SC, fp64 stitch, solve, back-substitute, step, re-linearise, "
-                                   "applyRes)", "window": args.window, "keyframes": win.n, "points_per_gpu": win.P,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": (f"{args.window}: {win.n} KF x {win.P} points per GPU, {win.w}x{win.h}, "
+                                    f"{R_local} point-residuals per GPU" if args.scaling == "weak" or world == 1 else
+                                    f"{args.window} (BASELINE.json config 5): ONE window of {win.n} KF, {R_total} point-residuals, "
+                                    f"{win.w}x{win.h}, points sharded over {world} GPUs ({win.P} points / {R_local} residuals on rank 0)") +
+                                   "; step = one Gauss-Newton iteration (accumulate A/L/SC, fp64 stitch, solve, back-substitute, "
+                                   f"step, re-linearise, applyRes), timed as the mean of {inner} consecutive iterations",
+                       "window": args.window, "keyframes": win.n, "points_per_gpu": win.P, "inner_repeat": inner,
+                       "timed_region_ms": round(dt * 1e3, 2),
                        "residuals_per_gpu": R_local, "residuals_total": R_total,
                        "parallelism": ("single GPU" if dist is None else
                                        f"{world} ranks, points sharded, frames replicated; one RCCL all-reduce of the "
                                        "packed fp32 accumulator + one all-gather of newest-frame energies per "
                                        "iteration, " + exchange)},
-            "gn_iter_per_s": args.steps / dt,
+            "gn_iter_per_s": iters / dt,
+            "exchange_allreduce_us": exchange_us,
             "linearize_point_residuals_per_s": R_local / (lin_ms * 1e-3),
             "kernels_us": dict(linearize_us=round(lin_ms * 1e3, 2), **kern),
-            "host_phases_us": {k: round(v / args.steps * 1e6, 1) for k, v in zip(
+            "host_phases_us": {k: round(v / iters * 1e6, 1) for k, v in zip(
                 ("gn_accumulate_wait", "assemble", "ldlt", "step_and_precalc", "precalc", "gn_step_call_and_post", "post",
                  "backup"), phases)},
             "roofline": {"kernel": "k_linearize (fused: linearize + applyRes + top-Hessian tile sums, J kept in LDS)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.window),
                          "bytes_per_residual": fused_bytes,
+                         "min_bytes_per_residual": FUSED_MIN_BYTES_PER_RESIDUAL, "achieved_min_bytes": achieved_min,
+                         "frac_min_bytes": achieved_min / HBM_PEAK_GBS,
+                         "large_buffer_stream_gbs": (1 << 30) / (large_ms * 1e-3) / 1e9,
+                         "frac_of_large_buffer_stream": achieved / ((1 << 30) / (large_ms * 1e-3) / 1e9),
                          "bytes_per_residual_parts": {"linearize": LINEARIZE_BYTES_PER_RESIDUAL, "top_accumulate": TOP_BYTES_PER_RESIDUAL},
                          "avg_launch_us": fused_ms * 1e3,
                          "launch_floor_us": floor_ms * 1e3, "equal_bytes_stream_read_us": stream_ms * 1e3,
@@ -212,7 +258,10 @@ def main():
                                  "equal_bytes_stream_read_us = coalesced 16 B/lane read of residuals x bytes_per_residual "
                                  "bytes (both back to back on the same stream, like avg_launch_us); measured_stream_peak = "
                                  "those bytes / that time in GB/s, frac_of_measured_stream = achieved / measured_stream_peak "
-                                 "(the north star's 'measured HBM roofline'; `peak` / `frac` use the nominal 8 TB/s)",
+                                 "(the north star's 'measured HBM roofline'; `peak` / `frac` use the nominal 8 TB/s); "
+                                 "achieved / frac price the SURVEY 8(d) bytes of the functions the kernel replaces (incl. the "
+                                 "J write + J read the fusion removed), achieved_min_bytes / frac_min_bytes only what the fused "
+                                 "kernel must move; large_buffer_stream_gbs = coalesced read of 1 GiB in the same run",
                          "unfused_linearize": {"avg_launch_us": lin_ms * 1e3, "bytes_per_residual": LINEARIZE_BYTES_PER_RESIDUAL,
                                                "achieved": R_local * LINEARIZE_BYTES_PER_RESIDUAL / (lin_ms * 1e-3) / 1e9,
                                                "frac": R_local * LINEARIZE_BYTES_PER_RESIDUAL / (lin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
@@ -221,6 +270,8 @@ def main():
         comm.close()
     sysm.close()
     if rank == 0:
+        if world > 1:
+            out["roofline"]["note"] += "; N > 1: rank 0's kernel on its own shard"
         if not args.no_cpu_baseline and world == 1:
             out["tracker"] = tracker_timing(args.window, local_rank)
             out["cpu_baseline"] = cpu_baseline(win, args.cpu_seconds)

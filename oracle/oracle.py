@@ -13,6 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_LIB_FAST = None
 
 c_float_p = C.POINTER(C.c_float)
 c_double_p = C.POINTER(C.c_double)
@@ -24,17 +25,45 @@ from sos_slam_amd.records import Calib, Params  # noqa: E402  (record mirrors on
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))] + [os.path.join(_HERE, "Makefile")]
     srcs.append(os.path.join(_HERE, "..", "include", "sos_slam.h"))
-    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+    stale = lambda t: not os.path.exists(t) or any(os.path.getmtime(s) > os.path.getmtime(t) for s in srcs)  # noqa: E731
+    if force or stale(so):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
+
+
+def lib_fast():
+    """The -O3 -march=native timing build of the same sources (bench.py's cpu_baseline leg); never the parity oracle.
+    Built on THIS machine (it is bound to the host CPU), into a per-CPU scratch directory."""
+    global _LIB_FAST
+    if _LIB_FAST is None:
+        import hashlib
+        import tempfile
+        try:
+            flags = [ln for ln in open("/proc/cpuinfo") if ln.startswith(("flags", "model name"))][:2]
+        except OSError:
+            flags = []
+        srcs = sorted(f for f in os.listdir(_HERE) if f.endswith((".c", ".h")))
+        h = hashlib.sha256(("".join(flags) + "".join(open(os.path.join(_HERE, f)).read() for f in srcs)).encode()).hexdigest()[:16]
+        out = os.path.join(tempfile.gettempdir(), "sos_oracle_fast_" + h)
+        os.makedirs(out, exist_ok=True)
+        so = os.path.join(out, "liboracle_fast.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-C", _HERE, "-s", "fast", "FASTOUT=" + out])
+        _LIB_FAST = _bind(C.CDLL(so))
+    return _LIB_FAST
 
 
 def lib():
     global _LIB
     if _LIB is None:
-        L = C.CDLL(build())
+        _LIB = _bind(C.CDLL(build()))
+    return _LIB
+
+
+def _bind(L):
+    if True:
         vp = C.c_void_p
         L.orc_window_create.restype = vp
         L.orc_window_create.argtypes = [C.POINTER(Params), C.c_int, C.c_int, vp, C.c_int, vp]
@@ -125,8 +154,7 @@ def lib():
         L.orc_tracker_track.argtypes = [vp, vp, C.c_float, C.c_float, vp, vp, vp, C.c_int, vp, vp, vp]
         L.orc_tracker_optimize_scale.restype = C.c_float
         L.orc_tracker_optimize_scale.argtypes = [vp, vp, vp, vp, vp, C.c_int]
-        _LIB = L
-    return _LIB
+    return L
 
 
 def _p(a):
@@ -304,10 +332,10 @@ class PixelSelector:
 class OracleWindow:
     """One EnergyFunctional window inside the oracle."""
 
-    def __init__(self, params: dict, n: int, points: np.ndarray, resid: np.ndarray):
+    def __init__(self, params: dict, n: int, points: np.ndarray, resid: np.ndarray, fast: bool = False):
         from sos_slam_amd import synth  # dtypes only
         self._synth = synth
-        self.L = lib()
+        self.L = lib_fast() if fast else lib()
         self.params = Params.from_dict(params)
         self.n, self.P, self.R = n, len(points), len(resid)
         pts = np.ascontiguousarray(points)
@@ -524,9 +552,9 @@ class OracleWindow:
         return HM, bM
 
 
-def window_from_synth(win, nthreads=1):
+def window_from_synth(win, nthreads=1, fast=False):
     """OracleWindow with images (built by the oracle's makeImages) and host state of a synth.Window."""
-    ow = OracleWindow(win.params, win.n, win.points, win.resid)
+    ow = OracleWindow(win.params, win.n, win.points, win.resid, fast=fast)
     ow.dI = []
     for i in range(win.n):
         dI, _ = make_images(win.images[i])

@@ -2359,6 +2359,8 @@ struct sos_ba {
   DevBuf<char> d_outpack;  // [tile_esum ntilesA doubles | newest energies | point steps]
   DevBuf<double> d_C;      // stitch stage-1 products
   DevBuf<double> d_ar64;   // sos_ba_allreduce_f64 staging
+  DevBuf<float> d_xchg;    // sos_ba_time_kernel("exchange") scratch
+  DevBuf<float> d_large;   // sos_ba_time_kernel("stream_large") 1 GiB yardstick buffer
   DevBuf<float> d_Jnew, d_JpJd_new, d_pterm_new;  // PointFrameResidual::J side of the two-step protocol (lazily allocated)
   bool pending_new = false;  // a sos_ba_linearize result waits in d_Jnew for sos_ba_apply_res
   size_t st_pre = 0, st_adh = 0, st_cd = 0, st_th = 0, st_xc = 0, st_xad = 0, st_floats = 0;
@@ -2440,7 +2442,7 @@ extern "C" int sos_ba_destroy(sos_ba *ba) {
     b->release();
   ba->d_rawjac.release();
   ba->d_t_pre.release(); ba->d_t_img.release(); ba->d_t_ht.release();
-  ba->d_p_list2.release(); ba->d_p_list16.release(); ba->d_r_geo.release(); ba->d_r_cw.release(); ba->d_stage.release(); ba->d_outpack.release(); ba->d_C.release(); ba->d_ar64.release(); ba->d_Jnew.release(); ba->d_JpJd_new.release(); ba->d_pterm_new.release();
+  ba->d_p_list2.release(); ba->d_p_list16.release(); ba->d_r_geo.release(); ba->d_r_cw.release(); ba->d_stage.release(); ba->d_outpack.release(); ba->d_C.release(); ba->d_ar64.release(); ba->d_xchg.release(); ba->d_large.release(); ba->d_Jnew.release(); ba->d_JpJd_new.release(); ba->d_pterm_new.release();
   if (ba->pin) hipHostFree(ba->pin);
   if (ba->ev_step) hipEventDestroy(ba->ev_step);
   if (ba->pin_newest) hipHostFree(ba->pin_newest);
@@ -2817,6 +2819,23 @@ __global__ void k_calib_read(const float4 *__restrict__ src, size_t n4, float *_
     a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
   }
   if (a.x + a.y + a.z + a.w == 1234.5678f) sink[0] = a.x;  // keeps the loads alive, never true in practice
+}
+// large-buffer streaming yardstick (bench.py roofline.large_buffer_stream_gbs): 1 GiB read with four independent 16-byte
+// loads in flight per lane and iteration -- far beyond the 256 MB of MALL, so this is HBM bandwidth without launch effects
+__global__ __launch_bounds__(256) void k_stream_large(const float4 *__restrict__ src, size_t n4, float *__restrict__ sink) {
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const float4 v0 = src[i], v1 = src[i + stride], v2 = src[i + 2 * stride], v3 = src[i + 3 * stride];
+    a.x += v0.x + v1.x + v2.x + v3.x; a.y += v0.y + v1.y + v2.y + v3.y;
+    a.z += v0.z + v1.z + v2.z + v3.z; a.w += v0.w + v1.w + v2.w + v3.w;
+  }
+  for (; i < n4; i += stride) {
+    const float4 v = src[i];
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  if (a.x + a.y + a.z + a.w == 1234.5678f) sink[0] = a.x;
 }
 __global__ void k_calib_write(float4 *__restrict__ dst, size_t n4) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
@@ -3714,6 +3733,15 @@ extern "C" int sos_ba_time_kernel(sos_ba *ba, const char *kernel, const float *f
       k_calib_read<<<2048, 256, 0, st>>>(reinterpret_cast<const float4 *>(ba->d_calib.p), floats / 4, ba->d_top_part.p);
       return SOS_OK;
     }
+    if (k == "stream_large") {  // 1 GiB coalesced read: the streaming bandwidth of the chip, measured in the same run
+      const size_t floats = (size_t)1 << 28;
+      if (ba->d_large.cap < floats) {
+        if (ba->d_large.ensure(floats)) return SOS_ERR_NOMEM;
+        SOS_HIP(hipMemsetAsync(ba->d_large.p, 0, sizeof(float) * floats, st));
+      }
+      k_stream_large<<<256 * 16, 256, 0, st>>>(reinterpret_cast<const float4 *>(ba->d_large.p), floats / 4, ba->d_top_part.p);
+      return SOS_OK;
+    }
     if (k == "lin_floor") {  // empty kernel with the linearisation's grid, block and LDS size
       int ndFloor;
       k_lin_floor<<<lin_grid(ba, &ndFloor), 256 * L2_TILES, 0, st>>>(nullptr);
@@ -3722,6 +3750,14 @@ extern "C" int sos_ba_time_kernel(sos_ba *ba, const char *kernel, const float *f
     if (k == "sc_gram_prep") {
       if (ba->nchunks > 0) k_sc_gram_prep<<<ba->nchunks, 256, gram_lds(ba), st>>>(ba->dev, ba->d_chunk_pt.p, ba->Dm, ba->ld, ba->d_gram_part.p, nullptr, 0);
       return SOS_OK;
+    }
+    if (k == "exchange") {  // the per-iteration collective alone: all-reduce of a buffer the size of the packed fp32 accumulator
+      if (!ba->comm) return SOS_OK;  // (every rank has to make this call with the same iteration count)
+      if (ba->d_xchg.cap < ba->acc_floats) {
+        if (ba->d_xchg.ensure(ba->acc_floats)) return SOS_ERR_NOMEM;
+        SOS_HIP(hipMemsetAsync(ba->d_xchg.p, 0, sizeof(float) * ba->acc_floats, st));
+      }
+      return sos_comm_allreduce_sum_f32(ba->comm, ba->d_xchg.p, ba->acc_floats, st);
     }
     if (k == "apply_res") return sos_ba_apply_res(ba);
     if (k == "top_accumulate") return launch_top(ba);
