@@ -272,6 +272,42 @@ int sos_ba_gn_resub(sos_ba *ba, const double *x, float stepfacD);
  * the per-point results (sos_ba_get_point_hessian) always belong to the latest accumulate that ran. */
 int sos_ba_set_prefetch(sos_ba *ba, int on);
 
+/* ---- device-resident Gauss-Newton loop: the loop body of FullSystem::optimize (FS/FullSystemOptimize.cpp:358-413, with
+ * setting_forceAceptStep) with the HOST OUT OF THE ITERATION.  Besides the accumulate / back-substitution / linearisation
+ * kernels above, one kernel per iteration does what solveSystemF (OB/EnergyFunctional.cpp:1046-1148: priors, HM / bM around
+ * delta, Schur side, Jacobi scaling, LDL^T; IMU off), the frame / calibration half of doStepFromBackup
+ * (FS/FullSystemOptimize.cpp:185-257), FrameHessian::setState (SE3 exp), FrameFramePrecalc::set x n^2
+ * (FS/HessianBlocks.cpp:431-461) and setDeltaF (OB/EnergyFunctional.cpp:163-194) do on the host, in fp64; the order statistic
+ * of setNewFrameEnergyTH (FS/FullSystemOptimize.cpp:84-124) is an exact selection on the device.  Frame states, calibration,
+ * FEJ poses and the marginalisation prior stay on the device between begin and end.
+ *   begin    after the window has been packed, its state set (adjoints included) and linearised + applied once
+ *            (FS/FullSystemOptimize.cpp:316-344): uploads what the loop needs
+ *   enqueue  one whole iteration as one chain of launches; returns at once with its sequence number
+ *   wait     the results of iteration `seq`: they are published when its solve has run, BEFORE its back-substitution and
+ *            linearisation, so the caller decides about the next iteration (canbreak) and enqueues it while this one finishes
+ *   end      drains the stream, returns the point steps / inverse depths / newest-frame energies of the last iteration
+ * Not available (SOS_ERR_STATE from begin; use the fused calls above): more than 17 keyframes, an empty window. */
+typedef struct sos_gn_frame {
+  double camToWorld_evalPT[12];  /* FrameHessian::get_camToWorld_evalPT(): R row-major | t */
+  double state[10];              /* FrameHessian::state */
+  double state_zero[10];         /* FrameHessian::state_zero */
+  double prior[8];               /* EFFrame::prior (FS/HessianBlocks.h:280-302) */
+  float ab_exposure;
+  int32_t pad;
+} sos_gn_frame;
+int sos_ba_gn_resident_supported(sos_ba *ba);
+int sos_ba_gn_resident_begin(sos_ba *ba, const sos_gn_frame *frames, const double *calib_value4, const double *calib_value_zero4,
+                             double cPrior, const double *HM, const double *bM, const float *frameEnergyTH /* n */);
+int sos_ba_gn_resident_enqueue(sos_ba *ba, int *seq_out);
+/* header16: [0] seq, [1] failed (non-positive pivot: nothing was stepped), [2..5] sumA sumB sumT sumR of doStepFromBackup,
+ * [6] sum |idepth_backup|, [7] number of points, [8] resInA, [9] resInL, [10] frameEnergyTH of the newest keyframe used by
+ * this iteration's linearisation; x: 4 + 8 n; states: n x 10 (the new FrameHessian::state); camToWorld: n x 12
+ * (PRE_camToWorld); calib_value4: CalibHessian::value */
+int sos_ba_gn_resident_wait(sos_ba *ba, int seq, double *header16, double *x, double *states, double *camToWorld,
+                            double *calib_value4);
+int sos_ba_gn_resident_end(sos_ba *ba, float *pointStep, float *idepth_scaled, double *energySum, float *newestEnergies,
+                           int *newestCount);
+
 /* ---- multi-GPU exchange; the reference has no counterpart: it is a single-process CPU backend ----
  * One process per GPU, every rank the same keyframes and its own shard of the points.  librccl is bound at run
  * time: sos_rccl_load(path) (NULL = "librccl.so" from the loader path; pass the copy the host process already uses).

@@ -723,6 +723,7 @@ FullSystem::FullSystem(const sos_params &p, int device, void *stream) : prm(p) {
   }
 }
 FullSystem::~FullSystem() {
+  if (ef && residentActive) residentFlush();
   delete ef;
   for (FrameHessian *f : frameHessians) delete f;
   if (ctx) sos_ctx_destroy(ctx);
@@ -991,6 +992,7 @@ bool FullSystem::doStepFromBackup(float stepfacC, float stepfacT, float stepfacR
 void FullSystem::solveSystem(int iteration, double lambda) { rcAcc(ef->solveSystemF(iteration, lambda, &HCalib, false)); }
 
 int FullSystem::prepare() {  // FS/FullSystemOptimize.cpp:316-344
+  residentFlush();
   activeResiduals.clear();
   for (FrameHessian *fh : frameHessians)
     for (PointHessian *ph : fh->pointHessians)
@@ -1020,6 +1022,19 @@ int FullSystem::prepare() {  // FS/FullSystemOptimize.cpp:316-344
 }
 
 bool FullSystem::gnIteration(int iteration, bool mayContinue) {  // :358-413 with setting_forceAceptStep
+  if (residentActive || residentUsable()) {
+    if (!residentActive) {
+      if (residentBegin() != SOS_OK) goto host_path;
+      rcAcc(sos_ba_gn_resident_enqueue(ef->ba, &residentQueued));
+    }
+    // benchmark loops (pipelineAlways) keep the device one iteration ahead of the host
+    if (pipelineAlways && residentQueued == residentSeq + 1) rcAcc(sos_ba_gn_resident_enqueue(ef->ba, &residentQueued));
+    if (residentQueued == residentSeq) rcAcc(sos_ba_gn_resident_enqueue(ef->ba, &residentQueued));
+    const bool cb = residentConsume(residentSeq + 1);
+    if (!pipelineAlways) residentFlush();
+    return cb;
+  }
+host_path:
   { PhaseTimer tb(7); backupState(); }
   if (rcAcc(ef->solveSystemF(iteration, 1e-1, &HCalib, true)) != SOS_OK) {  // x, frame / calib steps; back-substitution deferred
     isLost = true;  // a failed device call: no step is taken on undelivered H / b
@@ -1065,6 +1080,105 @@ bool FullSystem::gnIteration(int iteration, bool mayContinue) {  // :358-413 wit
     setNewFrameEnergyTH(newestE);
   }
   return canbreak;
+}
+
+// ------------------------------------------------------------------------------------------------
+// device-resident Gauss-Newton loop: what is left for the host is the loop control (canbreak) and its mirrors
+// ------------------------------------------------------------------------------------------------
+bool FullSystem::residentUsable() const {
+  static const bool off = getenv("SOS_NO_RESIDENT") != nullptr;
+  return residentAllowed && !off && forceAcceptStep && !ef->imuSettings && !ef->allreduceHook && !ef->commAttached && !ef->keepSystem &&
+         sos_ba_gn_resident_supported(ef->ba) == 1;
+}
+
+int FullSystem::residentBegin() {
+  const int n = (int)frameHessians.size();
+  std::vector<sos_gn_frame> fr(n);
+  for (int i = 0; i < n; i++) {
+    const FrameHessian *fh = frameHessians[i];
+    fh->camToWorld_evalPT.to12(fr[i].camToWorld_evalPT);
+    std::memcpy(fr[i].state, fh->state, sizeof(double) * 10);
+    std::memcpy(fr[i].state_zero, fh->state_zero, sizeof(double) * 10);
+    std::memcpy(fr[i].prior, fh->efFrame->prior, sizeof(double) * 8);
+    fr[i].ab_exposure = fh->ab_exposure;
+    fr[i].pad = 0;
+  }
+  std::vector<float> th(n);
+  for (int i = 0; i < n; i++) th[i] = frameHessians[i]->frameEnergyTH;
+  const int rc = sos_ba_gn_resident_begin(ef->ba, fr.data(), HCalib.value, HCalib.value_zero, ef->cPrior[0], ef->HM.data(), ef->bM.data(), th.data());
+  residentActive = rc == SOS_OK;
+  residentSeq = residentQueued = 0;
+  return rc;
+}
+
+bool FullSystem::residentConsume(int seq) {
+  const int n = (int)frameHessians.size(), dim = SOS_CPARS + 8 * n;
+  double hdr[16], cal[4];
+  std::vector<double> x(dim), st((size_t)10 * n), poses((size_t)12 * n);
+  const int rc = sos_ba_gn_resident_wait(ef->ba, seq, hdr, x.data(), st.data(), poses.data(), cal);
+  if (rc != SOS_OK) {
+    rcAcc(rc);
+    isLost = true;
+    return true;
+  }
+  residentSeq = seq;
+  ef->lastX = x;
+  ef->resInA = (int)hdr[8];
+  ef->resInL = (int)hdr[9];
+  for (int i = 0; i < 4; i++) HCalib.step[i] = -x[i];
+  HCalib.setValue(cal);
+  for (int h = 0; h < n; h++) {
+    FrameHessian *fh = frameHessians[h];
+    for (int i = 0; i < 8; i++) fh->step[i] = -x[SOS_CPARS + 8 * h + i];
+    fh->step[8] = fh->step[9] = 0;
+    // setState with the pose the device formed (its SE3 exp is the one the kernels used)
+    const double *s = &st[(size_t)10 * h];
+    for (int i = 0; i < 10; i++) fh->state[i] = s[i];
+    for (int i = 0; i < 3; i++) fh->state_scaled[i] = SOS_SCALE_XI_TRANS * s[i];
+    for (int i = 3; i < 6; i++) fh->state_scaled[i] = SOS_SCALE_XI_ROT * s[i];
+    fh->state_scaled[6] = SOS_SCALE_A * s[6]; fh->state_scaled[7] = SOS_SCALE_B * s[7];
+    fh->state_scaled[8] = SOS_SCALE_A * s[8]; fh->state_scaled[9] = SOS_SCALE_B * s[9];
+    fh->PRE_camToWorld = SE3::from12(&poses[(size_t)12 * h]);
+    fh->PRE_worldToCam = fh->PRE_camToWorld.inverse();
+  }
+  frameHessians.back()->frameEnergyTH = (float)hdr[10];
+  // the termination test of doStepFromBackup (FS/FullSystemOptimize.cpp:240-257)
+  float sumA = (float)hdr[2], sumB = (float)hdr[3], sumT = (float)hdr[4], sumR = (float)hdr[5];
+  float sumNID = (float)hdr[6];
+  const float numID = (float)hdr[7], nf = (float)n;
+  sumA /= nf; sumB /= nf; sumR /= nf; sumT /= nf;
+  sumNID /= numID;
+  return sqrtf(sumA) < 0.0005 * setting_thOptIterations && sqrtf(sumB) < 0.00005 * setting_thOptIterations &&
+         sqrtf(sumR) < 0.00005 * setting_thOptIterations && sqrtf(sumT) * sumNID < 0.00005 * setting_thOptIterations;
+}
+
+int FullSystem::residentFlush() {
+  if (!residentActive) return SOS_OK;
+  while (residentSeq < residentQueued) residentConsume(residentSeq + 1);   // iterations the caller has not asked about yet
+  residentActive = false;
+  const size_t P = ef->allPoints.size();
+  ef->pointStep.resize(P);
+  std::vector<float> idp(P);
+  int cap = 0, cnt = 0;
+  sos_ba_newest_capacity(ef->ba, &cap);
+  newestE.resize((size_t)cap + 1);
+  double E = 0;
+  const int rc = sos_ba_gn_resident_end(ef->ba, ef->pointStep.data(), idp.data(), &E, newestE.data(), &cnt);
+  if (rc != SOS_OK) return rcAcc(rc);
+  newestE.resize(cnt);
+  for (size_t k = 0; k < P; k++) {
+    PointHessian *ph = ef->allPoints[k]->data;
+    ph->step = ef->pointStep[k];
+    ph->setIdepth(idp[k] * (1.0f / SOS_SCALE_IDEPTH));
+    ph->setIdepthZero(idp[k] * (1.0f / SOS_SCALE_IDEPTH));
+    ef->allPoints[k]->deltaF = 0;
+  }
+  // host-side per-step state the non-resident calls expect: precalc records / deltas of the final state, and the
+  // threshold the last linearisation leaves behind (setNewFrameEnergyTH)
+  ef->EFDeltaValid = false;
+  setPrecalcValues(false);
+  setNewFrameEnergyTH(newestE);
+  return SOS_OK;
 }
 
 void FullSystem::loadSateBackup() {  // FS/FullSystemOptimize.cpp:271-287 (IMU off)
@@ -1119,10 +1233,23 @@ float FullSystem::optimize(int mnumOptIts, int *iterations) {
   int it = 0;
   stepsRejected = 0;
   double lastE = prepareEnergy, lastEL = prepareEnergyL, lastEM = prepareEnergyM;
-  for (int iteration = 0; iteration < mnumOptIts; iteration++) {
-    const bool canbreak = forceAcceptStep ? gnIteration(iteration, iteration + 1 < mnumOptIts) : gnIterationChecked(iteration, lastE, lastEL, lastEM);
-    it++;
-    if (canbreak && iteration >= setting_minOptIterations) break;
+  if (residentUsable() && residentBegin() == SOS_OK) {
+    // the whole loop body runs on the device; the host learns x / canbreak of iteration k while its back-substitution and
+    // linearisation are still running and enqueues iteration k + 1 behind them
+    rcAcc(sos_ba_gn_resident_enqueue(ef->ba, &residentQueued));
+    for (int iteration = 0; iteration < mnumOptIts; iteration++) {
+      const bool canbreak = residentConsume(residentQueued);
+      it++;
+      if (isLost || (canbreak && iteration >= setting_minOptIterations)) break;
+      if (iteration + 1 < mnumOptIts) rcAcc(sos_ba_gn_resident_enqueue(ef->ba, &residentQueued));
+    }
+    residentFlush();
+  } else {
+    for (int iteration = 0; iteration < mnumOptIts; iteration++) {
+      const bool canbreak = forceAcceptStep ? gnIteration(iteration, iteration + 1 < mnumOptIts) : gnIterationChecked(iteration, lastE, lastEL, lastEM);
+      it++;
+      if (canbreak && iteration >= setting_minOptIterations) break;
+    }
   }
   if (iterations) *iterations = it;
   const double tp2 = now_s();
@@ -1174,6 +1301,7 @@ void FullSystem::removeOutliers() {  // FS/FullSystemOptimize.cpp:507-526
 // flagPointsForRemoval for an explicit set (FS/FullSystem.cpp:566-601) followed by
 // ef->marginalizePointsF (FS/FullSystem.cpp:912)
 int FullSystem::marginalizePoints(const std::vector<PointHessian *> &pts, bool alreadyDetached) {
+  residentFlush();
   if (pts.empty()) {  // nothing to linearise: only the PS_DROP points leave (ef->dropPointsF, FS/FullSystem.cpp:909)
     ef->dropPointsF();
     return SOS_OK;
@@ -1929,8 +2057,15 @@ extern "C" int sosf_get_rejected_steps(sosf_system *s, int *count) {
   *count = s->fs->stepsRejected;
   return SOS_OK;
 }
+extern "C" int sosf_set_resident(sosf_system *s, int on) {
+  if (!s) return SOS_ERR_ARG;
+  s->fs->residentFlush();
+  s->fs->residentAllowed = on != 0;
+  return SOS_OK;
+}
 extern "C" int sosf_set_pipeline(sosf_system *s, int on) {
   if (!s) return SOS_ERR_ARG;
+  if (!on) s->fs->residentFlush();
   s->fs->pipelineAlways = on != 0;
   if (!on) sos_ba_set_prefetch(s->fs->ef->ba, 0);
   return SOS_OK;
@@ -1951,6 +2086,7 @@ extern "C" int sosf_counts(sosf_system *s, int *nF, int *nP, int *nR) {
 }
 extern "C" int sosf_get_frame(sosf_system *s, int idx, double *c2w, double *state, double *state_zero, float *th) {
   if (!s || idx < 0 || idx >= (int)s->fs->frameHessians.size()) return SOS_ERR_ARG;
+  s->fs->residentFlush();
   const FrameHessian *f = s->fs->frameHessians[idx];
   if (c2w) f->PRE_camToWorld.to12(c2w);
   if (state) std::memcpy(state, f->state, sizeof(double) * 10);
@@ -1960,11 +2096,13 @@ extern "C" int sosf_get_frame(sosf_system *s, int idx, double *c2w, double *stat
 }
 extern "C" int sosf_get_calib(sosf_system *s, double *vs) {
   if (!s || !vs) return SOS_ERR_ARG;
+  s->fs->residentFlush();
   std::memcpy(vs, s->fs->HCalib.value_scaled, sizeof(double) * 4);
   return SOS_OK;
 }
 extern "C" int sosf_get_points(sosf_system *s, float *idepth, float *idh, float *mrb, int32_t *ngr) {
   if (!s) return SOS_ERR_ARG;
+  s->fs->residentFlush();
   size_t k = 0;
   for (FrameHessian *fh : s->fs->frameHessians)
     for (EFPoint *p : fh->efFrame->points) {

@@ -255,6 +255,15 @@ class FullSystem {
   bool gnIteration(int iteration, bool mayContinue = false);  // :358-413
   sos_comm *comm = nullptr;     // RCCL communicator attached to the backend (multi-GPU), not owned
   bool pipelineAlways = false;  // flat API: the caller iterates regardless of canbreak
+  // device-resident Gauss-Newton loop (sos_ba_gn_resident_*): the solve, the frame step and the precalc records on the device
+  bool residentAllowed = true;  // sosf_set_resident
+  bool residentActive = false;
+  int residentSeq = 0;          // sequence number of the iteration whose results the host has consumed
+  int residentQueued = 0;       // ... and of the last one enqueued
+  bool residentUsable() const;
+  int residentBegin();
+  bool residentConsume(int seq);            // waits for iteration seq, refreshes the host mirrors, returns canbreak
+  int residentFlush();                      // leaves the loop: mirrors of points / thresholds brought up to date
   bool forceAcceptStep = true;  // setting_forceAceptStep (util/settings.cpp:117); false: energy-checked steps with loadSateBackup
   int stepsRejected = 0;        // rejected steps of the last optimize()
   void loadSateBackup();                                      // FS/FullSystemOptimize.cpp:271-287

@@ -43,7 +43,8 @@ struct BaDev {
   int lin_nd;  // k_linearize2: number of leading two-tile blocks (set per launch, lin_grid)
   int w, h;
   float wM3G, hM3G;
-  sos_calib calib;
+  sos_calib calib;      // host-side copy (kernels read calibp: a device-resident Gauss-Newton loop moves the calibration itself)
+  const float *calibp;  // fxl fyl cxl cyl fxli fyli cxli cyli in the staging buffer
   float huberTH, outlierTH, modeA, modeB;
   const float *img[SOS_MAX_FRAMES];
   const float *imgT[SOS_MAX_FRAMES];  // tiled level-0 copies (sos_common.h), read by k_linearize2
@@ -322,8 +323,8 @@ __global__ __launch_bounds__(256, SOS_LIN_WAVES) void k_linearize(BaDev d, const
 
   LIN_STAMP(3);  // per-pixel part + DPP sums done
   if (idx == 7) {
-    const float fxl = d.calib.fxl, fyl = d.calib.fyl, cxl = d.calib.cxl, cyl = d.calib.cyl;
-    const float fxli = d.calib.fxli, fyli = d.calib.fyli;
+    const float fxl = d.calibp[0], fyl = d.calibp[1], cxl = d.calibp[2], cyl = d.calibp[3];
+    const float fxli = d.calibp[4], fyli = d.calibp[5];
     const float *R0 = pc->PRE_RTll_0, *t0 = pc->PRE_tTll_0;
     // ---- centre projection with the FEJ pose / idepth (FS/ResidualProjections.h:52-73)
     const float KliP0 = (pu - cxl) * fxli;
@@ -838,8 +839,8 @@ __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(const float4 *
     const float wJI2_sum = sS[11][c];
     const bool grp_oob = sS[17][c] != 0.f;
 
-    const float fxl = d.calib.fxl, fyl = d.calib.fyl, cxl = d.calib.cxl, cyl = d.calib.cyl;
-    const float fxli = d.calib.fxli, fyli = d.calib.fyli;
+    const float fxl = d.calibp[0], fyl = d.calibp[1], cxl = d.calibp[2], cyl = d.calibp[3];
+    const float fxli = d.calibp[4], fyli = d.calibp[5];
     // ---- centre projection with the FEJ pose / idepth (FS/ResidualProjections.h:52-73)
     const float KliP0 = (pu - cxl) * fxli;
     const float KliP1 = (pv - cyl) * fyli;
@@ -2018,7 +2019,8 @@ __global__ __launch_bounds__(SOS_RSB) void k_stage_expand(BaDev d, float4 *__res
 __global__ __launch_bounds__(SOS_RSB) void k_resub_fused(BaDev d, XArg x, const float *__restrict__ adHF, const float *__restrict__ adTF,
                                                      float *__restrict__ step_out, float stepfacD, int nPointBlocks,
                                                      float4 *__restrict__ stage_dst, const float4 *__restrict__ stage_src, int n4,
-                                                     int nStageBlocks, const float4 *__restrict__ pre_src, float4 *__restrict__ t_pre) {
+                                                     int nStageBlocks, const float4 *__restrict__ pre_src, float4 *__restrict__ t_pre,
+                                                     const float *__restrict__ x_dev) {
   extern __shared__ __attribute__((aligned(16))) float sxAd[];  // [n*n*8] table, then [dim] copy of x
   const int tid = threadIdx.x;
   if ((int)blockIdx.x >= nPointBlocks) {
@@ -2038,7 +2040,7 @@ __global__ __launch_bounds__(SOS_RSB) void k_resub_fused(BaDev d, XArg x, const 
   constexpr int RU = 16;  // residuals held in registers; longer lists finish in the tail loop below
   int2 e[RU];
   float4 ja[RU], jb[RU];
-  for (int i = tid; i < dim; i += SOS_RSB) sx[i] = x.v[i];  // one coalesced read of the kernel argument
+  for (int i = tid; i < dim; i += SOS_RSB) sx[i] = x_dev ? x_dev[i] : x.v[i];  // the kernel argument, or the device-resident loop's x
   __syncthreads();
   // The table (item = (pair idx = n*h + t, half jh): 4 of the 8 outputs from 8 + 8 float4 loads of the adjoint rows)
   // depends on nothing else: its loads are issued ahead of the point's dependent chain (list entries -> JpJd rows), so the
@@ -2355,15 +2357,23 @@ struct sos_ba {
   DevBuf<int2> d_p_list2, d_p_list16;
   DevBuf<float4> d_r_geo;
   DevBuf<float> d_r_cw;
-  DevBuf<float> d_stage;   // [precalc n*n*28 | adHTdelta n*n*8 | cdelta 4 | frameTH n(+pad) | xc 4 | xAd n*n*8]
+  DevBuf<float> d_stage;   // [precalc n*n*28 | adHTdelta n*n*8 | cdelta 4 | frameTH n(+pad) | calib 8 | xc 4 | xAd n*n*8]
   DevBuf<char> d_outpack;  // [tile_esum ntilesA doubles | newest energies | point steps]
   DevBuf<double> d_C;      // stitch stage-1 products
   DevBuf<double> d_ar64;   // sos_ba_allreduce_f64 staging
   DevBuf<float> d_xchg;    // sos_ba_time_kernel("exchange") scratch
   DevBuf<float> d_large;   // sos_ba_time_kernel("stream_large") 1 GiB yardstick buffer
+  // device-resident Gauss-Newton loop (sos_gn_resident.inc)
+  DevBuf<double> d_gn;       // HM | bM | evalC2W | state_zero | prior | state | calib (value 4, value_zero 4, cPrior)
+  DevBuf<float> d_gn_f;      // ab_exposure n | xF dim
+  size_t gn_HM = 0, gn_bM = 0, gn_eval = 0, gn_sz = 0, gn_prior = 0, gn_state = 0, gn_calib = 0;
+  double *gn_pin = nullptr, *gn_pin_dev = nullptr;  // mapped ring of GN_SLOTS result slots + flag
+  size_t gn_pin_doubles = 0, gn_slot_doubles = 0;
+  bool gn_active = false, gn_have_top = false;
+  int gn_seq = 0;
   DevBuf<float> d_Jnew, d_JpJd_new, d_pterm_new;  // PointFrameResidual::J side of the two-step protocol (lazily allocated)
   bool pending_new = false;  // a sos_ba_linearize result waits in d_Jnew for sos_ba_apply_res
-  size_t st_pre = 0, st_adh = 0, st_cd = 0, st_th = 0, st_xc = 0, st_xad = 0, st_floats = 0;
+  size_t st_pre = 0, st_adh = 0, st_cd = 0, st_th = 0, st_cal = 0, st_xc = 0, st_xad = 0, st_floats = 0;
   bool resub_pending = false;  // sos_ba_gn_resub enqueued the back-substitution of the step sos_ba_gn_step is about to take
   size_t out_esum = 0, out_newest = 0, out_step = 0, out_bytes = 0;
   int newest_begin = 0, newest_count = 0;
@@ -2442,7 +2452,8 @@ extern "C" int sos_ba_destroy(sos_ba *ba) {
     b->release();
   ba->d_rawjac.release();
   ba->d_t_pre.release(); ba->d_t_img.release(); ba->d_t_ht.release();
-  ba->d_p_list2.release(); ba->d_p_list16.release(); ba->d_r_geo.release(); ba->d_r_cw.release(); ba->d_stage.release(); ba->d_outpack.release(); ba->d_C.release(); ba->d_ar64.release(); ba->d_xchg.release(); ba->d_large.release(); ba->d_Jnew.release(); ba->d_JpJd_new.release(); ba->d_pterm_new.release();
+  ba->d_p_list2.release(); ba->d_p_list16.release(); ba->d_r_geo.release(); ba->d_r_cw.release(); ba->d_stage.release(); ba->d_outpack.release(); ba->d_C.release(); ba->d_ar64.release(); ba->d_xchg.release(); ba->d_large.release(); ba->d_gn.release(); ba->d_gn_f.release();
+  if (ba->gn_pin) hipHostFree(ba->gn_pin); ba->d_Jnew.release(); ba->d_JpJd_new.release(); ba->d_pterm_new.release();
   if (ba->pin) hipHostFree(ba->pin);
   if (ba->ev_step) hipEventDestroy(ba->ev_step);
   if (ba->pin_newest) hipHostFree(ba->pin_newest);
@@ -2649,14 +2660,15 @@ extern "C" int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, i
   ba->st_adh = ba->st_pre + nn * 28;
   ba->st_cd = ba->st_adh + nn * 8;
   ba->st_th = ba->st_cd + 4;
-  ba->st_xc = ba->st_th + ((size_t)n + 3) / 4 * 4;
+  ba->st_cal = ba->st_th + ((size_t)n + 3) / 4 * 4;  // sos_calib (8 floats): the kernels read it from here, not from a kernel argument
+  ba->st_xc = ba->st_cal + 8;
   ba->st_xad = ba->st_xc + 4;
   ba->st_floats = ba->st_xad + nn * 8;
   ENSURE(ba->d_stage, ba->st_floats);
   ENSURE(ba->d_adHost, nn * 64); ENSURE(ba->d_adTarget, nn * 64);
   const size_t dim = 4 + 8 * (size_t)n;
   ba->hb_mode_stride = dim * dim + dim;
-  ENSURE(ba->d_Hout, 3 * ba->hb_mode_stride); ENSURE(ba->d_scalar, 8); ENSURE(ba->d_perres, Rp);
+  ENSURE(ba->d_Hout, 3 * ba->hb_mode_stride + 8); ENSURE(ba->d_scalar, 8); ENSURE(ba->d_perres, Rp);
   ENSURE(ba->d_C, 2 * nn * SOS_TOPC + nn * n * SOS_SCC + nn * SOS_SCE + 64);
   // packed per-step outputs (one D2H per step)
   ba->newest_begin = pair_tile_begin[n * (n - 1)] * SOS_TILE;
@@ -2712,6 +2724,7 @@ extern "C" int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, i
   d.precalc = reinterpret_cast<const sos_precalc *>(ba->d_stage.p + ba->st_pre);
   d.adHTdelta = ba->d_stage.p + ba->st_adh;
   d.cdelta = ba->d_stage.p + ba->st_cd;
+  d.calibp = ba->d_stage.p + ba->st_cal;
   d.tile_esum = reinterpret_cast<double *>(ba->d_outpack.p + ba->out_esum);
   d.o_newest = reinterpret_cast<float *>(ba->d_outpack.p + ba->out_newest);
   d.newest_begin = ba->newest_begin;
@@ -2768,7 +2781,11 @@ extern "C" int sos_ba_set_state(sos_ba *ba, const sos_calib *calib, const sos_pr
   hipStream_t st = c->stream;
   SOS_HIP(hipStreamSynchronize(st));  // the pinned staging area may still be in flight
   const size_t nn = (size_t)ba->n * ba->n;
-  if (calib) { ba->calib = *calib; ba->dev.calib = *calib; }
+  if (calib) {
+    ba->calib = *calib; ba->dev.calib = *calib;
+    memcpy(pstg(ba, ba->st_cal), calib, sizeof(sos_calib));
+    SOS_HIP(hipMemcpyAsync(stg(ba, ba->st_cal), pstg(ba, ba->st_cal), sizeof(sos_calib), hipMemcpyHostToDevice, st));
+  }
   if (precalc) {
     memcpy(pstg(ba, ba->st_pre), precalc, sizeof(sos_precalc) * nn);
     SOS_HIP(hipMemcpyAsync(stg(ba, ba->st_pre), pstg(ba, ba->st_pre), sizeof(sos_precalc) * nn, hipMemcpyHostToDevice, st));
@@ -3185,7 +3202,7 @@ static int launch_reduce(sos_ba *ba) {
   return SOS_OK;
 }
 // stitch kernels: d_Hout = [H_A | b_A | H_L | b_L | H_sc | b_sc]
-static int launch_stitch(sos_ba *ba, const float *acc, int nmodes, double *Hout = nullptr) {
+static int launch_stitch(sos_ba *ba, const float *acc, int nmodes, double *Hout = nullptr, bool toDevice = false) {
   hipStream_t st = ba->ctx->stream;
   const int n = ba->n;
   const size_t nn = (size_t)n * n;
@@ -3203,6 +3220,14 @@ static int launch_stitch(sos_ba *ba, const float *acc, int nmodes, double *Hout 
   a.sg = {nullptr, nullptr, 0, 0};
   const int nb2 = (n * (n + 1) / 2 + 1) * nmodes + n * n + 1;
   static const bool inKernel = getenv("SOS_SIGNAL_IN_KERNEL") != nullptr;
+  if (toDevice) {  // the device-resident loop: upper triangles + counts into d_Hout, nobody polls
+    a.H = ba->d_Hout.p;
+    a.nres_out = reinterpret_cast<float *>(ba->d_Hout.p + 3 * ba->hb_mode_stride);
+    a.upperOnly = 1;
+    k_stitch_stage1<<<(n * n + 20) * nmodes + n * n * n, 64, sizeof(double) * 128 * (size_t)n, st>>>(a);
+    k_stitch_stage2<<<nb2, 64, 0, st>>>(a);
+    return SOS_OK;
+  }
   if (Hout) {  // the fused path: the host polls for the end of stage 2
     ++ba->sig_st_seq;
     if (inKernel) {
@@ -3423,7 +3448,7 @@ extern "C" int sos_ba_gn_resub(sos_ba *ba, const double *x, float stepfacD) {
   float *dstep = reinterpret_cast<float *>(ba->pin_dev + ba->pin_out + ba->out_step);
   const int nPB = divup(ba->P, SOS_RSB);
   k_resub_fused<<<nPB, SOS_RSB, sizeof(float) * (8 * nn + 4 + 8 * (size_t)ba->n), c->stream>>>(
-      ba->dev, xa, ba->d_adHostF.p, ba->d_adTargetF.p, dstep, stepfacD, nPB, nullptr, nullptr, 0, 0, nullptr, nullptr);
+      ba->dev, xa, ba->d_adHostF.p, ba->d_adTargetF.p, dstep, stepfacD, nPB, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr);
   SOS_HIP(hipGetLastError());
   ba->resub_pending = true;
   return SOS_OK;
@@ -3446,6 +3471,7 @@ extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const
   memcpy(pstg(ba, ba->st_adh), adHTdeltaF, sizeof(float) * 8 * nn);
   memcpy(pstg(ba, ba->st_cd), cDeltaF, sizeof(float) * 4);
   memcpy(pstg(ba, ba->st_th), frameEnergyTH, sizeof(float) * ba->n);
+  memcpy(pstg(ba, ba->st_cal), calib, sizeof(sos_calib));
   // outputs go straight to the device-mapped pinned block: per-tile energy sums, newest-frame energies, point steps
   char *po = ba->pin + ba->pin_out, *po_dev = ba->pin_dev + ba->pin_out;
   float *dstep = reinterpret_cast<float *>(po_dev + ba->out_step);
@@ -3471,7 +3497,7 @@ extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const
     k_resub_fused<<<nPB + nSB + nEB, SOS_RSB, sizeof(float) * (8 * nn + 4 + 8 * (size_t)ba->n), st>>>(
         dv, xa, ba->d_adHostF.p, ba->d_adTargetF.p, dstep, stepfacD, nPB, reinterpret_cast<float4 *>(ba->d_stage.p),
         reinterpret_cast<const float4 *>(ba->pin_dev + ba->pin_stage), n4, nSB,
-        reinterpret_cast<const float4 *>(ba->pin_dev + ba->pin_stage + sizeof(float) * ba->st_pre), ba->d_t_pre.p);
+        reinterpret_cast<const float4 *>(ba->pin_dev + ba->pin_stage + sizeof(float) * ba->st_pre), ba->d_t_pre.p, nullptr);
   } else if (x) {
     fill_x(ba, x);
     stage_in(ba, ba->st_floats);
@@ -3781,7 +3807,7 @@ extern "C" int sos_ba_time_kernel(sos_ba *ba, const char *kernel, const float *f
         const int nPB = divup(ba->P, SOS_RSB);
         k_resub_fused<<<nPB, SOS_RSB, sizeof(float) * (8 * nn + 4 + 8 * (size_t)ba->n), st>>>(
             ba->dev, xa, ba->d_adHostF.p, ba->d_adTargetF.p, reinterpret_cast<float *>(ba->d_outpack.p + ba->out_step), 0.f, nPB, nullptr, nullptr, 0, 0,
-            nullptr, nullptr);
+            nullptr, nullptr, nullptr);
       }
       return SOS_OK;
     }
@@ -3806,3 +3832,5 @@ extern "C" int sos_ba_time_kernel(sos_ba *ba, const char *kernel, const float *f
   *avg_ms = ms / iters;
   return SOS_OK;
 }
+
+#include "sos_gn_resident.inc"

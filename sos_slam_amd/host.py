@@ -37,6 +37,7 @@ def load():
     L.sosf_prepare.argtypes = [vp]
     L.sosf_gn_iteration.argtypes = [vp, ci, C.POINTER(ci)]
     L.sosf_set_pipeline.argtypes = [vp, ci]
+    L.sosf_set_resident.argtypes = [vp, ci]
     L.sosf_set_comm.argtypes = [vp, vp]
     L.sosf_counts.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
     L.sosf_get_frame.argtypes = [vp, ci, vp, vp, vp, C.POINTER(C.c_float)]
@@ -242,6 +243,10 @@ class System:
         ss, st = C.c_double(0), np.zeros((n, 21))
         _chk(self.L.sosf_get_imu_step(self.h_, C.byref(ss), _p(st)), "sosf_get_imu_step")
         return ss.value, st, np.array([list(arr[i].state_imu) for i in range(n)]), calib.scale
+
+    def set_resident(self, on=True):
+        """device-resident Gauss-Newton loop on / off (off: the host solves, as in round 1)"""
+        _chk(self.L.sosf_set_resident(self.h_, int(on)), "sosf_set_resident")
 
     def set_pipeline(self, on=True):
         _chk(self.L.sosf_set_pipeline(self.h_, int(on)), "sosf_set_pipeline")
