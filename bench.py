@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--window", default=None, help="W7 / W12 / W16 (default: W12, or W16 with --scaling strong)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--inner", type=int, default=0, help="GN iterations per timed step (0 = enough for a >= 50 ms region)")
+    ap.add_argument("--resident", action="store_true",
+                    help="device-resident Gauss-Newton loop (solve / step / precalc kernels; measured slower than the host solve)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=14.0)
     a = ap.parse_args()
@@ -85,8 +87,27 @@ def cpu_baseline(win, seconds):
         ow.close()
         return win.R * it / dt, it / dt, it
 
-    v6, g6, it6 = run(cores, seconds * 0.6)
-    v1, g1, it1 = run(1, seconds * 0.4)
+    v6, g6, it6 = run(cores, seconds * 0.55)
+    v1, g1, it1 = run(1, seconds * 0.35)
+
+    def phases(nthreads, reps=3):   # where the threads help and where they do not (ms per call)
+        ow = orc.window_from_synth(win, fast=True)
+        ow.reset_oob()
+        th = np.array([ow.frame(f)["frameEnergyTH"] for f in range(win.n)], np.float32)
+        ow.linearize(th, nthreads=nthreads)
+        ow.apply_res()
+        out = {}
+        for name, fn in (("linearize", lambda: ow.linearize(th, nthreads=nthreads)), ("accumulate_stitch", lambda: ow.accumulate(nthreads=nthreads)),
+                         ("gn_iteration", lambda: ow.gn_iteration(0, nthreads=nthreads))):
+            fn()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            out[name + "_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 3)
+        ow.close()
+        return out
+
+    ph = {"threads_1": phases(1), f"threads_{cores}": phases(cores)}
     try:
         model = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
     except Exception:  # noqa: BLE001
@@ -96,7 +117,7 @@ def cpu_baseline(win, seconds):
                       f"reference's {cores}-thread pool structure; 1 thread: {it1} iterations",
             "build": "gcc -O3 -march=native (oracle/Makefile: fast), built on this host", "host_cpu": model,
             "host_logical_cpus": os.cpu_count(),
-            "gn_iter_per_s": g6, "value_1thread": v1, "gn_iter_per_s_1thread": g1, "thread_scaling": g6 / g1}
+            "gn_iter_per_s": g6, "value_1thread": v1, "gn_iter_per_s_1thread": g1, "thread_scaling": g6 / g1, "phases": ph}
 
 
 def main():
@@ -150,6 +171,8 @@ def main():
                     comm = None
                 sdist.attach(sysm, dist, torch)
                 exchange = "rccl via torch.distributed hooks"
+    if args.resident:
+        sysm.set_resident(True)
     sysm.prepare()
     sysm.set_pipeline(True)  # the loop below never stops on `canbreak`: every step may prefetch the next accumulate
     R_local = win.R
@@ -227,6 +250,7 @@ def main():
                                     f"{win.w}x{win.h}, points sharded over {world} GPUs ({win.P} points / {R_local} residuals on rank 0)") +
                                    "; step = one Gauss-Newton iteration (accumulate A/L/SC, fp64 stitch, solve, back-substitute, "
                                    f"step, re-linearise, applyRes), timed as the mean of {inner} consecutive iterations",
+                       "gn_loop": "device-resident (k_gn_solve)" if args.resident else "host solve (blocked LDL^T), device everything else",
                        "window": args.window, "keyframes": win.n, "points_per_gpu": win.P, "inner_repeat": inner,
                        "timed_region_ms": round(dt * 1e3, 2),
                        "residuals_per_gpu": R_local, "residuals_total": R_total,

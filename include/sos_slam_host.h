@@ -95,10 +95,11 @@ int sosf_gn_iteration(sosf_system *sys, int iteration, int *canbreak);
 /* the caller will keep calling sosf_gn_iteration whatever `canbreak` says (benchmark loops): lets every iteration
  * prefetch the next accumulate (sos_ba_set_prefetch); optimize() decides per iteration by itself */
 int sosf_set_pipeline(sosf_system *sys, int on);
-/* Device-resident Gauss-Newton loop (sos_ba_gn_resident_*, default on): solveSystemF, the frame half of doStepFromBackup and
- * setPrecalcValues run on the device, the host only decides whether to continue.  Off: the host solves (blocked LDL^T) as
- * in round 1.  Taken automatically off while IMU factors, callback hooks or an RCCL communicator are attached, with
- * setting_forceAceptStep off, and for windows of more than 17 keyframes. */
+/* Device-resident Gauss-Newton loop (sos_ba_gn_resident_*): solveSystemF, the frame half of doStepFromBackup and
+ * setPrecalcValues run on the device, the host only decides whether to continue.  OFF by default: the (4 + 8 n)-dimensional
+ * LDL^T is a chain of ~100 dependent pivots, which one compute unit walks in ~45 us where a host core needs 16 (DESIGN.md,
+ * "host out of the loop: measured"); with it off the host solves (blocked LDL^T).  Never taken while IMU factors, callback
+ * hooks or an RCCL communicator are attached, with setting_forceAceptStep off, or for windows of more than 16 keyframes. */
 int sosf_set_resident(sosf_system *sys, int on);
 int sosf_counts(sosf_system *sys, int *nFrames, int *nPoints, int *nResiduals);
 

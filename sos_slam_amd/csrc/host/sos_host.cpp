@@ -1122,6 +1122,7 @@ bool FullSystem::residentConsume(int seq) {
     return true;
   }
   residentSeq = seq;
+  if (getenv("SOS_TIMING")) fprintf(stderr, "[k_gn_solve] assemble %.1f ldlt %.1f backsub %.1f step %.1f precalc %.1f us\n", hdr[11], hdr[12], hdr[13], hdr[14], hdr[15]);
   ef->lastX = x;
   ef->resInA = (int)hdr[8];
   ef->resInL = (int)hdr[9];

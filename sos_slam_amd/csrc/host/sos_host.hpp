@@ -256,7 +256,7 @@ class FullSystem {
   sos_comm *comm = nullptr;     // RCCL communicator attached to the backend (multi-GPU), not owned
   bool pipelineAlways = false;  // flat API: the caller iterates regardless of canbreak
   // device-resident Gauss-Newton loop (sos_ba_gn_resident_*): the solve, the frame step and the precalc records on the device
-  bool residentAllowed = true;  // sosf_set_resident
+  bool residentAllowed = false;  // sosf_set_resident (off by default: measured slower than the host solve)
   bool residentActive = false;
   int residentSeq = 0;          // sequence number of the iteration whose results the host has consumed
   int residentQueued = 0;       // ... and of the last one enqueued

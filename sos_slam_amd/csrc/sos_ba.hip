@@ -2366,6 +2366,7 @@ struct sos_ba {
   // device-resident Gauss-Newton loop (sos_gn_resident.inc)
   DevBuf<double> d_gn;       // HM | bM | evalC2W | state_zero | prior | state | calib (value 4, value_zero 4, cPrior)
   DevBuf<float> d_gn_f;      // ab_exposure n | xF dim
+  DevBuf<short> d_gn_map;    // k_gn_solve: thread -> tile (I, K)
   size_t gn_HM = 0, gn_bM = 0, gn_eval = 0, gn_sz = 0, gn_prior = 0, gn_state = 0, gn_calib = 0;
   double *gn_pin = nullptr, *gn_pin_dev = nullptr;  // mapped ring of GN_SLOTS result slots + flag
   size_t gn_pin_doubles = 0, gn_slot_doubles = 0;
@@ -2452,7 +2453,7 @@ extern "C" int sos_ba_destroy(sos_ba *ba) {
     b->release();
   ba->d_rawjac.release();
   ba->d_t_pre.release(); ba->d_t_img.release(); ba->d_t_ht.release();
-  ba->d_p_list2.release(); ba->d_p_list16.release(); ba->d_r_geo.release(); ba->d_r_cw.release(); ba->d_stage.release(); ba->d_outpack.release(); ba->d_C.release(); ba->d_ar64.release(); ba->d_xchg.release(); ba->d_large.release(); ba->d_gn.release(); ba->d_gn_f.release();
+  ba->d_p_list2.release(); ba->d_p_list16.release(); ba->d_r_geo.release(); ba->d_r_cw.release(); ba->d_stage.release(); ba->d_outpack.release(); ba->d_C.release(); ba->d_ar64.release(); ba->d_xchg.release(); ba->d_large.release(); ba->d_gn.release(); ba->d_gn_f.release(); ba->d_gn_map.release();
   if (ba->gn_pin) hipHostFree(ba->gn_pin); ba->d_Jnew.release(); ba->d_JpJd_new.release(); ba->d_pterm_new.release();
   if (ba->pin) hipHostFree(ba->pin);
   if (ba->ev_step) hipEventDestroy(ba->ev_step);

@@ -141,13 +141,14 @@ def test_pipelined_iterations_match(name):
 @pytest.mark.parametrize("name", ["T3", "T4", "T6", "W7"])
 def test_device_resident_loop_equals_host_solve(name):
     """The Gauss-Newton loop with solveSystemF / doStepFromBackup / setPrecalcValues on the device (sos_ba_gn_resident_*,
-    the default) against the same loop with the host solving (blocked pivoted LDL^T, libm SE3 exp): the first solve sees
+    opt-in) against the same loop with the host solving (blocked pivoted LDL^T, libm SE3 exp): the first solve sees
     bit-identical H / b (same kernels), so x may differ by solver round-off only; over a whole optimize() the two paths take
     the same number of iterations, end on the same index sets and on poses that agree far inside the 1e-5 bar -- the
     yardstick of the device-side sin / cos and unpivoted factorisation."""
     from sos_slam_amd import host
     win = synth.make_window(name)
     dev, hst = host.System.from_window(win), host.System.from_window(win)
+    dev.set_resident(True)
     hst.set_resident(False)
     dev.prepare(); hst.prepare()
     dev.gn_iteration(0); hst.gn_iteration(0)
@@ -162,6 +163,7 @@ def test_device_resident_loop_equals_host_solve(name):
     assert np.array_equal(dev.points()["idepth"], hst.points()["idepth"])    # same x (to 1e-9) -> same fp32 point steps
     dev.close(); hst.close()
     dev, hst = host.System.from_window(win), host.System.from_window(win)
+    dev.set_resident(True)
     hst.set_resident(False)
     ra, ia = dev.optimize(6)
     rb, ib = hst.optimize(6)
