@@ -416,6 +416,35 @@ int sos_tracker_set_gs_hint(sos_tracker *trk, int on, float b0);
  * a = affLL[0] of the pose being linearized, b0 = lastRef_aff_g2l.b.  H 8x8 row-major, b 8. */
 int sos_tracker_calc_gs(sos_tracker *trk, int lvl, float a, float b0, double *H, double *b);
 
+/* CoarseTracker::trackNewestCoarse (FS/CoarseTracker.cpp:366-552) -- and, on a tracker in 3-D point mode
+ * (sos_tracker_set_points3d), the LM loop of PoseEstimator::estimate (src/LoopClosure/PoseEstimator.cpp:288-495) -- for
+ * nHyp initial poses in ONE launch: residual passes, accept / reject, the damped 8x8 solve, SE3::exp, level changes,
+ * cutoff repeats and the minResForAbort test all run on the device; the host polls one flag per hypothesis.
+ * Per hypothesis in: refToNew (row-major R | t) and aff_g2l; out: the same two, lastResiduals / lastInners per level,
+ * lastFlowIndicators, `aborted` (the :527 test fired), the levels in the order they finished with their residual
+ * (a repeated level appears twice) and the number of residual evaluations.  The caller applies the final affine sanity
+ * tests of :538-551.  Ki = the caller's inverse intrinsics per level (9 floats each; identity for the loop aligner),
+ * refAff = lastRef_aff_g2l (a, b). */
+typedef struct sos_track_hyp {
+  double refToNew[12];
+  double aff[2];
+  double lastResiduals[5];
+  double flow[3];
+  double visit_res[8];
+  int32_t lastInners[5];
+  int32_t visit_lvl[8];
+  int32_t aborted, nvisits, evals;
+} sos_track_hyp;
+int sos_tracker_track(sos_tracker *trk, int newSlot, const float *Ki, float ref_ab_exposure, float new_ab_exposure,
+                      const double *refAff, int coarsestLvl, const double *minResForAbort /*5*/, int nHyp,
+                      sos_track_hyp *hyp);
+
+/* ScaleOptimizer::optimizeScale (FS/ScaleOptimizer.cpp:120-230) as one launch of the same device loop: RKi = rot(tfmF0ToF1) *
+ * Ki[lvl] per level (9 floats each), t = trans(tfmF0ToF1), K1 = (fx1, fy1, cx1, cy1) per level; *scale is in / out,
+ * lastResiduals (5, NaN for levels not visited) and the number of residual evaluations are optional outputs. */
+int sos_tracker_optimize_scale(sos_tracker *trk, int stereoSlot, const float *RKi, const float *t, const float *K1,
+                               int coarsestLvl, float *scale, double *lastResiduals, int *evals);
+
 /* ScaleOptimizer::calcResScale / calcGSSSEScale (FS/ScaleOptimizer.cpp:273-437, 232-271).
  * RKi = rot(tfmF0ToF1) * Ki[lvl], t = trans(tfmF0ToF1); K1 = (fx1,fy1,cx1,cy1) of level `lvl`. */
 int sos_tracker_calc_res_scale(sos_tracker *trk, int lvl, int stereoSlot, const float *RKi,

@@ -156,7 +156,7 @@ int sosf_set_allreduce_f64_hook(sosf_system *sys, sosf_allreduce_f64_fn allreduc
 int sosf_set_comm(sosf_system *sys, sos_comm *comm);
 
 /* ---- CoarseTracker / ScaleOptimizer (FS/CoarseTracker.h:27-48, FS/ScaleOptimizer.h:43-104) -------------
- * The LM loops run on the host (8x8 fp64 / scalar solves, SE3 updates), the per-pixel work on the device. */
+ * The pose LM loop runs on the device (one launch per call); the scale loop on the host around device residual passes. */
 typedef struct sosf_tracker sosf_tracker;
 /* makeImages of a frame that is not (yet) a keyframe (FS/FullSystem.cpp:650, 1114): returns its image slot */
 int sosf_upload_image(sosf_system *sys, const float *image, int *slot_out);
@@ -175,6 +175,23 @@ sos_tracker *sosf_tracker_handle(sosf_tracker *trk);
 /* trackNewestCoarse (FS/CoarseTracker.cpp:366-552); lastToNew12 / aff2 are in/out */
 int sosf_tracker_track(sosf_tracker *trk, int newSlot, float new_ab_exposure, double *lastToNew12, double *aff2,
                        int coarsestLvl, const double *minResForAbort5, double *lastResiduals5, double *flow3, int *ok);
+/* The LM loop of trackNewestCoarse / pose_estimate runs on the device as one launch (sos_tracker_track, include/sos_slam.h)
+ * by default; 0 selects the loop on the host with one device round trip per residual evaluation (same decisions, same
+ * arithmetic per pixel; the two differ by the rounding of the 8x8 solve).  last_evals: residual evaluations of the last call. */
+int sosf_tracker_set_device_lm(sosf_tracker *trk, int on);
+int sosf_tracker_last_evals(sosf_tracker *trk, int *evals);
+/* FullSystem::trackNewCoarse, the hypothesis list (FS/FullSystem.cpp:150-213): slast_2_sprelast and lastF_2_slast as the
+ * reference forms them from the frame history, lastF_2_fh_imu12 = the IMU-predicted motion or NULL; posesValid = all
+ * three shells have poseValid.  Writes n tries (12 doubles each, row-major R | t); 84 without / 85 with the IMU try. */
+int sosf_tracker_make_tries(const double *slast_2_sprelast12, const double *lastF_2_slast12, const double *lastF_2_fh_imu12,
+                            int posesValid, int cap, double *tries12, int *n_out);
+/* FullSystem::trackNewCoarse, the loop over the tries (FS/FullSystem.cpp:219-283) with the tries evaluated `batch` at a time
+ * in one launch (the first try alone); the sequential take-over / early-exit decisions of the reference are replayed in
+ * order on the batch results, so the outcome equals the one-by-one loop.  Out: lastF_2_fh, aff_g2l, achievedRes (the new
+ * lastCoarseRMSE), flowVecs; info4 = {tryIterations, index of the winning try or -1, tries evaluated, haveOneGood}. */
+int sosf_tracker_track_hypotheses(sosf_tracker *trk, int newSlot, float new_ab_exposure, int nTries, const double *tries12,
+                                  const double *aff_last2, int coarsestLvl, const double *lastCoarseRMSE5, double reTrackThreshold,
+                                  int batch, double *lastF_2_fh12, double *aff2, double *achievedRes5, double *flow3, int *info4);
 /* Loop-closure aligner (N4), PoseEstimator::estimate (src/LoopClosure/PoseEstimator.cpp:288-495): set_points3d takes
  * `matched_frame->pts_dso` (xyz AoS; colors[l * n + i]), the camera of the current frame and the matched frame's
  * exposure; pose_estimate runs the LM loop from refToNew12 (in / out) on the pyramid in newSlot and applies the three

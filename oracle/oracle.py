@@ -677,6 +677,98 @@ class OracleTracker:
         return r, s.value
 
 
+# ---- FullSystem::trackNewCoarse: hypothesis list and the loop over it (FS/FullSystem.cpp:150-283) -------------
+def _se3(fn, *args):
+    L = lib()
+    out = np.zeros(12)
+    getattr(L, fn)(*[_p(np.ascontiguousarray(a, dtype=np.float64)) for a in args], _p(out))
+    return out
+
+
+def se3_mul12(A, B):
+    return _se3("orc_se3_mul12", A, B)
+
+
+def se3_inv12(A):
+    return _se3("orc_se3_inv12", A)
+
+
+def se3_exp12(a6):
+    return _se3("orc_se3_exp12", a6)
+
+
+def se3_log12(T):
+    out = np.zeros(6)
+    lib().orc_se3_log12(_p(np.ascontiguousarray(T, dtype=np.float64)), _p(out))
+    return out
+
+
+_ROT_SIGNS = [(1, 0, 0), (0, 1, 0), (0, 0, 1), (-1, 0, 0), (0, -1, 0), (0, 0, -1), (1, 1, 0), (0, 1, 1), (1, 0, 1), (-1, 1, 0),
+              (0, -1, 1), (-1, 0, 1), (1, -1, 0), (0, 1, -1), (1, 0, -1), (-1, -1, 0), (0, -1, -1), (-1, 0, -1), (-1, -1, -1),
+              (-1, -1, 1), (-1, 1, -1), (-1, 1, 1), (1, -1, -1), (1, -1, 1), (1, 1, -1), (1, 1, 1)]
+
+
+def _quat_se3(w, x, y, z):
+    """Sophus::SE3(Quaterniond(w, x, y, z), 0): SO3's constructor normalises, Eigen's toRotationMatrix on the unit quaternion."""
+    q = np.array([w, x, y, z], dtype=np.float64)
+    q = q / np.sqrt(np.sum(q * q))
+    w, x, y, z = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    return np.concatenate([R.reshape(-1), np.zeros(3)])
+
+
+def make_track_tries(slast_2_sprelast, lastF_2_slast, imu=None, poses_valid=True):
+    """lastF_2_fh_tries, FS/FullSystem.cpp:150-213."""
+    ident = np.concatenate([np.eye(3).reshape(-1), np.zeros(3)])
+    if not poses_valid:
+        return np.array([ident])
+    fh_2_slast = np.asarray(slast_2_sprelast, dtype=np.float64)
+    inv = se3_inv12(fh_2_slast)
+    tries = []
+    if imu is not None:
+        tries.append(np.asarray(imu, dtype=np.float64))
+    tries.append(se3_mul12(inv, lastF_2_slast))
+    tries.append(se3_mul12(se3_mul12(inv, inv), lastF_2_slast))
+    tries.append(se3_mul12(se3_inv12(se3_exp12(se3_log12(fh_2_slast) * 0.5)), lastF_2_slast))
+    tries.append(np.asarray(lastF_2_slast, dtype=np.float64).copy())
+    tries.append(ident.copy())
+    const = se3_mul12(inv, lastF_2_slast)
+    rot_delta = np.float32(0.02)
+    while float(rot_delta) < 0.05:   # `float rot_delta; rot_delta < 0.05; rot_delta += 0.01`: the sum and the comparison are
+        for rs in _ROT_SIGNS:        # double, the store rounds to float -> 0.02, 0.03, 0.04, then 0.05000000074 ends the loop
+            d = [float(np.float32(r) * rot_delta) for r in rs]
+            tries.append(se3_mul12(const, _quat_se3(1.0, *d)))
+        rot_delta = np.float32(float(rot_delta) + 0.01)
+    return np.array(tries)
+
+
+def track_new_coarse(tracker, new_dI, ref_ab, new_ab, ref_aff, tries, aff_last, coarsest, last_coarse_rmse, retrack_threshold=1.5):
+    """The loop of FS/FullSystem.cpp:219-283 around OracleTracker.track, one try after the other."""
+    achieved = np.full(5, np.nan)
+    flow = np.array([100.0, 100.0, 100.0])
+    best_T = np.concatenate([np.eye(3).reshape(-1), np.zeros(3)])
+    best_aff = np.zeros(2)
+    have, chosen, its = False, -1, 0
+    for i, T0 in enumerate(tries):
+        ok, T, aff, cur, fl = tracker.track(new_dI, ref_ab, new_ab, ref_aff, T0, aff_last, coarsest, minRes=achieved.copy())
+        its += 1
+        if ok and np.isfinite(np.float32(cur[0])) and not (cur[0] >= achieved[0]):
+            flow, best_aff, best_T, have, chosen = fl.copy(), aff.copy(), T.copy(), True, i
+        if have:
+            for q in range(5):
+                if (not np.isfinite(np.float32(achieved[q]))) or achieved[q] > cur[q]:
+                    achieved[q] = cur[q]
+        if have and achieved[0] < last_coarse_rmse[0] * retrack_threshold:
+            break
+    if not have:
+        flow = np.zeros(3)
+        best_aff = np.asarray(aff_last, dtype=np.float64).copy()
+        best_T = np.asarray(tries[0], dtype=np.float64).copy()
+    return dict(lastF_2_fh=best_T, aff=best_aff, achievedRes=achieved, flow=flow, tryIterations=its, chosen=chosen, haveOneGood=have)
+
+
 def imu():
     """The oracle's IMU / spline factor assembly (orc_imu_*), same call surface as sos_slam_amd.host.imu()."""
     from sos_slam_amd.host import _ImuApi

@@ -33,7 +33,7 @@ def _stale(target, sources):
         return True
     t = os.path.getmtime(target)
     deps = list(sources) + [os.path.join(INCLUDE, "sos_slam.h"), os.path.join(INCLUDE, "sos_slam_host.h")]
-    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     hostdir = os.path.join(CSRC, "host")
     if os.path.isdir(hostdir):
         deps += [os.path.join(hostdir, f) for f in os.listdir(hostdir) if f.endswith((".h", ".hpp"))]

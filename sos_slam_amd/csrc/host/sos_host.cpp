@@ -1686,8 +1686,159 @@ static void rki_of(const SE3 &T, const float *Ki, float *RKi, float *t) {
   for (int i = 0; i < 3; i++) t[i] = (float)T.t[i];
 }
 
+// what trackNewestCoarse leaves behind for a run of the device loop that finished `nvis` levels (all of them, or the
+// levels up to the one where the :527 test fires): lastResiduals / lastInners / lastFlowIndicators, and for a complete run
+// the pose, the affine parameters and their sanity tests, FS/CoarseTracker.cpp:535-551
+bool CoarseTracker::finishTrack(const sos_track_hyp &h, int nvis, SE3 &lastToNew_out, AffLight &aff_g2l_out, double *lastResiduals) {
+  for (int i = 0; i < 5; i++) lastResiduals[i] = NAN;
+  for (int j = 0; j < nvis && j < 8; j++) lastResiduals[h.visit_lvl[j]] = h.visit_res[j];
+  lastEvals = h.evals;
+  const bool complete = !h.aborted && nvis == h.nvisits;
+  if (!complete) return false;
+  for (int i = 0; i < 5; i++) lastInners[i] = h.lastInners[i];
+  for (int i = 0; i < 3; i++) lastFlowIndicators[i] = h.flow[i];
+  lastToNew_out = SE3::from12(h.refToNew);
+  aff_g2l_out = AffLight(h.aff[0], h.aff[1]);
+  const float modeA = prm.affineOptModeA, modeB = prm.affineOptModeB;
+  if ((modeA != 0 && (fabsf((float)aff_g2l_out.a) > 1.2)) || (modeB != 0 && (fabsf((float)aff_g2l_out.b) > 200))) return false;
+  double rel[2];
+  AffLight::fromToVecExposure(ref_ab_exposure, new_ab_exposure_last, lastRef_aff_g2l, aff_g2l_out, rel);
+  const float relA = (float)rel[0], relB = (float)rel[1];
+  if ((modeA == 0 && (fabsf(logf(relA)) > 1.5)) || (modeB == 0 && (fabsf(relB) > 200))) return false;
+  if (modeA < 0) aff_g2l_out.a = 0;
+  if (modeB < 0) aff_g2l_out.b = 0;
+  return true;
+}
+
+void CoarseTracker::makeTrackTries(const SE3 &slast_2_sprelast, const SE3 &lastF_2_slast, const SE3 *lastF_2_fh_imu, bool posesValid,
+                                   std::vector<SE3> &tries) {
+  tries.clear();
+  if (!posesValid) {  // :208-211
+    tries.push_back(SE3());
+    return;
+  }
+  const SE3 fh_2_slast = slast_2_sprelast;  // assumed to be the same as fh_2_slast
+  if (lastF_2_fh_imu) tries.push_back(*lastF_2_fh_imu);
+  const SE3 inv = fh_2_slast.inverse();
+  tries.push_back(inv * lastF_2_slast);        // constant motion
+  tries.push_back(inv * inv * lastF_2_slast);  // double motion (frame skipped)
+  double lg[6];
+  fh_2_slast.log(lg);
+  for (int i = 0; i < 6; i++) lg[i] *= 0.5;
+  tries.push_back(SE3::exp(lg).inverse() * lastF_2_slast);  // half motion
+  tries.push_back(lastF_2_slast);                           // zero motion
+  tries.push_back(SE3());                                   // zero motion from the keyframe
+  const SE3 lastF_2_fh_const = inv * lastF_2_slast;
+  static const float rot_signs[26][3] = {{1, 0, 0},   {0, 1, 0},   {0, 0, 1},   {-1, 0, 0},   {0, -1, 0},  {0, 0, -1},  {1, 1, 0},
+                                         {0, 1, 1},   {1, 0, 1},   {-1, 1, 0},  {0, -1, 1},   {-1, 0, 1},  {1, -1, 0},  {0, 1, -1},
+                                         {1, 0, -1},  {-1, -1, 0}, {0, -1, -1}, {-1, 0, -1},  {-1, -1, -1}, {-1, -1, 1}, {-1, 1, -1},
+                                         {-1, 1, 1},  {1, -1, -1}, {1, -1, 1},  {1, 1, -1},   {1, 1, 1}};
+  for (float rot_delta = 0.02; rot_delta < 0.05; rot_delta += 0.01) {  // the float loop variable of :199 (three passes)
+    for (int k = 0; k < 26; k++) {
+      // Sophus::SO3(Quaterniond(1, x, y, z)) normalises the quaternion; then the rotation matrix of the unit quaternion
+      double q[4] = {1, (double)(rot_signs[k][0] * rot_delta), (double)(rot_signs[k][1] * rot_delta), (double)(rot_signs[k][2] * rot_delta)};
+      const double nrm = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+      for (int i = 0; i < 4; i++) q[i] /= nrm;
+      const double qw = q[0], qx = q[1], qy = q[2], qz = q[3];
+      const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+      const double twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy,
+                   tzz = tz * qz;
+      SE3 D;
+      D.R[0] = 1 - (tyy + tzz); D.R[1] = txy - twz; D.R[2] = txz + twy;
+      D.R[3] = txy + twz; D.R[4] = 1 - (txx + tzz); D.R[5] = tyz - twx;
+      D.R[6] = txz - twy; D.R[7] = tyz + twx; D.R[8] = 1 - (txx + tyy);
+      tries.push_back(lastF_2_fh_const * D);
+    }
+  }
+}
+
+int CoarseTracker::trackHypotheses(int newSlot, float new_ab_exposure, const std::vector<SE3> &tries, const AffLight &aff_last_2_l,
+                                   int coarsestLvl, const double *lastCoarseRMSE, double reTrackThreshold, int batch, TrackResult &out) {
+  out = TrackResult();
+  out.flowVecs[0] = out.flowVecs[1] = out.flowVecs[2] = 100;
+  out.lastF_2_fh = SE3();
+  out.aff_g2l = AffLight(0, 0);
+  double achievedRes[5] = {NAN, NAN, NAN, NAN, NAN};
+  if (tries.empty()) return SOS_ERR_ARG;
+  if (batch < 1) batch = 1;
+  new_ab_exposure_last = new_ab_exposure;
+  const double refAff[2] = {lastRef_aff_g2l.a, lastRef_aff_g2l.b};
+  const size_t n = tries.size();
+  std::vector<sos_track_hyp> hyp;
+  bool stop = false;
+  for (size_t i0 = 0; i0 < n && !stop;) {
+    const size_t cnt = (i0 == 0) ? 1 : std::min<size_t>((size_t)batch, n - i0);
+    hyp.assign(cnt, sos_track_hyp());
+    for (size_t k = 0; k < cnt; k++) {
+      memset(&hyp[k], 0, sizeof(sos_track_hyp));
+      tries[i0 + k].to12(hyp[k].refToNew);
+      hyp[k].aff[0] = aff_last_2_l.a;
+      hyp[k].aff[1] = aff_last_2_l.b;
+    }
+    if (deviceLM) {
+      const int rc = sos_tracker_track(trk, newSlot, &Ki[0][0], ref_ab_exposure, new_ab_exposure, refAff, coarsestLvl, achievedRes, (int)cnt, hyp.data());
+      if (rc != SOS_OK) return rc;
+    }
+    out.evaluated += (int)cnt;
+    for (size_t k = 0; k < cnt && !stop; k++) {
+      SE3 lastF_2_fh_this = tries[i0 + k];
+      AffLight aff_g2l_this = aff_last_2_l;
+      double currentRes[5];
+      bool trackingIsGood;
+      if (deviceLM) {
+        // where would the sequential loop have stopped this try?  thresholds only tighten, so never later than the device did
+        const sos_track_hyp &h = hyp[k];
+        int nvis = h.nvisits;
+        for (int j = 0; j < h.nvisits && j < 8; j++)
+          if (h.visit_res[j] > 1.5 * achievedRes[h.visit_lvl[j]]) { nvis = j + 1; break; }
+        sos_track_hyp cut = h;
+        if (nvis < h.nvisits) cut.aborted = 1;
+        trackingIsGood = finishTrack(cut, nvis, lastF_2_fh_this, aff_g2l_this, currentRes);
+      } else {
+        trackingIsGood = trackNewestCoarse(newSlot, new_ab_exposure, lastF_2_fh_this, aff_g2l_this, coarsestLvl, achievedRes, currentRes);
+      }
+      out.tryIterations++;
+      if (trackingIsGood && std::isfinite((float)currentRes[0]) && !(currentRes[0] >= achievedRes[0])) {  // a new winner, :239-247
+        for (int q = 0; q < 3; q++) out.flowVecs[q] = lastFlowIndicators[q];
+        out.aff_g2l = aff_g2l_this;
+        out.lastF_2_fh = lastF_2_fh_this;
+        out.haveOneGood = true;
+        out.chosen = (int)(i0 + k);
+      }
+      if (out.haveOneGood) {  // take over achieved res (always), :250-257
+        for (int q = 0; q < 5; q++)
+          if (!std::isfinite((float)achievedRes[q]) || achievedRes[q] > currentRes[q]) achievedRes[q] = currentRes[q];
+      }
+      if (out.haveOneGood && achievedRes[0] < lastCoarseRMSE[0] * reTrackThreshold) stop = true;
+    }
+    i0 += cnt;
+  }
+  if (!out.haveOneGood) {  // :276-283
+    out.flowVecs[0] = out.flowVecs[1] = out.flowVecs[2] = 0;
+    out.aff_g2l = aff_last_2_l;
+    out.lastF_2_fh = tries[0];
+  }
+  for (int q = 0; q < 5; q++) out.achievedRes[q] = achievedRes[q];
+  if (firstCoarseRMSE < 0) firstCoarseRMSE = achievedRes[0];
+  return SOS_OK;
+}
+
 bool CoarseTracker::trackNewestCoarse(int newSlot, float new_ab_exposure, SE3 &lastToNew_out, AffLight &aff_g2l_out,
                                       int coarsestLvl, const double *minResForAbort, double *lastResiduals) {
+  new_ab_exposure_last = new_ab_exposure;
+  if (deviceLM) {
+    sos_track_hyp hyp;
+    memset(&hyp, 0, sizeof(hyp));
+    lastToNew_out.to12(hyp.refToNew);
+    hyp.aff[0] = aff_g2l_out.a;
+    hyp.aff[1] = aff_g2l_out.b;
+    for (int i = 0; i < 5; i++) lastResiduals[i] = NAN;
+    lastFlowIndicators[0] = lastFlowIndicators[1] = lastFlowIndicators[2] = 1000;
+    const double refAff[2] = {lastRef_aff_g2l.a, lastRef_aff_g2l.b};
+    if (sos_tracker_track(trk, newSlot, &Ki[0][0], ref_ab_exposure, new_ab_exposure, refAff, coarsestLvl, minResForAbort, 1, &hyp) != SOS_OK)
+      return false;
+    return finishTrack(hyp, hyp.nvisits, lastToNew_out, aff_g2l_out, lastResiduals);
+  }
   for (int i = 0; i < 5; i++) lastResiduals[i] = NAN;
   lastFlowIndicators[0] = lastFlowIndicators[1] = lastFlowIndicators[2] = 1000;
   const int maxIterations[] = {10, 20, 50, 50, 50};
@@ -1698,6 +1849,7 @@ bool CoarseTracker::trackNewestCoarse(int newSlot, float new_ab_exposure, SE3 &l
   const float modeA = prm.affineOptModeA, modeB = prm.affineOptModeB;
   sos_tracker_set_gs_hint(trk, 1, (float)lastRef_aff_g2l.b);  // calcGSSSE rides behind every calcRes (accepted steps: 1 round trip)
   bool devError = false;
+  lastEvals = 0;
   auto calcRes = [&](int lvl, const SE3 &T, const AffLight &aff, float cutoff, double *rs, float *a_out) {
     float RKi[9], t[3], affLL[2];
     rki_of(T, Ki[lvl], RKi, t);
@@ -1706,6 +1858,7 @@ bool CoarseTracker::trackNewestCoarse(int newSlot, float new_ab_exposure, SE3 &l
     affLL[0] = (float)a2[0];
     affLL[1] = (float)a2[1];
     if (a_out) *a_out = affLL[0];
+    lastEvals++;
     if (sos_tracker_calc_res(trk, lvl, newSlot, RKi, t, affLL, cutoff, rs) != SOS_OK) {
       devError = true;  // a failed device call must not leave uninitialised sums behind: the loop sees a lost track
       rs[0] = NAN; rs[1] = 0; rs[2] = rs[3] = rs[4] = NAN; rs[5] = 0;
@@ -1847,6 +2000,18 @@ float CoarseTracker::optimizeScale(int stereoSlot, const SE3 &tfmF0ToF1, const f
     cx1[l] = (cx1[0] + 0.5) / ((int)1 << l) - 0.5;
     cy1[l] = (cy1[0] + 0.5) / ((int)1 << l) - 0.5;
   }
+  if (deviceLM) {  // the whole loop as one launch
+    float RKiAll[SOS_PYR_LEVELS * 9], K1All[SOS_PYR_LEVELS * 4], tf[3];
+    for (int l = 0; l < levels; l++) {
+      rki_of(tfmF0ToF1, Ki[l], RKiAll + 9 * l, tf);
+      K1All[4 * l] = fx1[l]; K1All[4 * l + 1] = fy1[l]; K1All[4 * l + 2] = cx1[l]; K1All[4 * l + 3] = cy1[l];
+    }
+    float s = scale;
+    if (sos_tracker_optimize_scale(trk, stereoSlot, RKiAll, tf, K1All, coarsestLvl, &s, last_residuals, &lastEvals) != SOS_OK) return NAN;
+    scale = s;
+    return (float)last_residuals[0];
+  }
+  lastEvals = 0;
   sos_tracker_set_gs_hint(trk, 1, 0.f);
   for (int lvl = coarsestLvl; lvl >= 0; lvl--) {
     float H = 0, b = 0, levelCutoffRepeat = 1;
@@ -1855,8 +2020,10 @@ float CoarseTracker::optimizeScale(int stereoSlot, const SE3 &tfmF0ToF1, const f
     float RKi[9], tf[3];
     rki_of(tfmF0ToF1, Ki[lvl], RKi, tf);
     sos_tracker_calc_res_scale(trk, lvl, stereoSlot, RKi, tf, K1, scale_current, prm.coarseCutoffTH * levelCutoffRepeat, resOld);
+    lastEvals++;
     while (resOld[5] > 0.6 && levelCutoffRepeat < 50) {
       levelCutoffRepeat *= 2;
+      lastEvals++;
       sos_tracker_calc_res_scale(trk, lvl, stereoSlot, RKi, tf, K1, scale_current, prm.coarseCutoffTH * levelCutoffRepeat, resOld);
     }
     sos_tracker_calc_gs_scale(trk, lvl, tf, K1, scale_current, &H, &b);
@@ -1871,6 +2038,7 @@ float CoarseTracker::optimizeScale(int stereoSlot, const SE3 &tfmF0ToF1, const f
       if (!std::isfinite(inc) || fabs(inc) > scale_current) inc = 0.0;
       const float scale_new = scale_current + inc;
       sos_tracker_calc_res_scale(trk, lvl, stereoSlot, RKi, tf, K1, scale_new, prm.coarseCutoffTH * levelCutoffRepeat, resNew);
+      lastEvals++;
       const bool accept = (resNew[0] / resNew[1]) < (resOld[0] / resOld[1]);
       if (accept) {
         sos_tracker_calc_gs_scale(trk, lvl, tf, K1, scale_new, &H, &b);
@@ -2309,6 +2477,48 @@ extern "C" int sosf_tracker_track(sosf_tracker *t, int newSlot, float new_ab_exp
   aff2[1] = aff.b;
   if (flow3) for (int i = 0; i < 3; i++) flow3[i] = t->ct->lastFlowIndicators[i];
   if (ok) *ok = good ? 1 : 0;
+  return SOS_OK;
+}
+extern "C" int sosf_tracker_set_device_lm(sosf_tracker *t, int on) {
+  if (!t) return SOS_ERR_ARG;
+  t->ct->deviceLM = on != 0;
+  return SOS_OK;
+}
+extern "C" int sosf_tracker_last_evals(sosf_tracker *t, int *evals) {
+  if (!t || !evals) return SOS_ERR_ARG;
+  *evals = t->ct->lastEvals;
+  return SOS_OK;
+}
+extern "C" int sosf_tracker_make_tries(const double *slast_2_sprelast12, const double *lastF_2_slast12, const double *lastF_2_fh_imu12,
+                                       int posesValid, int cap, double *tries12, int *n_out) {
+  if (!slast_2_sprelast12 || !lastF_2_slast12 || !tries12 || !n_out) return SOS_ERR_ARG;
+  std::vector<SE3> tries;
+  SE3 imu;
+  if (lastF_2_fh_imu12) imu = SE3::from12(lastF_2_fh_imu12);
+  CoarseTracker::makeTrackTries(SE3::from12(slast_2_sprelast12), SE3::from12(lastF_2_slast12), lastF_2_fh_imu12 ? &imu : nullptr,
+                                posesValid != 0, tries);
+  *n_out = (int)tries.size();
+  if ((int)tries.size() > cap) return SOS_ERR_ARG;
+  for (size_t i = 0; i < tries.size(); i++) tries[i].to12(tries12 + 12 * i);
+  return SOS_OK;
+}
+extern "C" int sosf_tracker_track_hypotheses(sosf_tracker *t, int newSlot, float new_ab_exposure, int nTries, const double *tries12,
+                                             const double *aff_last2, int coarsestLvl, const double *lastCoarseRMSE5,
+                                             double reTrackThreshold, int batch, double *lastF_2_fh12, double *aff2,
+                                             double *achievedRes5, double *flow3, int *info4) {
+  if (!t || !tries12 || nTries < 1 || !aff_last2 || !lastCoarseRMSE5 || !lastF_2_fh12 || !aff2 || !achievedRes5) return SOS_ERR_ARG;
+  std::vector<SE3> tries(nTries);
+  for (int i = 0; i < nTries; i++) tries[i] = SE3::from12(tries12 + 12 * i);
+  CoarseTracker::TrackResult r;
+  const int rc = t->ct->trackHypotheses(newSlot, new_ab_exposure, tries, AffLight(aff_last2[0], aff_last2[1]), coarsestLvl, lastCoarseRMSE5,
+                                        reTrackThreshold, batch, r);
+  if (rc != SOS_OK) return rc;
+  r.lastF_2_fh.to12(lastF_2_fh12);
+  aff2[0] = r.aff_g2l.a;
+  aff2[1] = r.aff_g2l.b;
+  for (int i = 0; i < 5; i++) achievedRes5[i] = r.achievedRes[i];
+  if (flow3) for (int i = 0; i < 3; i++) flow3[i] = r.flowVecs[i];
+  if (info4) { info4[0] = r.tryIterations; info4[1] = r.chosen; info4[2] = r.evaluated; info4[3] = r.haveOneGood ? 1 : 0; }
   return SOS_OK;
 }
 extern "C" int sosf_set_imu(sosf_system *sy, const sosf_imu_settings *S, sosf_imu_calib *C, sosf_imu_frame *frames, const double *HM,

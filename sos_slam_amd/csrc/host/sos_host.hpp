@@ -321,6 +321,30 @@ class CoarseTracker {
   bool trackNewestCoarse(int newSlot, float new_ab_exposure, SE3 &lastToNew_out, AffLight &aff_g2l_out, int coarsestLvl,
                          const double *minResForAbort5, double *lastResiduals5);   // :366-552
   float optimizeScale(int stereoSlot, const SE3 &tfmF0ToF1, const float *K1_level0, float &scale, int coarsestLvl);  // FS/ScaleOptimizer.cpp:120-230
+  // the pose hypotheses of FullSystem::trackNewCoarse (FS/FullSystem.cpp:150-213): IMU prediction (optional), constant /
+  // double / half / zero motion, zero motion from the keyframe, then 26 rotation signs x 3 magnitudes around the constant-
+  // motion guess; one identity try when a pose is not valid
+  static void makeTrackTries(const SE3 &slast_2_sprelast, const SE3 &lastF_2_slast, const SE3 *lastF_2_fh_imu, bool posesValid,
+                             std::vector<SE3> &tries);
+  // the loop over the hypotheses, FS/FullSystem.cpp:219-262.  The tries are evaluated `batch` at a time in one launch of the
+  // device loop (the first one alone: it usually wins) and the reference's sequential decisions -- each try must be at
+  // least as good as the best so far on every level it reaches, the loop stops at the first result below
+  // lastCoarseRMSE[0] * setting_reTrackThreshold -- are replayed on the results in order; a try that the sequential loop
+  // would have aborted on a coarse level is cut at that level from the list of levels it finished.
+  struct TrackResult {
+    SE3 lastF_2_fh;
+    AffLight aff_g2l;
+    double achievedRes[5];
+    double flowVecs[3];
+    int tryIterations = 0, chosen = -1, evaluated = 0;
+    bool haveOneGood = false;
+  };
+  int trackHypotheses(int newSlot, float new_ab_exposure, const std::vector<SE3> &tries, const AffLight &aff_last_2_l, int coarsestLvl,
+                      const double *lastCoarseRMSE5, double reTrackThreshold, int batch, TrackResult &out);
+  bool finishTrack(const sos_track_hyp &h, int nvis, SE3 &lastToNew_out, AffLight &aff_g2l_out, double *lastResiduals5);
+  float new_ab_exposure_last = 1;
+  bool deviceLM = true;  // trackNewestCoarse / poseEstimate as one launch (sos_tracker_track); false: the LM loop on the host
+  int lastEvals = 0;     // residual evaluations of the last trackNewestCoarse
   void scaleCoarseDepthL0(float scale);
   // loop-closure aligner (src/LoopClosure/PoseEstimator.cpp): template = 3-D points of the matched keyframe with one colour per
   // level; estimate() = the same Levenberg-Marquardt loop with zero reference affine parameters, no abort thresholds and

@@ -58,6 +58,49 @@ struct SE3 {
         Ad[6 * i + j + 3] = H[3 * i] * R[j] + H[3 * i + 1] * R[3 + j] + H[3 * i + 2] * R[6 + j];
       }
   }
+  // tangent of this transform (Sophus se3.hpp:437-470 with so3.hpp:491-526 on the matrix -> quaternion conversion)
+  void log(double *a) const {
+    double q[4];  // w x y z
+    const double tr = R[0] + R[4] + R[8];
+    if (tr > 0) {
+      double s = std::sqrt(tr + 1.0);
+      q[0] = 0.5 * s;
+      s = 0.5 / s;
+      q[1] = (R[7] - R[5]) * s;
+      q[2] = (R[2] - R[6]) * s;
+      q[3] = (R[3] - R[1]) * s;
+    } else {
+      int i = 0;
+      if (R[4] > R[0]) i = 1;
+      if (R[8] > R[4 * i]) i = 2;
+      const int j = (i + 1) % 3, k = (j + 1) % 3;
+      double s = std::sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
+      q[1 + i] = 0.5 * s;
+      s = 0.5 / s;
+      q[0] = (R[3 * k + j] - R[3 * j + k]) * s;
+      q[1 + j] = (R[3 * j + i] + R[3 * i + j]) * s;
+      q[1 + k] = (R[3 * k + i] + R[3 * i + k]) * s;
+    }
+    const double sq = q[1] * q[1] + q[2] * q[2] + q[3] * q[3], nrm = std::sqrt(sq), w = q[0];
+    double f;
+    if (nrm < 1e-10) f = 2.0 / w - 2.0 * sq / (w * w * w);
+    else if (std::fabs(w) < 1e-10) f = (w > 0 ? M_PI : -M_PI) / nrm;
+    else f = 2.0 * std::atan(nrm / w) / nrm;
+    const double om[3] = {f * q[1], f * q[2], f * q[3]};
+    const double theta = f * nrm;
+    const double Om[9] = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
+    double Om2[9], Vi[9];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) Om2[3 * r + c] = Om[3 * r] * Om[c] + Om[3 * r + 1] * Om[3 + c] + Om[3 * r + 2] * Om[6 + c];
+    double c2;
+    if (std::fabs(theta) < 1e-10) c2 = 1.0 / 12.0;
+    else c2 = (1.0 - theta / (2.0 * std::tan(0.5 * theta))) / (theta * theta);
+    for (int i = 0; i < 9; i++) Vi[i] = ((i % 4 == 0) ? 1.0 : 0.0) - 0.5 * Om[i] + c2 * Om2[i];
+    for (int i = 0; i < 3; i++) {
+      a[i] = Vi[3 * i] * t[0] + Vi[3 * i + 1] * t[1] + Vi[3 * i + 2] * t[2];
+      a[3 + i] = om[i];
+    }
+  }
   // tangent = [upsilon(3), omega(3)]
   static SE3 exp(const double *a) {
     const double eps = 1e-10;

@@ -29,6 +29,7 @@
 // (hipcc default), sums in the order of the reference source; the 8-pixel pattern sums are evaluated
 // sequentially pixel 0..7 through a DPP row_shr chain so that IN/OOB/OUTLIER sets are bit-exact.
 #include "sos_common.h"
+#include "sos_devmath.h"
 
 #include <algorithm>
 #include <numeric>

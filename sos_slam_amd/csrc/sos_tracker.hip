@@ -64,6 +64,10 @@ struct sos_tracker {
   float *l_xyz[3] = {nullptr, nullptr, nullptr}, *l_col[SOS_PYR_LEVELS] = {nullptr};
   int l_n = 0, l_cap = 0;
   float gss_key[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // device-resident LM loop (sos_tracker_lm.inc): granule buffers, mapped result block, launch counter
+  unsigned long long *lm_part = nullptr;
+  double *lm_out = nullptr, *lm_out_dev = nullptr;
+  int lm_seq = 0;
 };
 
 static inline int divup(int a, int b) { return (a + b - 1) / b; }
@@ -119,6 +123,8 @@ extern "C" int sos_tracker_destroy(sos_tracker *T) {
   for (int l = 0; l < SOS_PYR_LEVELS; l++) hipFree(T->l_col[l]);
   hipFree(T->d_part2);
   hipFree(T->d_fusectr);
+  hipFree(T->lm_part);
+  if (T->lm_out) hipHostFree(T->lm_out);
   if (T->pin_o) hipHostFree(T->pin_o);
   hipFree(T->d_counts); hipFree(T->d_part); hipFree(T->d_out); hipFree(T->d_pix); hipFree(T->d_pixv);
   delete T;
@@ -435,7 +441,7 @@ __device__ __forceinline__ float wave_sum63(float a) {
 }
 // block-level fixed-tree sum of NV floats held per thread; result in sm[0..NV) of thread 0's view
 template <int NV>
-__device__ __forceinline__ void block_sum(float *v, float *sm /* NV*4 */, float *out) {
+__device__ __forceinline__ float block_sum_val(float *v, float *sm /* NV*4 */) {  // thread k < NV returns sum k
 #pragma unroll
   for (int k = 0; k < NV; k++) v[k] = wave_sum63(v[k]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -444,7 +450,13 @@ __device__ __forceinline__ void block_sum(float *v, float *sm /* NV*4 */, float 
     for (int k = 0; k < NV; k++) sm[k * 4 + wave] = v[k];
   }
   __syncthreads();
-  if (threadIdx.x < NV) out[threadIdx.x] = (sm[threadIdx.x * 4] + sm[threadIdx.x * 4 + 1]) + (sm[threadIdx.x * 4 + 2] + sm[threadIdx.x * 4 + 3]);
+  if (threadIdx.x < NV) return (sm[threadIdx.x * 4] + sm[threadIdx.x * 4 + 1]) + (sm[threadIdx.x * 4 + 2] + sm[threadIdx.x * 4 + 3]);
+  return 0.f;
+}
+template <int NV>
+__device__ __forceinline__ void block_sum(float *v, float *sm /* NV*4 */, float *out) {
+  const float r = block_sum_val<NV>(v, sm);
+  if (threadIdx.x < NV) out[threadIdx.x] = r;
 }
 
 // parameters of the calcGSSSE that may ride inside k_calc_res (speculation, see sos_tracker)
@@ -489,15 +501,11 @@ __device__ __forceinline__ void fused_final_sum(const FuseSum &fs, const float *
   __threadfence_system();
   if (k == 0) __hip_atomic_store(fs.flag, fs.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-template <int MODE, bool GS>
-__global__ __launch_bounds__(256) void k_calc_res(ResArgs a, float *__restrict__ part /* nblk*8 */, GsFuse gf,
-                                                  float *__restrict__ part_gs /* nblk*45 | nblk*3 */, FuseSum fs) {
-  __shared__ float sm[8 * 4];
-  __shared__ float smg[(MODE == 1 ? 3 : 45) * 4];
-  float gsb[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // this pixel's warp-buffer entries, as stored
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // E, numTermsInE, numWarped, numSaturated, flowT, flowRT, flowNum, -
-  if (i < a.n) {
+// one template pixel of calcRes: v = (E, numTermsInE, numWarped, numSaturated, flowT, flowRT, flowNum, -), gsb = this pixel's
+// warp-buffer entries as the reference stores them (zero weight for dropped pixels)
+template <int MODE>
+__device__ __forceinline__ void res_pixel(const ResArgs &a, int i, float *v, float *gsb) {
+  {
     const float id = a.pid[i], x = a.pu[i], y = a.pv[i];  // MODE 2: id holds z
     float pt0, pt1, pt2;
     if (MODE == 2) {  // pt = R (x, y, z) + t, src/LoopClosure/PoseEstimator.cpp:181-183
@@ -586,14 +594,12 @@ __global__ __launch_bounds__(256) void k_calc_res(ResArgs a, float *__restrict__
     }
     gsb[0] = warped ? o0 : 0.f; gsb[1] = warped ? o1 : 0.f; gsb[2] = warped ? o2 : 0.f;
     gsb[3] = b3; gsb[4] = b4; gsb[5] = b5; gsb[6] = b6; gsb[7] = b7;
-#pragma unroll
-    for (int k = 0; k < 8; k++) a.buf[k][i] = gsb[k];
   }
-  block_sum<8>(v, sm, part + 8 * (size_t)blockIdx.x);
-  if (GS) {  // the same arithmetic as k_calc_gs / k_calc_gs_scale on the values just stored
-    if (MODE == 1) {
-      float g3[3] = {0, 0, 0};
-      if (i < a.n) {
+}
+// the calcGSSSE products of one pixel from its warp-buffer entries: the arithmetic of k_calc_gs / k_calc_gs_scale
+__device__ __forceinline__ void gs_pixel_scale(const float *gsb, const GsFuse &gf, float *g3) {
+  {
+      {
         const float dxfx = gsb[3] * gf.fxl, dyfy = gsb[4] * gf.fyl;
         const float rx1 = gsb[0], rx2 = gsb[1], rx3 = gsb[2];
         const float deno_sqrt = gf.s * rx3 + gf.tz;
@@ -608,12 +614,11 @@ __global__ __launch_bounds__(256) void k_calc_res(ResArgs a, float *__restrict__
           g3[2] = J1w * J1;
         }
       }
-      block_sum<3>(g3, smg, part_gs + 3 * (size_t)blockIdx.x);
-    } else {
-      float g45[45];
-#pragma unroll
-      for (int k = 0; k < 45; k++) g45[k] = 0.f;
-      if (i < a.n) {
+  }
+}
+__device__ __forceinline__ void gs_pixel_pose(const float *gsb, const GsFuse &gf, float *g45) {
+  {
+      {
         const float dx = gsb[3] * gf.fxl, dy = gsb[4] * gf.fyl;
         const float u = gsb[1], vv = gsb[2], id = gsb[0];
         float J[9];
@@ -635,6 +640,32 @@ __global__ __launch_bounds__(256) void k_calc_res(ResArgs a, float *__restrict__
           for (int cc = r; cc < 9; cc++) g45[idx++] = Jw * J[cc];
         }
       }
+  }
+}
+template <int MODE, bool GS>
+__global__ __launch_bounds__(256) void k_calc_res(ResArgs a, float *__restrict__ part /* nblk*8 */, GsFuse gf,
+                                                  float *__restrict__ part_gs /* nblk*45 | nblk*3 */, FuseSum fs) {
+  __shared__ float sm[8 * 4];
+  __shared__ float smg[(MODE == 1 ? 3 : 45) * 4];
+  float gsb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (i < a.n) {
+    res_pixel<MODE>(a, i, v, gsb);
+#pragma unroll
+    for (int k = 0; k < 8; k++) a.buf[k][i] = gsb[k];
+  }
+  block_sum<8>(v, sm, part + 8 * (size_t)blockIdx.x);
+  if (GS) {  // the same arithmetic as k_calc_gs / k_calc_gs_scale on the values just stored
+    if (MODE == 1) {
+      float g3[3] = {0, 0, 0};
+      if (i < a.n) gs_pixel_scale(gsb, gf, g3);
+      block_sum<3>(g3, smg, part_gs + 3 * (size_t)blockIdx.x);
+    } else {
+      float g45[45];
+#pragma unroll
+      for (int k = 0; k < 45; k++) g45[k] = 0.f;
+      if (i < a.n) gs_pixel_pose(gsb, gf, g45);
       block_sum<45>(g45, smg, part_gs + 45 * (size_t)blockIdx.x);
     }
   }
@@ -973,3 +1004,5 @@ extern "C" int sos_tracker_calc_gs_scale(sos_tracker *T, int lvl, const float *t
   *b_out = (float)o[1] * (1.0f / n);
   return SOS_OK;
 }
+
+#include "sos_tracker_lm.inc"

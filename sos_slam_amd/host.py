@@ -76,6 +76,10 @@ def load():
     L.sosf_tracker_handle.argtypes = [vp]
     L.sosf_tracker_track.argtypes = [vp, ci, C.c_float, vp, vp, ci, vp, vp, vp, C.POINTER(ci)]
     L.sosf_write_poses.argtypes = [C.c_char_p, ci, vp, vp]
+    L.sosf_tracker_set_device_lm.argtypes = [vp, ci]
+    L.sosf_tracker_last_evals.argtypes = [vp, C.POINTER(ci)]
+    L.sosf_tracker_make_tries.argtypes = [vp, vp, vp, ci, ci, vp, C.POINTER(ci)]
+    L.sosf_tracker_track_hypotheses.argtypes = [vp, ci, C.c_float, ci, vp, vp, ci, vp, C.c_double, ci, vp, vp, vp, vp, vp]
     L.sosf_set_imu.argtypes = [vp, vp, vp, vp, vp, vp]
     L.sosf_get_imu_step.argtypes = [vp, vp, vp]
     L.sosf_tracker_set_points3d.argtypes = [vp, vp, C.c_float, ci, vp, vp]
@@ -468,6 +472,40 @@ class HostTracker:
         _chk(self.L.sosf_tracker_track(self.h_, newSlot, new_ab_exposure, _p(T), _p(aff), coarsest, _p(mr), _p(lr), _p(fl),
                                        C.byref(ok)), "sosf_tracker_track")
         return bool(ok.value), T, aff, lr, fl
+
+    def set_device_lm(self, on: bool):
+        """LM loop of track / pose_estimate as one device launch (default) or on the host around device residual passes."""
+        _chk(self.L.sosf_tracker_set_device_lm(self.h_, 1 if on else 0), "sosf_tracker_set_device_lm")
+
+    def last_evals(self) -> int:
+        n = C.c_int(0)
+        _chk(self.L.sosf_tracker_last_evals(self.h_, C.byref(n)), "sosf_tracker_last_evals")
+        return n.value
+
+    def make_tries(self, slast_2_sprelast12, lastF_2_slast12, imu12=None, poses_valid=True):
+        """The pose hypotheses of FullSystem::trackNewCoarse (FS/FullSystem.cpp:150-213) as an (n, 12) array."""
+        a = np.ascontiguousarray(slast_2_sprelast12, dtype=np.float64)
+        b = np.ascontiguousarray(lastF_2_slast12, dtype=np.float64)
+        im = None if imu12 is None else np.ascontiguousarray(imu12, dtype=np.float64)
+        out = np.zeros((96, 12))
+        n = C.c_int(0)
+        _chk(self.L.sosf_tracker_make_tries(_p(a), _p(b), None if im is None else _p(im), 1 if poses_valid else 0, 96, _p(out),
+                                            C.byref(n)), "sosf_tracker_make_tries")
+        return out[:n.value].copy()
+
+    def track_hypotheses(self, newSlot, new_ab_exposure, tries12, aff_last2, coarsest, last_coarse_rmse5, retrack_threshold=1.5,
+                         batch=16):
+        """FullSystem::trackNewCoarse's loop over the tries (FS/FullSystem.cpp:219-283)."""
+        tr = np.ascontiguousarray(tries12, dtype=np.float64).reshape(-1, 12)
+        af = np.ascontiguousarray(aff_last2, dtype=np.float64)
+        lc = np.ascontiguousarray(last_coarse_rmse5, dtype=np.float64)
+        T, aff, ach, fl = np.zeros(12), np.zeros(2), np.zeros(5), np.zeros(3)
+        info = np.zeros(4, dtype=np.int32)
+        _chk(self.L.sosf_tracker_track_hypotheses(self.h_, newSlot, new_ab_exposure, len(tr), _p(tr), _p(af), coarsest, _p(lc),
+                                                  float(retrack_threshold), batch, _p(T), _p(aff), _p(ach), _p(fl), _p(info)),
+             "sosf_tracker_track_hypotheses")
+        return dict(lastF_2_fh=T, aff=aff, achievedRes=ach, flow=fl, tryIterations=int(info[0]), chosen=int(info[1]),
+                    evaluated=int(info[2]), haveOneGood=bool(info[3]))
 
     def set_points3d(self, calib, matched_ab_exposure, xyz, colors):
         """PoseEstimator template (loop-closure aligner): xyz (n, 3), colors (levels, n)."""

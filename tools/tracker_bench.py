@@ -40,11 +40,28 @@ def timeit(fn, reps):
 
 
 t_set = timeit(lambda: ht.set_ref(), 20)
-t_trk = timeit(lambda: ht.track(new_slot, 1.0, Tinit, np.zeros(2), levels - 1), 20)
+t_trk = timeit(lambda: ht.track(new_slot, 1.0, Tinit, np.zeros(2), levels - 1), 50)   # device-resident LM loop (default)
+evals = ht.last_evals()
+ht.set_device_lm(False)
+t_trk_host = timeit(lambda: ht.track(new_slot, 1.0, Tinit, np.zeros(2), levels - 1), 20)  # LM loop on the host, one round trip per evaluation
+ht.set_device_lm(True)
+# hypothesis loop of trackNewCoarse: 83 tries that all have to be looked at (lastCoarseRMSE tiny -> no early exit), batched vs one by one
+kf, sl = win.frames[win.n - 1]["camToWorld"], win.extra_poses[0]
+from sos_slam_amd.synth import se3_inv12 as se3_inv  # noqa: E402
+tries = ht.make_tries(se3_mul(se3_inv(kf), sl), se3_mul(se3_inv(sl), kf))
+tiny = np.full(5, 1e-6)
+t_hyp16 = timeit(lambda: ht.track_hypotheses(st_slot, 1.0, tries, np.zeros(2), levels - 1, tiny, batch=16), 5)
+t_hyp1 = timeit(lambda: ht.track_hypotheses(st_slot, 1.0, tries, np.zeros(2), levels - 1, tiny, batch=1), 5)
+ht.set_device_lm(False)
+t_hyp_host = timeit(lambda: ht.track_hypotheses(st_slot, 1.0, tries, np.zeros(2), levels - 1, tiny, batch=1), 3)
+ht.set_device_lm(True)
 K1 = np.array(sysm.calib_value_scaled(), np.float32)
 t_scl = timeit(lambda: ht.optimize_scale(st_slot, win.stereo_tfm, K1, 1.2, levels - 1), 20)
 out = {"window": name, "template_pixels_per_level": [int(x) for x in pc_n[:levels]],
-       "gpu_ms": {"set_ref": t_set * 1e3, "track": t_trk * 1e3, "optimize_scale": t_scl * 1e3}}
+       "gpu_ms": {"set_ref": t_set * 1e3, "track": t_trk * 1e3, "track_host_loop": t_trk_host * 1e3, "optimize_scale": t_scl * 1e3,
+                  "track_83_hypotheses_batch16": t_hyp16 * 1e3, "track_83_hypotheses_batch1": t_hyp1 * 1e3,
+                  "track_83_hypotheses_host_loop": t_hyp_host * 1e3},
+       "residual_evaluations_per_track": evals, "us_per_evaluation": t_trk * 1e6 / max(evals, 1)}
 
 # oracle port on the host (single thread, as the reference's tracker is)
 ow = orc.window_from_synth(win)
