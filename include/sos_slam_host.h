@@ -294,6 +294,34 @@ int sosf_imu_solve(const sosf_imu_settings *S, const sosf_imu_calib *C, int n, c
 int sosf_imu_marginalize_frame(const sosf_imu_settings *S, const sosf_imu_calib *C, int n, const sosf_imu_frame *frames, int idx,
                                const double *delta, const double *prior8, const double *delta_prior8, double margWeightFac,
                                const double *HM, const double *bM, double *HM_out, double *bM_out);
+/* ---- VIO front-end around the assembly (FS/HessianBlocks.cpp:225-429; called from FullSystem::addActiveFrame :693-706,
+ * makeKeyFrame :806-882 and optimize, FS/FullSystemOptimize.cpp:462-478).  Host fp64.  sosf_imu_shell = the fields of
+ * FrameShell they touch; biases and spline coefficients live in sosf_imu_frame::state_imu (unscaled, 21). */
+typedef struct sosf_imu_shell {
+  double timestamp;
+  double camToWorld[12];   /* shell->camToWorld, R row-major | t */
+  double velInWorld[3];
+} sosf_imu_shell;
+/* FrameHessian::propagateImuState(last_shell, last_imu_bias, HCalib) (:357-404): gyroscope integration from the last
+ * shell's rotation, least-squares fit of the quadratic / cubic spline coefficients to the frame's IMU samples, then
+ * setImuStateScaled + setImuStateZero and the velocity.  last_imu_bias6 = the previous frame's imu_bias (scaled: ba, bg).
+ * The accelerometer fit has a zero design column (the linear term is carried by velInWorld); the reference relies on how
+ * Eigen's dynamic-size inverse treats the singular normal matrix, which is reproduced (see lu_inverse in sos_imu.cpp). */
+int sosf_imu_propagate_state(const sosf_imu_settings *S, const sosf_imu_calib *C, sosf_imu_frame *f, sosf_imu_shell *shell,
+                             const sosf_imu_shell *last_shell, const double *last_imu_bias6);
+/* FrameHessian::updateVel(last_shell) (:406-412) */
+int sosf_imu_update_vel(const sosf_imu_frame *f, sosf_imu_shell *shell, const sosf_imu_shell *last_shell);
+/* FrameHessian::initializeImu(frame_hessians, HCalib) (:253-355) on exactly five keyframes (frames[4] = the newest = the base
+ * frame; frames[i].camToWorld = PRE_camToWorld, shells[i] = its shell): cubic spline through the poses of frames 1..3,
+ * velocities and spline states of all five, gyroscope bias as the mean prediction error over the IMU samples of frames
+ * 2..4, and (unless setting_enable_scale_opt) the metric scale as a one-parameter least squares; *ok = 0 when that scale
+ * is negative ("IMU initialization failed").  Writes state_imu / state_imu_zero, velInWorld, calib->scale / scale_zero /
+ * imu_initialized. */
+int sosf_imu_initialize(const sosf_imu_settings *S, sosf_imu_calib *calib, sosf_imu_frame *frames5, sosf_imu_shell *shells5, int *ok);
+/* CalibHessian::tryTrapScale() (:414-429): scale_queue10 / scale_queue_i are the caller's copy of CalibHessian's ring
+ * (initially LinSpaced(10, -10, -100), index 0); thres = setting_scale_trap_thres */
+int sosf_imu_try_trap_scale(sosf_imu_calib *calib, double *scale_queue10, int32_t *scale_queue_i, double thres);
+
 /* Switches the facade's solveSystemF to the IMU branch (S != NULL) or back (S == NULL).  The records are caller-owned and
  * must outlive the system's iterations: frames[i] belongs to keyframe idx i (its camToWorld / evalPT_R are refreshed by
  * the facade before every solve; state_imu and calib->scale are stepped after it, as doStepFromBackup does with unit

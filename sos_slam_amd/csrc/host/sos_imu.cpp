@@ -565,3 +565,251 @@ extern "C" int sosf_imu_marginalize_frame(const sosf_imu_settings *S, const sosf
   }
   return SOS_OK;
 }
+
+// ================================================================================================
+// VIO front-end around the assembly (FS/HessianBlocks.cpp:225-429): the spline / bias / scale state of a frame before it
+// enters the window.  Host fp64, called once per frame (propagateImuState, updateVel), once per run (initializeImu) or
+// once per optimisation (tryTrapScale).
+// ================================================================================================
+namespace {
+// FS/HessianBlocks.h:84-89, 93: the *_INVERSE constants are float quotients widened to double
+const double kInvState[7] = {(double)(1.0f / 100.0f), (double)(1.0f / 1.0f), (double)(1.0f / 100.0f), (double)(1.0f / 1000.0f),
+                             (double)(1.0f / 1000.0f), (double)(1.0f / 1000.0f), (double)(1.0f / 1000.0f)};
+const double kScaleInv = (double)(1.0f / 200.0f);
+
+// setImuStateScaled(scaled) + setImuStateZero: state_imu = INVERSE * scaled, state_imu_zero = state_imu (the cached
+// per-sample Jacobians of setImuStateZero are recomputed by sosf_imu_hessian when needed)
+void store_scaled_state(sosf_imu_frame &f, const double *scaled) {
+  for (int s = 0; s < 7; s++)
+    for (int i = 0; i < 3; i++) f.state_imu[3 * s + i] = kInvState[s] * scaled[3 * s + i];
+  for (int i = 0; i < 21; i++) f.state_imu_zero[i] = f.state_imu[i];
+}
+void load_scaled_state(const sosf_imu_frame &f, double *scaled) {
+  const double k[7] = {kBa, kBg, kSlRot, kSqTrans, kSqRot, kScTrans, kScRot};
+  for (int s = 0; s < 7; s++)
+    for (int i = 0; i < 3; i++) scaled[3 * s + i] = k[s] * f.state_imu[3 * s + i];
+}
+
+// Eigen's inverse() of a DYNAMIC-size expression: PartialPivLU (unblocked for this size) and a solve against the identity.
+// A zero pivot is not divided by during the factorisation (Eigen/src/LU/PartialPivLU.h, partial_lu_impl::unblocked_lu)
+// but IS divided by in the back-substitution -- which is what makes propagateImuState work: the first column of its
+// accelerometer design matrix is identically zero, the 3 x 3 normal matrix is singular, and the rows of the "inverse"
+// that the function goes on to use (1 and 2) come out as the inverse of the regular 2 x 2 block, with inf / NaN
+// confined to row 0.
+void lu_inverse(const double *Ain, int n, double *inv) {
+  std::vector<double> lu(Ain, Ain + n * n);
+  std::vector<int> perm(n);
+  for (int i = 0; i < n; i++) perm[i] = i;
+  for (int k = 0; k < n; k++) {
+    int p = k;
+    double best = std::fabs(lu[k * n + k]);
+    for (int i = k + 1; i < n; i++)
+      if (std::fabs(lu[i * n + k]) > best) { best = std::fabs(lu[i * n + k]); p = i; }
+    if (best != 0.0) {
+      if (p != k) {
+        for (int j = 0; j < n; j++) std::swap(lu[k * n + j], lu[p * n + j]);
+        std::swap(perm[k], perm[p]);
+      }
+      for (int i = k + 1; i < n; i++) lu[i * n + k] /= lu[k * n + k];
+    }
+    for (int i = k + 1; i < n; i++)
+      for (int j = k + 1; j < n; j++) lu[i * n + j] -= lu[i * n + k] * lu[k * n + j];
+  }
+  for (int c = 0; c < n; c++) {
+    std::vector<double> y(n);
+    for (int i = 0; i < n; i++) y[i] = perm[i] == c ? 1.0 : 0.0;
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < i; j++) y[i] -= lu[i * n + j] * y[j];
+    for (int i = n - 1; i >= 0; i--) {
+      for (int j = i + 1; j < n; j++) y[i] -= lu[i * n + j] * y[j];
+      y[i] /= lu[i * n + i];
+    }
+    for (int i = 0; i < n; i++) inv[i * n + c] = y[i];
+  }
+}
+// x (3 x 3) = inverse(A^T A) * (A^T B) for an m x 3 design matrix A and m x 3 right-hand sides B
+void normal_solve3(const std::vector<double> &A, const std::vector<double> &B, int m, double *x) {
+  double M[9] = {0}, R[9] = {0}, Mi[9];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) {
+      double s = 0, q = 0;
+      for (int i = 0; i < m; i++) {
+        s += A[3 * i + r] * A[3 * i + c];
+        q += A[3 * i + r] * B[3 * i + c];
+      }
+      M[3 * r + c] = s;
+      R[3 * r + c] = q;
+    }
+  lu_inverse(M, 3, Mi);
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) x[3 * r + c] = Mi[3 * r] * R[c] + Mi[3 * r + 1] * R[3 + c] + Mi[3 * r + 2] * R[6 + c];
+}
+// fixed-size Mat33::inverse(): cofactors and one reciprocal of the determinant (Eigen/src/LU/InverseImpl.h, size 3)
+void inverse3_cofactor(const double *m, double *r) {
+  const double c00 = m[4] * m[8] - m[5] * m[7], c10 = m[5] * m[6] - m[3] * m[8], c20 = m[3] * m[7] - m[4] * m[6];
+  const double det = c00 * m[0] + c10 * m[1] + c20 * m[2];
+  const double id = 1.0 / det;
+  r[0] = c00 * id; r[3] = c10 * id; r[6] = c20 * id;
+  r[1] = (m[2] * m[7] - m[1] * m[8]) * id; r[4] = (m[0] * m[8] - m[2] * m[6]) * id; r[7] = (m[1] * m[6] - m[0] * m[7]) * id;
+  r[2] = (m[1] * m[5] - m[2] * m[4]) * id; r[5] = (m[2] * m[3] - m[0] * m[5]) * id; r[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+}  // namespace
+
+extern "C" int sosf_imu_propagate_state(const sosf_imu_settings *S, const sosf_imu_calib *C, sosf_imu_frame *f, sosf_imu_shell *shell,
+                                        const sosf_imu_shell *last_shell, const double *last_imu_bias6) {
+  if (!S || !C || !f || !shell || !last_shell || !last_imu_bias6 || (f->n_imu > 0 && !f->imu)) return SOS_ERR_ARG;
+  double sc[21];
+  load_scaled_state(*f, sc);
+  for (int i = 0; i < 6; i++) sc[i] = last_imu_bias6[i];  // imu_bias = last_imu_bias
+  const int m = f->n_imu;
+  double imu_ts = last_shell->timestamp;
+  M3 R = M3::from(last_shell->camToWorld);
+  const M3 RicT = M3::from(S->rot_imu_cam).T();
+  const double scale_scaled = C->scale * kScale;
+  std::vector<double> Aa(3 * (size_t)m, 0.0), ba(3 * (size_t)m), Ag(3 * (size_t)m), bg(3 * (size_t)m);
+  for (int i = 0; i < m; i++) {
+    const double *d = f->imu + 7 * (size_t)i;
+    const double dt = d[0] - imu_ts;
+    if (!(dt >= 0)) return SOS_ERR_ARG;  // assert(dt >= 0)
+    imu_ts = d[0];
+    const double t = d[0] - shell->timestamp;
+    const V3 ua{{d[1] - sc[0], d[2] - sc[1], d[3] - sc[2]}}, ug{{d[4] - sc[3], d[5] - sc[4], d[6] - sc[5]}};
+    R = R * so3_exp(V3{{ug[0] * dt, ug[1] * dt, ug[2] * dt}});  // integrate the gyroscope
+    Aa[3 * i] = 0; Aa[3 * i + 1] = 2 * scale_scaled; Aa[3 * i + 2] = 6 * t * scale_scaled;
+    const V3 aw = (R * RicT) * ua;
+    for (int k = 0; k < 3; k++) ba[3 * i + k] = aw[k] - S->gravity[k];
+    Ag[3 * i] = 1; Ag[3 * i + 1] = 2 * t; Ag[3 * i + 2] = 3 * t * t;
+    const V3 gw = RicT * ug;
+    for (int k = 0; k < 3; k++) bg[3 * i + k] = gw[k];
+  }
+  double xa[9], xg[9];
+  normal_solve3(Aa, ba, m, xa);
+  normal_solve3(Ag, bg, m, xg);
+  for (int k = 0; k < 3; k++) {
+    sc[9 + k] = xa[3 + k];   // spline_q.head(3) = xa.row(1)
+    sc[15 + k] = xa[6 + k];  // spline_c.head(3) = xa.row(2)
+    sc[6 + k] = xg[k];       // spline_l_rot = xg.row(0)
+    sc[12 + k] = xg[3 + k];  // spline_q.tail(3)
+    sc[18 + k] = xg[6 + k];  // spline_c.tail(3)
+  }
+  store_scaled_state(*f, sc);
+  const double t = last_shell->timestamp - shell->timestamp;
+  for (int k = 0; k < 3; k++) shell->velInWorld[k] = last_shell->velInWorld[k] - (2 * t * sc[9 + k] + 3 * t * t * sc[15 + k]);
+  return SOS_OK;
+}
+
+extern "C" int sosf_imu_update_vel(const sosf_imu_frame *f, sosf_imu_shell *shell, const sosf_imu_shell *last_shell) {
+  if (!f || !shell || !last_shell) return SOS_ERR_ARG;
+  const double t = last_shell->timestamp - shell->timestamp;
+  for (int k = 0; k < 3; k++) {
+    const double q = kSqTrans * f->state_imu[9 + k];
+    shell->velInWorld[k] = (last_shell->camToWorld[9 + k] - shell->camToWorld[9 + k]) / t - t * q - t * t * q;  // (sic) spline_q twice, :411
+  }
+  return SOS_OK;
+}
+
+extern "C" int sosf_imu_initialize(const sosf_imu_settings *S, sosf_imu_calib *C, sosf_imu_frame *F, sosf_imu_shell *sh, int *ok) {
+  if (!S || !C || !F || !sh || !ok) return SOS_ERR_ARG;
+  *ok = 0;
+  const int B = 4;  // base_frame = frame_hessians.back()
+  double A[9], b[18];
+  const SE3 baseInv = SE3::from12(sh[B].camToWorld).inverse();
+  for (int i = 0; i < 3; i++) {
+    const int cur = i + 1;
+    A[3 * i] = sh[cur].timestamp - sh[B].timestamp;
+    A[3 * i + 1] = A[3 * i] * A[3 * i];
+    A[3 * i + 2] = A[3 * i + 1] * A[3 * i];
+    double lg[6];
+    (baseInv * SE3::from12(sh[cur].camToWorld)).log(lg);
+    for (int k = 0; k < 3; k++) {
+      b[6 * i + k] = sh[cur].camToWorld[9 + k] - sh[B].camToWorld[9 + k];
+      b[6 * i + 3 + k] = lg[3 + k];
+    }
+  }
+  double Ai[9], x[18];
+  inverse3_cofactor(A, Ai);
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 6; c++) x[6 * r + c] = Ai[3 * r] * b[c] + Ai[3 * r + 1] * b[6 + c] + Ai[3 * r + 2] * b[12 + c];
+  const double *l0 = x, *q0 = x + 6, *c0 = x + 12;
+  double sc[5][21];
+  for (int fidx = 0; fidx < 5; fidx++) {
+    load_scaled_state(F[fidx], sc[fidx]);
+    const double t0 = sh[fidx].timestamp - sh[B].timestamp;
+    for (int k = 0; k < 6; k++) {
+      const double vel = l0[k] + 2 * q0[k] * t0 + 3 * c0[k] * t0 * t0;
+      if (k < 3) sh[fidx].velInWorld[k] = vel;
+      else sc[fidx][6 + (k - 3)] = vel;                        // spline_l_rot
+      sc[fidx][9 + k] = q0[k] + 3 * c0[k] * t0;                 // spline_q
+      sc[fidx][15 + k] = c0[k];                                 // spline_c
+    }
+  }
+  size_t total = 0;
+  for (int i = 2; i < 5; i++) total += (size_t)F[i].n_imu;
+  // gyro bias: mean of measurement - prediction over the samples of frames 2..4
+  const M3 Ric = M3::from(S->rot_imu_cam);
+  const double *bs = sc[B];
+  double gb[3] = {0, 0, 0};
+  for (int i = 2; i < 5; i++)
+    for (int j = 0; j < F[i].n_imu; j++) {
+      const double *d = F[i].imu + 7 * (size_t)j;
+      const double t = d[0] - sh[B].timestamp;
+      V3 g;
+      for (int k = 0; k < 3; k++) g[k] = bs[6 + k] + (2 * t * bs[12 + k] + 3 * t * t * bs[18 + k]);
+      const V3 pred = Ric * g;
+      for (int k = 0; k < 3; k++) gb[k] += d[4 + k] - pred[k];
+    }
+  for (int k = 0; k < 3; k++) gb[k] /= (double)total;
+  for (int fidx = 0; fidx < 5; fidx++)
+    for (int k = 0; k < 3; k++) sc[fidx][3 + k] = gb[k];
+  // scale (accelerometer bias stays zero): one-parameter least squares of measured against predicted acceleration
+  double scale = C->scale * kScale;
+  if (!S->enable_scale_opt) {
+    const M3 Rw2c = M3::from(F[B].camToWorld).T();  // PRE_worldToCam.rotationMatrix()
+    double ab = 0, aa = 0;
+    for (int i = 2; i < 5; i++)
+      for (int j = 0; j < F[i].n_imu; j++) {
+        const double *d = F[i].imu + 7 * (size_t)j;
+        const double t = d[0] - sh[B].timestamp, t2 = t * t;
+        V3 w, acc;
+        for (int k = 0; k < 3; k++) {
+          w[k] = t * bs[6 + k] + (t2 * bs[12 + k] + t * t2 * bs[18 + k]);
+          acc[k] = 2 * bs[9 + k] + 6 * t * bs[15 + k];
+        }
+        const M3 rot_ti_w = (Ric * so3_exp(w).T()) * Rw2c;
+        const V3 pred = rot_ti_w * acc, gr = rot_ti_w * V3{{S->gravity[0], S->gravity[1], S->gravity[2]}};
+        for (int k = 0; k < 3; k++) {
+          ab += pred[k] * (d[1 + k] - gr[k]);
+          aa += pred[k] * pred[k];
+        }
+      }
+    scale = ab / aa;
+    C->scale = kScaleInv * scale;  // setScaleScaledZero
+    C->scale_zero = C->scale;
+  }
+  if (scale < 0) return SOS_OK;  // "IMU initialization failed": the spline / velocity fields stay as computed, as in the reference
+  for (int fidx = 0; fidx < 5; fidx++) {
+    for (int k = 0; k < 3; k++) sc[fidx][k] = 0.0;
+    store_scaled_state(F[fidx], sc[fidx]);
+  }
+  C->imu_initialized = 1;
+  *ok = 1;
+  return SOS_OK;
+}
+
+extern "C" int sosf_imu_try_trap_scale(sosf_imu_calib *C, double *scale_queue10, int32_t *scale_queue_i, double thres) {
+  if (!C || !scale_queue10 || !scale_queue_i || *scale_queue_i < 0 || *scale_queue_i > 9) return SOS_ERR_ARG;
+  C->scale_zero = C->scale;
+  scale_queue10[*scale_queue_i] = C->scale;
+  *scale_queue_i = (*scale_queue_i + 1) % 10;
+  double mean = 0;
+  for (int i = 0; i < 10; i++) mean += scale_queue10[i];
+  mean /= 10.0;
+  double sq = 0;
+  for (int i = 0; i < 10; i++) sq += (scale_queue10[i] - mean) * (scale_queue10[i] - mean);
+  const double var = 1.0 / 9.0 * kScale * kScale * sq;
+  if (var < thres) {
+    C->scale_trapped = 1;
+    C->scale_zero = mean;
+  }
+  return SOS_OK;
+}

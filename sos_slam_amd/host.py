@@ -595,6 +595,39 @@ class _ImuApi:
         return x, ss.value, si
 
 
+class ImuFrontEnd:
+    """The VIO front-end functions of the facade (sosf_imu_propagate_state / update_vel / initialize / try_trap_scale)."""
+
+    def __init__(self):
+        self.L = load()
+        vp = C.c_void_p
+        self.L.sosf_imu_propagate_state.argtypes = [vp, vp, vp, vp, vp, vp]
+        self.L.sosf_imu_update_vel.argtypes = [vp, vp, vp]
+        self.L.sosf_imu_initialize.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_int)]
+        self.L.sosf_imu_try_trap_scale.argtypes = [vp, vp, C.POINTER(C.c_int32), C.c_double]
+
+    def propagate_state(self, S, Cal, frame, shell, last_shell, last_bias6):
+        lb = np.ascontiguousarray(last_bias6, dtype=np.float64)
+        _chk(self.L.sosf_imu_propagate_state(C.byref(S), C.byref(Cal), C.byref(frame), C.byref(shell), C.byref(last_shell), _p(lb)),
+             "sosf_imu_propagate_state")
+
+    def update_vel(self, frame, shell, last_shell):
+        _chk(self.L.sosf_imu_update_vel(C.byref(frame), C.byref(shell), C.byref(last_shell)), "sosf_imu_update_vel")
+
+    def initialize(self, S, Cal, frames5, shells5):
+        from sos_slam_amd.records import ImuFrame, ImuShell
+        fa, sa = (ImuFrame * 5)(*frames5), (ImuShell * 5)(*shells5)
+        ok = C.c_int(0)
+        _chk(self.L.sosf_imu_initialize(C.byref(S), C.byref(Cal), fa, sa, C.byref(ok)), "sosf_imu_initialize")
+        return bool(ok.value), list(fa), list(sa)
+
+    def try_trap_scale(self, Cal, queue10, qi, thres):
+        q = np.ascontiguousarray(queue10, dtype=np.float64).copy()
+        i = C.c_int32(qi)
+        _chk(self.L.sosf_imu_try_trap_scale(C.byref(Cal), _p(q), C.byref(i), thres), "sosf_imu_try_trap_scale")
+        return q, i.value
+
+
 def imu():
     """The facade's IMU / spline factor assembly (sosf_imu_*)."""
     return _ImuApi(load(), "sosf_imu_")

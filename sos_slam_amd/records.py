@@ -132,5 +132,10 @@ class ImuFrame(C.Structure):
                 ("n_imu", C.c_int32), ("imu", C.c_void_p)]
 
 
+class ImuShell(C.Structure):
+    """sosf_imu_shell: the FrameShell fields the VIO front-end touches."""
+    _fields_ = [("timestamp", C.c_double), ("camToWorld", C.c_double * 12), ("velInWorld", C.c_double * 3)]
+
+
 def imu_dim(n):
     return 4 + 1 + 29 * n
