@@ -36,14 +36,21 @@ def global_nth(dist, local: np.ndarray, frac: float) -> float:
     return float(np.partition(allv, k)[k])
 
 
-def attach(sysm, dist, torch):
-    """Install the all-reduce / order-statistic hooks of a host.System for a multi-rank run."""
-    from . import host
+def make_hooks(dist, torch):
+    """The three exchange callbacks of a multi-rank run as ctypes function objects (AR_FN, NTH_FN, AR64_FN):
+    all-reduce of the packed fp32 accumulator (a DEVICE pointer with the nccl backend; with gloo -- CPU tests -- the pointer is
+    host memory), the global order statistic of setNewFrameEnergyTH, and the all-reduce of the keyframe-rate fp64 sums."""
+    on_gpu = dist.get_backend() == "nccl"
 
     def _ar(user, ptr, n):
-        t = torch.as_tensor(_DevView(ptr, n), device="cuda")
-        dist.all_reduce(t)
-        torch.cuda.synchronize()
+        if on_gpu:
+            t = torch.as_tensor(_DevView(ptr, n), device="cuda")
+            dist.all_reduce(t)
+            torch.cuda.synchronize()
+        else:
+            buf = np.ctypeslib.as_array((C.c_float * n).from_address(ptr))
+            t = torch.from_numpy(buf)  # shares the memory: summed in place
+            dist.all_reduce(t)
 
     def _nth(user, ptr, count, frac):
         local = np.ctypeslib.as_array(ptr, shape=(count,)).copy() if count > 0 else np.zeros(0, np.float32)
@@ -52,16 +59,20 @@ def attach(sysm, dist, torch):
     def _ar64(user, ptr, n):
         # keyframe-rate fp64 sums (marginalisation prior update, mean |idepth| of the termination test): host buffer
         buf = np.ctypeslib.as_array(ptr, shape=(n,))
-        on_gpu = dist.get_backend() == "nccl"
         t = torch.from_numpy(buf.copy())
         if on_gpu:
             t = t.cuda()
         dist.all_reduce(t)
         buf[:] = t.cpu().numpy()
 
-    sysm._ar_cb = AR_FN(_ar)  # keep the callbacks alive
-    sysm._nth_cb = NTH_FN(_nth)
-    sysm._ar64_cb = AR64_FN(_ar64)
+    return AR_FN(_ar), NTH_FN(_nth), AR64_FN(_ar64)
+
+
+def attach(sysm, dist, torch):
+    """Install the all-reduce / order-statistic hooks of a host.System for a multi-rank run."""
+    from . import host
+
+    sysm._ar_cb, sysm._nth_cb, sysm._ar64_cb = make_hooks(dist, torch)  # the system keeps the callbacks alive
     L = host.load()
     L.sosf_set_hooks.argtypes = [C.c_void_p, AR_FN, NTH_FN, C.c_void_p]
     rc = L.sosf_set_hooks(sysm.h_, sysm._ar_cb, sysm._nth_cb, None)

@@ -95,3 +95,78 @@ def test_shards_partition_the_window():
         assert max(counts) - min(counts) <= win.R / world * 0.25  # balanced by residual count
         sh = synth.take_shard(win, idx[1])
         assert np.all(np.diff(sh.resid["point"]) >= 0) and sh.resid["point"].max() == sh.P - 1
+
+
+def _hook_worker(rank, port, q):
+    """Drives sos_slam_amd.distributed's exchange callbacks the way the facade does -- through their ctypes signatures, with raw
+    pointers -- around the oracle's shard-local accumulation: one GN iteration's exchange (packed fp32 accumulator, newest-frame
+    order statistic) and the keyframe-rate fp64 sums of a marginalisation."""
+    import ctypes as C
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    ar, nth, ar64 = sdist.make_hooks(dist, torch)
+    win = synth.make_window("T4")
+    shard = synth.take_shard(win, synth.shard_points(win, rank, WORLD))
+    ow = orc.window_from_synth(shard)
+    th = np.full(win.n, 512.0, np.float32)
+    ow.reset_oob()
+    E = ow.linearize(th)
+    ow.apply_res()
+    acc = ow.accumulate()
+    # (1) the packed fp32 accumulator, as sos_ba_acc_buffer exposes it: summed in place through the callback
+    packed = np.ascontiguousarray(np.concatenate([acc[k].reshape(-1) for k in ("H_A", "b_A", "H_sc", "b_sc")]), dtype=np.float32)
+    ar(None, packed.ctypes.data, packed.size)
+    # (2) the order statistic of setNewFrameEnergyTH over all ranks' newest-frame energies
+    res = ow.res()
+    wo = ow.new_energy_wo()
+    local = np.ascontiguousarray(wo[(res["target"] == win.n - 1) & (wo >= 0)], dtype=np.float32)
+    v = nth(None, local.ctypes.data_as(C.POINTER(C.c_float)), len(local), 0.7)
+    # (3) keyframe-rate fp64 sums: shard-local marginalisation accumulators + the count
+    m = np.ascontiguousarray(np.concatenate([acc["H_A"].reshape(-1)[:64].astype(np.float64), [float(shard.R), float(E)]]))
+    ar64(None, m.ctypes.data_as(C.POINTER(C.c_double)), m.size)
+    if rank == 0:
+        q.put((packed.copy(), float(v), m.copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_hooks_end_to_end():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hook_worker, args=(r, port, q)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    packed, v, m = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    win = synth.make_window("T4")
+    parts, Es, Rs, heads, energies = [], [], [], [], []
+    for r in range(WORLD):
+        shard = synth.take_shard(win, synth.shard_points(win, r, WORLD))
+        ow = orc.window_from_synth(shard)
+        th = np.full(win.n, 512.0, np.float32)
+        ow.reset_oob()
+        Es.append(ow.linearize(th))
+        ow.apply_res()
+        acc = ow.accumulate()
+        parts.append(np.concatenate([acc[k].reshape(-1) for k in ("H_A", "b_A", "H_sc", "b_sc")]).astype(np.float32))
+        heads.append(acc["H_A"].reshape(-1)[:64].astype(np.float64))
+        Rs.append(shard.R)
+        res, wo = ow.res(), ow.new_energy_wo()
+        energies.append(wo[(res["target"] == win.n - 1) & (wo >= 0)])
+    assert np.array_equal(packed, parts[0] + parts[1])                      # fp32 sum of two addends: exact either way
+    allv = np.sort(np.concatenate(energies))
+    assert v == float(allv[int(0.7 * len(allv))])
+    assert np.array_equal(m[:64], heads[0] + heads[1])
+    assert m[64] == win.R and m[65] == pytest.approx(Es[0] + Es[1], rel=1e-15)
+    # and against the unsharded window: the exchanged system is the whole window's system
+    ow = orc.window_from_synth(win)
+    ow.reset_oob()
+    ow.linearize(np.full(win.n, 512.0, np.float32))
+    ow.apply_res()
+    acc = ow.accumulate(fp64_truth=True)
+    ref = np.concatenate([acc[k].reshape(-1) for k in ("H_A", "b_A", "H_sc", "b_sc")])
+    assert np.abs(packed - ref).max() <= 2e-5 * np.abs(ref).max()
