@@ -503,10 +503,10 @@ __device__ __forceinline__ void fused_final_sum(const FuseSum &fs, const float *
 }
 // one template pixel of calcRes: v = (E, numTermsInE, numWarped, numSaturated, flowT, flowRT, flowNum, -), gsb = this pixel's
 // warp-buffer entries as the reference stores them (zero weight for dropped pixels)
+// (x, y, id, refColor) = the template pixel's record (pc_u, pc_v, pc_idepth, pc_color; MODE 2: a 3-D point, id holds z)
 template <int MODE>
-__device__ __forceinline__ void res_pixel(const ResArgs &a, int i, float *v, float *gsb) {
+__device__ __forceinline__ void res_pixel(const ResArgs &a, int i, float x, float y, float id, float refColor, float *v, float *gsb) {
   {
-    const float id = a.pid[i], x = a.pu[i], y = a.pv[i];  // MODE 2: id holds z
     float pt0, pt1, pt2;
     if (MODE == 2) {  // pt = R (x, y, z) + t, src/LoopClosure/PoseEstimator.cpp:181-183
       pt0 = a.M[0] * x + a.M[1] * y + a.M[2] * id + a.t[0];
@@ -567,7 +567,6 @@ __device__ __forceinline__ void res_pixel(const ResArgs &a, int i, float *v, flo
     float b3 = 0, b4 = 0, b5 = 0, b6 = 0, b7 = 0;
     bool warped = false;
     if (Ku > 2 && Kv > 2 && Ku < (float)(a.wl - 3) && Kv < (float)(a.hl - 3) && new_idepth > 0) {
-      const float refColor = a.pcol[i];
       int ix = (int)Ku, iy = (int)Kv;
       const float fdx = Ku - (float)ix, fdy = Kv - (float)iy, dxdy = fdx * fdy;
       const float *bp = a.dINew + 3 * (ix + iy * a.wl);
@@ -651,7 +650,7 @@ __global__ __launch_bounds__(256) void k_calc_res(ResArgs a, float *__restrict__
   const int i = blockIdx.x * 256 + threadIdx.x;
   float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (i < a.n) {
-    res_pixel<MODE>(a, i, v, gsb);
+    res_pixel<MODE>(a, i, a.pu[i], a.pv[i], a.pid[i], a.pcol[i], v, gsb);
 #pragma unroll
     for (int k = 0; k < 8; k++) a.buf[k][i] = gsb[k];
   }
