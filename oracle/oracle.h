@@ -94,6 +94,10 @@ void orc_host_get_evalpt(orc_window *W, int frame, double *camToWorld_evalPT12);
 int32_t *orc_num_good_residuals(orc_window *W);
 /* optimize() with setting_forceAceptStep selectable (FS/FullSystemOptimize.cpp:387-413: loadSateBackup on a rejected step) */
 float orc_optimize_ex(orc_window *W, int mnumOptIts, int nthreads, int forceAccept, int *iterations_out, int *rejected_out);
+/* switches solveSystemF of the host loop to the IMU branch (OB/EnergyFunctional.cpp:1053-1171 via orc_imu_solve): S, C, frames are
+ * sosf_imu_settings / sosf_imu_calib / sosf_imu_frame[n] owned by the caller (poses refreshed before every solve, scale and
+ * state_imu stepped after it with unit step factors), HM / bM the prior in the expanded dimension.  S = NULL switches back. */
+void orc_host_set_imu(orc_window *W, const void *S, void *C, void *frames, const double *HM, const double *bM);
 /* runs optimize(mnumOptIts); returns RMSE; fills iteration count */
 float orc_optimize(orc_window *W, int mnumOptIts, int nthreads, int *iterations_out);
 /* one loop body of FS/FullSystemOptimize.cpp:358-413 (used by the CPU-baseline timing) */

@@ -472,6 +472,25 @@ class OracleWindow:
         rmse = self.L.orc_optimize_ex(self.h, iters, nthreads, int(force_accept), C.byref(it), C.byref(rej))
         return rmse, it.value, rej.value
 
+    def set_imu(self, S=None, cal=None, frames=None, HM=None, bM=None):
+        """IMU branch of the host loop's solveSystemF (orc_host_set_imu); records as in sos_slam_amd.records, kept alive here."""
+        self.L.orc_host_set_imu.argtypes = [C.c_void_p] * 6
+        self.L.orc_host_set_imu.restype = None
+        if S is None:
+            self._imu = None
+            self.L.orc_host_set_imu(self.h, None, None, None, None, None)
+            return
+        from sos_slam_amd.records import ImuFrame
+        arr = (ImuFrame * len(frames))(*frames)
+        hm = np.ascontiguousarray(HM, dtype=np.float64)
+        bm = np.ascontiguousarray(bM, dtype=np.float64)
+        self._imu = (S, cal, arr, hm, bm)
+        self.L.orc_host_set_imu(self.h, C.addressof(S), C.addressof(cal), C.addressof(arr), _p(hm), _p(bm))
+
+    def imu_state(self):
+        S, cal, arr, _, _ = self._imu
+        return cal.scale, np.array([list(f.state_imu) for f in arr])
+
     def num_good_residuals(self):
         return _view(self.L.orc_num_good_residuals(self.h), np.int32, (self.P,))
 

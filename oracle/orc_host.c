@@ -13,6 +13,12 @@
  *   AffLight::fromToVecExposure                               util/NumType.h:149-171
  */
 #include "orc_internal.h"
+#include "../include/sos_slam_host.h"
+
+/* orc_imu.c */
+int orc_imu_solve(const sosf_imu_settings *S, const sosf_imu_calib *C, int n, const sosf_imu_frame *F, const double *H_top,
+                  const double *b_top, const double *H_sc, const double *b_sc, const double *HM, const double *bM, const double *delta,
+                  double lambda, double *x_out, double *scale_step, double *step_imu);
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -372,6 +378,33 @@ static void solve_system(orc_window *W, int nthreads) {
   for (int i = 0; i < 4; i++) delta[i] = (double)W->cDeltaF[i];
   for (int h = 0; h < n; h++)
     for (int i = 0; i < 8; i++) delta[4 + 8 * h + i] = W->hf[h].delta[i];
+  if (W->imuS) { /* setting_enable_imu && imu_initialized: :1053-1171 through the restatement in orc_imu.c */
+    const sosf_imu_settings *S = (const sosf_imu_settings *)W->imuS;
+    sosf_imu_calib *C = (sosf_imu_calib *)W->imuC;
+    sosf_imu_frame *F = (sosf_imu_frame *)W->imuF;
+    for (int h = 0; h < n; h++) {
+      memcpy(F[h].camToWorld, W->hf[h].PRE_camToWorld.R, sizeof(double) * 9);
+      memcpy(F[h].camToWorld + 9, W->hf[h].PRE_camToWorld.t, sizeof(double) * 3);
+      memcpy(F[h].evalPT_R, W->hf[h].camToWorld_evalPT.R, sizeof(double) * 9);
+    }
+    double *x = (double *)malloc(sizeof(double) * dim);
+    free(W->imuStep);
+    W->imuStep = (double *)calloc((size_t)21 * n, sizeof(double));
+    orc_imu_solve(S, C, n, F, H, b, Hsc, bsc, W->imuHM, W->imuBM, delta, lambda, x, &W->imuScaleStep, W->imuStep);
+    memcpy(W->lastX, x, sizeof(double) * dim);
+    for (int i = 0; i < 4; i++) W->c_step[i] = -x[i];
+    for (int h = 0; h < n; h++) {
+      for (int i = 0; i < 8; i++) W->hf[h].step[i] = -x[4 + 8 * h + i];
+      W->hf[h].step[8] = W->hf[h].step[9] = 0;
+    }
+    /* IMU and scale update of doStepFromBackup with unit step factors, FS/FullSystemOptimize.cpp:218-230 */
+    C->scale += W->imuScaleStep;
+    for (int h = 0; h < n; h++)
+      for (int k = 0; k < 21; k++) F[h].state_imu[k] += W->imuStep[(size_t)21 * h + k];
+    orc_resubstitute(W, x, 0, nthreads);
+    free(HA); free(HL); free(Hsc); free(bA); free(bL); free(bsc); free(H); free(b); free(delta); free(x);
+    return;
+  }
   for (int i = 0; i < dim; i++) {
     double s = W->bM[i];
     for (int j = 0; j < dim; j++) s += W->HM[(size_t)i * dim + j] * delta[j];
@@ -400,6 +433,10 @@ static void solve_system(orc_window *W, int nthreads) {
   }
   orc_resubstitute(W, x, 0, nthreads);
   free(HA); free(HL); free(Hsc); free(bA); free(bL); free(bsc); free(H); free(b); free(delta); free(S); free(x);
+}
+
+void orc_host_set_imu(orc_window *W, const void *S, void *C, void *frames, const double *HM, const double *bM) {
+  W->imuS = S; W->imuC = C; W->imuF = frames; W->imuHM = HM; W->imuBM = bM;
 }
 
 static void backup_state(orc_window *W) { /* :260-269 */

@@ -44,6 +44,9 @@ struct orc_window {
   double c_value[4], c_value_zero[4], c_value_scaled[4], c_step[4], c_value_backup[4],
       c_value_minus_value_zero[4];
   double *HM, *bM, *lastX;
+  /* IMU branch of solveSystemF (orc_host_set_imu): caller-owned records, the prior in the expanded dimension */
+  const void *imuS; void *imuC; void *imuF; const double *imuHM, *imuBM;
+  double imuScaleStep; double *imuStep;
   int resInA, resInL;
   int truth_mode; /* 1: the GN loop accumulates H/b in fp64 (not the reference's behaviour; error yardstick) */
 };

@@ -147,3 +147,52 @@ def test_imu_branch_step_equals_oracle_solve_on_device_system(name, trapped):
     assert np.abs(st_g - st_o).max() <= 1e-7 * max(np.abs(st_o).max(), 1e-12)
     assert np.abs(st_o).max() > 0 and ss_o != 0
     sysm.close()
+
+
+@pytest.mark.parametrize("name,trapped", [("T6", 1), ("T6", 0), ("W7", 1)])
+def test_optimize_with_imu_matches_oracle_loop(name, trapped):
+    """Six Gauss-Newton iterations with the IMU branch on both sides: the facade's loop on the device's H / b against the
+    oracle's host loop (orc_optimize with orc_host_set_imu).  The IMU factors couple poses, scale and the 21 IMU states of
+    every keyframe, so this exercises the assembly at a moving linearisation point (poses of every solve, stepped states)."""
+    from sos_slam_amd import host
+    win = synth.make_window(name)
+    n = win.n
+    d0, dI = 4 + 8 * n, imu_dim(n)
+    idx = np.array([k if k < 4 else 5 + 29 * ((k - 4) // 8) + (k - 4) % 8 for k in range(d0)])
+    HMi, bMi = np.zeros((dI, dI)), np.zeros(dI)
+    HMi[np.ix_(idx, idx)] = win.HM
+    bMi[idx] = win.bM
+    HMi += np.eye(dI) * 1e-3
+    from tests import helpers as hp
+    out = {}
+    for side in ("device", "oracle", "truth"):
+        S, cal, frames, keep = _records(win)
+        cal.scale_trapped = trapped
+        if side == "device":
+            sysm = host.System.from_window(win)
+            sysm.set_imu(S, cal, frames, HMi, bMi)
+            rm, it = sysm.optimize(6)
+            _, _, st, scale = sysm.imu_state()
+            poses = np.array([sysm.frame(f)["camToWorld"] for f in range(n)])
+            sysm.close()
+        else:
+            ow = hp.oracle_window(win)
+            ow.set_truth_mode(side == "truth")
+            ow.set_imu(S, cal, frames, HMi, bMi)
+            rm, it = ow.optimize(6, nthreads=1)
+            scale, st = ow.imu_state()
+            poses = np.array([ow.frame(f)["camToWorld"] for f in range(n)])
+            ow.close()
+        out[side] = (rm, it, poses, scale, st)
+    (rg, ig, pg, sg, stg), (ro, io, po, so, sto), (rt, itt, pt, stt_, stt) = out["device"], out["oracle"], out["truth"]
+    e_go, e_gt, e_ot = np.abs(pg - po).max(), np.abs(pg - pt).max(), np.abs(po - pt).max()
+    print(f"{name} trapped={trapped}: iterations {ig}/{io}, pose device-oracle {e_go:.3g} device-truth {e_gt:.3g} oracle-truth {e_ot:.3g}; "
+          f"scale {sg:.9g} / {so:.9g}; max |state_imu| {np.abs(stg).max():.3g}")
+    assert ig == io
+    assert abs(rg - ro) <= 1e-5 * abs(ro)
+    assert e_go < max(1e-5, 3 * e_ot)
+    assert e_gt < max(1e-5, 2 * e_ot)
+    assert abs(sg - so) <= max(1e-7 * abs(so), 3 * abs(so - stt_))
+    sc = max(np.abs(sto).max(), 1e-12)
+    assert np.abs(stg - sto).max() <= max(1e-5 * sc, 3 * np.abs(sto - stt).max())
+    assert sg != 1.0 / 200 and np.abs(stg).max() > 2e-4            # the IMU states did move
