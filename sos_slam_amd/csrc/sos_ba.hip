@@ -1735,17 +1735,31 @@ __device__ __forceinline__ void stitch_top_sum_body(int bx, int by, int n, const
     double sH = 0, sHc = 0, sb = 0;
     // fixed order: pairs (a,t) t = 0..n-1 (host side), then pairs (h,a) h = 0..n-1 (target side; (a,a) is empty)
     const int hc = tid & 31, bc_ = tid & 7;
-#pragma unroll 4
-    for (int t = 0; t < n; t++) {
-      const double *c = Cm + (size_t)(a + n * t) * SOS_TOPC;
-      const double v0 = c[tid], v1 = c[192 + hc], v2 = c[256 + bc_];
-      sH += v0; sHc += v1; sb += v2;
+    // every load of a round of 16 terms is in flight before the first add (the adds keep their order): the sums were a chain
+    // of n / 4 dependent L2 round trips
+    for (int t0 = 0; t0 < n; t0 += 16) {
+      double v0[16], v1[16], v2[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++)
+        if (t0 + u < n) {
+          const double *c = Cm + (size_t)(a + n * (t0 + u)) * SOS_TOPC;
+          v0[u] = c[tid]; v1[u] = c[192 + hc]; v2[u] = c[256 + bc_];
+        }
+#pragma unroll
+      for (int u = 0; u < 16; u++)
+        if (t0 + u < n) { sH += v0[u]; sHc += v1[u]; sb += v2[u]; }
     }
-#pragma unroll 4
-    for (int h = 0; h < n; h++) {
-      const double *c = Cm + (size_t)(h + n * a) * SOS_TOPC;
-      const double v0 = c[64 + tid], v1 = c[224 + hc], v2 = c[264 + bc_];
-      sH += v0; sHc += v1; sb += v2;
+    for (int h0 = 0; h0 < n; h0 += 16) {
+      double v0[16], v1[16], v2[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++)
+        if (h0 + u < n) {
+          const double *c = Cm + (size_t)((h0 + u) + n * a) * SOS_TOPC;
+          v0[u] = c[64 + tid]; v1[u] = c[224 + hc]; v2[u] = c[264 + bc_];
+        }
+#pragma unroll
+      for (int u = 0; u < 16; u++)
+        if (h0 + u < n) { sH += v0[u]; sHc += v1[u]; sb += v2[u]; }
     }
     H[(size_t)(4 + 8 * a + i) * dim + 4 + 8 * a + j] = sH;
     if (tid < 32) {
@@ -1859,24 +1873,50 @@ __device__ __forceinline__ void sc_sum_body(int bx, int by, int n, const double 
   double s = 0, sc = 0, sb = 0;
   // the (h = g1, t1 = g1) terms are exact zeros (a point has no residual to its own host), so both sums
   // can run branch-free over all n
-#pragma unroll 4
-  for (int t1 = 0; t1 < n; t1++) s += C[((size_t)(g1 * n + t1) * n + g2) * SOS_SCC + tid];
-#pragma unroll 4
-  for (int h = 0; h < n; h++) s += C[((size_t)(h * n + g1) * n + g2) * SOS_SCC + 64 + tid];
+  for (int t0 = 0; t0 < n; t0 += 16) {  // loads of a round in flight together, adds in the old order (see stitch_top_sum_body)
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++)
+      if (t0 + u < n) v[u] = C[((size_t)(g1 * n + t0 + u) * n + g2) * SOS_SCC + tid];
+#pragma unroll
+    for (int u = 0; u < 16; u++)
+      if (t0 + u < n) s += v[u];
+  }
+  for (int h0 = 0; h0 < n; h0 += 16) {
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++)
+      if (h0 + u < n) v[u] = C[((size_t)((h0 + u) * n + g1) * n + g2) * SOS_SCC + 64 + tid];
+#pragma unroll
+    for (int u = 0; u < 16; u++)
+      if (h0 + u < n) s += v[u];
+  }
   H[(size_t)(4 + 8 * g1 + i) * dim + 4 + 8 * g2 + j] = s;
   if (g1 == g2) {
     const int hc = tid & 31, bc_ = tid & 7;
-#pragma unroll 4
-    for (int t1 = 0; t1 < n; t1++) {
-      const double *e = Ce + (size_t)(g1 + n * t1) * SOS_SCE;
-      const double v1 = e[hc], v2 = e[64 + bc_];
-      sc += v1; sb += v2;
+    for (int t0 = 0; t0 < n; t0 += 16) {
+      double v1[16], v2[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++)
+        if (t0 + u < n) {
+          const double *e = Ce + (size_t)(g1 + n * (t0 + u)) * SOS_SCE;
+          v1[u] = e[hc]; v2[u] = e[64 + bc_];
+        }
+#pragma unroll
+      for (int u = 0; u < 16; u++)
+        if (t0 + u < n) { sc += v1[u]; sb += v2[u]; }
     }
-#pragma unroll 4
-    for (int h = 0; h < n; h++) {
-      const double *e = Ce + (size_t)(h + n * g1) * SOS_SCE;
-      const double v1 = e[32 + hc], v2 = e[72 + bc_];
-      sc += v1; sb += v2;
+    for (int h0 = 0; h0 < n; h0 += 16) {
+      double v1[16], v2[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++)
+        if (h0 + u < n) {
+          const double *e = Ce + (size_t)((h0 + u) + n * g1) * SOS_SCE;
+          v1[u] = e[32 + hc]; v2[u] = e[72 + bc_];
+        }
+#pragma unroll
+      for (int u = 0; u < 16; u++)
+        if (h0 + u < n) { sc += v1[u]; sb += v2[u]; }
     }
     if (tid < 32) {
       const int r = tid >> 2, c = tid & 3;
