@@ -325,9 +325,16 @@ int sosf_imu_try_trap_scale(sosf_imu_calib *calib, double *scale_queue10, int32_
 /* Switches the facade's solveSystemF to the IMU branch (S != NULL) or back (S == NULL).  The records are caller-owned and
  * must outlive the system's iterations: frames[i] belongs to keyframe idx i (its camToWorld / evalPT_R are refreshed by
  * the facade before every solve; state_imu and calib->scale are stepped after it, as doStepFromBackup does with unit
- * step factors); HM / bM: the marginalisation prior in the expanded dimension SOSF_IMU_DIM(n). */
+ * step factors); HM / bM: the marginalisation prior in the expanded dimension SOSF_IMU_DIM(n).
+ * HM = bM = NULL: the facade keeps the expanded prior itself, as EnergyFunctional does with setting_enable_imu: it starts from
+ * expandHbtoFitImu of the current (visual) prior, insertFrame grows it by 29 states (OB/EnergyFunctional.cpp:666-677),
+ * marginalizePointsF adds the expanded M - Msc (:928-932), marginalizeFrame runs the IMU form (:733-889) before it drops the
+ * keyframe.  frames[i] must describe keyframe idx i whenever a solve or a frame marginalisation runs: the caller appends a
+ * record when it adds a keyframe and erases record idx after sosf_marginalize_frame / sosf_marginalize_flagged_frames (calling
+ * sosf_set_imu again with NULL priors only renews the pointers).  sosf_get_imu_prior copies the expanded prior out. */
 int sosf_set_imu(sosf_system *sys, const sosf_imu_settings *S, sosf_imu_calib *calib, sosf_imu_frame *frames, const double *HM,
                  const double *bM);
+int sosf_get_imu_prior(sosf_system *sys, double *HM, double *bM, int *dim);
 /* scale_step and step_imu (n x 21) of the last solve */
 int sosf_get_imu_step(sosf_system *sys, double *scale_step, double *step_imu);
 

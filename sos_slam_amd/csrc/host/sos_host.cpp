@@ -287,6 +287,17 @@ EFFrame *EnergyFunctional::insertFrame(FrameHessian *fh, CalibHessian *HCalib) {
   }
   HM.swap(HMn);
   bM.swap(bMn);
+  if (imuOwnPrior) {  // step = 29, ndim = CPARS + 1 + 29 nFrames, :666-677
+    const int nd = SOSF_IMU_DIM(nFrames), od = nd - 29;
+    MatXX Hn((size_t)nd * nd, 0.0);
+    VecX bn(nd, 0.0);
+    for (int i = 0; i < od; i++) {
+      for (int j = 0; j < od; j++) Hn[(size_t)i * nd + j] = HMi[(size_t)i * od + j];
+      bn[i] = bMi[i];
+    }
+    HMi.swap(Hn);
+    bMi.swap(bn);
+  }
   EFIndicesValid = EFAdjointsValid = EFDeltaValid = false;
   setAdjointsF(HCalib);
   makeIDX();
@@ -486,7 +497,8 @@ int EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib, boo
     }
     VecX x(dim);
     imuStep.assign((size_t)21 * n, 0.0);
-    sosf_imu_solve(imuSettings, imuCalib, n, imuFrames, H.data(), b.data(), Hsc.data(), bsc.data(), imuHM, imuBM, delta.data(), lambda,
+    sosf_imu_solve(imuSettings, imuCalib, n, imuFrames, H.data(), b.data(), Hsc.data(), bsc.data(), imuOwnPrior ? HMi.data() : imuHM,
+                   imuOwnPrior ? bMi.data() : imuBM, delta.data(), lambda,
                    x.data(), &imuScaleStep, imuStep.data());
     lastX = x;
     for (int i = 0; i < 4; i++) HCalib->step[i] = -x[i];
@@ -612,6 +624,14 @@ int EnergyFunctional::marginalizePointsF() {  // :891-936, IMU off
       for (size_t i = 0; i < dd; i++) HM[i] += prm.margWeightFac * upd[i];
       for (int i = 0; i < dim; i++) bM[i] += prm.margWeightFac * upd[dd + i];
       resInM += (int)upd[dd + dim];
+      if (imuOwnPrior) {  // expandHbtoFitImu(H, b); HM += setting_margWeightFac * H, :928-932
+        const int nd = SOSF_IMU_DIM(nFrames);
+        MatXX He((size_t)nd * nd);
+        VecX be(nd);
+        sosf_imu_expand(nFrames, upd.data(), upd.data() + dd, He.data(), be.data());
+        for (size_t i = 0; i < He.size(); i++) HMi[i] += prm.margWeightFac * He[i];
+        for (int i = 0; i < nd; i++) bMi[i] += prm.margWeightFac * be[i];
+      }
     }
   }
   EFIndicesValid = false;
@@ -632,7 +652,31 @@ void EnergyFunctional::dropPointsF() {  // :938-952
   makeIDX();
 }
 
-int EnergyFunctional::marginalizeFrame(EFFrame *fh) {  // :730-889, IMU off
+void EnergyFunctional::imuAdoptPrior() {
+  const int nd = SOSF_IMU_DIM(nFrames);
+  HMi.assign((size_t)nd * nd, 0.0);
+  bMi.assign(nd, 0.0);
+  if (nFrames > 0) sosf_imu_expand(nFrames, HM.data(), bM.data(), HMi.data(), bMi.data());
+  imuOwnPrior = true;
+}
+
+int EnergyFunctional::marginalizeFrame(EFFrame *fh) {  // :730-889; the IMU form first when the expanded prior lives here
+  if (imuOwnPrior) {
+    if (!imuSettings || !imuCalib || !imuFrames) return SOS_ERR_STATE;
+    for (int h = 0; h < nFrames; h++) {  // the records carry the poses the factors are linearised at
+      frames[h]->data->PRE_camToWorld.to12(imuFrames[h].camToWorld);
+      std::memcpy(imuFrames[h].evalPT_R, frames[h]->data->camToWorld_evalPT.R, sizeof(double) * 9);
+    }
+    const VecX delta = getStitchedDeltaF();
+    const int nd = SOSF_IMU_DIM(nFrames - 1);
+    MatXX Ho((size_t)nd * nd);
+    VecX bo(nd);
+    const int rci = sosf_imu_marginalize_frame(imuSettings, imuCalib, nFrames, imuFrames, fh->idx, delta.data(), fh->prior, fh->delta_prior,
+                                               prm.margWeightFac, HMi.data(), bMi.data(), Ho.data(), bo.data());
+    if (rci != SOS_OK) return rci;
+    HMi.swap(Ho);
+    bMi.swap(bo);
+  }
   const int step = 8, odim = SOS_CPARS + nFrames * step, ndim = odim - step;
   const int io = SOS_CPARS + fh->idx * step;
   // move the frame's block to the end (row/column permutation)
@@ -2525,8 +2569,23 @@ extern "C" int sosf_set_imu(sosf_system *sy, const sosf_imu_settings *S, sosf_im
                             const double *bM) {
   if (!sy) return SOS_ERR_ARG;
   EnergyFunctional *ef = sy->fs->ef;
-  if (S && (!C || !frames || !HM || !bM)) return SOS_ERR_ARG;
+  if (S && (!C || !frames || (HM == nullptr) != (bM == nullptr))) return SOS_ERR_ARG;
   ef->imuSettings = S; ef->imuCalib = C; ef->imuFrames = frames; ef->imuHM = HM; ef->imuBM = bM;
+  if (S && !HM) {
+    if (!ef->imuOwnPrior) ef->imuAdoptPrior();  // first call: the visual prior, expanded; later calls only renew the records
+  } else {
+    ef->imuOwnPrior = false;
+  }
+  return SOS_OK;
+}
+extern "C" int sosf_get_imu_prior(sosf_system *sy, double *HM, double *bM, int *dim) {
+  if (!sy) return SOS_ERR_ARG;
+  EnergyFunctional *ef = sy->fs->ef;
+  if (!ef->imuOwnPrior) return SOS_ERR_STATE;
+  const int nd = SOSF_IMU_DIM(ef->nFrames);
+  if (dim) *dim = nd;
+  if (HM) std::memcpy(HM, ef->HMi.data(), sizeof(double) * (size_t)nd * nd);
+  if (bM) std::memcpy(bM, ef->bMi.data(), sizeof(double) * nd);
   return SOS_OK;
 }
 extern "C" int sosf_get_imu_step(sosf_system *sy, double *scale_step, double *step_imu) {

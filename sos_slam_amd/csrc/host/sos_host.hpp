@@ -215,6 +215,13 @@ class EnergyFunctional {  // OB/EnergyFunctional.h:52-154
   sosf_imu_calib *imuCalib = nullptr;
   sosf_imu_frame *imuFrames = nullptr;
   const double *imuHM = nullptr, *imuBM = nullptr;
+  // setting_enable_imu with the prior kept here: HM / bM in the expanded dimension CPARS + 1 + 29 n, grown by insertFrame
+  // (OB/EnergyFunctional.cpp:666-677), fed by marginalizePointsF through expandHbtoFitImu (:928-932) and reduced by the IMU
+  // form of marginalizeFrame (:733-889).  The 8-per-keyframe HM / bM above stay maintained as the visual-only prior.
+  bool imuOwnPrior = false;
+  MatXX HMi;
+  VecX bMi;
+  void imuAdoptPrior();  // HMi / bMi = expandHbtoFitImu(HM, bM)
   double imuScaleStep = 0;
   std::vector<double> imuStep;
   float (*nthHook)(void *, const float *, int, float) = nullptr;

@@ -81,6 +81,7 @@ def load():
     L.sosf_tracker_make_tries.argtypes = [vp, vp, vp, ci, ci, vp, C.POINTER(ci)]
     L.sosf_tracker_track_hypotheses.argtypes = [vp, ci, C.c_float, ci, vp, vp, ci, vp, C.c_double, ci, vp, vp, vp, vp, vp]
     L.sosf_set_imu.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.sosf_get_imu_prior.argtypes = [vp, vp, vp, C.POINTER(ci)]
     L.sosf_get_imu_step.argtypes = [vp, vp, vp]
     L.sosf_tracker_set_points3d.argtypes = [vp, vp, C.c_float, ci, vp, vp]
     L.sosf_tracker_pose_estimate.argtypes = [vp, ci, C.c_float, vp, ci, C.c_float, ci, vp, vp, vp]
@@ -235,10 +236,22 @@ class System:
             return
         from .records import ImuFrame
         arr = (ImuFrame * len(frames))(*frames)
+        if HM is None:   # the facade keeps the expanded prior (setting_enable_imu semantics)
+            self._imu = (S, calib, arr, frames, None, None)
+            _chk(self.L.sosf_set_imu(self.h_, C.byref(S), C.byref(calib), arr, None, None), "sosf_set_imu")
+            return
         HM = np.ascontiguousarray(HM, dtype=np.float64)
         bM = np.ascontiguousarray(bM, dtype=np.float64)
         self._imu = (S, calib, arr, frames, HM, bM)
         _chk(self.L.sosf_set_imu(self.h_, C.byref(S), C.byref(calib), arr, _p(HM), _p(bM)), "sosf_set_imu")
+
+    def imu_prior(self):
+        """the expanded prior kept by the facade (sosf_get_imu_prior): (HM (d, d), bM (d))"""
+        d = C.c_int(0)
+        _chk(self.L.sosf_get_imu_prior(self.h_, None, None, C.byref(d)), "sosf_get_imu_prior")
+        HM, bM = np.zeros((d.value, d.value)), np.zeros(d.value)
+        _chk(self.L.sosf_get_imu_prior(self.h_, _p(HM), _p(bM), None), "sosf_get_imu_prior")
+        return HM, bM
 
     def imu_state(self):
         """(scale_step, step_imu (n, 21), state_imu (n, 21), scale) after the last solve"""

@@ -196,3 +196,113 @@ def test_optimize_with_imu_matches_oracle_loop(name, trapped):
     sc = max(np.abs(sto).max(), 1e-12)
     assert np.abs(stg - sto).max() <= max(1e-5 * sc, 3 * np.abs(sto - stt).max())
     assert sg != 1.0 / 200 and np.abs(stg).max() > 2e-4            # the IMU states did move
+
+
+def _refresh_records(ow, frames):
+    """poses the IMU factors are linearised at: PRE_camToWorld and the rotation of the evaluation point (as the facade does)"""
+    for i, f in enumerate(frames):
+        f.camToWorld[:] = list(ow.frame(i)["camToWorld"])
+        f.evalPT_R[:] = list(ow.evalpt(i)[:9])
+
+
+def _stitched_delta(ow, n):
+    v, vz = ow.calib_value()
+    d = np.zeros(4 + 8 * n)
+    d[:4] = (v - vz).astype(np.float32)            # cDeltaF is float (OB/EnergyFunctional.cpp:176)
+    for f in range(n):
+        fr = ow.frame(f)
+        d[4 + 8 * f:12 + 8 * f] = fr["state"][:8] - fr["state_zero"][:8]
+    return d
+
+
+@pytest.mark.parametrize("name", ["T6", "W7"])
+def test_imu_prior_lifecycle(name):
+    """setting_enable_imu with the prior kept by the facade (sosf_set_imu with NULL priors): expansion at the start, six IMU
+    iterations, marginalizePointsF into the expanded prior, the IMU form of marginalizeFrame, then the reduced window and a
+    new keyframe -- against the same sequence assembled from the oracle's pieces (host loop with orc_host_set_imu,
+    marginalize_points, expandHbtoFitImu, orc_imu_marginalize_frame) with the prior kept in NumPy."""
+    from sos_slam_amd import host
+    from tests import helpers as hp
+    from tests.test_gpu_marginalize import _yardstick
+    win = synth.make_window(name)
+    n, w = win.n, float(win.params["margWeightFac"])
+    api = orc.imu()
+    # ---- device
+    S, cal, frames, keep = _records(win)
+    sysm = host.System.from_window(win)
+    sysm.set_imu(S, cal, frames)
+    H0, b0 = sysm.imu_prior()
+    He, be = api.expand(n, win.HM, win.bM)
+    assert np.array_equal(H0, He) and np.array_equal(b0, be)
+    sysm.optimize(6)
+    # ---- oracle (fp32 restatement and fp64-accumulated yardstick), prior in NumPy
+    sides = {}
+    for truth in (False, True):
+        S2, cal2, frames2, keep2 = _records(win)
+        ow = hp.oracle_window(win)
+        ow.set_truth_mode(truth)
+        HMo, bMo = api.expand(n, win.HM, win.bM)
+        ow.set_imu(S2, cal2, frames2, HMo, bMo)
+        ow.optimize(6)
+        sides[truth] = dict(ow=ow, S=S2, cal=cal2, HM=HMo, bM=bMo)
+    # ---- marginalizePointsF: points of keyframe 0 that still have residuals
+    ow = sides[False]["ow"]
+    res = ow.res()
+    live = (res["flags"] & 0x100) == 0
+    has = np.zeros(win.P, bool)
+    has[res["point"][live]] = True
+    alive0 = np.flatnonzero(has & (win.points["host"] == 0)).astype(np.int32)
+    empty0 = np.flatnonzero(~has & (win.points["host"] == 0)).astype(np.int32)
+    sel, rest = alive0[::2], alive0[1::2]
+    for truth, sd in sides.items():
+        o = sd["ow"]
+        Hb, bb = o.get_prior()
+        o.marginalize_points(sel)
+        Ha, ba_ = o.get_prior()
+        dH, db = api.expand(n, Ha - Hb, ba_ - bb)          # = margWeightFac * expandHbtoFitImu(M - Msc)
+        sd["HM"] = sd["HM"] + dH
+        sd["bM"] = sd["bM"] + db
+    sysm.marginalize_points(sel)
+    Hg, bg = sysm.imu_prior()
+    _yardstick(Hg, sides[False]["HM"], sides[True]["HM"], "expanded HM after marginalizePointsF")
+    _yardstick(bg, sides[False]["bM"], sides[True]["bM"], "expanded bM after marginalizePointsF")
+    assert np.abs(Hg - H0).max() > 0
+    # ---- marginalizeFrame(0), IMU form
+    ids2 = sysm.point_ids()
+    sysm.drop_points(np.concatenate([rest, empty0[np.isin(empty0, ids2)]]))
+    for truth, sd in sides.items():
+        o = sd["ow"]
+        o.drop_points(rest)
+        fr = o._imu[2]
+        _refresh_records(o, fr)
+        pr, dp = o.frame_prior(0)
+        sd["HM"], sd["bM"] = api.marginalize_frame(sd["S"], sd["cal"], list(fr), 0, _stitched_delta(o, n), pr, dp, sd["HM"], sd["bM"],
+                                                   marg_weight=w)
+    sysm.marginalize_frame(0)
+    arr = sysm._imu[2]
+    kept = [arr[i] for i in range(1, n)]                 # the caller erases record idx ...
+    sysm.set_imu(S, cal, kept)                           # ... and renews the pointers; the prior stays with the facade
+    Hg, bg = sysm.imu_prior()
+    assert Hg.shape == sides[False]["HM"].shape == (imu_dim(n - 1),) * 2
+    _yardstick(Hg, sides[False]["HM"], sides[True]["HM"], "expanded HM after marginalizeFrame")
+    _yardstick(bg, sides[False]["bM"], sides[True]["bM"], "expanded bM after marginalizeFrame")
+    assert np.abs(Hg - Hg.T).max() <= 1e-9 * np.abs(Hg).max()
+    # ---- the reduced window optimises with the carried prior; the states keep moving, nothing blows up
+    sc0 = cal.scale
+    rm, it = sysm.optimize(3)
+    assert np.isfinite(rm) and rm > 0
+    _, st, st_new, scale = sysm.imu_state()
+    assert st.shape == (n - 1, 21) and np.isfinite(st_new).all() and np.isfinite(scale) and scale != sc0
+    # ---- insertFrame: 29 new states, zero rows / columns (OB/EnergyFunctional.cpp:666-677)
+    Hb, bb = sysm.imu_prior()
+    fr = win.frames[0].copy()
+    fr["frameID"] = 1000
+    sysm.add_frame(fr, win.images[0])
+    Ha, ba_ = sysm.imu_prior()
+    d = imu_dim(n - 1)
+    assert Ha.shape == (imu_dim(n),) * 2
+    assert np.array_equal(Ha[:d, :d], Hb) and np.array_equal(ba_[:d], bb)
+    assert not Ha[d:, :].any() and not Ha[:, d:].any() and not ba_[d:].any()
+    sysm.close()
+    for sd in sides.values():
+        sd["ow"].close()
