@@ -330,8 +330,10 @@ int sosf_imu_try_trap_scale(sosf_imu_calib *calib, double *scale_queue10, int32_
  * expandHbtoFitImu of the current (visual) prior, insertFrame grows it by 29 states (OB/EnergyFunctional.cpp:666-677),
  * marginalizePointsF adds the expanded M - Msc (:928-932), marginalizeFrame runs the IMU form (:733-889) before it drops the
  * keyframe.  frames[i] must describe keyframe idx i whenever a solve or a frame marginalisation runs: the caller appends a
- * record when it adds a keyframe and erases record idx after sosf_marginalize_frame / sosf_marginalize_flagged_frames (calling
- * sosf_set_imu again with NULL priors only renews the pointers).  sosf_get_imu_prior copies the expanded prior out. */
+ * record when it adds a keyframe (calling sosf_set_imu again with NULL priors only renews the pointers); a frame
+ * marginalisation erases record idx from the caller's array in place (the later records move down by one), so the array
+ * stays aligned when several keyframes leave in one sosf_marginalize_flagged_frames.  sosf_get_imu_prior copies the
+ * expanded prior out. */
 int sosf_set_imu(sosf_system *sys, const sosf_imu_settings *S, sosf_imu_calib *calib, sosf_imu_frame *frames, const double *HM,
                  const double *bM);
 int sosf_get_imu_prior(sosf_system *sys, double *HM, double *bM, int *dim);

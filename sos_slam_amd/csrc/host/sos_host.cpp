@@ -676,6 +676,7 @@ int EnergyFunctional::marginalizeFrame(EFFrame *fh) {  // :730-889; the IMU form
     if (rci != SOS_OK) return rci;
     HMi.swap(Ho);
     bMi.swap(bo);
+    for (int h = fh->idx; h + 1 < nFrames; h++) imuFrames[h] = imuFrames[h + 1];  // the records stay aligned with the window
   }
   const int step = 8, odim = SOS_CPARS + nFrames * step, ndim = odim - step;
   const int io = SOS_CPARS + fh->idx * step;

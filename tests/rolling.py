@@ -53,8 +53,9 @@ class Scenario:
     window (what the initialiser would hand over: n0 keyframes at their true poses with noisy inverse depths)."""
 
     def __init__(self, w=320, h=240, n_frames=26, n0=4, points0=360, seed=synth.SEED + 77, step=0.07, noise_sigma=1.0,
-                 desired_points=1000.0, immature_density=450.0):
+                 desired_points=1000.0, immature_density=450.0, vio=False):
         self.w, self.h, self.n_frames, self.n0 = w, h, n_frames, n0
+        self.vio = vio
         self.desired_points, self.immature_density = desired_points, immature_density
         rng = np.random.default_rng(seed)
         s = w / 752.0
@@ -62,9 +63,13 @@ class Scenario:
         self.K = K.astype(np.float32).astype(np.float64)
         self.scene = synth._Scene(rng, s)
         self.poses, self.raw, self.depth, self.aff_true = [], [], [], []
+        if vio:
+            self._make_imu(n_frames, step)
         for i in range(n_frames):
             R = synth.so3_exp(0.008 * i * np.array([0.3, 1.0, 0.2]))
             t = step * i * np.array([1.0, 0.1, 0.05])
+            if vio:
+                R, t = self._traj(float(i))
             a_i, b_i = (0.0, 0.0) if i == 0 else (rng.normal(0, 0.01), rng.normal(0, 1.0))
             img, dep = self.scene.render(R, t, self.K, w, h)
             img = np.exp(a_i) * img + b_i + rng.normal(0, noise_sigma, img.shape)
@@ -77,6 +82,43 @@ class Scenario:
         self.pattern = random_pattern(w * h)
         self.seed_boot = seed + 1
         self.points0 = points0
+
+    # ---- visual-inertial variant: a trajectory with acceleration, and the IMU samples that belong to it
+    def _traj(self, tau, step=None):
+        """camToWorld at frame time tau (frames are dt apart): the straight path plus a small loop"""
+        step = self._step if step is None else step
+        R = synth.so3_exp(0.008 * tau * self._axis)
+        t = step * tau * np.array([1.0, 0.1, 0.05]) + self._amp * (np.sin(self._om * tau) * self._e1 + (1 - np.cos(self._om * tau)) * self._e2)
+        return R, t
+
+    def _make_imu(self, n_frames, step, m=10):
+        from sos_slam_amd.records import ImuSettings
+        self._step, self._axis = step, np.array([0.3, 1.0, 0.2])
+        self._amp, self._om = 0.012, 0.8
+        self._e1, self._e2 = np.array([0.0, 1.0, 0.0]), np.array([0.0, 0.0, 1.0])
+        self.dt = 0.05
+        self.ts = 1.0 + self.dt * np.arange(n_frames)
+        self.scale_true, self.bias_g = 1.0, np.array([0.004, -0.003, 0.002])
+        S = ImuSettings()
+        S.weight_imu[:] = list(np.diag([25.0, 25.0, 25.0, 2500.0, 2500.0, 2500.0]).reshape(-1))
+        S.weight_imu_bias[:] = list(np.diag([1e3, 1e3, 1e3, 1e5, 1e5, 1e5]).reshape(-1))
+        S.gravity[:] = [0.0, 9.81, 0.0]
+        Ric = synth.so3_exp(np.array([0.1, -0.2, 0.05]))
+        S.rot_imu_cam[:] = list(Ric.reshape(-1))
+        S.maxImuInterval, S.enable_scale_opt = 0.5, 0
+        self.imu_settings = S
+        g = np.array(S.gravity[:])
+        self.imu = [np.zeros((0, 7))]
+        for k in range(1, n_frames):
+            rows = np.zeros((m, 7))
+            for j in range(m):
+                tau = (k - 1) + (j + 1) / m
+                R, _ = self._traj(tau)
+                a_w = self._amp * self._om ** 2 * (-np.sin(self._om * tau) * self._e1 + np.cos(self._om * tau) * self._e2) / self.dt ** 2
+                rows[j, 0] = 1.0 + self.dt * tau
+                rows[j, 1:4] = Ric @ R.T @ (self.scale_true * a_w + g)
+                rows[j, 4:7] = Ric @ (0.008 * self._axis / self.dt) + self.bias_g
+            self.imu.append(rows)
 
     def bootstrap_points(self, images):
         """(POINT_DTYPE records, residual (point, target idx) list) of the bootstrap window from its undistorted images"""
@@ -208,6 +250,7 @@ class KeyframeLog:
     marginalized: list       # [(frameID, camToWorld (12))]
     HM: np.ndarray
     bM: np.ndarray
+    vio: dict = None         # visual-inertial runs: scale, scale_zero, trapped, states {frameID: 21}, vel {frameID: 3}, HMi, bMi
 
 
 class Chain:
@@ -222,6 +265,13 @@ class Chain:
         self.logs = []
         self.handles = {}    # frameID -> front-end handle of the keyframes in the window
         self.next_frame = sc.n0
+        # visual-inertial mode (FS/FullSystem.cpp:800-807, 841-849, 878-886; FS/FullSystemOptimize.cpp:459-479): per keyframe the
+        # FrameShell fields, the 21 IMU states (unscaled) and their linearisation point; the IMU part of CalibHessian
+        self.vio = bool(getattr(sc, "vio", False))
+        self.shells, self.imu_state, self.imu_zero = {}, {}, {}
+        self.cal = dict(scale=1.0 / 200.0, scale_zero=1.0 / 200.0, trapped=0, init=0)
+        self.scale_queue, self.scale_qi = np.linspace(-10, -100, 10), 0
+        self.n_kf_total = 0
 
     # ---- backend interface (implemented by DeviceChain / OracleChain)
     def n(self): raise NotImplementedError
@@ -237,6 +287,11 @@ class Chain:
             self.handles[i] = hs[i]
             self.imm[i] = np.zeros(0, dtype=IMMATURE_DTYPE)
             self.imm_type[i] = np.zeros(0, np.float32)
+        if self.vio:
+            for i in range(sc.n0):
+                self.shells[i] = dict(ts=float(sc.ts[i]), c2w=np.array(sc.poses[i], dtype=np.float64), vel=np.zeros(3))
+                self.imu_state[i], self.imu_zero[i] = np.zeros(21), np.zeros(21)
+            self.n_kf_total = sc.n0
         rmse, its = self.optimize(6)
         self.remove_outliers()
         self.tracker_set_ref()
@@ -283,6 +338,13 @@ class Chain:
             KRKi, Kt, a = host_to_frame(K4, poses[i], c2w, affs[i], aff)
             self.imm[fid] = self.trace(h_new, self.imm[fid], KRKi, Kt, a)
         flagged = self.flag_frames([len(self.imm[f]) for f in ids])
+        if self.vio:   # fh->setImuData; propagateImuState(allKeyFramesHistory.back(), coarseTracker->lastRef->imu_bias), :800-807
+            self.shells[k] = dict(ts=float(sc.ts[k]), c2w=np.array(c2w, dtype=np.float64), vel=np.zeros(3))
+            self.imu_state[k], self.imu_zero[k] = np.zeros(21), np.zeros(21)
+            if self.cal["init"]:
+                last = ids[-1]
+                self.vio_propagate(k, last, self.vio_scaled(self.imu_state[last])[:6])
+            self.n_kf_total += 1
         self.add_keyframe(h_new, c2w, aff, k)
         self.handles[k] = h_new
         self.imm[k] = np.zeros(0, dtype=IMMATURE_DTYPE)
@@ -290,11 +352,32 @@ class Chain:
         self.add_old_point_residuals()
         activated, deleted = self.activate_points(flagged)
         npts = self.n_points()
+        if self.vio and self.n_kf_total == 5:     # imu initialization, :841-849
+            wid = self.window_ids()
+            assert len(wid) == 5, "the window must still hold the first five keyframes"
+            assert self.vio_initialize(wid), "IMU initialization failed"
+            self.cal["init"] = 1
         rmse, its = self.optimize(6)
         ids2 = self.window_ids()
         window_poses = {fid: self.kf_pose(i).copy() for i, fid in enumerate(ids2)}
+        if self.vio:
+            for i, fid in enumerate(ids2):        # shell->camToWorld = PRE_camToWorld, FS/FullSystemOptimize.cpp:437-443
+                self.shells[fid]["c2w"] = np.array(window_poses[fid], dtype=np.float64)
+            if self.cal["init"]:                  # :459-479
+                self.vio_update_vel(ids2[-1], ids2[-2])
+                self.imu_zero[ids2[-1]] = self.imu_state[ids2[-1]].copy()
+                if not self.cal["trapped"]:
+                    self.vio_try_trap()
+                    if self.cal["trapped"]:
+                        for fid in ids2:
+                            self.imu_zero[fid] = self.imu_state[fid].copy()
         residual_set = self.residual_set()
         nout = self.remove_outliers()
+        if self.vio and self.n_kf_total == 5:     # reset imu states for imu initialization, :878-886
+            for i, fid in enumerate(ids2):
+                self.imu_zero[fid] = self.imu_state[fid].copy()
+                if i > 0:
+                    self.vio_update_vel(fid, ids2[i - 1])
         self.tracker_set_ref()
         nmarg, ndrop = self.flag_points_for_removal()
         point_set = self.point_set()
@@ -304,10 +387,52 @@ class Chain:
             self.release(self.handles.pop(fid))
             self.imm.pop(fid)
             self.imm_type.pop(fid)
+            if self.vio:
+                self.imu_state.pop(fid)
+                self.imu_zero.pop(fid)
         HM, bM = self.prior()
+        vio = None
+        if self.vio:
+            Hi, bi = self.prior_imu()
+            vio = dict(scale=self.cal["scale"], scale_zero=self.cal["scale_zero"], trapped=self.cal["trapped"], init=self.cal["init"],
+                       states={f: self.imu_state[f].copy() for f in self.window_ids()}, vel={f: self.shells[f]["vel"].copy() for f in self.window_ids()},
+                       HMi=Hi, bMi=bi)
         self.logs.append(KeyframeLog(k, T, np.asarray(aff, dtype=np.float64), [ids[i] for i in np.flatnonzero(flagged)], activated, deleted, npts, rmse,
-                                     its, ids2, window_poses, residual_set, nout, nmarg, ndrop, point_set, nimm, marg, HM, bM))
+                                     its, ids2, window_poses, residual_set, nout, nmarg, ndrop, point_set, nimm, marg, HM, bM, vio))
         return self.logs[-1]
+
+    # ---- visual-inertial helpers shared by the chains (state layout and records); the arithmetic is per chain
+    _IMU_K = np.repeat([100.0, 1.0, 100.0, 1000.0, 1000.0, 1000.0, 1000.0], 3)   # SCALE_BA, BG, SL_ROT, SQ_TRANS, SQ_ROT, SC_TRANS, SC_ROT
+
+    def vio_scaled(self, state):
+        return self._IMU_K * np.asarray(state, dtype=np.float64)
+
+    def vio_records(self, ids):
+        """sosf_imu_frame records of the keyframes `ids` (window order) from the chain's state; camToWorld / evalPT_R are
+        filled by whoever solves"""
+        from sos_slam_amd.records import ImuFrame
+        out, keep = [], []
+        for i, fid in enumerate(ids):
+            f = ImuFrame()
+            f.timestamp = self.shells[fid]["ts"]
+            f.camToWorld[:] = list(self.shells[fid]["c2w"])
+            f.evalPT_R[:] = list(self.shells[fid]["c2w"][:9])
+            f.state_imu[:] = list(self.imu_state[fid])
+            f.state_imu_zero[:] = list(self.imu_zero[fid])
+            f.trackingRefIsPrev = 1 if fid > 0 else 0
+            arr = np.ascontiguousarray(self.sc.imu[fid], dtype=np.float64).reshape(-1, 7)
+            keep.append(arr)
+            f.n_imu = len(arr)
+            f.imu = arr.ctypes.data if len(arr) else None
+            out.append(f)
+        return out, keep
+
+    def vio_calib(self):
+        from sos_slam_amd.records import ImuCalib
+        return ImuCalib(self.cal["scale"], self.cal["scale_zero"], int(self.cal["trapped"]), int(self.cal["init"]))
+
+    def vio_take_calib(self, c):
+        self.cal.update(scale=c.scale, scale_zero=c.scale_zero, trapped=int(c.scale_trapped), init=int(c.imu_initialized) or self.cal["init"])
 
     def activate_points(self, flagged_old):     # FS/FullSystem.cpp:376-533
         sc = self.sc
@@ -474,7 +599,72 @@ class DeviceChain(Chain):
         self.sysm.add_activated_points(pts, masks)
 
     def optimize(self, its):
-        return self.sysm.optimize(its)
+        if self.vio and self.cal["init"]:
+            self._push_imu()
+        r = self.sysm.optimize(its)
+        if self.vio and self.cal["init"]:
+            self._pull_imu()
+        return r
+
+    # ---- visual-inertial: the facade's front-end functions and its own expanded prior (sosf_set_imu with NULL priors)
+    def _fe(self):
+        if not hasattr(self, "_imu_fe"):
+            self._imu_fe = self.host.ImuFrontEnd()
+        return self._imu_fe
+
+    def _shell(self, fid):
+        from sos_slam_amd.records import ImuShell
+        sh = ImuShell()
+        sh.timestamp = self.shells[fid]["ts"]
+        sh.camToWorld[:] = list(self.shells[fid]["c2w"])
+        sh.velInWorld[:] = list(self.shells[fid]["vel"])
+        return sh
+
+    def _push_imu(self):
+        recs, self._imu_keep = self.vio_records(self.window_ids())
+        self._cal_struct = self.vio_calib()
+        self.sysm.set_imu(self.sc.imu_settings, self._cal_struct, recs)
+
+    def _pull_imu(self):
+        arr = self.sysm._imu[2]
+        for i, fid in enumerate(self.window_ids()):
+            self.imu_state[fid] = np.array(arr[i].state_imu[:])
+        self.vio_take_calib(self._cal_struct)
+
+    def vio_propagate(self, fid, last_fid, last_bias):
+        recs, keep = self.vio_records([fid])
+        sh, cal = self._shell(fid), self.vio_calib()
+        self._fe().propagate_state(self.sc.imu_settings, cal, recs[0], sh, self._shell(last_fid), last_bias)
+        self.imu_state[fid], self.imu_zero[fid] = np.array(recs[0].state_imu[:]), np.array(recs[0].state_imu_zero[:])
+        self.shells[fid]["vel"] = np.array(sh.velInWorld[:])
+
+    def vio_initialize(self, ids):
+        recs, keep = self.vio_records(ids)
+        for i, r in enumerate(recs):
+            r.camToWorld[:] = list(self.kf_pose(i))          # PRE_camToWorld
+        cal = self.vio_calib()
+        ok, fo, so = self._fe().initialize(self.sc.imu_settings, cal, recs, [self._shell(f) for f in ids])
+        for i, fid in enumerate(ids):
+            self.imu_state[fid], self.imu_zero[fid] = np.array(fo[i].state_imu[:]), np.array(fo[i].state_imu_zero[:])
+            self.shells[fid]["vel"] = np.array(so[i].velInWorld[:])
+        self.vio_take_calib(cal)
+        return ok
+
+    def vio_update_vel(self, fid, last_fid):
+        recs, keep = self.vio_records([fid])
+        sh = self._shell(fid)
+        self._fe().update_vel(recs[0], sh, self._shell(last_fid))
+        self.shells[fid]["vel"] = np.array(sh.velInWorld[:])
+
+    def vio_try_trap(self):
+        cal = self.vio_calib()
+        self.scale_queue, self.scale_qi = self._fe().try_trap_scale(cal, self.scale_queue, self.scale_qi, 1e-4)
+        self.vio_take_calib(cal)
+
+    def prior_imu(self):
+        if not self.cal["init"]:
+            return None, None
+        return self.sysm.imu_prior()
 
     def remove_outliers(self):
         return self.sysm.remove_outliers()
@@ -490,6 +680,8 @@ class DeviceChain(Chain):
         return self.ctx.immature_init(self.tprm, slot, u, v)
 
     def marginalize_flagged(self):
+        if self.vio and self.cal["init"]:
+            self._push_imu()        # the IMU form of marginalizeFrame reads the records of the window as it is now
         ids, poses = self.sysm.marginalize_flagged_frames()
         return [(int(i), p.copy()) for i, p in zip(ids, poses)]
 
@@ -568,6 +760,7 @@ class OracleChain(Chain):
         self.calib_value = np.array([float(np.float32(1.0) / np.float32(50.0)) * v for v in sc.K])
         self.calib_value_zero = self.calib_value.copy()
         self.HM, self.bM = np.zeros((4, 4)), np.zeros(4)
+        self.HMi = self.bMi = None      # visual-inertial: the prior in the expanded dimension, from the first IMU solve on
         self.trk = None
         self.sel_slot = None
 
@@ -598,6 +791,66 @@ class OracleChain(Chain):
         HM, bM = np.zeros((odim + 8, odim + 8)), np.zeros(odim + 8)
         HM[:odim, :odim], bM[:odim] = self.HM, self.bM
         self.HM, self.bM = HM, bM
+
+    # ---- visual-inertial: NumPy front-end (oracle/imu_frontend.py), orc_imu_* for the assembly, the expanded prior kept here
+    def _Sd(self):
+        S = self.sc.imu_settings
+        return dict(gravity=np.array(S.gravity[:]), rot_imu_cam=np.array(S.rot_imu_cam[:]))
+
+    def vio_propagate(self, fid, last_fid, last_bias):
+        from oracle import imu_frontend as fe
+        a, b = self.shells[fid], self.shells[last_fid]
+        sc_, vel = fe.propagate_imu_state(self._Sd(), self.cal["scale"], a["ts"], self.sc.imu[fid], b["ts"], b["c2w"][:9].reshape(3, 3), b["vel"],
+                                          last_bias, fe.scaled_of(self.imu_state[fid]))
+        self.imu_state[fid] = fe.state_of(sc_)
+        self.imu_zero[fid] = self.imu_state[fid].copy()
+        a["vel"] = vel
+
+    def vio_initialize(self, ids):
+        from oracle import imu_frontend as fe
+        ts = [self.shells[f]["ts"] for f in ids]
+        c2w = [self.shells[f]["c2w"] for f in ids]
+        r = fe.initialize_imu(self._Sd(), self.cal["scale"], bool(self.sc.imu_settings.enable_scale_opt), ts, c2w, self.kf_pose(4)[:9],
+                              [self.sc.imu[f] for f in ids], [fe.scaled_of(self.imu_state[f]) for f in ids])
+        if not self.sc.imu_settings.enable_scale_opt:        # setScaleScaledZero
+            self.cal["scale"] = self.cal["scale_zero"] = fe.SCALE_SCALE_INVERSE * r["scale_scaled"]
+        for i, f in enumerate(ids):
+            self.shells[f]["vel"] = r["vel"][i].copy()
+            if r["ok"]:
+                self.imu_state[f] = fe.state_of(r["scaled"][i])
+                self.imu_zero[f] = self.imu_state[f].copy()
+        return r["ok"]
+
+    def vio_update_vel(self, fid, last_fid):
+        from oracle import imu_frontend as fe
+        a, b = self.shells[fid], self.shells[last_fid]
+        a["vel"] = fe.update_vel(fe.scaled_of(self.imu_state[fid]), a["ts"], a["c2w"][9:], b["ts"], b["c2w"][9:])
+
+    def vio_try_trap(self):
+        from oracle import imu_frontend as fe
+        zero, trapped, self.scale_queue, self.scale_qi = fe.try_trap_scale(self.cal["scale"], self.scale_queue, self.scale_qi, 1e-4)
+        self.cal["scale_zero"] = zero
+        self.cal["trapped"] = int(trapped)
+
+    def prior_imu(self):
+        if self.HMi is None:
+            return None, None
+        return self.HMi.copy(), self.bMi.copy()
+
+    def _window_records(self):
+        recs, keep = self.vio_records(self.window_ids())
+        for f, r in zip(self.frames, recs):
+            r.camToWorld[:] = list(f.pre)
+            r.evalPT_R[:] = list(f.evalPT[:9])
+        return recs, keep
+
+    def _stitched_delta(self):
+        n = len(self.frames)
+        d = np.zeros(4 + 8 * n)
+        d[:4] = (self.calib_value - self.calib_value_zero).astype(np.float32)
+        for i, f in enumerate(self.frames):
+            d[4 + 8 * i:12 + 8 * i] = f.state[:8] - f.state_zero[:8]
+        return d
 
     def init_window(self, hs, poses, affs, pts, res):
         for i, (h, T, aff) in enumerate(zip(hs, poses, affs)):
@@ -676,6 +929,11 @@ class OracleChain(Chain):
     def add_keyframe(self, h, c2w, aff, frameID):
         self.frames.append(OFrame(frameID, h, c2w, aff))
         self._grow_prior()
+        if self.HMi is not None:     # step = 29, OB/EnergyFunctional.cpp:666-677
+            od = self.HMi.shape[0]
+            Hn, bn = np.zeros((od + 29, od + 29)), np.zeros(od + 29)
+            Hn[:od, :od], bn[:od] = self.HMi, self.bMi
+            self.HMi, self.bMi = Hn, bn
 
     def add_old_point_residuals(self):    # FS/FullSystem.cpp:818-832
         new = self.frames[-1]
@@ -764,7 +1022,19 @@ class OracleChain(Chain):
 
     def optimize(self, its):
         ow, plist, rlist = self._pack()
+        imu_on = self.vio and self.cal["init"]
+        if imu_on:
+            if self.HMi is None:     # the reference keeps HM expanded from the start; nothing was marginalised before this point
+                self.HMi, self.bMi = orc.imu().expand(len(self.frames), self.HM, self.bM)
+            recs, keep = self._window_records()
+            cal = self.vio_calib()
+            ow.set_imu(self.sc.imu_settings, cal, recs, self.HMi, self.bMi)
         rmse, it = ow.optimize(its)
+        if imu_on:
+            _, st = ow.imu_state()
+            for f, x in zip(self.frames, st):
+                self.imu_state[f.frameID] = x.copy()
+            self.vio_take_calib(cal)
         self._unpack_frames(ow)
         po, ro, cen = ow.pts(), ow.res(), ow.center()
         ngr, mrb = ow.num_good_residuals(), ow.point_field("maxRelBaseline")
@@ -863,7 +1133,11 @@ class OracleChain(Chain):
                 idh[k] = p.idepth_hessian
             sel = np.array([pos[id(p)] for p in inliers], dtype=np.int32)
             flag = ow.marginalize_points(sel)
+            Hold, bold = self.HM, self.bM
             self.HM, self.bM = ow.get_prior()
+            if self.HMi is not None:     # expandHbtoFitImu(H, b); HM += setting_margWeightFac * H, OB/EnergyFunctional.cpp:928-932
+                dH, db = orc.imu().expand(len(self.frames), self.HM - Hold, self.bM - bold)
+                self.HMi, self.bMi = self.HMi + dH, self.bMi + db
             for p, fl in zip(inliers, flag):
                 if fl:
                     p.host.n_marg += 1
@@ -898,6 +1172,11 @@ class OracleChain(Chain):
             assert not f.points
             out.append((f.frameID, f.pre.copy()))
             ow, plist, rlist = self._pack()
+            if self.HMi is not None:     # the IMU form, OB/EnergyFunctional.cpp:733-889 (orc_imu_marginalize_frame)
+                recs, keep = self._window_records()
+                pr, dp = ow.frame_prior(i)
+                self.HMi, self.bMi = orc.imu().marginalize_frame(self.sc.imu_settings, self.vio_calib(), recs, i, self._stitched_delta(), pr, dp,
+                                                                 self.HMi, self.bMi, marg_weight=float(self.sc.params["margWeightFac"]))
             self.HM, self.bM = ow.marginalize_frame_prior(i)
             ow.close()
             for g in self.frames:

@@ -280,8 +280,9 @@ def test_imu_prior_lifecycle(name):
                                                    marg_weight=w)
     sysm.marginalize_frame(0)
     arr = sysm._imu[2]
-    kept = [arr[i] for i in range(1, n)]                 # the caller erases record idx ...
-    sysm.set_imu(S, cal, kept)                           # ... and renews the pointers; the prior stays with the facade
+    kept = [arr[i] for i in range(n - 1)]                # the facade erased record 0 in place; the prior stays with it
+    assert [f.timestamp for f in kept] == [frames[i].timestamp for i in range(1, n)]
+    sysm.set_imu(S, cal, kept)
     Hg, bg = sysm.imu_prior()
     assert Hg.shape == sides[False]["HM"].shape == (imu_dim(n - 1),) * 2
     _yardstick(Hg, sides[False]["HM"], sides[True]["HM"], "expanded HM after marginalizeFrame")

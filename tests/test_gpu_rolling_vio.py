@@ -1,0 +1,103 @@
+"""Rolling-window parity in visual-inertial mode (BASELINE configs 2-3 in synthetic form: a monocular sequence with IMU samples
+generated from the rendered trajectory).  The chain of tests/test_gpu_rolling_window.py plus, per keyframe, what setting_enable_imu
+adds (FS/FullSystem.cpp:800-807, 841-849, 878-886; FS/FullSystemOptimize.cpp:459-479; OB/EnergyFunctional.cpp:666-677, 733-889,
+928-932, 1053-1171): setImuData + propagateImuState, initializeImu at the fifth keyframe, the IMU branch of solveSystemF in every
+optimize() from then on, updateVel / setImuStateZero / tryTrapScale after it, marginalizePointsF into the expanded prior and the
+IMU form of marginalizeFrame.
+
+Device chain: the facade keeps the expanded prior (sosf_set_imu with NULL priors), its front-end functions (sosf_imu_*) do the
+state propagation; oracle chains (fp32 restatement, and fp64-accumulated as the yardstick): oracle/imu_frontend.py (NumPy),
+orc_imu_* for the assembly, the prior kept in NumPy.  Free-running from the same raw frames and IMU samples.
+
+Compared per keyframe: keyframe-level decisions (flagged / marginalised keyframes, window, IMU initialisation and scale trap:
+identical; iteration counts: at most two knife-edge differences of the termination test over the sequence), poses in the window
+and leaving it, metric scale, the 21 IMU states and the velocity of every keyframe, the expanded prior.  The visual-inertial
+window is far more sensitive to fp32 rounding than the visual one (the cubic spline coefficients are barely constrained over
+50 ms: the two ORACLE chains end 0.28 apart in the scaled IMU states and 3e-4 in the poses), so the yardstick is the only
+meaningful bar: every quantity within FACTOR x the running maximum of the oracle's own fp32-vs-fp64 distance, or the stated
+absolute tolerance, whichever is larger."""
+import numpy as np
+import pytest
+
+from tests import rolling
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL, SCALE_TOL, STATE_TOL, VEL_TOL = 5e-5, 5e-4, 5e-2, 2e-3   # camToWorld entries; scale * 200; scaled IMU states; m/s
+FACTOR = 5.0
+
+
+def _scaled(A, ref):
+    s = 1.0 / np.sqrt(np.abs(np.diag(ref)) + 10)
+    return A * s[:, None] * s[None, :]
+
+
+def test_rolling_window_visual_inertial():
+    sc = rolling.Scenario(n_frames=20, vio=True)
+    dev, orc_, tru = rolling.DeviceChain(sc), rolling.OracleChain(sc), rolling.OracleChain(sc, truth=True)
+    for c in (dev, orc_, tru):
+        c.bootstrap()
+    bad = []
+
+    def check(cond, what):
+        if not cond:
+            bad.append(what)
+
+    run = dict(pose=0.0, scale=0.0, state=0.0, vel=0.0, HM=0.0)
+    worst = dict(pose=0.0, scale=0.0, state=0.0, vel=0.0, leave=0.0, leave_noise=0.0)
+    left = its_diff = 0
+    while dev.next_frame < sc.n_frames:
+        lg, lo, lt = dev.step(), orc_.step(), tru.step()
+        k = lg.frameID
+        vg, vo, vt = lg.vio, lo.vio, lt.vio
+        assert lg.flagged == lo.flagged and lg.window_ids == lo.window_ids, k
+        assert (vg["init"], vg["trapped"]) == (vo["init"], vo["trapped"]), k
+        its_diff += int(lg.iterations != lo.iterations)
+        for fid in lg.window_ids:
+            run["pose"] = max(run["pose"], np.abs(lo.window_poses[fid] - lt.window_poses[fid]).max())
+        for fid in lg.window_ids:
+            e = np.abs(lg.window_poses[fid] - lo.window_poses[fid]).max()
+            worst["pose"] = max(worst["pose"], e)
+            check(e < max(POSE_TOL, FACTOR * run["pose"]), (k, fid, "pose", e, run["pose"]))
+        e_s, n_s = abs(vg["scale"] - vo["scale"]) * 200, abs(vo["scale"] - vt["scale"]) * 200
+        run["scale"] = max(run["scale"], n_s)
+        worst["scale"] = max(worst["scale"], e_s)
+        check(e_s < max(SCALE_TOL, FACTOR * run["scale"]), (k, "scale", e_s, run["scale"]))
+        assert set(vg["states"]) == set(vo["states"])
+        for fid in vg["states"]:
+            sg, so, st = (dev.vio_scaled(v["states"][fid]) for v in (vg, vo, vt))
+            run["state"] = max(run["state"], np.abs(so - st).max())
+            run["vel"] = max(run["vel"], np.abs(vo["vel"][fid] - vt["vel"][fid]).max())
+        for fid in vg["states"]:
+            sg, so = dev.vio_scaled(vg["states"][fid]), dev.vio_scaled(vo["states"][fid])
+            e = np.abs(sg - so).max()
+            worst["state"] = max(worst["state"], e)
+            check(e < max(STATE_TOL, FACTOR * run["state"]), (k, fid, "state_imu", e, run["state"]))
+            ev = np.abs(vg["vel"][fid] - vo["vel"][fid]).max()
+            worst["vel"] = max(worst["vel"], ev)
+            check(ev < max(VEL_TOL, FACTOR * run["vel"]), (k, fid, "vel", ev, run["vel"]))
+        assert [f for f, _ in lg.marginalized] == [f for f, _ in lo.marginalized], k
+        for (fid, pg), (_, po), (_, pt) in zip(lg.marginalized, lo.marginalized, lt.marginalized):
+            e_go, e_ot = np.abs(pg - po).max(), np.abs(po - pt).max()
+            worst["leave"], worst["leave_noise"] = max(worst["leave"], e_go), max(worst["leave_noise"], e_ot)
+            left += 1
+            check(e_go < max(POSE_TOL, FACTOR * run["pose"]), (fid, "leaves", e_go, run["pose"]))
+        if vg["HMi"] is not None:
+            assert vg["HMi"].shape == vo["HMi"].shape
+            eg = np.abs(_scaled(vg["HMi"] - vt["HMi"], vt["HMi"])).max()
+            eo = np.abs(_scaled(vo["HMi"] - vt["HMi"], vt["HMi"])).max()
+            m = np.abs(_scaled(vt["HMi"], vt["HMi"])).max()
+            run["HM"] = max(run["HM"], eo)
+            check(eg <= FACTOR * run["HM"] + 2e-3 * m, (k, "HMi", eg, eo, m))
+        print(f"KF {k}: its {lg.iterations}/{lo.iterations} rmse {lg.rmse:.5f}/{lo.rmse:.5f}; scale {vg['scale'] * 200:.6f}/{vo['scale'] * 200:.6f}/{vt['scale'] * 200:.6f} "
+              f"trapped {vg['trapped']}; flagged {lg.flagged}; leaves {[f for f, _ in lg.marginalized]}; running oracle-vs-truth: pose {run['pose']:.2e} "
+              f"scale {run['scale']:.2e} state {run['state']:.2e} vel {run['vel']:.2e}")
+    print(f"{left} keyframes left; worst |dev-orc|: window pose {worst['pose']:.2e}, leaving pose {worst['leave']:.2e} (oracle fp32-vs-fp64 "
+          f"{worst['leave_noise']:.2e}), scale {worst['scale']:.2e}, scaled IMU state {worst['state']:.2e}, velocity {worst['vel']:.2e}; "
+          f"final scale {vg['scale'] * 200:.5f} (true {sc.scale_true})")
+    print("violations:", bad)
+    dev.close()
+    assert not bad, bad
+    assert its_diff <= 2, its_diff
+    assert left >= 10 and vg["init"] == 1
+    assert abs(vg["scale"] - vo["scale"]) * 200 < 5e-3 and abs(vo["scale"] * 200 - sc.scale_true) < 0.2

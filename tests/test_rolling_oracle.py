@@ -27,3 +27,34 @@ def test_oracle_chain_slides_the_window():
     for fid, pose in left:
         assert np.abs(pose - sc.poses[fid]).max() < 2e-3
     assert ch.n() <= 7 and 0 in ch.window_ids()                          # frame 0 carries the gauge and is never picked by distance
+
+
+def test_oracle_chain_visual_inertial():
+    """The same harness in visual-inertial mode (configs 2-3 in synthetic form): IMU samples generated from the rendered
+    trajectory (metric scale 1, a constant gyroscope bias), initializeImu at the fifth keyframe, propagateImuState for every later
+    keyframe, the IMU branch of solveSystemF in every optimize(), the expanded prior through marginalizePointsF and the IMU form of
+    marginalizeFrame, updateVel / tryTrapScale after every optimisation.  The chain must recover what generated the data."""
+    from sos_slam_amd.records import imu_dim
+    sc = rolling.Scenario(n_frames=14, vio=True)
+    ch = rolling.OracleChain(sc)
+    ch.bootstrap()
+    left, scales = [], []
+    while ch.next_frame < sc.n_frames:
+        lg = ch.step()
+        v = lg.vio
+        assert v["init"] == 1
+        scales.append(v["scale"] * 200.0)
+        assert abs(scales[-1] - sc.scale_true) < 0.05                   # metric scale from the accelerometer
+        bg = np.array([x[3:6] for x in v["states"].values()])          # gyroscope bias (SCALE_BG = 1) of the keyframes that stay
+        assert np.abs(bg - sc.bias_g).max() < 2e-3
+        assert v["HMi"].shape == (imu_dim(ch.n()),) * 2
+        assert np.isfinite(v["HMi"]).all() and np.isfinite(v["bMi"]).all()
+        gt = rolling.se3_mul(rolling.se3_inv(sc.poses[lg.frameID]), sc.poses[lg.frameID - 1])
+        assert np.abs(lg.tracked_pose - gt).max() < 2e-3
+        for fid in lg.window_ids:
+            assert np.abs(lg.window_poses[fid] - sc.poses[fid]).max() < 5e-3 + 0.03 * np.abs(sc.poses[fid][9:]).max()   # monocular gauge drift
+        left += lg.marginalized
+    assert len(left) >= 5
+    assert np.abs(np.array(scales[-4:]) - sc.scale_true).max() < 0.05
+    vel_true = (sc.poses[sc.n_frames - 1][9:] - sc.poses[sc.n_frames - 2][9:]) / sc.dt
+    assert np.abs(ch.shells[sc.n_frames - 1]["vel"] - vel_true).max() < 0.2 * np.abs(vel_true).max() + 0.05
