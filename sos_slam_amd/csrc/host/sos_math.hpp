@@ -291,6 +291,76 @@ __attribute__((target("avx2,fma"))) inline void ldlt_trailing_update(double *U, 
     }
   }
 }
+// The same update with 512-bit vectors where the host has them (the bench host is a Zen 5 EPYC): the whole panel of eight columns
+// in one pass -- 24 broadcast registers + 3 accumulators + 1 operand of the 32 zmm registers -- and masked tails instead of scalar
+// remainders.  Per element the operations are the ones of the 256-bit version in the same order (a chain of fnmadd over the
+// panel columns, ascending).
+__attribute__((target("avx512f,fma"))) inline void ldlt_trailing_update_512(double *U, const double *WT, const double *LT, int n, int k1, int kb) {
+  const size_t N = (size_t)n;
+  int j = k1;
+  for (; j + 2 < n; j += 3) {
+    double *r0 = U + (size_t)j * N, *r1 = r0 + N, *r2 = r1 + N;
+    {
+      double s01 = 0, s02 = 0, s12 = 0;
+      for (int c = 0; c < kb; c++) {
+        const double l0 = LT[c * N + j], l1 = LT[c * N + j + 1];
+        s01 += l0 * WT[c * N + j + 1];
+        s02 += l0 * WT[c * N + j + 2];
+        s12 += l1 * WT[c * N + j + 2];
+      }
+      r0[j + 1] -= s01;
+      r0[j + 2] -= s02;
+      r1[j + 2] -= s12;
+    }
+    __m512d l0[8], l1[8], l2[8];
+    const double *w[8];
+    for (int c = 0; c < 8; c++) {
+      const bool on = c < kb;
+      l0[c] = _mm512_set1_pd(on ? LT[c * N + j] : 0.0);
+      l1[c] = _mm512_set1_pd(on ? LT[c * N + j + 1] : 0.0);
+      l2[c] = _mm512_set1_pd(on ? LT[c * N + j + 2] : 0.0);
+      w[c] = WT + (size_t)(on ? c : 0) * N;
+    }
+    for (int i = j + 3; i < n; i += 8) {
+      const __mmask8 m = (n - i >= 8) ? (__mmask8)0xff : (__mmask8)((1u << (n - i)) - 1u);
+      __m512d a0 = _mm512_maskz_loadu_pd(m, r0 + i), a1 = _mm512_maskz_loadu_pd(m, r1 + i), a2 = _mm512_maskz_loadu_pd(m, r2 + i);
+#pragma GCC unroll 8
+      for (int c = 0; c < 8; c++) {
+        const __m512d wv = _mm512_maskz_loadu_pd(m, w[c] + i);
+        a0 = _mm512_fnmadd_pd(l0[c], wv, a0);
+        a1 = _mm512_fnmadd_pd(l1[c], wv, a1);
+        a2 = _mm512_fnmadd_pd(l2[c], wv, a2);
+      }
+      _mm512_mask_storeu_pd(r0 + i, m, a0);
+      _mm512_mask_storeu_pd(r1 + i, m, a1);
+      _mm512_mask_storeu_pd(r2 + i, m, a2);
+    }
+  }
+  for (; j + 1 < n; j++) {
+    double *r0 = U + (size_t)j * N;
+    for (int i = j + 1; i < n; i++) {
+      double s0 = 0;
+      for (int c = 0; c < kb; c++) s0 += LT[c * N + j] * WT[c * N + i];
+      r0[i] -= s0;
+    }
+  }
+}
+// column k of a panel brought up to date with its q earlier pivots, 512-bit form of the loop inside ldlt_solve
+__attribute__((target("avx512f,fma"))) inline void ldlt_column_update_512(const double *uk, const double *WT, const double *LT, double *wt, int n, int k, int q) {
+  const size_t N = (size_t)n;
+  __m512d lk[LDLT_NB];
+  for (int c = 0; c < q; c++) lk[c] = _mm512_set1_pd(LT[c * N + k]);
+  for (int i = k + 1; i < n; i += 8) {
+    const __mmask8 m = (n - i >= 8) ? (__mmask8)0xff : (__mmask8)((1u << (n - i)) - 1u);
+    __m512d a = _mm512_maskz_loadu_pd(m, uk + i);
+    for (int c = 0; c < q; c++) a = _mm512_fnmadd_pd(_mm512_maskz_loadu_pd(m, &WT[c * N + i]), lk[c], a);
+    _mm512_mask_storeu_pd(wt + i, m, a);
+  }
+}
+inline bool ldlt_have_avx512() {
+  static const bool have = __builtin_cpu_supports("avx512f") && getenv("SOS_NO_AVX512") == nullptr;
+  return have;
+}
 __attribute__((target("avx2,fma"))) inline void ldlt_solve(const std::vector<double> &A, const std::vector<double> &b, std::vector<double> &x, int n) {
   const size_t N = (size_t)n;
   static thread_local std::vector<double> U, D, y, diag, WT, LT;
@@ -330,7 +400,9 @@ __attribute__((target("avx2,fma"))) inline void ldlt_solve(const std::vector<dou
         continue;
       }
       // bring column k (rows below the diagonal) up to date with the q earlier pivots of the panel
-      {
+      if (ldlt_have_avx512()) {
+        ldlt_column_update_512(uk, WT.data(), LT.data(), wt, n, k, q);
+      } else {
         int i = k + 1;
         __m256d lk[LDLT_NB];
         for (int c = 0; c < q; c++) lk[c] = _mm256_set1_pd(LT[c * N + k]);
@@ -353,7 +425,10 @@ __attribute__((target("avx2,fma"))) inline void ldlt_solve(const std::vector<dou
         diag[i] -= a * l;
       }
     }
-    if (k1 < n) ldlt_trailing_update(U.data(), WT.data(), LT.data(), n, k1, kb);
+    if (k1 < n) {
+      if (ldlt_have_avx512()) ldlt_trailing_update_512(U.data(), WT.data(), LT.data(), n, k1, kb);
+      else ldlt_trailing_update(U.data(), WT.data(), LT.data(), n, k1, kb);
+    }
   }
   for (int i = 0; i < n; i++) y[i] = b[i];
   for (int k = 0; k < n; k++) {  // L z = P b, column-oriented: L(i,k) = U[k][i]
