@@ -37,8 +37,16 @@ def _symdiff(a, b):
     return len(set(a) ^ set(b))
 
 
-def test_rolling_window_marginalised_poses_and_index_sets():
-    sc = rolling.Scenario(n_frames=26)
+GEOMETRIES = {
+    "qvga": dict(n_frames=26),
+    # EuRoC cam0 geometry at full size, the reference's default point densities (2000 active, 1500 immature per keyframe)
+    "euroc_752x480": dict(w=752, h=480, n_frames=16, points0=1200, desired_points=2000.0, immature_density=1500.0),
+}
+
+
+@pytest.mark.parametrize("geom", list(GEOMETRIES))
+def test_rolling_window_marginalised_poses_and_index_sets(geom):
+    sc = rolling.Scenario(**GEOMETRIES[geom])
     dev, orc_, tru = rolling.DeviceChain(sc), rolling.OracleChain(sc), rolling.OracleChain(sc, truth=True)
     boots = [c.bootstrap() for c in (dev, orc_, tru)]
     assert boots[0][1] == boots[1][1] and abs(boots[0][0] - boots[1][0]) <= 1e-5 * boots[1][0]
@@ -116,6 +124,8 @@ def test_rolling_window_marginalised_poses_and_index_sets():
           f"index sets identical through keyframe {identical_until - 1 if identical_until else sc.n_frames - 1}; totals {tot}")
     print('violations:', bad)
     assert not bad, bad
-    assert left >= 18
-    assert identical_until is None or identical_until > sc.n0      # at least the first rolled keyframe is identical in every set
+    assert left >= (18 if geom == "qvga" else 6)
+    if geom == "qvga":      # 264 candidates at the first rolled keyframe: identical in every set.  At 752x480 the same keyframe has 2 456
+        # activations, and 26 of them are knife edges -- 22 between the two oracle chains
+        assert identical_until is None or identical_until > sc.n0
     dev.close()
