@@ -37,6 +37,8 @@ GEOMETRIES = {
     # the EuRoC cam0 geometry at full size with the reference's default densities (setting_desiredPointDensity 2000,
     # setting_desiredImmatureDensity 1500): BASELINE config 2 in synthetic form
     "euroc_752x480": dict(w=752, h=480, n_frames=16, points0=1200, desired_points=2000.0, immature_density=1500.0),
+    # TUM-VI geometry (BASELINE config 3): 512 x 512, four pyramid levels
+    "tumvi_512x512": dict(w=512, h=512, n_frames=14, points0=1000, desired_points=2000.0, immature_density=1500.0),
 }
 
 
@@ -108,5 +110,5 @@ def test_rolling_window_visual_inertial(geom):
     dev.close()
     assert not bad, bad
     assert its_diff <= 2, its_diff
-    assert left >= (10 if geom == "qvga" else 6) and vg["init"] == 1
+    assert left >= (10 if geom == "qvga" else 5) and vg["init"] == 1
     assert abs(vg["scale"] - vo["scale"]) * 200 < 5e-3 and abs(vo["scale"] * 200 - sc.scale_true) < 0.2
