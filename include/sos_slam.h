@@ -439,11 +439,13 @@ int sos_tracker_track(sos_tracker *trk, int newSlot, const float *Ki, float ref_
                       const double *refAff, int coarsestLvl, const double *minResForAbort /*5*/, int nHyp,
                       sos_track_hyp *hyp);
 
-/* ScaleOptimizer::optimizeScale (FS/ScaleOptimizer.cpp:120-230) as one launch of the same device loop: RKi = rot(tfmF0ToF1) *
- * Ki[lvl] per level (9 floats each), t = trans(tfmF0ToF1), K1 = (fx1, fy1, cx1, cy1) per level; *scale is in / out,
- * lastResiduals (5, NaN for levels not visited) and the number of residual evaluations are optional outputs. */
+/* ScaleOptimizer::optimizeScale (FS/ScaleOptimizer.cpp:120-230) as one launch of the same device loop, for nHyp initial scales
+ * side by side (FullSystem::optimizeScale tries seven of them until the scale is trapped, FS/FullSystem.cpp:1135-1148): RKi =
+ * rot(tfmF0ToF1) * Ki[lvl] per level (9 floats each), t = trans(tfmF0ToF1), K1 = (fx1, fy1, cx1, cy1) per level; scales[nHyp] is
+ * in / out, lastResiduals (nHyp x 5, NaN for levels not visited; [5 k] is hypothesis k's return value of optimizeScale) and the
+ * total number of residual evaluations are optional outputs. */
 int sos_tracker_optimize_scale(sos_tracker *trk, int stereoSlot, const float *RKi, const float *t, const float *K1,
-                               int coarsestLvl, float *scale, double *lastResiduals, int *evals);
+                               int coarsestLvl, int nHyp, float *scales, double *lastResiduals, int *evals);
 
 /* ScaleOptimizer::calcResScale / calcGSSSEScale (FS/ScaleOptimizer.cpp:273-437, 232-271).
  * RKi = rot(tfmF0ToF1) * Ki[lvl], t = trans(tfmF0ToF1); K1 = (fx1,fy1,cx1,cy1) of level `lvl`. */

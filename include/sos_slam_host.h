@@ -175,6 +175,14 @@ sos_tracker *sosf_tracker_handle(sosf_tracker *trk);
 /* trackNewestCoarse (FS/CoarseTracker.cpp:366-552); lastToNew12 / aff2 are in/out */
 int sosf_tracker_track(sosf_tracker *trk, int newSlot, float new_ab_exposure, double *lastToNew12, double *aff2,
                        int coarsestLvl, const double *minResForAbort5, double *lastResiduals5, double *flow3, int *ok);
+/* FullSystem::optimizeScale(scale_optimizer) (FS/FullSystem.cpp:1117-1177, called from makeKeyFrame :897-903): while the scale is
+ * not trapped the seven guesses {0.1, 0.2, 0.5, 1, 2, 5, 10} are optimised -- side by side in one launch -- and the smallest positive
+ * error wins; once trapped, one run from trackingRefScale (frameHessians.back()->shell->trackingRef->scale).  state2 = {scaleTrapped,
+ * scale_opt_fails} of the reference, kept by the caller; thres = setting_scale_opt_thres.  *new_scale = the accepted scale or -1
+ * (rejected: error not in (0, thres)); the caller then does HCalib.setScaleScaledZero(new_scale) if it is positive. */
+int sosf_tracker_optimize_scale_kf(sosf_tracker *trk, int stereoSlot, const double *tfmF0ToF1_12, const float *K1_level0,
+                                   float trackingRefScale, int coarsestLvl, float thres, int32_t *state2, float *new_scale,
+                                   float *scale_error);
 /* The LM loop of trackNewestCoarse / pose_estimate runs on the device as one launch (sos_tracker_track, include/sos_slam.h)
  * by default; 0 selects the loop on the host with one device round trip per residual evaluation (same decisions, same
  * arithmetic per pixel; the two differ by the rounding of the 8x8 solve).  last_evals: residual evaluations of the last call. */

@@ -788,6 +788,31 @@ def track_new_coarse(tracker, new_dI, ref_ab, new_ab, ref_aff, tries, aff_last, 
     return dict(lastF_2_fh=best_T, aff=best_aff, achievedRes=achieved, flow=flow, tryIterations=its, chosen=chosen, haveOneGood=have)
 
 
+def optimize_scale_kf(tracker, stereo_dI, tfm12, K1, tracking_ref_scale, coarsest, thres, state):
+    """FullSystem::optimizeScale (FS/FullSystem.cpp:1117-1177) around OracleTracker.optimize_scale, one guess after the other.
+    state = [scaleTrapped, scale_opt_fails] (updated in place).  Returns (new_scale or -1, scale_error)."""
+    if thres <= 0:
+        return 1.0, -1.0
+    new_scale, err = np.float32(1.0), np.float32(-1.0)
+    if state[0]:
+        e, s = tracker.optimize_scale(stereo_dI, tfm12, K1, float(np.float32(tracking_ref_scale)), coarsest)
+        new_scale, err = np.float32(s), np.float32(e)
+    else:
+        for g in (0.1, 0.2, 0.5, 1, 2, 5, 10):
+            e, s = tracker.optimize_scale(stereo_dI, tfm12, K1, float(np.float32(g)), coarsest)
+            if e > 0 and (err < 0 or err > e):
+                new_scale, err = np.float32(s), np.float32(e)
+    ok = 0 < err < thres
+    state[1] = 0 if ok else state[1] + 1
+    if state[1] > 5:
+        state[0] = 0
+    if not ok:
+        return -1.0, float(err)
+    if not state[0]:
+        state[0] = 1
+    return float(new_scale), float(err)
+
+
 def imu():
     """The oracle's IMU / spline factor assembly (orc_imu_*), same call surface as sos_slam_amd.host.imu()."""
     from sos_slam_amd.host import _ImuApi

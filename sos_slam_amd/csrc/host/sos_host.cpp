@@ -2031,6 +2031,52 @@ bool CoarseTracker::poseEstimate(int newSlot, float new_ab_exposure, SE3 &refToN
   return aff_good && low_res && enough_inlier;
 }
 
+int CoarseTracker::optimizeScaleHyp(int stereoSlot, const SE3 &tfmF0ToF1, const float *K1_0, int n, float *scales, float *errors, int coarsestLvl) {
+  if (n < 1) return SOS_ERR_ARG;
+  if (!deviceLM) {
+    for (int k = 0; k < n; k++) errors[k] = optimizeScale(stereoSlot, tfmF0ToF1, K1_0, scales[k], coarsestLvl);
+    return SOS_OK;
+  }
+  float RKiAll[SOS_PYR_LEVELS * 9], K1All[SOS_PYR_LEVELS * 4], tf[3];
+  for (int l = 0; l < levels; l++) {  // FS/ScaleOptimizer.cpp:66-76
+    rki_of(tfmF0ToF1, Ki[l], RKiAll + 9 * l, tf);
+    K1All[4 * l] = l == 0 ? K1_0[0] : K1All[4 * (l - 1)] * 0.5f;
+    K1All[4 * l + 1] = l == 0 ? K1_0[1] : K1All[4 * (l - 1) + 1] * 0.5f;
+    K1All[4 * l + 2] = l == 0 ? K1_0[2] : (float)((K1_0[2] + 0.5) / ((int)1 << l) - 0.5);
+    K1All[4 * l + 3] = l == 0 ? K1_0[3] : (float)((K1_0[3] + 0.5) / ((int)1 << l) - 0.5);
+  }
+  std::vector<double> lr((size_t)5 * n);
+  const int rc = sos_tracker_optimize_scale(trk, stereoSlot, RKiAll, tf, K1All, coarsestLvl, n, scales, lr.data(), &lastEvals);
+  if (rc != SOS_OK) return rc;
+  for (int k = 0; k < n; k++) errors[k] = (float)lr[(size_t)5 * k];
+  return SOS_OK;
+}
+
+float CoarseTracker::optimizeScaleKF(int stereoSlot, const SE3 &tfmF0ToF1, const float *K1_0, float trackingRefScale, int coarsestLvl, float thres,
+                                     ScaleOptState &st, float *scale_error_out) {
+  if (thres <= 0) return 1.0;
+  float new_scale = 1.0, scale_error = -1;
+  if (st.scaleTrapped) {
+    new_scale = trackingRefScale;
+    if (optimizeScaleHyp(stereoSlot, tfmF0ToF1, K1_0, 1, &new_scale, &scale_error, coarsestLvl) != SOS_OK) scale_error = -1;
+  } else {
+    float guess[7] = {0.1f, 0.2f, 0.5f, 1, 2, 5, 10}, err[7];
+    if (optimizeScaleHyp(stereoSlot, tfmF0ToF1, K1_0, 7, guess, err, coarsestLvl) == SOS_OK)
+      for (int k = 0; k < 7; k++)
+        if (err[k] > 0 && (scale_error < 0 || scale_error > err[k])) {
+          new_scale = guess[k];
+          scale_error = err[k];
+        }
+  }
+  const bool succeed = (0 < scale_error) && (scale_error < thres);
+  st.fails = succeed ? 0 : st.fails + 1;  // when it fails continuously the scale is re-initialised
+  if (st.fails > 5) st.scaleTrapped = 0;
+  if (scale_error_out) *scale_error_out = scale_error;
+  if (!succeed) return -1.0f;
+  if (!st.scaleTrapped) st.scaleTrapped = 1;
+  return new_scale;
+}
+
 float CoarseTracker::optimizeScale(int stereoSlot, const SE3 &tfmF0ToF1, const float *K1_0, float &scale, int coarsestLvl) {
   double last_residuals[5] = {NAN, NAN, NAN, NAN, NAN};
   const int maxIterations[] = {10, 20, 50, 50, 50};
@@ -2052,7 +2098,7 @@ float CoarseTracker::optimizeScale(int stereoSlot, const SE3 &tfmF0ToF1, const f
       K1All[4 * l] = fx1[l]; K1All[4 * l + 1] = fy1[l]; K1All[4 * l + 2] = cx1[l]; K1All[4 * l + 3] = cy1[l];
     }
     float s = scale;
-    if (sos_tracker_optimize_scale(trk, stereoSlot, RKiAll, tf, K1All, coarsestLvl, &s, last_residuals, &lastEvals) != SOS_OK) return NAN;
+    if (sos_tracker_optimize_scale(trk, stereoSlot, RKiAll, tf, K1All, coarsestLvl, 1, &s, last_residuals, &lastEvals) != SOS_OK) return NAN;
     scale = s;
     return (float)last_residuals[0];
   }
@@ -2522,6 +2568,18 @@ extern "C" int sosf_tracker_track(sosf_tracker *t, int newSlot, float new_ab_exp
   aff2[1] = aff.b;
   if (flow3) for (int i = 0; i < 3; i++) flow3[i] = t->ct->lastFlowIndicators[i];
   if (ok) *ok = good ? 1 : 0;
+  return SOS_OK;
+}
+extern "C" int sosf_tracker_optimize_scale_kf(sosf_tracker *t, int stereoSlot, const double *tfmF0ToF1_12, const float *K1_level0,
+                                              float trackingRefScale, int coarsestLvl, float thres, int32_t *state2, float *new_scale,
+                                              float *scale_error) {
+  if (!t || !tfmF0ToF1_12 || !K1_level0 || !state2 || !new_scale) return SOS_ERR_ARG;
+  CoarseTracker::ScaleOptState st;
+  st.scaleTrapped = state2[0];
+  st.fails = state2[1];
+  *new_scale = t->ct->optimizeScaleKF(stereoSlot, SE3::from12(tfmF0ToF1_12), K1_level0, trackingRefScale, coarsestLvl, thres, st, scale_error);
+  state2[0] = st.scaleTrapped;
+  state2[1] = st.fails;
   return SOS_OK;
 }
 extern "C" int sosf_tracker_set_device_lm(sosf_tracker *t, int on) {

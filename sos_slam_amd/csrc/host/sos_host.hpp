@@ -328,6 +328,17 @@ class CoarseTracker {
   bool trackNewestCoarse(int newSlot, float new_ab_exposure, SE3 &lastToNew_out, AffLight &aff_g2l_out, int coarsestLvl,
                          const double *minResForAbort5, double *lastResiduals5);   // :366-552
   float optimizeScale(int stereoSlot, const SE3 &tfmF0ToF1, const float *K1_level0, float &scale, int coarsestLvl);  // FS/ScaleOptimizer.cpp:120-230
+  // FullSystem::optimizeScale (FS/FullSystem.cpp:1117-1177): until the scale is trapped the seven guesses {0.1 ... 10} are optimised
+  // (side by side in one launch of the device loop) and the one with the smallest positive error wins; afterwards one run from
+  // the tracking reference's scale.  state = the function's scaleTrapped / static scale_opt_fails.  Returns the new scale, or -1
+  // when the error is not below `thres` (setting_scale_opt_thres)
+  struct ScaleOptState {
+    int scaleTrapped = 0, fails = 0;
+  };
+  float optimizeScaleKF(int stereoSlot, const SE3 &tfmF0ToF1, const float *K1_level0, float trackingRefScale, int coarsestLvl, float thres,
+                        ScaleOptState &state, float *scale_error_out);
+  // n initial scales -> n optimised scales and their optimizeScale() return values
+  int optimizeScaleHyp(int stereoSlot, const SE3 &tfmF0ToF1, const float *K1_level0, int n, float *scales, float *errors, int coarsestLvl);
   // the pose hypotheses of FullSystem::trackNewCoarse (FS/FullSystem.cpp:150-213): IMU prediction (optional), constant /
   // double / half / zero motion, zero motion from the keyframe, then 26 rotation signs x 3 magnitudes around the constant-
   // motion guess; one identity try when a pose is not valid

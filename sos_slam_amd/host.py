@@ -77,6 +77,7 @@ def load():
     L.sosf_tracker_track.argtypes = [vp, ci, C.c_float, vp, vp, ci, vp, vp, vp, C.POINTER(ci)]
     L.sosf_write_poses.argtypes = [C.c_char_p, ci, vp, vp]
     L.sosf_tracker_set_device_lm.argtypes = [vp, ci]
+    L.sosf_tracker_optimize_scale_kf.argtypes = [vp, ci, vp, vp, C.c_float, ci, C.c_float, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.sosf_tracker_last_evals.argtypes = [vp, C.POINTER(ci)]
     L.sosf_tracker_make_tries.argtypes = [vp, vp, vp, ci, ci, vp, C.POINTER(ci)]
     L.sosf_tracker_track_hypotheses.argtypes = [vp, ci, C.c_float, ci, vp, vp, ci, vp, C.c_double, ci, vp, vp, vp, vp, vp]
@@ -485,6 +486,18 @@ class HostTracker:
         _chk(self.L.sosf_tracker_track(self.h_, newSlot, new_ab_exposure, _p(T), _p(aff), coarsest, _p(mr), _p(lr), _p(fl),
                                        C.byref(ok)), "sosf_tracker_track")
         return bool(ok.value), T, aff, lr, fl
+
+    def optimize_scale_kf(self, stereoSlot, tfm12, K1, tracking_ref_scale, coarsest, thres, state):
+        """FullSystem::optimizeScale (FS/FullSystem.cpp:1117-1177); state = [scaleTrapped, scale_opt_fails], updated in place.
+        Returns (new_scale or -1, scale_error)."""
+        tf = np.ascontiguousarray(tfm12, dtype=np.float64)
+        k1 = np.ascontiguousarray(K1, dtype=np.float32)
+        st = np.ascontiguousarray(state, dtype=np.int32)
+        ns, er = C.c_float(0), C.c_float(0)
+        _chk(self.L.sosf_tracker_optimize_scale_kf(self.h_, stereoSlot, _p(tf), _p(k1), float(tracking_ref_scale), coarsest, float(thres), _p(st),
+                                                   C.byref(ns), C.byref(er)), "sosf_tracker_optimize_scale_kf")
+        state[0], state[1] = int(st[0]), int(st[1])
+        return ns.value, er.value
 
     def set_device_lm(self, on: bool):
         """LM loop of track / pose_estimate as one device launch (default) or on the host around device residual passes."""

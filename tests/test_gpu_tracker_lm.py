@@ -215,3 +215,37 @@ def test_scale_loop_on_device_equals_host_loop(rig, s0):
     assert abs(sd - so) <= max(2 * abs(so - stt), 2e-5 * so)
     assert rd == pytest.approx(ro, rel=1e-4)
     sysm.release_image(slot)
+
+
+def test_optimize_scale_keyframe_function(rig):
+    """FullSystem::optimizeScale (FS/FullSystem.cpp:1117-1177): the seven scale guesses side by side in one launch until the
+    scale is trapped, then single runs from the tracking reference's scale; rejection above setting_scale_opt_thres and the
+    re-initialisation after six failures -- against the oracle's one-by-one restatement, and against the facade's own host loop."""
+    win, sysm, ht, levels = rig["win"], rig["sysm"], rig["ht"], rig["levels"]
+    st_dI, _ = orc.make_images(win.extra_images[1])
+    slot = sysm.upload_image(win.extra_images[1])
+    K1 = rig["ow"].calib_value_scaled().astype(np.float32)
+    sg, so, sh = [0, 0], [0, 0], [0, 0]
+    # not trapped: seven guesses
+    ng, eg = ht.optimize_scale_kf(slot, win.stereo_tfm, K1, 1.0, levels - 1, 12.0, sg)
+    no, eo = orc.optimize_scale_kf(rig["ot"], st_dI, win.stereo_tfm, K1, 1.0, levels - 1, 12.0, so)
+    ht.set_device_lm(False)
+    nh, eh = ht.optimize_scale_kf(slot, win.stereo_tfm, K1, 1.0, levels - 1, 12.0, sh)
+    ht.set_device_lm(True)
+    print(f"{rig['key']}: seven guesses -> scale {ng:.6f} / oracle {no:.6f} / host loop {nh:.6f}; error {eg:.5f} / {eo:.5f}; state {sg} {so}")
+    assert sg == so == sh == [1, 0]
+    assert (ng, eg) == (nh, eh)                                   # all-fp32 loop: device == host loop bit for bit
+    assert abs(ng - no) <= 1e-4 * no and eg == pytest.approx(eo, rel=1e-4)
+    assert abs(ng - 1.0) < 0.05
+    # trapped: one run from the reference's scale
+    ng2, eg2 = ht.optimize_scale_kf(slot, win.stereo_tfm, K1, ng, levels - 1, 12.0, sg)
+    no2, eo2 = orc.optimize_scale_kf(rig["ot"], st_dI, win.stereo_tfm, K1, no, levels - 1, 12.0, so)
+    assert sg == so == [1, 0] and abs(ng2 - no2) <= 1e-4 * no2 and eg2 == pytest.approx(eo2, rel=1e-4)
+    # an impossible threshold: rejected six times -> the scale is released and the guesses come back
+    for k in range(6):
+        ng3, _ = ht.optimize_scale_kf(slot, win.stereo_tfm, K1, ng, levels - 1, 1e-3, sg)
+        no3, _ = orc.optimize_scale_kf(rig["ot"], st_dI, win.stereo_tfm, K1, no, levels - 1, 1e-3, so)
+        assert ng3 == no3 == -1.0 and sg == so
+    assert sg == [0, 6]
+    assert ht.optimize_scale_kf(slot, win.stereo_tfm, K1, 1.0, levels - 1, 0.0, sg)[0] == 1.0      # setting_scale_opt_thres <= 0
+    sysm.release_image(slot)
