@@ -53,9 +53,13 @@ class Scenario:
     window (what the initialiser would hand over: n0 keyframes at their true poses with noisy inverse depths)."""
 
     def __init__(self, w=320, h=240, n_frames=26, n0=4, points0=360, seed=synth.SEED + 77, step=0.07, noise_sigma=1.0,
-                 desired_points=1000.0, immature_density=450.0, vio=False):
+                 desired_points=1000.0, immature_density=450.0, vio=False, stereo=False):
         self.w, self.h, self.n_frames, self.n0 = w, h, n_frames, n0
-        self.vio = vio
+        self.vio, self.stereo = vio, stereo
+        self.scale_opt_thres = 12.0          # tests/EuRoC/euroc.launch: scale_opt_thres
+        self.raw_right = []
+        stereo_off = np.array([0.11, 0.0012, 0.0021])
+        self.stereo_tfm = np.concatenate([np.eye(3).reshape(-1), -stereo_off])   # tfmF0ToF1: p1 = R p0 + t
         self.desired_points, self.immature_density = desired_points, immature_density
         rng = np.random.default_rng(seed)
         s = w / 752.0
@@ -74,6 +78,10 @@ class Scenario:
             img, dep = self.scene.render(R, t, self.K, w, h)
             img = np.exp(a_i) * img + b_i + rng.normal(0, noise_sigma, img.shape)
             self.raw.append(np.clip(np.rint(img), 0, 255).astype(np.uint8))
+            if stereo:    # the stereo partner: same intrinsics, shifted by the baseline in the camera frame, same exposure
+                img1, _ = self.scene.render(R, t + R @ stereo_off, self.K, w, h)
+                img1 = np.exp(a_i) * img1 + b_i + rng.normal(0, noise_sigma, img1.shape)
+                self.raw_right.append(np.clip(np.rint(img1), 0, 255).astype(np.uint8))
             self.depth.append(dep)
             self.poses.append(np.concatenate([R.reshape(-1), t]))
             self.aff_true.append((a_i, b_i))
@@ -105,7 +113,7 @@ class Scenario:
         S.gravity[:] = [0.0, 9.81, 0.0]
         Ric = synth.so3_exp(np.array([0.1, -0.2, 0.05]))
         S.rot_imu_cam[:] = list(Ric.reshape(-1))
-        S.maxImuInterval, S.enable_scale_opt = 0.5, 0
+        S.maxImuInterval, S.enable_scale_opt = 0.5, int(self.stereo)
         self.imu_settings = S
         g = np.array(S.gravity[:])
         self.imu = [np.zeros((0, 7))]
@@ -272,6 +280,9 @@ class Chain:
         self.cal = dict(scale=1.0 / 200.0, scale_zero=1.0 / 200.0, trapped=0, init=0)
         self.scale_queue, self.scale_qi = np.linspace(-10, -100, 10), 0
         self.n_kf_total = 0
+        self.stereo = bool(getattr(sc, "stereo", False))
+        self.scale_state = [0, 0]     # FullSystem::scaleTrapped, scale_opt_fails
+        self.scale_log = []
 
     # ---- backend interface (implemented by DeviceChain / OracleChain)
     def n(self): raise NotImplementedError
@@ -295,6 +306,8 @@ class Chain:
         rmse, its = self.optimize(6)
         self.remove_outliers()
         self.tracker_set_ref()
+        if self.stereo:
+            self.scale_optimization(sc.n0 - 1)
         for i in range(sc.n0):      # makeNewTraces on every bootstrap keyframe: the sequence starts with candidates
             self.make_new_traces(i)
         self.last_rel = None
@@ -366,6 +379,8 @@ class Chain:
             if self.cal["init"]:                  # :459-479
                 self.vio_update_vel(ids2[-1], ids2[-2])
                 self.imu_zero[ids2[-1]] = self.imu_state[ids2[-1]].copy()
+                if self.sc.imu_settings.enable_scale_opt:     # FS/FullSystemOptimize.cpp:471-473
+                    self.cal["trapped"] = 1
                 if not self.cal["trapped"]:
                     self.vio_try_trap()
                     if self.cal["trapped"]:
@@ -379,6 +394,8 @@ class Chain:
                 if i > 0:
                     self.vio_update_vel(fid, ids2[i - 1])
         self.tracker_set_ref()
+        if self.stereo:               # scale optimization, FS/FullSystem.cpp:897-903
+            self.scale_optimization(k)
         nmarg, ndrop = self.flag_points_for_removal()
         point_set = self.point_set()
         nimm = self.make_new_traces(k)
@@ -403,6 +420,16 @@ class Chain:
 
     # ---- visual-inertial helpers shared by the chains (state layout and records); the arithmetic is per chain
     _IMU_K = np.repeat([100.0, 1.0, 100.0, 1000.0, 1000.0, 1000.0, 1000.0], 3)   # SCALE_BA, BG, SL_ROT, SQ_TRANS, SQ_ROT, SC_TRANS, SC_ROT
+
+    def scale_optimization(self, k):
+        """FullSystem::optimizeScale on the stereo partner of keyframe k; HCalib.setScaleScaledZero when it is accepted"""
+        h = self.front_end(self.sc.raw_right[k])
+        ref_scale = np.float32(200.0 * self.cal["scale"])      # shell->trackingRef->scale = HCalib.getScaleScaled() of the last optimize
+        new_scale, err = self.optimize_scale_kf(h, float(ref_scale))
+        self.release_plain(h)
+        self.scale_log.append((k, new_scale, err, list(self.scale_state)))
+        if new_scale > 0:
+            self.cal["scale"] = self.cal["scale_zero"] = float(np.float32(1.0) / np.float32(200.0)) * float(new_scale)
 
     def vio_scaled(self, state):
         return self._IMU_K * np.asarray(state, dtype=np.float64)
@@ -557,6 +584,13 @@ class DeviceChain(Chain):
         if self.trk is None:
             self.trk = self.host.HostTracker(self.sysm)
         self.trk.set_ref()
+
+    def optimize_scale_kf(self, slot, ref_scale):
+        K1 = np.asarray(self.K(), dtype=np.float32)
+        return self.trk.optimize_scale_kf(slot, self.sc.stereo_tfm, K1, ref_scale, self.ctx.levels - 1, self.sc.scale_opt_thres, self.scale_state)
+
+    def release_plain(self, slot):
+        self.sysm.release_image(slot)
 
     def track(self, slot, T_init, ref_aff):
         levels = self.ctx.levels
@@ -882,6 +916,14 @@ class OracleChain(Chain):
         self.trk.set_ref(Calib.from_K(self.K()), last.handle["dI"], np.array(u, np.float32), np.array(v, np.float32), np.array(idp, np.float32),
                          np.array(hdi, np.float32))
         self.trk_ref_aff = np.array(self.kf_aff(len(self.frames) - 1))
+
+    def optimize_scale_kf(self, h, ref_scale):
+        K1 = np.asarray(self.K(), dtype=np.float32)
+        return orc.optimize_scale_kf(self.trk, h["dI"], self.sc.stereo_tfm, K1, ref_scale, self.trk.levels - 1, self.sc.scale_opt_thres,
+                                     self.scale_state)
+
+    def release_plain(self, h):
+        pass
 
     def track(self, h, T_init, ref_aff):
         levels = self.trk.levels

@@ -58,3 +58,18 @@ def test_oracle_chain_visual_inertial():
     assert np.abs(np.array(scales[-4:]) - sc.scale_true).max() < 0.05
     vel_true = (sc.poses[sc.n_frames - 1][9:] - sc.poses[sc.n_frames - 2][9:]) / sc.dt
     assert np.abs(ch.shells[sc.n_frames - 1]["vel"] - vel_true).max() < 0.2 * np.abs(vel_true).max() + 0.05
+
+
+def test_oracle_chain_stereo_inertial():
+    """stereo-inertial: FullSystem::optimizeScale on the stereo partner of every keyframe gives the metric scale (trapped at the
+    first keyframe from the seven guesses), setting_enable_scale_opt semantics elsewhere"""
+    sc = rolling.Scenario(n_frames=10, vio=True, stereo=True)
+    ch = rolling.OracleChain(sc)
+    ch.bootstrap()
+    assert ch.scale_log[0][3] == [1, 0] and abs(ch.scale_log[0][1] - 1.0) < 0.02
+    while ch.next_frame < sc.n_frames:
+        lg = ch.step()
+        k, new_scale, err, st = ch.scale_log[-1]
+        assert k == lg.frameID and st == [1, 0] and 0 < err < sc.scale_opt_thres
+        assert abs(new_scale - sc.scale_true) < 0.02 and abs(lg.vio["scale"] * 200 - new_scale) < 1e-6
+        assert lg.vio["trapped"] == 1 and lg.vio["init"] == 1
