@@ -57,10 +57,16 @@ t_hyp_host = timeit(lambda: ht.track_hypotheses(st_slot, 1.0, tries, np.zeros(2)
 ht.set_device_lm(True)
 K1 = np.array(sysm.calib_value_scaled(), np.float32)
 t_scl = timeit(lambda: ht.optimize_scale(st_slot, win.stereo_tfm, K1, 1.2, levels - 1), 20)
+# FullSystem::optimizeScale before the scale is trapped: seven guesses (one launch on the device, one by one with the host loop)
+t_sc7 = timeit(lambda: ht.optimize_scale_kf(st_slot, win.stereo_tfm, K1, 1.0, levels - 1, 12.0, [0, 0]), 20)
+ht.set_device_lm(False)
+t_sc7_host = timeit(lambda: ht.optimize_scale_kf(st_slot, win.stereo_tfm, K1, 1.0, levels - 1, 12.0, [0, 0]), 5)
+ht.set_device_lm(True)
 out = {"window": name, "template_pixels_per_level": [int(x) for x in pc_n[:levels]],
        "gpu_ms": {"set_ref": t_set * 1e3, "track": t_trk * 1e3, "track_host_loop": t_trk_host * 1e3, "optimize_scale": t_scl * 1e3,
                   "track_83_hypotheses_batch16": t_hyp16 * 1e3, "track_83_hypotheses_batch1": t_hyp1 * 1e3,
-                  "track_83_hypotheses_host_loop": t_hyp_host * 1e3},
+                  "track_83_hypotheses_host_loop": t_hyp_host * 1e3,
+                  "optimize_scale_7_guesses": t_sc7 * 1e3, "optimize_scale_7_guesses_host_loop": t_sc7_host * 1e3},
        "residual_evaluations_per_track": evals, "us_per_evaluation": t_trk * 1e6 / max(evals, 1)}
 
 # oracle port on the host (single thread, as the reference's tracker is)
