@@ -225,3 +225,59 @@ def dense_system(J, active, resid, points, n, adHost, adTarget, cDeltaF):
     (void := cDeltaF)   # the calibration delta only enters through the L (linearised) residuals and the prior terms
     return dict(H_A=H_A, b_A=b_A, H_sc=H_sc, b_sc=b_sc, idepth_hessian=np.where(has, Hdd, 0.0), HdiF=Hdi,
                 bdSumF=np.where(has, bd, 0.0))
+
+
+# ------------------------------------------------------------------------------------------------
+# CoarseTracker::calcResPose + calcGSSSEPose (FS/CoarseTracker.cpp:612-764, 554-610) as ONE vectorised fp64 function: the energy /
+# counts of a pose, and the 8 x 8 system of the accepted pixels.  No warp buffers, no SSE accumulator: every template pixel
+# contributes w * j j^T with j = (8 Jacobian entries, residual), FS/CoarseTracker.cpp:571-591 + OB/MatrixAccumulators.h
+# (Accumulator9::updateSSE_eighted).
+# ------------------------------------------------------------------------------------------------
+def tracker_res_gs(pc_u, pc_v, pc_idepth, pc_color, dI, K4, R, t, affLL, b0, huber, cutoff, lvl0):
+    """pc_*: template pixels of the level; dI: (h, w, 3) new frame level; K4 = (fx, fy, cx, cy) of the level; (R, t) = refToNew;
+    affLL = (a, b) of fromToVecExposure; b0 = lastRef_aff_g2l.b.  Returns dict(E, numTermsInE, numWarped, numSaturated, flowT,
+    flowRT, H (8, 8), b (8)) -- H, b before the SCALE_* factors and with the reference's 1 / n (n = numWarped rounded up to 4)."""
+    x, y, idp, col = (np.asarray(a, dtype=np.float64) for a in (pc_u, pc_v, pc_idepth, pc_color))
+    fx, fy, cx, cy = (float(v) for v in K4)
+    hl, wl = dI.shape[:2]
+    Ki = np.array([[1 / fx, 0, -cx / fx], [0, 1 / fy, -cy / fy], [0, 0, 1]])
+    R = np.asarray(R, dtype=np.float64).reshape(3, 3)
+    t = np.asarray(t, dtype=np.float64)
+    ray = Ki @ np.stack([x, y, np.ones_like(x)])               # Ki * (x, y, 1)
+    pt = R @ ray + t[:, None] * idp
+    u, v = pt[0] / pt[2], pt[1] / pt[2]
+    Ku, Kv = fx * u + cx, fy * v + cy
+    new_id = idp / pt[2]
+    out = {}
+    if lvl0:       # flow indicators over every 32nd template pixel, :666-696
+        s = np.arange(len(x)) % 32 == 0
+        def proj(p):
+            return fx * p[0] / p[2] + cx, fy * p[1] / p[2] + cy
+        KuT, KvT = proj(ray[:, s] + t[:, None] * idp[s])
+        KuT2, KvT2 = proj(ray[:, s] - t[:, None] * idp[s])
+        Ku3, Kv3 = proj(R @ ray[:, s] - t[:, None] * idp[s])
+        sT = np.sum((KuT - x[s]) ** 2 + (KvT - y[s]) ** 2 + (KuT2 - x[s]) ** 2 + (KvT2 - y[s]) ** 2)
+        sRT = np.sum((Ku[s] - x[s]) ** 2 + (Kv[s] - y[s]) ** 2 + (Ku3 - x[s]) ** 2 + (Kv3 - y[s]) ** 2)
+        num = 2.0 * np.count_nonzero(s)
+        out["flowT"], out["flowRT"] = sT / (num + 0.1), sRT / (num + 0.1)
+    ok = (Ku > 2) & (Kv > 2) & (Ku < wl - 3) & (Kv < hl - 3) & (new_id > 0)
+    Ku, Kv, u, v, new_id, col = Ku[ok], Kv[ok], u[ok], v[ok], new_id[ok], col[ok]
+    hit = _interp33(np.asarray(dI, dtype=np.float64), Ku, Kv)
+    fin = np.isfinite(hit[:, 0])
+    hit, u, v, new_id, col = hit[fin], u[fin], v[fin], new_id[fin], col[fin]
+    r = hit[:, 0] - (affLL[0] * col + affLL[1])
+    hw = np.where(np.abs(r) < huber, 1.0, huber / np.maximum(np.abs(r), 1e-300))
+    sat = np.abs(r) > cutoff
+    maxE = 2 * huber * cutoff - huber * huber
+    out["E"] = float(np.sum(np.where(sat, maxE, hw * r * r * (2 - hw))))
+    out["numTermsInE"], out["numSaturated"] = int(len(r)), int(np.count_nonzero(sat))
+    g = ~sat
+    out["numWarped"] = int(np.count_nonzero(g))
+    dx, dy = hit[g, 1] * fx, hit[g, 2] * fy
+    u, v, idn, r, hw, col = u[g], v[g], new_id[g], r[g], hw[g], col[g]
+    J = np.stack([idn * dx, idn * dy, -idn * (u * dx + v * dy), -(u * v * dx + dy * (1 + v * v)), u * v * dy + dx * (1 + u * u),
+                  u * dy - v * dx, affLL[0] * (b0 - col), -np.ones_like(u), r], axis=1)
+    H9 = (J * hw[:, None]).T @ J
+    n = (out["numWarped"] + 3) // 4 * 4
+    out["H"], out["b"] = H9[:8, :8] / max(n, 1), H9[:8, 8] / max(n, 1)
+    return out

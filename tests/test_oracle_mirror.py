@@ -99,3 +99,56 @@ def test_precalc_linearize_and_system_agree_with_the_numpy_mirror(name, kw):
         xm = np.linalg.solve(d["H_A"] - d["H_sc"] + win.HM + reg, d["b_A"] - d["b_sc"])
         assert np.linalg.norm(xo - xm) <= 5e-3 * np.linalg.norm(xo)
     ow.close()
+
+
+@pytest.mark.parametrize("name,kw", [("T6", {}), ("W7", {}), ("T6", dict(w=154, h=46))])
+def test_tracker_residual_and_system_agree_with_the_numpy_mirror(name, kw):
+    """CoarseTracker::calcResPose / calcGSSSEPose (FS/CoarseTracker.cpp:554-764): the C restatement (orc_tracker.c; per-pixel fp32,
+    sums in fp64 -- its truth mode) against the vectorised fp64 reading in oracle/mirror_np.py, on every pyramid level, at the
+    true relative pose and at a perturbed one (pixels near the image border / the cutoff change sides between fp32 and fp64:
+    counts may differ by a few, sums by their share)."""
+    from sos_slam_amd.records import Calib
+    from sos_slam_amd.synth import se3_exp12, se3_mul12
+    win = synth.make_window(name, extra_frames=1, **kw)
+    ow = orc.window_from_synth(win)
+    ow.optimize(3)
+    res = ow.res()
+    sel = (res["target"] == win.n - 1) & ((res["flags"] & 0x101) == 1) & (res["state_state"] == synth.RES_IN)
+    c = ow.center()[sel]
+    hdi = ow.point_field("HdiF")[res["point"][sel]]
+    K0 = ow.calib_value_scaled()
+    t = orc.OracleTracker(win.params, win.w, win.h)
+    t.set_truth_mode(True)
+    t.set_ref(Calib.from_K(K0), ow.dI[win.n - 1], c[:, 0], c[:, 1], c[:, 2], hdi)
+    new_dI, _ = orc.make_images(win.extra_images[0])
+    ref, new = win.frames[win.n - 1]["camToWorld"], win.extra_poses[0]
+    Rr, tr, Rn, tn = ref[:9].reshape(3, 3), ref[9:], new[:9].reshape(3, 3), new[9:]
+    T0 = np.concatenate([(Rn.T @ Rr).reshape(-1), Rn.T @ (tr - tn)])
+    huber, cutoff = float(win.params["huberTH"]), float(win.params["coarseCutoffTH"])
+    for T in (T0, se3_mul12(se3_exp12(np.array([0.01, -0.008, 0.004, 0.004, -0.003, 0.002])), T0)):
+        for lvl in range(len(t.pc_n)):
+            if t.pc_n[lvl] == 0:
+                continue
+            fx, fy = np.float32(K0[0] / 2 ** lvl), np.float32(K0[1] / 2 ** lvl)
+            cx, cy = np.float32((K0[2] + 0.5) / 2 ** lvl - 0.5), np.float32((K0[3] + 0.5) / 2 ** lvl - 0.5)
+            Ki = np.array([[1 / fx, 0, -cx / fx], [0, 1 / fy, -cy / fy], [0, 0, 1]], dtype=np.float32)
+            RKi = (T[:9].reshape(3, 3).astype(np.float32) @ Ki).astype(np.float32)
+            aff = np.array([1.02, -0.7], np.float32)
+            rs = t.calc_res(lvl, new_dI[lvl], RKi, T[9:].astype(np.float32), aff, cutoff)
+            H, b = t.calc_gs(lvl, float(aff[0]), 0.3)
+            pu, pv, pid, pcol = t.get_pc(lvl)
+            m = mir.tracker_res_gs(pu, pv, pid, pcol, new_dI[lvl], (fx, fy, cx, cy), T[:9], T[9:], aff.astype(np.float64), 0.3, huber, cutoff,
+                                   lvl == 0)
+            nE = int(rs[1])
+            assert abs(m["numTermsInE"] - nE) <= 2 and nE > 0.5 * t.pc_n[lvl], (lvl, m["numTermsInE"], nE)
+            assert abs(m["numSaturated"] - round(rs[5] * nE)) <= 2
+            share = 3.0 * (2 * huber * cutoff) / max(rs[0], 1.0)          # what three border / cutoff pixels can move
+            assert abs(m["E"] - rs[0]) <= (2e-5 + share) * rs[0], (lvl, m["E"], rs[0])
+            if lvl == 0:
+                assert m["flowT"] == pytest.approx(rs[2], rel=1e-4) and m["flowRT"] == pytest.approx(rs[4], rel=1e-4)
+            # the oracle returns H, b with the SCALE_* factors applied (FS/CoarseTracker.cpp:597-609): undo them
+            sc = np.array([1.0, 1.0, 1.0, 0.5, 0.5, 0.5, 10.0, 1000.0])
+            Hm, bm = m["H"] * np.outer(sc, sc), m["b"] * sc
+            d = np.sqrt(np.abs(np.diag(H)))
+            assert np.abs((Hm - H) / np.outer(d, d)).max() <= 2e-4 + share, (lvl, np.abs((Hm - H) / np.outer(d, d)).max())
+            assert np.abs((bm - b) / d).max() <= (2e-4 + share) * max(np.abs(b / d).max(), 1e-3) + 1e-6
