@@ -281,3 +281,28 @@ def tracker_res_gs(pc_u, pc_v, pc_idepth, pc_color, dI, K4, R, t, affLL, b0, hub
     n = (out["numWarped"] + 3) // 4 * 4
     out["H"], out["b"] = H9[:8, :8] / max(n, 1), H9[:8, 8] / max(n, 1)
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# EnergyFunctional::marginalizeFrame, visual part (OB/EnergyFunctional.cpp:788-859): restated as index selection + a scaled Schur
+# complement instead of the block moves of the reference
+# ------------------------------------------------------------------------------------------------
+def marginalize_frame(HM, bM, idx, prior8, delta_prior8):
+    HM, bM = np.asarray(HM, dtype=np.float64), np.asarray(bM, dtype=np.float64)
+    odim = HM.shape[0]
+    io = 4 + 8 * idx
+    gone = np.arange(io, io + 8)
+    keep = np.array([i for i in range(odim) if i < io or i >= io + 8])
+    order = np.concatenate([keep, gone])
+    H, b = HM[np.ix_(order, order)].copy(), bM[order].copy()
+    nd = odim - 8
+    H[nd:, nd:] += np.diag(prior8)
+    b[nd:] += np.asarray(prior8) * np.asarray(delta_prior8)
+    S = np.sqrt(np.abs(np.diag(H)) + 10.0)
+    Hs, bs = H / np.outer(S, S), b / S
+    hpi = np.linalg.inv(Hs[nd:, nd:])
+    bli = Hs[nd:, :nd].T @ hpi
+    Ht = Hs[:nd, :nd] - bli @ Hs[nd:, :nd]
+    bt = bs[:nd] - bli @ bs[nd:]
+    Ht, bt = Ht * np.outer(S[:nd], S[:nd]), bt * S[:nd]
+    return 0.5 * (Ht + Ht.T), bt

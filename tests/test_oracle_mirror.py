@@ -152,3 +152,22 @@ def test_tracker_residual_and_system_agree_with_the_numpy_mirror(name, kw):
             d = np.sqrt(np.abs(np.diag(H)))
             assert np.abs((Hm - H) / np.outer(d, d)).max() <= 2e-4 + share, (lvl, np.abs((Hm - H) / np.outer(d, d)).max())
             assert np.abs((bm - b) / d).max() <= (2e-4 + share) * max(np.abs(b / d).max(), 1e-3) + 1e-6
+
+
+@pytest.mark.parametrize("idx", [0, 2, 4])
+def test_marginalize_frame_agrees_with_the_numpy_mirror(idx):
+    """EnergyFunctional::marginalizeFrame (visual part, OB/EnergyFunctional.cpp:788-859): the C restatement against a NumPy reading
+    written as index selection + scaled Schur complement (the reference moves blocks in place)."""
+    win = synth.make_window("T6")
+    ow = orc.window_from_synth(win)
+    ow.optimize(3)
+    alive = np.flatnonzero(win.points["host"] == 1)[:40].astype(np.int32)
+    ow.marginalize_points(alive)                      # a prior with real structure: the window's own + marginalised points
+    H0, b0 = ow.get_prior()
+    pr, dp = ow.frame_prior(idx)
+    Ho, bo = ow.marginalize_frame_prior(idx)
+    Hm, bm = mir.marginalize_frame(H0, b0, idx, pr, dp)
+    s = 1.0 / np.sqrt(np.abs(np.diag(Hm)) + 10)
+    assert np.abs((Ho - Hm) * np.outer(s, s)).max() <= 1e-9 * max(np.abs(Hm * np.outer(s, s)).max(), 1.0)
+    assert np.abs((bo - bm) * s).max() <= 1e-9 * max(np.abs(bm * s).max(), 1.0)
+    assert np.abs(H0).max() > 0
