@@ -295,6 +295,15 @@ typedef struct sos_gn_frame {
   float ab_exposure;
   int32_t pad;
 } sos_gn_frame;
+/* Device-side step of the fused loop (host solves, device does everything else): after sos_ba_gn_devstep_begin the frame states
+ * (evaluation point, state, state_zero, exposure) and the calibration value stay on the device, and sos_ba_gn_step called with x,
+ * frameEnergyTH and precalc == NULL (calib / adHTdeltaF / cDeltaF ignored) derives doStepFromBackup's new states, SE3::exp, the n^2
+ * FrameFramePrecalc records and setDeltaF's arrays from x itself, inside the launch of the back-substitution: the host neither
+ * stages them nor launches the stage-in.  The host keeps stepping its own copies of the states (same fp64 arithmetic; its SE3::exp
+ * and the device's differ in the last bits, which is why the mode is explicit).  sos_ba_set_window / sos_ba_set_state end the mode.
+ * SOS_ERR_STATE: more than 17 keyframes, an empty window, no fp32 adjoints. */
+int sos_ba_gn_devstep_begin(sos_ba *ba, const sos_gn_frame *frames, const double *calib_value4, const double *calib_value_zero4);
+int sos_ba_gn_devstep_end(sos_ba *ba);
 int sos_ba_gn_resident_supported(sos_ba *ba);
 int sos_ba_gn_resident_begin(sos_ba *ba, const sos_gn_frame *frames, const double *calib_value4, const double *calib_value_zero4,
                              double cPrior, const double *HM, const double *bM, const float *frameEnergyTH /* n */);

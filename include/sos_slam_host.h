@@ -95,6 +95,11 @@ int sosf_gn_iteration(sosf_system *sys, int iteration, int *canbreak);
 /* the caller will keep calling sosf_gn_iteration whatever `canbreak` says (benchmark loops): lets every iteration
  * prefetch the next accumulate (sos_ba_set_prefetch); optimize() decides per iteration by itself */
 int sosf_set_pipeline(sosf_system *sys, int on);
+/* Device-side step of the Gauss-Newton loop (default on; sos_ba_gn_devstep_begin in include/sos_slam.h): the host solves and hands x
+ * over, the device forms the frames' new poses, the n^2 precalc records and the deltas inside the launch of the back-substitution.
+ * 0: the host computes and stages them as in round 1 (the two differ in the last bits of SE3::exp).  Used when steps are always
+ * accepted, without IMU branch, exchange hooks or communicator, up to 17 keyframes. */
+int sosf_set_device_step(sosf_system *sys, int on);
 /* Device-resident Gauss-Newton loop (sos_ba_gn_resident_*): solveSystemF, the frame half of doStepFromBackup and
  * setPrecalcValues run on the device, the host only decides whether to continue.  OFF by default: the (4 + 8 n)-dimensional
  * LDL^T is a chain of ~100 dependent pivots, which one compute unit walks in ~45 us where a host core needs 16 (DESIGN.md,

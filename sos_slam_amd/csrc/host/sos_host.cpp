@@ -997,7 +997,8 @@ void FullSystem::backupState() {  // :260-269
   }
 }
 
-bool FullSystem::doStepFromBackup(float stepfacC, float stepfacT, float stepfacR, float stepfacA, float stepfacD, bool pointsOnDevice) {
+bool FullSystem::doStepFromBackup(float stepfacC, float stepfacT, float stepfacR, float stepfacA, float stepfacD, bool pointsOnDevice,
+                                  bool precalcOnDevice) {
   double pstepfac[10];
   for (int i = 0; i < 3; i++) pstepfac[i] = stepfacT;
   for (int i = 3; i < 6; i++) pstepfac[i] = stepfacR;
@@ -1029,7 +1030,20 @@ bool FullSystem::doStepFromBackup(float stepfacC, float stepfacT, float stepfacR
   sumID /= numID; sumNID /= numID;
   (void)sumID;
   ef->EFDeltaValid = false;
-  { PhaseTimer tp(4); setPrecalcValues(!pointsOnDevice); }
+  if (precalcOnDevice) {
+    // the device forms FrameFramePrecalc / adHTdeltaF / cDeltaF itself (k_resub_devstep); what the host's next solve reads are the
+    // frame deltas of setDeltaF (OB/EnergyFunctional.cpp:183-190) and cDeltaF (getStitchedDeltaF)
+    for (int i = 0; i < 4; i++) ef->cDeltaF[i] = (float)HCalib.value_minus_value_zero[i];
+    for (EFFrame *f : ef->frames)
+      for (int i = 0; i < 8; i++) {
+        f->delta[i] = f->data->state[i] - f->data->state_zero[i];
+        f->delta_prior[i] = f->data->state[i];
+      }
+    ef->EFDeltaValid = true;
+  } else {
+    PhaseTimer tp(4);
+    setPrecalcValues(!pointsOnDevice);
+  }
   return sqrtf(sumA) < 0.0005 * setting_thOptIterations && sqrtf(sumB) < 0.00005 * setting_thOptIterations &&
          sqrtf(sumR) < 0.00005 * setting_thOptIterations && sqrtf(sumT) * sumNID < 0.00005 * setting_thOptIterations;
 }
@@ -1038,6 +1052,7 @@ void FullSystem::solveSystem(int iteration, double lambda) { rcAcc(ef->solveSyst
 
 int FullSystem::prepare() {  // FS/FullSystemOptimize.cpp:316-344
   residentFlush();
+  devStepActive = false;
   activeResiduals.clear();
   for (FrameHessian *fh : frameHessians)
     for (PointHessian *ph : fh->pointHessians)
@@ -1080,10 +1095,45 @@ bool FullSystem::gnIteration(int iteration, bool mayContinue) {  // :358-413 wit
     return cb;
   }
 host_path:
+  if (!devStepActive && devStepUsable()) devStepBegin();  // (prepare() ended the previous one: the host re-uploaded its states)
   { PhaseTimer tb(7); backupState(); }
   if (rcAcc(ef->solveSystemF(iteration, 1e-1, &HCalib, true)) != SOS_OK) {  // x, frame / calib steps; back-substitution deferred
     isLost = true;  // a failed device call: no step is taken on undelivered H / b
     return true;
+  }
+  if (devStepActive) {
+    // x goes to the device as it is: back-substitution, the frames' new poses, the precalc records and the deltas are formed
+    // there inside ONE launch, the linearisation follows without waiting for the host
+    bool canbreak;
+    { PhaseTimer t(3); canbreak = doStepFromBackup(1, 1, 1, 1, 1, true, true); }
+    PhaseTimer t(5);
+    const int n = (int)frameHessians.size();
+    std::vector<float> th(n);
+    for (int i = 0; i < n; i++) th[i] = frameHessians[i]->frameEnergyTH;
+    const sos_calib cal = HCalib.toCalib();
+    {
+      int cap = 0;
+      sos_ba_newest_capacity(ef->ba, &cap);
+      newestE.resize((size_t)cap + 1);
+    }
+    int cnt = 0;
+    double E = 0;
+    ef->pointStep.resize(ef->allPoints.size());
+    const bool more = pipelineAlways || (mayContinue && !(canbreak && iteration >= setting_minOptIterations));
+    sos_ba_set_prefetch(ef->ba, more ? 1 : 0);
+    lastError = sos_ba_gn_step(ef->ba, ef->lastX.data(), 1.0f, &cal, nullptr, nullptr, nullptr, th.data(), 1, &E, newestE.data(), &cnt,
+                               ef->pointStep.data());
+    newestE.resize(cnt);
+    PhaseTimer tpost(6);
+    for (size_t k = 0; k < ef->allPoints.size(); k++) {
+      PointHessian *ph = ef->allPoints[k]->data;
+      ph->step = ef->pointStep[k];
+      ph->setIdepth(ph->idepth_backup + 1.0f * ph->step);
+      ph->setIdepthZero(ph->idepth_backup + 1.0f * ph->step);
+      ef->allPoints[k]->deltaF = 0;
+    }
+    setNewFrameEnergyTH(newestE);
+    return canbreak;
   }
   // the back-substitution needs x alone: it runs on the device while the host derives the new poses and precalc records
   const bool resubAhead = sos_ba_gn_resub(ef->ba, ef->lastX.data(), 1.0f) == SOS_OK;
@@ -1130,6 +1180,28 @@ host_path:
 // ------------------------------------------------------------------------------------------------
 // device-resident Gauss-Newton loop: what is left for the host is the loop control (canbreak) and its mirrors
 // ------------------------------------------------------------------------------------------------
+bool FullSystem::devStepUsable() const {
+  static const bool off = getenv("SOS_NO_DEVSTEP") != nullptr;
+  return devStepAllowed && !off && forceAcceptStep && !ef->imuSettings && !ef->allreduceHook && !ef->commAttached && !ef->keepSystem &&
+         (int)frameHessians.size() <= 17 && !ef->allPoints.empty();
+}
+
+int FullSystem::devStepBegin() {
+  const int n = (int)frameHessians.size();
+  std::vector<sos_gn_frame> fr(n);
+  for (int i = 0; i < n; i++) {
+    const FrameHessian *fh = frameHessians[i];
+    fh->camToWorld_evalPT.to12(fr[i].camToWorld_evalPT);
+    std::memcpy(fr[i].state, fh->state, sizeof(double) * 10);
+    std::memcpy(fr[i].state_zero, fh->state_zero, sizeof(double) * 10);
+    std::memset(fr[i].prior, 0, sizeof(fr[i].prior));
+    fr[i].ab_exposure = fh->ab_exposure;
+    fr[i].pad = 0;
+  }
+  devStepActive = sos_ba_gn_devstep_begin(ef->ba, fr.data(), HCalib.value, HCalib.value_zero) == SOS_OK;
+  return devStepActive ? SOS_OK : SOS_ERR_STATE;
+}
+
 bool FullSystem::residentUsable() const {
   static const bool off = getenv("SOS_NO_RESIDENT") != nullptr;
   return residentAllowed && !off && forceAcceptStep && !ef->imuSettings && !ef->allreduceHook && !ef->commAttached && !ef->keepSystem &&
@@ -1295,6 +1367,10 @@ float FullSystem::optimize(int mnumOptIts, int *iterations) {
       const bool canbreak = forceAcceptStep ? gnIteration(iteration, iteration + 1 < mnumOptIts) : gnIterationChecked(iteration, lastE, lastEL, lastEM);
       it++;
       if (canbreak && iteration >= setting_minOptIterations) break;
+    }
+    if (devStepActive) {
+      sos_ba_gn_devstep_end(ef->ba);
+      devStepActive = false;
     }
   }
   if (iterations) *iterations = it;
@@ -2299,6 +2375,15 @@ extern "C" int sosf_optimize(sosf_system *s, int mnumOptIts, float *rmse, int *i
   const float r = s->fs->optimize(mnumOptIts, iterations);
   if (rmse) *rmse = r;
   return s->fs->lastError;
+}
+extern "C" int sosf_set_device_step(sosf_system *s, int on) {
+  if (!s) return SOS_ERR_ARG;
+  s->fs->devStepAllowed = on != 0;
+  if (!on && s->fs->devStepActive) {
+    sos_ba_gn_devstep_end(s->fs->ef->ba);
+    s->fs->devStepActive = false;
+  }
+  return SOS_OK;
 }
 extern "C" int sosf_prepare(sosf_system *s) { return s ? s->fs->prepare() : SOS_ERR_ARG; }
 extern "C" int sosf_gn_iteration(sosf_system *s, int iteration, int *canbreak) {

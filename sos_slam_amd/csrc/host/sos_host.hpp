@@ -265,6 +265,11 @@ class FullSystem {
   // device-resident Gauss-Newton loop (sos_ba_gn_resident_*): the solve, the frame step and the precalc records on the device
   bool residentAllowed = false;  // sosf_set_resident (off by default: measured slower than the host solve)
   bool residentActive = false;
+  // device-side step of the fused loop (sos_ba_gn_devstep_begin): the device derives poses / precalc / deltas from x; the host
+  // keeps stepping its own states but neither computes nor stages the n^2 precalc records inside the loop
+  bool devStepAllowed = true, devStepActive = false;
+  bool devStepUsable() const;
+  int devStepBegin();
   int residentSeq = 0;          // sequence number of the iteration whose results the host has consumed
   int residentQueued = 0;       // ... and of the last one enqueued
   bool residentUsable() const;
@@ -306,7 +311,7 @@ class FullSystem {
   double prepareEnergy = 0, prepareEnergyL = 0, prepareEnergyM = 0;
   int rcAcc(int rc) { if (rc != SOS_OK && lastError == SOS_OK) lastError = rc; return rc; }
   bool doStepFromBackup(float stepfacC, float stepfacT, float stepfacR, float stepfacA, float stepfacD,
-                        bool pointsOnDevice = false);  // :185-257
+                        bool pointsOnDevice = false, bool precalcOnDevice = false);  // :185-257
   void solveSystem(int iteration, double lambda);             // :491-497
   std::vector<PointFrameResidual *> activeResiduals;
   std::vector<uint8_t> h_newState;

@@ -2057,17 +2057,9 @@ __global__ __launch_bounds__(SOS_RSB) void k_stage_expand(BaDev d, float4 *__res
                                                       int nStageBlocks, const float4 *__restrict__ pre_src, float4 *__restrict__ t_pre) {
   stage_block((int)blockIdx.x, threadIdx.x, d, stage_dst, stage_src, n4, nStageBlocks, pre_src, t_pre);
 }
-__global__ __launch_bounds__(SOS_RSB) void k_resub_fused(BaDev d, XArg x, const float *__restrict__ adHF, const float *__restrict__ adTF,
-                                                     float *__restrict__ step_out, float stepfacD, int nPointBlocks,
-                                                     float4 *__restrict__ stage_dst, const float4 *__restrict__ stage_src, int n4,
-                                                     int nStageBlocks, const float4 *__restrict__ pre_src, float4 *__restrict__ t_pre,
-                                                     const float *__restrict__ x_dev) {
-  extern __shared__ __attribute__((aligned(16))) float sxAd[];  // [n*n*8] table, then [dim] copy of x
+__device__ __forceinline__ void resub_point_block(const BaDev &d, const XArg &x, const float *__restrict__ adHF, const float *__restrict__ adTF,
+                                                  float *__restrict__ step_out, float stepfacD, const float *__restrict__ x_dev, float *sxAd) {
   const int tid = threadIdx.x;
-  if ((int)blockIdx.x >= nPointBlocks) {
-    stage_block((int)blockIdx.x - nPointBlocks, tid, d, stage_dst, stage_src, n4, nStageBlocks, pre_src, t_pre);
-    return;
-  }
   const int n = d.n, dim = SOS_CPARS + 8 * n;
   float *sx = sxAd + n * n * 8;
   // ---- every global load of this thread's point is issued before the table is built: the memory latencies of the
@@ -2179,6 +2171,163 @@ __global__ __launch_bounds__(SOS_RSB) void k_resub_fused(BaDev d, XArg x, const 
   for (int k = 0; k < RU; k++)
     if (e[k].x >= 0) *(reinterpret_cast<float2 *>(d.r_geo + e[k].x) + 1) = make_float2(idn, idn);
   for (int q = q0 + RU; q < q1; q++) *(reinterpret_cast<float2 *>(d.r_geo + d.p_list2[q].x) + 1) = make_float2(idn, idn);
+}
+__global__ __launch_bounds__(SOS_RSB) void k_resub_fused(BaDev d, XArg x, const float *__restrict__ adHF, const float *__restrict__ adTF,
+                                                     float *__restrict__ step_out, float stepfacD, int nPointBlocks,
+                                                     float4 *__restrict__ stage_dst, const float4 *__restrict__ stage_src, int n4,
+                                                     int nStageBlocks, const float4 *__restrict__ pre_src, float4 *__restrict__ t_pre,
+                                                     const float *__restrict__ x_dev) {
+  extern __shared__ __attribute__((aligned(16))) float sxAd[];  // [n*n*8] table, then [dim] copy of x
+  if ((int)blockIdx.x >= nPointBlocks) {
+    stage_block((int)blockIdx.x - nPointBlocks, threadIdx.x, d, stage_dst, stage_src, n4, nStageBlocks, pre_src, t_pre);
+    return;
+  }
+  resub_point_block(d, x, adHF, adTF, step_out, stepfacD, x_dev, sxAd);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Device-side step of the fused loop (sos_ba_gn_devstep_begin): the blocks behind the point blocks do what the host does between
+// the solve and the next linearisation -- doStepFromBackup for the calibration and the frames (state += -x, SE3::exp,
+// PRE_camToWorld), FrameFramePrecalc::set for the n^2 ordered pairs, setDeltaF's adHTdeltaF / cDeltaF -- from x alone (a kernel
+// argument, in double) and the frame states that stay on the device.  Every one of these blocks computes the (tiny) records
+// itself in LDS and then writes its share of the per-tile precalc copies; the first one also writes the canonical arrays and
+// the new states.  Nothing waits for the host's precalc any more, and the stage-in launch disappears.
+// ------------------------------------------------------------------------------------------------
+struct DevStep {
+  const double *evalC2W, *state_zero, *state_in, *calib_in;  // n x 12, n x 10, n x 10, 4 value | 4 value_zero
+  double *state_out, *calib_out;
+  const double *abexp;                                        // n
+  float *stage;                                               // device staging buffer of the linearisation
+  size_t st_pre, st_adh, st_cd, st_th, st_cal;
+  double xd[SOS_CPARS + 8 * 17];                              // x of the solve (the window sizes this path accepts: n <= 17)
+  float th[17];                                               // frameEnergyTH of the coming linearisation
+};
+__device__ __forceinline__ void devstep_block(int sb, int nsb, const BaDev &d, const DevStep &g, const float *__restrict__ adHF, const float *__restrict__ adTF,
+                                              float4 *__restrict__ t_pre, float *smemf) {
+  const int tid = threadIdx.x, n = d.n;
+  // LDS: [28 n^2 floats: the records] then doubles: c2w 12 n | w2c 12 n | state 10 n | calib 4, then 8 floats K
+  float *pre = smemf;
+  double *dsm = reinterpret_cast<double *>(smemf + ((28 * n * n + 3) / 4) * 4 + 4);
+  double *c2w = dsm, *w2c = dsm + 12 * n, *stN = dsm + 24 * n, *cvN = dsm + 34 * n;
+  float *sK = reinterpret_cast<float *>(cvN + 4);
+  if (tid < n) {  // FrameHessian::setState, FS/HessianBlocks.h:217-230
+    const int f = tid;
+    double st[10], scv[6];
+    for (int i = 0; i < 8; i++) st[i] = g.state_in[10 * f + i] + (-g.xd[SOS_CPARS + 8 * f + i]);
+    st[8] = g.state_in[10 * f + 8];
+    st[9] = g.state_in[10 * f + 9];
+    for (int i = 0; i < 10; i++) stN[10 * f + i] = st[i];
+    for (int i = 0; i < 3; i++) scv[i] = (double)SOS_SCALE_XI_TRANS * st[i];
+    for (int i = 3; i < 6; i++) scv[i] = (double)SOS_SCALE_XI_ROT * st[i];
+    double R[9], t[3];
+    sos_dev_se3_exp(scv, R, t);
+    const double *E = g.evalC2W + 12 * f;
+    double *C = c2w + 12 * f, *W = w2c + 12 * f;
+    for (int i = 0; i < 3; i++) {
+      for (int j = 0; j < 3; j++) C[3 * i + j] = R[3 * i] * E[j] + R[3 * i + 1] * E[3 + j] + R[3 * i + 2] * E[6 + j];
+      C[9 + i] = t[i] + (R[3 * i] * E[9] + R[3 * i + 1] * E[10] + R[3 * i + 2] * E[11]);
+    }
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) W[3 * i + j] = C[3 * j + i];
+    for (int i = 0; i < 3; i++) W[9 + i] = -(W[3 * i] * C[9] + W[3 * i + 1] * C[10] + W[3 * i + 2] * C[11]);
+  }
+  if (tid == 64) {  // CalibHessian::setValue, FS/HessianBlocks.h:476-491
+    double vs[4];
+    for (int i = 0; i < 4; i++) cvN[i] = g.calib_in[i] + (-g.xd[i]);
+    vs[0] = SOS_SCALE_F * cvN[0]; vs[1] = SOS_SCALE_F * cvN[1]; vs[2] = SOS_SCALE_C * cvN[2]; vs[3] = SOS_SCALE_C * cvN[3];
+    for (int i = 0; i < 4; i++) sK[i] = (float)vs[i];
+    sK[4] = 1.0f / sK[0]; sK[5] = 1.0f / sK[1]; sK[6] = -sK[2] / sK[0]; sK[7] = -sK[3] / sK[1];
+  }
+  __syncthreads();
+  const sos_precalc *old = reinterpret_cast<const sos_precalc *>(g.stage + g.st_pre);  // the FEJ parts do not change inside the loop
+  for (int pidx = tid; pidx < n * n; pidx += SOS_RSB) {  // FrameFramePrecalc::set, FS/HessianBlocks.cpp:431-461
+    const int h = pidx % n, t = pidx / n;
+    const double *Wt = w2c + 12 * t, *Ch = c2w + 12 * h;
+    float Rf[9], tf[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+      for (int j = 0; j < 3; j++) Rf[3 * i + j] = (float)(Wt[3 * i] * Ch[j] + Wt[3 * i + 1] * Ch[3 + j] + Wt[3 * i + 2] * Ch[6 + j]);
+      tf[i] = (float)(Wt[9 + i] + (Wt[3 * i] * Ch[9] + Wt[3 * i + 1] * Ch[10] + Wt[3 * i + 2] * Ch[11]));
+    }
+    const float Km[9] = {sK[0], 0, sK[2], 0, sK[1], sK[3], 0, 0, 1};
+    const float Ki[9] = {sK[4], 0, sK[6], 0, sK[5], sK[7], 0, 0, 1};
+    float KR[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) KR[3 * i + j] = Km[3 * i] * Rf[j] + Km[3 * i + 1] * Rf[3 + j] + Km[3 * i + 2] * Rf[6 + j];
+    sos_precalc *pc = reinterpret_cast<sos_precalc *>(pre) + pidx;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) pc->PRE_KRKiTll[3 * i + j] = KR[3 * i] * Ki[j] + KR[3 * i + 1] * Ki[3 + j] + KR[3 * i + 2] * Ki[6 + j];
+#pragma unroll
+    for (int i = 0; i < 3; i++) pc->PRE_KtTll[i] = Km[3 * i] * tf[0] + Km[3 * i + 1] * tf[1] + Km[3 * i + 2] * tf[2];
+    const sos_precalc *o = old + pidx;
+#pragma unroll
+    for (int i = 0; i < 9; i++) pc->PRE_RTll_0[i] = o->PRE_RTll_0[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) pc->PRE_tTll_0[i] = o->PRE_tTll_0[i];
+    pc->PRE_b0_mode = o->PRE_b0_mode;
+    pc->pad = 0.f;
+    float eF = (float)g.abexp[h], eT = (float)g.abexp[t];  // AffLight::fromToVecExposure
+    if (eF == 0 || eT == 0) eT = eF = 1;
+    const double ha = SOS_SCALE_A * stN[10 * h + 6], hb = SOS_SCALE_B * stN[10 * h + 7];
+    const double ta = SOS_SCALE_A * stN[10 * t + 6], tb = SOS_SCALE_B * stN[10 * t + 7];
+    const double aa = exp(ta - ha) * eT / eF;
+    pc->PRE_aff_mode[0] = (float)aa;
+    pc->PRE_aff_mode[1] = (float)(tb - aa * hb);
+  }
+  __syncthreads();
+  // this block's share of the per-tile copies (expand_precalc_item from the records in LDS)
+  {
+    const int e = sb * SOS_RSB + tid, tile = e >> 3, q = e & 7;
+    if (tile < d.ntiles && q != 7) t_pre[e] = reinterpret_cast<const float4 *>(pre)[7 * (size_t)d.t_pair[tile] + q];
+  }
+  // ---- the canonical arrays and the new states, spread over the blocks (every block holds all of it in LDS): role 0 = states /
+  // calibration / thresholds, role 1 = the precalc array, roles 2.. = 256 entries of adHTdeltaF each
+  const int nRoles = 2 + (8 * n * n + SOS_RSB - 1) / SOS_RSB;
+  for (int role = sb; role < nRoles; role += nsb) {
+    if (role == 0) {
+      if (tid < 4) {
+        g.stage[g.st_cd + tid] = (float)(cvN[tid] - g.calib_in[4 + tid]);
+        g.calib_out[tid] = cvN[tid];
+        g.calib_out[4 + tid] = g.calib_in[4 + tid];
+      }
+      if (tid < 8) g.stage[g.st_cal + tid] = sK[tid];
+      if (tid < n) g.stage[g.st_th + tid] = g.th[tid];
+      for (int q = tid; q < 10 * n; q += SOS_RSB) g.state_out[q] = stN[q];
+    } else if (role == 1) {
+      float4 *cpre = reinterpret_cast<float4 *>(g.stage + g.st_pre);
+      for (int q = tid; q < 7 * n * n; q += SOS_RSB) cpre[q] = reinterpret_cast<const float4 *>(pre)[q];
+    } else {  // setDeltaF, OB/EnergyFunctional.cpp:163-181 (fp32, i ascending)
+      const int e = (role - 2) * SOS_RSB + tid;
+      if (e < 8 * n * n) {
+        const int pidx = e >> 3, j = e & 7;
+        const int h = pidx % n, t = pidx / n;
+        const float *AH = adHF + 64 * (size_t)pidx, *AT = adTF + 64 * (size_t)pidx;
+        float s1 = 0, s2 = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const float dh = (float)(stN[10 * h + i] - g.state_zero[10 * h + i]), dt = (float)(stN[10 * t + i] - g.state_zero[10 * t + i]);
+          s1 += dh * AH[8 * i + j];
+          s2 += dt * AT[8 * i + j];
+        }
+        g.stage[g.st_adh + e] = s1 + s2;
+      }
+    }
+  }
+}
+__global__ __launch_bounds__(SOS_RSB) void k_resub_devstep(BaDev d, XArg x, const float *__restrict__ adHF, const float *__restrict__ adTF,
+                                                       float *__restrict__ step_out, float stepfacD, int nPointBlocks, DevStep g,
+                                                       float4 *__restrict__ t_pre) {
+  extern __shared__ __attribute__((aligned(16))) float sxAd[];
+  if ((int)blockIdx.x >= nPointBlocks) {
+    devstep_block((int)blockIdx.x - nPointBlocks, (int)gridDim.x - nPointBlocks, d, g, adHF, adTF, t_pre, sxAd);
+    return;
+  }
+  resub_point_block(d, x, adHF, adTF, step_out, stepfacD, nullptr, sxAd);
 }
 
 // ================================================================================================
@@ -2417,6 +2566,10 @@ struct sos_ba {
   bool pending_new = false;  // a sos_ba_linearize result waits in d_Jnew for sos_ba_apply_res
   size_t st_pre = 0, st_adh = 0, st_cd = 0, st_th = 0, st_cal = 0, st_xc = 0, st_xad = 0, st_floats = 0;
   bool resub_pending = false;  // sos_ba_gn_resub enqueued the back-substitution of the step sos_ba_gn_step is about to take
+  // device-side step (sos_ba_gn_devstep_begin): frame states that stay on the device between the iterations of one optimize()
+  bool devstep = false;
+  double *d_ds = nullptr;    // evalC2W 12 n | state_zero 10 n | state[0] 10 n | state[1] 10 n | calib[0] 8 | calib[1] 8 | ab_exposure n
+  int ds_n = 0, ds_cur = 0;
   size_t out_esum = 0, out_newest = 0, out_step = 0, out_bytes = 0;
   int newest_begin = 0, newest_count = 0;
   char *pin = nullptr;     // pinned + device-mapped host block: [stage | outpack | Hb]; the fused per-iteration
@@ -2480,6 +2633,7 @@ extern "C" int sos_ba_destroy(sos_ba *ba) {
   }
   hipSetDevice(ba->ctx->device);
   hipStreamSynchronize(ba->ctx->stream);
+  if (ba->d_ds) hipFree(ba->d_ds);
   ba->d_pts.release();
   for (DevBuf<int> *b : {&ba->d_s_point, &ba->d_s_orig, &ba->d_t_pair, &ba->d_p_begin, &ba->d_p_list, &ba->d_p_res_t,
                          &ba->d_pair_tile_begin, &ba->d_chunk_pt, &ba->d_host_chunk_begin, &ba->d_tmp_int, &ba->d_sigctr})
@@ -2522,6 +2676,7 @@ static int comm_setup_window(sos_ba *ba);
 
 extern "C" int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, int P, const sos_point *pts, int R,
                                  const sos_resid *res, const float *res_toZeroF, const sos_rawjac *lin_J) {
+  if (ba) ba->devstep = false;  // the device-side frame states belong to the previous snapshot
   if (ba) ba->acc_inflight = false;  // any state change invalidates a prefetched accumulate
   if (!ba || n < 1 || n > SOS_MAX_FRAMES || P < 0 || R < 0 || !frame_slot || (P && !pts) || (R && !res)) return SOS_ERR_ARG;
   sos_ctx *c = ba->ctx;
@@ -2816,6 +2971,7 @@ extern "C" int sos_ba_set_state(sos_ba *ba, const sos_calib *calib, const sos_pr
                                 const float *cDeltaF, const double *adHost, const double *adTarget,
                                 const float *point_idepth_scaled, const float *point_idepth_zero_scaled,
                                 const float *point_deltaF) {
+  if (ba) ba->devstep = false;  // the host is the source of the states again
   if (ba) ba->acc_inflight = false;  // any state change invalidates a prefetched accumulate
   if (!ba || !ba->have_window) return SOS_ERR_STATE;
   sos_ctx *c = ba->ctx;
@@ -3499,21 +3655,27 @@ extern "C" int sos_ba_gn_resub(sos_ba *ba, const double *x, float stepfacD) {
 extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const sos_calib *calib, const sos_precalc *precalc,
                               const float *adHTdeltaF, const float *cDeltaF, const float *frameEnergyTH, int applyRes,
                               double *energySum, float *newestEnergies, int *newestCount, float *pointStep) {
-  if (!ba || !ba->have_window || !ba->have_state || !calib || !precalc || !adHTdeltaF || !cDeltaF || !frameEnergyTH)
+  const bool devStep = ba && ba->devstep && x && !precalc;  // the device derives poses / precalc / deltas from x itself
+  if (!ba || !ba->have_window || !ba->have_state || !frameEnergyTH || (!devStep && (!calib || !precalc || !adHTdeltaF || !cDeltaF)))
     return SOS_ERR_STATE;
+  if (devStep && !(ba->P > 0 && ba->d_adHostF.p && ba->d_adTargetF.p && ba->ds_n == ba->n)) return SOS_ERR_STATE;
   sos_ctx *c = ba->ctx;
   SOS_HIP(hipSetDevice(c->device));
   hipStream_t st = c->stream;
   const size_t nn = (size_t)ba->n * ba->n;
-  ba->calib = *calib;
-  ba->dev.calib = *calib;
+  if (calib) {
+    ba->calib = *calib;
+    ba->dev.calib = *calib;
+  }
   ba->acc_inflight = false;
   const double t0 = now_s();
-  memcpy(pstg(ba, ba->st_pre), precalc, sizeof(sos_precalc) * nn);
-  memcpy(pstg(ba, ba->st_adh), adHTdeltaF, sizeof(float) * 8 * nn);
-  memcpy(pstg(ba, ba->st_cd), cDeltaF, sizeof(float) * 4);
-  memcpy(pstg(ba, ba->st_th), frameEnergyTH, sizeof(float) * ba->n);
-  memcpy(pstg(ba, ba->st_cal), calib, sizeof(sos_calib));
+  if (!devStep) {
+    memcpy(pstg(ba, ba->st_pre), precalc, sizeof(sos_precalc) * nn);
+    memcpy(pstg(ba, ba->st_adh), adHTdeltaF, sizeof(float) * 8 * nn);
+    memcpy(pstg(ba, ba->st_cd), cDeltaF, sizeof(float) * 4);
+    memcpy(pstg(ba, ba->st_th), frameEnergyTH, sizeof(float) * ba->n);
+    memcpy(pstg(ba, ba->st_cal), calib, sizeof(sos_calib));
+  }
   // outputs go straight to the device-mapped pinned block: per-tile energy sums, newest-frame energies, point steps
   char *po = ba->pin + ba->pin_out, *po_dev = ba->pin_dev + ba->pin_out;
   float *dstep = reinterpret_cast<float *>(po_dev + ba->out_step);
@@ -3523,7 +3685,26 @@ extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const
   const double t1 = now_s();
   const bool resubAhead = !x && ba->resub_pending;
   ba->resub_pending = false;
-  if (resubAhead) {  // the back-substitution is already running: only the stage-in is left, one launch
+  if (devStep) {  // back-substitution + the host's step / precalc work, one launch, nothing staged from the host
+    static_assert(sizeof(BaDev) + sizeof(XArg) + sizeof(DevStep) + 64 < 4096, "kernel arguments of k_resub_devstep");
+    const int n = ba->n, dim = 4 + 8 * n;
+    XArg xa;
+    DevStep g;
+    for (int i = 0; i < dim; i++) { xa.v[i] = (float)x[i]; g.xd[i] = x[i]; }
+    for (int i = 0; i < n; i++) g.th[i] = frameEnergyTH[i];
+    double *b = ba->d_ds;
+    g.evalC2W = b; g.state_zero = b + 12 * n;
+    g.state_in = b + 22 * n + 10 * n * ba->ds_cur; g.state_out = b + 22 * n + 10 * n * (ba->ds_cur ^ 1);
+    g.calib_in = b + 42 * n + 8 * ba->ds_cur; g.calib_out = b + 42 * n + 8 * (ba->ds_cur ^ 1);
+    g.abexp = b + 42 * n + 16;
+    ba->ds_cur ^= 1;
+    g.stage = ba->d_stage.p;
+    g.st_pre = ba->st_pre; g.st_adh = ba->st_adh; g.st_cd = ba->st_cd; g.st_th = ba->st_th; g.st_cal = ba->st_cal;
+    const int nPB = divup(ba->P, SOS_RSB), nEB = divup(8 * ba->ntiles, SOS_RSB);
+    const size_t lds = std::max(sizeof(float) * (8 * nn + 4 + 8 * (size_t)n), sizeof(float) * (28 * nn + 16) + sizeof(double) * (34 * (size_t)n + 8));
+    ba->tm[1] += now_s() - t1;
+    k_resub_devstep<<<nPB + nEB, SOS_RSB, lds, st>>>(dv, xa, ba->d_adHostF.p, ba->d_adTargetF.p, dstep, stepfacD, nPB, g, ba->d_t_pre.p);
+  } else if (resubAhead) {  // the back-substitution is already running: only the stage-in is left, one launch
     const int n4 = (int)((ba->st_xc + 3) / 4), nSB = divup(n4, SOS_RSB), nEB = divup(8 * ba->ntiles, SOS_RSB);
     k_stage_expand<<<nSB + nEB, SOS_RSB, 0, st>>>(dv, reinterpret_cast<float4 *>(ba->d_stage.p), reinterpret_cast<const float4 *>(ba->pin_dev + ba->pin_stage),
                                                  n4, nSB, reinterpret_cast<const float4 *>(ba->pin_dev + ba->pin_stage + sizeof(float) * ba->st_pre),
@@ -3610,6 +3791,39 @@ extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const
     if (pointStep) memcpy(pointStep, hs, sizeof(float) * ba->P);
   }
   ba->tm[5] += now_s() - t4;
+  return SOS_OK;
+}
+
+extern "C" int sos_ba_gn_devstep_begin(sos_ba *ba, const sos_gn_frame *frames, const double *calib_value4, const double *calib_value_zero4) {
+  if (!ba || !frames || !calib_value4 || !calib_value_zero4) return SOS_ERR_ARG;
+  if (!ba->have_window || !ba->have_state || ba->n < 1 || ba->n > 17 || ba->P <= 0 || !ba->d_adHostF.p || !ba->d_adTargetF.p || lin_v1())
+    return SOS_ERR_STATE;
+  SOS_HIP(hipSetDevice(ba->ctx->device));
+  const int n = ba->n;
+  const size_t cnt = (size_t)43 * n + 16;
+  if (ba->ds_n != n) {
+    if (ba->d_ds) hipFree(ba->d_ds);
+    ba->d_ds = nullptr;
+    SOS_HIP(hipMalloc(&ba->d_ds, sizeof(double) * cnt));
+    ba->ds_n = n;
+  }
+  std::vector<double> h(cnt, 0.0);
+  for (int f = 0; f < n; f++) {
+    memcpy(&h[12 * f], frames[f].camToWorld_evalPT, sizeof(double) * 12);
+    memcpy(&h[12 * n + 10 * f], frames[f].state_zero, sizeof(double) * 10);
+    memcpy(&h[22 * n + 10 * f], frames[f].state, sizeof(double) * 10);
+    h[42 * n + 16 + f] = (double)frames[f].ab_exposure;
+  }
+  for (int i = 0; i < 4; i++) { h[42 * n + i] = calib_value4[i]; h[42 * n + 4 + i] = calib_value_zero4[i]; }
+  ba->ds_cur = 0;
+  SOS_HIP(hipMemcpyAsync(ba->d_ds, h.data(), sizeof(double) * cnt, hipMemcpyHostToDevice, ba->ctx->stream));
+  SOS_HIP(hipStreamSynchronize(ba->ctx->stream));  // h is pageable and local
+  ba->devstep = true;
+  return SOS_OK;
+}
+extern "C" int sos_ba_gn_devstep_end(sos_ba *ba) {
+  if (!ba) return SOS_ERR_ARG;
+  ba->devstep = false;
   return SOS_OK;
 }
 

@@ -14,8 +14,10 @@ __device__ static inline void sos_dev_se3_exp(const double *a, double *R, double
     imag = 0.5 - (1.0 / 48.0) * theta_sq + (1.0 / 3840.0) * po4;
     real = 1.0 - 0.5 * theta_sq + (1.0 / 384.0) * po4;
   } else {
-    imag = sin(0.5 * theta) / theta;
-    real = cos(0.5 * theta);
+    double sh, ch;
+    sincos(0.5 * theta, &sh, &ch);  // one argument reduction for the pair
+    imag = sh / theta;
+    real = ch;
   }
   double qw = real, qx = imag * om[0], qy = imag * om[1], qz = imag * om[2];
   const double nrm = sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
@@ -34,7 +36,9 @@ __device__ static inline void sos_dev_se3_exp(const double *a, double *R, double
     double Om2[9];
     for (int i = 0; i < 3; i++)
       for (int j = 0; j < 3; j++) Om2[3 * i + j] = Om[3 * i] * Om[j] + Om[3 * i + 1] * Om[3 + j] + Om[3 * i + 2] * Om[6 + j];
-    const double c1 = (1.0 - cos(theta)) / theta_sq, c2 = (theta - sin(theta)) / (theta_sq * theta);
+    double st_, ct_;
+    sincos(theta, &st_, &ct_);
+    const double c1 = (1.0 - ct_) / theta_sq, c2 = (theta - st_) / (theta_sq * theta);
     for (int i = 0; i < 9; i++) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + c1 * Om[i] + c2 * Om2[i];
   }
   for (int i = 0; i < 3; i++) t[i] = V[3 * i] * a[0] + V[3 * i + 1] * a[1] + V[3 * i + 2] * a[2];

@@ -262,6 +262,11 @@ class System:
         _chk(self.L.sosf_get_imu_step(self.h_, C.byref(ss), _p(st)), "sosf_get_imu_step")
         return ss.value, st, np.array([list(arr[i].state_imu) for i in range(n)]), calib.scale
 
+    def set_device_step(self, on=True):
+        """device-side step of the GN loop (poses / precalc / deltas formed on the device from x) on / off"""
+        self.L.sosf_set_device_step.argtypes = [C.c_void_p, C.c_int]
+        _chk(self.L.sosf_set_device_step(self.h_, 1 if on else 0), "sosf_set_device_step")
+
     def set_resident(self, on=True):
         """device-resident Gauss-Newton loop on / off (off: the host solves, as in round 1)"""
         _chk(self.L.sosf_set_resident(self.h_, int(on)), "sosf_set_resident")

@@ -175,3 +175,28 @@ def test_device_resident_loop_equals_host_solve(name):
     pb, tb = hst.residual_ids()
     assert set(zip(pa.tolist(), ta.tolist())) == set(zip(pb.tolist(), tb.tolist()))
     dev.close(); hst.close()
+
+
+@pytest.mark.parametrize("name", ["T6", "W7", "W12", "W16"])
+def test_device_step_equals_host_step(name):
+    """The device-side step of the fused loop (k_resub_devstep: new frame states, SE3::exp, the n^2 precalc records, adHTdeltaF / cDeltaF
+    formed on the device from x) against the loop in which the host computes and stages them: the same iterations, the same residual
+    state sets, x and poses equal up to what the last bits of the two SE3::exp implementations can move."""
+    from sos_slam_amd import host
+    win = synth.make_window(name)
+    out = {}
+    for on in (True, False):
+        sysm = host.System.from_window(win)
+        sysm.set_device_step(on)
+        rm, it = sysm.optimize(6)
+        pi, tf = sysm.residual_ids()
+        out[on] = (rm, it, np.array([sysm.frame(f)["camToWorld"] for f in range(win.n)]), sysm.lastX(), set(zip(pi.tolist(), tf.tolist())),
+                   sysm.points()["idepth"].copy())
+        sysm.close()
+    (rd, itd, pd, xd, sd, idd), (rh, ith, ph, xh, sh, idh) = out[True], out[False]
+    print(f"{name}: iterations {itd}/{ith}; |pose dev-host| {np.abs(pd - ph).max():.3g}; |x| rel {np.abs(xd - xh).max() / np.abs(xh).max():.3g}")
+    assert itd == ith and sd == sh
+    assert abs(rd - rh) <= 1e-6 * rh
+    assert np.abs(pd - ph).max() < 1e-9
+    assert np.abs(xd - xh).max() <= 1e-5 * np.abs(xh).max()
+    assert np.abs(idd - idh).max() <= 1e-5
