@@ -250,7 +250,7 @@ def main():
                                     f"{win.w}x{win.h}, points sharded over {world} GPUs ({win.P} points / {R_local} residuals on rank 0)") +
                                    "; step = one Gauss-Newton iteration (accumulate A/L/SC, fp64 stitch, solve, back-substitute, "
                                    f"step, re-linearise, applyRes), timed as the mean of {inner} consecutive iterations",
-                       "gn_loop": "device-resident (k_gn_solve)" if args.resident else "host solve (blocked LDL^T), device everything else",
+                       "gn_loop": "device-resident (k_gn_solve)" if args.resident else "host solve (blocked LDL^T), device everything else incl. the step (poses, precalc, deltas from x)",
                        "window": args.window, "keyframes": win.n, "points_per_gpu": win.P, "inner_repeat": inner,
                        "timed_region_ms": round(dt * 1e3, 2),
                        "residuals_per_gpu": R_local, "residuals_total": R_total,
