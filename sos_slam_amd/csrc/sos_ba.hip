@@ -2057,8 +2057,9 @@ __global__ __launch_bounds__(SOS_RSB) void k_stage_expand(BaDev d, float4 *__res
                                                       int nStageBlocks, const float4 *__restrict__ pre_src, float4 *__restrict__ t_pre) {
   stage_block((int)blockIdx.x, threadIdx.x, d, stage_dst, stage_src, n4, nStageBlocks, pre_src, t_pre);
 }
-__device__ __forceinline__ void resub_point_block(const BaDev &d, const XArg &x, const float *__restrict__ adHF, const float *__restrict__ adTF,
-                                                  float *__restrict__ step_out, float stepfacD, const float *__restrict__ x_dev, float *sxAd) {
+__device__ __forceinline__ void resub_point_block(const BaDev &d, const XArg *x, const float *__restrict__ adHF, const float *__restrict__ adTF,
+                                                  float *__restrict__ step_out, float stepfacD, const float *__restrict__ x_dev, float *sxAd,
+                                                  const double *xd = nullptr) {
   const int tid = threadIdx.x;
   const int n = d.n, dim = SOS_CPARS + 8 * n;
   float *sx = sxAd + n * n * 8;
@@ -2073,7 +2074,7 @@ __device__ __forceinline__ void resub_point_block(const BaDev &d, const XArg &x,
   constexpr int RU = 16;  // residuals held in registers; longer lists finish in the tail loop below
   int2 e[RU];
   float4 ja[RU], jb[RU];
-  for (int i = tid; i < dim; i += SOS_RSB) sx[i] = x_dev ? x_dev[i] : x.v[i];  // the kernel argument, or the device-resident loop's x
+  for (int i = tid; i < dim; i += SOS_RSB) sx[i] = xd ? (float)xd[i] : (x_dev ? x_dev[i] : x->v[i]);  // a kernel argument, or the device-resident loop's x
   __syncthreads();
   // The table (item = (pair idx = n*h + t, half jh): 4 of the 8 outputs from 8 + 8 float4 loads of the adjoint rows)
   // depends on nothing else: its loads are issued ahead of the point's dependent chain (list entries -> JpJd rows), so the
@@ -2182,7 +2183,7 @@ __global__ __launch_bounds__(SOS_RSB) void k_resub_fused(BaDev d, XArg x, const 
     stage_block((int)blockIdx.x - nPointBlocks, threadIdx.x, d, stage_dst, stage_src, n4, nStageBlocks, pre_src, t_pre);
     return;
   }
-  resub_point_block(d, x, adHF, adTF, step_out, stepfacD, x_dev, sxAd);
+  resub_point_block(d, &x, adHF, adTF, step_out, stepfacD, x_dev, sxAd);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2210,6 +2211,20 @@ __device__ __forceinline__ void devstep_block(int sb, int nsb, const BaDev &d, c
   double *dsm = reinterpret_cast<double *>(smemf + ((28 * n * n + 3) / 4) * 4 + 4);
   double *c2w = dsm, *w2c = dsm + 12 * n, *stN = dsm + 24 * n, *cvN = dsm + 34 * n;
   float *sK = reinterpret_cast<float *>(cvN + 4);
+  // requested first, used last: the FEJ parts of this thread's pair record and the pair of its expansion tile (their latency
+  // runs under the frame exponentials)
+  const sos_precalc *old = reinterpret_cast<const sos_precalc *>(g.stage + g.st_pre);
+  float fej[13];
+  if (tid < n * n) {
+    const sos_precalc *o = old + tid;
+#pragma unroll
+    for (int i = 0; i < 9; i++) fej[i] = o->PRE_RTll_0[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) fej[9 + i] = o->PRE_tTll_0[i];
+    fej[12] = o->PRE_b0_mode;
+  }
+  const int ex_e = sb * SOS_RSB + tid, ex_tile = ex_e >> 3, ex_q = ex_e & 7;
+  const int ex_pair = (ex_tile < d.ntiles && ex_q != 7) ? d.t_pair[ex_tile] : -1;
   if (tid < n) {  // FrameHessian::setState, FS/HessianBlocks.h:217-230
     const int f = tid;
     double st[10], scv[6];
@@ -2239,7 +2254,6 @@ __device__ __forceinline__ void devstep_block(int sb, int nsb, const BaDev &d, c
     sK[4] = 1.0f / sK[0]; sK[5] = 1.0f / sK[1]; sK[6] = -sK[2] / sK[0]; sK[7] = -sK[3] / sK[1];
   }
   __syncthreads();
-  const sos_precalc *old = reinterpret_cast<const sos_precalc *>(g.stage + g.st_pre);  // the FEJ parts do not change inside the loop
   for (int pidx = tid; pidx < n * n; pidx += SOS_RSB) {  // FrameFramePrecalc::set, FS/HessianBlocks.cpp:431-461
     const int h = pidx % n, t = pidx / n;
     const double *Wt = w2c + 12 * t, *Ch = c2w + 12 * h;
@@ -2264,12 +2278,20 @@ __device__ __forceinline__ void devstep_block(int sb, int nsb, const BaDev &d, c
       for (int j = 0; j < 3; j++) pc->PRE_KRKiTll[3 * i + j] = KR[3 * i] * Ki[j] + KR[3 * i + 1] * Ki[3 + j] + KR[3 * i + 2] * Ki[6 + j];
 #pragma unroll
     for (int i = 0; i < 3; i++) pc->PRE_KtTll[i] = Km[3 * i] * tf[0] + Km[3 * i + 1] * tf[1] + Km[3 * i + 2] * tf[2];
-    const sos_precalc *o = old + pidx;
+    if (pidx == tid) {  // the FEJ parts do not change inside the loop (first round of the loop: prefetched above)
 #pragma unroll
-    for (int i = 0; i < 9; i++) pc->PRE_RTll_0[i] = o->PRE_RTll_0[i];
+      for (int i = 0; i < 9; i++) pc->PRE_RTll_0[i] = fej[i];
 #pragma unroll
-    for (int i = 0; i < 3; i++) pc->PRE_tTll_0[i] = o->PRE_tTll_0[i];
-    pc->PRE_b0_mode = o->PRE_b0_mode;
+      for (int i = 0; i < 3; i++) pc->PRE_tTll_0[i] = fej[9 + i];
+      pc->PRE_b0_mode = fej[12];
+    } else {
+      const sos_precalc *o = old + pidx;
+#pragma unroll
+      for (int i = 0; i < 9; i++) pc->PRE_RTll_0[i] = o->PRE_RTll_0[i];
+#pragma unroll
+      for (int i = 0; i < 3; i++) pc->PRE_tTll_0[i] = o->PRE_tTll_0[i];
+      pc->PRE_b0_mode = o->PRE_b0_mode;
+    }
     pc->pad = 0.f;
     float eF = (float)g.abexp[h], eT = (float)g.abexp[t];  // AffLight::fromToVecExposure
     if (eF == 0 || eT == 0) eT = eF = 1;
@@ -2281,10 +2303,7 @@ __device__ __forceinline__ void devstep_block(int sb, int nsb, const BaDev &d, c
   }
   __syncthreads();
   // this block's share of the per-tile copies (expand_precalc_item from the records in LDS)
-  {
-    const int e = sb * SOS_RSB + tid, tile = e >> 3, q = e & 7;
-    if (tile < d.ntiles && q != 7) t_pre[e] = reinterpret_cast<const float4 *>(pre)[7 * (size_t)d.t_pair[tile] + q];
-  }
+  if (ex_pair >= 0) t_pre[ex_e] = reinterpret_cast<const float4 *>(pre)[7 * (size_t)ex_pair + ex_q];
   // ---- the canonical arrays and the new states, spread over the blocks (every block holds all of it in LDS): role 0 = states /
   // calibration / thresholds, role 1 = the precalc array, roles 2.. = 256 entries of adHTdeltaF each
   const int nRoles = 2 + (8 * n * n + SOS_RSB - 1) / SOS_RSB;
@@ -2319,7 +2338,7 @@ __device__ __forceinline__ void devstep_block(int sb, int nsb, const BaDev &d, c
     }
   }
 }
-__global__ __launch_bounds__(SOS_RSB) void k_resub_devstep(BaDev d, XArg x, const float *__restrict__ adHF, const float *__restrict__ adTF,
+__global__ __launch_bounds__(SOS_RSB) void k_resub_devstep(BaDev d, const float *__restrict__ adHF, const float *__restrict__ adTF,
                                                        float *__restrict__ step_out, float stepfacD, int nPointBlocks, DevStep g,
                                                        float4 *__restrict__ t_pre) {
   extern __shared__ __attribute__((aligned(16))) float sxAd[];
@@ -2327,7 +2346,7 @@ __global__ __launch_bounds__(SOS_RSB) void k_resub_devstep(BaDev d, XArg x, cons
     devstep_block((int)blockIdx.x - nPointBlocks, (int)gridDim.x - nPointBlocks, d, g, adHF, adTF, t_pre, sxAd);
     return;
   }
-  resub_point_block(d, x, adHF, adTF, step_out, stepfacD, nullptr, sxAd);
+  resub_point_block(d, nullptr, adHF, adTF, step_out, stepfacD, nullptr, sxAd, g.xd);
 }
 
 // ================================================================================================
@@ -3686,11 +3705,10 @@ extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const
   const bool resubAhead = !x && ba->resub_pending;
   ba->resub_pending = false;
   if (devStep) {  // back-substitution + the host's step / precalc work, one launch, nothing staged from the host
-    static_assert(sizeof(BaDev) + sizeof(XArg) + sizeof(DevStep) + 64 < 4096, "kernel arguments of k_resub_devstep");
+    static_assert(sizeof(BaDev) + sizeof(DevStep) + 64 < 4096, "kernel arguments of k_resub_devstep");
     const int n = ba->n, dim = 4 + 8 * n;
-    XArg xa;
     DevStep g;
-    for (int i = 0; i < dim; i++) { xa.v[i] = (float)x[i]; g.xd[i] = x[i]; }
+    for (int i = 0; i < dim; i++) g.xd[i] = x[i];
     for (int i = 0; i < n; i++) g.th[i] = frameEnergyTH[i];
     double *b = ba->d_ds;
     g.evalC2W = b; g.state_zero = b + 12 * n;
@@ -3703,7 +3721,7 @@ extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const
     const int nPB = divup(ba->P, SOS_RSB), nEB = divup(8 * ba->ntiles, SOS_RSB);
     const size_t lds = std::max(sizeof(float) * (8 * nn + 4 + 8 * (size_t)n), sizeof(float) * (28 * nn + 16) + sizeof(double) * (34 * (size_t)n + 8));
     ba->tm[1] += now_s() - t1;
-    k_resub_devstep<<<nPB + nEB, SOS_RSB, lds, st>>>(dv, xa, ba->d_adHostF.p, ba->d_adTargetF.p, dstep, stepfacD, nPB, g, ba->d_t_pre.p);
+    k_resub_devstep<<<nPB + nEB, SOS_RSB, lds, st>>>(dv, ba->d_adHostF.p, ba->d_adTargetF.p, dstep, stepfacD, nPB, g, ba->d_t_pre.p);
   } else if (resubAhead) {  // the back-substitution is already running: only the stage-in is left, one launch
     const int n4 = (int)((ba->st_xc + 3) / 4), nSB = divup(n4, SOS_RSB), nEB = divup(8 * ba->ntiles, SOS_RSB);
     k_stage_expand<<<nSB + nEB, SOS_RSB, 0, st>>>(dv, reinterpret_cast<float4 *>(ba->d_stage.p), reinterpret_cast<const float4 *>(ba->pin_dev + ba->pin_stage),
