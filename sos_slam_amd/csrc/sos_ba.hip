@@ -2040,7 +2040,9 @@ __global__ void k_expand_precalc(int ntiles, const int *__restrict__ t_pair, con
 // beyond the point blocks copy the per-step inputs of the following linearisation (precalc, adHTdelta, cDelta,
 // frame thresholds) from the device-mapped pinned block into device memory.
 struct XArg { float v[SOS_CPARS + 8 * SOS_MAX_FRAMES]; };
-#define SOS_RSB 256
+#ifndef SOS_RSB
+#define SOS_RSB 128
+#endif
 // one stage-in block: the first nStageBlocks copy the per-step inputs, the rest write the per-tile precalc records
 // straight from the mapped block
 __device__ __forceinline__ void stage_block(int sb, int tid, const BaDev &d, float4 *__restrict__ stage_dst, const float4 *__restrict__ stage_src,
@@ -2246,7 +2248,7 @@ __device__ __forceinline__ void devstep_block(int sb, int nsb, const BaDev &d, c
       for (int j = 0; j < 3; j++) W[3 * i + j] = C[3 * j + i];
     for (int i = 0; i < 3; i++) W[9 + i] = -(W[3 * i] * C[9] + W[3 * i + 1] * C[10] + W[3 * i + 2] * C[11]);
   }
-  if (tid == 64) {  // CalibHessian::setValue, FS/HessianBlocks.h:476-491
+  if (tid == 32) {  // CalibHessian::setValue, FS/HessianBlocks.h:476-491 (a lane behind the <= 17 frame lanes)
     double vs[4];
     for (int i = 0; i < 4; i++) cvN[i] = g.calib_in[i] + (-g.xd[i]);
     vs[0] = SOS_SCALE_F * cvN[0]; vs[1] = SOS_SCALE_F * cvN[1]; vs[2] = SOS_SCALE_C * cvN[2]; vs[3] = SOS_SCALE_C * cvN[3];
