@@ -293,8 +293,9 @@ __attribute__((target("avx2,fma"))) inline void ldlt_trailing_update(double *U, 
 }
 // The same update with 512-bit vectors where the host has them (the bench host is a Zen 5 EPYC): the whole panel of eight columns
 // in one pass -- 24 broadcast registers + 3 accumulators + 1 operand of the 32 zmm registers -- and masked tails instead of scalar
-// remainders.  Per element the operations are the ones of the 256-bit version in the same order (a chain of fnmadd over the
-// panel columns, ascending).
+// remainders.  Per element the operations are the ones of the 256-bit version's vector body in the same order (a chain of fnmadd
+// over the panel columns, ascending); that version's scalar remainders sum the products first, so the two paths agree to rounding,
+// not bit for bit.
 __attribute__((target("avx512f,fma"))) inline void ldlt_trailing_update_512(double *U, const double *WT, const double *LT, int n, int k1, int kb) {
   const size_t N = (size_t)n;
   int j = k1;
@@ -345,17 +346,29 @@ __attribute__((target("avx512f,fma"))) inline void ldlt_trailing_update_512(doub
     }
   }
 }
-// column k of a panel brought up to date with its q earlier pivots, 512-bit form of the loop inside ldlt_solve
-__attribute__((target("avx512f,fma"))) inline void ldlt_column_update_512(const double *uk, const double *WT, const double *LT, double *wt, int n, int k, int q) {
+// one pivot of a panel in ONE pass over rows k+1..n (512-bit): column k brought up to date with the q earlier pivots of the panel,
+// L(i,k) = a / d into both copies, the candidate diagonal updated -- the operations of the three loops of the 256-bit path, per
+// element in the same order -- and the largest |diagonal| that is left, so that the next pivot's threshold test needs no search
+__attribute__((target("avx512f,fma"))) inline double ldlt_pivot_512(double *uk, const double *WT, const double *LT, double *wt, double *lt, double *diag,
+                                                                    int n, int k, int q, double dinv) {
   const size_t N = (size_t)n;
   __m512d lk[LDLT_NB];
   for (int c = 0; c < q; c++) lk[c] = _mm512_set1_pd(LT[c * N + k]);
+  const __m512d dv = _mm512_set1_pd(dinv);
+  __m512d mx = _mm512_setzero_pd();
   for (int i = k + 1; i < n; i += 8) {
     const __mmask8 m = (n - i >= 8) ? (__mmask8)0xff : (__mmask8)((1u << (n - i)) - 1u);
     __m512d a = _mm512_maskz_loadu_pd(m, uk + i);
     for (int c = 0; c < q; c++) a = _mm512_fnmadd_pd(_mm512_maskz_loadu_pd(m, &WT[c * N + i]), lk[c], a);
+    const __m512d l = _mm512_mul_pd(a, dv);
     _mm512_mask_storeu_pd(wt + i, m, a);
+    _mm512_mask_storeu_pd(lt + i, m, l);
+    _mm512_mask_storeu_pd(uk + i, m, l);
+    const __m512d dg = _mm512_sub_pd(_mm512_maskz_loadu_pd(m, diag + i), _mm512_mul_pd(a, l));
+    _mm512_mask_storeu_pd(diag + i, m, dg);
+    mx = _mm512_max_pd(mx, _mm512_abs_pd(dg));
   }
+  return _mm512_reduce_max_pd(mx);
 }
 inline bool ldlt_have_avx512() {
   static const bool have = __builtin_cpu_supports("avx512f") && getenv("SOS_NO_AVX512") == nullptr;
@@ -373,15 +386,22 @@ __attribute__((target("avx2,fma"))) inline void ldlt_solve(const std::vector<dou
     for (int i = j + 1; i < n; i++) dst[i] = src[i];
     diag[j] = src[j];
   }
+  const bool wide = ldlt_have_avx512();
+  double restMax = -1.0;  // max |diag[k..n)| when the previous pivot's pass has left it (512-bit path), else < 0
   for (int k0 = 0; k0 < n; k0 += LDLT_NB) {
     const int kb = std::min(LDLT_NB, n - k0), k1 = k0 + kb;
     for (int k = k0; k < k1; k++) {
       const int q = k - k0;  // pivots of this panel already eliminated
-      int p = ldlt_argmax_abs(diag.data(), k, n);
       // threshold pivoting: the natural pivot is kept while it is within a factor 10 of the largest candidate (element
       // growth stays bounded by that factor); interchanges -- strided row/column swaps -- happen only when they buy
-      // stability.  Jacobi-scaled normal matrices (diagonal ~ 1) hardly ever need one.
-      if (std::fabs(diag[k]) >= 0.1 * std::fabs(diag[p])) p = k;
+      // stability.  Jacobi-scaled normal matrices (diagonal ~ 1) hardly ever need one.  The 512-bit path knows the largest
+      // candidate from the previous pivot's pass and searches for its position only when the test fails.
+      int p = k;
+      if (!(restMax >= 0.0 && std::fabs(diag[k]) >= 0.1 * restMax)) {
+        p = ldlt_argmax_abs(diag.data(), k, n);
+        if (std::fabs(diag[k]) >= 0.1 * std::fabs(diag[p])) p = k;
+      }
+      restMax = -1.0;
       perm[k] = p;  // interchange k (LAPACK ipiv style)
       if (p != k) {  // symmetric swap k <-> p (k < p) of the not yet eliminated part.  Finished L columns keep the row
                      // order they were computed in; the substitutions below replay the interchanges one by one instead
@@ -399,10 +419,12 @@ __attribute__((target("avx2,fma"))) inline void ldlt_solve(const std::vector<dou
         for (int i = k + 1; i < n; i++) { uk[i] = 0.0; wt[i] = 0.0; lt[i] = 0.0; }
         continue;
       }
+      if (wide) {
+        restMax = ldlt_pivot_512(uk, WT.data(), LT.data(), wt, lt, diag.data(), n, k, q, 1.0 / d);
+        continue;
+      }
       // bring column k (rows below the diagonal) up to date with the q earlier pivots of the panel
-      if (ldlt_have_avx512()) {
-        ldlt_column_update_512(uk, WT.data(), LT.data(), wt, n, k, q);
-      } else {
+      {
         int i = k + 1;
         __m256d lk[LDLT_NB];
         for (int c = 0; c < q; c++) lk[c] = _mm256_set1_pd(LT[c * N + k]);
@@ -426,7 +448,7 @@ __attribute__((target("avx2,fma"))) inline void ldlt_solve(const std::vector<dou
       }
     }
     if (k1 < n) {
-      if (ldlt_have_avx512()) ldlt_trailing_update_512(U.data(), WT.data(), LT.data(), n, k1, kb);
+      if (wide) ldlt_trailing_update_512(U.data(), WT.data(), LT.data(), n, k1, kb);
       else ldlt_trailing_update(U.data(), WT.data(), LT.data(), n, k1, kb);
     }
   }
