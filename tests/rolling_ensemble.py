@@ -1,0 +1,112 @@
+"""Ensemble form of the rolling-window parity check (used by tests/test_gpu_rolling_ensemble.py and tools/rolling_sweep.py).
+
+tests/test_gpu_rolling_window.py / test_gpu_rolling_vio.py pin ONE synthetic sequence per geometry and measure the device chain
+against the oracle chain with a yardstick taken from the same sequence: the distance between the fp32 oracle chain and the oracle
+chain with fp64-accumulated H/b.  That yardstick is a single draw from a heavy-tailed distribution -- two free-running chains part
+at knife-edge decisions (one candidate activated on one side only), and how far one such decision moves a pose or the scale of a
+freshly initialised visual-inertial window varies over two orders of magnitude from sequence to sequence -- so on another seed the
+pinned factors can fail although nothing is wrong (and could pass although something is).  Here the same three chains run over
+several seeds and the two distances are compared as DISTRIBUTIONS:
+
+  * keyframe-level decisions (flagged keyframes, window, the keyframes that leave and their order, IMU initialisation / trapped
+    scale) identical on every seed -- hard;
+  * per quantity q (pose leaving the window, window pose, scale, scaled IMU state, index-set symmetric differences):
+    geometric mean over seeds of worst |dev - orc|   <=  GEO_FACTOR x  geometric mean of worst |orc - truth|, and
+    max over seeds of worst |dev - orc|              <=  MAX_FACTOR x  max over seeds of worst |orc - truth|.
+"""
+import numpy as np
+
+from tests import rolling
+
+GEO_FACTOR = 3.0
+MAX_FACTOR = 3.0
+
+
+def _symdiff(a, b):
+    return len(set(a) ^ set(b))
+
+
+def run_seed(seed, vio=False, **scenario):
+    """One sequence through the device chain, the oracle chain and the fp64-accumulation oracle chain.  Returns the worst
+    distances (device-oracle `d_*`, oracle-truth `n_*`) and the list of hard-decision mismatches."""
+    sc = rolling.Scenario(vio=vio, seed=seed, **scenario)
+    dev, orc_, tru = rolling.DeviceChain(sc), rolling.OracleChain(sc), rolling.OracleChain(sc, truth=True)
+    for c in (dev, orc_, tru):
+        c.bootstrap()
+    m = dict(seed=seed, vio=vio, keyframes=0, left=0, hard=[], its_mismatch=0,
+             d_leave=0.0, n_leave=0.0, d_win=0.0, n_win=0.0, d_track=0.0, n_track=0.0,
+             d_res=0, n_res=0, d_act=0, n_act=0, d_pts=0, n_pts=0, first_sets_equal=None)
+    if vio:
+        m.update(d_scale=0.0, n_scale=0.0, d_state=0.0, n_state=0.0)
+    try:
+        while dev.next_frame < sc.n_frames:
+            lg, lo, lt = dev.step(), orc_.step(), tru.step()
+            k = lg.frameID
+            m["keyframes"] += 1
+            if lg.flagged != lo.flagged:
+                m["hard"].append((k, "flagged", lg.flagged, lo.flagged))
+            if lg.window_ids != lo.window_ids:
+                m["hard"].append((k, "window", lg.window_ids, lo.window_ids))
+                break
+            if [f for f, _ in lg.marginalized] != [f for f, _ in lo.marginalized]:
+                m["hard"].append((k, "leaving", [f for f, _ in lg.marginalized], [f for f, _ in lo.marginalized]))
+                break
+            m["its_mismatch"] += int(lg.iterations != lo.iterations)
+            m["d_track"] = max(m["d_track"], np.abs(lg.tracked_pose - lo.tracked_pose).max())
+            m["n_track"] = max(m["n_track"], np.abs(lo.tracked_pose - lt.tracked_pose).max())
+            sets = [("res", "residual_set"), ("act", "activated"), ("pts", "point_set_after")]
+            for key, attr in sets:
+                m["d_" + key] += _symdiff(getattr(lg, attr), getattr(lo, attr))
+                if lt.window_ids == lo.window_ids:
+                    m["n_" + key] += _symdiff(getattr(lo, attr), getattr(lt, attr))
+            if m["first_sets_equal"] is None:
+                m["first_sets_equal"] = all(_symdiff(getattr(lg, a), getattr(lo, a)) == 0 for _, a in sets)
+            for fid in lg.window_ids:
+                m["d_win"] = max(m["d_win"], np.abs(lg.window_poses[fid] - lo.window_poses[fid]).max())
+                if fid in lt.window_poses:
+                    m["n_win"] = max(m["n_win"], np.abs(lo.window_poses[fid] - lt.window_poses[fid]).max())
+            tm = dict(lt.marginalized)
+            for (fid, pg), (_, po) in zip(lg.marginalized, lo.marginalized):
+                m["left"] += 1
+                m["d_leave"] = max(m["d_leave"], np.abs(pg - po).max())
+                if fid in tm:
+                    m["n_leave"] = max(m["n_leave"], np.abs(po - tm[fid]).max())
+            if vio:
+                vg, vo, vt = lg.vio, lo.vio, lt.vio
+                if (vg["init"], vg["trapped"]) != (vo["init"], vo["trapped"]):
+                    m["hard"].append((k, "imu init / trapped", (vg["init"], vg["trapped"]), (vo["init"], vo["trapped"])))
+                m["d_scale"] = max(m["d_scale"], abs(vg["scale"] - vo["scale"]) * 200)
+                m["n_scale"] = max(m["n_scale"], abs(vo["scale"] - vt["scale"]) * 200)
+                for fid in vg["states"]:
+                    if fid in vo["states"]:
+                        m["d_state"] = max(m["d_state"], np.abs(dev.vio_scaled(vg["states"][fid]) - dev.vio_scaled(vo["states"][fid])).max())
+                    if fid in vo["states"] and fid in vt["states"]:
+                        m["n_state"] = max(m["n_state"], np.abs(dev.vio_scaled(vo["states"][fid]) - dev.vio_scaled(vt["states"][fid])).max())
+    finally:
+        dev.close()
+    return {k: (float(v) if isinstance(v, (np.floating, float)) else v) for k, v in m.items()}
+
+
+def summarize(runs):
+    """Geometric means and maxima over the runs, per quantity; `violations` lists what breaks the ensemble criteria."""
+    keys = ["leave", "win", "res", "act", "pts"] + (["scale", "state"] if runs and runs[0]["vio"] else [])
+    out, bad = {}, []
+    for r in runs:
+        for h in r["hard"]:
+            bad.append((r["seed"], "hard decision") + tuple(h))
+    for key in keys:
+        d = np.array([max(float(r["d_" + key]), 1e-12) for r in runs])
+        n = np.array([max(float(r["n_" + key]), 1e-12) for r in runs])
+        floor = 1.0 if key in ("res", "act", "pts") else 0.0   # a set difference of 0 counts as 1 in the geometric mean
+        gd, gn = np.exp(np.mean(np.log(np.maximum(d, floor or 1e-12)))), np.exp(np.mean(np.log(np.maximum(n, floor or 1e-12))))
+        out[key] = dict(geo_dev_orc=float(gd), geo_orc_truth=float(gn), geo_ratio=float(gd / gn), max_dev_orc=float(d.max()),
+                        max_orc_truth=float(n.max()), max_ratio=float(d.max() / n.max()))
+        if gd > GEO_FACTOR * gn:
+            bad.append((key, "geometric mean", float(gd), float(gn)))
+        if d.max() > MAX_FACTOR * n.max():
+            bad.append((key, "maximum", float(d.max()), float(n.max())))
+    out["its_mismatch_total"] = int(sum(r["its_mismatch"] for r in runs))
+    out["keyframes_total"] = int(sum(r["keyframes"] for r in runs))
+    out["left_total"] = int(sum(r["left"] for r in runs))
+    out["violations"] = bad
+    return out
