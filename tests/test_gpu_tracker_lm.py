@@ -26,10 +26,11 @@ def _rel_pose(win, k=0):
     return np.concatenate([(Rn.T @ Rr).reshape(-1), Rn.T @ (tr - tn)])
 
 
-@pytest.fixture(scope="module", params=["W7", "T6"])
-def rig(request):
+def make_rig(name, **window_args):
+    """The tracker rig of this file (device facade + oracle trackers on the optimised window `name`); a generator, also used by
+    tools/tracker_sweep.py with other seeds."""
     from sos_slam_amd import host
-    win = synth.make_window(request.param, extra_frames=2)
+    win = synth.make_window(name, extra_frames=2, **window_args)
     ow = hp.oracle_window(win)
     ow.optimize(6, nthreads=6)
     sysm = host.System.from_window(win)
@@ -49,12 +50,17 @@ def rig(request):
     ht.set_ref_raw(c[:, 0], c[:, 1], c[:, 2], hdi)
     new_dI, _ = orc.make_images(win.extra_images[0])
     st = ow.frame(win.n - 1)["state"]
-    yield dict(key=request.param, win=win, ow=ow, sysm=sysm, ot=trackers[0], ott=trackers[1], ht=ht, new_dI=new_dI,
+    yield dict(key=name, win=win, ow=ow, sysm=sysm, ot=trackers[0], ott=trackers[1], ht=ht, new_dI=new_dI,
                new_slot=sysm.upload_image(win.extra_images[0]), ref_aff=np.array([st[6] * 10.0, st[7] * 1000.0]),
                levels=len(trackers[0].pc_n))
     ht.close()
     sysm.close()
     ow.close()
+
+
+@pytest.fixture(scope="module", params=["W7", "T6"])
+def rig(request):
+    yield from make_rig(request.param)
 
 
 PERTURB = [np.zeros(6), np.array([0.004, -0.003, 0.002, 0.002, -0.002, 0.001]), np.array([-0.01, 0.008, 0.005, -0.004, 0.003, 0.004]),
