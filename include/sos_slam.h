@@ -61,6 +61,7 @@ extern "C" {
 #define SOS_ERR_HIP (-2)
 #define SOS_ERR_STATE (-3)
 #define SOS_ERR_NOMEM (-4)
+#define SOS_ERR_TIMEOUT (-5) /* a device-resident loop gave up waiting for its own workgroups (see sos_tracker_set_lm_spin_limit) */
 
 /* ------------------------------------------------------------------------------------------------
  * plain-data records
@@ -433,7 +434,10 @@ int sos_tracker_calc_gs(sos_tracker *trk, int lvl, float a, float b0, double *H,
  * lastFlowIndicators, `aborted` (the :527 test fired), the levels in the order they finished with their residual
  * (a repeated level appears twice) and the number of residual evaluations.  The caller applies the final affine sanity
  * tests of :538-551.  Ki = the caller's inverse intrinsics per level (9 floats each; identity for the loop aligner),
- * refAff = lastRef_aff_g2l (a, b). */
+ * refAff = lastRef_aff_g2l (a, b).
+ * The workgroups of the launch exchange their sums in flight, so all of them have to be resident; every wait is bounded (see
+ * sos_tracker_set_lm_spin_limit).  SOS_ERR_TIMEOUT: a workgroup gave up, the launch drained, `hyp` holds no results -- the
+ * tracker stays usable; retry, or run the loop around the primitives above (what the facade's CoarseTracker does). */
 typedef struct sos_track_hyp {
   double refToNew[12];
   double aff[2];
@@ -455,6 +459,12 @@ int sos_tracker_track(sos_tracker *trk, int newSlot, const float *Ki, float ref_
  * total number of residual evaluations are optional outputs. */
 int sos_tracker_optimize_scale(sos_tracker *trk, int stereoSlot, const float *RKi, const float *t, const float *K1,
                                int coarsestLvl, int nHyp, float *scales, double *lastResiduals, int *evals);
+
+/* Bound of every in-flight wait of the two loops above, in polling rounds (about a microsecond each; default 2^18).  A device that
+ * runs other streams beside the tracker's may keep some workgroups of a loop from becoming resident for a while; the loop then
+ * waits up to this bound and returns SOS_ERR_TIMEOUT instead of hanging.  0 makes every wait that is not satisfied at once give up
+ * (tests use it to drive the fallback). */
+int sos_tracker_set_lm_spin_limit(sos_tracker *trk, unsigned rounds);
 
 /* ScaleOptimizer::calcResScale / calcGSSSEScale (FS/ScaleOptimizer.cpp:273-437, 232-271).
  * RKi = rot(tfmF0ToF1) * Ki[lvl], t = trans(tfmF0ToF1); K1 = (fx1,fy1,cx1,cy1) of level `lvl`. */

@@ -193,6 +193,12 @@ int sosf_tracker_optimize_scale_kf(sosf_tracker *trk, int stereoSlot, const doub
  * arithmetic per pixel; the two differ by the rounding of the 8x8 solve).  last_evals: residual evaluations of the last call. */
 int sosf_tracker_set_device_lm(sosf_tracker *trk, int on);
 int sosf_tracker_last_evals(sosf_tracker *trk, int *evals);
+/* The one-launch loops need all their workgroups resident; their waits are bounded (sos_tracker_set_lm_spin_limit, include/sos_slam.h).
+ * When a launch comes back SOS_ERR_TIMEOUT -- other streams kept the device busy -- the facade redoes that call with the host loop
+ * around the device passes (same decisions; hypotheses of the batch one by one) and counts it here.  set_lm_spin_limit forwards the
+ * bound (rounds of about a microsecond, default 2^18; 0 = give up at the first unmet wait). */
+int sosf_tracker_set_lm_spin_limit(sosf_tracker *trk, unsigned rounds);
+int sosf_tracker_lm_fallbacks(sosf_tracker *trk, int *count);
 /* FullSystem::trackNewCoarse, the hypothesis list (FS/FullSystem.cpp:150-213): slast_2_sprelast and lastF_2_slast as the
  * reference forms them from the frame history, lastF_2_fh_imu12 = the IMU-predicted motion or NULL; posesValid = all
  * three shells have poseValid.  Writes n tries (12 doubles each, row-major R | t); 84 without / 85 with the IMU try. */

@@ -1896,9 +1896,13 @@ int CoarseTracker::trackHypotheses(int newSlot, float new_ab_exposure, const std
       hyp[k].aff[0] = aff_last_2_l.a;
       hyp[k].aff[1] = aff_last_2_l.b;
     }
-    if (deviceLM) {
+    bool onDevice = deviceLM;
+    if (onDevice) {
       const int rc = sos_tracker_track(trk, newSlot, &Ki[0][0], ref_ab_exposure, new_ab_exposure, refAff, coarsestLvl, achievedRes, (int)cnt, hyp.data());
-      if (rc != SOS_OK) return rc;
+      if (rc == SOS_ERR_TIMEOUT) {  // the launch could not get all its workgroups resident in time: this batch one by one, host loop
+        onDevice = false;
+        lmFallbacks++;
+      } else if (rc != SOS_OK) return rc;
     }
     out.evaluated += (int)cnt;
     for (size_t k = 0; k < cnt && !stop; k++) {
@@ -1906,7 +1910,7 @@ int CoarseTracker::trackHypotheses(int newSlot, float new_ab_exposure, const std
       AffLight aff_g2l_this = aff_last_2_l;
       double currentRes[5];
       bool trackingIsGood;
-      if (deviceLM) {
+      if (onDevice) {
         // where would the sequential loop have stopped this try?  thresholds only tighten, so never later than the device did
         const sos_track_hyp &h = hyp[k];
         int nvis = h.nvisits;
@@ -1916,7 +1920,10 @@ int CoarseTracker::trackHypotheses(int newSlot, float new_ab_exposure, const std
         if (nvis < h.nvisits) cut.aborted = 1;
         trackingIsGood = finishTrack(cut, nvis, lastF_2_fh_this, aff_g2l_this, currentRes);
       } else {
+        const bool keep = deviceLM;
+        deviceLM = false;
         trackingIsGood = trackNewestCoarse(newSlot, new_ab_exposure, lastF_2_fh_this, aff_g2l_this, coarsestLvl, achievedRes, currentRes);
+        deviceLM = keep;
       }
       out.tryIterations++;
       if (trackingIsGood && std::isfinite((float)currentRes[0]) && !(currentRes[0] >= achievedRes[0])) {  // a new winner, :239-247
@@ -1956,9 +1963,10 @@ bool CoarseTracker::trackNewestCoarse(int newSlot, float new_ab_exposure, SE3 &l
     for (int i = 0; i < 5; i++) lastResiduals[i] = NAN;
     lastFlowIndicators[0] = lastFlowIndicators[1] = lastFlowIndicators[2] = 1000;
     const double refAff[2] = {lastRef_aff_g2l.a, lastRef_aff_g2l.b};
-    if (sos_tracker_track(trk, newSlot, &Ki[0][0], ref_ab_exposure, new_ab_exposure, refAff, coarsestLvl, minResForAbort, 1, &hyp) != SOS_OK)
-      return false;
-    return finishTrack(hyp, hyp.nvisits, lastToNew_out, aff_g2l_out, lastResiduals);
+    const int rc = sos_tracker_track(trk, newSlot, &Ki[0][0], ref_ab_exposure, new_ab_exposure, refAff, coarsestLvl, minResForAbort, 1, &hyp);
+    if (rc == SOS_OK) return finishTrack(hyp, hyp.nvisits, lastToNew_out, aff_g2l_out, lastResiduals);
+    if (rc != SOS_ERR_TIMEOUT) return false;
+    lmFallbacks++;  // the one-launch loop gave up waiting for its workgroups: the same loop around the device passes, below
   }
   for (int i = 0; i < 5; i++) lastResiduals[i] = NAN;
   lastFlowIndicators[0] = lastFlowIndicators[1] = lastFlowIndicators[2] = 1000;
@@ -2123,6 +2131,14 @@ int CoarseTracker::optimizeScaleHyp(int stereoSlot, const SE3 &tfmF0ToF1, const 
   }
   std::vector<double> lr((size_t)5 * n);
   const int rc = sos_tracker_optimize_scale(trk, stereoSlot, RKiAll, tf, K1All, coarsestLvl, n, scales, lr.data(), &lastEvals);
+  if (rc == SOS_ERR_TIMEOUT) {  // (scales is untouched) one by one with the host loop
+    lmFallbacks++;
+    const bool keep = deviceLM;
+    deviceLM = false;
+    for (int k = 0; k < n; k++) errors[k] = optimizeScale(stereoSlot, tfmF0ToF1, K1_0, scales[k], coarsestLvl);
+    deviceLM = keep;
+    return SOS_OK;
+  }
   if (rc != SOS_OK) return rc;
   for (int k = 0; k < n; k++) errors[k] = (float)lr[(size_t)5 * k];
   return SOS_OK;
@@ -2174,9 +2190,13 @@ float CoarseTracker::optimizeScale(int stereoSlot, const SE3 &tfmF0ToF1, const f
       K1All[4 * l] = fx1[l]; K1All[4 * l + 1] = fy1[l]; K1All[4 * l + 2] = cx1[l]; K1All[4 * l + 3] = cy1[l];
     }
     float s = scale;
-    if (sos_tracker_optimize_scale(trk, stereoSlot, RKiAll, tf, K1All, coarsestLvl, 1, &s, last_residuals, &lastEvals) != SOS_OK) return NAN;
-    scale = s;
-    return (float)last_residuals[0];
+    const int rc = sos_tracker_optimize_scale(trk, stereoSlot, RKiAll, tf, K1All, coarsestLvl, 1, &s, last_residuals, &lastEvals);
+    if (rc == SOS_OK) {
+      scale = s;
+      return (float)last_residuals[0];
+    }
+    if (rc != SOS_ERR_TIMEOUT) return NAN;
+    lmFallbacks++;
   }
   lastEvals = 0;
   sos_tracker_set_gs_hint(trk, 1, 0.f);
@@ -2675,6 +2695,15 @@ extern "C" int sosf_tracker_set_device_lm(sosf_tracker *t, int on) {
 extern "C" int sosf_tracker_last_evals(sosf_tracker *t, int *evals) {
   if (!t || !evals) return SOS_ERR_ARG;
   *evals = t->ct->lastEvals;
+  return SOS_OK;
+}
+extern "C" int sosf_tracker_set_lm_spin_limit(sosf_tracker *t, unsigned rounds) {
+  if (!t) return SOS_ERR_ARG;
+  return sos_tracker_set_lm_spin_limit(t->ct->trk, rounds);
+}
+extern "C" int sosf_tracker_lm_fallbacks(sosf_tracker *t, int *count) {
+  if (!t || !count) return SOS_ERR_ARG;
+  *count = t->ct->lmFallbacks;
   return SOS_OK;
 }
 extern "C" int sosf_tracker_make_tries(const double *slast_2_sprelast12, const double *lastF_2_slast12, const double *lastF_2_fh_imu12,

@@ -368,6 +368,7 @@ class CoarseTracker {
   float new_ab_exposure_last = 1;
   bool deviceLM = true;  // trackNewestCoarse / poseEstimate as one launch (sos_tracker_track); false: the LM loop on the host
   int lastEvals = 0;     // residual evaluations of the last trackNewestCoarse
+  int lmFallbacks = 0;   // launches of the device loop that came back SOS_ERR_TIMEOUT and were redone with the host loop
   void scaleCoarseDepthL0(float scale);
   // loop-closure aligner (src/LoopClosure/PoseEstimator.cpp): template = 3-D points of the matched keyframe with one colour per
   // level; estimate() = the same Levenberg-Marquardt loop with zero reference affine parameters, no abort thresholds and

@@ -68,6 +68,7 @@ struct sos_tracker {
   unsigned long long *lm_part = nullptr;
   double *lm_out = nullptr, *lm_out_dev = nullptr;
   int lm_seq = 0;
+  unsigned lm_spin_limit = 1u << 18;  // LM_SPIN_LIMIT of sos_tracker_lm.inc
 };
 
 static inline int divup(int a, int b) { return (a + b - 1) / b; }

@@ -508,6 +508,14 @@ class HostTracker:
         """LM loop of track / pose_estimate as one device launch (default) or on the host around device residual passes."""
         _chk(self.L.sosf_tracker_set_device_lm(self.h_, 1 if on else 0), "sosf_tracker_set_device_lm")
 
+    def set_lm_spin_limit(self, rounds: int):
+        _chk(self.L.sosf_tracker_set_lm_spin_limit(self.h_, C.c_uint(int(rounds))), "sosf_tracker_set_lm_spin_limit")
+
+    def lm_fallbacks(self) -> int:
+        n = C.c_int(0)
+        _chk(self.L.sosf_tracker_lm_fallbacks(self.h_, C.byref(n)), "sosf_tracker_lm_fallbacks")
+        return int(n.value)
+
     def last_evals(self) -> int:
         n = C.c_int(0)
         _chk(self.L.sosf_tracker_last_evals(self.h_, C.byref(n)), "sosf_tracker_last_evals")

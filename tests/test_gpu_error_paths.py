@@ -64,3 +64,63 @@ def test_tracker_loop_entry_points_reject_misuse():
     assert rc == ERR_ARG
     ht.close()
     sysm.close()
+
+
+def test_device_loop_timeout_falls_back_to_host_loop():
+    """A one-launch loop whose workgroups do not all become resident in time returns SOS_ERR_TIMEOUT (bounded waits, no hang); the
+    facade then runs the same loop around the device passes.  Driven here with a spin limit of 0 (the first unmet wait gives up)."""
+    from sos_slam_amd import host, lib
+    from sos_slam_amd.synth import se3_exp12 as se3_exp, se3_mul12 as se3_mul
+    L = lib.load()
+    vp = C.c_void_p
+    L.sos_tracker_track.argtypes = [vp, C.c_int, vp, C.c_float, C.c_float, vp, C.c_int, vp, C.c_int, vp]
+    win = synth.make_window("W7", extra_frames=2)
+    sysm = host.System.from_window(win)
+    sysm.optimize(3)
+    ht = host.HostTracker(sysm)
+    ht.set_ref()
+    slot = sysm.upload_image(win.extra_images[0])
+    st_slot = sysm.upload_image(win.extra_images[1])
+    levels = sysm.context().levels
+    ref, new = win.frames[win.n - 1]["camToWorld"], win.extra_poses[0]
+    Rr, tr, Rn, tn = ref[:9].reshape(3, 3), ref[9:], new[:9].reshape(3, 3), new[9:]
+    T0 = se3_mul(se3_exp(np.array([0.004, -0.003, 0.002, 0.002, -0.002, 0.001])), np.concatenate([(Rn.T @ Rr).reshape(-1), Rn.T @ (tr - tn)]))
+    # references: the host loop and the device loop with the default bound
+    ht.set_device_lm(False)
+    ok_h, Th, ah, lh, fh = ht.track(slot, 1.0, T0, np.zeros(2), levels - 1)
+    ev_h = ht.last_evals()
+    ht.set_device_lm(True)
+    ok_d, Td, ad, ld, fd = ht.track(slot, 1.0, T0, np.zeros(2), levels - 1)
+    assert ok_h and ok_d and ht.lm_fallbacks() == 0
+    # the C-ABI itself: a multi-workgroup launch with limit 0 reports the timeout, and works again with the bound restored
+    trk = C.c_void_p(sysm.L.sosf_tracker_handle(ht.h_))
+    Ki = np.zeros((levels, 9), np.float32)
+    K = sysm.calib_value_scaled()
+    for l in range(levels):
+        fx, fy = K[0] / 2 ** l, K[1] / 2 ** l
+        cx, cy = (K[2] + 0.5) / 2 ** l - 0.5, (K[3] + 0.5) / 2 ** l - 0.5
+        Ki[l] = np.array([1 / fx, 0, -cx / fx, 0, 1 / fy, -cy / fy, 0, 0, 1], np.float32)
+    h = Hyp()
+    h.refToNew[:] = list(T0)
+    aff, mr = np.zeros(2), np.full(5, np.nan)
+    p = lambda a: a.ctypes.data_as(vp)
+    ht.set_lm_spin_limit(0)
+    assert L.sos_tracker_track(trk, slot, p(Ki), 1.0, 1.0, p(aff), levels - 1, p(mr), 1, C.byref(h)) == -5     # SOS_ERR_TIMEOUT
+    assert list(h.refToNew) == list(T0)                                                                       # nothing was written
+    # the facade: same call, redone by the host loop -- the host loop's result exactly
+    ok_f, Tf, af, lf, ff = ht.track(slot, 1.0, T0, np.zeros(2), levels - 1)
+    assert ok_f and ht.lm_fallbacks() == 1 and ht.last_evals() == ev_h
+    assert np.array_equal(Tf, Th) and np.array_equal(af, ah) and np.array_equal(lf[:levels], lh[:levels])
+    # the scale loop falls back the same way
+    tfm = np.concatenate([np.eye(3).reshape(-1), np.array([-0.11, 0.0, 0.0])])
+    K1 = np.asarray(K, np.float32)
+    ht.set_device_lm(False)
+    s_h, e_h = ht.optimize_scale(st_slot, tfm, K1, 1.3, levels - 1)
+    ht.set_device_lm(True)
+    s_f, e_f = ht.optimize_scale(st_slot, tfm, K1, 1.3, levels - 1)
+    assert ht.lm_fallbacks() == 2 and s_f == s_h and e_f == e_h
+    ht.set_lm_spin_limit(1 << 18)
+    ok_r, Tr, ar, lr_, fr = ht.track(slot, 1.0, T0, np.zeros(2), levels - 1)
+    assert ok_r and ht.lm_fallbacks() == 2 and np.array_equal(Tr, Td)
+    ht.close()
+    sysm.close()
