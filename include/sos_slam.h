@@ -532,6 +532,26 @@ int sos_immature_trace(sos_ctx *ctx, const sos_trace_params *prm, int frameSlot,
 int sos_immature_trace_all(sos_ctx *ctx, const sos_trace_params *prm, int frameSlot, int count, sos_immature *pts,
                            const int32_t *hostOfPoint, int nhosts, const float *KRKi, const float *Kt, const float *aff);
 
+/* Device-resident form of the same loop.  FullSystem::traceNewCoarse runs on EVERY frame, and between two keyframes nothing on the
+ * host reads what it writes (idepth_min / idepth_max / quality / lastTrace*: their readers are activatePointsMT and the
+ * marginalisation flags of makeKeyFrame, FS/FullSystem.cpp:375-531, 783-931) -- so the records of a keyframe's immature points can
+ * stay on the device from makeNewTraces until the next keyframe decision instead of crossing the bus twice per frame.
+ *   put     the immature points of host keyframe `hostKey` (records as sos_immature_init / the array calls produce them);
+ *           replaces an earlier list of that key, count = 0 removes it (keyframe marginalised, points activated / deleted)
+ *   trace   traceNewCoarse against the frame in frameSlot: every point of the listed keys, in place, ONE launch, nothing
+ *           copied and nothing waited for; KRKi / Kt / aff hold one entry per listed key (9 / 3 / 2 floats), as for trace_all.
+ *           Keys without points are skipped; SOS_ERR_ARG for a key listed twice or more than SOS_MAX_FRAMES keys
+ *   get     the records of a key back to the host (count must equal the stored count); count() reports it (0 if absent)
+ * Records come out bit-identical to the same sequence of sos_immature_trace_all calls. */
+typedef struct sos_immset sos_immset;
+int sos_immset_create(sos_ctx *ctx, sos_immset **out);
+void sos_immset_destroy(sos_immset *set);
+int sos_immset_put(sos_immset *set, int hostKey, int count, const sos_immature *pts);
+int sos_immset_trace(sos_immset *set, const sos_trace_params *prm, int frameSlot, int nhosts, const int32_t *hostKeys,
+                     const float *KRKi, const float *Kt, const float *aff);
+int sos_immset_count(sos_immset *set, int hostKey, int *count);
+int sos_immset_get(sos_immset *set, int hostKey, int count, sos_immature *out);
+
 /* ---- point activation: FullSystem::optimizeImmaturePoint over the candidates chosen by activatePointsMT ------------
  * (FS/FullSystemOptPoint.cpp:47-192 with ImmaturePoint::linearizeResidual, FS/ImmaturePoint.cpp:475-545; the loop
  * FS/FullSystem.cpp:365-374,476-487).  A 1-D Levenberg-Marquardt on the inverse depth of every candidate against

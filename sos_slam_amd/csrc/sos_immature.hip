@@ -74,12 +74,27 @@ __global__ void k_immature_init(sos_trace_params P, const float *__restrict__ dI
   out[i] = p;
 }
 
+#ifndef TRACE_G
+#define TRACE_G 16   // lanes per immature point in the trace kernels (1 = thread per point)
+#endif
+#define TRACE_PPB (64 / TRACE_G)   // points per 64-thread block
 struct TraceArgs {
   float K[9], Kt[3], aff[2];
 };
 
+// GL = 1: one thread per point.  GL = 16: one 16-lane group (a DPP row) per point -- every lane runs the scalar logic on its own copy
+// of the record (identical values, identical branches within the group), and the three loops that carry the work are split over the
+// lanes without changing a single operation or its order:
+//   * the discrete search: lane gl evaluates the steps gl, gl + 16, ... (positions by the reference's repeated addition, every step's
+//     energy summed over the pattern in the reference's order by ONE lane), then the first minimum in step order = the minimum with
+//     ties to the lower index (a symmetric 4-stage exchange), the second-best score likewise a plain minimum;
+//   * the Gauss-Newton refinement: lanes 0..7 fetch one pattern pixel each, the three running sums are folded in pattern order by
+//     every lane from the lanes' addends (the reference's `continue` for a non-finite pixel included).
+// A point's dependent memory round trips drop from (steps / 4 + iterations) to about (steps / 16 + iterations), and four times as
+// many waves are in flight.  Lanes of a group return together, so the exchanges (width 16) only ever read active lanes.
+template <int GL>
 __device__ __forceinline__ int trace_one(const sos_trace_params &P, const float *dI, int w, int h, sos_immature &p,
-                                         const TraceArgs &A) {
+                                         const TraceArgs &A, int gl = 0) {
 #define OOB_RETURN(st)             \
   do {                             \
     p.lastTraceUV[0] = -1;         \
@@ -153,15 +168,9 @@ __device__ __forceinline__ int trace_one(const sos_trace_params &P, const float 
   }
   if (!isfinite(dx) || !isfinite(dy)) OOB_RETURN(SOS_IPS_OOB);
 
-  // the discrete search.  errors[] is only needed for the second-best score outside +-radius of the best: kept in
-  // local memory (99 floats per thread would not fit the register budget anyway)
-  float errors[100];
   float bestU = 0, bestV = 0, bestEnergy = 1e10f;
   int bestIdx = -1;
   if (numSteps >= 100) numSteps = 99;
-  // The steps are independent of each other (only the best-so-far bookkeeping is sequential): four of them are
-  // evaluated together so that their 4 x 32 texel requests are in flight at once instead of one step per memory round
-  // trip; positions by repeated addition and the bookkeeping in step order, as in the one-step loop -> same records.
   auto step_energy = [&](float qx, float qy) -> float {
     float energy = 0;
 #pragma unroll
@@ -174,40 +183,93 @@ __device__ __forceinline__ int trace_one(const sos_trace_params &P, const float 
     }
     return energy;
   };
-  constexpr int TU = 4;
-  for (int i0 = 0; i0 < numSteps; i0 += TU) {
-    float qx[TU], qy[TU], en[TU];
+  float secondBest = 1e10f;
+  if constexpr (GL == 1) {
+    // errors[] is only needed for the second-best score outside +-radius of the best: kept in local memory (99 floats per
+    // thread would not fit the register budget anyway).
+    // The steps are independent of each other (only the best-so-far bookkeeping is sequential): four of them are
+    // evaluated together so that their 4 x 32 texel requests are in flight at once instead of one step per memory round
+    // trip; positions by repeated addition and the bookkeeping in step order, as in the one-step loop -> same records.
+    float errors[100];
+    constexpr int TU = 4;
+    for (int i0 = 0; i0 < numSteps; i0 += TU) {
+      float qx[TU], qy[TU], en[TU];
 #pragma unroll
-    for (int k = 0; k < TU; k++) {
-      qx[k] = ptx;
-      qy[k] = pty;
-      ptx += dx;
-      pty += dy;
-    }
-    if (i0 + TU <= numSteps) {  // full group: no per-step branches between the requests
+      for (int k = 0; k < TU; k++) {
+        qx[k] = ptx;
+        qy[k] = pty;
+        ptx += dx;
+        pty += dy;
+      }
+      if (i0 + TU <= numSteps) {  // full group: no per-step branches between the requests
 #pragma unroll
-      for (int k = 0; k < TU; k++) en[k] = step_energy(qx[k], qy[k]);
-    } else {
+        for (int k = 0; k < TU; k++) en[k] = step_energy(qx[k], qy[k]);
+      } else {
 #pragma unroll
-      for (int k = 0; k < TU; k++) en[k] = (i0 + k < numSteps) ? step_energy(qx[k], qy[k]) : 0.f;
-    }
+        for (int k = 0; k < TU; k++) en[k] = (i0 + k < numSteps) ? step_energy(qx[k], qy[k]) : 0.f;
+      }
 #pragma unroll
-    for (int k = 0; k < TU; k++) {
-      const int i = i0 + k;
-      if (i < numSteps) {
-        errors[i] = en[k];
-        if (en[k] < bestEnergy) {
-          bestU = qx[k];
-          bestV = qy[k];
-          bestEnergy = en[k];
-          bestIdx = i;
+      for (int k = 0; k < TU; k++) {
+        const int i = i0 + k;
+        if (i < numSteps) {
+          errors[i] = en[k];
+          if (en[k] < bestEnergy) {
+            bestU = qx[k];
+            bestV = qy[k];
+            bestEnergy = en[k];
+            bestIdx = i;
+          }
         }
       }
     }
+    for (int i = 0; i < numSteps; i++)
+      if ((i < bestIdx - P.minTraceTestRadius || i > bestIdx + P.minTraceTestRadius) && errors[i] < secondBest) secondBest = errors[i];
+  } else {
+    constexpr int RMAX = (99 + GL - 1) / GL;
+    float qx[RMAX], qy[RMAX], en[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; r++) {
+      qx[r] = qy[r] = en[r] = 0.f;
+      if (GL * r < numSteps) {  // (uniform in the group)
+        for (int k = 0; k < GL && GL * r + k < numSteps; k++) {
+          if (k == gl) { qx[r] = ptx; qy[r] = pty; }
+          ptx += dx;
+          pty += dy;
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RMAX; r++)
+      if (GL * r + gl < numSteps) en[r] = step_energy(qx[r], qy[r]);
+#pragma unroll
+    for (int r = 0; r < RMAX; r++) {
+      const int i = GL * r + gl;
+      if (i < numSteps && en[r] < bestEnergy) {
+        bestU = qx[r];
+        bestV = qy[r];
+        bestEnergy = en[r];
+        bestIdx = i;
+      }
+    }
+#pragma unroll
+    for (int o = GL / 2; o > 0; o >>= 1) {
+      const float oe = __shfl_xor(bestEnergy, o, GL), ou = __shfl_xor(bestU, o, GL), ov = __shfl_xor(bestV, o, GL);
+      const int oi = __shfl_xor(bestIdx, o, GL);
+      // a lane without a candidate carries (1e10, -1): any candidate (energy < 1e10) beats it; equal energies -> the earlier step
+      const bool take = (oi >= 0) && (bestIdx < 0 || oe < bestEnergy || (oe == bestEnergy && oi < bestIdx));
+      if (take) { bestEnergy = oe; bestU = ou; bestV = ov; bestIdx = oi; }
+    }
+#pragma unroll
+    for (int r = 0; r < RMAX; r++) {
+      const int i = GL * r + gl;
+      if (i < numSteps && (i < bestIdx - P.minTraceTestRadius || i > bestIdx + P.minTraceTestRadius) && en[r] < secondBest) secondBest = en[r];
+    }
+#pragma unroll
+    for (int o = GL / 2; o > 0; o >>= 1) {
+      const float os = __shfl_xor(secondBest, o, GL);
+      if (os < secondBest) secondBest = os;
+    }
   }
-  float secondBest = 1e10f;
-  for (int i = 0; i < numSteps; i++)
-    if ((i < bestIdx - P.minTraceTestRadius || i > bestIdx + P.minTraceTestRadius) && errors[i] < secondBest) secondBest = errors[i];
   const float newQuality = secondBest / bestEnergy;
   if (newQuality < p.quality || numSteps > 10) p.quality = newQuality;
 
@@ -216,20 +278,47 @@ __device__ __forceinline__ int trace_one(const sos_trace_params &P, const float 
   if (P.GNIterations > 0) bestEnergy = 1e5f;
   for (int it = 0; it < P.GNIterations; it++) {
     float H = 1, bb = 0, energy = 0;
+    if constexpr (GL == 1) {
 #pragma unroll
-    for (int idx = 0; idx < 8; idx++) {
-      float hit[3];
-      interp33(dI, (float)(bestU + rp[idx][0]), (float)(bestV + rp[idx][1]), w, h, hit);
-      if (!isfinite(hit[0])) {
-        energy += 1e5f;
-        continue;
+      for (int idx = 0; idx < 8; idx++) {
+        float hit[3];
+        interp33(dI, (float)(bestU + rp[idx][0]), (float)(bestV + rp[idx][1]), w, h, hit);
+        if (!isfinite(hit[0])) {
+          energy += 1e5f;
+          continue;
+        }
+        const float residual = hit[0] - (aff[0] * p.color[idx] + aff[1]);
+        const float dResdDist = dx * hit[1] + dy * hit[2];
+        const float hw = fabsf(residual) < P.huberTH ? 1 : P.huberTH / fabsf(residual);
+        H += hw * dResdDist * dResdDist;
+        bb += hw * residual * dResdDist;
+        energy += p.weights[idx] * p.weights[idx] * hw * residual * residual * (2 - hw);
       }
-      const float residual = hit[0] - (aff[0] * p.color[idx] + aff[1]);
+    } else {
+      // lane gl < 8: the addends of pattern pixel gl (rp / color / weights picked by a select chain: no dynamic register index)
+      float rx = 0, ry = 0, col = 0, wgt = 0;
+#pragma unroll
+      for (int idx = 0; idx < 8; idx++)
+        if ((gl & 7) == idx) { rx = rp[idx][0]; ry = rp[idx][1]; col = p.color[idx]; wgt = p.weights[idx]; }
+      float hit[3];
+      interp33(dI, (float)(bestU + rx), (float)(bestV + ry), w, h, hit);
+      const float residual = hit[0] - (aff[0] * col + aff[1]);
       const float dResdDist = dx * hit[1] + dy * hit[2];
       const float hw = fabsf(residual) < P.huberTH ? 1 : P.huberTH / fabsf(residual);
-      H += hw * dResdDist * dResdDist;
-      bb += hw * residual * dResdDist;
-      energy += p.weights[idx] * p.weights[idx] * hw * residual * residual * (2 - hw);
+      const float aH = hw * dResdDist * dResdDist, ab = hw * residual * dResdDist, ae = wgt * wgt * hw * residual * residual * (2 - hw);
+      const int fin = isfinite(hit[0]) ? 1 : 0;
+#pragma unroll
+      for (int idx = 0; idx < 8; idx++) {
+        const int f = __shfl(fin, idx, GL);
+        const float tH = __shfl(aH, idx, GL), tb = __shfl(ab, idx, GL), te = __shfl(ae, idx, GL);
+        if (!f) {
+          energy += 1e5f;
+        } else {
+          H += tH;
+          bb += tb;
+          energy += te;
+        }
+      }
     }
     if (energy > bestEnergy) {
       stepBack *= 0.5f;
@@ -281,11 +370,11 @@ __device__ __forceinline__ int trace_one(const sos_trace_params &P, const float 
 
 __global__ __launch_bounds__(64) void k_immature_trace(sos_trace_params P, const float *__restrict__ dI, int w, int h, int count,
                                                        sos_immature *__restrict__ pts, TraceArgs A) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) / TRACE_G, gl = threadIdx.x % TRACE_G;
   if (i >= count) return;
   sos_immature p = pts[i];
-  trace_one(P, dI, w, h, p, A);
-  pts[i] = p;
+  trace_one<TRACE_G>(P, dI, w, h, p, A, gl);
+  if (gl == 0) pts[i] = p;
 }
 
 // whole traceNewCoarse in one launch: every point carries the index of its host keyframe, the host -> frame
@@ -293,14 +382,32 @@ __global__ __launch_bounds__(64) void k_immature_trace(sos_trace_params P, const
 __global__ __launch_bounds__(64) void k_immature_trace_batch(sos_trace_params P, const float *__restrict__ dI, int w, int h, int count,
                                                              sos_immature *__restrict__ pts, const int *__restrict__ hostOf,
                                                              const TraceArgs *__restrict__ table) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) / TRACE_G, gl = threadIdx.x % TRACE_G;
   if (i >= count) return;
   sos_immature p = pts[i];
   const TraceArgs A = table[hostOf[i]];
-  trace_one(P, dI, w, h, p, A);
-  pts[i] = p;
+  trace_one<TRACE_G>(P, dI, w, h, p, A, gl);
+  if (gl == 0) pts[i] = p;
 }
 
+// the device-resident sets (sos_immset): up to SOS_MAX_FRAMES segments, one per host keyframe; block -> segment through a table in
+// the kernel arguments
+struct ImmSegs {
+  sos_immature *ptr[SOS_MAX_FRAMES];
+  int blockBegin[SOS_MAX_FRAMES + 1];
+  int count[SOS_MAX_FRAMES];
+  TraceArgs A[SOS_MAX_FRAMES];
+  int nseg;
+};
+__global__ __launch_bounds__(64) void k_immature_trace_sets(sos_trace_params P, const float *__restrict__ dI, int w, int h, ImmSegs S) {
+  int s = 0;
+  while (s + 1 < S.nseg && (int)blockIdx.x >= S.blockBegin[s + 1]) s++;
+  const int i = ((int)blockIdx.x - S.blockBegin[s]) * TRACE_PPB + (int)threadIdx.x / TRACE_G, gl = threadIdx.x % TRACE_G;
+  if (i >= S.count[s]) return;
+  sos_immature p = S.ptr[s][i];
+  trace_one<TRACE_G>(P, dI, w, h, p, S.A[s], gl);
+  if (gl == 0) S.ptr[s][i] = p;
+}
 
 // ---- point activation: FullSystem::optimizeImmaturePoint (FS/FullSystemOptPoint.cpp:47-192) ---------------------------
 // One wave per candidate: lane = (residual slot g = lane >> 3, pattern pixel = lane & 7), residuals beyond 8 in further
@@ -570,7 +677,7 @@ extern "C" int sos_immature_trace(sos_ctx *c, const sos_trace_params *prm, int f
   memcpy(A.K, KRKi, sizeof(A.K));
   memcpy(A.Kt, Kt, sizeof(A.Kt));
   memcpy(A.aff, aff, sizeof(A.aff));
-  k_immature_trace<<<(count + 63) / 64, 64, 0, c->stream>>>(*prm, c->dI[frameSlot][0], c->w, c->h, count,
+  k_immature_trace<<<(count + TRACE_PPB - 1) / TRACE_PPB, 64, 0, c->stream>>>(*prm, c->dI[frameSlot][0], c->w, c->h, count,
                                                             reinterpret_cast<sos_immature *>(st->dev), A);
   SOS_HIP(hipGetLastError());
   SOS_HIP(hipStreamSynchronize(c->stream));
@@ -600,12 +707,22 @@ extern "C" int sos_immature_trace_all(sos_ctx *c, const sos_trace_params *prm, i
     memcpy(tab[k].Kt, Kt + 3 * k, sizeof(tab[k].Kt));
     memcpy(tab[k].aff, aff + 2 * k, sizeof(tab[k].aff));
   }
-  k_immature_trace_batch<<<(count + 63) / 64, 64, 0, c->stream>>>(*prm, c->dI[frameSlot][0], c->w, c->h, count,
+  static const bool timing = getenv("SOS_TIMING") != nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (timing) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, c->stream); }
+  k_immature_trace_batch<<<(count + TRACE_PPB - 1) / TRACE_PPB, 64, 0, c->stream>>>(*prm, c->dI[frameSlot][0], c->w, c->h, count,
                                                                   reinterpret_cast<sos_immature *>(st->dev),
                                                                   reinterpret_cast<const int *>(st->dev + off_h),
                                                                   reinterpret_cast<const TraceArgs *>(st->dev + off_t));
   SOS_HIP(hipGetLastError());
+  if (timing) hipEventRecord(e1, c->stream);
   SOS_HIP(hipStreamSynchronize(c->stream));
+  if (timing) {
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    fprintf(stderr, "[sos] immature_trace_all: %d points, kernel %.1f us\n", count, ms * 1e3f);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+  }
   memcpy(pts, st->host, sizeof(sos_immature) * (size_t)count);
   return SOS_OK;
 }
@@ -642,5 +759,123 @@ extern "C" int sos_immature_activate(sos_ctx *c, const sos_activate_params *prm,
   SOS_HIP(hipGetLastError());
   SOS_HIP(hipStreamSynchronize(c->stream));
   memcpy(out, st->host + szP + szH + szT, szO);
+  return SOS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// device-resident immature sets
+// ------------------------------------------------------------------------------------------------
+struct sos_immset {
+  sos_ctx *ctx = nullptr;
+  struct Seg {
+    int key = 0, count = 0;
+    sos_immature *dev = nullptr;
+    size_t cap = 0;
+  };
+  std::vector<Seg> segs;
+  Seg *find(int key) {
+    for (auto &g : segs)
+      if (g.key == key) return &g;
+    return nullptr;
+  }
+};
+
+extern "C" int sos_immset_create(sos_ctx *c, sos_immset **out) {
+  if (!c || !out) return SOS_ERR_ARG;
+  sos_immset *s = new (std::nothrow) sos_immset();
+  if (!s) return SOS_ERR_NOMEM;
+  s->ctx = c;
+  *out = s;
+  return SOS_OK;
+}
+extern "C" void sos_immset_destroy(sos_immset *s) {
+  if (!s) return;
+  if (s->ctx) {
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+  }
+  for (auto &g : s->segs)
+    if (g.dev) (void)hipFree(g.dev);
+  delete s;
+}
+extern "C" int sos_immset_put(sos_immset *s, int hostKey, int count, const sos_immature *pts) {
+  if (!s || count < 0 || (count && !pts)) return SOS_ERR_ARG;
+  sos_ctx *c = s->ctx;
+  SOS_HIP(hipSetDevice(c->device));
+  sos_immset::Seg *g = s->find(hostKey);
+  if (count == 0) {
+    if (g) {
+      SOS_HIP(hipStreamSynchronize(c->stream));  // a trace of the old list may still be in flight
+      if (g->dev) SOS_HIP(hipFree(g->dev));
+      s->segs.erase(s->segs.begin() + (g - s->segs.data()));
+    }
+    return SOS_OK;
+  }
+  if (!g) {
+    if ((int)s->segs.size() >= SOS_MAX_FRAMES) return SOS_ERR_STATE;
+    s->segs.emplace_back();
+    g = &s->segs.back();
+    g->key = hostKey;
+  }
+  if ((size_t)count > g->cap) {
+    SOS_HIP(hipStreamSynchronize(c->stream));
+    if (g->dev) SOS_HIP(hipFree(g->dev));
+    g->dev = nullptr;
+    g->cap = 0;
+    g->count = 0;
+    const size_t want = (size_t)count + (size_t)count / 4 + 64;
+    if (hipMalloc((void **)&g->dev, sizeof(sos_immature) * want) != hipSuccess) return SOS_ERR_NOMEM;
+    g->cap = want;
+  }
+  SOS_HIP(hipMemcpyAsync(g->dev, pts, sizeof(sos_immature) * (size_t)count, hipMemcpyHostToDevice, c->stream));
+  SOS_HIP(hipStreamSynchronize(c->stream));  // pts belongs to the caller again
+  g->count = count;
+  return SOS_OK;
+}
+extern "C" int sos_immset_count(sos_immset *s, int hostKey, int *count) {
+  if (!s || !count) return SOS_ERR_ARG;
+  sos_immset::Seg *g = s->find(hostKey);
+  *count = g ? g->count : 0;
+  return SOS_OK;
+}
+extern "C" int sos_immset_get(sos_immset *s, int hostKey, int count, sos_immature *out) {
+  if (!s || count < 0 || (count && !out)) return SOS_ERR_ARG;
+  sos_immset::Seg *g = s->find(hostKey);
+  if ((g ? g->count : 0) != count) return SOS_ERR_STATE;
+  if (count == 0) return SOS_OK;
+  sos_ctx *c = s->ctx;
+  SOS_HIP(hipSetDevice(c->device));
+  SOS_HIP(hipMemcpyAsync(out, g->dev, sizeof(sos_immature) * (size_t)count, hipMemcpyDeviceToHost, c->stream));
+  SOS_HIP(hipStreamSynchronize(c->stream));
+  return SOS_OK;
+}
+extern "C" int sos_immset_trace(sos_immset *s, const sos_trace_params *prm, int frameSlot, int nhosts, const int32_t *hostKeys,
+                                const float *KRKi, const float *Kt, const float *aff) {
+  if (!s || !prm || nhosts < 0 || nhosts > SOS_MAX_FRAMES || (nhosts && (!hostKeys || !KRKi || !Kt || !aff))) return SOS_ERR_ARG;
+  sos_ctx *c = s->ctx;
+  if (frameSlot < 0 || frameSlot >= SOS_MAX_SLOTS || !c->dI[frameSlot][0]) return SOS_ERR_STATE;
+  for (int k = 0; k < nhosts; k++)
+    for (int j = 0; j < k; j++)
+      if (hostKeys[j] == hostKeys[k]) return SOS_ERR_ARG;
+  ImmSegs S;
+  memset(&S, 0, sizeof(S));
+  int blocks = 0;
+  for (int k = 0; k < nhosts; k++) {
+    sos_immset::Seg *g = s->find(hostKeys[k]);
+    if (!g || g->count == 0) continue;
+    const int q = S.nseg++;
+    S.ptr[q] = g->dev;
+    S.count[q] = g->count;
+    S.blockBegin[q] = blocks;
+    blocks += (g->count + TRACE_PPB - 1) / TRACE_PPB;
+    memcpy(S.A[q].K, KRKi + 9 * k, sizeof(S.A[q].K));
+    memcpy(S.A[q].Kt, Kt + 3 * k, sizeof(S.A[q].Kt));
+    memcpy(S.A[q].aff, aff + 2 * k, sizeof(S.A[q].aff));
+  }
+  if (S.nseg == 0) return SOS_OK;
+  S.blockBegin[S.nseg] = blocks;
+  SOS_HIP(hipSetDevice(c->device));
+  k_immature_trace_sets<<<blocks, 64, 0, c->stream>>>(*prm, c->dI[frameSlot][0], c->w, c->h, S);
+  SOS_HIP(hipGetLastError());
   return SOS_OK;
 }

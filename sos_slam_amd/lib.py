@@ -87,6 +87,13 @@ def load():
     L.sos_immature_trace.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp]
     L.sos_immature_trace_all.argtypes = [vp, vp, ci, ci, vp, vp, ci, vp, vp, vp]
     L.sos_immature_activate.argtypes = [vp, vp, vp, ci, vp, vp, ci, vp, vp, vp]
+    L.sos_immset_create.argtypes = [vp, C.POINTER(vp)]
+    L.sos_immset_destroy.argtypes = [vp]
+    L.sos_immset_destroy.restype = None
+    L.sos_immset_put.argtypes = [vp, ci, ci, vp]
+    L.sos_immset_trace.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp]
+    L.sos_immset_count.argtypes = [vp, ci, C.POINTER(ci)]
+    L.sos_immset_get.argtypes = [vp, ci, ci, vp]
     L.sos_pixsel_create.argtypes = [vp, vp, vp, C.POINTER(vp)]
     L.sos_pixsel_destroy.argtypes = [vp]
     L.sos_pixsel_make_hists.argtypes = [vp, ci, vp, vp]
@@ -236,6 +243,48 @@ class Context:
 
     def release(self, slot: int):
         _chk(self.L.sos_frame_release(self.h_, slot), "sos_frame_release")
+
+
+class ImmatureSet:
+    """sos_immset: the immature points of the window's keyframes resident on the device between frames (traceNewCoarse without
+    host traffic); records cross the bus at keyframe decisions only."""
+
+    def __init__(self, ctx: Context):
+        self.L, self.ctx = ctx.L, ctx
+        self.h_ = C.c_void_p()
+        _chk(self.L.sos_immset_create(ctx.h_, C.byref(self.h_)), "sos_immset_create")
+
+    def close(self):
+        if self.h_:
+            self.L.sos_immset_destroy(self.h_)
+            self.h_ = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def put(self, host_key: int, pts):
+        pts = np.ascontiguousarray(pts)
+        _chk(self.L.sos_immset_put(self.h_, int(host_key), len(pts), _p(pts) if len(pts) else None), "sos_immset_put")
+
+    def count(self, host_key: int) -> int:
+        n = C.c_int(0)
+        _chk(self.L.sos_immset_count(self.h_, int(host_key), C.byref(n)), "sos_immset_count")
+        return int(n.value)
+
+    def get(self, host_key: int):
+        from .records import IMMATURE_DTYPE
+        out = np.zeros(self.count(host_key), dtype=IMMATURE_DTYPE)
+        _chk(self.L.sos_immset_get(self.h_, int(host_key), len(out), _p(out) if len(out) else None), "sos_immset_get")
+        return out
+
+    def trace(self, prm, frame_slot: int, host_keys, KRKi, Kt, aff):
+        keys = np.ascontiguousarray(host_keys, dtype=np.int32)
+        a = [np.ascontiguousarray(x, dtype=np.float32) for x in (KRKi, Kt, aff)]
+        assert a[0].size == 9 * len(keys) and a[1].size == 3 * len(keys) and a[2].size == 2 * len(keys)
+        _chk(self.L.sos_immset_trace(self.h_, C.byref(prm), int(frame_slot), len(keys), _p(keys), *[_p(x) for x in a]), "sos_immset_trace")
 
 
 class BorrowedContext(Context):

@@ -195,3 +195,69 @@ def test_activate_points_flow_index_sets():
     survivors = set(range(len(cand))) - gone - set(activated)
     assert len(survivors) + len(gone) + len(activated) == len(cand)
     ctx.close()
+
+
+def test_resident_sets_equal_array_calls():
+    """sos_immset: the immature points of several keyframes stay on the device over a sequence of frames (traceNewCoarse per frame with
+    no host traffic); the records downloaded at the end -- and in between -- are bit-identical to the same sequence of
+    sos_immature_trace_all calls on host arrays.  Lists are replaced / removed the way makeKeyFrame does."""
+    from sos_slam_amd import lib
+    win = synth.make_window("W7", extra_frames=2)
+    prm = TraceParams.default()
+    ctx = lib.Context(win.w, win.h)
+    for i in range(win.n):
+        ctx.make_pyramid(i, win.images[i])
+    ctx.make_pyramid(win.n, win.extra_images[0])
+    ctx.make_pyramid(win.n + 1, win.extra_images[1])
+    keys = [3, 0, 5, 2]                      # host keyframes (arbitrary ids), list sizes that are not multiples of 64
+    sizes = [700, 65, 1500, 1]
+    arrays = {}
+    st = lib.ImmatureSet(ctx)
+    for k, sz in zip(keys, sizes):
+        u, v, _ = ih.candidates(win, k, sz, seed=k)
+        arrays[k] = ctx.immature_init(prm, k, u, v)
+        st.put(k, arrays[k])
+    assert [st.count(k) for k in keys] == sizes and st.count(77) == 0
+
+    def tables(ks, c2w):
+        t = [ih.host_to_frame(win.K, win.frames[k]["camToWorld"], c2w, frame_aff=(0.01, 0.7)) for k in ks]
+        return np.stack([x[0].reshape(-1) for x in t]), np.stack([x[1] for x in t]), np.stack([x[2] for x in t])
+
+    def array_trace(ks, slot, c2w):
+        KR, KT, AF = tables(ks, c2w)
+        allp = ctx.immature_trace_all(prm, slot, np.concatenate([arrays[k] for k in ks]),
+                                      np.concatenate([np.full(len(arrays[k]), j, np.int32) for j, k in enumerate(ks)]), KR, KT, AF)
+        o = 0
+        for k in ks:
+            arrays[k] = allp[o:o + len(arrays[k])]
+            o += len(arrays[k])
+
+    frames = [(win.n, win.extra_poses[0]), (win.n + 1, win.extra_poses[1]), (6, win.frames[6]["camToWorld"])]
+    for slot, c2w in frames[:2]:
+        st.trace(prm, slot, keys, *tables(keys, c2w))
+        array_trace(keys, slot, c2w)
+    for k in keys:
+        assert _same(st.get(k), arrays[k]) is None, (k, _same(st.get(k), arrays[k]))
+    # a keyframe decision: key 0 leaves, key 5 keeps a subset (activated / deleted points removed), a new keyframe 6 arrives
+    st.put(0, arrays[0][:0])
+    del arrays[0]
+    arrays[5] = np.ascontiguousarray(arrays[5][::3])
+    st.put(5, arrays[5])
+    u, v, _ = ih.candidates(win, 6, 2000, seed=9)
+    arrays[6] = ctx.immature_init(prm, 6, u, v)
+    st.put(6, arrays[6])
+    keys2 = [3, 5, 2, 6]
+    assert st.count(0) == 0 and st.count(5) == len(arrays[5]) and st.count(6) == 2000
+    # a key without points in the list is skipped; the same key twice is refused
+    st.trace(prm, frames[2][0], [3, 5, 2, 0], *tables([3, 5, 2, 0][:3] + [3], frames[2][1]))
+    array_trace([3, 5, 2], *frames[2])
+    with pytest.raises(lib.SosError):
+        st.trace(prm, frames[2][0], [3, 3], *tables([3, 3], frames[2][1]))
+    st.trace(prm, win.n, keys2, *tables(keys2, win.extra_poses[0]))
+    array_trace(keys2, win.n, win.extra_poses[0])
+    seen = set()
+    for k in keys2:
+        assert _same(st.get(k), arrays[k]) is None, (k, _same(st.get(k), arrays[k]))
+        seen |= set(int(s) for s in arrays[k]["lastTraceStatus"])
+    assert len(seen) >= 3, seen
+    st.close()

@@ -61,6 +61,22 @@ t0 = time.perf_counter()
 for _ in range(10):
     run_gpu()
 t_gpu = (time.perf_counter() - t0) / 10
+# the same trace on device-resident records (sos_immset): what a frame between two keyframes costs.  Every timed trace starts from
+# the same records (put + synchronise outside the timed region), like the array call above
+iset = lib.ImmatureSet(ctx)
+t_res, reps = 0.0, 10
+for _ in range(reps + 1):
+    for k, (p, _) in enumerate(hosts):
+        iset.put(k, p)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    iset.trace(prm, win.n, np.arange(len(hosts)), KR, KT, AF)
+    ctx.synchronize()
+    if _:
+        t_res += time.perf_counter() - t0
+t_res /= reps
+res_same = all(np.array_equal(iset.get(k).tobytes(), g[k].tobytes()) for k in range(len(hosts)))
+iset.close()
 c = run_cpu()
 t0 = time.perf_counter()
 for _ in range(3):
@@ -116,7 +132,7 @@ t_sel_cpu = (time.perf_counter() - t0) / 5
 pixsel = {"make_maps_gpu_ms": t_sel_gpu * 1e3, "make_maps_cpu_port_ms": t_sel_cpu * 1e3, "selected": int(n_g),
           "identical_to_oracle": bool(n_g == n_o and np.array_equal(m_g, m_o))}
 sel_g.close()
-print(json.dumps({"window": name, "keyframes": win.n, "immature_points": int(len(st)), "gpu_ms": t_gpu * 1e3, "cpu_port_ms_1thread": t_cpu * 1e3,
+print(json.dumps({"window": name, "keyframes": win.n, "immature_points": int(len(st)), "gpu_ms": t_gpu * 1e3, "gpu_resident_ms": t_res * 1e3, "resident_identical_to_array_call": bool(res_same), "cpu_port_ms_1thread": t_cpu * 1e3,
                   "points_per_s_gpu": len(st) / t_gpu, "identical_to_oracle": bool(same),
                   "status_histogram": np.bincount(st, minlength=6).tolist(), "activation": act, "pixel_selection": pixsel}))
 ctx.close()
