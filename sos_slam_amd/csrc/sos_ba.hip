@@ -1526,7 +1526,9 @@ __global__ void k_point_prep(BaDev d, int shiftPriorToZero, const int *__restric
 // v_mfma_f32_16x16x4_f32: K = points.  4 waves share the Dm/16 x Dm/16 output tiles.
 // JpJd rows of inactive residuals are zero (see k_linearize / k_apply_res), so no flag lookups.
 // ================================================================================================
+#ifndef SOS_GC
 #define SOS_GC 32
+#endif
 
 // PREP: -1 = the per-point sums were produced by k_point_prep (p_out); 0 / 1 = produce them here for the chunk's
 // own points with shiftPriorToZero = PREP (the points of a window are partitioned over the chunks)
