@@ -53,7 +53,7 @@ class Scenario:
     window (what the initialiser would hand over: n0 keyframes at their true poses with noisy inverse depths)."""
 
     def __init__(self, w=320, h=240, n_frames=26, n0=4, points0=360, seed=synth.SEED + 77, step=0.07, noise_sigma=1.0,
-                 desired_points=1000.0, immature_density=450.0, vio=False, stereo=False):
+                 desired_points=1000.0, immature_density=450.0, vio=False, stereo=False, kf_every=1, rot=0.008):
         self.w, self.h, self.n_frames, self.n0 = w, h, n_frames, n0
         self.vio, self.stereo = vio, stereo
         self.scale_opt_thres = 12.0          # tests/EuRoC/euroc.launch: scale_opt_thres
@@ -61,6 +61,9 @@ class Scenario:
         stereo_off = np.array([0.11, 0.0012, 0.0021])
         self.stereo_tfm = np.concatenate([np.eye(3).reshape(-1), -stereo_off])   # tfmF0ToF1: p1 = R p0 + t
         self.desired_points, self.immature_density = desired_points, immature_density
+        # kf_every > 1: only every kf_every-th frame becomes a keyframe; the frames between are tracked and traced (makeNonKeyFrame)
+        self.kf_every = int(kf_every)
+        assert self.kf_every == 1 or not (vio or stereo)
         rng = np.random.default_rng(seed)
         s = w / 752.0
         K = np.array([458.654 * s, 457.296 * s, (367.215 + 0.5) * s - 0.5, (248.375 + 0.5) * s - 0.5])
@@ -70,7 +73,7 @@ class Scenario:
         if vio:
             self._make_imu(n_frames, step)
         for i in range(n_frames):
-            R = synth.so3_exp(0.008 * i * np.array([0.3, 1.0, 0.2]))
+            R = synth.so3_exp(rot * i * np.array([0.3, 1.0, 0.2]))
             t = step * i * np.array([1.0, 0.1, 0.05])
             if vio:
                 R, t = self._traj(float(i))
@@ -258,6 +261,7 @@ class KeyframeLog:
     marginalized: list       # [(frameID, camToWorld (12))]
     HM: np.ndarray
     bM: np.ndarray
+    nonkf: list = None       # [(frameID, refToNew (12))] of the frames tracked + traced since the previous keyframe (kf_every > 1)
     vio: dict = None         # visual-inertial runs: scale, scale_zero, trapped, states {frameID: 21}, vel {frameID: 3}, HMi, bMi
 
 
@@ -283,6 +287,7 @@ class Chain:
         self.stereo = bool(getattr(sc, "stereo", False))
         self.scale_state = [0, 0]     # FullSystem::scaleTrapped, scale_opt_fails
         self.scale_log = []
+        self.track_hist = []     # camToWorld of the last tracked frames (initial guess of the tracker when kf_every > 1)
 
     # ---- backend interface (implemented by DeviceChain / OracleChain)
     def n(self): raise NotImplementedError
@@ -322,34 +327,57 @@ class Chain:
         return int(ok.sum())
 
     # ---- one new frame = one keyframe
-    def step(self):
-        sc = self.sc
-        k = self.next_frame
-        self.next_frame += 1
-        h_new = self.front_end(sc.raw[k])
-        ids = self.window_ids()
-        ref_pose = self.kf_pose(len(ids) - 1)
-        # initial guess: constant motion (the last relative pose), FS/FullSystem.cpp:163-200 tries this one first
-        if self.last_rel is None:
-            T_init = se3_mul(se3_inv(sc.poses[k]), sc.poses[k - 1])
-            T_init = se3_mul(synth.se3_exp12(np.array([0.002, -0.001, 0.001, 0.001, -0.001, 0.0005])), T_init)
-        else:
-            T_init = self.last_rel
-        ok, T, aff, lres, flow = self.track(h_new, T_init, np.array(self.kf_aff(len(ids) - 1)))
-        assert ok, "tracking lost"
-        self.last_rel = T.copy()
-        c2w = se3_mul(ref_pose, se3_inv(T))          # shell->camToWorld = trackingRef->camToWorld * camToTrackingRef
-        # ---- makeKeyFrame
-        n = self.n()
-        poses = [self.kf_pose(i) for i in range(n)]
-        affs = [self.kf_aff(i) for i in range(n)]
-        K4 = self.K()
-        # traceNewCoarse
+    def trace_new_coarse(self, h_new, ids, poses, affs, K4, c2w, aff, keyframe):
+        """FullSystem::traceNewCoarse (FS/FullSystem.cpp:311-350): every immature point of every keyframe against the new frame"""
         for i, fid in enumerate(ids):
             if len(self.imm[fid]) == 0:
                 continue
             KRKi, Kt, a = host_to_frame(K4, poses[i], c2w, affs[i], aff)
             self.imm[fid] = self.trace(h_new, self.imm[fid], KRKi, Kt, a)
+
+    def step(self):
+        """Frames up to and including the next keyframe; None when the sequence ends before one."""
+        sc = self.sc
+        nonkf = []
+        while True:
+            if self.next_frame >= sc.n_frames:
+                return None
+            k = self.next_frame
+            self.next_frame += 1
+            is_kf = (k - sc.n0) % sc.kf_every == sc.kf_every - 1
+            h_new = self.front_end(sc.raw[k])
+            ids = self.window_ids()
+            ref_pose = self.kf_pose(len(ids) - 1)
+            if sc.kf_every == 1:
+                # initial guess: constant motion (the last relative pose), FS/FullSystem.cpp:163-200 tries this one first
+                if self.last_rel is None:
+                    T_init = se3_mul(se3_inv(sc.poses[k]), sc.poses[k - 1])
+                    T_init = se3_mul(synth.se3_exp12(np.array([0.002, -0.001, 0.001, 0.001, -0.001, 0.0005])), T_init)
+                else:
+                    T_init = self.last_rel
+            elif len(self.track_hist) >= 1:
+                # "no motion since the last frame" (the second entry of the reference's try list, FS/FullSystem.cpp:163-200).  One
+                # frame's motion is well inside the tracker's basin; extrapolating two tracked poses instead feeds the tracking
+                # error of a short baseline back into the next guess and drifts away within ten keyframes (tried)
+                T_init = se3_mul(se3_inv(self.track_hist[-1]), ref_pose)
+            else:
+                T_init = se3_mul(se3_inv(sc.poses[k]), sc.poses[ids[-1]])
+                T_init = se3_mul(synth.se3_exp12(np.array([0.002, -0.001, 0.001, 0.001, -0.001, 0.0005])), T_init)
+            ok, T, aff, lres, flow = self.track(h_new, T_init, np.array(self.kf_aff(len(ids) - 1)))
+            assert ok, "tracking lost"
+            self.last_rel = T.copy()
+            c2w = se3_mul(ref_pose, se3_inv(T))          # shell->camToWorld = trackingRef->camToWorld * camToTrackingRef
+            self.track_hist = (self.track_hist + [c2w])[-2:]
+            n = self.n()
+            poses = [self.kf_pose(i) for i in range(n)]
+            affs = [self.kf_aff(i) for i in range(n)]
+            K4 = self.K()
+            self.trace_new_coarse(h_new, ids, poses, affs, K4, c2w, aff, is_kf)
+            if is_kf:
+                break
+            nonkf.append((k, T.copy()))     # makeNonKeyFrame: traced, nothing else; the frame is dropped
+            self.release_plain(h_new)
+        # ---- makeKeyFrame
         flagged = self.flag_frames([len(self.imm[f]) for f in ids])
         if self.vio:   # fh->setImuData; propagateImuState(allKeyFramesHistory.back(), coarseTracker->lastRef->imu_bias), :800-807
             self.shells[k] = dict(ts=float(sc.ts[k]), c2w=np.array(c2w, dtype=np.float64), vel=np.zeros(3))
@@ -415,7 +443,7 @@ class Chain:
                        states={f: self.imu_state[f].copy() for f in self.window_ids()}, vel={f: self.shells[f]["vel"].copy() for f in self.window_ids()},
                        HMi=Hi, bMi=bi)
         self.logs.append(KeyframeLog(k, T, np.asarray(aff, dtype=np.float64), [ids[i] for i in np.flatnonzero(flagged)], activated, deleted, npts, rmse,
-                                     its, ids2, window_poses, residual_set, nout, nmarg, ndrop, point_set, nimm, marg, HM, bM, vio))
+                                     its, ids2, window_poses, residual_set, nout, nmarg, ndrop, point_set, nimm, marg, HM, bM, nonkf, vio))
         return self.logs[-1]
 
     # ---- visual-inertial helpers shared by the chains (state layout and records); the arithmetic is per chain
@@ -544,7 +572,33 @@ class DeviceChain(Chain):
         self.trk = None
 
     def close(self):
+        if getattr(self, "iset", None) is not None:
+            self.iset.close()
         self.sysm.close()
+
+    def trace_new_coarse(self, h_new, ids, poses, affs, K4, c2w, aff, keyframe):
+        """With frames between the keyframes the immature lists live in a device-resident set (sos_immset): a non-keyframe costs one
+        launch and no copies; the records come back at the keyframe, where activatePointsMT / makeNewTraces / marginalisation edit them
+        (and are put again before the next trace)."""
+        if self.sc.kf_every == 1:
+            return super().trace_new_coarse(h_new, ids, poses, affs, K4, c2w, aff, keyframe)
+        if getattr(self, "iset", None) is None:
+            self.iset, self.iset_keys = self.lib.ImmatureSet(self.ctx), {}
+        for fid in list(self.iset_keys):          # keyframes that left the window
+            if fid not in ids:
+                self.iset.put(fid, self.imm.get(fid, np.zeros(0, dtype=IMMATURE_DTYPE))[:0])
+                del self.iset_keys[fid]
+        for fid in ids:                           # lists edited on the host since the last trace (every list after a keyframe)
+            if self.iset_keys.get(fid) != "resident":
+                self.iset.put(fid, self.imm[fid])
+                self.iset_keys[fid] = "resident"
+        tabs = [host_to_frame(K4, poses[i], c2w, affs[i], aff) for i in range(len(ids))]
+        self.iset.trace(self.tprm, h_new, ids, np.stack([t[0].reshape(-1) for t in tabs]), np.stack([t[1] for t in tabs]),
+                        np.stack([t[2] for t in tabs]))
+        if keyframe:
+            for fid in ids:
+                self.imm[fid] = self.iset.get(fid)
+                self.iset_keys[fid] = "host"      # about to be edited
 
     def n(self): return self.sysm.counts()[0]
     def n_points(self): return self.sysm.counts()[1]

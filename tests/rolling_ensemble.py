@@ -41,7 +41,14 @@ def run_seed(seed, vio=False, **scenario):
     try:
         while dev.next_frame < sc.n_frames:
             lg, lo, lt = dev.step(), orc_.step(), tru.step()
+            if lg is None or lo is None or lt is None:      # the sequence ended on frames that are not keyframes
+                assert lg is None and lo is None and lt is None
+                break
             k = lg.frameID
+            for (fg, Tg), (fo, To), (ft, Tt) in zip(lg.nonkf or [], lo.nonkf or [], lt.nonkf or []):   # frames between the keyframes
+                m["nonkf"] = m.get("nonkf", 0) + 1
+                m["d_track"] = max(m["d_track"], np.abs(Tg - To).max())
+                m["n_track"] = max(m["n_track"], np.abs(To - Tt).max())
             m["keyframes"] += 1
             if lg.flagged != lo.flagged:
                 m["hard"].append((k, "flagged", lg.flagged, lo.flagged))

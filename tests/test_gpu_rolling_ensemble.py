@@ -23,3 +23,16 @@ def test_rolling_ensemble(vio):
     assert not s["violations"], s["violations"]
     # iteration counts: the loop ends on a threshold of the step norm -- a knife edge of its own; rare
     assert s["its_mismatch_total"] <= 0.08 * s["keyframes_total"] + 1, s["its_mismatch_total"]
+
+
+def test_rolling_ensemble_with_non_keyframes():
+    """Every third frame a keyframe: the two frames between are tracked against the last keyframe and traced (makeNonKeyFrame) -- on
+    the device chain through the device-resident immature sets (sos_immset: one launch per frame, records back at the keyframe).
+    Same ensemble criteria; the immature points now see three traces between two activations."""
+    runs = [re_.run_seed(s, vio=False, n_frames=4 + 3 * 11, kf_every=3, step=0.07 / 3, rot=0.008 / 3) for s in SEEDS[:4]]
+    s = re_.summarize(runs)
+    print(json.dumps(s, indent=1, default=str))
+    assert all(r.get("nonkf", 0) == 2 * r["keyframes"] for r in runs), [(r.get("nonkf"), r["keyframes"]) for r in runs]
+    assert s["left_total"] >= 4 * 4
+    assert not s["violations"], s["violations"]
+    assert s["its_mismatch_total"] <= 0.08 * s["keyframes_total"] + 1, s["its_mismatch_total"]

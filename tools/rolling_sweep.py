@@ -2,7 +2,7 @@
 """Seed sweep of the free-running rolling-window parity chains (GPU box): device chain vs oracle chain vs the oracle chain with
 fp64-accumulated H/b over many seeds, per-seed worst distances and the ensemble summary of tests/rolling_ensemble.py.
 
-    python tools/rolling_sweep.py [--seeds 12] [--frames 20] [--out gpurun_out/rolling_sweep.json]
+    python tools/rolling_sweep.py [--seeds 12] [--frames 20] [--kf-every 3] [--out gpurun_out/rolling_sweep.json]
 """
 import argparse
 import json
@@ -21,15 +21,17 @@ def main():
     ap.add_argument("--seeds", type=int, default=12)
     ap.add_argument("--frames", type=int, default=20)
     ap.add_argument("--out", default="gpurun_out/rolling_sweep.json")
+    ap.add_argument("--kf-every", type=int, default=1, help="> 1: only every k-th frame is a keyframe (visual only; --frames counts keyframes then)")
     a = ap.parse_args()
     os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
     res = {}
     rc = 0
-    for vio in (False, True):
+    for vio in ((False,) if a.kf_every > 1 else (False, True)):
         runs = []
+        kw = dict(n_frames=a.frames) if a.kf_every == 1 else dict(n_frames=4 + a.kf_every * a.frames, kf_every=a.kf_every, step=0.07 / a.kf_every, rot=0.008 / a.kf_every)
         for s in range(a.seeds):
             t0 = time.time()
-            r = re_.run_seed(synth.SEED + 1000 + 37 * s, vio=vio, n_frames=a.frames)
+            r = re_.run_seed(synth.SEED + 1000 + 37 * s, vio=vio, **kw)
             r["seconds"] = round(time.time() - t0, 1)
             runs.append(r)
             print({k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in r.items()}, flush=True)
