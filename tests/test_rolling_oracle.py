@@ -73,3 +73,29 @@ def test_oracle_chain_stereo_inertial():
         assert k == lg.frameID and st == [1, 0] and 0 < err < sc.scale_opt_thres
         assert abs(new_scale - sc.scale_true) < 0.02 and abs(lg.vio["scale"] * 200 - new_scale) < 1e-6
         assert lg.vio["trapped"] == 1 and lg.vio["init"] == 1
+
+
+def test_ensemble_summary_criteria():
+    """tests/rolling_ensemble.summarize (the criteria of the GPU ensemble tests) on hand-made runs: hard decisions always count, the
+    geometric mean and the maximum are compared per quantity with their own factors, set differences of zero count as one."""
+    from tests import rolling_ensemble as re_
+
+    def run(seed, d, n, hard=()):
+        r = dict(seed=seed, vio=False, keyframes=10, left=5, hard=list(hard), its_mismatch=0)
+        for k in ("leave", "win"):
+            r["d_" + k], r["n_" + k] = d, n
+        for k in ("res", "act", "pts"):
+            r["d_" + k], r["n_" + k] = 0, 0
+        return r
+
+    ok = re_.summarize([run(1, 2e-5, 1e-5), run(2, 1e-6, 4e-5), run(3, 3e-5, 2e-5)])
+    assert not ok["violations"] and ok["left_total"] == 15 and ok["keyframes_total"] == 30
+    assert abs(ok["leave"]["max_ratio"] - 0.75) < 1e-12 and ok["res"]["geo_ratio"] == 1.0
+    geo = re_.summarize([run(1, 4e-5, 1e-5), run(2, 4e-5, 1e-5), run(3, 4e-5, 5e-5)])          # mean 2.3x above... max within 3x
+    assert not geo["violations"]
+    bad_geo = re_.summarize([run(1, 4e-5, 1e-5), run(2, 4e-5, 1e-5), run(3, 4e-5, 1e-5)])
+    assert {v[:2] for v in bad_geo["violations"]} == {("leave", "geometric mean"), ("leave", "maximum"), ("win", "geometric mean"), ("win", "maximum")}
+    bad_max = re_.summarize([run(1, 1e-6, 1e-5), run(2, 1e-6, 1e-5), run(3, 4e-5, 1e-5)])      # one outlier: the tail criterion
+    assert {v[:2] for v in bad_max["violations"]} == {("leave", "maximum"), ("win", "maximum")}
+    hard = re_.summarize([run(1, 1e-6, 1e-5, hard=[(7, "flagged", [1], [2])])])
+    assert hard["violations"] and hard["violations"][0][:2] == (1, "hard decision")
