@@ -265,7 +265,8 @@ EFResidual *EnergyFunctional::insertResidual(PointFrameResidual *r) {  // OB/Ene
   EFResidual *efr = new EFResidual(r, r->point->efPoint, r->host->efFrame, r->target->efFrame);
   efr->idxInAll = (int)r->point->efPoint->residualsAll.size();
   r->point->efPoint->residualsAll.push_back(efr);
-  connectivityMap[(((uint64_t)efr->host->frameID) << 32) + ((uint64_t)efr->target->frameID)].first++;
+  efr->connKey = (((uint64_t)efr->host->frameID) << 32) + ((uint64_t)efr->target->frameID);
+  connectivityMap[efr->connKey].first++;
   nResiduals++;
   r->efResidual = efr;
   packDirty = true;
@@ -325,7 +326,8 @@ void EnergyFunctional::dropResidual(EFResidual *r) {  // :710-728
   p->residualsAll[r->idxInAll] = p->residualsAll.back();
   p->residualsAll[r->idxInAll]->idxInAll = r->idxInAll;
   p->residualsAll.pop_back();
-  connectivityMap[(((uint64_t)r->host->frameID) << 32) + ((uint64_t)r->target->frameID)].first--;
+  // (the reference reads r->target->frameID here, also when marginalizeFrame has just deleted that EFFrame: FS/FullSystemMarginalize.cpp:146-176)
+  connectivityMap[r->connKey].first--;
   nResiduals--;
   r->data->efResidual = nullptr;
   delete r;

@@ -136,6 +136,7 @@ struct EFResidual {  // OB/EnergyFunctionalStructs.h:43-81
   EFPoint *point;
   EFFrame *host, *target;
   int idxInAll = 0;
+  uint64_t connKey = 0;  // (host frameID << 32) + target frameID, kept here: the target's EFFrame may be gone when the residual is dropped
   bool isLinearized = false;
   bool isActiveAndIsGoodNEW = false;
   bool isActive() const { return isActiveAndIsGoodNEW; }
