@@ -112,3 +112,46 @@ def test_facade_ldlt_variants_agree():
             keep = np.arange(n) != 5
             yr = np.linalg.solve(A2[np.ix_(keep, keep)], b[keep])
             assert np.abs(y0[keep] - yr).max() < 1e-9 * np.abs(yr).max()
+
+
+_ZERO_CALLER = r'''
+import ctypes as C, re, sys
+hip = C.CDLL(sys.argv[1], mode=C.RTLD_GLOBAL)
+libs = {"sos_slam.h": hip, "sos_slam_host.h": C.CDLL(sys.argv[2], mode=C.RTLD_GLOBAL)}
+n = 0
+for hdr, L in libs.items():
+    txt = re.sub(r"/\*.*?\*/", " ", open(sys.argv[3] + "/" + hdr).read(), flags=re.S)
+    for m in re.finditer(r"\bint\s+(sosf?_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S):
+        name, args = m.group(1), m.group(2).strip()
+        vals = []
+        for a in ([] if args in ("", "void") else args.split(",")):
+            a = a.strip()
+            if "*" in a or "[" in a: vals.append(C.c_void_p(None))
+            elif re.match(r"(const\s+)?float\b", a): vals.append(C.c_float(0))
+            elif re.match(r"(const\s+)?double\b", a): vals.append(C.c_double(0))
+            else: vals.append(C.c_int(0))
+        f = getattr(L, name)
+        f.restype = C.c_int
+        print(name, f(*vals), flush=True)
+        n += 1
+print("CALLED", n)
+'''
+
+
+def test_entry_points_survive_zero_arguments():
+    """Every `int` entry point of the two headers called with NULL for every pointer and 0 for every scalar: a status comes back
+    (SOS_ERR_ARG / SOS_ERR_STATE for all but a few queries that have an answer for 'nothing'), nothing dereferences, nothing aborts.
+    Runs in a child process so that a crash is a test failure, not the end of the session; needs no GPU."""
+    import subprocess
+    import sys
+    from sos_slam_amd import host, lib
+    lib.load(), host.load()
+    p = subprocess.run([sys.executable, "-c", _ZERO_CALLER, lib.lib_path(), os.path.join(os.path.dirname(lib.lib_path()), "libsos_host.so"),
+                        os.path.join(ROOT, "include")], capture_output=True, text=True, timeout=300)
+    lines = p.stdout.strip().splitlines()
+    assert p.returncode == 0, (p.returncode, lines[-3:], p.stderr[-500:])
+    assert lines[-1].startswith("CALLED") and int(lines[-1].split()[1]) >= 140, lines[-1]
+    rc = {ln.split()[0]: int(ln.split()[1]) for ln in lines[:-1]}
+    ok_zero = {"sos_ba_gn_resident_supported", "sos_rccl_load", "sos_comm_size", "sos_comm_rank", "sosf_get_timing"}
+    bad = {k: v for k, v in rc.items() if v not in (-1, -3) and k not in ok_zero and not (k.endswith("_destroy") and v == 0)}   # destroying nothing is not an error
+    assert not bad, bad
