@@ -255,3 +255,35 @@ def test_optimize_scale_keyframe_function(rig):
     assert sg == [0, 6]
     assert ht.optimize_scale_kf(slot, win.stereo_tfm, K1, 1.0, levels - 1, 0.0, sg)[0] == 1.0      # setting_scale_opt_thres <= 0
     sysm.release_image(slot)
+
+
+@pytest.mark.parametrize("name", ["T3", "T4", "T6"])
+def test_degenerate_templates_and_initial_poses(name):
+    """Small templates (96 x 64: two pyramid levels, a handful of 256-pixel chunks) and initial poses from exact to absurd -- 0.3 rad off,
+    the camera turned around, 50 units away: with nothing left to warp every sum is zero and the level residuals are NaN.  The device loop,
+    the host loop around device passes and the oracle port take the same number of evaluations, report the same `ok`, the same NaN pattern,
+    and the same pose where there is one to find."""
+    gen = make_rig(name)
+    rig = next(gen)
+    ht, win, ot, levels = rig["ht"], rig["win"], rig["ot"], rig["levels"]
+    T0 = _rel_pose(win)
+    perts = {"exact": np.zeros(6), "large": np.array([0.3, 0.2, -0.2, 0.1, -0.12, 0.08]), "behind": np.array([0, 0, 0, 0, 3.1, 0.0]),
+             "far": np.array([50.0, 0, 0, 0, 0, 0])}
+    for pn, p in perts.items():
+        Tinit = se3_mul(se3_exp(p), T0)
+        out = {}
+        for mode in (True, False):
+            ht.set_device_lm(mode)
+            out[mode] = ht.track(rig["new_slot"], 1.0, Tinit, np.zeros(2), levels - 1) + (ht.last_evals(),)
+        ht.set_device_lm(True)
+        ok_o, To, ao, lo, fo = ot.track(rig["new_dI"], 1.0, 1.0, rig["ref_aff"], Tinit, np.zeros(2), levels - 1)
+        (ok_d, Td, ad, ld, fd, ev_d), (ok_h, Th, ah, lh, fh, ev_h) = out[True], out[False]
+        print(f"{name} ({levels} levels) {pn}: ok {ok_d}/{ok_h}/{bool(ok_o)}, evaluations {ev_d}/{ev_h}, residuals {ld[:levels]}")
+        assert ok_d == ok_h == bool(ok_o) and ev_d == ev_h
+        assert np.allclose(Td, Th, rtol=0, atol=1e-9) and np.allclose(ld[:levels], lh[:levels], rtol=1e-6, equal_nan=True)
+        assert np.array_equal(np.isnan(ld[:levels]), np.isnan(lo[:levels]))
+        if pn in ("exact", "large"):
+            assert np.isfinite(ld[:levels]).all() and np.abs(Td - To).max() < 1e-4
+        else:
+            assert np.isnan(ld[:levels]).all()
+    gen.close()
