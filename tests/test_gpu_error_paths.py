@@ -124,3 +124,65 @@ def test_device_loop_timeout_falls_back_to_host_loop():
     assert ok_r and ht.lm_fallbacks() == 2 and np.array_equal(Tr, Td)
     ht.close()
     sysm.close()
+
+
+def test_more_hypotheses_than_one_launch_holds():
+    """sos_tracker_track with 37 hypotheses in ONE call (three launches of at most 16 inside the library) and sos_tracker_optimize_scale with
+    19 scales: every hypothesis comes back exactly as when it is run alone."""
+    from sos_slam_amd import host, lib
+    from sos_slam_amd.synth import se3_exp12 as se3_exp, se3_mul12 as se3_mul
+    L = lib.load()
+    vp = C.c_void_p
+    L.sos_tracker_track.argtypes = [vp, C.c_int, vp, C.c_float, C.c_float, vp, C.c_int, vp, C.c_int, vp]
+    L.sos_tracker_optimize_scale.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
+    win = synth.make_window("T6", extra_frames=2)
+    sysm = host.System.from_window(win)
+    sysm.optimize(3)
+    ht = host.HostTracker(sysm)
+    ht.set_ref()
+    slot, st_slot = sysm.upload_image(win.extra_images[0]), sysm.upload_image(win.extra_images[1])
+    levels = sysm.context().levels
+    trk = C.c_void_p(sysm.L.sosf_tracker_handle(ht.h_))
+    K = sysm.calib_value_scaled()
+    Ki = np.zeros((levels, 9), np.float32)
+    for l in range(levels):
+        fx, fy = K[0] / 2 ** l, K[1] / 2 ** l
+        cx, cy = (K[2] + 0.5) / 2 ** l - 0.5, (K[3] + 0.5) / 2 ** l - 0.5
+        Ki[l] = np.array([1 / fx, 0, -cx / fx, 0, 1 / fy, -cy / fy, 0, 0, 1], np.float32)
+    ref, new = win.frames[win.n - 1]["camToWorld"], win.extra_poses[0]
+    Rr, tr, Rn, tn = ref[:9].reshape(3, 3), ref[9:], new[:9].reshape(3, 3), new[9:]
+    T0 = np.concatenate([(Rn.T @ Rr).reshape(-1), Rn.T @ (tr - tn)])
+    rng = np.random.default_rng(5)
+    N = 37
+    starts = [se3_mul(se3_exp(rng.normal(0, 0.004, 6)), T0) for _ in range(N)]
+    aff, mr = np.zeros(2), np.full(5, np.nan)
+    p = lambda a: a.ctypes.data_as(vp)
+    hyps = (Hyp * N)()
+    for k in range(N):
+        hyps[k].refToNew[:] = list(starts[k])
+    assert L.sos_tracker_track(trk, slot, p(Ki), 1.0, 1.0, p(aff), levels - 1, p(mr), N, hyps) == 0
+    for k in (0, 7, 15, 16, 17, 31, 32, 36):
+        one = Hyp()
+        one.refToNew[:] = list(starts[k])
+        assert L.sos_tracker_track(trk, slot, p(Ki), 1.0, 1.0, p(aff), levels - 1, p(mr), 1, C.byref(one)) == 0
+        assert bytes(one) == bytes(hyps[k]), k
+    assert len({bytes(hyps[k]) for k in range(N)}) > 1
+    # the scale loop
+    t3 = np.array([-0.11, 0.0, 0.0], np.float32)
+    RK = np.ascontiguousarray(Ki.copy())           # rot(tfmF0ToF1) = I
+    K1 = np.zeros((levels, 4), np.float32)
+    for l in range(levels):
+        K1[l] = (K[0] / 2 ** l, K[1] / 2 ** l, (K[2] + 0.5) / 2 ** l - 0.5, (K[3] + 0.5) / 2 ** l - 0.5)
+    M = 19
+    scales = np.linspace(0.5, 2.5, M).astype(np.float32)
+    s_all, lr_all, ev = scales.copy(), np.zeros(5 * M), C.c_int(0)
+    assert L.sos_tracker_optimize_scale(trk, st_slot, p(RK), p(t3), p(K1), levels - 1, M, p(s_all), p(lr_all), C.byref(ev)) == 0
+    tot = 0
+    for k in range(M):
+        s1, lr1, e1 = scales[k:k + 1].copy(), np.zeros(5), C.c_int(0)
+        assert L.sos_tracker_optimize_scale(trk, st_slot, p(RK), p(t3), p(K1), levels - 1, 1, p(s1), p(lr1), C.byref(e1)) == 0
+        assert s1[0] == s_all[k] and np.array_equal(lr1, lr_all[5 * k:5 * k + 5], equal_nan=True), k
+        tot += e1.value
+    assert tot == ev.value
+    ht.close()
+    sysm.close()
