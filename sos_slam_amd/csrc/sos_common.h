@@ -12,6 +12,23 @@
 
 #include "../../include/sos_slam.h"
 
+// SOS_POISON=1 (debugging): every device allocation of the library is filled with 0xFF bytes (NaN as float / double, -1 as int) before it is
+// used, so a kernel that reads something nobody wrote shows up in the parity tests instead of being hidden by whatever a fresh hipMalloc holds.
+static inline bool sos_poison_on() {
+  static const bool on = getenv("SOS_POISON") != nullptr;
+  return on;
+}
+template <typename T>
+static inline hipError_t sos_malloc_poisoned(T **p, size_t bytes) {
+  const hipError_t e = (hipMalloc)(p, bytes);   // (parenthesised: not the macro below)
+  if (e == hipSuccess && sos_poison_on() && bytes) {
+    (void)hipMemset(*p, 0xFF, bytes);
+    (void)hipDeviceSynchronize();
+  }
+  return e;
+}
+#define hipMalloc(p, n) sos_malloc_poisoned((p), (n))
+
 #define SOS_HIP(expr)                                                                          \
   do {                                                                                         \
     hipError_t e_ = (expr);                                                                    \
