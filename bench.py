@@ -134,14 +134,20 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # SOS_BENCH_SINGLE_GPU=1: a rehearsal of the N > 1 flow on a box with one GPU -- every rank on device 0, gloo instead of RCCL (which
+    # refuses two ranks on one device), the exchange through the torch.distributed hooks on host copies.  Timings mean nothing in this
+    # mode; it exists to show that the ranks issue matching collectives and that rank 0 prints the line.
+    single_gpu = os.environ.get("SOS_BENCH_SINGLE_GPU") == "1"
+    dev = 0 if single_gpu else local_rank
+    tdev = "cpu" if single_gpu else "cuda"
+    torch.cuda.set_device(dev)
     dist = None
     force_dist = world == 1 and os.environ.get("SOS_BENCH_FORCE_DIST") == "1"  # exercise the exchange path on one GPU
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if single_gpu else "nccl", rank=rank, world_size=world)
 
     from sos_slam_amd import host, lib, synth
     from sos_slam_amd import distributed as sdist
@@ -153,21 +159,24 @@ def main():
     else:
         # every rank: same frames / images (seed), its own point set (point_seed): per-GPU work fixed
         win = synth.make_window(args.window, point_seed=synth.SEED + 1000 * rank if world > 1 else None)
-    sysm = host.System.from_window(win, device=local_rank)
+    sysm = host.System.from_window(win, device=dev)
     comm = None
     exchange = "enqueued by the library on its stream"
     if dist is not None:
-        if os.environ.get("SOS_BENCH_HOOKS") == "1":  # callback-based exchange through torch.distributed (slower)
+        if single_gpu:
+            sdist.attach(sysm, dist, torch, device_pointers=True)
+            exchange = "gloo on host copies (single-GPU rehearsal)"
+        elif os.environ.get("SOS_BENCH_HOOKS") == "1":  # callback-based exchange through torch.distributed (slower)
             sdist.attach(sysm, dist, torch)
             exchange = "rccl via torch.distributed hooks"
         else:  # RCCL collectives enqueued by the library itself on its stream
             err = None
             try:
-                comm = sdist.NativeComm(dist, torch, local_rank)
+                comm = sdist.NativeComm(dist, torch, dev)
                 comm.attach(sysm)
             except Exception as e:  # noqa: BLE001 -- every rank has to take the same exchange path
                 err, comm = e, None
-            ok = torch.tensor([0 if err else 1], dtype=torch.int32, device="cuda")
+            ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=tdev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 0:  # some rank could not set up the library's communicator: exchange through torch.distributed
                 if rank == 0:
@@ -202,7 +211,7 @@ def main():
     iters = args.steps * inner
     R_total = R_local
     if dist is not None:
-        t = torch.tensor([dt, float(R_local)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, float(R_local)], dtype=torch.float64, device=tdev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)

@@ -36,14 +36,23 @@ def global_nth(dist, local: np.ndarray, frac: float) -> float:
     return float(np.partition(allv, k)[k])
 
 
-def make_hooks(dist, torch):
+def make_hooks(dist, torch, device_pointers=None):
     """The three exchange callbacks of a multi-rank run as ctypes function objects (AR_FN, NTH_FN, AR64_FN):
     all-reduce of the packed fp32 accumulator (a DEVICE pointer with the nccl backend; with gloo -- CPU tests -- the pointer is
     host memory), the global order statistic of setNewFrameEnergyTH, and the all-reduce of the keyframe-rate fp64 sums."""
     on_gpu = dist.get_backend() == "nccl"
+    # gloo with the GPU facade (several ranks sharing ONE GPU, bench.py's SOS_BENCH_SINGLE_GPU=1 rehearsal of the N > 1 flow): the
+    # accumulator pointer is device memory, the collective runs on a host copy
+    staged = (not on_gpu) and bool(device_pointers)
 
     def _ar(user, ptr, n):
-        if on_gpu:
+        if staged:
+            t = torch.as_tensor(_DevView(ptr, n), device="cuda")
+            h = t.cpu()
+            dist.all_reduce(h)
+            t.copy_(h)
+            torch.cuda.synchronize()
+        elif on_gpu:
             t = torch.as_tensor(_DevView(ptr, n), device="cuda")
             dist.all_reduce(t)
             torch.cuda.synchronize()
@@ -68,11 +77,11 @@ def make_hooks(dist, torch):
     return AR_FN(_ar), NTH_FN(_nth), AR64_FN(_ar64)
 
 
-def attach(sysm, dist, torch):
+def attach(sysm, dist, torch, device_pointers=None):
     """Install the all-reduce / order-statistic hooks of a host.System for a multi-rank run."""
     from . import host
 
-    sysm._ar_cb, sysm._nth_cb, sysm._ar64_cb = make_hooks(dist, torch)  # the system keeps the callbacks alive
+    sysm._ar_cb, sysm._nth_cb, sysm._ar64_cb = make_hooks(dist, torch, device_pointers)  # the system keeps the callbacks alive
     L = host.load()
     L.sosf_set_hooks.argtypes = [C.c_void_p, AR_FN, NTH_FN, C.c_void_p]
     rc = L.sosf_set_hooks(sysm.h_, sysm._ar_cb, sysm._nth_cb, None)
