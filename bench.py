@@ -120,6 +120,11 @@ def cpu_baseline(win, seconds):
             "gn_iter_per_s": g6, "value_1thread": v1, "gn_iter_per_s_1thread": g1, "thread_scaling": g6 / g1, "phases": ph}
 
 
+GN_LOOP_NAMES = {0: "host solve (blocked LDL^T) and host-side step, device everything else",
+                 1: "host solve (blocked LDL^T), device everything else incl. the step (poses, precalc, deltas from x)",
+                 2: "device-resident (k_gn_solve)", 3: "energy-checked steps (host solve)"}
+
+
 def main():
     args = parse()
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner to stdout whenever a
@@ -208,6 +213,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     phases = host.timing()
+    loop_mode = sysm.loop_mode()      # what the iterations actually ran as, not what was asked for
     iters = args.steps * inner
     R_total = R_local
     if dist is not None:
@@ -265,7 +271,8 @@ def main():
                                     f"{win.w}x{win.h}, points sharded over {world} GPUs ({win.P} points / {R_local} residuals on rank 0)") +
                                    "; step = one Gauss-Newton iteration (accumulate A/L/SC, fp64 stitch, solve, back-substitute, "
                                    f"step, re-linearise, applyRes), timed as the mean of {inner} consecutive iterations",
-                       "gn_loop": "device-resident (k_gn_solve)" if args.resident else "host solve (blocked LDL^T), device everything else incl. the step (poses, precalc, deltas from x)",
+                       "gn_loop": GN_LOOP_NAMES.get(loop_mode, f"mode {loop_mode}") + ("" if (loop_mode == 2) == bool(args.resident) else
+                                                                                      " -- --resident was requested but the facade did not take it (communicator / hooks attached)"),
                        "window": args.window, "keyframes": win.n, "points_per_gpu": win.P, "inner_repeat": inner,
                        "timed_region_ms": round(dt * 1e3, 2),
                        "residuals_per_gpu": R_local, "residuals_total": R_total,

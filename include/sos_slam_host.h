@@ -106,6 +106,9 @@ int sosf_set_device_step(sosf_system *sys, int on);
  * "host out of the loop: measured"); with it off the host solves (blocked LDL^T).  Never taken while IMU factors, callback
  * hooks or an RCCL communicator are attached, with setting_forceAceptStep off, or for windows of more than 16 keyframes. */
 int sosf_set_resident(sosf_system *sys, int on);
+/* How the last Gauss-Newton iteration actually ran (the two switches above are requests; the conditions listed with them decide):
+ * 0 = step on the host, 1 = step on the device, 2 = device-resident loop, 3 = energy-checked step (setting_forceAceptStep off), -1 = none yet. */
+int sosf_get_loop_mode(sosf_system *sys, int *mode);
 int sosf_counts(sosf_system *sys, int *nFrames, int *nPoints, int *nResiduals);
 
 int sosf_get_frame(sosf_system *sys, int idx, double *camToWorld12, double *state10, double *state_zero10,

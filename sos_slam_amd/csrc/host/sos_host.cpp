@@ -1094,6 +1094,7 @@ bool FullSystem::gnIteration(int iteration, bool mayContinue) {  // :358-413 wit
     if (residentQueued == residentSeq) rcAcc(sos_ba_gn_resident_enqueue(ef->ba, &residentQueued));
     const bool cb = residentConsume(residentSeq + 1);
     if (!pipelineAlways) residentFlush();
+    lastLoopMode = 2;
     return cb;
   }
 host_path:
@@ -1107,6 +1108,7 @@ host_path:
     // x goes to the device as it is: back-substitution, the frames' new poses, the precalc records and the deltas are formed
     // there inside ONE launch, the linearisation follows without waiting for the host
     bool canbreak;
+    lastLoopMode = 1;
     { PhaseTimer t(3); canbreak = doStepFromBackup(1, 1, 1, 1, 1, true, true); }
     PhaseTimer t(5);
     const int n = (int)frameHessians.size();
@@ -1139,6 +1141,7 @@ host_path:
   }
   // the back-substitution needs x alone: it runs on the device while the host derives the new poses and precalc records
   const bool resubAhead = sos_ba_gn_resub(ef->ba, ef->lastX.data(), 1.0f) == SOS_OK;
+  lastLoopMode = 0;
   bool canbreak;
   { PhaseTimer t(3); canbreak = doStepFromBackup(1, 1, 1, 1, 1, true); }
   {
@@ -1318,6 +1321,7 @@ void FullSystem::loadSateBackup() {  // FS/FullSystemOptimize.cpp:271-287 (IMU o
 // two-step device protocol (sos_ba_linearize fills PointFrameResidual::J, nothing is committed), accepted with applyRes
 // when the total energy decreased, otherwise undone with loadSateBackup and the window is linearised again at the old state.
 bool FullSystem::gnIterationChecked(int iteration, double &lastE, double &lastEL, double &lastEM) {
+  lastLoopMode = 3;
   backupState();
   if (rcAcc(ef->solveSystemF(iteration, 1e-1, &HCalib, false)) != SOS_OK) {
     isLost = true;
@@ -1357,6 +1361,7 @@ float FullSystem::optimize(int mnumOptIts, int *iterations) {
     // the whole loop body runs on the device; the host learns x / canbreak of iteration k while its back-substitution and
     // linearisation are still running and enqueues iteration k + 1 behind them
     rcAcc(sos_ba_gn_resident_enqueue(ef->ba, &residentQueued));
+    lastLoopMode = 2;
     for (int iteration = 0; iteration < mnumOptIts; iteration++) {
       const bool canbreak = residentConsume(residentQueued);
       it++;
@@ -2422,6 +2427,11 @@ extern "C" int sosf_set_force_accept_step(sosf_system *s, int on) {
 extern "C" int sosf_get_rejected_steps(sosf_system *s, int *count) {
   if (!s || !count) return SOS_ERR_ARG;
   *count = s->fs->stepsRejected;
+  return SOS_OK;
+}
+extern "C" int sosf_get_loop_mode(sosf_system *s, int *mode) {
+  if (!s || !mode) return SOS_ERR_ARG;
+  *mode = s->fs->lastLoopMode;
   return SOS_OK;
 }
 extern "C" int sosf_set_resident(sosf_system *s, int on) {

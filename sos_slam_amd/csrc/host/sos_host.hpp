@@ -279,6 +279,7 @@ class FullSystem {
   int residentFlush();                      // leaves the loop: mirrors of points / thresholds brought up to date
   bool forceAcceptStep = true;  // setting_forceAceptStep (util/settings.cpp:117); false: energy-checked steps with loadSateBackup
   int stepsRejected = 0;        // rejected steps of the last optimize()
+  int lastLoopMode = -1;        // how the last Gauss-Newton iteration ran: 0 host step, 1 device-side step, 2 device-resident loop, 3 energy-checked
   void loadSateBackup();                                      // FS/FullSystemOptimize.cpp:271-287
   bool gnIterationChecked(int iteration, double &lastE, double &lastEL, double &lastEM);  // :358-413, forceAceptStep off
   void setPrecalcValues(bool points = true);                  // FS/FullSystem.cpp:1099-1107

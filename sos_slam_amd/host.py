@@ -267,6 +267,12 @@ class System:
         self.L.sosf_set_device_step.argtypes = [C.c_void_p, C.c_int]
         _chk(self.L.sosf_set_device_step(self.h_, 1 if on else 0), "sosf_set_device_step")
 
+    def loop_mode(self) -> int:
+        """0 host step, 1 device-side step, 2 device-resident loop, 3 energy-checked step, -1 before the first iteration"""
+        m = C.c_int(-1)
+        _chk(self.L.sosf_get_loop_mode(self.h_, C.byref(m)), "sosf_get_loop_mode")
+        return int(m.value)
+
     def set_resident(self, on=True):
         """device-resident Gauss-Newton loop on / off (off: the host solves, as in round 1)"""
         _chk(self.L.sosf_set_resident(self.h_, int(on)), "sosf_set_resident")

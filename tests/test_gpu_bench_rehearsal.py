@@ -39,3 +39,6 @@ def test_two_ranks_weak_and_strong():
     assert s["config"]["residuals_total"] == synth.make_window("W16").R                    # the shards add up to the one window
     for d in (w, s):
         assert "roofline" in d and d["roofline"]["bound"] == "hbm" and d["higher_is_better"] is True
+        # the line names the loop that RAN: with an exchange attached the facade steps on the host (the device-side step and the
+        # device-resident loop are single-rank paths), and says so
+        assert d["config"]["gn_loop"].startswith("host solve (blocked LDL^T) and host-side step"), d["config"]["gn_loop"]

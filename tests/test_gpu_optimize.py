@@ -200,3 +200,25 @@ def test_device_step_equals_host_step(name):
     assert np.abs(pd - ph).max() < 1e-9
     assert np.abs(xd - xh).max() <= 1e-5 * np.abs(xh).max()
     assert np.abs(idd - idh).max() <= 1e-5
+
+
+def test_loop_mode_reports_what_ran():
+    """sosf_get_loop_mode: the switches (device step, resident loop, forced acceptance) are requests; the mode reported is the one the last
+    iteration really took -- bench.py labels its line from it."""
+    from sos_slam_amd import host
+    win = synth.make_window("T6")
+    sysm = host.System.from_window(win)
+    assert sysm.loop_mode() == -1
+    sysm.optimize(2)
+    assert sysm.loop_mode() == 1                      # default: host solve, step on the device
+    sysm.set_device_step(False)
+    sysm.optimize(2)
+    assert sysm.loop_mode() == 0
+    sysm.set_device_step(True)
+    sysm.set_resident(True)
+    sysm.optimize(2)
+    assert sysm.loop_mode() == 2
+    sysm.set_force_accept_step(False)                 # the resident loop needs forced acceptance: request stays, mode changes
+    sysm.optimize(2)
+    assert sysm.loop_mode() == 3
+    sysm.close()
