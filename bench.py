@@ -214,6 +214,7 @@ def main():
     dt = time.perf_counter() - t0
     phases = host.timing()
     loop_mode = sysm.loop_mode()      # what the iterations actually ran as, not what was asked for
+    last_x = np.asarray(sysm.lastX(), dtype=np.float64)   # the last solve's step: identical on every rank, and (strong mode) for every N up to summation order
     iters = args.steps * inner
     R_total = R_local
     if dist is not None:
@@ -281,6 +282,7 @@ def main():
                                        "packed fp32 accumulator + one all-gather of newest-frame energies per "
                                        "iteration, " + exchange)},
             "gn_iter_per_s": iters / dt,
+            "last_step_l2": float(np.linalg.norm(last_x)), "last_step_head": [float(v) for v in last_x[:6]],
             "exchange_allreduce_us": exchange_us,
             "linearize_point_residuals_per_s": R_local / (lin_ms * 1e-3),
             "kernels_us": dict(linearize_us=round(lin_ms * 1e3, 2), **kern),

@@ -15,13 +15,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(n, scaling):
+def _run(n, scaling, steps=3, warmup=1, inner=None):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, SOS_BENCH_SINGLE_GPU="1")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1", "--scaling", scaling],
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", str(steps), "--warmup", str(warmup), "--scaling", scaling] +
+                       (["--inner", str(inner)] if inner else []),
                        capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stderr[-800:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
@@ -42,3 +43,16 @@ def test_two_ranks_weak_and_strong():
         # the line names the loop that RAN: with an exchange attached the facade steps on the host (the device-side step and the
         # device-resident loop are single-rank paths), and says so
         assert d["config"]["gn_loop"].startswith("host solve (blocked LDL^T) and host-side step"), d["config"]["gn_loop"]
+
+
+def test_sharded_first_step_equals_the_unsharded_one():
+    """Strong mode, ONE Gauss-Newton iteration: the step the solve produces from the window sharded over two and three ranks (partial
+    accumulators summed by the exchange) is the step of the unsharded window up to fp32 summation order."""
+    import numpy as np
+    ref = _run(1, "strong", steps=1, warmup=0, inner=1)
+    assert ref["last_step_l2"] > 1e-3
+    for n in (2, 3):
+        d = _run(n, "strong", steps=1, warmup=0, inner=1)
+        assert d["config"]["residuals_total"] == ref["config"]["residuals_total"]
+        assert abs(d["last_step_l2"] - ref["last_step_l2"]) <= 1e-5 * ref["last_step_l2"], (n, d["last_step_l2"], ref["last_step_l2"])
+        assert np.allclose(d["last_step_head"], ref["last_step_head"], rtol=1e-3, atol=1e-9)
