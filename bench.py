@@ -8,7 +8,8 @@ host solve, back-substitution, step + precalc, re-linearise every active residua
 point-residuals linearised per second through whole iterations, summed over all ranks.
 
   python bench.py --gpus 1 --steps K --warmup W           single GPU
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   one rank per GPU (RCCL)
+  python bench.py --gpus N ...                            starts N ranks of itself under torch.distributed.run (one per GPU, RCCL)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   the same with the launcher outside
 
 Multi-GPU: every rank holds the same keyframes and a shard of the points; the packed fp32 H/b
 accumulators are all-reduced over RCCL once per iteration (by the library itself, on its stream, inside the prefetched
@@ -18,7 +19,7 @@ accumulate chain: sos_ba_set_comm), every rank then runs the identical fp64 stit
                    the ranks (contiguous slices of the allPoints order balanced by residual count)
 The timed region is bracketed by barrier + torch.cuda.synchronize and the MAX over ranks is reported.  A Gauss-Newton
 iteration takes under 0.1 ms, so every step is timed as the mean of `--inner` consecutive iterations (default: enough for
-a timed region of >= 50 ms); ms_per_step and value are per single iteration.
+a timed region of about 1 s); ms_per_step and value are per single iteration.
 """
 from __future__ import annotations
 
@@ -49,7 +50,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--window", default=None, help="W7 / W12 / W16 (default: W12, or W16 with --scaling strong)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
-    ap.add_argument("--inner", type=int, default=0, help="GN iterations per timed step (0 = enough for a >= 50 ms region)")
+    ap.add_argument("--inner", type=int, default=0, help="GN iterations per timed step (0 = enough for a ~1 s region)")
     ap.add_argument("--resident", action="store_true",
                     help="device-resident Gauss-Newton loop (solve / step / precalc kernels; measured slower than the host solve)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -58,8 +59,27 @@ def parse():
     if a.window is None:
         a.window = "W16" if a.scaling == "strong" else "W12"
     if a.inner <= 0:
-        a.inner = max(1, -(-700 // max(a.steps, 1)))   # ~0.08 ms per iteration: steps x inner >= 700 iterations
+        a.inner = max(1, -(-14000 // max(a.steps, 1)))   # ~0.07 ms per iteration: steps x inner >= 14000 iterations, a timed region of ~1 s
     return a
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start N ranks of this script under torch.distributed.run
+    (one per GPU, RCCL) and let rank 0's line through.  Fails loudly when the node has fewer than N GPUs."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if os.environ.get("SOS_BENCH_SINGLE_GPU") != "1" and have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: this node has {have} GPU(s) visible")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def cpu_baseline(win, seconds):
@@ -127,6 +147,10 @@ GN_LOOP_NAMES = {0: "host solve (blocked LDL^T) and host-side step, device every
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+    if args.gpus != int(os.environ.get("WORLD_SIZE", "1")):
+        raise SystemExit(f"bench.py --gpus {args.gpus} under a launcher with WORLD_SIZE={os.environ.get('WORLD_SIZE')}")
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner to stdout whenever a
     # communicator has existed -- every N > 1 run): file descriptor 1 is pointed at stderr for the life of the process and the line
     # goes to the saved descriptor.
@@ -214,6 +238,7 @@ def main():
     dt = time.perf_counter() - t0
     phases = host.timing()
     loop_mode = sysm.loop_mode()      # what the iterations actually ran as, not what was asked for
+    res_in = sysm.stats()             # residuals that were IN in the last solve of the timed region (all ranks: the counts ride in the exchange)
     last_x = np.asarray(sysm.lastX(), dtype=np.float64)   # the last solve's step: identical on every rank, and (strong mode) for every N up to summation order
     iters = args.steps * inner
     R_total = R_local
@@ -277,6 +302,7 @@ def main():
                        "window": args.window, "keyframes": win.n, "points_per_gpu": win.P, "inner_repeat": inner,
                        "timed_region_ms": round(dt * 1e3, 2),
                        "residuals_per_gpu": R_local, "residuals_total": R_total,
+                       "resInA_last_iteration": res_in["resInA"], "resInL_last_iteration": res_in["resInL"],
                        "parallelism": ("single GPU" if dist is None else
                                        f"{world} ranks, points sharded, frames replicated; one RCCL all-reduce of the "
                                        "packed fp32 accumulator + one all-gather of newest-frame energies per "
@@ -320,6 +346,7 @@ def main():
     if rank == 0:
         if world > 1:
             out["roofline"]["note"] += "; N > 1: rank 0's kernel on its own shard"
+        out["cpu_baseline"] = None   # timed on rank 0 at N = 1 only
         if not args.no_cpu_baseline and world == 1:
             out["tracker"] = tracker_timing(args.window, local_rank)
             out["cpu_baseline"] = cpu_baseline(win, args.cpu_seconds)

@@ -1124,7 +1124,7 @@ host_path:
     double E = 0;
     ef->pointStep.resize(ef->allPoints.size());
     const bool more = pipelineAlways || (mayContinue && !(canbreak && iteration >= setting_minOptIterations));
-    sos_ba_set_prefetch(ef->ba, more ? 1 : 0);
+    sos_ba_set_prefetch(ef->ba, (more && !ef->allreduceHook) ? 1 : 0);  // a callback exchange runs between accumulate and stitch
     lastError = sos_ba_gn_step(ef->ba, ef->lastX.data(), 1.0f, &cal, nullptr, nullptr, nullptr, th.data(), 1, &E, newestE.data(), &cnt,
                                ef->pointStep.data());
     newestE.resize(cnt);
@@ -1187,8 +1187,10 @@ host_path:
 // ------------------------------------------------------------------------------------------------
 bool FullSystem::devStepUsable() const {
   static const bool off = getenv("SOS_NO_DEVSTEP") != nullptr;
-  return devStepAllowed && !off && forceAcceptStep && !ef->imuSettings && !ef->allreduceHook && !ef->commAttached && !ef->keepSystem &&
-         (int)frameHessians.size() <= 17 && !ef->allPoints.empty();
+  // x is replicated over the ranks (identical stitch + solve on the all-reduced accumulator) and so are the frame states: the
+  // device-side step needs nothing from the exchange.  The IMU branch of the solve (OB/EnergyFunctional.cpp:1053-1171) sits between
+  // stitch and back-substitution on the host and delivers the same x vector.
+  return devStepAllowed && !off && forceAcceptStep && !ef->keepSystem && (int)frameHessians.size() <= 17 && !ef->allPoints.empty();
 }
 
 int FullSystem::devStepBegin() {

@@ -3754,7 +3754,8 @@ extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const
   // pipelined iterations of a window without linearised residuals reduce the tiles on chip (no J traffic at all)
   const bool fuseTop = ba->prefetch && applyRes && ba->ntiles == ba->ntilesA;
   // when the next accumulate is enqueued right behind, its first kernel publishes this step's completion
-  const bool chainPublish = ba->prefetch && applyRes && ba->comm == nullptr && !lin_v1() && getenv("SOS_SIGNAL_IN_KERNEL") == nullptr && getenv("SOS_NO_CHAIN_PUBLISH") == nullptr;
+  // (with a communicator the all-gathered energies are copied out behind the linearisation; the chained publish then follows them)
+  const bool chainPublish = ba->prefetch && applyRes && !lin_v1() && getenv("SOS_SIGNAL_IN_KERNEL") == nullptr && getenv("SOS_NO_CHAIN_PUBLISH") == nullptr;
   int waitSeq = launch_lin_kernel(ba, dv, applyRes ? 1 : 0, fuseTop ? ba->d_top_part.p : nullptr, ba->comm == nullptr, chainPublish);
   if (ba->comm) {  // energies of the newest frame of ALL ranks (same frameEnergyTH everywhere), then tell the host
     const int tot = ba->newest_cap * ba->comm_size;
@@ -3762,7 +3763,7 @@ extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const
     if (rcc) return rcc;
     k_copy_f32<<<divup(tot, 256), 256, 0, st>>>(ba->pin_newest_dev, ba->d_newest_all.p, tot);
     waitSeq = ++ba->sig_lin_seq;
-    k_publish<<<1, 1, 0, st>>>(reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags), waitSeq);
+    if (!chainPublish) k_publish<<<1, 1, 0, st>>>(reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags), waitSeq);
   }
   ba->J_valid = !fuseTop;
   SOS_HIP(hipGetLastError());
