@@ -172,6 +172,7 @@ def test_optimize_with_imu_matches_oracle_loop(name, trapped):
             sysm = host.System.from_window(win)
             sysm.set_imu(S, cal, frames, HMi, bMi)
             rm, it = sysm.optimize(6)
+            assert sysm.loop_mode() == 1     # the device-side step: the IMU block only changes what the host solves
             _, _, st, scale = sysm.imu_state()
             poses = np.array([sysm.frame(f)["camToWorld"] for f in range(n)])
             sysm.close()
