@@ -221,6 +221,33 @@ int sos_ba_apply_res(sos_ba *ba);
  * FS/FullSystemOptimize.cpp:321-324). */
 int sos_ba_reset_oob(sos_ba *ba);
 
+/* The front of FullSystem::optimize with setting_forceAceptStep (FS/FullSystemOptimize.cpp:316-344): resetOOB of the
+ * active residuals (resetOOB != 0), linearizeAll(false) and applyRes_Reductor as ONE launch chain; with sos_ba_set_prefetch
+ * the first iteration's accumulate is enqueued behind it.  energySum = stats[0] of linearizeAll; newestEnergies / newestCount =
+ * state_NewEnergyWithOutlier of the residuals that target the newest keyframe (what setNewFrameEnergyTH sorts, :91-99). */
+int sos_ba_linearize_apply(sos_ba *ba, const float *frameEnergyTH, int resetOOB, double *energySum, float *newestEnergies,
+                           int *newestCount);
+
+/* What linearizeAll(true) leaves in a PointFrameResidual (FS/FullSystemOptimize.cpp:44-77, 148-179; FS/Residuals.cpp:304-321). */
+typedef struct sos_resid_final {
+  float state_NewEnergy, state_NewEnergyWithOutlier;
+  float state_energy;              /* after applyRes(true) */
+  float centerProjectedTo[3];      /* the last centre projection that succeeded */
+  uint8_t state_NewState;          /* SOS_RES_* */
+  uint8_t state_state;             /* after applyRes(true) */
+  uint8_t active;                  /* efResidual->isActive() after applyRes(true): 0 = the residual goes to toRemove (:72-73) */
+  uint8_t pad;                     /* 28 B */
+} sos_resid_final;
+
+/* FullSystem::linearizeAll(true) -- the final linearisation of optimize() (FS/FullSystemOptimize.cpp:425 -> 125-182):
+ * linearize + applyRes(true) of every active residual, then in ONE device-to-host copy
+ *   records              R records in the order of sos_ba_set_window (entries of linearized residuals are not written)
+ *   pointMaxRelBaseline  per point the largest relBS over its active isNew residuals (:55-70), -1 when it has none
+ *   pointNewGood         per point the number of those residuals (numGoodResiduals += ...)
+ * The three arrays live in pinned memory owned by the handle and stay valid until the next call on it. */
+int sos_ba_linearize_final(sos_ba *ba, const float *frameEnergyTH, double *energySum, const sos_resid_final **records,
+                           const float **pointMaxRelBaseline, const int32_t **pointNewGood, float *newestEnergies, int *newestCount);
+
 /* EFResidual::fixLinearizationF for `count` residuals (FS/FullSystem.cpp:581;
  * OB/EnergyFunctionalStructs.cpp:75-103).  Uses the adHTdeltaF/cDeltaF/deltaF of the last set_state. */
 int sos_ba_fix_linearization(sos_ba *ba, const int32_t *residIdx, int count);
@@ -270,7 +297,9 @@ int sos_ba_gn_resub(sos_ba *ba, const double *x, float stepfacD);
  * the NEXT iteration right behind the linearisation (it depends on device state only) and returns as soon as the
  * linearisation results are on the host; the following sos_ba_gn_accumulate then only waits for it.  Any other
  * state-changing call in between discards the prefetched result.  Leave it off for the last iteration of a loop:
- * the per-point results (sos_ba_get_point_hessian) always belong to the latest accumulate that ran. */
+ * the per-point results (sos_ba_get_point_hessian) always belong to the latest accumulate that ran.
+ * on = 2: nothing is enqueued, but the linearisation still reduces its Jacobian tiles to the 13x13 block sums of
+ * AccumulatedTopHessianSSE::addPoint<0> on chip, and the next sos_ba_gn_accumulate (or the device-resident loop) uses them. */
 int sos_ba_set_prefetch(sos_ba *ba, int on);
 
 /* ---- device-resident Gauss-Newton loop: the loop body of FullSystem::optimize (FS/FullSystemOptimize.cpp:358-413, with

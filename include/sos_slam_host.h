@@ -95,10 +95,17 @@ int sosf_gn_iteration(sosf_system *sys, int iteration, int *canbreak);
 /* the caller will keep calling sosf_gn_iteration whatever `canbreak` says (benchmark loops): lets every iteration
  * prefetch the next accumulate (sos_ba_set_prefetch); optimize() decides per iteration by itself */
 int sosf_set_pipeline(sosf_system *sys, int on);
+/* the next sosf_prepare / sosf_optimize packs and uploads the window again although the graph did not change (measurements of the
+ * per-keyframe cost: in a running system every keyframe changes the graph, FS/FullSystem.cpp:814-838) */
+int sosf_invalidate_pack(sosf_system *sys);
+/* setting_minOptIterations (util/settings.cpp:77, default 1): optimize() does not leave its loop on the convergence test before
+ * this many iterations (FS/FullSystemOptimize.cpp:411) */
+int sosf_set_min_opt_iterations(sosf_system *sys, int iterations);
 /* Device-side step of the Gauss-Newton loop (default on; sos_ba_gn_devstep_begin in include/sos_slam.h): the host solves and hands x
  * over, the device forms the frames' new poses, the n^2 precalc records and the deltas inside the launch of the back-substitution.
  * 0: the host computes and stages them as in round 1 (the two differ in the last bits of SE3::exp).  Used when steps are always
- * accepted, without IMU branch, exchange hooks or communicator, up to 17 keyframes. */
+ * accepted, up to 17 keyframes; also with the IMU branch of the solve, exchange hooks or a communicator (x and the frame states are
+ * replicated over the ranks). */
 int sosf_set_device_step(sosf_system *sys, int on);
 /* Device-resident Gauss-Newton loop (sos_ba_gn_resident_*): solveSystemF, the frame half of doStepFromBackup and
  * setPrecalcValues run on the device, the host only decides whether to continue.  OFF by default: the (4 + 8 n)-dimensional
@@ -354,8 +361,11 @@ int sosf_imu_try_trap_scale(sosf_imu_calib *calib, double *scale_queue10, int32_
  * keyframe.  frames[i] must describe keyframe idx i whenever a solve or a frame marginalisation runs: the caller appends a
  * record when it adds a keyframe (calling sosf_set_imu again with NULL priors only renews the pointers); a frame
  * marginalisation erases record idx from the caller's array in place (the later records move down by one), so the array
- * stays aligned when several keyframes leave in one sosf_marginalize_flagged_frames.  sosf_get_imu_prior copies the
- * expanded prior out. */
+ * stays aligned when several keyframes leave in one sosf_marginalize_flagged_frames.  The IMU samples of the leaving
+ * keyframe go in front of those of its successor (FS/FullSystemMarginalize.cpp:226-228: the successor's factor then spans the
+ * whole interval): the facade rewrites n_imu / imu of record idx + 1 to a merged list it owns (valid while that record refers to
+ * it; released when no record does, or with sosf_set_imu(NULL)).  A caller that rebuilds its records from its own sample
+ * storage afterwards has to carry the same hand-over there.  sosf_get_imu_prior copies the expanded prior out. */
 int sosf_set_imu(sosf_system *sys, const sosf_imu_settings *S, sosf_imu_calib *calib, sosf_imu_frame *frames, const double *HM,
                  const double *bM);
 int sosf_get_imu_prior(sosf_system *sys, double *HM, double *bM, int *dim);

@@ -35,7 +35,6 @@ static const float setting_initialTransPrior = 1e10f;
 static const float setting_initialAffBPrior = 1e14f;
 static const float setting_initialAffAPrior = 1e14f;
 static const float setting_thOptIterations = 1.2f;
-static const int setting_minOptIterations = 1;
 static const float setting_minIdepthH_marg = 50;
 
 // ------------------------------------------------------------------------------------------------
@@ -375,21 +374,42 @@ int EnergyFunctional::allreduceF64(double *buf, size_t count) {
   return allreduceHook ? SOS_ERR_STATE : SOS_OK;
 }
 
-int EnergyFunctional::packWindow() {
+int EnergyFunctional::packWindow(std::vector<PointFrameResidual *> *active) {
   // graph edits are shard-local (linearizeAll(true) / removeOutliers drop residuals on some ranks only), and
   // sos_ba_set_window agrees on capacities with a collective once a communicator is attached: every rank repacks
-  if (!packDirty && !commAttached) return SOS_OK;
+  if (!packDirty && !commAttached) {
+    if (active)  // FS/FullSystemOptimize.cpp:316-329 on the unchanged graph
+      for (EFPoint *p : allPoints)
+        for (PointFrameResidual *r : p->data->residuals)
+          if (!r->efResidual->isLinearized) {
+            active->push_back(r);
+            r->resetOOB();
+          }
+    return SOS_OK;
+  }
   const double tpk0 = now_s();
   makeIDX();
   const int n = nFrames;
   std::vector<int32_t> slots(n);
   for (int i = 0; i < n; i++) slots[i] = frames[i]->data->slot;
-  std::vector<sos_point> pts(allPoints.size());
-  std::vector<sos_resid> res;
+  // ONE walk over the graph: the activeResiduals list with resetOOB (when asked for), the point and the residual records.  The
+  // record vectors are members: no allocation (and no page faults) per keyframe
+  std::vector<sos_point> &pts = packPts;
+  std::vector<sos_resid> &res = packRes;
+  pts.resize(allPoints.size());
+  res.clear();
+  res.reserve((size_t)nResiduals + 16);
   allResiduals.clear();
+  allResiduals.reserve((size_t)nResiduals + 16);
   for (size_t k = 0; k < allPoints.size(); k++) {
     EFPoint *p = allPoints[k];
     PointHessian *ph = p->data;
+    if (active)
+      for (PointFrameResidual *r : ph->residuals)
+        if (!r->efResidual->isLinearized) {
+          active->push_back(r);
+          r->resetOOB();
+        }
     ph->packIdx = (int)k;
     sos_point &o = pts[k];
     o.u = ph->u; o.v = ph->v;
@@ -416,26 +436,36 @@ int EnergyFunctional::packWindow() {
   }
   const double tq = now_s();
   int rc = sos_ba_set_window(ba, n, slots.data(), (int)pts.size(), pts.data(), (int)res.size(), res.data(), nullptr, nullptr);
-  if (getenv("SOS_TIMING")) fprintf(stderr, "[packWindow] host records %.0f us, sos_ba_set_window %.0f us\n", (tq - tpk0) * 1e6, (now_s() - tq) * 1e6);
+  if (getenv("SOS_TIMING")) fprintf(stderr, "[packWindow] graph walk + records %.0f us, sos_ba_set_window %.0f us\n", (tq - tpk0) * 1e6, (now_s() - tq) * 1e6);
   if (rc == SOS_OK) packDirty = false;
+  pointsOnDeviceCurrent = rc == SOS_OK;
   pointStep.assign(pts.size(), 0.f);
   return rc;
 }
 
-int EnergyFunctional::pushState(CalibHessian *HCalib, bool adjoints) {
+int EnergyFunctional::pushState(CalibHessian *HCalib, bool adjoints, bool points) {
   const int n = nFrames;
-  std::vector<sos_precalc> pc((size_t)n * n);
+  std::vector<sos_precalc> &pc = scrPrecalc;
+  pc.resize((size_t)n * n);
   for (int h = 0; h < n; h++)
     for (int t = 0; t < n; t++) pc[(size_t)(h + n * t)] = frames[h]->data->targetPrecalc[t].dev;
-  std::vector<float> id(allPoints.size()), idz(allPoints.size()), dl(allPoints.size());
+  const sos_calib c = HCalib->toCalib();
+  // points = false: the device's point values are the host's (they were uploaded by the pack, or stepped on both sides by the
+  // fused iterations with the same fp32 operation): nothing to send
+  if (!points && pointsOnDeviceCurrent)
+    return sos_ba_set_state(ba, &c, pc.data(), adHTdeltaF.data(), cDeltaF, adjoints ? adHost.data() : nullptr,
+                            adjoints ? adTarget.data() : nullptr, nullptr, nullptr, nullptr);
+  std::vector<float> &id = scrId, &idz = scrIdz, &dl = scrDl;
+  id.resize(allPoints.size()); idz.resize(allPoints.size()); dl.resize(allPoints.size());
   for (size_t k = 0; k < allPoints.size(); k++) {
     id[k] = allPoints[k]->data->idepth_scaled;
     idz[k] = allPoints[k]->data->idepth_zero_scaled;
     dl[k] = allPoints[k]->deltaF;
   }
-  const sos_calib c = HCalib->toCalib();
-  return sos_ba_set_state(ba, &c, pc.data(), adHTdeltaF.data(), cDeltaF, adjoints ? adHost.data() : nullptr,
-                          adjoints ? adTarget.data() : nullptr, id.data(), idz.data(), dl.data());
+  const int rc = sos_ba_set_state(ba, &c, pc.data(), adHTdeltaF.data(), cDeltaF, adjoints ? adHost.data() : nullptr,
+                                  adjoints ? adTarget.data() : nullptr, id.data(), idz.data(), dl.data());
+  pointsOnDeviceCurrent = rc == SOS_OK;
+  return rc;
 }
 
 int EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib, bool deferResubstitute) {  // :1029-1184, IMU off
@@ -663,6 +693,10 @@ void EnergyFunctional::imuAdoptPrior() {
 }
 
 int EnergyFunctional::marginalizeFrame(EFFrame *fh) {  // :730-889; the IMU form first when the expanded prior lives here
+  // both reductions are formed into temporaries and committed together at the end: a failure of either leaves HM / bM, HMi / bMi,
+  // the frame list and the caller's IMU records describing the same window
+  MatXX Ho;
+  VecX bo;
   if (imuOwnPrior) {
     if (!imuSettings || !imuCalib || !imuFrames) return SOS_ERR_STATE;
     for (int h = 0; h < nFrames; h++) {  // the records carry the poses the factors are linearised at
@@ -671,14 +705,11 @@ int EnergyFunctional::marginalizeFrame(EFFrame *fh) {  // :730-889; the IMU form
     }
     const VecX delta = getStitchedDeltaF();
     const int nd = SOSF_IMU_DIM(nFrames - 1);
-    MatXX Ho((size_t)nd * nd);
-    VecX bo(nd);
+    Ho.resize((size_t)nd * nd);
+    bo.resize(nd);
     const int rci = sosf_imu_marginalize_frame(imuSettings, imuCalib, nFrames, imuFrames, fh->idx, delta.data(), fh->prior, fh->delta_prior,
                                                prm.margWeightFac, HMi.data(), bMi.data(), Ho.data(), bo.data());
     if (rci != SOS_OK) return rci;
-    HMi.swap(Ho);
-    bMi.swap(bo);
-    for (int h = fh->idx; h + 1 < nFrames; h++) imuFrames[h] = imuFrames[h + 1];  // the records stay aligned with the window
   }
   const int step = 8, odim = SOS_CPARS + nFrames * step, ndim = odim - step;
   const int io = SOS_CPARS + fh->idx * step;
@@ -739,6 +770,30 @@ int EnergyFunctional::marginalizeFrame(EFFrame *fh) {  // :730-889; the IMU form
   for (int i = 0; i < ndim; i++)
     for (int j = 0; j < ndim; j++) HM[(size_t)i * ndim + j] = 0.5 * (HMn[(size_t)i * ndim + j] + HMn[(size_t)j * ndim + i]);
   bM = bMn;
+  if (imuOwnPrior) {
+    HMi.swap(Ho);
+    bMi.swap(bo);
+    // the leaving keyframe's IMU samples go in front of its successor's (FS/FullSystemMarginalize.cpp:226-228): the factor of
+    // keyframe idx + 1 then covers the whole interval from idx - 1.  The merged list lives here until the next sosf_set_imu; a
+    // caller that hands in fresh records afterwards has to hand in the merged samples (include/sos_slam_host.h)
+    if (fh->idx + 1 < nFrames) {
+      const sosf_imu_frame &cur = imuFrames[fh->idx];
+      sosf_imu_frame &nx = imuFrames[fh->idx + 1];
+      imuMergedSamples.emplace_back();
+      std::vector<double> &m = imuMergedSamples.back();
+      m.reserve((size_t)7 * (cur.n_imu + nx.n_imu));
+      if (cur.n_imu > 0) m.insert(m.end(), cur.imu, cur.imu + (size_t)7 * cur.n_imu);
+      if (nx.n_imu > 0) m.insert(m.end(), nx.imu, nx.imu + (size_t)7 * nx.n_imu);
+      nx.n_imu = cur.n_imu + nx.n_imu;
+      nx.imu = m.empty() ? nullptr : m.data();
+    }
+    for (int h = fh->idx; h + 1 < nFrames; h++) imuFrames[h] = imuFrames[h + 1];  // the records stay aligned with the window
+    for (auto it = imuMergedSamples.begin(); it != imuMergedSamples.end();) {  // lists no record points at any more
+      bool used = false;
+      for (int h = 0; h + 1 < nFrames && !used; h++) used = imuFrames[h].imu == it->data();
+      it = used ? std::next(it) : imuMergedSamples.erase(it);
+    }
+  }
   for (unsigned i = fh->idx; i + 1 < frames.size(); i++) {
     frames[i] = frames[i + 1];
     frames[i]->idx = (int)i;
@@ -909,52 +964,50 @@ double FullSystem::linearizeAll(bool fix) {  // FS/FullSystemOptimize.cpp:125-18
     setNewFrameEnergyTH();
     return E;
   }
-  h_newState.resize(R);
-  h_newEnergy.resize(R);
-  h_center.resize(3 * R);
-  lastError = sos_ba_linearize(ef->ba, th.data(), &E, h_newState.data(), h_newEnergy.data(), h_newEnergyWO.data(), h_center.data());
-  sos_ba_apply_res(ef->ba);  // r->applyRes(true) inside the reductor, :51
-  std::vector<uint32_t> flags(R);
-  std::vector<int32_t> st(R);
-  std::vector<float> en(R);
-  sos_ba_get_residual_flags(ef->ba, flags.data(), st.data(), en.data());
+  const bool tmg = getenv("SOS_TIMING") != nullptr;
+  const double tl0 = now_s();
+  const sos_resid_final *rec = nullptr;
+  const float *pmax = nullptr;
+  const int32_t *pcnt = nullptr;
+  {
+    int cap = 0, cnt = 0;
+    sos_ba_newest_capacity(ef->ba, &cap);
+    newestE.resize((size_t)cap + 1);
+    lastError = sos_ba_linearize_final(ef->ba, th.data(), &E, &rec, &pmax, &pcnt, newestE.data(), &cnt);
+    newestE.resize(lastError == SOS_OK ? cnt : 0);
+  }
+  if (lastError != SOS_OK) return NAN;
+  const double tl1 = now_s();
+  // ONE walk over the active residuals: r->applyRes(true) inside the reductor (:51), the removal list (:72-73) and the
+  // lastResiduals states (:150-156, which only read what this walk has just written for the same residual)
   std::vector<PointFrameResidual *> toRemove;
   for (PointFrameResidual *r : activeResiduals) {
-    const int k = r->packIdx;
-    r->state_NewState = (ResState)h_newState[k];
-    r->state_NewEnergy = h_newEnergy[k];
-    r->state_NewEnergyWithOutlier = h_newEnergyWO[k];
-    if (r->state_NewState != OOB || st[k] != OOB) {
-      // centerProjectedTo is written whenever the centre projection succeeded
-    }
-    r->centerProjectedTo[0] = h_center[3 * k];
-    r->centerProjectedTo[1] = h_center[3 * k + 1];
-    r->centerProjectedTo[2] = h_center[3 * k + 2];
-    r->state_state = (ResState)st[k];
-    r->state_energy = en[k];
-    r->efResidual->isActiveAndIsGoodNEW = (flags[k] & SOS_RF_ACTIVE) != 0;
-    if (r->efResidual->isActive()) {
-      if (r->isNew) {  // :55-71
-        PointHessian *p = r->point;
-        const sos_precalc &pc = r->host->targetPrecalc[r->target->idx].dev;
-        const float *K = pc.PRE_KRKiTll, *Kt = pc.PRE_KtTll;
-        const float inf0 = K[0] * p->u + K[1] * p->v + K[2], inf1 = K[3] * p->u + K[4] * p->v + K[5], inf2 = K[6] * p->u + K[7] * p->v + K[8];
-        const float q0 = inf0 + Kt[0] * p->idepth_scaled, q1 = inf1 + Kt[1] * p->idepth_scaled, q2 = inf2 + Kt[2] * p->idepth_scaled;
-        const float dx = inf0 / inf2 - q0 / q2, dy = inf1 / inf2 - q1 / q2;
-        const float relBS = (float)(0.01 * sqrtf(dx * dx + dy * dy));
-        if (relBS > p->maxRelBaseline) p->maxRelBaseline = relBS;
-        p->numGoodResiduals++;
-      }
-    } else {
-      toRemove.push_back(r);
-    }
-  }
-  setNewFrameEnergyTH();
-  for (PointFrameResidual *r : activeResiduals) {  // :150-156
+    const sos_resid_final &q = rec[r->packIdx];
+    r->state_NewState = (ResState)q.state_NewState;
+    r->state_NewEnergy = q.state_NewEnergy;
+    r->state_NewEnergyWithOutlier = q.state_NewEnergyWithOutlier;
+    r->centerProjectedTo[0] = q.centerProjectedTo[0];
+    r->centerProjectedTo[1] = q.centerProjectedTo[1];
+    r->centerProjectedTo[2] = q.centerProjectedTo[2];
+    r->state_state = (ResState)q.state_state;
+    r->state_energy = q.state_energy;
+    r->efResidual->isActiveAndIsGoodNEW = q.active != 0;
+    if (!q.active) toRemove.push_back(r);
     PointHessian *ph = r->point;
     if (ph->lastResiduals[0].first == r) ph->lastResiduals[0].second = r->state_state;
     else if (ph->lastResiduals[1].first == r) ph->lastResiduals[1].second = r->state_state;
   }
+  // isNew bookkeeping (:55-71), formed per point on the device over its active residuals
+  for (size_t k = 0; k < ef->allPoints.size(); k++) {
+    PointHessian *p = ef->allPoints[k]->data;
+    if (pcnt[k] > 0) {
+      if (pmax[k] > p->maxRelBaseline) p->maxRelBaseline = pmax[k];
+      p->numGoodResiduals += pcnt[k];
+    }
+  }
+  const double tl2 = now_s();
+  setNewFrameEnergyTH(newestE);
+  const double tl3 = now_s();
   for (PointFrameResidual *r : toRemove) {  // :158-176
     PointHessian *ph = r->point;
     if (ph->lastResiduals[0].first == r) ph->lastResiduals[0].first = nullptr;
@@ -968,6 +1021,8 @@ double FullSystem::linearizeAll(bool fix) {  // FS/FullSystemOptimize.cpp:125-18
         break;
       }
   }
+  if (tmg) fprintf(stderr, "[linearizeAll(true)] device call + readback %.0f us, residual / point walk %.0f us, threshold %.0f us, removal (%zu) %.0f us\n",
+                   (tl1 - tl0) * 1e6, (tl2 - tl1) * 1e6, (tl3 - tl2) * 1e6, toRemove.size(), (now_s() - tl3) * 1e6);
   return E;
 }
 
@@ -1018,6 +1073,7 @@ bool FullSystem::doStepFromBackup(float stepfacC, float stepfacT, float stepfacR
     sumT += fh->step[0] * fh->step[0] + fh->step[1] * fh->step[1] + fh->step[2] * fh->step[2];
     sumR += fh->step[3] * fh->step[3] + fh->step[4] * fh->step[4] + fh->step[5] * fh->step[5];
     if (pointsOnDevice) continue;  // sumNID / numID come from backupState (they only read idepth_backup)
+    ef->pointsOnDeviceCurrent = false;
     for (PointHessian *ph : fh->pointHessians) {
       ph->setIdepth(ph->idepth_backup + stepfacD * ph->step);
       sumID += ph->step * ph->step;
@@ -1055,31 +1111,48 @@ void FullSystem::solveSystem(int iteration, double lambda) { rcAcc(ef->solveSyst
 int FullSystem::prepare() {  // FS/FullSystemOptimize.cpp:316-344
   residentFlush();
   devStepActive = false;
-  activeResiduals.clear();
-  for (FrameHessian *fh : frameHessians)
-    for (PointHessian *ph : fh->pointHessians)
-      for (PointFrameResidual *r : ph->residuals)
-        if (!r->efResidual->isLinearized) {
-          activeResiduals.push_back(r);
-          r->resetOOB();
-        }
   const bool tmg = getenv("SOS_TIMING") != nullptr;
   const double t0 = now_s();
-  int rc = ef->packWindow();
-  if (rc) return rc;
-  const double t1 = now_s();
+  // the deltas first (EFPoint::deltaF is part of the point records), then ONE walk over the graph: activeResiduals with
+  // resetOOB and the snapshot records
   setPrecalcValues();
-  rc = ef->pushState(&HCalib, true);
+  const double t1 = now_s();
+  activeResiduals.clear();
+  int rc = ef->packWindow(&activeResiduals);
   if (rc) return rc;
   const double t2 = now_s();
-  sos_ba_reset_oob(ef->ba);
-  prepareEnergy = linearizeAll(false);
-  if (!forceAcceptStep) {  // lastEnergyL / lastEnergyM of FS/FullSystemOptimize.cpp:335-336, evaluated before the first applyRes
-    prepareEnergyL = ef->calcLEnergyF_MT();
-    prepareEnergyM = ef->calcMEnergyF();
+  rc = ef->pushState(&HCalib, true, false);  // the points went up with the pack
+  if (rc) return rc;
+  const double t3 = now_s();
+  if (forceAcceptStep) {
+    // resetOOB + linearizeAll(false) + applyRes as one launch chain; the threshold statistic comes back with it
+    const int n = (int)frameHessians.size();
+    std::vector<float> th(n);
+    for (int i = 0; i < n; i++) th[i] = frameHessians[i]->frameEnergyTH;
+    int cap = 0, cnt = 0;
+    sos_ba_newest_capacity(ef->ba, &cap);
+    newestE.resize((size_t)cap + 1);
+    double E = 0;
+    // the Gauss-Newton loop follows: its first accumulate + stitch is enqueued right behind this linearisation (the tile sums of
+    // the top Hessian come out of it), unless a callback exchange has to run between accumulate and stitch
+    static const bool noPrefetch = getenv("SOS_NO_PREPARE_PREFETCH") != nullptr;  // A/B knob
+    // (2: only the tile sums are formed -- the device-resident loop and a callback exchange enqueue their own accumulate)
+    static const char *pm = getenv("SOS_PREPARE_MODE");  // A/B knob
+    sos_ba_set_prefetch(ef->ba, pm ? atoi(pm) : noPrefetch ? 0 : (ef->allreduceHook || residentUsable()) ? 2 : 1);
+    lastError = sos_ba_linearize_apply(ef->ba, th.data(), 1, &E, newestE.data(), &cnt);
+    newestE.resize(cnt);
+    setNewFrameEnergyTH(newestE);
+    prepareEnergy = E;
+  } else {
+    sos_ba_reset_oob(ef->ba);
+    prepareEnergy = linearizeAll(false);
+    if (!forceAcceptStep) {  // lastEnergyL / lastEnergyM of FS/FullSystemOptimize.cpp:335-336, evaluated before the first applyRes
+      prepareEnergyL = ef->calcLEnergyF_MT();
+      prepareEnergyM = ef->calcMEnergyF();
+    }
+    applyRes();
   }
-  applyRes();
-  if (tmg) fprintf(stderr, "[prepare] packWindow %.0f us, precalc+pushState %.0f us, resetOOB+linearize+apply %.0f us\n", (t1 - t0) * 1e6, (t2 - t1) * 1e6, (now_s() - t2) * 1e6);
+  if (tmg) fprintf(stderr, "[prepare] precalc %.0f us, packWindow %.0f us, pushState %.0f us, resetOOB+linearize+apply %.0f us\n", (t1 - t0) * 1e6, (t2 - t1) * 1e6, (t3 - t2) * 1e6, (now_s() - t3) * 1e6);
   return lastError;
 }
 
@@ -1123,7 +1196,7 @@ host_path:
     int cnt = 0;
     double E = 0;
     ef->pointStep.resize(ef->allPoints.size());
-    const bool more = pipelineAlways || (mayContinue && !(canbreak && iteration >= setting_minOptIterations));
+    const bool more = pipelineAlways || (mayContinue && !(canbreak && iteration >= minOptIterations));
     sos_ba_set_prefetch(ef->ba, (more && !ef->allreduceHook) ? 1 : 0);  // a callback exchange runs between accumulate and stitch
     lastError = sos_ba_gn_step(ef->ba, ef->lastX.data(), 1.0f, &cal, nullptr, nullptr, nullptr, th.data(), 1, &E, newestE.data(), &cnt,
                                ef->pointStep.data());
@@ -1163,7 +1236,7 @@ host_path:
     double E = 0;
     ef->pointStep.resize(ef->allPoints.size());
     // the next iteration's accumulate can be enqueued behind this linearisation when there will be one
-    const bool more = pipelineAlways || (mayContinue && !(canbreak && iteration >= setting_minOptIterations));
+    const bool more = pipelineAlways || (mayContinue && !(canbreak && iteration >= minOptIterations));
     sos_ba_set_prefetch(ef->ba, (more && !ef->allreduceHook) ? 1 : 0);
     lastError = sos_ba_gn_step(ef->ba, resubAhead ? nullptr : ef->lastX.data(), 1.0f, &cal, pc.data(), ef->adHTdeltaF.data(), ef->cDeltaF, th.data(),
                                1, &E, newestE.data(), &cnt, ef->pointStep.data());
@@ -1307,6 +1380,7 @@ int FullSystem::residentFlush() {
 }
 
 void FullSystem::loadSateBackup() {  // FS/FullSystemOptimize.cpp:271-287 (IMU off)
+  ef->pointsOnDeviceCurrent = false;
   HCalib.setValue(HCalib.value_backup);
   for (FrameHessian *fh : frameHessians) {
     fh->setState(fh->state_backup);
@@ -1367,7 +1441,7 @@ float FullSystem::optimize(int mnumOptIts, int *iterations) {
     for (int iteration = 0; iteration < mnumOptIts; iteration++) {
       const bool canbreak = residentConsume(residentQueued);
       it++;
-      if (isLost || (canbreak && iteration >= setting_minOptIterations)) break;
+      if (isLost || (canbreak && iteration >= minOptIterations)) break;
       if (iteration + 1 < mnumOptIts) rcAcc(sos_ba_gn_resident_enqueue(ef->ba, &residentQueued));
     }
     residentFlush();
@@ -1375,7 +1449,7 @@ float FullSystem::optimize(int mnumOptIts, int *iterations) {
     for (int iteration = 0; iteration < mnumOptIts; iteration++) {
       const bool canbreak = forceAcceptStep ? gnIteration(iteration, iteration + 1 < mnumOptIts) : gnIterationChecked(iteration, lastE, lastEL, lastEM);
       it++;
-      if (canbreak && iteration >= setting_minOptIterations) break;
+      if (canbreak && iteration >= minOptIterations) break;
     }
     if (devStepActive) {
       sos_ba_gn_devstep_end(ef->ba);
@@ -1393,7 +1467,7 @@ float FullSystem::optimize(int mnumOptIts, int *iterations) {
   ef->EFDeltaValid = ef->EFAdjointsValid = false;
   ef->setAdjointsF(&HCalib);
   setPrecalcValues();
-  ef->pushState(&HCalib, true);
+  ef->pushState(&HCalib, true, false);  // the point values on the device are the host's after the loop (or were re-sent by its last pushState)
   const double tp3 = now_s();
   const double lastEnergy = linearizeAll(true);
   const double tp4 = now_s();
@@ -2442,6 +2516,18 @@ extern "C" int sosf_set_resident(sosf_system *s, int on) {
   s->fs->residentAllowed = on != 0;
   return SOS_OK;
 }
+extern "C" int sosf_set_min_opt_iterations(sosf_system *s, int its) {
+  if (!s || its < 0) return SOS_ERR_ARG;
+  s->fs->minOptIterations = its;
+  return SOS_OK;
+}
+
+extern "C" int sosf_invalidate_pack(sosf_system *s) {
+  if (!s) return SOS_ERR_ARG;
+  s->fs->ef->packDirty = true;
+  return SOS_OK;
+}
+
 extern "C" int sosf_set_pipeline(sosf_system *s, int on) {
   if (!s) return SOS_ERR_ARG;
   if (!on) s->fs->residentFlush();
@@ -2758,6 +2844,7 @@ extern "C" int sosf_set_imu(sosf_system *sy, const sosf_imu_settings *S, sosf_im
   EnergyFunctional *ef = sy->fs->ef;
   if (S && (!C || !frames || (HM == nullptr) != (bM == nullptr))) return SOS_ERR_ARG;
   ef->imuSettings = S; ef->imuCalib = C; ef->imuFrames = frames; ef->imuHM = HM; ef->imuBM = bM;
+  if (!S) ef->imuMergedSamples.clear();
   if (S && !HM) {
     if (!ef->imuOwnPrior) ef->imuAdoptPrior();  // first call: the visual prior, expanded; later calls only renew the records
   } else {

@@ -13,6 +13,7 @@
 #pragma once
 
 #include <cstdint>
+#include <list>
 #include <map>
 #include <vector>
 
@@ -190,8 +191,15 @@ class EnergyFunctional {  // OB/EnergyFunctional.h:52-154
   void setAdjointsF(CalibHessian *HCalib);
 
   // device snapshot management
-  int packWindow();                       // sos_ba_set_window from the current graph (when dirty)
-  int pushState(CalibHessian *HCalib, bool adjoints);  // sos_ba_set_state
+  // sos_ba_set_window from the current graph (when dirty).  active != nullptr: the same walk collects the residuals that are not
+  // linearised and resets them (FS/FullSystemOptimize.cpp:316-329)
+  int packWindow(std::vector<PointFrameResidual *> *active = nullptr);
+  int pushState(CalibHessian *HCalib, bool adjoints, bool points = true);  // sos_ba_set_state
+  bool pointsOnDeviceCurrent = false;  // the device's idepth / idepth_zero / deltaF equal the host mirrors
+  std::vector<sos_point> packPts;      // record vectors of packWindow / pushState, kept between keyframes
+  std::vector<sos_resid> packRes;
+  std::vector<sos_precalc> scrPrecalc;
+  std::vector<float> scrId, scrIdz, scrDl;
   sos_ba *ba = nullptr;
   sos_ctx *ctx = nullptr;
   bool packDirty = true;
@@ -223,6 +231,7 @@ class EnergyFunctional {  // OB/EnergyFunctional.h:52-154
   MatXX HMi;
   VecX bMi;
   void imuAdoptPrior();  // HMi / bMi = expandHbtoFitImu(HM, bM)
+  std::list<std::vector<double>> imuMergedSamples;  // sample lists merged by marginalizeFrame, kept while a record points at them
   double imuScaleStep = 0;
   std::vector<double> imuStep;
   float (*nthHook)(void *, const float *, int, float) = nullptr;
@@ -277,6 +286,7 @@ class FullSystem {
   int residentBegin();
   bool residentConsume(int seq);            // waits for iteration seq, refreshes the host mirrors, returns canbreak
   int residentFlush();                      // leaves the loop: mirrors of points / thresholds brought up to date
+  int minOptIterations = 1;     // setting_minOptIterations (util/settings.cpp:77)
   bool forceAcceptStep = true;  // setting_forceAceptStep (util/settings.cpp:117); false: energy-checked steps with loadSateBackup
   int stepsRejected = 0;        // rejected steps of the last optimize()
   int lastLoopMode = -1;        // how the last Gauss-Newton iteration ran: 0 host step, 1 device-side step, 2 device-resident loop, 3 energy-checked

@@ -2454,6 +2454,13 @@ __global__ void k_expand_points(BaDev d) {
   o[0] = make_float4(c0.x, w0.x, c0.y, w0.y); o[1] = make_float4(c0.z, w0.z, c0.w, w0.w);
   o[2] = make_float4(c1.x, w1.x, c1.y, w1.y); o[3] = make_float4(c1.z, w1.z, c1.w, w1.w);
 }
+__global__ void k_unsort_center(BaDev d) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= d.Rpad) return;
+  const int o = d.s_orig[s];
+  if (o < 0) return;
+  d.o_center[3 * o] = d.s_center[3 * s]; d.o_center[3 * o + 1] = d.s_center[3 * s + 1]; d.o_center[3 * o + 2] = d.s_center[3 * s + 2];
+}
 __global__ void k_refresh_geo(BaDev d) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= d.Rpad) return;
@@ -2523,20 +2530,23 @@ template <typename T>
 struct DevBuf {
   T *p = nullptr;
   size_t cap = 0;
+  bool view = false;  // a sub-buffer of a slab owned elsewhere (sos_ba_set_window)
   int ensure(size_t n) {
     if (n <= cap) return SOS_OK;
-    if (p) hipFree(p);
+    if (p && !view) hipFree(p);
     p = nullptr;
     cap = 0;
+    view = false;
     size_t want = n + n / 4 + 64;
     if (hipMalloc(&p, sizeof(T) * want) != hipSuccess) return SOS_ERR_NOMEM;
     cap = want;
     return SOS_OK;
   }
   void release() {
-    if (p) hipFree(p);
+    if (p && !view) hipFree(p);
     p = nullptr;
     cap = 0;
+    view = false;
   }
 };
 
@@ -2554,6 +2564,17 @@ struct sos_ba {
   std::vector<sos_point> h_pts;
   std::vector<sos_resid> h_res;
   std::vector<int> h_p_begin;
+  std::vector<int> h_keys, h_kcount;  // sos_ba_set_window scratch (kept: no allocation per keyframe)
+  // per-window slabs: every index table of the snapshot is built in ONE pinned block and uploaded with one copy; the
+  // scratch that has to start at zero is ONE device block cleared by one kernel.  The DevBufs of those tables are views.
+  char *up_host = nullptr, *up_dev = nullptr, *zr_dev = nullptr;
+  size_t up_cap = 0, zr_cap = 0;
+  char *fin_host = nullptr, *fin_dev = nullptr;  // sos_ba_linearize_final: packed results, device side and pinned host side
+  size_t fin_cap = 0;
+  int adj_n = 0;
+  size_t up_pts_off = 0;    // offset of the point records in the upload slab
+  char *adj_host = nullptr, *adj_dev = nullptr;  // adjoints [adHost | adTarget] fp64 + [adHostF | adTargetF] fp32: one pinned block, one copy
+  size_t adj_cap = 0;
   sos_calib calib;
   // device buffers
   DevBuf<sos_point> d_pts;
@@ -2591,6 +2612,8 @@ struct sos_ba {
   bool resub_pending = false;  // sos_ba_gn_resub enqueued the back-substitution of the step sos_ba_gn_step is about to take
   // device-side step (sos_ba_gn_devstep_begin): frame states that stay on the device between the iterations of one optimize()
   bool devstep = false;
+  double *ds_host = nullptr; // pinned source of the upload below (two halves)
+  int ds_flip = 0;
   double *d_ds = nullptr;    // evalC2W 12 n | state_zero 10 n | state[0] 10 n | state[1] 10 n | calib[0] 8 | calib[1] 8 | ab_exposure n
   int ds_n = 0, ds_cur = 0;
   size_t out_esum = 0, out_newest = 0, out_step = 0, out_bytes = 0;
@@ -2601,6 +2624,8 @@ struct sos_ba {
   bool prefetch = false;      // sos_ba_set_prefetch: gn_step enqueues the next gn_accumulate behind the linearisation
   bool acc_inflight = false;  // ... and this says its result is (or will be) in the mapped Hb block
   bool acc_inflight_haveL = false;
+  bool top_valid = false;     // d_top_part holds the tile sums of the current linearisation (the last one ran fused and nothing changed since)
+  bool fuse_only = false;     // sos_ba_set_prefetch(ba, 2): the linearisation forms the tile sums, nothing is enqueued behind it
   DevBuf<int> d_sigctr;       // [0] linearize launches, [1] stitch launches (cumulative block counters)
   int sig_lin_blocks = 0, sig_lin_seq = 0, sig_st_seq = 0, sig_st_blocks_total = 0;
   // multi-GPU (sos_ba_set_comm): common capacity of the newest-frame energy lists, local / gathered device lists and
@@ -2641,8 +2666,9 @@ extern "C" int sos_ba_create(sos_ctx *ctx, const sos_params *prm, sos_ba **out) 
 
 extern "C" int sos_ba_set_prefetch(sos_ba *ba, int on) {
   if (!ba) return SOS_ERR_ARG;
-  ba->prefetch = on != 0;
-  if (!on) ba->acc_inflight = false;
+  ba->prefetch = on == 1;
+  ba->fuse_only = on == 2;  // the tile sums of the top Hessian come out of the next linearisation, but no accumulate is enqueued behind it
+  if (on != 1) ba->acc_inflight = false;
   return SOS_OK;
 }
 
@@ -2657,6 +2683,14 @@ extern "C" int sos_ba_destroy(sos_ba *ba) {
   hipSetDevice(ba->ctx->device);
   hipStreamSynchronize(ba->ctx->stream);
   if (ba->d_ds) hipFree(ba->d_ds);
+  if (ba->ds_host) hipHostFree(ba->ds_host);
+  if (ba->up_host) hipHostFree(ba->up_host);
+  if (ba->up_dev) hipFree(ba->up_dev);
+  if (ba->zr_dev) hipFree(ba->zr_dev);
+  if (ba->fin_host) hipHostFree(ba->fin_host);
+  if (ba->fin_dev) hipFree(ba->fin_dev);
+  if (ba->adj_host) hipHostFree(ba->adj_host);
+  if (ba->adj_dev) hipFree(ba->adj_dev);
   ba->d_pts.release();
   for (DevBuf<int> *b : {&ba->d_s_point, &ba->d_s_orig, &ba->d_t_pair, &ba->d_p_begin, &ba->d_p_list, &ba->d_p_res_t,
                          &ba->d_pair_tile_begin, &ba->d_chunk_pt, &ba->d_host_chunk_begin, &ba->d_tmp_int, &ba->d_sigctr})
@@ -2697,172 +2731,225 @@ static int upload(hipStream_t st, DevBuf<T> &buf, const std::vector<T> &v) {
 
 static int comm_setup_window(sos_ba *ba);
 
+// zero fill of the per-window scratch slab (one launch instead of a dozen memset commands)
+__global__ __launch_bounds__(256) void k_zero_slab(float4 *__restrict__ p, size_t n4) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// bump allocator over a slab: 256-byte aligned sub-buffers
+struct SlabLayout {
+  size_t off = 0;
+  size_t take(size_t bytes) {
+    const size_t o = off;
+    off = (off + bytes + 255) / 256 * 256;
+    return o;
+  }
+};
+template <typename T>
+static inline void slab_view(DevBuf<T> &b, char *base, size_t off, size_t count) {
+  b.release();
+  b.p = reinterpret_cast<T *>(base + off);
+  b.cap = count;
+  b.view = true;
+}
+
 extern "C" int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, int P, const sos_point *pts, int R,
                                  const sos_resid *res, const float *res_toZeroF, const sos_rawjac *lin_J) {
   if (ba) ba->devstep = false;  // the device-side frame states belong to the previous snapshot
-  if (ba) ba->acc_inflight = false;  // any state change invalidates a prefetched accumulate
+  if (ba) ba->acc_inflight = false, ba->top_valid = false;  // any state change invalidates a prefetched accumulate
   if (!ba || n < 1 || n > SOS_MAX_FRAMES || P < 0 || R < 0 || !frame_slot || (P && !pts) || (R && !res)) return SOS_ERR_ARG;
   sos_ctx *c = ba->ctx;
   SOS_HIP(hipSetDevice(c->device));
   hipStream_t st = c->stream;
-  SOS_HIP(hipStreamSynchronize(st));
+  SOS_HIP(hipStreamSynchronize(st));  // (also: the previous snapshot's upload has left the pinned slab)
   const double tw0 = now_s();
   for (int i = 0; i < n; i++) {
     if (frame_slot[i] < 0 || frame_slot[i] >= SOS_MAX_SLOTS || !c->dI[frame_slot[i]][0]) return SOS_ERR_STATE;
     ba->slot[i] = frame_slot[i];
   }
-  // ---- validate the graph: residuals contiguous per point, in point order
-  std::vector<int> p_begin(P + 1, 0);
+  const int nn2 = 2 * n * n;
+  // ---- pass 1: validate the graph (residuals contiguous per point, in point order; allPoints order: frames -> points),
+  // key = (isLinearized, pair) of every residual and the key histogram
+  std::vector<int> &p_begin = ba->h_p_begin, &keys = ba->h_keys, &kcount = ba->h_kcount;
+  p_begin.resize((size_t)P + 1);
+  keys.resize(R ? R : 1);
+  kcount.assign((size_t)nn2 + 1, 0);
   {
     int r = 0;
     for (int p = 0; p < P; p++) {
+      if (p && pts[p].host < pts[p - 1].host) return SOS_ERR_ARG;
       p_begin[p] = r;
-      while (r < R && res[r].point == p) r++;
+      const int ph = pts[p].host;
+      while (r < R && res[r].point == p) {
+        const sos_resid &q = res[r];
+        if (q.host != ph || q.host < 0 || q.host >= n || q.target < 0 || q.target >= n) return SOS_ERR_ARG;
+        const int k = ((q.flags & SOS_RF_LINEARIZED) ? n * n : 0) + q.host + n * q.target;
+        keys[r] = k;
+        kcount[k + 1]++;
+        r++;
+      }
     }
     p_begin[P] = r;
     if (r != R) return SOS_ERR_ARG;
-    for (int i = 0; i < R; i++)
-      if (res[i].host < 0 || res[i].host >= n || res[i].target < 0 || res[i].target >= n || res[i].host != pts[res[i].point].host)
-        return SOS_ERR_ARG;
-    for (int p = 1; p < P; p++)
-      if (pts[p].host < pts[p - 1].host) return SOS_ERR_ARG;  // allPoints order: frames -> points
   }
-  // ---- sort residuals by (isLinearized, pair), stable in the original (point) order
-  auto key = [&](int r) { return ((res[r].flags & SOS_RF_LINEARIZED) ? n * n : 0) + res[r].host + n * res[r].target; };
-  std::vector<int> order(R);
-  {  // counting sort over the 2 n^2 keys (stable): O(R), this runs once per keyframe on the host
-    std::vector<int> kcount(2 * n * n + 1, 0), keys(R);
-    for (int r = 0; r < R; r++) { keys[r] = key(r); kcount[keys[r] + 1]++; }
-    for (int k = 0; k < 2 * n * n; k++) kcount[k + 1] += kcount[k];
-    for (int r = 0; r < R; r++) order[kcount[keys[r]]++] = r;
+  // ---- tiles: every key padded to whole tiles of SOS_TILE residuals
+  std::vector<int> &pair_tile_begin = ba->h_pair_tile_begin;
+  pair_tile_begin.resize((size_t)nn2 + 1);
+  int ntilesA = 0, ntiles = 0;
+  for (int k = 0; k < nn2; k++) {
+    pair_tile_begin[k] = ntiles;
+    ntiles += (kcount[k + 1] + SOS_TILE - 1) / SOS_TILE;
+    if (k == n * n - 1) ntilesA = ntiles;
   }
-  std::vector<int> s_point, s_orig, t_pair, pair_tile_begin(2 * n * n + 1, 0);
-  std::vector<int> s_of_orig(R, -1);
-  int ntilesA = 0;
-  {
-    size_t pos = 0;
-    for (int k = 0; k < 2 * n * n; k++) {
-      pair_tile_begin[k] = (int)t_pair.size();
-      size_t start = pos;
-      while (pos < order.size() && key(order[pos]) == k) pos++;
-      size_t cnt = pos - start;
-      int tiles = (int)((cnt + SOS_TILE - 1) / SOS_TILE);
-      for (int t = 0; t < tiles; t++) {
-        t_pair.push_back(k % (n * n));
-        for (int q = 0; q < SOS_TILE; q++) {
-          size_t idx = start + (size_t)t * SOS_TILE + q;
-          if (idx < pos) {
-            s_of_orig[order[idx]] = (int)s_point.size();
-            s_point.push_back(res[order[idx]].point);
-            s_orig.push_back(order[idx]);
-          } else {
-            s_point.push_back(-1);
-            s_orig.push_back(-1);
-          }
-        }
-      }
-      if (k == n * n - 1) ntilesA = (int)t_pair.size();
-    }
-    pair_tile_begin[2 * n * n] = (int)t_pair.size();
-  }
-  const int ntiles = (int)t_pair.size();
+  pair_tile_begin[nn2] = ntiles;
   const int Rpad = ntiles * SOS_TILE;
-  ba->n = n; ba->P = P; ba->R = R; ba->Rpad = Rpad; ba->ntiles = ntiles; ba->ntilesA = ntilesA;
-  ba->h_s_of_orig = s_of_orig;
-  ba->h_pair_tile_begin = pair_tile_begin;
-  ba->h_pts.assign(pts, pts + P);
-  ba->h_res.assign(res, res + R);
-  ba->h_p_begin = p_begin;
-
-  std::vector<uint8_t> s_flags(Rpad ? Rpad : 1, 0), s_state(Rpad ? Rpad : 1, SOS_RES_OOB);
-  std::vector<float> s_energy(Rpad ? Rpad : 1, 0.f), s_rtz(res_toZeroF ? (size_t)(Rpad ? Rpad : 1) * 8 : 0, 0.f);
-  for (int s = 0; s < Rpad; s++) {
-    int o = s_orig[s];
-    if (o < 0) continue;
-    unsigned f = DF_VALID;
-    if (res[o].flags & SOS_RF_ACTIVE) f |= DF_ACTIVE;
-    if (res[o].flags & SOS_RF_LINEARIZED) f |= DF_LINEARIZED;
-    if (res[o].flags & SOS_RF_ISNEW) f |= DF_ISNEW;
-    s_flags[s] = (uint8_t)f;
-    s_state[s] = (uint8_t)res[o].state_state;
-    s_energy[s] = res[o].state_energy;
-    if (res_toZeroF) memcpy(&s_rtz[(size_t)s * 8], res_toZeroF + (size_t)o * 8, 8 * sizeof(float));
-  }
-  // per point lists
-  std::vector<int> p_list(R ? R : 1, 0), p_res_t((size_t)(P ? P : 1) * n, -1);
-  std::vector<int2> p_list2(R ? R : 1);
-  for (int o = 0; o < R; o++) {
-    p_list[o] = s_of_orig[o];
-    p_list2[o] = make_int2(s_of_orig[o], n * res[o].host + res[o].target);
-    p_res_t[(size_t)res[o].point * n + res[o].target] = s_of_orig[o];
-  }
-  // chunks of 64 points per host for the Gram kernel
-  std::vector<int> chunk_pt, host_chunk_begin(n + 1, 0);
+  // chunks of SOS_GC points per host for the Gram kernel
+  int nchunks = 0;
+  std::vector<int> host_chunk_begin(n + 1, 0), host_pt_begin(n + 1, 0);
   {
     int p = 0;
     for (int h = 0; h < n; h++) {
-      host_chunk_begin[h] = (int)(chunk_pt.size() / SOS_GC);
-      int start = p;
+      host_chunk_begin[h] = nchunks;
+      host_pt_begin[h] = p;
+      const int start = p;
       while (p < P && pts[p].host == h) p++;
-      for (int q = start; q < p; q += SOS_GC)
-        for (int k = 0; k < SOS_GC; k++) chunk_pt.push_back(q + k < p ? q + k : -1);
+      nchunks += (p - start + SOS_GC - 1) / SOS_GC;
     }
-    host_chunk_begin[n] = (int)(chunk_pt.size() / SOS_GC);
+    host_chunk_begin[n] = nchunks;
+    host_pt_begin[n] = P;
   }
-  ba->nchunks = host_chunk_begin[n];
+  ba->n = n; ba->P = P; ba->R = R; ba->Rpad = Rpad; ba->ntiles = ntiles; ba->ntilesA = ntilesA;
+  ba->nchunks = nchunks;
   ba->Dm = ((8 * n + 5) + 15) / 16 * 16;
   ba->ld = (ba->Dm % 32 == 16) ? ba->Dm : ba->Dm + 16;
+  const size_t Rp = Rpad ? Rpad : 1, Pp = P ? P : 1, Rr = R ? R : 1, Tp = ntiles ? ntiles : 1;
 
-  const double tw1 = now_s();
-  // ---- upload
-  int rc;
-  if ((rc = upload(st, ba->d_pts, ba->h_pts))) return rc;
-  if ((rc = upload(st, ba->d_s_point, s_point))) return rc;
-  if ((rc = upload(st, ba->d_s_orig, s_orig))) return rc;
-  if ((rc = upload(st, ba->d_t_pair, t_pair))) return rc;
-  {  // static per-tile tables of the linearisation: target image, (host, target) indices
-    std::vector<const float *> t_img(t_pair.size());
-    std::vector<int> t_ht(t_pair.size());
-    for (size_t t = 0; t < t_pair.size(); t++) {
-      const int hI = t_pair[t] % n, tI = t_pair[t] / n;
+  // ---- layout of the upload slab (built in pinned host memory, one H2D) and of the zeroed scratch slab
+  SlabLayout up, zr;
+  const size_t u_pts = up.take(sizeof(sos_point) * Pp), u_s_point = up.take(sizeof(int) * Rp), u_s_orig = up.take(sizeof(int) * Rp),
+               u_t_pair = up.take(sizeof(int) * Tp), u_t_img = up.take(sizeof(const float *) * Tp), u_t_ht = up.take(sizeof(int) * Tp),
+               u_p_begin = up.take(sizeof(int) * ((size_t)P + 1)), u_p_list = up.take(sizeof(int) * Rr),
+               u_p_list2 = up.take(sizeof(int2) * Rr), u_p_list16 = up.take(sizeof(int2) * Pp * 16),
+               u_p_res_t = up.take(sizeof(int) * Pp * n), u_ptb = up.take(sizeof(int) * ((size_t)nn2 + 1)),
+               u_chunk = up.take(sizeof(int) * (size_t)(nchunks ? nchunks : 1) * SOS_GC), u_hcb = up.take(sizeof(int) * ((size_t)n + 1)),
+               u_flags = up.take(Rp), u_state = up.take(Rp), u_newstate = up.take(Rp), u_energy = up.take(sizeof(float) * Rp),
+               u_rtz = res_toZeroF ? up.take(sizeof(float) * Rp * 8) : 0;
+  const size_t z_newenergy = zr.take(sizeof(float) * Rp), z_newenergywo = zr.take(sizeof(float) * Rp), z_ret = zr.take(sizeof(float) * Rp),
+               z_center = zr.take(sizeof(float) * Rp * 3), z_pterm = zr.take(sizeof(float) * Rp * 8),
+               z_J = zr.take(sizeof(float) * Tp * SOS_TILE_FLOATS), z_JpJd = zr.take(sizeof(float) * Rp * 8),
+               z_pout = zr.take(sizeof(float) * Pp * 16), z_ocenter = zr.take(sizeof(float) * Rr * 3), z_sig = zr.take(sizeof(int) * 32),
+               z_rtz = res_toZeroF ? 0 : zr.take(sizeof(float) * Rp * 8);
+  if (up.off > ba->up_cap) {
+    if (ba->up_host) hipHostFree(ba->up_host);
+    if (ba->up_dev) hipFree(ba->up_dev);
+    ba->up_host = ba->up_dev = nullptr;
+    ba->up_cap = 0;
+    const size_t want = up.off + up.off / 4 + 4096;
+    SOS_HIP(hipHostMalloc((void **)&ba->up_host, want, hipHostMallocDefault));
+    if (hipMalloc((void **)&ba->up_dev, want) != hipSuccess) return SOS_ERR_NOMEM;
+    ba->up_cap = want;
+  }
+  if (zr.off > ba->zr_cap) {
+    if (ba->zr_dev) hipFree(ba->zr_dev);
+    ba->zr_dev = nullptr;
+    ba->zr_cap = 0;
+    const size_t want = zr.off + zr.off / 4 + 4096;
+    if (hipMalloc((void **)&ba->zr_dev, want) != hipSuccess) return SOS_ERR_NOMEM;
+    ba->zr_cap = want;
+  }
+  char *uh = ba->up_host, *ud = ba->up_dev, *zd = ba->zr_dev;
+  slab_view(ba->d_pts, ud, u_pts, Pp); slab_view(ba->d_s_point, ud, u_s_point, Rp); slab_view(ba->d_s_orig, ud, u_s_orig, Rp);
+  slab_view(ba->d_t_pair, ud, u_t_pair, Tp); slab_view(ba->d_t_img, ud, u_t_img, Tp); slab_view(ba->d_t_ht, ud, u_t_ht, Tp);
+  slab_view(ba->d_p_begin, ud, u_p_begin, (size_t)P + 1); slab_view(ba->d_p_list, ud, u_p_list, Rr); slab_view(ba->d_p_list2, ud, u_p_list2, Rr);
+  slab_view(ba->d_p_list16, ud, u_p_list16, Pp * 16); slab_view(ba->d_p_res_t, ud, u_p_res_t, Pp * n);
+  slab_view(ba->d_pair_tile_begin, ud, u_ptb, (size_t)nn2 + 1); slab_view(ba->d_chunk_pt, ud, u_chunk, (size_t)(nchunks ? nchunks : 1) * SOS_GC);
+  slab_view(ba->d_host_chunk_begin, ud, u_hcb, (size_t)n + 1);
+  slab_view(ba->d_s_flags, ud, u_flags, Rp); slab_view(ba->d_s_state, ud, u_state, Rp); slab_view(ba->d_s_newstate, ud, u_newstate, Rp);
+  slab_view(ba->d_s_energy, ud, u_energy, Rp);
+  slab_view(ba->d_s_newenergy, zd, z_newenergy, Rp); slab_view(ba->d_s_newenergywo, zd, z_newenergywo, Rp); slab_view(ba->d_s_ret, zd, z_ret, Rp);
+  slab_view(ba->d_s_center, zd, z_center, Rp * 3); slab_view(ba->d_s_pterm, zd, z_pterm, Rp * 8);
+  slab_view(ba->d_J, zd, z_J, Tp * SOS_TILE_FLOATS); slab_view(ba->d_JpJd, zd, z_JpJd, Rp * 8); slab_view(ba->d_p_out, zd, z_pout, Pp * 16);
+  slab_view(ba->d_o_center, zd, z_ocenter, Rr * 3); slab_view(ba->d_sigctr, zd, z_sig, 32);
+  if (res_toZeroF) slab_view(ba->d_s_rtz, ud, u_rtz, Rp * 8);
+  else slab_view(ba->d_s_rtz, zd, z_rtz, Rp * 8);
+
+  // ---- pass 2: the tables, written where they are uploaded from.  Residuals sorted by (isLinearized, pair), stable in the
+  // original (point) order: a counting sort over the 2 n^2 keys whose slots already include the tile padding
+  ba->up_pts_off = u_pts;
+  sos_point *h_pts_up = reinterpret_cast<sos_point *>(uh + u_pts);
+  int *s_point = reinterpret_cast<int *>(uh + u_s_point), *s_orig = reinterpret_cast<int *>(uh + u_s_orig);
+  int *t_pair = reinterpret_cast<int *>(uh + u_t_pair), *t_ht = reinterpret_cast<int *>(uh + u_t_ht);
+  const float **t_img = reinterpret_cast<const float **>(uh + u_t_img);
+  int *p_list = reinterpret_cast<int *>(uh + u_p_list), *p_res_t = reinterpret_cast<int *>(uh + u_p_res_t);
+  int2 *p_list2 = reinterpret_cast<int2 *>(uh + u_p_list2), *p_list16 = reinterpret_cast<int2 *>(uh + u_p_list16);
+  uint8_t *s_flags = reinterpret_cast<uint8_t *>(uh + u_flags), *s_state = reinterpret_cast<uint8_t *>(uh + u_state);
+  float *s_energy = reinterpret_cast<float *>(uh + u_energy), *s_rtz = res_toZeroF ? reinterpret_cast<float *>(uh + u_rtz) : nullptr;
+  if (P) memcpy(h_pts_up, pts, sizeof(sos_point) * P);
+  memcpy(uh + u_p_begin, p_begin.data(), sizeof(int) * ((size_t)P + 1));
+  memcpy(uh + u_ptb, pair_tile_begin.data(), sizeof(int) * ((size_t)nn2 + 1));
+  memcpy(uh + u_hcb, host_chunk_begin.data(), sizeof(int) * ((size_t)n + 1));
+  memset(uh + u_newstate, SOS_RES_OOB, Rp);
+  for (int k = 0; k < nn2; k++) {  // per key: its tiles, and the padding slots behind its residuals
+    const int t0 = pair_tile_begin[k], t1 = pair_tile_begin[k + 1];
+    const int hI = (k % (n * n)) % n, tI = (k % (n * n)) / n;
+    for (int t = t0; t < t1; t++) {
+      t_pair[t] = k % (n * n);
       t_img[t] = c->dIt[frame_slot[tI]];
       t_ht[t] = hI | (tI << 16);
     }
-    if ((rc = upload(st, ba->d_t_img, t_img))) return rc;
-    if ((rc = upload(st, ba->d_t_ht, t_ht))) return rc;
-    if ((rc = ba->d_t_pre.ensure(8 * (t_pair.size() ? t_pair.size() : 1)))) return rc;
+    for (int sI = t0 * SOS_TILE + kcount[k + 1]; sI < t1 * SOS_TILE; sI++) {
+      s_point[sI] = -1; s_orig[sI] = -1; s_flags[sI] = 0; s_state[sI] = SOS_RES_OOB; s_energy[sI] = 0.f;
+      if (s_rtz) memset(s_rtz + (size_t)sI * 8, 0, 8 * sizeof(float));
+    }
+    kcount[k + 1] = t0 * SOS_TILE;  // from here on: next free slot of key k
   }
-  if ((rc = upload(st, ba->d_p_begin, p_begin))) return rc;
-  if ((rc = upload(st, ba->d_p_list, p_list))) return rc;
-  if ((rc = upload(st, ba->d_p_list2, p_list2))) return rc;
+  if (Rpad == 0) { s_point[0] = s_orig[0] = -1; s_flags[0] = 0; s_state[0] = SOS_RES_OOB; s_energy[0] = 0.f; }
+  std::vector<int> &s_of_orig = ba->h_s_of_orig;
+  s_of_orig.resize(R);
+  if (P) memset(p_res_t, 0xff, sizeof(int) * (size_t)P * n);
+  for (int pt = 0; pt < P; pt++) {
+    int2 *l16 = p_list16 + (size_t)pt * 16;
+    int k16 = 0;
+    for (int o = p_begin[pt]; o < p_begin[pt + 1]; o++) {
+      const sos_resid &q = res[o];
+      const int sI = kcount[keys[o] + 1]++;
+      s_of_orig[o] = sI;
+      s_point[sI] = pt;
+      s_orig[sI] = o;
+      unsigned f = DF_VALID;
+      if (q.flags & SOS_RF_ACTIVE) f |= DF_ACTIVE;
+      if (q.flags & SOS_RF_LINEARIZED) f |= DF_LINEARIZED;
+      if (q.flags & SOS_RF_ISNEW) f |= DF_ISNEW;
+      s_flags[sI] = (uint8_t)f;
+      s_state[sI] = (uint8_t)q.state_state;
+      s_energy[sI] = q.state_energy;
+      if (s_rtz) memcpy(s_rtz + (size_t)sI * 8, res_toZeroF + (size_t)o * 8, 8 * sizeof(float));
+      p_list[o] = sI;
+      p_list2[o] = make_int2(sI, n * q.host + q.target);
+      p_res_t[(size_t)pt * n + q.target] = sI;
+      if (k16 < 16) l16[k16++] = p_list2[o];
+    }
+    for (; k16 < 16; k16++) l16[k16] = make_int2(-1, 0);
+  }
   {
-    std::vector<int2> p_list16((size_t)(P ? P : 1) * 16, make_int2(-1, 0));
-    for (int pt = 0; pt < P; pt++)
-      for (int q = p_begin[pt], k = 0; q < p_begin[pt + 1] && k < 16; q++, k++) p_list16[(size_t)pt * 16 + k] = p_list2[q];
-    if ((rc = upload(st, ba->d_p_list16, p_list16))) return rc;
+    int *chunk_pt = reinterpret_cast<int *>(uh + u_chunk);
+    size_t w = 0;
+    for (int h = 0; h < n; h++)
+      for (int q = host_pt_begin[h]; q < host_pt_begin[h + 1]; q += SOS_GC)
+        for (int k = 0; k < SOS_GC; k++) chunk_pt[w++] = q + k < host_pt_begin[h + 1] ? q + k : -1;
   }
-  if ((rc = upload(st, ba->d_p_res_t, p_res_t))) return rc;
-  if ((rc = upload(st, ba->d_pair_tile_begin, pair_tile_begin))) return rc;
-  if ((rc = upload(st, ba->d_chunk_pt, chunk_pt))) return rc;
-  if ((rc = upload(st, ba->d_host_chunk_begin, host_chunk_begin))) return rc;
-  if ((rc = upload(st, ba->d_s_flags, s_flags))) return rc;
-  if ((rc = upload(st, ba->d_s_state, s_state))) return rc;
-  if ((rc = upload(st, ba->d_s_energy, s_energy))) return rc;
-  if (res_toZeroF) {
-    if ((rc = upload(st, ba->d_s_rtz, s_rtz))) return rc;
-  } else {
-    if (ba->d_s_rtz.ensure((size_t)(Rpad ? Rpad : 1) * 8)) return SOS_ERR_NOMEM;
-    SOS_HIP(hipMemsetAsync(ba->d_s_rtz.p, 0, sizeof(float) * (size_t)(Rpad ? Rpad : 1) * 8, st));
-  }
+  ba->h_pts.assign(pts, pts + P);
+  ba->h_res.assign(res, res + R);
+  const double tw1 = now_s();
+  // ---- one upload, one zero fill
+  SOS_HIP(hipMemcpyAsync(ud, uh, up.off, hipMemcpyHostToDevice, st));
+  k_zero_slab<<<1024, 256, 0, st>>>(reinterpret_cast<float4 *>(zd), zr.off / 16);
   const double tw2 = now_s();
-  const size_t Rp = Rpad ? Rpad : 1, Pp = P ? P : 1, Rr = R ? R : 1;
-  ENSURE(ba->d_s_newstate, Rp); ENSURE(ba->d_s_newenergy, Rp); ENSURE(ba->d_s_newenergywo, Rp); ENSURE(ba->d_s_ret, Rp);
-  ENSURE(ba->d_s_center, Rp * 3); ENSURE(ba->d_s_pterm, Rp * 8);
   ENSURE(ba->d_r_geo, Rp); ENSURE(ba->d_r_cw, Rp * 16);
-  ENSURE(ba->d_J, (size_t)(ntiles ? ntiles : 1) * SOS_TILE_FLOATS); ENSURE(ba->d_JpJd, Rp * 8);
-  ENSURE(ba->d_p_out, Pp * 16);
-  ENSURE(ba->d_o_newstate, Rr); ENSURE(ba->d_o_newenergy, Rr); ENSURE(ba->d_o_newenergywo, Rr); ENSURE(ba->d_o_center, Rr * 3);
-  ENSURE(ba->d_top_part, (size_t)(ntiles ? ntiles : 1) * SOS_TOPN + 64 * SOS_TOPN);
+  ENSURE(ba->d_t_pre, 8 * Tp);
+  ENSURE(ba->d_o_newstate, Rr); ENSURE(ba->d_o_newenergy, Rr); ENSURE(ba->d_o_newenergywo, Rr);
+  ENSURE(ba->d_top_part, Tp * SOS_TOPN + 64 * SOS_TOPN);
   ENSURE(ba->d_gram_part, (size_t)(ba->nchunks ? ba->nchunks : 1) * ba->Dm * ba->Dm);
   const size_t nn = (size_t)n * n;
   ba->off_topA = 0;
@@ -2885,7 +2972,24 @@ extern "C" int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, i
   ba->st_xad = ba->st_xc + 4;
   ba->st_floats = ba->st_xad + nn * 8;
   ENSURE(ba->d_stage, ba->st_floats);
-  ENSURE(ba->d_adHost, nn * 64); ENSURE(ba->d_adTarget, nn * 64);
+  {  // adjoints: [adHost | adTarget] fp64 + [adHostF | adTargetF] fp32 in one pinned / one device block (sos_ba_set_state)
+    const size_t o_t = sizeof(double) * 64 * nn, o_hf = 2 * o_t, o_tf = o_hf + sizeof(float) * 64 * nn, tot = o_tf + sizeof(float) * 64 * nn;
+    if (tot > ba->adj_cap) {
+      if (ba->adj_host) hipHostFree(ba->adj_host);
+      if (ba->adj_dev) hipFree(ba->adj_dev);
+      ba->adj_host = ba->adj_dev = nullptr;
+      ba->adj_cap = 0;
+      SOS_HIP(hipHostMalloc((void **)&ba->adj_host, tot + tot / 2, hipHostMallocDefault));
+      if (hipMalloc((void **)&ba->adj_dev, tot + tot / 2) != hipSuccess) return SOS_ERR_NOMEM;
+      ba->adj_cap = tot + tot / 2;
+    }
+    slab_view(ba->d_adHost, ba->adj_dev, 0, nn * 64); slab_view(ba->d_adTarget, ba->adj_dev, o_t, nn * 64);
+    // the fp32 copies exist once sos_ba_set_state delivered adjoints for this n (their DevBufs are null until then)
+    const bool keepF = ba->adj_n == n && ba->d_adHostF.p && ba->d_adTargetF.p;
+    ba->adj_n = n;
+    ba->d_adHostF.release(); ba->d_adTargetF.release();
+    if (keepF) { slab_view(ba->d_adHostF, ba->adj_dev, o_hf, nn * 64); slab_view(ba->d_adTargetF, ba->adj_dev, o_tf, nn * 64); }
+  }
   const size_t dim = 4 + 8 * (size_t)n;
   ba->hb_mode_stride = dim * dim + dim;
   ENSURE(ba->d_Hout, 3 * ba->hb_mode_stride + 8); ENSURE(ba->d_scalar, 8); ENSURE(ba->d_perres, Rp);
@@ -2916,20 +3020,8 @@ extern "C" int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, i
     ba->pin_flags = ba->pin_hb + (sizeof(double) * 3 * ba->hb_mode_stride + 16 + 63) / 64 * 64;
     memset(ba->pin + ba->pin_flags, 0, 128);
   }
-  ENSURE(ba->d_sigctr, 32);
-  SOS_HIP(hipMemsetAsync(ba->d_sigctr.p, 0, sizeof(int) * 32, st));
   ba->sig_lin_seq = ba->sig_st_seq = 0;
   ba->sig_lin_blocks = ba->sig_st_blocks_total = 0;
-  SOS_HIP(hipMemsetAsync(ba->d_s_newstate.p, SOS_RES_OOB, Rp, st));
-  SOS_HIP(hipMemsetAsync(ba->d_s_newenergy.p, 0, sizeof(float) * Rp, st));
-  SOS_HIP(hipMemsetAsync(ba->d_s_newenergywo.p, 0, sizeof(float) * Rp, st));
-  SOS_HIP(hipMemsetAsync(ba->d_s_ret.p, 0, sizeof(float) * Rp, st));
-  SOS_HIP(hipMemsetAsync(ba->d_s_center.p, 0, sizeof(float) * Rp * 3, st));
-  SOS_HIP(hipMemsetAsync(ba->d_s_pterm.p, 0, sizeof(float) * Rp * 8, st));
-  SOS_HIP(hipMemsetAsync(ba->d_J.p, 0, sizeof(float) * (size_t)(ntiles ? ntiles : 1) * SOS_TILE_FLOATS, st));
-  SOS_HIP(hipMemsetAsync(ba->d_JpJd.p, 0, sizeof(float) * Rp * 8, st));
-  SOS_HIP(hipMemsetAsync(ba->d_p_out.p, 0, sizeof(float) * Pp * 16, st));
-  SOS_HIP(hipMemsetAsync(ba->d_o_center.p, 0, sizeof(float) * Rr * 3, st));
 
   BaDev &d = ba->dev;
   memset(&d, 0, sizeof(d));
@@ -2972,16 +3064,17 @@ extern "C" int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, i
     for (int o = 0; o < R; o++)
       if (res[o].flags & SOS_RF_LINEARIZED) { sl.push_back(s_of_orig[o]); jl.push_back(lin_J[o]); }
     if (!sl.empty()) {
+      int rc;
       if ((rc = upload(st, ba->d_tmp_int, sl))) return rc;
       if ((rc = upload(st, ba->d_rawjac, jl))) return rc;
       k_put_jac<<<divup((int)sl.size(), 64), 64, 0, st>>>(d, ba->d_tmp_int.p, ba->d_rawjac.p, (int)sl.size());
+      SOS_HIP(hipStreamSynchronize(st));  // sl / jl are pageable locals
     }
   }
   SOS_HIP(hipGetLastError());
-  SOS_HIP(hipStreamSynchronize(st));
   ba->have_window = true;
   ba->have_state = false;
-  if (getenv("SOS_TIMING")) fprintf(stderr, "[set_window] host sort/lists %.0f us, uploads %.0f us, alloc/memset/sync %.0f us\n", (tw1 - tw0) * 1e6, (tw2 - tw1) * 1e6, (now_s() - tw2) * 1e6);
+  if (getenv("SOS_TIMING")) fprintf(stderr, "[set_window] host tables %.0f us, upload + zero enqueue %.0f us, ensure / layout %.0f us (slab %.2f MB, zeroed %.2f MB)\n", (tw1 - tw0) * 1e6, (tw2 - tw1) * 1e6, (now_s() - tw2) * 1e6, up.off / 1e6, zr.off / 1e6);
   return comm_setup_window(ba);
 }
 
@@ -2995,55 +3088,69 @@ extern "C" int sos_ba_set_state(sos_ba *ba, const sos_calib *calib, const sos_pr
                                 const float *point_idepth_scaled, const float *point_idepth_zero_scaled,
                                 const float *point_deltaF) {
   if (ba) ba->devstep = false;  // the host is the source of the states again
-  if (ba) ba->acc_inflight = false;  // any state change invalidates a prefetched accumulate
+  if (ba) ba->acc_inflight = false, ba->top_valid = false;  // any state change invalidates a prefetched accumulate
   if (!ba || !ba->have_window) return SOS_ERR_STATE;
   sos_ctx *c = ba->ctx;
   SOS_HIP(hipSetDevice(c->device));
   hipStream_t st = c->stream;
-  SOS_HIP(hipStreamSynchronize(st));  // the pinned staging area may still be in flight
+  SOS_HIP(hipStreamSynchronize(st));  // the pinned staging areas may still be in flight
+  // every source below is copied into pinned memory first: the caller's (pageable) buffers are free when this returns and
+  // nothing has to be waited for
   const size_t nn = (size_t)ba->n * ba->n;
   if (calib) {
     ba->calib = *calib; ba->dev.calib = *calib;
     memcpy(pstg(ba, ba->st_cal), calib, sizeof(sos_calib));
-    SOS_HIP(hipMemcpyAsync(stg(ba, ba->st_cal), pstg(ba, ba->st_cal), sizeof(sos_calib), hipMemcpyHostToDevice, st));
   }
-  if (precalc) {
-    memcpy(pstg(ba, ba->st_pre), precalc, sizeof(sos_precalc) * nn);
-    SOS_HIP(hipMemcpyAsync(stg(ba, ba->st_pre), pstg(ba, ba->st_pre), sizeof(sos_precalc) * nn, hipMemcpyHostToDevice, st));
-    launch_expand_precalc(ba);
+  if (precalc) memcpy(pstg(ba, ba->st_pre), precalc, sizeof(sos_precalc) * nn);
+  if (adHTdeltaF) memcpy(pstg(ba, ba->st_adh), adHTdeltaF, sizeof(float) * 8 * nn);
+  if (cDeltaF) memcpy(pstg(ba, ba->st_cd), cDeltaF, sizeof(float) * 4);
+  if (calib && precalc && adHTdeltaF && cDeltaF) {  // the usual case: the stage block [precalc | adHTdelta | cdelta | th | calib] in one copy
+    SOS_HIP(hipMemcpyAsync(stg(ba, ba->st_pre), pstg(ba, ba->st_pre), sizeof(float) * ba->st_xc, hipMemcpyHostToDevice, st));
+  } else {
+    if (calib) SOS_HIP(hipMemcpyAsync(stg(ba, ba->st_cal), pstg(ba, ba->st_cal), sizeof(sos_calib), hipMemcpyHostToDevice, st));
+    if (precalc) SOS_HIP(hipMemcpyAsync(stg(ba, ba->st_pre), pstg(ba, ba->st_pre), sizeof(sos_precalc) * nn, hipMemcpyHostToDevice, st));
+    if (adHTdeltaF) SOS_HIP(hipMemcpyAsync(stg(ba, ba->st_adh), pstg(ba, ba->st_adh), sizeof(float) * 8 * nn, hipMemcpyHostToDevice, st));
+    if (cDeltaF) SOS_HIP(hipMemcpyAsync(stg(ba, ba->st_cd), pstg(ba, ba->st_cd), sizeof(float) * 4, hipMemcpyHostToDevice, st));
   }
-  if (adHTdeltaF) {
-    memcpy(pstg(ba, ba->st_adh), adHTdeltaF, sizeof(float) * 8 * nn);
-    SOS_HIP(hipMemcpyAsync(stg(ba, ba->st_adh), pstg(ba, ba->st_adh), sizeof(float) * 8 * nn, hipMemcpyHostToDevice, st));
-  }
-  if (cDeltaF) {
-    memcpy(pstg(ba, ba->st_cd), cDeltaF, sizeof(float) * 4);
-    SOS_HIP(hipMemcpyAsync(stg(ba, ba->st_cd), pstg(ba, ba->st_cd), sizeof(float) * 4, hipMemcpyHostToDevice, st));
-  }
-  if (adHost) {
-    SOS_HIP(hipMemcpyAsync(ba->d_adHost.p, adHost, sizeof(double) * 64 * nn, hipMemcpyHostToDevice, st));
+  if (precalc) launch_expand_precalc(ba);
+  if (adHost || adTarget) {  // fp64 adjoints of the stitch + their fp32 copies (OB/EnergyFunctional.cpp:94-98) for the in-kernel xAd table
+    const size_t o_t = sizeof(double) * 64 * nn, o_hf = 2 * o_t, o_tf = o_hf + sizeof(float) * 64 * nn, tot = o_tf + sizeof(float) * 64 * nn;
+    double *hH = reinterpret_cast<double *>(ba->adj_host), *hT = reinterpret_cast<double *>(ba->adj_host + o_t);
+    float *hHF = reinterpret_cast<float *>(ba->adj_host + o_hf), *hTF = reinterpret_cast<float *>(ba->adj_host + o_tf);
     ba->h_adHostF.resize(64 * nn);
-    for (size_t i = 0; i < 64 * nn; i++) ba->h_adHostF[i] = (float)adHost[i];  // OB/EnergyFunctional.cpp:94-98
-    if (ba->d_adHostF.ensure(64 * nn)) return SOS_ERR_NOMEM;
-    SOS_HIP(hipMemcpyAsync(ba->d_adHostF.p, ba->h_adHostF.data(), sizeof(float) * 64 * nn, hipMemcpyHostToDevice, st));
-  }
-  if (adTarget) {
-    SOS_HIP(hipMemcpyAsync(ba->d_adTarget.p, adTarget, sizeof(double) * 64 * nn, hipMemcpyHostToDevice, st));
     ba->h_adTargetF.resize(64 * nn);
-    for (size_t i = 0; i < 64 * nn; i++) ba->h_adTargetF[i] = (float)adTarget[i];
-    if (ba->d_adTargetF.ensure(64 * nn)) return SOS_ERR_NOMEM;
-    SOS_HIP(hipMemcpyAsync(ba->d_adTargetF.p, ba->h_adTargetF.data(), sizeof(float) * 64 * nn, hipMemcpyHostToDevice, st));
+    if (adHost) {
+      memcpy(hH, adHost, o_t);
+      for (size_t i = 0; i < 64 * nn; i++) hHF[i] = ba->h_adHostF[i] = (float)adHost[i];
+    }
+    if (adTarget) {
+      memcpy(hT, adTarget, o_t);
+      for (size_t i = 0; i < 64 * nn; i++) hTF[i] = ba->h_adTargetF[i] = (float)adTarget[i];
+    }
+    if (adHost && adTarget) {
+      SOS_HIP(hipMemcpyAsync(ba->adj_dev, ba->adj_host, tot, hipMemcpyHostToDevice, st));
+    } else if (adHost) {
+      SOS_HIP(hipMemcpyAsync(ba->adj_dev, ba->adj_host, o_t, hipMemcpyHostToDevice, st));
+      SOS_HIP(hipMemcpyAsync(ba->adj_dev + o_hf, ba->adj_host + o_hf, sizeof(float) * 64 * nn, hipMemcpyHostToDevice, st));
+    } else {
+      SOS_HIP(hipMemcpyAsync(ba->adj_dev + o_t, ba->adj_host + o_t, o_t, hipMemcpyHostToDevice, st));
+      SOS_HIP(hipMemcpyAsync(ba->adj_dev + o_tf, ba->adj_host + o_tf, sizeof(float) * 64 * nn, hipMemcpyHostToDevice, st));
+    }
+    if (adHost) slab_view(ba->d_adHostF, ba->adj_dev, o_hf, nn * 64);
+    if (adTarget) slab_view(ba->d_adTargetF, ba->adj_dev, o_tf, nn * 64);
   }
-  if (point_idepth_scaled || point_idepth_zero_scaled || point_deltaF) {
+  if ((point_idepth_scaled || point_idepth_zero_scaled || point_deltaF) && ba->P) {
+    sos_point *pp = reinterpret_cast<sos_point *>(ba->up_host + ba->up_pts_off);  // pinned region the snapshot's points were uploaded from
     for (int p = 0; p < ba->P; p++) {
       if (point_idepth_scaled) ba->h_pts[p].idepth_scaled = point_idepth_scaled[p];
       if (point_idepth_zero_scaled) ba->h_pts[p].idepth_zero_scaled = point_idepth_zero_scaled[p];
       if (point_deltaF) ba->h_pts[p].deltaF = point_deltaF[p];
     }
-    if (ba->P) SOS_HIP(hipMemcpyAsync(ba->d_pts.p, ba->h_pts.data(), sizeof(sos_point) * ba->P, hipMemcpyHostToDevice, st));
+    memcpy(pp, ba->h_pts.data(), sizeof(sos_point) * ba->P);  // the mirror also carries the steps / priors applied since the pack
+    SOS_HIP(hipMemcpyAsync(ba->d_pts.p, pp, sizeof(sos_point) * ba->P, hipMemcpyHostToDevice, st));
     if (ba->Rpad > 0) k_refresh_geo<<<divup(ba->Rpad, 256), 256, 0, st>>>(ba->dev);
   }
-  SOS_HIP(hipStreamSynchronize(st));  // caller buffers are pageable
+  SOS_HIP(hipGetLastError());
   ba->have_state = true;
   return SOS_OK;
 }
@@ -3226,7 +3333,7 @@ extern "C" int sos_ba_set_comm(sos_ba *ba, sos_comm *comm) {
   if (!ba) return SOS_ERR_ARG;
   SOS_HIP(hipSetDevice(ba->ctx->device));
   SOS_HIP(hipStreamSynchronize(ba->ctx->stream));
-  ba->acc_inflight = false;
+  ba->acc_inflight = false, ba->top_valid = false;
   ba->comm = comm;
   ba->comm_size = comm ? sos_comm_size(comm) : 1;
   if (!comm) { ba->anyL = false; return SOS_OK; }
@@ -3297,7 +3404,7 @@ static int ensure_J(sos_ba *ba) {
 
 extern "C" int sos_ba_linearize(sos_ba *ba, const float *frameEnergyTH, double *energySum, uint8_t *newState,
                                 float *newEnergy, float *newEnergyWithOutlier, float *centerProjectedTo) {
-  if (ba) ba->acc_inflight = false;  // any state change invalidates a prefetched accumulate
+  if (ba) ba->acc_inflight = false, ba->top_valid = false;  // any state change invalidates a prefetched accumulate
   if (!ba || !ba->have_window || !ba->have_state || !frameEnergyTH) return SOS_ERR_STATE;
   sos_ctx *c = ba->ctx;
   SOS_HIP(hipSetDevice(c->device));
@@ -3324,8 +3431,10 @@ extern "C" int sos_ba_linearize(sos_ba *ba, const float *frameEnergyTH, double *
   if (newEnergy && R) SOS_HIP(hipMemcpyAsync(newEnergy, ba->d_o_newenergy.p, sizeof(float) * R, hipMemcpyDeviceToHost, st));
   if (newEnergyWithOutlier && R)
     SOS_HIP(hipMemcpyAsync(newEnergyWithOutlier, ba->d_o_newenergywo.p, sizeof(float) * R, hipMemcpyDeviceToHost, st));
-  if (centerProjectedTo && R)
+  if (centerProjectedTo && R) {  // the fused iterations keep the centres in tile order only
+    k_unsort_center<<<divup(ba->Rpad, 256), 256, 0, st>>>(ba->dev);
     SOS_HIP(hipMemcpyAsync(centerProjectedTo, ba->d_o_center.p, sizeof(float) * 3 * R, hipMemcpyDeviceToHost, st));
+  }
   SOS_HIP(hipGetLastError());
   SOS_HIP(hipStreamSynchronize(st));
   // linearized residuals are not part of activeResiduals: report their stored state
@@ -3339,7 +3448,7 @@ extern "C" int sos_ba_linearize(sos_ba *ba, const float *frameEnergyTH, double *
 }
 
 extern "C" int sos_ba_apply_res(sos_ba *ba) {
-  if (ba) ba->acc_inflight = false;  // any state change invalidates a prefetched accumulate
+  if (ba) ba->acc_inflight = false, ba->top_valid = false;  // any state change invalidates a prefetched accumulate
   if (!ba || !ba->have_window) return SOS_ERR_STATE;
   SOS_HIP(hipSetDevice(ba->ctx->device));
   const int nthr = ba->ntilesA * SOS_TILE;
@@ -3354,7 +3463,7 @@ extern "C" int sos_ba_apply_res(sos_ba *ba) {
 }
 
 extern "C" int sos_ba_reset_oob(sos_ba *ba) {
-  if (ba) ba->acc_inflight = false;  // any state change invalidates a prefetched accumulate
+  if (ba) ba->acc_inflight = false, ba->top_valid = false;  // any state change invalidates a prefetched accumulate
   if (!ba || !ba->have_window) return SOS_ERR_STATE;
   SOS_HIP(hipSetDevice(ba->ctx->device));
   const int nthr = ba->ntilesA * SOS_TILE;
@@ -3365,7 +3474,7 @@ extern "C" int sos_ba_reset_oob(sos_ba *ba) {
 
 extern "C" int sos_ba_fix_linearization(sos_ba *ba, const int32_t *residIdx, int count) {
   if (ba && ba->have_window && ba->have_state) ensure_J(ba);
-  if (ba) ba->acc_inflight = false;  // any state change invalidates a prefetched accumulate
+  if (ba) ba->acc_inflight = false, ba->top_valid = false;  // any state change invalidates a prefetched accumulate
   if (!ba || !ba->have_window || !ba->have_state || (count && !residIdx)) return SOS_ERR_STATE;
   if (count <= 0) return SOS_OK;
   SOS_HIP(hipSetDevice(ba->ctx->device));
@@ -3466,7 +3575,7 @@ static int launch_stitch(sos_ba *ba, const float *acc, int nmodes, double *Hout 
 }
 
 extern "C" int sos_ba_accumulate_local(sos_ba *ba) {
-  if (ba) ba->acc_inflight = false;  // any state change invalidates a prefetched accumulate
+  if (ba) ba->acc_inflight = false, ba->top_valid = false;  // any state change invalidates a prefetched accumulate
   if (!ba || !ba->have_window || !ba->have_state) return SOS_ERR_STATE;
   SOS_HIP(hipSetDevice(ba->ctx->device));
   launch_top(ba);
@@ -3511,7 +3620,7 @@ static int fetch_hb(sos_ba *ba, const float *acc, double *H_A, double *b_A, doub
 
 extern "C" int sos_ba_stitch(sos_ba *ba, double *H_A, double *b_A, double *H_L, double *b_L, double *H_sc, double *b_sc,
                              int *resInA, int *resInL) {
-  if (ba) ba->acc_inflight = false;  // any state change invalidates a prefetched accumulate
+  if (ba) ba->acc_inflight = false, ba->top_valid = false;  // any state change invalidates a prefetched accumulate
   if (!ba || !ba->have_window || !ba->have_state) return SOS_ERR_STATE;
   SOS_HIP(hipSetDevice(ba->ctx->device));
   launch_stitch(ba, ba->d_acc.p, 2);
@@ -3562,10 +3671,10 @@ extern "C" int sos_ba_gn_accumulate(sos_ba *ba, double *H_top, double *b_top, do
   if (!ba || !ba->have_window || !ba->have_state || !H_top || !b_top || !H_sc || !b_sc) return SOS_ERR_STATE;
   SOS_HIP(hipSetDevice(ba->ctx->device));
   if (!ba->acc_inflight) {  // otherwise the previous sos_ba_gn_step already enqueued it (sos_ba_set_prefetch)
-    enqueue_gn_accumulate(ba);
+    enqueue_gn_accumulate(ba, ba->top_valid);
     SOS_HIP(hipGetLastError());
   }
-  ba->acc_inflight = false;
+  ba->acc_inflight = false, ba->top_valid = false;
   const bool haveL = ba->acc_inflight_haveL;
   const double ta = now_s();
   {
@@ -3634,7 +3743,7 @@ static void fill_x(sos_ba *ba, const double *x) {
 }
 
 extern "C" int sos_ba_resubstitute(sos_ba *ba, const double *x, float *pointStep) {
-  if (ba) ba->acc_inflight = false;  // any state change invalidates a prefetched accumulate
+  if (ba) ba->acc_inflight = false, ba->top_valid = false;  // any state change invalidates a prefetched accumulate
   if (!ba || !ba->have_window || !ba->have_state || !x) return SOS_ERR_STATE;
   SOS_HIP(hipSetDevice(ba->ctx->device));
   hipStream_t st = ba->ctx->stream;
@@ -3661,7 +3770,7 @@ extern "C" int sos_ba_gn_resub(sos_ba *ba, const double *x, float stepfacD) {
   if (!(ba->P > 0 && ba->d_adHostF.p && ba->d_adTargetF.p)) return SOS_ERR_STATE;  // caller passes x to sos_ba_gn_step instead
   sos_ctx *c = ba->ctx;
   SOS_HIP(hipSetDevice(c->device));
-  ba->acc_inflight = false;
+  ba->acc_inflight = false, ba->top_valid = false;
   const size_t nn = (size_t)ba->n * ba->n;
   XArg xa;
   const int dim = 4 + 8 * ba->n;
@@ -3675,84 +3784,18 @@ extern "C" int sos_ba_gn_resub(sos_ba *ba, const double *x, float stepfacD) {
   return SOS_OK;
 }
 
-extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const sos_calib *calib, const sos_precalc *precalc,
-                              const float *adHTdeltaF, const float *cDeltaF, const float *frameEnergyTH, int applyRes,
-                              double *energySum, float *newestEnergies, int *newestCount, float *pointStep) {
-  const bool devStep = ba && ba->devstep && x && !precalc;  // the device derives poses / precalc / deltas from x itself
-  if (!ba || !ba->have_window || !ba->have_state || !frameEnergyTH || (!devStep && (!calib || !precalc || !adHTdeltaF || !cDeltaF)))
-    return SOS_ERR_STATE;
-  if (devStep && !(ba->P > 0 && ba->d_adHostF.p && ba->d_adTargetF.p && ba->ds_n == ba->n)) return SOS_ERR_STATE;
+// Back half of a fused iteration: linearizeAll(false) + applyRes on the state the stream has reached, the next
+// iteration's accumulate chain enqueued behind it (sos_ba_set_prefetch), results through the mapped block.
+static int lin_apply_tail(sos_ba *ba, BaDev &dv, int applyRes, bool havePointStep, float stepfacD, double *energySum,
+                          float *newestEnergies, int *newestCount, float *pointStep, double t0, double t1) {
   sos_ctx *c = ba->ctx;
-  SOS_HIP(hipSetDevice(c->device));
   hipStream_t st = c->stream;
-  const size_t nn = (size_t)ba->n * ba->n;
-  if (calib) {
-    ba->calib = *calib;
-    ba->dev.calib = *calib;
-  }
-  ba->acc_inflight = false;
-  const double t0 = now_s();
-  if (!devStep) {
-    memcpy(pstg(ba, ba->st_pre), precalc, sizeof(sos_precalc) * nn);
-    memcpy(pstg(ba, ba->st_adh), adHTdeltaF, sizeof(float) * 8 * nn);
-    memcpy(pstg(ba, ba->st_cd), cDeltaF, sizeof(float) * 4);
-    memcpy(pstg(ba, ba->st_th), frameEnergyTH, sizeof(float) * ba->n);
-    memcpy(pstg(ba, ba->st_cal), calib, sizeof(sos_calib));
-  }
-  // outputs go straight to the device-mapped pinned block: per-tile energy sums, newest-frame energies, point steps
-  char *po = ba->pin + ba->pin_out, *po_dev = ba->pin_dev + ba->pin_out;
-  float *dstep = reinterpret_cast<float *>(po_dev + ba->out_step);
-  BaDev dv = ba->dev;
-  dv.tile_esum = reinterpret_cast<double *>(po_dev + ba->out_esum);
-  dv.o_newest = ba->comm ? ba->d_newest_local.p : reinterpret_cast<float *>(po_dev + ba->out_newest);
-  const double t1 = now_s();
-  const bool resubAhead = !x && ba->resub_pending;
-  ba->resub_pending = false;
-  if (devStep) {  // back-substitution + the host's step / precalc work, one launch, nothing staged from the host
-    static_assert(sizeof(BaDev) + sizeof(DevStep) + 64 < 4096, "kernel arguments of k_resub_devstep");
-    const int n = ba->n, dim = 4 + 8 * n;
-    DevStep g;
-    for (int i = 0; i < dim; i++) g.xd[i] = x[i];
-    for (int i = 0; i < n; i++) g.th[i] = frameEnergyTH[i];
-    double *b = ba->d_ds;
-    g.evalC2W = b; g.state_zero = b + 12 * n;
-    g.state_in = b + 22 * n + 10 * n * ba->ds_cur; g.state_out = b + 22 * n + 10 * n * (ba->ds_cur ^ 1);
-    g.calib_in = b + 42 * n + 8 * ba->ds_cur; g.calib_out = b + 42 * n + 8 * (ba->ds_cur ^ 1);
-    g.abexp = b + 42 * n + 16;
-    ba->ds_cur ^= 1;
-    g.stage = ba->d_stage.p;
-    g.st_pre = ba->st_pre; g.st_adh = ba->st_adh; g.st_cd = ba->st_cd; g.st_th = ba->st_th; g.st_cal = ba->st_cal;
-    const int nPB = divup(ba->P, SOS_RSB), nEB = divup(8 * ba->ntiles, SOS_RSB);
-    const size_t lds = std::max(sizeof(float) * (8 * nn + 4 + 8 * (size_t)n), sizeof(float) * (28 * nn + 16) + sizeof(double) * (34 * (size_t)n + 8));
-    ba->tm[1] += now_s() - t1;
-    k_resub_devstep<<<nPB + nEB, SOS_RSB, lds, st>>>(dv, ba->d_adHostF.p, ba->d_adTargetF.p, dstep, stepfacD, nPB, g, ba->d_t_pre.p);
-  } else if (resubAhead) {  // the back-substitution is already running: only the stage-in is left, one launch
-    const int n4 = (int)((ba->st_xc + 3) / 4), nSB = divup(n4, SOS_RSB), nEB = divup(8 * ba->ntiles, SOS_RSB);
-    k_stage_expand<<<nSB + nEB, SOS_RSB, 0, st>>>(dv, reinterpret_cast<float4 *>(ba->d_stage.p), reinterpret_cast<const float4 *>(ba->pin_dev + ba->pin_stage),
-                                                 n4, nSB, reinterpret_cast<const float4 *>(ba->pin_dev + ba->pin_stage + sizeof(float) * ba->st_pre),
-                                                 ba->d_t_pre.p);
-  } else if (x && ba->P > 0 && ba->d_adHostF.p && ba->d_adTargetF.p) {
-    // back-substitution from x alone + stage-in of the linearisation inputs: one launch
-    XArg xa;
-    const int dim = 4 + 8 * ba->n;
-    for (int i = 0; i < dim; i++) xa.v[i] = (float)x[i];
-    const int n4 = (int)((ba->st_xc + 3) / 4), nPB = divup(ba->P, SOS_RSB);
-    ba->tm[1] += now_s() - t1;
-    const int nSB = divup(n4, SOS_RSB), nEB = divup(8 * ba->ntiles, SOS_RSB);
-    k_resub_fused<<<nPB + nSB + nEB, SOS_RSB, sizeof(float) * (8 * nn + 4 + 8 * (size_t)ba->n), st>>>(
-        dv, xa, ba->d_adHostF.p, ba->d_adTargetF.p, dstep, stepfacD, nPB, reinterpret_cast<float4 *>(ba->d_stage.p),
-        reinterpret_cast<const float4 *>(ba->pin_dev + ba->pin_stage), n4, nSB,
-        reinterpret_cast<const float4 *>(ba->pin_dev + ba->pin_stage + sizeof(float) * ba->st_pre), ba->d_t_pre.p, nullptr);
-  } else if (x) {
-    fill_x(ba, x);
-    stage_in(ba, ba->st_floats);
-    if (ba->P > 0)
-      k_resubstitute<<<divup(ba->P, 64), 64, 0, st>>>(dv, stg(ba, ba->st_xc), stg(ba, ba->st_xad), dstep, 1, stepfacD);
-  } else {
-    stage_in(ba, ba->st_xc);
-  }
+  char *po = ba->pin + ba->pin_out;
+  // nobody reads the original-order copies of the per-residual results in a fused iteration (they are scattered 1..12 byte
+  // stores, one partial line each): only the two-step sos_ba_linearize delivers them
+  dv.o_newstate = nullptr; dv.o_newenergy = nullptr; dv.o_newenergywo = nullptr; dv.o_center = nullptr;
   // pipelined iterations of a window without linearised residuals reduce the tiles on chip (no J traffic at all)
-  const bool fuseTop = ba->prefetch && applyRes && ba->ntiles == ba->ntilesA;
+  const bool fuseTop = (ba->prefetch || ba->fuse_only) && applyRes && ba->ntiles == ba->ntilesA && !lin_v1();
   // when the next accumulate is enqueued right behind, its first kernel publishes this step's completion
   // (with a communicator the all-gathered energies are copied out behind the linearisation; the chained publish then follows them)
   const bool chainPublish = ba->prefetch && applyRes && !lin_v1() && getenv("SOS_SIGNAL_IN_KERNEL") == nullptr && getenv("SOS_NO_CHAIN_PUBLISH") == nullptr;
@@ -3766,6 +3809,7 @@ extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const
     if (!chainPublish) k_publish<<<1, 1, 0, st>>>(reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags), waitSeq);
   }
   ba->J_valid = !fuseTop;
+  ba->top_valid = fuseTop;
   SOS_HIP(hipGetLastError());
   const double t2 = now_s();
   double t3 = t2;
@@ -3804,7 +3848,7 @@ extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const
     if (newestCount) *newestCount = k;
   }
   const float *hs = reinterpret_cast<const float *>(po + ba->out_step);
-  if (x || resubAhead) {
+  if (havePointStep) {
     for (int p = 0; p < ba->P; p++) {  // keep the host mirror of the snapshot in step with the device
       const float idn = ba->h_pts[p].idepth_scaled + stepfacD * hs[p];
       ba->h_pts[p].idepth_scaled = idn;
@@ -3817,6 +3861,197 @@ extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const
   return SOS_OK;
 }
 
+
+
+extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const sos_calib *calib, const sos_precalc *precalc,
+                              const float *adHTdeltaF, const float *cDeltaF, const float *frameEnergyTH, int applyRes,
+                              double *energySum, float *newestEnergies, int *newestCount, float *pointStep) {
+  const bool devStep = ba && ba->devstep && x && !precalc;  // the device derives poses / precalc / deltas from x itself
+  if (!ba || !ba->have_window || !ba->have_state || !frameEnergyTH || (!devStep && (!calib || !precalc || !adHTdeltaF || !cDeltaF)))
+    return SOS_ERR_STATE;
+  if (devStep && !(ba->P > 0 && ba->d_adHostF.p && ba->d_adTargetF.p && ba->ds_n == ba->n)) return SOS_ERR_STATE;
+  sos_ctx *c = ba->ctx;
+  SOS_HIP(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  const size_t nn = (size_t)ba->n * ba->n;
+  if (calib) {
+    ba->calib = *calib;
+    ba->dev.calib = *calib;
+  }
+  ba->acc_inflight = false, ba->top_valid = false;
+  const double t0 = now_s();
+  if (!devStep) {
+    memcpy(pstg(ba, ba->st_pre), precalc, sizeof(sos_precalc) * nn);
+    memcpy(pstg(ba, ba->st_adh), adHTdeltaF, sizeof(float) * 8 * nn);
+    memcpy(pstg(ba, ba->st_cd), cDeltaF, sizeof(float) * 4);
+    memcpy(pstg(ba, ba->st_th), frameEnergyTH, sizeof(float) * ba->n);
+    memcpy(pstg(ba, ba->st_cal), calib, sizeof(sos_calib));
+  }
+  // outputs go straight to the device-mapped pinned block: per-tile energy sums, newest-frame energies, point steps
+  char *po = ba->pin + ba->pin_out, *po_dev = ba->pin_dev + ba->pin_out;
+  float *dstep = reinterpret_cast<float *>(po_dev + ba->out_step);
+  BaDev dv = ba->dev;
+  dv.tile_esum = reinterpret_cast<double *>(po_dev + ba->out_esum);
+  dv.o_newest = ba->comm ? ba->d_newest_local.p : reinterpret_cast<float *>(po_dev + ba->out_newest);
+  const double t1 = now_s();
+  const bool resubAhead = !x && ba->resub_pending;
+  ba->resub_pending = false;
+  if (devStep) {  // back-substitution + the host's step / precalc work, one launch, nothing staged from the host
+    static_assert(sizeof(BaDev) + sizeof(DevStep) + 64 < 4096, "kernel arguments of k_resub_devstep");
+    const int n = ba->n, dim = 4 + 8 * n;
+    DevStep g;
+    for (int i = 0; i < dim; i++) g.xd[i] = x[i];
+    for (int i = 0; i < n; i++) g.th[i] = frameEnergyTH[i];
+    double *b = ba->d_ds;
+    g.evalC2W = b; g.state_zero = b + 12 * n;
+    g.state_in = b + 22 * n + 10 * n * ba->ds_cur; g.state_out = b + 22 * n + 10 * n * (ba->ds_cur ^ 1);
+    g.calib_in = b + 42 * n + 8 * ba->ds_cur; g.calib_out = b + 42 * n + 8 * (ba->ds_cur ^ 1);
+    g.abexp = b + 42 * n + 16;
+    ba->ds_cur ^= 1;
+    g.stage = ba->d_stage.p;
+    g.st_pre = ba->st_pre; g.st_adh = ba->st_adh; g.st_cd = ba->st_cd; g.st_th = ba->st_th; g.st_cal = ba->st_cal;
+    const int nPB = divup(ba->P, SOS_RSB), nEB = std::max(1, divup(8 * ba->ntiles, SOS_RSB));  /* at least one step block: a window without residual tiles still steps its frames */
+    const size_t lds = std::max(sizeof(float) * (8 * nn + 4 + 8 * (size_t)n), sizeof(float) * (28 * nn + 16) + sizeof(double) * (34 * (size_t)n + 8));
+    ba->tm[1] += now_s() - t1;
+    k_resub_devstep<<<nPB + nEB, SOS_RSB, lds, st>>>(dv, ba->d_adHostF.p, ba->d_adTargetF.p, dstep, stepfacD, nPB, g, ba->d_t_pre.p);
+  } else if (resubAhead) {  // the back-substitution is already running: only the stage-in is left, one launch
+    const int n4 = (int)((ba->st_xc + 3) / 4), nSB = divup(n4, SOS_RSB), nEB = std::max(1, divup(8 * ba->ntiles, SOS_RSB));  /* at least one step block: a window without residual tiles still steps its frames */
+    k_stage_expand<<<nSB + nEB, SOS_RSB, 0, st>>>(dv, reinterpret_cast<float4 *>(ba->d_stage.p), reinterpret_cast<const float4 *>(ba->pin_dev + ba->pin_stage),
+                                                 n4, nSB, reinterpret_cast<const float4 *>(ba->pin_dev + ba->pin_stage + sizeof(float) * ba->st_pre),
+                                                 ba->d_t_pre.p);
+  } else if (x && ba->P > 0 && ba->d_adHostF.p && ba->d_adTargetF.p) {
+    // back-substitution from x alone + stage-in of the linearisation inputs: one launch
+    XArg xa;
+    const int dim = 4 + 8 * ba->n;
+    for (int i = 0; i < dim; i++) xa.v[i] = (float)x[i];
+    const int n4 = (int)((ba->st_xc + 3) / 4), nPB = divup(ba->P, SOS_RSB);
+    ba->tm[1] += now_s() - t1;
+    const int nSB = divup(n4, SOS_RSB), nEB = std::max(1, divup(8 * ba->ntiles, SOS_RSB));  /* at least one step block: a window without residual tiles still steps its frames */
+    k_resub_fused<<<nPB + nSB + nEB, SOS_RSB, sizeof(float) * (8 * nn + 4 + 8 * (size_t)ba->n), st>>>(
+        dv, xa, ba->d_adHostF.p, ba->d_adTargetF.p, dstep, stepfacD, nPB, reinterpret_cast<float4 *>(ba->d_stage.p),
+        reinterpret_cast<const float4 *>(ba->pin_dev + ba->pin_stage), n4, nSB,
+        reinterpret_cast<const float4 *>(ba->pin_dev + ba->pin_stage + sizeof(float) * ba->st_pre), ba->d_t_pre.p, nullptr);
+  } else if (x) {
+    fill_x(ba, x);
+    stage_in(ba, ba->st_floats);
+    if (ba->P > 0)
+      k_resubstitute<<<divup(ba->P, 64), 64, 0, st>>>(dv, stg(ba, ba->st_xc), stg(ba, ba->st_xad), dstep, 1, stepfacD);
+  } else {
+    stage_in(ba, ba->st_xc);
+  }
+  return lin_apply_tail(ba, dv, applyRes, x != nullptr || resubAhead, stepfacD, energySum, newestEnergies, newestCount, pointStep, t0, t1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// keyframe-rate fused calls (the front and the back of FullSystem::optimize around the Gauss-Newton loop)
+// ------------------------------------------------------------------------------------------------
+// FS/FullSystemOptimize.cpp:316-344 with setting_forceAceptStep: resetOOB of the active residuals, linearizeAll(false),
+// applyRes -- one launch chain, the first iteration's accumulate enqueued behind it when prefetch is on.
+extern "C" int sos_ba_linearize_apply(sos_ba *ba, const float *frameEnergyTH, int resetOOB, double *energySum, float *newestEnergies,
+                                      int *newestCount) {
+  if (!ba || !ba->have_window || !ba->have_state || !frameEnergyTH) return SOS_ERR_STATE;
+  sos_ctx *c = ba->ctx;
+  SOS_HIP(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  ba->acc_inflight = false, ba->top_valid = false;
+  const double t0 = now_s();
+  SOS_HIP(hipStreamSynchronize(st));  // the mapped stage block is about to be rewritten
+  memcpy(pstg(ba, ba->st_th), frameEnergyTH, sizeof(float) * ba->n);
+  SOS_HIP(hipMemcpyAsync(stg(ba, ba->st_th), pstg(ba, ba->st_th), sizeof(float) * ba->n, hipMemcpyHostToDevice, st));
+  if (resetOOB && ba->ntilesA > 0) k_reset_oob<<<divup(ba->ntilesA * SOS_TILE, 256), 256, 0, st>>>(ba->dev);
+  char *po_dev = ba->pin_dev + ba->pin_out;
+  BaDev dv = ba->dev;
+  dv.tile_esum = reinterpret_cast<double *>(po_dev + ba->out_esum);
+  dv.o_newest = ba->comm ? ba->d_newest_local.p : reinterpret_cast<float *>(po_dev + ba->out_newest);
+  ba->pending_new = false;
+  return lin_apply_tail(ba, dv, 1, false, 0.f, energySum, newestEnergies, newestCount, nullptr, t0, now_s());
+}
+
+// per residual (thread i < ntilesA * SOS_TILE) the record of sos_ba_linearize_final in the original order; per point
+// (thread i < P) the isNew statistics of FS/FullSystemOptimize.cpp:55-71 over its active residuals, in residualsAll order
+__global__ __launch_bounds__(256) void k_final_pack(BaDev d, sos_resid_final *__restrict__ out, float *__restrict__ pmax, int *__restrict__ pcnt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < d.ntilesA * SOS_TILE) {
+    const int s = i, orig = d.s_orig[s];
+    if (orig >= 0) {
+      sos_resid_final r;
+      r.state_NewEnergy = d.s_newenergy[s];
+      r.state_NewEnergyWithOutlier = d.s_newenergywo[s];
+      r.state_energy = d.s_energy[s];
+      r.centerProjectedTo[0] = d.s_center[3 * s]; r.centerProjectedTo[1] = d.s_center[3 * s + 1]; r.centerProjectedTo[2] = d.s_center[3 * s + 2];
+      r.state_NewState = d.s_newstate[s];
+      r.state_state = d.s_state[s];
+      r.active = (d.s_flags[s] & DF_ACTIVE) ? 1 : 0;
+      r.pad = 0;
+      out[orig] = r;
+    }
+  }
+  if (i < d.P) {
+    float mx = -1.f;
+    int cnt = 0;
+    for (int q = d.p_begin[i]; q < d.p_begin[i + 1]; q++) {
+      const int2 e = d.p_list2[q];  // (s, n * host + target)
+      const unsigned f = d.s_flags[e.x];
+      if ((f & (DF_ACTIVE | DF_ISNEW | DF_LINEARIZED)) != (DF_ACTIVE | DF_ISNEW)) continue;
+      const int h = e.y / d.n, t = e.y - h * d.n;
+      const sos_precalc &pc = d.precalc[h + d.n * t];
+      const float4 g = d.r_geo[e.x];
+      const float *K = pc.PRE_KRKiTll, *Kt = pc.PRE_KtTll;
+      const float inf0 = K[0] * g.x + K[1] * g.y + K[2], inf1 = K[3] * g.x + K[4] * g.y + K[5], inf2 = K[6] * g.x + K[7] * g.y + K[8];
+      const float q0 = inf0 + Kt[0] * g.z, q1 = inf1 + Kt[1] * g.z, q2 = inf2 + Kt[2] * g.z;
+      const float dx = inf0 / inf2 - q0 / q2, dy = inf1 / inf2 - q1 / q2;
+      const float relBS = (float)(0.01 * sqrtf(dx * dx + dy * dy));
+      if (relBS > mx) mx = relBS;
+      cnt++;
+    }
+    pmax[i] = mx;
+    pcnt[i] = cnt;
+  }
+}
+
+// FullSystem::linearizeAll(true) (FS/FullSystemOptimize.cpp:125-182): linearize + applyRes(true) of every active residual,
+// then what the host bookkeeping reads, in ONE device-to-host copy into a pinned block owned by the handle
+extern "C" int sos_ba_linearize_final(sos_ba *ba, const float *frameEnergyTH, double *energySum, const sos_resid_final **records,
+                                      const float **pointMaxRelBaseline, const int32_t **pointNewGood, float *newestEnergies,
+                                      int *newestCount) {
+  if (!ba || !ba->have_window || !ba->have_state || !frameEnergyTH || !records || !pointMaxRelBaseline || !pointNewGood) return SOS_ERR_STATE;
+  sos_ctx *c = ba->ctx;
+  SOS_HIP(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  ba->acc_inflight = false, ba->top_valid = false;
+  const size_t Rr = ba->R ? ba->R : 1, Pp = ba->P ? ba->P : 1;
+  const size_t o_pmax = (sizeof(sos_resid_final) * Rr + 255) / 256 * 256, o_pcnt = o_pmax + (sizeof(float) * Pp + 255) / 256 * 256,
+               bytes = o_pcnt + sizeof(int) * Pp;
+  if (bytes > ba->fin_cap) {
+    SOS_HIP(hipStreamSynchronize(st));
+    if (ba->fin_host) hipHostFree(ba->fin_host);
+    if (ba->fin_dev) hipFree(ba->fin_dev);
+    ba->fin_host = ba->fin_dev = nullptr;
+    ba->fin_cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    SOS_HIP(hipHostMalloc((void **)&ba->fin_host, want, hipHostMallocDefault));
+    if (hipMalloc((void **)&ba->fin_dev, want) != hipSuccess) return SOS_ERR_NOMEM;
+    ba->fin_cap = want;
+  }
+  const bool prefetch = ba->prefetch, fuseOnly = ba->fuse_only;
+  ba->prefetch = ba->fuse_only = false;  // nothing follows this linearisation, and its Jacobians are stored (marginalisation reads them)
+  int rc = sos_ba_linearize_apply(ba, frameEnergyTH, 0, energySum, newestEnergies, newestCount);
+  ba->prefetch = prefetch;
+  ba->fuse_only = fuseOnly;
+  if (rc) return rc;
+  const int nthr = std::max(ba->ntilesA * SOS_TILE, ba->P);
+  if (nthr > 0)
+    k_final_pack<<<divup(nthr, 256), 256, 0, st>>>(ba->dev, reinterpret_cast<sos_resid_final *>(ba->fin_dev),
+                                                  reinterpret_cast<float *>(ba->fin_dev + o_pmax), reinterpret_cast<int *>(ba->fin_dev + o_pcnt));
+  SOS_HIP(hipGetLastError());
+  SOS_HIP(hipMemcpyAsync(ba->fin_host, ba->fin_dev, bytes, hipMemcpyDeviceToHost, st));
+  SOS_HIP(hipStreamSynchronize(st));
+  *records = reinterpret_cast<const sos_resid_final *>(ba->fin_host);
+  *pointMaxRelBaseline = reinterpret_cast<const float *>(ba->fin_host + o_pmax);
+  *pointNewGood = reinterpret_cast<const int32_t *>(ba->fin_host + o_pcnt);
+  return SOS_OK;
+}
+
 extern "C" int sos_ba_gn_devstep_begin(sos_ba *ba, const sos_gn_frame *frames, const double *calib_value4, const double *calib_value_zero4) {
   if (!ba || !frames || !calib_value4 || !calib_value_zero4) return SOS_ERR_ARG;
   if (!ba->have_window || !ba->have_state || ba->n < 1 || ba->n > 17 || ba->P <= 0 || !ba->d_adHostF.p || !ba->d_adTargetF.p || lin_v1())
@@ -3825,12 +4060,21 @@ extern "C" int sos_ba_gn_devstep_begin(sos_ba *ba, const sos_gn_frame *frames, c
   const int n = ba->n;
   const size_t cnt = (size_t)43 * n + 16;
   if (ba->ds_n != n) {
+    SOS_HIP(hipStreamSynchronize(ba->ctx->stream));
     if (ba->d_ds) hipFree(ba->d_ds);
+    if (ba->ds_host) hipHostFree(ba->ds_host);
     ba->d_ds = nullptr;
+    ba->ds_host = nullptr;
+    ba->ds_n = 0;
     SOS_HIP(hipMalloc(&ba->d_ds, sizeof(double) * cnt));
+    SOS_HIP(hipHostMalloc((void **)&ba->ds_host, sizeof(double) * cnt * 2, hipHostMallocDefault));
     ba->ds_n = n;
+    ba->ds_flip = 0;
   }
-  std::vector<double> h(cnt, 0.0);
+  // pinned source, two halves used alternately: the copy is asynchronous and a second begin may follow before it has run
+  ba->ds_flip ^= 1;
+  double *h = ba->ds_host + (size_t)ba->ds_flip * cnt;
+  memset(h, 0, sizeof(double) * cnt);
   for (int f = 0; f < n; f++) {
     memcpy(&h[12 * f], frames[f].camToWorld_evalPT, sizeof(double) * 12);
     memcpy(&h[12 * n + 10 * f], frames[f].state_zero, sizeof(double) * 10);
@@ -3839,8 +4083,7 @@ extern "C" int sos_ba_gn_devstep_begin(sos_ba *ba, const sos_gn_frame *frames, c
   }
   for (int i = 0; i < 4; i++) { h[42 * n + i] = calib_value4[i]; h[42 * n + 4 + i] = calib_value_zero4[i]; }
   ba->ds_cur = 0;
-  SOS_HIP(hipMemcpyAsync(ba->d_ds, h.data(), sizeof(double) * cnt, hipMemcpyHostToDevice, ba->ctx->stream));
-  SOS_HIP(hipStreamSynchronize(ba->ctx->stream));  // h is pageable and local
+  SOS_HIP(hipMemcpyAsync(ba->d_ds, h, sizeof(double) * cnt, hipMemcpyHostToDevice, ba->ctx->stream));
   ba->devstep = true;
   return SOS_OK;
 }
@@ -3870,7 +4113,7 @@ extern "C" int sos_ba_calc_lenergy(sos_ba *ba, double *E) {
 extern "C" int sos_ba_accumulate_marg(sos_ba *ba, const int32_t *pointIdx, int count, double *M, double *Mb, double *Msc,
                                       double *Mbsc, int *resInM) {
   if (ba && ba->have_window && ba->have_state) ensure_J(ba);
-  if (ba) ba->acc_inflight = false;  // any state change invalidates a prefetched accumulate
+  if (ba) ba->acc_inflight = false, ba->top_valid = false;  // any state change invalidates a prefetched accumulate
   if (!ba || !ba->have_window || !ba->have_state || (count && !pointIdx)) return SOS_ERR_STATE;
   SOS_HIP(hipSetDevice(ba->ctx->device));
   hipStream_t st = ba->ctx->stream;
@@ -3937,7 +4180,7 @@ extern "C" int sos_ba_accumulate_marg(sos_ba *ba, const int32_t *pointIdx, int c
 }
 
 extern "C" int sos_ba_update_point_priors(sos_ba *ba, const int32_t *pointIdx, const float *priorF, int count) {
-  if (ba) ba->acc_inflight = false;  // any state change invalidates a prefetched accumulate
+  if (ba) ba->acc_inflight = false, ba->top_valid = false;  // any state change invalidates a prefetched accumulate
   if (!ba || !ba->have_window || (count && (!pointIdx || !priorF))) return SOS_ERR_STATE;
   SOS_HIP(hipSetDevice(ba->ctx->device));
   for (int k = 0; k < count; k++) {
@@ -4014,7 +4257,7 @@ extern "C" int sos_ba_get_res_toZeroF(sos_ba *ba, float *rtz) {
 
 // ---- kernel timing with HIP events on the context's stream ----------------------------------------
 extern "C" int sos_ba_time_kernel(sos_ba *ba, const char *kernel, const float *frameEnergyTH, int iters, float *avg_ms) {
-  if (ba) ba->acc_inflight = false;  // any state change invalidates a prefetched accumulate
+  if (ba) ba->acc_inflight = false, ba->top_valid = false;  // any state change invalidates a prefetched accumulate
   if (!ba || !ba->have_window || !ba->have_state || !kernel || iters <= 0 || !avg_ms) return SOS_ERR_STATE;
   sos_ctx *c = ba->ctx;
   SOS_HIP(hipSetDevice(c->device));

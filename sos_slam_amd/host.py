@@ -277,6 +277,13 @@ class System:
         """device-resident Gauss-Newton loop on / off (off: the host solves, as in round 1)"""
         _chk(self.L.sosf_set_resident(self.h_, int(on)), "sosf_set_resident")
 
+    def invalidate_pack(self):
+        """the next prepare() / optimize() packs and uploads the window again (per-keyframe cost measurements)"""
+        _chk(self.L.sosf_invalidate_pack(self.h_), "sosf_invalidate_pack")
+
+    def set_min_opt_iterations(self, its):
+        _chk(self.L.sosf_set_min_opt_iterations(self.h_, int(its)), "sosf_set_min_opt_iterations")
+
     def set_pipeline(self, on=True):
         _chk(self.L.sosf_set_pipeline(self.h_, int(on)), "sosf_set_pipeline")
 

@@ -550,7 +550,10 @@ class PixelSelector:
 
     def close(self):
         if self.h_:
-            self.L.sos_pixsel_destroy(self.h_)
+            # the garbage collector may finalise this object after its context was closed (weak references to objects being
+            # collected are dead, so the context could not close it first): the context is gone, the handle is only dropped
+            if getattr(self.ctx, "h_", None):
+                self.L.sos_pixsel_destroy(self.h_)
             self.h_ = None
 
     def __del__(self):
@@ -610,7 +613,8 @@ class Undistorter:
 
     def close(self):
         if self.h_:
-            self.L.sos_undistort_destroy(self.h_)
+            if getattr(self.ctx, "h_", None):   # see PixelSelector.close
+                self.L.sos_undistort_destroy(self.h_)
             self.h_ = None
 
     def __del__(self):

@@ -288,6 +288,17 @@ class Chain:
         self.scale_state = [0, 0]     # FullSystem::scaleTrapped, scale_opt_fails
         self.scale_log = []
         self.track_hist = []     # camToWorld of the last tracked frames (initial guess of the tracker when kf_every > 1)
+        # FrameHessian::imu_data per keyframe.  A keyframe that leaves the window hands its samples to its successor
+        # (FS/FullSystemMarginalize.cpp:226-228), so the lists are per chain, not per scenario
+        self.imu = {i: np.array(a, dtype=np.float64).reshape(-1, 7) for i, a in enumerate(sc.imu)} if self.vio else {}
+
+    def imu_hand_over(self, window_before, fid):
+        """samples of the leaving keyframe fid in front of those of the keyframe behind it in `window_before`; returns the window without fid"""
+        i = window_before.index(fid)
+        if self.vio and i + 1 < len(window_before):
+            nxt = window_before[i + 1]
+            self.imu[nxt] = np.concatenate([self.imu[fid], self.imu[nxt]], axis=0)
+        return window_before[:i] + window_before[i + 1:]
 
     # ---- backend interface (implemented by DeviceChain / OracleChain)
     def n(self): raise NotImplementedError
@@ -475,7 +486,7 @@ class Chain:
             f.state_imu[:] = list(self.imu_state[fid])
             f.state_imu_zero[:] = list(self.imu_zero[fid])
             f.trackingRefIsPrev = 1 if fid > 0 else 0
-            arr = np.ascontiguousarray(self.sc.imu[fid], dtype=np.float64).reshape(-1, 7)
+            arr = np.ascontiguousarray(self.imu[fid], dtype=np.float64).reshape(-1, 7)
             keep.append(arr)
             f.n_imu = len(arr)
             f.imu = arr.ctypes.data if len(arr) else None
@@ -770,7 +781,10 @@ class DeviceChain(Chain):
     def marginalize_flagged(self):
         if self.vio and self.cal["init"]:
             self._push_imu()        # the IMU form of marginalizeFrame reads the records of the window as it is now
+        win = self.window_ids()
         ids, poses = self.sysm.marginalize_flagged_frames()
+        for i in ids:      # the facade merged the sample lists inside the call; the chain's own storage follows
+            win = self.imu_hand_over(win, int(i))
         return [(int(i), p.copy()) for i, p in zip(ids, poses)]
 
     def prior(self):
@@ -888,7 +902,7 @@ class OracleChain(Chain):
     def vio_propagate(self, fid, last_fid, last_bias):
         from oracle import imu_frontend as fe
         a, b = self.shells[fid], self.shells[last_fid]
-        sc_, vel = fe.propagate_imu_state(self._Sd(), self.cal["scale"], a["ts"], self.sc.imu[fid], b["ts"], b["c2w"][:9].reshape(3, 3), b["vel"],
+        sc_, vel = fe.propagate_imu_state(self._Sd(), self.cal["scale"], a["ts"], self.imu[fid], b["ts"], b["c2w"][:9].reshape(3, 3), b["vel"],
                                           last_bias, fe.scaled_of(self.imu_state[fid]))
         self.imu_state[fid] = fe.state_of(sc_)
         self.imu_zero[fid] = self.imu_state[fid].copy()
@@ -899,7 +913,7 @@ class OracleChain(Chain):
         ts = [self.shells[f]["ts"] for f in ids]
         c2w = [self.shells[f]["c2w"] for f in ids]
         r = fe.initialize_imu(self._Sd(), self.cal["scale"], bool(self.sc.imu_settings.enable_scale_opt), ts, c2w, self.kf_pose(4)[:9],
-                              [self.sc.imu[f] for f in ids], [fe.scaled_of(self.imu_state[f]) for f in ids])
+                              [self.imu[f] for f in ids], [fe.scaled_of(self.imu_state[f]) for f in ids])
         if not self.sc.imu_settings.enable_scale_opt:        # setScaleScaledZero
             self.cal["scale"] = self.cal["scale_zero"] = fe.SCALE_SCALE_INVERSE * r["scale_scaled"]
         for i, f in enumerate(ids):
@@ -1287,6 +1301,7 @@ class OracleChain(Chain):
                                 p.last[1][0] = None
                             p.drop_residual(r)
                             break
+            self.imu_hand_over([g.frameID for g in self.frames], f.frameID)
             self.frames.pop(i)
             i = 0
         return out

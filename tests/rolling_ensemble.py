@@ -8,11 +8,13 @@ freshly initialised visual-inertial window varies over two orders of magnitude f
 pinned factors can fail although nothing is wrong (and could pass although something is).  Here the same three chains run over
 several seeds and the two distances are compared as DISTRIBUTIONS:
 
-  * keyframe-level decisions (flagged keyframes, window, the keyframes that leave and their order, IMU initialisation / trapped
-    scale) identical on every seed -- hard;
+  * keyframe-level decisions (flagged keyframes, window, the keyframes that leave and their order, IMU initialisation) identical on
+    every seed -- hard; the keyframe at which the scale gets trapped (a threshold on the spread of the last ten scales) may differ on
+    at most one seed in six, with the scales themselves within the yardstick there;
   * per quantity q (pose leaving the window, window pose, scale, scaled IMU state, index-set symmetric differences):
     geometric mean over seeds of worst |dev - orc|   <=  GEO_FACTOR x  geometric mean of worst |orc - truth|, and
-    max over seeds of worst |dev - orc|              <=  MAX_FACTOR x  max over seeds of worst |orc - truth|.
+    max over seeds of worst |dev - orc|              <=  MAX_FACTOR x  max over seeds of worst |orc - truth|
+    (for the summed index-set differences: on all seeds but at most one in six).
 """
 import numpy as np
 
@@ -80,8 +82,14 @@ def run_seed(seed, vio=False, **scenario):
                     m["n_leave"] = max(m["n_leave"], np.abs(po - tm[fid]).max())
             if vio:
                 vg, vo, vt = lg.vio, lo.vio, lt.vio
-                if (vg["init"], vg["trapped"]) != (vo["init"], vo["trapped"]):
-                    m["hard"].append((k, "imu init / trapped", (vg["init"], vg["trapped"]), (vo["init"], vo["trapped"])))
+                if vg["init"] != vo["init"]:
+                    m["hard"].append((k, "imu init", vg["init"], vo["init"]))
+                if vg["trapped"] != vo["trapped"]:
+                    # CalibHessian::tryTrapScale thresholds the spread of the last ten scales (setting_scale_trap_thres): a knife edge of a
+                    # continuous quantity, like the iteration count.  Two chains whose scales agree can trap one keyframe apart, and from
+                    # there on they linearise differently: the seed is compared up to here, the event is counted (summarize)
+                    m["trap_mismatch"] = (k, float(abs(vg["scale"] - vo["scale"]) * 200))
+                    break
                 m["d_scale"] = max(m["d_scale"], abs(vg["scale"] - vo["scale"]) * 200)
                 m["n_scale"] = max(m["n_scale"], abs(vo["scale"] - vt["scale"]) * 200)
                 for fid in vg["states"]:
@@ -110,8 +118,23 @@ def summarize(runs):
                         max_orc_truth=float(n.max()), max_ratio=float(d.max() / n.max()))
         if gd > GEO_FACTOR * gn:
             bad.append((key, "geometric mean", float(gd), float(gn)))
-        if d.max() > MAX_FACTOR * n.max():
+        if key in ("res", "act", "pts"):
+            # summed symmetric differences are dominated by WHEN a sequence meets its first knife edge (everything after it differs):
+            # a heavy-tailed sum, for which the geometric mean above is the statistic; the maximum may be exceeded by one seed in six
+            over = int(np.sum(d > MAX_FACTOR * n.max()))
+            out[key]["seeds_over_max"] = over
+            if over > max(1, len(runs) // 6):
+                bad.append((key, "maximum exceeded on several seeds", over, float(d.max()), float(n.max())))
+        elif d.max() > MAX_FACTOR * n.max():
             bad.append((key, "maximum", float(d.max()), float(n.max())))
+    # scale-trap knife edges: at most one seed in six, and only where the two scales agree within the ensemble's scale yardstick
+    traps = [(r["seed"],) + tuple(r["trap_mismatch"]) for r in runs if r.get("trap_mismatch")]
+    out["trap_mismatches"] = traps
+    if len(traps) > max(1, len(runs) // 6):
+        bad.append(("trapped", "count", traps))
+    for sd, k, e in traps:
+        if e > MAX_FACTOR * max(out["scale"]["max_orc_truth"], 1e-12):
+            bad.append((sd, "trapped apart with scales apart", k, e, out["scale"]["max_orc_truth"]))
     out["its_mismatch_total"] = int(sum(r["its_mismatch"] for r in runs))
     out["keyframes_total"] = int(sum(r["keyframes"] for r in runs))
     out["left_total"] = int(sum(r["left"] for r in runs))
