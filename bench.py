@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--inner", type=int, default=0, help="GN iterations per timed step (0 = enough for a ~1 s region)")
     ap.add_argument("--resident", action="store_true",
                     help="device-resident Gauss-Newton loop (solve / step / precalc kernels; measured slower than the host solve)")
+    ap.add_argument("--imu", action="store_true",
+                    help="visual-inertial window (BASELINE.json configs 2-3): the IMU / spline block of solveSystemF "
+                         "(OB/EnergyFunctional.cpp:1053-1171) sits between stitch and solve on the host")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=14.0)
     a = ap.parse_args()
@@ -217,6 +220,12 @@ def main():
                 exchange = "rccl via torch.distributed hooks"
     if args.resident:
         sysm.set_resident(True)
+    imu_keep = None
+    if args.imu:   # IMU records of the window's keyframes + the prior in the expanded dimension (sosf_set_imu)
+        S_imu, cal_imu, fr_imu, keep_imu = synth.make_imu_records(win, consistent=True)
+        HMi, bMi = synth.expand_prior_imu(win)
+        sysm.set_imu(S_imu, cal_imu, fr_imu, HMi, bMi)
+        imu_keep = (S_imu, cal_imu, fr_imu, keep_imu, HMi, bMi)
     sysm.prepare()
     sysm.set_pipeline(True)  # the loop below never stops on `canbreak`: every step may prefetch the next accumulate
     R_local = win.R
@@ -295,6 +304,7 @@ def main():
                                     f"{R_local} point-residuals per GPU" if args.scaling == "weak" or world == 1 else
                                     f"{args.window} (BASELINE.json config 5): ONE window of {win.n} KF, {R_total} point-residuals, "
                                     f"{win.w}x{win.h}, points sharded over {world} GPUs ({win.P} points / {R_local} residuals on rank 0)") +
+                                   ("; visual-inertial: IMU / spline factors of every keyframe assembled and eliminated on the host inside the solve" if args.imu else "") +
                                    "; step = one Gauss-Newton iteration (accumulate A/L/SC, fp64 stitch, solve, back-substitute, "
                                    f"step, re-linearise, applyRes), timed as the mean of {inner} consecutive iterations",
                        "gn_loop": GN_LOOP_NAMES.get(loop_mode, f"mode {loop_mode}") + ("" if (loop_mode == 2) == bool(args.resident) else
@@ -308,6 +318,7 @@ def main():
                                        "packed fp32 accumulator + one all-gather of newest-frame energies per "
                                        "iteration, " + exchange)},
             "gn_iter_per_s": iters / dt,
+            "imu": bool(args.imu),
             "last_step_l2": float(np.linalg.norm(last_x)), "last_step_head": [float(v) for v in last_x[:6]],
             "exchange_allreduce_us": exchange_us,
             "linearize_point_residuals_per_s": R_local / (lin_ms * 1e-3),
@@ -347,6 +358,10 @@ def main():
         if world > 1:
             out["roofline"]["note"] += "; N > 1: rank 0's kernel on its own shard"
         out["cpu_baseline"] = None   # timed on rank 0 at N = 1 only
+        if world == 1 and not args.imu:
+            out["keyframe"] = keyframe_timing(args.window, local_rank)
+            out["optimize_ms"] = out["keyframe"]["optimize_ms"]
+            out["keyframe_ms"] = out["keyframe"]["keyframe_ms"]
         if not args.no_cpu_baseline and world == 1:
             out["tracker"] = tracker_timing(args.window, local_rank)
             out["cpu_baseline"] = cpu_baseline(win, args.cpu_seconds)
@@ -355,6 +370,50 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def keyframe_timing(window, device):
+    """What ONE keyframe pays for the backend, as opposed to the steady-state iteration above (FS/FullSystem.cpp:853-927):
+    optimize() on a freshly packed window -- pack + upload, first linearisation, the Gauss-Newton iterations until the step test
+    passes, setEvalPT, linearizeAll(true) -- then removeOutliers + setCoarseTrackingRef, flagPointsForRemoval with the point
+    marginalisation, and marginalizeFrame of the flagged keyframes.  Medians over fresh systems (the graph changes); the handles'
+    buffers are warm (one optimize() before the timed one, as in a running system)."""
+    from sos_slam_amd import host, synth
+    win = synth.make_window(window)
+    rows = []
+    for _ in range(4):
+        sysm = host.System.from_window(win, device=device)
+        ht = host.HostTracker(sysm)
+        sysm.optimize(6)
+        sysm.invalidate_pack()
+        t0 = time.perf_counter()
+        _, its = sysm.optimize(6)
+        t1 = time.perf_counter()
+        sysm.remove_outliers()
+        ht.set_ref()
+        t2 = time.perf_counter()
+        sysm.flag_frames_for_marginalization(np.zeros(win.n, np.int32))
+        nm, nd = sysm.flag_points_for_removal()
+        t3 = time.perf_counter()
+        ids, _ = sysm.marginalize_flagged_frames(cap=win.n)
+        t4 = time.perf_counter()
+        sysm.set_min_opt_iterations(6)
+        sysm.invalidate_pack()
+        t5 = time.perf_counter()
+        _, its6 = sysm.optimize(6)
+        t6 = time.perf_counter()
+        rows.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (t6 - t5) * 1e3, its, nm, nd, len(ids), its6))
+        sysm.close()
+    r = np.array([x[:5] for x in rows[1:]])
+    med = np.median(r, axis=0)
+    return {"optimize_ms": float(med[0]), "optimize_iterations": int(rows[-1][5]),
+            "remove_outliers_set_tracking_ref_ms": float(med[1]), "flag_points_marginalize_points_ms": float(med[2]),
+            "marginalize_frames_ms": float(med[3]), "keyframe_ms": float(med[:4].sum()),
+            "points_marginalized": int(rows[-1][6]), "points_dropped": int(rows[-1][7]), "frames_marginalized": int(rows[-1][8]),
+            "optimize_6_iterations_ms": float(med[4]), "optimize_6_iterations_ran": int(rows[-1][9]),
+            "note": "optimize_ms: pack + first linearisation + iterations until the step test passes + final linearizeAll(true); "
+                    "optimize_6_iterations_ms: the same on the window after the marginalisations with setting_minOptIterations = 6; "
+                    "keyframe_ms = the four stages above"}
 
 
 def tracker_timing(window, device):

@@ -11,6 +11,10 @@
 #include "../../../include/sos_slam_host.h"
 #include "sos_math.hpp"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+static inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 namespace {
 using sos::SE3;
 constexpr int CP = 4;
@@ -381,14 +385,19 @@ extern "C" int sosf_imu_solve(const sosf_imu_settings *S, const sosf_imu_calib *
                               const double *delta, double lambda, double *x, double *scale_step, double *step_imu) {
   if (!S || !C || n < 1 || !F || !H_top || !b_top || !H_sc || !b_sc || !HM || !bM || !delta || !x || !scale_step || !step_imu) return SOS_ERR_ARG;
   const int dimI = SOSF_IMU_DIM(n);
+  static const bool tmg = getenv("SOS_TIMING_IMU") != nullptr;
+  const double tA0 = tmg ? now_us() : 0;
   Assembly A = assemble(*S, *C, n, F);  // H_imu, b_imu, constraints
-  Dense Hf(dimI, dimI);
-  std::vector<double> bf(dimI, 0.0);
-  expand(n, H_top, b_top, Hf, bf);       // expandHbtoFitImu(HFinal_top, bFinal_top); += H_imu, b_imu
-  for (size_t k = 0; k < Hf.a.size(); k++) Hf.a[k] += A.H.a[k];
-  for (int k = 0; k < dimI; k++) bf[k] += A.b[k];
+  const double tA1 = tmg ? now_us() : 0;
+  // The KKT system of OB/EnergyFunctional.cpp:1062-1140 formed in ONE pass over the kept states, already Jacobi-scaled:
+  //   K = [(H_imu + expand(H_top) + HM) with the diagonal times (1 + lambda)  -  expand(H_sc) / (1 + lambda)   J^T ; J  0]
+  //   rhs = [expand(b_top) + b_imu + bM + HM d2 - expand(b_sc) ; r_cst]
+  // restricted to the constrained states (kept indices in order), without the dimI x dimI temporaries of the literal form.
+  const int d0 = CP + 8 * n;
+  auto gidx = [&](int a) { return a < CP ? a : CP + 1 + 29 * ((a - CP) / 8) + (a - CP) % 8; };  // dso index -> expanded index
   // marginalisation prior around the expanded delta
-  std::vector<double> d2(dimI, 0.0);
+  static thread_local std::vector<double> d2, bf, diagK;
+  d2.assign(dimI, 0.0);
   for (int i = 0; i < CP; i++) d2[i] = delta[i];
   if (C->scale_trapped) d2[CP] = C->scale - C->scale_zero;
   for (int i = 0; i < n; i++) {
@@ -396,43 +405,82 @@ extern "C" int sosf_imu_solve(const sosf_imu_settings *S, const sosf_imu_calib *
     if (C->scale_trapped)
       for (int k = 0; k < 21; k++) d2[CP + 1 + 29 * i + 8 + k] = F[i].state_imu[k] - F[i].state_imu_zero[k];
   }
-  for (int r = 0; r < dimI; r++) {
-    double s = bM[r];
-    for (int c = 0; c < dimI; c++) {
-      s += HM[(size_t)r * dimI + c] * d2[c];
-      Hf(r, c) += HM[(size_t)r * dimI + c];
-    }
-    bf[r] += s;
-  }
-  // Schur complement of the points
-  Dense Hs(dimI, dimI);
-  std::vector<double> bs(dimI, 0.0);
-  expand(n, H_sc, b_sc, Hs, bs);
-  for (int i = 0; i < dimI; i++) Hf(i, i) *= (1 + lambda);
-  const double f = 1.0f / (1 + lambda);
-  for (size_t k = 0; k < Hf.a.size(); k++) Hf.a[k] -= Hs.a[k] * f;
-  for (int k = 0; k < dimI; k++) bf[k] -= bs[k];
-  // KKT system with the spline constraints, then only the states that are constrained: the kept indices in order
   const int cdim = (int)A.Jrows.size();
-  std::vector<int> keep;
+  static thread_local std::vector<int> keep, pos;
+  keep.clear();
   for (int i = 0; i < CP; i++) keep.push_back(i);
   if (!S->enable_scale_opt) keep.push_back(CP);
   for (int i = 0; i < n; i++)
     for (int k = 0; k < (A.spline_valid[i] ? 29 : 14); k++) keep.push_back(CP + 1 + 29 * i + k);
   const int ms = (int)keep.size(), m = ms + cdim;
-  std::vector<double> K((size_t)m * m, 0.0), rhs(m, 0.0), sI(m), sol;
+  pos.assign(dimI, -1);
+  for (int r = 0; r < ms; r++) pos[keep[r]] = r;
+  const double f = 1.0f / (1 + lambda);
+  // right-hand side of the kept states (HM d2 runs over ALL expanded columns) and the unscaled diagonal
+  bf.assign(m, 0.0);
+  diagK.assign(m, 0.0);
   for (int r = 0; r < ms; r++) {
-    for (int c = 0; c < ms; c++) K[(size_t)r * m + c] = Hf(keep[r], keep[c]);
-    for (int k = 0; k < cdim; k++) K[(size_t)r * m + ms + k] = K[(size_t)(ms + k) * m + r] = A.Jrows[k][keep[r]];
-    rhs[r] = bf[keep[r]];
+    const int g = keep[r];
+    const double *hm = HM + (size_t)g * dimI;
+    double sv = bM[g] + A.b[g];
+    for (int c = 0; c < dimI; c++) sv += hm[c] * d2[c];
+    bf[r] = sv;
+    diagK[r] = A.H(g, g) + hm[g];
   }
-  for (int k = 0; k < cdim; k++) rhs[ms + k] = A.r[k];
-  for (int i = 0; i < m; i++) sI[i] = 1.0 / std::sqrt(K[(size_t)i * m + i] + 10);
-  for (int r = 0; r < m; r++) {
-    for (int c = 0; c < m; c++) K[(size_t)r * m + c] *= sI[r] * sI[c];
-    rhs[r] *= sI[r];
+  for (int a = 0; a < d0; a++) {
+    const int r = pos[gidx(a)];
+    if (r < 0) continue;
+    bf[r] += b_top[a] - b_sc[a];
+    diagK[r] += H_top[(size_t)a * d0 + a];
   }
-  sos::ldlt_solve_ref(K, rhs, sol, m);  // Eigen-style pivoting on the largest |diagonal|: the KKT matrix is indefinite
+  static thread_local std::vector<double> K, rhs, sI, sol;
+  K.assign((size_t)m * m, 0.0);
+  rhs.assign(m, 0.0);
+  sI.assign(m, 0.0);
+  for (int r = 0; r < ms; r++) diagK[r] *= (1 + lambda);
+  for (int a = 0; a < d0; a++) {
+    const int r = pos[gidx(a)];
+    if (r >= 0) diagK[r] -= H_sc[(size_t)a * d0 + a] * f;
+  }
+  for (int i = 0; i < m; i++) sI[i] = 1.0 / std::sqrt(diagK[i] + 10);  // multipliers: zero diagonal
+  for (int r = 0; r < ms; r++) {
+    const int g = keep[r];
+    const double *hm = HM + (size_t)g * dimI, *hi = &A.H.a[(size_t)g * dimI];
+    double *kr = &K[(size_t)r * m];
+    const double sr = sI[r];
+    for (int c = 0; c < ms; c++) {
+      const int gc = keep[c];
+      kr[c] = (hi[gc] + hm[gc]) * (sr * sI[c]);
+    }
+    rhs[r] = bf[r] * sr;
+  }
+  for (int a = 0; a < d0; a++) {  // the visual system: dense over calibration and poses
+    const int r = pos[gidx(a)];
+    if (r < 0) continue;
+    double *kr = &K[(size_t)r * m];
+    const double *ht = H_top + (size_t)a * d0, *hs = H_sc + (size_t)a * d0;
+    const double sr = sI[r];
+    for (int b2 = 0; b2 < d0; b2++) {
+      const int c = pos[gidx(b2)];
+      if (c >= 0) kr[c] += (ht[b2] - hs[b2] * f) * (sr * sI[c]);
+    }
+  }
+  for (int r = 0; r < ms; r++) K[(size_t)r * m + r] = diagK[r] * sI[r] * sI[r];  // (1 + lambda) on the whole diagonal
+  for (int k = 0; k < cdim; k++) {
+    const std::vector<double> &J = A.Jrows[k];
+    double *kk = &K[(size_t)(ms + k) * m];
+    const double sk = sI[ms + k];
+    for (int r = 0; r < ms; r++) {
+      const double v = J[keep[r]];
+      if (v != 0.0) kk[r] = K[(size_t)r * m + ms + k] = v * (sk * sI[r]);
+    }
+    rhs[ms + k] = A.r[k] * sk;
+  }
+  const double tA2 = tmg ? now_us() : 0;
+  // blocked LDL^T with threshold pivoting on the diagonal (sos_math.hpp): the KKT matrix is indefinite, but quasi-definite in the order
+  // states first, multipliers last -- the multipliers only become pivots once the states they constrain are eliminated
+  sos::ldlt_solve(K, rhs, sol, m);
+  if (tmg) fprintf(stderr, "[imu_solve] assemble %.0f us, dense build (dim %d, kkt %d) %.0f us, ldlt %.0f us\n", tA1 - tA0, dimI, m, tA2 - tA1, now_us() - tA2);
   for (int i = 0; i < m; i++) sol[i] *= sI[i];
   // split into the dso increment, the scale step and the IMU steps
   std::memset(x, 0, sizeof(double) * (CP + 8 * n));

@@ -313,3 +313,66 @@ def take_shard(win: Window, point_idx: np.ndarray) -> Window:
     resid = win.resid[keep].copy()
     resid["point"] = remap[resid["point"]]
     return dataclasses.replace(win, points=win.points[point_idx].copy(), resid=resid)
+
+
+def make_imu_records(win, weights=True, valid=True, seed=0, trapped=1, consistent=False, dt=0.1):
+    """IMU settings, calibration part and one sosf_imu_frame record per keyframe of a synthetic window (eight samples before each
+    keyframe): the inputs of sosf_set_imu for parity tests and for bench.py --imu.  Returns (settings, calib, records, keep) --
+    `keep` holds the sample arrays the records point at.
+    consistent = False: arbitrary samples and small random IMU states (exercises the assembly; a long loop on it drifts away).
+    consistent = True: the samples an IMU would deliver on make_window's trajectory (keyframe i at rotation exp(0.01 i axis),
+    translation 0.08 i (1, 0.1, 0.05): constant velocity and rate, so the accelerometer sees gravity only), zero IMU states: the
+    visual-inertial problem then has the visual solution as its fixed point and a long loop converges on it."""
+    from .records import ImuCalib, ImuFrame, ImuSettings
+    rng = np.random.default_rng(seed)
+    S = ImuSettings()
+    S.weight_imu[:] = list((np.eye(6) * (4.0 if weights else 0.0)).reshape(-1))
+    S.weight_imu_bias[:] = list((np.eye(6) * (10.0 if weights else 0.0)).reshape(-1))
+    S.gravity[:] = [0, 9.81, 0]
+    S.rot_imu_cam[:] = list(so3_exp(np.array([0.1, -0.2, 0.05])).reshape(-1))
+    S.maxImuInterval = 0.5
+    S.enable_scale_opt = 0
+    cal = ImuCalib(1.0 / 200, 1.0 / 200, int(trapped), 1)
+    frames, keep = [], []
+    for i in range(win.n):
+        f = ImuFrame()
+        f.timestamp = 1.0 + 0.1 * i
+        st = rng.normal(0, 1e-4, 21)
+        f.state_imu[:] = list(st)
+        f.state_imu_zero[:] = list(st)
+        f.trackingRefIsPrev = 1 if valid else 0
+        imu = np.zeros((8, 7))
+        imu[:, 0] = f.timestamp - np.linspace(0.07, 0.0, 8)
+        imu[:, 1:4] = [0.2, 9.6, -0.1]
+        imu[:, 4:7] = rng.normal(0, 0.02, (8, 3))
+        if consistent:
+            Ric, g, axis = so3_exp(np.array([0.1, -0.2, 0.05])), np.array([0.0, 9.81, 0.0]), np.array([0.3, 1.0, 0.2])
+            f.timestamp = 1.0 + dt * i
+            f.state_imu[:] = [0.0] * 21
+            f.state_imu_zero[:] = [0.0] * 21
+            imu = np.zeros((8 if i > 0 else 0, 7))
+            for j in range(len(imu)):
+                tau = (i - 1) + (j + 1) / 8.0
+                imu[j, 0] = 1.0 + dt * tau
+                imu[j, 1:4] = Ric @ so3_exp(0.01 * tau * axis).T @ g
+                imu[j, 4:7] = Ric @ (0.01 * axis / dt)
+            f.trackingRefIsPrev = 1 if (valid and i > 0) else 0
+        imu = np.ascontiguousarray(imu)
+        keep.append(imu)
+        f.n_imu = len(imu)
+        f.imu = imu.ctypes.data if len(imu) else None
+        frames.append(f)
+    return S, cal, frames, keep
+
+
+def expand_prior_imu(win, eps=1e-3):
+    """the window's marginalisation prior in the expanded (IMU) dimension CPARS + 1 + 29 n (expandHbtoFitImu,
+    OB/EnergyFunctional.cpp:256-286) plus eps on the diagonal"""
+    from .records import imu_dim
+    n = win.n
+    d0, dI = 4 + 8 * n, imu_dim(n)
+    idx = np.array([k if k < 4 else 5 + 29 * ((k - 4) // 8) + (k - 4) % 8 for k in range(d0)])
+    HMi, bMi = np.zeros((dI, dI)), np.zeros(dI)
+    HMi[np.ix_(idx, idx)] = win.HM
+    bMi[idx] = win.bM
+    return HMi + np.eye(dI) * eps, bMi
