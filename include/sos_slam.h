@@ -244,9 +244,15 @@ typedef struct sos_resid_final {
  *   records              R records in the order of sos_ba_set_window (entries of linearized residuals are not written)
  *   pointMaxRelBaseline  per point the largest relBS over its active isNew residuals (:55-70), -1 when it has none
  *   pointNewGood         per point the number of those residuals (numGoodResiduals += ...)
- * The three arrays live in pinned memory owned by the handle and stay valid until the next call on it. */
-int sos_ba_linearize_final(sos_ba *ba, const float *frameEnergyTH, double *energySum, const sos_resid_final **records,
+ * The three arrays live in pinned memory owned by the handle and stay valid until the next call on it.
+ * resetOOB != 0: PointFrameResidual::resetOOB first -- the relinearisation of flagPointsForRemoval (FS/FullSystem.cpp:575-583). */
+int sos_ba_linearize_final(sos_ba *ba, const float *frameEnergyTH, int resetOOB, double *energySum, const sos_resid_final **records,
                            const float **pointMaxRelBaseline, const int32_t **pointNewGood, float *newestEnergies, int *newestCount);
+
+/* EnergyFunctional::dropResidual (OB/EnergyFunctional.cpp:710-728) for residuals of the current snapshot: they stay in the
+ * arrays but are dead from here on (no flags, state OOB, zero JpJdF / point terms), so that the snapshot serves the rest of the
+ * keyframe (flagPointsForRemoval, marginalizePointsF) without a second sos_ba_set_window. */
+int sos_ba_kill_residuals(sos_ba *ba, const int32_t *residIdx, int count);
 
 /* EFResidual::fixLinearizationF for `count` residuals (FS/FullSystem.cpp:581;
  * OB/EnergyFunctionalStructs.cpp:75-103).  Uses the adHTdeltaF/cDeltaF/deltaF of the last set_state. */

@@ -268,7 +268,7 @@ EFResidual *EnergyFunctional::insertResidual(PointFrameResidual *r) {  // OB/Ene
   connectivityMap[efr->connKey].first++;
   nResiduals++;
   r->efResidual = efr;
-  packDirty = true;
+  packDirty = structDirty = true;
   return efr;
 }
 
@@ -305,7 +305,7 @@ EFFrame *EnergyFunctional::insertFrame(FrameHessian *fh, CalibHessian *HCalib) {
     connectivityMap[(((uint64_t)eff->frameID) << 32) + ((uint64_t)fh2->frameID)] = std::make_pair(0, 0);
     if (fh2 != eff) connectivityMap[(((uint64_t)fh2->frameID) << 32) + ((uint64_t)eff->frameID)] = std::make_pair(0, 0);
   }
-  packDirty = true;
+  packDirty = structDirty = true;
   return eff;
 }
 
@@ -316,7 +316,7 @@ EFPoint *EnergyFunctional::insertPoint(PointHessian *ph) {  // :697-708
   nPoints++;
   ph->efPoint = efp;
   EFIndicesValid = false;
-  packDirty = true;
+  packDirty = structDirty = true;
   return efp;
 }
 
@@ -329,6 +329,8 @@ void EnergyFunctional::dropResidual(EFResidual *r) {  // :710-728
   connectivityMap[r->connKey].first--;
   nResiduals--;
   r->data->efResidual = nullptr;
+  if (r->data->packIdx >= 0) droppedSincePack.push_back(r->data->packIdx);  // the device snapshot still holds it (sos_ba_kill_residuals)
+  r->data->packIdx = -1;
   delete r;
   packDirty = true;
 }
@@ -437,10 +439,25 @@ int EnergyFunctional::packWindow(std::vector<PointFrameResidual *> *active) {
   const double tq = now_s();
   int rc = sos_ba_set_window(ba, n, slots.data(), (int)pts.size(), pts.data(), (int)res.size(), res.data(), nullptr, nullptr);
   if (getenv("SOS_TIMING")) fprintf(stderr, "[packWindow] graph walk + records %.0f us, sos_ba_set_window %.0f us\n", (tq - tpk0) * 1e6, (now_s() - tq) * 1e6);
-  if (rc == SOS_OK) packDirty = false;
+  if (rc == SOS_OK) {
+    packDirty = structDirty = false;
+    droppedSincePack.clear();
+  }
   pointsOnDeviceCurrent = rc == SOS_OK;
   pointStep.assign(pts.size(), 0.f);
   return rc;
+}
+
+// The graph only LOST residuals since the last pack (linearizeAll(true), removeOutliers): the snapshot stays, the dropped residuals
+// are marked dead on the device.  Returns false when a full pack is needed instead.
+bool EnergyFunctional::syncDropsToDevice() {
+  if (!packDirty) return true;
+  if (structDirty || commAttached) return false;
+  if (!droppedSincePack.empty()) {
+    if (sos_ba_kill_residuals(ba, droppedSincePack.data(), (int)droppedSincePack.size()) != SOS_OK) return false;
+    droppedSincePack.clear();
+  }
+  return true;  // packDirty stays set: the next optimize() packs the graph as it is then
 }
 
 int EnergyFunctional::pushState(CalibHessian *HCalib, bool adjoints, bool points) {
@@ -803,7 +820,7 @@ int EnergyFunctional::marginalizeFrame(EFFrame *fh) {  // :730-889; the IMU form
   fh->data->efFrame = nullptr;
   EFIndicesValid = EFAdjointsValid = EFDeltaValid = false;
   makeIDX();
-  packDirty = true;
+  packDirty = structDirty = true;
   delete fh;
   return SOS_OK;
 }
@@ -973,7 +990,7 @@ double FullSystem::linearizeAll(bool fix) {  // FS/FullSystemOptimize.cpp:125-18
     int cap = 0, cnt = 0;
     sos_ba_newest_capacity(ef->ba, &cap);
     newestE.resize((size_t)cap + 1);
-    lastError = sos_ba_linearize_final(ef->ba, th.data(), &E, &rec, &pmax, &pcnt, newestE.data(), &cnt);
+    lastError = sos_ba_linearize_final(ef->ba, th.data(), 0, &E, &rec, &pmax, &pcnt, newestE.data(), &cnt);
     newestE.resize(lastError == SOS_OK ? cnt : 0);
   }
   if (lastError != SOS_OK) return NAN;
@@ -1511,41 +1528,40 @@ int FullSystem::marginalizePoints(const std::vector<PointHessian *> &pts, bool a
     ef->dropPointsF();
     return SOS_OK;
   }
-  int rc = ef->packWindow();
-  if (rc) return rc;
-  setPrecalcValues();
-  rc = ef->pushState(&HCalib, true);
-  if (rc) return rc;
+  // After optimize() the graph has only lost residuals (its final linearisation, removeOutliers): the snapshot of that optimize() is
+  // kept and the lost residuals are marked dead on it -- no second pack + upload per keyframe.  Anything else repacks.
+  int rc = SOS_OK;
+  if (!ef->syncDropsToDevice()) {
+    rc = ef->packWindow();
+    if (rc) return rc;
+    setPrecalcValues();
+    rc = ef->pushState(&HCalib, true);
+    if (rc) return rc;
+  }
   // r->resetOOB(); r->linearize(); r->applyRes(true) for the residuals of the listed points.  The
   // device linearizes every active residual at the current state, which leaves all the others unchanged
-  // in value (same state, same thresholds) -- only the listed ones are reset first.
-  const int n = (int)frameHessians.size();
-  std::vector<float> th(n);
-  for (int i = 0; i < n; i++) th[i] = frameHessians[i]->frameEnergyTH;
-  const size_t R = ef->allResiduals.size();
+  // in value (same state, same thresholds) -- only the listed ones are read back.
   // (after optimize() every surviving residual is IN and active, so re-evaluating the untouched ones at
   // the unchanged state is value-neutral; their host mirrors are not modified and the next pack rebuilds
   // the device copy from them.)
-  std::vector<uint32_t> f1(R);
-  std::vector<int32_t> s1(R);
-  std::vector<float> e1(R);
-  sos_ba_reset_oob(ef->ba);
-  h_newState.resize(R);
-  h_newEnergy.resize(R);
+  const int n = (int)frameHessians.size();
+  std::vector<float> th(n);
+  for (int i = 0; i < n; i++) th[i] = frameHessians[i]->frameEnergyTH;
+  const sos_resid_final *rec = nullptr;
+  const float *pmax = nullptr;
+  const int32_t *pcnt = nullptr;
   double E = 0;
-  rc = sos_ba_linearize(ef->ba, th.data(), &E, h_newState.data(), h_newEnergy.data(), nullptr, nullptr);
+  rc = sos_ba_linearize_final(ef->ba, th.data(), 1, &E, &rec, &pmax, &pcnt, nullptr, nullptr);
   if (rc) return rc;
-  sos_ba_apply_res(ef->ba);
-  sos_ba_get_residual_flags(ef->ba, f1.data(), s1.data(), e1.data());
   std::vector<int32_t> fixIdx;
   for (PointHessian *ph : pts) {
     int ngoodRes = 0;
     for (PointFrameResidual *r : ph->residuals) {
       const int k = r->packIdx;
-      r->state_state = (ResState)s1[k];
-      r->state_energy = e1[k];
+      r->state_state = (ResState)rec[k].state_state;
+      r->state_energy = rec[k].state_energy;
       r->efResidual->isLinearized = false;
-      r->efResidual->isActiveAndIsGoodNEW = (f1[k] & SOS_RF_ACTIVE) != 0;
+      r->efResidual->isActiveAndIsGoodNEW = rec[k].active != 0;
       if (r->efResidual->isActive()) {
         fixIdx.push_back(k);
         r->efResidual->isLinearized = true;
@@ -2524,7 +2540,7 @@ extern "C" int sosf_set_min_opt_iterations(sosf_system *s, int its) {
 
 extern "C" int sosf_invalidate_pack(sosf_system *s) {
   if (!s) return SOS_ERR_ARG;
-  s->fs->ef->packDirty = true;
+  s->fs->ef->packDirty = s->fs->ef->structDirty = true;
   return SOS_OK;
 }
 

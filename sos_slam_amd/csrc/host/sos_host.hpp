@@ -203,6 +203,9 @@ class EnergyFunctional {  // OB/EnergyFunctional.h:52-154
   sos_ba *ba = nullptr;
   sos_ctx *ctx = nullptr;
   bool packDirty = true;
+  bool structDirty = true;                 // ... by more than dropped residuals / points since the last pack
+  std::vector<int32_t> droppedSincePack;   // snapshot indices of the residuals dropped since the last pack
+  bool syncDropsToDevice();
 
   std::vector<EFFrame *> frames;
   int nPoints = 0, nFrames = 0, nResiduals = 0;

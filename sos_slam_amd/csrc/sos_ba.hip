@@ -1203,7 +1203,7 @@ __global__ __launch_bounds__(256) void k_commit_new(BaDev d, const float *__rest
 __global__ void k_reset_oob(BaDev d) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= d.ntilesA * SOS_TILE) return;
-  if (d.s_point[s] < 0 || (d.s_flags[s] & DF_LINEARIZED)) return;
+  if (d.s_point[s] < 0 || (d.s_flags[s] & DF_LINEARIZED) || !(d.s_flags[s] & DF_VALID)) return;  // (dead: sos_ba_kill_residuals)
   d.s_newenergy[s] = 0;
   d.s_energy[s] = 0;
   d.s_newstate[s] = SOS_RES_OUTLIER;
@@ -3472,6 +3472,39 @@ extern "C" int sos_ba_reset_oob(sos_ba *ba) {
   return SOS_OK;
 }
 
+// residuals the host dropped from its graph since the snapshot was made: dead on the device from here on (no flags, zero
+// JpJdF / point terms, state OOB), so the snapshot can serve the rest of the keyframe without a second pack
+__global__ void k_kill_residuals(BaDev d, const int *__restrict__ slist, int count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const int s = slist[i];
+  d.s_flags[s] = 0;
+  d.s_state[s] = SOS_RES_OOB;
+  d.s_newstate[s] = SOS_RES_OOB;
+  float4 *jp = reinterpret_cast<float4 *>(d.JpJd + 8 * (size_t)s), *pt = reinterpret_cast<float4 *>(d.s_pterm + 8 * (size_t)s);
+  jp[0] = jp[1] = pt[0] = pt[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+extern "C" int sos_ba_kill_residuals(sos_ba *ba, const int32_t *residIdx, int count) {
+  if (ba) ba->acc_inflight = false, ba->top_valid = false;
+  if (!ba || !ba->have_window || (count && !residIdx)) return SOS_ERR_STATE;
+  if (count <= 0) return SOS_OK;
+  SOS_HIP(hipSetDevice(ba->ctx->device));
+  hipStream_t st = ba->ctx->stream;
+  std::vector<int> sl(count);
+  for (int k = 0; k < count; k++) {
+    if (residIdx[k] < 0 || residIdx[k] >= ba->R) return SOS_ERR_ARG;
+    sl[k] = ba->h_s_of_orig[residIdx[k]];
+    ba->h_res[residIdx[k]].flags = 0;
+    ba->h_res[residIdx[k]].state_state = SOS_RES_OOB;
+  }
+  int rc = upload(st, ba->d_tmp_int, sl);
+  if (rc) return rc;
+  k_kill_residuals<<<divup(count, 64), 64, 0, st>>>(ba->dev, ba->d_tmp_int.p, count);
+  SOS_HIP(hipGetLastError());
+  SOS_HIP(hipStreamSynchronize(st));  // sl is pageable
+  return SOS_OK;
+}
+
 extern "C" int sos_ba_fix_linearization(sos_ba *ba, const int32_t *residIdx, int count) {
   if (ba && ba->have_window && ba->have_state) ensure_J(ba);
   if (ba) ba->acc_inflight = false, ba->top_valid = false;  // any state change invalidates a prefetched accumulate
@@ -4011,7 +4044,7 @@ __global__ __launch_bounds__(256) void k_final_pack(BaDev d, sos_resid_final *__
 
 // FullSystem::linearizeAll(true) (FS/FullSystemOptimize.cpp:125-182): linearize + applyRes(true) of every active residual,
 // then what the host bookkeeping reads, in ONE device-to-host copy into a pinned block owned by the handle
-extern "C" int sos_ba_linearize_final(sos_ba *ba, const float *frameEnergyTH, double *energySum, const sos_resid_final **records,
+extern "C" int sos_ba_linearize_final(sos_ba *ba, const float *frameEnergyTH, int resetOOB, double *energySum, const sos_resid_final **records,
                                       const float **pointMaxRelBaseline, const int32_t **pointNewGood, float *newestEnergies,
                                       int *newestCount) {
   if (!ba || !ba->have_window || !ba->have_state || !frameEnergyTH || !records || !pointMaxRelBaseline || !pointNewGood) return SOS_ERR_STATE;
@@ -4035,7 +4068,7 @@ extern "C" int sos_ba_linearize_final(sos_ba *ba, const float *frameEnergyTH, do
   }
   const bool prefetch = ba->prefetch, fuseOnly = ba->fuse_only;
   ba->prefetch = ba->fuse_only = false;  // nothing follows this linearisation, and its Jacobians are stored (marginalisation reads them)
-  int rc = sos_ba_linearize_apply(ba, frameEnergyTH, 0, energySum, newestEnergies, newestCount);
+  int rc = sos_ba_linearize_apply(ba, frameEnergyTH, resetOOB, energySum, newestEnergies, newestCount);
   ba->prefetch = prefetch;
   ba->fuse_only = fuseOnly;
   if (rc) return rc;
@@ -4268,7 +4301,11 @@ extern "C" int sos_ba_time_kernel(sos_ba *ba, const char *kernel, const float *f
     if (k == "linearize") return launch_linearize(ba, 0);
     if (k == "linearize_apply") return launch_linearize(ba, 1);
     if (k == "linearize_fused") {  // what the pipelined iterations run: linearize + applyRes + tile block sums, no J store
-      launch_lin_kernel(ba, ba->dev, 1, ba->d_top_part.p);
+      BaDev dv = ba->dev;  // exactly the loop's launch: no original-order result copies (lin_apply_tail)
+      dv.o_newstate = nullptr; dv.o_newenergy = nullptr; dv.o_newenergywo = nullptr; dv.o_center = nullptr;
+      dv.tile_esum = reinterpret_cast<double *>(ba->pin_dev + ba->pin_out + ba->out_esum);
+      dv.o_newest = reinterpret_cast<float *>(ba->pin_dev + ba->pin_out + ba->out_newest);
+      launch_lin_kernel(ba, dv, 1, ba->d_top_part.p);
       ba->J_valid = false;
       return SOS_OK;
     }
