@@ -293,7 +293,8 @@ def main():
         stream_ms = ms.value
         L.sos_ba_time_kernel(L_host_ba(sysm), b"stream_large", th.ctypes.data_as(C.c_void_p), 50, C.byref(ms))
         large_ms = ms.value   # coalesced read of a 1 GiB buffer: the chip's streaming bandwidth without launch effects
-        for name in ("apply_res", "top_accumulate", "sc_accumulate", "sc_gram_prep", "reduce", "stitch", "resub_fused"):
+        for name in ("apply_res", "top_accumulate", "sc_accumulate", "sc_gram_prep", "reduce", "stitch", "resub_fused", "sc_gram_abs",
+                     "abs_reduce_stitch1", "abs_stitch2"):
             L.sos_ba_time_kernel(L_host_ba(sysm), name.encode(), th.ctypes.data_as(C.c_void_p), 200, C.byref(ms))
             kern[name + "_us"] = round(ms.value * 1e3, 2)
         out = {

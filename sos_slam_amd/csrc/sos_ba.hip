@@ -1961,6 +1961,266 @@ __global__ __launch_bounds__(64) void k_stitch_stage2(StitchArgs a) {
 }
 
 // ================================================================================================
+// Schur complement in ABSOLUTE coordinates (the pipelined Gauss-Newton loop of a window without linearised residuals).
+//
+// The reference accumulates the Schur blocks per (host, target1, target2) in relative coordinates and stitches the n^3 blocks
+// with the adjoints afterwards (OB/AccumulatedSCHessian.cpp:63-77, 105-139).  The stitch is linear, so it can be applied to the
+// per-residual row JpJdF BEFORE the products: with  w_p = [ sum_t adHost[h,t] JpJd_t  (block of the host h) ;
+// adTarget[h,t] JpJd_t (block of target t) ; Hcd ; bdSum ]  the stitched system is  H_sc|b_sc = sum_p Hdi_p w_p w_p^T  -- ONE Gram
+// product of dimension 8 n + 5 per chunk of points, whose sum over the chunks IS the (4 + 8 n)-dimensional H_sc / b_sc.  The n^3
+// blocks, their reduction and both stages of their stitch disappear from the iteration.  fp32 like the reference's accumulators
+// (adjoints in their fp32 copies, OB/EnergyFunctional.cpp:94-98, products on the fp32 matrix cores), chunk sums in fp64.
+// ================================================================================================
+static inline size_t gram_abs_lds_floats(int n, int ld) { return (size_t)SOS_GC * ld + SOS_GC + (size_t)SOS_GC * n * 8 + 2 * (size_t)n * 64; }
+__global__ __launch_bounds__(256) void k_sc_gram_abs(BaDev d, const int *__restrict__ chunk_pt, int Dm, int ld, float *__restrict__ gram_part,
+                                                     const float *__restrict__ adHF, const float *__restrict__ adTF, int *flag, int seq) {
+  if (flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n = d.n, blk = blockIdx.x, tid = threadIdx.x;
+  float *A = smem;                      // [SOS_GC][ld]: the rows w_p
+  float *sHdi = A + SOS_GC * ld;        // [SOS_GC]
+  float *W = sHdi + SOS_GC;             // [SOS_GC][n][8]: adHost[h,t] JpJd_t per (point, target), summed into the host block below
+  float *sAH = W + SOS_GC * n * 8;      // [n][64] adjoints of the chunk's host
+  float *sAT = sAH + n * 64;
+  const int p0 = chunk_pt[blk * SOS_GC];  // a chunk starts with a real point; all its points share the host
+  const int h = p0 >= 0 ? d.pts[p0].host : 0;
+  for (int q = tid; q < (SOS_GC * ld + SOS_GC + SOS_GC * n * 8) / 4; q += 256) reinterpret_cast<float4 *>(smem)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int q = tid; q < n * 16; q += 256) {
+    const int t = q >> 4, k4 = q & 15;
+    reinterpret_cast<float4 *>(sAH)[q] = reinterpret_cast<const float4 *>(adHF + 64 * (size_t)(h + n * t))[k4];
+    reinterpret_cast<float4 *>(sAT)[q] = reinterpret_cast<const float4 *>(adTF + 64 * (size_t)(h + n * t))[k4];
+  }
+  __syncthreads();
+  for (int q = tid; q < SOS_GC * (n + 1); q += 256) {
+    const int t = q / SOS_GC, pl = q - t * SOS_GC;  // the 32 prep items (t == n) end up in one half-wave
+    const int p = chunk_pt[blk * SOS_GC + pl];
+    if (p < 0) continue;
+    if (t == n) {
+      const PrepOut r = point_prep_body(d, 1, p);
+      float *row = A + pl * ld + 8 * n;
+      sHdi[pl] = r.hdi;
+      row[0] = r.hcd[0]; row[1] = r.hcd[1]; row[2] = r.hcd[2]; row[3] = r.hcd[3];
+      row[4] = r.bdsum;
+    } else {
+      const int s = d.p_res_t[(size_t)p * n + t];
+      if (s >= 0) {
+        const float4 *jp = reinterpret_cast<const float4 *>(d.JpJd + 8 * (size_t)s);
+        const float4 j0 = jp[0], j1 = jp[1];
+        const float J[8] = {j0.x, j0.y, j0.z, j0.w, j1.x, j1.y, j1.z, j1.w};
+        const float *ah = sAH + 64 * t, *at = sAT + 64 * t;
+        float *rowT = A + pl * ld + 8 * t, *rowH = W + (pl * n + t) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          float vt = 0.f, vh = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            vt += at[8 * i + j] * J[j];
+            vh += ah[8 * i + j] * J[j];
+          }
+          rowT[i] = vt;
+          rowH[i] = vh;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int q = tid; q < SOS_GC * 8; q += 256) {  // the host's own block: sum over the targets, t ascending
+    const int pl = q >> 3, i = q & 7;
+    float sv = 0.f;
+    for (int t = 0; t < n; t++) sv += W[(pl * n + t) * 8 + i];
+    A[pl * ld + 8 * h + i] = sv;
+  }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;
+  const int T = Dm >> 4;
+  const int kq = lane >> 4, col = lane & 15;
+  float *g = gram_part + (size_t)blk * Dm * Dm;
+  for (int ut = wave; ut < T * (T + 1) / 2; ut += 4) {  // the 16x16 tiles on and above the diagonal
+    int mt = 0, rem = ut;
+    while (rem >= T - mt) { rem -= T - mt; mt++; }
+    const int m0 = mt << 4, n0 = (mt + rem) << 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < SOS_GC / 4; kk++) {
+      const int k = kk * 4 + kq;
+      const float av = sHdi[k] * A[k * ld + m0 + col];
+      const float bv = A[k * ld + n0 + col];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int rgi = 0; rgi < 4; rgi++) g[(size_t)(m0 + kq * 4 + rgi) * Dm + n0 + col] = acc[rgi];
+  }
+}
+
+// One launch behind the Gram kernel:
+//   blocks [0, n^2)   pair (h,t): the tile sums of the pair added in fp64, then the products of stitch stage 1
+//                     (OB/AccumulatedTopHessian.cpp:261-288) from them; the pair's calibration entries and residual count aside
+//   the rest          H_sc | b_sc: one block per row of a 16x16 tile of the Gram matrix, eight partial sums over the chunks per
+//                     element (chunks k, k + 8, ...), added in that order; written where the host (or the exchange) reads them
+struct AbsStitchArgs {
+  int n, Dm, nchunks;
+  const float *top_part;
+  const int *pair_tile_begin;
+  const float *gram_part;
+  const double *adHost, *adTarget;
+  double *Ctop, *Pcc;  // per pair: SOS_TOPC doubles of products; 24 doubles (16 Hcc, 4 bc, count)
+  double *H;           // [H_A | b_A] at 0, [H_sc | b_sc] at mode_stride, the residual count at 2 * mode_stride
+  size_t mode_stride;
+};
+__global__ __launch_bounds__(128) void k_abs_reduce_stitch1(AbsStitchArgs a) {
+  const int n = a.n, tid = threadIdx.x;
+  __shared__ double sSum[96], sB[64], sAH[64], sAT[64], sT1[64], sT2[64], sBpc[32], sbp[8], sPart[8][16];
+  if ((int)blockIdx.x < n * n) {
+    const int pidx = blockIdx.x;
+    if (tid < 96) {
+      const int t0 = a.pair_tile_begin[pidx], t1 = a.pair_tile_begin[pidx + 1];
+      double sv = 0;
+#pragma unroll 8
+      for (int t = t0; t < t1; t++) sv += (double)a.top_part[(size_t)t * SOS_TOPN + tid];
+      sSum[tid] = sv;
+    }
+    if (tid < 64) {
+      sAH[tid] = a.adHost[(size_t)pidx * 64 + tid];
+      sAT[tid] = a.adTarget[(size_t)pidx * 64 + tid];
+    }
+    __syncthreads();
+    if (tid < 24) {
+      double v = 0;
+      if (tid < 16) v = sSum[top_idx(tid >> 2, tid & 3)];
+      else if (tid < 20) v = sSum[top_idx(tid - 16, 12)];
+      else if (tid == 20) v = sSum[91];
+      a.Pcc[(size_t)pidx * 24 + tid] = v;
+    }
+    const int i = (tid & 63) >> 3, j = tid & 7;
+    if (tid < 64) sB[tid] = sSum[top_idx(4 + i, 4 + j)];
+    if (tid < 32) sBpc[tid] = sSum[top_idx(4 + (tid >> 2), tid & 3)];
+    if (tid < 8) sbp[tid] = sSum[top_idx(4 + tid, 12)];
+    __syncthreads();
+    if (tid < 64) {
+      double t1 = 0, t2 = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        t1 += sAH[i * 8 + k] * sB[k * 8 + j];
+        t2 += sAT[i * 8 + k] * sB[k * 8 + j];
+      }
+      sT1[tid] = t1;
+      sT2[tid] = t2;
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+    double p1 = 0, p2 = 0, p3 = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      p1 += sT1[i * 8 + k] * sAH[j * 8 + k];
+      p2 += sT2[i * 8 + k] * sAT[j * 8 + k];
+      p3 += sT1[i * 8 + k] * sAT[j * 8 + k];
+    }
+    double *out = a.Ctop + (size_t)pidx * SOS_TOPC;
+    out[tid] = p1;
+    out[64 + tid] = p2;
+    out[128 + tid] = p3;
+    if (tid < 32) {
+      const int r = tid >> 2, c = tid & 3;
+      double h1 = 0, h2 = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        h1 += sAH[r * 8 + k] * sBpc[k * 4 + c];
+        h2 += sAT[r * 8 + k] * sBpc[k * 4 + c];
+      }
+      out[192 + tid] = h1;
+      out[224 + tid] = h2;
+    }
+    if (tid < 8) {
+      double b1 = 0, b2 = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        b1 += sAH[tid * 8 + k] * sbp[k];
+        b2 += sAT[tid * 8 + k] * sbp[k];
+      }
+      out[256 + tid] = b1;
+      out[264 + tid] = b2;
+    }
+    return;
+  }
+  // ---- H_sc | b_sc
+  const int b = blockIdx.x - n * n, T = a.Dm >> 4;
+  const int ut = b >> 4, rr = b & 15;
+  int mt = 0, rem = ut;
+  while (rem >= T - mt) { rem -= T - mt; mt++; }
+  const int r = (mt << 4) + rr, c = ((mt + rem) << 4) + (tid & 15), sub = tid >> 4;
+  const int cols = 8 * n + 5;
+  double sv = 0;
+  if (r < cols - 1 && c < cols && c >= r) {
+    const float *gp = a.gram_part + (size_t)r * a.Dm + c;
+    const size_t stride = (size_t)a.Dm * a.Dm;
+    for (int k0 = sub; k0 < a.nchunks; k0 += 64) {  // eight loads in flight per thread
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (k0 + 8 * u < a.nchunks) v[u] = gp[(size_t)(k0 + 8 * u) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (k0 + 8 * u < a.nchunks) sv += (double)v[u];
+    }
+  }
+  sPart[sub][tid & 15] = sv;
+  __syncthreads();
+  if (tid < 16 && r < cols - 1 && c < cols && c >= r) {
+    double tot = 0;
+#pragma unroll
+    for (int u = 0; u < 8; u++) tot += sPart[u][tid];
+    const int dim = 4 + 8 * n;
+    double *Hs = a.H + a.mode_stride, *bs = Hs + (size_t)dim * dim;
+    const int R = r < 8 * n ? 4 + r : r - 8 * n;  // Gram order [frames | calib | b]  ->  system order [calib | frames]
+    if (c == cols - 1) bs[R] = tot;
+    else {
+      const int Cc = c < 8 * n ? 4 + c : c - 8 * n;
+      if (R <= Cc) Hs[(size_t)R * dim + Cc] = tot;
+      else Hs[(size_t)Cc * dim + R] = tot;
+    }
+  }
+}
+// ... and the second one: the sums of stitch stage 2 for the top system (upper triangle), the calibration block / b_c / the
+// residual count from the per-pair entries
+__global__ __launch_bounds__(64) void k_abs_stitch2(AbsStitchArgs a) {
+  const int n = a.n, nblk = n * (n + 1) / 2, tid = threadIdx.x;
+  if ((int)blockIdx.x < nblk) {
+    stitch_top_sum_body(blockIdx.x, 0, n, nullptr, a.Ctop, a.H, a.mode_stride, true);
+    return;
+  }
+  // 21 scalars, each the sum over the n^2 pairs in pair order: three threads per scalar take a third of the pairs each
+  __shared__ double sp[3][21];
+  const int o = tid % 21, part = tid / 21;
+  if (part < 3) {
+    const int nn = n * n, per = (nn + 2) / 3, k0 = part * per, k1 = min(nn, k0 + per);
+    double sv = 0;
+    for (int k = k0; k < k1; k += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (k + u < k1) v[u] = a.Pcc[(size_t)(k + u) * 24 + o];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (k + u < k1) sv += v[u];
+    }
+    sp[part][o] = sv;
+  }
+  __syncthreads();
+  if (tid < 21) {
+    const double tot = (sp[0][tid] + sp[1][tid]) + sp[2][tid];
+    const int dim = 4 + 8 * n;
+    if (tid < 16) {
+      if ((tid >> 2) <= (tid & 3)) a.H[(size_t)(tid >> 2) * dim + (tid & 3)] = tot;
+    } else if (tid < 20) a.H[(size_t)dim * dim + (tid - 16)] = tot;
+    else a.H[2 * a.mode_stride] = tot;
+  }
+}
+__global__ void k_copy_f64(double *__restrict__ dst, const double *__restrict__ src, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+// ================================================================================================
 // resubstituteFPt (OB/EnergyFunctional.cpp:526-551): one thread per point; loads of 4 residuals are in
 // flight together, the subtraction order is the reference's.  With applyStep the point's idepth is
 // advanced on the device exactly as doStepFromBackup does on the host
@@ -2624,6 +2884,7 @@ struct sos_ba {
   bool prefetch = false;      // sos_ba_set_prefetch: gn_step enqueues the next gn_accumulate behind the linearisation
   bool acc_inflight = false;  // ... and this says its result is (or will be) in the mapped Hb block
   bool acc_inflight_haveL = false;
+  bool acc_inflight_abs = false;  // ... in the layout of the absolute-coordinate path
   bool top_valid = false;     // d_top_part holds the tile sums of the current linearisation (the last one ran fused and nothing changed since)
   bool fuse_only = false;     // sos_ba_set_prefetch(ba, 2): the linearisation forms the tile sums, nothing is enqueued behind it
   DevBuf<int> d_sigctr;       // [0] linearize launches, [1] stitch launches (cumulative block counters)
@@ -3670,7 +3931,57 @@ extern "C" int sos_ba_accumulate(sos_ba *ba, double *H_A, double *b_A, double *H
 
 // accumulate + stitch of the whole window with the stage-2 stitch kernels writing H/b (and the residual counts)
 // straight into the device-mapped pinned block: no copy command between the last kernel and the host
+// the absolute-coordinate Schur path (k_sc_gram_abs): windows without linearised residuals on any rank
+static bool abs_path_ok(const sos_ba *ba) {
+  // opt-in (SOS_ABS_SC=1) until the GPU suite has run on it
+  static const bool off = getenv("SOS_ABS_SC") == nullptr || getenv("SOS_NO_ABS_SC") != nullptr;
+  return !off && ba->ntiles == ba->ntilesA && ba->ntilesA > 0 && ba->nchunks > 0 && !(ba->comm && ba->anyL) && ba->d_adHostF.p &&
+         ba->d_adTargetF.p;
+}
+static int enqueue_gn_accumulate_abs(sos_ba *ba, bool topDone, int *pubFlag, int pubSeq) {
+  hipStream_t st = ba->ctx->stream;
+  const int n = ba->n;
+  const size_t nn = (size_t)n * n, ms = ba->hb_mode_stride;
+  const size_t lds = sizeof(float) * gram_abs_lds_floats(n, ba->ld);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_sc_gram_abs), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    attr_done = true;
+  }
+  if (!topDone) {  // the tile sums from the stored Jacobians first
+    if (pubFlag) k_publish<<<1, 1, 0, st>>>(pubFlag, pubSeq);
+    ensure_J(ba);
+    k_top_accumulate<false><<<divup(ba->ntilesA, 8), 256, 0, st>>>(ba->dev, 0, ba->ntilesA, 0, nullptr, nullptr, ba->d_top_part.p, nullptr);
+    pubFlag = nullptr;
+  }
+  k_sc_gram_abs<<<ba->nchunks, 256, lds, st>>>(ba->dev, ba->d_chunk_pt.p, ba->Dm, ba->ld, ba->d_gram_part.p, ba->d_adHostF.p, ba->d_adTargetF.p,
+                                               pubFlag, pubSeq);
+  AbsStitchArgs a;
+  a.n = n; a.Dm = ba->Dm; a.nchunks = ba->nchunks;
+  a.top_part = ba->d_top_part.p; a.pair_tile_begin = ba->d_pair_tile_begin.p; a.gram_part = ba->d_gram_part.p;
+  a.adHost = ba->d_adHost.p; a.adTarget = ba->d_adTarget.p;
+  a.Ctop = ba->d_C.p;
+  a.Pcc = ba->d_C.p + 2 * nn * SOS_TOPC;  // (the n^3 blocks of the relative-coordinate stitch are not used on this path)
+  double *pinH = reinterpret_cast<double *>(ba->pin_dev + ba->pin_hb);
+  a.H = ba->comm ? ba->d_Hout.p : pinH;
+  a.mode_stride = ms;
+  const int T = ba->Dm >> 4;
+  k_abs_reduce_stitch1<<<(int)nn + T * (T + 1) / 2 * 16, 128, 0, st>>>(a);
+  k_abs_stitch2<<<n * (n + 1) / 2 + 1, 64, 0, st>>>(a);
+  if (ba->comm) {  // THE exchange step of the path, on the stitched fp64 system (the stitch is linear): [H_A b_A | H_sc b_sc | count]
+    const int rcc = sos_comm_allreduce_sum_f64(ba->comm, ba->d_Hout.p, 2 * ms + 1, st);
+    if (rcc) return rcc;
+    k_copy_f64<<<divup((int)(2 * ms + 1), 256), 256, 0, st>>>(pinH, ba->d_Hout.p, 2 * ms + 1);
+  }
+  ++ba->sig_st_seq;
+  k_publish<<<1, 1, 0, st>>>(reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags + 64), ba->sig_st_seq);
+  ba->acc_inflight_haveL = false;
+  ba->acc_inflight_abs = true;
+  return SOS_OK;
+}
 static int enqueue_gn_accumulate(sos_ba *ba, bool topDone = false, int *pubFlag = nullptr, int pubSeq = 0) {
+  if (abs_path_ok(ba)) return enqueue_gn_accumulate_abs(ba, topDone, pubFlag, pubSeq);
+  ba->acc_inflight_abs = false;
   const bool haveL = ba->ntiles > ba->ntilesA || (ba->comm && ba->anyL);
   if (topDone && ba->ntiles == ba->ntilesA) {  // the tile sums came out of the linearisation itself: only the Schur half is left
     if (ba->nchunks > 0)
@@ -3718,6 +4029,18 @@ extern "C" int sos_ba_gn_accumulate(sos_ba *ba, double *H_top, double *b_top, do
   const size_t dim = 4 + 8 * (size_t)ba->n, ms = ba->hb_mode_stride;
   const double *ph = reinterpret_cast<const double *>(ba->pin + ba->pin_hb);
   const float *pn = reinterpret_cast<const float *>(ph + 3 * ms);
+  if (ba->acc_inflight_abs) {  // [H_A b_A | H_sc b_sc | count] from the absolute-coordinate path
+    for (size_t i = 0; i < dim; i++) {
+      const size_t o = i * dim + i, len = dim - i;
+      memcpy(H_top + o, ph + o, sizeof(double) * len);
+      memcpy(H_sc + o, ph + ms + o, sizeof(double) * len);
+    }
+    memcpy(b_top, ph + dim * dim, sizeof(double) * dim);
+    memcpy(b_sc, ph + ms + dim * dim, sizeof(double) * dim);
+    if (resInA) *resInA = (int)ph[2 * ms];
+    if (resInL) *resInL = 0;
+    return SOS_OK;
+  }
   // only the upper triangle (col >= row) is produced and copied: it is all the solve reads
   for (size_t i = 0; i < dim; i++) {
     const size_t o = i * dim + i, len = dim - i;
@@ -4334,6 +4657,27 @@ extern "C" int sos_ba_time_kernel(sos_ba *ba, const char *kernel, const float *f
     }
     if (k == "sc_gram_prep") {
       if (ba->nchunks > 0) k_sc_gram_prep<<<ba->nchunks, 256, gram_lds(ba), st>>>(ba->dev, ba->d_chunk_pt.p, ba->Dm, ba->ld, ba->d_gram_part.p, nullptr, 0);
+      return SOS_OK;
+    }
+    if (k == "sc_gram_abs" || k == "abs_reduce_stitch1" || k == "abs_stitch2") {  // the kernels of the absolute-coordinate Schur path, one at a time
+      if (!abs_path_ok(ba)) return SOS_OK;
+      const int n = ba->n;
+      const size_t nn = (size_t)n * n;
+      if (k == "sc_gram_abs") {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_sc_gram_abs), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        k_sc_gram_abs<<<ba->nchunks, 256, sizeof(float) * gram_abs_lds_floats(n, ba->ld), st>>>(ba->dev, ba->d_chunk_pt.p, ba->Dm, ba->ld, ba->d_gram_part.p,
+                                                                                                 ba->d_adHostF.p, ba->d_adTargetF.p, nullptr, 0);
+        return SOS_OK;
+      }
+      AbsStitchArgs a;
+      a.n = n; a.Dm = ba->Dm; a.nchunks = ba->nchunks;
+      a.top_part = ba->d_top_part.p; a.pair_tile_begin = ba->d_pair_tile_begin.p; a.gram_part = ba->d_gram_part.p;
+      a.adHost = ba->d_adHost.p; a.adTarget = ba->d_adTarget.p;
+      a.Ctop = ba->d_C.p; a.Pcc = ba->d_C.p + 2 * nn * SOS_TOPC;
+      a.H = ba->d_Hout.p; a.mode_stride = ba->hb_mode_stride;
+      const int T = ba->Dm >> 4;
+      if (k == "abs_reduce_stitch1") k_abs_reduce_stitch1<<<(int)nn + T * (T + 1) / 2 * 16, 128, 0, st>>>(a);
+      else k_abs_stitch2<<<n * (n + 1) / 2 + 1, 64, 0, st>>>(a);
       return SOS_OK;
     }
     if (k == "exchange") {  // the per-iteration collective alone: all-reduce of a buffer the size of the packed fp32 accumulator
