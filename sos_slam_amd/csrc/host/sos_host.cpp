@@ -916,7 +916,12 @@ PointFrameResidual *FullSystem::addResidual(PointHessian *ph, FrameHessian *targ
   return r;
 }
 
+void FullSystem::ensureHostPrecalc() {  // after iterations through the flat API with the device-side step (sosf_gn_iteration)
+  if (hostPrecalcStale) setPrecalcValues(false);
+}
+
 void FullSystem::setPrecalcValues(bool points) {  // FS/FullSystem.cpp:1099-1107
+  hostPrecalcStale = false;
   for (FrameHessian *fh : frameHessians) {
     fh->targetPrecalc.resize(frameHessians.size());
     for (size_t i = 0; i < frameHessians.size(); i++) fh->targetPrecalc[i].set(fh, frameHessians[i], &HCalib);
@@ -1106,6 +1111,7 @@ bool FullSystem::doStepFromBackup(float stepfacC, float stepfacT, float stepfacR
   (void)sumID;
   ef->EFDeltaValid = false;
   if (precalcOnDevice) {
+    hostPrecalcStale = true;  // targetPrecalc (distanceLL, PRE_KRKiTll ...) is refreshed by whoever reads it next (ensureHostPrecalc)
     // the device forms FrameFramePrecalc / adHTdeltaF / cDeltaF itself (k_resub_devstep); what the host's next solve reads are the
     // frame deltas of setDeltaF (OB/EnergyFunctional.cpp:183-190) and cDeltaF (getStitchedDeltaF)
     for (int i = 0; i < 4; i++) ef->cDeltaF[i] = (float)HCalib.value_minus_value_zero[i];
@@ -1217,6 +1223,12 @@ host_path:
     sos_ba_set_prefetch(ef->ba, (more && !ef->allreduceHook) ? 1 : 0);  // a callback exchange runs between accumulate and stitch
     lastError = sos_ba_gn_step(ef->ba, ef->lastX.data(), 1.0f, &cal, nullptr, nullptr, nullptr, th.data(), 1, &E, newestE.data(), &cnt,
                                ef->pointStep.data());
+    if (lastError != SOS_OK) {  // e.g. the device-side frame states were dropped by a state upload in between: no step was taken
+      devStepActive = false;
+      sos_ba_gn_devstep_end(ef->ba);
+      isLost = true;
+      return true;
+    }
     newestE.resize(cnt);
     PhaseTimer tpost(6);
     for (size_t k = 0; k < ef->allPoints.size(); k++) {
@@ -1415,6 +1427,7 @@ void FullSystem::loadSateBackup() {  // FS/FullSystemOptimize.cpp:271-287 (IMU o
 // when the total energy decreased, otherwise undone with loadSateBackup and the window is linearised again at the old state.
 bool FullSystem::gnIterationChecked(int iteration, double &lastE, double &lastEL, double &lastEM) {
   lastLoopMode = 3;
+  devStepActive = false;  // (this loop steps on the host and uploads the states)
   backupState();
   if (rcAcc(ef->solveSystemF(iteration, 1e-1, &HCalib, false)) != SOS_OK) {
     isLost = true;
@@ -1532,6 +1545,7 @@ int FullSystem::marginalizePoints(const std::vector<PointHessian *> &pts, bool a
   // kept and the lost residuals are marked dead on it -- no second pack + upload per keyframe.  Anything else repacks.
   int rc = SOS_OK;
   if (!ef->syncDropsToDevice()) {
+    devStepActive = false;  // the upload below makes the host the source of the states again
     rc = ef->packWindow();
     if (rc) return rc;
     setPrecalcValues();
@@ -1657,6 +1671,7 @@ static const int setting_minGoodActiveResForMarg = 3, setting_minGoodResForMarg 
 
 // FS/FullSystemMarginalize.cpp:53-133; called BEFORE the new keyframe joins frameHessians (FS/FullSystem.cpp:798)
 void FullSystem::flagFramesForMarginalization() {
+  ensureHostPrecalc();  // distanceLL of the current states
   if (setting_minFrameAge > setting_maxFrames) {
     for (int i = setting_maxFrames; i < (int)frameHessians.size(); i++) frameHessians[i - setting_maxFrames]->flaggedForMarginalization = true;
     return;

@@ -296,6 +296,8 @@ class FullSystem {
   void loadSateBackup();                                      // FS/FullSystemOptimize.cpp:271-287
   bool gnIterationChecked(int iteration, double &lastE, double &lastEL, double &lastEM);  // :358-413, forceAceptStep off
   void setPrecalcValues(bool points = true);                  // FS/FullSystem.cpp:1099-1107
+  bool hostPrecalcStale = false;  // the device-side step moved the states: targetPrecalc is refreshed on the next read
+  void ensureHostPrecalc();
   void removeOutliers();                                      // FS/FullSystemOptimize.cpp:507-526
   int marginalizePoints(const std::vector<PointHessian *> &pts, bool alreadyDetached = false);  // flagPointsForRemoval core + marginalizePointsF
   void flagFramesForMarginalization();                        // FS/FullSystemMarginalize.cpp:53-133

@@ -139,3 +139,9 @@ class ImuShell(C.Structure):
 
 def imu_dim(n):
     return 4 + 1 + 29 * n
+
+
+# sos_resid_final (include/sos_slam.h): what linearizeAll(true) leaves in a PointFrameResidual, one record per residual
+RESID_FINAL_DTYPE = np.dtype([("state_NewEnergy", "f4"), ("state_NewEnergyWithOutlier", "f4"), ("state_energy", "f4"),
+                              ("centerProjectedTo", "f4", (3,)), ("state_NewState", "u1"), ("state_state", "u1"), ("active", "u1"),
+                              ("pad", "u1")], align=True)

@@ -66,7 +66,7 @@ def test_record_sizes_against_the_compiled_header(tmp_path):
                "sos_trace_params": C.sizeof(records.TraceParams), "sos_immature": records.IMMATURE_DTYPE.itemsize,
                "sos_activate_params": C.sizeof(records.ActivateParams), "sos_pair_tfm": records.PAIR_TFM_DTYPE.itemsize,
                "sos_activation": records.ACTIVATION_DTYPE.itemsize, "sos_pixsel_params": C.sizeof(records.PixselParams),
-               "sos_camera_model": C.sizeof(records.CameraModel)}
+               "sos_camera_model": C.sizeof(records.CameraModel), "sos_resid_final": records.RESID_FINAL_DTYPE.itemsize}
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include "sos_slam.h"\nint main(void) {\n' +
                    "".join(f'  printf("{n} %zu\\n", sizeof({n}));\n' for n in mirrors) + "  return 0;\n}\n")
