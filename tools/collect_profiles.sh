@@ -22,6 +22,11 @@ for W in W12 W16; do
     python tools/rocpd_summary.py counters $OUT/pmc_${W}_$C/p_results.db $OUT/pmc_${W}_$C.csv
   done
 done
+for W in W12 W16; do  # what bench.py's roofline.traffic reads: regenerated from THIS collection
+  python tools/pmc_json.py $W $OUT/pmc_${W}_FETCH_SIZE.csv $OUT/pmc_${W}_WRITE_SIZE.csv profiles/pmc_$W.json avg > /dev/null
+  cp profiles/pmc_$W.json $OUT/pmc_$W.json
+done
+python bench.py --imu --no-cpu-baseline > $OUT/bench_imu.json 2>> $OUT/bench.err
 python tools/tracker_bench.py W12 > $OUT/tracker_W12.json 2>> $OUT/bench.err
 rm -rf $OUT/prof_bench $OUT/prof_res $OUT/pmc_*/
 ls -la $OUT
