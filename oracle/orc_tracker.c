@@ -331,6 +331,7 @@ static void calc_res(orc_tracker *T, int lvl, const float *dINewl, const float *
 static void calc_res_loop(orc_tracker *T, int lvl, const float *dINewl, const float *R, const float *t, float aff0, float aff1,
                           float cutoffTH, double *rs) {
   float E = 0;
+  double Ed = 0; /* truth-mode (fp64) shadow of E */
   int numTermsInE = 0, numTermsInWarped = 0, numSaturated = 0;
   int wl = T->w[lvl], hl = T->h[lvl];
   float fxl = T->fx[lvl], fyl = T->fy[lvl], cxl = T->cx[lvl], cyl = T->cy[lvl];
@@ -369,10 +370,12 @@ static void calc_res_loop(orc_tracker *T, int lvl, const float *dINewl, const fl
     float hw = fabsf(residual) < huber ? 1 : huber / fabsf(residual);
     if (fabsf(residual) > cutoffTH) {
       E += maxEnergy;
+      Ed += (double)maxEnergy;
       numTermsInE++;
       numSaturated++;
     } else {
       E += hw * residual * residual * (2 - hw);
+      Ed += (double)(hw * residual * residual * (2 - hw));
       numTermsInE++;
       int k = numTermsInWarped;
       T->buf[0][k] = new_idepth; T->buf[1][k] = u; T->buf[2][k] = v; T->buf[3][k] = hit[1]; T->buf[4][k] = hit[2];
@@ -385,7 +388,7 @@ static void calc_res_loop(orc_tracker *T, int lvl, const float *dINewl, const fl
     numTermsInWarped++;
   }
   T->buf_n = numTermsInWarped;
-  rs[0] = E;
+  rs[0] = T->truth ? Ed : E;
   rs[1] = numTermsInE;
   rs[2] = sumSquaredShiftT / (sumSquaredShiftNum + 0.1);
   rs[3] = 0;
