@@ -360,9 +360,17 @@ def main():
             out["roofline"]["note"] += "; N > 1: rank 0's kernel on its own shard"
         out["cpu_baseline"] = None   # timed on rank 0 at N = 1 only
         if world == 1 and not args.imu:
-            out["keyframe"] = keyframe_timing(args.window, local_rank)
-            out["optimize_ms"] = out["keyframe"]["optimize_ms"]
-            out["keyframe_ms"] = out["keyframe"]["keyframe_ms"]
+            # side measurements: a failure in one of them must not cost the headline line
+            try:
+                out["keyframe"] = keyframe_timing(args.window, local_rank)
+                out["optimize_ms"] = out["keyframe"]["optimize_ms"]
+                out["keyframe_ms"] = out["keyframe"]["keyframe_ms"]
+            except Exception as e:  # noqa: BLE001
+                out["keyframe"] = {"error": repr(e)}
+            try:
+                out["visual_inertial"] = imu_timing(args.window, local_rank)
+            except Exception as e:  # noqa: BLE001
+                out["visual_inertial"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             out["tracker"] = tracker_timing(args.window, local_rank)
             out["cpu_baseline"] = cpu_baseline(win, args.cpu_seconds)
@@ -415,6 +423,32 @@ def keyframe_timing(window, device):
             "note": "optimize_ms: pack + first linearisation + iterations until the step test passes + final linearizeAll(true); "
                     "optimize_6_iterations_ms: the same on the window after the marginalisations with setting_minOptIterations = 6; "
                     "keyframe_ms = the four stages above"}
+
+
+def imu_timing(window, device, iters=400):
+    """The same loop body with the IMU / spline block of solveSystemF (BASELINE.json configs 2-3; OB/EnergyFunctional.cpp:1053-1171):
+    the device work is unchanged, the host assembles the IMU factors and solves the KKT system of dimension 4 + 1 + 29 n + constraints.
+    `python bench.py --imu` times it as the headline loop; this is the short form for the default line."""
+    from sos_slam_amd import host, synth
+    win = synth.make_window(window)
+    sysm = host.System.from_window(win, device=device)
+    S, cal, fr, keep = synth.make_imu_records(win, consistent=True)
+    HMi, bMi = synth.expand_prior_imu(win)
+    sysm.set_imu(S, cal, fr, HMi, bMi)
+    sysm.prepare()
+    sysm.set_pipeline(True)
+    for i in range(20):
+        sysm.gn_iteration(i)
+    host.timing(reset=True)
+    t0 = time.perf_counter()
+    for i in range(iters):
+        sysm.gn_iteration(20 + i)
+    dt = time.perf_counter() - t0
+    ph = host.timing()
+    out = {"ms_per_iteration": dt / iters * 1e3, "gn_iter_per_s": iters / dt, "host_kkt_solve_us": ph[2] / iters * 1e6,
+           "kkt_dimension": 4 + 1 + 29 * win.n + 6 * (win.n - 2) + 3, "loop_mode": sysm.loop_mode(), "resInA_last_iteration": sysm.stats()["resInA"]}
+    sysm.close()
+    return out
 
 
 def tracker_timing(window, device):
