@@ -193,3 +193,32 @@ def test_try_trap_scale():
         elif trapped_at is None:
             assert cal.scale_zero == cal.scale
     assert trapped_at == 9                                          # the ten LinSpaced entries have to be flushed out first
+
+
+def test_consistent_imu_records_of_the_bench_window_have_small_residuals():
+    """synth.make_imu_records(consistent=True) (bench.py --imu): samples an IMU would deliver on make_window's trajectory.  At the
+    trajectory's own poses the spline constraints and the IMU residuals of the oracle's assembly vanish up to the small-angle terms
+    the zero spline states leave out -- orders of magnitude below what arbitrary samples produce."""
+    from oracle import oracle as orc
+    from sos_slam_amd import synth
+
+    class W:
+        n = 7
+    for consistent in (True, False):
+        S, cal, frames, keep = synth.make_imu_records(W, consistent=consistent)
+        for i, f in enumerate(frames):
+            R = synth.so3_exp(0.01 * i * np.array([0.3, 1.0, 0.2]))
+            t = 0.08 * i * np.array([1.0, 0.1, 0.05])
+            f.camToWorld[:] = list(R.reshape(-1)) + list(t)
+            f.evalPT_R[:] = list(R.reshape(-1))
+        H, b, J, r, sv = orc.imu().hessian(S, cal, frames)
+        if consistent:
+            assert list(sv) == [0] + [1] * (W.n - 1)
+            rot_rows = np.abs(r).max()
+            b_c = np.abs(b).max()
+        else:
+            b_a = np.abs(b).max()
+    # rotation constraint: the spline's linear-rotation state is zero while the keyframes turn by 0.0108 rad -> r = that angle;
+    # velocity constraint and IMU residuals: zero (constant velocity, gravity only)
+    assert rot_rows < 0.02
+    assert b_c < 0.05 * b_a, (b_c, b_a)
