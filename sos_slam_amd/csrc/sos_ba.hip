@@ -2066,6 +2066,7 @@ struct AbsStitchArgs {
   double *Ctop, *Pcc;  // per pair: SOS_TOPC doubles of products; 24 doubles (16 Hcc, 4 bc, count)
   double *H;           // [H_A | b_A] at 0, [H_sc | b_sc] at mode_stride, the residual count at 2 * mode_stride
   size_t mode_stride;
+  DoneSignal sg;       // k_abs_stitch2 -> host (SOS_ABS_SIGNAL_IN_KERNEL=1: the last block raises the flag, no k_publish behind it)
 };
 __global__ __launch_bounds__(128) void k_abs_reduce_stitch1(AbsStitchArgs a) {
   const int n = a.n, tid = threadIdx.x;
@@ -2186,6 +2187,10 @@ __global__ __launch_bounds__(64) void k_abs_stitch2(AbsStitchArgs a) {
   const int n = a.n, nblk = n * (n + 1) / 2, tid = threadIdx.x;
   if ((int)blockIdx.x < nblk) {
     stitch_top_sum_body(blockIdx.x, 0, n, nullptr, a.Ctop, a.H, a.mode_stride, true);
+    if (a.sg.ctr) {
+      __syncthreads();  // all stores of the block issued
+      if (tid == 0) signal_block_done(a.sg);
+    }
     return;
   }
   // 21 scalars, each the sum over the n^2 pairs in pair order: three threads per scalar take a third of the pairs each
@@ -2213,6 +2218,10 @@ __global__ __launch_bounds__(64) void k_abs_stitch2(AbsStitchArgs a) {
       if ((tid >> 2) <= (tid & 3)) a.H[(size_t)(tid >> 2) * dim + (tid & 3)] = tot;
     } else if (tid < 20) a.H[(size_t)dim * dim + (tid - 16)] = tot;
     else a.H[2 * a.mode_stride] = tot;
+  }
+  if (a.sg.ctr) {
+    __syncthreads();
+    if (tid == 0) signal_block_done(a.sg);
   }
 }
 __global__ void k_copy_f64(double *__restrict__ dst, const double *__restrict__ src, size_t n) {
@@ -2888,7 +2897,7 @@ struct sos_ba {
   bool top_valid = false;     // d_top_part holds the tile sums of the current linearisation (the last one ran fused and nothing changed since)
   bool fuse_only = false;     // sos_ba_set_prefetch(ba, 2): the linearisation forms the tile sums, nothing is enqueued behind it
   DevBuf<int> d_sigctr;       // [0] linearize launches, [1] stitch launches (cumulative block counters)
-  int sig_lin_blocks = 0, sig_lin_seq = 0, sig_st_seq = 0, sig_st_blocks_total = 0;
+  int sig_lin_blocks = 0, sig_lin_seq = 0, sig_st_seq = 0, sig_st_blocks_total = 0, sig_abs_blocks_total = 0;
   // multi-GPU (sos_ba_set_comm): common capacity of the newest-frame energy lists, local / gathered device lists and
   // the device-mapped host copy of the gathered list
   sos_comm *comm = nullptr;
@@ -3282,7 +3291,7 @@ extern "C" int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, i
     memset(ba->pin + ba->pin_flags, 0, 128);
   }
   ba->sig_lin_seq = ba->sig_st_seq = 0;
-  ba->sig_lin_blocks = ba->sig_st_blocks_total = 0;
+  ba->sig_lin_blocks = ba->sig_st_blocks_total = ba->sig_abs_blocks_total = 0;
 
   BaDev &d = ba->dev;
   memset(&d, 0, sizeof(d));
@@ -3967,14 +3976,26 @@ static int enqueue_gn_accumulate_abs(sos_ba *ba, bool topDone, int *pubFlag, int
   a.mode_stride = ms;
   const int T = ba->Dm >> 4;
   k_abs_reduce_stitch1<<<(int)nn + T * (T + 1) / 2 * 16, 128, 0, st>>>(a);
-  k_abs_stitch2<<<n * (n + 1) / 2 + 1, 64, 0, st>>>(a);
+  // completion: a k_publish behind the last kernel, or (A/B knob) the last block of k_abs_stitch2 itself -- 80 blocks, one
+  // system-scope fence each; H_sc was written by the previous launch and is visible at its end
+  static const bool inKernel = getenv("SOS_ABS_SIGNAL_IN_KERNEL") != nullptr;
+  const int nb2 = n * (n + 1) / 2 + 1;
+  a.sg = {nullptr, nullptr, 0, 0};
+  ++ba->sig_st_seq;
+  if (inKernel && !ba->comm) {
+    ba->sig_abs_blocks_total += nb2;
+    a.sg.ctr = ba->d_sigctr.p + 24;
+    a.sg.flag = reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags + 64);
+    a.sg.target = ba->sig_abs_blocks_total;
+    a.sg.seq = ba->sig_st_seq;
+  }
+  k_abs_stitch2<<<nb2, 64, 0, st>>>(a);
   if (ba->comm) {  // THE exchange step of the path, on the stitched fp64 system (the stitch is linear): [H_A b_A | H_sc b_sc | count]
     const int rcc = sos_comm_allreduce_sum_f64(ba->comm, ba->d_Hout.p, 2 * ms + 1, st);
     if (rcc) return rcc;
     k_copy_f64<<<divup((int)(2 * ms + 1), 256), 256, 0, st>>>(pinH, ba->d_Hout.p, 2 * ms + 1);
   }
-  ++ba->sig_st_seq;
-  k_publish<<<1, 1, 0, st>>>(reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags + 64), ba->sig_st_seq);
+  if (!a.sg.ctr) k_publish<<<1, 1, 0, st>>>(reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags + 64), ba->sig_st_seq);
   ba->acc_inflight_haveL = false;
   ba->acc_inflight_abs = true;
   return SOS_OK;
@@ -4675,6 +4696,7 @@ extern "C" int sos_ba_time_kernel(sos_ba *ba, const char *kernel, const float *f
       a.adHost = ba->d_adHost.p; a.adTarget = ba->d_adTarget.p;
       a.Ctop = ba->d_C.p; a.Pcc = ba->d_C.p + 2 * nn * SOS_TOPC;
       a.H = ba->d_Hout.p; a.mode_stride = ba->hb_mode_stride;
+      a.sg = {nullptr, nullptr, 0, 0};
       const int T = ba->Dm >> 4;
       if (k == "abs_reduce_stitch1") k_abs_reduce_stitch1<<<(int)nn + T * (T + 1) / 2 * 16, 128, 0, st>>>(a);
       else k_abs_stitch2<<<n * (n + 1) / 2 + 1, 64, 0, st>>>(a);
