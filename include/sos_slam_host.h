@@ -245,6 +245,50 @@ int sosf_get_timing(double *phases8, int reset);
  * which = 0: blocked production variant, 1: unblocked reference variant.  Exposed for the CPU test-suite. */
 int sosf_ldlt_solve(const double *A, const double *b, double *x, int n, int which);
 
+/* ---- the frame-rate loop: FullSystem::addActiveFrame -> trackNewestCoarse -> traceNewCoarse -> keyframe decision -> makeKeyFrame
+ * (FS/FullSystem.cpp:616-766, 311-361, 783-931, 375-531, 1071-1097), visual part, in C++ (csrc/host/sos_sequence.cpp).  The object
+ * owns a CoarseTracker, a PixelSelector and the immature points of every keyframe (FrameHessian::immaturePoints).  The IMU / stereo
+ * branches of makeKeyFrame are not strung in yet (their stages are the sosf_imu_* / sosf_tracker_optimize_scale_kf calls). */
+typedef struct sosf_sequence sosf_sequence;
+typedef struct sosf_sequence_params {
+  sos_trace_params trace;
+  sos_activate_params activate;
+  sos_pixsel_params pixsel;
+  float desiredPointDensity;   /* setting_desiredPointDensity (util/settings.cpp:66) */
+  float immatureDensity;       /* setting_desiredImmatureDensity (:65) */
+  float minTraceQuality;       /* setting_minTraceQuality = 3 */
+  int32_t kfEvery;             /* > 0: every kfEvery-th frame is a keyframe (test sequences); 0: the decision of FS/FullSystem.cpp:709-732 */
+  int32_t maxOptIterations;    /* setting_maxOptIterations = 6 */
+  int32_t patternPadding;      /* 2 */
+  float kfGlobalWeight, maxShiftWeightT, maxShiftWeightR, maxShiftWeightRT, maxAffineWeight; /* util/settings.cpp:36-42 */
+} sosf_sequence_params;
+typedef struct sosf_frame_result {
+  int32_t trackingOk, isKeyframe;
+  double refToNew[12];         /* lastF_2_fh of trackNewCoarse */
+  double camToWorld[12];       /* shell->camToWorld = trackingRef->camToWorld * camToTrackingRef */
+  double aff[2];               /* aff_g2l */
+  double trackResiduals[5];    /* achievedRes */
+  double flow[3];              /* lastFlowIndicators */
+  /* keyframes only */
+  int32_t nActivated, nDeletedImmature, nPointsBeforeOpt, iterations;
+  float rmse;
+  int32_t nOutliersRemoved, nMargPoints, nDroppedPoints, nNewImmature, nMargFrames;
+  int32_t margFrameIDs[8];
+  double margCamToWorld[8 * 12];
+} sosf_frame_result;
+int sosf_sequence_create(sosf_system *sys, const sosf_sequence_params *prm, const uint8_t *randomPattern /* w*h, as sos_pixsel_create */,
+                         sosf_sequence **out);
+int sosf_sequence_destroy(sosf_sequence *seq);
+/* the window the initialiser hands over is in the system (sosf_add_frame* / sosf_add_points / sosf_add_residuals): optimize(),
+ * removeOutliers, setCoarseTrackingRef, makeNewTraces on every keyframe (FS/FullSystem.cpp:933-1069 tail) */
+int sosf_sequence_bootstrap(sosf_sequence *seq, float *rmse, int *iterations);
+/* FullSystem::addActiveFrame for the frame whose pyramid is in image slot `slot` (sos_undistort_frame / sosf_upload_image).
+ * T_init12: initial refToNew (NULL: the motion model).  A frame that does not become a keyframe leaves its slot to the caller
+ * (sosf_release_image); a keyframe's slot belongs to the window until the keyframe is marginalised. */
+int sosf_add_active_frame(sosf_sequence *seq, int slot, int frameID, float ab_exposure, const double *T_init12, sosf_frame_result *out);
+int sosf_sequence_immature_count(sosf_sequence *seq, int frameID, int *count);
+int sosf_sequence_get_immature(sosf_sequence *seq, int frameID, int capacity, sos_immature *out, float *type);
+
 /* ---- candidate selection of FullSystem::activatePointsMT (FS/FullSystem.cpp:375-470) with CoarseDistanceMap
  * (FS/CoarseTracker.cpp:766-954): host logic around sos_immature_activate.  The loop is inherently ordered (every
  * accepted candidate is inserted into the distance map before the next one is tested), so it stays on the host.

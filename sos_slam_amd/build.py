@@ -17,7 +17,7 @@ INCLUDE = os.path.join(HERE, "..", "include")
 
 HIP_SOURCES = ["sos_ctx.hip", "sos_ba.hip", "sos_tracker.hip", "sos_comm.hip", "sos_immature.hip", "sos_pixsel.hip", "sos_undistort.hip"]
 HIP_LIB = os.path.join(CSRC, "libsos_slam_hip.so")
-HOST_SOURCES = ["host/sos_host.cpp", "host/sos_imu.cpp"]
+HOST_SOURCES = ["host/sos_host.cpp", "host/sos_imu.cpp", "host/sos_sequence.cpp"]
 HOST_LIB = os.path.join(CSRC, "libsos_host.so")
 
 HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared",

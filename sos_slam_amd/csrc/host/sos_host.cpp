@@ -2372,6 +2372,7 @@ using namespace sos;
 struct sosf_system {
   FullSystem *fs;
 };
+sos::FullSystem *sosf_system_full(sosf_system *s) { return s ? s->fs : nullptr; }
 
 extern "C" int sosf_create(const sos_params *params, int device, void *hip_stream, sosf_system **out) {
   if (!params || !out) return SOS_ERR_ARG;

@@ -412,3 +412,6 @@ class CoarseTracker {
 };
 
 }  // namespace sos
+
+// the FullSystem behind a facade handle (for the other translation units of the facade)
+sos::FullSystem *sosf_system_full(sosf_system *s);

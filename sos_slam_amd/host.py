@@ -683,3 +683,59 @@ class ImuFrontEnd:
 def imu():
     """The facade's IMU / spline factor assembly (sosf_imu_*)."""
     return _ImuApi(load(), "sosf_imu_")
+
+
+class Sequence:
+    """sosf_sequence: the frame-rate loop of FullSystem in C++ (addActiveFrame -> track -> traceNewCoarse -> keyframe decision ->
+    makeKeyFrame), csrc/host/sos_sequence.cpp.  `sysm` holds the bootstrap window."""
+
+    def __init__(self, sysm: System, params, random_pattern):
+        from .records import SequenceParams
+        self.L, self.sysm = load(), sysm
+        assert isinstance(params, SequenceParams)
+        self.params = params
+        pat = np.ascontiguousarray(random_pattern, dtype=np.uint8)
+        self.h_ = C.c_void_p()
+        self.L.sosf_sequence_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _chk(self.L.sosf_sequence_create(sysm.h_, C.byref(self.params), _p(pat), C.byref(self.h_)), "sosf_sequence_create")
+        sysm._trackers = getattr(sysm, "_trackers", [])
+        sysm._trackers.append(self)     # closed before the system (it borrows the context)
+
+    def close(self):
+        if getattr(self, "h_", None):
+            if getattr(self.sysm, "h_", None):  # after the system is gone its context is gone too
+                self.L.sosf_sequence_destroy.argtypes = [C.c_void_p]
+                self.L.sosf_sequence_destroy(self.h_)
+            self.h_ = None
+        if self in getattr(self.sysm, "_trackers", []):
+            self.sysm._trackers.remove(self)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def bootstrap(self):
+        r, it = C.c_float(0), C.c_int(0)
+        self.L.sosf_sequence_bootstrap.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _chk(self.L.sosf_sequence_bootstrap(self.h_, C.byref(r), C.byref(it)), "sosf_sequence_bootstrap")
+        return r.value, it.value
+
+    def add_active_frame(self, slot, frame_id, T_init=None, ab_exposure=1.0):
+        from .records import FrameResult
+        out = FrameResult()
+        t = None if T_init is None else np.ascontiguousarray(T_init, dtype=np.float64)
+        self.L.sosf_add_active_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+        _chk(self.L.sosf_add_active_frame(self.h_, int(slot), int(frame_id), float(ab_exposure), _p(t), C.byref(out)), "sosf_add_active_frame")
+        return out
+
+    def immature(self, frame_id):
+        from .records import IMMATURE_DTYPE
+        c = C.c_int(0)
+        self.L.sosf_sequence_immature_count.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        _chk(self.L.sosf_sequence_immature_count(self.h_, int(frame_id), C.byref(c)), "sosf_sequence_immature_count")
+        rec, ty = np.zeros(c.value, dtype=IMMATURE_DTYPE), np.zeros(c.value, np.float32)
+        self.L.sosf_sequence_get_immature.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        _chk(self.L.sosf_sequence_get_immature(self.h_, int(frame_id), c.value, _p(rec), _p(ty)), "sosf_sequence_get_immature")
+        return rec, ty

@@ -145,3 +145,31 @@ def imu_dim(n):
 RESID_FINAL_DTYPE = np.dtype([("state_NewEnergy", "f4"), ("state_NewEnergyWithOutlier", "f4"), ("state_energy", "f4"),
                               ("centerProjectedTo", "f4", (3,)), ("state_NewState", "u1"), ("state_state", "u1"), ("active", "u1"),
                               ("pad", "u1")], align=True)
+
+
+class SequenceParams(C.Structure):
+    """sosf_sequence_params (include/sos_slam_host.h)"""
+    _fields_ = [("trace", TraceParams), ("activate", ActivateParams), ("pixsel", PixselParams),
+                ("desiredPointDensity", C.c_float), ("immatureDensity", C.c_float), ("minTraceQuality", C.c_float),
+                ("kfEvery", C.c_int32), ("maxOptIterations", C.c_int32), ("patternPadding", C.c_int32),
+                ("kfGlobalWeight", C.c_float), ("maxShiftWeightT", C.c_float), ("maxShiftWeightR", C.c_float),
+                ("maxShiftWeightRT", C.c_float), ("maxAffineWeight", C.c_float)]
+
+    @classmethod
+    def default(cls, desired_points=2000.0, immature_density=1500.0, kf_every=0):
+        p = cls()
+        p.trace, p.activate, p.pixsel = TraceParams.default(), ActivateParams.default(), PixselParams.default()
+        p.desiredPointDensity, p.immatureDensity, p.minTraceQuality = desired_points, immature_density, 3.0
+        p.kfEvery, p.maxOptIterations, p.patternPadding = kf_every, 6, 2
+        # util/settings.cpp:36-42
+        p.kfGlobalWeight, p.maxShiftWeightT, p.maxShiftWeightR, p.maxShiftWeightRT, p.maxAffineWeight = 1.0, 0.04 * (640 + 480), 0.0, 0.02 * (640 + 480), 2.0
+        return p
+
+
+class FrameResult(C.Structure):
+    """sosf_frame_result"""
+    _fields_ = [("trackingOk", C.c_int32), ("isKeyframe", C.c_int32), ("refToNew", C.c_double * 12), ("camToWorld", C.c_double * 12),
+                ("aff", C.c_double * 2), ("trackResiduals", C.c_double * 5), ("flow", C.c_double * 3),
+                ("nActivated", C.c_int32), ("nDeletedImmature", C.c_int32), ("nPointsBeforeOpt", C.c_int32), ("iterations", C.c_int32),
+                ("rmse", C.c_float), ("nOutliersRemoved", C.c_int32), ("nMargPoints", C.c_int32), ("nDroppedPoints", C.c_int32),
+                ("nNewImmature", C.c_int32), ("nMargFrames", C.c_int32), ("margFrameIDs", C.c_int32 * 8), ("margCamToWorld", C.c_double * 96)]

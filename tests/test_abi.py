@@ -68,7 +68,8 @@ def test_record_sizes_against_the_compiled_header(tmp_path):
                "sos_activation": records.ACTIVATION_DTYPE.itemsize, "sos_pixsel_params": C.sizeof(records.PixselParams),
                "sos_camera_model": C.sizeof(records.CameraModel), "sos_resid_final": records.RESID_FINAL_DTYPE.itemsize}
     src = tmp_path / "sizes.c"
-    src.write_text('#include <stdio.h>\n#include "sos_slam.h"\nint main(void) {\n' +
+    mirrors.update({"sosf_sequence_params": C.sizeof(records.SequenceParams), "sosf_frame_result": C.sizeof(records.FrameResult)})
+    src.write_text('#include <stdio.h>\n#include "sos_slam.h"\n#include "sos_slam_host.h"\nint main(void) {\n' +
                    "".join(f'  printf("{n} %zu\\n", sizeof({n}));\n' for n in mirrors) + "  return 0;\n}\n")
     exe = tmp_path / "sizes"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])

@@ -1,0 +1,80 @@
+"""The frame-rate loop in C++ (sosf_sequence: addActiveFrame -> trackNewestCoarse -> traceNewCoarse -> keyframe decision -> makeKeyFrame,
+csrc/host/sos_sequence.cpp) against the same loop strung together in Python over the same facade calls (tests/rolling.py DeviceChain,
+which the rolling-window tests hold against the oracle chains): same keyframes, same windows, same keyframes leaving in the same order,
+poses within the sensitivity two free-running chains have (their float transforms are formed with differently ordered 3 x 3 products)."""
+import numpy as np
+import pytest
+
+from sos_slam_amd import synth
+from sos_slam_amd.records import SequenceParams
+from tests import rolling
+
+pytestmark = pytest.mark.gpu
+
+
+def _cpp_chain(sc):
+    """a DeviceChain used for its front end and window set-up only; the loop runs in sosf_sequence"""
+    from sos_slam_amd import host
+    d = rolling.DeviceChain(sc)
+    hs = [d.front_end(sc.raw[i]) for i in range(sc.n0)]
+    images = [d.irradiance(h) for h in hs]
+    pts, res = sc.bootstrap_points(images)
+    d.init_window(hs, [sc.poses[i] for i in range(sc.n0)], [sc.aff_true[i] for i in range(sc.n0)], pts, res)
+    prm = SequenceParams.default(desired_points=sc.desired_points, immature_density=sc.immature_density, kf_every=sc.kf_every)
+    seq = host.Sequence(d.sysm, prm, sc.pattern)
+    return d, seq
+
+
+@pytest.mark.parametrize("kf_every,n_frames", [(1, 14), (3, 4 + 3 * 5)])
+def test_cpp_sequence_loop_matches_the_python_loop(kf_every, n_frames):
+    kw = dict(n_frames=n_frames, kf_every=kf_every)
+    if kf_every > 1:
+        kw.update(step=0.07 / 3, rot=0.008 / 3)
+    sc = rolling.Scenario(**kw)
+    ref = rolling.DeviceChain(sc)
+    r_ref, it_ref = ref.bootstrap()
+    d, seq = _cpp_chain(sc)
+    r_cpp, it_cpp = seq.bootstrap()
+    assert it_ref == it_cpp and abs(r_ref - r_cpp) <= 1e-6 * r_ref
+    for f in range(sc.n0):      # the first immature sets: pixel selection + constructors are bit-exact stages
+        rec, ty = seq.immature(f)
+        assert np.array_equal(rec["u"], ref.imm[f]["u"]) and np.array_equal(rec["energyTH"], ref.imm[f]["energyTH"])
+        assert np.array_equal(ty, ref.imm_type[f])
+    k, kfs, worst = sc.n0, 0, 0.0
+    while True:
+        lg = ref.step()
+        if lg is None:
+            break
+        # the same frames through the C++ loop, up to and including the keyframe
+        while True:
+            slot = d.front_end(sc.raw[k])
+            T_init = None
+            if k == sc.n0:   # the first frame has no motion history: the scenario's guess, as the Python loop takes it
+                ids = d.window_ids()
+                T_init = rolling.se3_mul(rolling.se3_inv(sc.poses[k]), sc.poses[k - 1] if kf_every == 1 else sc.poses[ids[-1]])
+                T_init = rolling.se3_mul(synth.se3_exp12(np.array([0.002, -0.001, 0.001, 0.001, -0.001, 0.0005])), T_init)
+            out = seq.add_active_frame(slot, k, T_init)
+            assert out.trackingOk == 1, k
+            k += 1
+            if out.isKeyframe:
+                break
+            d.sysm.release_image(slot)
+        assert k - 1 == lg.frameID
+        kfs += 1
+        assert d.window_ids() == lg.window_ids, (k, d.window_ids(), lg.window_ids)
+        assert list(out.margFrameIDs[:out.nMargFrames]) == [f for f, _ in lg.marginalized]
+        assert out.iterations == lg.iterations or abs(out.rmse - lg.rmse) <= 1e-3 * lg.rmse
+        e_trk = np.abs(np.array(out.refToNew[:]) - lg.tracked_pose).max()
+        assert e_trk < 1e-4, (k, e_trk)
+        for i, fid in enumerate(lg.window_ids):
+            e = np.abs(d.kf_pose(i) - lg.window_poses[fid]).max()
+            worst = max(worst, e)
+            assert e < 2e-4, (k, fid, e)
+        assert abs(out.nActivated - len(lg.activated)) <= max(4, 0.02 * len(lg.activated)), (out.nActivated, len(lg.activated))
+        assert abs(out.nMargPoints - lg.marg_points) <= max(4, 0.03 * lg.marg_points)
+        assert abs(out.nNewImmature - lg.new_immature) <= 2
+    print(f"{kfs} keyframes through both loops; worst window pose difference {worst:.2e}")
+    assert kfs >= 5
+    seq.close()
+    d.close()
+    ref.close()
