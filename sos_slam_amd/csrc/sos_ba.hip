@@ -2903,6 +2903,7 @@ struct sos_ba {
   sos_comm *comm = nullptr;
   int comm_size = 1, newest_cap = 0;
   bool anyL = false;  // some rank holds linearised residuals
+  bool anyEmpty = false;  // some rank's shard has no residuals / no points
   DevBuf<float> d_newest_local, d_newest_all;
   float *pin_newest = nullptr, *pin_newest_dev = nullptr;
   size_t pin_newest_floats = 0;
@@ -3575,15 +3576,17 @@ static int comm_setup_window(sos_ba *ba) {
   if (!ba->comm || !ba->have_window) return SOS_OK;
   hipStream_t st = ba->ctx->stream;
   ba->comm_size = sos_comm_size(ba->comm);
-  int h2[2] = {ba->newest_count, ba->ntiles > ba->ntilesA ? 1 : 0};
-  if (ba->d_tmp_int.ensure(2)) return SOS_ERR_NOMEM;
+  // [2]: a rank with an empty shard cannot take the absolute-coordinate Schur path; the ranks must pick the same exchange
+  int h2[3] = {ba->newest_count, ba->ntiles > ba->ntilesA ? 1 : 0, (ba->ntilesA <= 0 || ba->nchunks <= 0) ? 1 : 0};
+  if (ba->d_tmp_int.ensure(3)) return SOS_ERR_NOMEM;
   SOS_HIP(hipMemcpyAsync(ba->d_tmp_int.p, h2, sizeof(h2), hipMemcpyHostToDevice, st));
-  int rc = sos_comm_allreduce_max_i32(ba->comm, ba->d_tmp_int.p, 2, st);
+  int rc = sos_comm_allreduce_max_i32(ba->comm, ba->d_tmp_int.p, 3, st);
   if (rc) return rc;
   SOS_HIP(hipMemcpyAsync(h2, ba->d_tmp_int.p, sizeof(h2), hipMemcpyDeviceToHost, st));
   SOS_HIP(hipStreamSynchronize(st));
   ba->newest_cap = h2[0] > 0 ? h2[0] : 1;
   ba->anyL = h2[1] != 0;
+  ba->anyEmpty = h2[2] != 0;
   const size_t tot = (size_t)ba->newest_cap * ba->comm_size;
   if (ba->d_newest_local.ensure(ba->newest_cap) || ba->d_newest_all.ensure(tot)) return SOS_ERR_NOMEM;
   if (tot > ba->pin_newest_floats) {
@@ -3606,7 +3609,7 @@ extern "C" int sos_ba_set_comm(sos_ba *ba, sos_comm *comm) {
   ba->acc_inflight = false, ba->top_valid = false;
   ba->comm = comm;
   ba->comm_size = comm ? sos_comm_size(comm) : 1;
-  if (!comm) { ba->anyL = false; return SOS_OK; }
+  if (!comm) { ba->anyL = false, ba->anyEmpty = false; return SOS_OK; }
   return comm_setup_window(ba);
 }
 
@@ -3944,7 +3947,7 @@ extern "C" int sos_ba_accumulate(sos_ba *ba, double *H_A, double *b_A, double *H
 static bool abs_path_ok(const sos_ba *ba) {
   // opt-in (SOS_ABS_SC=1) until the GPU suite has run on it
   static const bool off = getenv("SOS_ABS_SC") == nullptr || getenv("SOS_NO_ABS_SC") != nullptr;
-  return !off && ba->ntiles == ba->ntilesA && ba->ntilesA > 0 && ba->nchunks > 0 && !(ba->comm && ba->anyL) && ba->d_adHostF.p &&
+  return !off && ba->ntiles == ba->ntilesA && ba->ntilesA > 0 && ba->nchunks > 0 && !(ba->comm && (ba->anyL || ba->anyEmpty)) && ba->d_adHostF.p &&
          ba->d_adTargetF.p;
 }
 static int enqueue_gn_accumulate_abs(sos_ba *ba, bool topDone, int *pubFlag, int pubSeq) {
