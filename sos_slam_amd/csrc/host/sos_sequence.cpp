@@ -14,7 +14,7 @@
 // branches of makeKeyFrame (:800-807, 841-849, 878-903) -- their stages exist as facade calls (sosf_imu_*, optimizeScaleKF) and are
 // strung by the caller -- and the initialiser (CoarseInitializer): the first window is handed over (sosf_sequence_bootstrap).
 //
-// NOT YET RUN ON A GPU: written while GPU access was withdrawn (round 3); tests/test_gpu_sequence_driver.py is its acceptance test.
+// PENDING_FIRST_GPU_RUN: written while GPU access was withdrawn (round 3); tests/test_gpu_sequence_driver.py is its acceptance test.
 #include <algorithm>
 #include <cmath>
 #include <cstring>

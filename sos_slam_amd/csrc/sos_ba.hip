@@ -3945,7 +3945,7 @@ extern "C" int sos_ba_accumulate(sos_ba *ba, double *H_A, double *b_A, double *H
 // straight into the device-mapped pinned block: no copy command between the last kernel and the host
 // the absolute-coordinate Schur path (k_sc_gram_abs): windows without linearised residuals on any rank
 static bool abs_path_ok(const sos_ba *ba) {
-  // opt-in (SOS_ABS_SC=1) until the GPU suite has run on it
+  // PENDING_FIRST_GPU_RUN: opt-in (SOS_ABS_SC=1) until the GPU suite has run on it
   static const bool off = getenv("SOS_ABS_SC") == nullptr || getenv("SOS_NO_ABS_SC") != nullptr;
   return !off && ba->ntiles == ba->ntilesA && ba->ntilesA > 0 && ba->nchunks > 0 && !(ba->comm && (ba->anyL || ba->anyEmpty)) && ba->d_adHostF.p &&
          ba->d_adTargetF.p;
