@@ -11,19 +11,19 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 F='^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl'
-timeout 1500 python -X faulthandler -m pytest tests -m gpu -q > $OUT/gputests_default.log 2>&1
-grep -v "$F" $OUT/gputests_default.log | grep -E "passed|failed|FAILED|Fatal" | head -12
+timeout 1500 python -X faulthandler -m pytest tests -m gpu -q -rxX > $OUT/gputests_default.log 2>&1
+grep -v "$F" $OUT/gputests_default.log | grep -E "passed|failed|FAILED|Fatal|XPASS|XFAIL" | head -20
 SOS_ABS_SC=1 timeout 1500 python -X faulthandler -m pytest tests/test_gpu_backend.py tests/test_gpu_optimize.py tests/test_gpu_baseline_sizes.py \
   tests/test_gpu_distributed.py tests/test_gpu_edge_windows.py tests/test_gpu_variants.py tests/test_gpu_bench_rehearsal.py tests/test_golden.py \
   tests/test_golden_t6.py tests/test_gpu_imu_hook.py tests/test_gpu_rolling_window.py tests/test_gpu_rolling_vio.py tests/test_gpu_rolling_ensemble.py \
   tests/test_gpu_keyframe_pipeline.py tests/test_gpu_marginalize.py -q > $OUT/gputests_abs.log 2>&1
 grep -v "$F" $OUT/gputests_abs.log | grep -E "passed|failed|FAILED|Fatal" | head -12
-python tools/first_solve_probe.py 2>&1 | grep variant | sed 's/^/default: /'
-SOS_ABS_SC=1 python tools/first_solve_probe.py 2>&1 | grep variant | sed 's/^/abs:     /'
+timeout 300 python tools/first_solve_probe.py 2>&1 | grep variant | sed 's/^/default: /'
+SOS_ABS_SC=1 timeout 300 python tools/first_solve_probe.py 2>&1 | grep variant | sed 's/^/abs:     /'
 for W in W12 W16; do
-  python bench.py --window $W --no-cpu-baseline > $OUT/bench_${W}_default.json 2>> $OUT/bench.err
-  SOS_ABS_SC=1 python bench.py --window $W --no-cpu-baseline > $OUT/bench_${W}_abs.json 2>> $OUT/bench.err
-  SOS_ABS_SC=1 SOS_ABS_SIGNAL_IN_KERNEL=1 python bench.py --window $W --no-cpu-baseline > $OUT/bench_${W}_abs_sig.json 2>> $OUT/bench.err
+  timeout 300 python bench.py --window $W --no-cpu-baseline > $OUT/bench_${W}_default.json 2>> $OUT/bench.err
+  SOS_ABS_SC=1 timeout 300 python bench.py --window $W --no-cpu-baseline > $OUT/bench_${W}_abs.json 2>> $OUT/bench.err
+  SOS_ABS_SC=1 SOS_ABS_SIGNAL_IN_KERNEL=1 timeout 300 python bench.py --window $W --no-cpu-baseline > $OUT/bench_${W}_abs_sig.json 2>> $OUT/bench.err
 done
 python - <<PY
 import json, glob, os
@@ -36,7 +36,17 @@ for f in sorted(glob.glob("$OUT/bench_*.json")):
     except Exception as e:
         print(f, "ERR", e)
 PY
-(cd /tmp && SOS_ABS_SC=1 rocprofv3 --kernel-trace --stats -d $OUT/prof_abs -o b -- python $OLDPWD/bench.py --no-cpu-baseline --steps 30 --inner 50 > /dev/null 2>> $OUT/prof.err)
+(cd /tmp && SOS_ABS_SC=1 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_abs -o b -- python $OLDPWD/bench.py --no-cpu-baseline --steps 30 --inner 50 > /dev/null 2>> $OUT/prof.err)
 python tools/rocpd_summary.py kernels $OUT/prof_abs/b_results.db $OUT/bench_abs_kernel_stats.csv
 rm -rf $OUT/prof_abs
 head -12 $OUT/bench_abs_kernel_stats.csv | cut -c1-50,150-260
+# the tracker after the scratch removal (r03n: trackNewestCoarse 0.235 ms, 9.1 us per evaluation)
+timeout 300 python tools/tracker_bench.py W12 > $OUT/tracker_W12.json 2>> $OUT/bench.err
+python - <<PY
+import json
+try:
+    d = json.load(open("$OUT/tracker_W12.json"))
+    print("tracker", {k: v for k, v in d.items() if "ms" in k or "us" in k})
+except Exception as e:
+    print("tracker ERR", e)
+PY
