@@ -57,6 +57,7 @@ def parse():
                     help="visual-inertial window (BASELINE.json configs 2-3): the IMU / spline block of solveSystemF "
                          "(OB/EnergyFunctional.cpp:1053-1171) sits between stitch and solve on the host")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--side", choices=("imu",), default=None, help=argparse.SUPPRESS)   # one side measurement as its own process
     ap.add_argument("--cpu-seconds", type=float, default=14.0)
     a = ap.parse_args()
     if a.window is None:
@@ -150,6 +151,14 @@ GN_LOOP_NAMES = {0: "host solve (blocked LDL^T) and host-side step, device every
 
 def main():
     args = parse()
+    if args.side == "imu":   # child of side_process(): the measurement alone, one JSON line
+        import torch
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
+        os.write(json_fd, (json.dumps(imu_timing(args.window, int(os.environ.get("LOCAL_RANK", "0")))) + "\n").encode())
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
     if args.gpus != int(os.environ.get("WORLD_SIZE", "1")):
@@ -367,10 +376,7 @@ def main():
                 out["keyframe_ms"] = out["keyframe"]["keyframe_ms"]
             except Exception as e:  # noqa: BLE001
                 out["keyframe"] = {"error": repr(e)}
-            try:
-                out["visual_inertial"] = imu_timing(args.window, local_rank)
-            except Exception as e:  # noqa: BLE001
-                out["visual_inertial"] = {"error": repr(e)}
+            out["visual_inertial"] = side_process("imu", args.window)
         if not args.no_cpu_baseline and world == 1:
             out["tracker"] = tracker_timing(args.window, local_rank)
             out["cpu_baseline"] = cpu_baseline(win, args.cpu_seconds)
@@ -379,6 +385,21 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def side_process(what, window, timeout=240):
+    """A side measurement in a process of its own: whatever happens to it (an exception, a crash of the native code, a hang) costs
+    its entry of the line, not the line."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--side", what, "--window", window]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout)
+        lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": f"exit code {r.returncode}"}
+        return json.loads(lines[-1])
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)}
 
 
 def keyframe_timing(window, device):

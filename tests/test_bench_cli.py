@@ -38,3 +38,17 @@ def test_no_cpu_fallback():
 def test_gpus_flag_must_match_the_launcher():
     p = _run("--gpus", "2", "--steps", "1", "--warmup", "0", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr, p.stderr[-400:]
+
+
+def test_side_measurement_process_fails_loudly_without_a_gpu_and_costs_only_its_entry():
+    if _have_gpu():
+        return
+    p = _run("--side", "imu", "--window", "W7")
+    assert p.returncode != 0 and "no CPU fallback" in p.stderr and p.stdout.strip() == ""
+    sys.path.insert(0, ROOT)
+    try:
+        import bench
+        r = bench.side_process("imu", "W7", timeout=120)   # the parent's view of the same failure: an error entry, no exception
+    finally:
+        sys.path.pop(0)
+    assert set(r) == {"error"} and "exit code" in r["error"]
