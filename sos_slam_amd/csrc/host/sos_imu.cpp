@@ -134,7 +134,8 @@ void get_Hi(const sosf_imu_settings &S, const sosf_imu_calib &C, const sosf_imu_
   const M3 rot_i_w = Ric * rot_t_w;
   const M3 R_acc_t_hat = Ric * M3::hat(rot_t_w * acc_w);
   double Js[6] = {0, 0, 0, 0, 0, 0};
-  std::vector<double> Jf(6 * 29, 0.0);
+  double Jf[6 * 29];
+  std::memset(Jf, 0, sizeof(Jf));
   auto J = [&](int r, int c) -> double & { return Jf[29 * r + c]; };
   const V3 ra = rot_i_w * a;
   for (int i = 0; i < 3; i++) Js[i] = kScale * ra[i];
@@ -286,16 +287,12 @@ void add_frame(const sosf_imu_settings &S, const sosf_imu_calib &C, int n, const
     }
   };
   HiOut hi;
-  if (C.scale_trapped) {  // first-estimate Jacobians: the per-sample Hessians are summed once (setImuStateZero) and added whole
-    double sHss = 0;
-    std::vector<double> sHff(29 * 29, 0.0), sHfs(29, 0.0);
-    for (int j = 0; j < cur.n_imu; j++) {
-      get_Hi(S, C, cur, cur.imu[7 * j] - cur.timestamp, hi);
-      sHss += hi.Hss;
-      for (int k = 0; k < 29 * 29; k++) sHff[k] += hi.Hff[k];
-      for (int k = 0; k < 29; k++) sHfs[k] += hi.Hfs[k];
-    }
-    add_H(sHss, sHff.data(), sHfs.data());
+  // first-estimate Jacobians (scale trapped): the per-sample Hessians are summed (setImuStateZero) and added whole -- the sums are
+  // formed in the sample loop below, from the same get_Hi call that serves the right-hand side
+  double sHss = 0, sHff[29 * 29], sHfs[29];
+  if (C.scale_trapped) {
+    std::memset(sHff, 0, sizeof(sHff));
+    std::memset(sHfs, 0, sizeof(sHfs));
   }
   const M3 Ric = M3::from(S.rot_imu_cam), Rwc = Rc.T();
   const double scale_scaled = C.scale * kScale;
@@ -312,6 +309,11 @@ void add_frame(const sosf_imu_settings &S, const sosf_imu_calib &C, int n, const
     }
     get_Hi(S, C, cur, tt, hi);
     if (!C.scale_trapped) add_H(hi.Hss, hi.Hff, hi.Hfs);
+    else {
+      sHss += hi.Hss;
+      for (int k = 0; k < 29 * 29; k++) sHff[k] += hi.Hff[k];
+      for (int k = 0; k < 29; k++) sHfs[k] += hi.Hfs[k];
+    }
     double s = 0;
     for (int k = 0; k < 6; k++) s += hi.JsTW[k] * res[k];
     A.b[CP] += s;
@@ -321,6 +323,7 @@ void add_frame(const sosf_imu_settings &S, const sosf_imu_calib &C, int n, const
       A.b[ci + r] += t;
     }
   }
+  if (C.scale_trapped && cur.n_imu > 0) add_H(sHss, sHff, sHfs);
 }
 
 Assembly assemble(const sosf_imu_settings &S, const sosf_imu_calib &C, int n, const sosf_imu_frame *F) {
@@ -387,7 +390,17 @@ extern "C" int sosf_imu_solve(const sosf_imu_settings *S, const sosf_imu_calib *
   const int dimI = SOSF_IMU_DIM(n);
   static const bool tmg = getenv("SOS_TIMING_IMU") != nullptr;
   const double tA0 = tmg ? now_us() : 0;
-  Assembly A = assemble(*S, *C, n, F);  // H_imu, b_imu, constraints
+  // H_imu, b_imu, constraints.  H_imu is block-sparse (a 29 x 29 block per keyframe, the 6 x 6 bias blocks between neighbours, the
+  // scale row / column); its dense dimI x dimI holder is kept between calls and cleared block by block after use instead of being
+  // allocated and zeroed (1 MB) per solve
+  static thread_local std::unique_ptr<Assembly> PA;
+  if (!PA || PA->H.rows != dimI || (int)PA->spline_valid.size() != n) PA.reset(new Assembly(dimI, n));
+  Assembly &A = *PA;
+  std::fill(A.b.begin(), A.b.end(), 0.0);
+  A.Jrows.clear();
+  A.r.clear();
+  std::fill(A.spline_valid.begin(), A.spline_valid.end(), 0);
+  for (int i = 1; i < n; i++) add_frame(*S, *C, n, F, i, A);
   const double tA1 = tmg ? now_us() : 0;
   // The KKT system of OB/EnergyFunctional.cpp:1062-1140 formed in ONE pass over the kept states, already Jacobi-scaled:
   //   K = [(H_imu + expand(H_top) + HM) with the diagonal times (1 + lambda)  -  expand(H_sc) / (1 + lambda)   J^T ; J  0]
@@ -417,26 +430,35 @@ extern "C" int sosf_imu_solve(const sosf_imu_settings *S, const sosf_imu_calib *
   for (int r = 0; r < ms; r++) pos[keep[r]] = r;
   const double f = 1.0f / (1 + lambda);
   // right-hand side of the kept states (HM d2 runs over ALL expanded columns) and the unscaled diagonal
-  bf.assign(m, 0.0);
+  const double tB0 = tmg ? now_us() : 0;
+  bf.assign(m, 0.0);  // here: the visual part b_top - b_sc; the prior's H_M d2 joins in the fill loop below, which has the row in cache
   diagK.assign(m, 0.0);
   for (int r = 0; r < ms; r++) {
     const int g = keep[r];
-    const double *hm = HM + (size_t)g * dimI;
-    double sv = bM[g] + A.b[g];
-    for (int c = 0; c < dimI; c++) sv += hm[c] * d2[c];
-    bf[r] = sv;
-    diagK[r] = A.H(g, g) + hm[g];
+    diagK[r] = A.H(g, g) + HM[(size_t)g * dimI + g];
   }
   for (int a = 0; a < d0; a++) {
     const int r = pos[gidx(a)];
     if (r < 0) continue;
-    bf[r] += b_top[a] - b_sc[a];
+    bf[r] = b_top[a] - b_sc[a];
     diagK[r] += H_top[(size_t)a * d0 + a];
   }
+  const double tB1 = tmg ? now_us() : 0;
   static thread_local std::vector<double> K, rhs, sI, sol;
-  K.assign((size_t)m * m, 0.0);
+  K.resize((size_t)m * m);  // the state block is written whole below; the multiplier rows / columns are cleared here
+  for (int r = 0; r < ms; r++) std::memset(&K[(size_t)r * m + ms], 0, sizeof(double) * cdim);
+  for (int k = 0; k < cdim; k++) std::memset(&K[(size_t)(ms + k) * m + ms + k], 0, sizeof(double) * (cdim - k));  // (upper triangle)
   rhs.assign(m, 0.0);
   sI.assign(m, 0.0);
+  // the kept states are a few runs of consecutive expanded indices: (first expanded index, first kept position, length)
+  struct Run { int g0, r0, len; };
+  static thread_local std::vector<Run> runs;
+  runs.clear();
+  for (int r = 0; r < ms; r++) {
+    if (!runs.empty() && runs.back().g0 + runs.back().len == keep[r]) runs.back().len++;
+    else runs.push_back(Run{keep[r], r, 1});
+  }
+  const double tB2 = tmg ? now_us() : 0;
   for (int r = 0; r < ms; r++) diagK[r] *= (1 + lambda);
   for (int a = 0; a < d0; a++) {
     const int r = pos[gidx(a)];
@@ -448,12 +470,54 @@ extern "C" int sosf_imu_solve(const sosf_imu_settings *S, const sosf_imu_calib *
     const double *hm = HM + (size_t)g * dimI, *hi = &A.H.a[(size_t)g * dimI];
     double *kr = &K[(size_t)r * m];
     const double sr = sI[r];
-    for (int c = 0; c < ms; c++) {
-      const int gc = keep[c];
-      kr[c] = (hi[gc] + hm[gc]) * (sr * sI[c]);
+    {  // H_M d2 over ALL expanded columns (a single running sum is a chain of dimI dependent additions, 4 cycles each: four vector
+       // accumulators, combined at the end)
+      __m256d a0 = _mm256_setzero_pd(), a1 = a0, a2 = a0, a3 = a0;
+      int c = 0;
+      for (; c + 16 <= dimI; c += 16) {
+        a0 = _mm256_add_pd(a0, _mm256_mul_pd(_mm256_loadu_pd(hm + c), _mm256_loadu_pd(&d2[c])));
+        a1 = _mm256_add_pd(a1, _mm256_mul_pd(_mm256_loadu_pd(hm + c + 4), _mm256_loadu_pd(&d2[c + 4])));
+        a2 = _mm256_add_pd(a2, _mm256_mul_pd(_mm256_loadu_pd(hm + c + 8), _mm256_loadu_pd(&d2[c + 8])));
+        a3 = _mm256_add_pd(a3, _mm256_mul_pd(_mm256_loadu_pd(hm + c + 12), _mm256_loadu_pd(&d2[c + 12])));
+      }
+      double t4[4];
+      _mm256_storeu_pd(t4, _mm256_add_pd(_mm256_add_pd(a0, a1), _mm256_add_pd(a2, a3)));
+      double dot = (t4[0] + t4[1]) + (t4[2] + t4[3]);
+      for (; c < dimI; c++) dot += hm[c] * d2[c];
+      bf[r] = ((bM[g] + A.b[g]) + dot) + bf[r];
+    }
+    // (only the upper triangle, c >= r: it is all the factorisation reads)
+    if (g == CP) {  // the scale row of H_imu is dense
+      for (const Run &u : runs) {
+        const double *h1 = hi + u.g0, *h2 = hm + u.g0, *sc = &sI[u.r0];
+        double *ko = kr + u.r0;
+        for (int i = std::max(0, r - u.r0); i < u.len; i++) ko[i] = (h1[i] + h2[i]) * (sr * sc[i]);
+      }
+    } else {
+      for (const Run &u : runs) {
+        const double *h2 = hm + u.g0, *sc = &sI[u.r0];
+        double *ko = kr + u.r0;
+        for (int i = std::max(0, r - u.r0); i < u.len; i++) ko[i] = h2[i] * (sr * sc[i]);  // == (0 + hm) * scale of the dense form
+      }
+      if (g > CP) {  // ... and the entries of the row where H_imu has blocks, in the dense form's arithmetic
+        const int fi = (g - CP - 1) / 29, k = (g - CP - 1) % 29;
+        auto span = [&](int g0, int len) {
+          for (int gc = g0; gc < g0 + len; gc++) {
+            const int c = pos[gc];
+            if (c >= r) kr[c] = (hi[gc] + hm[gc]) * (sr * sI[c]);
+          }
+        };
+        span(CP, 1);
+        span(CP + 1 + 29 * fi, 29);
+        if (k >= 8 && k < 14) {
+          if (fi > 0) span(CP + 1 + 29 * (fi - 1) + 8, 6);
+          if (fi < n - 1) span(CP + 1 + 29 * (fi + 1) + 8, 6);
+        }
+      }
     }
     rhs[r] = bf[r] * sr;
   }
+  const double tB3 = tmg ? now_us() : 0;
   for (int a = 0; a < d0; a++) {  // the visual system: dense over calibration and poses
     const int r = pos[gidx(a)];
     if (r < 0) continue;
@@ -462,24 +526,41 @@ extern "C" int sosf_imu_solve(const sosf_imu_settings *S, const sosf_imu_calib *
     const double sr = sI[r];
     for (int b2 = 0; b2 < d0; b2++) {
       const int c = pos[gidx(b2)];
-      if (c >= 0) kr[c] += (ht[b2] - hs[b2] * f) * (sr * sI[c]);
+      if (c >= r) kr[c] += (ht[b2] - hs[b2] * f) * (sr * sI[c]);
     }
   }
+  const double tB4 = tmg ? now_us() : 0;
   for (int r = 0; r < ms; r++) K[(size_t)r * m + r] = diagK[r] * sI[r] * sI[r];  // (1 + lambda) on the whole diagonal
   for (int k = 0; k < cdim; k++) {
     const std::vector<double> &J = A.Jrows[k];
-    double *kk = &K[(size_t)(ms + k) * m];
     const double sk = sI[ms + k];
     for (int r = 0; r < ms; r++) {
       const double v = J[keep[r]];
-      if (v != 0.0) kk[r] = K[(size_t)r * m + ms + k] = v * (sk * sI[r]);
+      if (v != 0.0) K[(size_t)r * m + ms + k] = v * (sk * sI[r]);
     }
     rhs[ms + k] = A.r[k] * sk;
+  }
+  {  // H_imu back to zero for the next call (the blocks add_frame can touch)
+    double *Hh = A.H.a.data();
+    std::memset(Hh + (size_t)CP * dimI, 0, sizeof(double) * dimI);
+    for (int i = 0; i < n; i++) {
+      const int bi = CP + 1 + 29 * i;
+      for (int r = 0; r < 29; r++) {
+        double *row = Hh + (size_t)(bi + r) * dimI;
+        row[CP] = 0.0;
+        std::memset(row + bi, 0, sizeof(double) * 29);
+        if (r >= 8 && r < 14) {
+          if (i > 0) std::memset(row + bi - 29 + 8, 0, sizeof(double) * 6);
+          if (i < n - 1) std::memset(row + bi + 29 + 8, 0, sizeof(double) * 6);
+        }
+      }
+    }
   }
   const double tA2 = tmg ? now_us() : 0;
   // blocked LDL^T with threshold pivoting on the diagonal (sos_math.hpp): the KKT matrix is indefinite, but quasi-definite in the order
   // states first, multipliers last -- the multipliers only become pivots once the states they constrain are eliminated
-  sos::ldlt_solve(K, rhs, sol, m);
+  sos::ldlt_solve(K, rhs, sol, m, K.data());  // in place: K is rebuilt by every call
+  if (tmg) fprintf(stderr, "[imu_build] pre %.0f rhs %.0f zero %.0f fill %.0f visual %.0f cst %.0f\n", tB0 - tA1, tB1 - tB0, tB2 - tB1, tB3 - tB2, tB4 - tB3, tA2 - tB4);
   if (tmg) fprintf(stderr, "[imu_solve] assemble %.0f us, dense build (dim %d, kkt %d) %.0f us, ldlt %.0f us\n", tA1 - tA0, dimI, m, tA2 - tA1, now_us() - tA2);
   for (int i = 0; i < m; i++) sol[i] *= sI[i];
   // split into the dso increment, the scale step and the IMU steps

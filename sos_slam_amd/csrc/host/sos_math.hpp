@@ -7,8 +7,13 @@
 #include <immintrin.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 namespace sos {
@@ -374,19 +379,176 @@ inline bool ldlt_have_avx512() {
   static const bool have = __builtin_cpu_supports("avx512f") && getenv("SOS_NO_AVX512") == nullptr;
   return have;
 }
-__attribute__((target("avx2,fma"))) inline void ldlt_solve(const std::vector<double> &A, const std::vector<double> &b, std::vector<double> &x, int n) {
+
+// ---- the LARGE solves (the visual-inertial KKT system, dimension 4 + 1 + 29 n + constraints = 401 at n = 12) on a few cores --------
+// 97 % of the work of the factorisation is the rank-NB update of the trailing matrix, independent per row.  Rows are owned in
+// groups of three (the register tile of the update), cyclically by ABSOLUTE row index: a row stays in the cache of the core that
+// owns it from the copy-in to its elimination, and what is computed for an element does not depend on the number of threads.
+// The helpers are parked on a condition variable between solves and spin on a generation counter inside one (a panel is ~1 us).
+template <int R>
+__attribute__((target("avx512f,fma"))) inline void ldlt_rows_512(double *U, const double *WT, const double *LT, int n, int j, int kb) {
   const size_t N = (size_t)n;
-  static thread_local std::vector<double> U, D, y, diag, WT, LT;
-  static thread_local std::vector<int> perm;
-  U.resize(N * N); D.resize(N); y.resize(N); diag.resize(N); perm.resize(N);
-  WT.resize((size_t)LDLT_NB * N); LT.resize((size_t)LDLT_NB * N);
-  for (int j = 0; j < n; j++) {
-    const double *src = &A[j * N];  // A is symmetric: row j right of the diagonal == column j below it
-    double *dst = &U[j * N];
-    for (int i = j + 1; i < n; i++) dst[i] = src[i];
-    diag[j] = src[j];
+  double *r[R];
+  for (int a = 0; a < R; a++) r[a] = U + (size_t)(j + a) * N;
+  for (int a = 0; a < R; a++)  // entries between the rows of the group
+    for (int b = a + 1; b < R; b++) {
+      double sv = 0;
+      for (int c = 0; c < kb; c++) sv += LT[c * N + j + a] * WT[c * N + j + b];
+      r[a][j + b] -= sv;
+    }
+  __m512d l[R][8];
+  const double *w[8];
+  for (int c = 0; c < 8; c++) {
+    const bool on = c < kb;
+    for (int a = 0; a < R; a++) l[a][c] = _mm512_set1_pd(on ? LT[c * N + j + a] : 0.0);
+    w[c] = WT + (size_t)(on ? c : 0) * N;
   }
+  for (int i = j + R; i < n; i += 8) {
+    const __mmask8 m = (n - i >= 8) ? (__mmask8)0xff : (__mmask8)((1u << (n - i)) - 1u);
+    __m512d acc[R];
+    for (int a = 0; a < R; a++) acc[a] = _mm512_maskz_loadu_pd(m, r[a] + i);
+#pragma GCC unroll 8
+    for (int c = 0; c < 8; c++) {
+      const __m512d wv = _mm512_maskz_loadu_pd(m, w[c] + i);
+      for (int a = 0; a < R; a++) acc[a] = _mm512_fnmadd_pd(l[a][c], wv, acc[a]);
+    }
+    for (int a = 0; a < R; a++) _mm512_mask_storeu_pd(r[a] + i, m, acc[a]);
+  }
+}
+inline int ldlt_owner(int j, int T) { return (j / 3) % T; }
+// the share of thread `tid` of  U[j][i] -= sum_c L(j,c) W(i,c),  k1 <= j < i < n
+__attribute__((target("avx512f,fma"))) inline void ldlt_trailing_update_512_mt(double *U, const double *WT, const double *LT, int n, int k1, int kb, int tid,
+                                                                               int T) {
+  int j = k1;
+  const int head = std::min((3 - k1 % 3) % 3, n - k1);  // rows up to the next group boundary (the rest of a group begun by the panel)
+  if (head > 0) {
+    if (ldlt_owner(j, T) == tid) {
+      if (head == 2) ldlt_rows_512<2>(U, WT, LT, n, j, kb);
+      else ldlt_rows_512<1>(U, WT, LT, n, j, kb);
+    }
+    j += head;
+  }
+  for (; j + 2 < n; j += 3)
+    if (ldlt_owner(j, T) == tid) ldlt_rows_512<3>(U, WT, LT, n, j, kb);
+  if (n - j == 2 && ldlt_owner(j, T) == tid) ldlt_rows_512<2>(U, WT, LT, n, j, kb);  // (the last row has nothing right of the diagonal)
+}
+
+struct SolvePool {
+  enum { JOB_COPY = 1, JOB_UPDATE = 2 };
+  int T = 1;  // threads of a large solve, the caller included
+  std::vector<std::thread> th;
+  std::atomic<int> gen{0}, done{0};
+  std::atomic<bool> awake{false};
+  bool quit = false;
+  std::mutex mu;
+  std::condition_variable cv;
+  // the job
+  int job = 0, n = 0, k1 = 0, kb = 0;
+  const double *A = nullptr, *WT = nullptr, *LT = nullptr;
+  double *U = nullptr, *diag = nullptr;
+
+  SolvePool() {
+    // opt-in (SOS_SOLVE_THREADS=<n>): on the build container (8 virtual CPUs of a shared host) the helpers made the solve slower;
+    // whether they pay on the GPU box's host is for tools/validate_pending.sh to say
+    const char *e = getenv("SOS_SOLVE_THREADS");
+    T = e ? atoi(e) : 1;
+    if (T < 1 || !ldlt_have_avx512()) T = 1;
+    if (T > 16) T = 16;
+    for (int t = 1; t < T; t++) th.emplace_back([this, t] { worker(t); });
+  }
+  ~SolvePool() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      quit = true;
+    }
+    cv.notify_all();
+    for (std::thread &t : th) t.join();
+  }
+  void share(int tid) const {
+    if (job == JOB_COPY) {
+      const size_t N = (size_t)n;
+      for (int j = 0; j < n; j++)
+        if (ldlt_owner(j, T) == tid) {
+          const double *src = A + j * N;
+          double *dst = U + j * N;
+          for (int i = j + 1; i < n; i++) dst[i] = src[i];
+          diag[j] = src[j];
+        }
+    } else if (job == JOB_UPDATE) {
+      ldlt_trailing_update_512_mt(U, WT, LT, n, k1, kb, tid, T);
+    }
+  }
+  void worker(int tid) {
+    int seen = 0;  // (the pool is constructed with gen == 0 before any job; a helper that starts late must not skip the first one)
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return quit || awake.load(std::memory_order_acquire); });
+        if (quit) return;
+      }
+      while (awake.load(std::memory_order_acquire)) {
+        const int g = gen.load(std::memory_order_acquire);
+        if (g == seen) {
+          _mm_pause();
+          continue;
+        }
+        seen = g;
+        share(tid);
+        done.fetch_add(1, std::memory_order_release);
+      }
+    }
+  }
+  void begin() {  // wake the helpers for one solve
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      awake.store(true, std::memory_order_release);
+    }
+    cv.notify_all();
+  }
+  void end() { awake.store(false, std::memory_order_release); }
+  void run(int what) {  // every thread does its share of the job; returns when all are through
+    job = what;
+    done.store(0, std::memory_order_relaxed);
+    gen.fetch_add(1, std::memory_order_release);
+    share(0);
+    while (done.load(std::memory_order_acquire) != T - 1) _mm_pause();
+  }
+};
+inline SolvePool &solve_pool() {
+  static SolvePool pool;
+  return pool;
+}
+#define LDLT_MT_MIN_DIM 192  // below it (the visual system: 100 at W12, 132 at W16) a panel's update is too short to share
+// `inplace` != nullptr: the caller's matrix (== A.data(), upper triangle filled) is factorised where it lies and is destroyed -- the
+// large systems are built for this one solve, copying them first is 1.3 MB of traffic at dimension 401
+__attribute__((target("avx2,fma"))) inline void ldlt_solve(const std::vector<double> &A, const std::vector<double> &b, std::vector<double> &x, int n,
+                                                           double *inplace = nullptr) {
+  const size_t N = (size_t)n;
+  static thread_local std::vector<double> Uown, D, y, diag, WT, LT;
+  static thread_local std::vector<int> perm;
+  if (!inplace) Uown.resize(N * N);
+  double *const U = inplace ? inplace : Uown.data();
+  D.resize(N); y.resize(N); diag.resize(N); perm.resize(N);
+  WT.resize((size_t)LDLT_NB * N); LT.resize((size_t)LDLT_NB * N);
   const bool wide = ldlt_have_avx512();
+  SolvePool *pool = (wide && n >= LDLT_MT_MIN_DIM) ? &solve_pool() : nullptr;
+  if (pool && pool->T < 2) pool = nullptr;
+  if (pool) {
+    pool->n = n; pool->A = A.data(); pool->U = U; pool->diag = diag.data(); pool->WT = WT.data(); pool->LT = LT.data();
+    pool->begin();
+  }
+  if (inplace) {
+    for (int j = 0; j < n; j++) diag[j] = U[j * N + j];
+  } else if (pool) {
+    pool->run(SolvePool::JOB_COPY);
+  } else {
+    for (int j = 0; j < n; j++) {
+      const double *src = &A[j * N];  // A is symmetric: row j right of the diagonal == column j below it
+      double *dst = &U[j * N];
+      for (int i = j + 1; i < n; i++) dst[i] = src[i];
+      diag[j] = src[j];
+    }
+  }
   double restMax = -1.0;  // max |diag[k..n)| when the previous pivot's pass has left it (512-bit path), else < 0
   for (int k0 = 0; k0 < n; k0 += LDLT_NB) {
     const int kb = std::min(LDLT_NB, n - k0), k1 = k0 + kb;
@@ -448,10 +610,14 @@ __attribute__((target("avx2,fma"))) inline void ldlt_solve(const std::vector<dou
       }
     }
     if (k1 < n) {
-      if (wide) ldlt_trailing_update_512(U.data(), WT.data(), LT.data(), n, k1, kb);
-      else ldlt_trailing_update(U.data(), WT.data(), LT.data(), n, k1, kb);
+      if (pool) {
+        pool->k1 = k1; pool->kb = kb;
+        pool->run(SolvePool::JOB_UPDATE);
+      } else if (wide) ldlt_trailing_update_512(U, WT.data(), LT.data(), n, k1, kb);
+      else ldlt_trailing_update(U, WT.data(), LT.data(), n, k1, kb);
     }
   }
+  if (pool) pool->end();
   for (int i = 0; i < n; i++) y[i] = b[i];
   for (int k = 0; k < n; k++) {  // L z = P b, column-oriented: L(i,k) = U[k][i]
     std::swap(y[k], y[perm[k]]);

@@ -1,0 +1,62 @@
+"""The facade's blocked LDL^T on the LARGE systems (the visual-inertial KKT solve, dimension 401 at twelve keyframes): the in-place
+form used by sosf_imu_solve and the opt-in helper threads (SOS_SOLVE_THREADS) against the unblocked reference solve.  CPU only.
+The threaded runs happen in child processes with a timeout -- a barrier that does not release is a failure, not a hung suite."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_CHILD = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, %r)
+from sos_slam_amd import host
+out = {}
+for n in (100, 192, 401):
+    rng = np.random.default_rng(n)
+    B = rng.normal(size=(n, n + 4))
+    A = B @ B.T / n + np.eye(n)
+    # an indefinite border like the multipliers of the KKT system (zero diagonal, quasi-definite in this order)
+    k = 24 if n > 100 else 0
+    if k:
+        J = np.zeros((k, n - k)); J[np.arange(k), rng.integers(0, n - k, k)] = 1.0; J += 0.1 * rng.normal(size=J.shape) * (rng.random(J.shape) < 0.05)
+        A[n - k:, :n - k] = J; A[:n - k, n - k:] = J.T; A[n - k:, n - k:] = 0
+    b = rng.normal(size=n)
+    xs = [host.ldlt_solve(A, b, 0) for _ in range(3)]
+    assert all(np.array_equal(xs[0], x) for x in xs[1:])
+    xr = host.ldlt_solve(A, b, 1)
+    out[str(n)] = {"x": xs[0].tolist(), "err_ref": float(np.abs(xs[0] - xr).max() / np.abs(xr).max()),
+                   "resid": float(np.linalg.norm(A @ xs[0] - b) / np.linalg.norm(b))}
+print(json.dumps(out))
+"""
+
+
+def _run(threads):
+    env = dict(os.environ)
+    env.pop("SOS_SOLVE_THREADS", None)
+    if threads:
+        env["SOS_SOLVE_THREADS"] = str(threads)
+    p = subprocess.run([sys.executable, "-c", _CHILD % ROOT], capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_large_solve_single_thread_and_helper_threads_agree():
+    base = _run(None)
+    for n, r in base.items():
+        assert r["err_ref"] < 1e-9 and r["resid"] < 1e-10, (n, r)
+    two, three = _run(2), _run(3)
+    for n in base:
+        assert two[n]["err_ref"] < 1e-9 and two[n]["resid"] < 1e-10
+        # rows are owned by absolute index: what is computed for an element does not depend on the number of threads
+        assert two[n]["x"] == three[n]["x"], n
+        # below the threshold dimension the helpers are not used at all
+        if int(n) < 192:
+            assert two[n]["x"] == base[n]["x"]
+        else:
+            assert np.allclose(two[n]["x"], base[n]["x"], rtol=1e-9, atol=1e-12)

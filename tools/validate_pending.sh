@@ -50,3 +50,17 @@ try:
 except Exception as e:
     print("tracker ERR", e)
 PY
+# the visual-inertial iteration (r03n: 0.60 ms, host KKT solve 0.50 ms) after the leaner assembly / build, and with helper threads
+for T in 1 2 4; do
+  SOS_SOLVE_THREADS=$T timeout 300 python bench.py --imu --no-cpu-baseline --steps 10 --inner 60 > $OUT/bench_imu_T$T.json 2>> $OUT/bench.err
+done
+SOS_TIMING_IMU=1 timeout 120 python tools/imu_solve_bench.py W12 20 2>&1 | grep imu_solve | tail -3
+python - <<PY
+import json, glob, os
+for f in sorted(glob.glob("$OUT/bench_imu_T*.json")):
+    try:
+        d = json.load(open(f))
+        print(os.path.basename(f), "ms/iter %.3f" % d["ms_per_step"], "loop", d["config"].get("gn_loop"), "resInA", d["config"]["resInA_last_iteration"])
+    except Exception as e:
+        print(f, "ERR", e)
+PY
