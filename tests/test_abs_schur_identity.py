@@ -48,3 +48,76 @@ def test_gram_of_stitched_rows_is_the_stitched_schur_complement(name):
     assert np.abs(H_abs - H_ref).max() <= 2e-5 * np.abs(H_ref).max(), np.abs(H_abs - H_ref).max() / np.abs(H_ref).max()
     assert np.abs(b_abs - b_ref).max() <= 2e-5 * np.abs(b_ref).max()
     ow.close()
+
+
+def _tile_decode(ut, T):
+    mt, rem = 0, ut
+    while rem >= T - mt:
+        rem -= T - mt
+        mt += 1
+    return mt, rem
+
+
+@pytest.mark.parametrize("n,nchunks", [(3, 5), (6, 19), (12, 70), (17, 9)])
+def test_index_arithmetic_of_the_gram_store_and_the_chunk_sum(n, nchunks):
+    """k_sc_gram_abs stores only the 16 x 16 tiles on and above the diagonal of each chunk's Gram matrix (lane (kq, col) of the wave
+    owning tile `ut` writes rows m0 + 4 kq + 0..3, column n0 + col); k_abs_reduce_stitch1 sums them over the chunks (block = one row of
+    one tile, thread = (column, one of eight chunk classes)) and scatters Gram order [frames | calib | b] into the system order
+    [calib | frames].  The two index schemes transliterated from the kernels, run on random symmetric per-chunk matrices: every
+    entry of the upper triangle of H_sc and of b_sc must be written, from positions the Gram kernel has written, with the right sum."""
+    rng = np.random.default_rng(n * 100 + nchunks)
+    cols = 8 * n + 5
+    Dm = (cols + 15) // 16 * 16
+    T = Dm // 16
+    full = rng.normal(size=(nchunks, Dm, Dm))
+    full = full + full.transpose(0, 2, 1)
+    full[:, cols:, :] = 0
+    full[:, :, cols:] = 0                      # the padding columns of A are zero in the kernel
+    gram_part = np.full((nchunks, Dm, Dm), np.nan)
+    for blk in range(nchunks):                 # ---- the store of k_sc_gram_abs
+        for wave in range(4):
+            for ut in range(wave, T * (T + 1) // 2, 4):
+                mt, rem = _tile_decode(ut, T)
+                m0, n0 = mt << 4, (mt + rem) << 4
+                for lane in range(64):
+                    kq, col = lane >> 4, lane & 15
+                    for rgi in range(4):
+                        gram_part[blk, m0 + kq * 4 + rgi, n0 + col] = full[blk, m0 + kq * 4 + rgi, n0 + col]
+    dim = 4 + 8 * n
+    Hs, bs = np.full((dim, dim), np.nan), np.full(dim, np.nan)
+    writes = np.zeros((dim, dim), int)
+    for b in range(T * (T + 1) // 2 * 16):     # ---- the H_sc | b_sc half of k_abs_reduce_stitch1
+        ut, rr = b >> 4, b & 15
+        mt, rem = _tile_decode(ut, T)
+        sPart = np.zeros((8, 16))
+        for tid in range(128):
+            r, c, sub = (mt << 4) + rr, ((mt + rem) << 4) + (tid & 15), tid >> 4
+            sv = 0.0
+            if r < cols - 1 and c < cols and c >= r:
+                k0 = sub
+                while k0 < nchunks:
+                    for u in range(8):
+                        if k0 + 8 * u < nchunks:
+                            sv += gram_part[k0 + 8 * u, r, c]
+                    k0 += 64
+            sPart[sub][tid & 15] = sv
+        for tid in range(16):
+            r, c = (mt << 4) + rr, ((mt + rem) << 4) + tid
+            if r < cols - 1 and c < cols and c >= r:
+                tot = sum(sPart[u][tid] for u in range(8))
+                R = 4 + r if r < 8 * n else r - 8 * n
+                if c == cols - 1:
+                    assert np.isnan(bs[R])
+                    bs[R] = tot
+                else:
+                    Cc = 4 + c if c < 8 * n else c - 8 * n
+                    i, j = (R, Cc) if R <= Cc else (Cc, R)
+                    Hs[i, j] = tot
+                    writes[i, j] += 1
+    G = full.sum(axis=0)
+    order = np.array([8 * n + k for k in range(4)] + list(range(8 * n)))
+    H_ref, b_ref = G[np.ix_(order, order)], G[order, 8 * n + 4]
+    iu = np.triu_indices(dim)
+    assert not np.isnan(Hs[iu]).any() and not np.isnan(bs).any()
+    assert (writes[iu] == 1).all() and writes[np.tril_indices(dim, -1)].sum() == 0      # each entry once, nothing below the diagonal
+    assert np.allclose(Hs[iu], H_ref[iu], rtol=1e-12, atol=1e-12) and np.allclose(bs, b_ref, rtol=1e-12, atol=1e-12)
