@@ -65,7 +65,15 @@ def test_optimize_pose_rmse_and_index_sets(name):
     assert np.abs(pg["maxRelBaseline"] - mrb_o).max() <= 1e-4 * np.abs(mrb_o).max()
     assert np.abs(mrb_o).max() > 0
     idh_o = ow.point_field("idepth_hessian")
-    assert np.abs(pg["idepth_hessian"] - idh_o).max() <= 2e-3 * np.abs(idh_o).max()
+    e_idh = np.abs(pg["idepth_hessian"] - idh_o).max() / np.abs(idh_o).max()
+    assert e_idh <= 2e-3
+    # the yardstick form of the same check (verdict of round 2: 2e-3 is loose for a per-point fp32 sum).  On the CPU the oracle's own
+    # fp32-vs-fp64 distance is 1e-5 / 4e-6 / 7e-5 at W7 / W12 / W16, so the bar would be max(1e-4, 3 x that).  Written while the GPU
+    # was unreachable: reported as a warning until the device's number has been seen once, then to become the assertion.
+    y_idh = np.abs(idh_o - ot.point_field("idepth_hessian")).max() / np.abs(idh_o).max()
+    import warnings
+    warnings.warn(f"idepth_hessian {name}: device-oracle {e_idh:.3g}, oracle-truth {y_idh:.3g}, candidate bar {max(1e-4, 3 * y_idh):.3g} "
+                  f"({'within' if e_idh <= max(1e-4, 3 * y_idh) else 'OUTSIDE'})")
     po = ow.pts()
     assert np.abs(pg["idepth"] - po["idepth_scaled"]).max() <= 1e-4
     sysm.close()
