@@ -13,6 +13,7 @@ export TMPDIR=/tmp
 F='^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl'
 timeout 1500 python -X faulthandler -m pytest tests -m gpu -q -rxX > $OUT/gputests_default.log 2>&1
 grep -v "$F" $OUT/gputests_default.log | grep -E "passed|failed|FAILED|Fatal|XPASS|XFAIL" | head -20
+grep -h "idepth_hessian W" $OUT/gputests_default.log | sort -u | head -6
 SOS_ABS_SC=1 timeout 1500 python -X faulthandler -m pytest tests/test_gpu_backend.py tests/test_gpu_optimize.py tests/test_gpu_baseline_sizes.py \
   tests/test_gpu_distributed.py tests/test_gpu_edge_windows.py tests/test_gpu_variants.py tests/test_gpu_bench_rehearsal.py tests/test_golden.py \
   tests/test_golden_t6.py tests/test_gpu_imu_hook.py tests/test_gpu_rolling_window.py tests/test_gpu_rolling_vio.py tests/test_gpu_rolling_ensemble.py \
