@@ -248,7 +248,7 @@ int sosf_ldlt_solve(const double *A, const double *b, double *x, int n, int whic
 /* ---- the frame-rate loop: FullSystem::addActiveFrame -> trackNewestCoarse -> traceNewCoarse -> keyframe decision -> makeKeyFrame
  * (FS/FullSystem.cpp:616-766, 311-361, 783-931, 375-531, 1071-1097), visual part, in C++ (csrc/host/sos_sequence.cpp).  The object
  * owns a CoarseTracker, a PixelSelector and the immature points of every keyframe (FrameHessian::immaturePoints).  The IMU / stereo
- * branches of makeKeyFrame are not strung in yet (their stages are the sosf_imu_* / sosf_tracker_optimize_scale_kf calls). */
+ * branches of makeKeyFrame: sosf_sequence_enable_imu / _enable_stereo + sosf_add_active_frame_ex, declared behind the IMU records below. */
 typedef struct sosf_sequence sosf_sequence;
 typedef struct sosf_sequence_params {
   sos_trace_params trace;
@@ -275,6 +275,7 @@ typedef struct sosf_frame_result {
   int32_t nOutliersRemoved, nMargPoints, nDroppedPoints, nNewImmature, nMargFrames;
   int32_t margFrameIDs[8];
   double margCamToWorld[8 * 12];
+  float newScale, scaleError;  /* stereo branch: FullSystem::optimizeScale of this keyframe (newScale -1: rejected / not run) */
 } sosf_frame_result;
 int sosf_sequence_create(sosf_system *sys, const sosf_sequence_params *prm, const uint8_t *randomPattern /* w*h, as sos_pixsel_create */,
                          sosf_sequence **out);
@@ -415,6 +416,26 @@ int sosf_set_imu(sosf_system *sys, const sosf_imu_settings *S, sosf_imu_calib *c
 int sosf_get_imu_prior(sosf_system *sys, double *HM, double *bM, int *dim);
 /* scale_step and step_imu (n x 21) of the last solve */
 int sosf_get_imu_step(sosf_system *sys, double *scale_step, double *step_imu);
+
+/* ---- the IMU / stereo branches of the frame-rate loop (FS/FullSystem.cpp:800-807 setImuData + propagateImuState, :841-849 initializeImu
+ * at the fifth keyframe, FS/FullSystemOptimize.cpp:437-479 shell poses / updateVel / setImuStateZero / tryTrapScale, :878-886, :897-903
+ * optimizeScale, FS/FullSystemMarginalize.cpp:226-228 sample hand-over).  The sequence keeps per keyframe the FrameShell fields, the 21
+ * IMU states with their linearisation point and the samples, and the IMU part of CalibHessian; the facade keeps the expanded prior. */
+typedef struct sosf_frame_extra {
+  double timestamp;     /* shell->timestamp */
+  int32_t n_imu;        /* samples since the previous frame (FullSystem::addActiveFrame's new_imu_data) */
+  int32_t stereoSlot;   /* image slot of the stereo partner, -1: none (released by the caller after the call) */
+  const double *imu;    /* n_imu x 7: timestamp, acc xyz, gyro xyz */
+} sosf_frame_extra;
+/* after the bootstrap window is in the system, before sosf_sequence_bootstrap: timestamps / samples of its keyframes in window order */
+int sosf_sequence_enable_imu(sosf_sequence *seq, const sosf_imu_settings *S, int nBoot, const double *timestamps, const int32_t *n_imu,
+                             const double *const *imu);
+int sosf_sequence_enable_stereo(sosf_sequence *seq, const double *tfmF0ToF1_12, float scaleOptThres /* setting_scale_opt_thres */);
+int sosf_sequence_bootstrap_ex(sosf_sequence *seq, int stereoSlot /* of the newest bootstrap keyframe, -1: none */, float *rmse, int *iterations);
+int sosf_add_active_frame_ex(sosf_sequence *seq, int slot, int frameID, float ab_exposure, const double *T_init12, const sosf_frame_extra *extra,
+                             sosf_frame_result *out);
+int sosf_sequence_get_imu(sosf_sequence *seq, int frameID, double *state21, double *zero21, double *vel3);
+int sosf_sequence_get_imu_calib(sosf_sequence *seq, sosf_imu_calib *out);
 
 /* direct access to the underlying context / backend handles (tracker tests share the frame store) */
 sos_ctx *sosf_ctx(sosf_system *sys);

@@ -10,9 +10,9 @@
 //   FullSystem::makeNewTraces       :1071-1097                  PixelSelector::makeMaps + new ImmaturePoint per selected pixel
 //
 // Every stage is a call that already existed (facade C++ classes, device C-ABI); what is new is the loop that strings them together
-// and the per-keyframe containers of the immature points (FrameHessian::immaturePoints).  Out of this first form: the IMU / stereo
-// branches of makeKeyFrame (:800-807, 841-849, 878-903) -- their stages exist as facade calls (sosf_imu_*, optimizeScaleKF) and are
-// strung by the caller -- and the initialiser (CoarseInitializer): the first window is handed over (sosf_sequence_bootstrap).
+// and the per-keyframe containers of the immature points (FrameHessian::immaturePoints).  The IMU / stereo branches of makeKeyFrame
+// (:800-807, 841-849, 878-903; FS/FullSystemOptimize.cpp:437-479) are strung in behind sosf_sequence_enable_imu / _enable_stereo and
+// sosf_add_active_frame_ex.  Out of scope: the initialiser (CoarseInitializer) -- the first window is handed over (sosf_sequence_bootstrap).
 //
 // PENDING_FIRST_GPU_RUN: written while GPU access was withdrawn (round 3); tests/test_gpu_sequence_driver.py is its acceptance test.
 #include <algorithm>
@@ -40,6 +40,26 @@ struct sosf_sequence {
   std::vector<SE3> trackHist;        // camToWorld of the last tracked frames
   int framesSinceKF = 0;
   double lastCoarseRMSE0 = -1;
+  // ---- visual-inertial branch (setting_enable_imu): per keyframe the FrameShell fields, the 21 IMU states (unscaled) with their
+  // linearisation point and FrameHessian::imu_data; the IMU part of CalibHessian; FullSystem::imu_data (samples since the last keyframe)
+  struct VioFrame {
+    double ts = 0, c2w[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}, vel[3] = {0, 0, 0}, state[21] = {0}, zero[21] = {0};
+    std::vector<double> imu;  // n x 7
+  };
+  bool vio = false;
+  sosf_imu_settings S;
+  sosf_imu_calib cal = {1.0 / 200.0, 1.0 / 200.0, 0, 0};
+  std::map<int, VioFrame> vf;
+  std::vector<sosf_imu_frame> winRecs;  // the records the facade's solve reads (one per keyframe of the window, renewed before use)
+  std::vector<double> pendingImu;
+  double scaleQueue[10] = {-10, -20, -30, -40, -50, -60, -70, -80, -90, -100};  // CalibHessian's ring, LinSpaced(10, -10, -100)
+  int32_t scaleQi = 0;
+  int nKfTotal = 0;
+  // ---- stereo branch (FullSystem::optimizeScale on the stereo partner of every keyframe)
+  bool stereo = false;
+  SE3 stereoTfm;
+  float scaleOptThres = 0;
+  CoarseTracker::ScaleOptState scaleState;
 };
 
 namespace {
@@ -242,11 +262,95 @@ int activate_points(sosf_sequence *q, int *nActivated, int *nDeleted) {
   return SOS_OK;
 }
 
-// FullSystem::makeKeyFrame for the tracked frame in `slot` (FS/FullSystem.cpp:783-931, visual part)
-int make_keyframe(sosf_sequence *q, int slot, int frameID, const SE3 &c2w, const AffLight &aff, float ab_exposure, sosf_frame_result *out) {
+// FullSystem::optimizeScale on the stereo partner in `stereoSlot`; HCalib.setScaleScaledZero when it is accepted (FS/FullSystem.cpp:1117-1177)
+int optimize_scale(sosf_sequence *q, int stereoSlot, float *newScale, float *scaleError) {
+  FullSystem *fs = q->fs;
+  const float K1[4] = {fs->HCalib.fxl(), fs->HCalib.fyl(), fs->HCalib.cxl(), fs->HCalib.cyl()};
+  const float refScale = (float)(200.0 * q->cal.scale);  // shell->trackingRef->scale = HCalib.getScaleScaled() of the last optimize
+  float err = 0;
+  const float ns = q->ct->optimizeScaleKF(stereoSlot, q->stereoTfm, K1, refScale, q->ct->levels - 1, q->scaleOptThres, q->scaleState, &err);
+  if (newScale) *newScale = ns;
+  if (scaleError) *scaleError = err;
+  if (ns > 0) q->cal.scale = q->cal.scale_zero = (double)(1.0f / 200.0f) * (double)ns;
+  return SOS_OK;
+}
+
+// ---- visual-inertial helpers: records / shells of a keyframe from the sequence's own state
+const double kImuScale[21] = {100, 100, 100, 1, 1, 1, 100, 100, 100, 1000, 1000, 1000, 1000, 1000, 1000, 1000, 1000, 1000, 1000, 1000, 1000};  // SCALE_BA, BG, SL_ROT, SQ_TRANS, SQ_ROT, SC_TRANS, SC_ROT
+
+sosf_imu_frame vio_record(sosf_sequence *q, int fid) {
+  const sosf_sequence::VioFrame &v = q->vf[fid];
+  sosf_imu_frame f;
+  std::memset(&f, 0, sizeof(f));
+  f.timestamp = v.ts;
+  std::memcpy(f.camToWorld, v.c2w, sizeof(v.c2w));
+  std::memcpy(f.evalPT_R, v.c2w, sizeof(double) * 9);
+  std::memcpy(f.state_imu, v.state, sizeof(v.state));
+  std::memcpy(f.state_imu_zero, v.zero, sizeof(v.zero));
+  f.trackingRefIsPrev = fid > 0 ? 1 : 0;
+  f.n_imu = (int32_t)(v.imu.size() / 7);
+  f.imu = v.imu.empty() ? nullptr : v.imu.data();
+  return f;
+}
+sosf_imu_shell vio_shell(sosf_sequence *q, int fid) {
+  const sosf_sequence::VioFrame &v = q->vf[fid];
+  sosf_imu_shell sh;
+  sh.timestamp = v.ts;
+  std::memcpy(sh.camToWorld, v.c2w, sizeof(v.c2w));
+  std::memcpy(sh.velInWorld, v.vel, sizeof(v.vel));
+  return sh;
+}
+// sosf_set_imu(sys, S, calib, records, NULL, NULL): the facade keeps the expanded prior; the records are renewed from the sequence's state
+void vio_push(sosf_sequence *q) {
+  FullSystem *fs = q->fs;
+  q->winRecs.clear();
+  for (FrameHessian *fh : fs->frameHessians) q->winRecs.push_back(vio_record(q, fh->frameID));
+  EnergyFunctional *ef = fs->ef;
+  ef->imuSettings = &q->S; ef->imuCalib = &q->cal; ef->imuFrames = q->winRecs.data(); ef->imuHM = nullptr; ef->imuBM = nullptr;
+  if (!ef->imuOwnPrior) ef->imuAdoptPrior();
+}
+void vio_pull(sosf_sequence *q) {  // the states the solve stepped (doStepFromBackup with unit step factors)
+  FullSystem *fs = q->fs;
+  for (size_t i = 0; i < fs->frameHessians.size() && i < q->winRecs.size(); i++)
+    std::memcpy(q->vf[fs->frameHessians[i]->frameID].state, q->winRecs[i].state_imu, sizeof(double) * 21);
+}
+int vio_update_vel(sosf_sequence *q, int fid, int lastFid) {  // FrameHessian::updateVel(last_shell)
+  const sosf_imu_frame rec = vio_record(q, fid);
+  sosf_imu_shell sh = vio_shell(q, fid);
+  const sosf_imu_shell shl = vio_shell(q, lastFid);
+  const int rc = sosf_imu_update_vel(&rec, &sh, &shl);
+  if (rc == SOS_OK) std::memcpy(q->vf[fid].vel, sh.velInWorld, sizeof(sh.velInWorld));
+  return rc;
+}
+
+// FullSystem::makeKeyFrame for the tracked frame in `slot` (FS/FullSystem.cpp:783-931)
+int make_keyframe(sosf_sequence *q, int slot, int frameID, const SE3 &c2w, const AffLight &aff, float ab_exposure, const sosf_frame_extra *extra,
+                  sosf_frame_result *out) {
   FullSystem *fs = q->fs;
   for (FrameHessian *fh : fs->frameHessians) fh->numImmature = (int)q->imm[fh->frameID].size();
   fs->flagFramesForMarginalization();  // :798
+  if (q->vio) {  // fh->setImuData(imu_data); propagateImuState(allKeyFramesHistory.back(), coarseTracker->lastRef->imu_bias), :800-807
+    sosf_sequence::VioFrame &v = q->vf[frameID];
+    v = sosf_sequence::VioFrame();
+    v.ts = extra ? extra->timestamp : 0.0;
+    c2w.to12(v.c2w);
+    v.imu.swap(q->pendingImu);
+    q->pendingImu.clear();
+    if (q->cal.imu_initialized) {
+      const int last = fs->frameHessians.back()->frameID;
+      double bias6[6];
+      for (int i = 0; i < 6; i++) bias6[i] = kImuScale[i] * q->vf[last].state[i];
+      sosf_imu_frame rec = vio_record(q, frameID);
+      sosf_imu_shell sh = vio_shell(q, frameID);
+      const sosf_imu_shell shl = vio_shell(q, last);
+      const int rci = sosf_imu_propagate_state(&q->S, &q->cal, &rec, &sh, &shl, bias6);
+      if (rci != SOS_OK) return rci;
+      std::memcpy(v.state, rec.state_imu, sizeof(v.state));
+      std::memcpy(v.zero, rec.state_imu_zero, sizeof(v.zero));
+      std::memcpy(v.vel, sh.velInWorld, sizeof(v.vel));
+    }
+    q->nKfTotal++;
+  }
   double c2w12[12], st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   c2w.to12(c2w12);
   st[6] = aff.a / SOS_SCALE_A;
@@ -259,18 +363,70 @@ int make_keyframe(sosf_sequence *q, int slot, int frameID, const SE3 &c2w, const
   int rc = activate_points(q, &out->nActivated, &out->nDeletedImmature);  // :837
   if (rc != SOS_OK) return rc;
   out->nPointsBeforeOpt = fs->ef->nPoints;
+  const bool imuInitNow = q->vio && q->nKfTotal == 5;
+  if (imuInitNow) {  // imu initialization on the first five keyframes, :841-849
+    const int n5 = (int)fs->frameHessians.size();
+    if (n5 != 5) return SOS_ERR_STATE;  // the window must still hold them
+    sosf_imu_frame recs[5];
+    sosf_imu_shell shs[5];
+    for (int i = 0; i < 5; i++) {
+      const int fid = fs->frameHessians[i]->frameID;
+      recs[i] = vio_record(q, fid);
+      fs->frameHessians[i]->PRE_camToWorld.to12(recs[i].camToWorld);
+      shs[i] = vio_shell(q, fid);
+    }
+    int ok = 0;
+    rc = sosf_imu_initialize(&q->S, &q->cal, recs, shs, &ok);
+    if (rc != SOS_OK) return rc;
+    if (!ok) return SOS_ERR_STATE;  // "IMU initialization failed"
+    for (int i = 0; i < 5; i++) {
+      sosf_sequence::VioFrame &v = q->vf[fs->frameHessians[i]->frameID];
+      std::memcpy(v.state, recs[i].state_imu, sizeof(v.state));
+      std::memcpy(v.zero, recs[i].state_imu_zero, sizeof(v.zero));
+      std::memcpy(v.vel, shs[i].velInWorld, sizeof(v.vel));
+    }
+    q->cal.imu_initialized = 1;
+  }
+  const bool imuOn = q->vio && q->cal.imu_initialized;
   int its = 0;
+  if (imuOn) vio_push(q);
   out->rmse = fs->optimize(q->prm.maxOptIterations, &its);  // :853
   out->iterations = its;
   if (fs->lastError != SOS_OK) return fs->lastError;
+  if (imuOn) vio_pull(q);
+  if (q->vio) {
+    const int nw = (int)fs->frameHessians.size();
+    for (FrameHessian *fh : fs->frameHessians) fh->PRE_camToWorld.to12(q->vf[fh->frameID].c2w);  // shell->camToWorld = PRE_camToWorld, FS/FullSystemOptimize.cpp:437-443
+    if (imuOn && nw >= 2) {  // :459-479
+      const int last = fs->frameHessians[nw - 1]->frameID, prev = fs->frameHessians[nw - 2]->frameID;
+      if ((rc = vio_update_vel(q, last, prev)) != SOS_OK) return rc;
+      std::memcpy(q->vf[last].zero, q->vf[last].state, sizeof(double) * 21);
+      if (q->S.enable_scale_opt) q->cal.scale_trapped = 1;
+      if (!q->cal.scale_trapped) {
+        sosf_imu_try_trap_scale(&q->cal, q->scaleQueue, &q->scaleQi, 1e-4);
+        if (q->cal.scale_trapped)
+          for (FrameHessian *fh : fs->frameHessians) std::memcpy(q->vf[fh->frameID].zero, q->vf[fh->frameID].state, sizeof(double) * 21);
+      }
+    }
+  }
   {
     const int before = fs->ef->nPoints;
     fs->removeOutliers();  // :875
     out->nOutliersRemoved = before - fs->ef->nPoints;
   }
+  if (imuInitNow) {  // reset imu states for imu initialization, :878-886
+    for (size_t i = 0; i < fs->frameHessians.size(); i++) {
+      const int fid = fs->frameHessians[i]->frameID;
+      std::memcpy(q->vf[fid].zero, q->vf[fid].state, sizeof(double) * 21);
+      if (i > 0 && (rc = vio_update_vel(q, fid, fs->frameHessians[i - 1]->frameID)) != SOS_OK) return rc;
+    }
+  }
   q->ct->makeK(&fs->HCalib);  // :887-895
   rc = q->ct->setCoarseTrackingRef(fs->frameHessians);
   if (rc != SOS_OK) return rc;
+  if (q->stereo && extra && extra->stereoSlot >= 0) {  // scale optimization, :897-903
+    if ((rc = optimize_scale(q, extra->stereoSlot, &out->newScale, &out->scaleError)) != SOS_OK) return rc;
+  }
   rc = fs->flagPointsForRemoval(&out->nMargPoints, &out->nDroppedPoints);  // :908-912
   if (rc != SOS_OK) return rc;
   out->nNewImmature = make_new_traces(q, fs->frameHessians.back());  // :915
@@ -280,9 +436,23 @@ int make_keyframe(sosf_sequence *q, int slot, int frameID, const SE3 &c2w, const
   for (FrameHessian *f : fs->frameHessians)
     if (f->flaggedForMarginalization) flaggedIDs.push_back(f->frameID);
   int cnt = 0;
+  std::vector<int> win;
+  for (FrameHessian *f : fs->frameHessians) win.push_back(f->frameID);
+  if (q->vio && q->cal.imu_initialized) vio_push(q);  // the IMU form of marginalizeFrame reads the records of the window as it is now
   rc = fs->marginalizeFlaggedFrames(8, out->margFrameIDs, out->margCamToWorld, &cnt);
   if (rc != SOS_OK) return rc;
   out->nMargFrames = cnt;
+  for (int k = 0; k < cnt && q->vio; k++) {  // the samples of a leaving keyframe go in front of its successor's (FS/FullSystemMarginalize.cpp:226-228)
+    const int fid = out->margFrameIDs[k];
+    const auto it = std::find(win.begin(), win.end(), fid);
+    if (it == win.end()) continue;
+    if (it + 1 != win.end()) {
+      std::vector<double> &nxt = q->vf[*(it + 1)].imu, &cur = q->vf[fid].imu;
+      nxt.insert(nxt.begin(), cur.begin(), cur.end());
+    }
+    win.erase(it);
+    q->vf.erase(fid);
+  }
   for (int id : flaggedIDs) {
     q->imm.erase(id);
     q->immType.erase(id);
@@ -319,7 +489,49 @@ extern "C" int sosf_sequence_destroy(sosf_sequence *q) {
 
 // the window the initialiser would hand over is in the system already (sosf_add_frame / _points / _residuals): first optimize(),
 // removeOutliers, tracking reference, and makeNewTraces on every bootstrap keyframe
-extern "C" int sosf_sequence_bootstrap(sosf_sequence *q, float *rmse, int *iterations) {
+extern "C" int sosf_sequence_enable_imu(sosf_sequence *q, const sosf_imu_settings *S, int nBoot, const double *timestamps, const int32_t *n_imu,
+                                        const double *const *imu) {
+  if (!q || !S || nBoot < 0 || (nBoot && !timestamps)) return SOS_ERR_ARG;
+  FullSystem *fs = q->fs;
+  if ((int)fs->frameHessians.size() != nBoot) return SOS_ERR_STATE;
+  q->vio = true;
+  q->S = *S;
+  q->vf.clear();
+  for (int i = 0; i < nBoot; i++) {  // the shells of the window the initialiser handed over: poses as they are, velocities and states zero
+    sosf_sequence::VioFrame &v = q->vf[fs->frameHessians[i]->frameID];
+    v.ts = timestamps[i];
+    fs->frameHessians[i]->PRE_camToWorld.to12(v.c2w);
+    if (n_imu && imu && n_imu[i] > 0 && imu[i]) v.imu.assign(imu[i], imu[i] + (size_t)7 * n_imu[i]);
+  }
+  q->nKfTotal = nBoot;
+  return SOS_OK;
+}
+
+extern "C" int sosf_sequence_enable_stereo(sosf_sequence *q, const double *tfmF0ToF1_12, float scaleOptThres) {
+  if (!q || !tfmF0ToF1_12) return SOS_ERR_ARG;
+  q->stereo = true;
+  q->stereoTfm = SE3::from12(tfmF0ToF1_12);
+  q->scaleOptThres = scaleOptThres;
+  return SOS_OK;
+}
+
+extern "C" int sosf_sequence_get_imu(sosf_sequence *q, int frameID, double *state21, double *zero21, double *vel3) {
+  if (!q) return SOS_ERR_ARG;
+  const auto it = q->vf.find(frameID);
+  if (it == q->vf.end()) return SOS_ERR_STATE;
+  if (state21) std::memcpy(state21, it->second.state, sizeof(double) * 21);
+  if (zero21) std::memcpy(zero21, it->second.zero, sizeof(double) * 21);
+  if (vel3) std::memcpy(vel3, it->second.vel, sizeof(double) * 3);
+  return SOS_OK;
+}
+
+extern "C" int sosf_sequence_get_imu_calib(sosf_sequence *q, sosf_imu_calib *out) {
+  if (!q || !out) return SOS_ERR_ARG;
+  *out = q->cal;
+  return SOS_OK;
+}
+
+extern "C" int sosf_sequence_bootstrap_ex(sosf_sequence *q, int stereoSlot, float *rmse, int *iterations) {
   if (!q) return SOS_ERR_ARG;
   FullSystem *fs = q->fs;
   int its = 0;
@@ -331,6 +543,7 @@ extern "C" int sosf_sequence_bootstrap(sosf_sequence *q, float *rmse, int *itera
   q->ct->makeK(&fs->HCalib);
   int rc = q->ct->setCoarseTrackingRef(fs->frameHessians);
   if (rc != SOS_OK) return rc;
+  if (q->stereo && stereoSlot >= 0 && (rc = optimize_scale(q, stereoSlot, nullptr, nullptr)) != SOS_OK) return rc;
   for (FrameHessian *fh : fs->frameHessians)
     if (make_new_traces(q, fh) < 0) return SOS_ERR_HIP;
   q->haveLastRel = false;
@@ -338,6 +551,7 @@ extern "C" int sosf_sequence_bootstrap(sosf_sequence *q, float *rmse, int *itera
   q->framesSinceKF = 0;
   return SOS_OK;
 }
+extern "C" int sosf_sequence_bootstrap(sosf_sequence *q, float *rmse, int *iterations) { return sosf_sequence_bootstrap_ex(q, -1, rmse, iterations); }
 
 extern "C" int sosf_sequence_immature_count(sosf_sequence *q, int frameID, int *count) {
   if (!q || !count) return SOS_ERR_ARG;
@@ -358,10 +572,19 @@ extern "C" int sosf_sequence_get_immature(sosf_sequence *q, int frameID, int cap
 
 // FullSystem::addActiveFrame for a frame whose pyramid is in `slot` (sos_undistort_frame / sosf_upload_image made it)
 extern "C" int sosf_add_active_frame(sosf_sequence *q, int slot, int frameID, float ab_exposure, const double *T_init12, sosf_frame_result *out) {
+  return sosf_add_active_frame_ex(q, slot, frameID, ab_exposure, T_init12, nullptr, out);
+}
+// ... with what the IMU / stereo branches need: the frame's timestamp, the IMU samples since the last frame (FullSystem::imu_data is
+// extended by them, :625, and handed to the next keyframe, :802-803), the image slot of the stereo partner
+extern "C" int sosf_add_active_frame_ex(sosf_sequence *q, int slot, int frameID, float ab_exposure, const double *T_init12, const sosf_frame_extra *extra,
+                                        sosf_frame_result *out) {
   if (!q || !out || slot < 0 || slot >= SOS_MAX_SLOTS) return SOS_ERR_ARG;
+  if (q->vio && !extra) return SOS_ERR_ARG;
   std::memset(out, 0, sizeof(*out));
+  out->newScale = -1;
   FullSystem *fs = q->fs;
   if (fs->frameHessians.empty()) return SOS_ERR_STATE;
+  if (q->vio && extra->n_imu > 0 && extra->imu) q->pendingImu.insert(q->pendingImu.end(), extra->imu, extra->imu + (size_t)7 * extra->n_imu);
   FrameHessian *ref = fs->frameHessians.back();
   const SE3 refPose = ref->PRE_camToWorld;
   // ---- initial guess of refToNew: the caller's, else the motion model (FS/FullSystem.cpp:163-200 tries constant motion first; with
@@ -409,5 +632,5 @@ extern "C" int sosf_add_active_frame(sosf_sequence *q, int slot, int frameID, fl
   }
   q->framesSinceKF = 0;
   out->isKeyframe = 1;
-  return make_keyframe(q, slot, frameID, c2w, aff, ab_exposure, out);
+  return make_keyframe(q, slot, frameID, c2w, aff, ab_exposure, extra, out);
 }

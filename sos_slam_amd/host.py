@@ -716,19 +716,54 @@ class Sequence:
         except Exception:
             pass
 
-    def bootstrap(self):
+    def enable_imu(self, S, timestamps, imu_per_keyframe):
+        """visual-inertial branch: timestamps / IMU samples (n x 7) of the bootstrap keyframes, in window order"""
+        n = len(timestamps)
+        ts = np.ascontiguousarray(timestamps, dtype=np.float64)
+        arrs = [np.ascontiguousarray(a, dtype=np.float64).reshape(-1, 7) for a in imu_per_keyframe]
+        cnt = np.array([len(a) for a in arrs], np.int32)
+        ptrs = (C.c_void_p * max(n, 1))(*[a.ctypes.data if len(a) else None for a in arrs])
+        self._S = S
+        self.L.sosf_sequence_enable_imu.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _chk(self.L.sosf_sequence_enable_imu(self.h_, C.byref(S), n, _p(ts), _p(cnt), ptrs), "sosf_sequence_enable_imu")
+
+    def enable_stereo(self, tfm12, scale_opt_thres):
+        t = np.ascontiguousarray(tfm12, dtype=np.float64)
+        self.L.sosf_sequence_enable_stereo.argtypes = [C.c_void_p, C.c_void_p, C.c_float]
+        _chk(self.L.sosf_sequence_enable_stereo(self.h_, _p(t), float(scale_opt_thres)), "sosf_sequence_enable_stereo")
+
+    def bootstrap(self, stereo_slot=-1):
         r, it = C.c_float(0), C.c_int(0)
-        self.L.sosf_sequence_bootstrap.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-        _chk(self.L.sosf_sequence_bootstrap(self.h_, C.byref(r), C.byref(it)), "sosf_sequence_bootstrap")
+        self.L.sosf_sequence_bootstrap_ex.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        _chk(self.L.sosf_sequence_bootstrap_ex(self.h_, int(stereo_slot), C.byref(r), C.byref(it)), "sosf_sequence_bootstrap_ex")
         return r.value, it.value
 
-    def add_active_frame(self, slot, frame_id, T_init=None, ab_exposure=1.0):
-        from .records import FrameResult
+    def add_active_frame(self, slot, frame_id, T_init=None, ab_exposure=1.0, timestamp=None, imu=None, stereo_slot=-1):
+        from .records import FrameExtra, FrameResult
         out = FrameResult()
         t = None if T_init is None else np.ascontiguousarray(T_init, dtype=np.float64)
-        self.L.sosf_add_active_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
-        _chk(self.L.sosf_add_active_frame(self.h_, int(slot), int(frame_id), float(ab_exposure), _p(t), C.byref(out)), "sosf_add_active_frame")
+        ex = None
+        if timestamp is not None or imu is not None or stereo_slot >= 0:
+            a = np.ascontiguousarray(imu if imu is not None else np.zeros((0, 7)), dtype=np.float64).reshape(-1, 7)
+            ex = FrameExtra(float(timestamp or 0.0), len(a), int(stereo_slot), a.ctypes.data if len(a) else None)
+        self.L.sosf_add_active_frame_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        _chk(self.L.sosf_add_active_frame_ex(self.h_, int(slot), int(frame_id), float(ab_exposure), _p(t), C.byref(ex) if ex is not None else None,
+                                             C.byref(out)), "sosf_add_active_frame_ex")
         return out
+
+    def imu(self, frame_id):
+        """(state_imu (21, unscaled), state_imu_zero, velInWorld) of a keyframe in the window"""
+        st, ze, ve = np.zeros(21), np.zeros(21), np.zeros(3)
+        self.L.sosf_sequence_get_imu.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _chk(self.L.sosf_sequence_get_imu(self.h_, int(frame_id), _p(st), _p(ze), _p(ve)), "sosf_sequence_get_imu")
+        return st, ze, ve
+
+    def imu_calib(self):
+        from .records import ImuCalib
+        c = ImuCalib()
+        self.L.sosf_sequence_get_imu_calib.argtypes = [C.c_void_p, C.c_void_p]
+        _chk(self.L.sosf_sequence_get_imu_calib(self.h_, C.byref(c)), "sosf_sequence_get_imu_calib")
+        return c
 
     def immature(self, frame_id):
         from .records import IMMATURE_DTYPE

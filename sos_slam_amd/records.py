@@ -172,4 +172,10 @@ class FrameResult(C.Structure):
                 ("aff", C.c_double * 2), ("trackResiduals", C.c_double * 5), ("flow", C.c_double * 3),
                 ("nActivated", C.c_int32), ("nDeletedImmature", C.c_int32), ("nPointsBeforeOpt", C.c_int32), ("iterations", C.c_int32),
                 ("rmse", C.c_float), ("nOutliersRemoved", C.c_int32), ("nMargPoints", C.c_int32), ("nDroppedPoints", C.c_int32),
-                ("nNewImmature", C.c_int32), ("nMargFrames", C.c_int32), ("margFrameIDs", C.c_int32 * 8), ("margCamToWorld", C.c_double * 96)]
+                ("nNewImmature", C.c_int32), ("nMargFrames", C.c_int32), ("margFrameIDs", C.c_int32 * 8), ("margCamToWorld", C.c_double * 96),
+                ("newScale", C.c_float), ("scaleError", C.c_float)]
+
+
+class FrameExtra(C.Structure):
+    """sosf_frame_extra"""
+    _fields_ = [("timestamp", C.c_double), ("n_imu", C.c_int32), ("stereoSlot", C.c_int32), ("imu", C.c_void_p)]

@@ -68,7 +68,10 @@ def test_record_sizes_against_the_compiled_header(tmp_path):
                "sos_activation": records.ACTIVATION_DTYPE.itemsize, "sos_pixsel_params": C.sizeof(records.PixselParams),
                "sos_camera_model": C.sizeof(records.CameraModel), "sos_resid_final": records.RESID_FINAL_DTYPE.itemsize}
     src = tmp_path / "sizes.c"
-    mirrors.update({"sosf_sequence_params": C.sizeof(records.SequenceParams), "sosf_frame_result": C.sizeof(records.FrameResult)})
+    mirrors.update({"sosf_sequence_params": C.sizeof(records.SequenceParams), "sosf_frame_result": C.sizeof(records.FrameResult),
+                    "sosf_frame_extra": C.sizeof(records.FrameExtra), "sosf_imu_frame": C.sizeof(records.ImuFrame),
+                    "sosf_imu_calib": C.sizeof(records.ImuCalib), "sosf_imu_settings": C.sizeof(records.ImuSettings),
+                    "sosf_imu_shell": C.sizeof(records.ImuShell)})
     src.write_text('#include <stdio.h>\n#include "sos_slam.h"\n#include "sos_slam_host.h"\nint main(void) {\n' +
                    "".join(f'  printf("{n} %zu\\n", sizeof({n}));\n' for n in mirrors) + "  return 0;\n}\n")
     exe = tmp_path / "sizes"
