@@ -436,6 +436,12 @@ int sosf_add_active_frame_ex(sosf_sequence *seq, int slot, int frameID, float ab
                              sosf_frame_result *out);
 int sosf_sequence_get_imu(sosf_sequence *seq, int frameID, double *state21, double *zero21, double *vel3);
 int sosf_sequence_get_imu_calib(sosf_sequence *seq, sosf_imu_calib *out);
+int sosf_sequence_get_scale_state(sosf_sequence *seq, int32_t *state2 /* FullSystem::scaleTrapped, scale_opt_fails */);
+/* for the parity tests: what the graph looks like BETWEEN the stages of the last makeKeyFrame.  which = 0 keyframes flagged for
+ * marginalisation (frameID), 1 activated points (host frameID, u, v; insertion order), 2 residuals after optimize() (host frameID, u, v,
+ * target frameID), 3 points after flagPointsForRemoval (host frameID, u, v); *count = doubles available */
+int sosf_sequence_set_snapshots(sosf_sequence *seq, int on);
+int sosf_sequence_get_snapshot(sosf_sequence *seq, int which, int capacity, double *out, int *count);
 
 /* direct access to the underlying context / backend handles (tracker tests share the frame store) */
 sos_ctx *sosf_ctx(sosf_system *sys);

@@ -60,6 +60,11 @@ struct sosf_sequence {
   SE3 stereoTfm;
   float scaleOptThres = 0;
   CoarseTracker::ScaleOptState scaleState;
+  // ---- what the parity tests look at BETWEEN the stages of makeKeyFrame (sosf_sequence_set_snapshots): 0 keyframes flagged for
+  // marginalisation (frameID), 1 activated points (host frameID, u, v) in insertion order, 2 residuals after optimize() (host frameID,
+  // u, v, target frameID), 3 points after flagPointsForRemoval (host frameID, u, v)
+  bool snapshots = false;
+  std::vector<double> snap[4];
 };
 
 namespace {
@@ -226,6 +231,11 @@ int activate_points(sosf_sequence *q, int *nActivated, int *nDeleted) {
       std::memcpy(p.weights, cand[j].weights, sizeof(p.weights));
       p.host = candHost[j];
       if (!fs->addActivatedPoint(p, a.inMask)) return SOS_ERR_STATE;
+      if (q->snapshots) {
+        q->snap[1].push_back(fs->frameHessians[candHost[j]]->frameID);
+        q->snap[1].push_back(p.u);
+        q->snap[1].push_back(p.v);
+      }
       gone[j] = 1;
       activated++;
     } else if (a.status == SOS_ACT_DELETE || cand[j].lastTraceStatus == SOS_IPS_OOB) {  // :493-500
@@ -329,6 +339,11 @@ int make_keyframe(sosf_sequence *q, int slot, int frameID, const SE3 &c2w, const
   FullSystem *fs = q->fs;
   for (FrameHessian *fh : fs->frameHessians) fh->numImmature = (int)q->imm[fh->frameID].size();
   fs->flagFramesForMarginalization();  // :798
+  if (q->snapshots) {
+    for (int w = 0; w < 4; w++) q->snap[w].clear();
+    for (FrameHessian *fh : fs->frameHessians)
+      if (fh->flaggedForMarginalization) q->snap[0].push_back(fh->frameID);
+  }
   if (q->vio) {  // fh->setImuData(imu_data); propagateImuState(allKeyFramesHistory.back(), coarseTracker->lastRef->imu_bias), :800-807
     sosf_sequence::VioFrame &v = q->vf[frameID];
     v = sosf_sequence::VioFrame();
@@ -394,6 +409,15 @@ int make_keyframe(sosf_sequence *q, int slot, int frameID, const SE3 &c2w, const
   out->iterations = its;
   if (fs->lastError != SOS_OK) return fs->lastError;
   if (imuOn) vio_pull(q);
+  if (q->snapshots)
+    for (FrameHessian *fh : fs->frameHessians)
+      for (EFPoint *p : fh->efFrame->points)
+        for (EFResidual *r : p->residualsAll) {
+          q->snap[2].push_back(fh->frameID);
+          q->snap[2].push_back(p->data->u);
+          q->snap[2].push_back(p->data->v);
+          q->snap[2].push_back(r->target->frameID);
+        }
   if (q->vio) {
     const int nw = (int)fs->frameHessians.size();
     for (FrameHessian *fh : fs->frameHessians) fh->PRE_camToWorld.to12(q->vf[fh->frameID].c2w);  // shell->camToWorld = PRE_camToWorld, FS/FullSystemOptimize.cpp:437-443
@@ -429,6 +453,13 @@ int make_keyframe(sosf_sequence *q, int slot, int frameID, const SE3 &c2w, const
   }
   rc = fs->flagPointsForRemoval(&out->nMargPoints, &out->nDroppedPoints);  // :908-912
   if (rc != SOS_OK) return rc;
+  if (q->snapshots)
+    for (FrameHessian *fh : fs->frameHessians)
+      for (EFPoint *p : fh->efFrame->points) {
+        q->snap[3].push_back(fh->frameID);
+        q->snap[3].push_back(p->data->u);
+        q->snap[3].push_back(p->data->v);
+      }
   out->nNewImmature = make_new_traces(q, fs->frameHessians.back());  // :915
   if (out->nNewImmature < 0) return SOS_ERR_HIP;
   // :923-927 -- the keyframes that leave take their immature points with them
@@ -522,6 +553,25 @@ extern "C" int sosf_sequence_get_imu(sosf_sequence *q, int frameID, double *stat
   if (state21) std::memcpy(state21, it->second.state, sizeof(double) * 21);
   if (zero21) std::memcpy(zero21, it->second.zero, sizeof(double) * 21);
   if (vel3) std::memcpy(vel3, it->second.vel, sizeof(double) * 3);
+  return SOS_OK;
+}
+
+extern "C" int sosf_sequence_set_snapshots(sosf_sequence *q, int on) {
+  if (!q) return SOS_ERR_ARG;
+  q->snapshots = on != 0;
+  return SOS_OK;
+}
+extern "C" int sosf_sequence_get_snapshot(sosf_sequence *q, int which, int capacity, double *out, int *count) {
+  if (!q || which < 0 || which > 3 || capacity < 0 || !count) return SOS_ERR_ARG;
+  const std::vector<double> &v = q->snap[which];
+  *count = (int)v.size();
+  if (out && !v.empty()) std::memcpy(out, v.data(), sizeof(double) * std::min<size_t>(v.size(), (size_t)capacity));
+  return SOS_OK;
+}
+extern "C" int sosf_sequence_get_scale_state(sosf_sequence *q, int32_t *state2) {
+  if (!q || !state2) return SOS_ERR_ARG;
+  state2[0] = q->scaleState.scaleTrapped;
+  state2[1] = q->scaleState.fails;
   return SOS_OK;
 }
 

@@ -758,6 +758,27 @@ class Sequence:
         _chk(self.L.sosf_sequence_get_imu(self.h_, int(frame_id), _p(st), _p(ze), _p(ve)), "sosf_sequence_get_imu")
         return st, ze, ve
 
+    def set_snapshots(self, on=True):
+        self.L.sosf_sequence_set_snapshots.argtypes = [C.c_void_p, C.c_int]
+        _chk(self.L.sosf_sequence_set_snapshots(self.h_, int(on)), "sosf_sequence_set_snapshots")
+
+    def snapshot(self, which):
+        """graph state between the stages of the last makeKeyFrame: 0 flagged frameIDs, 1 activated (host frameID, u, v), 2 residuals
+        after optimize (host frameID, u, v, target frameID), 3 points after flagPointsForRemoval (host frameID, u, v); rows as float64"""
+        width = (1, 3, 4, 3)[which]
+        c = C.c_int(0)
+        self.L.sosf_sequence_get_snapshot.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        _chk(self.L.sosf_sequence_get_snapshot(self.h_, which, 0, None, C.byref(c)), "sosf_sequence_get_snapshot")
+        out = np.zeros(c.value)
+        _chk(self.L.sosf_sequence_get_snapshot(self.h_, which, c.value, _p(out), C.byref(c)), "sosf_sequence_get_snapshot")
+        return out.reshape(-1, width)
+
+    def scale_state(self):
+        st = np.zeros(2, np.int32)
+        self.L.sosf_sequence_get_scale_state.argtypes = [C.c_void_p, C.c_void_p]
+        _chk(self.L.sosf_sequence_get_scale_state(self.h_, _p(st)), "sosf_sequence_get_scale_state")
+        return [int(st[0]), int(st[1])]
+
     def imu_calib(self):
         from .records import ImuCalib
         c = ImuCalib()

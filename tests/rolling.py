@@ -802,6 +802,122 @@ class DeviceChain(Chain):
         return {(int(a), float(b), float(c)) for a, b, c in zip(hf, u, v)}
 
 
+class CppDeviceChain(DeviceChain):
+    """The device chain with the frame-rate loop in C++ (sosf_sequence, csrc/host/sos_sequence.cpp): this class only feeds frames and
+    fills the KeyframeLog from the sequence's results and snapshots.  PENDING_FIRST_GPU_RUN (written in round 3 without GPU access):
+    opt-in through device_chain() with SOS_ROLLING_CPP=1 until it has run."""
+
+    def bootstrap(self):
+        from sos_slam_amd.records import SequenceParams
+        sc = self.sc
+        hs = [self.front_end(sc.raw[i]) for i in range(sc.n0)]
+        images = [self.irradiance(h) for h in hs]
+        pts, res = sc.bootstrap_points(images)
+        self.init_window(hs, [sc.poses[i] for i in range(sc.n0)], [sc.aff_true[i] for i in range(sc.n0)], pts, res)
+        prm = SequenceParams.default(desired_points=sc.desired_points, immature_density=sc.immature_density, kf_every=sc.kf_every)
+        self.seq = self.host.Sequence(self.sysm, prm, sc.pattern)
+        self.seq.set_snapshots(True)
+        if self.vio:
+            self.seq.enable_imu(sc.imu_settings, [sc.ts[i] for i in range(sc.n0)], [sc.imu[i] for i in range(sc.n0)])
+            self.n_kf_total = sc.n0
+        sr = -1
+        if self.stereo:
+            self.seq.enable_stereo(sc.stereo_tfm, sc.scale_opt_thres)
+            sr = self.front_end(sc.raw_right[sc.n0 - 1])
+        rmse, its = self.seq.bootstrap(stereo_slot=sr)
+        if self.stereo:
+            self.release_plain(sr)
+            self._log_scale(sc.n0 - 1, None)
+        for i in range(sc.n0):
+            self.handles[i] = hs[i]
+            self.imm[i], self.imm_type[i] = self.seq.immature(i)
+        self.last_rel = None
+        return rmse, its
+
+    def _log_scale(self, k, out):
+        # (new_scale, error) of the bootstrap call are not returned by sosf_sequence_bootstrap_ex: the calibration says whether it was accepted
+        c = self.seq.imu_calib()
+        ns = float(out.newScale) if out is not None else (200.0 * c.scale if c.scale != 1.0 / 200.0 else -1.0)
+        err = float(out.scaleError) if out is not None else float("nan")
+        self.scale_state = self.seq.scale_state()
+        self.scale_log.append((k, ns, err, list(self.scale_state)))
+        self.cal["scale"], self.cal["scale_zero"] = c.scale, c.scale_zero
+
+    def close(self):
+        if getattr(self, "seq", None) is not None:
+            self.seq.close()
+            self.seq = None
+        super().close()
+
+    def step(self):
+        sc = self.sc
+        nonkf = []
+        while True:
+            if self.next_frame >= sc.n_frames:
+                return None
+            k = self.next_frame
+            self.next_frame += 1
+            slot = self.front_end(sc.raw[k])
+            ids = self.window_ids()
+            T_init = None
+            if (sc.kf_every == 1 and self.last_rel is None) or (sc.kf_every > 1 and not self.track_hist):
+                T_init = se3_mul(se3_inv(sc.poses[k]), sc.poses[k - 1] if sc.kf_every == 1 else sc.poses[ids[-1]])
+                T_init = se3_mul(synth.se3_exp12(np.array([0.002, -0.001, 0.001, 0.001, -0.001, 0.0005])), T_init)
+            sr = self.front_end(sc.raw_right[k]) if self.stereo else -1
+            kw = dict(timestamp=float(sc.ts[k]), imu=sc.imu[k]) if self.vio else {}
+            out = self.seq.add_active_frame(slot, k, T_init, stereo_slot=sr, **kw)
+            if self.stereo:
+                self.release_plain(sr)
+            assert out.trackingOk == 1, "tracking lost"
+            T = np.array(out.refToNew[:])
+            self.last_rel = T.copy()
+            self.track_hist = (self.track_hist + [np.array(out.camToWorld[:])])[-2:]
+            if out.isKeyframe:
+                break
+            nonkf.append((k, T.copy()))
+            self.release_plain(slot)
+        self.handles[k] = slot
+        sq = self.seq
+        flagged = [int(f) for f in sq.snapshot(0)[:, 0]]
+        activated = [(int(a), float(np.float32(b)), float(np.float32(c))) for a, b, c in sq.snapshot(1)]
+        residual_set = {(int(a), float(np.float32(b)), float(np.float32(c)), int(d)) for a, b, c, d in sq.snapshot(2)}
+        point_set = {(int(a), float(np.float32(b)), float(np.float32(c))) for a, b, c in sq.snapshot(3)}
+        ids2 = self.window_ids()
+        marg = [(int(out.margFrameIDs[i]), np.array(out.margCamToWorld[12 * i:12 * i + 12])) for i in range(out.nMargFrames)]
+        # window as optimize() left it = the window now plus the keyframes that left at the end of makeKeyFrame, in frameID order
+        win_opt = sorted(set(ids2) | {f for f, _ in marg})
+        poses_now = {fid: self.kf_pose(i).copy() for i, fid in enumerate(ids2)}
+        window_poses = {fid: (poses_now[fid] if fid in poses_now else dict(marg)[fid]) for fid in win_opt}
+        for fid, _ in marg:
+            self.handles.pop(fid, None)
+            self.imm.pop(fid, None)
+            self.imm_type.pop(fid, None)
+        for fid in ids2:
+            self.imm[fid], self.imm_type[fid] = sq.immature(fid)
+        HM, bM = self.prior()
+        vio = None
+        if self.vio:
+            self.n_kf_total += 1
+            c = sq.imu_calib()
+            self.cal.update(scale=c.scale, scale_zero=c.scale_zero, trapped=int(c.scale_trapped), init=int(c.imu_initialized))
+            st = {f: sq.imu(f) for f in ids2}
+            Hi, bi = self.prior_imu()
+            vio = dict(scale=c.scale, scale_zero=c.scale_zero, trapped=int(c.scale_trapped), init=int(c.imu_initialized),
+                       states={f: st[f][0].copy() for f in ids2}, vel={f: st[f][2].copy() for f in ids2}, HMi=Hi, bMi=bi)
+        if self.stereo:
+            self._log_scale(k, out)
+        self.logs.append(KeyframeLog(k, T, np.array(out.aff[:]), flagged, activated, int(out.nDeletedImmature), int(out.nPointsBeforeOpt),
+                                     float(out.rmse), int(out.iterations), win_opt, window_poses, residual_set, int(out.nOutliersRemoved),
+                                     int(out.nMargPoints), int(out.nDroppedPoints), point_set, int(out.nNewImmature), marg, HM, bM, nonkf, vio))
+        return self.logs[-1]
+
+
+def device_chain(sc):
+    """the device chain of the rolling tests: the Python loop over the facade's stages, or (SOS_ROLLING_CPP=1) the C++ loop"""
+    import os
+    return CppDeviceChain(sc) if os.environ.get("SOS_ROLLING_CPP") == "1" else DeviceChain(sc)
+
+
 # ------------------------------------------------------------------------------------------------
 # oracle chain: its own graph (second statement of the host logic) + the C restatement for the arithmetic
 # ------------------------------------------------------------------------------------------------

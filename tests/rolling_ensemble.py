@@ -32,7 +32,7 @@ def run_seed(seed, vio=False, **scenario):
     """One sequence through the device chain, the oracle chain and the fp64-accumulation oracle chain.  Returns the worst
     distances (device-oracle `d_*`, oracle-truth `n_*`) and the list of hard-decision mismatches."""
     sc = rolling.Scenario(vio=vio, seed=seed, **scenario)
-    dev, orc_, tru = rolling.DeviceChain(sc), rolling.OracleChain(sc), rolling.OracleChain(sc, truth=True)
+    dev, orc_, tru = rolling.device_chain(sc), rolling.OracleChain(sc), rolling.OracleChain(sc, truth=True)
     for c in (dev, orc_, tru):
         c.bootstrap()
     m = dict(seed=seed, vio=vio, keyframes=0, left=0, hard=[], its_mismatch=0,

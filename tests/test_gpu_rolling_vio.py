@@ -48,7 +48,7 @@ GEOMETRIES = {
 @pytest.mark.parametrize("geom", list(GEOMETRIES))
 def test_rolling_window_visual_inertial(geom):
     sc = rolling.Scenario(vio=True, **GEOMETRIES[geom])
-    dev, orc_, tru = rolling.DeviceChain(sc), rolling.OracleChain(sc), rolling.OracleChain(sc, truth=True)
+    dev, orc_, tru = rolling.device_chain(sc), rolling.OracleChain(sc), rolling.OracleChain(sc, truth=True)
     for c in (dev, orc_, tru):
         c.bootstrap()
     bad = []

@@ -49,7 +49,7 @@ GEOMETRIES = {
 @pytest.mark.parametrize("geom", list(GEOMETRIES))
 def test_rolling_window_marginalised_poses_and_index_sets(geom):
     sc = rolling.Scenario(**GEOMETRIES[geom])
-    dev, orc_, tru = rolling.DeviceChain(sc), rolling.OracleChain(sc), rolling.OracleChain(sc, truth=True)
+    dev, orc_, tru = rolling.device_chain(sc), rolling.OracleChain(sc), rolling.OracleChain(sc, truth=True)
     boots = [c.bootstrap() for c in (dev, orc_, tru)]
     assert boots[0][1] == boots[1][1] and abs(boots[0][0] - boots[1][0]) <= 1e-5 * boots[1][0]
     assert dev.point_set() == orc_.point_set()

@@ -65,3 +65,6 @@ for f in sorted(glob.glob("$OUT/bench_imu_T*.json")):
     except Exception as e:
         print(f, "ERR", e)
 PY
+# the rolling-window parity tests driven by the C++ frame-rate loop (sosf_sequence) instead of the Python loop
+SOS_ROLLING_CPP=1 timeout 1500 python -X faulthandler -m pytest tests/test_gpu_rolling_window.py tests/test_gpu_rolling_vio.py -q > $OUT/gputests_rolling_cpp.log 2>&1
+grep -v "$F" $OUT/gputests_rolling_cpp.log | grep -E "passed|failed|FAILED|Fatal|Error" | head -12
