@@ -512,6 +512,11 @@ extern "C" int sosf_sequence_create(sosf_system *s, const sosf_sequence_params *
 
 extern "C" int sosf_sequence_destroy(sosf_sequence *q) {
   if (!q) return SOS_OK;
+  if (q->vio && q->fs && q->fs->ef && q->fs->ef->imuSettings == &q->S) {  // the facade must not keep pointers into this object
+    EnergyFunctional *ef = q->fs->ef;
+    ef->imuSettings = nullptr; ef->imuCalib = nullptr; ef->imuFrames = nullptr;
+    ef->imuMergedSamples.clear();
+  }
   if (q->sel) sos_pixsel_destroy(q->sel);
   delete q->ct;
   delete q;
