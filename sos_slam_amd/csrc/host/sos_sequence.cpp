@@ -516,6 +516,7 @@ extern "C" int sosf_sequence_destroy(sosf_sequence *q) {
     EnergyFunctional *ef = q->fs->ef;
     ef->imuSettings = nullptr; ef->imuCalib = nullptr; ef->imuFrames = nullptr;
     ef->imuMergedSamples.clear();
+    ef->imuOwnPrior = false;  // (as sosf_set_imu(sys, NULL, ...) leaves it)
   }
   if (q->sel) sos_pixsel_destroy(q->sel);
   delete q->ct;
