@@ -244,6 +244,10 @@ int sosf_get_timing(double *phases8, int reset);
 /* the facade's dense symmetric solve (pivoted LDL^T standing in for Eigen's ldlt().solve, OB/EnergyFunctional.cpp:1148);
  * which = 0: blocked production variant, 1: unblocked reference variant.  Exposed for the CPU test-suite. */
 int sosf_ldlt_solve(const double *A, const double *b, double *x, int n, int which);
+/* the same system solved as the cached visual-inertial solve does (sos_imu.cpp): the leading m unknowns eliminated by a partial
+ * factorisation with pivots from the leading block only, forward pass, the trailing (n - m) block -- its Schur complement -- solved
+ * on its own, backward pass.  Exposed for the CPU test-suite. */
+int sosf_ldlt_partial_solve(const double *A, const double *b, double *x, int n, int m);
 
 /* ---- the frame-rate loop: FullSystem::addActiveFrame -> trackNewestCoarse -> traceNewCoarse -> keyframe decision -> makeKeyFrame
  * (FS/FullSystem.cpp:616-766, 311-361, 783-931, 375-531, 1071-1097), visual part, in C++ (csrc/host/sos_sequence.cpp).  The object
@@ -358,6 +362,24 @@ int sosf_imu_expand(int n, const double *H, const double *b, double *He, double 
 int sosf_imu_solve(const sosf_imu_settings *S, const sosf_imu_calib *C, int n, const sosf_imu_frame *frames, const double *H_top,
                    const double *b_top, const double *H_sc, const double *b_sc, const double *HM, const double *bM,
                    const double *delta, double lambda, double *x, double *scale_step, double *step_imu);
+/* The same solve in two calls, so that what does not need the device's H / b runs while the accumulation is in flight: _prepare takes
+ * the records, the prior and delta (kept by pointer until _finish, which must follow on the same thread with nothing changed in
+ * between), _finish the stitched system.  With the scale trapped (first-estimate Jacobians: getImuHi at state_imu_zero / scale_zero /
+ * evalPT, FS/HessianBlocks.cpp:178-225) everything of the KKT matrix except the visual block is constant over the iterations of one
+ * optimize(): the IMU states and constraint multipliers are eliminated once and the factor is kept (thread-local) for as long as the
+ * inputs it rests on -- settings, lambda, timestamps, linearisation points, the whole of HM -- compare equal value by value
+ * (prior_id != 0 is the caller's name for the VALUES of HM: a call with the same name, the same pointer and the same diagonal skips
+ * the comparison of the other dim^2 values -- the facade names its own prior by a counter of its writes; 0 = always compared); an
+ * iteration then costs the right-hand sides, the (4 + 1 + 8 n)-dimensional border solve and two substitutions.  Results agree with
+ * the literal form to rounding.  sosf_imu_solve_mode(0) selects the literal form for every call, (1) the cached one (default;
+ * SOS_IMU_CACHE=0 in the environment = 0), any other value only reads; returns the previous mode.  sosf_imu_solve_stats: solves on
+ * a kept factor / factor rebuilds / literal-form solves of the calling thread. */
+int sosf_imu_solve_prepare(const sosf_imu_settings *S, const sosf_imu_calib *C, int n, const sosf_imu_frame *frames, const double *HM,
+                           const double *bM, const double *delta, double lambda, uint64_t prior_id);
+int sosf_imu_solve_finish(const double *H_top, const double *b_top, const double *H_sc, const double *b_sc, double *x, double *scale_step,
+                          double *step_imu);
+int sosf_imu_solve_mode(int mode);
+int sosf_imu_solve_stats(int32_t *kept, int32_t *rebuilt, int32_t *literal, int reset);
 
 /* EnergyFunctional::marginalizeFrame with IMU enabled (OB/EnergyFunctional.cpp:730-889): the IMU factors linking keyframe
  * idx to its neighbours are folded into the prior (getImuHessianCurrentFrame of idx + 1 and, if idx > 0, of idx, linearised

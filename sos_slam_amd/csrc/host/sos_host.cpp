@@ -297,6 +297,7 @@ EFFrame *EnergyFunctional::insertFrame(FrameHessian *fh, CalibHessian *HCalib) {
     }
     HMi.swap(Hn);
     bMi.swap(bn);
+    imuPriorVersion++;
   }
   EFIndicesValid = EFAdjointsValid = EFDeltaValid = false;
   setAdjointsF(HCalib);
@@ -492,6 +493,22 @@ int EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib, boo
   MatXX &HA = scrHA, &Hsc = scrHsc, HL;  // scratch members: no per-iteration allocation / zero fill
   VecX &bA = scrbA, &bsc = scrbsc, bL;
   HA.resize(dd); Hsc.resize(dd); bA.resize(dim); bsc.resize(dim);
+  const VecX delta = getStitchedDeltaF();
+  if (imuSettings) {
+    // the IMU branch (OB/EnergyFunctional.cpp:1053-1171), first half: everything that does not need the device's H / b -- the IMU
+    // factors at the current states, the prior's right-hand side, and with first-estimate Jacobians the forward pass through the kept
+    // factor of the IMU states and multipliers (sos_imu.cpp) -- runs here, while the accumulation enqueued by the previous step (or by
+    // sosf_prepare) is in flight on the device
+    const double t_pre0 = now_s();
+    for (int h = 0; h < n; h++) {
+      frames[h]->data->PRE_camToWorld.to12(imuFrames[h].camToWorld);
+      std::memcpy(imuFrames[h].evalPT_R, frames[h]->data->camToWorld_evalPT.R, sizeof(double) * 9);
+    }
+    const int rcp = sosf_imu_solve_prepare(imuSettings, imuCalib, n, imuFrames, imuOwnPrior ? HMi.data() : imuHM, imuOwnPrior ? bMi.data() : imuBM,
+                                           delta.data(), lambda, imuOwnPrior ? imuPriorVersion : 0);
+    if (rcp != SOS_OK) return rcp;
+    g_phase[1] += now_s() - t_pre0;
+  }
   double t_acc0 = now_s();
   if (allreduceHook) {  // shard-local sums -> RCCL all-reduce of the packed fp32 blocks -> identical stitch on every rank
     HL.assign(dd, 0.0);
@@ -525,7 +542,6 @@ int EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib, boo
       H[(size_t)(4 + 8 * h + i) * dim + 4 + 8 * h + i] += frames[h]->prior[i];
       b[4 + 8 * h + i] += frames[h]->prior[i] * frames[h]->delta_prior[i];
     }
-  const VecX delta = getStitchedDeltaF();
   if (keepSystem) {  // inspection (sosf_get_last_system): the assembled H_top / b_top (priors in) and H_sc / b_sc, mirrored
     keptH = H; keptHsc = Hsc; keptb = b; keptbsc = bsc;
     for (int i = 0; i < dim; i++)
@@ -540,15 +556,10 @@ int EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib, boo
         H[(size_t)j * dim + i] = H[(size_t)i * dim + j];
         Hsc[(size_t)j * dim + i] = Hsc[(size_t)i * dim + j];
       }
-    for (int h = 0; h < n; h++) {
-      frames[h]->data->PRE_camToWorld.to12(imuFrames[h].camToWorld);
-      std::memcpy(imuFrames[h].evalPT_R, frames[h]->data->camToWorld_evalPT.R, sizeof(double) * 9);
-    }
     VecX x(dim);
     imuStep.assign((size_t)21 * n, 0.0);
-    sosf_imu_solve(imuSettings, imuCalib, n, imuFrames, H.data(), b.data(), Hsc.data(), bsc.data(), imuOwnPrior ? HMi.data() : imuHM,
-                   imuOwnPrior ? bMi.data() : imuBM, delta.data(), lambda,
-                   x.data(), &imuScaleStep, imuStep.data());
+    const int rcf = sosf_imu_solve_finish(H.data(), b.data(), Hsc.data(), bsc.data(), x.data(), &imuScaleStep, imuStep.data());
+    if (rcf != SOS_OK) return rcf;
     lastX = x;
     for (int i = 0; i < 4; i++) HCalib->step[i] = -x[i];
     for (EFFrame *h : frames) {
@@ -680,6 +691,7 @@ int EnergyFunctional::marginalizePointsF() {  // :891-936, IMU off
         sosf_imu_expand(nFrames, upd.data(), upd.data() + dd, He.data(), be.data());
         for (size_t i = 0; i < He.size(); i++) HMi[i] += prm.margWeightFac * He[i];
         for (int i = 0; i < nd; i++) bMi[i] += prm.margWeightFac * be[i];
+        imuPriorVersion++;
       }
     }
   }
@@ -706,6 +718,7 @@ void EnergyFunctional::imuAdoptPrior() {
   HMi.assign((size_t)nd * nd, 0.0);
   bMi.assign(nd, 0.0);
   if (nFrames > 0) sosf_imu_expand(nFrames, HM.data(), bM.data(), HMi.data(), bMi.data());
+  imuPriorVersion++;
   imuOwnPrior = true;
 }
 
@@ -790,6 +803,7 @@ int EnergyFunctional::marginalizeFrame(EFFrame *fh) {  // :730-889; the IMU form
   if (imuOwnPrior) {
     HMi.swap(Ho);
     bMi.swap(bo);
+    imuPriorVersion++;
     // the leaving keyframe's IMU samples go in front of its successor's (FS/FullSystemMarginalize.cpp:226-228): the factor of
     // keyframe idx + 1 then covers the whole interval from idx - 1.  The merged list lives here until the next sosf_set_imu; a
     // caller that hands in fresh records afterwards has to hand in the merged samples (include/sos_slam_host.h)
@@ -2709,6 +2723,29 @@ extern "C" int sosf_ldlt_solve(const double *A, const double *b, double *x, int 
   if (which == 0) ldlt_solve(Av, bv, xv, n);
   else ldlt_solve_ref(Av, bv, xv, n);
   std::memcpy(x, xv.data(), sizeof(double) * n);
+  return SOS_OK;
+}
+extern "C" int sosf_ldlt_partial_solve(const double *A, const double *b, double *x, int n, int m) {
+  if (!A || !b || !x || n <= 0 || m < 0 || m > n) return SOS_ERR_ARG;
+  sos::LdltPartial F;
+  F.n = n;
+  F.m = m;
+  F.U.assign(A, A + (size_t)n * n);
+  sos::ldlt_partial_factor(F);
+  std::vector<double> y(b, b + n);
+  sos::ldlt_partial_forward(F, y.data());
+  const int nb = n - m;
+  if (nb > 0) {  // the trailing block: Schur complement as the factorisation left it (strict upper part in U, diagonal apart)
+    std::vector<double> B((size_t)nb * nb, 0.0), rb(y.begin() + m, y.end()), xb;
+    for (int j = 0; j < nb; j++) {
+      B[(size_t)j * nb + j] = F.diag[m + j];
+      for (int c = j + 1; c < nb; c++) B[(size_t)j * nb + c] = B[(size_t)c * nb + j] = F.U[(size_t)(m + j) * n + m + c];
+    }
+    ldlt_solve(B, rb, xb, nb);
+    for (int j = 0; j < nb; j++) y[m + j] = xb[j];
+  }
+  sos::ldlt_partial_backward(F, y.data());
+  std::memcpy(x, y.data(), sizeof(double) * n);
   return SOS_OK;
 }
 extern "C" int sosf_get_timing(double *phases8, int reset) {

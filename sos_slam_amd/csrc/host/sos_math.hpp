@@ -519,6 +519,84 @@ inline SolvePool &solve_pool() {
   return pool;
 }
 #define LDLT_MT_MIN_DIM 192  // below it (the visual system: 100 at W12, 132 at W16) a panel's update is too short to share
+// The factorisation proper: eliminates the pivots [0, stop) of the n x n symmetric matrix held as the strict upper triangle of U
+// (row-major) with its diagonal in diag[]; pivot candidates are [k, pend).  stop == pend == n is the full factorisation of
+// ldlt_solve; stop < n leaves the Schur complement of the eliminated block in the rows >= stop of U (strict upper part) and in
+// diag[stop..n) (ldlt_partial_* below).  D[k], perm[k] for k < stop; row k of U = the sub-diagonal part of column k of L.
+__attribute__((target("avx2,fma"))) inline void ldlt_factor(double *U, int n, int stop, int pend, double *D, int *perm, double *diag, double *WTp, double *LTp,
+                                                            SolvePool *pool) {
+  const size_t N = (size_t)n;
+  const bool wide = ldlt_have_avx512();
+  const bool whole = pend == n;  // the 512-bit pivot pass reports the largest remaining |diagonal| over [k + 1, n): usable only then
+  double restMax = -1.0;  // max |diag[k..n)| when the previous pivot's pass has left it (512-bit path), else < 0
+  for (int k0 = 0; k0 < stop; k0 += LDLT_NB) {
+    const int kb = std::min(LDLT_NB, stop - k0), k1 = k0 + kb;
+    for (int k = k0; k < k1; k++) {
+      const int q = k - k0;  // pivots of this panel already eliminated
+      // threshold pivoting: the natural pivot is kept while it is within a factor 10 of the largest candidate (element
+      // growth stays bounded by that factor); interchanges -- strided row/column swaps -- happen only when they buy
+      // stability.  Jacobi-scaled normal matrices (diagonal ~ 1) hardly ever need one.  The 512-bit path knows the largest
+      // candidate from the previous pivot's pass and searches for its position only when the test fails.
+      int p = k;
+      if (!(whole && restMax >= 0.0 && std::fabs(diag[k]) >= 0.1 * restMax)) {
+        p = ldlt_argmax_abs(diag, k, pend);
+        if (std::fabs(diag[k]) >= 0.1 * std::fabs(diag[p])) p = k;
+      }
+      restMax = -1.0;
+      perm[k] = p;  // interchange k (LAPACK ipiv style)
+      if (p != k) {  // symmetric swap k <-> p (k < p) of the not yet eliminated part.  Finished L columns keep the row
+                     // order they were computed in; the substitutions below replay the interchanges one by one instead
+        for (int j = k + 1; j < p; j++) std::swap(U[k * N + j], U[j * N + p]);
+        double *rk = &U[k * N], *rp = &U[p * N];
+        for (int i = p + 1; i < n; i++) std::swap(rk[i], rp[i]);
+        std::swap(diag[k], diag[p]);
+        for (int c = 0; c < q; c++) { std::swap(WTp[c * N + k], WTp[c * N + p]); std::swap(LTp[c * N + k], LTp[c * N + p]); }
+      }
+      const double d = diag[k];
+      D[k] = d;
+      double *wt = &WTp[(size_t)q * N], *lt = &LTp[(size_t)q * N];  // column k of L*D and of L
+      double *uk = &U[k * N];
+      if (!(std::fabs(d) > 2.2250738585072014e-308)) {
+        for (int i = k + 1; i < n; i++) { uk[i] = 0.0; wt[i] = 0.0; lt[i] = 0.0; }
+        continue;
+      }
+      if (wide) {
+        restMax = ldlt_pivot_512(uk, WTp, LTp, wt, lt, diag, n, k, q, 1.0 / d);
+        continue;
+      }
+      // bring column k (rows below the diagonal) up to date with the q earlier pivots of the panel
+      {
+        int i = k + 1;
+        __m256d lk[LDLT_NB];
+        for (int c = 0; c < q; c++) lk[c] = _mm256_set1_pd(LTp[c * N + k]);
+        for (; i + 4 <= n; i += 4) {
+          __m256d a = _mm256_loadu_pd(uk + i);
+          for (int c = 0; c < q; c++) a = _mm256_fnmadd_pd(_mm256_loadu_pd(&WTp[c * N + i]), lk[c], a);
+          _mm256_storeu_pd(wt + i, a);
+        }
+        for (; i < n; i++) {
+          double a = uk[i];
+          for (int c = 0; c < q; c++) a -= WTp[c * N + i] * LTp[c * N + k];
+          wt[i] = a;
+        }
+      }
+      const double dinv = 1.0 / d;
+      for (int i = k + 1; i < n; i++) {
+        const double a = wt[i], l = a * dinv;
+        lt[i] = l;
+        uk[i] = l;  // L(i,k)
+        diag[i] -= a * l;
+      }
+    }
+    if (k1 < n) {
+      if (pool) {
+        pool->k1 = k1; pool->kb = kb;
+        pool->run(SolvePool::JOB_UPDATE);
+      } else if (wide) ldlt_trailing_update_512(U, WTp, LTp, n, k1, kb);
+      else ldlt_trailing_update(U, WTp, LTp, n, k1, kb);
+    }
+  }
+}
 // `inplace` != nullptr: the caller's matrix (== A.data(), upper triangle filled) is factorised where it lies and is destroyed -- the
 // large systems are built for this one solve, copying them first is 1.3 MB of traffic at dimension 401
 __attribute__((target("avx2,fma"))) inline void ldlt_solve(const std::vector<double> &A, const std::vector<double> &b, std::vector<double> &x, int n,
@@ -549,74 +627,7 @@ __attribute__((target("avx2,fma"))) inline void ldlt_solve(const std::vector<dou
       diag[j] = src[j];
     }
   }
-  double restMax = -1.0;  // max |diag[k..n)| when the previous pivot's pass has left it (512-bit path), else < 0
-  for (int k0 = 0; k0 < n; k0 += LDLT_NB) {
-    const int kb = std::min(LDLT_NB, n - k0), k1 = k0 + kb;
-    for (int k = k0; k < k1; k++) {
-      const int q = k - k0;  // pivots of this panel already eliminated
-      // threshold pivoting: the natural pivot is kept while it is within a factor 10 of the largest candidate (element
-      // growth stays bounded by that factor); interchanges -- strided row/column swaps -- happen only when they buy
-      // stability.  Jacobi-scaled normal matrices (diagonal ~ 1) hardly ever need one.  The 512-bit path knows the largest
-      // candidate from the previous pivot's pass and searches for its position only when the test fails.
-      int p = k;
-      if (!(restMax >= 0.0 && std::fabs(diag[k]) >= 0.1 * restMax)) {
-        p = ldlt_argmax_abs(diag.data(), k, n);
-        if (std::fabs(diag[k]) >= 0.1 * std::fabs(diag[p])) p = k;
-      }
-      restMax = -1.0;
-      perm[k] = p;  // interchange k (LAPACK ipiv style)
-      if (p != k) {  // symmetric swap k <-> p (k < p) of the not yet eliminated part.  Finished L columns keep the row
-                     // order they were computed in; the substitutions below replay the interchanges one by one instead
-        for (int j = k + 1; j < p; j++) std::swap(U[k * N + j], U[j * N + p]);
-        double *rk = &U[k * N], *rp = &U[p * N];
-        for (int i = p + 1; i < n; i++) std::swap(rk[i], rp[i]);
-        std::swap(diag[k], diag[p]);
-        for (int c = 0; c < q; c++) { std::swap(WT[c * N + k], WT[c * N + p]); std::swap(LT[c * N + k], LT[c * N + p]); }
-      }
-      const double d = diag[k];
-      D[k] = d;
-      double *wt = &WT[(size_t)q * N], *lt = &LT[(size_t)q * N];  // column k of L*D and of L
-      double *uk = &U[k * N];
-      if (!(std::fabs(d) > 2.2250738585072014e-308)) {
-        for (int i = k + 1; i < n; i++) { uk[i] = 0.0; wt[i] = 0.0; lt[i] = 0.0; }
-        continue;
-      }
-      if (wide) {
-        restMax = ldlt_pivot_512(uk, WT.data(), LT.data(), wt, lt, diag.data(), n, k, q, 1.0 / d);
-        continue;
-      }
-      // bring column k (rows below the diagonal) up to date with the q earlier pivots of the panel
-      {
-        int i = k + 1;
-        __m256d lk[LDLT_NB];
-        for (int c = 0; c < q; c++) lk[c] = _mm256_set1_pd(LT[c * N + k]);
-        for (; i + 4 <= n; i += 4) {
-          __m256d a = _mm256_loadu_pd(uk + i);
-          for (int c = 0; c < q; c++) a = _mm256_fnmadd_pd(_mm256_loadu_pd(&WT[c * N + i]), lk[c], a);
-          _mm256_storeu_pd(wt + i, a);
-        }
-        for (; i < n; i++) {
-          double a = uk[i];
-          for (int c = 0; c < q; c++) a -= WT[c * N + i] * LT[c * N + k];
-          wt[i] = a;
-        }
-      }
-      const double dinv = 1.0 / d;
-      for (int i = k + 1; i < n; i++) {
-        const double a = wt[i], l = a * dinv;
-        lt[i] = l;
-        uk[i] = l;  // L(i,k)
-        diag[i] -= a * l;
-      }
-    }
-    if (k1 < n) {
-      if (pool) {
-        pool->k1 = k1; pool->kb = kb;
-        pool->run(SolvePool::JOB_UPDATE);
-      } else if (wide) ldlt_trailing_update_512(U, WT.data(), LT.data(), n, k1, kb);
-      else ldlt_trailing_update(U, WT.data(), LT.data(), n, k1, kb);
-    }
-  }
+  ldlt_factor(U, n, n, n, D.data(), perm.data(), diag.data(), WT.data(), LT.data(), pool);
   if (pool) pool->end();
   for (int i = 0; i < n; i++) y[i] = b[i];
   for (int k = 0; k < n; k++) {  // L z = P b, column-oriented: L(i,k) = U[k][i]
@@ -642,6 +653,71 @@ __attribute__((target("avx2,fma"))) inline void ldlt_solve(const std::vector<dou
     std::swap(y[k], y[perm[k]]);
   }
   x.assign(y.begin(), y.begin() + n);
+}
+
+// ---- partial factorisation: K = [A B^T; B C] with the leading m x m block A eliminated once and reused for many right-hand sides
+// and many trailing blocks C (the visual-inertial KKT system with first-estimate Jacobians: everything except the visual block of
+// the border is constant over the iterations of one optimize(), sos_imu.cpp).  Pivots are taken from the leading block only.
+struct LdltPartial {
+  int n = 0, m = 0;
+  std::vector<double> U;     // n x n: rows < m hold L (row k = column k of L right of the diagonal, over ALL n columns); rows >= m the
+                             // strict upper triangle of the Schur complement C - B A^-1 B^T
+  std::vector<double> D;     // m pivots
+  std::vector<double> diag;  // n: [m, n) = the diagonal of the Schur complement
+  std::vector<int> perm;     // m interchanges (within the leading block)
+};
+// F.U holds the upper triangle INCLUDING the diagonal on entry
+inline void ldlt_partial_factor(LdltPartial &F) {
+  const int n = F.n, m = F.m;
+  const size_t N = (size_t)n;
+  F.D.assign(m, 0.0);
+  F.diag.resize(N);
+  F.perm.assign(m, 0);
+  static thread_local std::vector<double> WT, LT;
+  WT.resize((size_t)LDLT_NB * N); LT.resize((size_t)LDLT_NB * N);
+  for (int j = 0; j < n; j++) F.diag[j] = F.U[j * N + j];
+  SolvePool *pool = (ldlt_have_avx512() && n >= LDLT_MT_MIN_DIM) ? &solve_pool() : nullptr;
+  if (pool && pool->T < 2) pool = nullptr;
+  if (pool) {
+    pool->n = n; pool->A = F.U.data(); pool->U = F.U.data(); pool->diag = F.diag.data(); pool->WT = WT.data(); pool->LT = LT.data();
+    pool->begin();
+  }
+  ldlt_factor(F.U.data(), n, m, m, F.D.data(), F.perm.data(), F.diag.data(), WT.data(), LT.data(), pool);
+  if (pool) pool->end();
+}
+// y (n): right-hand side in, [L^-1 P a ; c - B A^-1 a] out (the leading part still to be divided by D: done by the backward pass)
+__attribute__((target("avx2,fma"))) inline void ldlt_partial_forward(const LdltPartial &F, double *__restrict y) {
+  const int n = F.n, m = F.m;
+  const size_t N = (size_t)n;
+  for (int k = 0; k < m; k++) {
+    std::swap(y[k], y[F.perm[k]]);
+    const __m256d yk = _mm256_set1_pd(y[k]);
+    const double *__restrict uk = &F.U[k * N];
+    int i = k + 1;
+    for (; i + 4 <= n; i += 4) _mm256_storeu_pd(y + i, _mm256_fnmadd_pd(_mm256_loadu_pd(uk + i), yk, _mm256_loadu_pd(y + i)));
+    for (; i < n; i++) y[i] -= uk[i] * y[k];
+  }
+}
+// y (n): leading part as ldlt_partial_forward left it, trailing part = the solution of the trailing block; out: the whole solution
+__attribute__((target("avx2,fma"))) inline void ldlt_partial_backward(const LdltPartial &F, double *__restrict y) {
+  const int n = F.n, m = F.m;
+  const size_t N = (size_t)n;
+  for (int i = 0; i < m; i++) y[i] = (std::fabs(F.D[i]) > 2.2250738585072014e-308) ? y[i] / F.D[i] : 0.0;
+  for (int k = m - 1; k >= 0; k--) {
+    const double *uk = &F.U[k * N];
+    __m256d a0 = _mm256_setzero_pd(), a1 = _mm256_setzero_pd();
+    int i = k + 1;
+    for (; i + 8 <= n; i += 8) {
+      a0 = _mm256_fmadd_pd(_mm256_loadu_pd(uk + i), _mm256_loadu_pd(&y[i]), a0);
+      a1 = _mm256_fmadd_pd(_mm256_loadu_pd(uk + i + 4), _mm256_loadu_pd(&y[i + 4]), a1);
+    }
+    double t[4];
+    _mm256_storeu_pd(t, _mm256_add_pd(a0, a1));
+    double dot = (t[0] + t[1]) + (t[2] + t[3]);
+    for (; i < n; i++) dot += uk[i] * y[i];
+    y[k] -= dot;
+    std::swap(y[k], y[F.perm[k]]);
+  }
 }
 
 // dense inverse (Gauss-Jordan, partial pivoting) in place of Eigen `.inverse()` (OB/EnergyFunctional.cpp:841)

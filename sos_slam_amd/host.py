@@ -114,6 +114,15 @@ def ldlt_solve(A, b, which=0):
     return x
 
 
+def ldlt_partial_solve(A, b, m):
+    """The same solve split as the cached visual-inertial solve splits it: leading m unknowns eliminated, trailing block on its own."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    x = np.zeros(len(b))
+    _chk(load().sosf_ldlt_partial_solve(_p(A), _p(b), _p(x), len(b), m), "sosf_ldlt_partial_solve")
+    return x
+
+
 def activate_select(w1, h1, newest, KRKi, Kt, act, min_dist, min_quality, cand, cand_host, cand_type, host_flagged):
     """Candidate loop of FullSystem::activatePointsMT (sosf_activate_select); `act` = structured array with u, v,
     idepth_scaled, host of the active points.  Returns (decision int8[nCand], fwdWarpedIDDistFinal (h1, w1))."""
@@ -594,6 +603,11 @@ class _ImuApi:
         getattr(L, prefix + "expand").argtypes = [C.c_int, vp, vp, vp, vp]
         getattr(L, prefix + "marginalize_frame").argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_double, vp, vp, vp, vp]
         getattr(L, prefix + "solve").argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_double, vp, vp, vp]
+        if prefix == "sosf_imu_":   # the facade's two-call form and its kept factor (no counterpart in the oracle)
+            L.sosf_imu_solve_prepare.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, C.c_double, C.c_uint64]
+            L.sosf_imu_solve_finish.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+            L.sosf_imu_solve_mode.argtypes = [C.c_int]
+            L.sosf_imu_solve_stats.argtypes = [vp, vp, vp, C.c_int]
 
     @staticmethod
     def _frames(frames):
@@ -644,6 +658,29 @@ class _ImuApi:
         x, ss, si = np.zeros(4 + 8 * n), C.c_double(0), np.zeros((n, 21))
         arr = self._frames(frames)
         getattr(self.L, self.p + "solve")(C.byref(S), C.byref(Cal), n, arr, *[_p(v) for v in a], lam, _p(x), C.byref(ss), _p(si))
+        return x, ss.value, si
+
+
+    def solve_mode(self, mode=-1):
+        """0: the literal form for every solve, 1: the kept factor with first-estimate Jacobians (default); returns the previous mode"""
+        return self.L.sosf_imu_solve_mode(mode)
+
+    def solve_stats(self, reset=False):
+        """(solves on a kept factor, factor rebuilds, literal-form solves) of this thread"""
+        k, r, l = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self.L.sosf_imu_solve_stats(C.byref(k), C.byref(r), C.byref(l), int(reset))
+        return k.value, r.value, l.value
+
+    def solve_two_calls(self, S, Cal, frames, H_top, b_top, H_sc, b_sc, HM, bM, delta, lam=1e-5, prior_id=0, between=None):
+        """sosf_imu_solve_prepare, then `between()` (what the facade does there: wait for the device), then sosf_imu_solve_finish"""
+        n = len(frames)
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (H_top, b_top, H_sc, b_sc, HM, bM, delta)]
+        x, ss, si = np.zeros(4 + 8 * n), C.c_double(0), np.zeros((n, 21))
+        arr = self._frames(frames)
+        _chk(self.L.sosf_imu_solve_prepare(C.byref(S), C.byref(Cal), n, arr, _p(a[4]), _p(a[5]), _p(a[6]), lam, prior_id), "sosf_imu_solve_prepare")
+        if between is not None:
+            between()
+        _chk(self.L.sosf_imu_solve_finish(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(x), C.byref(ss), _p(si)), "sosf_imu_solve_finish")
         return x, ss.value, si
 
 

@@ -1,0 +1,203 @@
+"""The visual-inertial solve with first-estimate Jacobians on a KEPT factor (sosf_imu_solve_prepare / _finish, csrc/host/sos_imu.cpp):
+once the scale is trapped everything of the KKT matrix of OB/EnergyFunctional.cpp:1062-1140 except the visual block is constant over
+the iterations of one optimize(), so the IMU states and constraint multipliers are eliminated once.  CPU only: against the oracle's
+literal solve, against the facade's own literal form, and the rules under which the kept factor is dropped."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from sos_slam_amd import host
+from sos_slam_amd.records import imu_dim
+from tests.test_imu_assembly import _scene
+
+
+def _system(n, seed=3, dense_prior=True):
+    rng = np.random.default_rng(seed)
+    d0, dI = 4 + 8 * n, imu_dim(n)
+    A = rng.normal(size=(d0, d0 + 4))
+    H_top = A @ A.T * 50 + np.eye(d0) * 200
+    B = rng.normal(size=(d0, 6))
+    H_sc = B @ B.T
+    b_top, b_sc, delta = rng.normal(size=d0) * 10, rng.normal(size=d0), rng.normal(size=d0) * 1e-3
+    Mq = rng.normal(size=(dI, 8))
+    HM, bM = (Mq @ Mq.T if dense_prior else 0) + np.eye(dI) * 5, rng.normal(size=dI)
+    return H_top, b_top, H_sc, b_sc, np.ascontiguousarray(HM), bM, delta
+
+
+def _close(a, b, tol):
+    xa, sa, ia = a
+    xb, sb, ib = b
+    sc = max(np.abs(xb).max(), np.abs(ib).max(), 1e-9)
+    return np.abs(xa - xb).max() < tol * sc and abs(sa - sb) < tol * max(abs(sb), 1e-9) and np.abs(ia - ib).max() < tol * sc
+
+
+@pytest.fixture
+def api():
+    f = host.imu()
+    before = f.solve_mode(1)
+    f.solve_stats(reset=True)
+    yield f
+    f.solve_mode(before)
+
+
+@pytest.mark.parametrize("scale_opt", [False, True])
+@pytest.mark.parametrize("n", [5, 8])
+def test_kept_factor_follows_the_iterations(api, n, scale_opt):
+    """Six 'iterations': the IMU states, the scale, delta and the visual system move, the linearisation points do not -- one factor,
+    five solves on it, each equal to the oracle's literal solve of the same inputs."""
+    S, cal, frames, keep = _scene(n=n, trapped=True, scale_opt=scale_opt, seed=n)
+    H_top, b_top, H_sc, b_sc, HM, bM, delta = _system(n)
+    rng = np.random.default_rng(11)
+    fo = orc.imu()
+    for it in range(6):
+        xo = fo.solve(S, cal, frames, H_top, b_top, H_sc, b_sc, HM, bM, delta)
+        xc = api.solve(S, cal, frames, H_top, b_top, H_sc, b_sc, HM, bM, delta)
+        assert _close(xc, xo, 1e-8), it
+        api.solve_mode(0)
+        xl = api.solve(S, cal, frames, H_top, b_top, H_sc, b_sc, HM, bM, delta)
+        api.solve_mode(1)
+        assert _close(xc, xl, 1e-8), it
+        # doStepFromBackup: states and scale step, the visual system is re-accumulated at the new states
+        for f in frames:
+            for k in range(21):
+                f.state_imu[k] += 1e-5 * rng.normal()
+            R = np.array(f.camToWorld[:9]).reshape(3, 3)
+            w = rng.normal(0, 1e-3, 3)
+            Kx = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+            f.camToWorld[:9] = list((R @ (np.eye(3) + Kx)).reshape(-1))
+            for k in range(3):
+                f.camToWorld[9 + k] += 1e-3 * rng.normal()
+        cal.scale += 1e-6 * rng.normal()
+        H_top = H_top * (1 + 0.02 * rng.random()) + np.diag(rng.random(len(b_top)))
+        b_top = b_top + rng.normal(size=len(b_top))
+        H_sc = H_sc * (1 + 0.02 * rng.random())
+        delta = delta + 1e-4 * rng.normal(size=len(delta))
+    kept, rebuilt, literal = api.solve_stats()
+    assert (kept, rebuilt, literal) == (5, 1, 6)        # (the six literal solves are the mode-0 calls above)
+
+
+def test_untrapped_scale_takes_the_literal_form(api):
+    S, cal, frames, keep = _scene(trapped=False)
+    sysm = _system(len(frames))
+    xo = orc.imu().solve(S, cal, frames, *sysm)
+    for _ in range(2):
+        assert _close(api.solve(S, cal, frames, *sysm), xo, 1e-8)
+    assert api.solve_stats() == (0, 0, 2)
+
+
+def test_what_drops_the_kept_factor(api):
+    S, cal, frames, keep = _scene(n=6, trapped=True)
+    H_top, b_top, H_sc, b_sc, HM, bM, delta = _system(6)
+    fo = orc.imu()
+
+    def both():
+        xo = fo.solve(S, cal, frames, H_top, b_top, H_sc, b_sc, HM, bM, delta)
+        xc = api.solve(S, cal, frames, H_top, b_top, H_sc, b_sc, HM, bM, delta)
+        assert _close(xc, xo, 1e-8)
+        return api.solve_stats(reset=True)
+
+    assert both() == (0, 1, 0)
+    assert both() == (1, 0, 0)
+    keep[4][3, 1:] += 0.01                       # a measurement: right-hand side only
+    assert both() == (1, 0, 0)
+    bM[7] += 1.0                                 # the prior's vector likewise
+    assert both() == (1, 0, 0)
+    HM[40, 91] += 0.5; HM[91, 40] += 0.5         # ONE off-diagonal pair of the prior
+    assert both() == (0, 1, 0)
+    assert both() == (1, 0, 0)
+    frames[2].state_imu_zero[15] += 1e-7         # a linearisation point
+    assert both() == (0, 1, 0)
+    keep[1][5, 0] -= 1e-4                        # a sample's timestamp (its Jacobian's time)
+    assert both() == (0, 1, 0)
+    frames[3].evalPT_R[1] += 1e-9
+    assert both() == (0, 1, 0)
+    frames[4].timestamp += 1e-6
+    # the fourth change in a row: the inputs move with every call, the literal form serves until they repeat
+    assert both() == (0, 0, 1)
+    assert both() == (0, 1, 0)
+    assert both() == (1, 0, 0)
+    S.weight_imu[0] *= 1.5
+    assert both() == (0, 1, 0)
+    cal.scale_zero *= 1.0001
+    assert both() == (0, 1, 0)
+    cal.scale *= 1.0001                          # the current scale: residuals and delta only
+    assert both() == (1, 0, 0)
+
+
+def test_named_prior(api):
+    """prior_id != 0: same name, same pointer, same diagonal = the same prior without comparing dim^2 values"""
+    S, cal, frames, keep = _scene(n=6, trapped=True)
+    H_top, b_top, H_sc, b_sc, HM, bM, delta = _system(6)
+    fo = orc.imu()
+
+    def both(pid):
+        xo = fo.solve(S, cal, frames, H_top, b_top, H_sc, b_sc, HM, bM, delta)
+        xc = api.solve_two_calls(S, cal, frames, H_top, b_top, H_sc, b_sc, HM, bM, delta, prior_id=pid)
+        assert _close(xc, xo, 1e-8)
+        return api.solve_stats(reset=True)
+
+    assert both(7) == (0, 1, 0)
+    assert both(7) == (1, 0, 0)
+    HM[10:20, 10:20] += np.eye(10)               # the facade writes its prior and renames it
+    assert both(8) == (0, 1, 0)
+    assert both(8) == (1, 0, 0)
+    HM[30, 30] += 1.0                            # a write that was NOT announced still shows on the diagonal
+    assert both(8) == (0, 1, 0)
+    assert both(0) == (0, 1, 0)                  # unnamed after named: compared by value from now on
+    assert both(0) == (1, 0, 0)
+
+
+def test_two_calls_protocol(api):
+    S, cal, frames, keep = _scene(n=5, trapped=True)
+    sysm = _system(5)
+    x = np.zeros(4 + 8 * 5)
+    import ctypes as C
+    ss, si = C.c_double(0), np.zeros((5, 21))
+    a = [np.ascontiguousarray(v) for v in sysm[:4]]
+    from sos_slam_amd.host import _p
+    assert api.L.sosf_imu_solve_finish(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(x), C.byref(ss), _p(si)) != 0      # nothing prepared
+    seen = []
+    xc = api.solve_two_calls(S, cal, frames, *sysm, between=lambda: seen.append(1))
+    assert seen == [1] and _close(xc, orc.imu().solve(S, cal, frames, *sysm), 1e-8)
+    assert api.L.sosf_imu_solve_finish(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(x), C.byref(ss), _p(si)) != 0      # consumed
+
+
+@pytest.mark.parametrize("n,m", [(60, 0), (60, 60), (60, 37), (401, 300), (193, 150)])
+def test_partial_factorisation_equals_the_full_solve(n, m):
+    """ldlt_partial_*: a quasi-definite leading block (states, then multipliers with a zero diagonal and one all-zero constraint row)
+    eliminated with pivots from that block only; the trailing block solved on its own"""
+    rng = np.random.default_rng(n + m)
+    B = rng.normal(size=(n, n + 4))
+    A = B @ B.T / n + np.eye(n)
+    k = min(12, m // 3)
+    if k:
+        s0 = m - k
+        J = np.zeros((k, n))
+        J[np.arange(k), rng.permutation(s0)[:k]] = 1.0     # independent rows within the leading block, as the spline constraints are
+        J[:, m:] = 0.3 * rng.normal(size=(k, n - m)) * (rng.random((k, n - m)) < 0.1)
+        J[k - 1] = 0.0
+        A[s0:m, :] = J
+        A[:, s0:m] = J.T
+        A[s0:m, s0:m] = 0
+    b = rng.normal(size=n)
+    if k:
+        b[m - 1] = 0.0
+    xr = host.ldlt_solve(A, b, 1)
+    xp = host.ldlt_partial_solve(A, b, m)
+    assert np.abs(xp - xr).max() < 1e-9 * np.abs(xr).max()
+
+
+def test_baseline_size_against_the_oracle(api):
+    """W12 (twelve keyframes, consistent IMU samples): dimension 353 + 66 constraints"""
+    from sos_slam_amd import synth
+    win = synth.make_window("W12")
+    S, cal, fr, keep = synth.make_imu_records(win, consistent=True)
+    HMi, bMi = synth.expand_prior_imu(win)
+    H_top, b_top, H_sc, b_sc, _, _, delta = _system(win.n, seed=1)
+    rng = np.random.default_rng(2)
+    Mq = rng.normal(size=(HMi.shape[0], 8))
+    HM = np.ascontiguousarray(HMi + Mq @ Mq.T)
+    xo = orc.imu().solve(S, cal, fr, H_top, b_top, H_sc, b_sc, HM, bMi, delta)
+    for _ in range(2):
+        assert _close(api.solve(S, cal, fr, H_top, b_top, H_sc, b_sc, HM, bMi, delta), xo, 1e-7)
+    assert api.solve_stats() == (1, 1, 0)
