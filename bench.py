@@ -466,8 +466,31 @@ def imu_timing(window, device, iters=400):
         sysm.gn_iteration(20 + i)
     dt = time.perf_counter() - t0
     ph = host.timing()
-    out = {"ms_per_iteration": dt / iters * 1e3, "gn_iter_per_s": iters / dt, "host_kkt_solve_us": ph[2] / iters * 1e6,
-           "kkt_dimension": 4 + 1 + 29 * win.n + 6 * (win.n - 2) + 3, "loop_mode": sysm.loop_mode(), "resInA_last_iteration": sysm.stats()["resInA"]}
+    api = host.imu()
+    out = {"ms_per_iteration": dt / iters * 1e3, "gn_iter_per_s": iters / dt,
+           # the solve in two calls (sos_imu.cpp): _prepare runs while the accumulation is in flight, _finish after the device's H / b
+           "host_kkt_prepare_us": ph[1] / iters * 1e6, "host_kkt_finish_us": ph[2] / iters * 1e6, "host_kkt_solve_us": (ph[1] + ph[2]) / iters * 1e6,
+           "kkt_dimension": 4 + 1 + 29 * win.n + 6 * (win.n - 2) + 3, "loop_mode": sysm.loop_mode(), "resInA_last_iteration": sysm.stats()["resInA"],
+           "kkt_form": "scale trapped (first-estimate Jacobians): IMU states + multipliers eliminated once, kept while the linearisation "
+                       "points and the prior stand; per iteration right-hand sides + border solve + two substitutions",
+           "solves_kept_rebuilt_literal": list(api.solve_stats(reset=True))}
+    try:   # what one optimize() pays once (new linearisation points after every keyframe), and the literal form for comparison
+        arr = sysm._imu[2]
+        arr[1].state_imu_zero[20] += 1e-12
+        t0 = time.perf_counter()
+        sysm.gn_iteration(20 + iters)
+        out["iteration_with_factor_rebuild_ms"] = (time.perf_counter() - t0) * 1e3
+        before = api.solve_mode(0)
+        for i in range(5):
+            sysm.gn_iteration(21 + iters + i)
+        t0 = time.perf_counter()
+        for i in range(60):
+            sysm.gn_iteration(26 + iters + i)
+        out["literal_form_ms_per_iteration"] = (time.perf_counter() - t0) / 60 * 1e3
+        api.solve_mode(before)
+        out["solves_kept_rebuilt_literal_after"] = list(api.solve_stats(reset=True))
+    except Exception as e:   # a side measurement of a side measurement
+        out["rebuild_literal_error"] = repr(e)[:200]
     sysm.close()
     return out
 

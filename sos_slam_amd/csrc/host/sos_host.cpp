@@ -505,7 +505,7 @@ int EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib, boo
       std::memcpy(imuFrames[h].evalPT_R, frames[h]->data->camToWorld_evalPT.R, sizeof(double) * 9);
     }
     const int rcp = sosf_imu_solve_prepare(imuSettings, imuCalib, n, imuFrames, imuOwnPrior ? HMi.data() : imuHM, imuOwnPrior ? bMi.data() : imuBM,
-                                           delta.data(), lambda, imuOwnPrior ? imuPriorVersion : 0);
+                                           delta.data(), lambda, imuOwnPrior ? imuPriorVersion : ((uint64_t)1 << 62) + imuCallerPriorName);
     if (rcp != SOS_OK) return rcp;
     g_phase[1] += now_s() - t_pre0;
   }
@@ -2913,6 +2913,7 @@ extern "C" int sosf_set_imu(sosf_system *sy, const sosf_imu_settings *S, sosf_im
   EnergyFunctional *ef = sy->fs->ef;
   if (S && (!C || !frames || (HM == nullptr) != (bM == nullptr))) return SOS_ERR_ARG;
   ef->imuSettings = S; ef->imuCalib = C; ef->imuFrames = frames; ef->imuHM = HM; ef->imuBM = bM;
+  ef->imuCallerPriorName++;  // a caller's prior is named by the call that handed it over (see the header: rewritten in place -> call again)
   if (!S) ef->imuMergedSamples.clear();
   if (S && !HM) {
     if (!ef->imuOwnPrior) ef->imuAdoptPrior();  // first call: the visual prior, expanded; later calls only renew the records

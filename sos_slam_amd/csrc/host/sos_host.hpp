@@ -232,6 +232,7 @@ class EnergyFunctional {  // OB/EnergyFunctional.h:52-154
   // form of marginalizeFrame (:733-889).  The 8-per-keyframe HM / bM above stay maintained as the visual-only prior.
   bool imuOwnPrior = false;
   MatXX HMi;
+  uint64_t imuCallerPriorName = 0;  // counts sosf_set_imu: the name of a caller-owned prior
   uint64_t imuPriorVersion = 1;  // counts the writes of HMi: the name under which the cached IMU solve keeps its factor (sos_imu.cpp)
   VecX bMi;
   void imuAdoptPrior();  // HMi / bMi = expandHbtoFitImu(HM, bM)

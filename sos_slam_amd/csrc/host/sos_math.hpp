@@ -684,18 +684,46 @@ inline void ldlt_partial_factor(LdltPartial &F) {
   }
   ldlt_factor(F.U.data(), n, m, m, F.D.data(), F.perm.data(), F.diag.data(), WT.data(), LT.data(), pool);
   if (pool) pool->end();
+  // the factorisation leaves the finished columns of L in the row order they were computed in; bring them to the final order (the
+  // later interchanges applied to the earlier columns), so that the substitutions can apply all interchanges to the vector first
+  double *U = F.U.data();
+  for (int k = 0; k < m; k++) {
+    const int p = F.perm[k];
+    if (p != k)
+      for (int c = 0; c < k; c++) std::swap(U[c * N + k], U[c * N + p]);
+  }
 }
-// y (n): right-hand side in, [L^-1 P a ; c - B A^-1 a] out (the leading part still to be divided by D: done by the backward pass)
+// y (n): right-hand side in, [L^-1 P a ; c - B A^-1 a] out (the leading part still to be divided by D: done by the backward pass).
+// L is in its final row order (ldlt_partial_factor), so the interchanges are applied to y up front and the pass is a plain
+// triangular solve, four pivots at a time: one load / store of y per four columns of L.
 __attribute__((target("avx2,fma"))) inline void ldlt_partial_forward(const LdltPartial &F, double *__restrict y) {
   const int n = F.n, m = F.m;
   const size_t N = (size_t)n;
-  for (int k = 0; k < m; k++) {
-    std::swap(y[k], y[F.perm[k]]);
-    const __m256d yk = _mm256_set1_pd(y[k]);
+  for (int k = 0; k < m; k++) std::swap(y[k], y[F.perm[k]]);
+  int k = 0;
+  for (; k + 4 <= m; k += 4) {
+    const double *__restrict u0 = &F.U[k * N], *__restrict u1 = u0 + N, *__restrict u2 = u1 + N, *__restrict u3 = u2 + N;
+    const double y0 = y[k];
+    const double y1 = y[k + 1] - u0[k + 1] * y0;
+    const double y2 = (y[k + 2] - u0[k + 2] * y0) - u1[k + 2] * y1;
+    const double y3 = ((y[k + 3] - u0[k + 3] * y0) - u1[k + 3] * y1) - u2[k + 3] * y2;
+    y[k + 1] = y1; y[k + 2] = y2; y[k + 3] = y3;
+    const __m256d v0 = _mm256_set1_pd(y0), v1 = _mm256_set1_pd(y1), v2 = _mm256_set1_pd(y2), v3 = _mm256_set1_pd(y3);
+    int i = k + 4;
+    for (; i + 4 <= n; i += 4) {
+      __m256d a = _mm256_loadu_pd(y + i);
+      a = _mm256_fnmadd_pd(_mm256_loadu_pd(u0 + i), v0, a);
+      a = _mm256_fnmadd_pd(_mm256_loadu_pd(u1 + i), v1, a);
+      a = _mm256_fnmadd_pd(_mm256_loadu_pd(u2 + i), v2, a);
+      a = _mm256_fnmadd_pd(_mm256_loadu_pd(u3 + i), v3, a);
+      _mm256_storeu_pd(y + i, a);
+    }
+    for (; i < n; i++) y[i] = (((y[i] - u0[i] * y0) - u1[i] * y1) - u2[i] * y2) - u3[i] * y3;
+  }
+  for (; k < m; k++) {
+    const double yk = y[k];
     const double *__restrict uk = &F.U[k * N];
-    int i = k + 1;
-    for (; i + 4 <= n; i += 4) _mm256_storeu_pd(y + i, _mm256_fnmadd_pd(_mm256_loadu_pd(uk + i), yk, _mm256_loadu_pd(y + i)));
-    for (; i < n; i++) y[i] -= uk[i] * y[k];
+    for (int i = k + 1; i < n; i++) y[i] -= uk[i] * yk;
   }
 }
 // y (n): leading part as ldlt_partial_forward left it, trailing part = the solution of the trailing block; out: the whole solution
@@ -703,21 +731,37 @@ __attribute__((target("avx2,fma"))) inline void ldlt_partial_backward(const Ldlt
   const int n = F.n, m = F.m;
   const size_t N = (size_t)n;
   for (int i = 0; i < m; i++) y[i] = (std::fabs(F.D[i]) > 2.2250738585072014e-308) ? y[i] / F.D[i] : 0.0;
-  for (int k = m - 1; k >= 0; k--) {
-    const double *uk = &F.U[k * N];
-    __m256d a0 = _mm256_setzero_pd(), a1 = _mm256_setzero_pd();
-    int i = k + 1;
-    for (; i + 8 <= n; i += 8) {
-      a0 = _mm256_fmadd_pd(_mm256_loadu_pd(uk + i), _mm256_loadu_pd(&y[i]), a0);
-      a1 = _mm256_fmadd_pd(_mm256_loadu_pd(uk + i + 4), _mm256_loadu_pd(&y[i + 4]), a1);
+  int k = m;
+  for (; k - 4 >= 0; k -= 4) {  // rows k-4 .. k-1: their dot products with the part already solved share the loads of y
+    const int r = k - 4;
+    const double *__restrict u0 = &F.U[r * N], *__restrict u1 = u0 + N, *__restrict u2 = u1 + N, *__restrict u3 = u2 + N;
+    __m256d a0 = _mm256_setzero_pd(), a1 = a0, a2 = a0, a3 = a0;
+    int i = k;
+    for (; i + 4 <= n; i += 4) {
+      const __m256d v = _mm256_loadu_pd(y + i);
+      a0 = _mm256_fmadd_pd(_mm256_loadu_pd(u0 + i), v, a0);
+      a1 = _mm256_fmadd_pd(_mm256_loadu_pd(u1 + i), v, a1);
+      a2 = _mm256_fmadd_pd(_mm256_loadu_pd(u2 + i), v, a2);
+      a3 = _mm256_fmadd_pd(_mm256_loadu_pd(u3 + i), v, a3);
     }
-    double t[4];
-    _mm256_storeu_pd(t, _mm256_add_pd(a0, a1));
-    double dot = (t[0] + t[1]) + (t[2] + t[3]);
-    for (; i < n; i++) dot += uk[i] * y[i];
-    y[k] -= dot;
-    std::swap(y[k], y[F.perm[k]]);
+    double t0[4], t1[4], t2[4], t3[4];
+    _mm256_storeu_pd(t0, a0); _mm256_storeu_pd(t1, a1); _mm256_storeu_pd(t2, a2); _mm256_storeu_pd(t3, a3);
+    double d0 = (t0[0] + t0[1]) + (t0[2] + t0[3]), d1 = (t1[0] + t1[1]) + (t1[2] + t1[3]), d2 = (t2[0] + t2[1]) + (t2[2] + t2[3]),
+           d3 = (t3[0] + t3[1]) + (t3[2] + t3[3]);
+    for (; i < n; i++) { d0 += u0[i] * y[i]; d1 += u1[i] * y[i]; d2 += u2[i] * y[i]; d3 += u3[i] * y[i]; }
+    const double y3 = y[r + 3] - d3;
+    const double y2 = (y[r + 2] - d2) - u2[r + 3] * y3;
+    const double y1 = ((y[r + 1] - d1) - u1[r + 2] * y2) - u1[r + 3] * y3;
+    const double y0 = (((y[r] - d0) - u0[r + 1] * y1) - u0[r + 2] * y2) - u0[r + 3] * y3;
+    y[r] = y0; y[r + 1] = y1; y[r + 2] = y2; y[r + 3] = y3;
   }
+  for (k--; k >= 0; k--) {
+    const double *uk = &F.U[k * N];
+    double dot = 0;
+    for (int i = k + 1; i < n; i++) dot += uk[i] * y[i];
+    y[k] -= dot;
+  }
+  for (int q = m - 1; q >= 0; q--) std::swap(y[q], y[F.perm[q]]);
 }
 
 // dense inverse (Gauss-Jordan, partial pivoting) in place of Eigen `.inverse()` (OB/EnergyFunctional.cpp:841)

@@ -1,19 +1,24 @@
-"""CPU micro-benchmark of the IMU branch of solveSystemF on the host (sosf_imu_solve, csrc/host/sos_imu.cpp): the 0.5 ms the
-visual-inertial iteration of `bench.py --imu` spends between the device's stitch and its back-substitution.  No GPU needed -- the
-function works on the stitched H / b the device hands over, which are synthetic here (dense SPD, the sizes of W12).
+"""CPU micro-benchmark of the IMU branch of solveSystemF on the host (csrc/host/sos_imu.cpp): what the visual-inertial iteration of
+`bench.py --imu` spends around the device's stitch.  No GPU needed -- the functions work on the stitched H / b the device hands
+over, which are synthetic here (dense SPD, the sizes of W12), with a prior that is dense over the IMU states too.
 
     python tools/imu_solve_bench.py [W12] [reps]          SOS_TIMING_IMU=1 prints the phases of every call
-"""
+
+Reports, per solve: the literal form (whole KKT system built and factorised), the kept factor with the prior compared by value
+(sosf_imu_solve) and named (what the facade does: prior_id = its write counter), split into sosf_imu_solve_prepare (runs while the
+accumulation is in flight) and sosf_imu_solve_finish (after the device's H / b); and the cost of rebuilding the factor (once per
+optimize(): the linearisation points move between keyframes)."""
+import ctypes as C
+import os
 import sys
 import time
-
-import os
 
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from sos_slam_amd import host, synth
+from sos_slam_amd.host import _p
 
 
 def main():
@@ -26,25 +31,48 @@ def main():
     d0 = 4 + 8 * n
     rng = np.random.default_rng(1)
     A = rng.normal(size=(d0, d0 + 4))
-    H_top = A @ A.T * 50 + np.eye(d0) * 200
+    H_top = np.ascontiguousarray(A @ A.T * 50 + np.eye(d0) * 200)
     B = rng.normal(size=(d0, 6))
-    H_sc = B @ B.T
+    H_sc = np.ascontiguousarray(B @ B.T)
     b_top, b_sc, delta = rng.normal(size=d0) * 10, rng.normal(size=d0), rng.normal(size=d0) * 1e-3
     # a prior that is dense over the IMU states too (what frame marginalisations leave behind)
     Mq = rng.normal(size=(HMi.shape[0], 8))
-    HM = HMi + Mq @ Mq.T
+    HM = np.ascontiguousarray(HMi + Mq @ Mq.T)
     f = host.imu()
-    x0 = f.solve(S, cal, fr, H_top, b_top, H_sc, b_sc, HM, bMi, delta)[0]
-    for _ in range(10):
-        f.solve(S, cal, fr, H_top, b_top, H_sc, b_sc, HM, bMi, delta)
-    ts = []
-    for _ in range(reps):
+    L = f.L
+    arr = f._frames(fr)
+    x, ss, si = np.zeros(d0), C.c_double(0), np.zeros((n, 21))
+
+    def two_calls(pid):
         t0 = time.perf_counter()
-        x = f.solve(S, cal, fr, H_top, b_top, H_sc, b_sc, HM, bMi, delta)[0]
-        ts.append(time.perf_counter() - t0)
-    ts = np.array(ts) * 1e6
-    print({"window": window, "n": n, "dim_expanded": HMi.shape[0], "median_us": float(np.median(ts)), "min_us": float(ts.min()),
-           "p90_us": float(np.percentile(ts, 90)), "x_norm": float(np.linalg.norm(x0)), "repeatable": bool(np.array_equal(x, x0))})
+        L.sosf_imu_solve_prepare(C.byref(S), C.byref(cal), n, arr, _p(HM), _p(bMi), _p(delta), 1e-5, pid)
+        t1 = time.perf_counter()
+        L.sosf_imu_solve_finish(_p(H_top), _p(b_top), _p(H_sc), _p(b_sc), _p(x), C.byref(ss), _p(si))
+        return t1 - t0, time.perf_counter() - t1
+
+    out = {"window": window, "n": n, "dim_expanded": HMi.shape[0]}
+    f.solve_mode(0)
+    two_calls(0)
+    x_lit = x.copy()
+    ts = np.array([sum(two_calls(0)) for _ in range(reps)]) * 1e6
+    out["literal_us"] = float(np.median(ts))
+    f.solve_mode(1)
+    for name, pid in (("kept_compared", 0), ("kept_named", 7)):
+        two_calls(pid)
+        ts = np.array([two_calls(pid) for _ in range(reps)]) * 1e6
+        out[name + "_prepare_us"], out[name + "_finish_us"] = float(np.median(ts[:, 0])), float(np.median(ts[:, 1]))
+    out["kept_vs_literal_x"] = float(np.abs(x - x_lit).max() / np.abs(x_lit).max())
+    rb = []
+    for k in range(min(reps, 30)):       # a new linearisation point every time: factor rebuilt (the literal form takes over after 3 in a row, so
+        fr[1].state_imu_zero[20] += 1e-9   # every fourth call repeats the inputs)
+        arr = f._frames(fr)
+        for rep in range(2):
+            t = sum(two_calls(7))
+            if rep == 0 and k % 3 != 2:
+                rb.append(t)
+    out["rebuild_us"] = float(np.median(rb) * 1e6)
+    out["stats_kept_rebuilt_literal"] = f.solve_stats()
+    print(out)
 
 
 if __name__ == "__main__":
