@@ -55,10 +55,13 @@ PY
 for T in 1 2 4; do
   SOS_SOLVE_THREADS=$T timeout 300 python bench.py --imu --no-cpu-baseline --steps 10 --inner 60 > $OUT/bench_imu_T$T.json 2>> $OUT/bench.err
 done
-SOS_TIMING_IMU=1 timeout 120 python tools/imu_solve_bench.py W12 20 2>&1 | grep imu_solve | tail -3
+# the kept-factor solve of the trapped-scale case (default) against the literal form, inside the loop and on its own
+SOS_IMU_CACHE=0 timeout 300 python bench.py --imu --no-cpu-baseline --steps 10 --inner 60 > $OUT/bench_imu_literal.json 2>> $OUT/bench.err
+timeout 120 python tools/imu_solve_bench.py W12 200 2>&1 | tail -1
+timeout 300 python bench.py --side imu --window W12 2>> $OUT/bench.err | tail -1 > $OUT/bench_imu_side.json; head -c 1200 $OUT/bench_imu_side.json; echo
 python - <<PY
 import json, glob, os
-for f in sorted(glob.glob("$OUT/bench_imu_T*.json")):
+for f in sorted(glob.glob("$OUT/bench_imu_*.json")):
     try:
         d = json.load(open(f))
         print(os.path.basename(f), "ms/iter %.3f" % d["ms_per_step"], "loop", d["config"].get("gn_loop"), "resInA", d["config"]["resInA_last_iteration"])
