@@ -626,6 +626,7 @@ struct ImuCache {
   HiStore hi;
   sos::LdltPartial F;
   int misses = 0;                   // rebuilds in a row
+  bool unusable = false;            // the leading block of THESE inputs (sig) is singular beyond its all-zero constraint rows: literal form
   // the call in flight (prepare -> finish)
   std::vector<double> y;            // nt: forward-substituted right-hand side
   std::vector<double> rhsB;         // nb: constant part of the border right-hand side (prior + IMU), before the forward pass
@@ -766,6 +767,20 @@ void build_cache(ImuCache &Q, const sosf_imu_settings &S, const sosf_imu_calib &
   const double tf0 = tmgb ? now_us() : 0;
   sos::ldlt_partial_factor(P);
   const double tf1 = tmgb ? now_us() : 0;
+  // A zero pivot is expected for every all-zero constraint row (velocity rows whose successor has no valid spline, :389-391) and
+  // nowhere else.  Any other one means states without information (a valid spline with no samples and no prior, say): the literal
+  // form's pivoting over the WHOLE system then decides what the step is, so those inputs are left to it.
+  {
+    int zeroRows = 0, zeroPiv = 0;
+    for (int k = 0; k < Q.cdim; k++) {
+      bool any = false;
+      for (int g = 0; g < dimI && !any; g++) any = A.Jrows[k][g] != 0.0;
+      if (!any) zeroRows++;
+    }
+    for (int k = 0; k < mI; k++)
+      if (!(std::fabs(P.D[k]) > 2.2250738585072014e-308)) zeroPiv++;
+    Q.unusable = zeroPiv != zeroRows;
+  }
   Q.prior_id = prior_id;
   Q.HMptr = HM;
   Q.HMdiag.resize(dimI);
@@ -866,6 +881,9 @@ int cached_prepare(ImuCache &Q, const Prepared &P) {
     g_stats[1]++;
     build_cache(Q, S, C, n, P.F, P.HM, P.lambda, P.prior_id);
     tb = tmg ? now_us() : 0;
+    if (Q.unusable) return 1;
+  } else if (Q.unusable) {
+    return 1;
   } else {
     Q.misses = 0;
     g_stats[0]++;

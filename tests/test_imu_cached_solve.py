@@ -201,3 +201,23 @@ def test_baseline_size_against_the_oracle(api):
     for _ in range(2):
         assert _close(api.solve(S, cal, fr, H_top, b_top, H_sc, b_sc, HM, bMi, delta), xo, 1e-7)
     assert api.solve_stats() == (1, 1, 0)
+
+
+def test_states_without_information_are_left_to_the_literal_form(api):
+    """A valid spline with no IMU sample and a prior that says nothing about its states: the leading block is singular beyond its
+    all-zero constraint rows, so what the step is there is decided by the literal form's pivoting over the whole system."""
+    S, cal, frames, keep = _scene(n=5, trapped=True)
+    frames[1].n_imu = 0
+    H_top, b_top, H_sc, b_sc, HM, bM, delta = _system(5, dense_prior=False)
+    g0 = 4 + 1 + 29 * 1 + 8 + 6
+    HM[g0:g0 + 15, :] = 0
+    HM[:, g0:g0 + 15] = 0
+    xs = []
+    for mode in (0, 1, 1):
+        api.solve_mode(mode)
+        xs.append(api.solve(S, cal, frames, H_top, b_top, H_sc, b_sc, HM, bM, delta))
+    api.solve_mode(1)
+    for a in xs[1:]:
+        assert all(np.array_equal(u, v) for u, v in zip(a, xs[0]))
+    kept, rebuilt, literal = api.solve_stats()
+    assert kept == 0 and rebuilt == 1 and literal == 3       # examined once, not again for the same inputs
