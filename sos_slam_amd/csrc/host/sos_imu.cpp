@@ -1060,17 +1060,69 @@ std::vector<double> inverse(std::vector<double> A, int n) {
 }
 }  // namespace
 
+namespace {
+// C[r][c] -= sum_k L[r][k] * B[k][c] for r, c < nd, with C = Hs (row stride ld), B = the rows nd .. nd + st of Hs, L = bli (nd x st)
+__attribute__((target("avx2,fma"))) void schur_sub(double *Hs, int ld, int nd, const double *L, int st) {
+  const double *B = Hs + (size_t)nd * ld;
+  int r = 0;
+  for (; r + 4 <= nd; r += 4) {
+    double *c0 = Hs + (size_t)r * ld, *c1 = c0 + ld, *c2 = c1 + ld, *c3 = c2 + ld;
+    const double *l0 = L + (size_t)r * st, *l1 = l0 + st, *l2 = l1 + st, *l3 = l2 + st;
+    int c = 0;
+    for (; c + 8 <= nd; c += 8) {
+      __m256d a00 = _mm256_loadu_pd(c0 + c), a01 = _mm256_loadu_pd(c0 + c + 4), a10 = _mm256_loadu_pd(c1 + c), a11 = _mm256_loadu_pd(c1 + c + 4),
+              a20 = _mm256_loadu_pd(c2 + c), a21 = _mm256_loadu_pd(c2 + c + 4), a30 = _mm256_loadu_pd(c3 + c), a31 = _mm256_loadu_pd(c3 + c + 4);
+      for (int k = 0; k < st; k++) {
+        const double *bk = B + (size_t)k * ld + c;
+        const __m256d b0 = _mm256_loadu_pd(bk), b1 = _mm256_loadu_pd(bk + 4);
+        __m256d l = _mm256_set1_pd(l0[k]);
+        a00 = _mm256_fnmadd_pd(l, b0, a00); a01 = _mm256_fnmadd_pd(l, b1, a01);
+        l = _mm256_set1_pd(l1[k]);
+        a10 = _mm256_fnmadd_pd(l, b0, a10); a11 = _mm256_fnmadd_pd(l, b1, a11);
+        l = _mm256_set1_pd(l2[k]);
+        a20 = _mm256_fnmadd_pd(l, b0, a20); a21 = _mm256_fnmadd_pd(l, b1, a21);
+        l = _mm256_set1_pd(l3[k]);
+        a30 = _mm256_fnmadd_pd(l, b0, a30); a31 = _mm256_fnmadd_pd(l, b1, a31);
+      }
+      _mm256_storeu_pd(c0 + c, a00); _mm256_storeu_pd(c0 + c + 4, a01); _mm256_storeu_pd(c1 + c, a10); _mm256_storeu_pd(c1 + c + 4, a11);
+      _mm256_storeu_pd(c2 + c, a20); _mm256_storeu_pd(c2 + c + 4, a21); _mm256_storeu_pd(c3 + c, a30); _mm256_storeu_pd(c3 + c + 4, a31);
+    }
+    for (; c < nd; c++) {
+      double s0 = c0[c], s1 = c1[c], s2 = c2[c], s3 = c3[c];
+      for (int k = 0; k < st; k++) {
+        const double b = B[(size_t)k * ld + c];
+        s0 -= l0[k] * b; s1 -= l1[k] * b; s2 -= l2[k] * b; s3 -= l3[k] * b;
+      }
+      c0[c] = s0; c1[c] = s1; c2[c] = s2; c3[c] = s3;
+    }
+  }
+  for (; r < nd; r++) {
+    double *cr = Hs + (size_t)r * ld;
+    const double *lr = L + (size_t)r * st;
+    for (int k = 0; k < st; k++) {
+      const double l = lr[k];
+      const double *bk = B + (size_t)k * ld;
+      for (int c = 0; c < nd; c++) cr[c] -= l * bk[c];
+    }
+  }
+}
+}  // namespace
+
 extern "C" int sosf_imu_marginalize_frame(const sosf_imu_settings *S, const sosf_imu_calib *C, int n, const sosf_imu_frame *F, int idx,
                                           const double *delta, const double *prior8, const double *delta_prior8, double margWeightFac,
                                           const double *HM_in, const double *bM_in, double *HM_out, double *bM_out) {
   if (!S || !C || !F || n < 2 || idx < 0 || idx >= n - 1 || !delta || !prior8 || !delta_prior8 || !HM_in || !bM_in || !HM_out || !bM_out)
     return SOS_ERR_ARG;
   const int dim = SOSF_IMU_DIM(n);
-  // the IMU factors that tie the keyframe to its neighbours, linearised at the current delta, go into the prior
-  Assembly A(dim, n);
+  static const bool tmg = getenv("SOS_TIMING_IMU") != nullptr;
+  const double t0 = tmg ? now_us() : 0;
+  // the IMU factors that tie the keyframe to its neighbours, linearised at the current delta, go into the prior.  HM_change lives in
+  // the persistent holder of H_imu: it has entries only in the scale row / column and in the blocks of keyframes idx - 1 .. idx + 1
+  Assembly &A = imu_holder(dim, n);
   add_frame(*S, *C, n, F, idx + 1, A);
   if (idx > 0) add_frame(*S, *C, n, F, idx, A);
-  std::vector<double> d2(dim, 0.0);
+  static thread_local std::vector<double> d2, bM, Hs, bs, sc, isc, blk, bli;
+  d2.assign(dim, 0.0);
   for (int i = 0; i < CP; i++) d2[i] = delta[i];
   if (C->scale_trapped) d2[CP] = C->scale - C->scale_zero;
   for (int nb : {idx + 1, idx - 1}) {
@@ -1079,65 +1131,94 @@ extern "C" int sosf_imu_marginalize_frame(const sosf_imu_settings *S, const sosf
     if (C->scale_trapped)
       for (int k = 0; k < 21; k++) d2[CP + 1 + 29 * nb + 8 + k] = F[nb].state_imu[k] - F[nb].state_imu_zero[k];
   }
-  Dense HM(dim, dim);
-  std::vector<double> bM(dim);
+  // bM + w (b_change - HM_change d2): the product runs over the columns where HM_change can have entries
+  const int f0 = std::max(0, idx - 1), f1 = std::min(n - 1, idx + 1);
+  const int c0 = CP + 1 + 29 * f0, c1 = CP + 1 + 29 * (f1 + 1);
+  bM.resize(dim);
   for (int r = 0; r < dim; r++) {
     double hd = 0;
-    for (int c = 0; c < dim; c++) {
-      hd += A.H(r, c) * d2[c];
-      HM(r, c) = HM_in[(size_t)r * dim + c] + margWeightFac * A.H(r, c);
+    if (r == CP || (r >= c0 && r < c1)) {
+      const double *hr = &A.H.a[(size_t)r * dim];
+      for (int c = 0; c <= CP; c++) hd += hr[c] * d2[c];
+      for (int c = c0; c < c1; c++) hd += hr[c] * d2[c];
     }
     bM[r] = bM_in[r] + margWeightFac * (A.b[r] - hd);
   }
   // order of the states with the keyframe's block last; without a valid spline its 15 spline states are not eliminated
-  // but simply dropped
+  // but simply dropped.  The order is three runs of consecutive indices: [0, io), [io + 29, dim), [io, io + step)
   const int args = CP + 1, io = args + 29 * idx, ndim = dim - 29;
   const bool constrained = idx > 0 && A.spline_valid[idx];
   const int step = constrained ? 29 : 14, cur = ndim + step;
-  std::vector<int> ord;
-  for (int k = 0; k < dim; k++)
-    if (k < io || k >= io + 29) ord.push_back(k);
-  for (int k = 0; k < step; k++) ord.push_back(io + k);
-  std::vector<double> Hs((size_t)cur * cur), bs(cur), sc(cur);
+  struct Run { int src, dst, len; };
+  const Run runs[3] = {{0, 0, io}, {io + 29, io, dim - io - 29}, {io, ndim, step}};
+  auto srcOf = [&](int r) { return r < io ? r : r < ndim ? r + 29 : io + (r - ndim); };
+  Hs.resize((size_t)cur * cur);
+  bs.resize(cur); sc.resize(cur); isc.resize(cur);
   for (int r = 0; r < cur; r++) {
-    for (int c = 0; c < cur; c++) Hs[(size_t)r * cur + c] = HM(ord[r], ord[c]);
-    bs[r] = bM[ord[r]];
+    const int g = srcOf(r);
+    double dg = HM_in[(size_t)g * dim + g] + margWeightFac * A.H(g, g);
+    if (r >= ndim && r < ndim + 8) dg += prior8[r - ndim];  // the keyframe's pose prior joins here (marginalizeFrame :812-813)
+    sc[r] = std::sqrt(std::fabs(dg) + 10);
+    isc[r] = 1.0 / sc[r];
+    double bv = bM[g];
+    if (r >= ndim && r < ndim + 8) bv += prior8[r - ndim] * delta_prior8[r - ndim];
+    bs[r] = isc[r] * bv;
   }
-  for (int k = 0; k < 8; k++) {  // the keyframe's pose prior joins here (marginalizeFrame :812-813)
-    Hs[(size_t)(ndim + k) * cur + ndim + k] += prior8[k];
-    bs[ndim + k] += prior8[k] * delta_prior8[k];
+  for (int r = 0; r < cur; r++) {  // HM + w HM_change, permuted and Jacobi-scaled (:825-836)
+    const int g = srcOf(r);
+    const double *hm = HM_in + (size_t)g * dim, *hc = &A.H.a[(size_t)g * dim];
+    double *dst = &Hs[(size_t)r * cur];
+    const double ir = isc[r];
+    const bool touched = g == CP || (g >= c0 && g < c1);  // rows where HM_change has entries anywhere
+    for (const Run &u : runs) {
+      const double *m = hm + u.src, *h = hc + u.src, *ic = &isc[u.dst];
+      double *o = dst + u.dst;
+      if (touched) {
+        for (int i = 0; i < u.len; i++) o[i] = ir * (m[i] + margWeightFac * h[i]) * ic[i];
+      } else {  // HM_change has only its scale column here (and that only if the row is in a touched block -- it is not): plain HM
+        for (int i = 0; i < u.len; i++) o[i] = ir * m[i] * ic[i];
+        if (CP >= u.src && CP < u.src + u.len) o[CP - u.src] = ir * (m[CP - u.src] + margWeightFac * h[CP - u.src]) * ic[CP - u.src];
+      }
+    }
+    if (r >= ndim && r < ndim + 8) dst[r] = ir * (hm[g] + margWeightFac * hc[g] + prior8[r - ndim]) * ir;
   }
-  for (int r = 0; r < cur; r++) sc[r] = std::sqrt(std::fabs(Hs[(size_t)r * cur + r]) + 10);
-  for (int r = 0; r < cur; r++) {
-    for (int c = 0; c < cur; c++) Hs[(size_t)r * cur + c] = (1.0 / sc[r]) * Hs[(size_t)r * cur + c] * (1.0 / sc[c]);
-    bs[r] = (1.0 / sc[r]) * bs[r];
-  }
-  std::vector<double> blk((size_t)step * step);
+  clear_imu_blocks(A, n);
+  const double t1 = tmg ? now_us() : 0;
+  blk.resize((size_t)step * step);
   for (int r = 0; r < step; r++)
     for (int c = 0; c < step; c++) blk[(size_t)r * step + c] = Hs[(size_t)(ndim + r) * cur + ndim + c];
   const std::vector<double> hpi = inverse(blk, step);
-  std::vector<double> bli((size_t)ndim * step);
-  for (int r = 0; r < ndim; r++)
-    for (int c = 0; c < step; c++) {
-      double s = 0;
-      for (int k = 0; k < step; k++) s += Hs[(size_t)(ndim + k) * cur + r] * hpi[(size_t)k * step + c];
-      bli[(size_t)r * step + c] = s;
+  // bli = B^T hpi with B = the keyframe's rows of the scaled matrix (step x ndim, contiguous rows)
+  bli.assign((size_t)ndim * step, 0.0);
+  for (int k = 0; k < step; k++) {
+    const double *bk = &Hs[(size_t)(ndim + k) * cur], *hk = &hpi[(size_t)k * step];
+    for (int r = 0; r < ndim; r++) {
+      const double v = bk[r];
+      double *o = &bli[(size_t)r * step];
+      for (int c = 0; c < step; c++) o[c] += v * hk[c];
     }
+  }
+  // Schur complement (:846-849): Hs[0..ndim)[0..ndim) -= bli * B, a 4 x 8 register tile over all eliminated states (fp64 prior
+  // algebra feeding the next solves: fused multiply-adds, like the LDL^T)
+  schur_sub(Hs.data(), cur, ndim, bli.data(), step);
   for (int r = 0; r < ndim; r++) {
-    for (int c = 0; c < ndim; c++) {
-      double s = 0;
-      for (int k = 0; k < step; k++) s += bli[(size_t)r * step + k] * Hs[(size_t)(ndim + k) * cur + c];
-      Hs[(size_t)r * cur + c] -= s;
+    const double *lr = &bli[(size_t)r * step];
+    double sb = 0;
+    for (int k = 0; k < step; k++) sb += lr[k] * bs[ndim + k];
+    bs[r] -= sb;
+  }
+  const double t2 = tmg ? now_us() : 0;
+  // unscale and symmetrise (:852-857), tile by tile so that the transposed reads stay in cache
+  const int TB = 32;
+  for (int r0 = 0; r0 < ndim; r0 += TB)
+    for (int q0 = 0; q0 < ndim; q0 += TB) {
+      const int r1 = std::min(ndim, r0 + TB), q1 = std::min(ndim, q0 + TB);
+      for (int r = r0; r < r1; r++)
+        for (int c = q0; c < q1; c++)
+          HM_out[(size_t)r * ndim + c] = 0.5 * (sc[r] * Hs[(size_t)r * cur + c] * sc[c] + sc[c] * Hs[(size_t)c * cur + r] * sc[r]);
     }
-    double s = 0;
-    for (int k = 0; k < step; k++) s += bli[(size_t)r * step + k] * bs[ndim + k];
-    bs[r] -= s;
-  }
-  for (int r = 0; r < ndim; r++) {
-    for (int c = 0; c < ndim; c++)
-      HM_out[(size_t)r * ndim + c] = 0.5 * (sc[r] * Hs[(size_t)r * cur + c] * sc[c] + sc[c] * Hs[(size_t)c * cur + r] * sc[r]);
-    bM_out[r] = sc[r] * bs[r];
-  }
+  for (int r = 0; r < ndim; r++) bM_out[r] = sc[r] * bs[r];
+  if (tmg) fprintf(stderr, "[imu_marg] factors + permuted scaled copy %.0f us, inverse + Schur %.0f us, unscale %.0f us\n", t1 - t0, t2 - t1, now_us() - t2);
   return SOS_OK;
 }
 
