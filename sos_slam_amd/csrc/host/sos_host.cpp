@@ -2986,10 +2986,16 @@ extern "C" int sosf_frame_slot(sosf_system *s, int frameIdx) {
 // ================================================================================================
 namespace {
 struct DistanceMap {
-  int w1, h1;
+  int w1 = 0, h1 = 0, W = 0;
   std::vector<float> dist;
   std::vector<int> bfs1, bfs2;  // packed (x | y << 16)
-  DistanceMap(int w, int h) : w1(w), h1(h), dist((size_t)w * h, 1000.f), bfs1((size_t)w * h), bfs2((size_t)w * h) {}
+  std::vector<uint64_t> visited, front, S, H, nxt;  // one bit per cell, W words per row (the seeding pass)
+  void reset(int w, int h) {  // buffers kept between calls (thread-local instance): only dist is re-initialised
+    w1 = w; h1 = h; W = (w + 63) / 64;
+    const size_t n = (size_t)w * h;
+    dist.assign(n, 1000.f);
+    if (bfs1.size() < n) { bfs1.resize(n); bfs2.resize(n); }
+  }
   inline void relax(int idx, int x, int y, int k, int &num) {
     if (dist[idx] > k) {
       dist[idx] = (float)k;
@@ -2997,7 +3003,7 @@ struct DistanceMap {
     }
   }
   void grow(int bfsNum) {  // growDistBFS, FS/CoarseTracker.cpp:828-917: 4-neighbours on even rounds, 8 on odd ones
-    for (int k = 1; k < 40; k++) {
+    for (int k = 1; k < 40 && bfsNum > 0; k++) {  // (an empty front stays empty: the remaining rounds do nothing)
       const int bfsNum2 = bfsNum;
       std::swap(bfs1, bfs2);
       bfsNum = 0;
@@ -3016,6 +3022,61 @@ struct DistanceMap {
           relax(idx + 1 - w1, x + 1, y - 1, k, bfsNum);
         }
       }
+    }
+  }
+  // The same rounds for the seeding pass (all active points at once, every other cell at 1000), on bitmaps.  With every cell either
+  // unreached or assigned in an earlier round, round k of growDistBFS assigns k to exactly the unreached cells next to the previous
+  // round's cells (4-neighbourhood for even k, 8 for odd k; cells on the image border are reached but do not spread): a dilation of
+  // the front, 64 cells per operation, instead of one queue entry per cell and eight tests per entry.  dist[] comes out as grow() leaves it.
+  void grow_seeds(int nSeeds) {
+    const size_t nw = (size_t)W * h1;
+    visited.assign(nw, 0);
+    front.assign(nw, 0);
+    S.assign(nw, 0);
+    H.assign(nw, 0);
+    nxt.assign(nw, 0);
+    for (int i = 0; i < nSeeds; i++) {
+      const int x = bfs1[i] & 0xffff, y = bfs1[i] >> 16;
+      front[(size_t)y * W + (x >> 6)] |= 1ull << (x & 63);
+    }
+    visited = front;
+    // column masks: cells that may spread (1 <= x <= w1 - 2) and cells that exist (x < w1)
+    std::vector<uint64_t> inner(W, ~0ull), valid(W, ~0ull);
+    if (w1 & 63) valid[W - 1] = (1ull << (w1 & 63)) - 1;
+    for (int i = 0; i < W; i++) inner[i] = valid[i];
+    inner[0] &= ~1ull;
+    inner[(w1 - 1) >> 6] &= ~(1ull << ((w1 - 1) & 63));
+    for (int k = 1; k < 40; k++) {
+      for (int y = 1; y < h1 - 1; y++) {  // rows 0 and h1 - 1 do not spread: their S / H stay zero
+        const uint64_t *f = &front[(size_t)y * W];
+        uint64_t *s = &S[(size_t)y * W], *h = &H[(size_t)y * W];
+        for (int i = 0; i < W; i++) s[i] = f[i] & inner[i];
+        for (int i = 0; i < W; i++)
+          h[i] = (s[i] << 1) | (i ? s[i - 1] >> 63 : 0) | (s[i] >> 1) | (i + 1 < W ? s[i + 1] << 63 : 0);
+      }
+      bool any = false;
+      const bool eight = (k & 1) != 0;
+      for (int y = 0; y < h1; y++) {
+        const uint64_t *hy = &H[(size_t)y * W], *su = y > 0 ? &S[(size_t)(y - 1) * W] : nullptr, *sd = y + 1 < h1 ? &S[(size_t)(y + 1) * W] : nullptr;
+        const uint64_t *hu = y > 0 ? &H[(size_t)(y - 1) * W] : nullptr, *hd = y + 1 < h1 ? &H[(size_t)(y + 1) * W] : nullptr;
+        uint64_t *v = &visited[(size_t)y * W], *o = &nxt[(size_t)y * W];
+        float *drow = &dist[(size_t)y * w1];
+        for (int i = 0; i < W; i++) {
+          uint64_t nb = hy[i];
+          if (su) nb |= su[i] | (eight ? hu[i] : 0);
+          if (sd) nb |= sd[i] | (eight ? hd[i] : 0);
+          uint64_t fresh = nb & ~v[i] & valid[i];
+          o[i] = fresh;
+          v[i] |= fresh;
+          any |= fresh != 0;
+          while (fresh) {
+            drow[(i << 6) + __builtin_ctzll(fresh)] = (float)k;
+            fresh &= fresh - 1;
+          }
+        }
+      }
+      if (!any) break;
+      front.swap(nxt);
     }
   }
   void add(int u, int v) {  // addIntoDistFinal, :919-925
@@ -3049,7 +3110,10 @@ extern "C" int sosf_activate_select(int w1, int h1, int nFrames, int newest, con
       nActive < 0 || nCand < 0 || (nActive && (!act_u || !act_v || !act_id || !act_host)) ||
       (nCand && (!cand || !cand_host || !cand_type || !hostFlagged || !decision)))
     return SOS_ERR_ARG;
-  DistanceMap dm(w1, h1);
+  static thread_local DistanceMap dm;
+  static const bool tmg = getenv("SOS_TIMING") != nullptr;
+  const double tq0 = tmg ? now_s() : 0;
+  dm.reset(w1, h1);
   // makeDistanceMap, FS/CoarseTracker.cpp:793-826
   int numItems = 0;
   for (int i = 0; i < nActive; i++) {
@@ -3065,7 +3129,10 @@ extern "C" int sosf_activate_select(int w1, int h1, int nFrames, int newest, con
     dm.dist[u + w1 * v] = 0;
     dm.bfs1[numItems++] = u | (v << 16);
   }
-  dm.grow(numItems);
+  static const bool queueSeeds = getenv("SOS_DISTMAP_QUEUE") != nullptr;  // A/B knob: the seeding pass with the queue of the single-seed pass
+  if (queueSeeds) dm.grow(numItems);
+  else dm.grow_seeds(numItems);
+  const double tq1 = tmg ? now_s() : 0;
   // the candidate loop, FS/FullSystem.cpp:417-470
   for (int i = 0; i < nCand; i++) {
     const sos_immature &ph = cand[i];
@@ -3100,6 +3167,7 @@ extern "C" int sosf_activate_select(int w1, int h1, int nFrames, int newest, con
       decision[i] = SOSF_SEL_DELETE;  // :468-471
     }
   }
+  if (tmg) fprintf(stderr, "[activate_select] distance map of %d seeds %.0f us, %d candidates %.0f us\n", numItems, (tq1 - tq0) * 1e6, nCand, (now_s() - tq1) * 1e6);
   if (distFinal) memcpy(distFinal, dm.dist.data(), sizeof(float) * (size_t)w1 * h1);
   return SOS_OK;
 }
