@@ -92,3 +92,33 @@ def test_facade_selection_equals_oracle():
     for cur, npts, des in ((2.0, 500, 2000.0), (2.0, 1700, 2000.0), (2.0, 1950, 2000.0), (2.0, 2500, 2000.0), (3.9, 4000, 2000.0), (0.1, 10, 2000.0)):
         assert host.next_min_act_dist(cur, npts, des) == orc.next_min_act_dist(cur, npts, des)
     assert orc.next_min_act_dist(0.1, 10, 2000.0) == 0.0 and orc.next_min_act_dist(3.9, 4000, 2000.0) == 4.0
+
+
+import pytest
+
+
+@pytest.mark.parametrize("w1,h1,n_seeds", [(64, 40, 30), (65, 33, 1), (127, 50, 5), (128, 9, 40), (376, 240, 3000), (130, 3, 7), (200, 120, 2)])
+def test_distance_map_of_the_facade_equals_the_oracle_at_word_boundaries(w1, h1, n_seeds):
+    """The facade forms the seeding pass of the distance map by bitmap dilations, 64 cells per word: widths at, just over and just
+    under a word boundary, three-row images, seeds on the image border (reached, never spreading), a single seed (cells beyond 39
+    rounds stay at 1000).  Identity projection: a point's cell is its (u, v)."""
+    from sos_slam_amd import host
+    rng = np.random.default_rng(w1 * 1000 + h1)
+    act = np.zeros(n_seeds + 4, dtype=[("u", "f4"), ("v", "f4"), ("idepth_scaled", "f4"), ("host", "i4")])
+    act["u"] = rng.integers(1, w1, n_seeds + 4)
+    act["v"] = rng.integers(1, h1, n_seeds + 4)
+    act["u"][:2] = w1 - 1                      # on the right border
+    act["v"][2] = h1 - 1                       # on the bottom border
+    act["u"][3], act["v"][3] = 63 % (w1 - 1) + 1 if w1 > 64 else 1, 1
+    act["idepth_scaled"] = 1.0
+    act["host"] = 0
+    act["host"][-1] = 1                        # a point of the newest keyframe: not a seed
+    KRKi = np.tile(np.eye(3, dtype=np.float32).reshape(-1), (2, 1))
+    Kt = np.zeros((2, 3), np.float32)
+    from sos_slam_amd.records import IMMATURE_DTYPE
+    none = np.zeros(0, dtype=IMMATURE_DTYPE)
+    flagged = np.zeros(2, np.uint8)
+    _, D_o = orc.activate_select(w1, h1, 1, KRKi, Kt, act, 2.0, 3.0, none, np.zeros(0, np.int32), np.zeros(0, np.float32), flagged)
+    _, D_f = host.activate_select(w1, h1, 1, KRKi, Kt, act, 2.0, 3.0, none, np.zeros(0, np.int32), np.zeros(0, np.float32), flagged)
+    assert np.array_equal(D_o, D_f)
+    assert D_o.min() == 0 and (n_seeds > 100 or D_o.max() == 1000 or max(w1, h1) < 80)
