@@ -379,6 +379,9 @@ int sosf_imu_solve_prepare(const sosf_imu_settings *S, const sosf_imu_calib *C, 
 int sosf_imu_solve_finish(const double *H_top, const double *b_top, const double *H_sc, const double *b_sc, double *x, double *scale_step,
                           double *step_imu);
 int sosf_imu_solve_mode(int mode);
+/* between _prepare and _finish: 1 = the kept factor will serve (it reads only the upper triangles of H_top / H_sc), 0 = the literal form
+ * (reads them whole), -1 = nothing prepared */
+int sosf_imu_solve_prepared_form(void);
 int sosf_imu_solve_stats(int32_t *kept, int32_t *rebuilt, int32_t *literal, int reset);
 
 /* EnergyFunctional::marginalizeFrame with IMU enabled (OB/EnergyFunctional.cpp:730-889): the IMU factors linking keyframe

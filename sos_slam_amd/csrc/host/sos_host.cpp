@@ -551,11 +551,12 @@ int EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib, boo
       }
   }
   if (imuSettings) {  // setting_enable_imu && HCalib->imu_initialized: the IMU branch, OB/EnergyFunctional.cpp:1053-1171
-    for (int i = 0; i < dim; i++)  // the fused device call delivers the upper triangle only
-      for (int j = i + 1; j < dim; j++) {
-        H[(size_t)j * dim + i] = H[(size_t)i * dim + j];
-        Hsc[(size_t)j * dim + i] = Hsc[(size_t)i * dim + j];
-      }
+    if (sosf_imu_solve_prepared_form() != 1)  // the fused device call delivers the upper triangle only; the literal form reads H whole
+      for (int i = 0; i < dim; i++)
+        for (int j = i + 1; j < dim; j++) {
+          H[(size_t)j * dim + i] = H[(size_t)i * dim + j];
+          Hsc[(size_t)j * dim + i] = Hsc[(size_t)i * dim + j];
+        }
     VecX x(dim);
     imuStep.assign((size_t)21 * n, 0.0);
     const int rcf = sosf_imu_solve_finish(H.data(), b.data(), Hsc.data(), bsc.data(), x.data(), &imuScaleStep, imuStep.data());

@@ -991,6 +991,8 @@ extern "C" int sosf_imu_solve_prepare(const sosf_imu_settings *S, const sosf_imu
   return SOS_OK;
 }
 
+extern "C" int sosf_imu_solve_prepared_form(void) { return !g_prep.active ? -1 : g_prep.cached ? 1 : 0; }
+
 extern "C" int sosf_imu_solve_mode(int mode) {
   if (g_mode < 0) g_mode = (getenv("SOS_IMU_CACHE") && atoi(getenv("SOS_IMU_CACHE")) == 0) ? 0 : 1;
   const int before = g_mode;

@@ -157,7 +157,8 @@ def test_two_calls_protocol(api):
     from sos_slam_amd.host import _p
     assert api.L.sosf_imu_solve_finish(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(x), C.byref(ss), _p(si)) != 0      # nothing prepared
     seen = []
-    xc = api.solve_two_calls(S, cal, frames, *sysm, between=lambda: seen.append(1))
+    assert api.L.sosf_imu_solve_prepared_form() == -1
+    xc = api.solve_two_calls(S, cal, frames, *sysm, between=lambda: seen.append(api.L.sosf_imu_solve_prepared_form()))
     assert seen == [1] and _close(xc, orc.imu().solve(S, cal, frames, *sysm), 1e-8)
     assert api.L.sosf_imu_solve_finish(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(x), C.byref(ss), _p(si)) != 0      # consumed
 
