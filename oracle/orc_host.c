@@ -16,6 +16,12 @@
 #include "../include/sos_slam_host.h"
 
 /* orc_imu.c */
+typedef void (*orc_imu_solve_tap_t)(const sosf_imu_settings *, const sosf_imu_calib *, int, const sosf_imu_frame *, const double *, const double *,
+                                   const double *, const double *, const double *, const double *, const double *, double, const double *, double,
+                                   const double *);
+static orc_imu_solve_tap_t orc_imu_solve_tap_fn = 0;
+/* test hook: called with the inputs and outputs of every IMU solve of orc_solve_system (inputs as the solve saw them) */
+void orc_set_imu_solve_tap(orc_imu_solve_tap_t fn) { orc_imu_solve_tap_fn = fn; }
 int orc_imu_solve(const sosf_imu_settings *S, const sosf_imu_calib *C, int n, const sosf_imu_frame *F, const double *H_top,
                   const double *b_top, const double *H_sc, const double *b_sc, const double *HM, const double *bM, const double *delta,
                   double lambda, double *x_out, double *scale_step, double *step_imu);
@@ -391,6 +397,8 @@ static void solve_system(orc_window *W, int nthreads) {
     free(W->imuStep);
     W->imuStep = (double *)calloc((size_t)21 * n, sizeof(double));
     orc_imu_solve(S, C, n, F, H, b, Hsc, bsc, W->imuHM, W->imuBM, delta, lambda, x, &W->imuScaleStep, W->imuStep);
+    if (orc_imu_solve_tap_fn)  /* tests: the systems a running chain actually solves, before the states are stepped */
+      orc_imu_solve_tap_fn(S, C, n, F, H, b, Hsc, bsc, W->imuHM, W->imuBM, delta, lambda, x, W->imuScaleStep, W->imuStep);
     memcpy(W->lastX, x, sizeof(double) * dim);
     for (int i = 0; i < 4; i++) W->c_step[i] = -x[i];
     for (int h = 0; h < n; h++) {

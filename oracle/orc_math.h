@@ -182,7 +182,12 @@ static inline int orc_ldlt_solve(const double *A, const double *b, double *x, in
   double *y = (double *)malloc(sizeof(double) * N);
   int *perm = (int *)malloc(sizeof(int) * N);
   if (!M || !L || !D || !y || !perm) return -1;
-  memcpy(M, A, sizeof(double) * N * N);
+  /* Eigen's LDLT<MatrixXd, Lower> (what `.ldlt()` is, OB/EnergyFunctional.cpp:1148) references ONLY the lower triangle of its input.
+   * The matrices it is handed are not exactly symmetric -- AccumulatedSCHessian.cpp:128-139 fills block (j, k) and block (k, j) from
+   * float accumulators whose entries were rounded as (w L_p) R_q and (w R_q) L_p -- so the elimination below, which carries both
+   * triangles along, starts from the lower triangle mirrored: on a symmetric matrix it is Eigen's arithmetic, pivot for pivot. */
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j <= i; j++) M[(size_t)i * N + j] = M[(size_t)j * N + i] = A[(size_t)i * N + j];
   for (int i = 0; i < n; i++) perm[i] = i;
   for (int k = 0; k < n; k++) {
     int p = k;
