@@ -52,3 +52,62 @@ def test_selection_and_imu_marginalisation_on_the_data_of_a_chain(monkeypatch):
     print(seen)
     assert seen["select"] >= 14 and seen["optimize"] > 500 and seen["marg"] >= 6
     assert seen["worst_H"] < 1e-9 and seen["worst_b"] < 1e-9
+
+
+def test_vio_front_end_on_the_data_of_a_chain():
+    """propagateImuState / initializeImu / updateVel / tryTrapScale (FS/HessianBlocks.cpp:225-429) of the facade on every call the
+    oracle's chain makes (NumPy front-end, oracle/imu_frontend.py): sample lists as the hand-over on frame marginalisation leaves
+    them, biases and spline states as the optimisation leaves them."""
+    import copy
+    worst = dict(propagate=0.0, initialize=0.0, update_vel=0.0, trap=0.0)
+    calls = dict(propagate=0, initialize=0, update_vel=0, trap=0)
+
+    def rel(a, b):
+        a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+        return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
+
+    class Both(rolling.OracleChain):
+        host = host
+        _fe = rolling.DeviceChain._fe
+        _shell = rolling.DeviceChain._shell
+
+        def _snap(self):
+            return copy.deepcopy((self.imu_state, self.imu_zero, {f: s["vel"].copy() for f, s in self.shells.items()}, dict(self.cal),
+                                  np.array(self.scale_queue), self.scale_qi))
+
+        def _restore(self, s):
+            self.imu_state, self.imu_zero = copy.deepcopy(s[0]), copy.deepcopy(s[1])
+            for f, v in s[2].items():
+                self.shells[f]["vel"] = v.copy()
+            self.cal = dict(s[3])
+            self.scale_queue, self.scale_qi = np.array(s[4]), s[5]
+
+        def _both(self, name, what, *a):
+            before = self._snap()
+            r_f = getattr(rolling.DeviceChain, name)(self, *a)
+            after_f = self._snap()
+            self._restore(before)
+            r_o = getattr(rolling.OracleChain, name)(self, *a)
+            after_o = self._snap()
+            calls[what] += 1
+            for f in after_o[0]:
+                worst[what] = max(worst[what], rel(after_f[0][f], after_o[0][f]), rel(after_f[1][f], after_o[1][f]), rel(after_f[2][f], after_o[2][f]))
+            worst[what] = max(worst[what], rel([after_f[3]["scale"], after_f[3]["scale_zero"]], [after_o[3]["scale"], after_o[3]["scale_zero"]]))
+            assert after_f[3]["trapped"] == after_o[3]["trapped"] and after_f[5] == after_o[5]
+            worst[what] = max(worst[what], rel(after_f[4], after_o[4]))
+            assert r_f == r_o or (r_f is None and r_o is None)
+            return r_o
+
+        def vio_propagate(self, *a): return self._both("vio_propagate", "propagate", *a)
+        def vio_initialize(self, *a): return self._both("vio_initialize", "initialize", *a)
+        def vio_update_vel(self, *a): return self._both("vio_update_vel", "update_vel", *a)
+        def vio_try_trap(self, *a): return self._both("vio_try_trap", "trap", *a)
+
+    sc = rolling.Scenario(n_frames=24, vio=True)
+    ch = Both(sc)
+    ch.bootstrap()
+    while ch.next_frame < sc.n_frames:
+        ch.step()
+    print(calls, worst)
+    assert calls["propagate"] >= 14 and calls["initialize"] == 1 and calls["update_vel"] >= 18 and calls["trap"] >= 5
+    assert max(worst.values()) < 1e-9, worst
