@@ -31,7 +31,12 @@ def main():
                 t = m.group(1).strip()
                 if t.startswith("Function Name:") or t.startswith("Name:"):
                     name = t.split(":", 1)[1].strip()
-                    name = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name], capture_output=True, text=True).stdout.strip()
+                    for filt in ("/opt/rocm/lib/llvm/bin/llvm-cxxfilt", "c++filt"):
+                        try:
+                            name = subprocess.run([filt, name], capture_output=True, text=True).stdout.strip() or name
+                            break
+                        except OSError:
+                            continue
                     name = re.sub(r"\(anonymous namespace\)::", "", name)
                     name = re.sub(r"^void ", "", name).split("(")[0]
                     cur = dict(name=name, file=f)
