@@ -282,6 +282,10 @@ int sos_ba_stitch(sos_ba *ba, double *H_A, double *b_A, double *H_L, double *b_L
  * LDL^T solve reads one triangle; the stitch kernels store straight into device-mapped pinned memory. */
 int sos_ba_gn_accumulate(sos_ba *ba, double *H_top, double *b_top, double *H_sc, double *b_sc, int *resInA,
                          int *resInL);
+/* the enqueue half alone (no wait): host work that does not depend on H / b -- the IMU factors between accumulation and solve,
+ * OB/EnergyFunctional.cpp:1053-1066 -- then overlaps the accumulation also when no sos_ba_gn_step prefetched it; the following
+ * sos_ba_gn_accumulate only waits */
+int sos_ba_gn_accumulate_begin(sos_ba *ba);
 /* sos_ba_gn_step = resubstituteF_MT(x) (OB/EnergyFunctional.cpp:1182) + the point part of
  * doStepFromBackup on the device (idepth += stepfacD*step; idepth_zero = idepth,
  * FS/FullSystemOptimize.cpp:207-213) + setPrecalcValues/setDeltaF upload + linearizeAll(false)

@@ -494,11 +494,12 @@ int EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib, boo
   VecX &bA = scrbA, &bsc = scrbsc, bL;
   HA.resize(dd); Hsc.resize(dd); bA.resize(dim); bsc.resize(dim);
   const VecX delta = getStitchedDeltaF();
-  if (imuSettings) {
-    // the IMU branch (OB/EnergyFunctional.cpp:1053-1171), first half: everything that does not need the device's H / b -- the IMU
-    // factors at the current states, the prior's right-hand side, and with first-estimate Jacobians the forward pass through the kept
-    // factor of the IMU states and multipliers (sos_imu.cpp) -- runs here, while the accumulation enqueued by the previous step (or by
-    // sosf_prepare) is in flight on the device
+  // the IMU branch (OB/EnergyFunctional.cpp:1053-1171), first half: everything that does not need the device's H / b -- the IMU factors
+  // at the current states, the prior's right-hand side, and with first-estimate Jacobians the forward pass through the kept factor of
+  // the IMU states and multipliers (sos_imu.cpp) -- runs while the accumulation is in flight on the device (enqueued by the previous
+  // step, by sosf_prepare, or just before this is called)
+  double imuPrepT = 0;  // (spent inside the accumulate phase's wall time: taken out of it below)
+  auto imuPrepare = [&]() -> int {
     const double t_pre0 = now_s();
     for (int h = 0; h < n; h++) {
       frames[h]->data->PRE_camToWorld.to12(imuFrames[h].camToWorld);
@@ -506,9 +507,10 @@ int EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib, boo
     }
     const int rcp = sosf_imu_solve_prepare(imuSettings, imuCalib, n, imuFrames, imuOwnPrior ? HMi.data() : imuHM, imuOwnPrior ? bMi.data() : imuBM,
                                            delta.data(), lambda, imuOwnPrior ? imuPriorVersion : ((uint64_t)1 << 62) + imuCallerPriorName);
-    if (rcp != SOS_OK) return rcp;
-    g_phase[1] += now_s() - t_pre0;
-  }
+    imuPrepT = now_s() - t_pre0;
+    g_phase[1] += imuPrepT;
+    return rcp;
+  };
   double t_acc0 = now_s();
   if (allreduceHook) {  // shard-local sums -> RCCL all-reduce of the packed fp32 blocks -> identical stitch on every rank
     HL.assign(dd, 0.0);
@@ -516,6 +518,7 @@ int EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib, boo
     float *dev = nullptr;
     size_t nfl = 0;
     int rc = sos_ba_accumulate_local(ba);
+    if (rc == SOS_OK && imuSettings) rc = imuPrepare();
     if (rc == SOS_OK) rc = sos_ba_acc_buffer(ba, &dev, &nfl);
     if (rc == SOS_OK) rc = sos_ctx_synchronize(ctx);
     if (rc != SOS_OK) return rc;
@@ -525,10 +528,15 @@ int EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib, boo
     for (size_t i = 0; i < dd; i++) HA[i] += HL[i];
     for (int i = 0; i < dim; i++) bA[i] += bL[i];
   } else {  // HA := HL_top + HA_top already summed by the library
+    if (imuSettings) {
+      int rcp = sos_ba_gn_accumulate_begin(ba);  // (a no-op when the previous step prefetched it)
+      if (rcp == SOS_OK) rcp = imuPrepare();
+      if (rcp != SOS_OK) return rcp;
+    }
     const int rc = sos_ba_gn_accumulate(ba, HA.data(), bA.data(), Hsc.data(), bsc.data(), &resInA, &resInL);
     if (rc != SOS_OK) return rc;  // H / b were not delivered: nothing below may consume them
   }
-  g_phase[0] += now_s() - t_acc0;
+  g_phase[0] += now_s() - t_acc0 - imuPrepT;
   double t_sol0 = now_s();
   MatXX &H = HA;
   VecX &b = bA;

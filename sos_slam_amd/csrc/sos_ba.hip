@@ -4033,6 +4033,20 @@ static int enqueue_gn_accumulate(sos_ba *ba, bool topDone = false, int *pubFlag 
   return SOS_OK;
 }
 
+// The enqueue half of sos_ba_gn_accumulate on its own: nothing is waited for.  A caller with host work that does not depend on H / b
+// (the IMU factors of the visual-inertial solve) calls this first, so that the work overlaps the accumulation also when no
+// sos_ba_gn_step prefetched it.  PENDING_FIRST_GPU_RUN (round 3, written without GPU access).
+extern "C" int sos_ba_gn_accumulate_begin(sos_ba *ba) {
+  if (!ba || !ba->have_window || !ba->have_state) return SOS_ERR_STATE;
+  SOS_HIP(hipSetDevice(ba->ctx->device));
+  if (!ba->acc_inflight) {
+    enqueue_gn_accumulate(ba, ba->top_valid);
+    SOS_HIP(hipGetLastError());
+    ba->acc_inflight = true;
+  }
+  return SOS_OK;
+}
+
 // Fused per-iteration call #1: accumulate + stitch, H_top = H_A + H_L, b_top = b_A + b_L (no priors).
 extern "C" int sos_ba_gn_accumulate(sos_ba *ba, double *H_top, double *b_top, double *H_sc, double *b_sc, int *resInA,
                                     int *resInL) {
