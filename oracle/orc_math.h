@@ -186,8 +186,14 @@ static inline int orc_ldlt_solve(const double *A, const double *b, double *x, in
    * The matrices it is handed are not exactly symmetric -- AccumulatedSCHessian.cpp:128-139 fills block (j, k) and block (k, j) from
    * float accumulators whose entries were rounded as (w L_p) R_q and (w R_q) L_p -- so the elimination below, which carries both
    * triangles along, starts from the lower triangle mirrored: on a symmetric matrix it is Eigen's arithmetic, pivot for pivot. */
-  for (int i = 0; i < n; i++)
-    for (int j = 0; j <= i; j++) M[(size_t)i * N + j] = M[(size_t)j * N + i] = A[(size_t)i * N + j];
+  {
+    static int both = -1; /* ORC_LDLT_BOTH_TRIANGLES=1: the elimination of rounds 1-2 (both triangles carried along), for A/B runs */
+    if (both < 0) both = getenv("ORC_LDLT_BOTH_TRIANGLES") != NULL;
+    if (both) memcpy(M, A, sizeof(double) * N * N);
+    else
+      for (int i = 0; i < n; i++)
+        for (int j = 0; j <= i; j++) M[(size_t)i * N + j] = M[(size_t)j * N + i] = A[(size_t)i * N + j];
+  }
   for (int i = 0; i < n; i++) perm[i] = i;
   for (int k = 0; k < n; k++) {
     int p = k;
