@@ -2999,11 +2999,11 @@ struct DistanceMap {
   std::vector<float> dist;
   std::vector<int> bfs1, bfs2;  // packed (x | y << 16)
   std::vector<uint64_t> visited, front, S, H, nxt;  // one bit per cell, W words per row (the seeding pass)
-  void reset(int w, int h) {  // buffers kept between calls (thread-local instance): only dist is re-initialised
+  void reset(int w, int h, int nSeedsMax) {  // buffers kept between calls (thread-local instance): only dist is re-initialised
     w1 = w; h1 = h; W = (w + 63) / 64;
-    const size_t n = (size_t)w * h;
+    const size_t n = (size_t)w * h, q = std::max(n, (size_t)nSeedsMax + 1);  // (several active points may share a cell: the seed list can be longer than the image)
     dist.assign(n, 1000.f);
-    if (bfs1.size() < n) { bfs1.resize(n); bfs2.resize(n); }
+    if (bfs1.size() < q) { bfs1.resize(q); bfs2.resize(q); }
   }
   inline void relax(int idx, int x, int y, int k, int &num) {
     if (dist[idx] > k) {
@@ -3122,7 +3122,7 @@ extern "C" int sosf_activate_select(int w1, int h1, int nFrames, int newest, con
   static thread_local DistanceMap dm;
   static const bool tmg = getenv("SOS_TIMING") != nullptr;
   const double tq0 = tmg ? now_s() : 0;
-  dm.reset(w1, h1);
+  dm.reset(w1, h1, nActive);
   // makeDistanceMap, FS/CoarseTracker.cpp:793-826
   int numItems = 0;
   for (int i = 0; i < nActive; i++) {

@@ -97,7 +97,8 @@ def test_facade_selection_equals_oracle():
 import pytest
 
 
-@pytest.mark.parametrize("w1,h1,n_seeds", [(64, 40, 30), (65, 33, 1), (127, 50, 5), (128, 9, 40), (376, 240, 3000), (130, 3, 7), (200, 120, 2)])
+@pytest.mark.parametrize("w1,h1,n_seeds", [(64, 40, 30), (65, 33, 1), (127, 50, 5), (128, 9, 40), (376, 240, 3000), (130, 3, 7), (200, 120, 2),
+                                              (20, 6, 500)])      # more active points than cells: many share one
 def test_distance_map_of_the_facade_equals_the_oracle_at_word_boundaries(w1, h1, n_seeds):
     """The facade forms the seeding pass of the distance map by bitmap dilations, 64 cells per word: widths at, just over and just
     under a word boundary, three-row images, seeds on the image border (reached, never spreading), a single seed (cells beyond 39
@@ -122,3 +123,4 @@ def test_distance_map_of_the_facade_equals_the_oracle_at_word_boundaries(w1, h1,
     _, D_f = host.activate_select(w1, h1, 1, KRKi, Kt, act, 2.0, 3.0, none, np.zeros(0, np.int32), np.zeros(0, np.float32), flagged)
     assert np.array_equal(D_o, D_f)
     assert D_o.min() == 0 and (n_seeds > 100 or D_o.max() == 1000 or max(w1, h1) < 80)
+    assert (D_o[0, :] > 0).all() and (D_o[:, 0] > 0).all()      # no seed in row / column 0 (u > 0 && v > 0, FS/CoarseTracker.cpp:815)
