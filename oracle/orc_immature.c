@@ -474,8 +474,11 @@ int orc_activate_select(int w1, int h1, int nFrames, int newest, const float *KR
   distmap m;
   m.w1 = w1; m.h1 = h1;
   m.dist = (float *)malloc(sizeof(float) * (size_t)w1 * h1);
-  m.l1 = (int *)malloc(sizeof(int) * 2 * (size_t)w1 * h1);
-  m.l2 = (int *)malloc(sizeof(int) * 2 * (size_t)w1 * h1);
+  /* (the reference sizes its lists by the image, FS/CoarseTracker.cpp:774-776; several active points may project into one cell, so the
+   * seed list is given room for all of them here -- test windows smaller than their point count must not write past the end) */
+  const size_t qn = (size_t)w1 * h1 > (size_t)nActive + 1 ? (size_t)w1 * h1 : (size_t)nActive + 1;
+  m.l1 = (int *)malloc(sizeof(int) * 2 * qn);
+  m.l2 = (int *)malloc(sizeof(int) * 2 * qn);
   for (int i = 0; i < w1 * h1; i++) m.dist[i] = 1000; /* :797-798 */
   int numItems = 0;
   for (int i = 0; i < nActive; i++) { /* :803-823 */
