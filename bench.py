@@ -436,7 +436,12 @@ def keyframe_timing(window, device):
         sysm.close()
     r = np.array([x[:5] for x in rows[1:]])
     med = np.median(r, axis=0)
-    return {"optimize_ms": float(med[0]), "optimize_iterations": int(rows[-1][5]),
+    try:
+        act_sel = activation_select_timing(win)
+    except Exception as e:   # noqa: BLE001 -- a side figure must not cost the entry
+        act_sel = {"error": repr(e)[:200]}
+    return {"activation_select": act_sel,
+            "optimize_ms": float(med[0]), "optimize_iterations": int(rows[-1][5]),
             "remove_outliers_set_tracking_ref_ms": float(med[1]), "flag_points_marginalize_points_ms": float(med[2]),
             "marginalize_frames_ms": float(med[3]), "keyframe_ms": float(med[:4].sum()),
             "points_marginalized": int(rows[-1][6]), "points_dropped": int(rows[-1][7]), "frames_marginalized": int(rows[-1][8]),
@@ -444,6 +449,54 @@ def keyframe_timing(window, device):
             "note": "optimize_ms: pack + first linearisation + iterations until the step test passes + final linearizeAll(true); "
                     "optimize_6_iterations_ms: the same on the window after the marginalisations with setting_minOptIterations = 6; "
                     "keyframe_ms = the four stages above"}
+
+
+def activation_select_timing(win, n_cand_per_point=4, reps=9):
+    """The host half of FullSystem::activatePointsMT (FS/FullSystem.cpp:375-470) at the window's size: distance map of the active points
+    in the newest keyframe at level 1 + the ordered candidate loop (sosf_activate_select; the device half is sos_immature_activate).
+    The window carries no immature points, so the candidates are synthetic: n_cand_per_point per active point, uniformly over the
+    image, traced states as a running sequence leaves them.  Needs no GPU."""
+    from sos_slam_amd import host
+    from sos_slam_amd.records import IMMATURE_DTYPE
+    n, newest = win.n, win.n - 1
+    w1, h1 = win.w // 2, win.h // 2
+    fx, fy, cx, cy = [np.float32(v) for v in win.K]
+    K1 = np.array([[fx * np.float32(0.5), 0, (cx + np.float32(0.5)) / np.float32(2) - np.float32(0.5)],
+                   [0, fy * np.float32(0.5), (cy + np.float32(0.5)) / np.float32(2) - np.float32(0.5)], [0, 0, 1]], dtype=np.float32)
+    Ki0 = np.linalg.inv(np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], dtype=np.float64)).astype(np.float32)
+    Tn = win.frames[newest]["camToWorld"]
+    Rn, tn = Tn[:9].reshape(3, 3), Tn[9:]
+    KRKi, Kt = [], []
+    for f in range(n):
+        Tf = win.frames[f]["camToWorld"]
+        R = (Rn.T @ Tf[:9].reshape(3, 3)).astype(np.float32)
+        t = (Rn.T @ (Tf[9:] - tn)).astype(np.float32)
+        KRKi.append(((K1 @ R).astype(np.float32) @ Ki0).astype(np.float32).reshape(-1))
+        Kt.append((K1 @ t).astype(np.float32))
+    KRKi, Kt = np.stack(KRKi), np.stack(Kt)
+    act = np.zeros(len(win.points), dtype=[("u", "f4"), ("v", "f4"), ("idepth_scaled", "f4"), ("host", "i4")])
+    for k in ("u", "v", "idepth_scaled", "host"):
+        act[k] = win.points[k]
+    rng = np.random.default_rng(5)
+    nc = n_cand_per_point * len(win.points)
+    cand = np.zeros(nc, dtype=IMMATURE_DTYPE)
+    hosts = np.sort(rng.integers(0, newest, nc)).astype(np.int32)
+    cand["u"], cand["v"] = rng.integers(4, win.w - 4, nc), rng.integers(4, win.h - 4, nc)
+    idm = rng.uniform(0.1, 1.5, nc)
+    cand["idepth_min"], cand["idepth_max"] = idm * 0.9, idm * 1.1
+    cand["quality"], cand["lastTracePixelInterval"] = rng.uniform(1.0, 8.0, nc), rng.uniform(0.0, 12.0, nc)
+    cand["lastTraceStatus"] = rng.choice([0, 0, 0, 3, 4, 1, 2, 5], nc)
+    ctype = rng.choice([1.0, 2.0, 4.0], nc).astype(np.float32)
+    flagged = np.zeros(n, np.uint8)
+    flagged[1 % n] = 1
+    ts, dec = [], None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        dec, _ = host.activate_select(w1, h1, newest, KRKi, Kt, act, 2.0, 3.0, cand, hosts, ctype, flagged)
+        ts.append(time.perf_counter() - t0)
+    return {"activate_select_ms": float(np.median(ts) * 1e3), "candidates": int(nc), "active_points": int(len(act)),
+            "chosen_for_optimisation": int((dec == 1).sum()), "deleted": int((dec == -1).sum()),
+            "note": "host half of activatePointsMT (distance map + ordered candidate loop) on synthetic candidates; not part of keyframe_ms"}
 
 
 def imu_timing(window, device, iters=400):

@@ -52,3 +52,15 @@ def test_side_measurement_process_fails_loudly_without_a_gpu_and_costs_only_its_
     finally:
         sys.path.pop(0)
     assert set(r) == {"error"} and "exit code" in r["error"]
+
+
+def test_activation_select_stage_runs_without_a_gpu():
+    """bench.py -> keyframe -> activation_select: the host half of activatePointsMT timed on synthetic candidates (pure host code)"""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    from sos_slam_amd import synth
+    r = bench.activation_select_timing(synth.make_window("T6"), reps=2)
+    assert r["candidates"] == 4 * r["active_points"] and 0 < r["chosen_for_optimisation"] < r["candidates"] and r["deleted"] > 0
+    assert 0 < r["activate_select_ms"] < 100
