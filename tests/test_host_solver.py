@@ -30,8 +30,12 @@ for n in (100, 192, 401):
     xs = [host.ldlt_solve(A, b, 0) for _ in range(3)]
     assert all(np.array_equal(xs[0], x) for x in xs[1:])
     xr = host.ldlt_solve(A, b, 1)
+    # the partial factorisation of the kept-factor visual-inertial solve (leading block = everything but the last n/4 unknowns; the
+    # multipliers sit at the end of the matrix above, so here the trailing block is indefinite and the leading one positive definite)
+    xp = host.ldlt_partial_solve(A, b, n - n // 4)
     out[str(n)] = {"x": xs[0].tolist(), "err_ref": float(np.abs(xs[0] - xr).max() / np.abs(xr).max()),
-                   "resid": float(np.linalg.norm(A @ xs[0] - b) / np.linalg.norm(b))}
+                   "resid": float(np.linalg.norm(A @ xs[0] - b) / np.linalg.norm(b)),
+                   "xp": xp.tolist(), "err_partial": float(np.abs(xp - xr).max() / np.abs(xr).max())}
 print(json.dumps(out))
 """
 
@@ -55,6 +59,8 @@ def test_large_solve_single_thread_and_helper_threads_agree():
         assert two[n]["err_ref"] < 1e-9 and two[n]["resid"] < 1e-10
         # rows are owned by absolute index: what is computed for an element does not depend on the number of threads
         assert two[n]["x"] == three[n]["x"], n
+        assert two[n]["xp"] == three[n]["xp"], n
+        assert two[n]["err_partial"] < 1e-9 and base[n]["err_partial"] < 1e-9
         # below the threshold dimension the helpers are not used at all
         if int(n) < 192:
             assert two[n]["x"] == base[n]["x"]
