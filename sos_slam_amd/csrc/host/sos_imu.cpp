@@ -733,35 +733,55 @@ void build_cache(ImuCache &Q, const sosf_imu_settings &S, const sosf_imu_calib &
   sos::LdltPartial &P = Q.F;
   P.n = nt;
   P.m = mI;
-  P.U.assign((size_t)nt * nt, 0.0);
+  P.U.resize((size_t)nt * nt);  // only the upper triangle is ever read: what is not written below is zeroed there, not the whole 1.3 MB
   double *U = P.U.data();
+  // the unknowns of the interior and of the border are a few runs of consecutive expanded indices each: rows are filled run by run
+  struct Run { int g0, u0, len; };
+  std::vector<Run> runsI, runsB;
+  for (int u = 0; u < nIs; u++) {
+    if (!runsI.empty() && runsI.back().g0 + runsI.back().len == Q.gI[u]) runsI.back().len++;
+    else runsI.push_back(Run{Q.gI[u], u, 1});
+  }
+  for (int j = 0; j < nb; j++) {
+    if (!runsB.empty() && runsB.back().g0 + runsB.back().len == Q.gB[j]) runsB.back().len++;
+    else runsB.push_back(Run{Q.gB[j], j, 1});
+  }
   for (int u = 0; u < nIs; u++) {  // interior state rows: interior states, multipliers, border
     const int g = Q.gI[u];
     const double *hi = &A.H.a[(size_t)g * dimI], *hm = HM + (size_t)g * dimI;
     double *row = U + (size_t)u * nt;
     const double su = Q.scI[u];
-    row[u] = (hi[g] + hm[g]) * (1 + lambda) * (su * su);
-    for (int v = u + 1; v < nIs; v++) row[v] = (hi[Q.gI[v]] + hm[Q.gI[v]]) * (su * Q.scI[v]);
-    for (int k = 0; k < Q.cdim; k++) {
-      const double v = A.Jrows[k][g];
-      if (v != 0.0) row[nIs + k] = v * (su * Q.scI[nIs + k]);
+    for (const Run &r : runsI) {
+      const int i0 = std::max(0, u + 1 - r.u0);
+      const double *h1 = hi + r.g0, *h2 = hm + r.g0, *sc = &Q.scI[r.u0];
+      double *o = row + r.u0;
+      for (int i = i0; i < r.len; i++) o[i] = (h1[i] + h2[i]) * (su * sc[i]);
     }
-    for (int j = 0; j < nb; j++) row[mI + j] = (hi[Q.gB[j]] + hm[Q.gB[j]]) * su;
+    row[u] = (hi[g] + hm[g]) * (1 + lambda) * (su * su);
+    for (int k = 0; k < Q.cdim; k++) row[nIs + k] = A.Jrows[k][g] * (su * Q.scI[nIs + k]);  // (mostly zeros: written, not assumed)
+    for (const Run &r : runsB) {
+      const double *h1 = hi + r.g0, *h2 = hm + r.g0;
+      double *o = row + mI + r.u0;
+      for (int i = 0; i < r.len; i++) o[i] = (h1[i] + h2[i]) * su;
+    }
   }
   for (int k = 0; k < Q.cdim; k++) {  // multiplier rows: zero diagonal block, the border columns of the constraint
     double *row = U + (size_t)(nIs + k) * nt;
     const double sk = Q.scI[nIs + k];
-    for (int j = 0; j < nb; j++) {
-      const double v = A.Jrows[k][Q.gB[j]];
-      if (v != 0.0) row[mI + j] = v * sk;
-    }
+    std::memset(row + nIs + k, 0, sizeof(double) * (size_t)(Q.cdim - k));
+    for (int j = 0; j < nb; j++) row[mI + j] = A.Jrows[k][Q.gB[j]] * sk;
   }
   for (int j = 0; j < nb; j++) {  // border rows: H_imu + HM, the diagonal times (1 + lambda); the visual block joins per iteration
     const int g = Q.gB[j];
     const double *hi = &A.H.a[(size_t)g * dimI], *hm = HM + (size_t)g * dimI;
     double *row = U + (size_t)(mI + j) * nt + mI;
+    for (const Run &r : runsB) {
+      const int i0 = std::max(0, j + 1 - r.u0);
+      const double *h1 = hi + r.g0, *h2 = hm + r.g0;
+      double *o = row + r.u0;
+      for (int i = i0; i < r.len; i++) o[i] = h1[i] + h2[i];
+    }
     row[j] = (hi[g] + hm[g]) * (1 + lambda);
-    for (int c = j + 1; c < nb; c++) row[c] = hi[Q.gB[c]] + hm[Q.gB[c]];
   }
   clear_imu_blocks(A, n);
   const double tf0 = tmgb ? now_us() : 0;
