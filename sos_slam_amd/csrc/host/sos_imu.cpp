@@ -462,7 +462,8 @@ static int imu_solve_dense(const sosf_imu_settings *S, const sosf_imu_calib *C, 
   const int ms = (int)keep.size(), m = ms + cdim;
   pos.assign(dimI, -1);
   for (int r = 0; r < ms; r++) pos[keep[r]] = r;
-  const double f = 1.0f / (1 + lambda);
+  const double f = 1.0f / (1 + lambda);  // a DOUBLE quotient (float literal over a double sum, :1098); as a float quotient it would be 1.3e-8
+                                         // off, and the solve amplifies that to 2e-4 of the step (tests/test_host_on_chain_data.py)
   // right-hand side of the kept states (HM d2 runs over ALL expanded columns) and the unscaled diagonal
   const double tB0 = tmg ? now_us() : 0;
   bf.assign(m, 0.0);  // here: the visual part b_top - b_sc; the prior's H_M d2 joins in the fill loop below, which has the row in cache

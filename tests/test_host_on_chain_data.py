@@ -111,3 +111,112 @@ def test_vio_front_end_on_the_data_of_a_chain():
     print(calls, worst)
     assert calls["propagate"] >= 14 and calls["initialize"] == 1 and calls["update_vel"] >= 18 and calls["trap"] >= 5
     assert max(worst.values()) < 1e-9, worst
+
+
+def test_imu_solve_against_an_independent_kkt_in_numpy():
+    """A third reading of the IMU branch of solveSystemF (OB/EnergyFunctional.cpp:1053-1148), independent of the two C implementations:
+    the KKT system assembled in NumPy from the pieces (getImuHessian, expandHbtoFitImu, prior around the expanded delta, (1 + lambda)
+    on the diagonal, H_sc / (1 + lambda), constraint rows, removal of the unconstrained states) and solved in extended precision, on
+    every system the oracle's rolling chain solves (lower triangles mirrored: what Eigen's ldlt() reads).
+    Two things it pins that a synthetic scene does not: the H_M d2 term of the right-hand side with d2's IMU part (scale trapped), and
+    `1.0f / (1 + lambda)` being a DOUBLE quotient (a float literal over a double sum) -- taken as a float quotient it is 1.3e-8 off,
+    which moves the step by 2e-4: the solve amplifies perturbations of H_sc by 1e4."""
+    import ctypes as C
+    from sos_slam_amd.records import ImuCalib, ImuFrame, ImuSettings, imu_dim
+    oapi, fac = orc.imu(), host.imu()
+    Lo = orc.lib()
+    vp = C.c_void_p
+    TAP = C.CFUNCTYPE(None, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_double, vp, C.c_double, vp)
+    Lo.orc_set_imu_solve_tap.argtypes = [TAP]
+    LD = np.longdouble
+
+    def arr(p, shape):
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_double)), shape).copy()
+
+    def low(A):
+        return np.tril(A) + np.tril(A, -1).T
+
+    def kkt(S, cal, frames, H_top, b_top, H_sc, b_sc, HM, bM, delta, lam):
+        n = len(frames)
+        dI, d0 = imu_dim(n), 4 + 8 * n
+        H, b, J, r, sv = oapi.hessian(S, cal, frames)
+        He, be = oapi.expand(n, H_top, b_top)
+        Hs, bs = oapi.expand(n, H_sc, b_sc)
+        d2 = np.zeros(dI)
+        d2[:4] = delta[:4]
+        if cal.scale_trapped:
+            d2[4] = cal.scale - cal.scale_zero
+        for i in range(n):
+            d2[5 + 29 * i:5 + 29 * i + 8] = delta[4 + 8 * i:12 + 8 * i]
+            if cal.scale_trapped:
+                d2[5 + 29 * i + 8:5 + 29 * (i + 1)] = np.array(frames[i].state_imu[:]) - np.array(frames[i].state_imu_zero[:])
+        Hf = (He + H + HM).astype(LD)
+        bf = (be + b + bM).astype(LD) + HM.astype(LD) @ d2.astype(LD)
+        Hf[np.diag_indices(dI)] *= LD(1 + lam)
+        Hf -= Hs.astype(LD) * LD(1.0 / (1 + lam))
+        bf -= bs
+        keep = [k for k in range(dI) if k < 4 or (k == 4 and not S.enable_scale_opt) or (k >= 5 and (k - 5) % 29 < (29 if sv[(k - 5) // 29] else 14))]
+        ms, c = len(keep), len(r)
+        K = np.zeros((ms + c, ms + c), LD)
+        K[:ms, :ms] = Hf[np.ix_(keep, keep)]
+        K[:ms, ms:] = J[:, keep].T
+        K[ms:, :ms] = J[:, keep]
+        rhs = np.concatenate([bf[keep], r.astype(LD)])
+        nz = np.abs(K).sum(1) > 0                      # all-zero constraint rows (velocity rows without a valid successor)
+        K2, r2 = K[np.ix_(nz, nz)], rhs[nz]
+        s = 1 / np.sqrt(np.abs(np.diag(K2)).astype(np.float64) + 10)
+        Ks = K2 * s[:, None] * s[None, :]
+        x = np.linalg.solve(Ks.astype(np.float64), (r2 * s).astype(np.float64)).astype(LD)
+        for _ in range(6):                               # iterative refinement with extended-precision residuals
+            x = x + np.linalg.solve(Ks.astype(np.float64), (r2 * s - Ks @ x).astype(np.float64)).astype(LD)
+        assert float(np.abs(r2 * s - Ks @ x).max()) < 1e-14 * max(float(np.abs(r2 * s).max()), 1.0)
+        full = np.zeros(ms + c, LD)
+        full[nz] = x * s
+        xs, imu_step, scale_step = np.zeros(d0), np.zeros((n, 21)), 0.0
+        for j, k in enumerate(keep):
+            if k < 4:
+                xs[k] = full[j]
+            elif k == 4:
+                scale_step = -float(full[j])
+            elif (k - 5) % 29 < 8:
+                xs[4 + 8 * ((k - 5) // 29) + (k - 5) % 29] = full[j]
+            else:
+                imu_step[(k - 5) // 29, (k - 5) % 29 - 8] = -float(full[j])
+        return xs, scale_step, imu_step
+
+    rows = []
+
+    def tap(S, Cal, n, F, H, b, Hsc, bsc, HM, bM, delta, lam, x, scale_step, step_imu):
+        d0, dI = 4 + 8 * n, imu_dim(n)
+        cal = C.cast(Cal, C.POINTER(ImuCalib)).contents
+        Sx = C.cast(S, C.POINTER(ImuSettings)).contents
+        frames = list((ImuFrame * n).from_address(F))
+        args = [low(arr(H, (d0, d0))), arr(b, (d0,)), low(arr(Hsc, (d0, d0))), arr(bsc, (d0,)), low(arr(HM, (dI, dI))), arr(bM, (dI,)), arr(delta, (d0,))]
+        xt, st, it = kkt(Sx, cal, frames, *args, lam)
+        xo, so, io = oapi.solve(Sx, cal, frames, *args, lam=lam)
+        xf, sf, if_ = fac.solve(Sx, cal, frames, *args, lam=lam)
+        sc = np.abs(xt).max()
+        si = max(np.abs(it).max(), 1e-300)
+        rows.append((np.abs(xo - xt).max() / sc, np.abs(xf - xt).max() / sc, np.abs(io - it).max() / si, np.abs(if_ - it).max() / si,
+                     abs(so - st) / max(abs(st), 1e-12), abs(sf - st) / max(abs(st), 1e-12), int(cal.scale_trapped)))
+
+    cb = TAP(tap)
+    Lo.orc_set_imu_solve_tap(cb)
+    try:
+        sc = rolling.Scenario(n_frames=22, vio=True)
+        ch = rolling.OracleChain(sc)
+        ch.bootstrap()
+        while ch.next_frame < sc.n_frames:
+            ch.step()
+    finally:
+        Lo.orc_set_imu_solve_tap(C.cast(None, TAP))
+    r = np.array(rows)
+    print("solves %d (trapped %d): oracle vs NumPy KKT x max %.1e median %.1e, imu %.1e, scale %.1e | facade x max %.1e median %.1e, imu %.1e, scale %.1e"
+          % (len(r), int(r[:, 6].sum()), r[:, 0].max(), np.median(r[:, 0]), r[:, 2].max(), r[:, 4].max(), r[:, 1].max(), np.median(r[:, 1]),
+             r[:, 3].max(), r[:, 5].max()))
+    assert len(r) >= 60 and r[:, 6].sum() >= 20
+    assert np.median(r[:, 0]) < 1e-9 and np.median(r[:, 1]) < 1e-9
+    # the oracle's elimination pivots like Eigen's (largest diagonal first): on the poorly conditioned systems right after the IMU
+    # initialisation it is the less accurate of the two; the facade's threshold pivoting stays at rounding level throughout
+    assert r[:, 0].max() < 1e-4 and r[:, 2].max() < 1e-4 and r[:, 4].max() < 1e-4
+    assert r[:, 1].max() < 1e-8 and r[:, 3].max() < 1e-8 and r[:, 5].max() < 1e-8
