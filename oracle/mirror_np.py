@@ -306,3 +306,29 @@ def marginalize_frame(HM, bM, idx, prior8, delta_prior8):
     bt = bs[:nd] - bli @ bs[nd:]
     Ht, bt = Ht * np.outer(S[:nd], S[:nd]), bt * S[:nd]
     return 0.5 * (Ht + Ht.T), bt
+
+
+def solve_system(H_top, b_top, H_sc, b_sc, HM, bM, delta, lam=1e-5):
+    """EnergyFunctional::solveSystemF with the IMU off (OB/EnergyFunctional.cpp:1046-1148) from its pieces: H_top = HL_top + HA_top
+    (priors in), the prior around delta (bM + HM delta), (1 + lambda) on the diagonal, H_sc * (1.0f / (1 + lambda)) -- a DOUBLE
+    quotient: float literal over a double sum --, Jacobi scaling by (diagonal + 10)^-1/2, solve.  Independent of the C code: NumPy,
+    the lower triangles mirrored (what Eigen's ldlt() reads), extended-precision residuals in an iterative refinement."""
+    LD = np.longdouble
+
+    def low(A):
+        A = np.asarray(A, dtype=np.float64)
+        return np.tril(A) + np.tril(A, -1).T
+
+    H = (low(H_top) + low(HM)).astype(LD)
+    # (bM + HM * delta is a full matrix-vector product, :1090: it sees BOTH triangles of an HM that carries the fp32-level asymmetry of
+    # M - Msc after marginalizePointsF; only the factorisation below reads one triangle)
+    b = np.asarray(b_top, LD) + np.asarray(bM, LD) + np.asarray(HM, LD) @ np.asarray(delta, LD)
+    H[np.diag_indices(len(b))] *= LD(1 + lam)
+    H -= low(H_sc).astype(LD) * LD(1.0 / (1 + lam))
+    b = b - np.asarray(b_sc, LD)
+    s = 1 / np.sqrt(np.diag(H).astype(np.float64) + 10)
+    Hs = H * s[:, None] * s[None, :]
+    x = np.linalg.solve(Hs.astype(np.float64), (b * s).astype(np.float64)).astype(LD)
+    for _ in range(5):
+        x = x + np.linalg.solve(Hs.astype(np.float64), (b * s - Hs @ x).astype(np.float64)).astype(LD)
+    return (x * s).astype(np.float64)

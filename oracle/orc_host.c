@@ -20,6 +20,11 @@ typedef void (*orc_imu_solve_tap_t)(const sosf_imu_settings *, const sosf_imu_ca
                                    const double *, const double *, const double *, const double *, const double *, double, const double *, double,
                                    const double *);
 static orc_imu_solve_tap_t orc_imu_solve_tap_fn = 0;
+/* ... and of the visual solve: (n, H_top + L (priors in), b, H_sc, b_sc, HM, bM, delta, lambda, x) */
+typedef void (*orc_solve_tap_t)(int, const double *, const double *, const double *, const double *, const double *, const double *, const double *,
+                               double, const double *);
+static orc_solve_tap_t orc_solve_tap_fn = 0;
+void orc_set_solve_tap(orc_solve_tap_t fn) { orc_solve_tap_fn = fn; }
 /* test hook: called with the inputs and outputs of every IMU solve of orc_solve_system (inputs as the solve saw them) */
 void orc_set_imu_solve_tap(orc_imu_solve_tap_t fn) { orc_imu_solve_tap_fn = fn; }
 int orc_imu_solve(const sosf_imu_settings *S, const sosf_imu_calib *C, int n, const sosf_imu_frame *F, const double *H_top,
@@ -418,6 +423,12 @@ static void solve_system(orc_window *W, int nthreads) {
     for (int j = 0; j < dim; j++) s += W->HM[(size_t)i * dim + j] * delta[j];
     b[i] += s;
   }
+  double *H0 = NULL, *b0 = NULL; /* (test hook: the pieces as they are before the assembly below) */
+  if (orc_solve_tap_fn) {
+    H0 = (double *)malloc(sizeof(double) * dd); b0 = (double *)malloc(sizeof(double) * dim);
+    for (size_t i = 0; i < dd; i++) H0[i] = HL[i] + HA[i];
+    for (int i = 0; i < dim; i++) b0[i] = bL[i] + bA[i];
+  }
   for (size_t i = 0; i < dd; i++) H[i] += W->HM[i];
   for (int i = 0; i < dim; i++) H[(size_t)i * dim + i] *= (1 + lambda);
   double isc = 1.0f / (1 + lambda);
@@ -432,6 +443,10 @@ static void solve_system(orc_window *W, int nthreads) {
   }
   orc_ldlt_solve(H, b, x, dim);
   for (int i = 0; i < dim; i++) x[i] *= S[i];
+  if (orc_solve_tap_fn) {
+    orc_solve_tap_fn(n, H0, b0, Hsc, bsc, W->HM, W->bM, delta, lambda, x);
+    free(H0); free(b0);
+  }
   memcpy(W->lastX, x, sizeof(double) * dim);
   /* resubstituteF_MT, :496-524 */
   for (int i = 0; i < 4; i++) W->c_step[i] = -x[i];

@@ -171,3 +171,44 @@ def test_marginalize_frame_agrees_with_the_numpy_mirror(idx):
     assert np.abs((Ho - Hm) * np.outer(s, s)).max() <= 1e-9 * max(np.abs(Hm * np.outer(s, s)).max(), 1.0)
     assert np.abs((bo - bm) * s).max() <= 1e-9 * max(np.abs(bm * s).max(), 1.0)
     assert np.abs(H0).max() > 0
+
+
+def test_solve_system_agrees_with_the_numpy_mirror():
+    """solveSystemF (IMU off) of the oracle against oracle/mirror_np.solve_system on every Gauss-Newton iteration of optimize() at T6
+    and W7, and on every solve of a rolling chain (priors out of real marginalisations)."""
+    import ctypes as C
+    from sos_slam_amd import synth
+    from tests import rolling
+    Lo = orc.lib()
+    vp = C.c_void_p
+    TAP = C.CFUNCTYPE(None, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_double, vp)
+    Lo.orc_set_solve_tap.argtypes = [TAP]
+    errs = []
+
+    def arr(p, shape):
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_double)), shape).copy()
+
+    def tap(n, H, b, Hsc, bsc, HM, bM, delta, lam, x):
+        d = 4 + 8 * n
+        xm = mir.solve_system(arr(H, (d, d)), arr(b, (d,)), arr(Hsc, (d, d)), arr(bsc, (d,)), arr(HM, (d, d)), arr(bM, (d,)), arr(delta, (d,)), lam)
+        xo = arr(x, (d,))
+        errs.append(float(np.abs(xo - xm).max() / np.abs(xm).max()))
+
+    cb = TAP(tap)
+    Lo.orc_set_solve_tap(cb)
+    try:
+        for name in ("T6", "W7"):
+            ow = orc.window_from_synth(synth.make_window(name))
+            ow.optimize(6)
+        n_win = len(errs)
+        sc = rolling.Scenario(n_frames=14)
+        ch = rolling.OracleChain(sc)
+        ch.bootstrap()
+        while ch.next_frame < sc.n_frames:
+            ch.step()
+    finally:
+        Lo.orc_set_solve_tap(C.cast(None, TAP))
+    e = np.array(errs)
+    print(f"{n_win} window solves, {len(e) - n_win} chain solves: max {e.max():.1e}, median {np.median(e):.1e}")
+    assert n_win >= 4 and len(e) - n_win >= 20
+    assert e.max() < 1e-8 and np.median(e) < 1e-10
