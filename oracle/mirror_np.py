@@ -224,7 +224,16 @@ def dense_system(J, active, resid, points, n, adHost, adTarget, cDeltaF):
     b_sc = Hpd @ (Hdi * bd)
     (void := cDeltaF)   # the calibration delta only enters through the L (linearised) residuals and the prior terms
     return dict(H_A=H_A, b_A=b_A, H_sc=H_sc, b_sc=b_sc, idepth_hessian=np.where(has, Hdd, 0.0), HdiF=Hdi,
-                bdSumF=np.where(has, bd, 0.0))
+                bdSumF=np.where(has, bd, 0.0), Hpd=Hpd, has=has)
+
+
+def resubstitute(dense, x):
+    """EnergyFunctional::resubstituteF_MT / resubstituteFPt (OB/EnergyFunctional.cpp:496-551) restated on the dense normal equations in
+    ABSOLUTE coordinates: the second block row  Hpd^T x + Hdd d = bd  gives d, and the point step is -d (the frame and calibration
+    steps are -x).  The reference gets there through relative coordinates (xAd = x_h^T adHost + x_t^T adTarget per frame pair, then
+    xAd . JpJdF per residual); no adjoint appears here.  `dense` = the result of dense_system."""
+    d = dense["HdiF"] * (dense["bdSumF"] - dense["Hpd"].T @ np.asarray(x, dtype=np.float64))
+    return np.where(dense["has"], -d, 0.0)
 
 
 # ------------------------------------------------------------------------------------------------

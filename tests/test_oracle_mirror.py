@@ -98,6 +98,13 @@ def test_precalc_linearize_and_system_agree_with_the_numpy_mirror(name, kw):
         xo = np.linalg.solve(t["H_A"] - t["H_sc"] + win.HM + reg, t["b_A"] - t["b_sc"])
         xm = np.linalg.solve(d["H_A"] - d["H_sc"] + win.HM + reg, d["b_A"] - d["b_sc"])
         assert np.linalg.norm(xo - xm) <= 5e-3 * np.linalg.norm(xo)
+        # ---- resubstituteF_MT: the point steps of that direction, relative-coordinate bookkeeping against the dense second block row
+        step_o = ow.resubstitute(xo).astype(np.float64)
+        step_m = mir.resubstitute(d, xo)
+        assert np.array_equal(step_o == 0, step_m == 0) or (np.abs(step_o[step_m == 0]).max() == 0)
+        print(name, "resubstitute: max |oracle - dense| / max |step| =", np.abs(step_o - step_m).max() / np.abs(step_m).max())
+        assert np.abs(step_o - step_m).max() <= 3e-4 * np.abs(step_m).max(), (np.abs(step_o - step_m).max(), np.abs(step_m).max())
+        assert np.abs(step_m).max() > 0
     ow.close()
 
 
