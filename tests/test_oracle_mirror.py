@@ -219,3 +219,29 @@ def test_solve_system_agrees_with_the_numpy_mirror():
     print(f"{n_win} window solves, {len(e) - n_win} chain solves: max {e.max():.1e}, median {np.median(e):.1e}")
     assert n_win >= 4 and len(e) - n_win >= 20
     assert e.max() < 1e-8 and np.median(e) < 1e-10
+
+
+@pytest.mark.parametrize("name", ["T6", "W7"])
+def test_set_state_agrees_with_the_matrix_exponential(name):
+    """FrameHessian::setState (FS/HessianBlocks.h:217-230): PRE_camToWorld = SE3::exp(c2w_leftEps) * camToWorld_evalPT with
+    c2w_leftEps = (SCALE_XI_TRANS * state[0:3], SCALE_XI_ROT * state[3:6]) -- the oracle's Sophus restatement (closed-form exp, left
+    increment on camToWorld) against scipy's matrix exponential of the 4 x 4 twist, on the states three Gauss-Newton iterations leave."""
+    from scipy.linalg import expm
+    win = synth.make_window(name)
+    ow = orc.window_from_synth(win)
+    ow.optimize(3)
+    moved = 0
+    for f in range(win.n):
+        ev, fr = ow.evalpt(f), ow.frame(f)
+        E, T = np.eye(4), np.eye(4)
+        E[:3, :3], E[:3, 3] = ev[:9].reshape(3, 3), ev[9:]
+        T[:3, :3], T[:3, 3] = fr["camToWorld"][:9].reshape(3, 3), fr["camToWorld"][9:]
+        v, w = synth.SCALE_XI_TRANS * fr["state"][:3], synth.SCALE_XI_ROT * fr["state"][3:6]
+        X = np.zeros((4, 4))
+        X[:3, :3] = [[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]
+        X[:3, 3] = v
+        assert np.abs(expm(X) @ E - T).max() < 1e-13
+        moved += int(np.abs(fr["state"][:6]).max() > 1e-5)
+        assert np.abs(T[:3, :3] @ T[:3, :3].T - np.eye(3)).max() < 1e-13
+    assert moved >= win.n - 2        # (the first keyframe carries the gauge, the newest one had its evaluation point reset)
+    ow.close()
