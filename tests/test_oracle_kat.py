@@ -240,3 +240,56 @@ def test_marginalize_points_is_additive():
     assert np.abs(b1 - b2).max() < 1e-5 * max(np.abs(b1).max(), 1e-12)
     observed = np.unique(win.resid["point"])
     assert np.isin(sel[np.isin(sel, observed)], rm1).all()
+
+
+def test_adjoints_are_the_derivatives_of_the_relative_pose():
+    """EnergyFunctional::setAdjointsF (OB/EnergyFunctional.cpp:42-84), pose block: with left increments on camToWorld
+    (FS/HessianBlocks.h:228) the host-to-target transform moves by a LEFT increment  delta = Ad(worldToTarget) (xi_host - xi_target),
+    so adHost = +Ad^T, adTarget = -Ad^T with the rows scaled by SCALE_XI_TRANS / SCALE_XI_ROT (stored transposed: row = the
+    frame's own coordinate).  Checked by central differences of log(T(xi) T(0)^-1) with scipy's expm / logm -- no Sophus, no closed
+    form of the adjoint -- on the evaluation points of a window after three iterations."""
+    from scipy.linalg import expm, logm
+    win = synth.make_window("T6")
+    ow = orc.window_from_synth(win)
+    ow.optimize(3)
+    n = win.n
+    E = []
+    for f in range(n):
+        ev, M = ow.evalpt(f), np.eye(4)
+        M[:3, :3], M[:3, 3] = ev[:9].reshape(3, 3), ev[9:]
+        E.append(M)
+    adH, adT = ow.adHost(), ow.adTarget()
+    scale = np.array([synth.SCALE_XI_TRANS] * 3 + [synth.SCALE_XI_ROT] * 3)
+
+    def twist(x):
+        X = np.zeros((4, 4))
+        X[:3, :3] = [[0, -x[5], x[4]], [x[5], 0, -x[3]], [-x[4], x[3], 0]]
+        X[:3, 3] = x[:3]
+        return X
+
+    def rel(h, t, sh, st):            # worldToTarget * hostToWorld with the (unscaled) state increments sh, st
+        return np.linalg.inv(expm(twist(scale * st)) @ E[t]) @ (expm(twist(scale * sh)) @ E[h])
+
+    def delta(T, T0):
+        L = np.real(logm(T @ np.linalg.inv(T0)))
+        return np.array([L[0, 3], L[1, 3], L[2, 3], L[2, 1], L[0, 2], L[1, 0]])
+
+    eps = 1e-6
+    worst = 0.0
+    for h, t in ((0, 3), (2, 5), (4, 1), (5, 0)):
+        T0 = rel(h, t, np.zeros(6), np.zeros(6))
+        k = h + n * t
+        for which, ad in (("host", adH[k]), ("target", adT[k])):
+            fd = np.zeros((6, 6))       # fd[i, j] = d delta_j / d state_i
+            for i in range(6):
+                e = np.zeros(6)
+                e[i] = eps
+                p = rel(h, t, e, np.zeros(6)) if which == "host" else rel(h, t, np.zeros(6), e)
+                m = rel(h, t, -e, np.zeros(6)) if which == "host" else rel(h, t, np.zeros(6), -e)
+                fd[i] = (delta(p, T0) - delta(m, T0)) / (2 * eps)
+            worst = max(worst, np.abs(fd - ad[:6, :6]).max() / np.abs(ad[:6, :6]).max())
+            assert np.abs(fd - ad[:6, :6]).max() < 1e-6 * np.abs(ad[:6, :6]).max(), (h, t, which)
+            assert np.all(ad[:6, 6:] == 0) and np.all(ad[6:, :6] == 0)       # poses and affine parameters do not mix
+        assert np.array_equal(adH[k][:6, :6], -adT[k][:6, :6])
+    print("adjoints vs central differences:", worst)
+    ow.close()
