@@ -245,3 +245,49 @@ def test_set_state_agrees_with_the_matrix_exponential(name):
         assert np.abs(T[:3, :3] @ T[:3, :3].T - np.eye(3)).max() < 1e-13
     assert moved >= win.n - 2        # (the first keyframe carries the gauge, the newest one had its evaluation point reset)
     ow.close()
+
+
+def test_fix_linearization_is_the_jacobian_times_the_absolute_deltas():
+    """EFResidual::fixLinearizationF (OB/EnergyFunctionalStructs.cpp:75-103) with EnergyFunctional::setDeltaF's adHTdeltaF
+    (OB/EnergyFunctional.cpp:163-194):  resF - res_toZeroF  must be the residual's Jacobian row in ABSOLUTE coordinates
+    (calibration | host frame | target frame | inverse depth -- the rows mirror_np.dense_system builds) times the absolute deltas
+    (value - value_zero, state - state_zero of the two frames, idepth - idepth_zero).  fp64 matrix products against the oracle's
+    float bookkeeping in relative coordinates."""
+    win = synth.make_window("T6")
+    ow = orc.window_from_synth(win)
+    ow.optimize(3)
+    n = win.n
+    res, pts = ow.res().copy(), ow.pts().copy()
+    J = ow.J().copy()
+    act = np.flatnonzero((res["flags"] & 1) != 0)[::3][:400]
+    v, vz = ow.calib_value()
+    cdelta = (v - vz).astype(np.float32).astype(np.float64)
+    dstate = np.stack([ow.frame(f)["state"][:8] - ow.frame(f)["state_zero"][:8] for f in range(n)])
+    assert np.abs(dstate).max() > 1e-5
+    adH, adT = ow.adHost(), ow.adTarget()
+    # setDeltaF: adHTdeltaF[h + n t] = delta_h^T adHost + delta_t^T adTarget
+    adHT = ow.adHTdeltaF().astype(np.float64)
+    for h in range(n):
+        for t in range(n):
+            k = h + n * t
+            want = dstate[h].astype(np.float32).astype(np.float64) @ adH[k] + dstate[t].astype(np.float32).astype(np.float64) @ adT[k]
+            assert np.abs(adHT[k] - want).max() <= 1e-5 * max(np.abs(want).max(), 1e-6), (h, t)
+    resF = J["resF"][act].astype(np.float64)
+    ow.fix_linearization(act)
+    rtz = ow.res_toZeroF()[act].astype(np.float64)
+    worst = 0.0
+    for j, r in enumerate(act):
+        h, t, p = int(res["host"][r]), int(res["target"][r]), int(res["point"][r])
+        k = h + n * t
+        JI = J["JIdx"][r].astype(np.float64)                              # (2, 8)
+        rel8 = np.concatenate([JI.T @ J["Jpdxi"][r].astype(np.float64), J["JabF"][r].astype(np.float64).T], axis=1)     # 8 pixels x 8 relative
+        row_c = JI.T @ J["Jpdc"][r].astype(np.float64)
+        row_h, row_t = rel8 @ adH[k].T, rel8 @ adT[k].T
+        row_d = JI.T @ J["Jpdd"][r].astype(np.float64)
+        lin = row_c @ cdelta + row_h @ dstate[h] + row_t @ dstate[t] + row_d * float(pts["deltaF"][p])
+        got = resF[j] - rtz[j]
+        worst = max(worst, np.abs(got - lin).max() / max(np.abs(lin).max(), 1e-3))
+    print("fixLinearizationF vs J_abs * delta_abs: worst relative difference", worst)
+    assert worst < 2e-3
+    assert ((ow.res()["flags"][act] & synth.RF_LINEARIZED) != 0).all() if hasattr(synth, "RF_LINEARIZED") else True
+    ow.close()
