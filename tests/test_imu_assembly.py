@@ -223,3 +223,87 @@ def test_marginalize_frame_facade_equals_oracle(idx, trapped):
     # the keyframe's IMU factors did enter: the result differs from the factor-free Schur complement
     H0, b0 = orc.imu().marginalize_frame(S, cal, frames, idx, delta, prior8, dprior8, HM, bM, marg_weight=0.0)
     assert np.abs(Ho - H0).max() > 1e-6 * np.abs(H0).max()
+
+
+def test_constraint_rows_match_finite_differences():
+    """The spline constraints of getImuHessianCurrentFrame (OB/EnergyFunctional.cpp:318-375): rotation of the spline over a keyframe
+    interval against the relative rotation of the two keyframes, velocity continuity across a keyframe.  J_cst rows against central
+    differences of r_cst: with respect to the spline states (unscaled), to left rotations of the two keyframes (rotation rows; the
+    analytic row is taken at evalPT = the current rotation) and to translations of the three keyframes (velocity rows)."""
+    # a CONSISTENT scene (IMU samples and spline states generated from the trajectory): the analytic rotation row takes
+    # d log(M^T exp(w)) / dw = I, which holds where the constraint residual is small -- as it is on data a spline was fitted to
+    from sos_slam_amd import synth
+    win = synth.make_window("T6")
+    S, cal, frames, keep = synth.make_imu_records(win, consistent=True)
+    frames = list(frames)[:5]
+    for i, f in enumerate(frames):            # (the records carry no poses of their own: whoever solves fills them in)
+        f.camToWorld[:] = list(win.frames[i]["camToWorld"])
+        f.evalPT_R[:] = list(f.camToWorld[:9])
+    api = orc.imu()
+    H, b, J, r, sv = api.hessian(S, cal, frames)
+    assert list(sv) == [0, 1, 1, 1, 1] and J.shape[0] == 6 * 3 + 3
+    assert np.abs(r).max() < 2e-2
+    CP = 4
+
+    def r_at(mod):
+        fr = []
+        for i, f in enumerate(frames):
+            g = type(f)()
+            C.memmove(C.byref(g), C.byref(f), C.sizeof(f))
+            fr.append(g)
+        mod(fr)
+        return api.hessian(S, cal, fr)[3]
+
+    def fd(mod_plus, mod_minus, eps):
+        return (r_at(mod_plus) - r_at(mod_minus)) / (2 * eps)
+
+    worst = 0.0
+    # spline states (columns 8 + 6 .. 8 + 20 of every keyframe with a valid spline, and of its successor for the velocity rows)
+    for i in range(1, 5):
+        for k in range(6, 21):
+            eps = 1e-7
+            col = CP + 1 + 29 * i + 8 + k
+
+            def mod(s):
+                def m(fr):
+                    fr[i].state_imu[k] += s * eps
+                return m
+            num = fd(mod(+1), mod(-1), eps)
+            scale_ = max(np.abs(J[:, col]).max(), 1.0)
+            worst = max(worst, np.abs(num - J[:, col]).max() / scale_)
+            # (the analytic rows drop the terms of first order in the rotation over the interval -- d log / dw = I + hat(w) / 2 + ... --
+            # 0.5 % at the 0.01 rad of this trajectory: the reference's rows, restated as they are)
+            assert np.allclose(num, J[:, col], rtol=0, atol=1e-2 * scale_), (i, k, num, J[:, col])
+    # left rotations R <- exp(w) R of one keyframe (translation untouched): rotation rows
+    rot_rows = [6 * (i - 1) + q for i in range(1, 4) for q in range(3)] + [18, 19, 20]
+    for i in range(0, 5):
+        for c in range(3):
+            eps = 1e-6
+
+            def mod(s):
+                def m(fr):
+                    w = np.zeros(3)
+                    w[c] = s * eps
+                    R = _rot(w) @ np.array(fr[i].camToWorld[:9]).reshape(3, 3)
+                    fr[i].camToWorld[:9] = list(R.reshape(-1))
+                return m
+            num = fd(mod(+1), mod(-1), eps)[rot_rows]
+            col = CP + 1 + 29 * i + 3 + c
+            worst = max(worst, np.abs(num - J[rot_rows, col]).max())
+            assert np.allclose(num, J[rot_rows, col], rtol=0, atol=1e-2), (i, c, num, J[rot_rows, col])
+    # translations t <- t + SCALE_XI_TRANS * s of one keyframe: velocity rows
+    vel_rows = [6 * (i - 1) + 3 + q for i in range(1, 4) for q in range(3)]
+    for i in range(0, 5):
+        for c in range(3):
+            eps = 1e-6
+
+            def mod(s):
+                def m(fr):
+                    fr[i].camToWorld[9 + c] += 0.5 * s * eps
+                return m
+            num = fd(mod(+1), mod(-1), eps)[vel_rows]
+            col = CP + 1 + 29 * i + c
+            worst = max(worst, np.abs(num - J[vel_rows, col]).max() / max(np.abs(J[vel_rows, col]).max(), 1.0))
+            assert np.allclose(num, J[vel_rows, col], rtol=1e-5, atol=1e-5 * max(np.abs(J[vel_rows, col]).max(), 1.0)), (i, c)
+    assert np.abs(J[vel_rows]).max() > 1 and np.abs(J[rot_rows]).max() > 0.5
+    print("constraint rows vs central differences: worst", worst)
