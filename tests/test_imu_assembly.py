@@ -307,3 +307,37 @@ def test_constraint_rows_match_finite_differences():
             assert np.allclose(num, J[vel_rows, col], rtol=1e-5, atol=1e-5 * max(np.abs(J[vel_rows, col]).max(), 1.0)), (i, c)
     assert np.abs(J[vel_rows]).max() > 1 and np.abs(J[rot_rows]).max() > 0.5
     print("constraint rows vs central differences: worst", worst)
+
+
+def test_trapped_pose_columns_match_finite_differences():
+    """getImuHi with the scale trapped (FS/HessianBlocks.cpp:200-204): the predicted accelerometer sample also depends on the keyframe's
+    rotation, columns 3..5 = SCALE_XI_ROT * rot_i_w * hat(acc_w).  Central differences of the prediction under left rotations
+    R <- exp(w) R of camToWorld, with the first-estimate point equal to the current one (state_imu_zero = state_imu, scale_zero =
+    scale, evalPT = R) so that both describe the same point."""
+    S, cal, frames, keep = _scene(trapped=True)
+    S.weight_imu[:] = list(np.eye(6).reshape(-1))
+    f, tt = frames[1], -0.04
+    f.state_imu_zero[:] = list(f.state_imu[:])
+    cal.scale_zero = cal.scale
+    f.evalPT_R[:] = list(f.camToWorld[:9])
+    api = orc.imu()
+    JsTW, JfTW, Hss, Hff, Hfs = api.get_Hi(S, cal, f, tt)
+    k = np.repeat([SC["BA"], SC["BG"], SC["SL_ROT"], SC["SQ_TRANS"], SC["SQ_ROT"], SC["SC_TRANS"], SC["SC_ROT"]], 3)
+    s = np.array(f.state_imu[:]) * k
+    Ric = np.array(S.rot_imu_cam).reshape(3, 3)
+    R0 = np.array(f.camToWorld[:9]).reshape(3, 3)
+
+    def predict(R):
+        so3 = tt * s[6:9] + tt * tt * s[12:15] + tt ** 3 * s[18:21]
+        acc = 2 * s[9:12] + 6 * tt * s[15:18]
+        gyro = s[6:9] + 2 * tt * s[12:15] + 3 * tt * tt * s[18:21]
+        pa = Ric @ _rot(so3).T @ R.T @ (cal.scale * SC["SCALE"] * acc + np.array(S.gravity))
+        return np.concatenate([pa, Ric @ gyro]) + s[:6]
+
+    for c in range(3):
+        w = np.zeros(3)
+        w[c] = 1e-6
+        num = (predict(_rot(w) @ R0) - predict(_rot(-w) @ R0)) / 2e-6
+        assert np.allclose(JfTW[3 + c], num, rtol=1e-5, atol=1e-6 * np.abs(JfTW[3:6]).max()), c
+    assert np.abs(JfTW[3:6, :3]).max() > 1.0 and np.all(JfTW[3:6, 3:] == 0)       # gravity turns with the keyframe; the gyroscope does not care
+    assert np.all(JfTW[:3] == 0) and np.all(JfTW[6:8] == 0)                        # no translation, no affine columns
