@@ -248,6 +248,11 @@ int sosf_ldlt_solve(const double *A, const double *b, double *x, int n, int whic
  * factorisation with pivots from the leading block only, forward pass, the trailing (n - m) block -- its Schur complement -- solved
  * on its own, backward pass.  Exposed for the CPU test-suite. */
 int sosf_ldlt_partial_solve(const double *A, const double *b, double *x, int n, int m);
+/* the prior algebra of EnergyFunctional::marginalizeFrame in its visual form (OB/EnergyFunctional.cpp:788-858) on its own: (HM, bM) of
+ * dimension 4 + 8 n, the keyframe idx with its pose prior -> the prior of dimension 4 + 8 (n - 1).  What sosf_marginalize_frame runs on
+ * the system's prior; exposed for the CPU test-suite. */
+int sosf_marginalize_frame_prior(int n, int idx, const double *HM, const double *bM, const double *prior8, const double *delta_prior8, double *HM_out,
+                                 double *bM_out);
 
 /* ---- the frame-rate loop: FullSystem::addActiveFrame -> trackNewestCoarse -> traceNewCoarse -> keyframe decision -> makeKeyFrame
  * (FS/FullSystem.cpp:616-766, 311-361, 783-931, 375-531, 1071-1097), visual part, in C++ (csrc/host/sos_sequence.cpp).  The object

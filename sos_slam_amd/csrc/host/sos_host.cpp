@@ -735,27 +735,14 @@ void EnergyFunctional::imuAdoptPrior() {
   imuOwnPrior = true;
 }
 
-int EnergyFunctional::marginalizeFrame(EFFrame *fh) {  // :730-889; the IMU form first when the expanded prior lives here
-  // both reductions are formed into temporaries and committed together at the end: a failure of either leaves HM / bM, HMi / bMi,
-  // the frame list and the caller's IMU records describing the same window
-  MatXX Ho;
-  VecX bo;
-  if (imuOwnPrior) {
-    if (!imuSettings || !imuCalib || !imuFrames) return SOS_ERR_STATE;
-    for (int h = 0; h < nFrames; h++) {  // the records carry the poses the factors are linearised at
-      frames[h]->data->PRE_camToWorld.to12(imuFrames[h].camToWorld);
-      std::memcpy(imuFrames[h].evalPT_R, frames[h]->data->camToWorld_evalPT.R, sizeof(double) * 9);
-    }
-    const VecX delta = getStitchedDeltaF();
-    const int nd = SOSF_IMU_DIM(nFrames - 1);
-    Ho.resize((size_t)nd * nd);
-    bo.resize(nd);
-    const int rci = sosf_imu_marginalize_frame(imuSettings, imuCalib, nFrames, imuFrames, fh->idx, delta.data(), fh->prior, fh->delta_prior,
-                                               prm.margWeightFac, HMi.data(), bMi.data(), Ho.data(), bo.data());
-    if (rci != SOS_OK) return rci;
-  }
+// The prior algebra of EnergyFunctional::marginalizeFrame in its visual form (OB/EnergyFunctional.cpp:788-858): the keyframe's block
+// moved to the end, its pose prior added there, Jacobi scaling, Schur complement on the scaled system, unscaling, symmetrisation.
+// Pure host arithmetic on (HM, bM): also reachable through sosf_marginalize_frame_prior for the CPU tests.  false: the block is
+// singular (the reference asserts isfinite(hpi) at :844); nothing is written then.
+static bool marginalize_frame_prior(const MatXX &HM, const VecX &bM, int nFrames, int idx, const double *prior8, const double *dprior8, MatXX &HMout,
+                                    VecX &bMout) {
   const int step = 8, odim = SOS_CPARS + nFrames * step, ndim = odim - step;
-  const int io = SOS_CPARS + fh->idx * step;
+  const int io = SOS_CPARS + idx * step;
   // move the frame's block to the end (row/column permutation)
   std::vector<int> perm;
   for (int i = 0; i < odim; i++)
@@ -769,8 +756,8 @@ int EnergyFunctional::marginalizeFrame(EFFrame *fh) {  // :730-889; the IMU form
   }
   // add the prior here (instead of to the active part)
   for (int i = 0; i < 8; i++) {
-    Hp[(size_t)(ndim + i) * odim + ndim + i] += fh->prior[i];
-    bp[ndim + i] += fh->prior[i] * fh->delta_prior[i];
+    Hp[(size_t)(ndim + i) * odim + ndim + i] += prior8[i];
+    bp[ndim + i] += prior8[i] * dprior8[i];
   }
   VecX SVec(odim), SVecI(odim);
   for (int i = 0; i < odim; i++) {
@@ -784,7 +771,7 @@ int EnergyFunctional::marginalizeFrame(EFFrame *fh) {  // :730-889; the IMU form
   std::vector<double> hpi((size_t)step * step), hpinv;
   for (int i = 0; i < step; i++)
     for (int j = 0; j < step; j++) hpi[(size_t)i * step + j] = Hp[(size_t)(ndim + i) * odim + ndim + j];
-  if (!mat_inverse(hpi, hpinv, step)) return SOS_ERR_STATE;  // the reference asserts isfinite(hpi) here (:844); HM / bM untouched
+  if (!mat_inverse(hpi, hpinv, step)) return false;
   // bli = bottomLeft^T * hpi ; top -= bli * bottomLeft
   MatXX bli((size_t)ndim * step);
   for (int i = 0; i < ndim; i++)
@@ -804,15 +791,41 @@ int EnergyFunctional::marginalizeFrame(EFFrame *fh) {  // :730-889; the IMU form
     bp[i] -= s;
   }
   MatXX HMn((size_t)ndim * ndim);
-  VecX bMn(ndim);
+  bMout.assign(ndim, 0.0);
   for (int i = 0; i < ndim; i++) {
     for (int j = 0; j < ndim; j++) HMn[(size_t)i * ndim + j] = Hp[(size_t)i * odim + j] * SVec[i] * SVec[j];
-    bMn[i] = bp[i] * SVec[i];
+    bMout[i] = bp[i] * SVec[i];
   }
-  HM.assign((size_t)ndim * ndim, 0.0);
+  HMout.assign((size_t)ndim * ndim, 0.0);
   for (int i = 0; i < ndim; i++)
-    for (int j = 0; j < ndim; j++) HM[(size_t)i * ndim + j] = 0.5 * (HMn[(size_t)i * ndim + j] + HMn[(size_t)j * ndim + i]);
-  bM = bMn;
+    for (int j = 0; j < ndim; j++) HMout[(size_t)i * ndim + j] = 0.5 * (HMn[(size_t)i * ndim + j] + HMn[(size_t)j * ndim + i]);
+  return true;
+}
+
+int EnergyFunctional::marginalizeFrame(EFFrame *fh) {  // :730-889; the IMU form first when the expanded prior lives here
+  // both reductions are formed into temporaries and committed together at the end: a failure of either leaves HM / bM, HMi / bMi,
+  // the frame list and the caller's IMU records describing the same window
+  MatXX Ho;
+  VecX bo;
+  if (imuOwnPrior) {
+    if (!imuSettings || !imuCalib || !imuFrames) return SOS_ERR_STATE;
+    for (int h = 0; h < nFrames; h++) {  // the records carry the poses the factors are linearised at
+      frames[h]->data->PRE_camToWorld.to12(imuFrames[h].camToWorld);
+      std::memcpy(imuFrames[h].evalPT_R, frames[h]->data->camToWorld_evalPT.R, sizeof(double) * 9);
+    }
+    const VecX delta = getStitchedDeltaF();
+    const int nd = SOSF_IMU_DIM(nFrames - 1);
+    Ho.resize((size_t)nd * nd);
+    bo.resize(nd);
+    const int rci = sosf_imu_marginalize_frame(imuSettings, imuCalib, nFrames, imuFrames, fh->idx, delta.data(), fh->prior, fh->delta_prior,
+                                               prm.margWeightFac, HMi.data(), bMi.data(), Ho.data(), bo.data());
+    if (rci != SOS_OK) return rci;
+  }
+  MatXX HMn;
+  VecX bMn;
+  if (!marginalize_frame_prior(HM, bM, nFrames, fh->idx, fh->prior, fh->delta_prior, HMn, bMn)) return SOS_ERR_STATE;  // HM / bM untouched
+  HM.swap(HMn);
+  bM.swap(bMn);
   if (imuOwnPrior) {
     HMi.swap(Ho);
     bMi.swap(bo);
@@ -2736,6 +2749,17 @@ extern "C" int sosf_ldlt_solve(const double *A, const double *b, double *x, int 
   if (which == 0) ldlt_solve(Av, bv, xv, n);
   else ldlt_solve_ref(Av, bv, xv, n);
   std::memcpy(x, xv.data(), sizeof(double) * n);
+  return SOS_OK;
+}
+extern "C" int sosf_marginalize_frame_prior(int n, int idx, const double *HM, const double *bM, const double *prior8, const double *delta_prior8,
+                                            double *HM_out, double *bM_out) {
+  if (n < 2 || idx < 0 || idx >= n || !HM || !bM || !prior8 || !delta_prior8 || !HM_out || !bM_out) return SOS_ERR_ARG;
+  const int od = SOS_CPARS + 8 * n, nd = od - 8;
+  MatXX H(HM, HM + (size_t)od * od), Ho;
+  VecX b(bM, bM + od), bo;
+  if (!marginalize_frame_prior(H, b, n, idx, prior8, delta_prior8, Ho, bo)) return SOS_ERR_STATE;
+  std::memcpy(HM_out, Ho.data(), sizeof(double) * (size_t)nd * nd);
+  std::memcpy(bM_out, bo.data(), sizeof(double) * nd);
   return SOS_OK;
 }
 extern "C" int sosf_ldlt_partial_solve(const double *A, const double *b, double *x, int n, int m) {

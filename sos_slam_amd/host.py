@@ -123,6 +123,18 @@ def ldlt_partial_solve(A, b, m):
     return x
 
 
+def marginalize_frame_prior(HM, bM, idx, prior8, delta_prior8):
+    """The facade's prior algebra of marginalizeFrame (visual form) on a prior of dimension 4 + 8 n; returns (HM', bM') of 4 + 8 (n - 1)."""
+    HM = np.ascontiguousarray(HM, dtype=np.float64)
+    bM = np.ascontiguousarray(bM, dtype=np.float64)
+    n = (len(bM) - 4) // 8
+    p8, d8 = np.ascontiguousarray(prior8, dtype=np.float64), np.ascontiguousarray(delta_prior8, dtype=np.float64)
+    nd = len(bM) - 8
+    Ho, bo = np.zeros((nd, nd)), np.zeros(nd)
+    _chk(load().sosf_marginalize_frame_prior(n, idx, _p(HM), _p(bM), _p(p8), _p(d8), _p(Ho), _p(bo)), "sosf_marginalize_frame_prior")
+    return Ho, bo
+
+
 def activate_select(w1, h1, newest, KRKi, Kt, act, min_dist, min_quality, cand, cand_host, cand_type, host_flagged):
     """Candidate loop of FullSystem::activatePointsMT (sosf_activate_select); `act` = structured array with u, v,
     idepth_scaled, host of the active points.  Returns (decision int8[nCand], fwdWarpedIDDistFinal (h1, w1))."""

@@ -220,3 +220,47 @@ def test_imu_solve_against_an_independent_kkt_in_numpy():
     # initialisation it is the less accurate of the two; the facade's threshold pivoting stays at rounding level throughout
     assert r[:, 0].max() < 1e-4 and r[:, 2].max() < 1e-4 and r[:, 4].max() < 1e-4
     assert r[:, 1].max() < 1e-8 and r[:, 3].max() < 1e-8 and r[:, 5].max() < 1e-8
+
+
+def test_frame_marginalisation_prior_on_the_data_of_a_chain(monkeypatch):
+    """The facade's prior algebra of EnergyFunctional::marginalizeFrame (visual form, sosf_marginalize_frame_prior = what
+    sosf_marginalize_frame runs on the system's prior) against the oracle's and against the NumPy mirror: on a window with a
+    structured prior, and on every frame marginalisation of a rolling chain."""
+    from oracle import mirror_np as mir
+    from sos_slam_amd import synth
+    seen = dict(n=0, worst_o=0.0, worst_m=0.0)
+    orig = orc.OracleWindow.marginalize_frame_prior
+
+    def scaled_err(A, B, bA, bB):
+        s = 1.0 / np.sqrt(np.abs(np.diag(B)) + 10)
+        return max(np.abs((A - B) * np.outer(s, s)).max() / max(np.abs(B * np.outer(s, s)).max(), 1.0),
+                   np.abs((bA - bB) * s).max() / max(np.abs(bB * s).max(), 1.0))
+
+    def both(self, idx):
+        H0, b0 = self.get_prior()
+        pr, dp = self.frame_prior(idx)
+        Ho, bo = orig(self, idx)
+        Hf, bf = host.marginalize_frame_prior(H0, b0, idx, pr, dp)
+        Hm, bm = mir.marginalize_frame(H0, b0, idx, pr, dp)
+        assert np.array_equal(Hf, Hf.T)
+        seen["n"] += 1
+        seen["worst_o"] = max(seen["worst_o"], scaled_err(Hf, Ho, bf, bo))
+        seen["worst_m"] = max(seen["worst_m"], scaled_err(Hf, Hm, bf, bm))
+        return Ho, bo
+
+    monkeypatch.setattr(orc.OracleWindow, "marginalize_frame_prior", both)
+    win = synth.make_window("T6")
+    for idx in (0, 2, 4):
+        ow = orc.window_from_synth(win)
+        ow.optimize(3)
+        ow.marginalize_points(np.flatnonzero(win.points["host"] == 1)[:40].astype(np.int32))
+        ow.marginalize_frame_prior(idx)
+        ow.close()
+    sc = rolling.Scenario(n_frames=20)
+    ch = rolling.OracleChain(sc)
+    ch.bootstrap()
+    while ch.next_frame < sc.n_frames:
+        ch.step()
+    print(seen)
+    assert seen["n"] >= 3 + 8
+    assert seen["worst_o"] < 1e-10 and seen["worst_m"] < 1e-9
