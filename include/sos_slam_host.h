@@ -251,6 +251,12 @@ int sosf_ldlt_partial_solve(const double *A, const double *b, double *x, int n, 
 /* the prior algebra of EnergyFunctional::marginalizeFrame in its visual form (OB/EnergyFunctional.cpp:788-858) on its own: (HM, bM) of
  * dimension 4 + 8 n, the keyframe idx with its pose prior -> the prior of dimension 4 + 8 (n - 1).  What sosf_marginalize_frame runs on
  * the system's prior; exposed for the CPU test-suite. */
+/* the visual solve of solveSystemF from its pieces (OB/EnergyFunctional.cpp:1069-1148): H_top with the priors of the L stitch in, b_top, H_sc,
+ * b_sc, the prior (HM, bM), delta = getStitchedDeltaF(), lambda -> x (dimension 4 + 8 n).  Reads the UPPER triangles of H_top / H_sc / HM
+ * for the matrix (what the device delivers), all of HM for bM + HM delta.  What every Gauss-Newton iteration runs between
+ * sos_ba_gn_accumulate and the step; exposed for the CPU test-suite. */
+int sosf_solve_system(int n, const double *H_top, const double *b_top, const double *H_sc, const double *b_sc, const double *HM, const double *bM,
+                      const double *delta, double lambda, double *x);
 int sosf_marginalize_frame_prior(int n, int idx, const double *HM, const double *bM, const double *prior8, const double *delta_prior8, double *HM_out,
                                  double *bM_out);
 

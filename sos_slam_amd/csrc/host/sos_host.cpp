@@ -486,6 +486,42 @@ int EnergyFunctional::pushState(CalibHessian *HCalib, bool adjoints, bool points
   return rc;
 }
 
+// The visual solve from its pieces (OB/EnergyFunctional.cpp:1069-1148, IMU off): H = H_top with the priors of the L stitch in (upper
+// triangle; destroyed), b likewise; the prior around delta (bM + HM delta: a full matrix-vector product), (1 + lambda) on the diagonal,
+// H_sc * (1.0f / (1 + lambda)) (a double quotient), Jacobi scaling by (diagonal + 10)^-1/2, LDL^T.  Only the upper triangles (col >=
+// row) of H, H_sc and HM enter the matrix: the fused device call delivers just that half, and the LDL^T reads just that half (Eigen's
+// LDLT likewise reads one triangle of HFinal_top).  Pure host arithmetic: also reachable through sosf_solve_system for the CPU tests.
+static void solve_visual_system(MatXX &H, VecX &b, const MatXX &Hsc, const VecX &bsc, const MatXX &HM, const VecX &bM, const VecX &delta, double lambda,
+                                VecX &x, double t_sol0) {
+  const int dim = (int)b.size();
+  for (int i = 0; i < dim; i++) {
+    double s = bM[i];
+    for (int j = 0; j < dim; j++) s += HM[(size_t)i * dim + j] * delta[j];
+    b[i] += s;
+  }
+  const double isc = 1.0f / (1 + lambda);
+  for (int i = 0; i < dim; i++) b[i] -= bsc[i];
+  VecX S(dim);
+  for (int i = 0; i < dim; i++) {
+    const size_t o = (size_t)i * dim + i;
+    const double hii = (H[o] + HM[o]) * (1 + lambda) - Hsc[o] * isc;
+    S[i] = 1.0 / std::sqrt(hii + 10);
+  }
+  for (int i = 0; i < dim; i++) {
+    double *hr = &H[(size_t)i * dim];
+    const double *mr = &HM[(size_t)i * dim], *sr = &Hsc[(size_t)i * dim];
+    const double si = S[i];
+    hr[i] = ((hr[i] + mr[i]) * (1 + lambda) - sr[i] * isc) * (si * si);
+    for (int j = i + 1; j < dim; j++) hr[j] = ((hr[j] + mr[j]) - sr[j] * isc) * (si * S[j]);
+    b[i] *= si;
+  }
+  const double t1 = now_s();
+  g_phase[1] += t1 - t_sol0;
+  ldlt_solve(H, b, x, dim);
+  for (int i = 0; i < dim; i++) x[i] *= S[i];
+  g_phase[2] += now_s() - t1;
+}
+
 int EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib, bool deferResubstitute) {  // :1029-1184, IMU off
   lambda = 1e-5;
   const int n = nFrames, dim = SOS_CPARS + 8 * n;
@@ -587,33 +623,8 @@ int EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib, boo
     for (size_t k = 0; k < allPoints.size(); k++) allPoints[k]->data->step = pointStep[k];
     return SOS_OK;
   }
-  for (int i = 0; i < dim; i++) {
-    double s = bM[i];
-    for (int j = 0; j < dim; j++) s += HM[(size_t)i * dim + j] * delta[j];
-    b[i] += s;
-  }
-  // from here on only the upper triangle (col >= row) of H is maintained: the fused device call delivers just that
-  // half, and the LDL^T below reads just that half (Eigen's LDLT likewise reads one triangle of HFinal_top)
-  const double isc = 1.0f / (1 + lambda);
-  for (int i = 0; i < dim; i++) b[i] -= bsc[i];
-  VecX S(dim), x;
-  for (int i = 0; i < dim; i++) {
-    const size_t o = (size_t)i * dim + i;
-    const double hii = (H[o] + HM[o]) * (1 + lambda) - Hsc[o] * isc;
-    S[i] = 1.0 / std::sqrt(hii + 10);
-  }
-  for (int i = 0; i < dim; i++) {
-    double *hr = &H[(size_t)i * dim];
-    const double *mr = &HM[(size_t)i * dim], *sr = &Hsc[(size_t)i * dim];
-    const double si = S[i];
-    hr[i] = ((hr[i] + mr[i]) * (1 + lambda) - sr[i] * isc) * (si * si);
-    for (int j = i + 1; j < dim; j++) hr[j] = ((hr[j] + mr[j]) - sr[j] * isc) * (si * S[j]);
-    b[i] *= si;
-  }
-  g_phase[1] += now_s() - t_sol0;
-  t_sol0 = now_s();
-  ldlt_solve(H, b, x, dim);
-  for (int i = 0; i < dim; i++) x[i] *= S[i];
+  VecX x;
+  solve_visual_system(H, b, Hsc, bsc, HM, bM, delta, lambda, x, t_sol0);
   lastX = x;
   // resubstituteF_MT, :496-524
   for (int i = 0; i < 4; i++) HCalib->step[i] = -x[i];
@@ -621,7 +632,6 @@ int EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib, boo
     for (int i = 0; i < 8; i++) h->data->step[i] = -x[SOS_CPARS + 8 * h->idx + i];
     h->data->step[8] = h->data->step[9] = 0;
   }
-  g_phase[2] += now_s() - t_sol0;
   if (deferResubstitute) return SOS_OK;  // done by sos_ba_gn_step together with the next linearisation
   pointStep.resize(allPoints.size());
   const int rcr = sos_ba_resubstitute(ba, x.data(), pointStep.data());
@@ -2749,6 +2759,19 @@ extern "C" int sosf_ldlt_solve(const double *A, const double *b, double *x, int 
   if (which == 0) ldlt_solve(Av, bv, xv, n);
   else ldlt_solve_ref(Av, bv, xv, n);
   std::memcpy(x, xv.data(), sizeof(double) * n);
+  return SOS_OK;
+}
+extern "C" int sosf_solve_system(int n, const double *H_top, const double *b_top, const double *H_sc, const double *b_sc, const double *HM,
+                                 const double *bM, const double *delta, double lambda, double *x) {
+  if (n < 1 || !H_top || !b_top || !H_sc || !b_sc || !HM || !bM || !delta || !x) return SOS_ERR_ARG;
+  const int dim = SOS_CPARS + 8 * n;
+  const size_t dd = (size_t)dim * dim;
+  MatXX H(H_top, H_top + dd), Hs(H_sc, H_sc + dd), M(HM, HM + dd);
+  VecX b(b_top, b_top + dim), bs(b_sc, b_sc + dim), bm(bM, bM + dim), dl(delta, delta + dim), xs;
+  double keep[2] = {g_phase[1], g_phase[2]};
+  solve_visual_system(H, b, Hs, bs, M, bm, dl, lambda, xs, now_s());
+  g_phase[1] = keep[0]; g_phase[2] = keep[1];  // (a test hook does not count as an iteration's phase)
+  std::memcpy(x, xs.data(), sizeof(double) * dim);
   return SOS_OK;
 }
 extern "C" int sosf_marginalize_frame_prior(int n, int idx, const double *HM, const double *bM, const double *prior8, const double *delta_prior8,

@@ -123,6 +123,15 @@ def ldlt_partial_solve(A, b, m):
     return x
 
 
+def solve_system(H_top, b_top, H_sc, b_sc, HM, bM, delta, lam=1e-5):
+    """The facade's visual solve from its pieces (sosf_solve_system): upper triangles of H_top / H_sc / HM, all of HM for bM + HM delta."""
+    a = [np.ascontiguousarray(v, dtype=np.float64) for v in (H_top, b_top, H_sc, b_sc, HM, bM, delta)]
+    n = (len(a[1]) - 4) // 8
+    x = np.zeros(len(a[1]))
+    _chk(load().sosf_solve_system(n, *[_p(v) for v in a], C.c_double(float(lam)), _p(x)), "sosf_solve_system")
+    return x
+
+
 def marginalize_frame_prior(HM, bM, idx, prior8, delta_prior8):
     """The facade's prior algebra of marginalizeFrame (visual form) on a prior of dimension 4 + 8 n; returns (HM', bM') of 4 + 8 (n - 1)."""
     HM = np.ascontiguousarray(HM, dtype=np.float64)

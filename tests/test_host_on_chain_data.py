@@ -264,3 +264,46 @@ def test_frame_marginalisation_prior_on_the_data_of_a_chain(monkeypatch):
     print(seen)
     assert seen["n"] >= 3 + 8
     assert seen["worst_o"] < 1e-10 and seen["worst_m"] < 1e-9
+
+
+def test_visual_solve_of_the_facade_on_the_data_of_a_chain():
+    """sosf_solve_system (= what every Gauss-Newton iteration of the facade runs between the device's accumulation and the step:
+    prior right-hand side, (1 + lambda), H_sc / (1 + lambda), Jacobi scaling, blocked LDL^T with threshold pivoting) against the NumPy
+    mirror in extended precision, on every system the oracle solves at T6 / W7 and along a rolling chain.  The facade reads upper
+    triangles, the mirror (as Eigen) lower ones: H_top and H_sc go in transposed; HM, of which bM + HM delta uses all, mirrored."""
+    import ctypes as C
+    from oracle import mirror_np as mir
+    from sos_slam_amd import synth
+    Lo = orc.lib()
+    vp = C.c_void_p
+    TAP = C.CFUNCTYPE(None, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_double, vp)
+    Lo.orc_set_solve_tap.argtypes = [TAP]
+    errs = []
+
+    def arr(p, shape):
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_double)), shape).copy()
+
+    def tap(n, H, b, Hsc, bsc, HM, bM, delta, lam, x):
+        d = 4 + 8 * n
+        Hh, Hs, M = arr(H, (d, d)), arr(Hsc, (d, d)), arr(HM, (d, d))
+        M = np.tril(M) + np.tril(M, -1).T
+        rest = (arr(b, (d,)), arr(bsc, (d,)), arr(bM, (d,)), arr(delta, (d,)))
+        xm = mir.solve_system(Hh, rest[0], Hs, rest[1], M, rest[2], rest[3], lam)
+        xf = host.solve_system(Hh.T, rest[0], Hs.T, rest[1], M, rest[2], rest[3], lam)
+        errs.append(float(np.abs(xf - xm).max() / np.abs(xm).max()))
+
+    cb = TAP(tap)
+    Lo.orc_set_solve_tap(cb)
+    try:
+        for name in ("T6", "W7"):
+            orc.window_from_synth(synth.make_window(name)).optimize(6)
+        sc = rolling.Scenario(n_frames=14)
+        ch = rolling.OracleChain(sc)
+        ch.bootstrap()
+        while ch.next_frame < sc.n_frames:
+            ch.step()
+    finally:
+        Lo.orc_set_solve_tap(C.cast(None, TAP))
+    e = np.array(errs)
+    print(f"{len(e)} systems: facade vs NumPy mirror max {e.max():.1e}, median {np.median(e):.1e}")
+    assert len(e) >= 25 and e.max() < 1e-8 and np.median(e) < 1e-10
