@@ -251,6 +251,13 @@ int sosf_ldlt_partial_solve(const double *A, const double *b, double *x, int n, 
 /* the prior algebra of EnergyFunctional::marginalizeFrame in its visual form (OB/EnergyFunctional.cpp:788-858) on its own: (HM, bM) of
  * dimension 4 + 8 n, the keyframe idx with its pose prior -> the prior of dimension 4 + 8 (n - 1).  What sosf_marginalize_frame runs on
  * the system's prior; exposed for the CPU test-suite. */
+/* the per-keyframe host math that feeds the device, on frames built for the occasion (no system, no device): setEvalPT(evalPT, state_zero) +
+ * setState(state) -> PRE_camToWorld (n x 12), FrameFramePrecalc::set of every pair (n x n records, index host + n target), setAdjointsF
+ * (adHost / adTarget: n x n row-major 8 x 8) and setDeltaF's adHTdeltaF (n x n x 8).  Any output may be NULL.  Exposed for the CPU
+ * test-suite. */
+int sosf_host_frame_math(int n, const double *evalPT12, const double *state_zero10, const double *state10, const float *ab_exposure,
+                         const double *calib_value4, const double *calib_value_zero4, double *camToWorld12, sos_precalc *precalc, double *adHost,
+                         double *adTarget, float *adHTdeltaF);
 /* the visual solve of solveSystemF from its pieces (OB/EnergyFunctional.cpp:1069-1148): H_top with the priors of the L stitch in, b_top, H_sc,
  * b_sc, the prior (HM, bM), delta = getStitchedDeltaF(), lambda -> x (dimension 4 + 8 n).  Reads the UPPER triangles of H_top / H_sc / HM
  * for the matrix (what the device delivers), all of HM for bM + HM delta.  What every Gauss-Newton iteration runs between

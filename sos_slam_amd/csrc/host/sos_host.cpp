@@ -199,31 +199,47 @@ EnergyFunctional::~EnergyFunctional() {
   if (ba) sos_ba_destroy(ba);
 }
 
+// one (host, target) pair of setAdjointsF (OB/EnergyFunctional.cpp:51-84): AH, AT row-major 8 x 8
+static void adjoint_pair(const FrameHessian *host, const FrameHessian *target, double *AH, double *AT) {
+  const SE3 worldToTarget = target->camToWorld_evalPT.inverse();
+  double Ad[36];
+  worldToTarget.Adj(Ad);
+  for (int i = 0; i < 64; i++) AH[i] = AT[i] = 0;
+  for (int i = 0; i < 8; i++) AH[9 * i] = AT[9 * i] = 1;
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) { AH[8 * i + j] = Ad[6 * j + i]; AT[8 * i + j] = -Ad[6 * j + i]; }
+  double aff[2];
+  AffLight::fromToVecExposure(host->ab_exposure, target->ab_exposure, host->aff_g2l_0(), target->aff_g2l_0(), aff);
+  const float a0 = (float)aff[0];
+  AT[8 * 6 + 6] = -a0; AH[8 * 6 + 6] = a0; AT[8 * 7 + 7] = -1; AH[8 * 7 + 7] = a0;
+  for (int j = 0; j < 8; j++) {
+    for (int i = 0; i < 3; i++) { AH[8 * i + j] *= SOS_SCALE_XI_TRANS; AT[8 * i + j] *= SOS_SCALE_XI_TRANS; }
+    for (int i = 3; i < 6; i++) { AH[8 * i + j] *= SOS_SCALE_XI_ROT; AT[8 * i + j] *= SOS_SCALE_XI_ROT; }
+    AH[8 * 6 + j] *= SOS_SCALE_A; AT[8 * 6 + j] *= SOS_SCALE_A;
+    AH[8 * 7 + j] *= SOS_SCALE_B; AT[8 * 7 + j] *= SOS_SCALE_B;
+  }
+}
+// one pair of setDeltaF (:168-176): adHTdeltaF = delta_host^T adHostF + delta_target^T adTargetF, in float, summed left to right
+static void ad_ht_delta_pair(const FrameHessian *host, const FrameHessian *target, const float *AHf, const float *ATf, float *out8) {
+  float dh[8], dt[8];
+  for (int i = 0; i < 8; i++) {
+    dh[i] = (float)(host->state[i] - host->state_zero[i]);
+    dt[i] = (float)(target->state[i] - target->state_zero[i]);
+  }
+  for (int j = 0; j < 8; j++) {
+    float s1 = 0, s2 = 0;
+    for (int i = 0; i < 8; i++) { s1 += dh[i] * AHf[8 * i + j]; s2 += dt[i] * ATf[8 * i + j]; }
+    out8[j] = s1 + s2;
+  }
+}
+
 void EnergyFunctional::setAdjointsF(CalibHessian *) {  // OB/EnergyFunctional.cpp:42-103
   const int n = nFrames;
   adHost.assign((size_t)n * n * 64, 0.0);
   adTarget.assign((size_t)n * n * 64, 0.0);
   for (int h = 0; h < n; h++)
-    for (int t = 0; t < n; t++) {
-      const FrameHessian *host = frames[h]->data, *target = frames[t]->data;
-      const SE3 worldToTarget = target->camToWorld_evalPT.inverse();
-      double Ad[36];
-      worldToTarget.Adj(Ad);
-      double *AH = &adHost[(size_t)(h + t * n) * 64], *AT = &adTarget[(size_t)(h + t * n) * 64];
-      for (int i = 0; i < 8; i++) AH[9 * i] = AT[9 * i] = 1;
-      for (int i = 0; i < 6; i++)
-        for (int j = 0; j < 6; j++) { AH[8 * i + j] = Ad[6 * j + i]; AT[8 * i + j] = -Ad[6 * j + i]; }
-      double aff[2];
-      AffLight::fromToVecExposure(host->ab_exposure, target->ab_exposure, host->aff_g2l_0(), target->aff_g2l_0(), aff);
-      const float a0 = (float)aff[0];
-      AT[8 * 6 + 6] = -a0; AH[8 * 6 + 6] = a0; AT[8 * 7 + 7] = -1; AH[8 * 7 + 7] = a0;
-      for (int j = 0; j < 8; j++) {
-        for (int i = 0; i < 3; i++) { AH[8 * i + j] *= SOS_SCALE_XI_TRANS; AT[8 * i + j] *= SOS_SCALE_XI_TRANS; }
-        for (int i = 3; i < 6; i++) { AH[8 * i + j] *= SOS_SCALE_XI_ROT; AT[8 * i + j] *= SOS_SCALE_XI_ROT; }
-        AH[8 * 6 + j] *= SOS_SCALE_A; AT[8 * 6 + j] *= SOS_SCALE_A;
-        AH[8 * 7 + j] *= SOS_SCALE_B; AT[8 * 7 + j] *= SOS_SCALE_B;
-      }
-    }
+    for (int t = 0; t < n; t++)
+      adjoint_pair(frames[h]->data, frames[t]->data, &adHost[(size_t)(h + t * n) * 64], &adTarget[(size_t)(h + t * n) * 64]);
   for (int i = 0; i < 4; i++) cPrior[i] = prm.initialCalibHessian;
   adHostF.resize(adHost.size());
   adTargetF.resize(adTarget.size());
@@ -237,16 +253,7 @@ void EnergyFunctional::setDeltaF(CalibHessian *HCalib, bool points) {  // OB/Ene
   for (int h = 0; h < n; h++)
     for (int t = 0; t < n; t++) {
       const size_t idx = (size_t)(h + t * n);
-      float dh[8], dt[8];
-      for (int i = 0; i < 8; i++) {
-        dh[i] = (float)(frames[h]->data->state[i] - frames[h]->data->state_zero[i]);
-        dt[i] = (float)(frames[t]->data->state[i] - frames[t]->data->state_zero[i]);
-      }
-      for (int j = 0; j < 8; j++) {
-        float s1 = 0, s2 = 0;
-        for (int i = 0; i < 8; i++) { s1 += dh[i] * adHostF[64 * idx + 8 * i + j]; s2 += dt[i] * adTargetF[64 * idx + 8 * i + j]; }
-        adHTdeltaF[8 * idx + j] = s1 + s2;
-      }
+      ad_ht_delta_pair(frames[h]->data, frames[t]->data, &adHostF[64 * idx], &adTargetF[64 * idx], &adHTdeltaF[8 * idx]);
     }
   for (int i = 0; i < 4; i++) cDeltaF[i] = (float)HCalib->value_minus_value_zero[i];
   for (EFFrame *f : frames) {
@@ -2759,6 +2766,45 @@ extern "C" int sosf_ldlt_solve(const double *A, const double *b, double *x, int 
   if (which == 0) ldlt_solve(Av, bv, xv, n);
   else ldlt_solve_ref(Av, bv, xv, n);
   std::memcpy(x, xv.data(), sizeof(double) * n);
+  return SOS_OK;
+}
+// The per-keyframe host math that feeds the device, on frames built for the occasion (no system, no device): setEvalPT + setState
+// (FS/HessianBlocks.h:217-260), FrameFramePrecalc::set of every pair (FS/HessianBlocks.cpp:90-120), setAdjointsF and setDeltaF's
+// adHTdeltaF (OB/EnergyFunctional.cpp:42-103, 163-176).  Pair index h + n t.  Exposed for the CPU test-suite.
+extern "C" int sosf_host_frame_math(int n, const double *evalPT12, const double *state_zero10, const double *state10, const float *ab_exposure,
+                                    const double *calib_value4, const double *calib_value_zero4, double *camToWorld12, sos_precalc *precalc,
+                                    double *adHost, double *adTarget, float *adHTdeltaF) {
+  if (n < 1 || n > SOS_MAX_FRAMES || !evalPT12 || !state_zero10 || !state10 || !ab_exposure || !calib_value4 || !calib_value_zero4) return SOS_ERR_ARG;
+  CalibHessian HC;
+  for (int i = 0; i < 4; i++) HC.value_zero[i] = calib_value_zero4[i];
+  HC.setValue(calib_value4);
+  std::vector<std::unique_ptr<FrameHessian>> F;
+  for (int f = 0; f < n; f++) {
+    F.emplace_back(new FrameHessian());
+    F[f]->idx = f;
+    F[f]->ab_exposure = ab_exposure[f];
+    F[f]->setEvalPT(SE3::from12(evalPT12 + 12 * f), state_zero10 + 10 * f);
+    F[f]->setState(state10 + 10 * f);
+    if (camToWorld12) F[f]->PRE_camToWorld.to12(camToWorld12 + 12 * f);
+  }
+  std::vector<float> ahf(64), atf(64);
+  for (int h = 0; h < n; h++)
+    for (int t = 0; t < n; t++) {
+      const size_t k = (size_t)(h + n * t);
+      if (precalc) {
+        FrameFramePrecalc pc;
+        pc.set(F[h].get(), F[t].get(), &HC);
+        precalc[k] = pc.dev;
+      }
+      double AH[64], AT[64];
+      adjoint_pair(F[h].get(), F[t].get(), AH, AT);
+      if (adHost) std::memcpy(adHost + 64 * k, AH, sizeof(AH));
+      if (adTarget) std::memcpy(adTarget + 64 * k, AT, sizeof(AT));
+      if (adHTdeltaF) {
+        for (int i = 0; i < 64; i++) { ahf[i] = (float)AH[i]; atf[i] = (float)AT[i]; }
+        ad_ht_delta_pair(F[h].get(), F[t].get(), ahf.data(), atf.data(), adHTdeltaF + 8 * k);
+      }
+    }
   return SOS_OK;
 }
 extern "C" int sosf_solve_system(int n, const double *H_top, const double *b_top, const double *H_sc, const double *b_sc, const double *HM,

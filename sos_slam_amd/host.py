@@ -853,3 +853,22 @@ class Sequence:
         self.L.sosf_sequence_get_immature.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         _chk(self.L.sosf_sequence_get_immature(self.h_, int(frame_id), c.value, _p(rec), _p(ty)), "sosf_sequence_get_immature")
         return rec, ty
+
+
+def host_frame_math(evalPT, state_zero, state, ab_exposure, calib_value, calib_value_zero):
+    """The facade's per-keyframe host math on frames built for the occasion (sosf_host_frame_math): returns PRE_camToWorld (n, 12), the
+    n x n precalc records (index host + n target), adHost / adTarget (n * n, 8, 8) and adHTdeltaF (n * n, 8)."""
+    from . import synth
+    ev = np.ascontiguousarray(evalPT, dtype=np.float64).reshape(-1, 12)
+    n = len(ev)
+    sz = np.ascontiguousarray(state_zero, dtype=np.float64).reshape(n, 10)
+    st = np.ascontiguousarray(state, dtype=np.float64).reshape(n, 10)
+    ab = np.ascontiguousarray(ab_exposure, dtype=np.float32).reshape(n)
+    v, vz = np.ascontiguousarray(calib_value, dtype=np.float64), np.ascontiguousarray(calib_value_zero, dtype=np.float64)
+    c2w = np.zeros((n, 12))
+    pc = np.zeros(n * n, dtype=synth.PRECALC_DTYPE)
+    adH, adT = np.zeros((n * n, 8, 8)), np.zeros((n * n, 8, 8))
+    adHT = np.zeros((n * n, 8), np.float32)
+    _chk(load().sosf_host_frame_math(n, _p(ev), _p(sz), _p(st), _p(ab), _p(v), _p(vz), _p(c2w), _p(pc), _p(adH), _p(adT), _p(adHT)),
+         "sosf_host_frame_math")
+    return c2w, pc, adH, adT, adHT

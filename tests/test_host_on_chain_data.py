@@ -4,6 +4,7 @@ the facade's implementation as well (sosf_activate_select with its bitmap distan
 blocked Schur update).  Priors out of real marginalisations span 1e8 .. 1e-19; candidate sets carry the trace states real traces
 leave.  CPU only."""
 import numpy as np
+import pytest
 
 from oracle import oracle as orc
 from sos_slam_amd import host
@@ -307,3 +308,30 @@ def test_visual_solve_of_the_facade_on_the_data_of_a_chain():
     e = np.array(errs)
     print(f"{len(e)} systems: facade vs NumPy mirror max {e.max():.1e}, median {np.median(e):.1e}")
     assert len(e) >= 25 and e.max() < 1e-8 and np.median(e) < 1e-10
+
+
+@pytest.mark.parametrize("name", ["T6", "W7", "W12"])
+def test_per_keyframe_host_math_of_the_facade_equals_the_oracle(name):
+    """setEvalPT / setState, FrameFramePrecalc::set of every pair, setAdjointsF and setDeltaF's adHTdeltaF as the FACADE computes them
+    (sosf_host_frame_math: the functions the system runs, on frames built for the occasion) against the oracle's, from the states three
+    Gauss-Newton iterations leave: everything the device is handed per step that is not an image or a point.  Bit for bit."""
+    from sos_slam_amd import synth
+    win = synth.make_window(name)
+    ow = orc.window_from_synth(win, nthreads=4)
+    ow.optimize(3)
+    n = win.n
+    ev = np.stack([ow.evalpt(f) for f in range(n)])
+    fr = [ow.frame(f) for f in range(n)]
+    v, vz = ow.calib_value()
+    c2w, pc, adH, adT, adHT = host.host_frame_math(ev, [f["state_zero"] for f in fr], [f["state"] for f in fr], win.frames["ab_exposure"], v, vz)
+    assert np.array_equal(c2w, np.stack([f["camToWorld"] for f in fr]))
+    po = ow.precalc()
+    offd = np.array([h != t for t in range(n) for h in range(n)])
+    for field in po.dtype.names:
+        if field == "pad":
+            continue
+        assert np.array_equal(np.asarray(pc[field])[offd], np.asarray(po[field])[offd]), field
+    assert np.array_equal(adH, ow.adHost()) and np.array_equal(adT, ow.adTarget())
+    assert np.array_equal(adHT, ow.adHTdeltaF())
+    assert np.abs(adHT).max() > 0 and np.abs(np.stack([f["state"] for f in fr])[:, :6]).max() > 1e-5
+    ow.close()
