@@ -32,7 +32,10 @@ def global_nth(dist, local: np.ndarray, frac: float) -> float:
     allv = np.concatenate(parts) if parts else np.zeros(0, np.float32)
     if allv.size == 0:
         return -1.0
-    k = int(np.float32(frac) * np.float32(allv.size)) if False else int(frac * allv.size)
+    # the index as the C code forms it (FS/FullSystemOptimize.cpp:104: a FLOAT setting times the count, truncated): in double
+    # 0.7f * 170 = 118.999998 -> 118, in float it rounds to 119.0 -> 119; one rank and N ranks must pick the same element
+    k = int(np.float32(frac) * np.float32(allv.size))
+    k = min(k, allv.size - 1)
     return float(np.partition(allv, k)[k])
 
 

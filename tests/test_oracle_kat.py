@@ -185,6 +185,27 @@ def test_energy_threshold_statistic():
     assert ow.frame(0)["frameEnergyTH"] == pytest.approx(512.0)
 
 
+@pytest.mark.parametrize("name", ["T4", "T6", "W7"])
+def test_energy_threshold_is_the_order_statistic_formula(name):
+    """setNewFrameEnergyTH restated in NumPy from the energies of the last linearisation (every residual towards the newest keyframe
+    with state_NewEnergyWithOutlier >= 0, those the final linearizeAll(true) then dropped included):
+        th = ((26 w + sqrt(e[k]) fac (1 - w)) overall)^2,   k = (int)(frameEnergyTHN * count)
+    with the index formed in FLOAT as the reference does (a float setting times the count): 0.7f * 170 = 119.0, where the double product
+    118.99999999999999 would truncate to 118 -- T4 (170 residuals) and W7 (1450 -> 1015 vs 1014) sit on such counts."""
+    win = synth.make_window(name)
+    ow = orc.window_from_synth(win)
+    ow.optimize(2)
+    res, wo, p = ow.res(), ow.new_energy_wo(), win.params
+    e = np.sort(wo[(res["target"] == win.n - 1) & (wo >= 0)])
+    k = int(np.float32(p["frameEnergyTHN"]) * np.float32(len(e)))
+    th = np.float32(np.sqrt(np.float32(e[k]))) * np.float32(p["frameEnergyTHFacMedian"])
+    th = np.float32(np.float32(26.0) * np.float32(p["frameEnergyTHConstWeight"]) + th * np.float32(1 - p["frameEnergyTHConstWeight"]))
+    th = np.float32(th * th) * np.float32(p["overallEnergyTHWeight"]) ** 2
+    assert ow.frame(win.n - 1)["frameEnergyTH"] == pytest.approx(float(th), rel=1e-6)
+    if name in ("T4", "W7"):
+        assert int(p["frameEnergyTHN"] * len(e)) == k - 1 and e[k] > e[k - 1]
+
+
 def test_marginalize_frame_is_dense_schur_complement():
     """marginalizeFrame (OB/EnergyFunctional.cpp:730-889, IMU off) = eliminating the frame's 8 variables (with its
     prior added) from HM / bM; the reference's Jacobi scaling and symmetrisation do not change the result."""
