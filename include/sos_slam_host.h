@@ -258,6 +258,10 @@ int sosf_ldlt_partial_solve(const double *A, const double *b, double *x, int n, 
 int sosf_host_frame_math(int n, const double *evalPT12, const double *state_zero10, const double *state10, const float *ab_exposure,
                          const double *calib_value4, const double *calib_value_zero4, double *camToWorld12, sos_precalc *precalc, double *adHost,
                          double *adTarget, float *adHTdeltaF);
+/* FullSystem::setNewFrameEnergyTH (FS/FullSystemOptimize.cpp:84-124) on a list of energies (state_NewEnergyWithOutlier >= 0 of the residuals
+ * towards the newest keyframe): the element at index (int)(frameEnergyTHN * count) -- a float product -- through the threshold formula;
+ * 12 * 12 * patternNum for an empty list.  Exposed for the CPU test-suite. */
+int sosf_new_frame_energy_th(const float *energies, int count, float frameEnergyTHN, float facMedian, float constWeight, float overall, float *th);
 /* the visual solve of solveSystemF from its pieces (OB/EnergyFunctional.cpp:1069-1148): H_top with the priors of the L stitch in, b_top, H_sc,
  * b_sc, the prior (HM, bM), delta = getStitchedDeltaF(), lambda -> x (dimension 4 + 8 n).  Reads the UPPER triangles of H_top / H_sc / HM
  * for the matrix (what the device delivers), all of HM for bM + HM delta.  What every Gauss-Newton iteration runs between

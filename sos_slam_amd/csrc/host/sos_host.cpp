@@ -1006,29 +1006,32 @@ void FullSystem::setNewFrameEnergyTH() {  // FS/FullSystemOptimize.cpp:84-124
   setNewFrameEnergyTH(allResVec);
 }
 
+// the threshold from the order statistic (FS/FullSystemOptimize.cpp:104-124): nthValue = the element at index (int)(frameEnergyTHN * count)
+// -- a FLOAT product, as the reference forms it -- of the newest frame's energies
+static float energy_threshold_from_nth(float nthValue, float facMedian, float constWeight, float overall) {
+  const float nthElement = sqrtf(nthValue);
+  float th = nthElement * facMedian;
+  th = 26.0f * constWeight + th * (1 - constWeight);
+  th = th * th;
+  th *= overall * overall;
+  return th;
+}
+static float energy_threshold(std::vector<float> &allResVec, float thn, float facMedian, float constWeight, float overall) {
+  if (allResVec.empty()) return 12 * 12 * SOS_PATTERN_NUM;
+  const int nthIdx = (int)(thn * allResVec.size());
+  std::nth_element(allResVec.begin(), allResVec.begin() + nthIdx, allResVec.end());
+  return energy_threshold_from_nth(allResVec[nthIdx], facMedian, constWeight, overall);
+}
+
 void FullSystem::setNewFrameEnergyTH(std::vector<float> &allResVec) {
   FrameHessian *newFrame = frameHessians.back();
-  float nthValue;
   if (ef->nthHook) {  // global order statistic over all shards
-    nthValue = ef->nthHook(ef->hookUser, allResVec.data(), (int)allResVec.size(), prm.frameEnergyTHN);
-    if (nthValue < 0) {
-      newFrame->frameEnergyTH = 12 * 12 * SOS_PATTERN_NUM;
-      return;
-    }
-  } else {
-    if (allResVec.empty()) {
-      newFrame->frameEnergyTH = 12 * 12 * SOS_PATTERN_NUM;
-      return;
-    }
-    const int nthIdx = (int)(prm.frameEnergyTHN * allResVec.size());
-    std::nth_element(allResVec.begin(), allResVec.begin() + nthIdx, allResVec.end());
-    nthValue = allResVec[nthIdx];
+    const float nthValue = ef->nthHook(ef->hookUser, allResVec.data(), (int)allResVec.size(), prm.frameEnergyTHN);
+    newFrame->frameEnergyTH = nthValue < 0 ? 12 * 12 * SOS_PATTERN_NUM
+                                           : energy_threshold_from_nth(nthValue, prm.frameEnergyTHFacMedian, prm.frameEnergyTHConstWeight, prm.overallEnergyTHWeight);
+    return;
   }
-  const float nthElement = sqrtf(nthValue);
-  newFrame->frameEnergyTH = nthElement * prm.frameEnergyTHFacMedian;
-  newFrame->frameEnergyTH = 26.0f * prm.frameEnergyTHConstWeight + newFrame->frameEnergyTH * (1 - prm.frameEnergyTHConstWeight);
-  newFrame->frameEnergyTH = newFrame->frameEnergyTH * newFrame->frameEnergyTH;
-  newFrame->frameEnergyTH *= prm.overallEnergyTHWeight * prm.overallEnergyTHWeight;
+  newFrame->frameEnergyTH = energy_threshold(allResVec, prm.frameEnergyTHN, prm.frameEnergyTHFacMedian, prm.frameEnergyTHConstWeight, prm.overallEnergyTHWeight);
 }
 
 double FullSystem::linearizeAll(bool fix) {  // FS/FullSystemOptimize.cpp:125-182
@@ -2805,6 +2808,13 @@ extern "C" int sosf_host_frame_math(int n, const double *evalPT12, const double 
         ad_ht_delta_pair(F[h].get(), F[t].get(), ahf.data(), atf.data(), adHTdeltaF + 8 * k);
       }
     }
+  return SOS_OK;
+}
+extern "C" int sosf_new_frame_energy_th(const float *energies, int count, float frameEnergyTHN, float facMedian, float constWeight, float overall,
+                                       float *th) {
+  if (count < 0 || (count && !energies) || !th) return SOS_ERR_ARG;
+  std::vector<float> v(energies, energies + count);
+  *th = energy_threshold(v, frameEnergyTHN, facMedian, constWeight, overall);
   return SOS_OK;
 }
 extern "C" int sosf_solve_system(int n, const double *H_top, const double *b_top, const double *H_sc, const double *b_sc, const double *HM,

@@ -872,3 +872,12 @@ def host_frame_math(evalPT, state_zero, state, ab_exposure, calib_value, calib_v
     _chk(load().sosf_host_frame_math(n, _p(ev), _p(sz), _p(st), _p(ab), _p(v), _p(vz), _p(c2w), _p(pc), _p(adH), _p(adT), _p(adHT)),
          "sosf_host_frame_math")
     return c2w, pc, adH, adT, adHT
+
+
+def new_frame_energy_th(energies, thn=0.7, fac_median=1.5, const_weight=0.5, overall=1.0):
+    """The facade's setNewFrameEnergyTH on a list of energies (sosf_new_frame_energy_th)."""
+    e = np.ascontiguousarray(energies, dtype=np.float32)
+    th = C.c_float(0)
+    _chk(load().sosf_new_frame_energy_th(_p(e), len(e), C.c_float(thn), C.c_float(fac_median), C.c_float(const_weight), C.c_float(overall), C.byref(th)),
+         "sosf_new_frame_energy_th")
+    return th.value

@@ -335,3 +335,20 @@ def test_per_keyframe_host_math_of_the_facade_equals_the_oracle(name):
     assert np.array_equal(adHT, ow.adHTdeltaF())
     assert np.abs(adHT).max() > 0 and np.abs(np.stack([f["state"] for f in fr])[:, :6]).max() > 1e-5
     ow.close()
+
+
+@pytest.mark.parametrize("name", ["T4", "T6", "W7"])
+def test_energy_threshold_of_the_facade_equals_the_oracle(name):
+    """setNewFrameEnergyTH of the facade (sosf_new_frame_energy_th: the function the system runs) on the energies the oracle's last
+    linearisation left, against the threshold the oracle set from them -- at counts where the float and the double product of the
+    index differ (170 at T4, 1450 at W7)."""
+    from sos_slam_amd import synth
+    win = synth.make_window(name)
+    ow = orc.window_from_synth(win)
+    ow.optimize(2)
+    res, wo, p = ow.res(), ow.new_energy_wo(), win.params
+    e = wo[(res["target"] == win.n - 1) & (wo >= 0)]
+    th = host.new_frame_energy_th(e, p["frameEnergyTHN"], p["frameEnergyTHFacMedian"], p["frameEnergyTHConstWeight"], p["overallEnergyTHWeight"])
+    assert th == ow.frame(win.n - 1)["frameEnergyTH"]
+    assert host.new_frame_energy_th(e[:0]) == 12 * 12 * 8
+    ow.close()
