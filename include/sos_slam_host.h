@@ -258,6 +258,12 @@ int sosf_ldlt_partial_solve(const double *A, const double *b, double *x, int n, 
 int sosf_host_frame_math(int n, const double *evalPT12, const double *state_zero10, const double *state10, const float *ab_exposure,
                          const double *calib_value4, const double *calib_value_zero4, double *camToWorld12, sos_precalc *precalc, double *adHost,
                          double *adTarget, float *adHTdeltaF);
+/* the decision of FullSystem::flagFramesForMarginalization (FS/FullSystemMarginalize.cpp:54-141) on plain arrays, window order: frameID, the
+ * points a keyframe still hosts (active + immature) / has lost (marginalised + dropped), refToFh[0] of fromToVecExposure(newest -> keyframe),
+ * distanceLL[h * n + t] of the pair (h, t); flagged[h] is set to 1 where the reference flags.  What sosf_flag_frames_for_marginalization
+ * runs on the system's own numbers; exposed for the CPU test-suite. */
+int sosf_flag_frames(int n, const int32_t *frameID, const int32_t *pointsIn, const int32_t *pointsOut, const double *refToFh0, const float *distanceLL,
+                     uint8_t *flagged);
 /* FullSystem::setNewFrameEnergyTH (FS/FullSystemOptimize.cpp:84-124) on a list of energies (state_NewEnergyWithOutlier >= 0 of the residuals
  * towards the newest keyframe): the element at index (int)(frameEnergyTHN * count) -- a float product -- through the threshold formula;
  * 12 * 12 * patternNum for an empty list.  Exposed for the CPU test-suite. */

@@ -1730,44 +1730,65 @@ static const int setting_minFrames = 5, setting_maxFrames = 7, setting_minFrameA
 static const int setting_minGoodActiveResForMarg = 3, setting_minGoodResForMarg = 4;     // :95-96
 
 // FS/FullSystemMarginalize.cpp:53-133; called BEFORE the new keyframe joins frameHessians (FS/FullSystem.cpp:798)
-void FullSystem::flagFramesForMarginalization() {
-  ensureHostPrecalc();  // distanceLL of the current states
+// The decision of FullSystem::flagFramesForMarginalization (FS/FullSystemMarginalize.cpp:54-141) on plain arrays: per keyframe (window
+// order) frameID, the points it still hosts (active + immature) and the ones it lost (marginalised + dropped), refToFh[0] of
+// AffLight::fromToVecExposure(newest -> keyframe), and distanceLL[h * n + t] = targetPrecalc[t].distanceLL of keyframe h.  Sets
+// flagged[h] = 1 where the reference sets flaggedForMarginalization (entries already set stay set).
+static void flag_frames_decision(int n, const int *frameID, const int *in, const int *out, const double *refToFh0, const float *distanceLL, uint8_t *flagged) {
   if (setting_minFrameAge > setting_maxFrames) {
-    for (int i = setting_maxFrames; i < (int)frameHessians.size(); i++) frameHessians[i - setting_maxFrames]->flaggedForMarginalization = true;
+    for (int i = setting_maxFrames; i < n; i++) flagged[i - setting_maxFrames] = 1;
     return;
   }
-  int flagged = 0;
-  for (FrameHessian *fh : frameHessians) {
-    const int in = (int)fh->pointHessians.size() + fh->numImmature;
-    const int out = (int)fh->pointHessiansMarginalized.size() + (int)fh->pointHessiansOut.size();
-    double refToFh[2];
-    AffLight::fromToVecExposure(frameHessians.back()->ab_exposure, fh->ab_exposure, frameHessians.back()->aff_g2l(), fh->aff_g2l(), refToFh);
-    if ((in < setting_minPointsRemaining * (in + out) || fabs(logf((float)refToFh[0])) > setting_maxLogAffFacInWindow) &&
-        ((int)frameHessians.size()) - flagged > setting_minFrames) {
-      fh->flaggedForMarginalization = true;
-      flagged++;
+  int nflagged = 0;
+  for (int h = 0; h < n; h++) {
+    if ((in[h] < setting_minPointsRemaining * (in[h] + out[h]) || fabs(logf((float)refToFh0[h])) > setting_maxLogAffFacInWindow) &&
+        n - nflagged > setting_minFrames) {
+      flagged[h] = 1;
+      nflagged++;
     }
   }
-  if ((int)frameHessians.size() - flagged >= setting_maxFrames) {  // marginalize one: the keyframe closest to the others
+  if (n - nflagged >= setting_maxFrames) {  // marginalize one: the keyframe closest to the others
     double smallestScore = 1;
-    FrameHessian *toMarginalize = nullptr;
-    FrameHessian *latest = frameHessians.back();
-    for (FrameHessian *fh : frameHessians) {
-      if (fh->frameID > latest->frameID - setting_minFrameAge || fh->frameID == 0) continue;
+    int toMarginalize = -1;
+    const int latestID = frameID[n - 1];
+    for (int h = 0; h < n; h++) {
+      if (frameID[h] > latestID - setting_minFrameAge || frameID[h] == 0) continue;
       double distScore = 0;
-      for (size_t t = 0; t < fh->targetPrecalc.size(); t++) {
-        const FrameHessian *target = frameHessians[t];
-        if (target->frameID > latest->frameID - setting_minFrameAge + 1 || target == fh) continue;
-        distScore += 1 / (1e-5 + fh->targetPrecalc[t].distanceLL);
+      for (int t = 0; t < n; t++) {
+        if (frameID[t] > latestID - setting_minFrameAge + 1 || t == h) continue;
+        distScore += 1 / (1e-5 + distanceLL[(size_t)h * n + t]);
       }
-      distScore *= -sqrtf(fh->targetPrecalc.back().distanceLL);
+      distScore *= -sqrtf(distanceLL[(size_t)h * n + n - 1]);
       if (distScore < smallestScore) {
         smallestScore = distScore;
-        toMarginalize = fh;
+        toMarginalize = h;
       }
     }
-    if (toMarginalize) toMarginalize->flaggedForMarginalization = true;  // (the reference dereferences unconditionally)
+    if (toMarginalize >= 0) flagged[toMarginalize] = 1;  // (the reference dereferences unconditionally)
   }
+}
+
+void FullSystem::flagFramesForMarginalization() {
+  ensureHostPrecalc();  // distanceLL of the current states
+  const int n = (int)frameHessians.size();
+  std::vector<int> ids(n), in(n), out(n);
+  std::vector<double> ref0(n);
+  std::vector<float> dist((size_t)n * n, 0.f);
+  std::vector<uint8_t> fl(n, 0);
+  for (int h = 0; h < n; h++) {
+    const FrameHessian *fh = frameHessians[h];
+    ids[h] = fh->frameID;
+    in[h] = (int)fh->pointHessians.size() + fh->numImmature;
+    out[h] = (int)fh->pointHessiansMarginalized.size() + (int)fh->pointHessiansOut.size();
+    double refToFh[2];
+    AffLight::fromToVecExposure(frameHessians.back()->ab_exposure, fh->ab_exposure, frameHessians.back()->aff_g2l(), fh->aff_g2l(), refToFh);
+    ref0[h] = refToFh[0];
+    for (size_t t = 0; t < fh->targetPrecalc.size() && (int)t < n; t++) dist[(size_t)h * n + t] = fh->targetPrecalc[t].distanceLL;
+    fl[h] = fh->flaggedForMarginalization ? 1 : 0;
+  }
+  flag_frames_decision(n, ids.data(), in.data(), out.data(), ref0.data(), dist.data(), fl.data());
+  for (int h = 0; h < n; h++)
+    if (fl[h]) frameHessians[h]->flaggedForMarginalization = true;
 }
 
 // the loop "add new residuals for old points" of makeKeyFrame, FS/FullSystem.cpp:818-832
@@ -2808,6 +2829,13 @@ extern "C" int sosf_host_frame_math(int n, const double *evalPT12, const double 
         ad_ht_delta_pair(F[h].get(), F[t].get(), ahf.data(), atf.data(), adHTdeltaF + 8 * k);
       }
     }
+  return SOS_OK;
+}
+extern "C" int sosf_flag_frames(int n, const int32_t *frameID, const int32_t *pointsIn, const int32_t *pointsOut, const double *refToFh0,
+                                const float *distanceLL, uint8_t *flagged) {
+  if (n < 1 || !frameID || !pointsIn || !pointsOut || !refToFh0 || !distanceLL || !flagged) return SOS_ERR_ARG;
+  std::vector<int> ids(frameID, frameID + n), in(pointsIn, pointsIn + n), out(pointsOut, pointsOut + n);
+  flag_frames_decision(n, ids.data(), in.data(), out.data(), refToFh0, distanceLL, flagged);
   return SOS_OK;
 }
 extern "C" int sosf_new_frame_energy_th(const float *energies, int count, float frameEnergyTHN, float facMedian, float constWeight, float overall,

@@ -881,3 +881,15 @@ def new_frame_energy_th(energies, thn=0.7, fac_median=1.5, const_weight=0.5, ove
     _chk(load().sosf_new_frame_energy_th(_p(e), len(e), C.c_float(thn), C.c_float(fac_median), C.c_float(const_weight), C.c_float(overall), C.byref(th)),
          "sosf_new_frame_energy_th")
     return th.value
+
+
+def flag_frames(frameID, points_in, points_out, ref_to_fh0, distanceLL):
+    """The facade's decision of flagFramesForMarginalization on plain arrays (sosf_flag_frames); returns the flags (uint8, window order)."""
+    ids = np.ascontiguousarray(frameID, dtype=np.int32)
+    n = len(ids)
+    pi, po = np.ascontiguousarray(points_in, dtype=np.int32), np.ascontiguousarray(points_out, dtype=np.int32)
+    r0 = np.ascontiguousarray(ref_to_fh0, dtype=np.float64)
+    d = np.ascontiguousarray(distanceLL, dtype=np.float32).reshape(n, n)
+    fl = np.zeros(n, np.uint8)
+    _chk(load().sosf_flag_frames(n, _p(ids), _p(pi), _p(po), _p(r0), _p(d), _p(fl)), "sosf_flag_frames")
+    return fl

@@ -352,3 +352,38 @@ def test_energy_threshold_of_the_facade_equals_the_oracle(name):
     assert th == ow.frame(win.n - 1)["frameEnergyTH"]
     assert host.new_frame_energy_th(e[:0]) == 12 * 12 * 8
     ow.close()
+
+
+def test_flag_frames_decision_of_the_facade_on_the_data_of_a_chain():
+    """flagFramesForMarginalization as the facade decides it (sosf_flag_frames: the function the system runs on its own numbers) against the
+    oracle chain's restatement, on every keyframe of a rolling sequence: which keyframes leave, and in which order, hangs on it."""
+    seen = dict(calls=0, flagged=0, by_distance=0)
+
+    class Both(rolling.OracleChain):
+        def flag_frames(self, num_immature):
+            fr = self.frames
+            n = len(fr)
+            before = np.array([f.flagged for f in fr], np.uint8)
+            ids = [f.frameID for f in fr]
+            n_in = [len(f.points) + ni for f, ni in zip(fr, num_immature)]
+            n_out = [f.n_marg + f.n_out for f in fr]
+            back = fr[-1]
+            ref0 = [np.exp(f.state[6] * rolling.SCALE_A - back.state[6] * rolling.SCALE_A) for f in fr]
+            dist = np.array([[self._distance(h, t) for t in fr] for h in fr], np.float32)
+            want = super().flag_frames(num_immature)
+            got = host.flag_frames(ids, n_in, n_out, ref0, dist) | before
+            assert np.array_equal(got.astype(bool), want), (ids, got, want)
+            seen["calls"] += 1
+            seen["flagged"] += int(want.sum())
+            seen["by_distance"] += int(n - int(want.sum()) < rolling.MAX_FRAMES and want.sum() > 0 and n >= rolling.MAX_FRAMES)
+            return want
+
+    for kw in (dict(n_frames=26), dict(n_frames=4 + 3 * 7, kf_every=3, step=0.07 / 3, rot=0.008 / 3)):
+        sc = rolling.Scenario(**kw)
+        ch = Both(sc)
+        ch.bootstrap()
+        while ch.next_frame < sc.n_frames:
+            if ch.step() is None:
+                break
+    print(seen)
+    assert seen["calls"] >= 25 and seen["flagged"] >= 15
