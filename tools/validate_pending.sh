@@ -14,6 +14,22 @@ F='^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl'
 timeout 1500 python -X faulthandler -m pytest tests -m gpu -q -rxX > $OUT/gputests_default.log 2>&1
 grep -v "$F" $OUT/gputests_default.log | grep -E "passed|failed|FAILED|Fatal|XPASS|XFAIL" | head -20
 grep -h "idepth_hessian W" $OUT/gputests_default.log | sort -u | head -6
+# the numbers that matter most first (a call cut short still leaves them): default bench lines, the visual-inertial loop, a kernel trace
+timeout 300 python bench.py --window W12 > $OUT/bench_W12_full.json 2>> $OUT/bench.err
+timeout 300 python bench.py --imu --no-cpu-baseline --steps 10 --inner 60 > $OUT/bench_imu_T1.json 2>> $OUT/bench.err
+SOS_IMU_CACHE=0 timeout 300 python bench.py --imu --no-cpu-baseline --steps 10 --inner 60 > $OUT/bench_imu_literal.json 2>> $OUT/bench.err
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_def -o b -- python $OLDPWD/bench.py --no-cpu-baseline --steps 30 --inner 50 > /dev/null 2>> $OUT/prof.err)
+python tools/rocpd_summary.py kernels $OUT/prof_def/b_results.db $OUT/bench_default_kernel_stats.csv 2>> $OUT/prof.err; rm -rf $OUT/prof_def
+python - <<PY
+import json
+for f in ("bench_W12_full", "bench_imu_T1", "bench_imu_literal"):
+    try:
+        d = json.load(open("$OUT/" + f + ".json"))
+        print(f, "ms/step %.4f" % d["ms_per_step"], "loop", d["config"].get("gn_loop", "")[:40], "frac", (d.get("roofline") or {}).get("frac"), "kf", d.get("keyframe_ms"),
+              "vio", {k: v for k, v in (d.get("visual_inertial") or {}).items() if "ms" in k or "us" in k or "solves" in k})
+    except Exception as e:
+        print(f, "ERR", e)
+PY
 SOS_ABS_SC=1 timeout 1500 python -X faulthandler -m pytest tests/test_gpu_backend.py tests/test_gpu_optimize.py tests/test_gpu_baseline_sizes.py \
   tests/test_gpu_distributed.py tests/test_gpu_edge_windows.py tests/test_gpu_variants.py tests/test_gpu_bench_rehearsal.py tests/test_golden.py \
   tests/test_golden_t6.py tests/test_gpu_imu_hook.py tests/test_gpu_rolling_window.py tests/test_gpu_rolling_vio.py tests/test_gpu_rolling_ensemble.py \
