@@ -452,10 +452,9 @@ int sosf_imu_try_trap_scale(sosf_imu_calib *calib, double *scale_queue10, int32_
 /* Switches the facade's solveSystemF to the IMU branch (S != NULL) or back (S == NULL).  The records are caller-owned and
  * must outlive the system's iterations: frames[i] belongs to keyframe idx i (its camToWorld / evalPT_R are refreshed by
  * the facade before every solve; state_imu and calib->scale are stepped after it, as doStepFromBackup does with unit
- * step factors); HM / bM: the marginalisation prior in the expanded dimension SOSF_IMU_DIM(n), read at every solve; a caller
- * that rewrites the VALUES of HM in place calls sosf_set_imu again -- with first-estimate Jacobians the solve keeps a factor of the
- * constant part of its system under the name of this call (sosf_imu_solve_prepare), and of a rewrite nobody announced it only
- * notices what shows on the diagonal.
+ * step factors); HM / bM: the marginalisation prior in the expanded dimension SOSF_IMU_DIM(n), read at every solve (with
+ * first-estimate Jacobians the solve keeps a factor of the constant part of its system, sosf_imu_solve_prepare; a caller-owned HM
+ * is compared WHOLE against the copy the factor was built from, so values rewritten in place are noticed without another call).
  * HM = bM = NULL: the facade keeps the expanded prior itself, as EnergyFunctional does with setting_enable_imu: it starts from
  * expandHbtoFitImu of the current (visual) prior, insertFrame grows it by 29 states (OB/EnergyFunctional.cpp:666-677),
  * marginalizePointsF adds the expanded M - Msc (:928-932), marginalizeFrame runs the IMU form (:733-889) before it drops the

@@ -549,11 +549,20 @@ int EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib, boo
       std::memcpy(imuFrames[h].evalPT_R, frames[h]->data->camToWorld_evalPT.R, sizeof(double) * 9);
     }
     const int rcp = sosf_imu_solve_prepare(imuSettings, imuCalib, n, imuFrames, imuOwnPrior ? HMi.data() : imuHM, imuOwnPrior ? bMi.data() : imuBM,
-                                           delta.data(), lambda, imuOwnPrior ? imuPriorVersion : ((uint64_t)1 << 62) + imuCallerPriorName);
+                                           delta.data(), lambda, imuOwnPrior ? imuPriorVersion : (uint64_t)0);  // a caller-owned prior is compared whole
     imuPrepT = now_s() - t_pre0;
     g_phase[1] += imuPrepT;
     return rcp;
   };
+  // SOS_IMU_OVERLAP=1: the first half runs BEHIND the enqueue of the accumulation (sos_ba_gn_accumulate_begin / sos_ba_accumulate_local) so
+  // that it overlaps the device also when nothing prefetched the accumulation.  Opt-in until that ordering has passed the GPU suite on
+  // an MI355X (it has run under tests/emu only); the default is the order of the last GPU-verified build: first half, then accumulate.
+  static const bool imuOverlap = getenv("SOS_IMU_OVERLAP") && atoi(getenv("SOS_IMU_OVERLAP")) != 0;
+  if (imuSettings && !imuOverlap) {
+    const int rcp = imuPrepare();
+    if (rcp != SOS_OK) return rcp;
+    imuPrepT = 0;  // outside the accumulate phase's wall time in this order
+  }
   double t_acc0 = now_s();
   if (allreduceHook) {  // shard-local sums -> RCCL all-reduce of the packed fp32 blocks -> identical stitch on every rank
     HL.assign(dd, 0.0);
@@ -561,7 +570,7 @@ int EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib, boo
     float *dev = nullptr;
     size_t nfl = 0;
     int rc = sos_ba_accumulate_local(ba);
-    if (rc == SOS_OK && imuSettings) rc = imuPrepare();
+    if (rc == SOS_OK && imuSettings && imuOverlap) rc = imuPrepare();
     if (rc == SOS_OK) rc = sos_ba_acc_buffer(ba, &dev, &nfl);
     if (rc == SOS_OK) rc = sos_ctx_synchronize(ctx);
     if (rc != SOS_OK) return rc;
@@ -571,7 +580,7 @@ int EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib, boo
     for (size_t i = 0; i < dd; i++) HA[i] += HL[i];
     for (int i = 0; i < dim; i++) bA[i] += bL[i];
   } else {  // HA := HL_top + HA_top already summed by the library
-    if (imuSettings) {
+    if (imuSettings && imuOverlap) {
       int rcp = sos_ba_gn_accumulate_begin(ba);  // (a no-op when the previous step prefetched it)
       if (rcp == SOS_OK) rcp = imuPrepare();
       if (rcp != SOS_OK) return rcp;
@@ -1018,7 +1027,8 @@ static float energy_threshold_from_nth(float nthValue, float facMedian, float co
 }
 static float energy_threshold(std::vector<float> &allResVec, float thn, float facMedian, float constWeight, float overall) {
   if (allResVec.empty()) return 12 * 12 * SOS_PATTERN_NUM;
-  const int nthIdx = (int)(thn * allResVec.size());
+  // (the reference asserts nthIdx < size, FS/FullSystemOptimize.cpp:110; a frameEnergyTHN close to 1 rounds the float product up to size)
+  const int nthIdx = std::min((int)(thn * allResVec.size()), (int)allResVec.size() - 1);
   std::nth_element(allResVec.begin(), allResVec.begin() + nthIdx, allResVec.end());
   return energy_threshold_from_nth(allResVec[nthIdx], facMedian, constWeight, overall);
 }
@@ -1221,7 +1231,8 @@ int FullSystem::prepare() {  // FS/FullSystemOptimize.cpp:316-344
     static const bool noPrefetch = getenv("SOS_NO_PREPARE_PREFETCH") != nullptr;  // A/B knob
     // (2: only the tile sums are formed -- the device-resident loop and a callback exchange enqueue their own accumulate)
     static const char *pm = getenv("SOS_PREPARE_MODE");  // A/B knob
-    sos_ba_set_prefetch(ef->ba, pm ? atoi(pm) : noPrefetch ? 0 : (ef->allreduceHook || residentUsable()) ? 2 : 1);
+    // (a callback exchange gets 0: sos_ba_accumulate_local resets the tile sums and needs J stored, which the fused form skips)
+    sos_ba_set_prefetch(ef->ba, pm ? atoi(pm) : (noPrefetch || ef->allreduceHook) ? 0 : residentUsable() ? 2 : 1);
     lastError = sos_ba_linearize_apply(ef->ba, th.data(), 1, &E, newestE.data(), &cnt);
     newestE.resize(cnt);
     setNewFrameEnergyTH(newestE);

@@ -45,6 +45,7 @@ struct sosf_sequence {
   struct VioFrame {
     double ts = 0, c2w[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}, vel[3] = {0, 0, 0}, state[21] = {0}, zero[21] = {0};
     std::vector<double> imu;  // n x 7
+    int trackRefId = -1;      // frameID of shell->trackingRef (coarseTracker->lastRef when the frame was tracked, FS/FullSystem.cpp:296; -1: none)
   };
   bool vio = false;
   sosf_imu_settings S;
@@ -288,7 +289,9 @@ int optimize_scale(sosf_sequence *q, int stereoSlot, float *newScale, float *sca
 // ---- visual-inertial helpers: records / shells of a keyframe from the sequence's own state
 const double kImuScale[21] = {100, 100, 100, 1, 1, 1, 100, 100, 100, 1000, 1000, 1000, 1000, 1000, 1000, 1000, 1000, 1000, 1000, 1000, 1000};  // SCALE_BA, BG, SL_ROT, SQ_TRANS, SQ_ROT, SC_TRANS, SC_ROT
 
-sosf_imu_frame vio_record(sosf_sequence *q, int fid) {
+// prevId = frameID of the keyframe that stands before `fid` in the window NOW (-1: none): spline_valid needs shell->trackingRef to be
+// exactly that keyframe's shell (OB/EnergyFunctional.cpp:318, :350), which stops holding once a keyframe between the two was marginalised
+sosf_imu_frame vio_record(sosf_sequence *q, int fid, int prevId) {
   const sosf_sequence::VioFrame &v = q->vf[fid];
   sosf_imu_frame f;
   std::memset(&f, 0, sizeof(f));
@@ -297,7 +300,7 @@ sosf_imu_frame vio_record(sosf_sequence *q, int fid) {
   std::memcpy(f.evalPT_R, v.c2w, sizeof(double) * 9);
   std::memcpy(f.state_imu, v.state, sizeof(v.state));
   std::memcpy(f.state_imu_zero, v.zero, sizeof(v.zero));
-  f.trackingRefIsPrev = fid > 0 ? 1 : 0;
+  f.trackingRefIsPrev = (prevId >= 0 && v.trackRefId == prevId) ? 1 : 0;
   f.n_imu = (int32_t)(v.imu.size() / 7);
   f.imu = v.imu.empty() ? nullptr : v.imu.data();
   return f;
@@ -314,7 +317,11 @@ sosf_imu_shell vio_shell(sosf_sequence *q, int fid) {
 void vio_push(sosf_sequence *q) {
   FullSystem *fs = q->fs;
   q->winRecs.clear();
-  for (FrameHessian *fh : fs->frameHessians) q->winRecs.push_back(vio_record(q, fh->frameID));
+  int prevId = -1;
+  for (FrameHessian *fh : fs->frameHessians) {
+    q->winRecs.push_back(vio_record(q, fh->frameID, prevId));
+    prevId = fh->frameID;
+  }
   EnergyFunctional *ef = fs->ef;
   ef->imuSettings = &q->S; ef->imuCalib = &q->cal; ef->imuFrames = q->winRecs.data(); ef->imuHM = nullptr; ef->imuBM = nullptr;
   if (!ef->imuOwnPrior) ef->imuAdoptPrior();
@@ -325,7 +332,7 @@ void vio_pull(sosf_sequence *q) {  // the states the solve stepped (doStepFromBa
     std::memcpy(q->vf[fs->frameHessians[i]->frameID].state, q->winRecs[i].state_imu, sizeof(double) * 21);
 }
 int vio_update_vel(sosf_sequence *q, int fid, int lastFid) {  // FrameHessian::updateVel(last_shell)
-  const sosf_imu_frame rec = vio_record(q, fid);
+  const sosf_imu_frame rec = vio_record(q, fid, lastFid);
   sosf_imu_shell sh = vio_shell(q, fid);
   const sosf_imu_shell shl = vio_shell(q, lastFid);
   const int rc = sosf_imu_update_vel(&rec, &sh, &shl);
@@ -334,8 +341,8 @@ int vio_update_vel(sosf_sequence *q, int fid, int lastFid) {  // FrameHessian::u
 }
 
 // FullSystem::makeKeyFrame for the tracked frame in `slot` (FS/FullSystem.cpp:783-931)
-int make_keyframe(sosf_sequence *q, int slot, int frameID, const SE3 &c2w, const AffLight &aff, float ab_exposure, const sosf_frame_extra *extra,
-                  sosf_frame_result *out) {
+int make_keyframe(sosf_sequence *q, int slot, int frameID, int trackRefId, const SE3 &c2w, const AffLight &aff, float ab_exposure,
+                  const sosf_frame_extra *extra, sosf_frame_result *out) {
   FullSystem *fs = q->fs;
   for (FrameHessian *fh : fs->frameHessians) fh->numImmature = (int)q->imm[fh->frameID].size();
   fs->flagFramesForMarginalization();  // :798
@@ -348,6 +355,7 @@ int make_keyframe(sosf_sequence *q, int slot, int frameID, const SE3 &c2w, const
     sosf_sequence::VioFrame &v = q->vf[frameID];
     v = sosf_sequence::VioFrame();
     v.ts = extra ? extra->timestamp : 0.0;
+    v.trackRefId = trackRefId;
     c2w.to12(v.c2w);
     v.imu.swap(q->pendingImu);
     q->pendingImu.clear();
@@ -355,7 +363,7 @@ int make_keyframe(sosf_sequence *q, int slot, int frameID, const SE3 &c2w, const
       const int last = fs->frameHessians.back()->frameID;
       double bias6[6];
       for (int i = 0; i < 6; i++) bias6[i] = kImuScale[i] * q->vf[last].state[i];
-      sosf_imu_frame rec = vio_record(q, frameID);
+      sosf_imu_frame rec = vio_record(q, frameID, last);
       sosf_imu_shell sh = vio_shell(q, frameID);
       const sosf_imu_shell shl = vio_shell(q, last);
       const int rci = sosf_imu_propagate_state(&q->S, &q->cal, &rec, &sh, &shl, bias6);
@@ -386,7 +394,7 @@ int make_keyframe(sosf_sequence *q, int slot, int frameID, const SE3 &c2w, const
     sosf_imu_shell shs[5];
     for (int i = 0; i < 5; i++) {
       const int fid = fs->frameHessians[i]->frameID;
-      recs[i] = vio_record(q, fid);
+      recs[i] = vio_record(q, fid, i > 0 ? fs->frameHessians[i - 1]->frameID : -1);
       fs->frameHessians[i]->PRE_camToWorld.to12(recs[i].camToWorld);
       shs[i] = vio_shell(q, fid);
     }
@@ -537,6 +545,7 @@ extern "C" int sosf_sequence_enable_imu(sosf_sequence *q, const sosf_imu_setting
   for (int i = 0; i < nBoot; i++) {  // the shells of the window the initialiser handed over: poses as they are, velocities and states zero
     sosf_sequence::VioFrame &v = q->vf[fs->frameHessians[i]->frameID];
     v.ts = timestamps[i];
+    v.trackRefId = i > 0 ? fs->frameHessians[i - 1]->frameID : -1;  // firstFrame->trackingRef = 0, newFrame->trackingRef = firstFrame (FS/FullSystem.cpp:1054-1062)
     fs->frameHessians[i]->PRE_camToWorld.to12(v.c2w);
     if (n_imu && imu && n_imu[i] > 0 && imu[i]) v.imu.assign(imu[i], imu[i] + (size_t)7 * n_imu[i]);
   }
@@ -688,5 +697,5 @@ extern "C" int sosf_add_active_frame_ex(sosf_sequence *q, int slot, int frameID,
   }
   q->framesSinceKF = 0;
   out->isKeyframe = 1;
-  return make_keyframe(q, slot, frameID, c2w, aff, ab_exposure, extra, out);
+  return make_keyframe(q, slot, frameID, ref->frameID, c2w, aff, ab_exposure, extra, out);
 }

@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "needs_device: a gpu test the CPU emulation (SOS_EMU=1) cannot stand in for")
 
 
 def _have_gpu():
@@ -20,8 +21,36 @@ def _have_gpu():
         return False
 
 
+def _emulated():
+    """SOS_EMU=1 (and no GPU): the -m gpu tests run against tests/emu's lockstep CPU emulation of the device library -- the kernels'
+    source executed on host fibers.  A logic check for code no GPU has run yet, never a GPU result: the session banner and
+    tests/emu/README.md say so, and nothing under sos_slam_amd/ knows about it (this hook redirects the two library paths)."""
+    return os.environ.get("SOS_EMU") == "1" and not _have_gpu()
+
+
+def pytest_sessionstart(session):
+    if not _emulated():
+        return
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    from sos_slam_amd import build as _b
+    _b.HIP_LIB, _b.HOST_LIB = build_emu.build()
+    _b.build_all = lambda *a, **k: (_b.HIP_LIB, _b.HOST_LIB)  # the product build is not what this session loads
+
+
+def pytest_report_header(config):
+    if _emulated():
+        return "SOS_EMU=1: device library = tests/emu lockstep CPU EMULATION (not a GPU run)"
+
+
 def pytest_collection_modifyitems(config, items):
     if _have_gpu():
+        return
+    if _emulated():
+        skip = pytest.mark.skip(reason="needs a real device (torch.cuda / RCCL / full-size timing), not the emulator")
+        for item in items:
+            if "needs_device" in item.keywords:
+                item.add_marker(skip)
         return
     skip = pytest.mark.skip(reason="no GPU in this container")
     for item in items:

@@ -316,7 +316,8 @@ class Chain:
             self.imm_type[i] = np.zeros(0, np.float32)
         if self.vio:
             for i in range(sc.n0):
-                self.shells[i] = dict(ts=float(sc.ts[i]), c2w=np.array(sc.poses[i], dtype=np.float64), vel=np.zeros(3))
+                # firstFrame->trackingRef = 0, newFrame->trackingRef = firstFrame (FS/FullSystem.cpp:1054-1062)
+                self.shells[i] = dict(ts=float(sc.ts[i]), c2w=np.array(sc.poses[i], dtype=np.float64), vel=np.zeros(3), track_ref=i - 1)
                 self.imu_state[i], self.imu_zero[i] = np.zeros(21), np.zeros(21)
             self.n_kf_total = sc.n0
         rmse, its = self.optimize(6)
@@ -391,7 +392,8 @@ class Chain:
         # ---- makeKeyFrame
         flagged = self.flag_frames([len(self.imm[f]) for f in ids])
         if self.vio:   # fh->setImuData; propagateImuState(allKeyFramesHistory.back(), coarseTracker->lastRef->imu_bias), :800-807
-            self.shells[k] = dict(ts=float(sc.ts[k]), c2w=np.array(c2w, dtype=np.float64), vel=np.zeros(3))
+            # shell->trackingRef = coarseTracker->lastRef = the newest keyframe when the frame was tracked (FS/FullSystem.cpp:296)
+            self.shells[k] = dict(ts=float(sc.ts[k]), c2w=np.array(c2w, dtype=np.float64), vel=np.zeros(3), track_ref=ids[-1])
             self.imu_state[k], self.imu_zero[k] = np.zeros(21), np.zeros(21)
             if self.cal["init"]:
                 last = ids[-1]
@@ -485,7 +487,9 @@ class Chain:
             f.evalPT_R[:] = list(self.shells[fid]["c2w"][:9])
             f.state_imu[:] = list(self.imu_state[fid])
             f.state_imu_zero[:] = list(self.imu_zero[fid])
-            f.trackingRefIsPrev = 1 if fid > 0 else 0
+            # spline_valid needs shell->trackingRef == the shell of the keyframe standing before it in the window NOW
+            # (OB/EnergyFunctional.cpp:318, :350): false for the successor of a marginalised middle keyframe
+            f.trackingRefIsPrev = 1 if (i > 0 and self.shells[fid]["track_ref"] == ids[i - 1]) else 0
             arr = np.ascontiguousarray(self.imu[fid], dtype=np.float64).reshape(-1, 7)
             keep.append(arr)
             f.n_imu = len(arr)

@@ -204,7 +204,7 @@ def test_imu_solve_against_an_independent_kkt_in_numpy():
     cb = TAP(tap)
     Lo.orc_set_imu_solve_tap(cb)
     try:
-        sc = rolling.Scenario(n_frames=22, vio=True)
+        sc = rolling.Scenario(n_frames=28, vio=True)
         ch = rolling.OracleChain(sc)
         ch.bootstrap()
         while ch.next_frame < sc.n_frames:

@@ -38,7 +38,7 @@ def test_oracle_chain_visual_inertial():
     sc = rolling.Scenario(n_frames=14, vio=True)
     ch = rolling.OracleChain(sc)
     ch.bootstrap()
-    left, scales = [], []
+    left, scales, broken = [], [], 0
     while ch.next_frame < sc.n_frames:
         lg = ch.step()
         v = lg.vio
@@ -54,7 +54,15 @@ def test_oracle_chain_visual_inertial():
         for fid in lg.window_ids:
             assert np.abs(lg.window_poses[fid] - sc.poses[fid]).max() < 5e-3 + 0.03 * np.abs(sc.poses[fid][9:]).max()   # monocular gauge drift
         left += lg.marginalized
-    assert len(left) >= 5
+        # shell->trackingRef == the shell of the window predecessor (OB/EnergyFunctional.cpp:318, :350) is what the records must say: the
+        # successor of a keyframe that left from the MIDDLE of the window keeps its tracking reference and loses its spline terms
+        ids = ch.window_ids()
+        recs, _keep = ch.vio_records(ids)
+        for i, fid in enumerate(ids):
+            want = 1 if (i > 0 and ids[i - 1] == fid - 1) else 0       # every frame is a keyframe here: the tracking reference of k is k - 1
+            assert recs[i].trackingRefIsPrev == want, (ids, fid)
+        broken += sum(1 for i, fid in enumerate(ids) if i > 0 and ids[i - 1] != fid - 1)
+    assert len(left) >= 5 and broken > 0                                # middle keyframes did leave the window
     assert np.abs(np.array(scales[-4:]) - sc.scale_true).max() < 0.05
     vel_true = (sc.poses[sc.n_frames - 1][9:] - sc.poses[sc.n_frames - 2][9:]) / sc.dt
     assert np.abs(ch.shells[sc.n_frames - 1]["vel"] - vel_true).max() < 0.2 * np.abs(vel_true).max() + 0.05
