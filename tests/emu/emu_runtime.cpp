@@ -489,9 +489,14 @@ struct Event {
 static std::mutex g_streams_m;
 static std::vector<Stream *> g_streams;
 static Stream *g_default = nullptr;
+// nullptr = the default stream; a handle that is not (or no longer) registered resolves to nullptr -> hipErrorInvalidValue, as the
+// real run time answers a stale handle (objects finalised in arbitrary order at interpreter exit) instead of touching freed memory
 static Stream *resolve(hipStream_t st) {
-  if (st) return st;
   std::unique_lock<std::mutex> lk(g_streams_m);
+  if (st) {
+    for (Stream *s : g_streams) if (s == st) return s;
+    return nullptr;
+  }
   if (!g_default) { g_default = new Stream(); g_streams.push_back(g_default); }
   return g_default;
 }
@@ -506,6 +511,7 @@ static void sync_all() {
 
 void enqueue_launch(hipStream_t st, LaunchBase *l) {
   Stream *s = resolve(st);
+  if (!s) { delete l; return; }
   s->push([s, l] {
     run_launch(&s->mach, l);
     delete l;
@@ -577,6 +583,7 @@ hipError_t hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind) {
 }
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind k, hipStream_t st) {
   Stream *s = emu::resolve(st);
+  if (!s) return hipErrorInvalidValue;
   if (k == hipMemcpyHostToDevice) {  // pageable sources are staged at the call; a correct caller cannot tell the difference
     std::vector<char> *stage = new std::vector<char>((const char *)src, (const char *)src + n);
     s->push([dst, stage] {
@@ -594,7 +601,9 @@ hipError_t hipMemset(void *p, int v, size_t n) {
   return hipSuccess;
 }
 hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t st) {
-  emu::resolve(st)->push([p, v, n] { memset(p, v, n); });
+  Stream *s = emu::resolve(st);
+  if (!s) return hipErrorInvalidValue;
+  s->push([p, v, n] { memset(p, v, n); });
   return hipSuccess;
 }
 hipError_t hipStreamCreateWithFlags(hipStream_t *st, unsigned) {
@@ -609,6 +618,7 @@ hipError_t hipStreamCreateWithFlags(hipStream_t *st, unsigned) {
 hipError_t hipStreamCreate(hipStream_t *st) { return hipStreamCreateWithFlags(st, 0); }
 hipError_t hipStreamDestroy(hipStream_t st) {
   if (!st) return hipSuccess;
+  if (!emu::resolve(st)) return hipErrorInvalidValue;
   st->sync();
   {
     std::unique_lock<std::mutex> lk(emu::g_streams_m);
@@ -618,8 +628,17 @@ hipError_t hipStreamDestroy(hipStream_t st) {
   delete st;
   return hipSuccess;
 }
-hipError_t hipStreamSynchronize(hipStream_t st) { emu::resolve(st)->sync(); return hipSuccess; }
-hipError_t hipStreamQuery(hipStream_t st) { return emu::resolve(st)->idle() ? hipSuccess : hipErrorNotReady; }
+hipError_t hipStreamSynchronize(hipStream_t st) {
+  Stream *s = emu::resolve(st);
+  if (!s) return hipErrorInvalidValue;
+  s->sync();
+  return hipSuccess;
+}
+hipError_t hipStreamQuery(hipStream_t st) {
+  Stream *s = emu::resolve(st);
+  if (!s) return hipErrorInvalidValue;
+  return s->idle() ? hipSuccess : hipErrorNotReady;
+}
 hipError_t hipEventCreate(hipEvent_t *e) { *e = new Event(); return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = new Event(); return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t e) {
@@ -631,7 +650,9 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t st) {
     std::unique_lock<std::mutex> lk(e->m);
     e->pending++;
   }
-  emu::resolve(st)->push([e] {
+  Stream *s = emu::resolve(st);
+  if (!s) { std::unique_lock<std::mutex> lk(e->m); e->pending--; return hipErrorInvalidValue; }
+  s->push([e] {
     std::unique_lock<std::mutex> lk(e->m);
     e->t = std::chrono::steady_clock::now();
     e->pending--;

@@ -37,6 +37,7 @@ def _run(n, scaling, steps=3, warmup=1, inner=None, launcher=False, extra_env=No
 MODE1 = "host solve (blocked LDL^T), device everything else incl. the step"
 
 
+@pytest.mark.needs_device   # torch.cuda / RCCL / bench.py timing: not something tests/emu stands in for
 def test_two_ranks_weak_and_strong():
     w = _run(2, "weak")
     assert w["n_gpus"] == 2 and w["scaling"] == "weak" and w["steps"] == 3 and w["value"] > 0
@@ -54,6 +55,7 @@ def test_two_ranks_weak_and_strong():
     assert t["n_gpus"] == 2 and abs(t["last_step_l2"] - w["last_step_l2"]) <= 1e-12 + 1e-9 * w["last_step_l2"]
 
 
+@pytest.mark.needs_device   # torch.cuda / RCCL / bench.py timing: not something tests/emu stands in for
 def test_sharded_first_step_equals_the_unsharded_one():
     """Strong mode, ONE Gauss-Newton iteration: the step the solve produces from the window sharded over two and three ranks (partial
     accumulators summed by the exchange) is the step of the unsharded window up to fp32 summation order."""
@@ -68,6 +70,7 @@ def test_sharded_first_step_equals_the_unsharded_one():
         assert d["config"]["gn_loop"].startswith(MODE1) and d["config"]["resInA_last_iteration"] == ref["config"]["resInA_last_iteration"]
 
 
+@pytest.mark.needs_device   # torch.cuda / RCCL / bench.py timing: not something tests/emu stands in for
 def test_one_rank_rccl_exchange_is_bit_identical_to_the_plain_run():
     """The library-enqueued RCCL path (all-reduce of the packed accumulator, all-gather of the newest-frame energies, chained publish)
     with ONE rank against the run without a communicator: same loop mode, the same step bit for bit after six iterations."""

@@ -22,6 +22,7 @@ def _free_port():
     return p
 
 
+@pytest.mark.needs_device   # torch.cuda / RCCL / bench.py timing: not something tests/emu stands in for
 def test_exchange_paths_equal_plain_run():
     import torch
     import torch.distributed as dist

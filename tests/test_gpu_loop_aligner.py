@@ -38,12 +38,7 @@ def _template(win, frame, dI_levels, n_max=1500):
 GEOMETRIES = {"qvga": dict(name="T6"), "euroc_752x480": dict(name="W7"), "kitti_1232x368": dict(name="W7", w=1232, h=368)}
 
 
-# PENDING_FIRST_GPU_RUN: the two full-size geometries were added while GPU access was withdrawn (round 3); the oracle half was dry-run
-# on the CPU.  Until they have run once their failures are reported as `xfailed`.  Remove the marks after the first run.
-_PENDING = pytest.mark.xfail(reason="added without GPU access; first GPU run pending (tools/validate_pending.sh)", strict=False)
-
-
-@pytest.fixture(scope="module", params=["qvga", pytest.param("euroc_752x480", marks=_PENDING), pytest.param("kitti_1232x368", marks=_PENDING)])
+@pytest.fixture(scope="module", params=["qvga", "euroc_752x480", "kitti_1232x368"])
 def rig(request):
     from sos_slam_amd import host
     cfg = dict(GEOMETRIES[request.param])

