@@ -498,13 +498,27 @@ int EnergyFunctional::pushState(CalibHessian *HCalib, bool adjoints, bool points
 // H_sc * (1.0f / (1 + lambda)) (a double quotient), Jacobi scaling by (diagonal + 10)^-1/2, LDL^T.  Only the upper triangles (col >=
 // row) of H, H_sc and HM enter the matrix: the fused device call delivers just that half, and the LDL^T reads just that half (Eigen's
 // LDLT likewise reads one triangle of HFinal_top).  Pure host arithmetic: also reachable through sosf_solve_system for the CPU tests.
-static void solve_visual_system(MatXX &H, VecX &b, const MatXX &Hsc, const VecX &bsc, const MatXX &HM, const VecX &bM, const VecX &delta, double lambda,
-                                VecX &x, double t_sol0) {
-  const int dim = (int)b.size();
+// bM + HM delta (OB/EnergyFunctional.cpp:1048): depends on nothing the device delivers -- solveSystemF forms it while the accumulation
+// is in flight and hands it in as `priorRhs`
+static void prior_rhs(const MatXX &HM, const VecX &bM, const VecX &delta, int dim, VecX &out) {
+  out.resize(dim);
   for (int i = 0; i < dim; i++) {
     double s = bM[i];
     for (int j = 0; j < dim; j++) s += HM[(size_t)i * dim + j] * delta[j];
-    b[i] += s;
+    out[i] = s;
+  }
+}
+static void solve_visual_system(MatXX &H, VecX &b, const MatXX &Hsc, const VecX &bsc, const MatXX &HM, const VecX &bM, const VecX &delta, double lambda,
+                                VecX &x, double t_sol0, const VecX *priorRhs = nullptr) {
+  const int dim = (int)b.size();
+  if (priorRhs) {
+    for (int i = 0; i < dim; i++) b[i] += (*priorRhs)[i];
+  } else {
+    for (int i = 0; i < dim; i++) {
+      double s = bM[i];
+      for (int j = 0; j < dim; j++) s += HM[(size_t)i * dim + j] * delta[j];
+      b[i] += s;
+    }
   }
   const double isc = 1.0f / (1 + lambda);
   for (int i = 0; i < dim; i++) b[i] -= bsc[i];
@@ -562,6 +576,12 @@ int EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib, boo
     const int rcp = imuPrepare();
     if (rcp != SOS_OK) return rcp;
     imuPrepT = 0;  // outside the accumulate phase's wall time in this order
+  }
+  const bool havePriorRhs = !imuSettings;
+  if (havePriorRhs) {  // (the accumulation was prefetched by the previous step: this runs in its shadow, not between H / b and x)
+    const double tpr = now_s();
+    prior_rhs(HM, bM, delta, dim, scrPriorRhs);
+    g_phase[1] += now_s() - tpr;
   }
   double t_acc0 = now_s();
   if (allreduceHook) {  // shard-local sums -> RCCL all-reduce of the packed fp32 blocks -> identical stitch on every rank
@@ -640,7 +660,7 @@ int EnergyFunctional::solveSystemF(int, double lambda, CalibHessian *HCalib, boo
     return SOS_OK;
   }
   VecX x;
-  solve_visual_system(H, b, Hsc, bsc, HM, bM, delta, lambda, x, t_sol0);
+  solve_visual_system(H, b, Hsc, bsc, HM, bM, delta, lambda, x, t_sol0, havePriorRhs ? &scrPriorRhs : nullptr);
   lastX = x;
   // resubstituteF_MT, :496-524
   for (int i = 0; i < 4; i++) HCalib->step[i] = -x[i];
@@ -1124,12 +1144,23 @@ void FullSystem::backupState() {  // :260-269
   std::memcpy(HCalib.value_backup, HCalib.value, sizeof(HCalib.value));
   backupSumNID = 0;
   backupNumID = 0;
-  for (FrameHessian *fh : frameHessians) {
-    std::memcpy(fh->state_backup, fh->state, sizeof(fh->state));
-    for (PointHessian *ph : fh->pointHessians) {
-      ph->idepth_backup = ph->idepth;
-      backupSumNID += fabsf(ph->idepth_backup);  // same order as the loop of doStepFromBackup, FS/FullSystemOptimize.cpp:207-213
-      backupNumID++;
+  if (pointMirrorsStale) {  // the loop's flat copies (snapshot order = frames -> points, the order of the walk below)
+    for (FrameHessian *fh : frameHessians) std::memcpy(fh->state_backup, fh->state, sizeof(fh->state));
+    const size_t P = flatIdepth.size();
+    flatBackup.resize(P);
+    if (P) std::memcpy(flatBackup.data(), flatIdepth.data(), sizeof(float) * P);
+    float s = 0;
+    for (size_t j = 0; j < P; j++) s += fabsf(flatBackup[(size_t)flatOrder[j]]);  // the walk's order: frames -> pointHessians
+    backupSumNID = s;
+    backupNumID = (float)P;
+  } else {
+    for (FrameHessian *fh : frameHessians) {
+      std::memcpy(fh->state_backup, fh->state, sizeof(fh->state));
+      for (PointHessian *ph : fh->pointHessians) {
+        ph->idepth_backup = ph->idepth;
+        backupSumNID += fabsf(ph->idepth_backup);  // same order as the loop of doStepFromBackup, FS/FullSystemOptimize.cpp:207-213
+        backupNumID++;
+      }
     }
   }
   // multi-GPU: the points are sharded, the termination test of doStepFromBackup (sqrtf(sumT) * sumNID) must come out the
@@ -1252,6 +1283,7 @@ int FullSystem::prepare() {  // FS/FullSystemOptimize.cpp:316-344
 
 bool FullSystem::gnIteration(int iteration, bool mayContinue) {  // :358-413 with setting_forceAceptStep
   if (residentActive || residentUsable()) {
+    flushPointMirrors();
     if (!residentActive) {
       if (residentBegin() != SOS_OK) goto host_path;
       rcAcc(sos_ba_gn_resident_enqueue(ef->ba, &residentQueued));
@@ -1266,6 +1298,8 @@ bool FullSystem::gnIteration(int iteration, bool mayContinue) {  // :358-413 wit
   }
 host_path:
   if (!devStepActive && devStepUsable()) devStepBegin();  // (prepare() ended the previous one: the host re-uploaded its states)
+  if (devStepActive && !pointMirrorsStale && (inOptimizeLoop || pipelineAlways)) beginLazyPointMirrors();
+  if (!devStepActive) flushPointMirrors();
   { PhaseTimer tb(7); backupState(); }
   if (rcAcc(ef->solveSystemF(iteration, 1e-1, &HCalib, true)) != SOS_OK) {  // x, frame / calib steps; back-substitution deferred
     isLost = true;  // a failed device call: no step is taken on undelivered H / b
@@ -1302,12 +1336,19 @@ host_path:
     }
     newestE.resize(cnt);
     PhaseTimer tpost(6);
-    for (size_t k = 0; k < ef->allPoints.size(); k++) {
-      PointHessian *ph = ef->allPoints[k]->data;
-      ph->step = ef->pointStep[k];
-      ph->setIdepth(ph->idepth_backup + 1.0f * ph->step);
-      ph->setIdepthZero(ph->idepth_backup + 1.0f * ph->step);
-      ef->allPoints[k]->deltaF = 0;
+    if (pointMirrorsStale) {  // ph->setIdepth(ph->idepth_backup + stepfacD * ph->step) on the flat copies; the objects follow in flushPointMirrors
+      const size_t P = flatIdepth.size();
+      const float *st = ef->pointStep.data(), *bk = flatBackup.data();
+      float *id = flatIdepth.data();
+      for (size_t k = 0; k < P; k++) id[k] = bk[k] + 1.0f * st[k];
+    } else {
+      for (size_t k = 0; k < ef->allPoints.size(); k++) {
+        PointHessian *ph = ef->allPoints[k]->data;
+        ph->step = ef->pointStep[k];
+        ph->setIdepth(ph->idepth_backup + 1.0f * ph->step);
+        ph->setIdepthZero(ph->idepth_backup + 1.0f * ph->step);
+        ef->allPoints[k]->deltaF = 0;
+      }
     }
     setNewFrameEnergyTH(newestE);
     return canbreak;
@@ -1450,7 +1491,41 @@ bool FullSystem::residentConsume(int seq) {
          sqrtf(sumR) < 0.00005 * setting_thOptIterations && sqrtf(sumT) * sumNID < 0.00005 * setting_thOptIterations;
 }
 
+// Lazy point mirrors (sos_host.hpp): the flat copies are gathered once, in snapshot order, with the reference's summation order beside them
+bool FullSystem::beginLazyPointMirrors() {
+  static const bool off = getenv("SOS_EAGER_POINT_MIRRORS") != nullptr;  // A/B knob
+  const size_t P = ef->allPoints.size();
+  if (off || P == 0) return false;
+  flatIdepth.resize(P);
+  flatOrder.clear();
+  flatOrder.reserve(P);
+  for (FrameHessian *fh : frameHessians)
+    for (PointHessian *ph : fh->pointHessians) {
+      if (ph->packIdx < 0 || (size_t)ph->packIdx >= P || ef->allPoints[(size_t)ph->packIdx]->data != ph) return false;  // not the snapshot's point set
+      flatOrder.push_back(ph->packIdx);
+      flatIdepth[(size_t)ph->packIdx] = ph->idepth;
+    }
+  if (flatOrder.size() != P) return false;
+  pointMirrorsStale = true;
+  return true;
+}
+void FullSystem::flushPointMirrors() {
+  if (!pointMirrorsStale) return;
+  pointMirrorsStale = false;
+  const size_t P = std::min(flatIdepth.size(), ef->allPoints.size());
+  const bool haveBackup = flatBackup.size() == flatIdepth.size(), haveStep = ef->pointStep.size() >= P;
+  for (size_t k = 0; k < P; k++) {
+    PointHessian *ph = ef->allPoints[k]->data;
+    if (haveBackup) ph->idepth_backup = flatBackup[k];
+    if (haveStep) ph->step = ef->pointStep[k];
+    ph->setIdepth(flatIdepth[k]);
+    ph->setIdepthZero(flatIdepth[k]);
+    ef->allPoints[k]->deltaF = 0;
+  }
+}
+
 int FullSystem::residentFlush() {
+  flushPointMirrors();
   if (!residentActive) return SOS_OK;
   while (residentSeq < residentQueued) residentConsume(residentSeq + 1);   // iterations the caller has not asked about yet
   residentActive = false;
@@ -1499,6 +1574,7 @@ void FullSystem::loadSateBackup() {  // FS/FullSystemOptimize.cpp:271-287 (IMU o
 bool FullSystem::gnIterationChecked(int iteration, double &lastE, double &lastEL, double &lastEM) {
   lastLoopMode = 3;
   devStepActive = false;  // (this loop steps on the host and uploads the states)
+  flushPointMirrors();
   backupState();
   if (rcAcc(ef->solveSystemF(iteration, 1e-1, &HCalib, false)) != SOS_OK) {
     isLost = true;
@@ -1547,11 +1623,14 @@ float FullSystem::optimize(int mnumOptIts, int *iterations) {
     }
     residentFlush();
   } else {
+    inOptimizeLoop = true;
     for (int iteration = 0; iteration < mnumOptIts; iteration++) {
       const bool canbreak = forceAcceptStep ? gnIteration(iteration, iteration + 1 < mnumOptIts) : gnIterationChecked(iteration, lastE, lastEL, lastEM);
       it++;
       if (canbreak && iteration >= minOptIterations) break;
     }
+    inOptimizeLoop = false;
+    flushPointMirrors();
     if (devStepActive) {
       sos_ba_gn_devstep_end(ef->ba);
       devStepActive = false;
@@ -1878,6 +1957,7 @@ static bool pointIsOOB(const PointHessian *ph, const std::vector<FrameHessian *>
 // (makeKeyFrame :908-912).  The decisions are the reference's; the per-residual work of the points that get
 // marginalised (resetOOB, linearize, applyRes, fixLinearizationF) runs on the device for the whole set at once.
 int FullSystem::flagPointsForRemoval(int *nMarg, int *nDrop) {
+  flushPointMirrors();
   std::vector<FrameHessian *> fhsToMargPoints;
   for (FrameHessian *fh : frameHessians)
     if (fh->flaggedForMarginalization) fhsToMargPoints.push_back(fh);

@@ -187,7 +187,7 @@ class EnergyFunctional {  // OB/EnergyFunctional.h:52-154
   bool keepSystem = false;  // sosf_keep_last_system: solveSystemF keeps a copy of what it assembled
   MatXX keptH, keptHsc;
   VecX keptb, keptbsc;
-  VecX scrbA, scrbsc;
+  VecX scrbA, scrbsc, scrPriorRhs;
   void setAdjointsF(CalibHessian *HCalib);
 
   // device snapshot management
@@ -283,6 +283,15 @@ class FullSystem {
   // device-side step of the fused loop (sos_ba_gn_devstep_begin): the device derives poses / precalc / deltas from x; the host
   // keeps stepping its own states but neither computes nor stages the n^2 precalc records inside the loop
   bool devStepAllowed = true, devStepActive = false;
+  // Lazy point mirrors of the device-step loop: inside optimize() (and in a pipelined flat-API loop) the per-iteration point part of
+  // doStepFromBackup (FS/FullSystemOptimize.cpp:207-213) and of backupState (:260-269) runs on flat arrays in snapshot order -- same
+  // float operations in the same order -- and the PointHessian objects are brought up to date once, by flushPointMirrors(), before
+  // anything reads them (it is called wherever residentFlush() is, and by every member that reads or writes the mirrors).
+  bool inOptimizeLoop = false, pointMirrorsStale = false;
+  std::vector<float> flatIdepth, flatBackup;
+  std::vector<int> flatOrder;  // snapshot index of the j-th point in the order frames -> pointHessians (the reference's summation order)
+  bool beginLazyPointMirrors();
+  void flushPointMirrors();
   bool devStepUsable() const;
   int devStepBegin();
   int residentSeq = 0;          // sequence number of the iteration whose results the host has consumed

@@ -22,7 +22,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "sos_slam_amd", "csrc")
-OUT = os.path.join(HERE, "_build")
+ASAN = os.environ.get("EMU_ASAN") == "1"   # AddressSanitizer build (run with LD_PRELOAD=<asan_runtime()> ASAN_OPTIONS=detect_leaks=0)
+OUT = os.path.join(HERE, "_build_asan" if ASAN else "_build")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 sys.path.insert(0, ROOT)
@@ -148,6 +149,10 @@ def preprocess(src, dst):
         open(dst, "w").write(s)
 
 
+def asan_runtime():
+    return subprocess.check_output([CLANG, "-print-file-name=libclang_rt.asan-x86_64.so"], text=True).strip()
+
+
 def _newer(target, deps):
     if not os.path.exists(target):
         return True
@@ -175,10 +180,12 @@ def build(force=False, verbose=False):
     rt = os.path.join(HERE, "emu_runtime.cpp")
     deps = [os.path.join(gen, f) for f in os.listdir(gen)] + [rt, os.path.join(HERE, "include", "hip", "hip_runtime.h"),
                                                               os.path.join(HERE, "include", "rccl", "rccl.h"), os.path.abspath(__file__)]
-    opt = os.environ.get("EMU_OPT", "-O2")
+    opt = os.environ.get("EMU_OPT", "-O1" if ASAN else "-O2")
     flags = [opt, "-g1", "-std=c++17", "-ffp-contract=off", "-fPIC", "-pthread", "-ftls-model=initial-exec", "-fno-omit-frame-pointer",
              "-Wno-unused-value", "-Wno-unknown-pragmas", "-Wno-pass-failed", "-Wno-unused-function", "-Wno-ignored-attributes",
              "-I" + os.path.join(HERE, "include")]
+    if ASAN:
+        flags += ["-fsanitize=address", "-shared-libasan", "-fsanitize-address-use-after-return=never"]
     if force or _newer(hip_lib, deps):
         objs, jobs = [], []
         for sfile in srcs + [rt]:
@@ -191,7 +198,7 @@ def build(force=False, verbose=False):
             objs.append(o)
         if any(j.wait() != 0 for j in jobs):
             raise SystemExit("tests/emu: compilation failed")
-        cmd = [CLANG, "-shared", "-pthread", "-o", hip_lib] + objs + ["-ldl"]
+        cmd = [CLANG, "-shared", "-pthread", "-o", hip_lib] + objs + ["-ldl"] + (["-fsanitize=address", "-shared-libasan"] if ASAN else [])
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

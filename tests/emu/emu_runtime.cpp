@@ -49,6 +49,18 @@ emu_switch:
 )");
 extern "C" void emu_switch(void **save_sp, void *new_sp);
 
+// EMU_ASAN build (build_emu.py, EMU_ASAN=1): AddressSanitizer is told about every stack switch, so that out-of-bounds accesses of the
+// kernels to "device" memory (hipMalloc = the instrumented malloc), LDS blocks and their own frames are reported instead of going
+// unnoticed as they would on the GPU
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define EMU_ASAN 1
+extern "C" void __sanitizer_start_switch_fiber(void **fake_stack_save, const void *bottom, size_t size);
+extern "C" void __sanitizer_finish_switch_fiber(void *fake_stack_save, const void **bottom_old, size_t *size_old);
+extern "C" void __asan_unpoison_memory_region(void const volatile *addr, size_t size);
+#endif
+#endif
+
 namespace emu {
 thread_local Fiber *cur = nullptr;
 
@@ -61,6 +73,10 @@ static const int g_malloc_fill = (int)env_long("EMU_MALLOC_FILL", 0xFF);
 static const int g_shared_fill = (int)env_long("EMU_SHARED_FILL", 0xFF);
 static const size_t g_stack_bytes = (size_t)env_long("EMU_STACK_KB", 64) * 1024;
 static const long g_resident_threads = env_long("EMU_RESIDENT_THREADS", 65536);
+// EMU_SCHED: the order in which the waves of a workgroup (and the lanes of a wave) get to run between meeting points.  0: ascending;
+// 1: descending; 2: rotated by a counter.  A kernel that is correct on hardware does not depend on it -- one that misses a barrier
+// between an LDS write and a read by another wave does (its tests then differ between EMU_SCHED values).
+static const int g_sched = (int)env_long("EMU_SCHED", 0);
 
 [[noreturn]] void die(const char *msg) {
   fprintf(stderr, "[emu] fatal: %s\n", msg);
@@ -76,6 +92,8 @@ struct Machine {
   void *sched_sp = nullptr;
   LaunchBase *launch = nullptr;
   size_t high_slot = 0;
+  const void *sched_bottom = nullptr;  // (ASan) the worker thread's own stack, learnt at the first switch back
+  size_t sched_size = 0;
   ~Machine() {
     if (pool) munmap(pool, nslots * g_stack_bytes);
   }
@@ -112,7 +130,14 @@ void *shared_static_lookup(const void *key, size_t bytes, size_t align) {
 
 static inline void to_scheduler() {
   Fiber *f = cur;
+#ifdef EMU_ASAN
+  void *fake = nullptr;
+  __sanitizer_start_switch_fiber(f->st == DEAD ? nullptr : &fake, tl_machine->sched_bottom, tl_machine->sched_size);
   emu_switch(&f->sp, tl_machine->sched_sp);
+  __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+#else
+  emu_switch(&f->sp, tl_machine->sched_sp);
+#endif
 }
 __attribute__((noinline)) void wave_op() {
   Fiber *f = cur;
@@ -132,6 +157,9 @@ void yield_lane() {
 }
 
 static void fiber_main() {
+#ifdef EMU_ASAN
+  __sanitizer_finish_switch_fiber(nullptr, &tl_machine->sched_bottom, &tl_machine->sched_size);
+#endif
   Fiber *f = cur;
   tl_machine->launch->run_thread();
   f = cur;
@@ -279,19 +307,31 @@ static void resolve_group(Fiber *w0, int nl, uint64_t mask, int first) {
 // ------------------------------------------------------------------------------------------------ launch execution
 static inline void run_fiber(Machine *M, Fiber *f) {
   cur = f;
+#ifdef EMU_ASAN
+  void *fake = nullptr;
+  const size_t slot = (size_t)(((char *)f->sp - M->pool) / g_stack_bytes);
+  __sanitizer_start_switch_fiber(&fake, M->pool + slot * g_stack_bytes, g_stack_bytes);
   emu_switch(&M->sched_sp, f->sp);
+  __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+#else
+  emu_switch(&M->sched_sp, f->sp);
+#endif
 }
 
 // one scheduling pass over a block; returns true if anything moved
 static bool pass_block(Machine *M, Block *b, bool *only_yield) {
   bool progressed = false;
-  for (int w = 0; w < b->nwaves; w++) {
+  static thread_local unsigned rot = 0;
+  rot += 7;
+  for (int wq = 0; wq < b->nwaves; wq++) {
+    const int w = g_sched == 0 ? wq : g_sched == 1 ? b->nwaves - 1 - wq : (int)((wq + rot) % (unsigned)b->nwaves);
     Fiber *w0 = b->fibers + (size_t)w * 64;
     const int nl = std::min(64, b->nthreads - w * 64);
     for (int l = 0; l < nl; l++) if (w0[l].st == YIELDED) { w0[l].st = RUNNABLE; }
     for (;;) {
       bool ran = false, yielded_only = true;
-      for (int l = 0; l < nl; l++) {
+      for (int lq = 0; lq < nl; lq++) {
+        const int l = g_sched == 0 ? lq : g_sched == 1 ? nl - 1 - lq : (int)((lq + rot) % (unsigned)nl);
         if (w0[l].st != RUNNABLE) continue;
         run_fiber(M, &w0[l]);
         ran = true;
@@ -373,6 +413,10 @@ static void run_launch(Machine *M, LaunchBase *L) {
         const int slot = M->free_slots.back();
         M->free_slots.pop_back();
         if ((size_t)slot > M->high_slot) M->high_slot = slot;
+#ifdef EMU_ASAN
+        // a fiber that ended left the redzones of its last frames poisoned in the shadow of this slot
+        __asan_unpoison_memory_region(M->pool + (size_t)slot * g_stack_bytes, g_stack_bytes);
+#endif
         init_fiber(f, M->pool + ((size_t)slot + 1) * g_stack_bytes);  // the slot is recovered from f->sp when the block retires
       }
       resident.push_back(b);
