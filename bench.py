@@ -58,6 +58,7 @@ def parse():
                          "(OB/EnergyFunctional.cpp:1053-1171) sits between stitch and solve on the host")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--side", choices=("imu",), default=None, help=argparse.SUPPRESS)   # one side measurement as its own process
+    ap.add_argument("--no-sides", action="store_true", help="headline loop only: no keyframe / visual-inertial / variants entries")
     ap.add_argument("--cpu-seconds", type=float, default=14.0)
     a = ap.parse_args()
     if a.window is None:
@@ -303,7 +304,7 @@ def main():
         L.sos_ba_time_kernel(L_host_ba(sysm), b"stream_large", th.ctypes.data_as(C.c_void_p), 50, C.byref(ms))
         large_ms = ms.value   # coalesced read of a 1 GiB buffer: the chip's streaming bandwidth without launch effects
         for name in ("apply_res", "top_accumulate", "sc_accumulate", "sc_gram_prep", "reduce", "stitch", "resub_fused", "sc_gram_abs",
-                     "abs_reduce_stitch1", "abs_stitch2"):
+                     "abs_reduce_stitch1", "abs_stitch2", "abs_coop"):
             L.sos_ba_time_kernel(L_host_ba(sysm), name.encode(), th.ctypes.data_as(C.c_void_p), 200, C.byref(ms))
             kern[name + "_us"] = round(ms.value * 1e3, 2)
         out = {
@@ -368,7 +369,7 @@ def main():
         if world > 1:
             out["roofline"]["note"] += "; N > 1: rank 0's kernel on its own shard"
         out["cpu_baseline"] = None   # timed on rank 0 at N = 1 only
-        if world == 1 and not args.imu:
+        if world == 1 and not args.imu and not args.no_sides:
             # side measurements: a failure in one of them must not cost the headline line
             try:
                 out["keyframe"] = keyframe_timing(args.window, local_rank)
@@ -377,6 +378,12 @@ def main():
             except Exception as e:  # noqa: BLE001
                 out["keyframe"] = {"error": repr(e)}
             out["visual_inertial"] = side_process("imu", args.window)
+            # (opt-in order of the IMU branch: first half of the solve behind the enqueue of the accumulation, csrc/host/sos_host.cpp)
+            out["visual_inertial_overlap"] = side_process("imu", args.window, env={"SOS_IMU_OVERLAP": "1"})
+            try:
+                out["variants"] = variant_timing(args.window)
+            except Exception as e:  # noqa: BLE001
+                out["variants"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             out["tracker"] = tracker_timing(args.window, local_rank)
             out["cpu_baseline"] = cpu_baseline(win, args.cpu_seconds)
@@ -387,19 +394,60 @@ def main():
         dist.destroy_process_group()
 
 
-def side_process(what, window, timeout=240):
+def side_process(what, window, timeout=240, env=None):
     """A side measurement in a process of its own: whatever happens to it (an exception, a crash of the native code, a hang) costs
     its entry of the line, not the line."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--side", what, "--window", window]
     try:
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout)
+        e = dict(os.environ)
+        e.update(env or {})
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout, env=e)
         lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
         if r.returncode != 0 or not lines:
             return {"error": f"exit code {r.returncode}"}
         return json.loads(lines[-1])
     except Exception as e:  # noqa: BLE001
         return {"error": repr(e)}
+
+
+# Opt-in paths that have not been measured on an MI355X from inside the build (GPU access was closed during rounds 3-4): the same loop
+# under each switch, in a process of its own, reported BESIDE the headline -- never instead of it.  `last_step_l2` / `resInA` show that
+# a variant computed the same iteration (the absolute-coordinate path differs in the last digits by design, DESIGN.md).
+VARIANTS = (
+    ("abs_schur", {"SOS_ABS_SC": "1"}, []),                                         # one Gram per chunk instead of the n^3 relative blocks + 2-stage stitch
+    ("abs_schur_signal_in_kernel", {"SOS_ABS_SC": "1", "SOS_ABS_SIGNAL_IN_KERNEL": "1"}, []),
+    ("abs_schur_cooperative", {"SOS_ABS_SC": "1", "SOS_ABS_COOP": "1"}, []),        # ... and its three launches as ONE with device-wide barriers
+    ("signal_in_kernel", {"SOS_SIGNAL_IN_KERNEL": "1"}, []),                          # completion flags stored by the last block instead of k_publish
+    ("eager_point_mirrors", {"SOS_EAGER_POINT_MIRRORS": "1"}, []),                    # the per-point host loop of every iteration as before round 4
+    ("resident", {}, ["--resident"]),                                                 # solve on the device (k_gn_solve)
+)
+
+
+def variant_timing(window, timeout=150):
+    import subprocess
+    out = {}
+    for name, env, extra in VARIANTS:
+        e = dict(os.environ)
+        e.update(env)
+        cmd = [sys.executable, os.path.abspath(__file__), "--window", window, "--steps", "20", "--warmup", "3", "--inner", "100",
+               "--no-cpu-baseline", "--no-sides"] + extra
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout, env=e)
+            lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                out[name] = {"error": f"exit code {r.returncode}"}
+                continue
+            d = json.loads(lines[-1])
+            k = d.get("kernels_us", {})
+            out[name] = {"env": env, "args": extra, "us_per_iteration": round(d["ms_per_step"] * 1e3, 2), "gn_loop": d["config"]["gn_loop"][:60],
+                         "resInA": d["config"]["resInA_last_iteration"], "last_step_l2": d["last_step_l2"],
+                         "host_phases_us": d.get("host_phases_us"),
+                         "kernels_us": {q: k.get(q) for q in ("sc_gram_prep_us", "reduce_us", "stitch_us", "sc_gram_abs_us", "abs_reduce_stitch1_us",
+                                                             "abs_stitch2_us", "abs_coop_us", "linearize_fused_us", "resub_fused_us")}}
+        except Exception as ex:  # noqa: BLE001
+            out[name] = {"error": repr(ex)[:200]}
+    return out
 
 
 def keyframe_timing(window, device):
@@ -440,7 +488,14 @@ def keyframe_timing(window, device):
         act_sel = activation_select_timing(win)
     except Exception as e:   # noqa: BLE001 -- a side figure must not cost the entry
         act_sel = {"error": repr(e)[:200]}
-    return {"activation_select": act_sel,
+    try:
+        act_dev = activation_device_timing(win, device)
+    except Exception as e:   # noqa: BLE001
+        act_dev = {"error": repr(e)[:200]}
+    # the whole backend part of makeKeyFrame (FS/FullSystem.cpp:783-931): activation (host selection + device optimisation) + optimize() +
+    # removeOutliers / tracking reference + point and frame marginalisation + makeNewTraces
+    act_ms = sum(d.get(k, 0.0) for d, k in ((act_sel, "activate_select_ms"), (act_dev, "immature_activate_ms"), (act_dev, "make_new_traces_ms")))
+    return {"activation_select": act_sel, "activation_device": act_dev, "keyframe_with_activation_ms": float(med[:4].sum()) + float(act_ms),
             "optimize_ms": float(med[0]), "optimize_iterations": int(rows[-1][5]),
             "remove_outliers_set_tracking_ref_ms": float(med[1]), "flag_points_marginalize_points_ms": float(med[2]),
             "marginalize_frames_ms": float(med[3]), "keyframe_ms": float(med[:4].sum()),
@@ -449,6 +504,79 @@ def keyframe_timing(window, device):
             "note": "optimize_ms: pack + first linearisation + iterations until the step test passes + final linearizeAll(true); "
                     "optimize_6_iterations_ms: the same on the window after the marginalisations with setting_minOptIterations = 6; "
                     "keyframe_ms = the four stages above"}
+
+
+def activation_device_timing(win, device, n_activate=800, density=1500.0, reps=7):
+    """The device half of FullSystem::activatePointsMT (FS/FullSystem.cpp:472-531: optimizeImmaturePoint of the chosen candidates against
+    every keyframe of the window, sos_immature_activate) and FullSystem::makeNewTraces on the new keyframe (FS/FullSystem.cpp:1071-1097:
+    PixelSelector::makeMaps at setting_desiredImmatureDensity + the ImmaturePoint constructors, sos_pixsel_make_maps / _list +
+    sos_immature_init).  The candidates stand on the window's own points (their inverse-depth interval around the point's value, as
+    earlier traces leave it), `n_activate` of them -- what the selection above picks per keyframe at 2000 desired points."""
+    from sos_slam_amd import lib
+    from sos_slam_amd.records import PAIR_TFM_DTYPE, ActivateParams, Calib, PixselParams, TraceParams
+    n = win.n
+    ctx = lib.Context(win.w, win.h, device=device)
+    try:
+        for i in range(n):
+            ctx.make_pyramid(i, win.images[i])
+        tprm, aprm, calib = TraceParams.default(), ActivateParams.default(), Calib.from_K(win.K)
+
+        def inv(T):
+            R, t = T[:9].reshape(3, 3), T[9:]
+            return np.concatenate([R.T.reshape(-1), -(R.T @ t)])
+
+        def mul(A, B):
+            Ra, ta, Rb, tb = A[:9].reshape(3, 3), A[9:], B[:9].reshape(3, 3), B[9:]
+            return np.concatenate([(Ra @ Rb).reshape(-1), Ra @ tb + ta])
+
+        pairs = np.zeros(n * n, dtype=PAIR_TFM_DTYPE)   # PRE_RTll / PRE_tTll / PRE_aff_mode of host -> target (FS/HessianBlocks.cpp:431-461)
+        for h in range(n):
+            for t in range(n):
+                T = mul(inv(win.frames[t]["camToWorld"]), win.frames[h]["camToWorld"])
+                o = pairs[h + n * t]
+                o["R"] = T[:9].astype(np.float32); o["t"] = T[9:].astype(np.float32); o["aff"] = (1.0, 0.0)
+        rng = np.random.default_rng(5)
+        parts, hosts = [], []
+        per_host = max(1, n_activate // max(1, n - 1))
+        for h in range(n - 1):   # (the newest keyframe has no immature points yet)
+            sel = np.flatnonzero(win.points["host"] == h)[:per_host]
+            if len(sel) == 0:
+                continue
+            u = np.rint(win.points["u"][sel]).astype(np.int32)
+            v = np.rint(win.points["v"][sel]).astype(np.int32)
+            pts = ctx.immature_init(tprm, h, u, v)
+            mid = win.points["idepth_scaled"][sel].astype(np.float64) * (1 + rng.uniform(-0.05, 0.05, len(sel)))
+            wdt = rng.uniform(0.05, 0.3, len(sel))
+            pts["idepth_min"] = (mid * (1 - wdt)).astype(np.float32)
+            pts["idepth_max"] = (mid * (1 + wdt)).astype(np.float32)
+            parts.append(pts)
+            hosts.append(np.full(len(pts), h, np.int32))
+        pts, hosts = np.concatenate(parts), np.concatenate(hosts)
+        slots = np.arange(n)
+        ctx.immature_activate(aprm, calib, slots, pairs, pts, hosts)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            res = ctx.immature_activate(aprm, calib, slots, pairs, pts, hosts)
+            ts.append(time.perf_counter() - t0)
+        act_ms = float(np.median(ts)) * 1e3
+        pattern = np.random.default_rng(7).integers(0, 256, win.w * win.h).astype(np.uint8)
+        sel = lib.PixelSelector(ctx, PixselParams.default(), pattern)
+        newest = n - 1
+        sel.make_maps(newest, density, want_map=False)
+        ts, cnt = [], 0
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            sel.make_maps(newest, density, want_map=False)
+            u, v, _t = sel.list(pattern_padding=2)
+            new_pts = ctx.immature_init(tprm, newest, u, v)
+            ts.append(time.perf_counter() - t0)
+            cnt = len(new_pts)
+        sel.close()
+        return {"immature_activate_ms": act_ms, "candidates_optimised": int(len(pts)), "activated": int(np.sum(res["status"] == 1)),
+                "make_new_traces_ms": float(np.median(ts)) * 1e3, "new_immature_points": int(cnt)}
+    finally:
+        ctx.close()
 
 
 def activation_select_timing(win, n_cand_per_point=4, reps=9):

@@ -1972,11 +1972,10 @@ __global__ __launch_bounds__(64) void k_stitch_stage2(StitchArgs a) {
 // (adjoints in their fp32 copies, OB/EnergyFunctional.cpp:94-98, products on the fp32 matrix cores), chunk sums in fp64.
 // ================================================================================================
 static inline size_t gram_abs_lds_floats(int n, int ld) { return (size_t)SOS_GC * ld + SOS_GC + (size_t)SOS_GC * n * 8 + 2 * (size_t)n * 64; }
-__global__ __launch_bounds__(256) void k_sc_gram_abs(BaDev d, const int *__restrict__ chunk_pt, int Dm, int ld, float *__restrict__ gram_part,
-                                                     const float *__restrict__ adHF, const float *__restrict__ adTF, int *flag, int seq) {
-  if (flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int n = d.n, blk = blockIdx.x, tid = threadIdx.x;
+// (the chunk `blk` of a 256-thread workgroup; every thread of the workgroup passes the same barriers)
+__device__ __forceinline__ void gram_abs_body(const BaDev &d, int blk, const int *__restrict__ chunk_pt, int Dm, int ld, float *__restrict__ gram_part,
+                                              const float *__restrict__ adHF, const float *__restrict__ adTF, float *smem) {
+  const int n = d.n, tid = threadIdx.x;
   float *A = smem;                      // [SOS_GC][ld]: the rows w_p
   float *sHdi = A + SOS_GC * ld;        // [SOS_GC]
   float *W = sHdi + SOS_GC;             // [SOS_GC][n][8]: adHost[h,t] JpJd_t per (point, target), summed into the host block below
@@ -2051,6 +2050,12 @@ __global__ __launch_bounds__(256) void k_sc_gram_abs(BaDev d, const int *__restr
     for (int rgi = 0; rgi < 4; rgi++) g[(size_t)(m0 + kq * 4 + rgi) * Dm + n0 + col] = acc[rgi];
   }
 }
+__global__ __launch_bounds__(256) void k_sc_gram_abs(BaDev d, const int *__restrict__ chunk_pt, int Dm, int ld, float *__restrict__ gram_part,
+                                                     const float *__restrict__ adHF, const float *__restrict__ adTF, int *flag, int seq) {
+  if (flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  gram_abs_body(d, blockIdx.x, chunk_pt, Dm, ld, gram_part, adHF, adTF, smem);
+}
 
 // One launch behind the Gram kernel:
 //   blocks [0, n^2)   pair (h,t): the tile sums of the pair added in fp64, then the products of stitch stage 1
@@ -2068,11 +2073,12 @@ struct AbsStitchArgs {
   size_t mode_stride;
   DoneSignal sg;       // k_abs_stitch2 -> host (SOS_ABS_SIGNAL_IN_KERNEL=1: the last block raises the flag, no k_publish behind it)
 };
-__global__ __launch_bounds__(128) void k_abs_reduce_stitch1(AbsStitchArgs a) {
+// (virtual block `vb`, worked by the first 128 threads of the workgroup; every thread of the workgroup passes the same barriers)
+__device__ __forceinline__ void abs_rs1_body(const AbsStitchArgs &a, int vb) {
   const int n = a.n, tid = threadIdx.x;
   __shared__ double sSum[96], sB[64], sAH[64], sAT[64], sT1[64], sT2[64], sBpc[32], sbp[8], sPart[8][16];
-  if ((int)blockIdx.x < n * n) {
-    const int pidx = blockIdx.x;
+  if (vb < n * n) {
+    const int pidx = vb;
     if (tid < 96) {
       const int t0 = a.pair_tile_begin[pidx], t1 = a.pair_tile_begin[pidx + 1];
       double sv = 0;
@@ -2108,7 +2114,7 @@ __global__ __launch_bounds__(128) void k_abs_reduce_stitch1(AbsStitchArgs a) {
       sT2[tid] = t2;
     }
     __syncthreads();
-    if (tid >= 64) return;
+    if (tid >= 64) return;  // (no barrier below this line in this branch)
     double p1 = 0, p2 = 0, p3 = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -2144,14 +2150,14 @@ __global__ __launch_bounds__(128) void k_abs_reduce_stitch1(AbsStitchArgs a) {
     return;
   }
   // ---- H_sc | b_sc
-  const int b = blockIdx.x - n * n, T = a.Dm >> 4;
+  const int b = vb - n * n, T = a.Dm >> 4;
   const int ut = b >> 4, rr = b & 15;
   int mt = 0, rem = ut;
   while (rem >= T - mt) { rem -= T - mt; mt++; }
-  const int r = (mt << 4) + rr, c = ((mt + rem) << 4) + (tid & 15), sub = tid >> 4;
+  const int r = (mt << 4) + rr, c = ((mt + rem) << 4) + (tid & 15), sub = (tid >> 4) & 7;
   const int cols = 8 * n + 5;
   double sv = 0;
-  if (r < cols - 1 && c < cols && c >= r) {
+  if (tid < 128 && r < cols - 1 && c < cols && c >= r) {
     const float *gp = a.gram_part + (size_t)r * a.Dm + c;
     const size_t stride = (size_t)a.Dm * a.Dm;
     for (int k0 = sub; k0 < a.nchunks; k0 += 64) {  // eight loads in flight per thread
@@ -2164,7 +2170,7 @@ __global__ __launch_bounds__(128) void k_abs_reduce_stitch1(AbsStitchArgs a) {
         if (k0 + 8 * u < a.nchunks) sv += (double)v[u];
     }
   }
-  sPart[sub][tid & 15] = sv;
+  if (tid < 128) sPart[sub][tid & 15] = sv;
   __syncthreads();
   if (tid < 16 && r < cols - 1 && c < cols && c >= r) {
     double tot = 0;
@@ -2181,16 +2187,14 @@ __global__ __launch_bounds__(128) void k_abs_reduce_stitch1(AbsStitchArgs a) {
     }
   }
 }
+__global__ __launch_bounds__(128) void k_abs_reduce_stitch1(AbsStitchArgs a) { abs_rs1_body(a, blockIdx.x); }
 // ... and the second one: the sums of stitch stage 2 for the top system (upper triangle), the calibration block / b_c / the
 // residual count from the per-pair entries
-__global__ __launch_bounds__(64) void k_abs_stitch2(AbsStitchArgs a) {
+// (virtual block `vb`, worked by the first 64 threads of the workgroup; every thread of the workgroup passes the same barriers)
+__device__ __forceinline__ void abs_st2_body(const AbsStitchArgs &a, int vb) {
   const int n = a.n, nblk = n * (n + 1) / 2, tid = threadIdx.x;
-  if ((int)blockIdx.x < nblk) {
-    stitch_top_sum_body(blockIdx.x, 0, n, nullptr, a.Ctop, a.H, a.mode_stride, true);
-    if (a.sg.ctr) {
-      __syncthreads();  // all stores of the block issued
-      if (tid == 0) signal_block_done(a.sg);
-    }
+  if (vb < nblk) {
+    if (tid < 64) stitch_top_sum_body(vb, 0, n, nullptr, a.Ctop, a.H, a.mode_stride, true);
     return;
   }
   // 21 scalars, each the sum over the n^2 pairs in pair order: three threads per scalar take a third of the pairs each
@@ -2219,9 +2223,79 @@ __global__ __launch_bounds__(64) void k_abs_stitch2(AbsStitchArgs a) {
     } else if (tid < 20) a.H[(size_t)dim * dim + (tid - 16)] = tot;
     else a.H[2 * a.mode_stride] = tot;
   }
+}
+__global__ __launch_bounds__(64) void k_abs_stitch2(AbsStitchArgs a) {
+  abs_st2_body(a, blockIdx.x);
   if (a.sg.ctr) {
+    __syncthreads();  // all stores of the block issued
+    if (threadIdx.x == 0) signal_block_done(a.sg);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The three launches above as ONE (SOS_ABS_COOP=1, opt-in): a grid of co-resident 256-thread workgroups (one per compute unit) walks
+// the chunks, then the blocks of the reduce / stitch-1 stage, then those of stitch-2, with a device-wide barrier between the stages.
+// At window sizes every stage is at most one partially filled round of blocks whose duration is launch + one block's dependency chain
+// (DESIGN.md 11): two barriers replace two launch gaps and the one-thread publish kernel.  The barrier is an arrival counter that only
+// grows (target = base + stage * grid) and every wait is BOUNDED: a workgroup that waits longer than the spin limit raises `fail`,
+// everybody leaves, the completion flag is never raised and the host's wait_flag falls back to the stream (SOS_ERR_HIP) -- a barrier
+// that does not release cannot hang the device.  Stage s + 1 reads what other workgroups wrote in stage s: release = __threadfence()
+// before the arrival, acquire = __threadfence() after the wait (agent scope: L2 write-back / invalidate across the XCDs), the
+// pattern of fused_final_sum (csrc/sos_tracker.hip).
+// ------------------------------------------------------------------------------------------------
+struct GridBar {
+  unsigned *ctr;   // arrival counter (zeroed with the window's scratch slab; the host tracks `base`)
+  int *fail;
+  unsigned base, spin_limit;
+};
+__device__ __forceinline__ bool grid_barrier(const GridBar &gb, unsigned stage) {
+  __shared__ int s_ok;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    atomicAdd(gb.ctr, 1u);
+    const unsigned target = gb.base + stage * gridDim.x;
+    unsigned spins = 0;
+    int ok = 1;
+    while ((int)(__hip_atomic_load(gb.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > gb.spin_limit || __hip_atomic_load(gb.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        __hip_atomic_store(gb.fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+    }
+    __threadfence();
+    s_ok = ok;
+  }
+  __syncthreads();
+  return s_ok != 0;
+}
+__global__ __launch_bounds__(256) void k_abs_coop(BaDev d, const int *__restrict__ chunk_pt, int Dm, int ld, float *__restrict__ gram_part,
+                                                  const float *__restrict__ adHF, const float *__restrict__ adTF, int *flag, int seq, AbsStitchArgs a,
+                                                  GridBar gb) {
+  if (flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n = a.n, T = Dm >> 4;
+  for (int vb = blockIdx.x; vb < a.nchunks; vb += gridDim.x) {
+    gram_abs_body(d, vb, chunk_pt, Dm, ld, gram_part, adHF, adTF, smem);
+    __syncthreads();  // the next chunk rewrites the staging area
+  }
+  if (!grid_barrier(gb, 1)) return;
+  const int nb1 = n * n + T * (T + 1) / 2 * 16;
+  for (int vb = blockIdx.x; vb < nb1; vb += gridDim.x) {
+    abs_rs1_body(a, vb);
     __syncthreads();
-    if (tid == 0) signal_block_done(a.sg);
+  }
+  if (!grid_barrier(gb, 2)) return;
+  const int nb2 = n * (n + 1) / 2 + 1;
+  for (int vb = blockIdx.x; vb < nb2; vb += gridDim.x) {
+    abs_st2_body(a, vb);
+    __syncthreads();
+  }
+  if (a.sg.ctr) {  // completion: every workgroup arrives once, the last raises the host's flag
+    __syncthreads();
+    if (threadIdx.x == 0) signal_block_done(a.sg);
   }
 }
 __global__ void k_copy_f64(double *__restrict__ dst, const double *__restrict__ src, size_t n) {
@@ -2898,6 +2972,7 @@ struct sos_ba {
   bool fuse_only = false;     // sos_ba_set_prefetch(ba, 2): the linearisation forms the tile sums, nothing is enqueued behind it
   DevBuf<int> d_sigctr;       // [0] linearize launches, [1] stitch launches (cumulative block counters)
   int sig_lin_blocks = 0, sig_lin_seq = 0, sig_st_seq = 0, sig_st_blocks_total = 0, sig_abs_blocks_total = 0;
+  unsigned coop_base = 0;  // arrivals the cooperative launches' barrier counter has seen (d_sigctr[28]; [29] = its fail flag)
   // multi-GPU (sos_ba_set_comm): common capacity of the newest-frame energy lists, local / gathered device lists and
   // the device-mapped host copy of the gathered list
   sos_comm *comm = nullptr;
@@ -3293,6 +3368,7 @@ extern "C" int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, i
   }
   ba->sig_lin_seq = ba->sig_st_seq = 0;
   ba->sig_lin_blocks = ba->sig_st_blocks_total = ba->sig_abs_blocks_total = 0;
+  ba->coop_base = 0;
 
   BaDev &d = ba->dev;
   memset(&d, 0, sizeof(d));
@@ -3966,8 +4042,10 @@ static int enqueue_gn_accumulate_abs(sos_ba *ba, bool topDone, int *pubFlag, int
     k_top_accumulate<false><<<divup(ba->ntilesA, 8), 256, 0, st>>>(ba->dev, 0, ba->ntilesA, 0, nullptr, nullptr, ba->d_top_part.p, nullptr);
     pubFlag = nullptr;
   }
-  k_sc_gram_abs<<<ba->nchunks, 256, lds, st>>>(ba->dev, ba->d_chunk_pt.p, ba->Dm, ba->ld, ba->d_gram_part.p, ba->d_adHostF.p, ba->d_adTargetF.p,
-                                               pubFlag, pubSeq);
+  static const bool coop = getenv("SOS_ABS_COOP") != nullptr;  // opt-in: ONE cooperative launch for the three stages (never run on an MI355X yet)
+  if (!coop)
+    k_sc_gram_abs<<<ba->nchunks, 256, lds, st>>>(ba->dev, ba->d_chunk_pt.p, ba->Dm, ba->ld, ba->d_gram_part.p, ba->d_adHostF.p, ba->d_adTargetF.p,
+                                                 pubFlag, pubSeq);
   AbsStitchArgs a;
   a.n = n; a.Dm = ba->Dm; a.nchunks = ba->nchunks;
   a.top_part = ba->d_top_part.p; a.pair_tile_begin = ba->d_pair_tile_begin.p; a.gram_part = ba->d_gram_part.p;
@@ -3978,21 +4056,34 @@ static int enqueue_gn_accumulate_abs(sos_ba *ba, bool topDone, int *pubFlag, int
   a.H = ba->comm ? ba->d_Hout.p : pinH;
   a.mode_stride = ms;
   const int T = ba->Dm >> 4;
-  k_abs_reduce_stitch1<<<(int)nn + T * (T + 1) / 2 * 16, 128, 0, st>>>(a);
+  if (!coop) k_abs_reduce_stitch1<<<(int)nn + T * (T + 1) / 2 * 16, 128, 0, st>>>(a);
   // completion: a k_publish behind the last kernel, or (A/B knob) the last block of k_abs_stitch2 itself -- 80 blocks, one
   // system-scope fence each; H_sc was written by the previous launch and is visible at its end
   static const bool inKernel = getenv("SOS_ABS_SIGNAL_IN_KERNEL") != nullptr;
   const int nb2 = n * (n + 1) / 2 + 1;
+  const int G = coop ? lin_ncu(ba) : 0;  // cooperative form: one workgroup per compute unit, all resident
   a.sg = {nullptr, nullptr, 0, 0};
   ++ba->sig_st_seq;
-  if (inKernel && !ba->comm) {
-    ba->sig_abs_blocks_total += nb2;
+  if ((inKernel || coop) && !ba->comm) {
+    ba->sig_abs_blocks_total += coop ? G : nb2;
     a.sg.ctr = ba->d_sigctr.p + 24;
     a.sg.flag = reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags + 64);
     a.sg.target = ba->sig_abs_blocks_total;
     a.sg.seq = ba->sig_st_seq;
   }
-  k_abs_stitch2<<<nb2, 64, 0, st>>>(a);
+  if (coop) {
+    static bool attr2 = false;
+    if (!attr2) {
+      hipFuncSetAttribute(reinterpret_cast<const void *>(k_abs_coop), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      attr2 = true;
+    }
+    static const unsigned spinLimit = getenv("SOS_COOP_SPIN_LIMIT") ? (unsigned)atoi(getenv("SOS_COOP_SPIN_LIMIT")) : (1u << 20);
+    GridBar gb = {reinterpret_cast<unsigned *>(ba->d_sigctr.p + 28), ba->d_sigctr.p + 29, ba->coop_base, spinLimit};
+    ba->coop_base += 2u * (unsigned)G;
+    k_abs_coop<<<G, 256, lds, st>>>(ba->dev, ba->d_chunk_pt.p, ba->Dm, ba->ld, ba->d_gram_part.p, ba->d_adHostF.p, ba->d_adTargetF.p, pubFlag, pubSeq, a, gb);
+  } else {
+    k_abs_stitch2<<<nb2, 64, 0, st>>>(a);
+  }
   if (ba->comm) {  // THE exchange step of the path, on the stitched fp64 system (the stitch is linear): [H_A b_A | H_sc b_sc | count]
     const int rcc = sos_comm_allreduce_sum_f64(ba->comm, ba->d_Hout.p, 2 * ms + 1, st);
     if (rcc) return rcc;
@@ -4697,7 +4788,7 @@ extern "C" int sos_ba_time_kernel(sos_ba *ba, const char *kernel, const float *f
       if (ba->nchunks > 0) k_sc_gram_prep<<<ba->nchunks, 256, gram_lds(ba), st>>>(ba->dev, ba->d_chunk_pt.p, ba->Dm, ba->ld, ba->d_gram_part.p, nullptr, 0);
       return SOS_OK;
     }
-    if (k == "sc_gram_abs" || k == "abs_reduce_stitch1" || k == "abs_stitch2") {  // the kernels of the absolute-coordinate Schur path, one at a time
+    if (k == "sc_gram_abs" || k == "abs_reduce_stitch1" || k == "abs_stitch2" || k == "abs_coop") {  // the kernels of the absolute-coordinate Schur path, one at a time
       if (!abs_path_ok(ba)) return SOS_OK;
       const int n = ba->n;
       const size_t nn = (size_t)n * n;
@@ -4715,6 +4806,15 @@ extern "C" int sos_ba_time_kernel(sos_ba *ba, const char *kernel, const float *f
       a.H = ba->d_Hout.p; a.mode_stride = ba->hb_mode_stride;
       a.sg = {nullptr, nullptr, 0, 0};
       const int T = ba->Dm >> 4;
+      if (k == "abs_coop") {  // the three stages as one cooperative launch (no completion signal: timed by the caller's events)
+        const int G = lin_ncu(ba);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_abs_coop), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        GridBar gb = {reinterpret_cast<unsigned *>(ba->d_sigctr.p + 28), ba->d_sigctr.p + 29, ba->coop_base, 1u << 20};
+        ba->coop_base += 2u * (unsigned)G;
+        k_abs_coop<<<G, 256, sizeof(float) * gram_abs_lds_floats(n, ba->ld), st>>>(ba->dev, ba->d_chunk_pt.p, ba->Dm, ba->ld, ba->d_gram_part.p,
+                                                                                  ba->d_adHostF.p, ba->d_adTargetF.p, nullptr, 0, a, gb);
+        return SOS_OK;
+      }
       if (k == "abs_reduce_stitch1") k_abs_reduce_stitch1<<<(int)nn + T * (T + 1) / 2 * 16, 128, 0, st>>>(a);
       else k_abs_stitch2<<<n * (n + 1) / 2 + 1, 64, 0, st>>>(a);
       return SOS_OK;

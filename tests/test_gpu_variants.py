@@ -78,6 +78,8 @@ def test_switches(modeA, modeB, huber, outlier):
     # 3.2x as far from the fp64-accumulated step as the reference's own fp32 arithmetic, tests/emu run of round 4; from T6 up it is at par)
     ({"SOS_ABS_SC": "1"}, "tests/test_gpu_edge_windows.py -k T6"),
     ({"SOS_ABS_SC": "1", "SOS_ABS_SIGNAL_IN_KERNEL": "1"}, "tests/test_golden_t6.py"),
+    # ... with its three launches as ONE cooperative launch (device-wide barriers with bounded waits, csrc/sos_ba.hip: k_abs_coop)
+    ({"SOS_ABS_SC": "1", "SOS_ABS_COOP": "1"}, "tests/test_gpu_edge_windows.py -k T6"),
 ])
 def test_launch_variants_keep_parity(env, target):
     """Launch-shape choices the library makes per window (read once per process from the environment when forced) must
