@@ -418,6 +418,8 @@ VARIANTS = (
     ("abs_schur", {"SOS_ABS_SC": "1"}, []),                                         # one Gram per chunk instead of the n^3 relative blocks + 2-stage stitch
     ("abs_schur_signal_in_kernel", {"SOS_ABS_SC": "1", "SOS_ABS_SIGNAL_IN_KERNEL": "1"}, []),
     ("abs_schur_cooperative", {"SOS_ABS_SC": "1", "SOS_ABS_COOP": "1"}, []),        # ... and its three launches as ONE with device-wide barriers
+    ("prelaunched_step", {"SOS_PRELAUNCH_STEP": "1"}, []),                            # the step's launches enqueued before the solve, x through a mapped mailbox
+    ("prelaunched_step_abs_cooperative", {"SOS_PRELAUNCH_STEP": "1", "SOS_ABS_SC": "1", "SOS_ABS_COOP": "1"}, []),
     ("signal_in_kernel", {"SOS_SIGNAL_IN_KERNEL": "1"}, []),                          # completion flags stored by the last block instead of k_publish
     ("eager_point_mirrors", {"SOS_EAGER_POINT_MIRRORS": "1"}, []),                    # the per-point host loop of every iteration as before round 4
     ("resident", {}, ["--resident"]),                                                 # solve on the device (k_gn_solve)

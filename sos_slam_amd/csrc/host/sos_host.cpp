@@ -1301,7 +1301,22 @@ host_path:
   if (devStepActive && !pointMirrorsStale && (inOptimizeLoop || pipelineAlways)) beginLazyPointMirrors();
   if (!devStepActive) flushPointMirrors();
   { PhaseTimer tb(7); backupState(); }
+  // SOS_PRELAUNCH_STEP=1 (opt-in, never run on an MI355X yet): the launches of this iteration's step -- back-substitution + device-side
+  // step, linearisation, the next accumulate -- are enqueued NOW, behind the accumulate whose H / b the solve below waits for; the first of
+  // them waits for x in a mapped mailbox (sos_ba_gn_step_prelaunch / _deliver), so no launch latency sits between solve and step.  Whether
+  // there will be another iteration is not known before the solve: the linearisation is launched in the form a following accumulate wants
+  // (tile sums instead of a stored J) and the accumulate itself is enqueued by the delivery, when it is known
+  bool prelaunched = false;
+  static const bool prelaunchOn = getenv("SOS_PRELAUNCH_STEP") != nullptr;
+  if (prelaunchOn && devStepActive && !ef->allreduceHook && !ef->commAttached) {
+    const int nf = (int)frameHessians.size();
+    std::vector<float> th(nf);
+    for (int i = 0; i < nf; i++) th[i] = frameHessians[i]->frameEnergyTH;
+    sos_ba_set_prefetch(ef->ba, (pipelineAlways || mayContinue) ? 1 : 0);
+    prelaunched = sos_ba_gn_step_prelaunch(ef->ba, 1.0f, th.data(), 1) == SOS_OK;
+  }
   if (rcAcc(ef->solveSystemF(iteration, 1e-1, &HCalib, true)) != SOS_OK) {  // x, frame / calib steps; back-substitution deferred
+    if (prelaunched) sos_ba_gn_step_deliver(ef->ba, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);  // (the waiting step steps by zero and drains)
     isLost = true;  // a failed device call: no step is taken on undelivered H / b
     return true;
   }
@@ -1325,9 +1340,14 @@ host_path:
     double E = 0;
     ef->pointStep.resize(ef->allPoints.size());
     const bool more = pipelineAlways || (mayContinue && !(canbreak && iteration >= minOptIterations));
-    sos_ba_set_prefetch(ef->ba, (more && !ef->allreduceHook) ? 1 : 0);  // a callback exchange runs between accumulate and stitch
-    lastError = sos_ba_gn_step(ef->ba, ef->lastX.data(), 1.0f, &cal, nullptr, nullptr, nullptr, th.data(), 1, &E, newestE.data(), &cnt,
-                               ef->pointStep.data());
+    if (prelaunched) {
+      sos_ba_set_prefetch(ef->ba, more ? 1 : 0);  // (the next accumulate is enqueued by the delivery, now that `more` is known)
+      lastError = sos_ba_gn_step_deliver(ef->ba, ef->lastX.data(), &cal, &E, newestE.data(), &cnt, ef->pointStep.data());
+    } else {
+      sos_ba_set_prefetch(ef->ba, (more && !ef->allreduceHook) ? 1 : 0);  // a callback exchange runs between accumulate and stitch
+      lastError = sos_ba_gn_step(ef->ba, ef->lastX.data(), 1.0f, &cal, nullptr, nullptr, nullptr, th.data(), 1, &E, newestE.data(), &cnt,
+                                 ef->pointStep.data());
+    }
     if (lastError != SOS_OK) {  // e.g. the device-side frame states were dropped by a state upload in between: no step was taken
       devStepActive = false;
       sos_ba_gn_devstep_end(ef->ba);

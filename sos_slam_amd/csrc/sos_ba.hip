@@ -2551,7 +2551,7 @@ struct DevStep {
   float th[17];                                               // frameEnergyTH of the coming linearisation
 };
 __device__ __forceinline__ void devstep_block(int sb, int nsb, const BaDev &d, const DevStep &g, const float *__restrict__ adHF, const float *__restrict__ adTF,
-                                              float4 *__restrict__ t_pre, float *smemf) {
+                                              float4 *__restrict__ t_pre, float *smemf, const double *xd) {
   const int tid = threadIdx.x, n = d.n;
   // LDS: [28 n^2 floats: the records] then doubles: c2w 12 n | w2c 12 n | state 10 n | calib 4, then 8 floats K
   float *pre = smemf;
@@ -2575,7 +2575,7 @@ __device__ __forceinline__ void devstep_block(int sb, int nsb, const BaDev &d, c
   if (tid < n) {  // FrameHessian::setState, FS/HessianBlocks.h:217-230
     const int f = tid;
     double st[10], scv[6];
-    for (int i = 0; i < 8; i++) st[i] = g.state_in[10 * f + i] + (-g.xd[SOS_CPARS + 8 * f + i]);
+    for (int i = 0; i < 8; i++) st[i] = g.state_in[10 * f + i] + (-xd[SOS_CPARS + 8 * f + i]);
     st[8] = g.state_in[10 * f + 8];
     st[9] = g.state_in[10 * f + 9];
     for (int i = 0; i < 10; i++) stN[10 * f + i] = st[i];
@@ -2595,7 +2595,7 @@ __device__ __forceinline__ void devstep_block(int sb, int nsb, const BaDev &d, c
   }
   if (tid == 32) {  // CalibHessian::setValue, FS/HessianBlocks.h:476-491 (a lane behind the <= 17 frame lanes)
     double vs[4];
-    for (int i = 0; i < 4; i++) cvN[i] = g.calib_in[i] + (-g.xd[i]);
+    for (int i = 0; i < 4; i++) cvN[i] = g.calib_in[i] + (-xd[i]);
     vs[0] = SOS_SCALE_F * cvN[0]; vs[1] = SOS_SCALE_F * cvN[1]; vs[2] = SOS_SCALE_C * cvN[2]; vs[3] = SOS_SCALE_C * cvN[3];
     for (int i = 0; i < 4; i++) sK[i] = (float)vs[i];
     sK[4] = 1.0f / sK[0]; sK[5] = 1.0f / sK[1]; sK[6] = -sK[2] / sK[0]; sK[7] = -sK[3] / sK[1];
@@ -2690,10 +2690,51 @@ __global__ __launch_bounds__(SOS_RSB) void k_resub_devstep(BaDev d, const float 
                                                        float4 *__restrict__ t_pre) {
   extern __shared__ __attribute__((aligned(16))) float sxAd[];
   if ((int)blockIdx.x >= nPointBlocks) {
-    devstep_block((int)blockIdx.x - nPointBlocks, (int)gridDim.x - nPointBlocks, d, g, adHF, adTF, t_pre, sxAd);
+    devstep_block((int)blockIdx.x - nPointBlocks, (int)gridDim.x - nPointBlocks, d, g, adHF, adTF, t_pre, sxAd, g.xd);
     return;
   }
   resub_point_block(d, nullptr, adHF, adTF, step_out, stepfacD, nullptr, sxAd, g.xd);
+}
+// The same launch enqueued BEFORE the solve (sos_ba_gn_step_prelaunch, opt-in): every workgroup waits for the host's x in a mailbox in
+// device-mapped host memory -- {x[dim], flag} -- instead of receiving it as a kernel argument, so that the launch latency of the step
+// (and of the linearisation and the next accumulate queued behind it) is off the path between the host's solve and the device's
+// back-substitution.  The wait is bounded: a workgroup that gives up raises `fail` (mapped) and steps with x = 0 (the state stays where it
+// is); the host reports the call as failed.
+struct StepMail {
+  const double *x;   // mapped host memory
+  const int *flag;   // ... raised to `seq` by sos_ba_gn_step_deliver after x is written
+  int *fail;
+  int seq;
+  unsigned spin_limit;
+};
+__global__ __launch_bounds__(SOS_RSB) void k_resub_devstep_wait(BaDev d, const float *__restrict__ adHF, const float *__restrict__ adTF,
+                                                            float *__restrict__ step_out, float stepfacD, int nPointBlocks, DevStep g,
+                                                            float4 *__restrict__ t_pre, StepMail m) {
+  extern __shared__ __attribute__((aligned(16))) float sxAd[];
+  __shared__ double sxd[SOS_CPARS + 8 * 17];
+  __shared__ int s_have;
+  const int dim = SOS_CPARS + 8 * d.n;
+  if (threadIdx.x == 0) {
+    unsigned spins = 0;
+    int have = 1;
+    while (__hip_atomic_load(m.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != m.seq) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > m.spin_limit) {
+        __hip_atomic_store(m.fail, m.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        have = 0;
+        break;
+      }
+    }
+    s_have = have;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < dim; i += SOS_RSB) sxd[i] = s_have ? __hip_atomic_load(m.x + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0;
+  __syncthreads();
+  if ((int)blockIdx.x >= nPointBlocks) {
+    devstep_block((int)blockIdx.x - nPointBlocks, (int)gridDim.x - nPointBlocks, d, g, adHF, adTF, t_pre, sxAd, sxd);
+    return;
+  }
+  resub_point_block(d, nullptr, adHF, adTF, step_out, stepfacD, nullptr, sxAd, sxd);
 }
 
 // ================================================================================================
@@ -2973,6 +3014,18 @@ struct sos_ba {
   DevBuf<int> d_sigctr;       // [0] linearize launches, [1] stitch launches (cumulative block counters)
   int sig_lin_blocks = 0, sig_lin_seq = 0, sig_st_seq = 0, sig_st_blocks_total = 0, sig_abs_blocks_total = 0;
   unsigned coop_base = 0;  // arrivals the cooperative launches' barrier counter has seen (d_sigctr[28]; [29] = its fail flag)
+  int acc_wait_seq = 0;    // sequence number the stitch of the accumulate to be consumed NEXT publishes
+  size_t pin_mail = 0;     // mailbox of a pre-launched step in the mapped block: (4 + 8 * 17) doubles of x, then flag and fail (ints)
+  int mail_seq = 0;
+  struct StepPend {        // a step whose launches are enqueued and whose results have not been collected yet
+    bool active = false, prelaunched = false, prefetchEnqueued = false, havePointStep = false;
+    int waitSeq = 0;
+    float stepfacD = 0;
+    double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    // a pre-launched step leaves the enqueue of the next accumulate to its delivery (whether there is a next iteration is known after
+    // the solve, and an accumulate nobody consumes would overwrite the per-point outputs of the last one): what that enqueue needs
+    bool fuseTop = false, chainPublish = false, applyRes = false;
+  } pend;
   // multi-GPU (sos_ba_set_comm): common capacity of the newest-frame energy lists, local / gathered device lists and
   // the device-mapped host copy of the gathered list
   sos_comm *comm = nullptr;
@@ -3351,7 +3404,8 @@ extern "C" int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, i
   {
     const size_t need_stage = sizeof(float) * ba->st_floats, need_out = ba->out_bytes,
                  need_hb = sizeof(double) * 3 * ba->hb_mode_stride + 16 + 128;  // + completion flags
-    const size_t tot = need_stage + need_out + need_hb + 256;
+    const size_t need_mail = sizeof(double) * (SOS_CPARS + 8 * 17) + 64;
+    const size_t tot = need_stage + need_out + need_hb + 256 + need_mail + 64;
     if (tot > ba->pin_bytes) {
       if (ba->pin) hipHostFree(ba->pin);
       ba->pin = nullptr;
@@ -3364,11 +3418,15 @@ extern "C" int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, i
     ba->pin_out = (need_stage + 63) / 64 * 64;
     ba->pin_hb = ba->pin_out + (need_out + 63) / 64 * 64;
     ba->pin_flags = ba->pin_hb + (sizeof(double) * 3 * ba->hb_mode_stride + 16 + 63) / 64 * 64;
-    memset(ba->pin + ba->pin_flags, 0, 128);
+    ba->pin_mail = ba->pin_flags + 128;
+    memset(ba->pin + ba->pin_flags, 0, 128 + need_mail);
   }
   ba->sig_lin_seq = ba->sig_st_seq = 0;
   ba->sig_lin_blocks = ba->sig_st_blocks_total = ba->sig_abs_blocks_total = 0;
   ba->coop_base = 0;
+  ba->acc_wait_seq = 0;
+  ba->mail_seq = 0;
+  ba->pend = sos_ba::StepPend();
 
   BaDev &d = ba->dev;
   memset(&d, 0, sizeof(d));
@@ -3560,15 +3618,20 @@ static bool lin_v1() {
 }
 // host side of DoneSignal: poll the mapped flag; after 50 ms fall back to a stream synchronisation (a failed launch
 // must not hang the caller)
-static int wait_flag(sos_ba *ba, size_t flag_off, int seq) {
+static int wait_flag(sos_ba *ba, size_t flag_off, int seq, bool flagOnly = false) {
   int *flag = reinterpret_cast<int *>(ba->pin + flag_off);
   const double t0 = now_s();
   unsigned spins = 0;
   while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) < seq) {
     __builtin_ia32_pause();
-    if ((++spins & 4095u) == 0 && now_s() - t0 > 0.05) {
-      SOS_HIP(hipStreamSynchronize(ba->ctx->stream));
-      return __atomic_load_n(flag, __ATOMIC_ACQUIRE) >= seq ? SOS_OK : SOS_ERR_HIP;
+    if ((++spins & 4095u) == 0) {
+      const double dt = now_s() - t0;
+      if (flagOnly) {  // a pre-launched step sits on the stream waiting for x: synchronising the stream here would wait for ourselves
+        if (dt > 30.0) return SOS_ERR_HIP;
+      } else if (dt > 0.05) {
+        SOS_HIP(hipStreamSynchronize(ba->ctx->stream));
+        return __atomic_load_n(flag, __ATOMIC_ACQUIRE) >= seq ? SOS_OK : SOS_ERR_HIP;
+      }
     }
   }
   return SOS_OK;
@@ -4092,6 +4155,7 @@ static int enqueue_gn_accumulate_abs(sos_ba *ba, bool topDone, int *pubFlag, int
   if (!a.sg.ctr) k_publish<<<1, 1, 0, st>>>(reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags + 64), ba->sig_st_seq);
   ba->acc_inflight_haveL = false;
   ba->acc_inflight_abs = true;
+  ba->acc_wait_seq = ba->sig_st_seq;
   return SOS_OK;
 }
 static int enqueue_gn_accumulate(sos_ba *ba, bool topDone = false, int *pubFlag = nullptr, int pubSeq = 0) {
@@ -4121,6 +4185,7 @@ static int enqueue_gn_accumulate(sos_ba *ba, bool topDone = false, int *pubFlag 
   }
   launch_stitch(ba, ba->d_acc.p, haveL ? 2 : 1, reinterpret_cast<double *>(ba->pin_dev + ba->pin_hb));
   ba->acc_inflight_haveL = haveL;
+  ba->acc_wait_seq = ba->sig_st_seq;
   return SOS_OK;
 }
 
@@ -4144,6 +4209,7 @@ extern "C" int sos_ba_gn_accumulate(sos_ba *ba, double *H_top, double *b_top, do
   if (!ba || !ba->have_window || !ba->have_state || !H_top || !b_top || !H_sc || !b_sc) return SOS_ERR_STATE;
   SOS_HIP(hipSetDevice(ba->ctx->device));
   if (!ba->acc_inflight) {  // otherwise the previous sos_ba_gn_step already enqueued it (sos_ba_set_prefetch)
+    if (ba->pend.active && ba->pend.prelaunched) return SOS_ERR_STATE;  // (it would queue behind a step that waits for this very result)
     enqueue_gn_accumulate(ba, ba->top_valid);
     SOS_HIP(hipGetLastError());
   }
@@ -4151,7 +4217,7 @@ extern "C" int sos_ba_gn_accumulate(sos_ba *ba, double *H_top, double *b_top, do
   const bool haveL = ba->acc_inflight_haveL;
   const double ta = now_s();
   {
-    const int rcw = wait_flag(ba, ba->pin_flags + 64, ba->sig_st_seq);
+    const int rcw = wait_flag(ba, ba->pin_flags + 64, ba->acc_wait_seq, ba->pend.active && ba->pend.prelaunched);
     if (rcw) return rcw;
   }
   ba->tm[6] += now_s() - ta;
@@ -4271,11 +4337,9 @@ extern "C" int sos_ba_gn_resub(sos_ba *ba, const double *x, float stepfacD) {
 
 // Back half of a fused iteration: linearizeAll(false) + applyRes on the state the stream has reached, the next
 // iteration's accumulate chain enqueued behind it (sos_ba_set_prefetch), results through the mapped block.
-static int lin_apply_tail(sos_ba *ba, BaDev &dv, int applyRes, bool havePointStep, float stepfacD, double *energySum,
-                          float *newestEnergies, int *newestCount, float *pointStep, double t0, double t1) {
+static int lin_apply_enqueue(sos_ba *ba, BaDev &dv, int applyRes, bool havePointStep, float stepfacD, double t0, double t1, bool deferPrefetch = false) {
   sos_ctx *c = ba->ctx;
   hipStream_t st = c->stream;
-  char *po = ba->pin + ba->pin_out;
   // nobody reads the original-order copies of the per-residual results in a fused iteration (they are scattered 1..12 byte
   // stores, one partial line each): only the two-step sos_ba_linearize delivers them
   dv.o_newstate = nullptr; dv.o_newenergy = nullptr; dv.o_newenergywo = nullptr; dv.o_center = nullptr;
@@ -4296,28 +4360,39 @@ static int lin_apply_tail(sos_ba *ba, BaDev &dv, int applyRes, bool havePointSte
   ba->J_valid = !fuseTop;
   ba->top_valid = fuseTop;
   SOS_HIP(hipGetLastError());
-  const double t2 = now_s();
-  double t3 = t2;
-  if (ba->prefetch && applyRes) {  // the next iteration's accumulate + stitch runs while the host digests this step
+  sos_ba::StepPend &pd = ba->pend;
+  pd.active = true;
+  pd.waitSeq = waitSeq; pd.havePointStep = havePointStep; pd.stepfacD = stepfacD;
+  pd.t0 = t0; pd.t1 = t1; pd.t2 = now_s(); pd.t3 = pd.t2;
+  pd.fuseTop = fuseTop; pd.chainPublish = chainPublish; pd.applyRes = applyRes != 0;
+  pd.prefetchEnqueued = ba->prefetch && applyRes && !deferPrefetch;
+  if (pd.prefetchEnqueued) {  // the next iteration's accumulate + stitch runs while the host digests this step
     if (!waitSeq) SOS_HIP(hipEventRecord(ba->ev_step, st));
     enqueue_gn_accumulate(ba, fuseTop, chainPublish ? reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags) : nullptr, waitSeq);
     SOS_HIP(hipGetLastError());
     ba->acc_inflight = true;
-    t3 = now_s();
-    if (waitSeq) {
-      const int rcw = wait_flag(ba, ba->pin_flags, waitSeq);
-      if (rcw) return rcw;
-    } else {
-      SOS_HIP(hipEventSynchronize(ba->ev_step));
-    }
-  } else if (waitSeq) {
-    const int rcw = wait_flag(ba, ba->pin_flags, waitSeq);
+    pd.t3 = now_s();
+  }
+  return SOS_OK;
+}
+// ... and the collecting half: wait for the step (never for the accumulate behind it), unpack the mapped results
+static int lin_apply_finish(sos_ba *ba, double *energySum, float *newestEnergies, int *newestCount, float *pointStep) {
+  hipStream_t st = ba->ctx->stream;
+  char *po = ba->pin + ba->pin_out;
+  sos_ba::StepPend &pd = ba->pend;
+  const int waitSeq = pd.waitSeq;
+  const bool flagOnly = pd.prelaunched;
+  pd.active = false;
+  if (waitSeq) {
+    const int rcw = wait_flag(ba, ba->pin_flags, waitSeq, flagOnly);
     if (rcw) return rcw;
+  } else if (pd.prefetchEnqueued) {
+    SOS_HIP(hipEventSynchronize(ba->ev_step));
   } else {
     SOS_HIP(hipStreamSynchronize(st));
   }
   const double t4 = now_s();
-  ba->tm[0] += t1 - t0; ba->tm[2] += t2 - t1; ba->tm[3] += t3 - t2; ba->tm[4] += t4 - t3; ba->tm_calls++;
+  ba->tm[0] += pd.t1 - pd.t0; ba->tm[2] += pd.t2 - pd.t1; ba->tm[3] += pd.t3 - pd.t2; ba->tm[4] += t4 - pd.t3; ba->tm_calls++;
   if (energySum) {
     const double *es = reinterpret_cast<const double *>(po + ba->out_esum);
     double e = 0;
@@ -4333,7 +4408,8 @@ static int lin_apply_tail(sos_ba *ba, BaDev &dv, int applyRes, bool havePointSte
     if (newestCount) *newestCount = k;
   }
   const float *hs = reinterpret_cast<const float *>(po + ba->out_step);
-  if (havePointStep) {
+  if (pd.havePointStep) {
+    const float stepfacD = pd.stepfacD;
     for (int p = 0; p < ba->P; p++) {  // keep the host mirror of the snapshot in step with the device
       const float idn = ba->h_pts[p].idepth_scaled + stepfacD * hs[p];
       ba->h_pts[p].idepth_scaled = idn;
@@ -4344,6 +4420,13 @@ static int lin_apply_tail(sos_ba *ba, BaDev &dv, int applyRes, bool havePointSte
   }
   ba->tm[5] += now_s() - t4;
   return SOS_OK;
+}
+static int lin_apply_tail(sos_ba *ba, BaDev &dv, int applyRes, bool havePointStep, float stepfacD, double *energySum,
+                          float *newestEnergies, int *newestCount, float *pointStep, double t0, double t1) {
+  ba->pend.prelaunched = false;
+  const int rc = lin_apply_enqueue(ba, dv, applyRes, havePointStep, stepfacD, t0, t1);
+  if (rc) { ba->pend.active = false; return rc; }
+  return lin_apply_finish(ba, energySum, newestEnergies, newestCount, pointStep);
 }
 
 
@@ -4425,6 +4508,105 @@ extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const
     stage_in(ba, ba->st_xc);
   }
   return lin_apply_tail(ba, dv, applyRes, x != nullptr || resubAhead, stepfacD, energySum, newestEnergies, newestCount, pointStep, t0, t1);
+}
+
+// The device-side step of sos_ba_gn_step enqueued BEFORE the solve (opt-in; see k_resub_devstep_wait): back-substitution + step +
+// linearisation + (sos_ba_set_prefetch) the next accumulate go onto the stream behind the accumulate whose H / b the host is about to
+// solve; sos_ba_gn_step_deliver hands x over through the mailbox and collects the step's results.  Between the two calls the stream
+// must not be synchronised (sos_ba_gn_accumulate knows).  SOS_ERR_STATE = not possible now (no device-side step, a communicator, no
+// accumulate in flight to queue behind): the caller uses sos_ba_gn_step as before.
+extern "C" int sos_ba_gn_step_prelaunch(sos_ba *ba, float stepfacD, const float *frameEnergyTH, int applyRes) {
+  if (!ba || !ba->have_window || !ba->have_state || !frameEnergyTH || !ba->devstep || ba->comm || ba->pend.active) return SOS_ERR_STATE;
+  if (!(ba->P > 0 && ba->d_adHostF.p && ba->d_adTargetF.p && ba->ds_n == ba->n) || !ba->acc_inflight || ba->ntilesA <= 0 || lin_v1()) return SOS_ERR_STATE;
+  sos_ctx *c = ba->ctx;
+  SOS_HIP(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  const size_t nn = (size_t)ba->n * ba->n;
+  // the bookkeeping of the accumulate that is still to be consumed (sos_ba_gn_accumulate) is set aside while the launches below write
+  // that of the next one
+  const bool cur_inflight = ba->acc_inflight, cur_haveL = ba->acc_inflight_haveL, cur_abs = ba->acc_inflight_abs, cur_top = ba->top_valid, cur_J = ba->J_valid;
+  const int cur_seq = ba->acc_wait_seq;
+  ba->acc_inflight = false, ba->top_valid = false;
+  const double t0 = now_s();
+  char *po_dev = ba->pin_dev + ba->pin_out;
+  float *dstep = reinterpret_cast<float *>(po_dev + ba->out_step);
+  BaDev dv = ba->dev;
+  dv.tile_esum = reinterpret_cast<double *>(po_dev + ba->out_esum);
+  dv.o_newest = reinterpret_cast<float *>(po_dev + ba->out_newest);
+  const double t1 = now_s();
+  const int n = ba->n;
+  DevStep g;
+  memset(g.xd, 0, sizeof(g.xd));  // (x arrives through the mailbox)
+  for (int i = 0; i < n; i++) g.th[i] = frameEnergyTH[i];
+  double *b = ba->d_ds;
+  g.evalC2W = b; g.state_zero = b + 12 * n;
+  g.state_in = b + 22 * n + 10 * n * ba->ds_cur; g.state_out = b + 22 * n + 10 * n * (ba->ds_cur ^ 1);
+  g.calib_in = b + 42 * n + 8 * ba->ds_cur; g.calib_out = b + 42 * n + 8 * (ba->ds_cur ^ 1);
+  g.abexp = b + 42 * n + 16;
+  ba->ds_cur ^= 1;
+  g.stage = ba->d_stage.p;
+  g.st_pre = ba->st_pre; g.st_adh = ba->st_adh; g.st_cd = ba->st_cd; g.st_th = ba->st_th; g.st_cal = ba->st_cal;
+  const int nPB = divup(ba->P, SOS_RSB), nEB = std::max(1, divup(8 * ba->ntiles, SOS_RSB));
+  const size_t lds = std::max(sizeof(float) * (8 * nn + 4 + 8 * (size_t)n), sizeof(float) * (28 * nn + 16) + sizeof(double) * (34 * (size_t)n + 8));
+  char *mail = ba->pin_dev + ba->pin_mail;
+  const size_t flagOff = sizeof(double) * (SOS_CPARS + 8 * 17);
+  static const unsigned spinLimit = getenv("SOS_PRELAUNCH_SPIN_LIMIT") ? (unsigned)atoi(getenv("SOS_PRELAUNCH_SPIN_LIMIT")) : (1u << 22);
+  StepMail m = {reinterpret_cast<const double *>(mail), reinterpret_cast<const int *>(mail + flagOff), reinterpret_cast<int *>(mail + flagOff + 4), ++ba->mail_seq, spinLimit};
+  ba->tm[1] += now_s() - t1;
+  k_resub_devstep_wait<<<nPB + nEB, SOS_RSB, lds, st>>>(dv, ba->d_adHostF.p, ba->d_adTargetF.p, dstep, stepfacD, nPB, g, ba->d_t_pre.p, m);
+  ba->pend.prelaunched = true;
+  const int rc = lin_apply_enqueue(ba, dv, applyRes, true, stepfacD, t0, t1, true);
+  sos_ba::StepPend &pd = ba->pend;
+  pd.prelaunched = true;
+  ba->acc_inflight = cur_inflight; ba->acc_inflight_haveL = cur_haveL; ba->acc_inflight_abs = cur_abs; ba->top_valid = cur_top; ba->J_valid = cur_J;
+  ba->acc_wait_seq = cur_seq;
+  if (rc) {  // (nothing failed that left the waiter without a delivery: hand it x = 0 and drain)
+    pd.active = true;
+    sos_ba_gn_step_deliver(ba, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    return rc;
+  }
+  return SOS_OK;
+}
+// x == NULL: cancel (a failed solve): the waiting step runs with x = 0 -- the state stays where it is -- and is drained
+extern "C" int sos_ba_gn_step_deliver(sos_ba *ba, const double *x, const sos_calib *calib, double *energySum, float *newestEnergies, int *newestCount,
+                                      float *pointStep) {
+  if (!ba || !ba->pend.active || !ba->pend.prelaunched) return SOS_ERR_STATE;
+  if (calib) {
+    ba->calib = *calib;
+    ba->dev.calib = *calib;
+  }
+  const int dim = 4 + 8 * ba->n;
+  char *mail = ba->pin + ba->pin_mail;
+  const size_t flagOff = sizeof(double) * (SOS_CPARS + 8 * 17);
+  double *mx = reinterpret_cast<double *>(mail);
+  static const int testDelayUs = getenv("SOS_PRELAUNCH_TEST_DELAY_US") ? atoi(getenv("SOS_PRELAUNCH_TEST_DELAY_US")) : 0;  // test knob: the step really waits
+  if (testDelayUs > 0) {
+    const double td = now_s();
+    while ((now_s() - td) * 1e6 < testDelayUs) __builtin_ia32_pause();
+  }
+  for (int i = 0; i < dim; i++) mx[i] = x ? x[i] : 0.0;
+  __atomic_store_n(reinterpret_cast<int *>(mail + flagOff), ba->mail_seq, __ATOMIC_RELEASE);
+  sos_ba::StepPend &pd = ba->pend;
+  // the step is running: what sos_ba_gn_step enqueues behind its linearisation follows now -- the next iteration's accumulate when the
+  // caller says there is one (sos_ba_set_prefetch, decided after the solve), otherwise the publish the linearisation left to it.  These
+  // launches overlap the step's kernels.
+  ba->J_valid = !pd.fuseTop;
+  ba->top_valid = pd.fuseTop;
+  ba->acc_inflight = false;
+  if (x && ba->prefetch && pd.applyRes) {
+    if (!pd.waitSeq) hipEventRecord(ba->ev_step, ba->ctx->stream);
+    enqueue_gn_accumulate(ba, pd.fuseTop, pd.chainPublish ? reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags) : nullptr, pd.waitSeq);
+    ba->acc_inflight = true;
+    pd.prefetchEnqueued = true;
+    pd.t3 = now_s();
+  } else if (pd.chainPublish && pd.waitSeq) {
+    k_publish<<<1, 1, 0, ba->ctx->stream>>>(reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags), pd.waitSeq);
+  }
+  int rc = lin_apply_finish(ba, energySum, newestEnergies, newestCount, pointStep);
+  pd.prelaunched = false;
+  if (rc == SOS_OK && __atomic_load_n(reinterpret_cast<int *>(mail + flagOff + 4), __ATOMIC_ACQUIRE) == ba->mail_seq) rc = SOS_ERR_TIMEOUT;  // a workgroup gave up waiting
+  if (!x && rc == SOS_OK) rc = SOS_ERR_STATE;
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------------------

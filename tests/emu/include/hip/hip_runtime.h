@@ -275,8 +275,30 @@ static inline unsigned long long clock64() { return wall_clock64(); }
 #define __HIP_MEMORY_SCOPE_WORKGROUP 2
 #define __HIP_MEMORY_SCOPE_AGENT 3
 #define __HIP_MEMORY_SCOPE_SYSTEM 4
-#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
-#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
+template <class T> static inline T emu_atomic_load(const T *p, int order) {
+  if constexpr (std::is_floating_point<T>::value) {
+    using U = typename std::conditional<sizeof(T) == 4, uint32_t, uint64_t>::type;
+    const U u = __atomic_load_n(reinterpret_cast<const U *>(p), order);
+    T v;
+    memcpy(&v, &u, sizeof(T));
+    return v;
+  } else {
+    return __atomic_load_n(p, order);
+  }
+}
+template <class T, class V> static inline void emu_atomic_store(T *p, V val, int order) {
+  if constexpr (std::is_floating_point<T>::value) {
+    using U = typename std::conditional<sizeof(T) == 4, uint32_t, uint64_t>::type;
+    const T t = (T)val;
+    U u;
+    memcpy(&u, &t, sizeof(T));
+    __atomic_store_n(reinterpret_cast<U *>(p), u, order);
+  } else {
+    __atomic_store_n(p, (T)val, order);
+  }
+}
+#define __hip_atomic_load(p, order, scope) emu_atomic_load((p), (order))
+#define __hip_atomic_store(p, v, order, scope) emu_atomic_store((p), (v), (order))
 #define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), (order))
 
 static inline float atomicAdd(float *p, float v) {

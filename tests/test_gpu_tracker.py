@@ -34,6 +34,7 @@ def rig():
     ref_dI = ow.dI[win.n - 1]
     pc_n = ot.set_ref(calib, ref_dI, c[:, 0], c[:, 1], c[:, 2], hdi)
     ht = host.HostTracker(sysm)
+    ht.set_ref_raw(c[:, 0], c[:, 1], c[:, 2], hdi)   # (every test below may run on its own: xdist, -k)
     new_dI, _ = orc.make_images(win.extra_images[0])
     st_dI, _ = orc.make_images(win.extra_images[1])
     new_slot = sysm.upload_image(win.extra_images[0])
