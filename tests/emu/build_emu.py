@@ -23,7 +23,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "sos_slam_amd", "csrc")
 ASAN = os.environ.get("EMU_ASAN") == "1"   # AddressSanitizer build (run with LD_PRELOAD=<asan_runtime()> ASAN_OPTIONS=detect_leaks=0)
-OUT = os.path.join(HERE, "_build_asan" if ASAN else "_build")
+OUT = os.path.join(HERE, ("_build_asan" if ASAN else "_build") + os.environ.get("EMU_TAG", ""))   # EMU_TAG: a second build beside the first (e.g. EMU_OPT=-O1)
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 sys.path.insert(0, ROOT)
@@ -210,6 +210,23 @@ def build(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
     return hip_lib, host_lib
+
+
+def build_selftest():
+    """tests/emu/selftest/emu_selftest.hip through the same rewrites and run time -> a library of kernels with known answers"""
+    out = os.path.join(OUT, "selftest")
+    os.makedirs(out, exist_ok=True)
+    src = os.path.join(HERE, "selftest", "emu_selftest.hip")
+    gen = os.path.join(out, "emu_selftest.cpp")
+    preprocess(src, gen)
+    lib = os.path.join(out, "libemu_selftest.so")
+    rt = os.path.join(HERE, "emu_runtime.cpp")
+    deps = [gen, rt, os.path.join(HERE, "include", "hip", "hip_runtime.h"), os.path.abspath(__file__)]
+    if _newer(lib, deps):
+        cmd = [CLANG, "-O2", "-g1", "-std=c++17", "-ffp-contract=off", "-fPIC", "-pthread", "-shared", "-Wno-unused-value", "-Wno-unknown-pragmas",
+               "-Wno-pass-failed", "-Wno-unused-function", "-I" + os.path.join(HERE, "include"), gen, rt, "-o", lib, "-ldl"]
+        subprocess.check_call(cmd)
+    return lib
 
 
 if __name__ == "__main__":
