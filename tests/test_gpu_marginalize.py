@@ -26,13 +26,13 @@ def _prep_oracle(win, truth):
     return ow
 
 
-def _yardstick(g, o, t, what):
+def _yardstick(g, o, t, what, fac=2.0):
     """The two fp32 runs (device, reference restatement) end optimize() at states ~1e-6 apart, and b = M_b - M_b,sc
     amplifies that; the bar is the one of tests/test_gpu_optimize.py: the device may be at most twice as far from
     the fp64-accumulated run as the fp32 restatement of the reference is (plus fp32 round-off of the sums)."""
     eg, m = _scaled_err(g, t)
     eo, _ = _scaled_err(o, t)
-    assert eg <= 2.0 * eo + 1e-5 * m, (what, eg, eo, m)
+    assert eg <= fac * eo + 1e-5 * m, (what, eg, eo, m)
     assert eg < 2e-2 * m, (what, eg, m)
 
 
