@@ -1790,10 +1790,13 @@ int FullSystem::dropPoints(const std::vector<PointHessian *> &pts) {
 
 int FullSystem::marginalizeFrame(FrameHessian *frame) {  // FS/FullSystemMarginalize.cpp:143-236 (backend part)
   if (!frame->pointHessians.empty()) return SOS_ERR_STATE;
+  const bool tmg = getenv("SOS_TIMING") != nullptr;
+  const double tm0 = now_s();
   {
     const int rc = ef->marginalizeFrame(frame->efFrame);
     if (rc != SOS_OK) { isLost = true; return lastError = rc; }
   }
+  const double tm1 = now_s();
   // drop all observations of existing points in that frame (:148-176)
   for (FrameHessian *fh : frameHessians) {
     if (fh == frame) continue;
@@ -1811,6 +1814,7 @@ int FullSystem::marginalizeFrame(FrameHessian *frame) {  // FS/FullSystemMargina
         }
       }
   }
+  const double tm2 = now_s();
   sos_frame_release(ctx, frame->slot);
   slotUsed[frame->slot] = false;
   for (size_t i = 0; i < frameHessians.size(); i++)
@@ -1825,9 +1829,12 @@ int FullSystem::marginalizeFrame(FrameHessian *frame) {  // FS/FullSystemMargina
   for (PointHessian *ph : frame->pointHessiansOut)
     if (ph->userIdx >= 0 && ph->userIdx < (int)userPoints.size()) userPoints[ph->userIdx] = nullptr;
   delete frame;  // (the reference hands it to LoopHandler instead, src/LoopClosure/LoopHandler.cpp:249)
+  const double tm3 = now_s();
   setPrecalcValues();
   ef->setAdjointsF(&HCalib);
   ef->setDeltaF(&HCalib);
+  if (tmg) fprintf(stderr, "[marginalizeFrame] prior algebra %.0f us, residual drop walk %.0f us, release + delete frame %.0f us, precalc / adjoints / deltas %.0f us\n",
+                   (tm1 - tm0) * 1e6, (tm2 - tm1) * 1e6, (tm3 - tm2) * 1e6, (now_s() - tm3) * 1e6);
   return SOS_OK;
 }
 
