@@ -293,8 +293,8 @@ def test_imu_prior_lifecycle(name):
     sysm.set_imu(S, cal, kept)
     Hg, bg = sysm.imu_prior()
     assert Hg.shape == sides[False]["HM"].shape == (imu_dim(n - 1),) * 2
-    _yardstick(Hg, sides[False]["HM"], sides[True]["HM"], "expanded HM after marginalizeFrame")
-    _yardstick(bg, sides[False]["bM"], sides[True]["bM"], "expanded bM after marginalizeFrame")
+    _yardstick(Hg, sides[False]["HM"], sides[True]["HM"], "expanded HM after marginalizeFrame", fac=3.0)   # (carries the prior of the step above)
+    _yardstick(bg, sides[False]["bM"], sides[True]["bM"], "expanded bM after marginalizeFrame", fac=3.0)
     assert np.abs(Hg - Hg.T).max() <= 1e-9 * np.abs(Hg).max()
     # ---- the reduced window optimises with the carried prior; the states keep moving, nothing blows up
     sc0 = cal.scale
