@@ -198,7 +198,9 @@ def build(force=False, verbose=False):
             objs.append(o)
         if any(j.wait() != 0 for j in jobs):
             raise SystemExit("tests/emu: compilation failed")
-        cmd = [CLANG, "-shared", "-pthread", "-o", hip_lib] + objs + ["-ldl"] + (["-fsanitize=address", "-shared-libasan"] if ASAN else [])
+        # -Bsymbolic: the library's calls of hipMalloc / hipMemcpyAsync / ... bind to ITS definitions, also in a process that has the real
+        # HIP run time loaded (the CPU suite loads the product library for its ABI checks)
+        cmd = [CLANG, "-shared", "-pthread", "-Wl,-Bsymbolic", "-o", hip_lib] + objs + ["-ldl"] + (["-fsanitize=address", "-shared-libasan"] if ASAN else [])
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
@@ -224,7 +226,7 @@ def build_selftest():
     deps = [gen, rt, os.path.join(HERE, "include", "hip", "hip_runtime.h"), os.path.abspath(__file__)]
     if _newer(lib, deps):
         cmd = [CLANG, "-O2", "-g1", "-std=c++17", "-ffp-contract=off", "-fPIC", "-pthread", "-shared", "-Wno-unused-value", "-Wno-unknown-pragmas",
-               "-Wno-pass-failed", "-Wno-unused-function", "-I" + os.path.join(HERE, "include"), gen, rt, "-o", lib, "-ldl"]
+               "-Wno-pass-failed", "-Wno-unused-function", "-Wl,-Bsymbolic", "-I" + os.path.join(HERE, "include"), gen, rt, "-o", lib, "-ldl"]
         subprocess.check_call(cmd)
     return lib
 

@@ -80,6 +80,13 @@ def test_switches(modeA, modeB, huber, outlier):
     ({"SOS_ABS_SC": "1", "SOS_ABS_SIGNAL_IN_KERNEL": "1"}, "tests/test_golden_t6.py"),
     # ... with its three launches as ONE cooperative launch (device-wide barriers with bounded waits, csrc/sos_ba.hip: k_abs_coop)
     ({"SOS_ABS_SC": "1", "SOS_ABS_COOP": "1"}, "tests/test_gpu_edge_windows.py -k T6"),
+    # the step's launches enqueued before the solve, x through a mapped mailbox (sos_ba_gn_step_prelaunch / _deliver); with a delayed delivery
+    # the device really waits
+    ({"SOS_PRELAUNCH_STEP": "1"}, "tests/test_gpu_optimize.py -k T6"),
+    ({"SOS_PRELAUNCH_STEP": "1", "SOS_PRELAUNCH_TEST_DELAY_US": "2000"}, "tests/test_golden_t6.py"),
+    # host-side orders kept as knobs: eager per-point mirrors, IMU first half behind the accumulate's enqueue
+    ({"SOS_EAGER_POINT_MIRRORS": "1"}, "tests/test_golden_t6.py"),
+    ({"SOS_IMU_OVERLAP": "1"}, "tests/test_gpu_imu_hook.py -k T6"),
 ])
 def test_launch_variants_keep_parity(env, target):
     """Launch-shape choices the library makes per window (read once per process from the environment when forced) must
