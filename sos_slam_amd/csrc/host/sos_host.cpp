@@ -1361,6 +1361,7 @@ host_path:
       const float *st = ef->pointStep.data(), *bk = flatBackup.data();
       float *id = flatIdepth.data();
       for (size_t k = 0; k < P; k++) id[k] = bk[k] + 1.0f * st[k];
+      flatStepped = true;
     } else {
       for (size_t k = 0; k < ef->allPoints.size(); k++) {
         PointHessian *ph = ef->allPoints[k]->data;
@@ -1527,11 +1528,13 @@ bool FullSystem::beginLazyPointMirrors() {
     }
   if (flatOrder.size() != P) return false;
   pointMirrorsStale = true;
+  flatStepped = false;
   return true;
 }
 void FullSystem::flushPointMirrors() {
   if (!pointMirrorsStale) return;
   pointMirrorsStale = false;
+  if (!flatStepped) return;  // no step was taken on the flat copies (a failed solve): the objects are what they were
   const size_t P = std::min(flatIdepth.size(), ef->allPoints.size());
   const bool haveBackup = flatBackup.size() == flatIdepth.size(), haveStep = ef->pointStep.size() >= P;
   for (size_t k = 0; k < P; k++) {

@@ -287,7 +287,7 @@ class FullSystem {
   // doStepFromBackup (FS/FullSystemOptimize.cpp:207-213) and of backupState (:260-269) runs on flat arrays in snapshot order -- same
   // float operations in the same order -- and the PointHessian objects are brought up to date once, by flushPointMirrors(), before
   // anything reads them (it is called wherever residentFlush() is, and by every member that reads or writes the mirrors).
-  bool inOptimizeLoop = false, pointMirrorsStale = false;
+  bool inOptimizeLoop = false, pointMirrorsStale = false, flatStepped = false;
   std::vector<float> flatIdepth, flatBackup;
   std::vector<int> flatOrder;  // snapshot index of the j-th point in the order frames -> pointHessians (the reference's summation order)
   bool beginLazyPointMirrors();
