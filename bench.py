@@ -420,6 +420,7 @@ VARIANTS = (
     ("abs_schur_cooperative", {"SOS_ABS_SC": "1", "SOS_ABS_COOP": "1"}, []),        # ... and its three launches as ONE with device-wide barriers
     ("prelaunched_step", {"SOS_PRELAUNCH_STEP": "1"}, []),                            # the step's launches enqueued before the solve, x through a mapped mailbox
     ("prelaunched_step_abs_cooperative", {"SOS_PRELAUNCH_STEP": "1", "SOS_ABS_SC": "1", "SOS_ABS_COOP": "1"}, []),
+    ("stitch_signal_in_kernel", {"SOS_STITCH_SIGNAL_IN_KERNEL": "1"}, []),          # only the stitch's last kernel raises the host flag itself (no k_publish)
     ("signal_in_kernel", {"SOS_SIGNAL_IN_KERNEL": "1"}, []),                          # completion flags stored by the last block instead of k_publish
     ("eager_point_mirrors", {"SOS_EAGER_POINT_MIRRORS": "1"}, []),                    # the per-point host loop of every iteration as before round 4
     ("resident", {}, ["--resident"]),                                                 # solve on the device (k_gn_solve)

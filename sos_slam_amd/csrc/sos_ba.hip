@@ -3994,7 +3994,9 @@ static int launch_stitch(sos_ba *ba, const float *acc, int nmodes, double *Hout 
   a.upperOnly = Hout ? 1 : 0;
   a.sg = {nullptr, nullptr, 0, 0};
   const int nb2 = (n * (n + 1) / 2 + 1) * nmodes + n * n + 1;
-  static const bool inKernel = getenv("SOS_SIGNAL_IN_KERNEL") != nullptr;
+  // (SOS_STITCH_SIGNAL_IN_KERNEL: only this chain's last kernel signals by itself -- ~160 blocks with one system fence each against the
+  // 4 us one-thread k_publish behind it; the linearisation keeps its chained publish, whose in-kernel form was measured slower)
+  static const bool inKernel = getenv("SOS_SIGNAL_IN_KERNEL") != nullptr || getenv("SOS_STITCH_SIGNAL_IN_KERNEL") != nullptr;
   if (toDevice) {  // the device-resident loop: upper triangles + counts into d_Hout, nobody polls
     a.H = ba->d_Hout.p;
     a.nres_out = reinterpret_cast<float *>(ba->d_Hout.p + 3 * ba->hb_mode_stride);

@@ -87,6 +87,7 @@ def test_switches(modeA, modeB, huber, outlier):
     # host-side orders kept as knobs: eager per-point mirrors, IMU first half behind the accumulate's enqueue
     ({"SOS_EAGER_POINT_MIRRORS": "1"}, "tests/test_golden_t6.py"),
     ({"SOS_IMU_OVERLAP": "1"}, "tests/test_gpu_imu_hook.py -k T6"),
+    ({"SOS_STITCH_SIGNAL_IN_KERNEL": "1"}, "tests/test_golden_t6.py"),    # the stitch's last kernel raises the host flag itself
 ])
 def test_launch_variants_keep_parity(env, target):
     """Launch-shape choices the library makes per window (read once per process from the environment when forced) must
