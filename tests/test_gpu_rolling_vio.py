@@ -63,6 +63,9 @@ def test_rolling_window_visual_inertial(geom):
     worst = dict(pose=0.0, scale=0.0, state=0.0, vel=0.0, leave=0.0, leave_noise=0.0)
     left = its_diff = 0
     trap_apart = None
+    from sos_slam_amd import host as _host
+    _host.imu().solve_stats(reset=True)
+    trapped_kfs = 0
     while dev.next_frame < sc.n_frames:
         lg, lo, lt = dev.step(), orc_.step(), tru.step()
         k = lg.frameID
@@ -81,6 +84,7 @@ def test_rolling_window_visual_inertial(geom):
             trap_apart = (k, abs(vg["scale"] - vo["scale"]) * 200)
             break
         its_diff += int(lg.iterations != lo.iterations)
+        trapped_kfs += int(vg["trapped"])
         for fid in lg.window_ids:
             run["pose"] = max(run["pose"], np.abs(lo.window_poses[fid] - lt.window_poses[fid]).max())
         for fid in lg.window_ids:
@@ -130,6 +134,12 @@ def test_rolling_window_visual_inertial(geom):
     for kind, val, tol, what in deferred:
         check(val < max(tol, FACTOR * run[kind]), what + (run[kind],))
     print("violations:", bad)
+    # once the scale is trapped the facade's loop solves on the kept factor (sosf_imu_solve_prepare / _finish: first-estimate Jacobians,
+    # OB/EnergyFunctional.cpp:1053-1171 with everything but the visual block constant): the form the solves of this chain actually took
+    kept, rebuilt, literal = _host.imu().solve_stats()
+    print(f"IMU solves of the device chain: {kept} on a kept factor, {rebuilt} factor rebuilds, {literal} literal")
+    if trapped_kfs >= 2:
+        assert kept > 0 and rebuilt >= 1, (kept, rebuilt, literal, trapped_kfs)
     dev.close()
     assert not bad, bad
     assert its_diff <= 2, its_diff
