@@ -808,8 +808,8 @@ class DeviceChain(Chain):
 
 class CppDeviceChain(DeviceChain):
     """The device chain with the frame-rate loop in C++ (sosf_sequence, csrc/host/sos_sequence.cpp): this class only feeds frames and
-    fills the KeyframeLog from the sequence's results and snapshots.  PENDING_FIRST_GPU_RUN (written in round 3 without GPU access):
-    opt-in through device_chain() with SOS_ROLLING_CPP=1 until it has run."""
+    fills the KeyframeLog from the sequence's results and snapshots.  Written in round 3 without GPU access, run under tests/emu in round
+    4; device_chain() picks it for the visual chains."""
 
     def bootstrap(self):
         from sos_slam_amd.records import SequenceParams
@@ -917,9 +917,14 @@ class CppDeviceChain(DeviceChain):
 
 
 def device_chain(sc):
-    """the device chain of the rolling tests: the Python loop over the facade's stages, or (SOS_ROLLING_CPP=1) the C++ loop"""
+    """the device chain of the rolling tests.  Visual chains: the frame-rate loop in C++ (sosf_sequence) -- what a SOS-SLAM maintainer would
+    run -- is what the oracle chain is compared with; visual-inertial chains: still the Python loop over the facade's stages (the C++ loop
+    passes the same tests under tests/emu except the stereo-inertial prior yardstick at one keyframe; it becomes the default there once it
+    has run on an MI355X).  SOS_ROLLING_CPP=1 / 0 forces the C++ / the Python loop for every chain."""
     import os
-    return CppDeviceChain(sc) if os.environ.get("SOS_ROLLING_CPP") == "1" else DeviceChain(sc)
+    v = os.environ.get("SOS_ROLLING_CPP")
+    use_cpp = (v == "1") or (v is None and not sc.vio)
+    return CppDeviceChain(sc) if use_cpp else DeviceChain(sc)
 
 
 # ------------------------------------------------------------------------------------------------
