@@ -332,6 +332,7 @@ def main():
             "imu": bool(args.imu),
             "last_step_l2": float(np.linalg.norm(last_x)), "last_step_head": [float(v) for v in last_x[:6]],
             "exchange_allreduce_us": exchange_us,
+            "exchange": exchange_info(sysm, win, world),
             "linearize_point_residuals_per_s": R_local / (lin_ms * 1e-3),
             "kernels_us": dict(linearize_us=round(lin_ms * 1e3, 2), **kern),
             "host_phases_us": {k: round(v / iters * 1e6, 1) for k, v in zip(
@@ -712,6 +713,24 @@ def tracker_timing(window, device):
            "optimize_scale_ms": timeit(lambda: ht.optimize_scale(st_slot, win.stereo_tfm, K1, 1.2, levels - 1))}
     sysm.close()
     return out
+
+
+def exchange_info(sysm, win, world):
+    """which per-iteration exchange the ranks run and how many bytes it moves (N > 1; null at N = 1)"""
+    if world <= 1:
+        return None
+    import ctypes as C
+    from sos_slam_amd import lib
+    dim = 4 + 8 * win.n
+    if os.environ.get("SOS_ABS_SC") and not os.environ.get("SOS_NO_ABS_SC"):
+        return {"kind": "all-reduce of the stitched fp64 system [H_A b_A | H_sc b_sc | count] (absolute-coordinate path)", "bytes": 8 * (2 * (dim * dim + dim) + 1)}
+    dev, nfl = C.c_void_p(), C.c_size_t(0)
+    try:
+        lib.load().sos_ba_acc_buffer(L_host_ba(sysm), C.byref(dev), C.byref(nfl))
+    except Exception:  # noqa: BLE001
+        return {"kind": "all-reduce of the packed fp32 accumulator", "bytes": None}
+    return {"kind": "all-reduce of the packed fp32 accumulator [top_A | top_L | accD | accE | accEB | Hcc | bc | counts] + all-gather of the newest-frame energies",
+            "bytes": 4 * int(nfl.value)}
 
 
 def pmc_traffic(window):
