@@ -88,12 +88,27 @@ FrameHessian::FrameHessian() {
   for (int i = 0; i < 10; i++) state_zero[i] = state_scaled[i] = state[i] = step[i] = state_backup[i] = 0;
 }
 FrameHessian::~FrameHessian() {
+  for (PointFrameResidual *r : targetedBy) r->idxInTarget = -1;  // (they outlive this frame in the containers of removed points of other frames)
+  targetedBy.clear();
   for (PointHessian *p : pointHessians) delete p;
   for (PointHessian *p : pointHessiansMarginalized) delete p;
   for (PointHessian *p : pointHessiansOut) delete p;
 }
 PointHessian::~PointHessian() {
   for (PointFrameResidual *r : residuals) delete r;
+}
+void PointFrameResidual::registerTarget() {
+  if (!target || idxInTarget >= 0) return;
+  idxInTarget = (int)target->targetedBy.size();
+  target->targetedBy.push_back(this);
+}
+PointFrameResidual::~PointFrameResidual() {
+  if (target && idxInTarget >= 0) {
+    std::vector<PointFrameResidual *> &v = target->targetedBy;
+    v[idxInTarget] = v.back();
+    v[idxInTarget]->idxInTarget = idxInTarget;
+    v.pop_back();
+  }
 }
 static int g_evalCounter = 0;  // unique id of every evalPT ever set: keys the cached FEJ products
 void FrameHessian::setState(const double *s) {  // FS/HessianBlocks.h:217-230
@@ -272,7 +287,8 @@ EFResidual *EnergyFunctional::insertResidual(PointFrameResidual *r) {  // OB/Ene
   efr->idxInAll = (int)r->point->efPoint->residualsAll.size();
   r->point->efPoint->residualsAll.push_back(efr);
   efr->connKey = (((uint64_t)efr->host->frameID) << 32) + ((uint64_t)efr->target->frameID);
-  connectivityMap[efr->connKey].first++;
+  efr->connEntry = &connectivityMap[efr->connKey];  // (node addresses of a std::map are stable and entries are never erased)
+  efr->connEntry->first++;
   nResiduals++;
   r->efResidual = efr;
   packDirty = structDirty = true;
@@ -334,7 +350,7 @@ void EnergyFunctional::dropResidual(EFResidual *r) {  // :710-728
   p->residualsAll[r->idxInAll]->idxInAll = r->idxInAll;
   p->residualsAll.pop_back();
   // (the reference reads r->target->frameID here, also when marginalizeFrame has just deleted that EFFrame: FS/FullSystemMarginalize.cpp:146-176)
-  connectivityMap[r->connKey].first--;
+  r->connEntry->first--;
   nResiduals--;
   r->data->efResidual = nullptr;
   if (r->data->packIdx >= 0) droppedSincePack.push_back(r->data->packIdx);  // the device snapshot still holds it (sos_ba_kill_residuals)
@@ -990,6 +1006,7 @@ PointFrameResidual *FullSystem::addResidual(PointHessian *ph, FrameHessian *targ
   r->point = ph;
   r->host = ph->host;
   r->target = target;
+  r->registerTarget();
   r->state_state = (ResState)q.state_state;
   r->state_energy = q.state_energy;
   r->isNew = (q.flags & SOS_RF_ISNEW) != 0;
@@ -1800,22 +1817,25 @@ int FullSystem::marginalizeFrame(FrameHessian *frame) {  // FS/FullSystemMargina
     if (rc != SOS_OK) { isLost = true; return lastError = rc; }
   }
   const double tm1 = now_s();
-  // drop all observations of existing points in that frame (:148-176)
-  for (FrameHessian *fh : frameHessians) {
-    if (fh == frame) continue;
-    for (PointHessian *ph : fh->pointHessians)
-      for (unsigned i = 0; i < ph->residuals.size(); i++) {
-        PointFrameResidual *r = ph->residuals[i];
-        if (r->target == frame) {
-          if (ph->lastResiduals[0].first == r) ph->lastResiduals[0].first = nullptr;
-          else if (ph->lastResiduals[1].first == r) ph->lastResiduals[1].first = nullptr;
-          ef->dropResidual(r->efResidual);
+  // drop all observations of existing points in that frame (:148-176): the residuals registered with it whose point is still active (a
+  // removed point's residuals have lost their EFResidual and stay with the point until it is deleted).  Every point has at most one
+  // residual per target, so the order of the drops does not matter to any container.
+  {
+    const std::vector<PointFrameResidual *> obs(frame->targetedBy);
+    for (PointFrameResidual *r : obs) {
+      if (!r->efResidual) continue;
+      PointHessian *ph = r->point;
+      if (ph->lastResiduals[0].first == r) ph->lastResiduals[0].first = nullptr;
+      else if (ph->lastResiduals[1].first == r) ph->lastResiduals[1].first = nullptr;
+      ef->dropResidual(r->efResidual);
+      for (unsigned i = 0; i < ph->residuals.size(); i++)
+        if (ph->residuals[i] == r) {
           ph->residuals[i] = ph->residuals.back();
           ph->residuals.pop_back();
-          delete r;
           break;
         }
-      }
+      delete r;
+    }
   }
   const double tm2 = now_s();
   sos_frame_release(ctx, frame->slot);
@@ -1920,6 +1940,7 @@ int FullSystem::addResidualsToNewestFrame() {
     for (PointHessian *ph : fh1->pointHessians) {
       PointFrameResidual *r = new PointFrameResidual();
       r->point = ph; r->host = fh1; r->target = fh;
+      r->registerTarget();
       r->state_state = IN;                      // r->setState(ResState::IN)
       ph->residuals.push_back(r);
       ef->insertResidual(r);
@@ -1952,6 +1973,7 @@ PointHessian *FullSystem::addActivatedPoint(const sos_point &p, uint32_t inMask)
     if (!((inMask >> t) & 1u) || frameHessians[t] == ph->host) continue;
     PointFrameResidual *r = new PointFrameResidual();
     r->point = ph; r->host = ph->host; r->target = frameHessians[t];
+    r->registerTarget();
     r->state_NewEnergy = r->state_energy = 0;
     r->state_NewState = OUTLIER;
     r->state_state = IN;

@@ -77,6 +77,9 @@ struct FrameHessian {
   bool flaggedForMarginalization = false;
   int numImmature = 0;  // immaturePoints.size(): the immature points live with the caller (records of sos_immature)
   std::vector<PointHessian *> pointHessians, pointHessiansMarginalized, pointHessiansOut;
+  // the residuals that observe a point IN this frame (target == this): marginalizeFrame drops exactly these (FS/FullSystemMarginalize.cpp:148-176)
+  // without walking every point of the window.  Kept by PointFrameResidual::registerTarget / its destructor.
+  std::vector<PointFrameResidual *> targetedBy;
   SE3 camToWorld_evalPT;
   SE3 worldToCam_evalPT;  // cached inverse
   int evalVersion = 0;    // bumped by setEvalPT
@@ -124,6 +127,9 @@ struct PointFrameResidual {  // FS/Residuals.h:49-93
   bool isNew = true;
   float centerProjectedTo[3] = {0, 0, 0};
   int packIdx = -1;
+  int idxInTarget = -1;  // position in target->targetedBy (-1: not registered, or the target frame is gone)
+  void registerTarget();
+  ~PointFrameResidual();
   void resetOOB() {
     state_NewEnergy = state_energy = 0;
     state_NewState = OUTLIER;
@@ -138,6 +144,7 @@ struct EFResidual {  // OB/EnergyFunctionalStructs.h:43-81
   EFFrame *host, *target;
   int idxInAll = 0;
   uint64_t connKey = 0;  // (host frameID << 32) + target frameID, kept here: the target's EFFrame may be gone when the residual is dropped
+  std::pair<int, int> *connEntry = nullptr;  // connectivityMap[connKey], looked up once at insertion
   bool isLinearized = false;
   bool isActiveAndIsGoodNEW = false;
   bool isActive() const { return isActiveAndIsGoodNEW; }
