@@ -14,7 +14,8 @@
 // (:800-807, 841-849, 878-903; FS/FullSystemOptimize.cpp:437-479) are strung in behind sosf_sequence_enable_imu / _enable_stereo and
 // sosf_add_active_frame_ex.  Out of scope: the initialiser (CoarseInitializer) -- the first window is handed over (sosf_sequence_bootstrap).
 //
-// PENDING_FIRST_GPU_RUN: written while GPU access was withdrawn (round 3); tests/test_gpu_sequence_driver.py is its acceptance test.
+// PENDING_FIRST_GPU_RUN: written while GPU access was withdrawn (round 3); tests/test_gpu_sequence_driver.py is its acceptance test (green under tests/emu
+// in round 4, where it also drives the visual rolling-window tests).
 #include <algorithm>
 #include <cmath>
 #include <cstring>

@@ -4086,7 +4086,8 @@ extern "C" int sos_ba_accumulate(sos_ba *ba, double *H_A, double *b_A, double *H
 // straight into the device-mapped pinned block: no copy command between the last kernel and the host
 // the absolute-coordinate Schur path (k_sc_gram_abs): windows without linearised residuals on any rank
 static bool abs_path_ok(const sos_ba *ba) {
-  // PENDING_FIRST_GPU_RUN: opt-in (SOS_ABS_SC=1) until the GPU suite has run on it
+  // PENDING_FIRST_GPU_RUN: opt-in (SOS_ABS_SC=1) until the GPU suite has run on it (executed under tests/emu in round 4: at par with the reference's fp32
+  // arithmetic from T6 up, 3.2x further from the fp64 step at T4)
   static const bool off = getenv("SOS_ABS_SC") == nullptr || getenv("SOS_NO_ABS_SC") != nullptr;
   return !off && ba->ntiles == ba->ntilesA && ba->ntilesA > 0 && ba->nchunks > 0 && !(ba->comm && (ba->anyL || ba->anyEmpty)) && ba->d_adHostF.p &&
          ba->d_adTargetF.p;
@@ -4193,7 +4194,7 @@ static int enqueue_gn_accumulate(sos_ba *ba, bool topDone = false, int *pubFlag 
 
 // The enqueue half of sos_ba_gn_accumulate on its own: nothing is waited for.  A caller with host work that does not depend on H / b
 // (the IMU factors of the visual-inertial solve) calls this first, so that the work overlaps the accumulation also when no
-// sos_ba_gn_step prefetched it.  PENDING_FIRST_GPU_RUN (round 3, written without GPU access).
+// sos_ba_gn_step prefetched it.  PENDING_FIRST_GPU_RUN (round 3, written without GPU access; executed under tests/emu in round 4; used with SOS_IMU_OVERLAP=1).
 extern "C" int sos_ba_gn_accumulate_begin(sos_ba *ba) {
   if (!ba || !ba->have_window || !ba->have_state) return SOS_ERR_STATE;
   SOS_HIP(hipSetDevice(ba->ctx->device));

@@ -581,7 +581,7 @@ __device__ __forceinline__ void res_pixel(const ResArgs &a, int i, float x, floa
         const float hw = fabsf(residual) < a.huber ? 1 : a.huber / fabsf(residual);
         // (written as selects: with `v[3] = 1` in one branch and `v[2] = 1` in the other the compiler merged the two stores into ONE
         // store through a run-time index, which put v[2..3] into scratch memory -- a store / load round trip in every pixel's chain)
-        // PENDING_FIRST_GPU_RUN: compile-verified (ScratchSize 16 -> 0), arithmetic unchanged by construction
+        // PENDING_FIRST_GPU_RUN: compile-verified (ScratchSize 16 -> 0); executed under tests/emu in round 4 (tracker tests bit-exact against the oracle)
         const bool sat = fabsf(residual) > a.cutoff;
         v[0] = sat ? a.maxEnergy : hw * residual * residual * (2 - hw);
         v[1] = 1.f;
