@@ -376,13 +376,9 @@ void EnergyFunctional::makeIDX() {  // :1186-1202
   for (size_t i = 0; i < frames.size(); i++) frames[i]->idx = (int)i;
   allPoints.clear();
   for (EFFrame *f : frames)
-    for (EFPoint *p : f->points) {
-      allPoints.push_back(p);
-      for (EFResidual *r : p->residualsAll) {
-        r->hostIDX = r->host->idx;
-        r->targetIDX = r->target->idx;
-      }
-    }
+    for (EFPoint *p : f->points) allPoints.push_back(p);
+  // (r->hostIDX / r->targetIDX of the reference are only read when the window is packed: packWindow takes them from the frames there,
+  // instead of every makeIDX -- insertFrame, dropPointsF, marginalizePointsF, marginalizeFrame: four walks over all residuals per keyframe)
   EFIndicesValid = true;
 }
 
@@ -450,8 +446,8 @@ int EnergyFunctional::packWindow(std::vector<PointFrameResidual *> *active) {
     for (EFResidual *r : p->residualsAll) {
       sos_resid q;
       q.point = (int)k;
-      q.host = r->hostIDX;
-      q.target = r->targetIDX;
+      q.host = r->hostIDX = r->host->idx;
+      q.target = r->targetIDX = r->target->idx;
       q.flags = (r->isActive() ? SOS_RF_ACTIVE : 0u) | (r->isLinearized ? SOS_RF_LINEARIZED : 0u) | (r->data->isNew ? SOS_RF_ISNEW : 0u);
       q.state_state = (int)r->data->state_state;
       q.state_energy = (float)r->data->state_energy;
