@@ -425,6 +425,7 @@ VARIANTS = (
     ("prelaunched_step_abs_cooperative", {"SOS_PRELAUNCH_STEP": "1", "SOS_ABS_SC": "1", "SOS_ABS_COOP": "1"}, []),
     ("stitch_signal_in_kernel", {"SOS_STITCH_SIGNAL_IN_KERNEL": "1"}, []),          # only the stitch's last kernel raises the host flag itself (no k_publish)
     ("signal_in_kernel", {"SOS_SIGNAL_IN_KERNEL": "1"}, []),                          # completion flags stored by the last block instead of k_publish
+    ("lin_one_tile_blocks", {"SOS_LIN_ND": "0"}, []),                                 # k_linearize2 with every block owning one tile (2x the blocks in flight)
     ("eager_point_mirrors", {"SOS_EAGER_POINT_MIRRORS": "1"}, []),                    # the per-point host loop of every iteration as before round 4
     ("resident", {}, ["--resident"]),                                                 # solve on the device (k_gn_solve)
 )
