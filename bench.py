@@ -381,16 +381,19 @@ def main():
             out["visual_inertial"] = side_process("imu", args.window)
             # (opt-in order of the IMU branch: first half of the solve behind the enqueue of the accumulation, csrc/host/sos_host.cpp)
             out["visual_inertial_overlap"] = side_process("imu", args.window, env={"SOS_IMU_OVERLAP": "1"})
-            try:
-                out["variants"] = variant_timing(args.window)
-            except Exception as e:  # noqa: BLE001
-                out["variants"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             out["tracker"] = tracker_timing(args.window, local_rank)
             out["cpu_baseline"] = cpu_baseline(win, args.cpu_seconds)
             out["speedup_vs_cpu_gn_iter"] = out["gn_iter_per_s"] / out["cpu_baseline"]["gn_iter_per_s"]
             # (the thread scaling of the CPU port swings by 1.5x between boxes of the pool: the 1-thread figure is the stable denominator)
             out["speedup_vs_cpu_gn_iter_1thread"] = out["gn_iter_per_s"] / out["cpu_baseline"]["gn_iter_per_s_1thread"]
+        if world == 1 and not args.imu and not args.no_sides:
+            # last: code paths the build has not seen on an MI355X yet -- whatever one of them does to the device, this process's own
+            # measurements are complete by now
+            try:
+                out["variants"] = variant_timing(args.window)
+            except Exception as e:  # noqa: BLE001
+                out["variants"] = {"error": repr(e)}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
@@ -416,25 +419,31 @@ def side_process(what, window, timeout=240, env=None):
 
 # Opt-in paths that have not been measured on an MI355X from inside the build (GPU access was closed during rounds 3-4): the same loop
 # under each switch, in a process of its own, reported BESIDE the headline -- never instead of it.  `last_step_l2` / `resInA` show that
-# a variant computed the same iteration (the absolute-coordinate path differs in the last digits by design).
+# a variant computed the same iteration (the absolute-coordinate path differs in the last digits by design).  Order: the switches
+# that only change plain launches first; the ones whose kernels WAIT on the device (grid barriers, the mailbox of the pre-launched step --
+# bounded spins, csrc/sos_ba.hip) last, and all of them after every measurement this process takes itself (main()).
 VARIANTS = (
     ("abs_schur", {"SOS_ABS_SC": "1"}, []),                                         # one Gram per chunk instead of the n^3 relative blocks + 2-stage stitch
     ("abs_schur_signal_in_kernel", {"SOS_ABS_SC": "1", "SOS_ABS_SIGNAL_IN_KERNEL": "1"}, []),
-    ("abs_schur_cooperative", {"SOS_ABS_SC": "1", "SOS_ABS_COOP": "1"}, []),        # ... and its three launches as ONE with device-wide barriers
-    ("prelaunched_step", {"SOS_PRELAUNCH_STEP": "1"}, []),                            # the step's launches enqueued before the solve, x through a mapped mailbox
-    ("prelaunched_step_abs_cooperative", {"SOS_PRELAUNCH_STEP": "1", "SOS_ABS_SC": "1", "SOS_ABS_COOP": "1"}, []),
     ("stitch_signal_in_kernel", {"SOS_STITCH_SIGNAL_IN_KERNEL": "1"}, []),          # only the stitch's last kernel raises the host flag itself (no k_publish)
     ("signal_in_kernel", {"SOS_SIGNAL_IN_KERNEL": "1"}, []),                          # completion flags stored by the last block instead of k_publish
     ("lin_one_tile_blocks", {"SOS_LIN_ND": "0"}, []),                                 # k_linearize2 with every block owning one tile (2x the blocks in flight)
     ("eager_point_mirrors", {"SOS_EAGER_POINT_MIRRORS": "1"}, []),                    # the per-point host loop of every iteration as before round 4
     ("resident", {}, ["--resident"]),                                                 # solve on the device (k_gn_solve)
+    ("abs_schur_cooperative", {"SOS_ABS_SC": "1", "SOS_ABS_COOP": "1"}, []),        # ... and its three launches as ONE with device-wide barriers
+    ("prelaunched_step", {"SOS_PRELAUNCH_STEP": "1"}, []),                            # the step's launches enqueued before the solve, x through a mapped mailbox
+    ("prelaunched_step_abs_cooperative", {"SOS_PRELAUNCH_STEP": "1", "SOS_ABS_SC": "1", "SOS_ABS_COOP": "1"}, []),
 )
 
 
-def variant_timing(window, timeout=150):
+def variant_timing(window, timeout=90, budget=300.0):
     import subprocess
     out = {}
+    t_begin = time.perf_counter()
     for name, env, extra in VARIANTS:
+        if time.perf_counter() - t_begin > budget:   # the default run has to end within minutes whatever a variant does
+            out[name] = {"error": "skipped: the variants' time budget of %.0f s was spent" % budget}
+            continue
         e = dict(os.environ)
         e.update(env)
         cmd = [sys.executable, os.path.abspath(__file__), "--window", window, "--steps", "20", "--warmup", "3", "--inner", "100",
