@@ -51,6 +51,13 @@ def pytest_report_header(config):
 
 def pytest_collection_modifyitems(config, items):
     if _have_gpu():
+        # on the GPU box the whole suite takes minutes (GPUTEST_r02: 206 s for 181 tests): a test that sits for a quarter of an hour is hung,
+        # and ending the session (with the stacks of all threads) is better than sitting out the lease.  Every wait of the library is
+        # bounded on its own (host flags 30 s, device spins by count); this is the belt over those braces.
+        if config.pluginmanager.hasplugin("timeout"):
+            for item in items:
+                if "gpu" in item.keywords and item.get_closest_marker("timeout") is None:
+                    item.add_marker(pytest.mark.timeout(900, method="thread"))
         return
     if _emulated():
         skip = pytest.mark.skip(reason="needs a real device (torch.cuda / RCCL / full-size timing), not the emulator")
