@@ -30,3 +30,20 @@ def test_gpu_parity_slice_under_emulation(target):
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], r.stdout[-500:]
+
+
+@pytest.mark.skipif(_have_gpu() or not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="a GPU is visible (the driver runs smoke() there) or no host clang++")
+def test_graft_entry_smoke_under_emulation():
+    """__graft_entry__.smoke() -- what the driver runs on the MI355X before the bench -- with the two library paths pointed at the emulation:
+    its asserts against the oracle hold for the sources as they are now."""
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import build_emu\n"
+            "from sos_slam_amd import build as _b\n"
+            "_b.HIP_LIB, _b.HOST_LIB = build_emu.build()\n"
+            "_b.build_all = lambda *a, **k: (_b.HIP_LIB, _b.HOST_LIB)\n"
+            "import __graft_entry__ as g\n"
+            "g.smoke()\n"
+            "print('EMU_SMOKE_OK')\n") % (os.path.join(ROOT, "tests", "emu"), ROOT)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "EMU_SMOKE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("smoke ok") == 2, r.stdout[-500:]
