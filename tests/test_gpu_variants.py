@@ -84,6 +84,8 @@ def test_switches(modeA, modeB, huber, outlier):
     # the device really waits
     ({"SOS_PRELAUNCH_STEP": "1"}, "tests/test_gpu_optimize.py -k T6"),
     ({"SOS_PRELAUNCH_STEP": "1", "SOS_PRELAUNCH_TEST_DELAY_US": "2000"}, "tests/test_golden_t6.py"),
+    # ... on top of the cooperative absolute-coordinate chain (bench.py's `prelaunched_step_abs_cooperative`)
+    ({"SOS_PRELAUNCH_STEP": "1", "SOS_ABS_SC": "1", "SOS_ABS_COOP": "1"}, "tests/test_gpu_edge_windows.py -k T6"),
     # host-side orders kept as knobs: eager per-point mirrors, IMU first half behind the accumulate's enqueue
     ({"SOS_EAGER_POINT_MIRRORS": "1"}, "tests/test_golden_t6.py"),
     ({"SOS_IMU_OVERLAP": "1"}, "tests/test_gpu_imu_hook.py -k T6"),
