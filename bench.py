@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--side", choices=("imu",), default=None, help=argparse.SUPPRESS)   # one side measurement as its own process
     ap.add_argument("--no-sides", action="store_true", help="headline loop only: no keyframe / visual-inertial / variants entries")
     ap.add_argument("--cpu-seconds", type=float, default=14.0)
+    ap.add_argument("--variants", action="store_true", help="also time the opt-in launch variants, each in a process of its own (not in the default run)")
     a = ap.parse_args()
     if a.window is None:
         a.window = "W16" if a.scaling == "strong" else "W12"
@@ -370,8 +371,22 @@ def main():
         if world > 1:
             out["roofline"]["note"] += "; N > 1: rank 0's kernel on its own shard"
         out["cpu_baseline"] = None   # timed on rank 0 at N = 1 only
-        if world == 1 and not args.imu and not args.no_sides:
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(win, args.cpu_seconds)
+            out["speedup_vs_cpu_gn_iter"] = out["gn_iter_per_s"] / out["cpu_baseline"]["gn_iter_per_s"]
+            # (the thread scaling of the CPU port swings by 1.5x between boxes of the pool: the 1-thread figure is the stable denominator)
+            out["speedup_vs_cpu_gn_iter_1thread"] = out["gn_iter_per_s"] / out["cpu_baseline"]["gn_iter_per_s_1thread"]
+        sides = world == 1 and not args.imu and not args.no_sides
+        if sides:
+            # The headline measurements + roofline + cpu_baseline are complete: the line goes out NOW, and again, enriched with the side
+            # measurements, at the end -- so whatever a side measurement does (a hang, a kill by the caller's clock) cannot cost the
+            # line.  A reader that takes the first or the last JSON line of stdout gets a complete contract line either way.
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
             # side measurements: a failure in one of them must not cost the headline line
+            try:
+                out["tracker"] = tracker_timing(args.window, local_rank)
+            except Exception as e:  # noqa: BLE001
+                out["tracker"] = {"error": repr(e)}
             try:
                 out["keyframe"] = keyframe_timing(args.window, local_rank)
                 out["optimize_ms"] = out["keyframe"]["optimize_ms"]
@@ -379,21 +394,12 @@ def main():
             except Exception as e:  # noqa: BLE001
                 out["keyframe"] = {"error": repr(e)}
             out["visual_inertial"] = side_process("imu", args.window)
-            # (opt-in order of the IMU branch: first half of the solve behind the enqueue of the accumulation, csrc/host/sos_host.cpp)
-            out["visual_inertial_overlap"] = side_process("imu", args.window, env={"SOS_IMU_OVERLAP": "1"})
-        if not args.no_cpu_baseline and world == 1:
-            out["tracker"] = tracker_timing(args.window, local_rank)
-            out["cpu_baseline"] = cpu_baseline(win, args.cpu_seconds)
-            out["speedup_vs_cpu_gn_iter"] = out["gn_iter_per_s"] / out["cpu_baseline"]["gn_iter_per_s"]
-            # (the thread scaling of the CPU port swings by 1.5x between boxes of the pool: the 1-thread figure is the stable denominator)
-            out["speedup_vs_cpu_gn_iter_1thread"] = out["gn_iter_per_s"] / out["cpu_baseline"]["gn_iter_per_s_1thread"]
-        if world == 1 and not args.imu and not args.no_sides:
-            # last: code paths the build has not seen on an MI355X yet -- whatever one of them does to the device, this process's own
-            # measurements are complete by now
-            try:
-                out["variants"] = variant_timing(args.window)
-            except Exception as e:  # noqa: BLE001
-                out["variants"] = {"error": repr(e)}
+            if args.variants:
+                # opt-in: the same loop under each remaining switch, each in a process of its own
+                try:
+                    out["variants"] = variant_timing(args.window)
+                except Exception as e:  # noqa: BLE001
+                    out["variants"] = {"error": repr(e)}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()

@@ -20,6 +20,8 @@ import numpy as np
 
 from tests import rolling
 
+import os as _os
+_EMULATED = _os.environ.get("SOS_EMU") == "1" and not __import__("torch").cuda.is_available()
 GEO_FACTOR = 3.0
 MAX_FACTOR = 3.0
 
@@ -133,7 +135,7 @@ def summarize(runs):
     # (one seed in THREE since round 4: with shell->trackingRef kept per keyframe the successor of a marginalised middle keyframe loses its
     # spline constraints, as in the reference, fewer factors hold the scale and the spread test sits on its edge more often -- two seeds of
     # six under tests/emu, both with the scales inside the yardstick)
-    if len(traps) > max(1, len(runs) // 3):
+    if len(traps) > max(1, len(runs) // (3 if _EMULATED else 6)):   # (one in three only under tests/emu; one in six on a GPU)
         bad.append(("trapped", "count", traps))
     for sd, k, e in traps:
         if e > MAX_FACTOR * max(out["scale"]["max_orc_truth"], 1e-12):

@@ -1,6 +1,8 @@
 """The IMU branch of the facade's solveSystemF on the device-accumulated H / b (sosf_set_imu): with IMU terms switched
 off (zero weights, no valid spline) and the expanded prior it must reproduce the plain solve of the same window; with
 real IMU records the step it takes satisfies the spline constraints and moves the IMU states / scale."""
+import os
+
 import numpy as np
 import pytest
 
@@ -11,6 +13,9 @@ from tests.test_imu_assembly import _rot
 
 pytestmark = pytest.mark.gpu
 
+
+# 3x only under tests/emu (whose roundings differ from the hardware); the round-3 bar of 2x stands on a GPU (advisor, round 4)
+_EMU_FAC = 3.0 if (os.environ.get("SOS_EMU") == "1" and not __import__("torch").cuda.is_available()) else 2.0
 
 def _records(win, weights=True, valid=True, seed=0):
     rng = np.random.default_rng(seed)
@@ -272,8 +277,8 @@ def test_imu_prior_lifecycle(name):
     # (W7 is larger than the windows of tests/test_gpu_marginalize.py, where the bar of 2 holds on the MI355X: under tests/emu the device's
     # tile sums land 2.5x as far from the fp64-accumulated prior as the reference's scalar sums do -- 5.3e-5 against 2.1e-5 of the largest
     # entry; this check has not run on a GPU yet)
-    _yardstick(Hg, sides[False]["HM"], sides[True]["HM"], "expanded HM after marginalizePointsF", fac=3.0)
-    _yardstick(bg, sides[False]["bM"], sides[True]["bM"], "expanded bM after marginalizePointsF", fac=3.0)
+    _yardstick(Hg, sides[False]["HM"], sides[True]["HM"], "expanded HM after marginalizePointsF", fac=_EMU_FAC)
+    _yardstick(bg, sides[False]["bM"], sides[True]["bM"], "expanded bM after marginalizePointsF", fac=_EMU_FAC)
     assert np.abs(Hg - H0).max() > 0
     # ---- marginalizeFrame(0), IMU form
     ids2 = sysm.point_ids()
@@ -293,8 +298,8 @@ def test_imu_prior_lifecycle(name):
     sysm.set_imu(S, cal, kept)
     Hg, bg = sysm.imu_prior()
     assert Hg.shape == sides[False]["HM"].shape == (imu_dim(n - 1),) * 2
-    _yardstick(Hg, sides[False]["HM"], sides[True]["HM"], "expanded HM after marginalizeFrame", fac=3.0)   # (carries the prior of the step above)
-    _yardstick(bg, sides[False]["bM"], sides[True]["bM"], "expanded bM after marginalizeFrame", fac=3.0)
+    _yardstick(Hg, sides[False]["HM"], sides[True]["HM"], "expanded HM after marginalizeFrame", fac=_EMU_FAC)   # (carries the prior of the step above)
+    _yardstick(bg, sides[False]["bM"], sides[True]["bM"], "expanded bM after marginalizeFrame", fac=_EMU_FAC)
     assert np.abs(Hg - Hg.T).max() <= 1e-9 * np.abs(Hg).max()
     # ---- the reduced window optimises with the carried prior; the states keep moving, nothing blows up
     sc0 = cal.scale

@@ -11,6 +11,8 @@ from sos_slam_amd import synth
 from sos_slam_amd.records import SequenceParams
 from tests import rolling
 
+_EMULATED = os.environ.get("SOS_EMU") == "1" and not __import__("torch").cuda.is_available()   # looser mono-VIO bar only under tests/emu
+
 pytestmark = pytest.mark.gpu
 
 
@@ -150,7 +152,7 @@ def _case_vio(stereo):
             pose = d.kf_pose(now.index(fid)) if fid in now else np.array(out.margCamToWorld[12 * left.index(fid):12 * left.index(fid) + 12])
             e = np.abs(pose - lg.window_poses[fid]).max()
             worst_pose = max(worst_pose, e)
-            assert e < (5e-4 if stereo else 1.5e-3), (k, fid, e)   # (without the stereo scale the loops drift along the scale direction: 5.3e-4 at keyframe 15 under tests/emu)
+            assert e < (5e-4 if stereo or not _EMULATED else 1.5e-3), (k, fid, e)   # (without the stereo scale the loops drift along the scale direction: 5.3e-4 at keyframe 15 under tests/emu)
             if fid not in now:       # the IMU states are logged (and kept) for the keyframes that stay
                 continue
             st, ze, ve = seq.imu(fid)
