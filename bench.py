@@ -305,7 +305,7 @@ def main():
         L.sos_ba_time_kernel(L_host_ba(sysm), b"stream_large", th.ctypes.data_as(C.c_void_p), 50, C.byref(ms))
         large_ms = ms.value   # coalesced read of a 1 GiB buffer: the chip's streaming bandwidth without launch effects
         for name in ("apply_res", "top_accumulate", "sc_accumulate", "sc_gram_prep", "reduce", "stitch", "resub_fused", "sc_gram_abs",
-                     "abs_reduce_stitch1", "abs_stitch2", "abs_coop"):
+                     "abs_reduce_stitch1", "abs_stitch2"):
             L.sos_ba_time_kernel(L_host_ba(sysm), name.encode(), th.ctypes.data_as(C.c_void_p), 200, C.byref(ms))
             kern[name + "_us"] = round(ms.value * 1e3, 2)
         out = {
@@ -430,15 +430,10 @@ def side_process(what, window, timeout=240, env=None):
 # bounded spins, csrc/sos_ba.hip) last, and all of them after every measurement this process takes itself (main()).
 VARIANTS = (
     ("abs_schur", {"SOS_ABS_SC": "1"}, []),                                         # one Gram per chunk instead of the n^3 relative blocks + 2-stage stitch
-    ("abs_schur_signal_in_kernel", {"SOS_ABS_SC": "1", "SOS_ABS_SIGNAL_IN_KERNEL": "1"}, []),
-    ("stitch_signal_in_kernel", {"SOS_STITCH_SIGNAL_IN_KERNEL": "1"}, []),          # only the stitch's last kernel raises the host flag itself (no k_publish)
-    ("signal_in_kernel", {"SOS_SIGNAL_IN_KERNEL": "1"}, []),                          # completion flags stored by the last block instead of k_publish
-    ("lin_one_tile_blocks", {"SOS_LIN_ND": "0"}, []),                                 # k_linearize2 with every block owning one tile (2x the blocks in flight)
-    ("eager_point_mirrors", {"SOS_EAGER_POINT_MIRRORS": "1"}, []),                    # the per-point host loop of every iteration as before round 4
-    ("resident", {}, ["--resident"]),                                                 # solve on the device (k_gn_solve)
-    ("abs_schur_cooperative", {"SOS_ABS_SC": "1", "SOS_ABS_COOP": "1"}, []),        # ... and its three launches as ONE with device-wide barriers
-    ("prelaunched_step", {"SOS_PRELAUNCH_STEP": "1"}, []),                            # the step's launches enqueued before the solve, x through a mapped mailbox
-    ("prelaunched_step_abs_cooperative", {"SOS_PRELAUNCH_STEP": "1", "SOS_ABS_SC": "1", "SOS_ABS_COOP": "1"}, []),
+    ("abs_schur_signal_in_kernel", {"SOS_ABS_SC": "1", "SOS_STITCH_SIGNAL_IN_KERNEL": "1"}, []),
+    ("stitch_signal_in_kernel", {"SOS_STITCH_SIGNAL_IN_KERNEL": "1"}, []),          # the stitch's last kernel raises the host flag itself (no k_publish)
+    ("resident", {}, ["--resident"]),                                                 # solve on the device (k_gn_solve), the host out of the loop
+    ("resident_abs_schur", {"SOS_ABS_SC": "1"}, ["--resident"]),
 )
 
 
@@ -466,7 +461,7 @@ def variant_timing(window, timeout=90, budget=300.0):
                          "resInA": d["config"]["resInA_last_iteration"], "last_step_l2": d["last_step_l2"],
                          "host_phases_us": d.get("host_phases_us"),
                          "kernels_us": {q: k.get(q) for q in ("sc_gram_prep_us", "reduce_us", "stitch_us", "sc_gram_abs_us", "abs_reduce_stitch1_us",
-                                                             "abs_stitch2_us", "abs_coop_us", "linearize_fused_us", "resub_fused_us")}}
+                                                             "abs_stitch2_us", "linearize_fused_us", "resub_fused_us")}}
         except Exception as ex:  # noqa: BLE001
             out[name] = {"error": repr(ex)[:200]}
     return out
@@ -738,7 +733,7 @@ def exchange_info(sysm, win, world):
     import ctypes as C
     from sos_slam_amd import lib
     dim = 4 + 8 * win.n
-    if os.environ.get("SOS_ABS_SC") and not os.environ.get("SOS_NO_ABS_SC"):
+    if os.environ.get("SOS_ABS_SC"):
         return {"kind": "all-reduce of the stitched fp64 system [H_A b_A | H_sc b_sc | count] (absolute-coordinate path)", "bytes": 8 * (2 * (dim * dim + dim) + 1)}
     dev, nfl = C.c_void_p(), C.c_size_t(0)
     try:

@@ -296,19 +296,6 @@ int sos_ba_gn_accumulate_begin(sos_ba *ba);
 int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const sos_calib *calib, const sos_precalc *precalc,
                    const float *adHTdeltaF, const float *cDeltaF, const float *frameEnergyTH, int applyRes,
                    double *energySum, float *newestEnergies, int *newestCount, float *pointStep);
-/* The device-side form of sos_ba_gn_step (x alone, sos_ba_gn_devstep_begin) split around the solve: _prelaunch enqueues the same
- * launches -- back-substitution + doStepFromBackup + setPrecalcValues / setDeltaF on the device, linearizeAll(false) + applyRes, and
- * with sos_ba_set_prefetch the NEXT iteration's accumulate -- BEFORE solveSystemF's LDLT (OB/EnergyFunctional.cpp:1141-1148) has
- * produced x; the first of them waits (bounded) for x in a mailbox in device-mapped host memory.  _deliver writes x there, waits for
- * the step and returns what sos_ba_gn_step returns.  The launch latency of the step is then off the path between solve and
- * back-substitution.  Between the two calls only sos_ba_gn_accumulate (which consumes the accumulate enqueued by the PREVIOUS step) may
- * touch this window.  _prelaunch: SOS_ERR_STATE = not possible now (no device-side step, a communicator attached, no accumulate in
- * flight to queue behind) -- call sos_ba_gn_step after the solve as before.  _deliver(x = NULL) cancels (a failed solve): the
- * waiting step runs with x = 0 and is drained, SOS_ERR_STATE is returned.  SOS_ERR_TIMEOUT: a workgroup gave up waiting for x. */
-int sos_ba_gn_step_prelaunch(sos_ba *ba, float stepfacD, const float *frameEnergyTH, int applyRes);
-int sos_ba_gn_step_deliver(sos_ba *ba, const double *x, const sos_calib *calib, double *energySum, float *newestEnergies, int *newestCount,
-                           float *pointStep);
-
 /* The back-substitution half of sos_ba_gn_step (resubstituteF_MT / resubstituteFPt, OB/EnergyFunctional.cpp:496-551), enqueued ahead: it needs x alone, so the caller issues it right after the
  * solve and computes the new poses / precalc records while it runs; the following sos_ba_gn_step must then be given
  * x = NULL.  SOS_ERR_STATE when the window cannot take this path (no points / no fp32 adjoints yet): pass x to

@@ -1272,11 +1272,10 @@ int FullSystem::prepare() {  // FS/FullSystemOptimize.cpp:316-344
     double E = 0;
     // the Gauss-Newton loop follows: its first accumulate + stitch is enqueued right behind this linearisation (the tile sums of
     // the top Hessian come out of it), unless a callback exchange has to run between accumulate and stitch
-    static const bool noPrefetch = getenv("SOS_NO_PREPARE_PREFETCH") != nullptr;  // A/B knob
+    static const bool noPrefetch = getenv("SOS_NO_PREPARE_PREFETCH") != nullptr;  // (tools/first_solve_probe.py: the stored-Jacobian accumulate, for comparison)
     // (2: only the tile sums are formed -- the device-resident loop and a callback exchange enqueue their own accumulate)
-    static const char *pm = getenv("SOS_PREPARE_MODE");  // A/B knob
     // (a callback exchange gets 0: sos_ba_accumulate_local resets the tile sums and needs J stored, which the fused form skips)
-    sos_ba_set_prefetch(ef->ba, pm ? atoi(pm) : (noPrefetch || ef->allreduceHook) ? 0 : residentUsable() ? 2 : 1);
+    sos_ba_set_prefetch(ef->ba, (noPrefetch || ef->allreduceHook) ? 0 : residentUsable() ? 2 : 1);
     lastError = sos_ba_linearize_apply(ef->ba, th.data(), 1, &E, newestE.data(), &cnt);
     newestE.resize(cnt);
     setNewFrameEnergyTH(newestE);
@@ -1314,22 +1313,7 @@ host_path:
   if (devStepActive && !pointMirrorsStale && (inOptimizeLoop || pipelineAlways)) beginLazyPointMirrors();
   if (!devStepActive) flushPointMirrors();
   { PhaseTimer tb(7); backupState(); }
-  // SOS_PRELAUNCH_STEP=1 (opt-in, never run on an MI355X yet): the launches of this iteration's step -- back-substitution + device-side
-  // step, linearisation, the next accumulate -- are enqueued NOW, behind the accumulate whose H / b the solve below waits for; the first of
-  // them waits for x in a mapped mailbox (sos_ba_gn_step_prelaunch / _deliver), so no launch latency sits between solve and step.  Whether
-  // there will be another iteration is not known before the solve: the linearisation is launched in the form a following accumulate wants
-  // (tile sums instead of a stored J) and the accumulate itself is enqueued by the delivery, when it is known
-  bool prelaunched = false;
-  static const bool prelaunchOn = getenv("SOS_PRELAUNCH_STEP") != nullptr;
-  if (prelaunchOn && devStepActive && !ef->allreduceHook && !ef->commAttached) {
-    const int nf = (int)frameHessians.size();
-    std::vector<float> th(nf);
-    for (int i = 0; i < nf; i++) th[i] = frameHessians[i]->frameEnergyTH;
-    sos_ba_set_prefetch(ef->ba, (pipelineAlways || mayContinue) ? 1 : 0);
-    prelaunched = sos_ba_gn_step_prelaunch(ef->ba, 1.0f, th.data(), 1) == SOS_OK;
-  }
   if (rcAcc(ef->solveSystemF(iteration, 1e-1, &HCalib, true)) != SOS_OK) {  // x, frame / calib steps; back-substitution deferred
-    if (prelaunched) sos_ba_gn_step_deliver(ef->ba, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);  // (the waiting step steps by zero and drains)
     isLost = true;  // a failed device call: no step is taken on undelivered H / b
     return true;
   }
@@ -1353,14 +1337,9 @@ host_path:
     double E = 0;
     ef->pointStep.resize(ef->allPoints.size());
     const bool more = pipelineAlways || (mayContinue && !(canbreak && iteration >= minOptIterations));
-    if (prelaunched) {
-      sos_ba_set_prefetch(ef->ba, more ? 1 : 0);  // (the next accumulate is enqueued by the delivery, now that `more` is known)
-      lastError = sos_ba_gn_step_deliver(ef->ba, ef->lastX.data(), &cal, &E, newestE.data(), &cnt, ef->pointStep.data());
-    } else {
-      sos_ba_set_prefetch(ef->ba, (more && !ef->allreduceHook) ? 1 : 0);  // a callback exchange runs between accumulate and stitch
-      lastError = sos_ba_gn_step(ef->ba, ef->lastX.data(), 1.0f, &cal, nullptr, nullptr, nullptr, th.data(), 1, &E, newestE.data(), &cnt,
-                                 ef->pointStep.data());
-    }
+    sos_ba_set_prefetch(ef->ba, (more && !ef->allreduceHook) ? 1 : 0);  // a callback exchange runs between accumulate and stitch
+    lastError = sos_ba_gn_step(ef->ba, ef->lastX.data(), 1.0f, &cal, nullptr, nullptr, nullptr, th.data(), 1, &E, newestE.data(), &cnt,
+                               ef->pointStep.data());
     if (lastError != SOS_OK) {  // e.g. the device-side frame states were dropped by a state upload in between: no step was taken
       devStepActive = false;
       sos_ba_gn_devstep_end(ef->ba);
@@ -1434,11 +1413,10 @@ host_path:
 // device-resident Gauss-Newton loop: what is left for the host is the loop control (canbreak) and its mirrors
 // ------------------------------------------------------------------------------------------------
 bool FullSystem::devStepUsable() const {
-  static const bool off = getenv("SOS_NO_DEVSTEP") != nullptr;
   // x is replicated over the ranks (identical stitch + solve on the all-reduced accumulator) and so are the frame states: the
   // device-side step needs nothing from the exchange.  The IMU branch of the solve (OB/EnergyFunctional.cpp:1053-1171) sits between
   // stitch and back-substitution on the host and delivers the same x vector.
-  return devStepAllowed && !off && forceAcceptStep && !ef->keepSystem && (int)frameHessians.size() <= 17 && !ef->allPoints.empty();
+  return devStepAllowed && forceAcceptStep && !ef->keepSystem && (int)frameHessians.size() <= 17 && !ef->allPoints.empty();
 }
 
 int FullSystem::devStepBegin() {
@@ -1458,8 +1436,7 @@ int FullSystem::devStepBegin() {
 }
 
 bool FullSystem::residentUsable() const {
-  static const bool off = getenv("SOS_NO_RESIDENT") != nullptr;
-  return residentAllowed && !off && forceAcceptStep && !ef->imuSettings && !ef->allreduceHook && !ef->commAttached && !ef->keepSystem &&
+  return residentAllowed && forceAcceptStep && !ef->imuSettings && !ef->allreduceHook && !ef->commAttached && !ef->keepSystem &&
          sos_ba_gn_resident_supported(ef->ba) == 1;
 }
 
@@ -1527,9 +1504,8 @@ bool FullSystem::residentConsume(int seq) {
 
 // Lazy point mirrors (sos_host.hpp): the flat copies are gathered once, in snapshot order, with the reference's summation order beside them
 bool FullSystem::beginLazyPointMirrors() {
-  static const bool off = getenv("SOS_EAGER_POINT_MIRRORS") != nullptr;  // A/B knob
   const size_t P = ef->allPoints.size();
-  if (off || P == 0) return false;
+  if (P == 0) return false;
   flatIdepth.resize(P);
   flatOrder.clear();
   flatOrder.reserve(P);

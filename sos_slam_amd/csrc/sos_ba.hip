@@ -218,353 +218,6 @@ extern "C" int sos_debug_lin_prof(unsigned long long *out, int nblocks) {
 #else
 #define LIN_STAMP(i)
 #endif
-// fuse_top != nullptr (requires doApply): the block also accumulates its tile's 13x13 block sums (mode 0 of
-// AccumulatedTopHessianSSE::addPoint) from the tile still in LDS into fuse_top[tile*96..] and does NOT write the tile
-// to HBM -- the Jacobians of a Gauss-Newton iteration are consumed where they are produced.
-__global__ __launch_bounds__(256, SOS_LIN_WAVES) void k_linearize(BaDev d, const float *__restrict__ frameTH, int doApply,
-                                                                  float *__restrict__ fuse_top) {
-  __shared__ float sJ[SOS_JPLANES * SJ_STRIDE];
-  __shared__ float sX[6 * SJ_STRIDE];  // per residual: JI_r0 JI_r1 Jab_r0 Jab_r1 rr use
-  __shared__ float sRet[SOS_TILE];
-  __shared__ unsigned int sLin;
-  const int tile = blockIdx.x;
-  const int tid = threadIdx.x;
-  LIN_STAMP(0);
-  const int rl = tid >> 3, idx = tid & 7;
-  const int lane = tid & 63;
-  const int s = tile * SOS_TILE + rl;
-  // independent vector loads first
-  const float4 geo = d.r_geo[s];                       // u, v, idepth, idepth_zero
-  const float2 cw = reinterpret_cast<const float2 *>(d.r_cw)[8 * (size_t)s + idx];
-  const float color = cw.x, pweight = cw.y;
-  const unsigned flags = d.s_flags[s];
-  const int st = d.s_state[s];
-  const int pair = d.t_pair[tile];
-  const int hIdx = pair % d.n, tIdx = pair / d.n;
-  const sos_precalc *pc = d.precalc + pair;
-  const float *__restrict__ img = d.img[tIdx];
-  if (tid == 0) sLin = 0;
-  __syncthreads();
-
-  const bool valid = (flags & DF_VALID) != 0;
-  const bool isLin = valid && (flags & DF_LINEARIZED);
-  const float pu = geo.x, pv = geo.y, id = geo.z, idz = geo.w;
-
-  // ---- this lane's pattern pixel with the current pose / idepth (FS/ResidualProjections.h:43-50)
-  const int px = (int)((0x21420312u >> (4 * idx)) & 0xf) - 2;  // {0,-1,1,-2,0,2,-1,0}
-  const int py = (int)((0x43222110u >> (4 * idx)) & 0xf) - 2;  // {-2,-1,-1,0,0,0,1,2}
-  const float u_pt = pu + (float)px, v_pt = pv + (float)py;
-  const float q0 = pc->PRE_KRKiTll[0] * u_pt + pc->PRE_KRKiTll[1] * v_pt + pc->PRE_KRKiTll[2] + pc->PRE_KtTll[0] * id;
-  const float q1 = pc->PRE_KRKiTll[3] * u_pt + pc->PRE_KRKiTll[4] * v_pt + pc->PRE_KRKiTll[5] + pc->PRE_KtTll[1] * id;
-  const float q2 = pc->PRE_KRKiTll[6] * u_pt + pc->PRE_KRKiTll[7] * v_pt + pc->PRE_KRKiTll[8] + pc->PRE_KtTll[2] * id;
-  const float Ku = q0 / q2, Kv = q1 / q2;
-  LIN_STAMP(1);  // first-level loads (geo, precalc) have arrived
-  const bool inb = Ku > 1.1f && Kv > 1.1f && Ku < d.wM3G && Kv < d.hM3G;
-
-  // ---- bilinear (I,dx,dy) tap (util/globalFuncs.h:68-82); addresses clamped so the loads are always legal
-  int ix = (int)Ku, iy = (int)Kv;
-  const float fdx = Ku - (float)ix, fdy = Kv - (float)iy;
-  ix = min(max(ix, 0), d.w - 2);
-  iy = min(max(iy, 0), d.h - 2);
-  const float *bp = img + 3 * (ix + iy * d.w);
-  const float a0 = bp[0], a1 = bp[1], a2 = bp[2], b0_ = bp[3], b1_ = bp[4], b2_ = bp[5];
-  const float *bq = bp + 3 * d.w;
-  const float c0 = bq[0], c1 = bq[1], c2 = bq[2], d0 = bq[3], d1 = bq[4], d2 = bq[5];
-  const float dxdy = fdx * fdy;
-  const float w11 = dxdy, w01 = fdy - dxdy, w10 = fdx - dxdy, w00 = 1 - fdx - fdy + dxdy;
-  const float hit0 = w11 * d0 + w01 * c0 + w10 * b0_ + w00 * a0;
-  float hit1 = w11 * d1 + w01 * c1 + w10 * b1_ + w00 * a1;
-  float hit2 = w11 * d2 + w01 * c2 + w10 * b2_ + w00 * a2;
-
-  LIN_STAMP(2);  // image taps have arrived
-  const bool lane_oob = !inb || !isfinite(hit0);
-  const unsigned long long oobmask = __ballot(lane_oob);
-  const bool grp_oob = ((oobmask >> (lane & 56)) & 0xffull) != 0;
-
-  // ---- photometric residual, weights (FS/Residuals.cpp:189-241)
-  const float affLL0 = pc->PRE_aff_mode[0], affLL1 = pc->PRE_aff_mode[1], b0 = pc->PRE_b0_mode;
-  const float residual = hit0 - (float)(affLL0 * color + affLL1);
-  const float drdA = color - b0;
-  float wgt = sqrtf(d.outlierTH / (d.outlierTH + (hit1 * hit1 + hit2 * hit2)));
-  wgt = 0.5f * (wgt + pweight);
-  float hw = fabsf(residual) < d.huberTH ? 1 : d.huberTH / fabsf(residual);
-  const float e_i = wgt * wgt * hw * residual * residual * (2 - hw);
-  if (hw < 1) hw = sqrtf(hw);
-  hw = hw * wgt;
-  hit1 *= hw;
-  hit2 *= hw;
-
-  // ---- per-pixel rows of the Jacobian -> LDS staging
-  sJ[(JP_RESF + idx) * SJ_STRIDE + rl] = residual * hw;
-  sJ[(JP_JIDX0 + idx) * SJ_STRIDE + rl] = hit1;
-  sJ[(JP_JIDX1 + idx) * SJ_STRIDE + rl] = hit2;
-  sJ[(JP_JAB0 + idx) * SJ_STRIDE + rl] = d.modeA < 0 ? 0.0f : drdA * hw;
-  sJ[(JP_JAB1 + idx) * SJ_STRIDE + rl] = d.modeB < 0 ? 0.0f : hw;
-
-  const float energyLeft0 = seqsum8(e_i);
-  const float JIdxJIdx_00 = seqsum8(hit1 * hit1);
-  const float JIdxJIdx_11 = seqsum8(hit2 * hit2);
-  const float JIdxJIdx_10 = seqsum8(hit1 * hit2);
-  const float JabJIdx_00 = seqsum8(drdA * hw * hit1);
-  const float JabJIdx_01 = seqsum8(drdA * hw * hit2);
-  const float JabJIdx_10 = seqsum8(hw * hit1);
-  const float JabJIdx_11 = seqsum8(hw * hit2);
-  const float JabJab_00 = seqsum8(drdA * drdA * hw * hw);
-  const float JabJab_01 = seqsum8(drdA * hw * hw);
-  const float JabJab_11 = seqsum8(hw * hw);
-  const float wJI2_sum = seqsum8(hw * hw * (hit1 * hit1 + hit2 * hit2));
-  // JI_r of AccumulatedTopHessianSSE::addPoint<0> (OB/AccumulatedTopHessian.cpp:101-110): feeds the per-residual
-  // terms of the point sums, produced here so that the Schur side does not have to wait for the top accumulation
-  const float JI_r0 = seqsum8(residual * hw * hit1);
-  const float JI_r1 = seqsum8(residual * hw * hit2);
-  const float jabF0 = d.modeA < 0 ? 0.0f : drdA * hw, jabF1 = d.modeB < 0 ? 0.0f : hw;
-  const float Jab_r0 = seqsum8(residual * hw * jabF0);
-  const float Jab_r1 = seqsum8(residual * hw * jabF1);
-  const float rr_sum = seqsum8(residual * hw * (residual * hw));
-
-  LIN_STAMP(3);  // per-pixel part + DPP sums done
-  if (idx == 7) {
-    const float fxl = d.calibp[0], fyl = d.calibp[1], cxl = d.calibp[2], cyl = d.calibp[3];
-    const float fxli = d.calibp[4], fyli = d.calibp[5];
-    const float *R0 = pc->PRE_RTll_0, *t0 = pc->PRE_tTll_0;
-    // ---- centre projection with the FEJ pose / idepth (FS/ResidualProjections.h:52-73)
-    const float KliP0 = (pu - cxl) * fxli;
-    const float KliP1 = (pv - cyl) * fyli;
-    const float ptp0 = R0[0] * KliP0 + R0[1] * KliP1 + R0[2] + t0[0] * idz;
-    const float ptp1 = R0[3] * KliP0 + R0[4] * KliP1 + R0[5] + t0[1] * idz;
-    const float ptp2 = R0[6] * KliP0 + R0[7] * KliP1 + R0[8] + t0[2] * idz;
-    const float drescale = 1.0f / ptp2;
-    const float new_idepth = idz * drescale;
-    const float cu = ptp0 * drescale, cv = ptp1 * drescale;
-    const float cKu = cu * fxl + cxl, cKv = cv * fyl + cyl;
-    const bool center_ok = (drescale > 0) && cKu > 1.1f && cKv > 1.1f && cKu < d.wM3G && cKv < d.hM3G;
-    // ---- geometric Jacobians (FS/Residuals.cpp:116-157)
-    const float d_d_x = drescale * (t0[0] - t0[2] * cu) * SOS_SCALE_IDEPTH * fxl;
-    const float d_d_y = drescale * (t0[1] - t0[2] * cv) * SOS_SCALE_IDEPTH * fyl;
-    float dCx2 = drescale * (R0[6] * cu - R0[0]);
-    float dCx3 = fxl * drescale * (R0[7] * cu - R0[1]) * fyli;
-    float dCx0 = KliP0 * dCx2;
-    float dCx1 = KliP1 * dCx3;
-    float dCy2 = fyl * drescale * (R0[6] * cv - R0[3]) * fxli;
-    float dCy3 = drescale * (R0[7] * cv - R0[4]);
-    float dCy0 = KliP0 * dCy2;
-    float dCy1 = KliP1 * dCy3;
-    dCx0 = (dCx0 + cu) * SOS_SCALE_F;
-    dCx1 *= SOS_SCALE_F;
-    dCx2 = (dCx2 + 1) * SOS_SCALE_C;
-    dCx3 *= SOS_SCALE_C;
-    dCy0 *= SOS_SCALE_F;
-    dCy1 = (dCy1 + cv) * SOS_SCALE_F;
-    dCy2 *= SOS_SCALE_C;
-    dCy3 = (dCy3 + 1) * SOS_SCALE_C;
-    const float dxi_x[6] = {new_idepth * fxl, 0.0f, -new_idepth * cu * fxl, -cu * cv * fxl, (1 + cu * cu) * fxl, -cv * fxl};
-    const float dxi_y[6] = {0.0f, new_idepth * fyl, -new_idepth * cv * fyl, -(1 + cv * cv) * fyl, cu * cv * fyl, cu * fyl};
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-      sJ[(JP_DXI0 + i) * SJ_STRIDE + rl] = dxi_x[i];
-      sJ[(JP_DXI1 + i) * SJ_STRIDE + rl] = dxi_y[i];
-    }
-    sJ[(JP_DC0 + 0) * SJ_STRIDE + rl] = dCx0;
-    sJ[(JP_DC0 + 1) * SJ_STRIDE + rl] = dCx1;
-    sJ[(JP_DC0 + 2) * SJ_STRIDE + rl] = dCx2;
-    sJ[(JP_DC0 + 3) * SJ_STRIDE + rl] = dCx3;
-    sJ[(JP_DC1 + 0) * SJ_STRIDE + rl] = dCy0;
-    sJ[(JP_DC1 + 1) * SJ_STRIDE + rl] = dCy1;
-    sJ[(JP_DC1 + 2) * SJ_STRIDE + rl] = dCy2;
-    sJ[(JP_DC1 + 3) * SJ_STRIDE + rl] = dCy3;
-    sJ[(JP_DD + 0) * SJ_STRIDE + rl] = d_d_x;
-    sJ[(JP_DD + 1) * SJ_STRIDE + rl] = d_d_y;
-    sJ[(JP_JIDX2 + 0) * SJ_STRIDE + rl] = JIdxJIdx_00;
-    sJ[(JP_JIDX2 + 1) * SJ_STRIDE + rl] = JIdxJIdx_10;
-    sJ[(JP_JIDX2 + 2) * SJ_STRIDE + rl] = JIdxJIdx_11;
-    sJ[(JP_JABJIDX + 0) * SJ_STRIDE + rl] = JabJIdx_00;
-    sJ[(JP_JABJIDX + 1) * SJ_STRIDE + rl] = JabJIdx_01;
-    sJ[(JP_JABJIDX + 2) * SJ_STRIDE + rl] = JabJIdx_10;
-    sJ[(JP_JABJIDX + 3) * SJ_STRIDE + rl] = JabJIdx_11;
-    sJ[(JP_JAB2 + 0) * SJ_STRIDE + rl] = JabJab_00;
-    sJ[(JP_JAB2 + 1) * SJ_STRIDE + rl] = JabJab_01;
-    sJ[(JP_JAB2 + 2) * SJ_STRIDE + rl] = JabJab_11;
-
-    // ---- classification (FS/Residuals.cpp:78-83,107-112,258-270)
-    int newState;
-    float newEnergy = 0.f, newEnergyWO = -1.f, ret;
-    if (!valid) {
-      newState = SOS_RES_OOB;
-      ret = 0.f;
-    } else if (isLin) {  // not in activeResiduals (FS/FullSystemOptimize.cpp:321)
-      newState = st;
-      ret = 0.f;
-      newEnergy = d.s_newenergy[s];
-      atomicOr(&sLin, 1u << rl);
-    } else if (st == SOS_RES_OOB || !center_ok || grp_oob) {
-      newState = SOS_RES_OOB;
-      ret = d.s_energy[s];
-      newEnergy = d.s_newenergy[s];
-    } else {
-      float energyLeft = energyLeft0;
-      newEnergyWO = energyLeft;
-      const float th = fmaxf(frameTH[hIdx], frameTH[tIdx]);
-      if (energyLeft > th || wJI2_sum < 2) {
-        energyLeft = th;
-        newState = SOS_RES_OUTLIER;
-      } else {
-        newState = SOS_RES_IN;
-      }
-      newEnergy = energyLeft;
-      ret = energyLeft;
-    }
-    const bool wr = doApply != 2;  // 2 = refresh: recompute the tile at the unchanged state and store nothing but J
-    if (wr) {
-    d.s_newstate[s] = (uint8_t)newState;
-    d.s_newenergy[s] = newEnergy;
-    d.s_newenergywo[s] = newEnergyWO;
-    d.s_ret[s] = ret;
-    sRet[rl] = ret;
-    if (d.o_newest && tIdx == d.n - 1) d.o_newest[s - d.newest_begin] = newEnergyWO;
-    }
-    bool activeAfter = (flags & DF_ACTIVE) != 0;
-    if (doApply == 1 && valid && !isLin && st != SOS_RES_OOB) {  // applyRes(true), FS/Residuals.cpp:304-321
-      activeAfter = newState == SOS_RES_IN;
-      d.s_flags[s] = (uint8_t)(activeAfter ? (flags | DF_ACTIVE) : (flags & ~DF_ACTIVE));
-      d.s_state[s] = (uint8_t)newState;
-      d.s_energy[s] = newEnergy;
-    }
-    const bool wrote_center = wr && valid && !isLin && st != SOS_RES_OOB && center_ok;
-    if (wrote_center) {
-      d.s_center[3 * s + 0] = cKu;
-      d.s_center[3 * s + 1] = cKv;
-      d.s_center[3 * s + 2] = new_idepth;
-    }
-    if (wr && valid && !isLin) {
-      // JpJdF of EFResidual::takeDataF (OB/EnergyFunctionalStructs.cpp:39-44)
-      const float v0 = JIdxJIdx_00 * d_d_x + JIdxJIdx_10 * d_d_y;
-      const float v1 = JIdxJIdx_10 * d_d_x + JIdxJIdx_11 * d_d_y;
-      float4 o0, o1;
-      o0.x = dxi_x[0] * v0 + dxi_y[0] * v1;
-      o0.y = dxi_x[1] * v0 + dxi_y[1] * v1;
-      o0.z = dxi_x[2] * v0 + dxi_y[2] * v1;
-      o0.w = dxi_x[3] * v0 + dxi_y[3] * v1;
-      o1.x = dxi_x[4] * v0 + dxi_y[4] * v1;
-      o1.y = dxi_x[5] * v0 + dxi_y[5] * v1;
-      o1.z = JabJIdx_00 * d_d_x + JabJIdx_01 * d_d_y;
-      o1.w = JabJIdx_10 * d_d_x + JabJIdx_11 * d_d_y;
-      // JpJd holds EFResidual::JpJdF while the residual is active and zeros otherwise, so the Schur
-      // and back-substitution kernels need no flag lookups (x - 0 == x exactly)
-      // per-residual terms of Hdd_acc / bd_acc / Hcd_acc (OB/AccumulatedTopHessian.cpp:124-127), zero while inactive.
-      // Without doApply they are provisional like JpJd: k_apply_res clears them if the residual does not end up IN.
-      const bool termsLive = doApply ? activeAfter : (st != SOS_RES_OOB);
-      float4 p0, p1;
-      p0.x = v0 * d_d_x + v1 * d_d_y;
-      p0.y = JI_r0 * d_d_x + JI_r1 * d_d_y;
-      p0.z = dCx0 * v0 + dCy0 * v1;
-      p0.w = dCx1 * v0 + dCy1 * v1;
-      p1.x = dCx2 * v0 + dCy2 * v1;
-      p1.y = dCx3 * v0 + dCy3 * v1;
-      p1.z = 1.f;  // counts towards ngoodres
-      p1.w = 0.f;  // *_accAF sums
-      if (!termsLive) o0 = o1 = p0 = p1 = make_float4(0.f, 0.f, 0.f, 0.f);
-      float4 *jp = reinterpret_cast<float4 *>(d.JpJd + 8 * (size_t)s);
-      jp[0] = o0;
-      jp[1] = o1;
-      float4 *pt = reinterpret_cast<float4 *>(d.s_pterm + 8 * (size_t)s);
-      pt[0] = p0;
-      pt[1] = p1;
-    }
-    if (fuse_top) {  // inputs of the fused block accumulation that are not planes of the tile
-      sX[0 * SJ_STRIDE + rl] = JI_r0;
-      sX[1 * SJ_STRIDE + rl] = JI_r1;
-      sX[2 * SJ_STRIDE + rl] = Jab_r0;
-      sX[3 * SJ_STRIDE + rl] = Jab_r1;
-      sX[4 * SJ_STRIDE + rl] = rr_sum;
-      sX[5 * SJ_STRIDE + rl] = (valid && !isLin && activeAfter) ? 1.f : 0.f;
-    }
-    const int orig = d.s_orig[s];
-    if (wr && orig >= 0) {
-      if (d.o_newstate) d.o_newstate[orig] = (uint8_t)newState;
-      if (d.o_newenergy) d.o_newenergy[orig] = newEnergy;
-      if (d.o_newenergywo) d.o_newenergywo[orig] = newEnergyWO;
-      if (d.o_center && wrote_center) {
-        d.o_center[3 * orig + 0] = cKu;
-        d.o_center[3 * orig + 1] = cKv;
-        d.o_center[3 * orig + 2] = new_idepth;
-      }
-    }
-  }
-  LIN_STAMP(4);  // leader part done (this wave)
-  __syncthreads();
-  LIN_STAMP(5);
-  if (tid < 64 && d.tile_esum && doApply != 2) {  // returned energies of the tile: fp64 butterfly over the 32 residuals
-    double a = (tid < SOS_TILE) ? (double)sRet[tid] : 0.0;
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-    if (tid == 0) d.tile_esum[tile] = a;
-  }
-
-  if (fuse_top) {
-    // ---- fused AccumulatedTopHessianSSE::addPoint<0> over the tile: thread = (residual r, part), part = 12 of the
-    // 96 values; sum over the 32 residuals by an xor butterfly inside each half-wave (fixed tree: deterministic)
-    const int r = tid & 31, part = tid >> 5;
-    TopIn in;
-#pragma unroll
-    for (int i = 0; i < 4; i++) { in.x[i] = sJ[(JP_DC0 + i) * SJ_STRIDE + r]; in.y[i] = sJ[(JP_DC1 + i) * SJ_STRIDE + r]; }
-#pragma unroll
-    for (int i = 0; i < 6; i++) { in.x[4 + i] = sJ[(JP_DXI0 + i) * SJ_STRIDE + r]; in.y[4 + i] = sJ[(JP_DXI1 + i) * SJ_STRIDE + r]; }
-    in.a = sJ[(JP_JIDX2 + 0) * SJ_STRIDE + r]; in.b = sJ[(JP_JIDX2 + 1) * SJ_STRIDE + r]; in.c = sJ[(JP_JIDX2 + 2) * SJ_STRIDE + r];
-    in.jab00 = sJ[(JP_JABJIDX + 0) * SJ_STRIDE + r]; in.jab01 = sJ[(JP_JABJIDX + 1) * SJ_STRIDE + r];
-    in.jab10 = sJ[(JP_JABJIDX + 2) * SJ_STRIDE + r]; in.jab11 = sJ[(JP_JABJIDX + 3) * SJ_STRIDE + r];
-    in.ab00 = sJ[(JP_JAB2 + 0) * SJ_STRIDE + r]; in.ab01 = sJ[(JP_JAB2 + 1) * SJ_STRIDE + r]; in.ab11 = sJ[(JP_JAB2 + 2) * SJ_STRIDE + r];
-    in.JI_r0 = sX[0 * SJ_STRIDE + r]; in.JI_r1 = sX[1 * SJ_STRIDE + r];
-    in.Jab_r0 = sX[2 * SJ_STRIDE + r]; in.Jab_r1 = sX[3 * SJ_STRIDE + r];
-    in.rr = sX[4 * SJ_STRIDE + r];
-    const bool use = sX[5 * SJ_STRIDE + r] != 0.f;
-    float v[12];
-    switch (part) {
-      case 0: top_values12<0>(in, v); break;
-      case 1: top_values12<1>(in, v); break;
-      case 2: top_values12<2>(in, v); break;
-      case 3: top_values12<3>(in, v); break;
-      case 4: top_values12<4>(in, v); break;
-      case 5: top_values12<5>(in, v); break;
-      case 6: top_values12<6>(in, v); break;
-      default: top_values12<7>(in, v); break;
-    }
-#pragma unroll
-    for (int k = 0; k < 12; k++) {
-      float a = use ? v[k] : 0.f;
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-      v[k] = a;
-    }
-    if (r == 0) {
-      float4 *o = reinterpret_cast<float4 *>(fuse_top + (size_t)tile * SOS_TOPN + 12 * part);
-      o[0] = make_float4(v[0], v[1], v[2], v[3]);
-      o[1] = make_float4(v[4], v[5], v[6], v[7]);
-      o[2] = make_float4(v[8], v[9], v[10], v[11]);
-    }
-    LIN_STAMP(6);
-    return;  // the tile itself stays on chip
-  }
-
-  // ---- copy the staged tile out: 72 rows x 128 B, contiguous 9216 B span of J
-  float *Jt = d.J + (size_t)tile * SOS_TILE_FLOATS;
-  const unsigned linmask = sLin;
-  for (int q = tid; q < SOS_JPLANES * 8; q += 256) {
-    const int plane = q >> 3, chunk = q & 7;
-    const float4 v = *reinterpret_cast<const float4 *>(&sJ[plane * SJ_STRIDE + 4 * chunk]);
-    float *dst = Jt + plane * SOS_TILE + 4 * chunk;
-    const unsigned lm = (linmask >> (4 * chunk)) & 0xfu;
-    if (lm == 0) {
-      *reinterpret_cast<float4 *>(dst) = v;
-    } else {  // keep the frozen Jacobian of linearized residuals sharing this tile (rare)
-      if (!(lm & 1u)) dst[0] = v.x;
-      if (!(lm & 2u)) dst[1] = v.y;
-      if (!(lm & 4u)) dst[2] = v.z;
-      if (!(lm & 8u)) dst[3] = v.w;
-    }
-  }
-  LIN_STAMP(6);
-}
-
 template <int HALF>
 __device__ __forceinline__ void bfly_step(float *v, int m, bool hi);
 
@@ -594,7 +247,7 @@ template <bool FUSED, bool SCALAR1>
 __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(const float4 *__restrict__ a_r_geo, const float *__restrict__ a_r_cw,
                                                                const float4 *__restrict__ a_t_pre, const float *const *__restrict__ a_t_img,
                                                                int a_ntilesA, int a_lin_nd, BaDev d, const float *__restrict__ frameTH,
-                                                               int doApply, float *__restrict__ fuse_top_, DoneSignal sg) {
+                                                               int doApply, float *__restrict__ fuse_top_) {
   // the leading scalar arguments (what the first loads of a block need) arrive preloaded in SGPRs
   // (-amdgpu-kernarg-preload-count): the block does not wait for the kernel-argument segment before its first requests
   float *__restrict__ const fuse_top = FUSED ? fuse_top_ : nullptr;
@@ -1059,7 +712,6 @@ __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(const float4 *
     }
   }
   // everything the host reads (tile energies, newest-frame energies) was stored by the phase-2 wave
-  if (sg.ctr && wave == w2 && lane == 0) signal_block_done(sg);
   if (fuse_top) {
     // ---- the 13x13 block sums of each tile on the matrix cores: D (16x16) = sum over the tile's 64 rows L^T R,
     // v_mfma_f32_16x16x4_f32 x 16, one wave per tile
@@ -2233,71 +1885,6 @@ __global__ __launch_bounds__(64) void k_abs_stitch2(AbsStitchArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// The three launches above as ONE (SOS_ABS_COOP=1, opt-in): a grid of co-resident 256-thread workgroups (one per compute unit) walks
-// the chunks, then the blocks of the reduce / stitch-1 stage, then those of stitch-2, with a device-wide barrier between the stages.
-// At window sizes every stage is at most one partially filled round of blocks whose duration is launch + one block's dependency chain
-// (DESIGN.md 11): two barriers replace two launch gaps and the one-thread publish kernel.  The barrier is an arrival counter that only
-// grows (target = base + stage * grid) and every wait is BOUNDED: a workgroup that waits longer than the spin limit raises `fail`,
-// everybody leaves, the completion flag is never raised and the host's wait_flag falls back to the stream (SOS_ERR_HIP) -- a barrier
-// that does not release cannot hang the device.  Stage s + 1 reads what other workgroups wrote in stage s: release = __threadfence()
-// before the arrival, acquire = __threadfence() after the wait (agent scope: L2 write-back / invalidate across the XCDs), the
-// pattern of fused_final_sum (csrc/sos_tracker.hip).
-// ------------------------------------------------------------------------------------------------
-struct GridBar {
-  unsigned *ctr;   // arrival counter (zeroed with the window's scratch slab; the host tracks `base`)
-  int *fail;
-  unsigned base, spin_limit;
-};
-__device__ __forceinline__ bool grid_barrier(const GridBar &gb, unsigned stage) {
-  __shared__ int s_ok;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    atomicAdd(gb.ctr, 1u);
-    const unsigned target = gb.base + stage * gridDim.x;
-    unsigned spins = 0;
-    int ok = 1;
-    while ((int)(__hip_atomic_load(gb.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > gb.spin_limit || __hip_atomic_load(gb.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-        __hip_atomic_store(gb.fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = 0;
-        break;
-      }
-    }
-    __threadfence();
-    s_ok = ok;
-  }
-  __syncthreads();
-  return s_ok != 0;
-}
-__global__ __launch_bounds__(256) void k_abs_coop(BaDev d, const int *__restrict__ chunk_pt, int Dm, int ld, float *__restrict__ gram_part,
-                                                  const float *__restrict__ adHF, const float *__restrict__ adTF, int *flag, int seq, AbsStitchArgs a,
-                                                  GridBar gb) {
-  if (flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int n = a.n, T = Dm >> 4;
-  for (int vb = blockIdx.x; vb < a.nchunks; vb += gridDim.x) {
-    gram_abs_body(d, vb, chunk_pt, Dm, ld, gram_part, adHF, adTF, smem);
-    __syncthreads();  // the next chunk rewrites the staging area
-  }
-  if (!grid_barrier(gb, 1)) return;
-  const int nb1 = n * n + T * (T + 1) / 2 * 16;
-  for (int vb = blockIdx.x; vb < nb1; vb += gridDim.x) {
-    abs_rs1_body(a, vb);
-    __syncthreads();
-  }
-  if (!grid_barrier(gb, 2)) return;
-  const int nb2 = n * (n + 1) / 2 + 1;
-  for (int vb = blockIdx.x; vb < nb2; vb += gridDim.x) {
-    abs_st2_body(a, vb);
-    __syncthreads();
-  }
-  if (a.sg.ctr) {  // completion: every workgroup arrives once, the last raises the host's flag
-    __syncthreads();
-    if (threadIdx.x == 0) signal_block_done(a.sg);
-  }
-}
 __global__ void k_copy_f64(double *__restrict__ dst, const double *__restrict__ src, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[i];
@@ -2695,51 +2282,6 @@ __global__ __launch_bounds__(SOS_RSB) void k_resub_devstep(BaDev d, const float 
   }
   resub_point_block(d, nullptr, adHF, adTF, step_out, stepfacD, nullptr, sxAd, g.xd);
 }
-// The same launch enqueued BEFORE the solve (sos_ba_gn_step_prelaunch, opt-in): every workgroup waits for the host's x in a mailbox in
-// device-mapped host memory -- {x[dim], flag} -- instead of receiving it as a kernel argument, so that the launch latency of the step
-// (and of the linearisation and the next accumulate queued behind it) is off the path between the host's solve and the device's
-// back-substitution.  The wait is bounded: a workgroup that gives up raises `fail` (mapped) and steps with x = 0 (the state stays where it
-// is); the host reports the call as failed.
-struct StepMail {
-  const double *x;   // mapped host memory
-  const int *flag;   // ... raised to `seq` by sos_ba_gn_step_deliver after x is written
-  int *fail;
-  int seq;
-  unsigned spin_limit;
-};
-__global__ __launch_bounds__(SOS_RSB) void k_resub_devstep_wait(BaDev d, const float *__restrict__ adHF, const float *__restrict__ adTF,
-                                                            float *__restrict__ step_out, float stepfacD, int nPointBlocks, DevStep g,
-                                                            float4 *__restrict__ t_pre, StepMail m) {
-  extern __shared__ __attribute__((aligned(16))) float sxAd[];
-  __shared__ double sxd[SOS_CPARS + 8 * 17];
-  __shared__ int s_have;
-  const int dim = SOS_CPARS + 8 * d.n;
-  if (threadIdx.x == 0) {
-    unsigned spins = 0;
-    int have = 1;
-    while (__hip_atomic_load(m.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != m.seq) {
-      __builtin_amdgcn_s_sleep(4);
-      if (++spins > m.spin_limit) {
-        __hip_atomic_store(m.fail, m.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        have = 0;
-        break;
-      }
-    }
-    s_have = have;
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < dim; i += SOS_RSB) sxd[i] = s_have ? __hip_atomic_load(m.x + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0;
-  __syncthreads();
-  if ((int)blockIdx.x >= nPointBlocks) {
-    devstep_block((int)blockIdx.x - nPointBlocks, (int)gridDim.x - nPointBlocks, d, g, adHF, adTF, t_pre, sxAd, sxd);
-    return;
-  }
-  resub_point_block(d, nullptr, adHF, adTF, step_out, stepfacD, nullptr, sxAd, sxd);
-}
-
-// ================================================================================================
-// fixLinearizationF (OB/EnergyFunctionalStructs.cpp:75-103): one thread per listed residual
-// ================================================================================================
 __global__ void k_fix_lin(BaDev d, const int *__restrict__ slist, int count) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= count) return;
@@ -3012,13 +2554,10 @@ struct sos_ba {
   bool top_valid = false;     // d_top_part holds the tile sums of the current linearisation (the last one ran fused and nothing changed since)
   bool fuse_only = false;     // sos_ba_set_prefetch(ba, 2): the linearisation forms the tile sums, nothing is enqueued behind it
   DevBuf<int> d_sigctr;       // [0] linearize launches, [1] stitch launches (cumulative block counters)
-  int sig_lin_blocks = 0, sig_lin_seq = 0, sig_st_seq = 0, sig_st_blocks_total = 0, sig_abs_blocks_total = 0;
-  unsigned coop_base = 0;  // arrivals the cooperative launches' barrier counter has seen (d_sigctr[28]; [29] = its fail flag)
+  int sig_lin_seq = 0, sig_st_seq = 0, sig_st_blocks_total = 0, sig_abs_blocks_total = 0;
   int acc_wait_seq = 0;    // sequence number the stitch of the accumulate to be consumed NEXT publishes
-  size_t pin_mail = 0;     // mailbox of a pre-launched step in the mapped block: (4 + 8 * 17) doubles of x, then flag and fail (ints)
-  int mail_seq = 0;
   struct StepPend {        // a step whose launches are enqueued and whose results have not been collected yet
-    bool active = false, prelaunched = false, prefetchEnqueued = false, havePointStep = false;
+    bool active = false, prefetchEnqueued = false, havePointStep = false;
     int waitSeq = 0;
     float stepfacD = 0;
     double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
@@ -3404,8 +2943,7 @@ extern "C" int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, i
   {
     const size_t need_stage = sizeof(float) * ba->st_floats, need_out = ba->out_bytes,
                  need_hb = sizeof(double) * 3 * ba->hb_mode_stride + 16 + 128;  // + completion flags
-    const size_t need_mail = sizeof(double) * (SOS_CPARS + 8 * 17) + 64;
-    const size_t tot = need_stage + need_out + need_hb + 256 + need_mail + 64;
+    const size_t tot = need_stage + need_out + need_hb + 256 + 64;
     if (tot > ba->pin_bytes) {
       if (ba->pin) hipHostFree(ba->pin);
       ba->pin = nullptr;
@@ -3418,14 +2956,11 @@ extern "C" int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, i
     ba->pin_out = (need_stage + 63) / 64 * 64;
     ba->pin_hb = ba->pin_out + (need_out + 63) / 64 * 64;
     ba->pin_flags = ba->pin_hb + (sizeof(double) * 3 * ba->hb_mode_stride + 16 + 63) / 64 * 64;
-    ba->pin_mail = ba->pin_flags + 128;
-    memset(ba->pin + ba->pin_flags, 0, 128 + need_mail);
+    memset(ba->pin + ba->pin_flags, 0, 128);
   }
   ba->sig_lin_seq = ba->sig_st_seq = 0;
-  ba->sig_lin_blocks = ba->sig_st_blocks_total = ba->sig_abs_blocks_total = 0;
-  ba->coop_base = 0;
+  ba->sig_st_blocks_total = ba->sig_abs_blocks_total = 0;
   ba->acc_wait_seq = 0;
-  ba->mail_seq = 0;
   ba->pend = sos_ba::StepPend();
 
   BaDev &d = ba->dev;
@@ -3610,15 +3145,9 @@ static void launch_expand_precalc(sos_ba *ba) {  // from the device copy of prec
                                                                              ba->d_t_pre.p);
 }
 
-// SOS_LINEARIZE_V1=1 selects the original one-tile-per-block kernel (kept for A/B measurements and as the reference
-// the restructured kernel is checked against bit for bit)
-static bool lin_v1() {
-  static const bool v = getenv("SOS_LINEARIZE_V1") != nullptr;
-  return v;
-}
 // host side of DoneSignal: poll the mapped flag; after 50 ms fall back to a stream synchronisation (a failed launch
 // must not hang the caller)
-static int wait_flag(sos_ba *ba, size_t flag_off, int seq, bool flagOnly = false) {
+static int wait_flag(sos_ba *ba, size_t flag_off, int seq) {
   int *flag = reinterpret_cast<int *>(ba->pin + flag_off);
   const double t0 = now_s();
   unsigned spins = 0;
@@ -3626,9 +3155,7 @@ static int wait_flag(sos_ba *ba, size_t flag_off, int seq, bool flagOnly = false
     __builtin_ia32_pause();
     if ((++spins & 4095u) == 0) {
       const double dt = now_s() - t0;
-      if (flagOnly) {  // a pre-launched step sits on the stream waiting for x: synchronising the stream here would wait for ourselves
-        if (dt > 30.0) return SOS_ERR_HIP;
-      } else if (dt > 0.05) {
+      if (dt > 0.05) {
         SOS_HIP(hipStreamSynchronize(ba->ctx->stream));
         return __atomic_load_n(flag, __ATOMIC_ACQUIRE) >= seq ? SOS_OK : SOS_ERR_HIP;
       }
@@ -3648,43 +3175,24 @@ static int lin_ncu(sos_ba *ba) {
 }
 static int lin_grid(sos_ba *ba, int *nd) {
   const int ncu = lin_ncu(ba);
-  static const char *ov = getenv("SOS_LIN_ND");  // experiment knob: number of two-tile blocks (-1 = all)
   const int T = ba->ntilesA, q = divup(T, ncu);
   int n2 = divup(T, L2_TILES);
-  if (ov && atoi(ov) >= 0) n2 = std::min(atoi(ov), T / 2);
-  else if (!ov && (q & 1) && q >= 3) n2 = std::min(T / 2, ncu * (q - 1) / 2);
+  if ((q & 1) && q >= 3) n2 = std::min(T / 2, ncu * (q - 1) / 2);
   *nd = n2;
   return n2 + std::max(0, T - L2_TILES * n2);
 }
 // returns the sequence number to wait for (0 = this launch does not signal)
 static int launch_lin_kernel(sos_ba *ba, const BaDev &dv, int mode, float *fuse_top, bool signal = false, bool deferPublish = false) {
   if (ba->ntilesA <= 0) return 0;
-  if (lin_v1()) {
-    k_linearize<<<ba->ntilesA, 256, 0, ba->ctx->stream>>>(dv, stg(ba, ba->st_th), mode, fuse_top);
-    return 0;
-  }
   int nd;
   const int nb = lin_grid(ba, &nd);
   BaDev dv2 = dv;
   dv2.lin_nd = nd;
-  DoneSignal sg = {nullptr, nullptr, 0, 0};
-  static const bool inKernel = getenv("SOS_SIGNAL_IN_KERNEL") != nullptr;  // per-block fences: measured slower
-  int seq = 0;
-  if (signal) {
-    seq = ++ba->sig_lin_seq;
-    if (inKernel) {
-      ba->sig_lin_blocks += nb;
-      sg.ctr = ba->d_sigctr.p;
-      sg.flag = reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags);
-      sg.target = ba->sig_lin_blocks;
-      sg.seq = seq;
-    }
-  }
+  const int seq = signal ? ++ba->sig_lin_seq : 0;
   // one round of resident blocks (3 per CU)?  then the scalar-cache form of the first loads
-  static const char *sc1 = getenv("SOS_LIN_SCALAR1");  // experiment knob: 0 / 1 overrides the rule
-  const bool scalar1 = sc1 ? atoi(sc1) != 0 : nb <= 3 * lin_ncu(ba);
+  const bool scalar1 = nb <= 3 * lin_ncu(ba);
 #define SOS_LAUNCH_LIN2(F, S1, FT) \
-  k_linearize2<F, S1><<<nb, 256 * L2_TILES, 0, ba->ctx->stream>>>(dv2.r_geo, dv2.r_cw, dv2.t_pre, dv2.t_img, dv2.ntilesA, nd, dv2, stg(ba, ba->st_th), mode, FT, sg)
+  k_linearize2<F, S1><<<nb, 256 * L2_TILES, 0, ba->ctx->stream>>>(dv2.r_geo, dv2.r_cw, dv2.t_pre, dv2.t_img, dv2.ntilesA, nd, dv2, stg(ba, ba->st_th), mode, FT)
   if (fuse_top && mode == 1) {
     if (scalar1) SOS_LAUNCH_LIN2(true, true, fuse_top);
     else SOS_LAUNCH_LIN2(true, false, fuse_top);
@@ -3693,7 +3201,7 @@ static int launch_lin_kernel(sos_ba *ba, const BaDev &dv, int mode, float *fuse_
     else SOS_LAUNCH_LIN2(false, false, nullptr);
   }
 #undef SOS_LAUNCH_LIN2
-  if (signal && !inKernel && !deferPublish) k_publish<<<1, 1, 0, ba->ctx->stream>>>(reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags), seq);
+  if (signal && !deferPublish) k_publish<<<1, 1, 0, ba->ctx->stream>>>(reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags), seq);
   return seq;
 }
 static int launch_linearize(sos_ba *ba, int doApply) {
@@ -3996,7 +3504,7 @@ static int launch_stitch(sos_ba *ba, const float *acc, int nmodes, double *Hout 
   const int nb2 = (n * (n + 1) / 2 + 1) * nmodes + n * n + 1;
   // (SOS_STITCH_SIGNAL_IN_KERNEL: only this chain's last kernel signals by itself -- ~160 blocks with one system fence each against the
   // 4 us one-thread k_publish behind it; the linearisation keeps its chained publish, whose in-kernel form was measured slower)
-  static const bool inKernel = getenv("SOS_SIGNAL_IN_KERNEL") != nullptr || getenv("SOS_STITCH_SIGNAL_IN_KERNEL") != nullptr;
+  static const bool inKernel = getenv("SOS_STITCH_SIGNAL_IN_KERNEL") != nullptr;
   if (toDevice) {  // the device-resident loop: upper triangles + counts into d_Hout, nobody polls
     a.H = ba->d_Hout.p;
     a.nres_out = reinterpret_cast<float *>(ba->d_Hout.p + 3 * ba->hb_mode_stride);
@@ -4088,7 +3596,7 @@ extern "C" int sos_ba_accumulate(sos_ba *ba, double *H_A, double *b_A, double *H
 static bool abs_path_ok(const sos_ba *ba) {
   // PENDING_FIRST_GPU_RUN: opt-in (SOS_ABS_SC=1) until the GPU suite has run on it (executed under tests/emu in round 4: at par with the reference's fp32
   // arithmetic from T6 up, 3.2x further from the fp64 step at T4)
-  static const bool off = getenv("SOS_ABS_SC") == nullptr || getenv("SOS_NO_ABS_SC") != nullptr;
+  static const bool off = getenv("SOS_ABS_SC") == nullptr;
   return !off && ba->ntiles == ba->ntilesA && ba->ntilesA > 0 && ba->nchunks > 0 && !(ba->comm && (ba->anyL || ba->anyEmpty)) && ba->d_adHostF.p &&
          ba->d_adTargetF.p;
 }
@@ -4108,10 +3616,8 @@ static int enqueue_gn_accumulate_abs(sos_ba *ba, bool topDone, int *pubFlag, int
     k_top_accumulate<false><<<divup(ba->ntilesA, 8), 256, 0, st>>>(ba->dev, 0, ba->ntilesA, 0, nullptr, nullptr, ba->d_top_part.p, nullptr);
     pubFlag = nullptr;
   }
-  static const bool coop = getenv("SOS_ABS_COOP") != nullptr;  // opt-in: ONE cooperative launch for the three stages (never run on an MI355X yet)
-  if (!coop)
-    k_sc_gram_abs<<<ba->nchunks, 256, lds, st>>>(ba->dev, ba->d_chunk_pt.p, ba->Dm, ba->ld, ba->d_gram_part.p, ba->d_adHostF.p, ba->d_adTargetF.p,
-                                                 pubFlag, pubSeq);
+  k_sc_gram_abs<<<ba->nchunks, 256, lds, st>>>(ba->dev, ba->d_chunk_pt.p, ba->Dm, ba->ld, ba->d_gram_part.p, ba->d_adHostF.p, ba->d_adTargetF.p,
+                                               pubFlag, pubSeq);
   AbsStitchArgs a;
   a.n = n; a.Dm = ba->Dm; a.nchunks = ba->nchunks;
   a.top_part = ba->d_top_part.p; a.pair_tile_begin = ba->d_pair_tile_begin.p; a.gram_part = ba->d_gram_part.p;
@@ -4122,34 +3628,21 @@ static int enqueue_gn_accumulate_abs(sos_ba *ba, bool topDone, int *pubFlag, int
   a.H = ba->comm ? ba->d_Hout.p : pinH;
   a.mode_stride = ms;
   const int T = ba->Dm >> 4;
-  if (!coop) k_abs_reduce_stitch1<<<(int)nn + T * (T + 1) / 2 * 16, 128, 0, st>>>(a);
-  // completion: a k_publish behind the last kernel, or (A/B knob) the last block of k_abs_stitch2 itself -- 80 blocks, one
-  // system-scope fence each; H_sc was written by the previous launch and is visible at its end
-  static const bool inKernel = getenv("SOS_ABS_SIGNAL_IN_KERNEL") != nullptr;
+  k_abs_reduce_stitch1<<<(int)nn + T * (T + 1) / 2 * 16, 128, 0, st>>>(a);
+  // completion: a k_publish behind the last kernel, or (SOS_STITCH_SIGNAL_IN_KERNEL, A/B knob) the last block of k_abs_stitch2 itself --
+  // 80 blocks, one system-scope fence each; H_sc was written by the previous launch and is visible at its end
+  static const bool inKernel = getenv("SOS_STITCH_SIGNAL_IN_KERNEL") != nullptr;
   const int nb2 = n * (n + 1) / 2 + 1;
-  const int G = coop ? lin_ncu(ba) : 0;  // cooperative form: one workgroup per compute unit, all resident
   a.sg = {nullptr, nullptr, 0, 0};
   ++ba->sig_st_seq;
-  if ((inKernel || coop) && !ba->comm) {
-    ba->sig_abs_blocks_total += coop ? G : nb2;
+  if (inKernel && !ba->comm) {
+    ba->sig_abs_blocks_total += nb2;
     a.sg.ctr = ba->d_sigctr.p + 24;
     a.sg.flag = reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags + 64);
     a.sg.target = ba->sig_abs_blocks_total;
     a.sg.seq = ba->sig_st_seq;
   }
-  if (coop) {
-    static bool attr2 = false;
-    if (!attr2) {
-      hipFuncSetAttribute(reinterpret_cast<const void *>(k_abs_coop), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      attr2 = true;
-    }
-    static const unsigned spinLimit = getenv("SOS_COOP_SPIN_LIMIT") ? (unsigned)atoi(getenv("SOS_COOP_SPIN_LIMIT")) : (1u << 20);
-    GridBar gb = {reinterpret_cast<unsigned *>(ba->d_sigctr.p + 28), ba->d_sigctr.p + 29, ba->coop_base, spinLimit};
-    ba->coop_base += 2u * (unsigned)G;
-    k_abs_coop<<<G, 256, lds, st>>>(ba->dev, ba->d_chunk_pt.p, ba->Dm, ba->ld, ba->d_gram_part.p, ba->d_adHostF.p, ba->d_adTargetF.p, pubFlag, pubSeq, a, gb);
-  } else {
-    k_abs_stitch2<<<nb2, 64, 0, st>>>(a);
-  }
+  k_abs_stitch2<<<nb2, 64, 0, st>>>(a);
   if (ba->comm) {  // THE exchange step of the path, on the stitched fp64 system (the stitch is linear): [H_A b_A | H_sc b_sc | count]
     const int rcc = sos_comm_allreduce_sum_f64(ba->comm, ba->d_Hout.p, 2 * ms + 1, st);
     if (rcc) return rcc;
@@ -4212,7 +3705,6 @@ extern "C" int sos_ba_gn_accumulate(sos_ba *ba, double *H_top, double *b_top, do
   if (!ba || !ba->have_window || !ba->have_state || !H_top || !b_top || !H_sc || !b_sc) return SOS_ERR_STATE;
   SOS_HIP(hipSetDevice(ba->ctx->device));
   if (!ba->acc_inflight) {  // otherwise the previous sos_ba_gn_step already enqueued it (sos_ba_set_prefetch)
-    if (ba->pend.active && ba->pend.prelaunched) return SOS_ERR_STATE;  // (it would queue behind a step that waits for this very result)
     enqueue_gn_accumulate(ba, ba->top_valid);
     SOS_HIP(hipGetLastError());
   }
@@ -4220,7 +3712,7 @@ extern "C" int sos_ba_gn_accumulate(sos_ba *ba, double *H_top, double *b_top, do
   const bool haveL = ba->acc_inflight_haveL;
   const double ta = now_s();
   {
-    const int rcw = wait_flag(ba, ba->pin_flags + 64, ba->acc_wait_seq, ba->pend.active && ba->pend.prelaunched);
+    const int rcw = wait_flag(ba, ba->pin_flags + 64, ba->acc_wait_seq);
     if (rcw) return rcw;
   }
   ba->tm[6] += now_s() - ta;
@@ -4340,17 +3832,17 @@ extern "C" int sos_ba_gn_resub(sos_ba *ba, const double *x, float stepfacD) {
 
 // Back half of a fused iteration: linearizeAll(false) + applyRes on the state the stream has reached, the next
 // iteration's accumulate chain enqueued behind it (sos_ba_set_prefetch), results through the mapped block.
-static int lin_apply_enqueue(sos_ba *ba, BaDev &dv, int applyRes, bool havePointStep, float stepfacD, double t0, double t1, bool deferPrefetch = false) {
+static int lin_apply_enqueue(sos_ba *ba, BaDev &dv, int applyRes, bool havePointStep, float stepfacD, double t0, double t1) {
   sos_ctx *c = ba->ctx;
   hipStream_t st = c->stream;
   // nobody reads the original-order copies of the per-residual results in a fused iteration (they are scattered 1..12 byte
   // stores, one partial line each): only the two-step sos_ba_linearize delivers them
   dv.o_newstate = nullptr; dv.o_newenergy = nullptr; dv.o_newenergywo = nullptr; dv.o_center = nullptr;
   // pipelined iterations of a window without linearised residuals reduce the tiles on chip (no J traffic at all)
-  const bool fuseTop = (ba->prefetch || ba->fuse_only) && applyRes && ba->ntiles == ba->ntilesA && !lin_v1();
+  const bool fuseTop = (ba->prefetch || ba->fuse_only) && applyRes && ba->ntiles == ba->ntilesA;
   // when the next accumulate is enqueued right behind, its first kernel publishes this step's completion
   // (with a communicator the all-gathered energies are copied out behind the linearisation; the chained publish then follows them)
-  const bool chainPublish = ba->prefetch && applyRes && !lin_v1() && getenv("SOS_SIGNAL_IN_KERNEL") == nullptr && getenv("SOS_NO_CHAIN_PUBLISH") == nullptr;
+  const bool chainPublish = ba->prefetch && applyRes;
   int waitSeq = launch_lin_kernel(ba, dv, applyRes ? 1 : 0, fuseTop ? ba->d_top_part.p : nullptr, ba->comm == nullptr, chainPublish);
   if (ba->comm) {  // energies of the newest frame of ALL ranks (same frameEnergyTH everywhere), then tell the host
     const int tot = ba->newest_cap * ba->comm_size;
@@ -4368,7 +3860,7 @@ static int lin_apply_enqueue(sos_ba *ba, BaDev &dv, int applyRes, bool havePoint
   pd.waitSeq = waitSeq; pd.havePointStep = havePointStep; pd.stepfacD = stepfacD;
   pd.t0 = t0; pd.t1 = t1; pd.t2 = now_s(); pd.t3 = pd.t2;
   pd.fuseTop = fuseTop; pd.chainPublish = chainPublish; pd.applyRes = applyRes != 0;
-  pd.prefetchEnqueued = ba->prefetch && applyRes && !deferPrefetch;
+  pd.prefetchEnqueued = ba->prefetch && applyRes;
   if (pd.prefetchEnqueued) {  // the next iteration's accumulate + stitch runs while the host digests this step
     if (!waitSeq) SOS_HIP(hipEventRecord(ba->ev_step, st));
     enqueue_gn_accumulate(ba, fuseTop, chainPublish ? reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags) : nullptr, waitSeq);
@@ -4384,10 +3876,9 @@ static int lin_apply_finish(sos_ba *ba, double *energySum, float *newestEnergies
   char *po = ba->pin + ba->pin_out;
   sos_ba::StepPend &pd = ba->pend;
   const int waitSeq = pd.waitSeq;
-  const bool flagOnly = pd.prelaunched;
   pd.active = false;
   if (waitSeq) {
-    const int rcw = wait_flag(ba, ba->pin_flags, waitSeq, flagOnly);
+    const int rcw = wait_flag(ba, ba->pin_flags, waitSeq);
     if (rcw) return rcw;
   } else if (pd.prefetchEnqueued) {
     SOS_HIP(hipEventSynchronize(ba->ev_step));
@@ -4426,7 +3917,6 @@ static int lin_apply_finish(sos_ba *ba, double *energySum, float *newestEnergies
 }
 static int lin_apply_tail(sos_ba *ba, BaDev &dv, int applyRes, bool havePointStep, float stepfacD, double *energySum,
                           float *newestEnergies, int *newestCount, float *pointStep, double t0, double t1) {
-  ba->pend.prelaunched = false;
   const int rc = lin_apply_enqueue(ba, dv, applyRes, havePointStep, stepfacD, t0, t1);
   if (rc) { ba->pend.active = false; return rc; }
   return lin_apply_finish(ba, energySum, newestEnergies, newestCount, pointStep);
@@ -4511,105 +4001,6 @@ extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const
     stage_in(ba, ba->st_xc);
   }
   return lin_apply_tail(ba, dv, applyRes, x != nullptr || resubAhead, stepfacD, energySum, newestEnergies, newestCount, pointStep, t0, t1);
-}
-
-// The device-side step of sos_ba_gn_step enqueued BEFORE the solve (opt-in; see k_resub_devstep_wait): back-substitution + step +
-// linearisation + (sos_ba_set_prefetch) the next accumulate go onto the stream behind the accumulate whose H / b the host is about to
-// solve; sos_ba_gn_step_deliver hands x over through the mailbox and collects the step's results.  Between the two calls the stream
-// must not be synchronised (sos_ba_gn_accumulate knows).  SOS_ERR_STATE = not possible now (no device-side step, a communicator, no
-// accumulate in flight to queue behind): the caller uses sos_ba_gn_step as before.
-extern "C" int sos_ba_gn_step_prelaunch(sos_ba *ba, float stepfacD, const float *frameEnergyTH, int applyRes) {
-  if (!ba || !ba->have_window || !ba->have_state || !frameEnergyTH || !ba->devstep || ba->comm || ba->pend.active) return SOS_ERR_STATE;
-  if (!(ba->P > 0 && ba->d_adHostF.p && ba->d_adTargetF.p && ba->ds_n == ba->n) || !ba->acc_inflight || ba->ntilesA <= 0 || lin_v1()) return SOS_ERR_STATE;
-  sos_ctx *c = ba->ctx;
-  SOS_HIP(hipSetDevice(c->device));
-  hipStream_t st = c->stream;
-  const size_t nn = (size_t)ba->n * ba->n;
-  // the bookkeeping of the accumulate that is still to be consumed (sos_ba_gn_accumulate) is set aside while the launches below write
-  // that of the next one
-  const bool cur_inflight = ba->acc_inflight, cur_haveL = ba->acc_inflight_haveL, cur_abs = ba->acc_inflight_abs, cur_top = ba->top_valid, cur_J = ba->J_valid;
-  const int cur_seq = ba->acc_wait_seq;
-  ba->acc_inflight = false, ba->top_valid = false;
-  const double t0 = now_s();
-  char *po_dev = ba->pin_dev + ba->pin_out;
-  float *dstep = reinterpret_cast<float *>(po_dev + ba->out_step);
-  BaDev dv = ba->dev;
-  dv.tile_esum = reinterpret_cast<double *>(po_dev + ba->out_esum);
-  dv.o_newest = reinterpret_cast<float *>(po_dev + ba->out_newest);
-  const double t1 = now_s();
-  const int n = ba->n;
-  DevStep g;
-  memset(g.xd, 0, sizeof(g.xd));  // (x arrives through the mailbox)
-  for (int i = 0; i < n; i++) g.th[i] = frameEnergyTH[i];
-  double *b = ba->d_ds;
-  g.evalC2W = b; g.state_zero = b + 12 * n;
-  g.state_in = b + 22 * n + 10 * n * ba->ds_cur; g.state_out = b + 22 * n + 10 * n * (ba->ds_cur ^ 1);
-  g.calib_in = b + 42 * n + 8 * ba->ds_cur; g.calib_out = b + 42 * n + 8 * (ba->ds_cur ^ 1);
-  g.abexp = b + 42 * n + 16;
-  ba->ds_cur ^= 1;
-  g.stage = ba->d_stage.p;
-  g.st_pre = ba->st_pre; g.st_adh = ba->st_adh; g.st_cd = ba->st_cd; g.st_th = ba->st_th; g.st_cal = ba->st_cal;
-  const int nPB = divup(ba->P, SOS_RSB), nEB = std::max(1, divup(8 * ba->ntiles, SOS_RSB));
-  const size_t lds = std::max(sizeof(float) * (8 * nn + 4 + 8 * (size_t)n), sizeof(float) * (28 * nn + 16) + sizeof(double) * (34 * (size_t)n + 8));
-  char *mail = ba->pin_dev + ba->pin_mail;
-  const size_t flagOff = sizeof(double) * (SOS_CPARS + 8 * 17);
-  static const unsigned spinLimit = getenv("SOS_PRELAUNCH_SPIN_LIMIT") ? (unsigned)atoi(getenv("SOS_PRELAUNCH_SPIN_LIMIT")) : (1u << 22);
-  StepMail m = {reinterpret_cast<const double *>(mail), reinterpret_cast<const int *>(mail + flagOff), reinterpret_cast<int *>(mail + flagOff + 4), ++ba->mail_seq, spinLimit};
-  ba->tm[1] += now_s() - t1;
-  k_resub_devstep_wait<<<nPB + nEB, SOS_RSB, lds, st>>>(dv, ba->d_adHostF.p, ba->d_adTargetF.p, dstep, stepfacD, nPB, g, ba->d_t_pre.p, m);
-  ba->pend.prelaunched = true;
-  const int rc = lin_apply_enqueue(ba, dv, applyRes, true, stepfacD, t0, t1, true);
-  sos_ba::StepPend &pd = ba->pend;
-  pd.prelaunched = true;
-  ba->acc_inflight = cur_inflight; ba->acc_inflight_haveL = cur_haveL; ba->acc_inflight_abs = cur_abs; ba->top_valid = cur_top; ba->J_valid = cur_J;
-  ba->acc_wait_seq = cur_seq;
-  if (rc) {  // (nothing failed that left the waiter without a delivery: hand it x = 0 and drain)
-    pd.active = true;
-    sos_ba_gn_step_deliver(ba, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-    return rc;
-  }
-  return SOS_OK;
-}
-// x == NULL: cancel (a failed solve): the waiting step runs with x = 0 -- the state stays where it is -- and is drained
-extern "C" int sos_ba_gn_step_deliver(sos_ba *ba, const double *x, const sos_calib *calib, double *energySum, float *newestEnergies, int *newestCount,
-                                      float *pointStep) {
-  if (!ba || !ba->pend.active || !ba->pend.prelaunched) return SOS_ERR_STATE;
-  if (calib) {
-    ba->calib = *calib;
-    ba->dev.calib = *calib;
-  }
-  const int dim = 4 + 8 * ba->n;
-  char *mail = ba->pin + ba->pin_mail;
-  const size_t flagOff = sizeof(double) * (SOS_CPARS + 8 * 17);
-  double *mx = reinterpret_cast<double *>(mail);
-  static const int testDelayUs = getenv("SOS_PRELAUNCH_TEST_DELAY_US") ? atoi(getenv("SOS_PRELAUNCH_TEST_DELAY_US")) : 0;  // test knob: the step really waits
-  if (testDelayUs > 0) {
-    const double td = now_s();
-    while ((now_s() - td) * 1e6 < testDelayUs) __builtin_ia32_pause();
-  }
-  for (int i = 0; i < dim; i++) mx[i] = x ? x[i] : 0.0;
-  __atomic_store_n(reinterpret_cast<int *>(mail + flagOff), ba->mail_seq, __ATOMIC_RELEASE);
-  sos_ba::StepPend &pd = ba->pend;
-  // the step is running: what sos_ba_gn_step enqueues behind its linearisation follows now -- the next iteration's accumulate when the
-  // caller says there is one (sos_ba_set_prefetch, decided after the solve), otherwise the publish the linearisation left to it.  These
-  // launches overlap the step's kernels.
-  ba->J_valid = !pd.fuseTop;
-  ba->top_valid = pd.fuseTop;
-  ba->acc_inflight = false;
-  if (x && ba->prefetch && pd.applyRes) {
-    if (!pd.waitSeq) hipEventRecord(ba->ev_step, ba->ctx->stream);
-    enqueue_gn_accumulate(ba, pd.fuseTop, pd.chainPublish ? reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags) : nullptr, pd.waitSeq);
-    ba->acc_inflight = true;
-    pd.prefetchEnqueued = true;
-    pd.t3 = now_s();
-  } else if (pd.chainPublish && pd.waitSeq) {
-    k_publish<<<1, 1, 0, ba->ctx->stream>>>(reinterpret_cast<int *>(ba->pin_dev + ba->pin_flags), pd.waitSeq);
-  }
-  int rc = lin_apply_finish(ba, energySum, newestEnergies, newestCount, pointStep);
-  pd.prelaunched = false;
-  if (rc == SOS_OK && __atomic_load_n(reinterpret_cast<int *>(mail + flagOff + 4), __ATOMIC_ACQUIRE) == ba->mail_seq) rc = SOS_ERR_TIMEOUT;  // a workgroup gave up waiting
-  if (!x && rc == SOS_OK) rc = SOS_ERR_STATE;
-  return rc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -4724,7 +4115,7 @@ extern "C" int sos_ba_linearize_final(sos_ba *ba, const float *frameEnergyTH, in
 
 extern "C" int sos_ba_gn_devstep_begin(sos_ba *ba, const sos_gn_frame *frames, const double *calib_value4, const double *calib_value_zero4) {
   if (!ba || !frames || !calib_value4 || !calib_value_zero4) return SOS_ERR_ARG;
-  if (!ba->have_window || !ba->have_state || ba->n < 1 || ba->n > 17 || ba->P <= 0 || !ba->d_adHostF.p || !ba->d_adTargetF.p || lin_v1())
+  if (!ba->have_window || !ba->have_state || ba->n < 1 || ba->n > 17 || ba->P <= 0 || !ba->d_adHostF.p || !ba->d_adTargetF.p)
     return SOS_ERR_STATE;
   SOS_HIP(hipSetDevice(ba->ctx->device));
   const int n = ba->n;
@@ -4973,7 +4364,7 @@ extern "C" int sos_ba_time_kernel(sos_ba *ba, const char *kernel, const float *f
       if (ba->nchunks > 0) k_sc_gram_prep<<<ba->nchunks, 256, gram_lds(ba), st>>>(ba->dev, ba->d_chunk_pt.p, ba->Dm, ba->ld, ba->d_gram_part.p, nullptr, 0);
       return SOS_OK;
     }
-    if (k == "sc_gram_abs" || k == "abs_reduce_stitch1" || k == "abs_stitch2" || k == "abs_coop") {  // the kernels of the absolute-coordinate Schur path, one at a time
+    if (k == "sc_gram_abs" || k == "abs_reduce_stitch1" || k == "abs_stitch2") {  // the kernels of the absolute-coordinate Schur path, one at a time
       if (!abs_path_ok(ba)) return SOS_OK;
       const int n = ba->n;
       const size_t nn = (size_t)n * n;
@@ -4991,15 +4382,6 @@ extern "C" int sos_ba_time_kernel(sos_ba *ba, const char *kernel, const float *f
       a.H = ba->d_Hout.p; a.mode_stride = ba->hb_mode_stride;
       a.sg = {nullptr, nullptr, 0, 0};
       const int T = ba->Dm >> 4;
-      if (k == "abs_coop") {  // the three stages as one cooperative launch (no completion signal: timed by the caller's events)
-        const int G = lin_ncu(ba);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_abs_coop), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        GridBar gb = {reinterpret_cast<unsigned *>(ba->d_sigctr.p + 28), ba->d_sigctr.p + 29, ba->coop_base, 1u << 20};
-        ba->coop_base += 2u * (unsigned)G;
-        k_abs_coop<<<G, 256, sizeof(float) * gram_abs_lds_floats(n, ba->ld), st>>>(ba->dev, ba->d_chunk_pt.p, ba->Dm, ba->ld, ba->d_gram_part.p,
-                                                                                  ba->d_adHostF.p, ba->d_adTargetF.p, nullptr, 0, a, gb);
-        return SOS_OK;
-      }
       if (k == "abs_reduce_stitch1") k_abs_reduce_stitch1<<<(int)nn + T * (T + 1) / 2 * 16, 128, 0, st>>>(a);
       else k_abs_stitch2<<<n * (n + 1) / 2 + 1, 64, 0, st>>>(a);
       return SOS_OK;

@@ -22,7 +22,7 @@ SYMBOLS = [
     "sos_frame_upload_dI", "sos_frame_download_level", "sos_frame_release", "sos_ba_create", "sos_ba_destroy",
     "sos_ba_set_window", "sos_ba_set_state", "sos_ba_linearize", "sos_ba_apply_res", "sos_ba_reset_oob",
     "sos_ba_fix_linearization", "sos_ba_accumulate", "sos_ba_accumulate_local", "sos_ba_acc_buffer",
-    "sos_ba_stitch", "sos_ba_gn_accumulate", "sos_ba_gn_accumulate_begin", "sos_ba_gn_step", "sos_ba_gn_step_prelaunch", "sos_ba_gn_step_deliver", "sos_ba_gn_resub", "sos_ba_get_point_hessian", "sos_ba_resubstitute", "sos_ba_calc_lenergy",
+    "sos_ba_stitch", "sos_ba_gn_accumulate", "sos_ba_gn_accumulate_begin", "sos_ba_gn_step", "sos_ba_gn_resub", "sos_ba_get_point_hessian", "sos_ba_resubstitute", "sos_ba_calc_lenergy",
     "sos_ba_accumulate_marg", "sos_ba_update_point_priors", "sos_ba_set_prefetch", "sos_tracker_set_gs_hint", "sos_immature_init", "sos_immature_trace", "sos_immature_trace_all", "sos_immature_activate", "sos_pixsel_create", "sos_pixsel_destroy", "sos_pixsel_make_hists", "sos_pixsel_select", "sos_pixsel_make_maps", "sos_pixsel_list", "sos_camera_parse", "sos_undistort_create", "sos_undistort_destroy", "sos_undistort_get", "sos_undistort_frame", "sos_rccl_load", "sos_rccl_unique_id", "sos_comm_create", "sos_comm_destroy", "sos_comm_size",
     "sos_comm_rank", "sos_ba_set_comm", "sos_ba_newest_capacity", "sos_ba_gather_energies", "sos_ba_allreduce_f64", "sos_ba_get_jacobian", "sos_ba_get_residual_flags", "sos_ba_get_JpJdF",
     "sos_ba_get_res_toZeroF", "sos_ba_time_kernel", "sos_tracker_create", "sos_tracker_destroy",

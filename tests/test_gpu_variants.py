@@ -69,25 +69,13 @@ def test_switches(modeA, modeB, huber, outlier):
 
 
 @pytest.mark.parametrize("env,target", [
-    ({"SOS_LIN_SCALAR1": "0"}, "tests/test_gpu_backend.py"),      # vector-load form of the phase-1 tile constants (multi-round grids)
-    ({"SOS_LIN_ND": "0"}, "tests/test_gpu_backend.py"),           # every block owns one tile
-    ({"SOS_LIN_ND": "-1"}, "tests/test_gpu_backend.py"),          # every block owns two tiles
     ({"SOS_TRACKER_FUSE_MAX": "0"}, "tests/test_gpu_tracker.py"),  # final sums by the second kernel on every level
     ({"SOS_TRACKER_FUSE_MAX": "1000"}, "tests/test_gpu_tracker.py"),  # ... by the last-arriving block on every level
     # the absolute-coordinate Schur path (opt-in): same yardstick tests.  (T4 -- four keyframes, 256 points -- is left out: there its step sits
     # 3.2x as far from the fp64-accumulated step as the reference's own fp32 arithmetic, tests/emu run of round 4; from T6 up it is at par)
     ({"SOS_ABS_SC": "1"}, "tests/test_gpu_edge_windows.py -k T6"),
-    ({"SOS_ABS_SC": "1", "SOS_ABS_SIGNAL_IN_KERNEL": "1"}, "tests/test_golden_t6.py"),
-    # ... with its three launches as ONE cooperative launch (device-wide barriers with bounded waits, csrc/sos_ba.hip: k_abs_coop)
-    ({"SOS_ABS_SC": "1", "SOS_ABS_COOP": "1"}, "tests/test_gpu_edge_windows.py -k T6"),
-    # the step's launches enqueued before the solve, x through a mapped mailbox (sos_ba_gn_step_prelaunch / _deliver); with a delayed delivery
-    # the device really waits
-    ({"SOS_PRELAUNCH_STEP": "1"}, "tests/test_gpu_optimize.py -k T6"),
-    ({"SOS_PRELAUNCH_STEP": "1", "SOS_PRELAUNCH_TEST_DELAY_US": "2000"}, "tests/test_golden_t6.py"),
-    # ... on top of the cooperative absolute-coordinate chain (bench.py's `prelaunched_step_abs_cooperative`)
-    ({"SOS_PRELAUNCH_STEP": "1", "SOS_ABS_SC": "1", "SOS_ABS_COOP": "1"}, "tests/test_gpu_edge_windows.py -k T6"),
-    # host-side orders kept as knobs: eager per-point mirrors, IMU first half behind the accumulate's enqueue
-    ({"SOS_EAGER_POINT_MIRRORS": "1"}, "tests/test_golden_t6.py"),
+    ({"SOS_ABS_SC": "1", "SOS_STITCH_SIGNAL_IN_KERNEL": "1"}, "tests/test_golden_t6.py"),   # ... its last kernel raising the host flag itself
+    # host-side order kept as a knob: IMU first half behind the accumulate's enqueue
     ({"SOS_IMU_OVERLAP": "1"}, "tests/test_gpu_imu_hook.py -k T6"),
     ({"SOS_STITCH_SIGNAL_IN_KERNEL": "1"}, "tests/test_golden_t6.py"),    # the stitch's last kernel raises the host flag itself
 ])
