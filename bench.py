@@ -394,6 +394,10 @@ def main():
             except Exception as e:  # noqa: BLE001
                 out["keyframe"] = {"error": repr(e)}
             out["visual_inertial"] = side_process("imu", args.window)
+            try:
+                out["device_solve"] = device_solve_timing(win.n, local_rank)
+            except Exception as e:  # noqa: BLE001
+                out["device_solve"] = {"error": repr(e)}
             if args.variants:
                 # opt-in: the same loop under each remaining switch, each in a process of its own
                 try:
@@ -691,6 +695,23 @@ def imu_timing(window, device, iters=400):
         out["rebuild_literal_error"] = repr(e)[:200]
     sysm.close()
     return out
+
+
+def device_solve_timing(n, device, reps=200):
+    """k_gn_solve alone (the single-workgroup solve of the device-resident loop, csrc/sos_gn_resident.inc) on a random positive definite
+    system of the window's dimension: HIP-event wall time per launch and the kernel's own phase stamps.  What it has to beat is the host
+    round trip of the default loop (host_phases_us: gn_accumulate_wait + assemble + ldlt + the step's launch)."""
+    from sos_slam_amd import lib
+    d = 4 + 8 * n
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((d, d))
+    H = A @ A.T + d * np.eye(d)
+    z, zv = np.zeros((d, d)), np.zeros(d)
+    ctx = lib.Context(64, 64, device=device)
+    x, ph = ctx.gn_solve_system(np.triu(H), rng.standard_normal(d), z, zv, z, zv, zv, reps=reps)
+    ctx.close()
+    return {"dim": d, "launches": reps, "wall_us_per_launch": round(float(ph[3]), 2), "assemble_us": round(float(ph[0]), 2),
+            "factorise_us": round(float(ph[1]), 2), "substitute_us": round(float(ph[2]), 2)}
 
 
 def tracker_timing(window, device):

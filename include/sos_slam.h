@@ -312,20 +312,20 @@ int sos_ba_gn_resub(sos_ba *ba, const double *x, float stepfacD);
 int sos_ba_set_prefetch(sos_ba *ba, int on);
 
 /* ---- device-resident Gauss-Newton loop: the loop body of FullSystem::optimize (FS/FullSystemOptimize.cpp:358-413, with
- * setting_forceAceptStep) with the HOST OUT OF THE ITERATION.  Besides the accumulate / back-substitution / linearisation
- * kernels above, one kernel per iteration does what solveSystemF (OB/EnergyFunctional.cpp:1046-1148: priors, HM / bM around
- * delta, Schur side, Jacobi scaling, LDL^T; IMU off), the frame / calibration half of doStepFromBackup
- * (FS/FullSystemOptimize.cpp:185-257), FrameHessian::setState (SE3 exp), FrameFramePrecalc::set x n^2
- * (FS/HessianBlocks.cpp:431-461) and setDeltaF (OB/EnergyFunctional.cpp:163-194) do on the host, in fp64; the order statistic
- * of setNewFrameEnergyTH (FS/FullSystemOptimize.cpp:84-124) is an exact selection on the device.  Frame states, calibration,
- * FEJ poses and the marginalisation prior stay on the device between begin and end.
+ * setting_forceAceptStep) with the HOST OUT OF THE ITERATION.  Besides the accumulate / linearisation kernels above, ONE single-workgroup
+ * kernel per iteration does what solveSystemF does on the host (OB/EnergyFunctional.cpp:1046-1148: priors, HM / bM around delta, Schur
+ * side, Jacobi scaling, LDL^T; IMU off), in fp64, and hands x to the step kernel of sos_ba_gn_devstep_begin through device memory
+ * (resubstituteF_MT, doStepFromBackup, FrameHessian::setState, FrameFramePrecalc::set x n^2, setDeltaF); the order statistic of
+ * setNewFrameEnergyTH (FS/FullSystemOptimize.cpp:84-124) is an exact selection on the device.  Frame states, calibration, FEJ poses
+ * and the marginalisation prior stay on the device between begin and end; the host keeps stepping its own copies from x, as in the
+ * device-side-step mode.
  *   begin    after the window has been packed, its state set (adjoints included) and linearised + applied once
- *            (FS/FullSystemOptimize.cpp:316-344): uploads what the loop needs
+ *            (FS/FullSystemOptimize.cpp:316-344): uploads what the loop needs (includes sos_ba_gn_devstep_begin)
  *   enqueue  one whole iteration as one chain of launches; returns at once with its sequence number
  *   wait     the results of iteration `seq`: they are published when its solve has run, BEFORE its back-substitution and
  *            linearisation, so the caller decides about the next iteration (canbreak) and enqueues it while this one finishes
  *   end      drains the stream, returns the point steps / inverse depths / newest-frame energies of the last iteration
- * Not available (SOS_ERR_STATE from begin; use the fused calls above): more than 17 keyframes, an empty window. */
+ * Not available (SOS_ERR_STATE from begin; use the fused calls above): more than 17 keyframes, an empty window, a communicator. */
 typedef struct sos_gn_frame {
   double camToWorld_evalPT[12];  /* FrameHessian::get_camToWorld_evalPT(): R row-major | t */
   double state[10];              /* FrameHessian::state */
@@ -347,14 +347,22 @@ int sos_ba_gn_resident_supported(sos_ba *ba);
 int sos_ba_gn_resident_begin(sos_ba *ba, const sos_gn_frame *frames, const double *calib_value4, const double *calib_value_zero4,
                              double cPrior, const double *HM, const double *bM, const float *frameEnergyTH /* n */);
 int sos_ba_gn_resident_enqueue(sos_ba *ba, int *seq_out);
-/* header16: [0] seq, [1] failed (non-positive pivot: nothing was stepped), [2..5] sumA sumB sumT sumR of doStepFromBackup,
- * [6] sum |idepth_backup|, [7] number of points, [8] resInA, [9] resInL, [10] frameEnergyTH of the newest keyframe used by
- * this iteration's linearisation; x: 4 + 8 n; states: n x 10 (the new FrameHessian::state); camToWorld: n x 12
- * (PRE_camToWorld); calib_value4: CalibHessian::value */
-int sos_ba_gn_resident_wait(sos_ba *ba, int seq, double *header16, double *x, double *states, double *camToWorld,
-                            double *calib_value4);
+/* header16: [0] seq, [1] failed (non-positive pivot: x is not usable), [6] sum |idepth_backup| and [7] the number of points
+ * (doStepFromBackup's sumNID, FS/FullSystemOptimize.cpp:207-213), [8] resInA, [9] resInL, [10] frameEnergyTH of the newest keyframe
+ * used by this iteration's linearisation, [11..13] microseconds the solve kernel spent assembling / factorising / substituting;
+ * x: 4 + 8 n (OB/EnergyFunctional.cpp:1148) */
+int sos_ba_gn_resident_wait(sos_ba *ba, int seq, double *header16, double *x);
 int sos_ba_gn_resident_end(sos_ba *ba, float *pointStep, float *idepth_scaled, double *energySum, float *newestEnergies,
                            int *newestCount);
+/* The solve kernel of the device-resident loop on a system handed in from the host: EnergyFunctional::solveSystemF's visual part
+ * (OB/EnergyFunctional.cpp:1046-1148) from its pieces -- H_top = HA_top + HL_top + priors and H_sc as UPPER triangles (dim x dim
+ * row-major, dim = 4 + 8 n), b_top (priors' part included), b_sc, the marginalisation prior HM (whole) / bM, delta =
+ * getStitchedDeltaF() -- with SOLVER_FIX_LAMBDA: x = S LDLT(S ((H_top + HM)(1 + lambda on the diagonal) - H_sc / (1 + lambda)) S)^-1
+ * S (b_top + bM + HM delta - b_sc).  The same arithmetic as sosf_solve_system (include/sos_slam_host.h), which the parity tests hold
+ * it against.  reps launches are timed: phase_us4 (may be NULL) = the kernel's own stamps (assemble, factorise, substitute) of the
+ * last launch and the HIP-event wall time per launch.  SOS_ERR_STATE: a non-positive pivot (the caller solves on the host). */
+int sos_gn_solve_system(sos_ctx *ctx, int n, const double *H_top, const double *b_top, const double *H_sc, const double *b_sc, const double *HM,
+                        const double *bM, const double *delta, double *x, int reps, double *phase_us4);
 
 /* ---- multi-GPU exchange; the reference has no counterpart: it is a single-process CPU backend ----
  * One process per GPU, every rank the same keyframes and its own shard of the points.  librccl is bound at run

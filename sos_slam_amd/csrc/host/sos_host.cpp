@@ -1462,44 +1462,34 @@ int FullSystem::residentBegin() {
 
 bool FullSystem::residentConsume(int seq) {
   const int n = (int)frameHessians.size(), dim = SOS_CPARS + 8 * n;
-  double hdr[16], cal[4];
-  std::vector<double> x(dim), st((size_t)10 * n), poses((size_t)12 * n);
-  const int rc = sos_ba_gn_resident_wait(ef->ba, seq, hdr, x.data(), st.data(), poses.data(), cal);
+  double hdr[16];
+  std::vector<double> x(dim);
+  const int rc = sos_ba_gn_resident_wait(ef->ba, seq, hdr, x.data());
   if (rc != SOS_OK) {
     rcAcc(rc);
     isLost = true;
     return true;
   }
   residentSeq = seq;
-  if (getenv("SOS_TIMING")) fprintf(stderr, "[k_gn_solve] assemble %.1f ldlt %.1f backsub %.1f step %.1f precalc %.1f us\n", hdr[11], hdr[12], hdr[13], hdr[14], hdr[15]);
+  if (getenv("SOS_TIMING")) fprintf(stderr, "[k_gn_solve] assemble %.1f factorise %.1f substitute %.1f us\n", hdr[11], hdr[12], hdr[13]);
   ef->lastX = x;
   ef->resInA = (int)hdr[8];
   ef->resInL = (int)hdr[9];
+  // the host's copies of the states follow x exactly as in the device-side-step loop (backupState + doStepFromBackup,
+  // FS/FullSystemOptimize.cpp:185-269); the points stay on the device until residentFlush, their |idepth| sum comes with the slot
+  std::memcpy(HCalib.value_backup, HCalib.value, sizeof(HCalib.value));
   for (int i = 0; i < 4; i++) HCalib.step[i] = -x[i];
-  HCalib.setValue(cal);
   for (int h = 0; h < n; h++) {
     FrameHessian *fh = frameHessians[h];
+    std::memcpy(fh->state_backup, fh->state, sizeof(fh->state));
     for (int i = 0; i < 8; i++) fh->step[i] = -x[SOS_CPARS + 8 * h + i];
     fh->step[8] = fh->step[9] = 0;
-    // setState with the pose the device formed (its SE3 exp is the one the kernels used)
-    const double *s = &st[(size_t)10 * h];
-    for (int i = 0; i < 10; i++) fh->state[i] = s[i];
-    for (int i = 0; i < 3; i++) fh->state_scaled[i] = SOS_SCALE_XI_TRANS * s[i];
-    for (int i = 3; i < 6; i++) fh->state_scaled[i] = SOS_SCALE_XI_ROT * s[i];
-    fh->state_scaled[6] = SOS_SCALE_A * s[6]; fh->state_scaled[7] = SOS_SCALE_B * s[7];
-    fh->state_scaled[8] = SOS_SCALE_A * s[8]; fh->state_scaled[9] = SOS_SCALE_B * s[9];
-    fh->PRE_camToWorld = SE3::from12(&poses[(size_t)12 * h]);
-    fh->PRE_worldToCam = fh->PRE_camToWorld.inverse();
   }
+  backupSumNID = (float)hdr[6];
+  backupNumID = (float)hdr[7];
+  const bool canbreak = doStepFromBackup(1, 1, 1, 1, 1, true, true);
   frameHessians.back()->frameEnergyTH = (float)hdr[10];
-  // the termination test of doStepFromBackup (FS/FullSystemOptimize.cpp:240-257)
-  float sumA = (float)hdr[2], sumB = (float)hdr[3], sumT = (float)hdr[4], sumR = (float)hdr[5];
-  float sumNID = (float)hdr[6];
-  const float numID = (float)hdr[7], nf = (float)n;
-  sumA /= nf; sumB /= nf; sumR /= nf; sumT /= nf;
-  sumNID /= numID;
-  return sqrtf(sumA) < 0.0005 * setting_thOptIterations && sqrtf(sumB) < 0.00005 * setting_thOptIterations &&
-         sqrtf(sumR) < 0.00005 * setting_thOptIterations && sqrtf(sumT) * sumNID < 0.00005 * setting_thOptIterations;
+  return canbreak;
 }
 
 // Lazy point mirrors (sos_host.hpp): the flat copies are gathered once, in snapshot order, with the reference's summation order beside them

@@ -2136,6 +2136,13 @@ struct DevStep {
   size_t st_pre, st_adh, st_cd, st_th, st_cal;
   double xd[SOS_CPARS + 8 * 17];                              // x of the solve (the window sizes this path accepts: n <= 17)
   float th[17];                                               // frameEnergyTH of the coming linearisation
+  // device-resident loop (sos_gn_resident.inc): x comes from k_gn_solve through device memory, the newest frame's threshold was written
+  // by the accumulate's order-statistic block, and the right-hand-side part bM + HM delta of the NEXT solve (OB/EnergyFunctional.cpp:
+  // 1046-1050: bM_top = bM + HM * getStitchedDeltaF()) is formed here from the stepped states
+  const double *x_dev;                                        // nullptr: xd above
+  int th_dev;                                                 // 1: leave the staged thresholds alone
+  const double *HM, *bM;                                      // nullptr: no bMd
+  double *bMd;
 };
 __device__ __forceinline__ void devstep_block(int sb, int nsb, const BaDev &d, const DevStep &g, const float *__restrict__ adHF, const float *__restrict__ adTF,
                                               float4 *__restrict__ t_pre, float *smemf, const double *xd) {
@@ -2240,8 +2247,26 @@ __device__ __forceinline__ void devstep_block(int sb, int nsb, const BaDev &d, c
   if (ex_pair >= 0) t_pre[ex_e] = reinterpret_cast<const float4 *>(pre)[7 * (size_t)ex_pair + ex_q];
   // ---- the canonical arrays and the new states, spread over the blocks (every block holds all of it in LDS): role 0 = states /
   // calibration / thresholds, role 1 = the precalc array, roles 2.. = 256 entries of adHTdeltaF each
-  const int nRoles = 2 + (8 * n * n + SOS_RSB - 1) / SOS_RSB;
+  const int nRolesStep = 2 + (8 * n * n + SOS_RSB - 1) / SOS_RSB;
+  const int dimx = SOS_CPARS + 8 * n;
+  const int nRoles = nRolesStep + (g.HM ? (dimx + SOS_RSB / 4 - 1) / (SOS_RSB / 4) : 0);
   for (int role = sb; role < nRoles; role += nsb) {
+    if (role >= nRolesStep) {  // bMd = bM + HM delta, four lanes per row (j = q, q + 4, ...)
+      const int i = (role - nRolesStep) * (SOS_RSB / 4) + (tid >> 2), q = tid & 3;
+      double sv = 0;
+      if (i < dimx) {
+        const double *hm = g.HM + (size_t)i * dimx;
+        for (int j = q; j < dimx; j += 4) {
+          const double dj = j < SOS_CPARS ? (double)(float)(cvN[j] - g.calib_in[4 + j])
+                                          : stN[10 * ((j - SOS_CPARS) >> 3) + ((j - SOS_CPARS) & 7)] - g.state_zero[10 * ((j - SOS_CPARS) >> 3) + ((j - SOS_CPARS) & 7)];
+          sv = fma(hm[j], dj, sv);
+        }
+      }
+      sv += __shfl_xor(sv, 1, 64);
+      sv += __shfl_xor(sv, 2, 64);
+      if (q == 0 && i < dimx) g.bMd[i] = g.bM[i] + sv;
+      continue;
+    }
     if (role == 0) {
       if (tid < 4) {
         g.stage[g.st_cd + tid] = (float)(cvN[tid] - g.calib_in[4 + tid]);
@@ -2249,7 +2274,7 @@ __device__ __forceinline__ void devstep_block(int sb, int nsb, const BaDev &d, c
         g.calib_out[4 + tid] = g.calib_in[4 + tid];
       }
       if (tid < 8) g.stage[g.st_cal + tid] = sK[tid];
-      if (tid < n) g.stage[g.st_th + tid] = g.th[tid];
+      if (tid < n && !g.th_dev) g.stage[g.st_th + tid] = g.th[tid];
       for (int q = tid; q < 10 * n; q += SOS_RSB) g.state_out[q] = stN[q];
     } else if (role == 1) {
       float4 *cpre = reinterpret_cast<float4 *>(g.stage + g.st_pre);
@@ -2277,10 +2302,10 @@ __global__ __launch_bounds__(SOS_RSB) void k_resub_devstep(BaDev d, const float 
                                                        float4 *__restrict__ t_pre) {
   extern __shared__ __attribute__((aligned(16))) float sxAd[];
   if ((int)blockIdx.x >= nPointBlocks) {
-    devstep_block((int)blockIdx.x - nPointBlocks, (int)gridDim.x - nPointBlocks, d, g, adHF, adTF, t_pre, sxAd, g.xd);
+    devstep_block((int)blockIdx.x - nPointBlocks, (int)gridDim.x - nPointBlocks, d, g, adHF, adTF, t_pre, sxAd, g.x_dev ? g.x_dev : g.xd);
     return;
   }
-  resub_point_block(d, nullptr, adHF, adTF, step_out, stepfacD, nullptr, sxAd, g.xd);
+  resub_point_block(d, nullptr, adHF, adTF, step_out, stepfacD, nullptr, sxAd, g.x_dev ? g.x_dev : g.xd);
 }
 __global__ void k_fix_lin(BaDev d, const int *__restrict__ slist, int count) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2524,10 +2549,9 @@ struct sos_ba {
   DevBuf<float> d_xchg;    // sos_ba_time_kernel("exchange") scratch
   DevBuf<float> d_large;   // sos_ba_time_kernel("stream_large") 1 GiB yardstick buffer
   // device-resident Gauss-Newton loop (sos_gn_resident.inc)
-  DevBuf<double> d_gn;       // HM | bM | evalC2W | state_zero | prior | state | calib (value 4, value_zero 4, cPrior)
-  DevBuf<float> d_gn_f;      // ab_exposure n | xF dim
-  DevBuf<short> d_gn_map;    // k_gn_solve: thread -> tile (I, K)
-  size_t gn_HM = 0, gn_bM = 0, gn_eval = 0, gn_sz = 0, gn_prior = 0, gn_state = 0, gn_calib = 0;
+  DevBuf<double> d_gn;       // HM | bM | prior | bMd (= bM + HM delta of the coming solve) | x (the solve's result, read by the step)
+  size_t gn_HM = 0, gn_bM = 0, gn_prior = 0, gn_bMd = 0, gn_x = 0;
+  double gn_cPrior = 0;
   double *gn_pin = nullptr, *gn_pin_dev = nullptr;  // mapped ring of GN_SLOTS result slots + flag
   size_t gn_pin_doubles = 0, gn_slot_doubles = 0;
   bool gn_active = false, gn_have_top = false;
@@ -2643,7 +2667,7 @@ extern "C" int sos_ba_destroy(sos_ba *ba) {
     b->release();
   ba->d_rawjac.release();
   ba->d_t_pre.release(); ba->d_t_img.release(); ba->d_t_ht.release();
-  ba->d_p_list2.release(); ba->d_p_list16.release(); ba->d_r_geo.release(); ba->d_r_cw.release(); ba->d_stage.release(); ba->d_outpack.release(); ba->d_C.release(); ba->d_ar64.release(); ba->d_xchg.release(); ba->d_large.release(); ba->d_gn.release(); ba->d_gn_f.release(); ba->d_gn_map.release();
+  ba->d_p_list2.release(); ba->d_p_list16.release(); ba->d_r_geo.release(); ba->d_r_cw.release(); ba->d_stage.release(); ba->d_outpack.release(); ba->d_C.release(); ba->d_ar64.release(); ba->d_xchg.release(); ba->d_large.release(); ba->d_gn.release();
   if (ba->gn_pin) hipHostFree(ba->gn_pin); ba->d_Jnew.release(); ba->d_JpJd_new.release(); ba->d_pterm_new.release();
   if (ba->pin) hipHostFree(ba->pin);
   if (ba->ev_step) hipEventDestroy(ba->ev_step);
@@ -3963,6 +3987,7 @@ extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const
     DevStep g;
     for (int i = 0; i < dim; i++) g.xd[i] = x[i];
     for (int i = 0; i < n; i++) g.th[i] = frameEnergyTH[i];
+    g.x_dev = nullptr; g.th_dev = 0; g.HM = g.bM = nullptr; g.bMd = nullptr;
     double *b = ba->d_ds;
     g.evalC2W = b; g.state_zero = b + 12 * n;
     g.state_in = b + 22 * n + 10 * n * ba->ds_cur; g.state_out = b + 22 * n + 10 * n * (ba->ds_cur ^ 1);

@@ -25,7 +25,7 @@ SYMBOLS = [
     "sos_ba_stitch", "sos_ba_gn_accumulate", "sos_ba_gn_accumulate_begin", "sos_ba_gn_step", "sos_ba_gn_resub", "sos_ba_get_point_hessian", "sos_ba_resubstitute", "sos_ba_calc_lenergy",
     "sos_ba_accumulate_marg", "sos_ba_update_point_priors", "sos_ba_set_prefetch", "sos_tracker_set_gs_hint", "sos_immature_init", "sos_immature_trace", "sos_immature_trace_all", "sos_immature_activate", "sos_pixsel_create", "sos_pixsel_destroy", "sos_pixsel_make_hists", "sos_pixsel_select", "sos_pixsel_make_maps", "sos_pixsel_list", "sos_camera_parse", "sos_undistort_create", "sos_undistort_destroy", "sos_undistort_get", "sos_undistort_frame", "sos_rccl_load", "sos_rccl_unique_id", "sos_comm_create", "sos_comm_destroy", "sos_comm_size",
     "sos_comm_rank", "sos_ba_set_comm", "sos_ba_newest_capacity", "sos_ba_gather_energies", "sos_ba_allreduce_f64", "sos_ba_get_jacobian", "sos_ba_get_residual_flags", "sos_ba_get_JpJdF",
-    "sos_ba_get_res_toZeroF", "sos_ba_time_kernel", "sos_tracker_create", "sos_tracker_destroy",
+    "sos_ba_get_res_toZeroF", "sos_ba_time_kernel", "sos_gn_solve_system", "sos_tracker_create", "sos_tracker_destroy",
     "sos_tracker_set_ref", "sos_tracker_set_points3d", "sos_tracker_scale_depth", "sos_tracker_get_pc", "sos_tracker_calc_res",
     "sos_tracker_calc_gs", "sos_tracker_calc_res_scale", "sos_tracker_calc_gs_scale", "sos_backend_name",
 ]
@@ -182,6 +182,17 @@ class Context:
 
     def synchronize(self):
         _chk(self.L.sos_ctx_synchronize(self.h_), "sos_ctx_synchronize")
+
+    def gn_solve_system(self, H_top, b_top, H_sc, b_sc, HM, bM, delta, reps: int = 1):
+        """k_gn_solve (the solve of the device-resident Gauss-Newton loop) on a system from the host: the device counterpart of
+        host.solve_system.  Returns (x, phases) with phases = microseconds (assemble, factorise, substitute, wall per launch)."""
+        a = [np.ascontiguousarray(v, dtype=np.float64) for v in (H_top, b_top, H_sc, b_sc, HM, bM, delta)]
+        n = (len(a[1]) - 4) // 8
+        x = np.zeros(len(a[1]))
+        ph = np.zeros(4)
+        self.L.sos_gn_solve_system.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_void_p]
+        _chk(self.L.sos_gn_solve_system(self.h_, n, *[_p(v) for v in a], _p(x), int(reps), _p(ph)), "sos_gn_solve_system")
+        return x, ph
 
     # ---- immature points (ImmaturePoint constructor / traceOn)
     def immature_init(self, prm, host_slot: int, u, v):

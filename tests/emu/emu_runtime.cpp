@@ -125,6 +125,8 @@ void *shared_static_lookup(const void *key, size_t bytes, size_t align) {
   void *p = aligned_alloc(align < 16 ? 16 : align, (bytes + 63) & ~(size_t)63);
   memset(p, g_shared_fill, bytes);
   m.emplace(key, p);
+  b->static_bytes += bytes;  // a workgroup cannot hold more than the 160 KB of LDS of one compute unit (gfx950)
+  if (b->static_bytes + b->dyn_bytes > 160 * 1024) die("workgroup needs more than 160 KB of LDS (static + dynamic)");
   return p;
 }
 
@@ -202,6 +204,7 @@ static int dpp_source(int lane, int ctrl, bool *valid) {
   if (ctrl == 0x141) return row + ((l & 8) | (7 - (l & 7)));               // row_half_mirror
   if (ctrl == 0x142) { *valid = row >= 16; return row - 1; }               // row_bcast:15 (lane 15 of the previous row)
   if (ctrl == 0x143) { *valid = lane >= 32; return 31; }                   // row_bcast:31
+  if (ctrl >= 0x150 && ctrl <= 0x15F) return row + (ctrl & 15);            // row_newbcast:n (gfx90a+): lane n of each row to the whole row
   die("unknown DPP control");
 }
 
@@ -271,6 +274,23 @@ static void resolve_group(Fiber *w0, int nl, uint64_t mask, int first) {
       for (int l = 0; l < nl; l++) if ((mask >> l) & 1) w0[l].out64 = outv[l];
       break;
     }
+    case OP_DPP64: {  // v_mov_b64_dpp: the DP-ALU DPP form exists with row_newbcast only
+      uint64_t outv[64];
+      for (int l = 0; l < nl; l++) {
+        if (!((mask >> l) & 1)) continue;
+        Fiber &f = w0[l];
+        const int ctrl = f.p0, rmask = f.p3 & 0xf, bmask = (f.p3 >> 4) & 0xf;
+        const bool bound = (f.p3 & 0x100) != 0;
+        if (ctrl < 0x150 || ctrl > 0x15F) die("64-bit DPP with a control other than row_newbcast");
+        if (!((rmask >> (l >> 4)) & 1) || !((bmask >> ((l >> 2) & 3)) & 1)) { outv[l] = f.old64; continue; }
+        bool valid;
+        const int src = dpp_source(l, ctrl, &valid);
+        if (valid && in_group(src)) outv[l] = w0[src].in64;
+        else outv[l] = bound ? 0 : f.old64;
+      }
+      for (int l = 0; l < nl; l++) if ((mask >> l) & 1) w0[l].out64 = outv[l];
+      break;
+    }
     case OP_SEQSUM8: {
       float outv[64];
       for (int l = 0; l < nl; l++) {
@@ -296,6 +316,21 @@ static void resolve_group(Fiber *w0, int nl, uint64_t mask, int first) {
         }
       for (int l = 0; l < 64; l++)
         for (int r = 0; r < 4; r++) w0[l].fout[r] = D[4 * (l / 16) + r][l & 15];
+      break;
+    }
+    case OP_MFMA_16x16x4_F64: {
+      // v_mfma_f64_16x16x4_f64: A[i][k] in lane i + 16 k, B[k][j] in lane j + 16 k (as the f32 16x16x4 form), but C / D with
+      // row = (lane >> 4) + 4 * reg, col = lane & 15 -- NOT the f32 row formula (cdna_hip_programming.md, fragment layout)
+      if (nl != 64 || mask != ~0ull) die("MFMA executed by a partial wave");
+      double D[16][16];
+      for (int i = 0; i < 16; i++)
+        for (int j = 0; j < 16; j++) {
+          double acc = w0[16 * (i & 3) + j].din[2 + (i >> 2)];
+          for (int k = 0; k < 4; k++) acc = fma(w0[16 * k + i].din[0], w0[16 * k + j].din[1], acc);
+          D[i][j] = acc;
+        }
+      for (int l = 0; l < 64; l++)
+        for (int r = 0; r < 4; r++) w0[l].dout[r] = D[(l >> 4) + 4 * r][l & 15];
       break;
     }
     case OP_WAVE_BARRIER: break;
@@ -386,6 +421,7 @@ static void run_launch(Machine *M, LaunchBase *L) {
   const long nthreads = (long)bd.x * bd.y * bd.z;
   const long nblocks = (long)g.x * g.y * g.z;
   if (nthreads <= 0 || nthreads > 1024) die("block size out of range");
+  if (L->shmem > 160 * 1024) die("launch asks for more than 160 KB of dynamic LDS");
   if (nblocks <= 0) { M->launch = nullptr; return; }
   const long max_resident = std::max(1L, (long)M->nslots / nthreads);
   std::vector<Block *> resident;

@@ -116,7 +116,7 @@ template <class T> static inline hipError_t hipMemcpyToSymbol(T &sym, const void
 // ------------------------------------------------------------------------------------------------ the SIMT machine
 namespace emu {
 enum St : uint8_t { RUNNABLE = 0, WAIT_WAVE, WAIT_BLOCK, YIELDED, DEAD };
-enum Op : int { OP_SHFL = 1, OP_SHFL_XOR, OP_SHFL_UP, OP_SHFL_DOWN, OP_BALLOT, OP_READFIRST, OP_READLANE, OP_DPP, OP_MFMA_16x16x4_F32, OP_WAVE_BARRIER, OP_SEQSUM8 };
+enum Op : int { OP_SHFL = 1, OP_SHFL_XOR, OP_SHFL_UP, OP_SHFL_DOWN, OP_BALLOT, OP_READFIRST, OP_READLANE, OP_DPP, OP_MFMA_16x16x4_F32, OP_WAVE_BARRIER, OP_SEQSUM8, OP_DPP64, OP_MFMA_16x16x4_F64 };
 struct Block;
 struct Fiber {
   void *sp;            // saved stack pointer while switched out
@@ -129,6 +129,8 @@ struct Fiber {
   const void *site;
   uint64_t in64, out64;
   float fin[6], fout[4];
+  double din[6], dout[4];  // v_mfma_f64_16x16x4_f64: a, b, c[4] -> d[4]
+  uint64_t old64;          // `old` operand of a 64-bit DPP move
   int pred;            // __syncthreads_or / _count
 };
 struct Block {
@@ -137,6 +139,7 @@ struct Block {
   Fiber *fibers;
   void *dyn_shared;
   size_t dyn_bytes;
+  size_t static_bytes = 0;          // __shared__ declarations reached so far
   int sync_acc_or, sync_acc_count;  // accumulated by the releasing barrier
   int sync_res_or, sync_res_count;
   void *statics;                    // per-block map: declaration key -> storage
@@ -232,7 +235,23 @@ static inline __attribute__((always_inline)) int emu_update_dpp(int old, int src
   f->p2 = old; f->p3 = (row_mask & 0xf) | ((bank_mask & 0xf) << 4) | (bound ? 0x100 : 0);
   return emu::xlane(emu::OP_DPP, src, ctrl, 0);
 }
+// 64-bit DPP (v_mov_b64_dpp; gfx90a+ allows it with row_newbcast only -- the resolver rejects any other control for this form)
+static inline __attribute__((always_inline)) double emu_update_dpp(double old, double src, int ctrl, int row_mask, int bank_mask, bool bound) {
+  emu::Fiber *f = emu::cur;
+  f->old64 = emu::to_bits(old); f->p3 = (row_mask & 0xf) | ((bank_mask & 0xf) << 4) | (bound ? 0x100 : 0);
+  return emu::xlane(emu::OP_DPP64, src, ctrl, 0);
+}
 typedef float emu_f32x4 __attribute__((ext_vector_type(4)));
+typedef double emu_f64x4 __attribute__((ext_vector_type(4)));
+static inline __attribute__((always_inline)) emu_f64x4 emu_mfma_f64_16x16x4f64(double a, double b, emu_f64x4 c, int, int, int) {
+  emu::Fiber *f = emu::cur;
+  f->op = emu::OP_MFMA_16x16x4_F64;
+  f->din[0] = a; f->din[1] = b; f->din[2] = c[0]; f->din[3] = c[1]; f->din[4] = c[2]; f->din[5] = c[3];
+  emu::wave_op();
+  f = emu::cur;
+  emu_f64x4 d = {f->dout[0], f->dout[1], f->dout[2], f->dout[3]};
+  return d;
+}
 static inline __attribute__((always_inline)) emu_f32x4 emu_mfma_f32_16x16x4f32(float a, float b, emu_f32x4 c, int, int, int) {
   emu::Fiber *f = emu::cur;
   f->op = emu::OP_MFMA_16x16x4_F32;
@@ -254,7 +273,9 @@ static inline __attribute__((always_inline)) float seqsum8(float v) {  // the v_
 #define __builtin_amdgcn_readlane(v, l) emu_readlane((v), (l))
 #define __builtin_amdgcn_update_dpp(o, s, c, r, b, bc) emu_update_dpp((o), (s), (c), (r), (b), (bc))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu_mfma_f32_16x16x4f32((a), (b), (c), (x), (y), (z))
+#define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, x, y, z) emu_mfma_f64_16x16x4f64((a), (b), (c), (x), (y), (z))
 #define __builtin_amdgcn_wave_barrier() ((void)emu::xlane<int>(emu::OP_WAVE_BARRIER, 0, 0, 0))
+#define __builtin_amdgcn_fence(order, scope) std::atomic_thread_fence(std::memory_order_seq_cst)
 #define __builtin_amdgcn_s_sleep(n) emu::yield_lane()
 #define __builtin_amdgcn_s_getreg(x) 0u
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
