@@ -620,9 +620,12 @@ struct ImuCache {
   uint64_t prior_id = 0;            // != 0: the caller's name for the values of HM (compared instead of the values; the diagonal still is)
   const double *HMptr = nullptr;
   std::vector<int> gI, gB;          // expanded index of interior state u (u < nIs) / of border unknown j
+  std::vector<int> pI, pC;          // position of interior state u / of constraint multiplier k in the interior's elimination order:
+                                    // keyframe by keyframe [bias + spline states | multipliers of the constraints the keyframe owns]
+  std::vector<double> bI0, rc0;     // b_imu / constraint residuals of the assembly the factor was built from (the untrapped solve's)
   std::vector<int> aB;              // dso index (4 + 8 n system) of border unknown j, -1 for the scale
   std::vector<int> spline_valid, rows_of;  // per frame: spline valid, constraint rows it owns
-  std::vector<double> scI;          // Jacobi scale of the interior unknowns (states, then multipliers)
+  std::vector<double> scI;          // Jacobi scale of the interior unknowns, by position
   std::vector<double> HcDiagB;      // (H_imu + HM) diagonal at the border unknowns, unscaled
   HiStore hi;
   sos::LdltPartial F;
@@ -687,7 +690,7 @@ __attribute__((target("avx2,fma"))) double dot4(const double *a, const double *b
 
 // the constant part of the KKT matrix in the cache's ordering, and its partial factorisation
 void build_cache(ImuCache &Q, const sosf_imu_settings &S, const sosf_imu_calib &C, int n, const sosf_imu_frame *F, const double *HM, double lambda,
-                 uint64_t prior_id) {
+                 uint64_t prior_id, bool keep = true) {
   const int dimI = SOSF_IMU_DIM(n);
   static const bool tmgb = getenv("SOS_TIMING_IMU") != nullptr;
   const double tq0 = tmgb ? now_us() : 0;
@@ -719,58 +722,110 @@ void build_cache(ImuCache &Q, const sosf_imu_settings &S, const sosf_imu_calib &
   Q.nb = (int)Q.gB.size();
   Q.nt = Q.mI + Q.nb;
   const int nt = Q.nt, nIs = Q.nIs, mI = Q.mI, nb = Q.nb;
+  // ---- elimination order of the interior: one pivot block per keyframe, [its bias + spline states | the multipliers of the
+  // constraint rows it owns].  H_imu couples a block to its neighbours only (bias random walk; velocity continuity reaches the next
+  // keyframe's spline states) and to the border (poses, calibration, scale); the prior a running chain leaves behind has the same
+  // shape.  What the data really couples is read off below (reach), so that an unusual prior widens the envelope instead of being
+  // assumed away.
+  std::vector<int> bstart(n + 1, 0), blockOfState(nIs, 0);
+  Q.pI.assign(nIs, 0);
+  Q.pC.assign(Q.cdim, 0);
+  {
+    int pos = 0, u = 0, k = 0;
+    for (int i = 0; i < n; i++) {
+      bstart[i] = pos;
+      for (int q = 8; q < (A.spline_valid[i] ? 29 : 14); q++, u++) { Q.pI[u] = pos++; blockOfState[u] = i; }
+      for (int q = 0; q < Q.rows_of[i]; q++, k++) Q.pC[k] = pos++;
+    }
+    bstart[n] = pos;
+  }
+  std::vector<int> reach(n);
+  for (int i = 0; i < n; i++) reach[i] = std::min(i + 1, n - 1);
+  {
+    std::vector<int> u0(n + 1, 0);  // first interior state of keyframe i
+    for (int u = 0; u < nIs; u++) u0[blockOfState[u] + 1] = u + 1;
+    for (int i = 1; i <= n; i++) u0[i] = std::max(u0[i], u0[i - 1]);
+    for (int i = 0; i < n; i++)       // the prior beyond the neighbour
+      for (int j = n - 1; j > reach[i]; j--) {
+        bool any = false;
+        for (int a = u0[i]; a < u0[i + 1] && !any; a++) {
+          const double *hm = HM + (size_t)Q.gI[a] * dimI;
+          for (int c = u0[j]; c < u0[j + 1] && !any; c++) any = hm[Q.gI[c]] != 0.0;
+        }
+        if (any) { reach[i] = j; break; }
+      }
+    int k = 0;
+    for (int i = 0; i < n; i++)       // constraint rows against the interior states of other keyframes
+      for (int q = 0; q < Q.rows_of[i]; q++, k++) {
+        const std::vector<double> &J = A.Jrows[k];
+        for (int u = 0; u < nIs; u++)
+          if (J[Q.gI[u]] != 0.0) {
+            const int f = blockOfState[u], lo = std::min(f, i), hi = std::max(f, i);
+            reach[lo] = std::max(reach[lo], hi);
+          }
+      }
+    for (int i = 1; i < n; i++) reach[i] = std::max(reach[i], reach[i - 1]);  // fill stays inside a monotone envelope
+  }
+  sos::LdltPartial &P = Q.F;
+  P.n = nt;
+  P.m = mI;
+  P.blk_end.assign(mI, mI);
+  P.env_end.assign(mI, mI);
+  for (int i = 0; i < n; i++)
+    for (int p = bstart[i]; p < bstart[i + 1]; p++) { P.blk_end[p] = bstart[i + 1]; P.env_end[p] = bstart[reach[i] + 1]; }
   // Jacobi scale of the interior: sqrt(diagonal + 10)^-1 as the reference scales the whole system (:1143-1146); the border is left
   // unscaled here (no pivot is taken from it) and scaled at the border solve, where its diagonal is complete
   Q.scI.assign(mI, 1.0 / std::sqrt(10.0));
   for (int u = 0; u < nIs; u++) {
     const int g = Q.gI[u];
-    Q.scI[u] = 1.0 / std::sqrt((A.H(g, g) + HM[(size_t)g * dimI + g]) * (1 + lambda) + 10);
+    Q.scI[Q.pI[u]] = 1.0 / std::sqrt((A.H(g, g) + HM[(size_t)g * dimI + g]) * (1 + lambda) + 10);
   }
   Q.HcDiagB.resize(nb);
   for (int j = 0; j < nb; j++) {
     const int g = Q.gB[j];
     Q.HcDiagB[j] = A.H(g, g) + HM[(size_t)g * dimI + g];
   }
-  sos::LdltPartial &P = Q.F;
-  P.n = nt;
-  P.m = mI;
-  P.U.resize((size_t)nt * nt);  // only the upper triangle is ever read: what is not written below is zeroed there, not the whole 1.3 MB
+  P.U.resize((size_t)nt * nt);  // only the envelope of the upper triangle and the border columns are ever read
   double *U = P.U.data();
-  // the unknowns of the interior and of the border are a few runs of consecutive expanded indices each: rows are filled run by run
+  // what sits at an interior position: the expanded index of a state (>= 0) or -1 - k for multiplier k
+  std::vector<int> what(mI);
+  for (int u = 0; u < nIs; u++) what[Q.pI[u]] = Q.gI[u];
+  for (int k = 0; k < Q.cdim; k++) what[Q.pC[k]] = -1 - k;
   struct Run { int g0, u0, len; };
-  std::vector<Run> runsI, runsB;
-  for (int u = 0; u < nIs; u++) {
-    if (!runsI.empty() && runsI.back().g0 + runsI.back().len == Q.gI[u]) runsI.back().len++;
-    else runsI.push_back(Run{Q.gI[u], u, 1});
-  }
+  std::vector<Run> runsB;
   for (int j = 0; j < nb; j++) {
     if (!runsB.empty() && runsB.back().g0 + runsB.back().len == Q.gB[j]) runsB.back().len++;
     else runsB.push_back(Run{Q.gB[j], j, 1});
   }
-  for (int u = 0; u < nIs; u++) {  // interior state rows: interior states, multipliers, border
-    const int g = Q.gI[u];
-    const double *hi = &A.H.a[(size_t)g * dimI], *hm = HM + (size_t)g * dimI;
-    double *row = U + (size_t)u * nt;
-    const double su = Q.scI[u];
-    for (const Run &r : runsI) {
-      const int i0 = std::max(0, u + 1 - r.u0);
-      const double *h1 = hi + r.g0, *h2 = hm + r.g0, *sc = &Q.scI[r.u0];
-      double *o = row + r.u0;
-      for (int i = i0; i < r.len; i++) o[i] = (h1[i] + h2[i]) * (su * sc[i]);
+  static thread_local std::vector<double> Jcol;  // the constraint rows, contiguous
+  Jcol.resize((size_t)Q.cdim * dimI);
+  for (int k = 0; k < Q.cdim; k++) std::memcpy(&Jcol[(size_t)k * dimI], A.Jrows[k].data(), sizeof(double) * dimI);
+  for (int p = 0; p < mI; p++) {
+    double *row = U + (size_t)p * nt;
+    const double sp = Q.scI[p];
+    const int ee = P.env_end[p];
+    if (what[p] >= 0) {  // a state row: states (H_imu + HM), multipliers (the constraint's entry), border
+      const int g = what[p];
+      const double *hi = &A.H.a[(size_t)g * dimI], *hm = HM + (size_t)g * dimI;
+      row[p] = (hi[g] + hm[g]) * (1 + lambda) * (sp * sp);
+      for (int c = p + 1; c < ee; c++) {
+        const int w = what[c];
+        row[c] = w >= 0 ? (hi[w] + hm[w]) * (sp * Q.scI[c]) : Jcol[(size_t)(-1 - w) * dimI + g] * (sp * Q.scI[c]);
+      }
+      for (const Run &r : runsB) {
+        const double *h1 = hi + r.g0, *h2 = hm + r.g0;
+        double *o = row + mI + r.u0;
+        for (int i = 0; i < r.len; i++) o[i] = (h1[i] + h2[i]) * sp;
+      }
+    } else {             // a multiplier row: zero against the other multipliers, the constraint's entries elsewhere
+      const double *J = &Jcol[(size_t)(-1 - what[p]) * dimI];
+      row[p] = 0.0;
+      for (int c = p + 1; c < ee; c++) {
+        const int w = what[c];
+        row[c] = w >= 0 ? J[w] * (sp * Q.scI[c]) : 0.0;
+      }
+      for (int j = 0; j < nb; j++) row[mI + j] = J[Q.gB[j]] * sp;
     }
-    row[u] = (hi[g] + hm[g]) * (1 + lambda) * (su * su);
-    for (int k = 0; k < Q.cdim; k++) row[nIs + k] = A.Jrows[k][g] * (su * Q.scI[nIs + k]);  // (mostly zeros: written, not assumed)
-    for (const Run &r : runsB) {
-      const double *h1 = hi + r.g0, *h2 = hm + r.g0;
-      double *o = row + mI + r.u0;
-      for (int i = 0; i < r.len; i++) o[i] = (h1[i] + h2[i]) * su;
-    }
-  }
-  for (int k = 0; k < Q.cdim; k++) {  // multiplier rows: zero diagonal block, the border columns of the constraint
-    double *row = U + (size_t)(nIs + k) * nt;
-    const double sk = Q.scI[nIs + k];
-    std::memset(row + nIs + k, 0, sizeof(double) * (size_t)(Q.cdim - k));
-    for (int j = 0; j < nb; j++) row[mI + j] = A.Jrows[k][Q.gB[j]] * sk;
   }
   for (int j = 0; j < nb; j++) {  // border rows: H_imu + HM, the diagonal times (1 + lambda); the visual block joins per iteration
     const int g = Q.gB[j];
@@ -784,6 +839,8 @@ void build_cache(ImuCache &Q, const sosf_imu_settings &S, const sosf_imu_calib &
     }
     row[j] = (hi[g] + hm[g]) * (1 + lambda);
   }
+  Q.bI0 = A.b;
+  Q.rc0 = A.r;
   clear_imu_blocks(A, n);
   const double tf0 = tmgb ? now_us() : 0;
   sos::ldlt_partial_factor(P);
@@ -804,11 +861,18 @@ void build_cache(ImuCache &Q, const sosf_imu_settings &S, const sosf_imu_calib &
   }
   Q.prior_id = prior_id;
   Q.HMptr = HM;
-  Q.HMdiag.resize(dimI);
-  for (int g = 0; g < dimI; g++) Q.HMdiag[g] = HM[(size_t)g * dimI + g];
-  if (prior_id == 0) Q.HMcopy.assign(HM, HM + (size_t)dimI * dimI);
+  if (keep) {  // what a later call is compared with
+    Q.HMdiag.resize(dimI);
+    for (int g = 0; g < dimI; g++) Q.HMdiag[g] = HM[(size_t)g * dimI + g];
+    if (prior_id == 0) Q.HMcopy.assign(HM, HM + (size_t)dimI * dimI);
+  }
   Q.valid = true;
-  if (tmgb) fprintf(stderr, "[imu_cached] build: assemble %.0f us, fill %.0f us, partial factorisation (%d of %d) %.0f us, copy %.0f us\n", tq1 - tq0, tf0 - tq1, mI, nt, tf1 - tf0, now_us() - tf1);
+  if (tmgb) {
+    long env = 0;
+    for (int p = 0; p < mI; p++) env += P.env_end[p] - p;
+    fprintf(stderr, "[imu_cached] build: assemble %.0f us, fill %.0f us, partial factorisation (%d of %d, mean envelope %.1f) %.0f us, copy %.0f us\n", tq1 - tq0, tf0 - tq1, mI, nt,
+            mI ? (double)env / mI : 0.0, tf1 - tf0, now_us() - tf1);
+  }
 }
 
 // b_imu (expanded dimension, kept between calls zeroed by the caller) and the constraint residuals at the current states, from the kept
@@ -876,7 +940,8 @@ void imu_rhs(const ImuCache &Q, const sosf_imu_settings &S, const sosf_imu_calib
   }
 }
 
-int cached_prepare(ImuCache &Q, const Prepared &P) {
+// trapped == false (the scale not yet trapped: Jacobians at the current states, nothing to keep): the same elimination, built and used once
+int cached_prepare(ImuCache &Q, const Prepared &P, bool trapped) {
   static const bool tmg = getenv("SOS_TIMING_IMU") != nullptr;
   const sosf_imu_settings &S = *P.S;
   const sosf_imu_calib &C = *P.C;
@@ -884,8 +949,8 @@ int cached_prepare(ImuCache &Q, const Prepared &P) {
   const double t0 = tmg ? now_us() : 0;
   double tb = t0;
   static thread_local std::vector<double> sig;
-  make_signature(S, C, n, P.F, P.lambda, sig);
-  bool same = Q.valid && sig == Q.sig && Q.prior_id == P.prior_id;
+  if (trapped) make_signature(S, C, n, P.F, P.lambda, sig);
+  bool same = trapped && Q.valid && sig == Q.sig && Q.prior_id == P.prior_id;
   if (same && P.prior_id != 0) {  // a named prior: same name, same place, same diagonal
     same = Q.HMptr == P.HM;
     for (int g = 0; same && g < dimI; g++) same = Q.HMdiag[g] == P.HM[(size_t)g * dimI + g];
@@ -893,16 +958,30 @@ int cached_prepare(ImuCache &Q, const Prepared &P) {
     same = std::memcmp(Q.HMcopy.data(), P.HM, sizeof(double) * (size_t)dimI * dimI) == 0;
   }
   tb = tmg ? now_us() : 0;
-  if (!same) {
+  bool once = !trapped;  // the elimination is built for this call alone (counted as a literal-form solve)
+  if (!trapped) {
+    build_cache(Q, S, C, n, P.F, P.HM, P.lambda, P.prior_id, false);
+    Q.valid = false;  // (nothing of it is kept: the next call's Jacobians are taken elsewhere)
+    Q.sig.clear();
+    tb = tmg ? now_us() : 0;
+    if (Q.unusable) return 1;
+  } else if (!same) {
     const bool repeats = !Q.sig.empty() && sig == Q.sig;  // same inputs as the previous call: a prior that moved, or a cache given up on
     Q.valid = false;
     Q.sig = sig;
-    if (Q.misses >= 3 && !repeats) return 1;  // the inputs move with every call: the literal form is the cheaper one
-    Q.misses++;
-    g_stats[1]++;
-    build_cache(Q, S, C, n, P.F, P.HM, P.lambda, P.prior_id);
-    tb = tmg ? now_us() : 0;
-    if (Q.unusable) return 1;
+    if (Q.misses >= 3 && !repeats) {  // the inputs move with every call: nothing is kept, the elimination is built and used once
+      build_cache(Q, S, C, n, P.F, P.HM, P.lambda, P.prior_id, false);
+      Q.valid = false;
+      tb = tmg ? now_us() : 0;
+      if (Q.unusable) return 1;
+      once = true;
+    } else {
+      Q.misses++;
+      g_stats[1]++;
+      build_cache(Q, S, C, n, P.F, P.HM, P.lambda, P.prior_id);
+      tb = tmg ? now_us() : 0;
+      if (Q.unusable) return 1;
+    }
   } else if (Q.unusable) {
     return 1;
   } else {
@@ -913,22 +992,28 @@ int cached_prepare(ImuCache &Q, const Prepared &P) {
   static thread_local std::vector<double> d2, bI, rc;
   d2.assign(dimI, 0.0);
   for (int i = 0; i < CP; i++) d2[i] = P.delta[i];
-  d2[CP] = C.scale - C.scale_zero;  // (scale trapped)
+  if (C.scale_trapped) d2[CP] = C.scale - C.scale_zero;
   for (int i = 0; i < n; i++) {
     for (int k = 0; k < 8; k++) d2[CP + 1 + 29 * i + k] = P.delta[CP + 8 * i + k];
-    for (int k = 0; k < 21; k++) d2[CP + 1 + 29 * i + 8 + k] = P.F[i].state_imu[k] - P.F[i].state_imu_zero[k];
+    if (C.scale_trapped)
+      for (int k = 0; k < 21; k++) d2[CP + 1 + 29 * i + 8 + k] = P.F[i].state_imu[k] - P.F[i].state_imu_zero[k];
   }
-  bI.assign(dimI, 0.0);
-  rc.assign(Q.cdim, 0.0);
-  imu_rhs(Q, S, C, n, P.F, bI.data(), rc.data());
+  if (C.scale_trapped) {
+    bI.assign(dimI, 0.0);
+    rc.assign(Q.cdim, 0.0);
+    imu_rhs(Q, S, C, n, P.F, bI.data(), rc.data());
+  } else {  // the assembly the factor was just built from holds b_imu and the constraint residuals of these very states
+    bI = Q.bI0;
+    rc = Q.rc0;
+  }
   const double t1 = tmg ? now_us() : 0;
   Q.y.assign(Q.nt, 0.0);
   Q.rhsB.assign(Q.nb, 0.0);
   for (int u = 0; u < Q.nIs; u++) {
-    const int g = Q.gI[u];
-    Q.y[u] = ((P.bM[g] + bI[g]) + dot4(P.HM + (size_t)g * dimI, d2.data(), dimI)) * Q.scI[u];
+    const int g = Q.gI[u], p = Q.pI[u];
+    Q.y[p] = ((P.bM[g] + bI[g]) + dot4(P.HM + (size_t)g * dimI, d2.data(), dimI)) * Q.scI[p];
   }
-  for (int k = 0; k < Q.cdim; k++) Q.y[Q.nIs + k] = rc[k] * Q.scI[Q.nIs + k];
+  for (int k = 0; k < Q.cdim; k++) Q.y[Q.pC[k]] = rc[k] * Q.scI[Q.pC[k]];
   for (int j = 0; j < Q.nb; j++) {
     const int g = Q.gB[j];
     Q.y[Q.mI + j] = (P.bM[g] + bI[g]) + dot4(P.HM + (size_t)g * dimI, d2.data(), dimI);
@@ -938,7 +1023,7 @@ int cached_prepare(ImuCache &Q, const Prepared &P) {
   if (tmg)
     fprintf(stderr, "[imu_cached] %s: compare/build %.0f us, residuals %.0f us, prior rhs %.0f us, forward %.0f us (interior %d, border %d)\n",
             same ? "hit" : "REBUILD", tb - t0, t1 - tb, t2 - t1, now_us() - t2, Q.mI, Q.nb);
-  return 0;
+  return once ? 2 : 0;
 }
 
 void cached_finish(ImuCache &Q, const Prepared &P, const double *H_top, const double *b_top, const double *H_sc, const double *b_sc, double *x,
@@ -995,7 +1080,7 @@ void cached_finish(ImuCache &Q, const Prepared &P, const double *H_top, const do
   }
   for (int u = 0; u < Q.nIs; u++) {
     const int g = Q.gI[u], i = (g - CP - 1) / 29, k = (g - CP - 1) % 29;
-    step_imu[21 * i + (k - 8)] = -(Q.y[u] * Q.scI[u]);
+    step_imu[21 * i + (k - 8)] = -(Q.y[Q.pI[u]] * Q.scI[Q.pI[u]]);
   }
   if (tmg) fprintf(stderr, "[imu_cached] border build %.0f us, border solve (dim %d) %.0f us, backward %.0f us\n", t1 - t0, nb, t2 - t1, now_us() - t2);
 }
@@ -1007,8 +1092,10 @@ extern "C" int sosf_imu_solve_prepare(const sosf_imu_settings *S, const sosf_imu
   if (!S || !C || n < 1 || !F || !HM || !bM || !delta) return SOS_ERR_ARG;
   if (g_mode < 0) g_mode = (getenv("SOS_IMU_CACHE") && atoi(getenv("SOS_IMU_CACHE")) == 0) ? 0 : 1;
   g_prep = Prepared{true, false, S, C, n, F, HM, bM, delta, lambda, prior_id};
-  if (C->scale_trapped && g_mode == 1) g_prep.cached = cached_prepare(g_cache, g_prep) == 0;
-  if (!g_prep.cached) g_stats[2]++;
+  int form = 1;  // 0 kept factor (or its rebuild), 2 the structured elimination built for this call alone, 1 the dense KKT system
+  if (g_mode == 1) form = cached_prepare(g_cache, g_prep, C->scale_trapped != 0);
+  g_prep.cached = form != 1;
+  if (form != 0) g_stats[2]++;  // (literal = the whole system built and factorised by this call, in either form)
   return SOS_OK;
 }
 

@@ -7,13 +7,10 @@
 #include <immintrin.h>
 
 #include <algorithm>
-#include <atomic>
 #include <cmath>
-#include <condition_variable>
+#include <memory>
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
-#include <thread>
 #include <vector>
 
 namespace sos {
@@ -380,151 +377,11 @@ inline bool ldlt_have_avx512() {
   return have;
 }
 
-// ---- the LARGE solves (the visual-inertial KKT system, dimension 4 + 1 + 29 n + constraints = 401 at n = 12) on a few cores --------
-// 97 % of the work of the factorisation is the rank-NB update of the trailing matrix, independent per row.  Rows are owned in
-// groups of three (the register tile of the update), cyclically by ABSOLUTE row index: a row stays in the cache of the core that
-// owns it from the copy-in to its elimination, and what is computed for an element does not depend on the number of threads.
-// The helpers are parked on a condition variable between solves and spin on a generation counter inside one (a panel is ~1 us).
-template <int R>
-__attribute__((target("avx512f,fma"))) inline void ldlt_rows_512(double *U, const double *WT, const double *LT, int n, int j, int kb) {
-  const size_t N = (size_t)n;
-  double *r[R];
-  for (int a = 0; a < R; a++) r[a] = U + (size_t)(j + a) * N;
-  for (int a = 0; a < R; a++)  // entries between the rows of the group
-    for (int b = a + 1; b < R; b++) {
-      double sv = 0;
-      for (int c = 0; c < kb; c++) sv += LT[c * N + j + a] * WT[c * N + j + b];
-      r[a][j + b] -= sv;
-    }
-  __m512d l[R][8];
-  const double *w[8];
-  for (int c = 0; c < 8; c++) {
-    const bool on = c < kb;
-    for (int a = 0; a < R; a++) l[a][c] = _mm512_set1_pd(on ? LT[c * N + j + a] : 0.0);
-    w[c] = WT + (size_t)(on ? c : 0) * N;
-  }
-  for (int i = j + R; i < n; i += 8) {
-    const __mmask8 m = (n - i >= 8) ? (__mmask8)0xff : (__mmask8)((1u << (n - i)) - 1u);
-    __m512d acc[R];
-    for (int a = 0; a < R; a++) acc[a] = _mm512_maskz_loadu_pd(m, r[a] + i);
-#pragma GCC unroll 8
-    for (int c = 0; c < 8; c++) {
-      const __m512d wv = _mm512_maskz_loadu_pd(m, w[c] + i);
-      for (int a = 0; a < R; a++) acc[a] = _mm512_fnmadd_pd(l[a][c], wv, acc[a]);
-    }
-    for (int a = 0; a < R; a++) _mm512_mask_storeu_pd(r[a] + i, m, acc[a]);
-  }
-}
-inline int ldlt_owner(int j, int T) { return (j / 3) % T; }
-// the share of thread `tid` of  U[j][i] -= sum_c L(j,c) W(i,c),  k1 <= j < i < n
-__attribute__((target("avx512f,fma"))) inline void ldlt_trailing_update_512_mt(double *U, const double *WT, const double *LT, int n, int k1, int kb, int tid,
-                                                                               int T) {
-  int j = k1;
-  const int head = std::min((3 - k1 % 3) % 3, n - k1);  // rows up to the next group boundary (the rest of a group begun by the panel)
-  if (head > 0) {
-    if (ldlt_owner(j, T) == tid) {
-      if (head == 2) ldlt_rows_512<2>(U, WT, LT, n, j, kb);
-      else ldlt_rows_512<1>(U, WT, LT, n, j, kb);
-    }
-    j += head;
-  }
-  for (; j + 2 < n; j += 3)
-    if (ldlt_owner(j, T) == tid) ldlt_rows_512<3>(U, WT, LT, n, j, kb);
-  if (n - j == 2 && ldlt_owner(j, T) == tid) ldlt_rows_512<2>(U, WT, LT, n, j, kb);  // (the last row has nothing right of the diagonal)
-}
-
-struct SolvePool {
-  enum { JOB_COPY = 1, JOB_UPDATE = 2 };
-  int T = 1;  // threads of a large solve, the caller included
-  std::vector<std::thread> th;
-  std::atomic<int> gen{0}, done{0};
-  std::atomic<bool> awake{false};
-  bool quit = false;
-  std::mutex mu;
-  std::condition_variable cv;
-  // the job
-  int job = 0, n = 0, k1 = 0, kb = 0;
-  const double *A = nullptr, *WT = nullptr, *LT = nullptr;
-  double *U = nullptr, *diag = nullptr;
-
-  SolvePool() {
-    // opt-in (SOS_SOLVE_THREADS=<n>): on the build container (8 virtual CPUs of a shared host) the helpers made the solve slower;
-    // whether they pay on the GPU box's host is for tools/validate_pending.sh to say
-    const char *e = getenv("SOS_SOLVE_THREADS");
-    T = e ? atoi(e) : 1;
-    if (T < 1 || !ldlt_have_avx512()) T = 1;
-    if (T > 16) T = 16;
-    for (int t = 1; t < T; t++) th.emplace_back([this, t] { worker(t); });
-  }
-  ~SolvePool() {
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      quit = true;
-    }
-    cv.notify_all();
-    for (std::thread &t : th) t.join();
-  }
-  void share(int tid) const {
-    if (job == JOB_COPY) {
-      const size_t N = (size_t)n;
-      for (int j = 0; j < n; j++)
-        if (ldlt_owner(j, T) == tid) {
-          const double *src = A + j * N;
-          double *dst = U + j * N;
-          for (int i = j + 1; i < n; i++) dst[i] = src[i];
-          diag[j] = src[j];
-        }
-    } else if (job == JOB_UPDATE) {
-      ldlt_trailing_update_512_mt(U, WT, LT, n, k1, kb, tid, T);
-    }
-  }
-  void worker(int tid) {
-    int seen = 0;  // (the pool is constructed with gen == 0 before any job; a helper that starts late must not skip the first one)
-    for (;;) {
-      {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return quit || awake.load(std::memory_order_acquire); });
-        if (quit) return;
-      }
-      while (awake.load(std::memory_order_acquire)) {
-        const int g = gen.load(std::memory_order_acquire);
-        if (g == seen) {
-          _mm_pause();
-          continue;
-        }
-        seen = g;
-        share(tid);
-        done.fetch_add(1, std::memory_order_release);
-      }
-    }
-  }
-  void begin() {  // wake the helpers for one solve
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      awake.store(true, std::memory_order_release);
-    }
-    cv.notify_all();
-  }
-  void end() { awake.store(false, std::memory_order_release); }
-  void run(int what) {  // every thread does its share of the job; returns when all are through
-    job = what;
-    done.store(0, std::memory_order_relaxed);
-    gen.fetch_add(1, std::memory_order_release);
-    share(0);
-    while (done.load(std::memory_order_acquire) != T - 1) _mm_pause();
-  }
-};
-inline SolvePool &solve_pool() {
-  static SolvePool pool;
-  return pool;
-}
-#define LDLT_MT_MIN_DIM 192  // below it (the visual system: 100 at W12, 132 at W16) a panel's update is too short to share
 // The factorisation proper: eliminates the pivots [0, stop) of the n x n symmetric matrix held as the strict upper triangle of U
 // (row-major) with its diagonal in diag[]; pivot candidates are [k, pend).  stop == pend == n is the full factorisation of
 // ldlt_solve; stop < n leaves the Schur complement of the eliminated block in the rows >= stop of U (strict upper part) and in
 // diag[stop..n) (ldlt_partial_* below).  D[k], perm[k] for k < stop; row k of U = the sub-diagonal part of column k of L.
-__attribute__((target("avx2,fma"))) inline void ldlt_factor(double *U, int n, int stop, int pend, double *D, int *perm, double *diag, double *WTp, double *LTp,
-                                                            SolvePool *pool) {
+__attribute__((target("avx2,fma"))) inline void ldlt_factor(double *U, int n, int stop, int pend, double *D, int *perm, double *diag, double *WTp, double *LTp) {
   const size_t N = (size_t)n;
   const bool wide = ldlt_have_avx512();
   const bool whole = pend == n;  // the 512-bit pivot pass reports the largest remaining |diagonal| over [k + 1, n): usable only then
@@ -589,10 +446,7 @@ __attribute__((target("avx2,fma"))) inline void ldlt_factor(double *U, int n, in
       }
     }
     if (k1 < n) {
-      if (pool) {
-        pool->k1 = k1; pool->kb = kb;
-        pool->run(SolvePool::JOB_UPDATE);
-      } else if (wide) ldlt_trailing_update_512(U, WTp, LTp, n, k1, kb);
+      if (wide) ldlt_trailing_update_512(U, WTp, LTp, n, k1, kb);
       else ldlt_trailing_update(U, WTp, LTp, n, k1, kb);
     }
   }
@@ -608,17 +462,8 @@ __attribute__((target("avx2,fma"))) inline void ldlt_solve(const std::vector<dou
   double *const U = inplace ? inplace : Uown.data();
   D.resize(N); y.resize(N); diag.resize(N); perm.resize(N);
   WT.resize((size_t)LDLT_NB * N); LT.resize((size_t)LDLT_NB * N);
-  const bool wide = ldlt_have_avx512();
-  SolvePool *pool = (wide && n >= LDLT_MT_MIN_DIM) ? &solve_pool() : nullptr;
-  if (pool && pool->T < 2) pool = nullptr;
-  if (pool) {
-    pool->n = n; pool->A = A.data(); pool->U = U; pool->diag = diag.data(); pool->WT = WT.data(); pool->LT = LT.data();
-    pool->begin();
-  }
   if (inplace) {
     for (int j = 0; j < n; j++) diag[j] = U[j * N + j];
-  } else if (pool) {
-    pool->run(SolvePool::JOB_COPY);
   } else {
     for (int j = 0; j < n; j++) {
       const double *src = &A[j * N];  // A is symmetric: row j right of the diagonal == column j below it
@@ -627,8 +472,7 @@ __attribute__((target("avx2,fma"))) inline void ldlt_solve(const std::vector<dou
       diag[j] = src[j];
     }
   }
-  ldlt_factor(U, n, n, n, D.data(), perm.data(), diag.data(), WT.data(), LT.data(), pool);
-  if (pool) pool->end();
+  ldlt_factor(U, n, n, n, D.data(), perm.data(), diag.data(), WT.data(), LT.data());
   for (int i = 0; i < n; i++) y[i] = b[i];
   for (int k = 0; k < n; k++) {  // L z = P b, column-oriented: L(i,k) = U[k][i]
     std::swap(y[k], y[perm[k]]);
@@ -656,74 +500,215 @@ __attribute__((target("avx2,fma"))) inline void ldlt_solve(const std::vector<dou
 }
 
 // ---- partial factorisation: K = [A B^T; B C] with the leading m x m block A eliminated once and reused for many right-hand sides
-// and many trailing blocks C (the visual-inertial KKT system with first-estimate Jacobians: everything except the visual block of
-// the border is constant over the iterations of one optimize(), sos_imu.cpp).  Pivots are taken from the leading block only.
+// and many trailing blocks C (the visual-inertial KKT system: everything except the visual block of the border is constant over the
+// iterations of one optimize() once the scale is trapped, sos_imu.cpp).  Pivots are taken from the leading block only.
+//
+// The leading block may carry STRUCTURE (round 5): pivot blocks (per keyframe: its bias / spline states, then the multipliers of its
+// constraints) that couple only to a few following blocks and to the border.  blk_end[k] = end of the pivot block of interior index k
+// (pivot candidates stay inside the block), env_end[k] = end of the interior columns a row of that block can be nonzero in (a block end,
+// the same for every k of a block, monotone in k).  The elimination then never leaves [k, env_end) + the border: per pivot
+// (env - k + border)^2 / 2 updates instead of (n - k)^2 / 2 -- at W12 (12 blocks of <= 27 interior unknowns, border 101) a quarter
+// of the dense count.  What lies outside the envelope is never read and need not be initialised.  Empty vectors: one block, full envelope.
 struct LdltPartial {
   int n = 0, m = 0;
-  std::vector<double> U;     // n x n: rows < m hold L (row k = column k of L right of the diagonal, over ALL n columns); rows >= m the
-                             // strict upper triangle of the Schur complement C - B A^-1 B^T
+  std::vector<double> U;     // n x n: rows < m hold L (row k = column k of L right of the diagonal, inside its envelope and over the
+                             // border); rows >= m the strict upper triangle of the Schur complement C - B A^-1 B^T
   std::vector<double> D;     // m pivots
   std::vector<double> diag;  // n: [m, n) = the diagonal of the Schur complement
-  std::vector<int> perm;     // m interchanges (within the leading block)
+  std::vector<int> perm;     // m interchanges (within the pivot blocks)
+  std::vector<int> blk_end, env_end;
+  int be(int k) const { return blk_end.empty() ? m : blk_end[k]; }
+  int ee(int k) const { return env_end.empty() ? m : env_end[k]; }
 };
-// F.U holds the upper triangle INCLUDING the diagonal on entry
+// U[j][i] -= sum_c L(j,c) W(i,c) for R consecutive rows j .. j + R - 1 and the columns i in [max(i0, j + 1), i1): the register tile
+// of the dense update (ldlt_rows_512) on a column range
+template <int R>
+__attribute__((target("avx512f,fma"))) inline void ldlt_range_rows_512(double *U, const double *WT, const double *LT, size_t N, int j, int kb, int i0, int i1) {
+  double *r[R];
+  for (int a = 0; a < R; a++) r[a] = U + (size_t)(j + a) * N;
+  for (int a = 0; a < R; a++)  // entries between the rows of the group
+    for (int b = a + 1; b < R; b++) {
+      if (j + b < i0 || j + b >= i1) continue;
+      double sv = 0;
+      for (int c = 0; c < kb; c++) sv += LT[c * N + j + a] * WT[c * N + j + b];
+      r[a][j + b] -= sv;
+    }
+  __m512d l[R][8];
+  const double *w[8];
+  for (int c = 0; c < 8; c++) {
+    const bool on = c < kb;
+    for (int a = 0; a < R; a++) l[a][c] = _mm512_set1_pd(on ? LT[c * N + j + a] : 0.0);
+    w[c] = WT + (size_t)(on ? c : 0) * N;
+  }
+  for (int i = std::max(i0, j + R); i < i1; i += 8) {
+    const __mmask8 m = (i1 - i >= 8) ? (__mmask8)0xff : (__mmask8)((1u << (i1 - i)) - 1u);
+    __m512d acc[R];
+    for (int a = 0; a < R; a++) acc[a] = _mm512_maskz_loadu_pd(m, r[a] + i);
+#pragma GCC unroll 8
+    for (int c = 0; c < 8; c++) {
+      const __m512d wv = _mm512_maskz_loadu_pd(m, w[c] + i);
+      for (int a = 0; a < R; a++) acc[a] = _mm512_fnmadd_pd(l[a][c], wv, acc[a]);
+    }
+    for (int a = 0; a < R; a++) _mm512_mask_storeu_pd(r[a] + i, m, acc[a]);
+  }
+}
+template <int R>
+__attribute__((target("avx2,fma"))) inline void ldlt_range_rows_256(double *U, const double *WT, const double *LT, size_t N, int j, int kb, int i0, int i1) {
+  double *r[R];
+  for (int a = 0; a < R; a++) r[a] = U + (size_t)(j + a) * N;
+  for (int a = 0; a < R; a++)
+    for (int b = a + 1; b < R; b++) {
+      if (j + b < i0 || j + b >= i1) continue;
+      double sv = 0;
+      for (int c = 0; c < kb; c++) sv += LT[c * N + j + a] * WT[c * N + j + b];
+      r[a][j + b] -= sv;
+    }
+  const int is = std::max(i0, j + R);
+  for (int c0 = 0; c0 < kb; c0 += 4) {
+    const int cb = std::min(4, kb - c0);
+    __m256d l[R][4];
+    const double *w[4];
+    for (int c = 0; c < 4; c++) {
+      const bool on = c < cb;
+      for (int a = 0; a < R; a++) l[a][c] = _mm256_set1_pd(on ? LT[(c0 + c) * N + j + a] : 0.0);
+      w[c] = WT + (size_t)(c0 + (on ? c : 0)) * N;
+    }
+    int i = is;
+    for (; i + 4 <= i1; i += 4) {
+      __m256d acc[R];
+      for (int a = 0; a < R; a++) acc[a] = _mm256_loadu_pd(r[a] + i);
+      for (int c = 0; c < 4; c++) {
+        const __m256d wv = _mm256_loadu_pd(w[c] + i);
+        for (int a = 0; a < R; a++) acc[a] = _mm256_fnmadd_pd(l[a][c], wv, acc[a]);
+      }
+      for (int a = 0; a < R; a++) _mm256_storeu_pd(r[a] + i, acc[a]);
+    }
+    for (; i < i1; i++)
+      for (int a = 0; a < R; a++) {
+        double sv = 0;
+        for (int c = 0; c < cb; c++) sv += LT[(c0 + c) * N + j + a] * WT[(c0 + c) * N + i];
+        r[a][i] -= sv;
+      }
+  }
+}
+// one pivot of a panel over a column range: column k brought up to date with the q earlier pivots of the panel, L = a / d into both
+// panel copies and the row of U, the candidate diagonal updated (the three loops of ldlt_factor's 256-bit path, fused)
+__attribute__((target("avx2,fma"))) inline void ldlt_pivot_range(double *uk, const double *WT, const double *LT, double *wt, double *lt, double *diag, size_t N,
+                                                               int k, int q, int a0, int a1, double dinv, bool zero) {
+  __m256d lk[LDLT_NB];
+  for (int c = 0; c < q; c++) lk[c] = _mm256_set1_pd(LT[c * N + k]);
+  const __m256d dv = _mm256_set1_pd(dinv);
+  int i = a0;
+  if (!zero)
+    for (; i + 4 <= a1; i += 4) {
+      __m256d a = _mm256_loadu_pd(uk + i);
+      for (int c = 0; c < q; c++) a = _mm256_fnmadd_pd(_mm256_loadu_pd(&WT[c * N + i]), lk[c], a);
+      const __m256d l = _mm256_mul_pd(a, dv);
+      _mm256_storeu_pd(wt + i, a);
+      _mm256_storeu_pd(lt + i, l);
+      _mm256_storeu_pd(uk + i, l);
+      _mm256_storeu_pd(diag + i, _mm256_fnmadd_pd(a, l, _mm256_loadu_pd(diag + i)));
+    }
+  for (; i < a1; i++) {
+    double a = uk[i];
+    for (int c = 0; c < q; c++) a -= WT[c * N + i] * LT[c * N + k];
+    if (zero) a = 0.0;  // an exact-zero pivot contributes nothing (Eigen LDLT::solve semantics)
+    const double l = a * dinv;
+    wt[i] = a; lt[i] = l; uk[i] = l;
+    diag[i] -= a * l;
+  }
+}
+// rows [j0, j1) x columns [max(i0, row + 1), i1)
+inline void ldlt_range_update(double *U, const double *WT, const double *LT, size_t N, int j0, int j1, int i0, int i1, int kb, bool wide) {
+  int j = j0;
+  if (wide) {
+    for (; j + 3 <= j1; j += 3) ldlt_range_rows_512<3>(U, WT, LT, N, j, kb, i0, i1);
+    if (j1 - j == 2) ldlt_range_rows_512<2>(U, WT, LT, N, j, kb, i0, i1);
+    else if (j1 - j == 1) ldlt_range_rows_512<1>(U, WT, LT, N, j, kb, i0, i1);
+  } else {
+    for (; j + 3 <= j1; j += 3) ldlt_range_rows_256<3>(U, WT, LT, N, j, kb, i0, i1);
+    if (j1 - j == 2) ldlt_range_rows_256<2>(U, WT, LT, N, j, kb, i0, i1);
+    else if (j1 - j == 1) ldlt_range_rows_256<1>(U, WT, LT, N, j, kb, i0, i1);
+  }
+}
+// F.U holds the upper triangle INCLUDING the diagonal on entry (inside the envelope and over the border)
 inline void ldlt_partial_factor(LdltPartial &F) {
   const int n = F.n, m = F.m;
   const size_t N = (size_t)n;
   F.D.assign(m, 0.0);
   F.diag.resize(N);
   F.perm.assign(m, 0);
-  static thread_local std::vector<double> WT, LT;
-  WT.resize((size_t)LDLT_NB * N); LT.resize((size_t)LDLT_NB * N);
-  for (int j = 0; j < n; j++) F.diag[j] = F.U[j * N + j];
-  SolvePool *pool = (ldlt_have_avx512() && n >= LDLT_MT_MIN_DIM) ? &solve_pool() : nullptr;
-  if (pool && pool->T < 2) pool = nullptr;
-  if (pool) {
-    pool->n = n; pool->A = F.U.data(); pool->U = F.U.data(); pool->diag = F.diag.data(); pool->WT = WT.data(); pool->LT = LT.data();
-    pool->begin();
+  static thread_local std::vector<double> WTv, LTv;
+  WTv.resize((size_t)LDLT_NB * N); LTv.resize((size_t)LDLT_NB * N);
+  double *U = F.U.data(), *diag = F.diag.data(), *WTp = WTv.data(), *LTp = LTv.data();
+  for (int j = 0; j < n; j++) diag[j] = U[j * N + j];
+  const bool wide = ldlt_have_avx512();
+  for (int k0 = 0; k0 < m;) {
+    const int bend = F.be(k0), eend = F.ee(k0);     // pivot block and interior envelope of this panel
+    const int kb = std::min(LDLT_NB, bend - k0), k1 = k0 + kb;
+    for (int k = k0; k < k1; k++) {
+      const int q = k - k0;
+      // threshold pivoting inside the pivot block (see ldlt_factor)
+      int p = k;
+      {
+        double best = std::fabs(diag[k]);
+        int pb = k;
+        for (int i = k + 1; i < bend; i++)
+          if (std::fabs(diag[i]) > best) { best = std::fabs(diag[i]); pb = i; }
+        if (!(std::fabs(diag[k]) >= 0.1 * best)) p = pb;
+      }
+      F.perm[k] = p;
+      if (p != k) {  // symmetric interchange k <-> p of the not yet eliminated part (both inside one block: same envelope)
+        for (int j = k + 1; j < p; j++) std::swap(U[k * N + j], U[j * N + p]);
+        double *rk = &U[k * N], *rp = &U[p * N];
+        for (int i = p + 1; i < eend; i++) std::swap(rk[i], rp[i]);
+        for (int i = m; i < n; i++) std::swap(rk[i], rp[i]);
+        std::swap(diag[k], diag[p]);
+        for (int c = 0; c < q; c++) { std::swap(WTp[c * N + k], WTp[c * N + p]); std::swap(LTp[c * N + k], LTp[c * N + p]); }
+      }
+      const double d = diag[k];
+      F.D[k] = d;
+      double *wt = &WTp[(size_t)q * N], *lt = &LTp[(size_t)q * N], *uk = &U[k * N];
+      const bool zero = !(std::fabs(d) > 2.2250738585072014e-308);
+      const double dinv = zero ? 0.0 : 1.0 / d;
+      // column k brought up to date with the q earlier pivots of the panel, L = a / d, candidate diagonal -- over its two ranges
+      for (int part = 0; part < 2; part++)
+        ldlt_pivot_range(uk, WTp, LTp, wt, lt, diag, N, k, q, part == 0 ? k + 1 : m, part == 0 ? eend : n, dinv, zero);
+    }
+    // trailing update: (interior rest of the envelope) x (itself + border), border x border
+    ldlt_range_update(U, WTp, LTp, N, k1, eend, k1, eend, kb, wide);
+    ldlt_range_update(U, WTp, LTp, N, k1, eend, m, n, kb, wide);
+    ldlt_range_update(U, WTp, LTp, N, m, n, m, n, kb, wide);
+    k0 = k1;
   }
-  ldlt_factor(F.U.data(), n, m, m, F.D.data(), F.perm.data(), F.diag.data(), WT.data(), LT.data(), pool);
-  if (pool) pool->end();
   // the factorisation leaves the finished columns of L in the row order they were computed in; bring them to the final order (the
-  // later interchanges applied to the earlier columns), so that the substitutions can apply all interchanges to the vector first
-  double *U = F.U.data();
+  // later interchanges applied to the earlier columns whose envelope holds them), so that the substitutions can apply all
+  // interchanges to the vector first
   for (int k = 0; k < m; k++) {
     const int p = F.perm[k];
     if (p != k)
-      for (int c = 0; c < k; c++) std::swap(U[c * N + k], U[c * N + p]);
+      for (int c = 0; c < k; c++)
+        if (F.ee(c) > k) std::swap(U[c * N + k], U[c * N + p]);
   }
 }
 // y (n): right-hand side in, [L^-1 P a ; c - B A^-1 a] out (the leading part still to be divided by D: done by the backward pass).
 // L is in its final row order (ldlt_partial_factor), so the interchanges are applied to y up front and the pass is a plain
-// triangular solve, four pivots at a time: one load / store of y per four columns of L.
+// triangular solve over each row's envelope and the border.
 __attribute__((target("avx2,fma"))) inline void ldlt_partial_forward(const LdltPartial &F, double *__restrict y) {
   const int n = F.n, m = F.m;
   const size_t N = (size_t)n;
   for (int k = 0; k < m; k++) std::swap(y[k], y[F.perm[k]]);
-  int k = 0;
-  for (; k + 4 <= m; k += 4) {
-    const double *__restrict u0 = &F.U[k * N], *__restrict u1 = u0 + N, *__restrict u2 = u1 + N, *__restrict u3 = u2 + N;
-    const double y0 = y[k];
-    const double y1 = y[k + 1] - u0[k + 1] * y0;
-    const double y2 = (y[k + 2] - u0[k + 2] * y0) - u1[k + 2] * y1;
-    const double y3 = ((y[k + 3] - u0[k + 3] * y0) - u1[k + 3] * y1) - u2[k + 3] * y2;
-    y[k + 1] = y1; y[k + 2] = y2; y[k + 3] = y3;
-    const __m256d v0 = _mm256_set1_pd(y0), v1 = _mm256_set1_pd(y1), v2 = _mm256_set1_pd(y2), v3 = _mm256_set1_pd(y3);
-    int i = k + 4;
-    for (; i + 4 <= n; i += 4) {
-      __m256d a = _mm256_loadu_pd(y + i);
-      a = _mm256_fnmadd_pd(_mm256_loadu_pd(u0 + i), v0, a);
-      a = _mm256_fnmadd_pd(_mm256_loadu_pd(u1 + i), v1, a);
-      a = _mm256_fnmadd_pd(_mm256_loadu_pd(u2 + i), v2, a);
-      a = _mm256_fnmadd_pd(_mm256_loadu_pd(u3 + i), v3, a);
-      _mm256_storeu_pd(y + i, a);
-    }
-    for (; i < n; i++) y[i] = (((y[i] - u0[i] * y0) - u1[i] * y1) - u2[i] * y2) - u3[i] * y3;
-  }
-  for (; k < m; k++) {
+  for (int k = 0; k < m; k++) {
     const double yk = y[k];
+    if (yk == 0.0) continue;
     const double *__restrict uk = &F.U[k * N];
-    for (int i = k + 1; i < n; i++) y[i] -= uk[i] * yk;
+    const __m256d v = _mm256_set1_pd(yk);
+    for (int part = 0; part < 2; part++) {
+      int i = part == 0 ? k + 1 : m;
+      const int a1 = part == 0 ? F.ee(k) : n;
+      for (; i + 4 <= a1; i += 4) _mm256_storeu_pd(y + i, _mm256_fnmadd_pd(_mm256_loadu_pd(uk + i), v, _mm256_loadu_pd(y + i)));
+      for (; i < a1; i++) y[i] -= uk[i] * yk;
+    }
   }
 }
 // y (n): leading part as ldlt_partial_forward left it, trailing part = the solution of the trailing block; out: the whole solution
@@ -731,35 +716,22 @@ __attribute__((target("avx2,fma"))) inline void ldlt_partial_backward(const Ldlt
   const int n = F.n, m = F.m;
   const size_t N = (size_t)n;
   for (int i = 0; i < m; i++) y[i] = (std::fabs(F.D[i]) > 2.2250738585072014e-308) ? y[i] / F.D[i] : 0.0;
-  int k = m;
-  for (; k - 4 >= 0; k -= 4) {  // rows k-4 .. k-1: their dot products with the part already solved share the loads of y
-    const int r = k - 4;
-    const double *__restrict u0 = &F.U[r * N], *__restrict u1 = u0 + N, *__restrict u2 = u1 + N, *__restrict u3 = u2 + N;
-    __m256d a0 = _mm256_setzero_pd(), a1 = a0, a2 = a0, a3 = a0;
-    int i = k;
-    for (; i + 4 <= n; i += 4) {
-      const __m256d v = _mm256_loadu_pd(y + i);
-      a0 = _mm256_fmadd_pd(_mm256_loadu_pd(u0 + i), v, a0);
-      a1 = _mm256_fmadd_pd(_mm256_loadu_pd(u1 + i), v, a1);
-      a2 = _mm256_fmadd_pd(_mm256_loadu_pd(u2 + i), v, a2);
-      a3 = _mm256_fmadd_pd(_mm256_loadu_pd(u3 + i), v, a3);
-    }
-    double t0[4], t1[4], t2[4], t3[4];
-    _mm256_storeu_pd(t0, a0); _mm256_storeu_pd(t1, a1); _mm256_storeu_pd(t2, a2); _mm256_storeu_pd(t3, a3);
-    double d0 = (t0[0] + t0[1]) + (t0[2] + t0[3]), d1 = (t1[0] + t1[1]) + (t1[2] + t1[3]), d2 = (t2[0] + t2[1]) + (t2[2] + t2[3]),
-           d3 = (t3[0] + t3[1]) + (t3[2] + t3[3]);
-    for (; i < n; i++) { d0 += u0[i] * y[i]; d1 += u1[i] * y[i]; d2 += u2[i] * y[i]; d3 += u3[i] * y[i]; }
-    const double y3 = y[r + 3] - d3;
-    const double y2 = (y[r + 2] - d2) - u2[r + 3] * y3;
-    const double y1 = ((y[r + 1] - d1) - u1[r + 2] * y2) - u1[r + 3] * y3;
-    const double y0 = (((y[r] - d0) - u0[r + 1] * y1) - u0[r + 2] * y2) - u0[r + 3] * y3;
-    y[r] = y0; y[r + 1] = y1; y[r + 2] = y2; y[r + 3] = y3;
-  }
-  for (k--; k >= 0; k--) {
-    const double *uk = &F.U[k * N];
+  for (int k = m - 1; k >= 0; k--) {
+    const double *__restrict uk = &F.U[k * N];
+    __m256d a0 = _mm256_setzero_pd(), a1 = a0;
     double dot = 0;
-    for (int i = k + 1; i < n; i++) dot += uk[i] * y[i];
-    y[k] -= dot;
+    for (int part = 0; part < 2; part++) {
+      int i = part == 0 ? k + 1 : m;
+      const int e1 = part == 0 ? F.ee(k) : n;
+      for (; i + 8 <= e1; i += 8) {
+        a0 = _mm256_fmadd_pd(_mm256_loadu_pd(uk + i), _mm256_loadu_pd(y + i), a0);
+        a1 = _mm256_fmadd_pd(_mm256_loadu_pd(uk + i + 4), _mm256_loadu_pd(y + i + 4), a1);
+      }
+      for (; i < e1; i++) dot += uk[i] * y[i];
+    }
+    double t[4];
+    _mm256_storeu_pd(t, _mm256_add_pd(a0, a1));
+    y[k] -= ((t[0] + t[1]) + (t[2] + t[3])) + dot;
   }
   for (int q = m - 1; q >= 0; q--) std::swap(y[q], y[F.perm[q]]);
 }

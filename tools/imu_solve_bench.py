@@ -85,6 +85,21 @@ def main():
             if rep == 0 and k % 3 != 2:
                 rb.append(t)
     out["rebuild_us"] = float(np.median(rb) * 1e6)
+    # the scale not trapped yet (Jacobians at the current states: nothing can be kept): the same per-keyframe elimination built and used by
+    # every call (round 5) against the dense KKT system of rounds 1-4
+    trapped = cal.scale_trapped
+    cal.scale_trapped = 0
+    for name, mode in (("untrapped_dense", 0), ("untrapped_structured", 1)):
+        f.solve_mode(mode)
+        two_calls(0)
+        xs = x.copy()
+        out[name + "_us"] = float(np.median(np.array([sum(two_calls(0)) for _ in range(reps)]) * 1e6))
+        if mode == 0:
+            x_ud = xs
+        else:
+            out["untrapped_structured_vs_dense_x"] = float(np.abs(xs - x_ud).max() / np.abs(x_ud).max())
+    cal.scale_trapped = trapped
+    f.solve_mode(1)
     out["stats_kept_rebuilt_literal"] = f.solve_stats()
     print(out)
 
