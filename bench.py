@@ -743,6 +743,13 @@ def tracker_timing(window, device):
            "set_coarse_tracking_ref_ms": timeit(ht.set_ref),
            "track_newest_coarse_ms": timeit(lambda: ht.track(new_slot, 1.0, Tinit, np.zeros(2), levels - 1)),
            "optimize_scale_ms": timeit(lambda: ht.optimize_scale(st_slot, win.stereo_tfm, K1, 1.2, levels - 1))}
+    # where one launch of trackNewestCoarse spends its time, from the kernel's own stamps (FS/CoarseTracker.cpp:366-552): residual
+    # passes / all-gather of the chunk sums / bookkeeping between evaluations (8 x 8 solve, SE3::exp)
+    try:
+        ht.track(new_slot, 1.0, Tinit, np.zeros(2), levels - 1)
+        out["track_lm_profile"] = ht.lm_profile(0)
+    except Exception as e:  # noqa: BLE001
+        out["track_lm_profile"] = {"error": repr(e)}
     sysm.close()
     return out
 

@@ -511,6 +511,11 @@ int sos_tracker_optimize_scale(sos_tracker *trk, int stereoSlot, const float *RK
  * waits up to this bound and returns SOS_ERR_TIMEOUT instead of hanging.  0 makes every wait that is not satisfied at once give up
  * (tests use it to drive the fallback). */
 int sos_tracker_set_lm_spin_limit(sos_tracker *trk, unsigned rounds);
+/* Phase times of the last one-launch loop (sos_tracker_track / _optimize_scale / the loop aligner), hypothesis `hyp`, in microseconds
+ * from the kernel's own 100 MHz stamps: us7 = [kernel, residual passes (calcRes + calcGSSSE products, FS/CoarseTracker.cpp:612-764,
+ * 554-610), all-gather of the per-chunk sums, bookkeeping between two evaluations (:432-510) -- of which the damped 8 x 8 solve and
+ * SE3::exp + the next request --, number of residual evaluations].  A profiling aid: nothing else reads it. */
+int sos_tracker_lm_profile(sos_tracker *T, int hyp, double *us7);
 
 /* ScaleOptimizer::calcResScale / calcGSSSEScale (FS/ScaleOptimizer.cpp:273-437, 232-271).
  * RKi = rot(tfmF0ToF1) * Ki[lvl], t = trans(tfmF0ToF1); K1 = (fx1,fy1,cx1,cy1) of level `lvl`. */

@@ -203,6 +203,9 @@ int sosf_tracker_optimize_scale_kf(sosf_tracker *trk, int stereoSlot, const doub
  * arithmetic per pixel; the two differ by the rounding of the 8x8 solve).  last_evals: residual evaluations of the last call. */
 int sosf_tracker_set_device_lm(sosf_tracker *trk, int on);
 int sosf_tracker_last_evals(sosf_tracker *trk, int *evals);
+/* where the last one-launch loop spent its time (sos_tracker_lm_profile, include/sos_slam.h): microseconds [kernel, residual passes,
+ * all-gather of the chunk sums, bookkeeping between evaluations, of which 8 x 8 solve, SE3::exp + request, number of evaluations] */
+int sosf_tracker_lm_profile(sosf_tracker *trk, int hyp, double *us7);
 /* The one-launch loops need all their workgroups resident; their waits are bounded (sos_tracker_set_lm_spin_limit, include/sos_slam.h).
  * When a launch comes back SOS_ERR_TIMEOUT -- other streams kept the device busy -- the facade redoes that call with the host loop
  * around the device passes (same decisions; hypotheses of the batch one by one) and counts it here.  set_lm_spin_limit forwards the

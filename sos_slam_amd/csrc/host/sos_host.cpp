@@ -3115,6 +3115,10 @@ extern "C" int sosf_tracker_last_evals(sosf_tracker *t, int *evals) {
   *evals = t->ct->lastEvals;
   return SOS_OK;
 }
+extern "C" int sosf_tracker_lm_profile(sosf_tracker *t, int hyp, double *us7) {
+  if (!t || !us7) return SOS_ERR_ARG;
+  return sos_tracker_lm_profile(t->ct->trk, hyp, us7);
+}
 extern "C" int sosf_tracker_set_lm_spin_limit(sosf_tracker *t, unsigned rounds) {
   if (!t) return SOS_ERR_ARG;
   return sos_tracker_set_lm_spin_limit(t->ct->trk, rounds);

@@ -559,6 +559,17 @@ class HostTracker:
         _chk(self.L.sosf_tracker_lm_fallbacks(self.h_, C.byref(n)), "sosf_tracker_lm_fallbacks")
         return int(n.value)
 
+    def lm_profile(self, hyp: int = 0) -> dict:
+        """Phase times of the last one-launch LM loop from the kernel's own stamps (sosf_tracker_lm_profile), per launch and per evaluation."""
+        us = np.zeros(7)
+        self.L.sosf_tracker_lm_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        _chk(self.L.sosf_tracker_lm_profile(self.h_, hyp, _p(us)), "sosf_tracker_lm_profile")
+        ev = max(1.0, us[6])
+        names = ("kernel", "residual_pass", "gather_chunk_sums", "bookkeeping", "solve_8x8", "se3_exp_and_request")
+        out = {"evaluations": int(us[6]), "us_per_launch": {k: round(float(v), 2) for k, v in zip(names, us[:6])},
+               "us_per_evaluation": {k: round(float(v / ev), 3) for k, v in zip(names, us[:6])}}
+        return out
+
     def last_evals(self) -> int:
         n = C.c_int(0)
         _chk(self.L.sosf_tracker_last_evals(self.h_, C.byref(n)), "sosf_tracker_last_evals")

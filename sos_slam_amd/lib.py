@@ -27,7 +27,7 @@ SYMBOLS = [
     "sos_comm_rank", "sos_ba_set_comm", "sos_ba_newest_capacity", "sos_ba_gather_energies", "sos_ba_allreduce_f64", "sos_ba_get_jacobian", "sos_ba_get_residual_flags", "sos_ba_get_JpJdF",
     "sos_ba_get_res_toZeroF", "sos_ba_time_kernel", "sos_gn_solve_system", "sos_tracker_create", "sos_tracker_destroy",
     "sos_tracker_set_ref", "sos_tracker_set_points3d", "sos_tracker_scale_depth", "sos_tracker_get_pc", "sos_tracker_calc_res",
-    "sos_tracker_calc_gs", "sos_tracker_calc_res_scale", "sos_tracker_calc_gs_scale", "sos_backend_name",
+    "sos_tracker_lm_profile", "sos_tracker_calc_gs", "sos_tracker_calc_res_scale", "sos_tracker_calc_gs_scale", "sos_backend_name",
 ]
 
 

@@ -41,9 +41,13 @@ def _worker(rank, port, q):
     E = ow.linearize(th)
     ow.apply_res()
     acc = ow.accumulate(fp64_truth=True)
-    # the exchange step: one all-reduce of the packed H/b blocks (fp64 here, fp32 on the device)
-    packed = torch.from_numpy(np.concatenate([acc[k].reshape(-1) for k in ("H_A", "b_A", "H_sc", "b_sc")] +
-                                             [np.array([E, acc["resInA"]], dtype=np.float64)]))
+    # the exchange step: one all-reduce.  The layout is the one the absolute-coordinate path (SOS_ABS_SC=1) exchanges on the device --
+    # the STITCHED fp64 system [H_A b_A | H_sc b_sc | count], 2 (dim^2 + dim) + 1 doubles (162 KB at W12; bench.py exchange_info);
+    # the default path exchanges the packed fp32 accumulator before the stitch instead (same sums, the stitch is linear)
+    dim = 4 + 8 * win.n
+    stitched = np.concatenate([acc[k].reshape(-1) for k in ("H_A", "b_A", "H_sc", "b_sc")] + [np.array([acc["resInA"]], dtype=np.float64)])
+    assert stitched.size == 2 * (dim * dim + dim) + 1
+    packed = torch.from_numpy(np.concatenate([stitched, np.array([E])]))   # (+ the energy, for the comparison below)
     dist.all_reduce(packed)
     # global order statistic of the newest frame's energies
     res = ow.res()
@@ -75,7 +79,7 @@ def test_sharded_accumulation_equals_whole_window():
     ow.apply_res()
     acc = ow.accumulate(fp64_truth=True)
     ref = np.concatenate([acc[k].reshape(-1) for k in ("H_A", "b_A", "H_sc", "b_sc")] +
-                         [np.array([E, acc["resInA"]], dtype=np.float64)])
+                         [np.array([acc["resInA"], E], dtype=np.float64)])
     assert np.allclose(packed, ref, rtol=1e-12, atol=1e-9 * np.abs(ref).max())
     res = ow.res()
     wo = ow.new_energy_wo()

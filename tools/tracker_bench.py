@@ -42,6 +42,7 @@ def timeit(fn, reps):
 t_set = timeit(lambda: ht.set_ref(), 20)
 t_trk = timeit(lambda: ht.track(new_slot, 1.0, Tinit, np.zeros(2), levels - 1), 50)   # device-resident LM loop (default)
 evals = ht.last_evals()
+lm_profile = ht.lm_profile(0)   # the kernel's own phase stamps of the last launch
 ht.set_device_lm(False)
 t_trk_host = timeit(lambda: ht.track(new_slot, 1.0, Tinit, np.zeros(2), levels - 1), 20)  # LM loop on the host, one round trip per evaluation
 ht.set_device_lm(True)
@@ -67,7 +68,7 @@ out = {"window": name, "template_pixels_per_level": [int(x) for x in pc_n[:level
                   "track_83_hypotheses_batch16": t_hyp16 * 1e3, "track_83_hypotheses_batch1": t_hyp1 * 1e3,
                   "track_83_hypotheses_host_loop": t_hyp_host * 1e3,
                   "optimize_scale_7_guesses": t_sc7 * 1e3, "optimize_scale_7_guesses_host_loop": t_sc7_host * 1e3},
-       "residual_evaluations_per_track": evals, "us_per_evaluation": t_trk * 1e6 / max(evals, 1)}
+       "residual_evaluations_per_track": evals, "us_per_evaluation": t_trk * 1e6 / max(evals, 1), "track_lm_profile": lm_profile}
 
 # oracle port on the host (single thread, as the reference's tracker is)
 ow = orc.window_from_synth(win)
