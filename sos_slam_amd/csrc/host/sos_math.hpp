@@ -522,8 +522,10 @@ struct LdltPartial {
 };
 // U[j][i] -= sum_c L(j,c) W(i,c) for R consecutive rows j .. j + R - 1 and the columns i in [max(i0, j + 1), i1): the register tile
 // of the dense update (ldlt_rows_512) on a column range
+// (a second column range [i2, i3) shares the set-up of the row group: the interior rows update their envelope AND the border)
 template <int R>
-__attribute__((target("avx512f,fma"))) inline void ldlt_range_rows_512(double *U, const double *WT, const double *LT, size_t N, int j, int kb, int i0, int i1) {
+__attribute__((target("avx512f,fma"))) inline void ldlt_range_rows_512(double *U, const double *WT, const double *LT, size_t N, int j, int kb, int i0, int i1,
+                                                                       int i2 = 0, int i3 = 0) {
   double *r[R];
   for (int a = 0; a < R; a++) r[a] = U + (size_t)(j + a) * N;
   for (int a = 0; a < R; a++)  // entries between the rows of the group
@@ -540,16 +542,19 @@ __attribute__((target("avx512f,fma"))) inline void ldlt_range_rows_512(double *U
     for (int a = 0; a < R; a++) l[a][c] = _mm512_set1_pd(on ? LT[c * N + j + a] : 0.0);
     w[c] = WT + (size_t)(on ? c : 0) * N;
   }
-  for (int i = std::max(i0, j + R); i < i1; i += 8) {
-    const __mmask8 m = (i1 - i >= 8) ? (__mmask8)0xff : (__mmask8)((1u << (i1 - i)) - 1u);
-    __m512d acc[R];
-    for (int a = 0; a < R; a++) acc[a] = _mm512_maskz_loadu_pd(m, r[a] + i);
+  for (int part = 0; part < 2; part++) {
+    const int e1 = part == 0 ? i1 : i3;
+    for (int i = part == 0 ? std::max(i0, j + R) : i2; i < e1; i += 8) {
+      const __mmask8 m = (e1 - i >= 8) ? (__mmask8)0xff : (__mmask8)((1u << (e1 - i)) - 1u);
+      __m512d acc[R];
+      for (int a = 0; a < R; a++) acc[a] = _mm512_maskz_loadu_pd(m, r[a] + i);
 #pragma GCC unroll 8
-    for (int c = 0; c < 8; c++) {
-      const __m512d wv = _mm512_maskz_loadu_pd(m, w[c] + i);
-      for (int a = 0; a < R; a++) acc[a] = _mm512_fnmadd_pd(l[a][c], wv, acc[a]);
+      for (int c = 0; c < 8; c++) {
+        const __m512d wv = _mm512_maskz_loadu_pd(m, w[c] + i);
+        for (int a = 0; a < R; a++) acc[a] = _mm512_fnmadd_pd(l[a][c], wv, acc[a]);
+      }
+      for (int a = 0; a < R; a++) _mm512_mask_storeu_pd(r[a] + i, m, acc[a]);
     }
-    for (int a = 0; a < R; a++) _mm512_mask_storeu_pd(r[a] + i, m, acc[a]);
   }
 }
 template <int R>
@@ -618,17 +623,63 @@ __attribute__((target("avx2,fma"))) inline void ldlt_pivot_range(double *uk, con
     diag[i] -= a * l;
   }
 }
-// rows [j0, j1) x columns [max(i0, row + 1), i1)
-inline void ldlt_range_update(double *U, const double *WT, const double *LT, size_t N, int j0, int j1, int i0, int i1, int kb, bool wide) {
+// rows [j0, j1) x columns [max(i0, row + 1), i1) and [i2, i3)
+inline void ldlt_range_update(double *U, const double *WT, const double *LT, size_t N, int j0, int j1, int i0, int i1, int kb, bool wide, int i2 = 0, int i3 = 0) {
   int j = j0;
   if (wide) {
-    for (; j + 3 <= j1; j += 3) ldlt_range_rows_512<3>(U, WT, LT, N, j, kb, i0, i1);
-    if (j1 - j == 2) ldlt_range_rows_512<2>(U, WT, LT, N, j, kb, i0, i1);
-    else if (j1 - j == 1) ldlt_range_rows_512<1>(U, WT, LT, N, j, kb, i0, i1);
+    for (; j + 3 <= j1; j += 3) ldlt_range_rows_512<3>(U, WT, LT, N, j, kb, i0, i1, i2, i3);
+    if (j1 - j == 2) ldlt_range_rows_512<2>(U, WT, LT, N, j, kb, i0, i1, i2, i3);
+    else if (j1 - j == 1) ldlt_range_rows_512<1>(U, WT, LT, N, j, kb, i0, i1, i2, i3);
   } else {
+    if (i3 > i2) ldlt_range_update(U, WT, LT, N, j0, j1, i2, i3, kb, false);
     for (; j + 3 <= j1; j += 3) ldlt_range_rows_256<3>(U, WT, LT, N, j, kb, i0, i1);
     if (j1 - j == 2) ldlt_range_rows_256<2>(U, WT, LT, N, j, kb, i0, i1);
     else if (j1 - j == 1) ldlt_range_rows_256<1>(U, WT, LT, N, j, kb, i0, i1);
+  }
+}
+// The trailing block's share of the elimination, applied ONCE behind the last pivot instead of panel by panel:
+//   U[m + j][m + i] -= sum_k WB[k][j] * G[k][i]   (j < i),   G[k] = row k of U over the border columns (L), WB[k] = the same row times D[k].
+// Nothing reads the trailing block before the factorisation ends, and in this form every element is loaded and stored once while the sum
+// over all m pivots runs in registers (3 x 16 tile: 5 loads per 6 multiply-adds) -- the panel-wise update spent as long on setting up
+// its 3-row groups (101 columns = 7 vector steps per group) as on the arithmetic.
+__attribute__((target("avx512f,fma"))) inline void ldlt_border_update_512(double *U, const double *WB, size_t N, int m, int n) {
+  const int nb = n - m;
+  for (int j = 0; j + 1 < nb; j += 3) {
+    const int R = std::min(3, nb - j);
+    for (int i = j + 1; i < nb; i += 16) {
+      const int c0 = std::min(8, nb - i), c1 = std::max(0, std::min(8, nb - i - 8));
+      const __mmask8 m0 = (__mmask8)((1u << c0) - 1u), m1 = (__mmask8)((1u << c1) - 1u);
+      __m512d a00 = _mm512_setzero_pd(), a01 = a00, a10 = a00, a11 = a00, a20 = a00, a21 = a00;
+      const double *g = U + m + i, *w = WB + j;
+      for (int k = 0; k < m; k++, g += N, w += nb) {
+        const __m512d g0 = _mm512_maskz_loadu_pd(m0, g), g1 = _mm512_maskz_loadu_pd(m1, g + 8);
+        const __m512d w0 = _mm512_set1_pd(w[0]);
+        a00 = _mm512_fmadd_pd(w0, g0, a00); a01 = _mm512_fmadd_pd(w0, g1, a01);
+        if (R > 1) { const __m512d w1 = _mm512_set1_pd(w[1]); a10 = _mm512_fmadd_pd(w1, g0, a10); a11 = _mm512_fmadd_pd(w1, g1, a11); }
+        if (R > 2) { const __m512d w2 = _mm512_set1_pd(w[2]); a20 = _mm512_fmadd_pd(w2, g0, a20); a21 = _mm512_fmadd_pd(w2, g1, a21); }
+      }
+      const __m512d acc[3][2] = {{a00, a01}, {a10, a11}, {a20, a21}};
+      for (int a = 0; a < R; a++) {  // only the columns right of the row's diagonal
+        double *row = U + (size_t)(m + j + a) * N + m + i;
+        const int skip = std::max(0, j + a + 1 - i);  // leading columns of the tile that are not above the diagonal for this row
+        const __mmask8 s0 = (__mmask8)(m0 & ~((1u << std::min(8, skip)) - 1u)), s1 = (__mmask8)(m1 & ~((1u << std::max(0, std::min(8, skip - 8))) - 1u));
+        _mm512_mask_storeu_pd(row, s0, _mm512_sub_pd(_mm512_maskz_loadu_pd(s0, row), acc[a][0]));
+        _mm512_mask_storeu_pd(row + 8, s1, _mm512_sub_pd(_mm512_maskz_loadu_pd(s1, row + 8), acc[a][1]));
+      }
+    }
+  }
+}
+inline void ldlt_border_update(double *U, const double *WB, size_t N, int m, int n, bool wide) {
+  if (wide) return ldlt_border_update_512(U, WB, N, m, n);
+  const int nb = n - m;
+  for (int k = 0; k < m; k++) {
+    const double *g = U + (size_t)k * N + m, *w = WB + (size_t)k * nb;
+    for (int j = 0; j < nb; j++) {
+      const double wj = w[j];
+      if (wj == 0.0) continue;
+      double *row = U + (size_t)(m + j) * N + m;
+      for (int i = j + 1; i < nb; i++) row[i] -= wj * g[i];
+    }
   }
 }
 // F.U holds the upper triangle INCLUDING the diagonal on entry (inside the envelope and over the border)
@@ -638,8 +689,9 @@ inline void ldlt_partial_factor(LdltPartial &F) {
   F.D.assign(m, 0.0);
   F.diag.resize(N);
   F.perm.assign(m, 0);
-  static thread_local std::vector<double> WTv, LTv;
+  static thread_local std::vector<double> WTv, LTv, WBv;
   WTv.resize((size_t)LDLT_NB * N); LTv.resize((size_t)LDLT_NB * N);
+  WBv.resize((size_t)m * (n - m));  // L D over the border columns, pivot by pivot, for the trailing block's update at the end
   double *U = F.U.data(), *diag = F.diag.data(), *WTp = WTv.data(), *LTp = LTv.data();
   for (int j = 0; j < n; j++) diag[j] = U[j * N + j];
   const bool wide = ldlt_have_avx512();
@@ -674,13 +726,13 @@ inline void ldlt_partial_factor(LdltPartial &F) {
       // column k brought up to date with the q earlier pivots of the panel, L = a / d, candidate diagonal -- over its two ranges
       for (int part = 0; part < 2; part++)
         ldlt_pivot_range(uk, WTp, LTp, wt, lt, diag, N, k, q, part == 0 ? k + 1 : m, part == 0 ? eend : n, dinv, zero);
+      if (n > m) std::memcpy(&WBv[(size_t)k * (n - m)], wt + m, sizeof(double) * (n - m));
     }
     // trailing update: (interior rest of the envelope) x (itself + border), border x border
-    ldlt_range_update(U, WTp, LTp, N, k1, eend, k1, eend, kb, wide);
-    ldlt_range_update(U, WTp, LTp, N, k1, eend, m, n, kb, wide);
-    ldlt_range_update(U, WTp, LTp, N, m, n, m, n, kb, wide);
+    ldlt_range_update(U, WTp, LTp, N, k1, eend, k1, eend, kb, wide, m, n);
     k0 = k1;
   }
+  if (n > m) ldlt_border_update(U, WBv.data(), N, m, n, wide);
   // the factorisation leaves the finished columns of L in the row order they were computed in; bring them to the final order (the
   // later interchanges applied to the earlier columns whose envelope holds them), so that the substitutions can apply all
   // interchanges to the vector first
