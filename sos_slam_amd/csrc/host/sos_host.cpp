@@ -423,22 +423,9 @@ int EnergyFunctional::packWindow(std::vector<PointFrameResidual *> *active) {
   res.reserve((size_t)nResiduals + 16);
   allResiduals.clear();
   allResiduals.reserve((size_t)nResiduals + 16);
-  const size_t nPts = allPoints.size();
-  for (size_t k = 0; k < nPts; k++) {
+  for (size_t k = 0; k < allPoints.size(); k++) {
     EFPoint *p = allPoints[k];
     PointHessian *ph = p->data;
-    // the graph is heap nodes: request what the walk touches a few points ahead (the point pair 6 ahead, its residual objects 3 ahead,
-    // what hangs off those 1 ahead)
-    if (k + 6 < nPts) { __builtin_prefetch(allPoints[k + 6]); }
-    if (k + 4 < nPts) { __builtin_prefetch(allPoints[k + 4]->data, 1); }
-    if (k + 3 < nPts) {
-      const EFPoint *p3 = allPoints[k + 3];
-      for (const EFResidual *r : p3->residualsAll) __builtin_prefetch(r);
-    }
-    if (k + 1 < nPts) {
-      const EFPoint *p1 = allPoints[k + 1];
-      for (const EFResidual *r : p1->residualsAll) __builtin_prefetch(r->data, 1);
-    }
     if (active)
       for (PointFrameResidual *r : ph->residuals)
         if (!r->efResidual->isLinearized) {
@@ -1119,18 +1106,7 @@ double FullSystem::linearizeAll(bool fix) {  // FS/FullSystemOptimize.cpp:125-18
   // ONE walk over the active residuals: r->applyRes(true) inside the reductor (:51), the removal list (:72-73) and the
   // lastResiduals states (:150-156, which only read what this walk has just written for the same residual)
   std::vector<PointFrameResidual *> toRemove;
-  // (the objects are heap nodes in allocation order, not in walk order: the walk is a chain of cache misses unless the next ones are
-  // requested ahead -- the residual itself 16 steps ahead, what hangs off it 8 steps ahead, when it has arrived)
-  const size_t nAct = activeResiduals.size();
-  for (size_t ia = 0; ia < nAct; ia++) {
-    PointFrameResidual *r = activeResiduals[ia];
-    if (ia + 16 < nAct) __builtin_prefetch(activeResiduals[ia + 16], 1);
-    if (ia + 8 < nAct) {
-      const PointFrameResidual *a8 = activeResiduals[ia + 8];
-      __builtin_prefetch(a8->efResidual, 1);
-      __builtin_prefetch(a8->point, 1);
-      __builtin_prefetch(&rec[a8->packIdx]);
-    }
+  for (PointFrameResidual *r : activeResiduals) {
     const sos_resid_final &q = rec[r->packIdx];
     r->state_NewState = (ResState)q.state_NewState;
     r->state_NewEnergy = q.state_NewEnergy;
