@@ -19,6 +19,8 @@ from __future__ import annotations
 
 import dataclasses
 
+import os
+
 import numpy as np
 
 from oracle import oracle as orc
@@ -585,6 +587,8 @@ class DeviceChain(Chain):
         self.und = lib.Undistorter(self.ctx, lib.camera_parse(sc.cam_txt))
         self.sel = lib.PixelSelector(self.ctx, self.pprm, sc.pattern)
         self.trk = None
+        if os.environ.get("SOS_TEST_RESIDENT") == "1":   # tests/test_gpu_variants.py: the same chain with the device-resident loop (k_gn_solve)
+            self.sysm.set_resident(True)
 
     def close(self):
         if getattr(self, "iset", None) is not None:

@@ -18,6 +18,8 @@ chain in the same way.  Stated tolerances: keyframe-level decisions (flagged / m
 counts) identical; point / residual / activation sets within 3x the oracle-vs-truth symmetric difference (+0.4 %); every
 pose -- in the window and leaving it -- within POSE_TOL of the oracle chain or 3x the oracle-vs-truth distance (running
 maximum over the sequence so far: drift accumulates); the prior within 3x in the reference's Jacobi-scaled metric."""
+import os
+
 import numpy as np
 import pytest
 
@@ -134,4 +136,6 @@ def test_rolling_window_marginalised_poses_and_index_sets(geom):
     print('violations:', bad)
     assert not bad, bad
     assert left >= (18 if geom == "qvga" else 4)
+    if os.environ.get("SOS_TEST_RESIDENT") == "1":   # (tests/test_gpu_variants.py) the chain really ran the device-resident loop
+        assert dev.sysm.loop_mode() == 2, dev.sysm.loop_mode()
     dev.close()

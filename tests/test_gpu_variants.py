@@ -78,6 +78,10 @@ def test_switches(modeA, modeB, huber, outlier):
     # host-side order kept as a knob: IMU first half behind the accumulate's enqueue
     ({"SOS_IMU_OVERLAP": "1"}, "tests/test_gpu_imu_hook.py -k T6"),
     ({"SOS_STITCH_SIGNAL_IN_KERNEL": "1"}, "tests/test_golden_t6.py"),    # the stitch's last kernel raises the host flag itself
+    # the device-resident loop over a rolling chain: k_gn_solve with a marginalisation prior that is not zero, linearised residuals
+    # in the window, bM + HM delta formed by the step kernel -- against the oracle chain with the same bars as the host-solve loop
+    ({"SOS_TEST_RESIDENT": "1"}, "tests/test_gpu_rolling_window.py -k qvga"),
+    ({"SOS_TEST_RESIDENT": "1"}, "tests/test_gpu_optimize.py -k T6"),
 ])
 def test_launch_variants_keep_parity(env, target):
     """Launch-shape choices the library makes per window (read once per process from the environment when forced) must
