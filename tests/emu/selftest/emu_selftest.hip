@@ -39,6 +39,30 @@ __global__ void k_mfma(const float *__restrict__ A, const float *__restrict__ B,
   for (int r = 0; r < 4; r++) D[(kq * 4 + r) * 16 + col] = acc[r];
 }
 
+// D = A (16 x 4k) B (4k x 16) with v_mfma_f64_16x16x4_f64: operands as the f32 form, ACCUMULATOR rows (lane >> 4) + 4 * reg
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+__global__ void k_mfma_f64(const double *__restrict__ A, const double *__restrict__ B, double *__restrict__ D, int K) {
+  const int lane = threadIdx.x & 63, kq = lane >> 4, col = lane & 15;
+  f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < K; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[col * K + k0 + kq], B[(k0 + kq) * 16 + col], acc, 0, 0, 0);
+  for (int r = 0; r < 4; r++) D[(kq + 4 * r) * 16 + col] = acc[r];
+}
+// v_mov_b64_dpp row_newbcast:n -- lane n of every 16-lane row to the whole row
+template <int N>
+__device__ double bc64(double v) { return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + N, 0xf, 0xf, true); }
+__global__ void k_row_newbcast(const double *__restrict__ in, double *__restrict__ out) {
+  const double v = in[threadIdx.x];
+  out[threadIdx.x] = bc64<0>(v);
+  out[64 + threadIdx.x] = bc64<5>(v);
+  out[128 + threadIdx.x] = bc64<15>(v);
+}
+__global__ void k_lds_hog(float *out) {
+  extern __shared__ float big[];
+  big[threadIdx.x] = 1.f;
+  __syncthreads();
+  out[threadIdx.x] = big[threadIdx.x];
+}
+
 // LDS transpose of a 32 x 32 tile by 256 threads (4 waves), one barrier
 __global__ void k_transpose(const float *__restrict__ in, float *__restrict__ out) {
   __shared__ float tile[32][33];
@@ -106,6 +130,36 @@ extern "C" int emu_selftest_mfma(const float *A, const float *B, float *D, int K
   hipDeviceSynchronize();
   hipMemcpy(D, dD, 4 * 256, hipMemcpyDeviceToHost);
   hipFree(dA); hipFree(dB); hipFree(dD);
+  return 0;
+}
+extern "C" int emu_selftest_mfma_f64(const double *A, const double *B, double *D, int K) {
+  double *dA, *dB, *dD;
+  hipMalloc(&dA, 8 * 16 * K); hipMalloc(&dB, 8 * 16 * K); hipMalloc(&dD, 8 * 256);
+  hipMemcpy(dA, A, 8 * 16 * K, hipMemcpyHostToDevice);
+  hipMemcpy(dB, B, 8 * 16 * K, hipMemcpyHostToDevice);
+  k_mfma_f64<<<1, 64, 0, 0>>>(dA, dB, dD, K);
+  hipDeviceSynchronize();
+  hipMemcpy(D, dD, 8 * 256, hipMemcpyDeviceToHost);
+  hipFree(dA); hipFree(dB); hipFree(dD);
+  return 0;
+}
+extern "C" int emu_selftest_row_newbcast(const double *in, double *out) {
+  double *di, *dout;
+  hipMalloc(&di, 8 * 64); hipMalloc(&dout, 8 * 192);
+  hipMemcpy(di, in, 8 * 64, hipMemcpyHostToDevice);
+  k_row_newbcast<<<1, 64, 0, 0>>>(di, dout);
+  hipDeviceSynchronize();
+  hipMemcpy(out, dout, 8 * 192, hipMemcpyDeviceToHost);
+  hipFree(di); hipFree(dout);
+  return 0;
+}
+// a launch that asks for more LDS than a compute unit has (160 KB on gfx950) must not be emulated as if it fitted
+extern "C" int emu_selftest_lds_limit(int kbytes) {
+  float *dout;
+  hipMalloc(&dout, 4 * 64);
+  k_lds_hog<<<1, 64, (size_t)kbytes * 1024, 0>>>(dout);
+  hipDeviceSynchronize();
+  hipFree(dout);
   return 0;
 }
 extern "C" int emu_selftest_transpose(const float *in, float *out, int nblocks) {

@@ -24,7 +24,8 @@ def _p(a):
 def L():
     import build_emu
     lib = C.CDLL(build_emu.build_selftest())
-    for f in ("emu_selftest_lane_ops", "emu_selftest_mfma", "emu_selftest_transpose", "emu_selftest_grid_barrier", "emu_selftest_mailbox"):
+    for f in ("emu_selftest_lane_ops", "emu_selftest_mfma", "emu_selftest_transpose", "emu_selftest_grid_barrier", "emu_selftest_mailbox",
+              "emu_selftest_mfma_f64", "emu_selftest_row_newbcast", "emu_selftest_lds_limit"):
         getattr(lib, f).restype = C.c_int
     return lib
 
@@ -72,6 +73,39 @@ def test_mfma_lane_layout(L, K):
     D = np.zeros((16, 16), np.float32)
     assert L.emu_selftest_mfma(_p(A), _p(B), _p(D), K) == 0
     assert np.abs(D - A.astype(np.float64) @ B.astype(np.float64)).max() < 1e-5 * K
+
+
+@pytest.mark.parametrize("K", [4, 16])
+def test_mfma_f64_lane_layout(L, K):
+    """v_mfma_f64_16x16x4_f64 (round 5, k_gn_solve's trailing update): its accumulator rows are (lane >> 4) + 4 * reg, NOT the f32 form's
+    4 * (lane >> 4) + reg (cdna_hip_programming.md) -- an asymmetric B tells the two apart."""
+    rng = np.random.default_rng(K + 1)
+    A, B = rng.normal(size=(16, K)), rng.normal(size=(K, 16))
+    D = np.zeros((16, 16))
+    assert L.emu_selftest_mfma_f64(_p(A), _p(B), _p(D), K) == 0
+    assert np.abs(D - A @ B).max() < 1e-13 * K
+    assert np.abs(D - (A @ B).T).max() > 1e-3
+
+
+def test_row_newbcast_of_64_bit_values(L):
+    """v_mov_b64_dpp row_newbcast:n (k_gn_solve's pivot-row broadcast): lane n of each 16-lane row to all 16 lanes of that row."""
+    v = np.random.default_rng(2).normal(size=64)
+    out = np.zeros(192)
+    assert L.emu_selftest_row_newbcast(_p(v), _p(out)) == 0
+    for q, n in enumerate((0, 5, 15)):
+        assert np.array_equal(out[64 * q:64 * q + 64], np.repeat(v[n::16][:4], 16))
+
+
+def test_lds_limit_of_a_compute_unit():
+    """More than 160 KB of LDS per workgroup does not exist on gfx950: the emulator refuses the launch (it ends the process, so the probe
+    runs in a child) instead of emulating a kernel that could not be launched."""
+    import subprocess
+    code = ("import ctypes, sys; sys.path.insert(0, %r); import build_emu; L = ctypes.CDLL(build_emu.build_selftest()); "
+            "L.emu_selftest_lds_limit(int(sys.argv[1])); print('ran')" % os.path.join(ROOT, "tests", "emu"))
+    ok = subprocess.run([sys.executable, "-c", code, "150"], capture_output=True, text=True, timeout=300)
+    assert ok.returncode == 0 and "ran" in ok.stdout, ok.stderr[-400:]
+    bad = subprocess.run([sys.executable, "-c", code, "170"], capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "160 KB" in bad.stderr, (bad.returncode, bad.stderr[-400:])
 
 
 def test_barriers_lds_and_coresident_workgroups(L):
