@@ -1,0 +1,19 @@
+"""bench.py end to end against tests/emu (TEST INFRASTRUCTURE; timings meaningless): shows that the line is printed twice -- complete after the
+headline + roofline + cpu_baseline, enriched at the end -- and that every side entry is filled.   python tools/emu_bench.py --window T6 --steps 2 --warmup 1 --inner 2 --cpu-seconds 1"""
+import os, sys, runpy
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+import build_emu
+from sos_slam_amd import build as _b
+_b.HIP_LIB, _b.HOST_LIB = build_emu.build()
+_b.build_all = lambda *a, **k: (_b.HIP_LIB, _b.HOST_LIB)
+import torch
+torch.cuda.is_available = lambda: True
+torch.cuda.set_device = lambda d: None
+torch.cuda.synchronize = lambda *a: None
+sys.argv = ["bench.py"] + sys.argv[1:]
+os.chdir(ROOT)
+import bench
+# side processes would start the real (GPU-less) bench: run the IMU side in-process
+bench.side_process = lambda what, window, timeout=240, env=None: bench.imu_timing(window, 0, iters=3)
+bench.main()
