@@ -1991,9 +1991,12 @@ __global__ __launch_bounds__(SOS_RSB) void k_stage_expand(BaDev d, float4 *__res
                                                       int nStageBlocks, const float4 *__restrict__ pre_src, float4 *__restrict__ t_pre) {
   stage_block((int)blockIdx.x, threadIdx.x, d, stage_dst, stage_src, n4, nStageBlocks, pre_src, t_pre);
 }
+// nid_part != nullptr (device-resident loop): every wave leaves the sum of |idepth| of its points AFTER the step in nid_part[2 block +
+// wave] -- doStepFromBackup's sumNID of the NEXT iteration (FS/FullSystemOptimize.cpp:207-213: it reads idepth_backup), so that the
+// single-workgroup solve kernel does not have to stride through the point records itself
 __device__ __forceinline__ void resub_point_block(const BaDev &d, const XArg *x, const float *__restrict__ adHF, const float *__restrict__ adTF,
                                                   float *__restrict__ step_out, float stepfacD, const float *__restrict__ x_dev, float *sxAd,
-                                                  const double *xd = nullptr) {
+                                                  const double *xd = nullptr, double *nid_part = nullptr) {
   const int tid = threadIdx.x;
   const int n = d.n, dim = SOS_CPARS + 8 * n;
   float *sx = sxAd + n * n * 8;
@@ -2060,7 +2063,8 @@ __device__ __forceinline__ void resub_point_block(const BaDev &d, const XArg *x,
     table_item(q, ah, at);
   }
   __syncthreads();
-  if (!live) return;
+  float idnAbs = 0.f;
+  if (live) {
   // ---- resubstituteFPt (OB/EnergyFunctional.cpp:526-551), subtraction order = EFPoint::residualsAll order
   float step = 0.f;
   if (v3.x != 0.f) {  // HdiF == 0 <=> no active residual (ngoodres == 0)
@@ -2106,6 +2110,20 @@ __device__ __forceinline__ void resub_point_block(const BaDev &d, const XArg *x,
   for (int k = 0; k < RU; k++)
     if (e[k].x >= 0) *(reinterpret_cast<float2 *>(d.r_geo + e[k].x) + 1) = make_float2(idn, idn);
   for (int q = q0 + RU; q < q1; q++) *(reinterpret_cast<float2 *>(d.r_geo + d.p_list2[q].x) + 1) = make_float2(idn, idn);
+  idnAbs = fabsf(idn);
+  }
+  if (nid_part) {  // (block-uniform)
+    double v = (double)idnAbs;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((tid & 63) == 0) nid_part[(SOS_RSB / 64) * blockIdx.x + (tid >> 6)] = v;
+  }
+}
+// the same partial sums from the point records as they are (once, when the device-resident loop begins)
+__global__ __launch_bounds__(SOS_RSB) void k_nid_partials(const sos_point *__restrict__ pts, int P, double *__restrict__ nid_part) {
+  const int p = blockIdx.x * SOS_RSB + threadIdx.x;
+  double v = p < P ? (double)fabsf(pts[p].idepth_scaled) : 0.0;
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if ((threadIdx.x & 63) == 0) nid_part[(SOS_RSB / 64) * blockIdx.x + (threadIdx.x >> 6)] = v;
 }
 __global__ __launch_bounds__(SOS_RSB) void k_resub_fused(BaDev d, XArg x, const float *__restrict__ adHF, const float *__restrict__ adTF,
                                                      float *__restrict__ step_out, float stepfacD, int nPointBlocks,
@@ -2143,6 +2161,7 @@ struct DevStep {
   int th_dev;                                                 // 1: leave the staged thresholds alone
   const double *HM, *bM;                                      // nullptr: no bMd
   double *bMd;
+  double *nid_part;                                           // nullptr, or the per-wave sums of |idepth| after the step (resub_point_block)
 };
 __device__ __forceinline__ void devstep_block(int sb, int nsb, const BaDev &d, const DevStep &g, const float *__restrict__ adHF, const float *__restrict__ adTF,
                                               float4 *__restrict__ t_pre, float *smemf, const double *xd) {
@@ -2305,7 +2324,7 @@ __global__ __launch_bounds__(SOS_RSB) void k_resub_devstep(BaDev d, const float 
     devstep_block((int)blockIdx.x - nPointBlocks, (int)gridDim.x - nPointBlocks, d, g, adHF, adTF, t_pre, sxAd, g.x_dev ? g.x_dev : g.xd);
     return;
   }
-  resub_point_block(d, nullptr, adHF, adTF, step_out, stepfacD, nullptr, sxAd, g.x_dev ? g.x_dev : g.xd);
+  resub_point_block(d, nullptr, adHF, adTF, step_out, stepfacD, nullptr, sxAd, g.x_dev ? g.x_dev : g.xd, g.nid_part);
 }
 __global__ void k_fix_lin(BaDev d, const int *__restrict__ slist, int count) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2549,8 +2568,8 @@ struct sos_ba {
   DevBuf<float> d_xchg;    // sos_ba_time_kernel("exchange") scratch
   DevBuf<float> d_large;   // sos_ba_time_kernel("stream_large") 1 GiB yardstick buffer
   // device-resident Gauss-Newton loop (sos_gn_resident.inc)
-  DevBuf<double> d_gn;       // HM | bM | prior | bMd (= bM + HM delta of the coming solve) | x (the solve's result, read by the step)
-  size_t gn_HM = 0, gn_bM = 0, gn_prior = 0, gn_bMd = 0, gn_x = 0;
+  DevBuf<double> d_gn;       // HM | bM | prior | bMd (= bM + HM delta of the coming solve) | x (the solve's result, read by the step) | per-wave sums of |idepth|
+  size_t gn_HM = 0, gn_bM = 0, gn_prior = 0, gn_bMd = 0, gn_x = 0, gn_nid = 0;
   double gn_cPrior = 0;
   double *gn_pin = nullptr, *gn_pin_dev = nullptr;  // mapped ring of GN_SLOTS result slots + flag
   size_t gn_pin_doubles = 0, gn_slot_doubles = 0;
@@ -3987,7 +4006,7 @@ extern "C" int sos_ba_gn_step(sos_ba *ba, const double *x, float stepfacD, const
     DevStep g;
     for (int i = 0; i < dim; i++) g.xd[i] = x[i];
     for (int i = 0; i < n; i++) g.th[i] = frameEnergyTH[i];
-    g.x_dev = nullptr; g.th_dev = 0; g.HM = g.bM = nullptr; g.bMd = nullptr;
+    g.x_dev = nullptr; g.th_dev = 0; g.HM = g.bM = nullptr; g.bMd = nullptr; g.nid_part = nullptr;
     double *b = ba->d_ds;
     g.evalC2W = b; g.state_zero = b + 12 * n;
     g.state_in = b + 22 * n + 10 * n * ba->ds_cur; g.state_out = b + 22 * n + 10 * n * (ba->ds_cur ^ 1);
