@@ -1044,8 +1044,15 @@ __global__ __launch_bounds__(128) void k_reduce_all(ReduceArgs a) {
     if (tid >= SOS_TOPN) return;
     const int t0 = a.pair_tile_begin[b], t1 = a.pair_tile_begin[b + 1];
     double s = 0;
-#pragma unroll 8
-    for (int t = t0; t < t1; t++) s += (double)a.top_part[(size_t)t * SOS_TOPN + tid];
+    // rounds of 16 tiles with every load of a round in flight before the first add (clamped addresses, the adds keep their order):
+    // a pair of W12 has ~9 tiles -- one memory round trip instead of a compiler-unrolled loop's two or three
+    for (int t = t0; t < t1; t += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) v[u] = a.top_part[(size_t)min(t + u, t1 - 1) * SOS_TOPN + tid];
+#pragma unroll
+      for (int u = 0; u < 16; u++) s += t + u < t1 ? (double)v[u] : 0.0;
+    }
     if (tid < 91) a.accTop[(size_t)b * 91 + tid] = (float)s;
     return;
   }
@@ -1060,8 +1067,13 @@ __global__ __launch_bounds__(128) void k_reduce_all(ReduceArgs a) {
     double s = 0;
     const int kc0 = a.host_chunk_begin[h], kc1 = a.host_chunk_begin[h + 1];
     const size_t off = (size_t)r * a.Dm + c;
-#pragma unroll 8
-    for (int k = kc0; k < kc1; k++) s += (double)a.gram_part[(size_t)k * a.Dm * a.Dm + off];
+    for (int k = kc0; k < kc1; k += 16) {  // (as above: W12 has ~11 chunks per host)
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) v[u] = a.gram_part[(size_t)min(k + u, kc1 - 1) * a.Dm * a.Dm + off];
+#pragma unroll
+      for (int u = 0; u < 16; u++) s += k + u < kc1 ? (double)v[u] : 0.0;
+    }
     const int t1 = r >> 3, i = r & 7;
     if (c < 8 * n) {
       const int t2 = c >> 3, j = c & 7;
@@ -1312,11 +1324,15 @@ __device__ __forceinline__ void stitch_top_pairs_body(int bx, int by, int n, con
   }
   const float *blk = acc_top + ((size_t)by * n * n + pidx) * 91;
   double *out = C + ((size_t)by * n * n + pidx) * SOS_TOPC;
-  sB[tid] = (double)blk[top_idx(4 + i, 4 + j)];
-  sAH[tid] = adHost[(size_t)pidx * 64 + tid];
-  sAT[tid] = adTarget[(size_t)pidx * 64 + tid];
-  if (tid < 32) sBpc[tid] = (double)blk[top_idx(4 + (tid >> 2), tid & 3)];
-  if (tid < 8) sbp[tid] = (double)blk[top_idx(4 + tid, 12)];
+  {  // all five operands requested before the first is used (clamped indices: a load behind a divergent guard is waited for on its own)
+    const float fB = blk[top_idx(4 + i, 4 + j)], fBpc = blk[top_idx(4 + ((tid & 31) >> 2), tid & 3)], fbp = blk[top_idx(4 + (tid & 7), 12)];
+    const double dAH = adHost[(size_t)pidx * 64 + tid], dAT = adTarget[(size_t)pidx * 64 + tid];
+    sB[tid] = (double)fB;
+    sAH[tid] = dAH;
+    sAT[tid] = dAT;
+    if (tid < 32) sBpc[tid] = (double)fBpc;
+    if (tid < 8) sbp[tid] = (double)fbp;
+  }
   __syncthreads();
   double t1 = 0, t2 = 0;
 #pragma unroll
@@ -1390,30 +1406,48 @@ __device__ __forceinline__ void stitch_top_sum_body(int bx, int by, int n, const
     // fixed order: pairs (a,t) t = 0..n-1 (host side), then pairs (h,a) h = 0..n-1 (target side; (a,a) is empty)
     const int hc = tid & 31, bc_ = tid & 7;
     // every load of a round of 16 terms is in flight before the first add (the adds keep their order): the sums were a chain
-    // of n / 4 dependent L2 round trips
-    for (int t0 = 0; t0 < n; t0 += 16) {
-      double v0[16], v1[16], v2[16];
+    // of n / 4 dependent L2 round trips.  Up to 16 keyframes the host-side and the target-side terms are requested TOGETHER (clamped
+    // addresses instead of guarded loads): one memory round trip for the block instead of two
+    if (n <= 16) {
+      double v0[16], v1[16], v2[16], w0[16], w1[16], w2[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const int q = min(u, n - 1);
+        const double *c = Cm + (size_t)(a + n * q) * SOS_TOPC, *d = Cm + (size_t)(q + n * a) * SOS_TOPC;
+        v0[u] = c[tid]; v1[u] = c[192 + hc]; v2[u] = c[256 + bc_];
+        w0[u] = d[64 + tid]; w1[u] = d[224 + hc]; w2[u] = d[264 + bc_];
+      }
 #pragma unroll
       for (int u = 0; u < 16; u++)
-        if (t0 + u < n) {
-          const double *c = Cm + (size_t)(a + n * (t0 + u)) * SOS_TOPC;
-          v0[u] = c[tid]; v1[u] = c[192 + hc]; v2[u] = c[256 + bc_];
-        }
+        if (u < n) { sH += v0[u]; sHc += v1[u]; sb += v2[u]; }
 #pragma unroll
       for (int u = 0; u < 16; u++)
-        if (t0 + u < n) { sH += v0[u]; sHc += v1[u]; sb += v2[u]; }
-    }
-    for (int h0 = 0; h0 < n; h0 += 16) {
-      double v0[16], v1[16], v2[16];
+        if (u < n) { sH += w0[u]; sHc += w1[u]; sb += w2[u]; }
+    } else {
+      for (int t0 = 0; t0 < n; t0 += 16) {
+        double v0[16], v1[16], v2[16];
 #pragma unroll
-      for (int u = 0; u < 16; u++)
-        if (h0 + u < n) {
-          const double *c = Cm + (size_t)((h0 + u) + n * a) * SOS_TOPC;
-          v0[u] = c[64 + tid]; v1[u] = c[224 + hc]; v2[u] = c[264 + bc_];
-        }
+        for (int u = 0; u < 16; u++)
+          if (t0 + u < n) {
+            const double *c = Cm + (size_t)(a + n * (t0 + u)) * SOS_TOPC;
+            v0[u] = c[tid]; v1[u] = c[192 + hc]; v2[u] = c[256 + bc_];
+          }
 #pragma unroll
-      for (int u = 0; u < 16; u++)
-        if (h0 + u < n) { sH += v0[u]; sHc += v1[u]; sb += v2[u]; }
+        for (int u = 0; u < 16; u++)
+          if (t0 + u < n) { sH += v0[u]; sHc += v1[u]; sb += v2[u]; }
+      }
+      for (int h0 = 0; h0 < n; h0 += 16) {
+        double v0[16], v1[16], v2[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++)
+          if (h0 + u < n) {
+            const double *c = Cm + (size_t)((h0 + u) + n * a) * SOS_TOPC;
+            v0[u] = c[64 + tid]; v1[u] = c[224 + hc]; v2[u] = c[264 + bc_];
+          }
+#pragma unroll
+        for (int u = 0; u < 16; u++)
+          if (h0 + u < n) { sH += v0[u]; sHc += v1[u]; sb += v2[u]; }
+      }
     }
     H[(size_t)(4 + 8 * a + i) * dim + 4 + 8 * a + j] = sH;
     if (tid < 32) {
@@ -1451,15 +1485,42 @@ __device__ __forceinline__ void sc_MC_body(int bx, int by, int n, const float *_
   const int h = bx % n, t1 = (bx / n) % n, g = bx / (n * n);
   const int t2lo = (g == h) ? 0 : g, t2hi = (g == h) ? n : g + 1;
   const int pidx = h + n * t1;
-  for (int t2 = t2lo; t2 < t2hi; t2++) {
-    sD[(t2 - t2lo) * 64 + tid] = (double)accD[(size_t)(h + n * t1 + n * n * t2) * 64 + tid];
-    sA[(t2 - t2lo) * 64 + tid] = ((g == h) ? adHost : adTarget)[(size_t)(h + n * t2) * 64 + tid];
+  // (round 5: the ISA of the loop "load (D, A) of t2, store to LDS" had one s_waitcnt vmcnt(0) per iteration -- n dependent round trips
+  // in the g == h blocks, the critical path of the stage -- and one more behind each guarded load below.  Now every load of the block is
+  // issued into registers first: 16 (D, A) pairs with clamped t2 in the g == h blocks, one pair in the others.)
+  const double dAH = adHost[(size_t)pidx * 64 + tid], dAT = adTarget[(size_t)pidx * 64 + tid];
+  const float fE = accE[(size_t)pidx * 32 + (tid & 31)], fEB = accEB[(size_t)pidx * 8 + (tid & 7)];
+  if (g == h && n <= 16) {
+    float fd[16];
+    double fa[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const int t2 = min(q, n - 1);
+      fd[q] = accD[(size_t)(h + n * t1 + n * n * t2) * 64 + tid];
+      fa[q] = adHost[(size_t)(h + n * t2) * 64 + tid];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; q++)
+      if (q < n) {
+        sD[q * 64 + tid] = (double)fd[q];
+        sA[q * 64 + tid] = fa[q];
+      }
+  } else if (g == h) {  // (windows beyond 16 keyframes: one pair per iteration)
+    for (int t2 = 0; t2 < n; t2++) {
+      sD[t2 * 64 + tid] = (double)accD[(size_t)(h + n * t1 + n * n * t2) * 64 + tid];
+      sA[t2 * 64 + tid] = adHost[(size_t)(h + n * t2) * 64 + tid];
+    }
+  } else {
+    const float fd = accD[(size_t)(h + n * t1 + n * n * g) * 64 + tid];
+    const double fa = adTarget[(size_t)(h + n * g) * 64 + tid];
+    sD[tid] = (double)fd;
+    sA[tid] = fa;
   }
-  sAH[tid] = adHost[(size_t)pidx * 64 + tid];
-  sAT[tid] = adTarget[(size_t)pidx * 64 + tid];
+  sAH[tid] = dAH;
+  sAT[tid] = dAT;
   if (g == 0) {
-    if (tid < 32) sE[tid] = (double)accE[(size_t)pidx * 32 + tid];
-    if (tid < 8) sEB[tid] = (double)accEB[(size_t)pidx * 8 + tid];
+    if (tid < 32) sE[tid] = (double)fE;
+    if (tid < 8) sEB[tid] = (double)fEB;
   }
   __syncthreads();
   double m = 0;
