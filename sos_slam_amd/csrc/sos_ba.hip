@@ -1588,6 +1588,42 @@ __device__ __forceinline__ void sc_sum_body(int bx, int by, int n, const double 
   double s = 0, sc = 0, sb = 0;
   // the (h = g1, t1 = g1) terms are exact zeros (a point has no residual to its own host), so both sums
   // can run branch-free over all n
+  const int hc = tid & 31, bc_ = tid & 7;
+  if (n <= 16) {
+    // every term of the block requested before the first add (clamped indices; the diagonal blocks' calib / b terms behind a
+    // block-uniform test): ONE memory round trip instead of two (four on the diagonal); the adds keep their order
+    double v[16], w[16], e1[16], e2[16], f1[16], f2[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int q = min(u, n - 1);
+      v[u] = C[((size_t)(g1 * n + q) * n + g2) * SOS_SCC + tid];
+      w[u] = C[((size_t)(q * n + g1) * n + g2) * SOS_SCC + 64 + tid];
+    }
+    if (g1 == g2) {
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const int q = min(u, n - 1);
+        const double *ea = Ce + (size_t)(g1 + n * q) * SOS_SCE, *eb = Ce + (size_t)(q + n * g1) * SOS_SCE;
+        e1[u] = ea[hc]; e2[u] = ea[64 + bc_];
+        f1[u] = eb[32 + hc]; f2[u] = eb[72 + bc_];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 16; u++)
+      if (u < n) s += v[u];
+#pragma unroll
+    for (int u = 0; u < 16; u++)
+      if (u < n) s += w[u];
+    H[(size_t)(4 + 8 * g1 + i) * dim + 4 + 8 * g2 + j] = s;
+    if (g1 == g2) {
+#pragma unroll
+      for (int u = 0; u < 16; u++)
+        if (u < n) { sc += e1[u]; sb += e2[u]; }
+#pragma unroll
+      for (int u = 0; u < 16; u++)
+        if (u < n) { sc += f1[u]; sb += f2[u]; }
+    }
+  } else {
   for (int t0 = 0; t0 < n; t0 += 16) {  // loads of a round in flight together, adds in the old order (see stitch_top_sum_body)
     double v[16];
 #pragma unroll
@@ -1608,7 +1644,6 @@ __device__ __forceinline__ void sc_sum_body(int bx, int by, int n, const double 
   }
   H[(size_t)(4 + 8 * g1 + i) * dim + 4 + 8 * g2 + j] = s;
   if (g1 == g2) {
-    const int hc = tid & 31, bc_ = tid & 7;
     for (int t0 = 0; t0 < n; t0 += 16) {
       double v1[16], v2[16];
 #pragma unroll
@@ -1633,6 +1668,9 @@ __device__ __forceinline__ void sc_sum_body(int bx, int by, int n, const double 
       for (int u = 0; u < 16; u++)
         if (h0 + u < n) { sc += v1[u]; sb += v2[u]; }
     }
+  }
+  }
+  if (g1 == g2) {
     if (tid < 32) {
       const int r = tid >> 2, c = tid & 3;
       if (!upperOnly) H[(size_t)(4 + 8 * g1 + r) * dim + c] = sc;
