@@ -1120,14 +1120,42 @@ struct PrepOut { float hdi, hcd[4], bdsum; };
 __device__ __forceinline__ PrepOut point_prep_body(const BaDev &d, int shiftPriorToZero, int p) {
   float HddA = 0, bdA = 0, HcdA[4] = {0, 0, 0, 0}, HddL = 0, bdL = 0, HcdL[4] = {0, 0, 0, 0};
   float ngood = 0;
-  const int q0 = d.p_begin[p], q1 = d.p_begin[p + 1];
-  // residual list, point record and the per-residual terms are requested level by level for ALL residuals of the
-  // point at once (groups of PU): the sums below stay in residualsAll order, only the memory latencies overlap
+  // The first 16 residuals of the point come from its fixed-stride list (p_list16: no lookup of p_begin in front of it), requested
+  // together with the list bounds, the point record and the old step; their per-residual terms then go out as ONE batch: two memory
+  // round trips for a point with up to 16 observations (three to five with the p_begin -> p_list2 -> s_pterm chain in groups of 8).
+  // The sums stay in residualsAll order.
   constexpr int PU = 8;
+  const int2 *l16 = d.p_list16 + 16 * (size_t)p;
+  int2 e16[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) e16[k] = l16[k];
+  const int q0 = d.p_begin[p], q1 = d.p_begin[p + 1];
   const sos_point *ptp = d.pts + p;
   const float priorF = ptp->priorF, deltaF = ptp->deltaF;
   const float stepOld = d.p_out[16 * (size_t)p + PO_STEP];
-  for (int q = q0; q < q1; q += PU) {
+  {
+    float4 a[16], b[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const float4 *pt = reinterpret_cast<const float4 *>(d.s_pterm + 8 * (size_t)max(e16[k].x, 0));
+      a[k] = pt[0];
+      b[k] = pt[1];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      if (e16[k].x < 0) continue;       // beyond the end of the list
+      if (b[k].z == 0.f) continue;      // not active
+      ngood += 1.f;
+      if (b[k].w != 0.f) {
+        HddL += a[k].x; bdL += a[k].y;
+        HcdL[0] += a[k].z; HcdL[1] += a[k].w; HcdL[2] += b[k].x; HcdL[3] += b[k].y;
+      } else {
+        HddA += a[k].x; bdA += a[k].y;
+        HcdA[0] += a[k].z; HcdA[1] += a[k].w; HcdA[2] += b[k].x; HcdA[3] += b[k].y;
+      }
+    }
+  }
+  for (int q = q0 + 16; q < q1; q += PU) {  // points seen from more than 16 keyframes
     int sidx[PU];
     float4 a[PU], b[PU];
 #pragma unroll
@@ -1177,7 +1205,7 @@ __device__ __forceinline__ PrepOut point_prep_body(const BaDev &d, int shiftPrio
   r.bdsum = o3.y;
   return r;
 }
-__global__ void k_point_prep(BaDev d, int shiftPriorToZero, const int *__restrict__ plist, int count) {
+__global__ __launch_bounds__(64) void k_point_prep(BaDev d, int shiftPriorToZero, const int *__restrict__ plist, int count) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   point_prep_body(d, shiftPriorToZero, plist ? plist[i] : i);
@@ -1206,38 +1234,61 @@ __device__ __forceinline__ void sc_gram_body(const BaDev &d, int blk, const int 
   const int n = d.n;
   for (int q = tid; q < SOS_GC * ld / 4; q += 256) reinterpret_cast<float4 *>(A)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
-  // stage: thread per (point, target); t == n is the point's own column block (Hcd, bdSum) and Hdi
-  for (int q = tid; q < SOS_GC * (n + 1); q += 256) {
-    const int t = q / SOS_GC, pl = q - t * SOS_GC;  // the 32 prep items (t == n) end up in one half-wave
+  // stage.  Roles by wave so that no thread walks two dependent chains one after the other (round 5; the loop "item = tid, tid + 256"
+  // gave the 32 threads of the point terms a JpJd item first and their own 4-level chain after it: ~8 memory round trips in a row):
+  //   wave 3, lanes 0..31: the point's own column block (Hcd, bdSum) and Hdi -- chunk_pt -> {list, bounds, record} -> terms
+  //   waves 0..2: the (point, target) items, SOS_GC n of them over 192 threads, every level of all items of a thread in one batch --
+  //               chunk_pt -> p_res_t -> JpJd
+  {
+    const int pl = tid & 31;  // (192 and 256 are multiples of 32: all items of a thread belong to the same point)
     const int p = chunk_pt[blk * SOS_GC + pl];
-    if (p < 0) {
-      if (t == n) sHdi[pl] = 0.f;
-      continue;
-    }
-    if (t == n) {
-      float *row = A + pl * ld + 8 * n;
-      if (PREP >= 0) {
-        const PrepOut r = point_prep_body(d, PREP, p);
-        sHdi[pl] = r.hdi;
-        row[0] = r.hcd[0]; row[1] = r.hcd[1]; row[2] = r.hcd[2]; row[3] = r.hcd[3];
-        row[4] = r.bdsum;
-      } else {
-        const float4 *po = reinterpret_cast<const float4 *>(d.p_out + 16 * (size_t)p);
-        const float4 v0 = po[0], v1 = po[1], v2 = po[2], v3 = po[3];
-        sHdi[pl] = v3.x;
-        row[0] = v0.z + v2.x;  // Hcd_accAF + Hcd_accLF
-        row[1] = v0.w + v2.y;
-        row[2] = v1.x + v2.z;
-        row[3] = v1.y + v2.w;
-        row[4] = v3.y;         // bdSumF
+    if (tid >= 192) {
+      if (tid < 192 + SOS_GC) {
+        if (p < 0) sHdi[pl] = 0.f;
+        else {
+          float *row = A + pl * ld + 8 * n;
+          if (PREP >= 0) {
+            const PrepOut r = point_prep_body(d, PREP, p);
+            sHdi[pl] = r.hdi;
+            row[0] = r.hcd[0]; row[1] = r.hcd[1]; row[2] = r.hcd[2]; row[3] = r.hcd[3];
+            row[4] = r.bdsum;
+          } else {
+            const float4 *po = reinterpret_cast<const float4 *>(d.p_out + 16 * (size_t)p);
+            const float4 v0 = po[0], v1 = po[1], v2 = po[2], v3 = po[3];
+            sHdi[pl] = v3.x;
+            row[0] = v0.z + v2.x;  // Hcd_accAF + Hcd_accLF
+            row[1] = v0.w + v2.y;
+            row[2] = v1.x + v2.z;
+            row[3] = v1.y + v2.w;
+            row[4] = v3.y;         // bdSumF
+          }
+        }
       }
     } else {
-      const int s = d.p_res_t[(size_t)p * n + t];
-      if (s >= 0) {
-        const float4 *jp = reinterpret_cast<const float4 *>(d.JpJd + 8 * (size_t)s);
-        float4 *row = reinterpret_cast<float4 *>(A + pl * ld + 8 * t);
-        row[0] = jp[0];
-        row[1] = jp[1];
+      constexpr int NI = 3;  // items of a thread requested together: one round up to 18 keyframes
+      const int pc = p < 0 ? 0 : p;
+      for (int base = 0; base < SOS_GC * n; base += 192 * NI) {
+        int sI[NI];
+#pragma unroll
+        for (int it = 0; it < NI; it++) {
+          const int t = (base + tid + 192 * it) >> 5;
+          sI[it] = d.p_res_t[(size_t)pc * n + min(t, n - 1)];
+          if (t >= n || p < 0) sI[it] = -1;
+        }
+        float4 j0[NI], j1[NI];
+#pragma unroll
+        for (int it = 0; it < NI; it++) {
+          const float4 *jp = reinterpret_cast<const float4 *>(d.JpJd + 8 * (size_t)max(sI[it], 0));
+          j0[it] = jp[0];
+          j1[it] = jp[1];
+        }
+#pragma unroll
+        for (int it = 0; it < NI; it++)
+          if (sI[it] >= 0) {
+            float4 *row = reinterpret_cast<float4 *>(A + pl * ld + 8 * ((base + tid + 192 * it) >> 5));
+            row[0] = j0[it];
+            row[1] = j1[it];
+          }
       }
     }
   }
