@@ -134,6 +134,10 @@ def rewrite_asm(s, fname):
     def repl(m):
         if "v_add_f32_dpp" in m.group(0) and "row_shr:7" in m.group(0):
             return "s = emu::seqsum8(v);"
+        if "v_fmac_f64_dpp" in m.group(0) and "row_newbcast" in m.group(0):
+            # csrc/sos_gn_resident.inc: gs_row_update<K> -- a[j] += bcast_K(a[j]) * nl for j = K + 1 .. 15, one instruction per j
+            k = 15 - m.group(0).count("v_fmac_f64_dpp")
+            return "for (int j_ = %d; j_ < 16; j_++) a[j_] = fma(gs_rowbc<%d>(a[j_]), nl, a[j_]);" % (k + 1, k)
         raise SystemExit("tests/emu: unknown inline assembly in %s -- teach build_emu.py its meaning" % fname)
 
     return re.sub(r"asm\s+volatile\s*\((?:[^;]|\n)*?\)\s*;", repl, s)
