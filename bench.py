@@ -398,6 +398,12 @@ def main():
                 out["device_solve"] = device_solve_timing(win.n, local_rank)
             except Exception as e:  # noqa: BLE001
                 out["device_solve"] = {"error": repr(e)}
+            # the device-resident loop (k_gn_solve in the chain, no host between two kernels): opt-in in the library until it has been
+            # timed; measured here in a process of its own (no device-side waits in it: the host polls a mapped slot with a timeout)
+            try:
+                out["resident_loop"] = variant_timing(args.window, only=("resident",)).get("resident")
+            except Exception as e:  # noqa: BLE001
+                out["resident_loop"] = {"error": repr(e)}
             if args.variants:
                 # opt-in: the same loop under each remaining switch, each in a process of its own
                 try:
@@ -441,11 +447,13 @@ VARIANTS = (
 )
 
 
-def variant_timing(window, timeout=90, budget=300.0):
+def variant_timing(window, timeout=90, budget=300.0, only=None):
     import subprocess
     out = {}
     t_begin = time.perf_counter()
     for name, env, extra in VARIANTS:
+        if only is not None and name not in only:
+            continue
         if time.perf_counter() - t_begin > budget:   # the default run has to end within minutes whatever a variant does
             out[name] = {"error": "skipped: the variants' time budget of %.0f s was spent" % budget}
             continue
