@@ -979,6 +979,7 @@ FrameHessian *FullSystem::addFrame(const double *c2w, const double *state10, flo
 }
 
 PointHessian *FullSystem::addPoint(const sos_point &p) {
+  flushPointMirrors();  // the flat API's lazily stepped points: the objects are current before anything reads, edits or reorders them
   if (p.host < 0 || p.host >= (int)frameHessians.size()) return nullptr;
   PointHessian *ph = new PointHessian();
   ph->host = frameHessians[p.host];
@@ -1671,6 +1672,7 @@ float FullSystem::optimize(int mnumOptIts, int *iterations) {
 }
 
 void FullSystem::removeOutliers() {  // FS/FullSystemOptimize.cpp:507-526
+  flushPointMirrors();  // the flat API's lazily stepped points: the objects are current before anything reads, edits or reorders them
   for (FrameHessian *fh : frameHessians)
     for (unsigned i = 0; i < fh->pointHessians.size(); i++) {
       PointHessian *ph = fh->pointHessians[i];
@@ -1755,6 +1757,7 @@ int FullSystem::marginalizePoints(const std::vector<PointHessian *> &pts, bool a
 }
 
 int FullSystem::dropPoints(const std::vector<PointHessian *> &pts) {
+  flushPointMirrors();  // the flat API's lazily stepped points: the objects are current before anything reads, edits or reorders them
   for (PointHessian *ph : pts) {
     ph->efPoint->stateFlag = PS_DROP;
     FrameHessian *host = ph->host;
@@ -1771,6 +1774,7 @@ int FullSystem::dropPoints(const std::vector<PointHessian *> &pts) {
 }
 
 int FullSystem::marginalizeFrame(FrameHessian *frame) {  // FS/FullSystemMarginalize.cpp:143-236 (backend part)
+  flushPointMirrors();  // the flat API's lazily stepped points: the objects are current before anything reads, edits or reorders them
   if (!frame->pointHessians.empty()) return SOS_ERR_STATE;
   const bool tmg = getenv("SOS_TIMING") != nullptr;
   const double tm0 = now_s();
@@ -1895,6 +1899,7 @@ void FullSystem::flagFramesForMarginalization() {
 
 // the loop "add new residuals for old points" of makeKeyFrame, FS/FullSystem.cpp:818-832
 int FullSystem::addResidualsToNewestFrame() {
+  flushPointMirrors();  // the flat API's lazily stepped points: the objects are current before anything reads, edits or reorders them
   FrameHessian *fh = frameHessians.back();
   int added = 0;
   for (FrameHessian *fh1 : frameHessians) {
@@ -1918,6 +1923,7 @@ int FullSystem::addResidualsToNewestFrame() {
 // (FS/FullSystem.cpp:497-505) for one candidate the device activated: PointHessian(rawPoint), residuals towards the
 // keyframes whose bit is set in inMask (frame idx order), lastResiduals as the reference leaves them
 PointHessian *FullSystem::addActivatedPoint(const sos_point &p, uint32_t inMask) {
+  flushPointMirrors();  // the flat API's lazily stepped points: the objects are current before anything reads, edits or reorders them
   if (p.host < 0 || p.host >= (int)frameHessians.size()) return nullptr;
   PointHessian *ph = new PointHessian();
   ph->host = frameHessians[p.host];
@@ -2699,6 +2705,7 @@ extern "C" int sosf_optimize(sosf_system *s, int mnumOptIts, float *rmse, int *i
 }
 extern "C" int sosf_set_device_step(sosf_system *s, int on) {
   if (!s) return SOS_ERR_ARG;
+  s->fs->flushPointMirrors();
   s->fs->devStepAllowed = on != 0;
   if (!on && s->fs->devStepActive) {
     sos_ba_gn_devstep_end(s->fs->ef->ba);

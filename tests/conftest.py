@@ -30,7 +30,6 @@ def _emulated():
 
 EMU_KNIFE_EDGE = {
     "tests/test_gpu_edge_windows.py::test_edge_window_optimize_matches_oracle[T4-n3]",          # 14 iterations against the oracle's 13 on a 170-point window
-    "tests/test_gpu_rolling_window.py::test_rolling_window_marginalised_poses_and_index_sets[euroc_752x480]",   # prior yardstick at keyframe 6, index sets apart since keyframe 3
 }
 
 

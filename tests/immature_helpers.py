@@ -13,14 +13,32 @@ def se3_mul(A, B):
     return np.concatenate([(Ra @ Rb).reshape(-1), Ra @ tb + ta])
 
 
+def mm3_f32(A, B):
+    """3 x 3 (or 3 x 3 times 3-vector) product in float32, every coefficient as (a0 b0 + a1 b1) + a2 b2 without fused multiply-adds:
+    the facade's statement of the reference's fixed-size Eigen products (sos_sequence.cpp host_to_frame / activate_points).  NumPy's
+    `@` goes through BLAS (FMA, blocked order) and np.linalg.inv through an LU: a few ulps away, enough to move a trace or an
+    activation that sits on a threshold, so the chains under comparison all use this form."""
+    A, B = np.asarray(A, dtype=np.float32), np.asarray(B, dtype=np.float32)
+    if B.ndim == 1:
+        return ((A[:, 0] * B[0] + A[:, 1] * B[1]) + A[:, 2] * B[2]).astype(np.float32)
+    return ((A[:, 0:1] * B[0:1, :] + A[:, 1:2] * B[1:2, :]) + A[:, 2:3] * B[2:3, :]).astype(np.float32)
+
+
+def kinv_f32(fx, fy, cx, cy):
+    """inverse of the pinhole matrix in closed form, float32 (1 / fx, -cx / fx, ...)"""
+    fx, fy, cx, cy = [np.float32(x) for x in (fx, fy, cx, cy)]
+    one = np.float32(1.0)
+    return np.array([[one / fx, 0, -cx / fx], [0, one / fy, -cy / fy], [0, 0, 1]], dtype=np.float32)
+
+
 def host_to_frame(K4, host_c2w, frame_c2w, host_aff=(0.0, 0.0), frame_aff=(0.0, 0.0), host_exp=1.0, frame_exp=1.0):
     """KRKi (3x3 float32), Kt (3), aff (2) as computed at FS/FullSystem.cpp:326-332."""
     K = np.array([[K4[0], 0, K4[2]], [0, K4[1], K4[3]], [0, 0, 1]], dtype=np.float32)
     T = se3_mul(se3_inv(frame_c2w), host_c2w)
     R = T[:9].reshape(3, 3).astype(np.float32)
     t = T[9:].astype(np.float32)
-    KRKi = (K @ R @ np.linalg.inv(K).astype(np.float32)).astype(np.float32)
-    Kt = (K @ t).astype(np.float32)
+    KRKi = mm3_f32(mm3_f32(K, R), kinv_f32(*K4))
+    Kt = mm3_f32(K, t)
     a = np.exp(frame_aff[0] - host_aff[0]) * frame_exp / host_exp   # AffLight::fromToVecExposure
     b = frame_aff[1] - a * host_aff[1]
     return KRKi, Kt, np.array([a, b], dtype=np.float32)
@@ -68,11 +86,11 @@ def level1_to_newest(win, newest):
     K0 = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], dtype=np.float32)
     K1 = np.array([[fx * np.float32(0.5), 0, (cx + np.float32(0.5)) / np.float32(2) - np.float32(0.5)],
                    [0, fy * np.float32(0.5), (cy + np.float32(0.5)) / np.float32(2) - np.float32(0.5)], [0, 0, 1]], dtype=np.float32)
-    Ki0 = np.linalg.inv(K0).astype(np.float32)
+    Ki0 = kinv_f32(fx, fy, cx, cy)
     KRKi, Kt = [], []
     for f in range(win.n):
         T = se3_mul(se3_inv(win.frames[newest]["camToWorld"]), win.frames[f]["camToWorld"])
         R, t = T[:9].reshape(3, 3).astype(np.float32), T[9:].astype(np.float32)
-        KRKi.append(((K1 @ R).astype(np.float32) @ Ki0).astype(np.float32).reshape(-1))
-        Kt.append((K1 @ t).astype(np.float32))
+        KRKi.append(mm3_f32(mm3_f32(K1, R), Ki0).reshape(-1))
+        Kt.append(mm3_f32(K1, t))
     return np.stack(KRKi), np.stack(Kt)

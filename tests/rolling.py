@@ -25,6 +25,7 @@ import numpy as np
 
 from oracle import oracle as orc
 from sos_slam_amd import synth
+from tests.immature_helpers import kinv_f32, mm3_f32
 from sos_slam_amd.records import (ACT_ACTIVATED, ACT_DELETE, IMMATURE_DTYPE, PAIR_TFM_DTYPE, ActivateParams, Calib, PixselParams,
                                   TraceParams, random_pattern)
 
@@ -192,9 +193,9 @@ def host_to_frame(K4, host_c2w, frame_c2w, host_aff, frame_aff):
     K = np.array([[K4[0], 0, K4[2]], [0, K4[1], K4[3]], [0, 0, 1]], dtype=np.float32)
     T = se3_mul(se3_inv(frame_c2w), host_c2w)
     R, t = T[:9].reshape(3, 3).astype(np.float32), T[9:].astype(np.float32)
-    KRKi = (K @ R @ np.linalg.inv(K).astype(np.float32)).astype(np.float32)
+    KRKi = mm3_f32(mm3_f32(K, R), kinv_f32(*K4))
     a = np.exp(frame_aff[0] - host_aff[0])
-    return KRKi.reshape(-1), (K @ t).astype(np.float32), np.array([a, frame_aff[1] - a * host_aff[1]], dtype=np.float32)
+    return KRKi.reshape(-1), mm3_f32(K, t), np.array([a, frame_aff[1] - a * host_aff[1]], dtype=np.float32)
 
 
 def level1_to_newest(K4, poses, newest):
@@ -202,13 +203,13 @@ def level1_to_newest(K4, poses, newest):
     K0 = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], dtype=np.float32)
     K1 = np.array([[fx * np.float32(0.5), 0, (cx + np.float32(0.5)) / np.float32(2) - np.float32(0.5)],
                    [0, fy * np.float32(0.5), (cy + np.float32(0.5)) / np.float32(2) - np.float32(0.5)], [0, 0, 1]], dtype=np.float32)
-    Ki0 = np.linalg.inv(K0).astype(np.float32)
+    Ki0 = kinv_f32(fx, fy, cx, cy)
     KRKi, Kt = [], []
     for f in range(len(poses)):
         T = se3_mul(se3_inv(poses[newest]), poses[f])
         R, t = T[:9].reshape(3, 3).astype(np.float32), T[9:].astype(np.float32)
-        KRKi.append(((K1 @ R).astype(np.float32) @ Ki0).astype(np.float32).reshape(-1))
-        Kt.append((K1 @ t).astype(np.float32))
+        KRKi.append(mm3_f32(mm3_f32(K1, R), Ki0).reshape(-1))
+        Kt.append(mm3_f32(K1, t))
     return np.stack(KRKi), np.stack(Kt)
 
 
@@ -921,13 +922,14 @@ class CppDeviceChain(DeviceChain):
 
 
 def device_chain(sc):
-    """the device chain of the rolling tests.  Visual chains: the frame-rate loop in C++ (sosf_sequence) -- what a SOS-SLAM maintainer would
-    run -- is what the oracle chain is compared with; visual-inertial chains: still the Python loop over the facade's stages (the C++ loop
-    passes the same tests under tests/emu except the stereo-inertial prior yardstick at one keyframe; it becomes the default there once it
-    has run on an MI355X).  SOS_ROLLING_CPP=1 / 0 forces the C++ / the Python loop for every chain."""
+    """the device chain of the rolling tests: the frame-rate loop in C++ (sosf_sequence) -- what a SOS-SLAM maintainer would run -- is what
+    the oracle chain is compared with, visual and visual-inertial.  SOS_ROLLING_CPP=0 puts the Python loop over the facade's stages in its
+    place (tests/test_gpu_variants.py keeps one visual and one visual-inertial chain on it; tests/test_gpu_sequence_driver.py compares the
+    two loops directly).  Both loops and the oracle chain form KRKi / Kt with the same float32 statement (immature_helpers.mm3_f32): with
+    NumPy's BLAS products on one side the traces of one keyframe in four sat a few ulps apart, enough to move ten activations at the
+    first keyframe of the stereo-inertial chain and, through one point marginalised on one side only, 11 % of a prior entry."""
     import os
-    v = os.environ.get("SOS_ROLLING_CPP")
-    use_cpp = (v == "1") or (v is None and not sc.vio)
+    use_cpp = os.environ.get("SOS_ROLLING_CPP") != "0"
     return CppDeviceChain(sc) if use_cpp else DeviceChain(sc)
 
 

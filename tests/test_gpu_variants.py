@@ -82,6 +82,9 @@ def test_switches(modeA, modeB, huber, outlier):
     # in the window, bM + HM delta formed by the step kernel -- against the oracle chain with the same bars as the host-solve loop
     ({"SOS_TEST_RESIDENT": "1"}, "tests/test_gpu_rolling_window.py -k qvga"),
     ({"SOS_TEST_RESIDENT": "1"}, "tests/test_gpu_optimize.py -k T6"),
+    # the Python loop over the facade's stage calls in place of sosf_sequence (rolling.device_chain)
+    ({"SOS_ROLLING_CPP": "0"}, "tests/test_gpu_rolling_window.py -k qvga"),
+    ({"SOS_ROLLING_CPP": "0"}, "tests/test_gpu_rolling_vio.py -k qvga"),
 ])
 def test_launch_variants_keep_parity(env, target):
     """Launch-shape choices the library makes per window (read once per process from the environment when forced) must
