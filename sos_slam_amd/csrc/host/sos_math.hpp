@@ -11,6 +11,8 @@
 #include <memory>
 #include <cstdlib>
 #include <cstring>
+#include <cstdio>
+#include <ctime>
 #include <vector>
 
 namespace sos {
@@ -523,8 +525,10 @@ struct LdltPartial {
 // U[j][i] -= sum_c L(j,c) W(i,c) for R consecutive rows j .. j + R - 1 and the columns i in [max(i0, j + 1), i1): the register tile
 // of the dense update (ldlt_rows_512) on a column range
 // (a second column range [i2, i3) shares the set-up of the row group: the interior rows update their envelope AND the border)
-template <int R>
-__attribute__((target("avx512f,fma"))) inline void ldlt_range_rows_512(double *U, const double *WT, const double *LT, size_t N, int j, int kb, int i0, int i1,
+// (KB = the pivots of the panel, a template parameter: a pivot block of 25 unknowns ends with a panel of one pivot, which costs an
+// eighth of a full one this way instead of all of it)
+template <int R, int KB>
+__attribute__((target("avx512f,fma"))) inline void ldlt_range_rows_512(double *U, const double *WT, const double *LT, size_t N, int j, int i0, int i1,
                                                                        int i2 = 0, int i3 = 0) {
   double *r[R];
   for (int a = 0; a < R; a++) r[a] = U + (size_t)(j + a) * N;
@@ -532,16 +536,12 @@ __attribute__((target("avx512f,fma"))) inline void ldlt_range_rows_512(double *U
     for (int b = a + 1; b < R; b++) {
       if (j + b < i0 || j + b >= i1) continue;
       double sv = 0;
-      for (int c = 0; c < kb; c++) sv += LT[c * N + j + a] * WT[c * N + j + b];
+      for (int c = 0; c < KB; c++) sv += LT[c * N + j + a] * WT[c * N + j + b];
       r[a][j + b] -= sv;
     }
-  __m512d l[R][8];
-  const double *w[8];
-  for (int c = 0; c < 8; c++) {
-    const bool on = c < kb;
-    for (int a = 0; a < R; a++) l[a][c] = _mm512_set1_pd(on ? LT[c * N + j + a] : 0.0);
-    w[c] = WT + (size_t)(on ? c : 0) * N;
-  }
+  __m512d l[R][KB];
+  for (int c = 0; c < KB; c++)
+    for (int a = 0; a < R; a++) l[a][c] = _mm512_set1_pd(LT[c * N + j + a]);
   for (int part = 0; part < 2; part++) {
     const int e1 = part == 0 ? i1 : i3;
     for (int i = part == 0 ? std::max(i0, j + R) : i2; i < e1; i += 8) {
@@ -549,13 +549,20 @@ __attribute__((target("avx512f,fma"))) inline void ldlt_range_rows_512(double *U
       __m512d acc[R];
       for (int a = 0; a < R; a++) acc[a] = _mm512_maskz_loadu_pd(m, r[a] + i);
 #pragma GCC unroll 8
-      for (int c = 0; c < 8; c++) {
-        const __m512d wv = _mm512_maskz_loadu_pd(m, w[c] + i);
+      for (int c = 0; c < KB; c++) {
+        const __m512d wv = _mm512_maskz_loadu_pd(m, WT + (size_t)c * N + i);
         for (int a = 0; a < R; a++) acc[a] = _mm512_fnmadd_pd(l[a][c], wv, acc[a]);
       }
       for (int a = 0; a < R; a++) _mm512_mask_storeu_pd(r[a] + i, m, acc[a]);
     }
   }
+}
+template <int KB>
+inline void ldlt_range_update_512(double *U, const double *WT, const double *LT, size_t N, int j0, int j1, int i0, int i1, int i2, int i3) {
+  int j = j0;
+  for (; j + 3 <= j1; j += 3) ldlt_range_rows_512<3, KB>(U, WT, LT, N, j, i0, i1, i2, i3);
+  if (j1 - j == 2) ldlt_range_rows_512<2, KB>(U, WT, LT, N, j, i0, i1, i2, i3);
+  else if (j1 - j == 1) ldlt_range_rows_512<1, KB>(U, WT, LT, N, j, i0, i1, i2, i3);
 }
 template <int R>
 __attribute__((target("avx2,fma"))) inline void ldlt_range_rows_256(double *U, const double *WT, const double *LT, size_t N, int j, int kb, int i0, int i1) {
@@ -623,13 +630,37 @@ __attribute__((target("avx2,fma"))) inline void ldlt_pivot_range(double *uk, con
     diag[i] -= a * l;
   }
 }
+__attribute__((target("avx512f,fma"))) inline void ldlt_pivot_range_512(double *uk, const double *WT, const double *LT, double *wt, double *lt, double *diag, size_t N,
+                                                                      int k, int q, int a0, int a1, double dinv, bool zero) {
+  if (zero) return ldlt_pivot_range(uk, WT, LT, wt, lt, diag, N, k, q, a0, a1, dinv, zero);
+  __m512d lk[LDLT_NB];
+  for (int c = 0; c < q; c++) lk[c] = _mm512_set1_pd(LT[c * N + k]);
+  const __m512d dv = _mm512_set1_pd(dinv);
+  for (int i = a0; i < a1; i += 8) {
+    const __mmask8 mk = (a1 - i >= 8) ? (__mmask8)0xff : (__mmask8)((1u << (a1 - i)) - 1u);
+    __m512d a = _mm512_maskz_loadu_pd(mk, uk + i);
+    for (int c = 0; c < q; c++) a = _mm512_fnmadd_pd(_mm512_maskz_loadu_pd(mk, &WT[c * N + i]), lk[c], a);
+    const __m512d l = _mm512_mul_pd(a, dv);
+    _mm512_mask_storeu_pd(wt + i, mk, a);
+    _mm512_mask_storeu_pd(lt + i, mk, l);
+    _mm512_mask_storeu_pd(uk + i, mk, l);
+    _mm512_mask_storeu_pd(diag + i, mk, _mm512_fnmadd_pd(a, l, _mm512_maskz_loadu_pd(mk, diag + i)));
+  }
+}
 // rows [j0, j1) x columns [max(i0, row + 1), i1) and [i2, i3)
 inline void ldlt_range_update(double *U, const double *WT, const double *LT, size_t N, int j0, int j1, int i0, int i1, int kb, bool wide, int i2 = 0, int i3 = 0) {
   int j = j0;
   if (wide) {
-    for (; j + 3 <= j1; j += 3) ldlt_range_rows_512<3>(U, WT, LT, N, j, kb, i0, i1, i2, i3);
-    if (j1 - j == 2) ldlt_range_rows_512<2>(U, WT, LT, N, j, kb, i0, i1, i2, i3);
-    else if (j1 - j == 1) ldlt_range_rows_512<1>(U, WT, LT, N, j, kb, i0, i1, i2, i3);
+    switch (kb) {
+      case 1: return ldlt_range_update_512<1>(U, WT, LT, N, j0, j1, i0, i1, i2, i3);
+      case 2: return ldlt_range_update_512<2>(U, WT, LT, N, j0, j1, i0, i1, i2, i3);
+      case 3: return ldlt_range_update_512<3>(U, WT, LT, N, j0, j1, i0, i1, i2, i3);
+      case 4: return ldlt_range_update_512<4>(U, WT, LT, N, j0, j1, i0, i1, i2, i3);
+      case 5: return ldlt_range_update_512<5>(U, WT, LT, N, j0, j1, i0, i1, i2, i3);
+      case 6: return ldlt_range_update_512<6>(U, WT, LT, N, j0, j1, i0, i1, i2, i3);
+      case 7: return ldlt_range_update_512<7>(U, WT, LT, N, j0, j1, i0, i1, i2, i3);
+      default: return ldlt_range_update_512<8>(U, WT, LT, N, j0, j1, i0, i1, i2, i3);
+    }
   } else {
     if (i3 > i2) ldlt_range_update(U, WT, LT, N, j0, j1, i2, i3, kb, false);
     for (; j + 3 <= j1; j += 3) ldlt_range_rows_256<3>(U, WT, LT, N, j, kb, i0, i1);
@@ -638,42 +669,92 @@ inline void ldlt_range_update(double *U, const double *WT, const double *LT, siz
   }
 }
 // The trailing block's share of the elimination, applied ONCE behind the last pivot instead of panel by panel:
-//   U[m + j][m + i] -= sum_k WB[k][j] * G[k][i]   (j < i),   G[k] = row k of U over the border columns (L), WB[k] = the same row times D[k].
-// Nothing reads the trailing block before the factorisation ends, and in this form every element is loaded and stored once while the sum
-// over all m pivots runs in registers (3 x 16 tile: 5 loads per 6 multiply-adds) -- the panel-wise update spent as long on setting up
-// its 3-row groups (101 columns = 7 vector steps per group) as on the arithmetic.
-__attribute__((target("avx512f,fma"))) inline void ldlt_border_update_512(double *U, const double *WB, size_t N, int m, int n) {
-  const int nb = n - m;
-  for (int j = 0; j + 1 < nb; j += 3) {
-    const int R = std::min(3, nb - j);
-    for (int i = j + 1; i < nb; i += 16) {
-      const int c0 = std::min(8, nb - i), c1 = std::max(0, std::min(8, nb - i - 8));
-      const __mmask8 m0 = (__mmask8)((1u << c0) - 1u), m1 = (__mmask8)((1u << c1) - 1u);
-      __m512d a00 = _mm512_setzero_pd(), a01 = a00, a10 = a00, a11 = a00, a20 = a00, a21 = a00;
-      const double *g = U + m + i, *w = WB + j;
-      for (int k = 0; k < m; k++, g += N, w += nb) {
-        const __m512d g0 = _mm512_maskz_loadu_pd(m0, g), g1 = _mm512_maskz_loadu_pd(m1, g + 8);
-        const __m512d w0 = _mm512_set1_pd(w[0]);
-        a00 = _mm512_fmadd_pd(w0, g0, a00); a01 = _mm512_fmadd_pd(w0, g1, a01);
-        if (R > 1) { const __m512d w1 = _mm512_set1_pd(w[1]); a10 = _mm512_fmadd_pd(w1, g0, a10); a11 = _mm512_fmadd_pd(w1, g1, a11); }
-        if (R > 2) { const __m512d w2 = _mm512_set1_pd(w[2]); a20 = _mm512_fmadd_pd(w2, g0, a20); a21 = _mm512_fmadd_pd(w2, g1, a21); }
-      }
-      const __m512d acc[3][2] = {{a00, a01}, {a10, a11}, {a20, a21}};
-      for (int a = 0; a < R; a++) {  // only the columns right of the row's diagonal
-        double *row = U + (size_t)(m + j + a) * N + m + i;
-        const int skip = std::max(0, j + a + 1 - i);  // leading columns of the tile that are not above the diagonal for this row
-        const __mmask8 s0 = (__mmask8)(m0 & ~((1u << std::min(8, skip)) - 1u)), s1 = (__mmask8)(m1 & ~((1u << std::max(0, std::min(8, skip - 8))) - 1u));
-        _mm512_mask_storeu_pd(row, s0, _mm512_sub_pd(_mm512_maskz_loadu_pd(s0, row), acc[a][0]));
-        _mm512_mask_storeu_pd(row + 8, s1, _mm512_sub_pd(_mm512_maskz_loadu_pd(s1, row + 8), acc[a][1]));
+//   U[m + j][m + i] -= sum_k W[k][j] * G[k][i]   (j < i),   G[k] = row k of L over the border columns, W[k] = the same row times D[k].
+// Nothing reads the trailing block before the factorisation ends, and in this form the sum over the pivots runs in registers (6 x 16
+// tile: 8 loads per 12 multiply-adds).  Both operands are PACKED while the pivots are produced -- G tile-major ([column tile of 16][pivot]
+// [16], zero-padded), W row-major with a short stride -- and the pivots go in blocks of LDLT_BK so that a column tile's G block stays in
+// L1 over all row groups: read from the rows of U (stride n doubles = a new page per pivot, no prefetcher follows that) the same loop
+// ran at 18 % of the FMA rate, one L2 latency per pivot and tile (131 of the 290 us of a W12 factorisation; 40 us now).
+#define LDLT_BK 128
+struct LdltBorderPack {
+  // column tiles RIGHT-aligned: tile t holds the border columns [16 t - off, 16 t - off + 16), off = 16 T - nb, so that the ragged tile is
+  // the first one -- which only the first row group needs -- instead of the last one, which every row group needs
+  int m = 0, nb = 0, T = 0, ldw = 0, off = 0;
+  std::vector<double> G, W;
+  void shape(int m_, int nb_) {
+    m = m_; nb = nb_; T = (nb + 15) / 16; off = 16 * T - nb;
+    ldw = (nb + 5) / 6 * 6 + 2;  // row groups of 6 read W[k][j .. j + 5]
+    G.resize((size_t)T * m * 16);
+    W.resize((size_t)m * ldw);
+  }
+  double g(int k, int i) const { return G[((size_t)((i + off) >> 4) * m + k) * 16 + ((i + off) & 15)]; }
+  void put(int k, const double *l, const double *w) {  // pivot k: its L and L D over the border columns
+    for (int z = 0; z < off; z++) G[(size_t)k * 16 + z] = 0.0;
+    for (int i = 0; i < nb; i++) G[((size_t)((i + off) >> 4) * m + k) * 16 + ((i + off) & 15)] = l[i];
+    double *dw = &W[(size_t)k * ldw];
+    std::memcpy(dw, w, sizeof(double) * nb);
+    for (int z = nb; z < ldw; z++) dw[z] = 0.0;
+  }
+  __attribute__((target("avx512f"))) void put_512(int k, const double *l, const double *w) {
+    double *dw = &W[(size_t)k * ldw];
+    {  // first tile: `off` zeros, then the first 16 - off columns (masked loads do not touch what lies in front of l)
+      const unsigned keep = 0xffffu & ~((1u << off) - 1u);
+      double *dst = &G[(size_t)k * 16];
+      _mm512_storeu_pd(dst, _mm512_maskz_loadu_pd((__mmask8)(keep & 0xffu), l - off));
+      _mm512_storeu_pd(dst + 8, _mm512_maskz_loadu_pd((__mmask8)(keep >> 8), l - off + 8));
+    }
+    for (int t = 1; t < T; t++) {
+      double *dst = &G[((size_t)t * m + k) * 16];
+      const double *src = l + 16 * t - off;
+      _mm512_storeu_pd(dst, _mm512_loadu_pd(src)); _mm512_storeu_pd(dst + 8, _mm512_loadu_pd(src + 8));
+    }
+    int i = 0;
+    for (; i + 8 <= nb; i += 8) _mm512_storeu_pd(dw + i, _mm512_loadu_pd(w + i));
+    if (i < nb) { const __mmask8 mk = (__mmask8)((1u << (nb - i)) - 1u); _mm512_mask_storeu_pd(dw + i, mk, _mm512_maskz_loadu_pd(mk, w + i)); }
+    for (int z = nb; z < ldw; z++) dw[z] = 0.0;  // the last row group reads up to five entries past nb
+  }
+};
+__attribute__((target("avx512f,fma"))) inline void ldlt_border_update_512(double *U, const LdltBorderPack &B, size_t N, int m, int n) {
+  const int nb = n - m, T = B.T, ldw = B.ldw;
+  for (int k0 = 0; k0 < m; k0 += LDLT_BK) {
+    const int k1 = std::min(m, k0 + LDLT_BK);
+    for (int t = 0; t < T; t++) {
+      const double *g0 = &B.G[((size_t)t * m + k0) * 16];
+      const int c0 = 16 * t - B.off, cend = c0 + 16;       // the tile's columns (c0 < 0 for the first tile: padding in front)
+      for (int j = 0; j + 1 < cend; j += 6) {              // row groups with a column right of their first row
+        const double *g = g0, *w = &B.W[(size_t)k0 * ldw + j];
+        __m512d acc[6][2];
+        for (int a = 0; a < 6; a++) acc[a][0] = acc[a][1] = _mm512_setzero_pd();
+        for (int k = k0; k < k1; k++, g += 16, w += ldw) {
+          const __m512d ga = _mm512_loadu_pd(g), gb = _mm512_loadu_pd(g + 8);
+#pragma GCC unroll 6
+          for (int a = 0; a < 6; a++) {
+            const __m512d wa = _mm512_set1_pd(w[a]);
+            acc[a][0] = _mm512_fmadd_pd(wa, ga, acc[a][0]);
+            acc[a][1] = _mm512_fmadd_pd(wa, gb, acc[a][1]);
+          }
+        }
+        for (int a = 0; a < 6 && j + a < nb; a++) {  // only the columns right of the row's diagonal
+          const int lo = std::max(j + a + 1, std::max(c0, 0)) - c0;  // local columns [lo, 16)
+          if (lo >= 16) continue;
+          const unsigned full = 0xffffu & ~((1u << lo) - 1u);
+          const __mmask8 s0 = (__mmask8)(full & 0xffu), s1 = (__mmask8)(full >> 8);
+          double *row = U + (ptrdiff_t)((size_t)(m + j + a) * N + m) + c0;
+          _mm512_mask_storeu_pd(row, s0, _mm512_sub_pd(_mm512_maskz_loadu_pd(s0, row), acc[a][0]));
+          _mm512_mask_storeu_pd(row + 8, s1, _mm512_sub_pd(_mm512_maskz_loadu_pd(s1, row + 8), acc[a][1]));
+        }
       }
     }
   }
 }
-inline void ldlt_border_update(double *U, const double *WB, size_t N, int m, int n, bool wide) {
-  if (wide) return ldlt_border_update_512(U, WB, N, m, n);
+inline void ldlt_border_update(double *U, const LdltBorderPack &B, size_t N, int m, int n, bool wide) {
+  if (wide) return ldlt_border_update_512(U, B, N, m, n);
   const int nb = n - m;
+  static thread_local std::vector<double> gk;
+  gk.resize((size_t)16 * B.T);
   for (int k = 0; k < m; k++) {
-    const double *g = U + (size_t)k * N + m, *w = WB + (size_t)k * nb;
+    for (int t = 0; t < B.T; t++) std::memcpy(&gk[16 * t], &B.G[((size_t)t * m + k) * 16], sizeof(double) * 16);
+    const double *w = &B.W[(size_t)k * B.ldw], *g = gk.data() + B.off;
     for (int j = 0; j < nb; j++) {
       const double wj = w[j];
       if (wj == 0.0) continue;
@@ -689,13 +770,18 @@ inline void ldlt_partial_factor(LdltPartial &F) {
   F.D.assign(m, 0.0);
   F.diag.resize(N);
   F.perm.assign(m, 0);
-  static thread_local std::vector<double> WTv, LTv, WBv;
+  static thread_local std::vector<double> WTv, LTv;
+  static thread_local LdltBorderPack BP;  // L and L D over the border columns, pivot by pivot, for the trailing block's update at the end
   WTv.resize((size_t)LDLT_NB * N); LTv.resize((size_t)LDLT_NB * N);
-  WBv.resize((size_t)m * (n - m));  // L D over the border columns, pivot by pivot, for the trailing block's update at the end
+  BP.shape(m, n - m);
   double *U = F.U.data(), *diag = F.diag.data(), *WTp = WTv.data(), *LTp = LTv.data();
   for (int j = 0; j < n; j++) diag[j] = U[j * N + j];
   const bool wide = ldlt_have_avx512();
+  static const bool TM = getenv("SOS_TIMING_IMU") != nullptr;  // phase split on stderr, with the other [imu_cached] lines
+  auto NOW = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; };
+  double tp = 0, tu = 0, tbd = 0, t_ = 0;
   for (int k0 = 0; k0 < m;) {
+    if (TM) t_ = NOW();
     const int bend = F.be(k0), eend = F.ee(k0);     // pivot block and interior envelope of this panel
     const int kb = std::min(LDLT_NB, bend - k0), k1 = k0 + kb;
     for (int k = k0; k < k1; k++) {
@@ -725,14 +811,19 @@ inline void ldlt_partial_factor(LdltPartial &F) {
       const double dinv = zero ? 0.0 : 1.0 / d;
       // column k brought up to date with the q earlier pivots of the panel, L = a / d, candidate diagonal -- over its two ranges
       for (int part = 0; part < 2; part++)
-        ldlt_pivot_range(uk, WTp, LTp, wt, lt, diag, N, k, q, part == 0 ? k + 1 : m, part == 0 ? eend : n, dinv, zero);
-      if (n > m) std::memcpy(&WBv[(size_t)k * (n - m)], wt + m, sizeof(double) * (n - m));
+        if (wide) ldlt_pivot_range_512(uk, WTp, LTp, wt, lt, diag, N, k, q, part == 0 ? k + 1 : m, part == 0 ? eend : n, dinv, zero);
+        else ldlt_pivot_range(uk, WTp, LTp, wt, lt, diag, N, k, q, part == 0 ? k + 1 : m, part == 0 ? eend : n, dinv, zero);
+      if (n > m) { if (wide) BP.put_512(k, lt + m, wt + m); else BP.put(k, lt + m, wt + m); }
     }
-    // trailing update: (interior rest of the envelope) x (itself + border), border x border
+    // trailing update: (interior rest of the envelope) x (itself + border); border x border once, behind the last pivot
+    if (TM) { const double t2 = NOW(); tp += t2 - t_; t_ = t2; }
     ldlt_range_update(U, WTp, LTp, N, k1, eend, k1, eend, kb, wide, m, n);
+    if (TM) { const double t2 = NOW(); tu += t2 - t_; t_ = t2; }
     k0 = k1;
   }
-  if (n > m) ldlt_border_update(U, WBv.data(), N, m, n, wide);
+  if (TM) t_ = NOW();
+  if (n > m) ldlt_border_update(U, BP, N, m, n, wide);
+  if (TM) { tbd = NOW() - t_; fprintf(stderr, "[ldlt_partial] pivots %.0f us, range update %.0f us, border update %.0f us\n", tp, tu, tbd); }
   // the factorisation leaves the finished columns of L in the row order they were computed in; bring them to the final order (the
   // later interchanges applied to the earlier columns whose envelope holds them), so that the substitutions can apply all
   // interchanges to the vector first

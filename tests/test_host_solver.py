@@ -66,3 +66,36 @@ def test_large_solve_single_thread_and_helper_threads_agree():
             assert two[n]["x"] == base[n]["x"]
         else:
             assert np.allclose(two[n]["x"], base[n]["x"], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("nb", [0, 1, 5, 6, 7, 15, 16, 17, 31, 32, 33, 48, 96, 101, 111, 128])
+def test_partial_factorisation_border_widths(nb):
+    """The trailing block's update of ldlt_partial_factor works on packed 6 x 16 register tiles, right-aligned over the border
+    columns: widths around the tile and row-group boundaries (a ragged first tile, none, a last row group that reads the padding)
+    against the dense solve, with AVX-512 and with the fallback path."""
+    m = 57
+    n = m + nb
+    rng = np.random.default_rng(1000 + nb)
+    B = rng.normal(size=(n, n + 3))
+    A = B @ B.T / n + np.eye(n)
+    A[5, 5] = 1e-3                      # a pivot the threshold test moves
+    b = rng.normal(size=n)
+    xr = np.linalg.solve(A, b)
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); from sos_slam_amd import host; "
+            "d = np.load(sys.argv[1]); print(json.dumps(host.ldlt_partial_solve(d['A'], d['b'], int(d['m'])).tolist()))" % ROOT)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        f = os.path.join(td, "sys.npz")
+        np.savez(f, A=A, b=b, m=m)
+        xs = []
+        for no512 in (False, True):
+            env = dict(os.environ)
+            env.pop("SOS_NO_AVX512", None)
+            if no512:
+                env["SOS_NO_AVX512"] = "1"
+            p = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+            assert p.returncode == 0, p.stderr[-2000:]
+            xs.append(np.array(json.loads(p.stdout.strip().splitlines()[-1])))
+    for x in xs:
+        assert np.abs(x - xr).max() <= 1e-10 * np.abs(xr).max()
+    assert np.abs(xs[0] - xs[1]).max() <= 1e-12 * np.abs(xr).max()
