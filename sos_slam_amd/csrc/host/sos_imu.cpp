@@ -634,6 +634,8 @@ struct ImuCache {
   // the call in flight (prepare -> finish)
   std::vector<double> y;            // nt: forward-substituted right-hand side
   std::vector<double> rhsB;         // nb: constant part of the border right-hand side (prior + IMU), before the forward pass
+  std::vector<double> HMd;          // nIs: (HM d2) at the interior states, left by the build that scanned those rows for THIS call's d2
+  bool HMd_fresh = false;
 };
 struct Prepared {
   bool active = false, cached = false;
@@ -690,7 +692,7 @@ __attribute__((target("avx2,fma"))) double dot4(const double *a, const double *b
 
 // the constant part of the KKT matrix in the cache's ordering, and its partial factorisation
 void build_cache(ImuCache &Q, const sosf_imu_settings &S, const sosf_imu_calib &C, int n, const sosf_imu_frame *F, const double *HM, double lambda,
-                 uint64_t prior_id, bool keep = true) {
+                 uint64_t prior_id, bool keep = true, const double *d2 = nullptr) {
   const int dimI = SOSF_IMU_DIM(n);
   static const bool tmgb = getenv("SOS_TIMING_IMU") != nullptr;
   const double tq0 = tmgb ? now_us() : 0;
@@ -748,19 +750,22 @@ void build_cache(ImuCache &Q, const sosf_imu_settings &S, const sosf_imu_calib &
     // (the interior states of a keyframe are consecutive expanded indices: a block of the prior is scanned as contiguous row segments,
     // a constraint row as one contiguous pass with the keyframe of each expanded index looked up.  The scan of a prior without
     // far couplings touches 3.5 k cache lines of HM, 33 us at W12 -- the price of not assuming the prior's shape)
-    for (int i = 0; i < n; i++)       // the prior beyond the neighbour
-      for (int j = n - 1; j > reach[i]; j--) {
-        const int len = u0[j + 1] - u0[j];
-        if (len <= 0 || u0[i + 1] <= u0[i]) continue;
-        const int gj = Q.gI[u0[j]];
-        bool any = false;
-        for (int a = u0[i]; a < u0[i + 1] && !any; a++) {
-          const double *seg = HM + (size_t)Q.gI[a] * dimI + gj;
+    // the prior beyond the neighbour, row by row; with the caller's expanded delta at hand the row's share of HM d2 is taken in the same
+    // visit (the right-hand side needs it, and the scan alone cost as much as that product: 3.5 k cold lines of HM at W12)
+    Q.HMd_fresh = d2 != nullptr;
+    if (d2) Q.HMd.resize(nIs);
+    for (int i = 0; i < n; i++)
+      for (int a = u0[i]; a < u0[i + 1]; a++) {
+        const double *row = HM + (size_t)Q.gI[a] * dimI;
+        if (d2) Q.HMd[a] = dot4(row, d2, dimI);
+        for (int j = n - 1; j > reach[i]; j--) {
+          const int len = u0[j + 1] - u0[j];
+          if (len <= 0) continue;
+          const double *seg = row + Q.gI[u0[j]];
           int nz = 0;
           for (int c = 0; c < len; c++) nz |= seg[c] != 0.0;
-          any = nz != 0;
+          if (nz) { reach[i] = j; break; }
         }
-        if (any) { reach[i] = j; break; }
       }
     std::vector<int> blockOfG(dimI, -1);  // keyframe of an interior state's expanded index, -1: border
     for (int u = 0; u < nIs; u++) blockOfG[Q.gI[u]] = blockOfState[u];
@@ -822,10 +827,15 @@ void build_cache(ImuCache &Q, const sosf_imu_settings &S, const sosf_imu_calib &
         const int w = what[c];
         row[c] = w >= 0 ? (hi[w] + hm[w]) * (sp * Q.scI[c]) : Jcol[(size_t)(-1 - w) * dimI + g] * (sp * Q.scI[c]);
       }
+      // H_imu couples a state to its own keyframe's columns, the neighbours' biases and the scale (add_frame): over the border it is
+      // zero outside the run with the keyframe's pose and the run with the scale column, and its row need not be read there
+      const int ci = CP + 1 + 29 * ((g - CP - 1) / 29);
       for (const Run &r : runsB) {
         const double *h1 = hi + r.g0, *h2 = hm + r.g0;
         double *o = row + mI + r.u0;
-        for (int i = 0; i < r.len; i++) o[i] = (h1[i] + h2[i]) * sp;
+        const bool imu = (r.g0 < ci + 8 && r.g0 + r.len > ci) || (r.g0 <= CP && r.g0 + r.len > CP);
+        if (imu) for (int i = 0; i < r.len; i++) o[i] = (h1[i] + h2[i]) * sp;
+        else for (int i = 0; i < r.len; i++) o[i] = h2[i] * sp;
       }
     } else {             // a multiplier row: zero against the other multipliers, the constraint's entries elsewhere
       const double *J = &Jcol[(size_t)(-1 - what[p]) * dimI];
@@ -968,9 +978,19 @@ int cached_prepare(ImuCache &Q, const Prepared &P, bool trapped) {
     same = std::memcmp(Q.HMcopy.data(), P.HM, sizeof(double) * (size_t)dimI * dimI) == 0;
   }
   tb = tmg ? now_us() : 0;
+  static thread_local std::vector<double> d2;  // the expanded delta the prior is taken around (:1081-1098)
+  d2.assign(dimI, 0.0);
+  for (int i = 0; i < CP; i++) d2[i] = P.delta[i];
+  if (C.scale_trapped) d2[CP] = C.scale - C.scale_zero;
+  for (int i = 0; i < n; i++) {
+    for (int k = 0; k < 8; k++) d2[CP + 1 + 29 * i + k] = P.delta[CP + 8 * i + k];
+    if (C.scale_trapped)
+      for (int k = 0; k < 21; k++) d2[CP + 1 + 29 * i + 8 + k] = P.F[i].state_imu[k] - P.F[i].state_imu_zero[k];
+  }
+  Q.HMd_fresh = false;
   bool once = !trapped;  // the elimination is built for this call alone (counted as a literal-form solve)
   if (!trapped) {
-    build_cache(Q, S, C, n, P.F, P.HM, P.lambda, P.prior_id, false);
+    build_cache(Q, S, C, n, P.F, P.HM, P.lambda, P.prior_id, false, d2.data());
     Q.valid = false;  // (nothing of it is kept: the next call's Jacobians are taken elsewhere)
     Q.sig.clear();
     tb = tmg ? now_us() : 0;
@@ -980,7 +1000,7 @@ int cached_prepare(ImuCache &Q, const Prepared &P, bool trapped) {
     Q.valid = false;
     Q.sig = sig;
     if (Q.misses >= 3 && !repeats) {  // the inputs move with every call: nothing is kept, the elimination is built and used once
-      build_cache(Q, S, C, n, P.F, P.HM, P.lambda, P.prior_id, false);
+      build_cache(Q, S, C, n, P.F, P.HM, P.lambda, P.prior_id, false, d2.data());
       Q.valid = false;
       tb = tmg ? now_us() : 0;
       if (Q.unusable) return 1;
@@ -988,7 +1008,7 @@ int cached_prepare(ImuCache &Q, const Prepared &P, bool trapped) {
     } else {
       Q.misses++;
       g_stats[1]++;
-      build_cache(Q, S, C, n, P.F, P.HM, P.lambda, P.prior_id);
+      build_cache(Q, S, C, n, P.F, P.HM, P.lambda, P.prior_id, true, d2.data());
       tb = tmg ? now_us() : 0;
       if (Q.unusable) return 1;
     }
@@ -999,15 +1019,7 @@ int cached_prepare(ImuCache &Q, const Prepared &P, bool trapped) {
     g_stats[0]++;
   }
   // right-hand side: prior around the expanded delta (bM + HM d2, :1081-1098), b_imu, constraint residuals
-  static thread_local std::vector<double> d2, bI, rc;
-  d2.assign(dimI, 0.0);
-  for (int i = 0; i < CP; i++) d2[i] = P.delta[i];
-  if (C.scale_trapped) d2[CP] = C.scale - C.scale_zero;
-  for (int i = 0; i < n; i++) {
-    for (int k = 0; k < 8; k++) d2[CP + 1 + 29 * i + k] = P.delta[CP + 8 * i + k];
-    if (C.scale_trapped)
-      for (int k = 0; k < 21; k++) d2[CP + 1 + 29 * i + 8 + k] = P.F[i].state_imu[k] - P.F[i].state_imu_zero[k];
-  }
+  static thread_local std::vector<double> bI, rc;
   if (C.scale_trapped) {
     bI.assign(dimI, 0.0);
     rc.assign(Q.cdim, 0.0);
@@ -1021,7 +1033,7 @@ int cached_prepare(ImuCache &Q, const Prepared &P, bool trapped) {
   Q.rhsB.assign(Q.nb, 0.0);
   for (int u = 0; u < Q.nIs; u++) {
     const int g = Q.gI[u], p = Q.pI[u];
-    Q.y[p] = ((P.bM[g] + bI[g]) + dot4(P.HM + (size_t)g * dimI, d2.data(), dimI)) * Q.scI[p];
+    Q.y[p] = ((P.bM[g] + bI[g]) + (Q.HMd_fresh ? Q.HMd[u] : dot4(P.HM + (size_t)g * dimI, d2.data(), dimI))) * Q.scI[p];
   }
   for (int k = 0; k < Q.cdim; k++) Q.y[Q.pC[k]] = rc[k] * Q.scI[Q.pC[k]];
   for (int j = 0; j < Q.nb; j++) {
