@@ -550,7 +550,7 @@ static void solve_visual_system(MatXX &H, VecX &b, const MatXX &Hsc, const VecX 
   }
   const double t1 = now_s();
   g_phase[1] += t1 - t_sol0;
-  ldlt_solve(H, b, x, dim);
+  ldlt_solve(H, b, x, dim, H.data());  // in place: H is this call's scratch (its upper triangle, diagonal included, is what was just formed)
   for (int i = 0; i < dim; i++) x[i] *= S[i];
   g_phase[2] += now_s() - t1;
 }

@@ -305,18 +305,6 @@ __attribute__((target("avx512f,fma"))) inline void ldlt_trailing_update_512(doub
   int j = k1;
   for (; j + 2 < n; j += 3) {
     double *r0 = U + (size_t)j * N, *r1 = r0 + N, *r2 = r1 + N;
-    {
-      double s01 = 0, s02 = 0, s12 = 0;
-      for (int c = 0; c < kb; c++) {
-        const double l0 = LT[c * N + j], l1 = LT[c * N + j + 1];
-        s01 += l0 * WT[c * N + j + 1];
-        s02 += l0 * WT[c * N + j + 2];
-        s12 += l1 * WT[c * N + j + 2];
-      }
-      r0[j + 1] -= s01;
-      r0[j + 2] -= s02;
-      r1[j + 2] -= s12;
-    }
     __m512d l0[8], l1[8], l2[8];
     const double *w[8];
     for (int c = 0; c < 8; c++) {
@@ -326,9 +314,13 @@ __attribute__((target("avx512f,fma"))) inline void ldlt_trailing_update_512(doub
       l2[c] = _mm512_set1_pd(on ? LT[c * N + j + 2] : 0.0);
       w[c] = WT + (size_t)(on ? c : 0) * N;
     }
-    for (int i = j + 3; i < n; i += 8) {
+    // the columns start at j + 1: the entries between the rows of the group -- (j, j+1), (j, j+2), (j+1, j+2) -- ride in the first
+    // vector, whose store masks leave out what is not right of each row's diagonal (they were a scalar prologue of 3 kb strided
+    // multiply-adds per group, a third of a group's time at dimension 101)
+    for (int i = j + 1; i < n; i += 8) {
       const __mmask8 m = (n - i >= 8) ? (__mmask8)0xff : (__mmask8)((1u << (n - i)) - 1u);
-      __m512d a0 = _mm512_maskz_loadu_pd(m, r0 + i), a1 = _mm512_maskz_loadu_pd(m, r1 + i), a2 = _mm512_maskz_loadu_pd(m, r2 + i);
+      const __mmask8 m1 = (i == j + 1) ? (__mmask8)(m & 0xfe) : m, m2 = (i == j + 1) ? (__mmask8)(m & 0xfc) : m;
+      __m512d a0 = _mm512_maskz_loadu_pd(m, r0 + i), a1 = _mm512_maskz_loadu_pd(m1, r1 + i), a2 = _mm512_maskz_loadu_pd(m2, r2 + i);
 #pragma GCC unroll 8
       for (int c = 0; c < 8; c++) {
         const __m512d wv = _mm512_maskz_loadu_pd(m, w[c] + i);
@@ -337,8 +329,8 @@ __attribute__((target("avx512f,fma"))) inline void ldlt_trailing_update_512(doub
         a2 = _mm512_fnmadd_pd(l2[c], wv, a2);
       }
       _mm512_mask_storeu_pd(r0 + i, m, a0);
-      _mm512_mask_storeu_pd(r1 + i, m, a1);
-      _mm512_mask_storeu_pd(r2 + i, m, a2);
+      _mm512_mask_storeu_pd(r1 + i, m1, a1);
+      _mm512_mask_storeu_pd(r2 + i, m2, a2);
     }
   }
   for (; j + 1 < n; j++) {
@@ -609,28 +601,28 @@ __attribute__((target("avx512f,fma"))) inline void ldlt_range_rows_512(double *U
                                                                        int i2 = 0, int i3 = 0) {
   double *r[R];
   for (int a = 0; a < R; a++) r[a] = U + (size_t)(j + a) * N;
-  for (int a = 0; a < R; a++)  // entries between the rows of the group
-    for (int b = a + 1; b < R; b++) {
-      if (j + b < i0 || j + b >= i1) continue;
-      double sv = 0;
-      for (int c = 0; c < KB; c++) sv += LT[c * N + j + a] * WT[c * N + j + b];
-      r[a][j + b] -= sv;
-    }
   __m512d l[R][KB];
   for (int c = 0; c < KB; c++)
     for (int a = 0; a < R; a++) l[a][c] = _mm512_set1_pd(LT[c * N + j + a]);
   for (int part = 0; part < 2; part++) {
     const int e1 = part == 0 ? i1 : i3;
-    for (int i = part == 0 ? std::max(i0, j + R) : i2; i < e1; i += 8) {
+    // the first range starts right of the group's FIRST row: the entries between the rows of the group ride in the first vector,
+    // whose per-row masks leave out what is not right of that row's diagonal (no scalar prologue)
+    for (int i = part == 0 ? std::max(i0, j + 1) : i2; i < e1; i += 8) {
       const __mmask8 m = (e1 - i >= 8) ? (__mmask8)0xff : (__mmask8)((1u << (e1 - i)) - 1u);
+      __mmask8 mr[R];
+      for (int a = 0; a < R; a++) {
+        const int lo = part == 0 ? j + a + 1 - i : 0;  // lanes below lo are at or left of row j + a's diagonal
+        mr[a] = lo > 0 ? (__mmask8)(m & ~((1u << std::min(lo, 8)) - 1u)) : m;
+      }
       __m512d acc[R];
-      for (int a = 0; a < R; a++) acc[a] = _mm512_maskz_loadu_pd(m, r[a] + i);
+      for (int a = 0; a < R; a++) acc[a] = _mm512_maskz_loadu_pd(mr[a], r[a] + i);
 #pragma GCC unroll 8
       for (int c = 0; c < KB; c++) {
         const __m512d wv = _mm512_maskz_loadu_pd(m, WT + (size_t)c * N + i);
         for (int a = 0; a < R; a++) acc[a] = _mm512_fnmadd_pd(l[a][c], wv, acc[a]);
       }
-      for (int a = 0; a < R; a++) _mm512_mask_storeu_pd(r[a] + i, m, acc[a]);
+      for (int a = 0; a < R; a++) _mm512_mask_storeu_pd(r[a] + i, mr[a], acc[a]);
     }
   }
 }
