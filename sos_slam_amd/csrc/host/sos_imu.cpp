@@ -122,6 +122,50 @@ struct ImuView {
 struct HiOut {
   double JsTW[6], JfTW[29 * 6], Hss, Hff[29 * 29], Hfs[29];
 };
+// The products of getImuHi (J^T W, J^T W J, J^T W J_s for the 6 x 29 frame Jacobian of one sample) with the six rows of J held in
+// 24 zmm registers: 29 x 29 x 6 multiply-adds per sample are what the assembly of a visual-inertial window spends its time on (0.8 us
+// of scalar code per sample, 8 - 50 samples per keyframe).  Sums over k ascending as the scalar statement, fused multiply-adds: equal
+// to rounding, not bit for bit (the kept J^T W of a sample and its Hessian come from the same call either way).
+__attribute__((target("avx512f,fma"))) void hi_products_512(const double *Jf, const double *Js, const double *W, HiOut &o) {
+  const __mmask8 tail = 0x1f;  // 29 = 3 x 8 + 5
+  __m512d Jv[6][4];
+  for (int k = 0; k < 6; k++) {
+    for (int v = 0; v < 3; v++) Jv[k][v] = _mm512_loadu_pd(Jf + 29 * k + 8 * v);
+    Jv[k][3] = _mm512_maskz_loadu_pd(tail, Jf + 29 * k + 24);
+  }
+  alignas(64) double T[6][32];  // T[c][r] = (J^T W)(r, c)
+  for (int c = 0; c < 6; c++) {
+    __m512d t[4] = {_mm512_setzero_pd(), _mm512_setzero_pd(), _mm512_setzero_pd(), _mm512_setzero_pd()};
+#pragma GCC unroll 6
+    for (int k = 0; k < 6; k++) {
+      const __m512d w = _mm512_set1_pd(W[6 * k + c]);
+      for (int v = 0; v < 4; v++) t[v] = _mm512_fmadd_pd(w, Jv[k][v], t[v]);
+    }
+    for (int v = 0; v < 4; v++) _mm512_store_pd(&T[c][8 * v], t[v]);
+  }
+  for (int r = 0; r < 29; r++)
+    for (int c = 0; c < 6; c++) o.JfTW[6 * r + c] = T[c][r];
+  for (int r = 0; r < 29; r++) {
+    __m512d h[4] = {_mm512_setzero_pd(), _mm512_setzero_pd(), _mm512_setzero_pd(), _mm512_setzero_pd()};
+#pragma GCC unroll 6
+    for (int k = 0; k < 6; k++) {
+      const __m512d t = _mm512_set1_pd(T[k][r]);
+      for (int v = 0; v < 4; v++) h[v] = _mm512_fmadd_pd(t, Jv[k][v], h[v]);
+    }
+    double *dst = &o.Hff[29 * r];
+    for (int v = 0; v < 3; v++) _mm512_storeu_pd(dst + 8 * v, h[v]);
+    _mm512_mask_storeu_pd(dst + 24, tail, h[3]);
+  }
+  {
+    __m512d sv[4] = {_mm512_setzero_pd(), _mm512_setzero_pd(), _mm512_setzero_pd(), _mm512_setzero_pd()};
+    for (int k = 0; k < 6; k++) {
+      const __m512d js = _mm512_set1_pd(Js[k]);
+      for (int v = 0; v < 4; v++) sv[v] = _mm512_fmadd_pd(js, _mm512_load_pd(&T[k][8 * v]), sv[v]);
+    }
+    for (int v = 0; v < 3; v++) _mm512_storeu_pd(o.Hfs + 8 * v, sv[v]);
+    _mm512_mask_storeu_pd(o.Hfs + 24, tail, sv[3]);
+  }
+}
 void get_Hi(const sosf_imu_settings &S, const sosf_imu_calib &C, const sosf_imu_frame &fr, double tt, HiOut &o) {
   const ImuView f(fr);
   const bool trapped = C.scale_trapped != 0;
@@ -163,14 +207,15 @@ void get_Hi(const sosf_imu_settings &S, const sosf_imu_calib &C, const sosf_imu_
     for (int k = 0; k < 6; k++) s += Js[k] * S.weight_imu[6 * k + c];
     o.JsTW[c] = s;
   }
+  o.Hss = 0;
+  for (int k = 0; k < 6; k++) o.Hss += o.JsTW[k] * Js[k];
+  if (sos::ldlt_have_avx512()) return hi_products_512(Jf, Js, S.weight_imu, o);
   for (int r = 0; r < 29; r++)
     for (int c = 0; c < 6; c++) {
       double s = 0;
       for (int k = 0; k < 6; k++) s += J(k, r) * S.weight_imu[6 * k + c];
       o.JfTW[6 * r + c] = s;
     }
-  o.Hss = 0;
-  for (int k = 0; k < 6; k++) o.Hss += o.JsTW[k] * Js[k];
   for (int r = 0; r < 29; r++) {
     for (int c = 0; c < 29; c++) {
       double s = 0;
@@ -192,13 +237,30 @@ struct Dense {
   double operator()(int r, int c) const { return a[(size_t)r * cols + c]; }
 };
 
+// the constraint rows, contiguous (rows x dim) and kept between uses: a vector per row was 48 allocations + zero fills per assembly at
+// W12 and a copy to get them side by side
+struct RowStore {
+  int dim = 0, rows = 0;
+  std::vector<double> a;
+  size_t size() const { return (size_t)rows; }
+  double *add_row() {
+    if (a.size() < (size_t)(rows + 1) * dim) a.resize((size_t)(rows + 8) * dim);
+    double *p = &a[(size_t)rows * dim];
+    std::memset(p, 0, sizeof(double) * dim);
+    rows++;
+    return p;
+  }
+  double *operator[](size_t k) { return &a[k * dim]; }
+  const double *operator[](size_t k) const { return &a[k * dim]; }
+  void clear() { rows = 0; }
+};
 struct Assembly {
   Dense H;
   std::vector<double> b;
-  std::vector<std::vector<double>> Jrows;  // constraint rows
+  RowStore Jrows;  // constraint rows
   std::vector<double> r;
   std::vector<int> spline_valid;
-  Assembly(int dim, int n) : H(dim, dim), b(dim, 0.0), spline_valid(n, 0) {}
+  Assembly(int dim, int n) : H(dim, dim), b(dim, 0.0), spline_valid(n, 0) { Jrows.dim = dim; }
 };
 
 // per-sample J^T W of the first-estimate case (scale trapped), kept by the cached solve: the Jacobians of getImuHi are then taken at
@@ -207,7 +269,6 @@ struct HiStore {
   std::vector<double> JsTW, JfTW;  // 6 / 29 x 6 per sample, samples of frame 1, 2, ... in order (valid splines only)
 };
 void add_frame(const sosf_imu_settings &S, const sosf_imu_calib &C, int n, const sosf_imu_frame *F, int fi, Assembly &A, HiStore *store = nullptr) {
-  const int dim = SOSF_IMU_DIM(n);
   const sosf_imu_frame &cur = F[fi], &prv = F[fi - 1];
   const ImuView vc(cur), vp(prv);
   const double tpf = prv.timestamp - cur.timestamp, tpf2 = tpf * tpf;
@@ -241,7 +302,7 @@ void add_frame(const sosf_imu_settings &S, const sosf_imu_calib &C, int n, const
   const bool vel_valid = fi < n - 1;
   const int rows = vel_valid ? 6 : 3, row0 = (int)A.Jrows.size();
   for (int k = 0; k < rows; k++) {
-    A.Jrows.emplace_back((size_t)dim, 0.0);
+    A.Jrows.add_row();
     A.r.push_back(0.0);
   }
   // spline rotation against the relative rotation of the two keyframes
@@ -251,7 +312,7 @@ void add_frame(const sosf_imu_settings &S, const sosf_imu_calib &C, int n, const
   const M3 Rpe = M3::from(prv.evalPT_R).T();
   for (int r = 0; r < 3; r++) {
     A.r[row0 + r] = rr[r];
-    std::vector<double> &J = A.Jrows[row0 + r];
+    double *J = A.Jrows[row0 + r];
     for (int c = 0; c < 3; c++) {
       J[pi + 3 + c] = -kXiRot * Rpe(r, c);
       J[ci + 3 + c] = kXiRot * Rpe(r, c);
@@ -271,7 +332,7 @@ void add_frame(const sosf_imu_settings &S, const sosf_imu_calib &C, int n, const
         const double dso = (1 / tpf) * (prv.camToWorld[9 + r] - cur.camToWorld[9 + r]) - (1 / tnf) * (cur.camToWorld[9 + r] - nxt.camToWorld[9 + r]);
         const double imu = tpf * vc.sc[9 + r] + tpf2 * vc.sc[15 + r] + tnf * vn.sc[9 + r] + 2 * tnf2 * vn.sc[15 + r];
         A.r[row0 + 3 + r] = imu - dso;
-        std::vector<double> &J = A.Jrows[row0 + 3 + r];
+        double *J = A.Jrows[row0 + 3 + r];
         J[pi + r] = -kXiTrans / tpf;
         J[ci + r] = kXiTrans * (1 / tpf + 1 / tnf);
         J[ni + r] = -kXiTrans / tnf;
@@ -392,7 +453,7 @@ extern "C" int sosf_imu_hessian(const sosf_imu_settings *S, const sosf_imu_calib
   std::memcpy(H, A.H.a.data(), sizeof(double) * (size_t)dim * dim);
   std::memcpy(b, A.b.data(), sizeof(double) * dim);
   for (size_t k = 0; k < A.Jrows.size(); k++) {
-    std::memcpy(J_cst + k * dim, A.Jrows[k].data(), sizeof(double) * dim);
+    std::memcpy(J_cst + k * dim, A.Jrows[k], sizeof(double) * dim);
     r_cst[k] = A.r[k];
   }
   *n_cst = (int32_t)A.Jrows.size();
@@ -567,7 +628,7 @@ static int imu_solve_dense(const sosf_imu_settings *S, const sosf_imu_calib *C, 
   const double tB4 = tmg ? now_us() : 0;
   for (int r = 0; r < ms; r++) K[(size_t)r * m + r] = diagK[r] * sI[r] * sI[r];  // (1 + lambda) on the whole diagonal
   for (int k = 0; k < cdim; k++) {
-    const std::vector<double> &J = A.Jrows[k];
+    const double *J = A.Jrows[k];
     const double sk = sI[ms + k];
     for (int r = 0; r < ms; r++) {
       const double v = J[keep[r]];
@@ -772,7 +833,7 @@ void build_cache(ImuCache &Q, const sosf_imu_settings &S, const sosf_imu_calib &
     int k = 0;
     for (int i = 0; i < n; i++)       // constraint rows against the interior states of other keyframes
       for (int q = 0; q < Q.rows_of[i]; q++, k++) {
-        const double *J = A.Jrows[k].data();
+        const double *J = A.Jrows[k];
         for (int g = 0; g < dimI; g++)
           if (J[g] != 0.0 && blockOfG[g] >= 0) {
             const int f = blockOfG[g], lo = std::min(f, i), hi = std::max(f, i);
@@ -812,9 +873,7 @@ void build_cache(ImuCache &Q, const sosf_imu_settings &S, const sosf_imu_calib &
     if (!runsB.empty() && runsB.back().g0 + runsB.back().len == Q.gB[j]) runsB.back().len++;
     else runsB.push_back(Run{Q.gB[j], j, 1});
   }
-  static thread_local std::vector<double> Jcol;  // the constraint rows, contiguous
-  Jcol.resize((size_t)Q.cdim * dimI);
-  for (int k = 0; k < Q.cdim; k++) std::memcpy(&Jcol[(size_t)k * dimI], A.Jrows[k].data(), sizeof(double) * dimI);
+  const double *Jcol = A.Jrows.a.data();  // the constraint rows, contiguous
   for (int p = 0; p < mI; p++) {
     double *row = U + (size_t)p * nt;
     const double sp = Q.scI[p];
