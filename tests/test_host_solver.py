@@ -99,3 +99,16 @@ def test_partial_factorisation_border_widths(nb):
     for x in xs:
         assert np.abs(x - xr).max() <= 1e-10 * np.abs(xr).max()
     assert np.abs(xs[0] - xs[1]).max() <= 1e-12 * np.abs(xr).max()
+
+
+def test_partial_factorisation_tiny_leading_blocks():
+    """leading blocks shorter than the padding in front of the first border tile, and none at all"""
+    from sos_slam_amd import host
+    for m, nb in [(3, 5), (1, 1), (2, 17), (9, 40), (1, 101), (0, 7)]:
+        n = m + nb
+        rng = np.random.default_rng(n * 31 + m)
+        B = rng.normal(size=(n, n + 3))
+        A = B @ B.T / n + np.eye(n)
+        b = rng.normal(size=n)
+        xr = np.linalg.solve(A, b)
+        assert np.abs(host.ldlt_partial_solve(A, b, m) - xr).max() <= 1e-12 * np.abs(xr).max(), (m, nb)
