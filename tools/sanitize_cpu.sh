@@ -2,7 +2,7 @@
 # The CPU test-suite with the oracle (C) and the host facade (C++) built under AddressSanitizer, then under UndefinedBehaviorSanitizer.
 # No GPU needed: what runs is everything the `-m "not gpu"` tests reach -- the oracle, the IMU assembly / solves, the candidate
 # selection, the dense solvers, the ABI zero-argument calls.  The in-tree libraries are swapped for the instrumented ones and restored.
-#   tools/sanitize_cpu.sh          (round 3: 115, round 4: 135 passed under both; the emulator tests have their own sanitizer runs: tools/emu_suite.sh, tools/emu_host_asan.sh)
+#   tools/sanitize_cpu.sh          (round 3: 115, round 4: 135, round 5: 152 passed under both; the emulator tests have their own sanitizer runs: tools/emu_suite.sh, tools/emu_host_asan.sh)
 set -u
 cd "$(dirname "$0")/.."
 T=$(mktemp -d)
