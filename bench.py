@@ -57,7 +57,7 @@ def parse():
                     help="visual-inertial window (BASELINE.json configs 2-3): the IMU / spline block of solveSystemF "
                          "(OB/EnergyFunctional.cpp:1053-1171) sits between stitch and solve on the host")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--side", choices=("imu",), default=None, help=argparse.SUPPRESS)   # one side measurement as its own process
+    ap.add_argument("--side", choices=("imu", "gnsolve"), default=None, help=argparse.SUPPRESS)   # one side measurement as its own process
     ap.add_argument("--no-sides", action="store_true", help="headline loop only: no keyframe / visual-inertial / variants entries")
     ap.add_argument("--cpu-seconds", type=float, default=14.0)
     ap.add_argument("--variants", action="store_true", help="also time the opt-in launch variants, each in a process of its own (not in the default run)")
@@ -160,6 +160,16 @@ def main():
         json_fd = os.dup(1)
         os.dup2(2, 1)
         os.write(json_fd, (json.dumps(imu_timing(args.window, int(os.environ.get("LOCAL_RANK", "0")))) + "\n").encode())
+        return
+    if args.side == "gnsolve":   # k_gn_solve alone: it has never run on an MI355X, so not in the process that owns the line
+        import torch
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+        from sos_slam_amd import synth
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
+        n = synth.WINDOWS[args.window]["n"]
+        os.write(json_fd, (json.dumps(device_solve_timing(n, int(os.environ.get("LOCAL_RANK", "0")))) + "\n").encode())
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
@@ -394,10 +404,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 out["keyframe"] = {"error": repr(e)}
             out["visual_inertial"] = side_process("imu", args.window)
-            try:
-                out["device_solve"] = device_solve_timing(win.n, local_rank)
-            except Exception as e:  # noqa: BLE001
-                out["device_solve"] = {"error": repr(e)}
+            out["device_solve"] = side_process("gnsolve", args.window, timeout=120)
             # the device-resident loop (k_gn_solve in the chain, no host between two kernels): opt-in in the library until it has been
             # timed; measured here in a process of its own (no device-side waits in it: the host polls a mapped slot with a timeout)
             try:

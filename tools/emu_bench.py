@@ -15,7 +15,12 @@ sys.argv = ["bench.py"] + sys.argv[1:]
 os.chdir(ROOT)
 import bench
 # side processes would start the real (GPU-less) bench: run the IMU side in-process
-bench.side_process = lambda what, window, timeout=240, env=None: bench.imu_timing(window, 0, iters=3)
+def _side(what, window, timeout=240, env=None):
+    if what == "gnsolve":
+        from sos_slam_amd import synth
+        return bench.device_solve_timing(synth.WINDOWS[window]["n"], 0, reps=3)
+    return bench.imu_timing(window, 0, iters=3)
+bench.side_process = _side
 # the launch variants are child processes of the real bench as well: not run here (their command lines run through this tool one by one,
 # e.g. `--no-cpu-baseline --no-sides --resident`)
 bench.variant_timing = lambda window, **k: {n: {"error": "child process: not run under tools/emu_bench.py"} for n in (k.get("only") or [v[0] for v in bench.VARIANTS])}
