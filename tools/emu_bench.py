@@ -14,11 +14,15 @@ torch.cuda.synchronize = lambda *a: None
 sys.argv = ["bench.py"] + sys.argv[1:]
 os.chdir(ROOT)
 import bench
-# side processes would start the real (GPU-less) bench: run the IMU side in-process
+# side processes would start the real (GPU-less) bench: run the sides in-process
 def _side(what, window, timeout=240, env=None):
     if what == "gnsolve":
         from sos_slam_amd import synth
         return bench.device_solve_timing(synth.WINDOWS[window]["n"], 0, reps=3)
+    if what == "tracker":
+        return bench.tracker_timing(window, 0)
+    if what == "keyframe":
+        return bench.keyframe_timing(window, 0)
     return bench.imu_timing(window, 0, iters=3)
 bench.side_process = _side
 # the launch variants are child processes of the real bench as well: not run here (their command lines run through this tool one by one,
