@@ -20,6 +20,11 @@ accumulate chain: sos_ba_set_comm), every rank then runs the identical fp64 stit
 The timed region is bracketed by barrier + torch.cuda.synchronize and the MAX over ranks is reported.  A Gauss-Newton
 iteration takes under 0.1 ms, so every step is timed as the mean of `--inner` consecutive iterations (default: enough for
 a timed region of about 1 s); ms_per_step and value are per single iteration.
+
+Output: ONE contract line is what a run is judged by, and it is the LAST JSON line of stdout.  The default N = 1 run prints the line
+twice: first with `"partial": true` as soon as the headline loop, the roofline and the CPU baseline are measured (so that a side
+measurement that hangs or is killed by the caller's clock cannot cost the line), then again, complete (`"partial": false`), with the side
+entries (tracker, keyframe, visual_inertial, device_solve, resident_loop).  `--no-sides` prints the line once.
 """
 from __future__ import annotations
 
@@ -360,7 +365,7 @@ def main():
                  "backup"), phases)},
             "roofline": {"kernel": "k_linearize (fused: linearize + applyRes + top-Hessian tile sums, J kept in LDS)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.window),
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, **pmc_traffic(args.window),
                          "bytes_per_residual": fused_bytes,
                          "min_bytes_per_residual": FUSED_MIN_BYTES_PER_RESIDUAL, "achieved_min_bytes": achieved_min,
                          "frac_min_bytes": achieved_min / HBM_PEAK_GBS,
@@ -400,7 +405,7 @@ def main():
             # The headline measurements + roofline + cpu_baseline are complete: the line goes out NOW, and again, enriched with the side
             # measurements, at the end -- so whatever a side measurement does (a hang, a kill by the caller's clock) cannot cost the
             # line.  A reader that takes the first or the last JSON line of stdout gets a complete contract line either way.
-            os.write(json_fd, (json.dumps(out) + "\n").encode())
+            os.write(json_fd, (json.dumps(dict(out, partial=True)) + "\n").encode())
             # side measurements: a failure in one of them must not cost the headline line
             # (each in a process of its own: most of what they run has not been on an MI355X since round 3 -- a fault of the native
             # code must cost the entry, not the process that owns the line)
@@ -423,6 +428,7 @@ def main():
                     out["variants"] = variant_timing(args.window)
                 except Exception as e:  # noqa: BLE001
                     out["variants"] = {"error": repr(e)}
+        out["partial"] = False
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
@@ -793,17 +799,33 @@ def exchange_info(sysm, win, world):
             "bytes": 4 * int(nfl.value)}
 
 
+def kernel_sources_sha():
+    """sha256 over the sources the roofline kernel is compiled from (what a committed counter value must have been measured on)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("sos_ba.hip", "sos_common.h", "sos_devmath.h"):
+        with open(os.path.join(ROOT, "sos_slam_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(window):
-    """HBM-side bytes per launch of the roofline kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; see
-    profiles/*pmc*.json and tools/pmc_probe.py).  Counters cannot be read from inside the process: null when no
-    summary for this window is committed."""
+    """roofline.traffic: HBM-side bytes per launch of the roofline kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; tools/collect_profiles.sh, tools/pmc_json.py).
+    Counters cannot be read from inside the process, so the value comes from profiles/pmc_<window>.json -- and only when that file was
+    collected on THESE kernel sources (its `kernel_sources_sha` equals the hash of the sources in the tree): otherwise `traffic` is null
+    and the committed value is reported beside it as `traffic_stale`, with the commit it was measured at."""
     path = os.path.join(ROOT, "profiles", f"pmc_{window}.json")
     try:
         with open(path) as f:
-            return json.load(f)["k_linearize_fused"]["traffic_bytes_per_launch"]
+            d = json.load(f)
+        val = d["k_linearize_fused"]["traffic_bytes_per_launch"]
     except Exception:
-        return None
+        return {"traffic": None, "traffic_source": None}
+    src = {"file": f"profiles/pmc_{window}.json", "source_commit": d.get("source_commit"), "kernel_sources_sha": d.get("kernel_sources_sha")}
+    if d.get("kernel_sources_sha") == kernel_sources_sha():
+        return {"traffic": val, "traffic_source": src}
+    return {"traffic": None, "traffic_stale": val, "traffic_source": dict(src, note="collected on other kernel sources than this tree's: not this run's traffic")}
 
 
 def L_host_ba(sysm):

@@ -147,8 +147,9 @@ __attribute__((noinline)) void wave_op() {
   f->st = WAIT_WAVE;
   to_scheduler();
 }
-void block_sync() {
+void block_sync(int site_id, const char *file, int line) {
   Fiber *f = cur;
+  f->bar_id = site_id; f->bar_file = file; f->bar_line = line;
   f->st = WAIT_BLOCK;
   f->blk->waiting_block++;
   to_scheduler();
@@ -400,6 +401,21 @@ static bool pass_block(Machine *M, Block *b, bool *only_yield) {
     }
   }
   if (b->alive > 0 && b->waiting_block == b->alive) {
+    // the barrier releases.  Wave-granular check: all waiting lanes of a wave are in the SAME __syncthreads statement (different waves
+    // may legitimately stand in different ones -- s_barrier is anonymous --, the lanes of one wave may not: see hip_runtime.h)
+    for (int w = 0; w < b->nwaves; w++) {
+      const Fiber *first = nullptr;
+      for (int l = 0; l < 64 && w * 64 + l < b->nthreads; l++) {
+        const Fiber *f = &b->fibers[w * 64 + l];
+        if (f->st != WAIT_BLOCK) continue;
+        if (!first) first = f;
+        else if (f->bar_id != first->bar_id || f->bar_file != first->bar_file) {
+          fprintf(stderr, "[emu] %s block (%u,%u,%u) wave %d: lane %d waits in the __syncthreads of %s:%d, lane %d in that of %s:%d\n", M->launch->name, b->idx.x,
+                  b->idx.y, b->idx.z, w, first->lane, first->bar_file, first->bar_line, f->lane, f->bar_file, f->bar_line);
+          die("divergent __syncthreads: lanes of one wave wait in different barrier statements (on hardware the wave executes an s_barrier for each)");
+        }
+      }
+    }
     int o = 0, c = 0;
     for (int t = 0; t < b->nthreads; t++)
       if (b->fibers[t].st == WAIT_BLOCK) { o |= b->fibers[t].pred != 0; c += b->fibers[t].pred != 0; }

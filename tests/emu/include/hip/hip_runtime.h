@@ -132,6 +132,8 @@ struct Fiber {
   double din[6], dout[4];  // v_mfma_f64_16x16x4_f64: a, b, c[4] -> d[4]
   uint64_t old64;          // `old` operand of a 64-bit DPP move
   int pred;            // __syncthreads_or / _count
+  int bar_id, bar_line;  // the __syncthreads statement this lane waits in
+  const char *bar_file;
 };
 struct Block {
   dim3 idx, bdim, gdim;
@@ -146,7 +148,7 @@ struct Block {
 };
 extern thread_local Fiber *cur;
 void wave_op();      // block the calling lane until its group has been resolved (noinline: the return address names the site)
-void block_sync();   // __syncthreads
+void block_sync(int site_id, const char *file, int line);   // __syncthreads, named by its place in the source
 void yield_lane();   // s_sleep: stay runnable, let everything else run first
 void *shared_static_lookup(const void *key, size_t bytes, size_t align);
 [[noreturn]] void die(const char *msg);
@@ -201,17 +203,24 @@ template <class T> static inline __attribute__((always_inline)) T xlane(int op, 
 #define blockDim (emu::cur->blk->bdim)
 #define gridDim (emu::cur->blk->gdim)
 
-static inline void __syncthreads() { emu::block_sync(); }
-static inline int __syncthreads_or(int p) {
+// s_barrier counts WAVES, not threads: a wave executes each s_barrier instruction it reaches once, with whatever lanes are active.  The
+// emulation runs the lanes as independent fibers, so it must notice by itself when the lanes of one wave wait in DIFFERENT barrier
+// statements (both arms of a lane-divergent branch holding one; a guarded barrier some lanes skipped): on hardware that wave passes
+// two barriers where its siblings pass one and runs out of step from there on (round 5's k_gn_solve).  Every textual occurrence gets a
+// number (__COUNTER__); the release in emu_runtime.cpp refuses a wave whose waiting lanes carry different numbers.
+static inline __attribute__((always_inline)) int emu_syncthreads_or(int p, int id, const char *file, int line) {
   emu::cur->pred = p;
-  emu::block_sync();
+  emu::block_sync(id, file, line);
   return emu::cur->blk->sync_res_or;
 }
-static inline int __syncthreads_count(int p) {
+static inline __attribute__((always_inline)) int emu_syncthreads_count(int p, int id, const char *file, int line) {
   emu::cur->pred = p;
-  emu::block_sync();
+  emu::block_sync(id, file, line);
   return emu::cur->blk->sync_res_count;
 }
+#define __syncthreads() emu::block_sync(__COUNTER__, __FILE__, __LINE__)
+#define __syncthreads_or(p) emu_syncthreads_or((p), __COUNTER__, __FILE__, __LINE__)
+#define __syncthreads_count(p) emu_syncthreads_count((p), __COUNTER__, __FILE__, __LINE__)
 // A wave executes in lockstep: every store a lane issues before a fence is visible before anything any lane of the wave does after
 // it ("all lanes store, fence, lane 0 raises the flag").  Fibers run independently between meeting points, so the fences are made
 // meeting points of the lanes that execute them.

@@ -63,6 +63,30 @@ __global__ void k_lds_hog(float *out) {
   out[threadIdx.x] = big[threadIdx.x];
 }
 
+// barriers and divergence.  mode 0: a barrier in both arms of `tid < n` (n = 112: wave 1 has lanes on both sides) -- the shape of round
+// 5's k_gn_solve, which a GPU runs one barrier out of step and the emulator must REFUSE; mode 1: a guarded barrier some lanes of wave
+// 1 skip on their way to the next one -- refused too; mode 2: the same guard at wave granularity (n = 128: whole waves skip or
+// take it, an anonymous s_barrier pairs whatever the waves execute) and mode 3: the barrier hoisted out of the guard -- both accepted.
+__global__ void k_barrier_shapes(float *out, int n, int mode) {
+  __shared__ float s[256];
+  const int tid = threadIdx.x;
+  s[tid] = (float)tid;
+  __syncthreads();
+  float v = 0.f;
+  if (mode == 0) {
+    if (tid < n) { v = s[(tid + 1) % n]; __syncthreads(); s[tid] = v; } else { __syncthreads(); }
+  } else if (mode == 1 || mode == 2) {
+    if (tid < n) { v = s[(tid + 1) % n]; __syncthreads(); s[tid] = v; }
+    if (mode == 2 && tid >= n) __syncthreads();
+  } else {
+    if (tid < n) v = s[(tid + 1) % n];
+    __syncthreads();
+    if (tid < n) s[tid] = v;
+  }
+  __syncthreads();
+  out[tid] = s[tid];
+}
+
 // LDS transpose of a 32 x 32 tile by 256 threads (4 waves), one barrier
 __global__ void k_transpose(const float *__restrict__ in, float *__restrict__ out) {
   __shared__ float tile[32][33];
@@ -159,6 +183,15 @@ extern "C" int emu_selftest_lds_limit(int kbytes) {
   hipMalloc(&dout, 4 * 64);
   k_lds_hog<<<1, 64, (size_t)kbytes * 1024, 0>>>(dout);
   hipDeviceSynchronize();
+  hipFree(dout);
+  return 0;
+}
+extern "C" int emu_selftest_barrier_shapes(float *out, int n, int mode) {
+  float *dout;
+  hipMalloc(&dout, 4 * 256);
+  k_barrier_shapes<<<1, 256, 0, 0>>>(dout, n, mode);
+  hipDeviceSynchronize();
+  hipMemcpy(out, dout, 4 * 256, hipMemcpyDeviceToHost);
   hipFree(dout);
   return 0;
 }

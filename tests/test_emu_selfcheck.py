@@ -108,6 +108,23 @@ def test_lds_limit_of_a_compute_unit():
     assert bad.returncode != 0 and "160 KB" in bad.stderr, (bad.returncode, bad.stderr[-400:])
 
 
+def test_divergent_barrier_is_refused():
+    """s_barrier counts waves: lanes of ONE wave waiting in different __syncthreads statements (a barrier in both arms of a lane-divergent
+    branch -- round 5's k_gn_solve --, or a guarded barrier part of the wave skipped) is a kernel the hardware runs out of step.  The
+    emulator ends the process on it; the wave-uniform and the hoisted forms run."""
+    import subprocess
+    code = ("import ctypes, sys, numpy as np; sys.path.insert(0, %r); import build_emu; L = ctypes.CDLL(build_emu.build_selftest()); "
+            "o = np.zeros(256, np.float32); L.emu_selftest_barrier_shapes(o.ctypes.data_as(ctypes.c_void_p), int(sys.argv[1]), int(sys.argv[2])); "
+            "n = int(sys.argv[1]); e = np.arange(256, dtype=np.float32); e[:n] = (np.arange(n) + 1) %% n; assert np.array_equal(o, e); print('ran')"
+            % os.path.join(ROOT, "tests", "emu"))
+    for n, mode in ((112, 0), (112, 1)):
+        bad = subprocess.run([sys.executable, "-c", code, str(n), str(mode)], capture_output=True, text=True, timeout=300)
+        assert bad.returncode != 0 and "divergent __syncthreads" in bad.stderr and "wave 1" in bad.stderr, (n, mode, bad.returncode, bad.stderr[-600:])
+    for n, mode in ((128, 0), (128, 2), (112, 3), (128, 3)):
+        ok = subprocess.run([sys.executable, "-c", code, str(n), str(mode)], capture_output=True, text=True, timeout=300)
+        assert ok.returncode == 0 and "ran" in ok.stdout, (n, mode, ok.stderr[-600:])
+
+
 def test_barriers_lds_and_coresident_workgroups(L):
     rng = np.random.default_rng(3)
     nb = 5

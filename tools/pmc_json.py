@@ -30,7 +30,15 @@ def main():
     from sos_slam_amd import synth
     win = synth.make_window(window)
     F, W = rows(fetch_csv), rows(write_csv)
-    d = {"source": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate kernel-trace-only passes over tools/pmc_probe.py {window} "
+    import subprocess
+    import bench
+    try:
+        commit = subprocess.run(["git", "rev-parse", "HEAD"], capture_output=True, text=True, cwd=bench.ROOT).stdout.strip() or None
+    except OSError:
+        commit = None
+    commit = commit or __import__("os").environ.get("SOS_SOURCE_COMMIT")   # (the GPU box has no .git: tools/gpu_settle.sh passes it in)
+    d = {"source_commit": commit, "kernel_sources_sha": bench.kernel_sources_sha(),
+         "source": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate kernel-trace-only passes over tools/pmc_probe.py {window} "
                    f"(tools/collect_profiles.sh): {fetch_csv}, {write_csv}; statistic over the dispatches: {stat}",
          "window": window, "residuals": int(win.R),
          "corrections": "FETCH_SIZE (KiB) doubled as MI355X_MICROARCH.md prescribes for gfx950; WRITE_SIZE (KiB) taken as is",
