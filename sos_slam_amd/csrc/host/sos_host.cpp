@@ -1437,7 +1437,10 @@ int FullSystem::devStepBegin() {
 }
 
 bool FullSystem::residentUsable() const {
-  return residentAllowed && forceAcceptStep && !ef->imuSettings && !ef->allreduceHook && !ef->commAttached && !ef->keepSystem &&
+  // (with a communicator attached the chain carries the exchange itself -- the library enqueues the all-reduce of the packed accumulator
+  // and the all-gather of the newest frame's energies on its stream --, so N = 1 and N > 1 run the same loop; a callback exchange
+  // (allreduceHook) needs the host between accumulate and stitch and stays on the default loop)
+  return residentAllowed && forceAcceptStep && !ef->imuSettings && !ef->allreduceHook && !ef->keepSystem &&
          sos_ba_gn_resident_supported(ef->ba) == 1;
 }
 
@@ -1466,12 +1469,12 @@ bool FullSystem::residentConsume(int seq) {
   double hdr[16];
   std::vector<double> x(dim);
   const int rc = sos_ba_gn_resident_wait(ef->ba, seq, hdr, x.data());
-  if (rc != SOS_OK) {
-    rcAcc(rc);
-    isLost = true;
+  residentSeq = seq;   // consumed whatever it brought: residentFlush's loop over the queued iterations must advance past a failed one
+  if (rc != SOS_OK) {  // a non-positive pivot of the unpivoted device solve (SOS_ERR_STATE) or a wait that timed out: no usable step --
+    rcAcc(rc);         // the system is reported lost (the kernels behind the solve have stepped the device's copies with that x: the
+    isLost = true;     // window is not continued from them)
     return true;
   }
-  residentSeq = seq;
   if (getenv("SOS_TIMING")) fprintf(stderr, "[k_gn_solve] assemble %.1f factorise %.1f substitute %.1f us\n", hdr[11], hdr[12], hdr[13]);
   ef->lastX = x;
   ef->resInA = (int)hdr[8];
@@ -1652,7 +1655,11 @@ float FullSystem::optimize(int mnumOptIts, int *iterations) {
   setPrecalcValues();
   ef->pushState(&HCalib, true, false);  // the point values on the device are the host's after the loop (or were re-sent by its last pushState)
   const double tp3 = now_s();
-  const double lastEnergy = linearizeAll(true);
+  double lastEnergy = linearizeAll(true);
+  if (ef->multiRank()) {  // sharded window: the returned rmse is the window's (energy of all shards over the global residual count)
+    double v = lastEnergy;
+    if (ef->allreduceF64(&v, 1) == SOS_OK) lastEnergy = v;
+  }
   const double tp4 = now_s();
   if (tmg) fprintf(stderr, "[optimize] prepare %.0f us, %d iterations %.0f us, adjoints+precalc+push %.0f us, linearizeAll(true) %.0f us\n", (tp1 - tp0) * 1e6, it, (tp2 - tp1) * 1e6, (tp3 - tp2) * 1e6, (tp4 - tp3) * 1e6);
   if (!std::isfinite(lastEnergy)) isLost = true;

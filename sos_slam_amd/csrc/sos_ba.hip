@@ -3092,7 +3092,7 @@ extern "C" int sos_ba_set_window(sos_ba *ba, int n, const int32_t *frame_slot, i
   ba->off_bc = ba->off_Hcc + 16;
   ba->off_nres = ba->off_bc + 4;
   ba->acc_floats = ba->off_nres + 2;
-  ENSURE(ba->d_acc, ba->acc_floats);
+  ENSURE(ba->d_acc, ba->acc_floats + 2);  // (+ 2: the sharded resident loop's [sum |idepth|, P] rides behind the blocks)
   // device staging of the per-step inputs (one H2D per step)
   ba->st_pre = 0;
   ba->st_adh = ba->st_pre + nn * 28;

@@ -235,5 +235,16 @@ def build_selftest():
     return lib
 
 
+def build_fake_rccl():
+    """tests/emu/fake_rccl.cpp -> a library with the six RCCL entry points csrc/sos_comm.hip binds, for ranks that are processes of the
+    emulated device library (collectives through POSIX shared memory, enqueued in stream order).  sos_rccl_load() is given its path."""
+    lib = os.path.join(OUT, "libfake_rccl.so")
+    src = os.path.join(HERE, "fake_rccl.cpp")
+    if _newer(lib, [src, os.path.join(HERE, "include", "hip", "hip_runtime.h"), os.path.join(HERE, "include", "rccl", "rccl.h")]):
+        subprocess.check_call([CLANG, "-O2", "-g1", "-std=c++17", "-fPIC", "-pthread", "-shared", "-Wno-unused-function", "-I" + os.path.join(HERE, "include"), src, "-o", lib,
+                               "-ldl", "-lrt"])
+    return lib
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

@@ -691,6 +691,14 @@ hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind k,
   }
   return hipSuccess;
 }
+// a host function in stream order (what the real run time offers under the same name): tests/emu/fake_rccl.cpp enqueues its collectives
+// with it, so that they run where ncclAllReduce would -- behind the kernels in front of them on the stream
+hipError_t hipLaunchHostFunc(hipStream_t st, void (*fn)(void *), void *user) {
+  Stream *s = emu::resolve(st);
+  if (!s || !fn) return hipErrorInvalidValue;
+  s->push([fn, user] { fn(user); });
+  return hipSuccess;
+}
 hipError_t hipMemset(void *p, int v, size_t n) {
   emu::sync_all();
   memset(p, v, n);

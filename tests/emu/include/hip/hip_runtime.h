@@ -79,6 +79,7 @@ hipError_t hipHostFree(void *p);
 hipError_t emu_hipHostGetDevicePointer(void **d, void *h, unsigned flags);
 hipError_t hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind k, hipStream_t st);
+hipError_t hipLaunchHostFunc(hipStream_t st, void (*fn)(void *), void *user);
 hipError_t hipMemset(void *p, int v, size_t n);
 hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t st);
 hipError_t hipStreamCreateWithFlags(hipStream_t *st, unsigned flags);
