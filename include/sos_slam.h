@@ -363,6 +363,11 @@ int sos_ba_gn_resident_end(sos_ba *ba, float *pointStep, float *idepth_scaled, d
  * last launch and the HIP-event wall time per launch.  SOS_ERR_STATE: a non-positive pivot (the caller solves on the host). */
 int sos_gn_solve_system(sos_ctx *ctx, int n, const double *H_top, const double *b_top, const double *H_sc, const double *b_sc, const double *HM,
                         const double *bM, const double *delta, double *x, int reps, double *phase_us4);
+/* Debug: the pivot-row update of the solve kernel's diagonal block (Eigen's LDLT inner loop, which OB/EnergyFunctional.cpp:1141-1148 calls,
+ * as one v_fmac_f64_dpp ... row_newbcast:K per column in hand-written asm statements) against the same update through the compiler's
+ * builtin, on ONE wave: lane l holds the row a_in[16 l .. 16 l + 15] and the multiplier nl[l]; for each pivot K = 0 .. 14 both forms
+ * are applied to that input: out_asm / out_ref [(K * 64 + l) * 16 + j].  The two must agree bit for bit. */
+int sos_dbg_gs_row_update(sos_ctx *ctx, const double *a_in, const double *nl, double *out_asm, double *out_ref);
 
 /* ---- multi-GPU exchange; the reference has no counterpart: it is a single-process CPU backend ----
  * One process per GPU, every rank the same keyframes and its own shard of the points.  librccl is bound at run

@@ -194,6 +194,16 @@ class Context:
         _chk(self.L.sos_gn_solve_system(self.h_, n, *[_p(v) for v in a], _p(x), int(reps), _p(ph)), "sos_gn_solve_system")
         return x, ph
 
+    def dbg_gs_row_update(self, a_in, nl):
+        """debug: k_gn_solve's pivot-row update on one wave, the asm statements and the builtin form on the same input (sos_dbg_gs_row_update).
+        a_in (64, 16), nl (64) -> (out_asm, out_ref), each (15, 64, 16): [K, lane, column]"""
+        a = np.ascontiguousarray(a_in, dtype=np.float64).reshape(64, 16)
+        m = np.ascontiguousarray(nl, dtype=np.float64).reshape(64)
+        oa, orf = np.zeros((15, 64, 16)), np.zeros((15, 64, 16))
+        self.L.sos_dbg_gs_row_update.argtypes = [C.c_void_p] * 5
+        _chk(self.L.sos_dbg_gs_row_update(self.h_, _p(a), _p(m), _p(oa), _p(orf)), "sos_dbg_gs_row_update")
+        return oa, orf
+
     # ---- immature points (ImmaturePoint constructor / traceOn)
     def immature_init(self, prm, host_slot: int, u, v):
         from .records import IMMATURE_DTYPE

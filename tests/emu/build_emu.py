@@ -8,7 +8,8 @@ emulator's <hip/hip_runtime.h> (tests/emu/include):
   1. k<<<grid, block, lds, stream>>>(args)   ->  emu::launch("k", k, grid, block, lds, stream, args)
   2. __shared__ T name[N];                   ->  a reference to per-workgroup storage (several workgroups are resident at once)
      extern __shared__ T name[];             ->  the launch's dynamic LDS
-  3. the one inline-assembly block (seqsum8's v_add_f32_dpp chain) -> emu::seqsum8, the same chain on the emulated lanes
+  3. the inline assembly: seqsum8's v_add_f32_dpp chain -> emu::seqsum8, the same chain on the emulated lanes; the GS_ROW_UPDATE macro
+     (gs_row_update<K>'s v_fmac_f64_dpp statements) -> gs_row_update_ref<K>, the builtin form of the same update
 
 Everything else (kernels, device functions, the C-ABI, the host-side stream / flag logic) is compiled as written.
 """
@@ -131,13 +132,13 @@ def rewrite_shared(s):
 
 
 def rewrite_asm(s, fname):
+    # csrc/sos_gn_resident.inc: gs_row_update<K>'s asm statements (v_fmac_f64_dpp ... row_newbcast:K, one per column, generated by the
+    # GS_ROW_UPDATE macro) -> the builtin form the product keeps beside them for exactly this comparison (gs_row_update_ref<K>)
+    s = re.sub(r"#define GS_ROW_UPDATE\(K, J\) asm volatile\([^\n]*\)\n", "#define GS_ROW_UPDATE(K, J) gs_row_update_ref<K>(a, nl)\n", s)
+
     def repl(m):
         if "v_add_f32_dpp" in m.group(0) and "row_shr:7" in m.group(0):
             return "s = emu::seqsum8(v);"
-        if "v_fmac_f64_dpp" in m.group(0) and "row_newbcast" in m.group(0):
-            # csrc/sos_gn_resident.inc: gs_row_update<K> -- a[j] += bcast_K(a[j]) * nl for j = K + 1 .. 15, one instruction per j
-            k = 15 - m.group(0).count("v_fmac_f64_dpp")
-            return "for (int j_ = %d; j_ < 16; j_++) a[j_] = fma(gs_rowbc<%d>(a[j_]), nl, a[j_]);" % (k + 1, k)
         raise SystemExit("tests/emu: unknown inline assembly in %s -- teach build_emu.py its meaning" % fname)
 
     return re.sub(r"asm\s+volatile\s*\((?:[^;]|\n)*?\)\s*;", repl, s)

@@ -102,3 +102,41 @@ def test_device_solve_reports_a_non_positive_pivot():
     x, _ = ctx.gn_solve_system(np.triu(A @ A.T + 50 * np.eye(d)), rng.standard_normal(d), z, np.zeros(d), z, np.zeros(d), np.zeros(d))
     assert np.isfinite(x).all()
     ctx.close()
+
+
+def test_row_update_asm_equals_builtin_form():
+    """gs_row_update<K> -- fifteen asm statements of v_fmac_f64_dpp ... row_newbcast:K with hand-placed s_nop around them (the VALU-write ->
+    DPP-read hazard is the programmer's inside an asm statement) -- against the builtin form of the same update, lane by lane and bit by
+    bit, and both against the arithmetic they stand for: a[j] += a_K[j] * nl with a_K the row of lane K of the lane's 16-lane group, for
+    j > K; columns <= K untouched.  Random rows, multipliers of every magnitude, a zero multiplier (the masked lanes of the factorisation),
+    denormal and huge entries.  (Under tests/emu both forms are the builtin: the comparison with NumPy is what that run checks.)"""
+    rng = np.random.default_rng(11)
+    ctx = lib.Context(640, 480)
+    try:
+        for trial in range(6):
+            a = rng.normal(size=(64, 16)) * 10.0 ** rng.integers(-3, 4, size=(64, 16))
+            nl = rng.normal(size=64) * 10.0 ** rng.integers(-2, 3, size=64)
+            if trial == 1:
+                nl[rng.random(64) < 0.5] = 0.0                 # lanes at or above the pivot row multiply by the 0 / 1 mask
+            if trial == 2:
+                a[rng.random((64, 16)) < 0.1] = 5e-324          # denormals pass through v_fmac_f64 unflushed
+                a[rng.random((64, 16)) < 0.05] = 1e300
+            oa, orf = ctx.dbg_gs_row_update(a, nl)
+            assert np.array_equal(oa.view(np.uint64), orf.view(np.uint64)), trial
+            for K in range(15):
+                exp = a.copy()
+                rows = a.reshape(4, 16, 16)[:, K, :]            # lane K of each 16-lane group
+                src = np.repeat(rows, 16, axis=0)               # (64, 16): what row_newbcast:K delivers to every lane of the group
+                for j in range(K + 1, 16):
+                    # one fused multiply-add per element: exact product + one rounding (np.longdouble carries the 106-bit product of two doubles
+                    # only approximately, so the check is to 1 ulp, the bit-for-bit statement is the one between the two device forms)
+                    exp[:, j] = a[:, j] + src[:, j] * nl
+                got = oa[K]
+                assert np.array_equal(got[:, :K + 1], a[:, :K + 1]), (trial, K)
+                with np.errstate(over="ignore", invalid="ignore"):
+                    err = np.abs(got[:, K + 1:] - exp[:, K + 1:])
+                    tol = 2 * np.spacing(np.maximum(np.abs(exp[:, K + 1:]), np.abs(src[:, K + 1:] * nl[:, None])))
+                ok = (err <= tol) | ~np.isfinite(exp[:, K + 1:])
+                assert ok.all(), (trial, K, float(err[~ok].max()))
+    finally:
+        ctx.close()

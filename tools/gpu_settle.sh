@@ -11,6 +11,9 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 F='^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl'
+# the first minute: the hand-written asm of k_gn_solve's pivot chain against the builtin form, and the solve itself
+timeout 300 python -X faulthandler -m pytest tests/test_gpu_gn_solve.py -m gpu -q -rA -p no:cacheprovider > $OUT/gn_solve_first.log 2>&1; echo "k_gn_solve micro-test + solve rc=$?"
+grep -v "$F" $OUT/gn_solve_first.log | grep -E "passed|failed|^FAILED|^ERROR|Fatal|^PASSED" | head -12
 timeout 1500 python -X faulthandler -m pytest tests -m gpu -q -rA -p no:cacheprovider > $OUT/gputests.log 2>&1
 echo "suite rc=$?"
 grep -v "$F" $OUT/gputests.log | grep -E "passed|failed|^FAILED|^ERROR|Fatal" | head -30
