@@ -463,6 +463,7 @@ VARIANTS = (
     ("stitch_signal_in_kernel", {"SOS_STITCH_SIGNAL_IN_KERNEL": "1"}, []),          # the stitch's last kernel raises the host flag itself (no k_publish)
     ("resident", {}, ["--resident"]),                                                 # solve on the device (k_gn_solve), the host out of the loop
     ("resident_abs_schur", {"SOS_ABS_SC": "1"}, ["--resident"]),
+    ("lin_xcd_ranges", {"SOS_LIN_XCD": "1"}, []),                                     # k_linearize2: a contiguous tile range per XCD (judged by FETCH_SIZE, tools/pmc_probe.py)
 )
 
 

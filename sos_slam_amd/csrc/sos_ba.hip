@@ -246,7 +246,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <bool FUSED, bool SCALAR1>
 __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(const float4 *__restrict__ a_r_geo, const float *__restrict__ a_r_cw,
                                                                const float4 *__restrict__ a_t_pre, const float *const *__restrict__ a_t_img,
-                                                               int a_ntilesA, int a_lin_nd, BaDev d, const float *__restrict__ frameTH,
+                                                               int a_ntilesA, int a_lin_nd_x, BaDev d, const float *__restrict__ frameTH,
                                                                int doApply, float *__restrict__ fuse_top_) {
   // the leading scalar arguments (what the first loads of a block need) arrive preloaded in SGPRs
   // (-amdgpu-kernarg-preload-count): the block does not wait for the kernel-argument segment before its first requests
@@ -265,7 +265,24 @@ __global__ __launch_bounds__(256 * L2_TILES, 6) void k_linearize2(const float4 *
   const int tloc = tid >> 8, t256 = tid & 255;
   // blocks [0, lin_nd) own two tiles, the blocks behind them one (the second half idles): with an odd number of tiles per
   // CU the grid is cut so that every CU gets the same number of tiles instead of whole two-tile blocks
-  const int tbase = (int)blockIdx.x < a_lin_nd ? (int)blockIdx.x * L2_TILES : a_lin_nd + (int)blockIdx.x;
+  // XCD-contiguous tile ranges (SOS_LIN_XCD=1, off by default): the dispatcher deals block b to XCD b % 8 (observed, MI355X_MICROARCH.md; a speed
+  // assumption only), and the tiles are sorted by (target, host) -- dealt round-robin, the hosts of one target image land on all eight
+  // XCDs and each L2 fetches its own copy of the texel lines they share (a fifth of the texel traffic at W12).  With the switch XCD x
+  // owns the CONTIGUOUS tile range [start_x, start_x + 2 nd_x + ns_x): its two-tile blocks first, then its one-tile blocks -- the same
+  // number of either as under the round-robin deal, so every CU still gets the tiles lin_grid meant for it.  Which block computes a
+  // tile changes, nothing a tile or a residual computes does: results are bit-identical (tests/test_gpu_variants.py).
+  // (the switch rides in bit 30 of the preloaded block count: nothing of this waits for the kernel-argument segment)
+  const int a_lin_nd = a_lin_nd_x & 0x3fffffff;
+  int tbase_;
+  if (a_lin_nd_x >> 30) {
+    const int b = (int)blockIdx.x, nb = a_ntilesA - a_lin_nd, x = b & 7, k = b >> 3;  // (lin_grid: tiles = 2 nd + (nb - nd); no gridDim load)
+    const int Dx = (a_lin_nd >> 3) * x + min(a_lin_nd & 7, x), Nx = (nb >> 3) * x + min(nb & 7, x);  // two-tile / all blocks of the XCDs before x
+    const int ndx = a_lin_nd > x ? (a_lin_nd - x + 7) >> 3 : 0;                                         // two-tile blocks of XCD x
+    tbase_ = Dx + Nx + (b < a_lin_nd ? 2 * k : 2 * ndx + (k - ndx));
+  } else {
+    tbase_ = (int)blockIdx.x < a_lin_nd ? (int)blockIdx.x * L2_TILES : a_lin_nd + (int)blockIdx.x;
+  }
+  const int tbase = tbase_;
   const int tlim = (int)blockIdx.x < a_lin_nd ? a_ntilesA : min(a_ntilesA, tbase + 1);
   const int tile = tbase + tloc;
   const bool tile_ok = tile < tlim;
@@ -3381,11 +3398,14 @@ static int launch_lin_kernel(sos_ba *ba, const BaDev &dv, int mode, float *fuse_
   const int nb = lin_grid(ba, &nd);
   BaDev dv2 = dv;
   dv2.lin_nd = nd;
+  // PENDING_FIRST_GPU_RUN: opt-in until the PMC passes have judged it (FETCH_SIZE x 2 <= 28 MB at W12 and no slower, else it leaves)
+  static const bool linXcd = getenv("SOS_LIN_XCD") != nullptr && atoi(getenv("SOS_LIN_XCD")) != 0;
+  const int ndx = nd | (linXcd ? 0x40000000 : 0);
   const int seq = signal ? ++ba->sig_lin_seq : 0;
   // one round of resident blocks (3 per CU)?  then the scalar-cache form of the first loads
   const bool scalar1 = nb <= 3 * lin_ncu(ba);
 #define SOS_LAUNCH_LIN2(F, S1, FT) \
-  k_linearize2<F, S1><<<nb, 256 * L2_TILES, 0, ba->ctx->stream>>>(dv2.r_geo, dv2.r_cw, dv2.t_pre, dv2.t_img, dv2.ntilesA, nd, dv2, stg(ba, ba->st_th), mode, FT)
+  k_linearize2<F, S1><<<nb, 256 * L2_TILES, 0, ba->ctx->stream>>>(dv2.r_geo, dv2.r_cw, dv2.t_pre, dv2.t_img, dv2.ntilesA, ndx, dv2, stg(ba, ba->st_th), mode, FT)
   if (fuse_top && mode == 1) {
     if (scalar1) SOS_LAUNCH_LIN2(true, true, fuse_top);
     else SOS_LAUNCH_LIN2(true, false, fuse_top);

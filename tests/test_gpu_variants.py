@@ -80,6 +80,9 @@ def test_switches(modeA, modeB, huber, outlier):
     ({"SOS_STITCH_SIGNAL_IN_KERNEL": "1"}, "tests/test_golden_t6.py"),    # the stitch's last kernel raises the host flag itself
     # the device-resident loop over a rolling chain: k_gn_solve with a marginalisation prior that is not zero, linearised residuals
     # in the window, bM + HM delta formed by the step kernel -- against the oracle chain with the same bars as the host-solve loop
+    # XCD-contiguous tile ranges of the linearisation (which block computes which tile; nothing a tile computes): the bit-exact files
+    ({"SOS_LIN_XCD": "1"}, "tests/test_gpu_backend.py"),
+    ({"SOS_LIN_XCD": "1"}, "tests/test_golden_t6.py"),
     ({"SOS_TEST_RESIDENT": "1"}, "tests/test_gpu_rolling_window.py -k qvga"),
     ({"SOS_TEST_RESIDENT": "1"}, "tests/test_gpu_optimize.py -k T6"),
     # the Python loop over the facade's stage calls in place of sosf_sequence (rolling.device_chain)
@@ -100,3 +103,53 @@ def test_launch_variants_keep_parity(env, target):
     r = subprocess.run([sys.executable, "-m", "pytest"] + target.split() + ["-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"], cwd=root, env=e,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+_HASH_CHILD = r"""
+import hashlib, os, sys
+import numpy as np
+root = sys.argv[1]
+sys.path.insert(0, root)
+emu = os.environ.get("SOS_EMU") == "1"
+if emu:
+    try:
+        import torch
+        emu = not torch.cuda.is_available()
+    except Exception:
+        pass
+if emu:   # what tests/conftest.py does at session start
+    sys.path.insert(0, os.path.join(root, "tests", "emu"))
+    import build_emu
+    from sos_slam_amd import build as _b
+    _b.HIP_LIB, _b.HOST_LIB = build_emu.build()
+    _b.build_all = lambda *a, **k: (_b.HIP_LIB, _b.HOST_LIB)
+from sos_slam_amd import host, synth
+win = synth.make_window(sys.argv[2])
+sysm = host.System.from_window(win)
+rm, it = sysm.optimize(4)
+h = hashlib.sha256()
+for a in (sysm.lastX(), sysm.points()["idepth"], np.array([sysm.frame(f)["camToWorld"] for f in range(win.n)]),
+          np.array([sysm.frame(f)["frameEnergyTH"] for f in range(win.n)], np.float32)):
+    h.update(np.ascontiguousarray(a).tobytes())
+pi, tf = sysm.residual_ids()
+h.update(pi.tobytes()); h.update(tf.tobytes())
+print("HASH", h.hexdigest(), it, float(rm))
+sysm.close()
+"""
+
+
+@pytest.mark.parametrize("name", ["T6", "W7"])
+def test_xcd_tile_ranges_are_bit_identical(name):
+    """SOS_LIN_XCD=1 changes which block of k_linearize2 computes which tile (a contiguous tile range per XCD instead of the round-robin
+    deal) and nothing else: a whole optimize() -- steps, depths, poses, thresholds, index sets -- comes out bit for bit the same."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for v in ("0", "1"):
+        e = dict(os.environ, SOS_LIN_XCD=v)
+        r = subprocess.run([sys.executable, "-c", _HASH_CHILD, root, name], env=e, capture_output=True, text=True, timeout=900, cwd=root)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][-1])
+    assert outs[0] == outs[1], outs
