@@ -1061,15 +1061,8 @@ __global__ __launch_bounds__(128) void k_reduce_all(ReduceArgs a) {
     if (tid >= SOS_TOPN) return;
     const int t0 = a.pair_tile_begin[b], t1 = a.pair_tile_begin[b + 1];
     double s = 0;
-    // rounds of 16 tiles with every load of a round in flight before the first add (clamped addresses, the adds keep their order):
-    // a pair of W12 has ~9 tiles -- one memory round trip instead of a compiler-unrolled loop's two or three
-    for (int t = t0; t < t1; t += 16) {
-      float v[16];
-#pragma unroll
-      for (int u = 0; u < 16; u++) v[u] = a.top_part[(size_t)min(t + u, t1 - 1) * SOS_TOPN + tid];
-#pragma unroll
-      for (int u = 0; u < 16; u++) s += t + u < t1 ? (double)v[u] : 0.0;
-    }
+#pragma unroll 8
+    for (int t = t0; t < t1; t++) s += (double)a.top_part[(size_t)t * SOS_TOPN + tid];
     if (tid < 91) a.accTop[(size_t)b * 91 + tid] = (float)s;
     return;
   }
@@ -1084,13 +1077,8 @@ __global__ __launch_bounds__(128) void k_reduce_all(ReduceArgs a) {
     double s = 0;
     const int kc0 = a.host_chunk_begin[h], kc1 = a.host_chunk_begin[h + 1];
     const size_t off = (size_t)r * a.Dm + c;
-    for (int k = kc0; k < kc1; k += 16) {  // (as above: W12 has ~11 chunks per host)
-      float v[16];
-#pragma unroll
-      for (int u = 0; u < 16; u++) v[u] = a.gram_part[(size_t)min(k + u, kc1 - 1) * a.Dm * a.Dm + off];
-#pragma unroll
-      for (int u = 0; u < 16; u++) s += k + u < kc1 ? (double)v[u] : 0.0;
-    }
+#pragma unroll 8
+    for (int k = kc0; k < kc1; k++) s += (double)a.gram_part[(size_t)k * a.Dm * a.Dm + off];
     const int t1 = r >> 3, i = r & 7;
     if (c < 8 * n) {
       const int t2 = c >> 3, j = c & 7;
@@ -1137,42 +1125,14 @@ struct PrepOut { float hdi, hcd[4], bdsum; };
 __device__ __forceinline__ PrepOut point_prep_body(const BaDev &d, int shiftPriorToZero, int p) {
   float HddA = 0, bdA = 0, HcdA[4] = {0, 0, 0, 0}, HddL = 0, bdL = 0, HcdL[4] = {0, 0, 0, 0};
   float ngood = 0;
-  // The first 16 residuals of the point come from its fixed-stride list (p_list16: no lookup of p_begin in front of it), requested
-  // together with the list bounds, the point record and the old step; their per-residual terms then go out as ONE batch: two memory
-  // round trips for a point with up to 16 observations (three to five with the p_begin -> p_list2 -> s_pterm chain in groups of 8).
-  // The sums stay in residualsAll order.
-  constexpr int PU = 8;
-  const int2 *l16 = d.p_list16 + 16 * (size_t)p;
-  int2 e16[16];
-#pragma unroll
-  for (int k = 0; k < 16; k++) e16[k] = l16[k];
   const int q0 = d.p_begin[p], q1 = d.p_begin[p + 1];
+  // residual list, point record and the per-residual terms are requested level by level for ALL residuals of the
+  // point at once (groups of PU): the sums below stay in residualsAll order, only the memory latencies overlap
+  constexpr int PU = 8;
   const sos_point *ptp = d.pts + p;
   const float priorF = ptp->priorF, deltaF = ptp->deltaF;
   const float stepOld = d.p_out[16 * (size_t)p + PO_STEP];
-  {
-    float4 a[16], b[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-      const float4 *pt = reinterpret_cast<const float4 *>(d.s_pterm + 8 * (size_t)max(e16[k].x, 0));
-      a[k] = pt[0];
-      b[k] = pt[1];
-    }
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-      if (e16[k].x < 0) continue;       // beyond the end of the list
-      if (b[k].z == 0.f) continue;      // not active
-      ngood += 1.f;
-      if (b[k].w != 0.f) {
-        HddL += a[k].x; bdL += a[k].y;
-        HcdL[0] += a[k].z; HcdL[1] += a[k].w; HcdL[2] += b[k].x; HcdL[3] += b[k].y;
-      } else {
-        HddA += a[k].x; bdA += a[k].y;
-        HcdA[0] += a[k].z; HcdA[1] += a[k].w; HcdA[2] += b[k].x; HcdA[3] += b[k].y;
-      }
-    }
-  }
-  for (int q = q0 + 16; q < q1; q += PU) {  // points seen from more than 16 keyframes
+  for (int q = q0; q < q1; q += PU) {
     int sidx[PU];
     float4 a[PU], b[PU];
 #pragma unroll
@@ -1222,7 +1182,7 @@ __device__ __forceinline__ PrepOut point_prep_body(const BaDev &d, int shiftPrio
   r.bdsum = o3.y;
   return r;
 }
-__global__ __launch_bounds__(64) void k_point_prep(BaDev d, int shiftPriorToZero, const int *__restrict__ plist, int count) {
+__global__ void k_point_prep(BaDev d, int shiftPriorToZero, const int *__restrict__ plist, int count) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   point_prep_body(d, shiftPriorToZero, plist ? plist[i] : i);
@@ -1251,61 +1211,38 @@ __device__ __forceinline__ void sc_gram_body(const BaDev &d, int blk, const int 
   const int n = d.n;
   for (int q = tid; q < SOS_GC * ld / 4; q += 256) reinterpret_cast<float4 *>(A)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
-  // stage.  Roles by wave so that no thread walks two dependent chains one after the other (round 5; the loop "item = tid, tid + 256"
-  // gave the 32 threads of the point terms a JpJd item first and their own 4-level chain after it: ~8 memory round trips in a row):
-  //   wave 3, lanes 0..31: the point's own column block (Hcd, bdSum) and Hdi -- chunk_pt -> {list, bounds, record} -> terms
-  //   waves 0..2: the (point, target) items, SOS_GC n of them over 192 threads, every level of all items of a thread in one batch --
-  //               chunk_pt -> p_res_t -> JpJd
-  {
-    const int pl = tid & 31;  // (192 and 256 are multiples of 32: all items of a thread belong to the same point)
+  // stage: thread per (point, target); t == n is the point's own column block (Hcd, bdSum) and Hdi
+  for (int q = tid; q < SOS_GC * (n + 1); q += 256) {
+    const int t = q / SOS_GC, pl = q - t * SOS_GC;  // the 32 prep items (t == n) end up in one half-wave
     const int p = chunk_pt[blk * SOS_GC + pl];
-    if (tid >= 192) {
-      if (tid < 192 + SOS_GC) {
-        if (p < 0) sHdi[pl] = 0.f;
-        else {
-          float *row = A + pl * ld + 8 * n;
-          if (PREP >= 0) {
-            const PrepOut r = point_prep_body(d, PREP, p);
-            sHdi[pl] = r.hdi;
-            row[0] = r.hcd[0]; row[1] = r.hcd[1]; row[2] = r.hcd[2]; row[3] = r.hcd[3];
-            row[4] = r.bdsum;
-          } else {
-            const float4 *po = reinterpret_cast<const float4 *>(d.p_out + 16 * (size_t)p);
-            const float4 v0 = po[0], v1 = po[1], v2 = po[2], v3 = po[3];
-            sHdi[pl] = v3.x;
-            row[0] = v0.z + v2.x;  // Hcd_accAF + Hcd_accLF
-            row[1] = v0.w + v2.y;
-            row[2] = v1.x + v2.z;
-            row[3] = v1.y + v2.w;
-            row[4] = v3.y;         // bdSumF
-          }
-        }
+    if (p < 0) {
+      if (t == n) sHdi[pl] = 0.f;
+      continue;
+    }
+    if (t == n) {
+      float *row = A + pl * ld + 8 * n;
+      if (PREP >= 0) {
+        const PrepOut r = point_prep_body(d, PREP, p);
+        sHdi[pl] = r.hdi;
+        row[0] = r.hcd[0]; row[1] = r.hcd[1]; row[2] = r.hcd[2]; row[3] = r.hcd[3];
+        row[4] = r.bdsum;
+      } else {
+        const float4 *po = reinterpret_cast<const float4 *>(d.p_out + 16 * (size_t)p);
+        const float4 v0 = po[0], v1 = po[1], v2 = po[2], v3 = po[3];
+        sHdi[pl] = v3.x;
+        row[0] = v0.z + v2.x;  // Hcd_accAF + Hcd_accLF
+        row[1] = v0.w + v2.y;
+        row[2] = v1.x + v2.z;
+        row[3] = v1.y + v2.w;
+        row[4] = v3.y;         // bdSumF
       }
     } else {
-      constexpr int NI = 3;  // items of a thread requested together: one round up to 18 keyframes
-      const int pc = p < 0 ? 0 : p;
-      for (int base = 0; base < SOS_GC * n; base += 192 * NI) {
-        int sI[NI];
-#pragma unroll
-        for (int it = 0; it < NI; it++) {
-          const int t = (base + tid + 192 * it) >> 5;
-          sI[it] = d.p_res_t[(size_t)pc * n + min(t, n - 1)];
-          if (t >= n || p < 0) sI[it] = -1;
-        }
-        float4 j0[NI], j1[NI];
-#pragma unroll
-        for (int it = 0; it < NI; it++) {
-          const float4 *jp = reinterpret_cast<const float4 *>(d.JpJd + 8 * (size_t)max(sI[it], 0));
-          j0[it] = jp[0];
-          j1[it] = jp[1];
-        }
-#pragma unroll
-        for (int it = 0; it < NI; it++)
-          if (sI[it] >= 0) {
-            float4 *row = reinterpret_cast<float4 *>(A + pl * ld + 8 * ((base + tid + 192 * it) >> 5));
-            row[0] = j0[it];
-            row[1] = j1[it];
-          }
+      const int s = d.p_res_t[(size_t)p * n + t];
+      if (s >= 0) {
+        const float4 *jp = reinterpret_cast<const float4 *>(d.JpJd + 8 * (size_t)s);
+        float4 *row = reinterpret_cast<float4 *>(A + pl * ld + 8 * t);
+        row[0] = jp[0];
+        row[1] = jp[1];
       }
     }
   }
@@ -1392,15 +1329,11 @@ __device__ __forceinline__ void stitch_top_pairs_body(int bx, int by, int n, con
   }
   const float *blk = acc_top + ((size_t)by * n * n + pidx) * 91;
   double *out = C + ((size_t)by * n * n + pidx) * SOS_TOPC;
-  {  // all five operands requested before the first is used (clamped indices: a load behind a divergent guard is waited for on its own)
-    const float fB = blk[top_idx(4 + i, 4 + j)], fBpc = blk[top_idx(4 + ((tid & 31) >> 2), tid & 3)], fbp = blk[top_idx(4 + (tid & 7), 12)];
-    const double dAH = adHost[(size_t)pidx * 64 + tid], dAT = adTarget[(size_t)pidx * 64 + tid];
-    sB[tid] = (double)fB;
-    sAH[tid] = dAH;
-    sAT[tid] = dAT;
-    if (tid < 32) sBpc[tid] = (double)fBpc;
-    if (tid < 8) sbp[tid] = (double)fbp;
-  }
+  sB[tid] = (double)blk[top_idx(4 + i, 4 + j)];
+  sAH[tid] = adHost[(size_t)pidx * 64 + tid];
+  sAT[tid] = adTarget[(size_t)pidx * 64 + tid];
+  if (tid < 32) sBpc[tid] = (double)blk[top_idx(4 + (tid >> 2), tid & 3)];
+  if (tid < 8) sbp[tid] = (double)blk[top_idx(4 + tid, 12)];
   __syncthreads();
   double t1 = 0, t2 = 0;
 #pragma unroll
@@ -1474,48 +1407,30 @@ __device__ __forceinline__ void stitch_top_sum_body(int bx, int by, int n, const
     // fixed order: pairs (a,t) t = 0..n-1 (host side), then pairs (h,a) h = 0..n-1 (target side; (a,a) is empty)
     const int hc = tid & 31, bc_ = tid & 7;
     // every load of a round of 16 terms is in flight before the first add (the adds keep their order): the sums were a chain
-    // of n / 4 dependent L2 round trips.  Up to 16 keyframes the host-side and the target-side terms are requested TOGETHER (clamped
-    // addresses instead of guarded loads): one memory round trip for the block instead of two
-    if (n <= 16) {
-      double v0[16], v1[16], v2[16], w0[16], w1[16], w2[16];
-#pragma unroll
-      for (int u = 0; u < 16; u++) {
-        const int q = min(u, n - 1);
-        const double *c = Cm + (size_t)(a + n * q) * SOS_TOPC, *d = Cm + (size_t)(q + n * a) * SOS_TOPC;
-        v0[u] = c[tid]; v1[u] = c[192 + hc]; v2[u] = c[256 + bc_];
-        w0[u] = d[64 + tid]; w1[u] = d[224 + hc]; w2[u] = d[264 + bc_];
-      }
+    // of n / 4 dependent L2 round trips
+    for (int t0 = 0; t0 < n; t0 += 16) {
+      double v0[16], v1[16], v2[16];
 #pragma unroll
       for (int u = 0; u < 16; u++)
-        if (u < n) { sH += v0[u]; sHc += v1[u]; sb += v2[u]; }
+        if (t0 + u < n) {
+          const double *c = Cm + (size_t)(a + n * (t0 + u)) * SOS_TOPC;
+          v0[u] = c[tid]; v1[u] = c[192 + hc]; v2[u] = c[256 + bc_];
+        }
 #pragma unroll
       for (int u = 0; u < 16; u++)
-        if (u < n) { sH += w0[u]; sHc += w1[u]; sb += w2[u]; }
-    } else {
-      for (int t0 = 0; t0 < n; t0 += 16) {
-        double v0[16], v1[16], v2[16];
+        if (t0 + u < n) { sH += v0[u]; sHc += v1[u]; sb += v2[u]; }
+    }
+    for (int h0 = 0; h0 < n; h0 += 16) {
+      double v0[16], v1[16], v2[16];
 #pragma unroll
-        for (int u = 0; u < 16; u++)
-          if (t0 + u < n) {
-            const double *c = Cm + (size_t)(a + n * (t0 + u)) * SOS_TOPC;
-            v0[u] = c[tid]; v1[u] = c[192 + hc]; v2[u] = c[256 + bc_];
-          }
+      for (int u = 0; u < 16; u++)
+        if (h0 + u < n) {
+          const double *c = Cm + (size_t)((h0 + u) + n * a) * SOS_TOPC;
+          v0[u] = c[64 + tid]; v1[u] = c[224 + hc]; v2[u] = c[264 + bc_];
+        }
 #pragma unroll
-        for (int u = 0; u < 16; u++)
-          if (t0 + u < n) { sH += v0[u]; sHc += v1[u]; sb += v2[u]; }
-      }
-      for (int h0 = 0; h0 < n; h0 += 16) {
-        double v0[16], v1[16], v2[16];
-#pragma unroll
-        for (int u = 0; u < 16; u++)
-          if (h0 + u < n) {
-            const double *c = Cm + (size_t)((h0 + u) + n * a) * SOS_TOPC;
-            v0[u] = c[64 + tid]; v1[u] = c[224 + hc]; v2[u] = c[264 + bc_];
-          }
-#pragma unroll
-        for (int u = 0; u < 16; u++)
-          if (h0 + u < n) { sH += v0[u]; sHc += v1[u]; sb += v2[u]; }
-      }
+      for (int u = 0; u < 16; u++)
+        if (h0 + u < n) { sH += v0[u]; sHc += v1[u]; sb += v2[u]; }
     }
     H[(size_t)(4 + 8 * a + i) * dim + 4 + 8 * a + j] = sH;
     if (tid < 32) {
@@ -1553,42 +1468,15 @@ __device__ __forceinline__ void sc_MC_body(int bx, int by, int n, const float *_
   const int h = bx % n, t1 = (bx / n) % n, g = bx / (n * n);
   const int t2lo = (g == h) ? 0 : g, t2hi = (g == h) ? n : g + 1;
   const int pidx = h + n * t1;
-  // (round 5: the ISA of the loop "load (D, A) of t2, store to LDS" had one s_waitcnt vmcnt(0) per iteration -- n dependent round trips
-  // in the g == h blocks, the critical path of the stage -- and one more behind each guarded load below.  Now every load of the block is
-  // issued into registers first: 16 (D, A) pairs with clamped t2 in the g == h blocks, one pair in the others.)
-  const double dAH = adHost[(size_t)pidx * 64 + tid], dAT = adTarget[(size_t)pidx * 64 + tid];
-  const float fE = accE[(size_t)pidx * 32 + (tid & 31)], fEB = accEB[(size_t)pidx * 8 + (tid & 7)];
-  if (g == h && n <= 16) {
-    float fd[16];
-    double fa[16];
-#pragma unroll
-    for (int q = 0; q < 16; q++) {
-      const int t2 = min(q, n - 1);
-      fd[q] = accD[(size_t)(h + n * t1 + n * n * t2) * 64 + tid];
-      fa[q] = adHost[(size_t)(h + n * t2) * 64 + tid];
-    }
-#pragma unroll
-    for (int q = 0; q < 16; q++)
-      if (q < n) {
-        sD[q * 64 + tid] = (double)fd[q];
-        sA[q * 64 + tid] = fa[q];
-      }
-  } else if (g == h) {  // (windows beyond 16 keyframes: one pair per iteration)
-    for (int t2 = 0; t2 < n; t2++) {
-      sD[t2 * 64 + tid] = (double)accD[(size_t)(h + n * t1 + n * n * t2) * 64 + tid];
-      sA[t2 * 64 + tid] = adHost[(size_t)(h + n * t2) * 64 + tid];
-    }
-  } else {
-    const float fd = accD[(size_t)(h + n * t1 + n * n * g) * 64 + tid];
-    const double fa = adTarget[(size_t)(h + n * g) * 64 + tid];
-    sD[tid] = (double)fd;
-    sA[tid] = fa;
+  for (int t2 = t2lo; t2 < t2hi; t2++) {
+    sD[(t2 - t2lo) * 64 + tid] = (double)accD[(size_t)(h + n * t1 + n * n * t2) * 64 + tid];
+    sA[(t2 - t2lo) * 64 + tid] = ((g == h) ? adHost : adTarget)[(size_t)(h + n * t2) * 64 + tid];
   }
-  sAH[tid] = dAH;
-  sAT[tid] = dAT;
+  sAH[tid] = adHost[(size_t)pidx * 64 + tid];
+  sAT[tid] = adTarget[(size_t)pidx * 64 + tid];
   if (g == 0) {
-    if (tid < 32) sE[tid] = (double)fE;
-    if (tid < 8) sEB[tid] = (double)fEB;
+    if (tid < 32) sE[tid] = (double)accE[(size_t)pidx * 32 + tid];
+    if (tid < 8) sEB[tid] = (double)accEB[(size_t)pidx * 8 + tid];
   }
   __syncthreads();
   double m = 0;
@@ -1656,42 +1544,6 @@ __device__ __forceinline__ void sc_sum_body(int bx, int by, int n, const double 
   double s = 0, sc = 0, sb = 0;
   // the (h = g1, t1 = g1) terms are exact zeros (a point has no residual to its own host), so both sums
   // can run branch-free over all n
-  const int hc = tid & 31, bc_ = tid & 7;
-  if (n <= 16) {
-    // every term of the block requested before the first add (clamped indices; the diagonal blocks' calib / b terms behind a
-    // block-uniform test): ONE memory round trip instead of two (four on the diagonal); the adds keep their order
-    double v[16], w[16], e1[16], e2[16], f1[16], f2[16];
-#pragma unroll
-    for (int u = 0; u < 16; u++) {
-      const int q = min(u, n - 1);
-      v[u] = C[((size_t)(g1 * n + q) * n + g2) * SOS_SCC + tid];
-      w[u] = C[((size_t)(q * n + g1) * n + g2) * SOS_SCC + 64 + tid];
-    }
-    if (g1 == g2) {
-#pragma unroll
-      for (int u = 0; u < 16; u++) {
-        const int q = min(u, n - 1);
-        const double *ea = Ce + (size_t)(g1 + n * q) * SOS_SCE, *eb = Ce + (size_t)(q + n * g1) * SOS_SCE;
-        e1[u] = ea[hc]; e2[u] = ea[64 + bc_];
-        f1[u] = eb[32 + hc]; f2[u] = eb[72 + bc_];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 16; u++)
-      if (u < n) s += v[u];
-#pragma unroll
-    for (int u = 0; u < 16; u++)
-      if (u < n) s += w[u];
-    H[(size_t)(4 + 8 * g1 + i) * dim + 4 + 8 * g2 + j] = s;
-    if (g1 == g2) {
-#pragma unroll
-      for (int u = 0; u < 16; u++)
-        if (u < n) { sc += e1[u]; sb += e2[u]; }
-#pragma unroll
-      for (int u = 0; u < 16; u++)
-        if (u < n) { sc += f1[u]; sb += f2[u]; }
-    }
-  } else {
   for (int t0 = 0; t0 < n; t0 += 16) {  // loads of a round in flight together, adds in the old order (see stitch_top_sum_body)
     double v[16];
 #pragma unroll
@@ -1712,6 +1564,7 @@ __device__ __forceinline__ void sc_sum_body(int bx, int by, int n, const double 
   }
   H[(size_t)(4 + 8 * g1 + i) * dim + 4 + 8 * g2 + j] = s;
   if (g1 == g2) {
+    const int hc = tid & 31, bc_ = tid & 7;
     for (int t0 = 0; t0 < n; t0 += 16) {
       double v1[16], v2[16];
 #pragma unroll
@@ -1736,9 +1589,6 @@ __device__ __forceinline__ void sc_sum_body(int bx, int by, int n, const double 
       for (int u = 0; u < 16; u++)
         if (h0 + u < n) { sc += v1[u]; sb += v2[u]; }
     }
-  }
-  }
-  if (g1 == g2) {
     if (tid < 32) {
       const int r = tid >> 2, c = tid & 3;
       if (!upperOnly) H[(size_t)(4 + 8 * g1 + r) * dim + c] = sc;
