@@ -579,15 +579,14 @@ __device__ __forceinline__ void res_pixel(const ResArgs &a, int i, float x, floa
       if (isfinite(hit0)) {
         const float residual = MODE == 1 ? hit0 - refColor : hit0 - (float)(a.aff0 * refColor + a.aff1);
         const float hw = fabsf(residual) < a.huber ? 1 : a.huber / fabsf(residual);
-        // (written as selects: with `v[3] = 1` in one branch and `v[2] = 1` in the other the compiler merged the two stores into ONE
-        // store through a run-time index, which put v[2..3] into scratch memory -- a store / load round trip in every pixel's chain)
-        // PENDING_FIRST_GPU_RUN: compile-verified (ScratchSize 16 -> 0); executed under tests/emu in round 4 (tracker tests bit-exact against the oracle)
-        const bool sat = fabsf(residual) > a.cutoff;
-        v[0] = sat ? a.maxEnergy : hw * residual * residual * (2 - hw);
-        v[1] = 1.f;
-        v[2] = sat ? 0.f : 1.f;
-        v[3] = sat ? 1.f : 0.f;
-        if (!sat) {
+        if (fabsf(residual) > a.cutoff) {
+          v[0] = a.maxEnergy;
+          v[1] = 1.f;
+          v[3] = 1.f;
+        } else {
+          v[0] = hw * residual * residual * (2 - hw);
+          v[1] = 1.f;
+          v[2] = 1.f;
           warped = true;
           b3 = hit1; b4 = hit2; b5 = residual; b6 = hw; b7 = refColor;
         }

@@ -20,4 +20,13 @@ for s in $SHAS; do
   echo "$s: $(git log -1 --format=%s $s | cut -c1-100)"
   ls -la $d/sos_slam_amd/csrc/*.so | awk '{print "   ", $5, $9}'
 done
+# HEAD + the device-code rewrites no GPU has run (out of the default path since round 6, kept as patches): the batched-load forms of the
+# four accumulate / stitch kernels (round 5) and the tracker's res_pixel written as selects (round 3, removes 16 B of scratch).
+# bisect/pending -- the A/B of the first lease decides, patch by patch, what is applied
+d=bisect/pending
+rm -rf $d; mkdir -p $d
+git archive HEAD | tar -x -C $d
+rm -rf $d/DESIGN_APPENDIX.md $d/gpurun_out
+(cd $d && patch -p1 -s < profiles/r06_chain_batched_loads.patch && patch -p1 -s < profiles/r06_tracker_res_pixel_selects.patch && rm -rf profiles && python -c "import __graft_entry__ as g; g.build()" > build.log 2>&1) || { echo "build of HEAD + pending patches failed: $d/build.log"; exit 1; }
+echo "pending: HEAD $(git rev-parse --short HEAD) + profiles/r06_chain_batched_loads.patch + profiles/r06_tracker_res_pixel_selects.patch"
 du -sh bisect
