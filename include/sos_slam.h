@@ -348,7 +348,7 @@ int sos_ba_gn_resident_begin(sos_ba *ba, const sos_gn_frame *frames, const doubl
                              double cPrior, const double *HM, const double *bM, const float *frameEnergyTH /* n */);
 int sos_ba_gn_resident_enqueue(sos_ba *ba, int *seq_out);
 /* header16: [0] seq, [1] failed (non-positive pivot: x is not usable), [6] sum |idepth_backup| and [7] the number of points
- * (doStepFromBackup's sumNID, FS/FullSystemOptimize.cpp:207-213), [8] resInA, [9] resInL, [10] frameEnergyTH of the newest keyframe
+ * (doStepFromBackup's sumNID, FS/FullSystemOptimize.cpp:207-213; with a communicator attached: over the points of ALL ranks), [8] resInA, [9] resInL, [10] frameEnergyTH of the newest keyframe
  * used by this iteration's linearisation, [11..13] microseconds the solve kernel spent assembling / factorising / substituting;
  * x: 4 + 8 n (OB/EnergyFunctional.cpp:1148) */
 int sos_ba_gn_resident_wait(sos_ba *ba, int seq, double *header16, double *x);
