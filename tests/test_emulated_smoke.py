@@ -23,6 +23,10 @@ def _have_gpu():
 @pytest.mark.parametrize("target", [
     "tests/test_golden_t6.py",                                   # backend, tracker and immature-point fixtures of the T6 window
     "tests/test_gpu_backend.py -k T4",                            # bit-exact linearisation / accumulation / back-substitution on the small window
+    # the exchange code with TWO ranks (processes of the emulation over tests/emu/fake_rccl.cpp): default and device-resident loop, sharded
+    # against each other and against the unsharded window; and k_gn_solve with its pivot-row micro-test
+    "tests/test_gpu_resident_comm.py -k two_ranks",
+    "tests/test_gpu_gn_solve.py -k row_update",
 ])
 def test_gpu_parity_slice_under_emulation(target):
     env = dict(os.environ, SOS_EMU="1")
