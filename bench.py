@@ -463,7 +463,10 @@ VARIANTS = (
     ("stitch_signal_in_kernel", {"SOS_STITCH_SIGNAL_IN_KERNEL": "1"}, []),          # the stitch's last kernel raises the host flag itself (no k_publish)
     ("resident", {}, ["--resident"]),                                                 # solve on the device (k_gn_solve), the host out of the loop
     ("resident_abs_schur", {"SOS_ABS_SC": "1"}, ["--resident"]),
-    ("lin_xcd_ranges", {"SOS_LIN_XCD": "1"}, []),                                     # k_linearize2: a contiguous tile range per XCD (judged by FETCH_SIZE, tools/pmc_probe.py)
+    ("lin_xcd_ranges", {"SOS_LIN_XCD": "1"}, []),
+    # (the `visual_inertial_overlap` entry of round 4 -- SOS_IMU_OVERLAP=1 on the --imu loop -- was retired with round 5's split into side
+    # processes: the knob is a host-side order selector whose A/B is `--imu` with and without the variable, two command lines, not a variant
+    # of the visual loop)                                     # k_linearize2: a contiguous tile range per XCD (judged by FETCH_SIZE, tools/pmc_probe.py)
 )
 
 
