@@ -549,6 +549,7 @@ def keyframe_timing(window, device):
     act_ms = sum(d.get(k, 0.0) for d, k in ((act_sel, "activate_select_ms"), (act_dev, "immature_activate_ms"), (act_dev, "make_new_traces_ms")))
     return {"activation_select": act_sel, "activation_device": act_dev, "keyframe_with_activation_ms": float(med[:4].sum()) + float(act_ms),
             "optimize_ms": float(med[0]), "optimize_iterations": int(rows[-1][5]),
+            "host_threads": int(__import__("sos_slam_amd.host", fromlist=["load"]).load().sosf_get_host_threads()),   # graph walks of the pack / final linearisation
             "remove_outliers_set_tracking_ref_ms": float(med[1]), "flag_points_marginalize_points_ms": float(med[2]),
             "marginalize_frames_ms": float(med[3]), "keyframe_ms": float(med[:4].sum()),
             "points_marginalized": int(rows[-1][6]), "points_dropped": int(rows[-1][7]), "frames_marginalized": int(rows[-1][8]),

@@ -101,6 +101,11 @@ int sosf_invalidate_pack(sosf_system *sys);
 /* setting_minOptIterations (util/settings.cpp:77, default 1): optimize() does not leave its loop on the convergence test before
  * this many iterations (FS/FullSystemOptimize.cpp:411) */
 int sosf_set_min_opt_iterations(sosf_system *sys, int iterations);
+/* Host threads of the facade's per-keyframe graph walks -- the record walk of the pack (FS/FullSystemOptimize.cpp:316-329 + the snapshot
+ * records) and the consumer of linearizeAll(true) (:125-182, which the reference runs on its IndexThreadReduce workers): contiguous
+ * ranges laid out by a prefix sum, so results do not depend on the count.  Process-wide; 1 = serial; default min(4, hardware threads / 2). */
+int sosf_set_host_threads(int n);
+int sosf_get_host_threads(void);
 /* Device-side step of the Gauss-Newton loop (default on; sos_ba_gn_devstep_begin in include/sos_slam.h): the host solves and hands x
  * over, the device forms the frames' new poses, the n^2 precalc records and the deltas inside the launch of the back-substitution.
  * 0: the host computes and stages them as in round 1 (the two differ in the last bits of SE3::exp).  Used when steps are always

@@ -2,6 +2,7 @@
 // (include/sos_slam_host.h).  Compiled with -ffp-contract=off: the fp32 host arithmetic that feeds the
 // C-ABI (precalc, adHTdeltaF, xAd) follows the same convention as the device kernels.
 #include "sos_host.hpp"
+#include "sos_pool.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -418,43 +419,80 @@ int EnergyFunctional::packWindow(std::vector<PointFrameResidual *> *active) {
   // record vectors are members: no allocation (and no page faults) per keyframe
   std::vector<sos_point> &pts = packPts;
   std::vector<sos_resid> &res = packRes;
-  pts.resize(allPoints.size());
-  res.clear();
-  res.reserve((size_t)nResiduals + 16);
-  allResiduals.clear();
-  allResiduals.reserve((size_t)nResiduals + 16);
-  for (size_t k = 0; k < allPoints.size(); k++) {
-    EFPoint *p = allPoints[k];
-    PointHessian *ph = p->data;
-    if (active)
-      for (PointFrameResidual *r : ph->residuals)
-        if (!r->efResidual->isLinearized) {
-          active->push_back(r);
-          r->resetOOB();
-        }
-    ph->packIdx = (int)k;
-    sos_point &o = pts[k];
-    o.u = ph->u; o.v = ph->v;
-    o.idepth_scaled = ph->idepth_scaled;
-    o.idepth_zero_scaled = ph->idepth_zero_scaled;
-    std::memcpy(o.color, ph->color, sizeof(o.color));
-    std::memcpy(o.weights, ph->weights, sizeof(o.weights));
-    o.priorF = p->priorF;
-    o.deltaF = p->deltaF;
-    o.host = p->host->idx;
-    o.pad = 0;
-    for (EFResidual *r : p->residualsAll) {
-      sos_resid q;
-      q.point = (int)k;
-      q.host = r->hostIDX = r->host->idx;
-      q.target = r->targetIDX = r->target->idx;
-      q.flags = (r->isActive() ? SOS_RF_ACTIVE : 0u) | (r->isLinearized ? SOS_RF_LINEARIZED : 0u) | (r->data->isNew ? SOS_RF_ISNEW : 0u);
-      q.state_state = (int)r->data->state_state;
-      q.state_energy = (float)r->data->state_energy;
-      r->data->packIdx = (int)res.size();
-      res.push_back(q);
-      allResiduals.push_back(r);
+  const size_t P = allPoints.size();
+  pts.resize(P);
+  // The walk is split into contiguous point ranges over the helper threads (sos_pool.hpp; the reference runs its per-residual loops on
+  // IndexThreadReduce workers as well).  Phase A: residual count of every range; a prefix sum gives every range its record slots;
+  // phase B: the ranges write their records / allResiduals entries / packIdx in place and collect their part of the active list, which
+  // is concatenated in range order -- byte for byte what the serial loop produces, for any thread count.
+  const int parts = (int)std::min<size_t>(P ? P : 1, (size_t)4 * (size_t)WalkPool::get().threads());
+  std::vector<size_t> partBegin((size_t)parts + 1, 0), partRes((size_t)parts + 1, 0);
+  for (int q = 0; q <= parts; q++) partBegin[(size_t)q] = P * (size_t)q / (size_t)parts;
+  WalkPool::get().run(parts, [&](int q) {
+    size_t c = 0;
+    for (size_t k = partBegin[(size_t)q]; k < partBegin[(size_t)q + 1]; k++) c += allPoints[k]->residualsAll.size();
+    partRes[(size_t)q + 1] = c;
+  });
+  for (int q = 0; q < parts; q++) partRes[(size_t)q + 1] += partRes[(size_t)q];
+  const size_t Rtot = partRes[(size_t)parts];
+  res.resize(Rtot);
+  allResiduals.resize(Rtot);
+  // (the active list of a range is written straight into the caller's vector at the range's record offset -- an upper bound of its
+  // position, a point has as many PointFrameResiduals as EFResiduals -- and the ranges are closed up afterwards)
+  const size_t act0 = active ? active->size() : 0;
+  if (active) active->resize(act0 + Rtot);
+  std::vector<size_t> partAct((size_t)parts, 0);
+  PointFrameResidual **actBase = active ? active->data() + act0 : nullptr;
+  WalkPool::get().run(parts, [&](int q) {
+    size_t w = partRes[(size_t)q];
+    PointFrameResidual **act = actBase ? actBase + w : nullptr;
+    size_t na = 0;
+    const size_t actCap = partRes[(size_t)q + 1] - w;
+    for (size_t k = partBegin[(size_t)q]; k < partBegin[(size_t)q + 1]; k++) {
+      EFPoint *p = allPoints[k];
+      PointHessian *ph = p->data;
+      if (active)
+        for (PointFrameResidual *r : ph->residuals)
+          if (!r->efResidual->isLinearized) {
+            if (na < actCap) act[na] = r;
+            na++;
+            r->resetOOB();
+          }
+      ph->packIdx = (int)k;
+      sos_point &o = pts[k];
+      o.u = ph->u; o.v = ph->v;
+      o.idepth_scaled = ph->idepth_scaled;
+      o.idepth_zero_scaled = ph->idepth_zero_scaled;
+      std::memcpy(o.color, ph->color, sizeof(o.color));
+      std::memcpy(o.weights, ph->weights, sizeof(o.weights));
+      o.priorF = p->priorF;
+      o.deltaF = p->deltaF;
+      o.host = p->host->idx;
+      o.pad = 0;
+      for (EFResidual *r : p->residualsAll) {
+        sos_resid qq;
+        qq.point = (int)k;
+        qq.host = r->hostIDX = r->host->idx;
+        qq.target = r->targetIDX = r->target->idx;
+        qq.flags = (r->isActive() ? SOS_RF_ACTIVE : 0u) | (r->isLinearized ? SOS_RF_LINEARIZED : 0u) | (r->data->isNew ? SOS_RF_ISNEW : 0u);
+        qq.state_state = (int)r->data->state_state;
+        qq.state_energy = (float)r->data->state_energy;
+        r->data->packIdx = (int)w;
+        res[w] = qq;
+        allResiduals[w] = r;
+        w++;
+      }
     }
+    partAct[(size_t)q] = na;
+  });
+  if (active) {
+    size_t wpos = 0;
+    for (int q = 0; q < parts; q++) {
+      if (partAct[(size_t)q] > partRes[(size_t)q + 1] - partRes[(size_t)q]) return SOS_ERR_STATE;  // a point with more PointFrameResiduals than EFResiduals: not a graph this facade builds
+      if (wpos != partRes[(size_t)q]) std::memmove(actBase + wpos, actBase + partRes[(size_t)q], sizeof(PointFrameResidual *) * partAct[(size_t)q]);
+      wpos += partAct[(size_t)q];
+    }
+    active->resize(act0 + wpos);
   }
   const double tq = now_s();
   int rc = sos_ba_set_window(ba, n, slots.data(), (int)pts.size(), pts.data(), (int)res.size(), res.data(), nullptr, nullptr);
@@ -1106,30 +1144,46 @@ double FullSystem::linearizeAll(bool fix) {  // FS/FullSystemOptimize.cpp:125-18
   const double tl1 = now_s();
   // ONE walk over the active residuals: r->applyRes(true) inside the reductor (:51), the removal list (:72-73) and the
   // lastResiduals states (:150-156, which only read what this walk has just written for the same residual)
+  // (ranges of the active list over the helper threads, sos_pool.hpp: every residual is written by the one range that holds it, a
+  // point's two lastResiduals slots are distinct objects, the removal lists are concatenated in range order = the serial loop's list)
   std::vector<PointFrameResidual *> toRemove;
-  for (PointFrameResidual *r : activeResiduals) {
-    const sos_resid_final &q = rec[r->packIdx];
-    r->state_NewState = (ResState)q.state_NewState;
-    r->state_NewEnergy = q.state_NewEnergy;
-    r->state_NewEnergyWithOutlier = q.state_NewEnergyWithOutlier;
-    r->centerProjectedTo[0] = q.centerProjectedTo[0];
-    r->centerProjectedTo[1] = q.centerProjectedTo[1];
-    r->centerProjectedTo[2] = q.centerProjectedTo[2];
-    r->state_state = (ResState)q.state_state;
-    r->state_energy = q.state_energy;
-    r->efResidual->isActiveAndIsGoodNEW = q.active != 0;
-    if (!q.active) toRemove.push_back(r);
-    PointHessian *ph = r->point;
-    if (ph->lastResiduals[0].first == r) ph->lastResiduals[0].second = r->state_state;
-    else if (ph->lastResiduals[1].first == r) ph->lastResiduals[1].second = r->state_state;
-  }
-  // isNew bookkeeping (:55-71), formed per point on the device over its active residuals
-  for (size_t k = 0; k < ef->allPoints.size(); k++) {
-    PointHessian *p = ef->allPoints[k]->data;
-    if (pcnt[k] > 0) {
-      if (pmax[k] > p->maxRelBaseline) p->maxRelBaseline = pmax[k];
-      p->numGoodResiduals += pcnt[k];
-    }
+  {
+    const size_t nA = activeResiduals.size();
+    const int parts = (int)std::min<size_t>(nA ? nA : 1, (size_t)4 * (size_t)WalkPool::get().threads());
+    std::vector<std::vector<PointFrameResidual *>> partRemove((size_t)parts);
+    WalkPool::get().run(parts, [&](int pq) {
+      std::vector<PointFrameResidual *> &rem = partRemove[(size_t)pq];
+      for (size_t i = nA * (size_t)pq / (size_t)parts, e = nA * ((size_t)pq + 1) / (size_t)parts; i < e; i++) {
+        PointFrameResidual *r = activeResiduals[i];
+        const sos_resid_final &q = rec[r->packIdx];
+        r->state_NewState = (ResState)q.state_NewState;
+        r->state_NewEnergy = q.state_NewEnergy;
+        r->state_NewEnergyWithOutlier = q.state_NewEnergyWithOutlier;
+        r->centerProjectedTo[0] = q.centerProjectedTo[0];
+        r->centerProjectedTo[1] = q.centerProjectedTo[1];
+        r->centerProjectedTo[2] = q.centerProjectedTo[2];
+        r->state_state = (ResState)q.state_state;
+        r->state_energy = q.state_energy;
+        r->efResidual->isActiveAndIsGoodNEW = q.active != 0;
+        if (!q.active) rem.push_back(r);
+        PointHessian *ph = r->point;
+        if (ph->lastResiduals[0].first == r) ph->lastResiduals[0].second = r->state_state;
+        else if (ph->lastResiduals[1].first == r) ph->lastResiduals[1].second = r->state_state;
+      }
+    });
+    for (int pq = 0; pq < parts; pq++) toRemove.insert(toRemove.end(), partRemove[(size_t)pq].begin(), partRemove[(size_t)pq].end());
+    // isNew bookkeeping (:55-71), formed per point on the device over its active residuals
+    const size_t nP = ef->allPoints.size();
+    const int pparts = (int)std::min<size_t>(nP ? nP : 1, (size_t)2 * (size_t)WalkPool::get().threads());
+    WalkPool::get().run(pparts, [&](int pq) {
+      for (size_t k = nP * (size_t)pq / (size_t)pparts, e = nP * ((size_t)pq + 1) / (size_t)pparts; k < e; k++) {
+        PointHessian *p = ef->allPoints[k]->data;
+        if (pcnt[k] > 0) {
+          if (pmax[k] > p->maxRelBaseline) p->maxRelBaseline = pmax[k];
+          p->numGoodResiduals += pcnt[k];
+        }
+      }
+    });
   }
   const double tl2 = now_s();
   setNewFrameEnergyTH(newestE);
@@ -2748,6 +2802,12 @@ extern "C" int sosf_set_resident(sosf_system *s, int on) {
   s->fs->residentAllowed = on != 0;
   return SOS_OK;
 }
+extern "C" int sosf_set_host_threads(int n) {
+  if (n < 1 || n > 16) return SOS_ERR_ARG;
+  sos::WalkPool::get().setThreads(n);
+  return SOS_OK;
+}
+extern "C" int sosf_get_host_threads(void) { return sos::WalkPool::get().threads(); }
 extern "C" int sosf_set_min_opt_iterations(sosf_system *s, int its) {
   if (!s || its < 0) return SOS_ERR_ARG;
   s->fs->minOptIterations = its;

@@ -311,6 +311,14 @@ class System:
         """the next prepare() / optimize() packs and uploads the window again (per-keyframe cost measurements)"""
         _chk(self.L.sosf_invalidate_pack(self.h_), "sosf_invalidate_pack")
 
+    def set_host_threads(self, n: int):
+        """threads of the facade's per-keyframe graph walks (process-wide; results do not depend on it)"""
+        self.L.sosf_set_host_threads.argtypes = [C.c_int]
+        _chk(self.L.sosf_set_host_threads(int(n)), "sosf_set_host_threads")
+
+    def host_threads(self) -> int:
+        return int(self.L.sosf_get_host_threads())
+
     def set_min_opt_iterations(self, its):
         _chk(self.L.sosf_set_min_opt_iterations(self.h_, int(its)), "sosf_set_min_opt_iterations")
 
