@@ -34,7 +34,9 @@ class WalkPool {
     nthreads_ = n;
   }
   template <class F> void run(int parts, F &&fn) {
-    if (parts <= 1 || nthreads_ <= 1) {
+    // one walk at a time owns the helpers: a second caller (two systems driven from two threads of one process) walks by itself
+    std::unique_lock<std::mutex> owner(run_m_, std::try_to_lock);
+    if (parts <= 1 || nthreads_ <= 1 || !owner.owns_lock()) {
       for (int p = 0; p < parts; p++) fn(p);
       return;
     }
@@ -114,7 +116,7 @@ class WalkPool {
       }
     }
   }
-  std::mutex m_;
+  std::mutex m_, run_m_;
   std::condition_variable cv_;
   std::vector<std::thread> workers_;
   std::function<void(int)> *job_ = nullptr;

@@ -43,3 +43,21 @@ def test_results_do_not_depend_on_the_host_thread_count(name):
     for t in (2, 3, 7):
         got = _digest(name, t)
         assert got == ref, (t, got[1], ref[1])
+
+
+def test_two_systems_driven_from_two_threads():
+    """The helper threads belong to one walk at a time; a second system optimised concurrently from another thread of the process walks by
+    itself -- both end exactly where they end when run one after the other."""
+    import threading
+    ref = [_digest("T4", 4), _digest("T6", 4)]
+    got = [None, None]
+
+    def work(i, name):
+        got[i] = _digest(name, 4)
+
+    ts = [threading.Thread(target=work, args=(0, "T4")), threading.Thread(target=work, args=(1, "T6"))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert got == ref
