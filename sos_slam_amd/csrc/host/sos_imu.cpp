@@ -710,7 +710,7 @@ struct Prepared {
 };
 thread_local ImuCache g_cache;
 thread_local Prepared g_prep;
-int g_mode = -1;                    // -1: from SOS_IMU_CACHE at first use; 0 literal form; 1 cached
+int g_mode = 1;                     // 0 literal form; 1 cached (sosf_imu_solve_mode switches)
 thread_local int g_stats[3] = {0, 0, 0};  // solves on a kept factor / rebuilds / literal-form solves
 
 void make_signature(const sosf_imu_settings &S, const sosf_imu_calib &C, int n, const sosf_imu_frame *F, double lambda, std::vector<double> &sig) {
@@ -1171,7 +1171,6 @@ extern "C" int sosf_imu_solve_prepare(const sosf_imu_settings *S, const sosf_imu
                                       const double *bM, const double *delta, double lambda, uint64_t prior_id) {
   g_prep.active = false;
   if (!S || !C || n < 1 || !F || !HM || !bM || !delta) return SOS_ERR_ARG;
-  if (g_mode < 0) g_mode = (getenv("SOS_IMU_CACHE") && atoi(getenv("SOS_IMU_CACHE")) == 0) ? 0 : 1;
   g_prep = Prepared{true, false, S, C, n, F, HM, bM, delta, lambda, prior_id};
   int form = 1;  // 0 kept factor (or its rebuild), 2 the structured elimination built for this call alone, 1 the dense KKT system
   if (g_mode == 1) form = cached_prepare(g_cache, g_prep, C->scale_trapped != 0);
@@ -1183,7 +1182,6 @@ extern "C" int sosf_imu_solve_prepare(const sosf_imu_settings *S, const sosf_imu
 extern "C" int sosf_imu_solve_prepared_form(void) { return !g_prep.active ? -1 : g_prep.cached ? 1 : 0; }
 
 extern "C" int sosf_imu_solve_mode(int mode) {
-  if (g_mode < 0) g_mode = (getenv("SOS_IMU_CACHE") && atoi(getenv("SOS_IMU_CACHE")) == 0) ? 0 : 1;
   const int before = g_mode;
   if (mode == 0 || mode == 1) g_mode = mode;
   return before;
