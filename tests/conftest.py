@@ -48,7 +48,16 @@ def pytest_report_header(config):
         return "SOS_EMU=1: device library = tests/emu lockstep CPU EMULATION (not a GPU run)"
 
 
+# Tests of device paths that are OPT-IN because no GPU has executed them yet (k_gn_solve and the resident loop, the launch variants).  The
+# driver runs the suite with -x: they go to the end of the run, so that a fault in one of them on first contact with the hardware cannot
+# hide the results of the default path's tests behind it.
+_OPT_IN_LAST = ("tests/test_gpu_gn_solve.py", "tests/test_gpu_resident_comm.py", "tests/test_gpu_variants.py", "device_resident_loop", "loop_mode_reports")
+
+
 def pytest_collection_modifyitems(config, items):
+    first = [it for it in items if not any(k in it.nodeid for k in _OPT_IN_LAST)]
+    last = [it for it in items if any(k in it.nodeid for k in _OPT_IN_LAST)]
+    items[:] = first + last
     if _have_gpu():
         # on the GPU box the whole suite takes minutes (GPUTEST_r02: 206 s for 181 tests): a test that sits for a quarter of an hour is hung,
         # and ending the session (with the stacks of all threads) is better than sitting out the lease.  Every wait of the library is
